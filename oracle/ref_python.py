@@ -1,0 +1,41 @@
+"""Import the reference's own Python classes (Signal, ProtocolAnalyzer, AutoInterpretation, ...)
+on top of the oracle/_ref Cython build.  Works ONLY where /root/reference exists (this build
+container); used by tests/golden/make_golden.py and by `-m "not gpu"` tests that pin the oracle.
+TEST INFRASTRUCTURE ONLY."""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_ROOT = os.environ.get("URH_REFERENCE", "/root/reference")
+
+
+def available() -> bool:
+    import build_ref  # noqa
+    return os.path.isdir(os.path.join(REF_ROOT, "src", "urh")) and build_ref.built()
+
+
+def setup():
+    """Put the PyQt6 stub + reference src on sys.path and graft oracle/_ref's compiled modules
+    into the reference's `urh.cythonext` package.  Returns the `urh` package."""
+    sys.path.insert(0, HERE)
+    import build_ref
+    if not build_ref.build():
+        raise RuntimeError("reference build unavailable")
+    stub = os.path.join(HERE, "pyqt6_stub")
+    for p in (os.path.join(REF_ROOT, "src"), stub):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import urh.cythonext as ce
+    pkg = os.path.join(build_ref.OUT, "urh", "cythonext")
+    if pkg not in ce.__path__:
+        ce.__path__.append(pkg)
+    # path_creator (plot decimation) needs a real PyQt6 and is off the hot path: inert placeholder.
+    import types
+    for name in ("path_creator",):
+        full = "urh.cythonext." + name
+        if full not in sys.modules:
+            mod = types.ModuleType(full)
+            sys.modules[full] = mod
+            setattr(ce, name, mod)
+    import urh
+    return urh
