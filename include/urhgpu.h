@@ -1,0 +1,193 @@
+/*
+ * urhgpu.h -- C ABI of the MI355X-native IQ->bits path (liburhgpu.so).
+ *
+ * This is the drop-in boundary for the reference's native layer: every entry point replaces one
+ * Python-visible function of the reference's Cython modules (urh.cythonext.signal_functions /
+ * util / auto_interpretation) or the one pure-Python tail function that sits on the hot path
+ * (ProtocolAnalyzer._ppseq_to_bits).  Reference citations are relative to /root/reference.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns an int status
+ *     (URHGPU_OK == 0, negative == error, see urhgpu_strerror); nothing throws across the ABI.
+ *   - "host" entry points take host pointers (numpy buffers): they upload, run the kernels and
+ *     download, synchronously.  They mirror the reference functions 1:1 (same argument meaning,
+ *     same edge cases) and are what the ctypes shim urh_amd/signal_functions.py calls.
+ *   - "_dev" entry points take DEVICE pointers (hipMalloc / torch tensors' data_ptr()) and are
+ *     asynchronous on the context's stream; nothing is copied to the host unless stated.  They
+ *     are what a device-resident pipeline (urh_amd/pipeline.py, bench.py) calls.
+ *   - Inputs are borrowed and never written; outputs are caller-allocated; device scratch is
+ *     owned by the context and grows on demand (never inside a steady-state call).
+ *   - dtype codes follow the reference's fused `iq` type (src/urh/cythonext/util.pxd:1-8).
+ *   - Not thread-safe per context; use one context per host thread (fork/spawn safe: HIP is
+ *     initialised lazily by urhgpu_ctx_create in the calling process).
+ */
+#ifndef URHGPU_H
+#define URHGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URHGPU_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define URHGPU_OK 0
+#define URHGPU_ERR_HIP (-1)          /* a HIP runtime call failed (urhgpu_last_hip_error) */
+#define URHGPU_ERR_DTYPE (-2)        /* reference: ValueError("Unsupported dtype") signal_functions.pyx:283,354 */
+#define URHGPU_ERR_ARG (-3)          /* bad argument (null pointer, negative size, misaligned device pointer) */
+#define URHGPU_ERR_CAPACITY (-4)     /* caller-provided output capacity too small; *n_* holds the needed size */
+#define URHGPU_ERR_UNSUPPORTED (-5)  /* parameter outside the supported range (e.g. bits_per_symbol > 7) */
+#define URHGPU_ERR_NO_DEVICE (-6)    /* no usable GPU: the product path never falls back to the CPU */
+
+/* dtype codes: element type of the interleaved (N,2) IQ array (util.pxd:1-8) */
+#define URHGPU_DT_I8 0
+#define URHGPU_DT_U8 1
+#define URHGPU_DT_I16 2
+#define URHGPU_DT_U16 3
+#define URHGPU_DT_F32 4
+
+/* modulation codes (Signal.modulation_type strings; signal_functions.pyx:31-44) */
+#define URHGPU_MOD_ASK 0
+#define URHGPU_MOD_FSK 1
+#define URHGPU_MOD_PSK 2
+#define URHGPU_MOD_OTHER 3 /* "OQPSK"/"QAM"/...: no demod branch in afp_demod (result stays 0) */
+
+typedef struct urhgpu_ctx urhgpu_ctx;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+int urhgpu_version(void);
+const char *urhgpu_strerror(int status);
+const char *urhgpu_last_hip_error(void);
+int urhgpu_device_count(int *count);
+/* device = HIP ordinal.  Creates a private stream and an (initially empty) scratch arena. */
+int urhgpu_ctx_create(int device, urhgpu_ctx **out);
+int urhgpu_ctx_destroy(urhgpu_ctx *ctx);
+/* Run on the caller's stream (hipStream_t passed as void*; NULL restores the private stream). */
+int urhgpu_ctx_set_stream(urhgpu_ctx *ctx, void *hip_stream);
+int urhgpu_ctx_sync(urhgpu_ctx *ctx);
+/* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no
+ * allocation happens inside later calls (bench / steady state). */
+int urhgpu_ctx_reserve(urhgpu_ctx *ctx, int64_t n_samples, int tolerance);
+/* Device properties the host side needs to size launches / report rooflines. */
+int urhgpu_ctx_info(urhgpu_ctx *ctx, int *compute_units, int *wavefront, int64_t *hbm_bytes, char *name, int name_cap);
+
+/* Time the dominant kernel (demod + run segmentation) of subsequent fused / grab_pulse_lens calls with
+ * HIP events recorded on the context's stream: begin(max_records) arms up to max_records records
+ * (one per call); end() synchronises the stream and returns the per-call durations in ms. */
+int urhgpu_ctx_profile_begin(urhgpu_ctx *ctx, int max_records);
+int urhgpu_ctx_profile_end(urhgpu_ctx *ctx, float *ms_out, int cap, int *n_records);
+
+/* ---- host-buffer entry points: 1:1 replacements of the reference's Cython functions ------------- */
+
+/* util.get_magnitudes (src/urh/cythonext/util.pyx:128-136): out[i] = sqrt(I*I+Q*Q), float64[n]. */
+int urhgpu_get_magnitudes(urhgpu_ctx *ctx, const void *iq, int dtype, int64_t n, double *out);
+
+/* signal_functions.afp_demod (src/urh/cythonext/signal_functions.pyx:333-378).
+ * n <= 2 -> zeros.  mod PSK runs the Costas loop (costa_demod, :252-330; out[0] is written as
+ * NOISE(-4) here whereas the reference leaves it uninitialised).  noise_other is the NOISE sentinel
+ * used when mod == URHGPU_MOD_OTHER (get_noise_for_mod_type, :31-44). */
+int urhgpu_afp_demod(urhgpu_ctx *ctx, const void *iq, int dtype, int64_t n, float noise_mag, int mod,
+                     int mod_order, float costas_loop_bandwidth, float noise_other, float *qad_out);
+
+/* signal_functions.get_center_thresholds (:380-390): out has modulation_order-1 floats.  Host only. */
+int urhgpu_get_center_thresholds(float center, float spacing, int modulation_order, float *out);
+
+/* signal_functions.grab_pulse_lens (:392-495): qad float32[n] -> rows int64[n_rows][2] = [state, length]
+ * (state -1 = pause).  rows_out has room for cap_rows rows; *n_rows receives the row count (also on
+ * URHGPU_ERR_CAPACITY, so the caller can retry). */
+int urhgpu_grab_pulse_lens(urhgpu_ctx *ctx, const float *qad, int64_t n, float center, uint16_t tolerance,
+                           int mod, uint32_t samples_per_symbol, uint8_t bits_per_symbol, float center_spacing,
+                           float noise_other, int64_t *rows_out, int64_t cap_rows, int64_t *n_rows);
+
+/* ProtocolAnalyzer._ppseq_to_bits (src/urh/signalprocessing/ProtocolAnalyzer.py:323-414), flat outputs:
+ *   bits[0..n_bits)      one byte per bit, all messages back to back
+ *   msg_off[0..n_msg]    offsets of each message in bits[]
+ *   pauses[0..n_msg)     pause after each message, in samples
+ *   pos[0..n_pos)        bit_sample_pos arrays back to back (only when write_pos != 0)
+ *   pos_off[0..n_msg]    offsets of each message in pos[]
+ * counts[3] receives {n_msg, n_bits, n_pos}. */
+int urhgpu_ppseq_to_bits(urhgpu_ctx *ctx, const int64_t *rows, int64_t n_rows, int64_t samples_per_symbol,
+                         int bits_per_symbol, int write_pos, int64_t pause_threshold,
+                         uint8_t *bits, int64_t cap_bits, int64_t *msg_off, int64_t *pauses, int64_t cap_msg,
+                         int64_t *pos, int64_t cap_pos, int64_t *pos_off, int64_t *counts);
+
+/* signal_functions.fir_filter (:513-525): complex64 x[n] (*) complex64 taps[m], causal, zero history,
+ * accumulation order of the reference's scatter loop. */
+int urhgpu_fir_filter(urhgpu_ctx *ctx, const float *x, int64_t n, const float *taps, int64_t m, float *out);
+
+/* signal_functions.iir_filter (:527-542). */
+int urhgpu_iir_filter(urhgpu_ctx *ctx, const double *a, int64_t na, const double *b, int64_t nb,
+                      const float *x, int64_t n, float *out);
+
+/* ---- device-resident entry points ------------------------------------------------------------------ */
+
+/* Demodulation + digitization parameters (Signal.py:42-109 defaults in comments). */
+typedef struct urhgpu_params {
+    int dtype;                  /* URHGPU_DT_* of the IQ buffer */
+    int mod;                    /* URHGPU_MOD_* */
+    int bits_per_symbol;        /* 1 */
+    float noise_threshold;      /* Signal.noise_threshold (magnitude, not squared) */
+    float center;               /* 0.02 */
+    float center_spacing;       /* 1.0 */
+    int tolerance;              /* 5 */
+    uint32_t samples_per_symbol; /* 100 */
+    float costas_loop_bandwidth; /* 0.1 */
+    int64_t pause_threshold;    /* 8 */
+    int write_bit_sample_pos;   /* 1 in the reference (get_protocol_from_signal) */
+    float noise_other;          /* NOISE sentinel for URHGPU_MOD_OTHER */
+    int mod_order;              /* 0 = 2^bits_per_symbol; afp_demod's mod_order argument (Costas loop order) */
+} urhgpu_params;
+
+/* Output descriptor of the fused path.  All pointers are DEVICE pointers owned by the caller; any
+ * of qad / pos may be NULL (not materialised).  counts (device int64[4]) receives
+ * {n_rows, n_msg, n_bits, n_pos}; the caller reads it back (32 bytes) when it needs the sizes.
+ * n_rows is clamped to cap_rows; a table that did not fit shows as n_rows == cap_rows. */
+typedef struct urhgpu_outputs {
+    float *qad;            /* float32[n]  demodulated signal (Signal.qad) or NULL */
+    int64_t *rows;         /* int64[cap_rows][2] pulse table (grab_pulse_lens result) */
+    int64_t cap_rows;
+    uint8_t *bits;         /* uint8[cap_bits] */
+    int64_t cap_bits;
+    int64_t *msg_off;      /* int64[cap_msg+1] */
+    int64_t *pauses;       /* int64[cap_msg] */
+    int64_t cap_msg;
+    int64_t *pos;          /* int64[cap_pos] or NULL */
+    int64_t cap_pos;
+    int64_t *pos_off;      /* int64[cap_msg+1] */
+    int64_t *counts;       /* int64[4] */
+} urhgpu_outputs;
+
+/* afp_demod on device memory (ASK/FSK/OTHER: one streaming kernel; PSK: Costas loop). */
+int urhgpu_afp_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad);
+
+/* grab_pulse_lens on device memory: d_qad float32[n] -> d_rows; d_n_rows is a device int64. */
+int urhgpu_grab_pulse_lens_dev(urhgpu_ctx *ctx, const float *d_qad, int64_t n, const urhgpu_params *p,
+                               int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows);
+
+/* _ppseq_to_bits on device memory (rows -> bits/pauses/positions); uses out->{bits..counts}. */
+int urhgpu_ppseq_to_bits_dev(urhgpu_ctx *ctx, const int64_t *d_rows, const int64_t *d_n_rows, int64_t cap_rows_hint,
+                             const urhgpu_params *p, const urhgpu_outputs *out);
+
+/* THE fused hot path: IQ (device) -> [qad] -> pulse table -> bits, everything device resident.
+ * ASK/FSK run demodulation and run segmentation in ONE pass over the IQ stream (8 B read +
+ * 4 B qad write per sample); PSK runs the Costas kernel and then the qad-input segmentation.
+ * left_halo: NULL for a capture that starts at global sample 0; otherwise DEVICE pointer to the 2 IQ
+ * samples preceding d_iq[0] (sharded captures, see urh_amd/sharding.py). */
+int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p,
+                          const urhgpu_outputs *out);
+
+/* Magnitude chunk statistics for AutoInterpretation.detect_noise_level
+ * (src/urh/ainterpretation/AutoInterpretation.py:60-91): chunks of `chunk` samples taken from the END
+ * of the capture backwards; d_sum[k] (float64) / d_max[k] (float64) for chunk k counted from the end. */
+int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, int64_t chunk,
+                                     int64_t n_chunks, double *d_sum, double *d_max);
+
+/* Test hook: elementwise bit-faithful atan2f (the device port of glibc 2.35 atan2f), device pointers. */
+int urhgpu_test_atan2f_dev(urhgpu_ctx *ctx, const float *d_y, const float *d_x, int64_t n, float *d_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* URHGPU_H */

@@ -22,13 +22,19 @@ def setup():
     if not build_ref.build():
         raise RuntimeError("reference build unavailable")
     stub = os.path.join(HERE, "pyqt6_stub")
-    for p in (os.path.join(REF_ROOT, "src"), stub):
+    src = os.path.join(REF_ROOT, "src")
+    for p in (src, stub):
         if p not in sys.path:
             sys.path.insert(0, p)
+    # `urh` may already have been imported from oracle/_ref (build_ref.import_ref()); either way make
+    # the package span both trees: Python sources from the reference, compiled modules from oracle/_ref.
+    import urh
     import urh.cythonext as ce
-    pkg = os.path.join(build_ref.OUT, "urh", "cythonext")
-    if pkg not in ce.__path__:
-        ce.__path__.append(pkg)
+    for pkg, sub in ((urh, ""), (ce, "cythonext")):
+        for base in (os.path.join(src, "urh"), os.path.join(build_ref.OUT, "urh")):
+            d = os.path.join(base, sub) if sub else base
+            if os.path.isdir(d) and d not in pkg.__path__:
+                pkg.__path__.append(d)
     # path_creator (plot decimation) needs a real PyQt6 and is off the hot path: inert placeholder.
     import types
     for name in ("path_creator",):

@@ -360,3 +360,8 @@ int64_t orc_ppseq_to_bits(const int64_t *ppseq, int64_t nrows, int64_t samples_p
     }
     return nmsg;
 }
+
+/* test helper: elementwise host-libm atan2f (what the reference's FSK branch calls) */
+void orc_atan2f_array(const float *y, const float *x, int64_t n, float *out) {
+    for (int64_t i = 0; i < n; i++) out[i] = atan2f(y[i], x[i]);
+}

@@ -68,6 +68,16 @@ def _iq2d(samples):
     return a
 
 
+def atan2f(y, x) -> np.ndarray:
+    """elementwise host-libm atan2f"""
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(y)
+    lib().orc_atan2f_array(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_int64(len(y)),
+                           out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def get_magnitudes(arr) -> np.ndarray:
     a = _iq2d(arr)
     out = np.zeros(len(a), dtype=np.float64)

@@ -1,0 +1,176 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the committed golden vectors of the
+real reference and against the oracle on seeded inputs.  Bit-exact everywhere: integer tables, bit
+strings AND the float32 demodulated signal (ASK: IEEE ops only; FSK: fdlibm atan2f restated on the GPU).
+Run on the GPU box:  python -m pytest tests -m gpu
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES, load_golden, synth_fsk
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sf():
+    from urh_amd import signal_functions
+    return signal_functions
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    from urh_amd.pipeline import DevicePipeline
+    return DevicePipeline()
+
+
+def bits_equal(a, b):
+    return np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_device_atan2f_is_glibc_atan2f(oracle):
+    import torch
+    from urh_amd import _lib
+    rng = np.random.default_rng(0)
+    n = 1 << 22
+    raw = rng.integers(0, 2 ** 32, size=(4, n), dtype=np.uint64).astype(np.uint32)
+    y = np.concatenate([raw[0].view(np.float32), (rng.standard_normal(n) * 0.3).astype(np.float32),
+                        np.array([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45, 3e38], np.float32)])
+    x = np.concatenate([raw[1].view(np.float32), (1 + rng.standard_normal(n) * 0.3).astype(np.float32),
+                        np.array([0.0, 0.0, -0.0, -0.0, 0.0, 0.0, np.inf, -np.inf, 1.0, 3e38, 1e-45], np.float32)])
+    want = oracle.atan2f(y, x)
+    dy, dx = torch.from_numpy(y).cuda(), torch.from_numpy(x).cuda()
+    out = torch.empty_like(dy)
+    ctx = _lib.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.load().urhgpu_test_atan2f_dev(ctx.handle, C.c_void_p(dy.data_ptr()), C.c_void_p(dx.data_ptr()),
+                                                  len(y), C.c_void_p(out.data_ptr())))
+    got = out.cpu().numpy()
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), f"{(~same).sum()} of {len(y)} differ"
+
+
+@pytest.mark.parametrize("name", GOLDEN_CASES)
+def test_golden_host_api(sf, name):
+    g = load_golden(name)
+    mod, bps = g["modulation_type"], g["bits_per_symbol"]
+    if mod != "PSK":
+        qad = sf.afp_demod(g["iq"], g["noise_threshold"], mod, 2 ** bps, g["costas_loop_bandwidth"])
+        assert bits_equal(qad, g["qad"]), int((qad.view(np.uint32) != g["qad"].view(np.uint32)).sum())
+    pp = sf.grab_pulse_lens(g["qad"], g["center"], g["tolerance"], mod, g["samples_per_symbol"], bps, g["center_spacing"])
+    assert np.array_equal(pp, g["ppseq"])
+    bits, off, pauses, pos, poff = sf.ppseq_to_bits_flat(g["ppseq"], g["samples_per_symbol"], bps, True, g["pause_threshold"])
+    assert np.array_equal(bits, g["bits"]) and np.array_equal(off, g["msg_off"])
+    assert np.array_equal(pauses, g["pauses"]) and np.array_equal(pos, g["pos"]) and np.array_equal(poff, g["pos_off"])
+    if g["kat"]:
+        first = "".join(map(str, bits[off[0]:off[1]]))
+        assert first == g["kat"] if g["kat_mode"] == "exact" else first.startswith(g["kat"])
+
+
+@pytest.mark.parametrize("name", [c for c in GOLDEN_CASES if not c.startswith("psk")])
+def test_golden_fused_device_path(pipe, name):
+    import torch
+    from urh_amd.pipeline import DemodParams
+    g = load_golden(name)
+    p = DemodParams(g["modulation_type"], g["bits_per_symbol"], g["noise_threshold"], g["center"], g["center_spacing"],
+                    g["tolerance"], g["samples_per_symbol"], g["costas_loop_bandwidth"], g["pause_threshold"], True)
+    iq = torch.from_numpy(g["iq"]).cuda()
+    res = pipe.iq_to_bits(iq, p, want_qad=True)
+    assert bits_equal(res.qad.cpu().numpy(), g["qad"])
+    assert np.array_equal(res.ppseq(), g["ppseq"])
+    bits, off, pauses, pos, poff = res.flat()
+    assert np.array_equal(bits, g["bits"]) and np.array_equal(off, g["msg_off"])
+    assert np.array_equal(pauses, g["pauses"]) and np.array_equal(pos, g["pos"]) and np.array_equal(poff, g["pos_off"])
+    # bits-only mode (qad not materialised) gives the same table
+    res2 = pipe.iq_to_bits(iq, p, want_qad=False)
+    assert np.array_equal(res2.ppseq(), g["ppseq"])
+
+
+SIZES = [1, 2, 3, 4, 5, 63, 64, 65, 511, 512, 513, 1023, 8191, 8192, 8193, 16384 + 7, 70001, 300000]
+
+
+@pytest.mark.parametrize("mod", ["FSK", "ASK"])
+def test_afp_demod_sizes_and_dtypes(sf, oracle, mod):
+    for dtype in (np.float32, np.int8, np.uint8, np.int16, np.uint16):
+        for n in SIZES:
+            iq = synth_fsk(n, sps=20, seed=n, noise=0.1, pause_every=500, pause_len=90, dtype=dtype)
+            scale = 1.0 if dtype == np.float32 else float(np.abs(iq.astype(np.float64)).max())
+            for noise in (0.0, 0.4 * scale):
+                want = oracle.afp_demod(iq, noise, mod, 2)
+                got = sf.afp_demod(iq, noise, mod, 2)
+                assert bits_equal(got, want), (mod, np.dtype(dtype).name, n, noise, int((got != want).sum()))
+
+
+def test_afp_demod_signed_zero_and_nonfinite(sf, oracle):
+    vals = np.array([0.0, -0.0, 1.0, -1.0, 1e-40, -1e-40, 1e-30, 3e38, -3e38, 0.5, -0.25], dtype=np.float32)
+    rng = np.random.default_rng(5)
+    iq = vals[rng.integers(0, len(vals), size=(100000, 2))]
+    for mod in ("FSK", "ASK"):
+        want = oracle.afp_demod(iq, 0.0, mod, 2)
+        got = sf.afp_demod(iq, 0.0, mod, 2)
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (mod, int((~same).sum()))
+
+
+def _rect(rng, n, mod, bps, noise_val):
+    levels = rng.choice([-1.0, -0.3, 0.3, 1.0] if bps == 2 else [-0.5, 0.5], size=n // max(1, int(rng.integers(1, 60))) + 1)
+    x = np.repeat(levels, n // len(levels) + 1)[:n].astype(np.float32)
+    x[rng.random(n) < rng.choice([0, 0.02, 0.1, 0.3])] *= -1
+    for _ in range(int(rng.integers(0, 5))):
+        a = int(rng.integers(0, n))
+        x[a:min(n, a + int(rng.integers(1, 3000)))] = noise_val
+    if mod == "ASK":
+        x = np.abs(x)
+    return x
+
+
+def test_grab_pulse_lens_randomised(sf, oracle):
+    rng = np.random.default_rng(3)
+    for it in range(150):
+        n = int(rng.choice(SIZES + [40000, 123457]))
+        mod = ["ASK", "FSK", "PSK"][it % 3]
+        bps = int(rng.integers(1, 4))
+        tol = int(rng.choice([0, 1, 2, 5, 7, 33, 100, 3000, 20000]))
+        sps = int(rng.choice([3, 8, 100]))
+        x = _rect(rng, n, mod, min(bps, 2), oracle.noise_for_mod_type(mod))
+        center, spacing = (0.0 if mod != "ASK" else 0.4), float(rng.choice([0.1, 0.6]))
+        want = oracle.grab_pulse_lens(x, center, tol, mod, sps, bps, spacing)
+        got = sf.grab_pulse_lens(x, center, tol, mod, sps, bps, spacing)
+        assert np.array_equal(want, got), (it, n, mod, bps, tol, sps, len(want), len(got))
+        for pt in (0, 8):
+            fb = oracle.ppseq_to_bits_flat(want, sps, bps, True, pt)
+            gb = sf.ppseq_to_bits_flat(got, sps, bps, True, pt)
+            assert all(np.array_equal(a, b) for a, b in zip(fb, gb)), (it, pt)
+
+
+def test_empty_and_tiny_inputs(sf):
+    assert sf.afp_demod(np.zeros((0, 2), np.float32), 0.0, "FSK", 2).shape == (0,)
+    assert sf.afp_demod(np.ones((2, 2), np.float32), 0.0, "FSK", 2).tolist() == [0.0, 0.0]       # n <= 2 -> zeros
+    assert sf.grab_pulse_lens(np.zeros(0, np.float32), 0.0, 5, "FSK", 100).shape == (0, 2)
+    with pytest.raises(ValueError):
+        sf.afp_demod(np.zeros((10, 2), np.float64), 0.0, "FSK", 2)                                # Unsupported dtype
+    b = sf.ppseq_to_bits(np.zeros((0, 2), np.int64), 100, 1)
+    assert b[0] == [] and list(b[1]) == [] and b[2] == []
+
+
+@pytest.mark.parametrize("mod", ["FSK", "ASK"])
+def test_fused_equals_oracle_medium(pipe, oracle, mod):
+    """1 M-sample noisy capture with silent gaps: fused device path vs the oracle, everything bit-exact."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    n = 1 << 20
+    iq = synth_fsk(n, sps=100, seed=21, noise=0.05, pause_every=150000, pause_len=9000)
+    if mod == "ASK":
+        rng = np.random.default_rng(4)
+        env = np.repeat(rng.integers(0, 2, n // 100 + 1), 100)[:n].astype(np.float32)
+        iq = (iq * (0.05 + 0.95 * env)[:, None]).astype(np.float32)
+    for noise, tol, center in ((0.0, 5, 0.0 if mod == "FSK" else 0.35), (0.2, 2, 0.0 if mod == "FSK" else 0.35)):
+        p = DemodParams(mod, 1, noise, center, 1.0, tol, 100, 0.1, 8, True)
+        qad = oracle.afp_demod(iq, noise, mod, 2)
+        pp = oracle.grab_pulse_lens(qad, center, tol, mod, 100, 1, 1.0)
+        fb = oracle.ppseq_to_bits_flat(pp, 100, 1, True, 8)
+        res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True)
+        assert bits_equal(res.qad.cpu().numpy(), qad)
+        assert np.array_equal(res.ppseq(), pp)
+        assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))

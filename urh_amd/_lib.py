@@ -1,0 +1,172 @@
+"""ctypes binding of liburhgpu.so (the C ABI declared in include/urhgpu.h).
+
+The library is the product: there is NO CPU fallback.  Importing this module only loads the shared
+object (that works without a GPU, e.g. for the symbol-export test); creating a context on a
+machine without a GPU raises `UrhGpuError`.
+"""
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liburhgpu.so")
+
+OK = 0
+ERR_HIP, ERR_DTYPE, ERR_ARG, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
+
+DT_I8, DT_U8, DT_I16, DT_U16, DT_F32 = 0, 1, 2, 3, 4
+MOD_ASK, MOD_FSK, MOD_PSK, MOD_OTHER = 0, 1, 2, 3
+
+
+class UrhGpuError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(msg)
+        self.status = status
+
+
+class Params(C.Structure):
+    """struct urhgpu_params (include/urhgpu.h)"""
+    _fields_ = [
+        ("dtype", C.c_int), ("mod", C.c_int), ("bits_per_symbol", C.c_int),
+        ("noise_threshold", C.c_float), ("center", C.c_float), ("center_spacing", C.c_float),
+        ("tolerance", C.c_int), ("samples_per_symbol", C.c_uint32), ("costas_loop_bandwidth", C.c_float),
+        ("pause_threshold", C.c_int64), ("write_bit_sample_pos", C.c_int), ("noise_other", C.c_float),
+        ("mod_order", C.c_int),
+    ]
+
+
+class Outputs(C.Structure):
+    """struct urhgpu_outputs (include/urhgpu.h); all pointers are device pointers"""
+    _fields_ = [
+        ("qad", C.c_void_p), ("rows", C.c_void_p), ("cap_rows", C.c_int64),
+        ("bits", C.c_void_p), ("cap_bits", C.c_int64),
+        ("msg_off", C.c_void_p), ("pauses", C.c_void_p), ("cap_msg", C.c_int64),
+        ("pos", C.c_void_p), ("cap_pos", C.c_int64), ("pos_off", C.c_void_p),
+        ("counts", C.c_void_p),
+    ]
+
+
+# every symbol include/urhgpu.h declares: name -> (restype, argtypes)
+_vp, _i64, _i, _f = C.c_void_p, C.c_int64, C.c_int, C.c_float
+PROTOTYPES = {
+    "urhgpu_version": (_i, []),
+    "urhgpu_strerror": (C.c_char_p, [_i]),
+    "urhgpu_last_hip_error": (C.c_char_p, []),
+    "urhgpu_device_count": (_i, [C.POINTER(_i)]),
+    "urhgpu_ctx_create": (_i, [_i, C.POINTER(_vp)]),
+    "urhgpu_ctx_destroy": (_i, [_vp]),
+    "urhgpu_ctx_set_stream": (_i, [_vp, _vp]),
+    "urhgpu_ctx_sync": (_i, [_vp]),
+    "urhgpu_ctx_reserve": (_i, [_vp, _i64, _i]),
+    "urhgpu_ctx_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.c_char_p, _i]),
+    "urhgpu_ctx_profile_begin": (_i, [_vp, _i]),
+    "urhgpu_ctx_profile_end": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
+    "urhgpu_get_magnitudes": (_i, [_vp, _vp, _i, _i64, _vp]),
+    "urhgpu_afp_demod": (_i, [_vp, _vp, _i, _i64, _f, _i, _i, _f, _f, _vp]),
+    "urhgpu_get_center_thresholds": (_i, [_f, _f, _i, _vp]),
+    "urhgpu_grab_pulse_lens": (_i, [_vp, _vp, _i64, _f, C.c_uint16, _i, C.c_uint32, C.c_uint8, _f, _f, _vp, _i64,
+                                    C.POINTER(_i64)]),
+    "urhgpu_ppseq_to_bits": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "urhgpu_fir_filter": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "urhgpu_iir_filter": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "urhgpu_afp_demod_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp]),
+    "urhgpu_grab_pulse_lens_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp, _i64, _vp]),
+    "urhgpu_ppseq_to_bits_dev": (_i, [_vp, _vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
+    "urhgpu_iq_to_bits_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
+    "urhgpu_magnitude_chunk_stats_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp]),
+    "urhgpu_test_atan2f_dev": (_i, [_vp, _vp, _vp, _i64, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """Load liburhgpu.so; raises if it has not been built (python -m urh_amd.build)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise UrhGpuError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: build it with `python -m urh_amd.build` "
+                                                 "(there is no CPU fallback)")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in PROTOTYPES.items():
+                fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(status: int):
+    if status == OK:
+        return
+    lib = load()
+    msg = lib.urhgpu_strerror(status).decode()
+    if status == ERR_HIP:
+        msg += ": " + lib.urhgpu_last_hip_error().decode()
+    if status == ERR_DTYPE:
+        raise ValueError("Unsupported dtype")      # same exception as the reference (signal_functions.pyx:283,354)
+    raise UrhGpuError(status, msg)
+
+
+class Context:
+    """One GPU context (stream + scratch arena).  Not thread-safe: one per host thread."""
+
+    def __init__(self, device: int = 0):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.urhgpu_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, stream_ptr):
+        check(load().urhgpu_ctx_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def sync(self):
+        check(load().urhgpu_ctx_sync(self._h))
+
+    def reserve(self, n_samples: int, tolerance: int):
+        check(load().urhgpu_ctx_reserve(self._h, int(n_samples), int(tolerance)))
+
+    def info(self):
+        cu, wf, mem = C.c_int(), C.c_int(), C.c_int64()
+        name = C.create_string_buffer(256)
+        check(load().urhgpu_ctx_info(self._h, C.byref(cu), C.byref(wf), C.byref(mem), name, 256))
+        return {"compute_units": cu.value, "wavefront": wf.value, "hbm_bytes": mem.value, "name": name.value.decode()}
+
+    def profile_begin(self, max_records: int):
+        check(load().urhgpu_ctx_profile_begin(self._h, int(max_records)))
+
+    def profile_end(self, cap: int = 4096):
+        ms = (C.c_float * cap)()
+        n = C.c_int(0)
+        check(load().urhgpu_ctx_profile_end(self._h, ms, cap, C.byref(n)))
+        return [float(ms[i]) for i in range(min(n.value, cap))]
+
+    def close(self):
+        if self._h:
+            load().urhgpu_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_tls = threading.local()
+
+
+def default_context() -> Context:
+    """Per-thread default context on device $URHGPU_DEVICE (default 0)."""
+    ctx = getattr(_tls, "ctx", None)
+    if ctx is None or ctx._h is None:
+        ctx = Context(int(os.environ.get("URHGPU_DEVICE", "0")))
+        _tls.ctx = ctx
+    return ctx

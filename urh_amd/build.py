@@ -1,0 +1,51 @@
+"""Build liburhgpu.so (hand-written HIP for gfx950 + the C ABI of include/urhgpu.h) in-tree.
+
+    python -m urh_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU.  Flags that matter for bit-exactness:
+  -ffp-contract=off   the reference's x86-64 build contains no FMA contraction
+  (fp32 division / sqrt are hipcc's default correctly rounded forms; fp32 denormals are on).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "liburhgpu.so")
+SOURCES = ["demod_runs.hip", "pulse_table.hip", "filters.hip", "capi.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _newest_source() -> float:
+    t = 0.0
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in os.listdir(root):
+            t = max(t, os.path.getmtime(os.path.join(root, f)))
+    return t
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for src, pr in procs:
+        if pr.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,508 @@
+// capi.hip -- the extern "C" surface declared in include/urhgpu.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <math.h>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+#include "runs.hpp"
+
+namespace urh {
+
+thread_local char g_hip_err[256] = "";
+
+int Arena::reserve(size_t bytes) {
+    if (bytes <= cap) return URHGPU_OK;
+    if (base) { URH_HIP(hipFree(base)); base = nullptr; cap = 0; }
+    const size_t want = (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+    URH_HIP(hipMalloc(&base, want));
+    cap = want;
+    used = 0;
+    return URHGPU_OK;
+}
+void Arena::release() {
+    if (base) { (void)hipFree(base); base = nullptr; cap = 0; used = 0; }
+}
+
+}  // namespace urh
+
+#include "launchers.hpp"
+
+using namespace urh;
+
+namespace {
+
+struct Plan {                 // how a capture of n samples is cut into chunks
+    int64_t n_chunks;
+    int64_t chunk_len;
+    int64_t slab_stride;
+};
+
+Plan make_plan(const urhgpu_ctx *ctx, int64_t n, int tol) {
+    Plan pl;
+    const int64_t tiles = std::max<int64_t>(1, (n + kTile - 1) / kTile);
+    const int64_t target = (int64_t)ctx->prop.multiProcessorCount * 8;       // ~8 workgroups per CU
+    const int64_t tiles_per_chunk = std::max<int64_t>(1, (tiles + target - 1) / target);
+    pl.chunk_len = tiles_per_chunk * kTile;
+    pl.n_chunks = std::max<int64_t>(1, (n + pl.chunk_len - 1) / pl.chunk_len);
+    pl.slab_stride = pl.chunk_len / ((int64_t)tol + 1) + 2;
+    return pl;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+size_t digitize_scratch_bytes(const Plan &pl, int64_t cap_rows, bool ask, bool bits) {
+    size_t b = 0;
+    b += align256((size_t)pl.n_chunks * sizeof(ChunkInfo));
+    b += align256((size_t)pl.n_chunks * pl.slab_stride * 8);
+    if (ask) b += align256((size_t)cap_rows * 16) + align256(merge_scratch_bytes(cap_rows));
+    if (bits) b += align256(bits_scratch_bytes(cap_rows));
+    b += 4096;
+    return b;
+}
+
+int fill_thresholds(RunArgs &a, const urhgpu_params *p) {
+    if (p->bits_per_symbol < 1 || p->bits_per_symbol > 7) return URHGPU_ERR_UNSUPPORTED;
+    a.order = 1 << p->bits_per_symbol;
+    urhgpu_get_center_thresholds(p->center, p->center_spacing, a.order, a.thr);
+    return URHGPU_OK;
+}
+
+float noise_for(const urhgpu_params *p) {
+    switch (p->mod) {
+        case URHGPU_MOD_ASK: return 0.0f;
+        case URHGPU_MOD_FSK:
+        case URHGPU_MOD_PSK: return -4.0f;
+        default: return p->noise_other;
+    }
+}
+
+// reference: signal_functions.pyx:343-354 (double sqrt of the integer constant, stored to float)
+int max_magnitude_for(int dtype, float *out) {
+    switch (dtype) {
+        case URHGPU_DT_I8: *out = (float)sqrt(32513.0); return URHGPU_OK;
+        case URHGPU_DT_U8: *out = (float)sqrt(65025.0); return URHGPU_OK;
+        case URHGPU_DT_I16: *out = (float)sqrt(2147418113.0); return URHGPU_OK;
+        case URHGPU_DT_U16: *out = (float)sqrt(4294836225.0); return URHGPU_OK;
+        case URHGPU_DT_F32: *out = (float)sqrt(2.0); return URHGPU_OK;
+        default: return URHGPU_ERR_DTYPE;
+    }
+}
+
+int dtype_bytes(int dtype) {
+    switch (dtype) {
+        case URHGPU_DT_I8: case URHGPU_DT_U8: return 2;
+        case URHGPU_DT_I16: case URHGPU_DT_U16: return 4;
+        case URHGPU_DT_F32: return 8;
+        default: return 0;
+    }
+}
+
+// Core of grab_pulse_lens / the fused path: run-segmentation kernel (IQ or qad source), resolve,
+// emit rows, optional ASK merge.  On return d_rows / d_n_rows hold the final pulse table.
+// scratch must come from ctx->arena (already reserved by the caller).
+int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const urhgpu_params *p, float *d_qad,
+             int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows, int64_t *d_n_rows_needed, int64_t *d_n_acc,
+             const Plan &pl) {
+    hipStream_t s = ctx->stream;
+    RunArgs a;
+    memset(&a, 0, sizeof(a));
+    URH_TRY(fill_thresholds(a, p));
+    a.in = d_in; a.qad = d_qad; a.left_halo = nullptr; a.n = n; a.pos_base = 0;
+    a.chunk_len = pl.chunk_len; a.slab_stride = pl.slab_stride;
+    a.noise_sqrd = p->noise_threshold * p->noise_threshold;
+    a.noise_val = noise_for(p);
+    a.tol = p->tolerance;
+    if (from_iq) URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
+    ChunkInfo *chunks = (ChunkInfo *)ctx->arena.take((size_t)pl.n_chunks * sizeof(ChunkInfo));
+    uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
+    if (!chunks || !slab) return URHGPU_ERR_ARG;
+    a.chunks = chunks; a.slab = slab;
+    const bool prof = ctx->prof_on && (size_t)(2 * ctx->prof_used + 1) < ctx->prof_events.size();
+    if (prof) URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used], s));
+    if (from_iq) URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, pl.n_chunks, d_qad != nullptr, s));
+    else URH_TRY(launch_runs_qad(a, pl.n_chunks, s));
+    if (prof) { URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], s)); ctx->prof_used += 1; }
+
+    const bool ask = (p->mod == URHGPU_MOD_ASK);
+    int64_t *rows_stage = d_rows;
+    int64_t *d_n_stage = d_n_rows;
+    void *merge_scratch = nullptr;
+    if (ask) {
+        rows_stage = (int64_t *)ctx->arena.take((size_t)cap_rows * 16);
+        merge_scratch = ctx->arena.take(merge_scratch_bytes(cap_rows));
+        d_n_stage = (int64_t *)ctx->arena.take(64);
+        if (!rows_stage || !merge_scratch || !d_n_stage) return URHGPU_ERR_ARG;
+    }
+    ResolveArgs r;
+    r.chunks = chunks; r.n_chunks = pl.n_chunks; r.n_total = n; r.tol = p->tolerance;
+    r.rows = rows_stage; r.cap_rows = cap_rows; r.d_n_acc = d_n_acc; r.d_n_rows = d_n_stage;
+    r.d_n_rows_needed = d_n_rows_needed; r.write_last_row = 1;
+    URH_TRY(launch_resolve(r, s));
+    EmitArgs e;
+    e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
+    e.rows = rows_stage; e.cap_rows = cap_rows; e.row_base = 0; e.is_ask = ask ? 1 : 0; e.sps = p->samples_per_symbol;
+    URH_TRY(launch_emit_rows(e, pl.n_chunks, s));
+    if (ask) URH_TRY(launch_merge_rows_ask(rows_stage, d_n_stage, cap_rows, d_rows, cap_rows, d_n_rows, merge_scratch, s));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+BitsParams bits_params(const urhgpu_params *p) {
+    BitsParams bp;
+    bp.sps = (int64_t)p->samples_per_symbol;
+    bp.bps = p->bits_per_symbol;
+    bp.pause_threshold = p->pause_threshold;
+    bp.samples_per_bit = (int64_t)((double)p->samples_per_symbol / (double)p->bits_per_symbol);   // int(sps / bps) :344
+    bp.write_pos = p->write_bit_sample_pos ? 1 : 0;
+    return bp;
+}
+
+}  // namespace
+
+extern "C" {
+
+int urhgpu_version(void) { return URHGPU_VERSION; }
+
+const char *urhgpu_strerror(int status) {
+    switch (status) {
+        case URHGPU_OK: return "ok";
+        case URHGPU_ERR_HIP: return "HIP runtime error";
+        case URHGPU_ERR_DTYPE: return "Unsupported dtype";
+        case URHGPU_ERR_ARG: return "bad argument";
+        case URHGPU_ERR_CAPACITY: return "output capacity too small";
+        case URHGPU_ERR_UNSUPPORTED: return "parameter outside the supported range";
+        case URHGPU_ERR_NO_DEVICE: return "no usable GPU";
+        default: return "unknown status";
+    }
+}
+
+const char *urhgpu_last_hip_error(void) { return g_hip_err; }
+
+int urhgpu_device_count(int *count) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; (void)hipGetLastError(); return URHGPU_ERR_NO_DEVICE; }
+    *count = c;
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_create(int device, urhgpu_ctx **out) {
+    if (!out) return URHGPU_ERR_ARG;
+    int c = 0;
+    if (urhgpu_device_count(&c) != URHGPU_OK || c <= 0 || device < 0 || device >= c) return URHGPU_ERR_NO_DEVICE;
+    urhgpu_ctx *ctx = new (std::nothrow) urhgpu_ctx();
+    if (!ctx) return URHGPU_ERR_ARG;
+    ctx->device = device;
+    URH_HIP(hipSetDevice(device));
+    URH_HIP(hipGetDeviceProperties(&ctx->prop, device));
+    URH_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    URH_HIP(hipMalloc((void **)&ctx->d_counts, 16 * sizeof(int64_t)));
+    URH_HIP(hipHostMalloc((void **)&ctx->h_counts, 16 * sizeof(int64_t)));
+    *out = ctx;
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
+    if (!ctx) return URHGPU_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->arena.release();
+    ctx->staging.release();
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_set_stream(urhgpu_ctx *ctx, void *hip_stream) {
+    if (!ctx) return URHGPU_ERR_ARG;
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_sync(urhgpu_ctx *ctx) {
+    if (!ctx) return URHGPU_ERR_ARG;
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_info(urhgpu_ctx *ctx, int *compute_units, int *wavefront, int64_t *hbm_bytes, char *name, int name_cap) {
+    if (!ctx) return URHGPU_ERR_ARG;
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (wavefront) *wavefront = ctx->prop.warpSize;
+    if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    if (name && name_cap > 0) { strncpy(name, ctx->prop.name, (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_reserve(urhgpu_ctx *ctx, int64_t n_samples, int tolerance) {
+    if (!ctx || n_samples < 0 || tolerance < 0) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    const Plan pl = make_plan(ctx, n_samples, tolerance);
+    const int64_t cap_rows = n_samples / ((int64_t)tolerance + 1) + 2;
+    return ctx->arena.reserve(digitize_scratch_bytes(pl, cap_rows, true, true));
+}
+
+int urhgpu_ctx_profile_begin(urhgpu_ctx *ctx, int max_records) {
+    if (!ctx || max_records < 0) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    while ((int)ctx->prof_events.size() < 2 * max_records) {
+        hipEvent_t e;
+        URH_HIP(hipEventCreate(&e));
+        ctx->prof_events.push_back(e);
+    }
+    ctx->prof_used = 0;
+    ctx->prof_on = max_records > 0;
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_profile_end(urhgpu_ctx *ctx, float *ms_out, int cap, int *n_records) {
+    if (!ctx || !n_records) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->prof_on = false;
+    const int n = ctx->prof_used;
+    *n_records = n;
+    for (int k = 0; k < n && k < cap; ++k)
+        URH_HIP(hipEventElapsedTime(&ms_out[k], ctx->prof_events[2 * k], ctx->prof_events[2 * k + 1]));
+    return URHGPU_OK;
+}
+
+int urhgpu_get_center_thresholds(float center, float spacing, int modulation_order, float *out) {
+    // signal_functions.pyx:380-390; int -> float conversion, fp32 multiply and add/sub, no contraction
+    const int n = modulation_order / 2;
+    for (int i = 0; i < n; ++i) out[i] = center - (float)(n - (i + 1)) * spacing;
+    for (int i = n; i < modulation_order - 1; ++i) out[i] = center + (float)(i + 1 - n) * spacing;
+    return URHGPU_OK;
+}
+
+// ---- device-pointer entry points -------------------------------------------------------------------
+int urhgpu_afp_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad) {
+    if (!ctx || !p || n < 0 || (n > 0 && (!d_iq || !d_qad))) return URHGPU_ERR_ARG;
+    if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
+    URH_HIP(hipSetDevice(ctx->device));
+    if (n <= 2) {                                   // signal_functions.pyx:335-336
+        if (n > 0) URH_HIP(hipMemsetAsync(d_qad, 0, (size_t)n * 4, ctx->stream));
+        return URHGPU_OK;
+    }
+    if (((uintptr_t)d_iq & 15) || ((uintptr_t)d_qad & 7)) return URHGPU_ERR_ARG;
+    if (p->mod == URHGPU_MOD_PSK) return launch_costas(ctx, d_iq, n, p, d_qad);
+    RunArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = d_iq; a.qad = d_qad; a.n = n; a.left_halo = nullptr;
+    a.noise_sqrd = p->noise_threshold * p->noise_threshold;
+    a.noise_val = noise_for(p);
+    URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
+    const int64_t rows = (n + kRowSamples - 1) / kRowSamples;
+    const int grid = (int)std::min<int64_t>(rows, (int64_t)ctx->prop.multiProcessorCount * 16);
+    URH_TRY(launch_afp_demod(a, p->dtype, p->mod, grid, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_grab_pulse_lens_dev(urhgpu_ctx *ctx, const float *d_qad, int64_t n, const urhgpu_params *p,
+                               int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows) {
+    if (!ctx || !p || n < 0 || cap_rows < 0 || !d_n_rows) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    if (n == 0) {                                   // signal_functions.pyx:416-417
+        URH_HIP(hipMemsetAsync(d_n_rows, 0, 8, ctx->stream));
+        URH_HIP(hipMemsetAsync(ctx->d_counts, 0, 16 * 8, ctx->stream));
+        return URHGPU_OK;
+    }
+    if (!d_qad || !d_rows || ((uintptr_t)d_qad & 7)) return URHGPU_ERR_ARG;
+    const Plan pl = make_plan(ctx, n, p->tolerance);
+    URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, cap_rows, p->mod == URHGPU_MOD_ASK, false)));
+    ctx->arena.reset();
+    return digitize(ctx, false, d_qad, n, p, nullptr, d_rows, cap_rows, d_n_rows, ctx->d_counts + 8, ctx->d_counts + 9, pl);
+}
+
+static int ppseq_to_bits_inner(urhgpu_ctx *ctx, const int64_t *d_rows, const int64_t *d_n_rows, int64_t cap,
+                               const urhgpu_params *p, const urhgpu_outputs *out, void *scratch) {
+    BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts};
+    URH_TRY(launch_ppseq_to_bits(d_rows, d_n_rows, cap, bits_params(p), bo, scratch, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_ppseq_to_bits_dev(urhgpu_ctx *ctx, const int64_t *d_rows, const int64_t *d_n_rows, int64_t cap_rows_hint,
+                             const urhgpu_params *p, const urhgpu_outputs *out) {
+    if (!ctx || !p || !out || !d_n_rows || cap_rows_hint < 0) return URHGPU_ERR_ARG;
+    if (p->bits_per_symbol < 1 || p->samples_per_symbol < 1) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    const int64_t cap = std::max<int64_t>(cap_rows_hint, 1);
+    URH_TRY(ctx->arena.reserve(bits_scratch_bytes(cap) + 4096));
+    ctx->arena.reset();
+    void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
+    if (!scratch) return URHGPU_ERR_ARG;
+    return ppseq_to_bits_inner(ctx, d_rows, d_n_rows, cap, p, out, scratch);
+}
+
+int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p,
+                          const urhgpu_outputs *out) {
+    if (!ctx || !p || !out || n <= 0 || !d_iq || !out->rows || !out->counts) return URHGPU_ERR_ARG;
+    if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
+    if (((uintptr_t)d_iq & 15) || (out->qad && ((uintptr_t)out->qad & 7))) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    const Plan pl = make_plan(ctx, n, p->tolerance);
+    const bool ask = (p->mod == URHGPU_MOD_ASK);
+    URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, out->cap_rows, ask, true) + (out->qad ? 0 : align256((size_t)n * 4))));
+    ctx->arena.reset();
+    int64_t *d_n_rows = ctx->d_counts + 10;
+    if (n <= 2 || p->mod == URHGPU_MOD_PSK) {
+        // no fused kernel: demodulate (zeros for n <= 2, Costas loop for PSK), then segment the qad
+        float *qad = out->qad;
+        if (!qad) { qad = (float *)ctx->arena.take((size_t)n * 4); if (!qad) return URHGPU_ERR_ARG; }
+        URH_TRY(urhgpu_afp_demod_dev(ctx, d_iq, n, p, qad));
+        URH_TRY(digitize(ctx, false, qad, n, p, nullptr, out->rows, out->cap_rows, d_n_rows, ctx->d_counts + 8,
+                         ctx->d_counts + 9, pl));
+    } else {
+        URH_TRY(digitize(ctx, true, d_iq, n, p, out->qad, out->rows, out->cap_rows, d_n_rows, ctx->d_counts + 8,
+                         ctx->d_counts + 9, pl));
+    }
+    if (!out->bits || !out->msg_off || !out->pauses || !out->pos_off) return URHGPU_OK;   // pulse table only
+    const int64_t cap = std::max<int64_t>(out->cap_rows, 1);
+    void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
+    if (!scratch) return URHGPU_ERR_ARG;
+    return ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch);
+}
+
+int urhgpu_test_atan2f_dev(urhgpu_ctx *ctx, const float *d_y, const float *d_x, int64_t n, float *d_out) {
+    if (!ctx) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    launch_test_atan2f(d_y, d_x, n, d_out, ctx->stream);
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+// ---- host-buffer entry points ---------------------------------------------------------------------
+static int stage_in(urhgpu_ctx *ctx, const void *host, size_t bytes, void **dev) {
+    void *d = ctx->staging.take(bytes ? bytes : 16);
+    if (!d) return URHGPU_ERR_ARG;
+    if (bytes) URH_HIP(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    *dev = d;
+    return URHGPU_OK;
+}
+
+int urhgpu_afp_demod(urhgpu_ctx *ctx, const void *iq, int dtype, int64_t n, float noise_mag, int mod,
+                     int mod_order, float costas_loop_bandwidth, float noise_other, float *qad_out) {
+    if (!ctx || n < 0 || (n > 0 && (!iq || !qad_out))) return URHGPU_ERR_ARG;
+    const int sb = dtype_bytes(dtype);
+    if (sb == 0) return URHGPU_ERR_DTYPE;
+    if (n == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    urhgpu_params p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = dtype; p.mod = mod; p.noise_threshold = noise_mag; p.costas_loop_bandwidth = costas_loop_bandwidth;
+    p.noise_other = noise_other;
+    int bps = 0; while ((1 << (bps + 1)) <= mod_order) ++bps;
+    p.bits_per_symbol = bps > 0 ? bps : 1;
+    p.samples_per_symbol = 1;
+    const size_t in_bytes = (size_t)n * sb, out_bytes = (size_t)n * 4;
+    URH_TRY(ctx->staging.reserve(align256(in_bytes) + align256(out_bytes) + 1024));
+    ctx->staging.reset();
+    void *d_in = nullptr;
+    URH_TRY(stage_in(ctx, iq, in_bytes, &d_in));
+    float *d_out = (float *)ctx->staging.take(out_bytes);
+    p.mod_order = mod_order;   // drives the Costas loop order directly (signal_functions.pyx:358)
+    URH_TRY(urhgpu_afp_demod_dev(ctx, d_in, n, &p, d_out));
+    URH_HIP(hipMemcpyAsync(qad_out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
+int urhgpu_grab_pulse_lens(urhgpu_ctx *ctx, const float *qad, int64_t n, float center, uint16_t tolerance,
+                           int mod, uint32_t samples_per_symbol, uint8_t bits_per_symbol, float center_spacing,
+                           float noise_other, int64_t *rows_out, int64_t cap_rows, int64_t *n_rows) {
+    if (!ctx || n < 0 || !n_rows || cap_rows < 0) return URHGPU_ERR_ARG;
+    *n_rows = 0;
+    if (n == 0) return URHGPU_OK;
+    if (!qad || (cap_rows > 0 && !rows_out)) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    urhgpu_params p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = URHGPU_DT_F32; p.mod = mod; p.bits_per_symbol = bits_per_symbol; p.center = center;
+    p.center_spacing = center_spacing; p.tolerance = tolerance; p.samples_per_symbol = samples_per_symbol;
+    p.noise_other = noise_other;
+    if (bits_per_symbol < 1 || bits_per_symbol > 7) return URHGPU_ERR_UNSUPPORTED;
+    // worst case one row per (tolerance+1) samples; stage at that size on the device, copy what fits
+    const int64_t dev_cap = n / ((int64_t)tolerance + 1) + 2;
+    URH_TRY(ctx->staging.reserve(align256((size_t)n * 4) + align256((size_t)dev_cap * 16) + 1024));
+    ctx->staging.reset();
+    void *d_in = nullptr;
+    URH_TRY(stage_in(ctx, qad, (size_t)n * 4, &d_in));
+    int64_t *d_rows = (int64_t *)ctx->staging.take((size_t)dev_cap * 16);
+    int64_t *d_n = ctx->d_counts + 10;
+    URH_TRY(urhgpu_grab_pulse_lens_dev(ctx, (const float *)d_in, n, &p, d_rows, dev_cap, d_n));
+    URH_HIP(hipMemcpyAsync(ctx->h_counts, d_n, 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t rows = ctx->h_counts[0];
+    *n_rows = rows;
+    if (rows > cap_rows) return URHGPU_ERR_CAPACITY;
+    if (rows > 0) {
+        URH_HIP(hipMemcpyAsync(rows_out, d_rows, (size_t)rows * 16, hipMemcpyDeviceToHost, ctx->stream));
+        URH_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return URHGPU_OK;
+}
+
+int urhgpu_ppseq_to_bits(urhgpu_ctx *ctx, const int64_t *rows, int64_t n_rows, int64_t samples_per_symbol,
+                         int bits_per_symbol, int write_pos, int64_t pause_threshold,
+                         uint8_t *bits, int64_t cap_bits, int64_t *msg_off, int64_t *pauses, int64_t cap_msg,
+                         int64_t *pos, int64_t cap_pos, int64_t *pos_off, int64_t *counts) {
+    if (!ctx || n_rows < 0 || !counts || !msg_off || !pos_off || samples_per_symbol < 1 || bits_per_symbol < 1)
+        return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    urhgpu_params p;
+    memset(&p, 0, sizeof(p));
+    p.samples_per_symbol = (uint32_t)samples_per_symbol; p.bits_per_symbol = bits_per_symbol;
+    p.pause_threshold = pause_threshold; p.write_bit_sample_pos = write_pos;
+    const int64_t cb = std::max<int64_t>(cap_bits, 1), cm = std::max<int64_t>(cap_msg, 1), cp = std::max<int64_t>(cap_pos, 1);
+    const size_t need = align256((size_t)std::max<int64_t>(n_rows, 1) * 16) + align256((size_t)cb) + 3 * align256((size_t)(cm + 1) * 8) +
+                        align256((size_t)cp * 8) + 4096;
+    URH_TRY(ctx->staging.reserve(need));
+    ctx->staging.reset();
+    void *d_rows = nullptr;
+    URH_TRY(stage_in(ctx, rows, (size_t)n_rows * 16, &d_rows));
+    urhgpu_outputs o;
+    memset(&o, 0, sizeof(o));
+    o.bits = (uint8_t *)ctx->staging.take((size_t)cb); o.cap_bits = cap_bits;
+    o.msg_off = (int64_t *)ctx->staging.take((size_t)(cm + 1) * 8);
+    o.pauses = (int64_t *)ctx->staging.take((size_t)(cm + 1) * 8); o.cap_msg = cap_msg;
+    o.pos_off = (int64_t *)ctx->staging.take((size_t)(cm + 1) * 8);
+    o.pos = (int64_t *)ctx->staging.take((size_t)cp * 8); o.cap_pos = cap_pos;
+    o.counts = ctx->d_counts;
+    int64_t *d_n = ctx->d_counts + 10;
+    ctx->h_counts[8] = n_rows;
+    URH_HIP(hipMemcpyAsync(d_n, ctx->h_counts + 8, 8, hipMemcpyHostToDevice, ctx->stream));
+    URH_TRY(urhgpu_ppseq_to_bits_dev(ctx, (const int64_t *)d_rows, d_n, n_rows, &p, &o));
+    URH_HIP(hipMemcpyAsync(ctx->h_counts, ctx->d_counts, 4 * 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    const int64_t n_msg = ctx->h_counts[1], n_bits = ctx->h_counts[2], n_pos = ctx->h_counts[3];
+    counts[0] = n_msg; counts[1] = n_bits; counts[2] = n_pos;
+    if (n_msg > cap_msg || n_bits > cap_bits || (write_pos && n_pos > cap_pos)) return URHGPU_ERR_CAPACITY;
+    if (n_bits) URH_HIP(hipMemcpyAsync(bits, o.bits, (size_t)n_bits, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipMemcpyAsync(msg_off, o.msg_off, (size_t)(n_msg + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipMemcpyAsync(pos_off, o.pos_off, (size_t)(n_msg + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_msg) URH_HIP(hipMemcpyAsync(pauses, o.pauses, (size_t)n_msg * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (write_pos && n_pos) URH_HIP(hipMemcpyAsync(pos, o.pos, (size_t)n_pos * 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
+// ---- not yet implemented on the GPU (round-1 order: FSK/ASK path first) ---------------------------
+int urhgpu_get_magnitudes(urhgpu_ctx *, const void *, int, int64_t, double *) { return URHGPU_ERR_UNSUPPORTED; }
+int urhgpu_fir_filter(urhgpu_ctx *, const float *, int64_t, const float *, int64_t, float *) { return URHGPU_ERR_UNSUPPORTED; }
+int urhgpu_iir_filter(urhgpu_ctx *, const double *, int64_t, const double *, int64_t, const float *, int64_t, float *) {
+    return URHGPU_ERR_UNSUPPORTED;
+}
+int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *, const void *, int, int64_t, int64_t, int64_t, double *, double *) {
+    return URHGPU_ERR_UNSUPPORTED;
+}
+
+}  // extern "C"

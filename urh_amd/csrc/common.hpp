@@ -1,0 +1,65 @@
+// Shared host-side plumbing for liburhgpu.so: context, scratch arena, error handling.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/urhgpu.h"
+
+namespace urh {
+
+extern thread_local char g_hip_err[256];
+
+inline int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+    snprintf(g_hip_err, sizeof(g_hip_err), "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    return URHGPU_ERR_HIP;
+}
+
+#define URH_HIP(call)                                                        \
+    do {                                                                     \
+        hipError_t _e = (call);                                              \
+        if (_e != hipSuccess) return urh::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+#define URH_TRY(call)                 \
+    do {                              \
+        int _s = (call);              \
+        if (_s != URHGPU_OK) return _s; \
+    } while (0)
+
+// Device scratch that only ever grows; re-used by every call on the context.
+struct Arena {
+    void *base = nullptr;
+    size_t cap = 0;
+    size_t used = 0;
+    int reserve(size_t bytes);   // ensure capacity (may hipMalloc; invalidates previous pointers)
+    void reset() { used = 0; }
+    // bump allocation, 256-byte aligned; returns nullptr when out of space (callers size first)
+    void *take(size_t bytes) {
+        size_t off = (used + 255) & ~size_t(255);
+        if (off + bytes > cap) return nullptr;
+        used = off + bytes;
+        return (char *)base + off;
+    }
+    void release();
+};
+
+}  // namespace urh
+
+struct urhgpu_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    urh::Arena arena;        // per-call scratch (tables, slabs, scan partials)
+    urh::Arena staging;      // device mirrors of host buffers for the host-pointer entry points
+    int64_t *d_counts = nullptr;   // small device result block (8 x int64)
+    int64_t *h_counts = nullptr;   // pinned host mirror
+    // optional timing of the dominant kernel (demod + run segmentation) with HIP events on `stream`
+    std::vector<hipEvent_t> prof_events;   // pairs: [2k] before, [2k+1] after
+    int prof_used = 0;                     // pairs recorded since urhgpu_ctx_profile_begin
+    bool prof_on = false;
+};

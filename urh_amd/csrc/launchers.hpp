@@ -1,0 +1,83 @@
+// Argument structs and host-side launcher prototypes shared by the kernel files and capi.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "common.hpp"
+#include "runs.hpp"
+
+namespace urh {
+
+// ---- demod_runs.hip ---------------------------------------------------------------------------------
+struct RunArgs {
+    const void *in;          // IQ (dtype) or qad (float) -- device pointer
+    float *qad;              // demodulated output or nullptr
+    const void *left_halo;   // 2 IQ samples (or 1 qad sample) preceding in[0]; nullptr = global start
+    int64_t n;               // samples
+    int64_t pos_base;        // absolute position of in[0] (sharded captures); positions in records are absolute
+    int64_t chunk_len;       // multiple of kTile
+    uint64_t *slab;          // accepted-run records, slab_stride per chunk
+    int64_t slab_stride;
+    ChunkInfo *chunks;
+    float noise_sqrd;
+    float noise_val;         // NOISE sentinel (0.0 ASK, -4.0 FSK/PSK)
+    float max_magnitude;     // ASK normalisation
+    int order;               // modulation order = 2^bits_per_symbol
+    int tol;                 // tolerance
+    float thr[kMaxOrder - 1];
+};
+int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, int64_t n_chunks, bool write_qad, hipStream_t s);
+int launch_runs_qad(const RunArgs &a, int64_t n_chunks, hipStream_t s);
+int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t s);
+void launch_test_atan2f(const float *y, const float *x, int64_t n, float *out, hipStream_t s);
+
+// ---- pulse_table.hip ---------------------------------------------------------------------------------
+struct ResolveArgs {
+    ChunkInfo *chunks;
+    int64_t n_chunks;        // chunks in the table (all shards)
+    int64_t n_total;         // samples in the whole capture
+    int tol;
+    int64_t *rows;           // pulse table (may be nullptr when only counting)
+    int64_t cap_rows;
+    int64_t *d_n_acc;        // out: number of accepted runs P
+    int64_t *d_n_rows;       // out: rows of the un-merged table (P+1, or P when P == n_total), clamped to cap_rows
+    int64_t *d_n_rows_needed; // out: the same, unclamped (capacity check on the host)
+    int write_last_row;      // 1 on the shard/GPU that owns the table's last row
+};
+struct EmitArgs {
+    const ChunkInfo *chunks;
+    int64_t chunk_first;      // index (in the table) of this GPU's first chunk
+    const uint64_t *slab;
+    int64_t slab_stride;
+    int64_t *rows;
+    int64_t cap_rows;
+    int64_t row_base;         // global row index that maps to rows[0] (0 on a single GPU)
+    int is_ask;
+    int64_t sps;
+};
+struct BitsParams {
+    int64_t sps;
+    int64_t bps;
+    int64_t pause_threshold;
+    int64_t samples_per_bit;
+    int write_pos;
+};
+struct BitsOut {
+    uint8_t *bits; int64_t cap_bits;
+    int64_t *msg_off; int64_t *pauses; int64_t cap_msg;
+    int64_t *pos; int64_t cap_pos; int64_t *pos_off;
+    int64_t *counts;
+};
+int launch_resolve(const ResolveArgs &a, hipStream_t s);
+int launch_emit_rows(const EmitArgs &a, int64_t n_local_chunks, hipStream_t s);
+size_t merge_scratch_bytes(int64_t cap);
+int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t cap, int64_t *rows_out,
+                          int64_t cap_out, int64_t *d_n_out, void *scratch, hipStream_t s);
+size_t bits_scratch_bytes(int64_t cap_rows);
+int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                         const BitsOut &o, void *scratch, hipStream_t s);
+
+// ---- filters.hip ---------------------------------------------------------------------------------------
+int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad);
+
+}  // namespace urh

@@ -1,0 +1,508 @@
+// pulse_table.hip -- from per-chunk accepted-run records to the reference's outputs:
+//   * the pulse table ("ppseq", int64[P][2]) of signal_functions.grab_pulse_lens
+//       /root/reference/src/urh/cythonext/signal_functions.pyx:392-495
+//   * bits / pauses / bit_sample_pos of ProtocolAnalyzer._ppseq_to_bits
+//       /root/reference/src/urh/signalprocessing/ProtocolAnalyzer.py:323-414
+// Integer-only work on ~N/samples_per_symbol items: a few small kernels, all device resident,
+// element counts passed through device memory so that nothing synchronises with the host.
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "launchers.hpp"
+#include "runs.hpp"
+#include "scan.hpp"
+
+namespace urh {
+
+// =====================================================================================================
+// K2  k_resolve_chunks: settle everything a chunk could not decide alone (single workgroup).
+//   - does a chunk's trailing short run grow past `tol` in the following chunks?  (ChunkInfo.lead)
+//   - is a chunk's first stable run "accepted", i.e. different from the last stable run before it?
+//   - global index of each chunk's first accepted run, and the accepted run preceding it
+// and write the last pulse-table row (signal_functions.pyx:485-493).
+// =====================================================================================================
+constexpr int kResolveBlock = 1024;
+
+struct LastValid {            // "last valid value" monoid for exclusive scans
+    int64_t pos;
+    uint32_t state;
+    int valid;
+};
+
+__device__ __forceinline__ LastValid lv_combine(const LastValid &a, const LastValid &b) { return b.valid ? b : a; }
+
+// exclusive scan of LastValid over the workgroup (thread order); `init` precedes thread 0
+__device__ LastValid block_excl_scan_lv(LastValid mine, LastValid init, LastValid *s_buf /*[kResolveBlock]*/) {
+    const int t = threadIdx.x;
+    s_buf[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < kResolveBlock; o <<= 1) {
+        LastValid v = s_buf[t];
+        if (t >= o) v = lv_combine(s_buf[t - o], v);
+        __syncthreads();
+        s_buf[t] = v;
+        __syncthreads();
+    }
+    LastValid r = (t == 0) ? init : lv_combine(init, s_buf[t - 1]);
+    __syncthreads();
+    return r;
+}
+
+__device__ int64_t block_excl_scan_i64(int64_t mine, int64_t &total, int64_t *s_buf /*[kResolveBlock]*/) {
+    const int t = threadIdx.x;
+    s_buf[t] = mine;
+    __syncthreads();
+    for (int o = 1; o < kResolveBlock; o <<= 1) {
+        int64_t v = s_buf[t];
+        if (t >= o) v += s_buf[t - o];
+        __syncthreads();
+        s_buf[t] = v;
+        __syncthreads();
+    }
+    total = s_buf[kResolveBlock - 1];
+    const int64_t r = s_buf[t] - mine;
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(kResolveBlock) void k_resolve_chunks(const ResolveArgs a) {
+    __shared__ LastValid s_lv[kResolveBlock];
+    __shared__ int64_t s_i64[kResolveBlock];
+    const int t = threadIdx.x;
+    const int64_t per = (a.n_chunks + kResolveBlock - 1) / kResolveBlock;
+    const int64_t c0 = (int64_t)t * per;
+    const int64_t c1 = (c0 + per < a.n_chunks) ? c0 + per : a.n_chunks;
+    ChunkInfo *ch = a.chunks;
+
+    // pass 1: trailing short runs; last stable state of my chunk range
+    LastValid mine = {0, 0, 0};
+    for (int64_t c = c0; c < c1; ++c) {
+        int ps = 0;
+        if (ch[c].pend_pos >= 0) {
+            int64_t len = ch[c].start + ch[c].len - ch[c].pend_pos;   // run length inside chunk c
+            for (int64_t u = c + 1; len <= a.tol && u < a.n_chunks; ++u) {
+                len += ch[u].lead;
+                if (ch[u].lead < ch[u].len) break;
+            }
+            ps = len > a.tol;
+        }
+        ch[c].pend_acc = ps;   // provisional: "stable"; refined to "accepted" in pass 2
+        if (ps) mine = {ch[c].pend_pos, ch[c].pend_state, 1};
+        else if (ch[c].cnt > 0) mine = {ch[c].last_pos, ch[c].last_state, 1};
+    }
+    LastValid init = {-1, ch[0].init_state, 1};
+    LastValid prev_stable = block_excl_scan_lv(mine, init, s_lv);
+
+    // pass 2: acceptance of tentative first records / pending runs, counts, last accepted run
+    int64_t my_cnt = 0;
+    LastValid my_last_acc = {0, 0, 0};
+    {
+        uint32_t prev_state = prev_stable.state;
+        for (int64_t c = c0; c < c1; ++c) {
+            const int cnt = ch[c].cnt;
+            const int ps = ch[c].pend_acc;
+            const int first_acc = (cnt > 0) && (ch[c].first_state != prev_state);
+            const uint32_t before_pend = (cnt > 0) ? ch[c].last_state : prev_state;
+            const int pend_acc = ps && (ch[c].pend_state != before_pend);
+            ch[c].first_acc = first_acc;
+            ch[c].pend_acc = pend_acc;
+            const int64_t out_cnt = (cnt > 0 ? cnt - 1 + first_acc : 0) + pend_acc;
+            ch[c].out_off = my_cnt;               // relative to my range; fixed up below
+            my_cnt += out_cnt;
+            if (pend_acc) my_last_acc = {ch[c].pend_pos, ch[c].pend_state, 1};
+            else if (cnt >= 2 || (cnt == 1 && first_acc)) my_last_acc = {ch[c].last_pos, ch[c].last_state, 1};
+            if (ps) prev_state = ch[c].pend_state;
+            else if (cnt > 0) prev_state = ch[c].last_state;
+        }
+    }
+    int64_t total = 0;
+    const int64_t my_off = block_excl_scan_i64(my_cnt, total, s_i64);
+    LastValid prev_acc = block_excl_scan_lv(my_last_acc, init, s_lv);
+    // the inclusive "last accepted" of the last thread is needed for the final row
+    __shared__ LastValid s_final;
+    if (t == kResolveBlock - 1) s_final = lv_combine(prev_acc, my_last_acc);
+
+    // pass 3: publish per-chunk offsets and predecessors
+    {
+        LastValid pa = prev_acc;
+        for (int64_t c = c0; c < c1; ++c) {
+            ch[c].out_off += my_off;
+            ch[c].prev_pos = pa.pos;
+            ch[c].prev_state = pa.state;
+            const int cnt = ch[c].cnt;
+            if (ch[c].pend_acc) pa = {ch[c].pend_pos, ch[c].pend_state, 1};
+            else if (cnt >= 2 || (cnt == 1 && ch[c].first_acc)) pa = {ch[c].last_pos, ch[c].last_state, 1};
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        const int64_t P = total;
+        *a.d_n_acc = P;
+        // final row (signal_functions.pyx:485-493); skipped when the table already has n rows (:487)
+        int64_t n_rows = P;
+        if (P < a.n_total) {
+            n_rows = P + 1;
+            if (a.write_last_row && a.rows != nullptr && P < a.cap_rows) {
+                const LastValid f = s_final;
+                const int64_t len = (P == 0) ? (a.n_total - a.tol) : (a.n_total - 1 - f.pos - a.tol);
+                a.rows[2 * P] = (int64_t)f.state - 1;
+                a.rows[2 * P + 1] = len;
+            }
+        }
+        *a.d_n_rows_needed = n_rows;
+        *a.d_n_rows = (a.rows != nullptr && n_rows > a.cap_rows) ? a.cap_rows : n_rows;
+    }
+}
+
+// =====================================================================================================
+// K3  k_emit_rows: one workgroup per chunk turns accepted run starts into pulse-table rows
+//   row g = (state of accepted run g-1, start_g - start_{g-1}); row 0 = (init state, start_0 + 1)
+//   ASK: pause rows shorter than samples_per_symbol are relabelled 0 (signal_functions.pyx:471-473).
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_emit_rows(const EmitArgs a) {
+    const ChunkInfo ci = a.chunks[a.chunk_first + blockIdx.x];
+    const uint64_t *slab = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+    const int skip = (ci.cnt > 0 && !ci.first_acc) ? 1 : 0;
+    const int64_t from_slab = (ci.cnt > 0) ? ci.cnt - skip : 0;
+    const int64_t total = from_slab + ci.pend_acc;
+    for (int64_t j = threadIdx.x; j < total; j += blockDim.x) {
+        int64_t pos; uint32_t st;
+        if (j < from_slab) { const uint64_t r = slab[j + skip]; pos = rec_pos(r); st = rec_state(r); }
+        else { pos = ci.pend_pos; st = ci.pend_state; }
+        int64_t ppos; uint32_t pst;
+        if (j == 0) { ppos = ci.prev_pos; pst = ci.prev_state; }
+        else { const uint64_t r = slab[j - 1 + skip]; ppos = rec_pos(r); pst = rec_state(r); }
+        (void)st;
+        const int64_t g = ci.out_off + j;
+        int64_t len = (g == 0) ? pos + 1 : pos - ppos;
+        int64_t state = (int64_t)pst - 1;
+        if (a.is_ask && state == -1 && len < a.sps) state = 0;
+        const int64_t o = g - a.row_base;
+        if (o >= 0 && o < a.cap_rows) { a.rows[2 * o] = state; a.rows[2 * o + 1] = len; }
+    }
+}
+
+// =====================================================================================================
+// ASK only: merge adjacent rows of equal state (signal_functions.pyx:475-480, 488-489).
+// =====================================================================================================
+struct MergeLoad {
+    const int64_t *rows;
+    __device__ VecK<2> operator()(int64_t i) const {
+        VecK<2> v;
+        v.v[0] = (i == 0 || rows[2 * i] != rows[2 * (i - 1)]) ? 1 : 0;   // head of a group
+        v.v[1] = rows[2 * i + 1];
+        return v;
+    }
+};
+struct MergeStore {
+    const int64_t *rows;
+    const int64_t *d_n;
+    int64_t *grp_state;      // [groups]
+    int64_t *grp_end_sum;    // [groups] inclusive length sum at the group's last row
+    __device__ void operator()(int64_t i, const VecK<2> &val, const VecK<2> &ex) const {
+        const int64_t n = *d_n;
+        const int64_t g = ex.v[0] + val.v[0] - 1;                 // group index of row i
+        if (val.v[0]) grp_state[g] = rows[2 * i];
+        const bool last = (i + 1 == n) || (rows[2 * (i + 1)] != rows[2 * i]);
+        if (last) grp_end_sum[g] = ex.v[1] + val.v[1];
+    }
+};
+__global__ void k_merge_finish(const VecK<2> *grand_total, const int64_t *grp_state, const int64_t *grp_end_sum,
+                               int64_t *rows_out, int64_t cap_rows, int64_t *d_n_rows_out) {
+    const int64_t groups = grand_total->v[0];
+    for (int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; g < groups; g += (int64_t)gridDim.x * blockDim.x) {
+        if (g < cap_rows) {
+            rows_out[2 * g] = grp_state[g];
+            rows_out[2 * g + 1] = grp_end_sum[g] - (g ? grp_end_sum[g - 1] : 0);
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_n_rows_out = groups;
+}
+
+// =====================================================================================================
+// _ppseq_to_bits on device  (ProtocolAnalyzer.py:323-414)
+//   row kinds: D data row with >= 1 symbol; S pause row with <= pause_threshold symbols (-> zero bits);
+//              L long pause (closes a message when data was seen, else discards what was gathered)
+//   groups   : stretches of rows between L rows; a group with at least one D row is a message.
+// =====================================================================================================
+__device__ __forceinline__ int64_t num_symbols_of(int64_t num_samples, int64_t sps) {
+    // int(n / sps) (+1 when the fractional part exceeds 0.5), in double like the Python source (:353-358)
+    const double f = (double)num_samples / (double)sps;
+    int64_t k = (int64_t)f;
+    if (f - (double)k > 0.5) k += 1;
+    return k;
+}
+
+struct RowInfo {             // per-row scan results kept for the expansion kernel
+    int64_t bit_prefix;      // bits before this row (all rows, kept or not)
+    int64_t ts_prefix;       // total_samples before this row
+    int32_t group;           // long pauses before this row
+    int32_t kbits;           // bits this row contributes (0 for L rows)
+};
+
+struct GroupInfo {
+    int64_t bits_end;        // bit_prefix at the closing row (== bits before + inside the group)
+    int64_t data_end;        // D rows before the closing row
+    int64_t ts_close;        // total_samples before the closing L row (or at the very end)
+    int64_t pause;           // pauses[] entry when this group is a message
+    int32_t closed;          // 1: closed by an L row, 0: the trailing group
+    int32_t pad;
+};
+
+struct BitsLoad {
+    const int64_t *rows;
+    const int64_t *d_n_rows;
+    BitsParams bp;
+    // i counts rows AFTER the skipped leading pause row? no: all rows; row 0 is neutralised when it is a pause
+    __device__ VecK<4> operator()(int64_t i) const {
+        VecK<4> v; v.zero();
+        const int64_t type = rows[2 * i], len = rows[2 * i + 1];
+        v.v[2] = len;
+        if (i == 0 && type == -1) return v;              // "Starts with Pause" (:346-348): only seeds total_samples
+        const int64_t ns = num_symbols_of(len, bp.sps);
+        if (type == -1) {
+            if (ns <= bp.pause_threshold || bp.pause_threshold == 0) v.v[0] = (ns > 0) ? ns * bp.bps : 0;
+            else v.v[1] = 1;
+        } else {
+            v.v[0] = (ns > 0) ? ns * bp.bps : 0;
+            v.v[3] = (ns > 0) ? 1 : 0;
+        }
+        return v;
+    }
+};
+
+struct BitsStore {
+    const int64_t *rows;
+    const int64_t *d_n_rows;
+    RowInfo *info;
+    GroupInfo *groups;
+    __device__ void operator()(int64_t i, const VecK<4> &val, const VecK<4> &ex) const {
+        const int64_t n = *d_n_rows;
+        RowInfo ri;
+        ri.bit_prefix = ex.v[0]; ri.ts_prefix = ex.v[2]; ri.group = (int32_t)ex.v[1]; ri.kbits = (int32_t)val.v[0];
+        info[i] = ri;
+        if (val.v[1]) {                                   // L row closes group ex.v[1]
+            GroupInfo g;
+            g.bits_end = ex.v[0]; g.data_end = ex.v[3]; g.ts_close = ex.v[2]; g.pause = val.v[2]; g.closed = 1; g.pad = 0;
+            groups[ex.v[1]] = g;
+        }
+        if (i + 1 == n) {                                 // trailing group (index = total L count)
+            GroupInfo g;
+            g.bits_end = ex.v[0] + val.v[0]; g.data_end = ex.v[3] + val.v[3]; g.ts_close = ex.v[2] + val.v[2];
+            g.pause = (rows[2 * i] == -1) ? rows[2 * i + 1] : 0;      // :411
+            g.closed = 0; g.pad = 0;
+            groups[ex.v[1] + val.v[1]] = g;
+        }
+    }
+};
+
+// groups -> messages: exclusive scan over (is_message, kept bits, kept positions)
+struct GroupLoad {
+    const GroupInfo *groups;
+    int write_pos;
+    __device__ VecK<3> operator()(int64_t g) const {
+        VecK<3> v; v.zero();
+        const GroupInfo gi = groups[g];
+        const int64_t d0 = g ? groups[g - 1].data_end : 0;
+        if (gi.data_end - d0 > 0) {
+            const int64_t b0 = g ? groups[g - 1].bits_end : 0;
+            v.v[0] = 1;
+            v.v[1] = gi.bits_end - b0;
+            v.v[2] = write_pos ? (gi.bits_end - b0) + (gi.closed ? 2 : 1) : 0;
+        }
+        return v;
+    }
+};
+struct GroupOut {            // per group, for the expansion kernel
+    int64_t bits_start;      // bit_prefix at the group's first row
+    int64_t out_bits;        // offset of the message in bits[]
+    int64_t out_pos;         // offset of the message in pos[]
+    int32_t is_msg;
+    int32_t pad;
+};
+struct GroupStore {
+    const GroupInfo *groups;
+    GroupOut *gout;
+    int64_t *msg_off, *pauses, *pos_off, *pos;
+    int64_t cap_msg, cap_pos;
+    int write_pos;
+    __device__ void operator()(int64_t g, const VecK<3> &val, const VecK<3> &ex) const {
+        GroupOut o;
+        o.bits_start = g ? groups[g - 1].bits_end : 0;
+        o.out_bits = ex.v[1]; o.out_pos = ex.v[2]; o.is_msg = (int32_t)val.v[0]; o.pad = 0;
+        gout[g] = o;
+        if (val.v[0]) {
+            const int64_t m = ex.v[0];
+            const GroupInfo gi = groups[g];
+            if (m < cap_msg) {
+                msg_off[m] = ex.v[1];
+                pos_off[m] = ex.v[2];
+                pauses[m] = gi.pause;
+            }
+            if (write_pos) {
+                const int64_t p0 = ex.v[2] + val.v[1];          // sentinels follow the per-bit positions
+                if (gi.closed) {
+                    if (p0 + 1 < cap_pos) { pos[p0] = gi.ts_close; pos[p0 + 1] = gi.ts_close + gi.pause; }
+                } else {
+                    if (p0 < cap_pos) pos[p0] = gi.ts_close;
+                }
+            }
+        }
+    }
+};
+
+// counts = {n_rows, n_msg, n_bits, n_pos}; also terminates msg_off / pos_off
+__global__ void k_bits_counts(const int64_t *d_n_rows, const VecK<3> *grand, int64_t *msg_off, int64_t *pos_off,
+                              int64_t cap_msg, int64_t *counts) {
+    const int64_t n_rows = *d_n_rows;
+    VecK<3> g; g.zero();
+    if (n_rows > 0) g = *grand;
+    counts[0] = n_rows; counts[1] = g.v[0]; counts[2] = g.v[1]; counts[3] = g.v[2];
+    if (g.v[0] <= cap_msg) { msg_off[g.v[0]] = g.v[1]; pos_off[g.v[0]] = g.v[2]; }
+}
+
+// number of groups = total L rows + 1, published for the group scan
+__global__ void k_group_count(const int64_t *d_n_rows, const VecK<4> *grand, int64_t *d_n_groups) {
+    *d_n_groups = (*d_n_rows > 0) ? grand->v[1] + 1 : 0;
+}
+
+struct ExpandArgs {
+    const int64_t *rows;
+    const int64_t *d_n_rows;
+    const RowInfo *info;
+    const GroupOut *gout;
+    uint8_t *bits;
+    int64_t cap_bits;
+    int64_t *pos;
+    int64_t cap_pos;
+    BitsParams bp;
+};
+
+// one thread per row; rows with many bits are expanded cooperatively by the whole wavefront
+__global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
+    const int64_t n = *a.d_n_rows;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave_base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
+    if (wave_base >= n) return;
+    const int64_t i = wave_base + lane;
+    int64_t kb = 0, ob = 0, op = 0, ts = 0, type = 0;
+    if (i < n) {
+        const RowInfo ri = a.info[i];
+        if (ri.kbits > 0) {
+            const GroupOut go = a.gout[ri.group];
+            if (go.is_msg) {
+                kb = ri.kbits;
+                ob = go.out_bits + (ri.bit_prefix - go.bits_start);
+                op = go.out_pos + (ri.bit_prefix - go.bits_start);
+                ts = ri.ts_prefix;
+                type = a.rows[2 * i];
+            }
+        }
+    }
+    const int bps = (int)a.bp.bps;
+    constexpr int kShort = 16;
+    if (kb > 0 && kb <= kShort) {
+        for (int64_t k = 0; k < kb; ++k) {
+            const uint8_t b = (type < 0) ? 0 : (uint8_t)((type >> (bps - 1 - (int)(k % bps))) & 1);
+            if (ob + k < a.cap_bits) a.bits[ob + k] = b;
+            if (a.bp.write_pos && op + k < a.cap_pos) a.pos[op + k] = ts + k * a.bp.samples_per_bit;
+        }
+    }
+    unsigned long long big = __ballot(kb > kShort);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1;
+        const int64_t kb_s = __shfl(kb, src), ob_s = __shfl(ob, src), op_s = __shfl(op, src), ts_s = __shfl(ts, src),
+                      ty_s = __shfl(type, src);
+        for (int64_t k = lane; k < kb_s; k += 64) {
+            const uint8_t b = (ty_s < 0) ? 0 : (uint8_t)((ty_s >> (bps - 1 - (int)(k % bps))) & 1);
+            if (ob_s + k < a.cap_bits) a.bits[ob_s + k] = b;
+            if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
+        }
+    }
+}
+
+// ---- host-side launchers ---------------------------------------------------------------------------
+int launch_resolve(const ResolveArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(k_resolve_chunks, dim3(1), dim3(kResolveBlock), 0, s, a);
+    return URHGPU_OK;
+}
+
+int launch_emit_rows(const EmitArgs &a, int64_t n_local_chunks, hipStream_t s) {
+    if (n_local_chunks > 0) hipLaunchKernelGGL(k_emit_rows, dim3((unsigned)n_local_chunks), dim3(256), 0, s, a);
+    return URHGPU_OK;
+}
+
+static inline int64_t scan_blocks(int64_t cap) { return (cap + kScanTile - 1) / kScanTile; }
+
+// scratch bytes needed by merge_rows_ask for up to cap rows
+size_t merge_scratch_bytes(int64_t cap) {
+    return (size_t)(scan_blocks(cap) + 1) * sizeof(VecK<2>) + 256 + (size_t)cap * 16 + 512;
+}
+
+// rows_in (d_n_in rows) -> rows_out (d_n_out rows); rows_in and rows_out must differ.
+int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t cap, int64_t *rows_out,
+                          int64_t cap_out, int64_t *d_n_out, void *scratch, hipStream_t s) {
+    if (cap <= 0) return URHGPU_OK;
+    const int64_t nb = scan_blocks(cap);
+    char *p = (char *)scratch;
+    VecK<2> *partials = (VecK<2> *)p; p += ((size_t)(nb + 1) * sizeof(VecK<2>) + 255) & ~size_t(255);
+    int64_t *grp_state = (int64_t *)p; p += (size_t)cap * 8;
+    int64_t *grp_end = (int64_t *)p;
+    MergeLoad ld{rows_in};
+    MergeStore st{rows_in, d_n_in, grp_state, grp_end};
+    hipLaunchKernelGGL((k_scan_reduce<2, MergeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld, partials);
+    hipLaunchKernelGGL((k_scan_partials<2>), dim3(1), dim3(kScanBlock), 0, s, d_n_in, partials, nb);
+    hipLaunchKernelGGL((k_scan_apply<2, MergeLoad, MergeStore>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld,
+                       partials, st);
+    int64_t fin_blocks = (cap + 255) / 256; if (fin_blocks > 4096) fin_blocks = 4096;
+    hipLaunchKernelGGL(k_merge_finish, dim3((unsigned)fin_blocks), dim3(256), 0, s, partials + nb, grp_state, grp_end,
+                       rows_out, cap_out, d_n_out);
+    return URHGPU_OK;
+}
+
+size_t bits_scratch_bytes(int64_t cap_rows) {
+    const int64_t nb = scan_blocks(cap_rows);
+    const int64_t cap_groups = cap_rows + 1;
+    const int64_t nbg = scan_blocks(cap_groups);
+    return (size_t)(nb + 1) * sizeof(VecK<4>) + (size_t)(nbg + 1) * sizeof(VecK<3>) + (size_t)cap_rows * sizeof(RowInfo) +
+           (size_t)cap_groups * (sizeof(GroupInfo) + sizeof(GroupOut)) + 64 + 8 * 256;
+}
+
+int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                         const BitsOut &o, void *scratch, hipStream_t s) {
+    if (cap_rows <= 0) cap_rows = 1;
+    const int64_t nb = scan_blocks(cap_rows);
+    const int64_t cap_groups = cap_rows + 1;
+    const int64_t nbg = scan_blocks(cap_groups);
+    char *p = (char *)scratch;
+    auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~size_t(255); return r; };
+    VecK<4> *part4 = (VecK<4> *)take((size_t)(nb + 1) * sizeof(VecK<4>));
+    VecK<3> *part3 = (VecK<3> *)take((size_t)(nbg + 1) * sizeof(VecK<3>));
+    RowInfo *info = (RowInfo *)take((size_t)cap_rows * sizeof(RowInfo));
+    GroupInfo *groups = (GroupInfo *)take((size_t)cap_groups * sizeof(GroupInfo));
+    GroupOut *gout = (GroupOut *)take((size_t)cap_groups * sizeof(GroupOut));
+    int64_t *d_n_groups = (int64_t *)take(64);
+
+    BitsLoad ld{rows, d_n_rows, bp};
+    BitsStore st{rows, d_n_rows, info, groups};
+    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_rows, ld, part4);
+    hipLaunchKernelGGL((k_scan_partials<4>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, part4, nb);
+    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_rows, ld,
+                       part4, st);
+    hipLaunchKernelGGL(k_group_count, dim3(1), dim3(1), 0, s, d_n_rows, part4 + nb, d_n_groups);
+    GroupLoad gl{groups, bp.write_pos};
+    GroupStore gs{groups, gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos, bp.write_pos};
+    hipLaunchKernelGGL((k_scan_reduce<3, GroupLoad>), dim3((unsigned)nbg), dim3(kScanBlock), 0, s, d_n_groups, gl, part3);
+    hipLaunchKernelGGL((k_scan_partials<3>), dim3(1), dim3(kScanBlock), 0, s, d_n_groups, part3, nbg);
+    hipLaunchKernelGGL((k_scan_apply<3, GroupLoad, GroupStore>), dim3((unsigned)nbg), dim3(kScanBlock), 0, s, d_n_groups,
+                       gl, part3, gs);
+    hipLaunchKernelGGL(k_bits_counts, dim3(1), dim3(1), 0, s, d_n_rows, part3 + nbg, o.msg_off, o.pos_off, o.cap_msg,
+                       o.counts);
+    ExpandArgs ea{rows, d_n_rows, info, gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp};
+    const int64_t eb = (cap_rows + 255) / 256;
+    hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)eb), dim3(256), 0, s, ea);
+    return URHGPU_OK;
+}
+
+}  // namespace urh

@@ -1,0 +1,196 @@
+"""Device-resident IQ -> bits pipeline: the capture stays in HBM, one call produces the demodulated
+signal (Signal.qad), the pulse table (grab_pulse_lens) and bits / pauses / bit_sample_pos
+(ProtocolAnalyzer._ppseq_to_bits) without touching the host.
+
+PyTorch is plumbing only (device allocations, streams, torch.distributed for sharded captures):
+every byte of arithmetic happens in liburhgpu.so behind the C ABI (include/urhgpu.h).
+
+Parameter names/defaults follow the reference's Signal object
+(/root/reference/src/urh/signalprocessing/Signal.py:42-109).
+"""
+import array
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .signal_functions import dtype_code, mod_code
+
+
+@dataclass
+class DemodParams:
+    modulation_type: str = "FSK"          # Signal.modulation_type
+    bits_per_symbol: int = 1
+    noise_threshold: float = 0.0
+    center: float = 0.02
+    center_spacing: float = 1.0
+    tolerance: int = 5
+    samples_per_symbol: int = 100
+    costas_loop_bandwidth: float = 0.1
+    pause_threshold: int = 8
+    write_bit_sample_pos: bool = True
+
+    def to_c(self, dtype) -> _lib.Params:
+        mod, sentinel = mod_code(self.modulation_type)
+        p = _lib.Params()
+        p.dtype = dtype_code(dtype)
+        p.mod = mod
+        p.bits_per_symbol = int(self.bits_per_symbol)
+        p.noise_threshold = float(self.noise_threshold)
+        p.center = float(self.center)
+        p.center_spacing = float(self.center_spacing)
+        p.tolerance = int(self.tolerance)
+        p.samples_per_symbol = int(self.samples_per_symbol)
+        p.costas_loop_bandwidth = float(self.costas_loop_bandwidth)
+        p.pause_threshold = int(self.pause_threshold)
+        p.write_bit_sample_pos = 1 if self.write_bit_sample_pos else 0
+        p.noise_other = float(sentinel)
+        p.mod_order = 0
+        return p
+
+
+_TORCH_DT = None
+
+
+def _torch_dtype(t):
+    import torch
+    m = {torch.int8: np.int8, torch.uint8: np.uint8, torch.int16: np.int16, torch.float32: np.float32}
+    if hasattr(torch, "uint16"):
+        m[torch.uint16] = np.uint16
+    if t.dtype not in m:
+        raise ValueError("Unsupported dtype")
+    return np.dtype(m[t.dtype])
+
+
+class BitsResult:
+    """Device-resident outputs of one IQ->bits pass (torch tensors) + lazy host views."""
+
+    def __init__(self, qad, rows, bits, msg_off, pauses, pos, pos_off, counts, params):
+        self.qad, self.rows_buf, self.bits_buf = qad, rows, bits
+        self.msg_off_buf, self.pauses_buf, self.pos_buf, self.pos_off_buf = msg_off, pauses, pos, pos_off
+        self.counts = counts
+        self.params = params
+        self._host_counts = None
+
+    def host_counts(self):
+        """(n_rows, n_msg, n_bits, n_pos): one 32-byte D2H copy (synchronises)."""
+        if self._host_counts is None:
+            c = self.counts.cpu().numpy()
+            self._host_counts = tuple(int(x) for x in c[:4])
+        return self._host_counts
+
+    def check_capacity(self):
+        n_rows, n_msg, n_bits, n_pos = self.host_counts()
+        if n_rows > self.rows_buf.shape[0] or n_msg > self.pauses_buf.shape[0] or n_bits > self.bits_buf.shape[0] \
+                or (self.pos_buf is not None and n_pos > self.pos_buf.shape[0]):
+            raise _lib.UrhGpuError(_lib.ERR_CAPACITY, f"output capacity too small: rows={n_rows} msgs={n_msg} "
+                                                      f"bits={n_bits} pos={n_pos}")
+
+    def ppseq(self) -> np.ndarray:
+        n_rows = self.host_counts()[0]
+        return self.rows_buf[:n_rows].cpu().numpy()
+
+    def flat(self):
+        """(bits u8, msg_off i64, pauses i64, pos i64, pos_off i64) on the host."""
+        self.check_capacity()
+        _, n_msg, n_bits, n_pos = self.host_counts()
+        bits = self.bits_buf[:n_bits].cpu().numpy()
+        msg_off = self.msg_off_buf[:n_msg + 1].cpu().numpy()
+        pauses = self.pauses_buf[:n_msg].cpu().numpy()
+        pos_off = self.pos_off_buf[:n_msg + 1].cpu().numpy()
+        pos = self.pos_buf[:n_pos].cpu().numpy() if self.pos_buf is not None else np.zeros(0, np.int64)
+        return bits, msg_off, pauses, pos, pos_off
+
+    def messages(self):
+        """Reference-shaped result of _ppseq_to_bits: (list of array('B'), array('L'), list of array('L'))."""
+        bits, off, pauses, pos, poff = self.flat()
+        data = [array.array("B", bits[off[i]:off[i + 1]].tobytes()) for i in range(len(pauses))]
+        pa = array.array("L", pauses.tolist())
+        bsp = [array.array("L", pos[poff[i]:poff[i + 1]].tolist()) for i in range(len(pauses))] \
+            if self.pos_buf is not None else []
+        return data, pa, bsp
+
+    def plain_bits_str(self):
+        data, _, _ = self.messages()
+        return ["".join(map(str, d)) for d in data]
+
+
+class DevicePipeline:
+    """Owns a liburhgpu context bound to torch's current stream and the output buffers."""
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise _lib.UrhGpuError(_lib.ERR_NO_DEVICE, "no GPU visible to torch: the IQ->bits path has no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.ctx = _lib.Context(self.device.index)
+        self._bufs = {}
+
+    def _buf(self, name, shape, dtype):
+        t = self._bufs.get(name)
+        need = int(np.prod(shape))
+        if t is None or t.numel() < need or t.dtype != dtype:
+            t = self.torch.empty(need, dtype=dtype, device=self.device)
+            self._bufs[name] = t
+        return t[:need].view(*shape)
+
+    def capacities(self, n: int, p: DemodParams, cap_rows=None):
+        sps = max(int(p.samples_per_symbol), 1)
+        if cap_rows is None:
+            # accepted runs cannot be denser than one per (tolerance+1) samples; the default assumes
+            # at most ~4 per symbol and is checked (ERR_CAPACITY) after the fact
+            cap_rows = min(n // (p.tolerance + 1) + 2, max(4096, 4 * (n // sps) + 4096))
+        cap_bits = (n // sps + 2 * cap_rows // 8 + 64) * int(p.bits_per_symbol) + cap_rows
+        cap_msg = max(64, cap_rows // 4)
+        cap_pos = cap_bits + 2 * cap_msg + 2
+        return cap_rows, cap_bits, cap_msg, cap_pos
+
+    def reserve(self, n: int, p: DemodParams):
+        self.ctx.reserve(n, p.tolerance)
+
+    def iq_to_bits(self, iq, p: DemodParams, want_qad=True, cap_rows=None) -> BitsResult:
+        """iq: torch tensor on this device, shape (N, 2) of int8/uint8/int16/uint16/float32, or complex64 (N,)."""
+        torch = self.torch
+        if iq.dtype == torch.complex64:
+            iq = torch.view_as_real(iq)
+        if iq.dim() != 2 or iq.shape[1] != 2 or not iq.is_contiguous():
+            raise ValueError("IQ must be a contiguous (N, 2) tensor")
+        npdt = _torch_dtype(iq)
+        n = iq.shape[0]
+        cp = p.to_c(npdt)
+        cap_rows, cap_bits, cap_msg, cap_pos = self.capacities(n, p, cap_rows)
+        qad = self._buf("qad", (n,), torch.float32) if want_qad else None
+        rows = self._buf("rows", (cap_rows, 2), torch.int64)
+        bits = self._buf("bits", (cap_bits,), torch.uint8)
+        msg_off = self._buf("msg_off", (cap_msg + 1,), torch.int64)
+        pauses = self._buf("pauses", (cap_msg,), torch.int64)
+        pos_off = self._buf("pos_off", (cap_msg + 1,), torch.int64)
+        pos = self._buf("pos", (cap_pos,), torch.int64) if p.write_bit_sample_pos else None
+        counts = self._buf("counts", (4,), torch.int64)
+        o = _lib.Outputs()
+        o.qad = qad.data_ptr() if qad is not None else None
+        o.rows = rows.data_ptr(); o.cap_rows = cap_rows
+        o.bits = bits.data_ptr(); o.cap_bits = cap_bits
+        o.msg_off = msg_off.data_ptr(); o.pauses = pauses.data_ptr(); o.cap_msg = cap_msg
+        o.pos = pos.data_ptr() if pos is not None else None
+        o.cap_pos = cap_pos if pos is not None else 0
+        o.pos_off = pos_off.data_ptr()
+        o.counts = counts.data_ptr()
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_iq_to_bits_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, C.byref(cp), C.byref(o)))
+        return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p)
+
+    def afp_demod(self, iq, p: DemodParams):
+        torch = self.torch
+        if iq.dtype == torch.complex64:
+            iq = torch.view_as_real(iq)
+        npdt = _torch_dtype(iq)
+        n = iq.shape[0]
+        qad = torch.empty(n, dtype=torch.float32, device=self.device)
+        cp = p.to_c(npdt)
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_afp_demod_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, C.byref(cp),
+                                                    C.c_void_p(qad.data_ptr())))
+        return qad
