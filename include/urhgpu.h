@@ -64,8 +64,12 @@ int urhgpu_device_count(int *count);
 /* device = HIP ordinal.  Creates a private stream and an (initially empty) scratch arena. */
 int urhgpu_ctx_create(int device, urhgpu_ctx **out);
 int urhgpu_ctx_destroy(urhgpu_ctx *ctx);
-/* Run on the caller's stream (hipStream_t passed as void*; NULL restores the private stream). */
+/* Run on the caller's stream (hipStream_t passed as void*).  NULL is the HIP null stream -- what
+ * torch calls the default stream -- NOT the private stream: work is then ordered with everything
+ * else the caller enqueues there. */
 int urhgpu_ctx_set_stream(urhgpu_ctx *ctx, void *hip_stream);
+/* Go back to the context's private (non-blocking) stream. */
+int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx);
 int urhgpu_ctx_sync(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no
  * allocation happens inside later calls (bench / steady state). */

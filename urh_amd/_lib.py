@@ -56,6 +56,7 @@ PROTOTYPES = {
     "urhgpu_ctx_create": (_i, [_i, C.POINTER(_vp)]),
     "urhgpu_ctx_destroy": (_i, [_vp]),
     "urhgpu_ctx_set_stream": (_i, [_vp, _vp]),
+    "urhgpu_ctx_use_private_stream": (_i, [_vp]),
     "urhgpu_ctx_sync": (_i, [_vp]),
     "urhgpu_ctx_reserve": (_i, [_vp, _i64, _i]),
     "urhgpu_ctx_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.c_char_p, _i]),
@@ -81,6 +82,28 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7) which libtorch_hip.so asks for by its UNVERSIONED file name, while liburhgpu.so
+    asks for the SONAME: if liburhgpu.so is loaded before torch, the system runtime and torch's copy
+    both end up in the process and the second one to initialise finds no device.  Pre-loading torch's
+    copy (when torch is installed) makes liburhgpu.so's DT_NEEDED resolve to it by SONAME, whatever the
+    import order; without torch the system runtime under /opt/rocm is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     """Load liburhgpu.so; raises if it has not been built (python -m urh_amd.build)."""
     global _lib
@@ -89,6 +112,7 @@ def load():
             if not os.path.exists(LIB_PATH):
                 raise UrhGpuError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: build it with `python -m urh_amd.build` "
                                                  "(there is no CPU fallback)")
+            _share_torch_hip_runtime()
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in PROTOTYPES.items():
                 fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -125,7 +149,11 @@ class Context:
         return self._h
 
     def set_stream(self, stream_ptr):
+        """Run on the given hipStream_t (0 / None = the HIP null stream, torch's default stream)."""
         check(load().urhgpu_ctx_set_stream(self._h, C.c_void_p(stream_ptr or 0)))
+
+    def use_private_stream(self):
+        check(load().urhgpu_ctx_use_private_stream(self._h))
 
     def sync(self):
         check(load().urhgpu_ctx_sync(self._h))

@@ -222,7 +222,13 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
 
 int urhgpu_ctx_set_stream(urhgpu_ctx *ctx, void *hip_stream) {
     if (!ctx) return URHGPU_ERR_ARG;
-    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->stream = (hipStream_t)hip_stream;
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx) {
+    if (!ctx) return URHGPU_ERR_ARG;
+    ctx->stream = ctx->own_stream;
     return URHGPU_OK;
 }
 
