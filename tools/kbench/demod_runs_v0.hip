@@ -16,14 +16,11 @@
 //   * the conj(prev)*cur product follows the exact operation sequence the reference's generated
 //     C++ performs (including the 0*x terms that decide signed zeros, see conj_mul()).
 //
-// Layout: one wavefront (a 64-thread workgroup) owns a whole chunk, so there is no barrier and no
-// cross-wavefront dependency anywhere in the kernel: each wavefront is its own software pipeline
-// and the SIMD scheduler interleaves wavefronts that are in different phases.  Inside a tile (2048
-// samples) load row r covers 128 consecutive samples, lane t owns samples 2t, 2t+1 of the row (one
-// 16-byte load, lane-contiguous => 1 KiB per wavefront instruction).  The previous sample of a
-// lane's first sample comes from lane t-1 by DPP wave_shr:1; lane 0 takes the last sample of the
-// previous row, carried in registers (v_readlane) from row to row and tile to tile.  State bytes go
-// to LDS in sample order; in the run phase lane t owns 32 consecutive samples.
+// Layout inside a tile (8192 samples, 256 threads): load row r covers 512 consecutive samples,
+// thread t owns samples 2t, 2t+1 of the row (one 16-byte load, lane-contiguous => 1 KiB per
+// wavefront instruction).  The previous sample of a thread's first sample comes from lane t-1 by
+// DPP wave_shr:1; lane 0 of a wavefront re-reads it through the scalar cache.  State bytes go to
+// LDS in sample order; in the run phase thread t owns 32 consecutive samples.
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"
@@ -35,21 +32,11 @@ namespace urh {
 
 enum { SRC_IQ = 0, SRC_QAD = 1 };
 
-// Tuning knobs (tools/kbench A/B builds override them): rows per load batch, __launch_bounds__ waves per SIMD.
-#ifndef URH_KBATCH
-#define URH_KBATCH 2
-#endif
-#ifndef URH_MINWAVES
-#define URH_MINWAVES 1
-#endif
-
 // ---- small device helpers ---------------------------------------------------------------------
-__device__ __forceinline__ float dpp_wave_shr1(float x, float lane0) {
-    // value of lane-1; lane 0 (no source lane) receives `lane0`
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0), __float_as_int(x), 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane63(float x) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+__device__ __forceinline__ float dpp_wave_shr1(float x) {
+    // value of lane-1 (lane 0 keeps its own value; the caller overrides it)
+    int xi = __float_as_int(x);
+    return __int_as_float(__builtin_amdgcn_update_dpp(xi, xi, 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
 }
 
 template <int DT> struct Iq;
@@ -145,26 +132,6 @@ __device__ __forceinline__ float atan2f_dev(float y, float x) {
     return (z - pi_lo) - pi;
 }
 
-// ---- FSK fast path --------------------------------------------------------------------------------
-// For the overwhelmingly common sample -- conj(prev)*cur has finite non-zero parts and
-// 2^-29 <= |im/re| < 0.4375 (|phase step| < 0.412 rad or within 0.412 rad of pi) -- fdlibm's atan2f
-// is straight-line code: one division, the 11-term polynomial without argument reduction and the
-// quadrant fix-up.  kAtanLo/kAtanSpan express that range as one unsigned compare on |im/re|'s bits
-// (NaN, inf, 0 and everything that needs argument reduction fall outside it).  A wavefront whose
-// every lane is in range (or noise-gated) takes this path; otherwise the whole wavefront runs the
-// general code (conj_mul + atan2f_dev above).  In range, the plain product below equals conj_mul():
-// the two only differ in the sign of exact zeros, and a signed zero cannot change a non-zero sum.
-constexpr uint32_t kAtanLo = 0x31000000u, kAtanSpan = 0x3ee00000u - 0x31000000u;
-
-__device__ __forceinline__ float atan2f_small(float r, float y, float x) {
-    // r = |y/x| in [2^-29, 0.4375)
-    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
-    const float z = r - urh_atanf_poly(r);
-    const float zx = pi - (z - pi_lo);                       // x < 0: pi - (z - pi_lo); y's sign negates exactly
-    const float base = (__float_as_int(x) < 0) ? zx : z;
-    return __uint_as_float((__float_as_uint(base) & 0x7fffffffu) | (__float_as_uint(y) & 0x80000000u));
-}
-
 template <bool ORDER2>
 __device__ __forceinline__ uint32_t classify(float q, const RunArgs &p, bool check_noise = true) {
     if (check_noise && q == p.noise_val) return kStPause;
@@ -189,90 +156,6 @@ __device__ __forceinline__ float demod_one(float pc, float pd, float c, float d,
     return 0.0f;   // MOD_OTHER: np.zeros stays
 }
 
-// One 16-byte row slice of a lane: its two consecutive samples (SRC_QAD: c0/d0 = two demodulated samples).
-struct RowIn { float c0, d0, c1, d1; };
-
-// Issue the loads of rows [rb, rb+NB) of the tile at sample ta.
-// FULL: the whole tile lies inside the capture, nothing is bounds-checked (the hot path).  Otherwise
-// (the single partial tile at the end of a capture) samples at or beyond a1 read as 0.
-template <int SRC, int DT, bool FULL, int NB>
-__device__ __forceinline__ void load_rows(const RunArgs &p, int64_t ta, int rb, int t, int64_t a1, RowIn (&r)[NB]) {
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int64_t i0 = ta + (rb + j) * kRowSamples + 2 * t;
-        r[j].c0 = r[j].d0 = r[j].c1 = r[j].d1 = 0.f;
-        if (SRC == SRC_QAD) {
-            const float *q = (const float *)p.in;
-            if (FULL || i0 + 1 < a1) { const float2 v = *(const float2 *)(q + i0); r[j].c0 = v.x; r[j].d0 = v.y; }
-            else if (i0 < a1) r[j].c0 = q[i0];
-        } else {
-            if (FULL || i0 + 1 < a1) Iq<DT>::load2(p.in, i0, r[j].c0, r[j].d0, r[j].c1, r[j].d1);
-            else if (i0 < a1) Iq<DT>::load1(p.in, i0, r[j].c0, r[j].d0);
-        }
-    }
-}
-
-// Demodulate a lane's two consecutive samples (q0, q1); all 64 lanes are active.  (prev_c, prev_d)
-// is the sample before lane 0's first sample (wavefront-uniform).
-// Returns 0 when q0/q1 are final and NO sample of the row is noise-gated (the fast path: states
-// follow from the thresholds alone), 1 when q0/q1 are final but some sample is gated, 2 (FSK only)
-// when some lane needs the general code: q0/q1 are then NOT valid and the caller redoes the row with
-// fsk_row_general().
-template <int MOD>
-__device__ __forceinline__ int demod_pair(const RowIn &r, float prev_c, float prev_d, const RunArgs &p, float &q0, float &q1) {
-    const float c0 = r.c0, d0 = r.d0, c1 = r.c1, d1 = r.d1;
-    const float mag0 = c0 * c0 + d0 * d0, mag1 = c1 * c1 + d1 * d1;
-    const bool n0 = mag0 <= p.noise_sqrd, n1 = mag1 <= p.noise_sqrd;
-    const bool any_noise = __builtin_amdgcn_ballot_w64(n0 | n1) != 0;
-    if (any_noise && __builtin_amdgcn_ballot_w64(n0 & n1) == ~0ull) {     // a row inside a pause: all NOISE
-        q0 = q1 = p.noise_val;
-        return 1;
-    }
-    if (MOD == URHGPU_MOD_FSK) {
-        // Forward-quadrant fast path: re > 0 and 2^-29 <= |im/re| < 0.4375.  There atan2f(im, re) is
-        // atanf(im/re) without argument reduction, and atanf is odd, so the signed quotient goes
-        // straight through the polynomial (a negated operand negates every product and sum exactly).
-        const float pc = dpp_wave_shr1(c1, prev_c), pd = dpp_wave_shr1(d1, prev_d);   // lane-1's second sample
-        const float re0 = pc * c0 + pd * d0, im0 = pc * d0 - pd * c0;
-        const float re1 = c0 * c1 + d0 * d1, im1 = c0 * d1 - d0 * c1;
-        const float t0 = im0 / re0, t1 = im1 / re1;
-        const bool ok0 = ((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (re0 > 0.0f);
-        const bool ok1 = ((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (re1 > 0.0f);
-        if (any_noise || __builtin_amdgcn_ballot_w64(!(ok0 & ok1)) != 0) return 2;
-        q0 = t0 - urh_atanf_poly(t0);
-        q1 = t1 - urh_atanf_poly(t1);
-        return 0;
-    }
-    if (MOD == URHGPU_MOD_ASK) {
-        q0 = __builtin_sqrtf(mag0) / p.max_magnitude;    // (double)sqrtf / (double)max == fp32 division
-        q1 = __builtin_sqrtf(mag1) / p.max_magnitude;
-    } else {
-        q0 = q1 = 0.0f;                                  // MOD_OTHER: np.zeros stays
-    }
-    if (!any_noise && MOD == URHGPU_MOD_ASK) return 0;   // (MOD_OTHER: 0.0 may equal the sentinel -0.0 of "QAM")
-    q0 = n0 ? p.noise_val : q0;
-    q1 = n1 ? p.noise_val : q1;
-    return 1;
-}
-
-// The general FSK row (any operand class, any angle, noise gating).  Deliberately rolled up (one
-// copy of the general atan2f per kernel) so that the hot loop stays small in the instruction cache.
-__device__ __forceinline__ void fsk_row_general(const RowIn &r, float prev_c, float prev_d, const RunArgs &p, float &q0, float &q1) {
-    const float pc = dpp_wave_shr1(r.c1, prev_c), pd = dpp_wave_shr1(r.d1, prev_d);
-    float out[2];
-#pragma unroll 1
-    for (int s = 0; s < 2; ++s) {
-        const float a = s ? r.c0 : pc, b = s ? r.d0 : pd, c = s ? r.c1 : r.c0, d = s ? r.d1 : r.d0;
-        float re, im, q = p.noise_val;
-        if (!(c * c + d * d <= p.noise_sqrd)) {
-            conj_mul(a, b, c, d, re, im);
-            q = atan2f_dev(im, re);
-        }
-        if (s) out[1] = q; else out[0] = q;
-    }
-    q0 = out[0]; q1 = out[1];
-}
-
 // Block-wide helpers --------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -293,20 +176,15 @@ __device__ __forceinline__ uint32_t diff_nibble(uint32_t w, uint32_t pw) {
 }
 
 // -----------------------------------------------------------------------------------------------------
-// k_demod_runs<SRC, DT, MOD, ORDER2, WRITE_QAD, FULL>
-//   one workgroup per chunk; workgroup b handles chunk p.chunk_base + b = samples
-//   [p.range_begin + b*chunk_len, min(.. + chunk_len, p.range_end)).  FULL: the range consists of whole
-//   tiles only (the hot launch); the partial tile at the end of a capture is a chunk of its own,
-//   handled by a one-workgroup launch of the bounds-checked instantiation.
+// k_demod_runs<SRC, DT, MOD, ORDER2, WRITE_QAD>
 // -----------------------------------------------------------------------------------------------------
-template <int SRC, int DT, int MOD, bool ORDER2, bool WRITE_QAD, bool FULL>
-__global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunArgs p) {
+template <int SRC, int DT, int MOD, bool ORDER2, bool WRITE_QAD>
+__global__ __launch_bounds__(kBlock) void k_demod_runs(const RunArgs p) {
     __shared__ __attribute__((aligned(16))) uint8_t s_state[16 + kTile];   // [15] = state of the sample before the tile
     __shared__ uint32_t s_bm[kBlock + 1];
     __shared__ int s_first, s_last;            // first / last boundary offset in the tile (or kTile / -1)
-    constexpr int kWaves = kBlock / 64;
-    __shared__ int s_wave_cnt[kWaves];
-    __shared__ uint32_t s_wave_last[kWaves];
+    __shared__ int s_wave_cnt[4];
+    __shared__ uint32_t s_wave_last[4];
     // chunk-level carries
     __shared__ int64_t s_pend_pos;             // unresolved run start (absolute) or -1
     __shared__ uint32_t s_pend_state;
@@ -319,16 +197,14 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
     __shared__ unsigned long long s_last_pos;  // position of the last record written (records are position-ordered)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int64_t chunk = p.chunk_base + blockIdx.x;
-    const int64_t a0 = p.range_begin + (int64_t)blockIdx.x * p.chunk_len;
-    const int64_t a1 = (a0 + p.chunk_len < p.range_end) ? a0 + p.chunk_len : p.range_end;
+    const int64_t chunk = blockIdx.x;
+    const int64_t a0 = chunk * p.chunk_len;
+    const int64_t a1 = (a0 + p.chunk_len < p.n) ? a0 + p.chunk_len : p.n;
     uint64_t *slab = p.slab + chunk * p.slab_stride;
     const bool global_start = (p.left_halo == nullptr);
 
-    // ---- chunk prologue: the two samples before the chunk (wavefront-uniform loads), the state of
-    // sample a0-1, initial carries ------------------------------------------------------------------
-    float prev_c = 0.f, prev_d = 0.f;          // IQ sample a0-1: seam operand of the chunk's first sample
-    {
+    // ---- chunk prologue: state of sample a0-1 (halo), init carries --------------------------------
+    if (t == 0) {
         uint32_t st = kStNone;
         if (SRC == SRC_QAD) {
             const float *q = (const float *)p.in;
@@ -336,99 +212,98 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
             else if (!global_start) st = classify<ORDER2>(((const float *)p.left_halo)[0], p);
         } else {
             // qad[a0-1] needs IQ[a0-1] and (FSK) IQ[a0-2]
-            float pc = 0, pd = 0;
+            float c = 0, d = 0, pc = 0, pd = 0;
             bool have = false, is_global0 = false;
             if (a0 >= 1) {
-                Iq<DT>::load1(p.in, a0 - 1, prev_c, prev_d);
+                Iq<DT>::load1(p.in, a0 - 1, c, d);
                 have = true;
                 if (a0 >= 2) Iq<DT>::load1(p.in, a0 - 2, pc, pd);
                 else if (!global_start) Iq<DT>::load1(p.left_halo, 1, pc, pd);
                 else is_global0 = true;           // sample a0-1 is global sample 0 -> NOISE
             } else if (!global_start) {
-                Iq<DT>::load1(p.left_halo, 1, prev_c, prev_d);
+                Iq<DT>::load1(p.left_halo, 1, c, d);
                 Iq<DT>::load1(p.left_halo, 0, pc, pd);
                 have = true;
             }
             if (have) {
-                const float q = is_global0 ? p.noise_val : demod_one<MOD>(pc, pd, prev_c, prev_d, p);
+                const float q = is_global0 ? p.noise_val : demod_one<MOD>(pc, pd, c, d, p);
                 st = classify<ORDER2>(q, p);
             }
         }
-        if (t == 0) {
-            s_prev_state8 = st;
-            s_pend_pos = -1; s_pend_state = 0; s_lead = -1; s_carry_last = 0xFFFFu; s_first_state = 0xFFFFu; s_count = 0; s_last_pos = 0;
-        }
+        s_prev_state8 = st;
+        s_pend_pos = -1; s_pend_state = 0; s_lead = -1; s_carry_last = 0xFFFFu; s_first_state = 0xFFFFu; s_count = 0; s_last_pos = 0;
     }
     __syncthreads();
 
-    constexpr int kBatch = URH_KBATCH;   // rows (16-byte loads per thread) in flight per batch
-    RowIn cur[kBatch], nxt[kBatch];
-    bool have_cur = false;         // cur[] already holds rows 0..kBatch-1 of the tile about to start (uniform)
     for (int64_t ta = a0; ta < a1; ta += kTile) {
         const int tv = (int)((a1 - ta < kTile) ? (a1 - ta) : kTile);     // valid samples in this tile
         if (t == 0) {
             s_state[15] = (uint8_t)s_prev_state8;
             s_first = kTile; s_last = -1; s_newpend = -1;
         }
-        // ================= phase 1: demodulate + classify, 2 samples per lane per row ====================
-        // Loads are software-pipelined one batch ahead; the last batch of a tile prefetches the first
-        // batch of the next tile, so the run phase below overlaps the memory latency.
-        {
-            const bool first_row = (ta == 0) && global_start && (t == 0);   // sample 0 of the capture is mine
-            if (!have_cur) load_rows<SRC, DT, FULL>(p, ta, 0, t, a1, cur);
+        // ================= phase 1: demodulate + classify, 2 samples per thread per row =================
+        // Rows are processed in batches of kBatch: all loads of a batch are issued before any of its
+        // arithmetic / stores so that kBatch 16-byte loads per thread are in flight.
+        constexpr int kBatch = 4;
 #pragma unroll 1
-            for (int rb = 0; rb < kRows; rb += kBatch) {
-                if (rb + kBatch < kRows) {
-                    load_rows<SRC, DT, FULL>(p, ta, rb + kBatch, t, a1, nxt);
-                } else {
-                    have_cur = (ta + kTile < a1);
-                    if (have_cur) load_rows<SRC, DT, FULL>(p, ta + kTile, 0, t, a1, nxt);
-                }
-                float q0[kBatch], q1[kBatch];
-                uint32_t general = 0, gated = 0;                        // per-row flags, wavefront-uniform
-                float pcs[kBatch], pds[kBatch];                         // seam operand of each row (uniform)
+        for (int rb = 0; rb < kRows; rb += kBatch) {
+            if (SRC == SRC_QAD) {
+                const float *q = (const float *)p.in;
+                float2 v[kBatch];
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) {
-                    if (SRC == SRC_QAD) { q0[j] = cur[j].c0; q1[j] = cur[j].d0; gated |= 1u << j; continue; }
-                    pcs[j] = prev_c; pds[j] = prev_d;
-                    const int k = demod_pair<MOD>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
-                    if (k == 2) general |= 1u << j;
-                    if (k != 0) gated |= 1u << j;
-                    if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
+                    const int64_t i0 = ta + (rb + j) * kRowSamples + 2 * t;
+                    v[j] = make_float2(0.f, 0.f);
+                    if (i0 + 1 < a1) v[j] = *(const float2 *)(q + i0);
+                    else if (i0 < a1) v[j].x = q[i0];
                 }
-                if (MOD == URHGPU_MOD_FSK && SRC == SRC_IQ && general) {
-#pragma unroll 1
-                    for (int j = 0; j < kBatch; ++j) {
-                        if (!((general >> j) & 1u)) continue;
-                        RowIn r = cur[0]; float pc = pcs[0], pd = pds[0];
 #pragma unroll
-                        for (int k = 1; k < kBatch; ++k) if (j == k) { r = cur[k]; pc = pcs[k]; pd = pds[k]; }
-                        float g0, g1;
-                        fsk_row_general(r, pc, pd, p, g0, g1);
+                for (int j = 0; j < kBatch; ++j) {
+                    const int off = (rb + j) * kRowSamples + 2 * t;
+                    const int64_t i0 = ta + off;
+                    const uint32_t st0 = (i0 < a1) ? classify<ORDER2>(v[j].x, p) : kStNone;
+                    const uint32_t st1 = (i0 + 1 < a1) ? classify<ORDER2>(v[j].y, p) : kStNone;
+                    *(uint16_t *)(s_state + 16 + off) = (uint16_t)(st0 | (st1 << 8));
+                }
+            } else {
+                float c0[kBatch], d0[kBatch], c1[kBatch], d1[kBatch], sc[kBatch], sd[kBatch];
 #pragma unroll
-                        for (int k = 0; k < kBatch; ++k) if (j == k) { q0[k] = g0; q1[k] = g1; }
+                for (int j = 0; j < kBatch; ++j) {
+                    const int off = (rb + j) * kRowSamples + 2 * t;
+                    const int64_t i0 = ta + off;
+                    c0[j] = d0[j] = c1[j] = d1[j] = 0.f; sc[j] = sd[j] = 0.f;
+                    if (i0 + 1 < a1) Iq<DT>::load2(p.in, i0, c0[j], d0[j], c1[j], d1[j]);
+                    else if (i0 < a1) Iq<DT>::load1(p.in, i0, c0[j], d0[j]);
+                    if (MOD == URHGPU_MOD_FSK) {
+                        // wavefront seam: the sample before this wavefront's row segment (uniform address)
+                        const int64_t w0 = ta + __builtin_amdgcn_readfirstlane(off - 2 * lane);
+                        if (w0 >= 1) { if (w0 - 1 < a1) Iq<DT>::load1(p.in, w0 - 1, sc[j], sd[j]); }
+                        else if (!global_start) Iq<DT>::load1(p.left_halo, 1, sc[j], sd[j]);
                     }
                 }
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) {
                     const int off = (rb + j) * kRowSamples + 2 * t;
-                    if (SRC == SRC_IQ) {
-                        if (j == 0 && rb == 0 && first_row) q0[0] = p.noise_val;        // result[0] = NOISE (:361)
-                        if (WRITE_QAD) {
-                            if (FULL || ta + off + 1 < a1) *(float2 *)(p.qad + ta + off) = make_float2(q0[j], q1[j]);
-                            else if (ta + off < a1) p.qad[ta + off] = q0[j];
+                    const int64_t i0 = ta + off;
+                    const bool v1 = (i0 + 1 < a1), v0 = (i0 < a1);
+                    uint32_t st0 = kStNone, st1 = kStNone;
+                    // previous sample of (c0,d0): lane-1's second sample, or the seam sample for lane 0
+                    float pc = dpp_wave_shr1(c1[j]), pd = dpp_wave_shr1(d1[j]);
+                    if (lane == 0) { pc = sc[j]; pd = sd[j]; }
+                    if (v0) {
+                        float q0 = demod_one<MOD>(pc, pd, c0[j], d0[j], p);
+                        if (i0 == 0 && global_start) q0 = p.noise_val;            // result[0] = NOISE  (:361)
+                        st0 = classify<ORDER2>(q0, p);
+                        if (v1) {
+                            const float q1 = demod_one<MOD>(c0[j], d0[j], c1[j], d1[j], p);
+                            st1 = classify<ORDER2>(q1, p);
+                            if (WRITE_QAD) *(float2 *)(p.qad + i0) = make_float2(q0, q1);
+                        } else if (WRITE_QAD) {
+                            p.qad[i0] = q0;
                         }
                     }
-                    uint32_t st0, st1;
-                    if (((gated >> j) & 1u) || (j == 0 && rb == 0 && ta == 0 && global_start)) {
-                        st0 = classify<ORDER2>(q0[j], p); st1 = classify<ORDER2>(q1[j], p);
-                    } else {                                            // nothing gated: thresholds only
-                        st0 = classify<ORDER2>(q0[j], p, false); st1 = classify<ORDER2>(q1[j], p, false);
-                    }
-                    *(uint16_t *)(s_state + 16 + off) = (uint16_t)(st0 | (st1 << 8));   // bytes beyond tv are masked in phase 2
+                    *(uint16_t *)(s_state + 16 + off) = (uint16_t)(st0 | (st1 << 8));
                 }
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) cur[j] = nxt[j];
             }
         }
         __syncthreads();   // A: states complete
@@ -560,7 +435,8 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
         }
         __syncthreads();   // E: all reads of this tile's LDS state done; next tile may overwrite it
         if (t == 0) {
-            for (int w = 0; w < kWaves; ++w) { s_count += s_wave_cnt[w]; if (s_wave_last[w] != 0xFFFFu) s_carry_last = s_wave_last[w]; }
+            s_count += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+            for (int w = 0; w < 4; ++w) if (s_wave_last[w] != 0xFFFFu) s_carry_last = s_wave_last[w];
             s_prev_state8 = t0_prev8;
             if (t0_newpend >= 0) { s_pend_pos = ta + t0_newpend; s_pend_state = t0_pend_state; }
         }
@@ -596,27 +472,25 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
 // Plain afp_demod kernel (no run segmentation): used by urhgpu_afp_demod[_dev] for MOD_OTHER and
 // when only Signal.qad is wanted.
 // -----------------------------------------------------------------------------------------------------
-constexpr int kAfpBlock = 256;                  // k_afp_demod: 4 wavefronts, 512 samples per workgroup-wide load
-constexpr int kAfpRow = kAfpBlock * 2;
-
 template <int DT, int MOD>
-__global__ __launch_bounds__(kAfpBlock) void k_afp_demod(const RunArgs p) {
+__global__ __launch_bounds__(kBlock) void k_afp_demod(const RunArgs p) {
     const int lane = threadIdx.x & 63;
     const bool global_start = (p.left_halo == nullptr);
-    const int64_t stride = (int64_t)gridDim.x * kAfpRow;
-    for (int64_t base = (int64_t)blockIdx.x * kAfpRow; base < p.n; base += stride) {
+    const int64_t stride = (int64_t)gridDim.x * kRowSamples;
+    for (int64_t base = (int64_t)blockIdx.x * kRowSamples; base < p.n; base += stride) {
         const int64_t i0 = base + 2 * threadIdx.x;
         float c0 = 0, d0 = 0, c1 = 0, d1 = 0;
         const bool v1 = (i0 + 1 < p.n), v0 = (i0 < p.n);
         if (v1) Iq<DT>::load2(p.in, i0, c0, d0, c1, d1);
         else if (v0) Iq<DT>::load1(p.in, i0, c0, d0);
-        float sc = 0, sd = 0;
+        float pc = dpp_wave_shr1(c1), pd = dpp_wave_shr1(d1);
         if (MOD == URHGPU_MOD_FSK) {
-            const int64_t w0 = base + 2 * (threadIdx.x - lane);      // wavefront seam (uniform address)
+            const int64_t w0 = base + 2 * (threadIdx.x - lane);
+            float sc = 0, sd = 0;
             if (w0 >= 1) { if (w0 - 1 < p.n) Iq<DT>::load1(p.in, w0 - 1, sc, sd); }
             else if (!global_start) Iq<DT>::load1(p.left_halo, 1, sc, sd);
+            if (lane == 0) { pc = sc; pd = sd; }
         }
-        const float pc = dpp_wave_shr1(c1, sc), pd = dpp_wave_shr1(d1, sd);
         if (v0) {
             float q0 = demod_one<MOD>(pc, pd, c0, d0, p);
             if (i0 == 0 && global_start) q0 = p.noise_val;
@@ -636,65 +510,50 @@ __global__ void k_test_atan2f(const float *y, const float *x, int64_t n, float *
 }
 
 // ---- host-side launchers ---------------------------------------------------------------------------
-// `a` describes the whole capture (a.n samples, chunk table / slab for n_main + has_tail chunks):
-// one launch over the whole tiles, one one-workgroup launch for the partial tile at the end.
-template <int SRC, int DT, int MOD, bool O2, bool WQ>
-static void launch_runs_4(RunArgs a, hipStream_t s) {
-    const int64_t n_full = (a.n / kTile) * kTile;
-    const int64_t n_main = (n_full + a.chunk_len - 1) / a.chunk_len;
-    if (n_main > 0) {
-        a.range_begin = 0; a.range_end = n_full; a.chunk_base = 0;
-        hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)n_main), dim3(kBlock), 0, s, a);
-    }
-    if (n_full < a.n) {
-        a.range_begin = n_full; a.range_end = a.n; a.chunk_base = n_main;
-        hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, false>), dim3(1), dim3(kBlock), 0, s, a);
-    }
-}
-
 template <int SRC, int DT, int MOD>
-static void launch_runs_3(const RunArgs &a, bool write_qad, hipStream_t s) {
+static void launch_runs_3(const RunArgs &a, int64_t n_chunks, bool write_qad, hipStream_t s) {
     const bool o2 = (a.order == 2);
+    dim3 g((unsigned)n_chunks), b(kBlock);
     if (o2) {
-        if (write_qad) launch_runs_4<SRC, DT, MOD, true, true>(a, s);
-        else launch_runs_4<SRC, DT, MOD, true, false>(a, s);
+        if (write_qad) hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, true, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, true, false>), g, b, 0, s, a);
     } else {
-        if (write_qad) launch_runs_4<SRC, DT, MOD, false, true>(a, s);
-        else launch_runs_4<SRC, DT, MOD, false, false>(a, s);
+        if (write_qad) hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, false, true>), g, b, 0, s, a);
+        else hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, false, false>), g, b, 0, s, a);
     }
 }
 
 template <int DT>
-static int launch_runs_2(const RunArgs &a, int mod, bool write_qad, hipStream_t s) {
+static int launch_runs_2(const RunArgs &a, int mod, int64_t n_chunks, bool write_qad, hipStream_t s) {
     switch (mod) {
-        case URHGPU_MOD_ASK: launch_runs_3<SRC_IQ, DT, URHGPU_MOD_ASK>(a, write_qad, s); return URHGPU_OK;
-        case URHGPU_MOD_FSK: launch_runs_3<SRC_IQ, DT, URHGPU_MOD_FSK>(a, write_qad, s); return URHGPU_OK;
-        case URHGPU_MOD_OTHER: launch_runs_3<SRC_IQ, DT, URHGPU_MOD_OTHER>(a, write_qad, s); return URHGPU_OK;
+        case URHGPU_MOD_ASK: launch_runs_3<SRC_IQ, DT, URHGPU_MOD_ASK>(a, n_chunks, write_qad, s); return URHGPU_OK;
+        case URHGPU_MOD_FSK: launch_runs_3<SRC_IQ, DT, URHGPU_MOD_FSK>(a, n_chunks, write_qad, s); return URHGPU_OK;
+        case URHGPU_MOD_OTHER: launch_runs_3<SRC_IQ, DT, URHGPU_MOD_OTHER>(a, n_chunks, write_qad, s); return URHGPU_OK;
         default: return URHGPU_ERR_ARG;
     }
 }
 
 // Fused demod + run segmentation over IQ (ASK / FSK / OTHER).
-int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s) {
+int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, int64_t n_chunks, bool write_qad, hipStream_t s) {
     switch (dtype) {
-        case URHGPU_DT_F32: return launch_runs_2<URHGPU_DT_F32>(a, mod, write_qad, s);
-        case URHGPU_DT_I8: return launch_runs_2<URHGPU_DT_I8>(a, mod, write_qad, s);
-        case URHGPU_DT_U8: return launch_runs_2<URHGPU_DT_U8>(a, mod, write_qad, s);
-        case URHGPU_DT_I16: return launch_runs_2<URHGPU_DT_I16>(a, mod, write_qad, s);
-        case URHGPU_DT_U16: return launch_runs_2<URHGPU_DT_U16>(a, mod, write_qad, s);
+        case URHGPU_DT_F32: return launch_runs_2<URHGPU_DT_F32>(a, mod, n_chunks, write_qad, s);
+        case URHGPU_DT_I8: return launch_runs_2<URHGPU_DT_I8>(a, mod, n_chunks, write_qad, s);
+        case URHGPU_DT_U8: return launch_runs_2<URHGPU_DT_U8>(a, mod, n_chunks, write_qad, s);
+        case URHGPU_DT_I16: return launch_runs_2<URHGPU_DT_I16>(a, mod, n_chunks, write_qad, s);
+        case URHGPU_DT_U16: return launch_runs_2<URHGPU_DT_U16>(a, mod, n_chunks, write_qad, s);
         default: return URHGPU_ERR_DTYPE;
     }
 }
 
 // Run segmentation over an already demodulated float32 signal (grab_pulse_lens proper).
-int launch_runs_qad(const RunArgs &a, hipStream_t s) {
-    launch_runs_3<SRC_QAD, URHGPU_DT_F32, URHGPU_MOD_OTHER>(a, false, s);
+int launch_runs_qad(const RunArgs &a, int64_t n_chunks, hipStream_t s) {
+    launch_runs_3<SRC_QAD, URHGPU_DT_F32, URHGPU_MOD_OTHER>(a, n_chunks, false, s);
     return URHGPU_OK;
 }
 
 template <int DT>
 static int launch_afp_2(const RunArgs &a, int mod, int grid, hipStream_t s) {
-    dim3 g(grid), b(kAfpBlock);
+    dim3 g(grid), b(kBlock);
     switch (mod) {
         case URHGPU_MOD_ASK: hipLaunchKernelGGL((k_afp_demod<DT, URHGPU_MOD_ASK>), g, b, 0, s, a); return URHGPU_OK;
         case URHGPU_MOD_FSK: hipLaunchKernelGGL((k_afp_demod<DT, URHGPU_MOD_FSK>), g, b, 0, s, a); return URHGPU_OK;

@@ -42,11 +42,13 @@ struct Plan {                 // how a capture of n samples is cut into chunks
 
 Plan make_plan(const urhgpu_ctx *ctx, int64_t n, int tol) {
     Plan pl;
-    const int64_t tiles = std::max<int64_t>(1, (n + kTile - 1) / kTile);
-    const int64_t target = (int64_t)ctx->prop.multiProcessorCount * 8;       // ~8 workgroups per CU
-    const int64_t tiles_per_chunk = std::max<int64_t>(1, (tiles + target - 1) / target);
+    // whole tiles are grouped into chunks of tiles_per_chunk tiles (one workgroup each); a partial
+    // tile at the end of the capture is one more chunk (see launch_runs_4 in demod_runs.hip)
+    const int64_t full_tiles = n / kTile;
+    const int64_t target = (int64_t)ctx->prop.multiProcessorCount * 64;      // chunks (= wavefronts): ~2-3 rounds of the resident set
+    const int64_t tiles_per_chunk = std::max<int64_t>(1, (full_tiles + target - 1) / target);
     pl.chunk_len = tiles_per_chunk * kTile;
-    pl.n_chunks = std::max<int64_t>(1, (n + pl.chunk_len - 1) / pl.chunk_len);
+    pl.n_chunks = (full_tiles * kTile + pl.chunk_len - 1) / pl.chunk_len + ((n % kTile) ? 1 : 0);
     pl.slab_stride = pl.chunk_len / ((int64_t)tol + 1) + 2;
     return pl;
 }
@@ -122,8 +124,8 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     a.chunks = chunks; a.slab = slab;
     const bool prof = ctx->prof_on && (size_t)(2 * ctx->prof_used + 1) < ctx->prof_events.size();
     if (prof) URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used], s));
-    if (from_iq) URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, pl.n_chunks, d_qad != nullptr, s));
-    else URH_TRY(launch_runs_qad(a, pl.n_chunks, s));
+    if (from_iq) URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, d_qad != nullptr, s));
+    else URH_TRY(launch_runs_qad(a, s));
     if (prof) { URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], s)); ctx->prof_used += 1; }
 
     const bool ask = (p->mod == URHGPU_MOD_ASK);
@@ -305,7 +307,7 @@ int urhgpu_afp_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urh
     a.noise_sqrd = p->noise_threshold * p->noise_threshold;
     a.noise_val = noise_for(p);
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
-    const int64_t rows = (n + kRowSamples - 1) / kRowSamples;
+    const int64_t rows = (n + 511) / 512;                        // k_afp_demod: 512 samples per workgroup-wide load
     const int grid = (int)std::min<int64_t>(rows, (int64_t)ctx->prop.multiProcessorCount * 16);
     URH_TRY(launch_afp_demod(a, p->dtype, p->mod, grid, ctx->stream));
     URH_HIP(hipGetLastError());

@@ -13,7 +13,10 @@ struct RunArgs {
     const void *in;          // IQ (dtype) or qad (float) -- device pointer
     float *qad;              // demodulated output or nullptr
     const void *left_halo;   // 2 IQ samples (or 1 qad sample) preceding in[0]; nullptr = global start
-    int64_t n;               // samples
+    int64_t n;               // samples in the buffer `in`
+    int64_t range_begin;     // per launch (set by the launchers): samples [range_begin, range_end) of `in`,
+    int64_t range_end;       //   workgroup b = chunk chunk_base + b
+    int64_t chunk_base;
     int64_t pos_base;        // absolute position of in[0] (sharded captures); positions in records are absolute
     int64_t chunk_len;       // multiple of kTile
     uint64_t *slab;          // accepted-run records, slab_stride per chunk
@@ -26,8 +29,8 @@ struct RunArgs {
     int tol;                 // tolerance
     float thr[kMaxOrder - 1];
 };
-int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, int64_t n_chunks, bool write_qad, hipStream_t s);
-int launch_runs_qad(const RunArgs &a, int64_t n_chunks, hipStream_t s);
+int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s);
+int launch_runs_qad(const RunArgs &a, hipStream_t s);
 int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t s);
 void launch_test_atan2f(const float *y, const float *x, int64_t n, float *out, hipStream_t s);
 

@@ -10,8 +10,9 @@
 //   accepted   stable run whose state differs from the previous stable run's state: each one is a
 //              row boundary of the pulse table ("ppseq")
 //
-// Work split: the capture is cut into sample-contiguous CHUNKS, one workgroup each; a chunk is
-// walked in TILES of 8192 samples.  Everything a chunk cannot decide alone (does its first stable
+// Work split: the capture is cut into sample-contiguous CHUNKS, one WAVEFRONT (= one 64-thread
+// workgroup) each, so that no wavefront ever waits for another one; a chunk is walked in TILES of
+// 2048 samples.  Everything a chunk cannot decide alone (does its first stable
 // run differ from the previous chunk's last one?  does its last, still-short run continue into
 // the next chunk?) goes into one ChunkInfo record, resolved by k_resolve_chunks over all chunks
 // (and, for sharded captures, over the chunks of all GPUs).
@@ -20,10 +21,10 @@
 
 namespace urh {
 
-constexpr int kBlock = 256;                    // threads per workgroup (4 wavefronts)
+constexpr int kBlock = 64;                     // threads per workgroup: ONE wavefront
 constexpr int kRows = 16;                      // 16-byte IQ loads per thread per tile
-constexpr int kRowSamples = kBlock * 2;        // samples covered by one workgroup-wide load
-constexpr int kTile = kRowSamples * kRows;     // 8192 samples per tile
+constexpr int kRowSamples = kBlock * 2;        // 128 samples (1 KiB of complex64) per wavefront-wide load
+constexpr int kTile = kRowSamples * kRows;     // 2048 samples per tile
 constexpr int kSpan = kTile / kBlock;          // 32 samples per thread in the run phase
 
 // State byte stored in LDS: reference state + 1 (PAUSE=-1 -> 0); 0xFF = "no sample".
