@@ -59,6 +59,7 @@ size_t digitize_scratch_bytes(const Plan &pl, int64_t cap_rows, bool ask, bool b
     size_t b = 0;
     b += align256((size_t)pl.n_chunks * sizeof(ChunkInfo));
     b += align256((size_t)pl.n_chunks * pl.slab_stride * 8);
+    b += align256(resolve_scratch_bytes(pl.n_chunks));
     if (ask) b += align256((size_t)cap_rows * 16) + align256(merge_scratch_bytes(cap_rows));
     if (bits) b += align256(bits_scratch_bytes(cap_rows));
     b += 4096;
@@ -138,12 +139,17 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
         d_n_stage = (int64_t *)ctx->arena.take(64);
         if (!rows_stage || !merge_scratch || !d_n_stage) return URHGPU_ERR_ARG;
     }
+    void *rs_mem = ctx->arena.take(resolve_scratch_bytes(pl.n_chunks));
+    if (!rs_mem) return URHGPU_ERR_ARG;
+    const ResolveScratch rsc = resolve_scratch_carve(rs_mem, pl.n_chunks);
     ResolveArgs r;
+    r.sc = rsc;
     r.chunks = chunks; r.n_chunks = pl.n_chunks; r.n_total = n; r.tol = p->tolerance;
     r.rows = rows_stage; r.cap_rows = cap_rows; r.d_n_acc = d_n_acc; r.d_n_rows = d_n_stage;
     r.d_n_rows_needed = d_n_rows_needed; r.write_last_row = 1;
     URH_TRY(launch_resolve(r, s));
     EmitArgs e;
+    e.sc = rsc;
     e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
     e.rows = rows_stage; e.cap_rows = cap_rows; e.row_base = 0; e.is_ask = ask ? 1 : 0; e.sps = p->samples_per_symbol;
     URH_TRY(launch_emit_rows(e, pl.n_chunks, s));

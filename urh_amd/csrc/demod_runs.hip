@@ -587,7 +587,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
             init = first_is_noise ? kStPause : classify<ORDER2>(0.0f, p, false);   // literal 0.0: thresholds only
         }
         ci.init_state = (uint16_t)init;
-        ci.first_acc = 0; ci.pend_acc = 0; ci.out_off = 0; ci.prev_pos = -1; ci.prev_state = 0; ci.pad = 0;
+        ci.first_acc = 0; ci.pend_acc = 0; ci.pend_stable = 0; ci.pad = 0;
         p.chunks[chunk] = ci;
     }
 }

@@ -35,6 +35,18 @@ int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t
 void launch_test_atan2f(const float *y, const float *x, int64_t n, float *out, hipStream_t s);
 
 // ---- pulse_table.hip ---------------------------------------------------------------------------------
+// Scratch of the resolve stage: one entry per chunk (ints are chunk indices or -1).
+struct ResolveScratch {
+    int32_t *has_stable;     // c if chunk c contains a stable run (incl. a pending run that turns stable) else -1
+    int32_t *prev_stable;    // last chunk before c that contains a stable run, or -1
+    int32_t *has_acc;        // c if chunk c contributes at least one accepted run else -1
+    int32_t *prev_acc;       // last chunk before c that contributes an accepted run, or -1
+    int64_t *out_cnt;        // accepted runs contributed by chunk c
+    int64_t *out_off;        // index of chunk c's first accepted run in the global accepted sequence
+};
+size_t resolve_scratch_bytes(int64_t n_chunks);
+ResolveScratch resolve_scratch_carve(void *mem, int64_t n_chunks);
+
 struct ResolveArgs {
     ChunkInfo *chunks;
     int64_t n_chunks;        // chunks in the table (all shards)
@@ -46,6 +58,7 @@ struct ResolveArgs {
     int64_t *d_n_rows;       // out: rows of the un-merged table (P+1, or P when P == n_total), clamped to cap_rows
     int64_t *d_n_rows_needed; // out: the same, unclamped (capacity check on the host)
     int write_last_row;      // 1 on the shard/GPU that owns the table's last row
+    ResolveScratch sc;
 };
 struct EmitArgs {
     const ChunkInfo *chunks;
@@ -57,6 +70,7 @@ struct EmitArgs {
     int64_t row_base;         // global row index that maps to rows[0] (0 on a single GPU)
     int is_ask;
     int64_t sps;
+    ResolveScratch sc;
 };
 struct BitsParams {
     int64_t sps;

@@ -15,137 +15,148 @@
 namespace urh {
 
 // =====================================================================================================
-// K2  k_resolve_chunks: settle everything a chunk could not decide alone (single workgroup).
+// Resolve stage: settle everything a chunk could not decide alone.
 //   - does a chunk's trailing short run grow past `tol` in the following chunks?  (ChunkInfo.lead)
 //   - is a chunk's first stable run "accepted", i.e. different from the last stable run before it?
 //   - global index of each chunk's first accepted run, and the accepted run preceding it
 // and write the last pulse-table row (signal_functions.pyx:485-493).
+// Two per-chunk kernels (one thread per chunk, any grid) separated by two single-workgroup scans
+// over small int arrays: "last chunk before me that has X" is an exclusive max-scan of (c if X else -1).
 // =====================================================================================================
 constexpr int kResolveBlock = 1024;
 
-struct LastValid {            // "last valid value" monoid for exclusive scans
-    int64_t pos;
-    uint32_t state;
-    int valid;
-};
+size_t resolve_scratch_bytes(int64_t n_chunks) { return (size_t)n_chunks * (4 * 4 + 2 * 8) + 6 * 256; }
 
-__device__ __forceinline__ LastValid lv_combine(const LastValid &a, const LastValid &b) { return b.valid ? b : a; }
-
-// exclusive scan of LastValid over the workgroup (thread order); `init` precedes thread 0
-__device__ LastValid block_excl_scan_lv(LastValid mine, LastValid init, LastValid *s_buf /*[kResolveBlock]*/) {
-    const int t = threadIdx.x;
-    s_buf[t] = mine;
-    __syncthreads();
-    for (int o = 1; o < kResolveBlock; o <<= 1) {
-        LastValid v = s_buf[t];
-        if (t >= o) v = lv_combine(s_buf[t - o], v);
-        __syncthreads();
-        s_buf[t] = v;
-        __syncthreads();
-    }
-    LastValid r = (t == 0) ? init : lv_combine(init, s_buf[t - 1]);
-    __syncthreads();
-    return r;
+ResolveScratch resolve_scratch_carve(void *mem, int64_t n_chunks) {
+    char *p = (char *)mem;
+    auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~size_t(255); return r; };
+    ResolveScratch sc;
+    sc.out_cnt = (int64_t *)take((size_t)n_chunks * 8);
+    sc.out_off = (int64_t *)take((size_t)n_chunks * 8);
+    sc.has_stable = (int32_t *)take((size_t)n_chunks * 4);
+    sc.prev_stable = (int32_t *)take((size_t)n_chunks * 4);
+    sc.has_acc = (int32_t *)take((size_t)n_chunks * 4);
+    sc.prev_acc = (int32_t *)take((size_t)n_chunks * 4);
+    return sc;
 }
 
-__device__ int64_t block_excl_scan_i64(int64_t mine, int64_t &total, int64_t *s_buf /*[kResolveBlock]*/) {
-    const int t = threadIdx.x;
-    s_buf[t] = mine;
-    __syncthreads();
-    for (int o = 1; o < kResolveBlock; o <<= 1) {
-        int64_t v = s_buf[t];
-        if (t >= o) v += s_buf[t - o];
-        __syncthreads();
-        s_buf[t] = v;
-        __syncthreads();
-    }
-    total = s_buf[kResolveBlock - 1];
-    const int64_t r = s_buf[t] - mine;
-    __syncthreads();
-    return r;
-}
-
-__global__ __launch_bounds__(kResolveBlock) void k_resolve_chunks(const ResolveArgs a) {
-    __shared__ LastValid s_lv[kResolveBlock];
-    __shared__ int64_t s_i64[kResolveBlock];
-    const int t = threadIdx.x;
-    const int64_t per = (a.n_chunks + kResolveBlock - 1) / kResolveBlock;
-    const int64_t c0 = (int64_t)t * per;
-    const int64_t c1 = (c0 + per < a.n_chunks) ? c0 + per : a.n_chunks;
+// R1: one thread per chunk.
+__global__ __launch_bounds__(256) void k_chunk_stable(const ResolveArgs a) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= a.n_chunks) return;
     ChunkInfo *ch = a.chunks;
-
-    // pass 1: trailing short runs; last stable state of my chunk range
-    LastValid mine = {0, 0, 0};
-    for (int64_t c = c0; c < c1; ++c) {
-        int ps = 0;
-        if (ch[c].pend_pos >= 0) {
-            int64_t len = ch[c].start + ch[c].len - ch[c].pend_pos;   // run length inside chunk c
-            for (int64_t u = c + 1; len <= a.tol && u < a.n_chunks; ++u) {
-                len += ch[u].lead;
-                if (ch[u].lead < ch[u].len) break;
-            }
-            ps = len > a.tol;
+    int ps = 0;
+    const int64_t pend_pos = ch[c].pend_pos;
+    if (pend_pos >= 0) {
+        int64_t len = ch[c].start + ch[c].len - pend_pos;              // run length inside chunk c
+        for (int64_t u = c + 1; len <= a.tol && u < a.n_chunks; ++u) {
+            const int64_t lead = ch[u].lead;
+            len += lead;
+            if (lead < ch[u].len) break;
         }
-        ch[c].pend_acc = ps;   // provisional: "stable"; refined to "accepted" in pass 2
-        if (ps) mine = {ch[c].pend_pos, ch[c].pend_state, 1};
-        else if (ch[c].cnt > 0) mine = {ch[c].last_pos, ch[c].last_state, 1};
+        ps = len > a.tol;
     }
-    LastValid init = {-1, ch[0].init_state, 1};
-    LastValid prev_stable = block_excl_scan_lv(mine, init, s_lv);
+    ch[c].pend_stable = ps;
+    a.sc.has_stable[c] = (ps || ch[c].cnt > 0) ? (int32_t)c : -1;
+}
 
-    // pass 2: acceptance of tentative first records / pending runs, counts, last accepted run
-    int64_t my_cnt = 0;
-    LastValid my_last_acc = {0, 0, 0};
-    {
-        uint32_t prev_state = prev_stable.state;
-        for (int64_t c = c0; c < c1; ++c) {
-            const int cnt = ch[c].cnt;
-            const int ps = ch[c].pend_acc;
-            const int first_acc = (cnt > 0) && (ch[c].first_state != prev_state);
-            const uint32_t before_pend = (cnt > 0) ? ch[c].last_state : prev_state;
-            const int pend_acc = ps && (ch[c].pend_state != before_pend);
-            ch[c].first_acc = first_acc;
-            ch[c].pend_acc = pend_acc;
-            const int64_t out_cnt = (cnt > 0 ? cnt - 1 + first_acc : 0) + pend_acc;
-            ch[c].out_off = my_cnt;               // relative to my range; fixed up below
-            my_cnt += out_cnt;
-            if (pend_acc) my_last_acc = {ch[c].pend_pos, ch[c].pend_state, 1};
-            else if (cnt >= 2 || (cnt == 1 && first_acc)) my_last_acc = {ch[c].last_pos, ch[c].last_state, 1};
-            if (ps) prev_state = ch[c].pend_state;
-            else if (cnt > 0) prev_state = ch[c].last_state;
-        }
-    }
-    int64_t total = 0;
-    const int64_t my_off = block_excl_scan_i64(my_cnt, total, s_i64);
-    LastValid prev_acc = block_excl_scan_lv(my_last_acc, init, s_lv);
-    // the inclusive "last accepted" of the last thread is needed for the final row
-    __shared__ LastValid s_final;
-    if (t == kResolveBlock - 1) s_final = lv_combine(prev_acc, my_last_acc);
-
-    // pass 3: publish per-chunk offsets and predecessors
-    {
-        LastValid pa = prev_acc;
-        for (int64_t c = c0; c < c1; ++c) {
-            ch[c].out_off += my_off;
-            ch[c].prev_pos = pa.pos;
-            ch[c].prev_state = pa.state;
-            const int cnt = ch[c].cnt;
-            if (ch[c].pend_acc) pa = {ch[c].pend_pos, ch[c].pend_state, 1};
-            else if (cnt >= 2 || (cnt == 1 && ch[c].first_acc)) pa = {ch[c].last_pos, ch[c].last_state, 1};
-        }
-    }
+// Single-workgroup exclusive scans over n <= 2^31 ints: out_max[i] = max(in_max[0..i)) (or -1);
+// optionally out_sum[i] = sum(in_sum[0..i)).  Returns (via shared) the inclusive totals.
+template <bool WITH_SUM>
+__device__ void block_scan_max_sum(const int32_t *in_max, int32_t *out_max, const int64_t *in_sum, int64_t *out_sum, int64_t n,
+                                   int32_t &total_max, int64_t &total_sum) {
+    __shared__ int32_t s_m[kResolveBlock / 64];
+    __shared__ int64_t s_s[kResolveBlock / 64];
+    __shared__ int32_t s_cm;
+    __shared__ int64_t s_cs;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    constexpr int kItems = 4;
+    if (t == 0) { s_cm = -1; s_cs = 0; }
     __syncthreads();
-    if (t == 0) {
-        const int64_t P = total;
+    for (int64_t base = 0; base < n; base += (int64_t)kResolveBlock * kItems) {
+        const int64_t i0 = base + (int64_t)t * kItems;
+        int32_t m[kItems]; int64_t v[kItems];
+        int32_t mm = -1; int64_t ss = 0;
+#pragma unroll
+        for (int j = 0; j < kItems; ++j) {
+            m[j] = (i0 + j < n) ? in_max[i0 + j] : -1;
+            v[j] = (WITH_SUM && i0 + j < n) ? in_sum[i0 + j] : 0;
+            mm = max(mm, m[j]); ss += v[j];
+        }
+        // inclusive scan across the workgroup (wave shuffles, then wave totals)
+        int32_t im = mm; int64_t is = ss;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int32_t um = __shfl_up(im, o); const int64_t us = WITH_SUM ? __shfl_up(is, o) : 0;
+            if (lane >= o) { im = max(im, um); is += us; }
+        }
+        if (lane == 63) { s_m[wave] = im; s_s[wave] = is; }
+        __syncthreads();
+        int32_t bm = s_cm; int64_t bs = s_cs;                 // carry from earlier rounds + earlier waves
+        for (int w = 0; w < wave; ++w) { bm = max(bm, s_m[w]); bs += s_s[w]; }
+        // exclusive prefix of this thread
+        int32_t em = __shfl_up(im, 1); int64_t es = WITH_SUM ? __shfl_up(is, 1) : 0;
+        if (lane == 0) { em = -1; es = 0; }
+        em = max(em, bm); es += bs;
+#pragma unroll
+        for (int j = 0; j < kItems; ++j) {
+            if (i0 + j < n) { out_max[i0 + j] = em; if (WITH_SUM) out_sum[i0 + j] = es; }
+            em = max(em, m[j]); es += v[j];
+        }
+        __syncthreads();
+        if (t == kResolveBlock - 1) { s_cm = em; s_cs = es; }   // inclusive total so far (last thread has seen everything)
+        __syncthreads();
+    }
+    total_max = s_cm; total_sum = s_cs;
+}
+
+// S1: prev_stable = exclusive last-valid scan of has_stable.
+__global__ __launch_bounds__(kResolveBlock) void k_scan_stable(const ResolveArgs a) {
+    int32_t tm; int64_t ts;
+    block_scan_max_sum<false>(a.sc.has_stable, a.sc.prev_stable, nullptr, nullptr, a.n_chunks, tm, ts);
+}
+
+__device__ __forceinline__ uint32_t chunk_last_stable_state(const ChunkInfo &ci) { return ci.pend_stable ? ci.pend_state : ci.last_state; }
+
+// R2: one thread per chunk: acceptance of the tentative first record / the pending run, counts.
+__global__ __launch_bounds__(256) void k_chunk_accept(const ResolveArgs a) {
+    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (c >= a.n_chunks) return;
+    ChunkInfo *ch = a.chunks;
+    const int32_t ip = a.sc.prev_stable[c];
+    const uint32_t prev_state = (ip < 0) ? ch[0].init_state : chunk_last_stable_state(ch[ip]);
+    const int cnt = ch[c].cnt;
+    const int ps = ch[c].pend_stable;
+    const int first_acc = (cnt > 0) && (ch[c].first_state != prev_state);
+    const uint32_t before_pend = (cnt > 0) ? ch[c].last_state : prev_state;
+    const int pend_acc = ps && (ch[c].pend_state != before_pend);
+    ch[c].first_acc = first_acc;
+    ch[c].pend_acc = pend_acc;
+    a.sc.out_cnt[c] = (cnt > 0 ? cnt - 1 + first_acc : 0) + pend_acc;
+    a.sc.has_acc[c] = (pend_acc || cnt >= 2 || (cnt == 1 && first_acc)) ? (int32_t)c : -1;
+}
+
+// position / state of the last accepted run of chunk ci (which contributes at least one)
+__device__ __forceinline__ void chunk_last_acc(const ChunkInfo &ci, int64_t &pos, uint32_t &state) {
+    if (ci.pend_acc) { pos = ci.pend_pos; state = ci.pend_state; }
+    else { pos = ci.last_pos; state = ci.last_state; }
+}
+
+// S2: out_off = exclusive sum of out_cnt, prev_acc = exclusive last-valid scan of has_acc; totals and
+// the final row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487).
+__global__ __launch_bounds__(kResolveBlock) void k_scan_accept(const ResolveArgs a) {
+    int32_t last_c; int64_t P;
+    block_scan_max_sum<true>(a.sc.has_acc, a.sc.prev_acc, a.sc.out_cnt, a.sc.out_off, a.n_chunks, last_c, P);
+    if (threadIdx.x == 0) {
         *a.d_n_acc = P;
-        // final row (signal_functions.pyx:485-493); skipped when the table already has n rows (:487)
         int64_t n_rows = P;
         if (P < a.n_total) {
             n_rows = P + 1;
             if (a.write_last_row && a.rows != nullptr && P < a.cap_rows) {
-                const LastValid f = s_final;
-                const int64_t len = (P == 0) ? (a.n_total - a.tol) : (a.n_total - 1 - f.pos - a.tol);
-                a.rows[2 * P] = (int64_t)f.state - 1;
+                int64_t fpos = -1; uint32_t fstate = a.chunks[0].init_state;
+                if (last_c >= 0) chunk_last_acc(a.chunks[last_c], fpos, fstate);
+                const int64_t len = (P == 0) ? (a.n_total - a.tol) : (a.n_total - 1 - fpos - a.tol);
+                a.rows[2 * P] = (int64_t)fstate - 1;
                 a.rows[2 * P + 1] = len;
             }
         }
@@ -155,26 +166,31 @@ __global__ __launch_bounds__(kResolveBlock) void k_resolve_chunks(const ResolveA
 }
 
 // =====================================================================================================
-// K3  k_emit_rows: one workgroup per chunk turns accepted run starts into pulse-table rows
+// k_emit_rows: one wavefront per chunk turns accepted run starts into pulse-table rows
 //   row g = (state of accepted run g-1, start_g - start_{g-1}); row 0 = (init state, start_0 + 1)
 //   ASK: pause rows shorter than samples_per_symbol are relabelled 0 (signal_functions.pyx:471-473).
 // =====================================================================================================
-__global__ __launch_bounds__(256) void k_emit_rows(const EmitArgs a) {
-    const ChunkInfo ci = a.chunks[a.chunk_first + blockIdx.x];
+__global__ __launch_bounds__(64) void k_emit_rows(const EmitArgs a) {
+    const int64_t c = a.chunk_first + blockIdx.x;
+    const ChunkInfo ci = a.chunks[c];
     const uint64_t *slab = a.slab + (int64_t)blockIdx.x * a.slab_stride;
     const int skip = (ci.cnt > 0 && !ci.first_acc) ? 1 : 0;
     const int64_t from_slab = (ci.cnt > 0) ? ci.cnt - skip : 0;
     const int64_t total = from_slab + ci.pend_acc;
+    if (total == 0) return;
+    const int64_t out_off = a.sc.out_off[c];
+    int64_t prev_pos = -1; uint32_t prev_state = a.chunks[0].init_state;   // before the very first accepted run
+    const int32_t ip = a.sc.prev_acc[c];
+    if (ip >= 0) chunk_last_acc(a.chunks[ip], prev_pos, prev_state);
     for (int64_t j = threadIdx.x; j < total; j += blockDim.x) {
-        int64_t pos; uint32_t st;
-        if (j < from_slab) { const uint64_t r = slab[j + skip]; pos = rec_pos(r); st = rec_state(r); }
-        else { pos = ci.pend_pos; st = ci.pend_state; }
+        int64_t pos;
+        if (j < from_slab) pos = rec_pos(slab[j + skip]);
+        else pos = ci.pend_pos;
         int64_t ppos; uint32_t pst;
-        if (j == 0) { ppos = ci.prev_pos; pst = ci.prev_state; }
+        if (j == 0) { ppos = prev_pos; pst = prev_state; }
         else { const uint64_t r = slab[j - 1 + skip]; ppos = rec_pos(r); pst = rec_state(r); }
-        (void)st;
-        const int64_t g = ci.out_off + j;
-        int64_t len = (g == 0) ? pos + 1 : pos - ppos;
+        const int64_t g = out_off + j;
+        const int64_t len = (g == 0) ? pos + 1 : pos - ppos;
         int64_t state = (int64_t)pst - 1;
         if (a.is_ask && state == -1 && len < a.sps) state = 0;
         const int64_t o = g - a.row_base;
@@ -424,12 +440,17 @@ __global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
 
 // ---- host-side launchers ---------------------------------------------------------------------------
 int launch_resolve(const ResolveArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(k_resolve_chunks, dim3(1), dim3(kResolveBlock), 0, s, a);
+    if (a.n_chunks <= 0) return URHGPU_ERR_ARG;
+    const unsigned g = (unsigned)((a.n_chunks + 255) / 256);
+    hipLaunchKernelGGL(k_chunk_stable, dim3(g), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_scan_stable, dim3(1), dim3(kResolveBlock), 0, s, a);
+    hipLaunchKernelGGL(k_chunk_accept, dim3(g), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_scan_accept, dim3(1), dim3(kResolveBlock), 0, s, a);
     return URHGPU_OK;
 }
 
 int launch_emit_rows(const EmitArgs &a, int64_t n_local_chunks, hipStream_t s) {
-    if (n_local_chunks > 0) hipLaunchKernelGGL(k_emit_rows, dim3((unsigned)n_local_chunks), dim3(256), 0, s, a);
+    if (n_local_chunks > 0) hipLaunchKernelGGL(k_emit_rows, dim3((unsigned)n_local_chunks), dim3(64), 0, s, a);
     return URHGPU_OK;
 }
 

@@ -49,13 +49,11 @@ struct ChunkInfo {
     uint16_t last_state;   // state byte of the chunk's last stable run
     uint16_t pend_state;
     uint16_t init_state;   // chunk 0 only: initial cur_state of the reference state machine
-    // ---- written by k_resolve_chunks ----
+    // ---- written by the resolve kernels (pulse_table.hip) ----
     int32_t first_acc;     // record 0 accepted?
     int32_t pend_acc;      // pending run resolved stable AND accepted?
-    int64_t out_off;       // index of this chunk's first accepted run in the global accepted sequence
-    int64_t prev_pos;      // position / state of the accepted run preceding this chunk's first one
-    uint32_t prev_state;   // (state byte; for the very first accepted run: init state, prev_pos = -1)
-    uint32_t pad;
+    int32_t pend_stable;   // pending run grows past `tolerance` in the following chunks?
+    int32_t pad;
 };
 
 }  // namespace urh
