@@ -30,6 +30,23 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (/opt/skills/guides/MI
 ALGO_BYTES_PER_SAMPLE = 12       # 8 B complex64 read + 4 B float32 qad write
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary under profiles/
+    (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, corrected as tools/prof_collect.py documents); the counters
+    cannot be collected inside this process, so this is the figure of the profiled run of the SAME command."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fsk_1gib_pmc.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for name, rec in d.items():
+            if kernel_substr in name and "hbm_traffic_bytes_per_launch" in rec:
+                return int(rec["hbm_traffic_bytes_per_launch"]["total"]), os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline(iq_host, sps, tol):
     """Reference CPU path on a bounded sample: afp_demod + grab_pulse_lens (+ _ppseq_to_bits port)."""
     import numpy as np
@@ -137,6 +154,8 @@ def main():
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         bytes_per_sample = ALGO_BYTES_PER_SAMPLE if want_qad else 8
         achieved = (n * bytes_per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, traffic_src = (pmc_traffic("k_demod_runs<0, 4, 1, true, true, true>") if want_qad and n == 128 * SEG
+                                else (None, None))
         out = {
             "metric": "Msamples/s IQ->bits (1 GiB complex64 2-FSK per GPU, qad materialised)",
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -148,7 +167,8 @@ def main():
                        "outputs": "qad+ppseq+bits+pauses+bit_sample_pos" if want_qad else "ppseq+bits+pauses+bit_sample_pos",
                        "rows": counts[0], "messages": counts[1], "bits": counts[2]},
             "roofline": {"bound": "hbm", "kernel": "k_demod_runs", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes": n * bytes_per_sample,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_sample": bytes_per_sample,
                          "end_to_end_frac": round(n * bytes_per_sample / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
