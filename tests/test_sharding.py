@@ -1,0 +1,133 @@
+"""The sharded IQ->bits protocol (urh_amd/sharding.py): halo / shard-summary / merge / message-flag
+all-gathers around per-rank engines.  On the CPU the engines are the executable model of the HIP kernels
+(tests/model_shard.py); the stitched result must equal the oracle's single-pass result bit for bit.
+  * W ranks as threads (ThreadComm) over many randomised captures and shard boundaries,
+  * the real multi-process path: world_size-2 torch.distributed group on gloo.
+The GPU version of the same check (HIP engines, W simulated ranks on one MI355X) is in test_gpu_parity.py."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+import model_shard
+from urh_amd.pipeline import DemodParams
+from urh_amd.sharding import ShardedPipeline, ThreadComm, TorchDistComm, shard_bounds, stitch
+
+
+def _signal(rng, n, mod, bps, noise_val):
+    levels = rng.choice([-1.0, -0.3, 0.3, 1.0] if bps == 2 else [-0.5, 0.5], size=n // max(1, int(rng.integers(1, 30))) + 1)
+    x = np.repeat(levels, n // len(levels) + 1)[:n].astype(np.float32)
+    x[rng.random(n) < rng.choice([0, 0.02, 0.1, 0.3])] *= -1
+    for _ in range(int(rng.integers(0, 4))):
+        a = int(rng.integers(0, n))
+        x[a:min(n, a + int(rng.integers(1, 120)))] = noise_val
+    if mod == "ASK":
+        x = np.abs(x)
+    return x
+
+
+def run_threads(world, make_engine, shards, bounds, n_total, p):
+    """Run the sharded protocol with `world` ranks as threads; returns the per-rank results."""
+    shared = ThreadComm.Shared(world)
+    out, err = [None] * world, []
+
+    def work(r):
+        try:
+            pipe = ShardedPipeline(make_engine(r), ThreadComm(shared, r))
+            out[r] = pipe.iq_to_bits(shards[r], p, want_qad=True, pos_base=bounds[r][0], n_total=n_total)
+        except BaseException as e:          # noqa: BLE001 -- re-raised in the main thread
+            err.append(e)
+            shared.barrier.abort()
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if err:
+        raise err[0]
+    return out
+
+
+def reference_result(oracle, x, p):
+    pp = oracle.grab_pulse_lens(x, p.center, p.tolerance, p.modulation_type, p.samples_per_symbol, p.bits_per_symbol,
+                                p.center_spacing)
+    return (pp,) + tuple(oracle.ppseq_to_bits_flat(pp, p.samples_per_symbol, p.bits_per_symbol, True, p.pause_threshold))
+
+
+def assert_same(got, want, tag):
+    names = ("ppseq", "bits", "msg_off", "pauses", "pos", "pos_off")
+    for k, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a, b), (tag, names[k], a[:12].tolist(), b[:12].tolist(), len(a), len(b))
+
+
+def test_sharded_model_equals_oracle(oracle):
+    rng = np.random.default_rng(17)
+    for it in range(int(os.environ.get("SHARD_ITERS", "400"))):
+        world = int(rng.choice([2, 3, 4, 8]))
+        n = int(rng.integers(2 * world, 900))
+        mod = ["ASK", "FSK", "PSK"][it % 3]
+        bps = int(rng.integers(1, 3))
+        tol = int(rng.choice([0, 1, 2, 3, 5, 7, 20, 100]))
+        sps = int(rng.choice([3, 8, 20, 100]))
+        pt = int(rng.choice([0, 1, 8]))
+        x = _signal(rng, n, mod, bps, oracle.noise_for_mod_type(mod))
+        center = 0.0 if mod != "ASK" else 0.4
+        # the model engine shards the demodulated signal, so "PSK" here only selects the -4.0 sentinel
+        p = DemodParams(mod if mod != "PSK" else "FSK", bps, 0.0, center, 0.6, tol, sps, 0.1, pt, True)
+        cuts = sorted(rng.choice(np.arange(1, n // 2), size=world - 1, replace=False) * 2) if n // 2 - 1 >= world - 1 else None
+        if cuts is None:
+            continue
+        edges = [0] + [int(c) for c in cuts] + [n]
+        bounds = [(edges[r], edges[r + 1]) for r in range(world)]
+        shards = [x[a:b] for a, b in bounds]
+        res = run_threads(world, lambda r: model_shard.ModelShardEngine(tile=int(rng.choice([16, 32])), span=8,
+                                                                        chunk_tiles=int(rng.choice([1, 2]))),
+                          shards, bounds, n, p)
+        assert_same(stitch(res), reference_result(oracle, x, p), (it, world, n, mod, bps, tol, sps, pt, bounds))
+
+
+def test_shard_bounds():
+    assert shard_bounds(8192, 2) == [(0, 4096), (4096, 8192)]
+    b = shard_bounds(10_000, 4)
+    assert b[0] == (0, 2560) and b[-1][1] == 10_000 and all(e - s >= 2 for s, e in b)
+    with pytest.raises(ValueError):
+        shard_bounds(5, 4)
+
+
+def _gloo_worker(rank, world, port, n, seed, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(seed)
+        x = _signal(rng, n, "FSK", 1, np.float32(-4.0))
+        x[n // 2 - 40:n // 2 + 25] = -4.0                      # a pause straddling the shard boundary
+        p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 20, 0.1, 8, True)
+        a, b = (0, n // 2) if rank == 0 else (n // 2, n)
+        pipe = ShardedPipeline(model_shard.ModelShardEngine(tile=32, span=8, chunk_tiles=2), TorchDistComm())
+        res = pipe.iq_to_bits(x[a:b], p, want_qad=True, pos_base=a, n_total=n)
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_protocol_over_gloo(oracle):
+    """world_size 2, one process per rank, torch.distributed gloo: the N>1 path of bench.py on CPU."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    n, seed, port = 3000, 5, 29500 + os.getpid() % 2000
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n, seed, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    rng = np.random.default_rng(seed)
+    x = _signal(rng, n, "FSK", 1, np.float32(-4.0))
+    x[n // 2 - 40:n // 2 + 25] = -4.0
+    p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 20, 0.1, 8, True)
+    assert_same(stitch([got[0], got[1]]), reference_result(oracle, x, p), "gloo")

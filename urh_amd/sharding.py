@@ -1,0 +1,137 @@
+"""Sample-contiguous sharding of one long capture over the GPUs of a node.
+
+Rank r holds samples [r*n_local, (r+1)*n_local) of the capture (the last rank may hold more or
+fewer).  The hot kernel runs on every shard independently; what crosses a shard boundary is tiny and
+is exchanged with three (ASK: four) small all-gathers -- no data-path collective ever moves samples:
+
+    1. halo        the last two IQ samples of every shard (16 B)      -> seam of the FSK conj-product and
+                                                                        the state of the sample before the shard
+    2. summary     one ChunkInfo (64 B) per shard: the shard's run structure reduced to what its
+                   neighbours need (leading run length, first / last stable run, still-short trailing run,
+                   number of accepted runs)                           -> pulse-table rows with global lengths
+    3. (ASK only)  first / last row of every shard's merged table     -> equal-state rows merged across shards
+    4. bits        three flags per shard (long pause present, data before the first / after the last one)
+                                                                      -> which boundary-spanning groups are messages
+
+The result stays sharded: rank r owns the pulse-table rows that END in its shard and the bits /
+bit_sample_pos those rows expand to; concatenating the ranks' pieces in rank order gives exactly the
+single-GPU (and reference) result (`stitch`).  Costas/PSK carries loop state across the whole capture and
+does not shard ("replicas only").
+
+The orchestration below is engine-agnostic: `engine` is the GPU engine (urh_amd.shard_engine.GpuShardEngine,
+HIP kernels behind the C ABI) in production; the CPU test-suite drives the same orchestration with the executable
+model of the kernels (tests/model_shard.py) over a world_size-2 gloo group.
+"""
+import numpy as np
+
+
+class TorchDistComm:
+    """all_gather over torch.distributed (backend "nccl" == RCCL over xGMI on the GPU box, "gloo" on CPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_gather(self, t):
+        """t: torch tensor (same shape/dtype on every rank) -> tensor [world, *t.shape] on t's device."""
+        import torch
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
+        return out
+
+
+class ThreadComm:
+    """W ranks as W threads of one process (lock-step through a barrier): lets a 1-GPU box (and plain CPU
+    tests) execute the sharded path for any world size."""
+
+    class Shared:
+        def __init__(self, world):
+            import threading
+            self.world = world
+            self.slots = [None] * world
+            self.barrier = threading.Barrier(world)
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.world = shared, rank, shared.world
+
+    def all_gather(self, t):
+        import torch
+        sh = self.shared
+        if t.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        sh.slots[self.rank] = t
+        sh.barrier.wait()
+        out = torch.stack([s.to(t.device) for s in sh.slots])
+        if out.is_cuda:
+            torch.cuda.current_stream(t.device).synchronize()
+        sh.barrier.wait()
+        return out
+
+
+def shard_bounds(n_total: int, world: int):
+    """[begin, end) of every rank's shard: equal shards of ceil(n/world) samples rounded up to a multiple of
+    64 (so that every shard starts 16-byte aligned for every IQ dtype), the last rank takes what is left.
+    Every shard needs >= 2 samples."""
+    per = -(-n_total // world)
+    per = -(-per // 64) * 64
+    b = [min(r * per, n_total) for r in range(world + 1)]
+    b[world] = n_total
+    if any(b[r + 1] - b[r] < 2 for r in range(world)):
+        raise ValueError(f"capture of {n_total} samples is too short to shard over {world} ranks")
+    return [(b[r], b[r + 1]) for r in range(world)]
+
+
+class ShardedPipeline:
+    """One rank's view of the sharded IQ->bits pass."""
+
+    def __init__(self, engine, comm):
+        self.engine, self.comm = engine, comm
+        self.rank, self.world = comm.rank, comm.world
+
+    # bench.py / DevicePipeline compatible surface ------------------------------------------------
+    @property
+    def ctx(self):
+        return self.engine.ctx
+
+    def reserve(self, n_local, p):
+        self.engine.reserve(n_local, p)
+
+    def iq_to_bits(self, iq_local, p, want_qad=True, pos_base=None, n_total=None):
+        """iq_local: this rank's shard.  pos_base / n_total default to equal shards of len(iq_local)."""
+        e, c = self.engine, self.comm
+        n_local = int(iq_local.shape[0])
+        if pos_base is None:
+            pos_base = self.rank * n_local
+        if n_total is None:
+            n_total = self.world * n_local
+        if p.modulation_type == "PSK":
+            raise ValueError("the Costas loop carries state across the whole capture: PSK does not shard")
+        halos = c.all_gather(e.tail(iq_local, p))
+        left = halos[self.rank - 1] if self.rank > 0 else None
+        summary = e.runs(iq_local, left, pos_base, n_total, self.rank, self.world, p, want_qad)
+        merge = e.rows(c.all_gather(summary))
+        merged_all = c.all_gather(merge) if merge is not None else None
+        flags = e.bits_prepare(merged_all)
+        return e.bits_finish(c.all_gather(flags))
+
+
+def stitch(pieces):
+    """Concatenate the per-rank pieces (rank order) of a sharded result into the single-GPU / reference
+    shaped flat result.  pieces[r] = dict(rows, bits, msg_end, pauses, pos, pos_end) of numpy arrays, where
+    msg_end / pos_end are LOCAL end offsets (in that rank's bits / pos) of the messages that close on rank r.
+    Returns (ppseq, bits, msg_off, pauses, pos, pos_off)."""
+    rows = np.concatenate([np.asarray(p["rows"], dtype=np.int64).reshape(-1, 2) for p in pieces])
+    bits = np.concatenate([np.asarray(p["bits"], dtype=np.uint8) for p in pieces])
+    pos = np.concatenate([np.asarray(p["pos"], dtype=np.int64) for p in pieces])
+    pauses = np.concatenate([np.asarray(p["pauses"], dtype=np.int64) for p in pieces])
+    msg_off, pos_off = [0], [0]
+    b0 = p0 = 0
+    for p in pieces:
+        msg_off.extend((b0 + np.asarray(p["msg_end"], dtype=np.int64)).tolist())
+        pos_off.extend((p0 + np.asarray(p["pos_end"], dtype=np.int64)).tolist())
+        b0 += len(p["bits"])
+        p0 += len(p["pos"])
+    return rows, bits, np.array(msg_off, np.int64), pauses, pos, np.array(pos_off, np.int64)
