@@ -112,8 +112,9 @@ def main():
     iq, tx_bits = fsk_capture(args.segments, dev, seed=1234, sps=sps, first_segment=rank * args.segments)
     n = iq.shape[0]
     if world > 1:
-        from urh_amd.sharding import ShardedPipeline
-        pipe = ShardedPipeline(dev, rank, world)
+        from urh_amd.shard_engine import GpuShardEngine
+        from urh_amd.sharding import ShardedPipeline, TorchDistComm
+        pipe = ShardedPipeline(GpuShardEngine(local_rank), TorchDistComm())
     else:
         pipe = DevicePipeline(local_rank)
     pipe.reserve(n, p)

@@ -177,10 +177,38 @@ int urhgpu_ppseq_to_bits_dev(urhgpu_ctx *ctx, const int64_t *d_rows, const int64
 /* THE fused hot path: IQ (device) -> [qad] -> pulse table -> bits, everything device resident.
  * ASK/FSK run demodulation and run segmentation in ONE pass over the IQ stream (8 B read +
  * 4 B qad write per sample); PSK runs the Costas kernel and then the qad-input segmentation.
- * left_halo: NULL for a capture that starts at global sample 0; otherwise DEVICE pointer to the 2 IQ
- * samples preceding d_iq[0] (sharded captures, see urh_amd/sharding.py). */
+ * msg_off[m] .. msg_off[m + 1] delimit message m in bits[] (msg_off[0] = 0); pos_off likewise.
+ * Sharded captures use the urhgpu_shard_* phases below instead. */
 int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p,
                           const urhgpu_outputs *out);
+
+/* ---- sharded captures: one long capture split sample-contiguously over the GPUs of a node ------------------
+ * (there is no reference counterpart: the reference processes a capture in one process.)
+ * Each rank calls the four phases below in order on its own context; between the phases the CALLER
+ * all-gathers a few bytes per rank (urh_amd/sharding.py does it with torch.distributed = RCCL over xGMI):
+ *
+ *   halo    : the last 2 IQ samples of every shard                          -> d_left_halo of the next rank
+ *   runs    : hot kernel on the shard + its 64-byte summary (d_summary out) -> all-gather -> d_summaries
+ *   rows    : this rank's pulse-table rows; ASK: d_merge (5 x int64) out    -> all-gather -> d_merge_all
+ *   prepare : cross-shard ASK merge, per-row scan; d_flags (3 x int64) out  -> all-gather -> d_flags_all
+ *   finish  : bits / pauses / bit_sample_pos of this rank's rows
+ *
+ * The result stays sharded: `out` (given to urhgpu_shard_runs_dev, filled by the later phases) holds the rows
+ * that END in this shard and what they expand to; concatenating the ranks' pieces in rank order gives exactly
+ * the single-GPU result.  Differences to urhgpu_iq_to_bits_dev's outputs:
+ *   - rows[0] may carry state URHGPU_ROW_ABSORBED (ASK: the row merged into the previous rank's last row;
+ *     skip it when concatenating);
+ *   - msg_off[m + 1] / pos_off[m + 1] are the LOCAL end offsets of the m-th message that closes on this rank;
+ *     bits / pos may continue past the last one (the message closes on a later rank);
+ *   - counts = {local rows, messages closed here, local bits, local positions}.
+ * PSK (Costas loop) does not shard: URHGPU_ERR_UNSUPPORTED. */
+#define URHGPU_ROW_ABSORBED (-(INT64_C(1) << 62))
+int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
+                          int rank, int world, const void *d_left_halo, const urhgpu_params *p,
+                          const urhgpu_outputs *out, void *d_summary);
+int urhgpu_shard_rows_dev(urhgpu_ctx *ctx, const void *d_summaries, int64_t *d_merge);
+int urhgpu_shard_bits_prepare_dev(urhgpu_ctx *ctx, const int64_t *d_merge_all, int64_t *d_flags);
+int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all);
 
 /* Magnitude chunk statistics for AutoInterpretation.detect_noise_level
  * (src/urh/ainterpretation/AutoInterpretation.py:60-91): chunks of `chunk` samples taken from the END

@@ -174,3 +174,43 @@ def test_fused_equals_oracle_medium(pipe, oracle, mod):
         assert bits_equal(res.qad.cpu().numpy(), qad)
         assert np.array_equal(res.ppseq(), pp)
         assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
+
+
+@pytest.mark.parametrize("mod", ["FSK", "ASK"])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_equals_single_gpu(pipe, oracle, mod, world):
+    """W simulated ranks (threads, one context each) on this GPU: the stitched sharded result equals the
+    single-GPU result and the oracle, bit for bit (qad included), for boundaries that cut runs, pauses and
+    messages at arbitrary places."""
+    import torch
+    from test_sharding import run_threads
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.shard_engine import GpuShardEngine
+    from urh_amd.sharding import shard_bounds, stitch
+    rng = np.random.default_rng(world * 7 + len(mod))
+    for n, sps, dtype in ((300_007, 100, np.float32), (1 << 20, 100, np.float32), (99_999, 20, np.int8)):
+        iq = synth_fsk(n, sps=sps, seed=n % 97, noise=0.05, pause_every=n // 5, pause_len=n // 23, dtype=dtype)
+        scale = 1.0 if dtype == np.float32 else 127.0
+        if mod == "ASK":
+            env = np.repeat(rng.integers(0, 2, n // sps + 1), sps)[:n]
+            iq = (iq.astype(np.float32) * (0.05 + 0.95 * env)[:, None]).astype(dtype)
+        noise, tol = 0.2 * scale, 3
+        center = 0.0 if mod == "FSK" else 0.35
+        p = DemodParams(mod, 1, noise, center, 1.0, tol, sps, 0.1, 8, True)
+        dev_iq = torch.from_numpy(iq).cuda()
+        single = pipe.iq_to_bits(dev_iq, p, want_qad=True)
+        want = (single.ppseq(),) + tuple(single.flat())
+        want_qad = single.qad.cpu().numpy().copy()
+        if n <= 300_007:
+            qad = oracle.afp_demod(iq, noise, mod, 2)
+            pp = oracle.grab_pulse_lens(qad, center, tol, mod, sps, 1, 1.0)
+            assert np.array_equal(want[0], pp) and bits_equal(want_qad, qad)
+        cuts = [0] + sorted(int(c) * 8 for c in rng.choice(np.arange(1, n // 8), size=world - 1, replace=False)) + [n]
+        for bounds in (shard_bounds(n, world), [(cuts[r], cuts[r + 1]) for r in range(world)]):
+            shards = [dev_iq[a:b] for a, b in bounds]
+            res = run_threads(world, lambda r: GpuShardEngine(0), shards, bounds, n, p)
+            got = stitch(res)
+            for k, (a, b) in enumerate(zip(got, want)):
+                assert np.array_equal(a, b), (mod, world, n, bounds, k, len(a), len(b))
+            got_qad = np.concatenate([r.qad.cpu().numpy() for r in res])
+            assert bits_equal(got_qad, want_qad)

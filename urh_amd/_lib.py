@@ -16,6 +16,7 @@ ERR_HIP, ERR_DTYPE, ERR_ARG, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NO_DEVICE = -1, 
 
 DT_I8, DT_U8, DT_I16, DT_U16, DT_F32 = 0, 1, 2, 3, 4
 MOD_ASK, MOD_FSK, MOD_PSK, MOD_OTHER = 0, 1, 2, 3
+ROW_ABSORBED = -(1 << 62)
 
 
 class UrhGpuError(RuntimeError):
@@ -74,6 +75,10 @@ PROTOTYPES = {
     "urhgpu_grab_pulse_lens_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp, _i64, _vp]),
     "urhgpu_ppseq_to_bits_dev": (_i, [_vp, _vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
     "urhgpu_iq_to_bits_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
+    "urhgpu_shard_runs_dev": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, _vp, C.POINTER(Params), C.POINTER(Outputs), _vp]),
+    "urhgpu_shard_rows_dev": (_i, [_vp, _vp, _vp]),
+    "urhgpu_shard_bits_prepare_dev": (_i, [_vp, _vp, _vp]),
+    "urhgpu_shard_bits_finish_dev": (_i, [_vp, _vp]),
     "urhgpu_magnitude_chunk_stats_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp]),
     "urhgpu_test_atan2f_dev": (_i, [_vp, _vp, _vp, _i64, _vp]),
 }

@@ -55,11 +55,13 @@ Plan make_plan(const urhgpu_ctx *ctx, int64_t n, int tol) {
 
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+constexpr int kMaxWorld = 1024;   // ranks of a sharded capture (table entries reserved for their summaries)
+
 size_t digitize_scratch_bytes(const Plan &pl, int64_t cap_rows, bool ask, bool bits) {
     size_t b = 0;
-    b += align256((size_t)pl.n_chunks * sizeof(ChunkInfo));
+    b += align256((size_t)(pl.n_chunks + kMaxWorld) * sizeof(ChunkInfo));
     b += align256((size_t)pl.n_chunks * pl.slab_stride * 8);
-    b += align256(resolve_scratch_bytes(pl.n_chunks));
+    b += align256(resolve_scratch_bytes(pl.n_chunks + kMaxWorld)) + 2 * 256;
     if (ask) b += align256((size_t)cap_rows * 16) + align256(merge_scratch_bytes(cap_rows));
     if (bits) b += align256(bits_scratch_bytes(cap_rows));
     b += 4096;
@@ -140,18 +142,21 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
         if (!rows_stage || !merge_scratch || !d_n_stage) return URHGPU_ERR_ARG;
     }
     void *rs_mem = ctx->arena.take(resolve_scratch_bytes(pl.n_chunks));
-    if (!rs_mem) return URHGPU_ERR_ARG;
+    ResolveAux *aux = (ResolveAux *)ctx->arena.take(sizeof(ResolveAux));
+    if (!rs_mem || !aux) return URHGPU_ERR_ARG;
     const ResolveScratch rsc = resolve_scratch_carve(rs_mem, pl.n_chunks);
     ResolveArgs r;
+    memset(&r, 0, sizeof(r));
     r.sc = rsc;
     r.chunks = chunks; r.n_chunks = pl.n_chunks; r.n_total = n; r.tol = p->tolerance;
     r.rows = rows_stage; r.cap_rows = cap_rows; r.d_n_acc = d_n_acc; r.d_n_rows = d_n_stage;
     r.d_n_rows_needed = d_n_rows_needed; r.write_last_row = 1;
+    r.local_pass = 0; r.aux = aux; r.summary_out = nullptr; r.chunk_first = 0; r.n_local = pl.n_chunks; r.d_ts_carry = nullptr;
     URH_TRY(launch_resolve(r, s));
     EmitArgs e;
     e.sc = rsc;
     e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
-    e.rows = rows_stage; e.cap_rows = cap_rows; e.row_base = 0; e.is_ask = ask ? 1 : 0; e.sps = p->samples_per_symbol;
+    e.rows = rows_stage; e.cap_rows = cap_rows; e.d_ts_carry = nullptr; e.is_ask = ask ? 1 : 0; e.sps = p->samples_per_symbol;
     URH_TRY(launch_emit_rows(e, pl.n_chunks, s));
     if (ask) URH_TRY(launch_merge_rows_ask(rows_stage, d_n_stage, cap_rows, d_rows, cap_rows, d_n_rows, merge_scratch, s));
     URH_HIP(hipGetLastError());
@@ -165,7 +170,32 @@ BitsParams bits_params(const urhgpu_params *p) {
     bp.pause_threshold = p->pause_threshold;
     bp.samples_per_bit = (int64_t)((double)p->samples_per_symbol / (double)p->bits_per_symbol);   // int(sps / bps) :344
     bp.write_pos = p->write_bit_sample_pos ? 1 : 0;
+    bp.d_row_base = nullptr; bp.d_ts_carry = nullptr; bp.d_absorbed = nullptr; bp.d_extra = nullptr; bp.is_last_rank = 1;
     return bp;
+}
+
+// State of one sharded pass (urhgpu_shard_*): lives in the context between the phases; every pointer is
+// carved from ctx->arena, which is not reset until the next pass begins.
+struct ShardSession {
+    int phase = 0;                 // 1: runs done, 2: rows done, 3: bits prepared
+    int rank = 0, world = 1;
+    int64_t n_local = 0, pos_base = 0, n_total = 0;
+    urhgpu_params p;
+    urhgpu_outputs out;
+    Plan pl;
+    ChunkInfo *table = nullptr;    // [world - 1 summaries interleaved | local chunks], see shard_rows
+    uint64_t *slab = nullptr;
+    ResolveAux *aux = nullptr;
+    void *rs_mem = nullptr;
+    int64_t *rows_stage = nullptr; void *merge_scratch = nullptr; int64_t *d_n_stage = nullptr;
+    void *bits_scratch = nullptr;
+    int64_t *d_small = nullptr;    // [0] ts_carry, [1] absorbed, [2] extra (2 x int32), [3] n_rows (final)
+    const int64_t *d_row_base = nullptr;
+};
+
+ShardSession *session(urhgpu_ctx *ctx) {
+    if (!ctx->shard) ctx->shard = new (std::nothrow) ShardSession();
+    return (ShardSession *)ctx->shard;
 }
 
 }  // namespace
@@ -220,6 +250,7 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->arena.release();
     ctx->staging.release();
+    delete (ShardSession *)ctx->shard;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
@@ -384,6 +415,157 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
     void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
     if (!scratch) return URHGPU_ERR_ARG;
     return ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch);
+}
+
+
+// ---- sharded captures (one rank's phases; the all-gathers in between belong to the caller) --------------
+int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
+                          int rank, int world, const void *d_left_halo, const urhgpu_params *p,
+                          const urhgpu_outputs *out, void *d_summary) {
+    if (!ctx || !p || !out || !d_iq || !d_summary || !out->rows || !out->counts) return URHGPU_ERR_ARG;
+    if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world || n_local < 2 || pos_base < 0 || pos_base + n_local > n_total)
+        return URHGPU_ERR_ARG;
+    if ((rank == 0) != (d_left_halo == nullptr) || (rank == 0 && pos_base != 0)) return URHGPU_ERR_ARG;
+    if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
+    if (p->mod == URHGPU_MOD_PSK) return URHGPU_ERR_UNSUPPORTED;      // the Costas loop does not shard
+    if (((uintptr_t)d_iq & 15) || (out->qad && ((uintptr_t)out->qad & 7))) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    ShardSession *ss = session(ctx);
+    if (!ss) return URHGPU_ERR_ARG;
+    hipStream_t s = ctx->stream;
+    ss->phase = 0; ss->rank = rank; ss->world = world; ss->n_local = n_local; ss->pos_base = pos_base; ss->n_total = n_total;
+    ss->p = *p; ss->out = *out;
+    const Plan pl = make_plan(ctx, n_local, p->tolerance);
+    ss->pl = pl;
+    const bool ask = (p->mod == URHGPU_MOD_ASK);
+    URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, out->cap_rows, ask, true)));
+    ctx->arena.reset();
+    const int64_t n_table = pl.n_chunks + world - 1;
+    ss->table = (ChunkInfo *)ctx->arena.take((size_t)n_table * sizeof(ChunkInfo));
+    ss->slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
+    ss->rs_mem = ctx->arena.take(resolve_scratch_bytes(n_table));
+    ss->aux = (ResolveAux *)ctx->arena.take(sizeof(ResolveAux));
+    ss->d_small = (int64_t *)ctx->arena.take(8 * 8);
+    ss->bits_scratch = ctx->arena.take(bits_scratch_bytes(std::max<int64_t>(out->cap_rows, 1)));
+    ss->rows_stage = out->rows; ss->merge_scratch = nullptr; ss->d_n_stage = ss->d_small + 3;
+    if (ask) {
+        ss->rows_stage = (int64_t *)ctx->arena.take((size_t)out->cap_rows * 16);
+        ss->merge_scratch = ctx->arena.take(merge_scratch_bytes(out->cap_rows));
+        ss->d_n_stage = (int64_t *)ctx->arena.take(64);
+    }
+    if (!ss->table || !ss->slab || !ss->rs_mem || !ss->aux || !ss->d_small || !ss->bits_scratch || !ss->rows_stage ||
+        !ss->d_n_stage || (ask && !ss->merge_scratch))
+        return URHGPU_ERR_ARG;
+    ChunkInfo *local = ss->table + rank;       // this rank's chunks sit at table[rank .. rank + n_chunks)
+    RunArgs a;
+    memset(&a, 0, sizeof(a));
+    URH_TRY(fill_thresholds(a, p));
+    a.in = d_iq; a.qad = out->qad; a.left_halo = d_left_halo; a.n = n_local; a.pos_base = pos_base;
+    a.chunk_len = pl.chunk_len; a.slab_stride = pl.slab_stride;
+    a.noise_sqrd = p->noise_threshold * p->noise_threshold;
+    a.noise_val = noise_for(p);
+    a.tol = p->tolerance;
+    URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
+    a.chunks = local; a.slab = ss->slab;
+    const bool prof = ctx->prof_on && (size_t)(2 * ctx->prof_used + 1) < ctx->prof_events.size();
+    if (prof) URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used], s));
+    URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s));
+    if (prof) { URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], s)); ctx->prof_used += 1; }
+    // local resolve pass: the shard on its own -> its summary
+    ResolveArgs r;
+    memset(&r, 0, sizeof(r));
+    r.sc = resolve_scratch_carve(ss->rs_mem, n_table);
+    r.chunks = local; r.n_chunks = pl.n_chunks; r.n_total = n_local; r.tol = p->tolerance;
+    r.rows = nullptr; r.cap_rows = 0; r.d_n_acc = ctx->d_counts + 9; r.d_n_rows = ctx->d_counts + 10;
+    r.d_n_rows_needed = ctx->d_counts + 8; r.write_last_row = 0;
+    r.local_pass = 1; r.aux = ss->aux; r.summary_out = (ChunkInfo *)d_summary; r.chunk_first = 0; r.n_local = pl.n_chunks;
+    URH_TRY(launch_resolve(r, s));
+    URH_HIP(hipGetLastError());
+    ss->phase = 1;
+    return URHGPU_OK;
+}
+
+int urhgpu_shard_rows_dev(urhgpu_ctx *ctx, const void *d_summaries, int64_t *d_merge) {
+    if (!ctx || !d_summaries) return URHGPU_ERR_ARG;
+    ShardSession *ss = (ShardSession *)ctx->shard;
+    if (!ss || ss->phase != 1) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const int rank = ss->rank, world = ss->world;
+    const Plan &pl = ss->pl;
+    const bool ask = (ss->p.mod == URHGPU_MOD_ASK);
+    if (ask && !d_merge) return URHGPU_ERR_ARG;
+    const int64_t n_table = pl.n_chunks + world - 1;
+    const ChunkInfo *S = (const ChunkInfo *)d_summaries;
+    // table = [S_0 .. S_{rank-1} | local chunks | S_{rank+1} .. S_{world-1}]
+    if (rank > 0) URH_HIP(hipMemcpyAsync(ss->table, S, (size_t)rank * sizeof(ChunkInfo), hipMemcpyDeviceToDevice, s));
+    if (rank + 1 < world)
+        URH_HIP(hipMemcpyAsync(ss->table + rank + pl.n_chunks, S + rank + 1, (size_t)(world - 1 - rank) * sizeof(ChunkInfo),
+                               hipMemcpyDeviceToDevice, s));
+    ResolveArgs r;
+    memset(&r, 0, sizeof(r));
+    r.sc = resolve_scratch_carve(ss->rs_mem, n_table);
+    r.chunks = ss->table; r.n_chunks = n_table; r.n_total = ss->n_total; r.tol = ss->p.tolerance;
+    r.rows = ss->rows_stage; r.cap_rows = ss->out.cap_rows; r.d_n_acc = ctx->d_counts + 9; r.d_n_rows = ss->d_n_stage;
+    r.d_n_rows_needed = ctx->d_counts + 8; r.write_last_row = (rank == world - 1) ? 1 : 0;
+    r.local_pass = 0; r.aux = ss->aux; r.summary_out = nullptr; r.chunk_first = rank; r.n_local = pl.n_chunks;
+    r.d_ts_carry = ss->d_small;
+    URH_HIP(hipMemsetAsync(ss->d_small, 0, 8 * 8, s));
+    URH_TRY(launch_resolve(r, s));
+    EmitArgs e;
+    e.sc = r.sc;
+    e.chunks = ss->table; e.chunk_first = rank; e.slab = ss->slab; e.slab_stride = pl.slab_stride;
+    e.rows = ss->rows_stage; e.cap_rows = ss->out.cap_rows; e.d_ts_carry = ss->d_small; e.is_ask = ask ? 1 : 0;
+    e.sps = ss->p.samples_per_symbol;
+    URH_TRY(launch_emit_rows(e, pl.n_chunks, s));
+    ss->d_row_base = r.sc.out_off + rank;
+    if (ask) {
+        URH_TRY(launch_merge_rows_ask(ss->rows_stage, ss->d_n_stage, ss->out.cap_rows, ss->out.rows, ss->out.cap_rows,
+                                      ss->d_small + 3, ss->merge_scratch, s));
+        launch_merge_summary(ss->out.rows, ss->d_small + 3, d_merge, s);
+    }
+    URH_HIP(hipGetLastError());
+    ss->phase = 2;
+    return URHGPU_OK;
+}
+
+int urhgpu_shard_bits_prepare_dev(urhgpu_ctx *ctx, const int64_t *d_merge_all, int64_t *d_flags) {
+    if (!ctx || !d_flags) return URHGPU_ERR_ARG;
+    ShardSession *ss = (ShardSession *)ctx->shard;
+    if (!ss || ss->phase != 2) return URHGPU_ERR_ARG;
+    const bool ask = (ss->p.mod == URHGPU_MOD_ASK);
+    if (ask && !d_merge_all) return URHGPU_ERR_ARG;
+    if (!ss->out.bits || !ss->out.msg_off || !ss->out.pauses || !ss->out.pos_off) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    int64_t *d_n_rows = ss->d_small + 3;
+    if (ask) launch_merge_fix(ss->out.rows, d_n_rows, d_merge_all, ss->rank, ss->world, ss->d_small + 1, s);
+    BitsParams bp = bits_params(&ss->p);
+    bp.d_row_base = ss->d_row_base; bp.d_ts_carry = ss->d_small; bp.d_absorbed = ask ? ss->d_small + 1 : nullptr;
+    bp.d_extra = (const int32_t *)(ss->d_small + 2); bp.is_last_rank = (ss->rank == ss->world - 1) ? 1 : 0;
+    URH_TRY(launch_bits_prepare(ss->out.rows, d_n_rows, std::max<int64_t>(ss->out.cap_rows, 1), bp, ss->bits_scratch, d_flags, s));
+    URH_HIP(hipGetLastError());
+    ss->phase = 3;
+    return URHGPU_OK;
+}
+
+int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
+    if (!ctx || !d_flags_all) return URHGPU_ERR_ARG;
+    ShardSession *ss = (ShardSession *)ctx->shard;
+    if (!ss || ss->phase != 3) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const bool ask = (ss->p.mod == URHGPU_MOD_ASK);
+    launch_bits_extra(d_flags_all, ss->rank, ss->world, (int32_t *)(ss->d_small + 2), s);
+    BitsParams bp = bits_params(&ss->p);
+    bp.d_row_base = ss->d_row_base; bp.d_ts_carry = ss->d_small; bp.d_absorbed = ask ? ss->d_small + 1 : nullptr;
+    bp.d_extra = (const int32_t *)(ss->d_small + 2); bp.is_last_rank = (ss->rank == ss->world - 1) ? 1 : 0;
+    const urhgpu_outputs &o = ss->out;
+    BitsOut bo{o.bits, o.cap_bits, o.msg_off, o.pauses, o.cap_msg, o.pos, o.cap_pos, o.pos_off, o.counts};
+    URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, s));
+    URH_HIP(hipGetLastError());
+    ss->phase = 0;
+    return URHGPU_OK;
 }
 
 int urhgpu_test_atan2f_dev(urhgpu_ctx *ctx, const float *d_y, const float *d_x, int64_t n, float *d_out) {

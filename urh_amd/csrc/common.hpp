@@ -62,4 +62,5 @@ struct urhgpu_ctx {
     std::vector<hipEvent_t> prof_events;   // pairs: [2k] before, [2k+1] after
     int prof_used = 0;                     // pairs recorded since urhgpu_ctx_profile_begin
     bool prof_on = false;
+    void *shard = nullptr;                 // state of a sharded pass between its phases (capi.hip: ShardSession)
 };

@@ -47,11 +47,31 @@ struct ResolveScratch {
 size_t resolve_scratch_bytes(int64_t n_chunks);
 ResolveScratch resolve_scratch_carve(void *mem, int64_t n_chunks);
 
+// Small device block shared by the resolve kernels of one pass.
+struct ResolveAux {
+    int32_t first_nonlead;   // first chunk that contains a run boundary (atomicMin; >= n_chunks: none)
+    int32_t open_chunk;      // local pass: chunk whose trailing short run reaches the shard end undecided
+    int32_t first_stable;    // first chunk with a stable run (atomicMin)
+    int32_t last_stable;     // last chunk with a stable run, -1: none
+};
+constexpr int32_t kAuxNone = 0x7F7F7F7F;   // hipMemsetAsync(aux, 0x7F, ...)
+
 struct ResolveArgs {
     ChunkInfo *chunks;
-    int64_t n_chunks;        // chunks in the table (all shards)
-    int64_t n_total;         // samples in the whole capture
+    int64_t n_chunks;        // entries in the table: the local chunks, for a sharded capture preceded /
+                             // followed by one summary entry per other shard
+    int64_t n_total;         // samples in the whole capture (local pass: in the shard)
     int tol;
+    // local_pass: the table is ONE shard of a sharded capture on its own.  The state before it is unknown
+    // (its first stable run counts as accepted, tentatively), a trailing short run that reaches the shard end
+    // stays open, no last row is written, and *summary_out receives the ChunkInfo that stands for the whole
+    // shard in the other ranks' tables.
+    int local_pass;
+    ResolveAux *aux;         // zero-cost when not sharded: still needed by the kernels (4 ints)
+    ChunkInfo *summary_out;
+    int64_t chunk_first;     // table index of this GPU's first chunk
+    int64_t n_local;         // this GPU's chunks
+    int64_t *d_ts_carry;     // out: sum of the row lengths before this GPU's first row (sharded captures)
     int64_t *rows;           // pulse table (may be nullptr when only counting)
     int64_t cap_rows;
     int64_t *d_n_acc;        // out: number of accepted runs P
@@ -65,9 +85,9 @@ struct EmitArgs {
     int64_t chunk_first;      // index (in the table) of this GPU's first chunk
     const uint64_t *slab;
     int64_t slab_stride;
-    int64_t *rows;
+    int64_t *rows;            // this GPU's rows: global row g goes to rows[g - out_off[chunk_first]]
     int64_t cap_rows;
-    int64_t row_base;         // global row index that maps to rows[0] (0 on a single GPU)
+    int64_t *d_ts_carry;
     int is_ask;
     int64_t sps;
     ResolveScratch sc;
@@ -78,7 +98,14 @@ struct BitsParams {
     int64_t pause_threshold;
     int64_t samples_per_bit;
     int write_pos;
+    // sharded captures (all nullptr / 1 on a single GPU):
+    const int64_t *d_row_base;    // global index of this GPU's first row
+    const int64_t *d_ts_carry;    // sum of the row lengths before it
+    const int64_t *d_absorbed;    // full length of the pause this GPU's only (absorbed) row belongs to, or -1
+    const int32_t *d_extra;       // [0]: the group my first rows continue has data on earlier ranks, [1]: later ranks
+    int is_last_rank;             // the capture ends on this GPU: the trailing group closes here
 };
+constexpr int64_t kRowAbsorbed = -(int64_t(1) << 62);   // == URHGPU_ROW_ABSORBED
 struct BitsOut {
     uint8_t *bits; int64_t cap_bits;
     int64_t *msg_off; int64_t *pauses; int64_t cap_msg;
@@ -93,6 +120,20 @@ int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t
 size_t bits_scratch_bytes(int64_t cap_rows);
 int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
                          const BitsOut &o, void *scratch, hipStream_t s);
+// The same in two halves (sharded captures: the boundary flags are exchanged in between).
+//   prepare: per-row scan; d_flags (3 x int64) = {long pause present, data before the first one, data after the last one}
+//   finish : groups -> messages, expansion (bp.d_extra resolved from every rank's flags)
+int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                        void *scratch, int64_t *d_flags, hipStream_t s);
+int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                       const BitsOut &o, void *scratch, hipStream_t s);
+// ASK, sharded: summary of the locally merged table {n_rows, first state, first length, last state, last length}
+void launch_merge_summary(const int64_t *rows, const int64_t *d_n_rows, int64_t *d_out5, hipStream_t s);
+// ASK, sharded: merge equal-state rows across shard boundaries (d_all: world x 5 int64)
+void launch_merge_fix(int64_t *rows, const int64_t *d_n_rows, const int64_t *d_all, int rank, int world,
+                      int64_t *d_absorbed, hipStream_t s);
+// sharded: d_extra[0..1] from every rank's flags (d_all: world x 3 int64)
+void launch_bits_extra(const int64_t *d_all, int rank, int world, int32_t *d_extra, hipStream_t s);
 
 // ---- filters.hip ---------------------------------------------------------------------------------------
 int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad);

@@ -49,15 +49,20 @@ __global__ __launch_bounds__(256) void k_chunk_stable(const ResolveArgs a) {
     const int64_t pend_pos = ch[c].pend_pos;
     if (pend_pos >= 0) {
         int64_t len = ch[c].start + ch[c].len - pend_pos;              // run length inside chunk c
+        bool hit = false;                                              // ended by a run boundary
         for (int64_t u = c + 1; len <= a.tol && u < a.n_chunks; ++u) {
             const int64_t lead = ch[u].lead;
             len += lead;
-            if (lead < ch[u].len) break;
+            if (lead < ch[u].len) { hit = true; break; }
         }
         ps = len > a.tol;
+        if (a.local_pass && !ps && !hit) a.aux->open_chunk = (int32_t)c;   // at most one chunk: everything after it is one run
     }
     ch[c].pend_stable = ps;
-    a.sc.has_stable[c] = (ps || ch[c].cnt > 0) ? (int32_t)c : -1;
+    const bool has = ps || ch[c].cnt > 0;
+    a.sc.has_stable[c] = has ? (int32_t)c : -1;
+    if (has) atomicMin(&a.aux->first_stable, (int32_t)c);
+    if (ch[c].lead < ch[c].len) atomicMin(&a.aux->first_nonlead, (int32_t)c);
 }
 
 // Single-workgroup exclusive scans over n <= 2^31 ints: out_max[i] = max(in_max[0..i)) (or -1);
@@ -114,6 +119,7 @@ __device__ void block_scan_max_sum(const int32_t *in_max, int32_t *out_max, cons
 __global__ __launch_bounds__(kResolveBlock) void k_scan_stable(const ResolveArgs a) {
     int32_t tm; int64_t ts;
     block_scan_max_sum<false>(a.sc.has_stable, a.sc.prev_stable, nullptr, nullptr, a.n_chunks, tm, ts);
+    if (threadIdx.x == 0) a.aux->last_stable = tm;
 }
 
 __device__ __forceinline__ uint32_t chunk_last_stable_state(const ChunkInfo &ci) { return ci.pend_stable ? ci.pend_state : ci.last_state; }
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256) void k_chunk_accept(const ResolveArgs a) {
     if (c >= a.n_chunks) return;
     ChunkInfo *ch = a.chunks;
     const int32_t ip = a.sc.prev_stable[c];
-    const uint32_t prev_state = (ip < 0) ? ch[0].init_state : chunk_last_stable_state(ch[ip]);
+    const uint32_t prev_state = (ip < 0) ? (a.local_pass ? 0xFFFFu : (uint32_t)ch[0].init_state) : chunk_last_stable_state(ch[ip]);
     const int cnt = ch[c].cnt;
     const int ps = ch[c].pend_stable;
     const int first_acc = (cnt > 0) && (ch[c].first_state != prev_state);
@@ -149,16 +155,45 @@ __global__ __launch_bounds__(kResolveBlock) void k_scan_accept(const ResolveArgs
     block_scan_max_sum<true>(a.sc.has_acc, a.sc.prev_acc, a.sc.out_cnt, a.sc.out_off, a.n_chunks, last_c, P);
     if (threadIdx.x == 0) {
         *a.d_n_acc = P;
-        int64_t n_rows = P;
-        if (P < a.n_total) {
-            n_rows = P + 1;
-            if (a.write_last_row && a.rows != nullptr && P < a.cap_rows) {
-                int64_t fpos = -1; uint32_t fstate = a.chunks[0].init_state;
-                if (last_c >= 0) chunk_last_acc(a.chunks[last_c], fpos, fstate);
-                const int64_t len = (P == 0) ? (a.n_total - a.tol) : (a.n_total - 1 - fpos - a.tol);
-                a.rows[2 * P] = (int64_t)fstate - 1;
-                a.rows[2 * P + 1] = len;
+        if (a.local_pass) {
+            // the ChunkInfo that stands for this whole shard in the other ranks' tables
+            const ChunkInfo *ch = a.chunks;
+            const ResolveAux ax = *a.aux;
+            ChunkInfo s;
+            s.start = ch[0].start; s.len = a.n_total;
+            s.lead = (ax.first_nonlead >= a.n_chunks) ? a.n_total : ch[ax.first_nonlead].start - ch[0].start + ch[ax.first_nonlead].lead;
+            s.pend_pos = -1; s.pend_state = 0;
+            if (ax.open_chunk < a.n_chunks) { s.pend_pos = ch[ax.open_chunk].pend_pos; s.pend_state = ch[ax.open_chunk].pend_state; }
+            s.cnt = (int32_t)P;
+            s.first_state = 0xFFFFu;
+            if (ax.first_stable < a.n_chunks) {
+                const ChunkInfo &f = ch[ax.first_stable];
+                s.first_state = f.cnt > 0 ? f.first_state : f.pend_state;
             }
+            s.last_state = (ax.last_stable < 0) ? (uint16_t)0xFFFFu : (uint16_t)chunk_last_stable_state(ch[ax.last_stable]);
+            int64_t lpos = 0; uint32_t lst = 0;
+            if (last_c >= 0) chunk_last_acc(ch[last_c], lpos, lst);
+            s.last_pos = lpos;
+            s.init_state = ch[0].init_state;
+            s.first_acc = 0; s.pend_acc = 0; s.pend_stable = 0; s.pad = 0;
+            *a.summary_out = s;
+            return;
+        }
+        // this GPU's rows are global rows [row_base, row_end) (+ the table's last row on the last GPU)
+        const int64_t row_base = a.sc.out_off[a.chunk_first];
+        const int64_t row_end = (a.chunk_first + a.n_local < a.n_chunks) ? a.sc.out_off[a.chunk_first + a.n_local] : P;
+        int64_t n_rows = row_end - row_base;
+        if (P < a.n_total && a.write_last_row) {
+            const int64_t o = P - row_base;
+            n_rows = o + 1;
+            int64_t fpos = -1; uint32_t fstate = a.chunks[0].init_state;
+            if (last_c >= 0) chunk_last_acc(a.chunks[last_c], fpos, fstate);
+            if (a.rows != nullptr && o < a.cap_rows) {
+                const int64_t len = (P == 0) ? (a.n_total - a.tol) : (a.n_total - 1 - fpos - a.tol);
+                a.rows[2 * o] = (int64_t)fstate - 1;
+                a.rows[2 * o + 1] = len;
+            }
+            if (o == 0 && a.d_ts_carry) *a.d_ts_carry = (P == 0) ? 0 : fpos + 1;
         }
         *a.d_n_rows_needed = n_rows;
         *a.d_n_rows = (a.rows != nullptr && n_rows > a.cap_rows) ? a.cap_rows : n_rows;
@@ -179,6 +214,7 @@ __global__ __launch_bounds__(64) void k_emit_rows(const EmitArgs a) {
     const int64_t total = from_slab + ci.pend_acc;
     if (total == 0) return;
     const int64_t out_off = a.sc.out_off[c];
+    const int64_t row_base = a.sc.out_off[a.chunk_first];
     int64_t prev_pos = -1; uint32_t prev_state = a.chunks[0].init_state;   // before the very first accepted run
     const int32_t ip = a.sc.prev_acc[c];
     if (ip >= 0) chunk_last_acc(a.chunks[ip], prev_pos, prev_state);
@@ -193,8 +229,9 @@ __global__ __launch_bounds__(64) void k_emit_rows(const EmitArgs a) {
         const int64_t len = (g == 0) ? pos + 1 : pos - ppos;
         int64_t state = (int64_t)pst - 1;
         if (a.is_ask && state == -1 && len < a.sps) state = 0;
-        const int64_t o = g - a.row_base;
+        const int64_t o = g - row_base;
         if (o >= 0 && o < a.cap_rows) { a.rows[2 * o] = state; a.rows[2 * o + 1] = len; }
+        if (o == 0 && a.d_ts_carry) *a.d_ts_carry = (g == 0) ? 0 : ppos + 1;
     }
 }
 
@@ -274,7 +311,9 @@ struct BitsLoad {
         VecK<4> v; v.zero();
         const int64_t type = rows[2 * i], len = rows[2 * i + 1];
         v.v[2] = len;
-        if (i == 0 && type == -1) return v;              // "Starts with Pause" (:346-348): only seeds total_samples
+        if (type == kRowAbsorbed) return v;              // merged into the previous GPU's last row: length only
+        const bool global_row0 = (i == 0) && (bp.d_row_base == nullptr || *bp.d_row_base == 0);
+        if (global_row0 && type == -1) return v;         // "Starts with Pause" (:346-348): only seeds total_samples
         const int64_t ns = num_symbols_of(len, bp.sps);
         if (type == -1) {
             if (ns <= bp.pause_threshold || bp.pause_threshold == 0) v.v[0] = (ns > 0) ? ns * bp.bps : 0;
@@ -292,76 +331,92 @@ struct BitsStore {
     const int64_t *d_n_rows;
     RowInfo *info;
     GroupInfo *groups;
+    const int64_t *d_ts_carry;   // sharded captures: total_samples before this GPU's first row (nullptr: 0)
+    const int64_t *d_absorbed;
     __device__ void operator()(int64_t i, const VecK<4> &val, const VecK<4> &ex) const {
         const int64_t n = *d_n_rows;
+        const int64_t ts0 = d_ts_carry ? *d_ts_carry : 0;
         RowInfo ri;
-        ri.bit_prefix = ex.v[0]; ri.ts_prefix = ex.v[2]; ri.group = (int32_t)ex.v[1]; ri.kbits = (int32_t)val.v[0];
+        ri.bit_prefix = ex.v[0]; ri.ts_prefix = ts0 + ex.v[2]; ri.group = (int32_t)ex.v[1]; ri.kbits = (int32_t)val.v[0];
         info[i] = ri;
         if (val.v[1]) {                                   // L row closes group ex.v[1]
             GroupInfo g;
-            g.bits_end = ex.v[0]; g.data_end = ex.v[3]; g.ts_close = ex.v[2]; g.pause = val.v[2]; g.closed = 1; g.pad = 0;
+            g.bits_end = ex.v[0]; g.data_end = ex.v[3]; g.ts_close = ts0 + ex.v[2]; g.pause = val.v[2]; g.closed = 1; g.pad = 0;
             groups[ex.v[1]] = g;
         }
         if (i + 1 == n) {                                 // trailing group (index = total L count)
             GroupInfo g;
-            g.bits_end = ex.v[0] + val.v[0]; g.data_end = ex.v[3] + val.v[3]; g.ts_close = ex.v[2] + val.v[2];
+            g.bits_end = ex.v[0] + val.v[0]; g.data_end = ex.v[3] + val.v[3]; g.ts_close = ts0 + ex.v[2] + val.v[2];
             g.pause = (rows[2 * i] == -1) ? rows[2 * i + 1] : 0;      // :411
+            if (rows[2 * i] == kRowAbsorbed && d_absorbed && *d_absorbed >= 0) g.pause = *d_absorbed;
             g.closed = 0; g.pad = 0;
             groups[ex.v[1] + val.v[1]] = g;
         }
     }
 };
 
-// groups -> messages: exclusive scan over (is_message, kept bits, kept positions)
+// groups -> messages: exclusive scan over (messages closed here, kept bits, kept positions).
+// A group is KEPT when it holds a data row -- on this GPU or, for the groups that continue across a shard
+// boundary (the first one and the trailing one), on the neighbouring GPUs (d_extra) -- and is a MESSAGE of this
+// GPU when it is kept and closes here (by a long pause, or by the end of the capture on the last GPU).
 struct GroupLoad {
     const GroupInfo *groups;
+    const int64_t *d_n_groups;
+    const int32_t *d_extra;
+    int is_last_rank;
     int write_pos;
+    __device__ bool kept(int64_t g, const GroupInfo &gi) const {
+        const int64_t d0 = g ? groups[g - 1].data_end : 0;
+        if (gi.data_end - d0 > 0) return true;
+        if (!d_extra) return false;
+        return (g == 0 && d_extra[0]) || (!gi.closed && d_extra[1]);
+    }
     __device__ VecK<3> operator()(int64_t g) const {
         VecK<3> v; v.zero();
         const GroupInfo gi = groups[g];
-        const int64_t d0 = g ? groups[g - 1].data_end : 0;
-        if (gi.data_end - d0 > 0) {
+        if (kept(g, gi)) {
             const int64_t b0 = g ? groups[g - 1].bits_end : 0;
-            v.v[0] = 1;
+            const bool closes = gi.closed || is_last_rank;
+            v.v[0] = closes ? 1 : 0;
             v.v[1] = gi.bits_end - b0;
-            v.v[2] = write_pos ? (gi.bits_end - b0) + (gi.closed ? 2 : 1) : 0;
+            v.v[2] = write_pos ? (gi.bits_end - b0) + (gi.closed ? 2 : (is_last_rank ? 1 : 0)) : 0;
         }
         return v;
     }
 };
 struct GroupOut {            // per group, for the expansion kernel
     int64_t bits_start;      // bit_prefix at the group's first row
-    int64_t out_bits;        // offset of the message in bits[]
-    int64_t out_pos;         // offset of the message in pos[]
-    int32_t is_msg;
+    int64_t out_bits;        // offset of the group's bits in bits[]
+    int64_t out_pos;         // offset of the group's positions in pos[]
+    int32_t is_msg;          // kept
     int32_t pad;
 };
 struct GroupStore {
-    const GroupInfo *groups;
+    GroupLoad ld;
     GroupOut *gout;
     int64_t *msg_off, *pauses, *pos_off, *pos;
     int64_t cap_msg, cap_pos;
-    int write_pos;
     __device__ void operator()(int64_t g, const VecK<3> &val, const VecK<3> &ex) const {
+        const GroupInfo gi = ld.groups[g];
+        const bool kept = ld.kept(g, gi);
         GroupOut o;
-        o.bits_start = g ? groups[g - 1].bits_end : 0;
-        o.out_bits = ex.v[1]; o.out_pos = ex.v[2]; o.is_msg = (int32_t)val.v[0]; o.pad = 0;
+        o.bits_start = g ? ld.groups[g - 1].bits_end : 0;
+        o.out_bits = ex.v[1]; o.out_pos = ex.v[2]; o.is_msg = kept ? 1 : 0; o.pad = 0;
         gout[g] = o;
-        if (val.v[0]) {
+        if (val.v[0]) {                                       // a message of this GPU: END offsets at [m + 1]
             const int64_t m = ex.v[0];
-            const GroupInfo gi = groups[g];
             if (m < cap_msg) {
-                msg_off[m] = ex.v[1];
-                pos_off[m] = ex.v[2];
+                msg_off[m + 1] = ex.v[1] + val.v[1];
+                pos_off[m + 1] = ex.v[2] + val.v[2];
                 pauses[m] = gi.pause;
             }
-            if (write_pos) {
-                const int64_t p0 = ex.v[2] + val.v[1];          // sentinels follow the per-bit positions
-                if (gi.closed) {
-                    if (p0 + 1 < cap_pos) { pos[p0] = gi.ts_close; pos[p0 + 1] = gi.ts_close + gi.pause; }
-                } else {
-                    if (p0 < cap_pos) pos[p0] = gi.ts_close;
-                }
+        }
+        if (kept && ld.write_pos) {
+            const int64_t p0 = ex.v[2] + val.v[1];            // sentinels follow the per-bit positions
+            if (gi.closed) {
+                if (p0 + 1 < cap_pos) { pos[p0] = gi.ts_close; pos[p0 + 1] = gi.ts_close + gi.pause; }
+            } else if (ld.is_last_rank) {
+                if (p0 < cap_pos) pos[p0] = gi.ts_close;
             }
         }
     }
@@ -374,12 +429,7 @@ __global__ void k_bits_counts(const int64_t *d_n_rows, const VecK<3> *grand, int
     VecK<3> g; g.zero();
     if (n_rows > 0) g = *grand;
     counts[0] = n_rows; counts[1] = g.v[0]; counts[2] = g.v[1]; counts[3] = g.v[2];
-    if (g.v[0] <= cap_msg) { msg_off[g.v[0]] = g.v[1]; pos_off[g.v[0]] = g.v[2]; }
-}
-
-// number of groups = total L rows + 1, published for the group scan
-__global__ void k_group_count(const int64_t *d_n_rows, const VecK<4> *grand, int64_t *d_n_groups) {
-    *d_n_groups = (*d_n_rows > 0) ? grand->v[1] + 1 : 0;
+    msg_off[0] = 0; pos_off[0] = 0;          // msg_off[m + 1] / pos_off[m + 1] = END of message m (GroupStore)
 }
 
 struct ExpandArgs {
@@ -442,6 +492,7 @@ __global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
 int launch_resolve(const ResolveArgs &a, hipStream_t s) {
     if (a.n_chunks <= 0) return URHGPU_ERR_ARG;
     const unsigned g = (unsigned)((a.n_chunks + 255) / 256);
+    if (hipMemsetAsync(a.aux, 0x7F, sizeof(ResolveAux), s) != hipSuccess) return URHGPU_ERR_HIP;
     hipLaunchKernelGGL(k_chunk_stable, dim3(g), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_scan_stable, dim3(1), dim3(kResolveBlock), 0, s, a);
     hipLaunchKernelGGL(k_chunk_accept, dim3(g), dim3(256), 0, s, a);
@@ -490,40 +541,142 @@ size_t bits_scratch_bytes(int64_t cap_rows) {
            (size_t)cap_groups * (sizeof(GroupInfo) + sizeof(GroupOut)) + 64 + 8 * 256;
 }
 
-int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                         const BitsOut &o, void *scratch, hipStream_t s) {
-    if (cap_rows <= 0) cap_rows = 1;
-    const int64_t nb = scan_blocks(cap_rows);
+namespace {
+struct BitsScratch {
+    VecK<4> *part4; VecK<3> *part3; RowInfo *info; GroupInfo *groups; GroupOut *gout; int64_t *d_n_groups;
+    int64_t nb, nbg;
+};
+BitsScratch carve_bits(void *scratch, int64_t cap_rows) {
+    BitsScratch b;
+    b.nb = scan_blocks(cap_rows);
     const int64_t cap_groups = cap_rows + 1;
-    const int64_t nbg = scan_blocks(cap_groups);
+    b.nbg = scan_blocks(cap_groups);
     char *p = (char *)scratch;
     auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~size_t(255); return r; };
-    VecK<4> *part4 = (VecK<4> *)take((size_t)(nb + 1) * sizeof(VecK<4>));
-    VecK<3> *part3 = (VecK<3> *)take((size_t)(nbg + 1) * sizeof(VecK<3>));
-    RowInfo *info = (RowInfo *)take((size_t)cap_rows * sizeof(RowInfo));
-    GroupInfo *groups = (GroupInfo *)take((size_t)cap_groups * sizeof(GroupInfo));
-    GroupOut *gout = (GroupOut *)take((size_t)cap_groups * sizeof(GroupOut));
-    int64_t *d_n_groups = (int64_t *)take(64);
+    b.part4 = (VecK<4> *)take((size_t)(b.nb + 1) * sizeof(VecK<4>));
+    b.part3 = (VecK<3> *)take((size_t)(b.nbg + 1) * sizeof(VecK<3>));
+    b.info = (RowInfo *)take((size_t)cap_rows * sizeof(RowInfo));
+    b.groups = (GroupInfo *)take((size_t)cap_groups * sizeof(GroupInfo));
+    b.gout = (GroupOut *)take((size_t)cap_groups * sizeof(GroupOut));
+    b.d_n_groups = (int64_t *)take(64);
+    return b;
+}
+}  // namespace
 
+// number of groups = total L rows + 1; flags = {long pause present, data before the first one, data after the last one}
+__global__ void k_group_count_flags(const int64_t *d_n_rows, const VecK<4> *grand, const GroupInfo *groups,
+                                    int64_t *d_n_groups, int64_t *d_flags) {
+    const int64_t n = *d_n_rows;
+    const int64_t n_l = (n > 0) ? grand->v[1] : 0;
+    *d_n_groups = (n > 0) ? n_l + 1 : 0;
+    if (d_flags) {
+        d_flags[0] = n_l > 0;
+        d_flags[1] = (n > 0) && groups[0].data_end > 0;
+        d_flags[2] = (n > 0) && (groups[n_l].data_end - (n_l ? groups[n_l - 1].data_end : 0) > 0);
+    }
+}
+
+int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                        void *scratch, int64_t *d_flags, hipStream_t s) {
+    if (cap_rows <= 0) cap_rows = 1;
+    const BitsScratch b = carve_bits(scratch, cap_rows);
     BitsLoad ld{rows, d_n_rows, bp};
-    BitsStore st{rows, d_n_rows, info, groups};
-    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_rows, ld, part4);
-    hipLaunchKernelGGL((k_scan_partials<4>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, part4, nb);
-    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_rows, ld,
-                       part4, st);
-    hipLaunchKernelGGL(k_group_count, dim3(1), dim3(1), 0, s, d_n_rows, part4 + nb, d_n_groups);
-    GroupLoad gl{groups, bp.write_pos};
-    GroupStore gs{groups, gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos, bp.write_pos};
-    hipLaunchKernelGGL((k_scan_reduce<3, GroupLoad>), dim3((unsigned)nbg), dim3(kScanBlock), 0, s, d_n_groups, gl, part3);
-    hipLaunchKernelGGL((k_scan_partials<3>), dim3(1), dim3(kScanBlock), 0, s, d_n_groups, part3, nbg);
-    hipLaunchKernelGGL((k_scan_apply<3, GroupLoad, GroupStore>), dim3((unsigned)nbg), dim3(kScanBlock), 0, s, d_n_groups,
-                       gl, part3, gs);
-    hipLaunchKernelGGL(k_bits_counts, dim3(1), dim3(1), 0, s, d_n_rows, part3 + nbg, o.msg_off, o.pos_off, o.cap_msg,
+    BitsStore st{rows, d_n_rows, b.info, b.groups, bp.d_ts_carry, bp.d_absorbed};
+    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4);
+    hipLaunchKernelGGL((k_scan_partials<4>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, b.part4, b.nb);
+    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld,
+                       b.part4, st);
+    hipLaunchKernelGGL(k_group_count_flags, dim3(1), dim3(1), 0, s, d_n_rows, b.part4 + b.nb, b.groups, b.d_n_groups, d_flags);
+    return URHGPU_OK;
+}
+
+int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                       const BitsOut &o, void *scratch, hipStream_t s) {
+    if (cap_rows <= 0) cap_rows = 1;
+    const BitsScratch b = carve_bits(scratch, cap_rows);
+    GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
+    GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
+    hipLaunchKernelGGL((k_scan_reduce<3, GroupLoad>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s, b.d_n_groups, gl, b.part3);
+    hipLaunchKernelGGL((k_scan_partials<3>), dim3(1), dim3(kScanBlock), 0, s, b.d_n_groups, b.part3, b.nbg);
+    hipLaunchKernelGGL((k_scan_apply<3, GroupLoad, GroupStore>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s, b.d_n_groups,
+                       gl, b.part3, gs);
+    hipLaunchKernelGGL(k_bits_counts, dim3(1), dim3(1), 0, s, d_n_rows, b.part3 + b.nbg, o.msg_off, o.pos_off, o.cap_msg,
                        o.counts);
-    ExpandArgs ea{rows, d_n_rows, info, gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp};
+    ExpandArgs ea{rows, d_n_rows, b.info, b.gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp};
     const int64_t eb = (cap_rows + 255) / 256;
     hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)eb), dim3(256), 0, s, ea);
     return URHGPU_OK;
+}
+
+int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                         const BitsOut &o, void *scratch, hipStream_t s) {
+    URH_TRY(launch_bits_prepare(rows, d_n_rows, cap_rows, bp, scratch, nullptr, s));
+    return launch_bits_finish(rows, d_n_rows, cap_rows, bp, o, scratch, s);
+}
+
+// ---- sharded captures: the tiny cross-shard fix-ups (one thread each; world <= a few dozen) ---------------
+__global__ void k_merge_summary(const int64_t *rows, const int64_t *d_n_rows, int64_t *out5) {
+    const int64_t n = *d_n_rows;
+    out5[0] = n;
+    out5[1] = n ? rows[0] : 0; out5[2] = n ? rows[1] : 0;
+    out5[3] = n ? rows[2 * (n - 1)] : 0; out5[4] = n ? rows[2 * (n - 1) + 1] : 0;
+}
+void launch_merge_summary(const int64_t *rows, const int64_t *d_n_rows, int64_t *d_out5, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_summary, dim3(1), dim3(1), 0, s, rows, d_n_rows, d_out5);
+}
+
+// ASK: rows of equal state merge across shard boundaries (signal_functions.pyx:475-480).  The merged row belongs
+// to the rank where it starts: my last row absorbs the first rows of the following ranks while their state
+// matches; my first row is marked absorbed when it continues the previous rank's last row.
+__global__ void k_merge_fix(int64_t *rows, const int64_t *d_n_rows, const int64_t *all, int rank, int world, int64_t *d_absorbed) {
+    const int64_t n = *d_n_rows;
+    *d_absorbed = -1;
+    if (n == 0) return;
+    auto M = [&](int q, int k) { return all[5 * q + k]; };
+    int prev = -1;
+    for (int q = rank - 1; q >= 0; --q) if (M(q, 0) > 0) { prev = q; break; }
+    const bool absorbed = prev >= 0 && M(prev, 3) == rows[0];
+    if (!(absorbed && n == 1)) {
+        const int64_t last_state = rows[2 * (n - 1)];
+        for (int q = rank + 1; q < world; ++q) {
+            if (M(q, 0) == 0) continue;
+            if (M(q, 1) != last_state) break;
+            rows[2 * (n - 1) + 1] += M(q, 2);
+            if (M(q, 0) > 1) break;
+        }
+    }
+    if (absorbed) {
+        if (n == 1 && rows[0] == -1) {
+            // my only row continues a pause owned by an earlier rank: the reference's last-row pause
+            // (ProtocolAnalyzer.py:411) is the owner's last row plus everything absorbed into it
+            int64_t tot = rows[1];
+            for (int q = rank + 1; q < world; ++q) tot += (M(q, 0) > 0) ? M(q, 2) : 0;
+            for (int q = rank - 1; q >= 0; --q) {
+                if (M(q, 0) == 0) continue;
+                tot += M(q, 4);
+                if (M(q, 0) > 1) break;
+                int pq = -1;
+                for (int u = q - 1; u >= 0; --u) if (M(u, 0) > 0) { pq = u; break; }
+                if (!(pq >= 0 && M(pq, 3) == M(q, 1))) break;
+            }
+            *d_absorbed = tot;
+        }
+        rows[0] = kRowAbsorbed;
+    }
+}
+void launch_merge_fix(int64_t *rows, const int64_t *d_n_rows, const int64_t *d_all, int rank, int world,
+                      int64_t *d_absorbed, hipStream_t s) {
+    hipLaunchKernelGGL(k_merge_fix, dim3(1), dim3(1), 0, s, rows, d_n_rows, d_all, rank, world, d_absorbed);
+}
+
+__global__ void k_bits_extra(const int64_t *all, int rank, int world, int32_t *extra) {
+    int head = 0, tail = 0;
+    for (int q = rank - 1; q >= 0; --q) { head |= (int)all[3 * q + 2]; if (all[3 * q]) break; }
+    for (int q = rank + 1; q < world; ++q) { tail |= (int)all[3 * q + 1]; if (all[3 * q]) break; }
+    extra[0] = head; extra[1] = tail;
+}
+void launch_bits_extra(const int64_t *d_all, int rank, int world, int32_t *d_extra, hipStream_t s) {
+    hipLaunchKernelGGL(k_bits_extra, dim3(1), dim3(1), 0, s, d_all, rank, world, d_extra);
 }
 
 }  // namespace urh

@@ -1,0 +1,121 @@
+"""Per-rank GPU engine of the sharded IQ->bits pass: the four urhgpu_shard_* phases of liburhgpu.so
+(include/urhgpu.h) behind the engine interface urh_amd/sharding.py orchestrates.  torch is plumbing
+(device buffers, the stream, the tensors the all-gathers move); all arithmetic is in the HIP kernels."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .pipeline import DevicePipeline, _torch_dtype
+
+
+class ShardResult:
+    """This rank's piece of a sharded result (device tensors) + host views for `sharding.stitch`."""
+
+    def __init__(self, qad, rows, bits, msg_off, pauses, pos, pos_off, counts, params):
+        self.qad, self.rows_buf, self.bits_buf = qad, rows, bits
+        self.msg_off_buf, self.pauses_buf, self.pos_buf, self.pos_off_buf = msg_off, pauses, pos, pos_off
+        self.counts, self.params = counts, params
+        self._host_counts = None
+
+    def host_counts(self):
+        if self._host_counts is None:
+            self._host_counts = tuple(int(x) for x in self.counts.cpu().numpy()[:4])
+        return self._host_counts
+
+    def check_capacity(self):
+        n_rows, n_msg, n_bits, n_pos = self.host_counts()
+        if n_rows > self.rows_buf.shape[0] or n_msg > self.pauses_buf.shape[0] or n_bits > self.bits_buf.shape[0] \
+                or (self.pos_buf is not None and n_pos > self.pos_buf.shape[0]):
+            raise _lib.UrhGpuError(_lib.ERR_CAPACITY, f"output capacity too small: rows={n_rows} msgs={n_msg} "
+                                                      f"bits={n_bits} pos={n_pos}")
+
+    def piece(self):
+        """dict(rows, bits, msg_end, pauses, pos, pos_end) of numpy arrays (see sharding.stitch)."""
+        self.check_capacity()
+        n_rows, n_msg, n_bits, n_pos = self.host_counts()
+        rows = self.rows_buf[:n_rows].cpu().numpy()
+        if n_rows and rows[0, 0] == _lib.ROW_ABSORBED:
+            rows = rows[1:]
+        return dict(rows=rows, bits=self.bits_buf[:n_bits].cpu().numpy(),
+                    msg_end=self.msg_off_buf[1:n_msg + 1].cpu().numpy(), pauses=self.pauses_buf[:n_msg].cpu().numpy(),
+                    pos=self.pos_buf[:n_pos].cpu().numpy() if self.pos_buf is not None else np.zeros(0, np.int64),
+                    pos_end=self.pos_off_buf[1:n_msg + 1].cpu().numpy())
+
+    # `stitch` accepts mappings: make the result itself usable as a piece
+    def __getitem__(self, k):
+        if not hasattr(self, "_piece"):
+            self._piece = self.piece()
+        return self._piece[k]
+
+
+class GpuShardEngine(DevicePipeline):
+    """DevicePipeline (context, stream, output buffers) + the shard phases."""
+
+    def tail(self, iq_local, p):
+        torch = self.torch
+        if iq_local.dtype == torch.complex64:
+            iq_local = torch.view_as_real(iq_local)
+        return iq_local[-2:].contiguous()                     # (2, 2): samples n-2, n-1
+
+    def runs(self, iq, left, pos_base, n_total, rank, world, p, want_qad):
+        torch = self.torch
+        if iq.dtype == torch.complex64:
+            iq = torch.view_as_real(iq)
+        if iq.dim() != 2 or iq.shape[1] != 2 or not iq.is_contiguous():
+            raise ValueError("IQ must be a contiguous (N, 2) tensor")
+        npdt = _torch_dtype(iq)
+        n = iq.shape[0]
+        cp = p.to_c(npdt)
+        cap_rows, cap_bits, cap_msg, cap_pos = self.capacities(n, p)
+        qad = self._buf("qad", (n,), torch.float32) if want_qad else None
+        rows = self._buf("rows", (cap_rows, 2), torch.int64)
+        bits = self._buf("bits", (cap_bits,), torch.uint8)
+        msg_off = self._buf("msg_off", (cap_msg + 1,), torch.int64)
+        pauses = self._buf("pauses", (cap_msg,), torch.int64)
+        pos_off = self._buf("pos_off", (cap_msg + 1,), torch.int64)
+        pos = self._buf("pos", (cap_pos,), torch.int64) if p.write_bit_sample_pos else None
+        counts = self._buf("counts", (4,), torch.int64)
+        o = _lib.Outputs()
+        o.qad = qad.data_ptr() if qad is not None else None
+        o.rows = rows.data_ptr(); o.cap_rows = cap_rows
+        o.bits = bits.data_ptr(); o.cap_bits = cap_bits
+        o.msg_off = msg_off.data_ptr(); o.pauses = pauses.data_ptr(); o.cap_msg = cap_msg
+        o.pos = pos.data_ptr() if pos is not None else None
+        o.cap_pos = cap_pos if pos is not None else 0
+        o.pos_off = pos_off.data_ptr()
+        o.counts = counts.data_ptr()
+        self._res = ShardResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p)
+        self._ask = p.modulation_type == "ASK"
+        self._keep = (iq, left)                                # keep the inputs alive until the pass is over
+        summary = self._buf("summary", (8,), torch.int64)      # one ChunkInfo (64 bytes)
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        lh = C.c_void_p(left.data_ptr()) if left is not None else None
+        _lib.check(_lib.load().urhgpu_shard_runs_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, int(pos_base), int(n_total),
+                                                     int(rank), int(world), lh, C.byref(cp), C.byref(o),
+                                                     C.c_void_p(summary.data_ptr())))
+        return summary
+
+    def rows(self, summaries):
+        torch = self.torch
+        self._keep += (summaries,)
+        merge = self._buf("merge", (5,), torch.int64) if self._ask else None
+        _lib.check(_lib.load().urhgpu_shard_rows_dev(self.ctx.handle, C.c_void_p(summaries.data_ptr()),
+                                                     C.c_void_p(merge.data_ptr()) if merge is not None else None))
+        return merge
+
+    def bits_prepare(self, merged_all):
+        torch = self.torch
+        self._keep += (merged_all,)
+        flags = self._buf("flags", (3,), torch.int64)
+        _lib.check(_lib.load().urhgpu_shard_bits_prepare_dev(
+            self.ctx.handle, C.c_void_p(merged_all.data_ptr()) if merged_all is not None else None, C.c_void_p(flags.data_ptr())))
+        return flags
+
+    def bits_finish(self, flags_all):
+        self._keep += (flags_all,)
+        _lib.check(_lib.load().urhgpu_shard_bits_finish_dev(self.ctx.handle, C.c_void_p(flags_all.data_ptr())))
+        res, self._res = self._res, None
+        res._keep = self._keep
+        self._keep = ()
+        return res
