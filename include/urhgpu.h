@@ -188,7 +188,7 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
  * all-gathers a few bytes per rank (urh_amd/sharding.py does it with torch.distributed = RCCL over xGMI):
  *
  *   halo    : the last 2 IQ samples of every shard                          -> d_left_halo of the next rank
- *   runs    : hot kernel on the shard + its 64-byte summary (d_summary out) -> all-gather -> d_summaries
+ *   runs    : hot kernel on the shard + its 72-byte summary (d_summary out) -> all-gather -> d_summaries
  *   rows    : this rank's pulse-table rows; ASK: d_merge (5 x int64) out    -> all-gather -> d_merge_all
  *   prepare : cross-shard ASK merge, per-row scan; d_flags (3 x int64) out  -> all-gather -> d_flags_all
  *   finish  : bits / pauses / bit_sample_pos of this rank's rows
@@ -203,6 +203,7 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
  *   - counts = {local rows, messages closed here, local bits, local positions}.
  * PSK (Costas loop) does not shard: URHGPU_ERR_UNSUPPORTED. */
 #define URHGPU_ROW_ABSORBED (-(INT64_C(1) << 62))
+#define URHGPU_SHARD_SUMMARY_BYTES 72 /* one shard summary (d_summary; d_summaries = world of them, back to back) */
 int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
                           int rank, int world, const void *d_left_halo, const urhgpu_params *p,
                           const urhgpu_outputs *out, void *d_summary);

@@ -55,5 +55,6 @@ struct ChunkInfo {
     int32_t pend_stable;   // pending run grows past `tolerance` in the following chunks?
     int32_t pad;
 };
+static_assert(sizeof(ChunkInfo) == 72, "URHGPU_SHARD_SUMMARY_BYTES (include/urhgpu.h) is sizeof(ChunkInfo)");
 
 }  // namespace urh

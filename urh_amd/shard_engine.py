@@ -88,7 +88,7 @@ class GpuShardEngine(DevicePipeline):
         self._res = ShardResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p)
         self._ask = p.modulation_type == "ASK"
         self._keep = (iq, left)                                # keep the inputs alive until the pass is over
-        summary = self._buf("summary", (8,), torch.int64)      # one ChunkInfo (64 bytes)
+        summary = self._buf("summary", (9,), torch.int64)      # URHGPU_SHARD_SUMMARY_BYTES = 72
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         lh = C.c_void_p(left.data_ptr()) if left is not None else None
         _lib.check(_lib.load().urhgpu_shard_runs_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, int(pos_base), int(n_total),

@@ -6,7 +6,7 @@ is exchanged with three (ASK: four) small all-gathers -- no data-path collective
 
     1. halo        the last two IQ samples of every shard (16 B)      -> seam of the FSK conj-product and
                                                                         the state of the sample before the shard
-    2. summary     one ChunkInfo (64 B) per shard: the shard's run structure reduced to what its
+    2. summary     one ChunkInfo (72 B) per shard: the shard's run structure reduced to what its
                    neighbours need (leading run length, first / last stable run, still-short trailing run,
                    number of accepted runs)                           -> pulse-table rows with global lengths
     3. (ASK only)  first / last row of every shard's merged table     -> equal-state rows merged across shards
