@@ -121,6 +121,11 @@ int urhgpu_ppseq_to_bits(urhgpu_ctx *ctx, const int64_t *rows, int64_t n_rows, i
  * accumulation order of the reference's scatter loop. */
 int urhgpu_fir_filter(urhgpu_ctx *ctx, const float *x, int64_t n, const float *taps, int64_t m, float *out);
 
+/* The same on device memory (asynchronous).  d_left_halo: NULL = zero history (the reference), or DEVICE pointer
+ * to the m - 1 samples that precede d_x[0] (sharded captures: the left neighbour's tail). */
+int urhgpu_fir_filter_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const float *d_taps, int64_t m,
+                          const float *d_left_halo, float *d_out);
+
 /* signal_functions.iir_filter (:527-542). */
 int urhgpu_iir_filter(urhgpu_ctx *ctx, const double *a, int64_t na, const double *b, int64_t nb,
                       const float *x, int64_t n, float *out);
@@ -216,6 +221,10 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all);
  * of the capture backwards; d_sum[k] (float64) / d_max[k] (float64) for chunk k counted from the end. */
 int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, int64_t chunk,
                                      int64_t n_chunks, double *d_sum, double *d_max);
+
+/* Test hook: the hot kernel's fast-path division (Newton + residual chain without scaling) against the IEEE
+ * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
+int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);
 
 /* Test hook: elementwise bit-faithful atan2f (the device port of glibc 2.35 atan2f), device pointers. */
 int urhgpu_test_atan2f_dev(urhgpu_ctx *ctx, const float *d_y, const float *d_x, int64_t n, float *d_out);

@@ -214,3 +214,98 @@ def test_sharded_equals_single_gpu(pipe, oracle, mod, world):
                 assert np.array_equal(a, b), (mod, world, n, bounds, k, len(a), len(b))
             got_qad = np.concatenate([r.qad.cpu().numpy() for r in res])
             assert bits_equal(got_qad, want_qad)
+
+
+# ---- filters, magnitudes, noise estimator ------------------------------------------------------------------
+def cbits_equal(a, b):
+    a, b = np.ascontiguousarray(a, np.complex64).view(np.uint32), np.ascontiguousarray(b, np.complex64).view(np.uint32)
+    fa, fb = a.view(np.float32), b.view(np.float32)
+    return bool(((a == b) | (np.isnan(fa) & np.isnan(fb))).all())
+
+
+def test_fir_kat(sf):
+    """/root/reference/tests/test_filter.py:20-31"""
+    x = np.array([1, 2, 3, 4, 5, 6, 7, 8, 9, 42], dtype=np.complex64)
+    out = sf.fir_filter(x, np.array([0.25] * 4, dtype=np.complex64))
+    assert np.allclose(out, [0.25, 0.75, 1.5, 2.5, 3.5, 4.5, 5.5, 6.5, 7.5, 16.5])
+
+
+def test_fir_equals_oracle(sf, oracle):
+    rng = np.random.default_rng(12)
+    for n in (1, 2, 3, 5, 63, 64, 1023, 1024, 1025, 4097, 50_001):
+        for m in (1, 2, 3, 4, 5, 10, 63, 64, 65, 257):
+            x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+            h = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
+            assert cbits_equal(sf.fir_filter(x, h), oracle.fir_filter(x, h)), (n, m)
+    # signed zeros, infinities, NaNs, denormals: the Annex G recovery path of the complex product
+    vals = np.array([0.0, -0.0, 1.0, -1.0, 1e-40, 3e38, -3e38, np.inf, -np.inf, np.nan, 0.5], dtype=np.float32)
+    x = (vals[rng.integers(0, len(vals), 5000)] + 1j * vals[rng.integers(0, len(vals), 5000)]).astype(np.complex64)
+    h = (vals[rng.integers(0, 7, 9)] + 1j * vals[rng.integers(0, 7, 9)]).astype(np.complex64)
+    assert cbits_equal(sf.fir_filter(x, h), oracle.fir_filter(x, h))
+    assert len(sf.fir_filter(np.zeros(0, np.complex64), h)) == 0
+
+
+def test_fir_with_left_halo_equals_one_pass(pipe, oracle):
+    """sharded FIR: a shard filtered with the m-1 preceding samples as halo equals the same stretch of the one-pass result"""
+    import torch
+    from urh_amd import _lib
+    rng = np.random.default_rng(2)
+    n, m, cut = 30_000, 64, 12_345
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    h = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
+    want = oracle.fir_filter(x, h)
+    dx, dh = torch.from_numpy(x).cuda(), torch.from_numpy(h).cuda()
+    out = torch.empty(n - cut, dtype=torch.complex64, device="cuda")
+    halo = dx[cut - (m - 1):cut].clone()
+    shard = dx[cut:].clone()
+    pipe.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.load().urhgpu_fir_filter_dev(pipe.ctx.handle, C.c_void_p(shard.data_ptr()), n - cut, C.c_void_p(dh.data_ptr()), m,
+                                                 C.c_void_p(halo.data_ptr()), C.c_void_p(out.data_ptr())))
+    assert cbits_equal(out.cpu().numpy(), want[cut:])
+
+
+def test_iir_equals_oracle(sf, oracle):
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal(5000) + 1j * rng.standard_normal(5000)).astype(np.complex64)
+    for na, nb in ((1, 0), (3, 2), (2, 4), (5, 5)):
+        a, b = rng.standard_normal(na) * 0.3, rng.standard_normal(nb) * 0.2
+        assert cbits_equal(sf.iir_filter(a, b, x), oracle.iir_filter(a, b, x)), (na, nb)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.uint8, np.int16, np.uint16])
+def test_get_magnitudes_equals_oracle(oracle, dtype):
+    from urh_amd import util
+    for n in (1, 7, 1000, 100_003):
+        iq = synth_fsk(n, sps=20, seed=n, noise=0.2, pause_every=300, pause_len=50, dtype=dtype)
+        if dtype == np.uint16:
+            iq[::7] = 65535                      # C-int overflow -> NaN, as in the reference
+        assert np.array_equal(util.get_magnitudes(iq), oracle.get_magnitudes(iq), equal_nan=True), (np.dtype(dtype).name, n)
+
+
+@pytest.mark.parametrize("name", [c for c in GOLDEN_CASES])
+def test_detect_noise_level_golden(pipe, oracle, name):
+    import torch
+    from urh_amd import estimators
+    g = load_golden(name)
+    want = oracle.detect_noise_level(oracle.get_magnitudes(g["iq"]))
+    got = estimators.detect_noise_level_dev(pipe, torch.from_numpy(g["iq"]).cuda())
+    assert got == want, (name, got, want)
+
+
+def test_detect_noise_level_synthetic(pipe, oracle):
+    import torch
+    from urh_amd import estimators
+    for n, pause_len in ((10, 0), (101, 0), (250_000, 30_000), (1_000_003, 150_000)):
+        iq = synth_fsk(n, sps=100, seed=n, noise=0.02, pause_every=max(n // 3, 1), pause_len=pause_len)
+        want = oracle.detect_noise_level(oracle.get_magnitudes(iq))
+        got = estimators.detect_noise_level_dev(pipe, torch.from_numpy(iq).cuda())
+        assert got == want, (n, got, want)
+
+
+def test_fast_path_division_is_ieee_division():
+    """the unscaled Newton/residual division of the FSK fast path returns the bits of the IEEE division"""
+    from urh_amd import _lib
+    ctx = _lib.Context(0)
+    bad = C.c_uint64(123)
+    _lib.check(_lib.load().urhgpu_test_fast_division_dev(ctx.handle, 7, 4096, C.byref(bad)))     # 4.3e9 pairs
+    assert bad.value == 0

@@ -70,6 +70,7 @@ PROTOTYPES = {
                                     C.POINTER(_i64)]),
     "urhgpu_ppseq_to_bits": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "urhgpu_fir_filter": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "urhgpu_fir_filter_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "urhgpu_iir_filter": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "urhgpu_afp_demod_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp]),
     "urhgpu_grab_pulse_lens_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp, _i64, _vp]),
@@ -80,6 +81,7 @@ PROTOTYPES = {
     "urhgpu_shard_bits_prepare_dev": (_i, [_vp, _vp, _vp]),
     "urhgpu_shard_bits_finish_dev": (_i, [_vp, _vp]),
     "urhgpu_magnitude_chunk_stats_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp]),
+    "urhgpu_test_fast_division_dev": (_i, [_vp, C.c_uint64, _i, C.POINTER(C.c_uint64)]),
     "urhgpu_test_atan2f_dev": (_i, [_vp, _vp, _vp, _i64, _vp]),
 }
 

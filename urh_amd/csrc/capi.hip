@@ -568,6 +568,18 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
     return URHGPU_OK;
 }
 
+int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch) {
+    if (!ctx || !n_mismatch || reps < 0) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_HIP(hipMemsetAsync(ctx->d_counts, 0, 8, ctx->stream));
+    launch_test_div(seed, reps, (unsigned long long *)ctx->d_counts, ctx->stream);
+    URH_HIP(hipGetLastError());
+    URH_HIP(hipMemcpyAsync(ctx->h_counts, ctx->d_counts, 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    *n_mismatch = (uint64_t)ctx->h_counts[0];
+    return URHGPU_OK;
+}
+
 int urhgpu_test_atan2f_dev(urhgpu_ctx *ctx, const float *d_y, const float *d_x, int64_t n, float *d_out) {
     if (!ctx) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
@@ -691,14 +703,85 @@ int urhgpu_ppseq_to_bits(urhgpu_ctx *ctx, const int64_t *rows, int64_t n_rows, i
     return URHGPU_OK;
 }
 
-// ---- not yet implemented on the GPU (round-1 order: FSK/ASK path first) ---------------------------
-int urhgpu_get_magnitudes(urhgpu_ctx *, const void *, int, int64_t, double *) { return URHGPU_ERR_UNSUPPORTED; }
-int urhgpu_fir_filter(urhgpu_ctx *, const float *, int64_t, const float *, int64_t, float *) { return URHGPU_ERR_UNSUPPORTED; }
-int urhgpu_iir_filter(urhgpu_ctx *, const double *, int64_t, const double *, int64_t, const float *, int64_t, float *) {
-    return URHGPU_ERR_UNSUPPORTED;
+int urhgpu_fir_filter_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const float *d_taps, int64_t m,
+                          const float *d_left_halo, float *d_out) {
+    if (!ctx || n < 0 || m < 0 || (n > 0 && (!d_x || !d_out)) || (m > 0 && !d_taps)) return URHGPU_ERR_ARG;
+    if (((uintptr_t)d_x & 7) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_taps & 7) || m > (int64_t)1 << 20) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(launch_fir((const float2 *)d_x, n, (const float2 *)d_taps, (int)m, (const float2 *)d_left_halo, (float2 *)d_out, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
 }
-int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *, const void *, int, int64_t, int64_t, int64_t, double *, double *) {
-    return URHGPU_ERR_UNSUPPORTED;
+
+int urhgpu_fir_filter(urhgpu_ctx *ctx, const float *x, int64_t n, const float *taps, int64_t m, float *out) {
+    if (!ctx || n < 0 || m < 0 || (n > 0 && (!x || !out)) || (m > 0 && !taps)) return URHGPU_ERR_ARG;
+    if (n == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(ctx->staging.reserve(2 * align256((size_t)n * 8) + align256((size_t)std::max<int64_t>(m, 1) * 8) + 1024));
+    ctx->staging.reset();
+    void *d_x = nullptr, *d_t = nullptr;
+    URH_TRY(stage_in(ctx, x, (size_t)n * 8, &d_x));
+    URH_TRY(stage_in(ctx, taps, (size_t)m * 8, &d_t));
+    float *d_out = (float *)ctx->staging.take((size_t)n * 8);
+    if (!d_out) return URHGPU_ERR_ARG;
+    URH_TRY(urhgpu_fir_filter_dev(ctx, (const float *)d_x, n, (const float *)d_t, m, nullptr, d_out));
+    URH_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
+int urhgpu_iir_filter(urhgpu_ctx *ctx, const double *a, int64_t na, const double *b, int64_t nb, const float *x, int64_t n,
+                      float *out) {
+    if (!ctx || n < 0 || na < 0 || nb < 0 || (n > 0 && (!x || !out)) || (na > 0 && !a) || (nb > 0 && !b)) return URHGPU_ERR_ARG;
+    if (n == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(ctx->staging.reserve(2 * align256((size_t)n * 8) + align256((size_t)(na + 1) * 8) + align256((size_t)(nb + 1) * 8) + 1024));
+    ctx->staging.reset();
+    void *d_x = nullptr, *d_a = nullptr, *d_b = nullptr;
+    URH_TRY(stage_in(ctx, x, (size_t)n * 8, &d_x));
+    URH_TRY(stage_in(ctx, a, (size_t)na * 8, &d_a));
+    URH_TRY(stage_in(ctx, b, (size_t)nb * 8, &d_b));
+    float *d_out = (float *)ctx->staging.take((size_t)n * 8);
+    if (!d_out) return URHGPU_ERR_ARG;
+    URH_TRY(launch_iir((const double *)d_a, na, (const double *)d_b, nb, (const float2 *)d_x, n, (float2 *)d_out, ctx->stream));
+    URH_HIP(hipGetLastError());
+    URH_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
+int urhgpu_get_magnitudes(urhgpu_ctx *ctx, const void *iq, int dtype, int64_t n, double *out) {
+    if (!ctx || n < 0 || (n > 0 && (!iq || !out))) return URHGPU_ERR_ARG;
+    const int sb = dtype_bytes(dtype);
+    if (sb == 0) return URHGPU_ERR_DTYPE;
+    if (n == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(ctx->staging.reserve(align256((size_t)n * sb) + align256((size_t)n * 8) + 1024));
+    ctx->staging.reset();
+    void *d_in = nullptr;
+    URH_TRY(stage_in(ctx, iq, (size_t)n * sb, &d_in));
+    double *d_out = (double *)ctx->staging.take((size_t)n * 8);
+    if (!d_out) return URHGPU_ERR_ARG;
+    URH_TRY(launch_magnitudes(d_in, dtype, n, d_out, ctx->stream));
+    URH_HIP(hipGetLastError());
+    URH_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
+int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, int64_t chunk, int64_t n_chunks,
+                                     double *d_sum, double *d_max) {
+    if (!ctx || n < 0 || n_chunks < 0 || (n_chunks > 0 && (!d_iq || !d_sum || !d_max))) return URHGPU_ERR_ARG;
+    if (dtype_bytes(dtype) == 0) return URHGPU_ERR_DTYPE;
+    if (n_chunks == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(ctx->arena.reserve(mag_chunk_scratch_bytes(n_chunks) + 1024));
+    ctx->arena.reset();
+    void *scratch = ctx->arena.take(mag_chunk_scratch_bytes(n_chunks));
+    if (!scratch) return URHGPU_ERR_ARG;
+    URH_TRY(launch_mag_chunk_stats(d_iq, dtype, n, chunk, n_chunks, d_sum, d_max, scratch, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
 }
 
 }  // extern "C"

@@ -156,6 +156,45 @@ __device__ __forceinline__ float atan2f_dev(float y, float x) {
 // the two only differ in the sign of exact zeros, and a signed zero cannot change a non-zero sum.
 constexpr uint32_t kAtanLo = 0x31000000u, kAtanSpan = 0x3ee00000u - 0x31000000u;
 
+// Fast-path division.  For a denominator d in [2^-40, 2^40] and a quotient below 1 the IEEE-correct fp32
+// division the compiler emits (v_div_scale / v_rcp / Newton / two residual corrections / v_div_fmas / v_div_fixup)
+// never scales and never fixes anything up, so the bare Newton + residual chain below returns the same bits with
+// three instructions less per quotient -- and, being plain fma/mul, it packs two quotients per v_pk_* instruction.
+// kReLo/kReSpan express "d is a positive float in [2^-40, 2^40)" as one unsigned compare on d's bits.
+#ifndef URH_FASTDIV
+#define URH_FASTDIV 1
+#endif
+constexpr uint32_t kReLo = 0x2b800000u /* 2^-40 */, kReSpan = 0x53800000u /* 2^40 */ - 0x2b800000u;
+__device__ __forceinline__ float div_fast(float n, float d) {
+#if URH_FASTDIV
+    float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    float q = n * r;
+    const float e2 = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(e2, r, q);
+    const float e3 = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(e3, r, q);
+#else
+    return n / d;
+#endif
+}
+// two quotients at once: the fma chain as 2-vectors (v_pk_fma_f32 / v_pk_mul_f32)
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void div_fast2(float n0, float d0, float n1, float d1, float &q0, float &q1) {
+    const v2f n = {n0, n1}, d = {d0, d1}, one = {1.0f, 1.0f};
+    v2f r = {__builtin_amdgcn_rcpf(d0), __builtin_amdgcn_rcpf(d1)};
+    const v2f e = __builtin_elementwise_fma(-d, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+    v2f q = n * r;
+    const v2f e2 = __builtin_elementwise_fma(-d, q, n);
+    q = __builtin_elementwise_fma(e2, r, q);
+    const v2f e3 = __builtin_elementwise_fma(-d, q, n);
+    q = __builtin_elementwise_fma(e3, r, q);
+    q0 = q.x; q1 = q.y;
+}
+
+
 __device__ __forceinline__ float atan2f_small(float r, float y, float x) {
     // r = |y/x| in [2^-29, 0.4375)
     const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
@@ -235,9 +274,16 @@ __device__ __forceinline__ int demod_pair(const RowIn &r, float prev_c, float pr
         const float pc = dpp_wave_shr1(c1, prev_c), pd = dpp_wave_shr1(d1, prev_d);   // lane-1's second sample
         const float re0 = pc * c0 + pd * d0, im0 = pc * d0 - pd * c0;
         const float re1 = c0 * c1 + d0 * d1, im1 = c0 * d1 - d0 * c1;
+#if URH_FASTDIV
+        float t0, t1;
+        div_fast2(im0, re0, im1, re1, t0, t1);
+        const bool ok0 = (int)((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re0) - kReLo < kReSpan);
+        const bool ok1 = (int)((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re1) - kReLo < kReSpan);
+#else
         const float t0 = im0 / re0, t1 = im1 / re1;
         const bool ok0 = ((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (re0 > 0.0f);
         const bool ok1 = ((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (re1 > 0.0f);
+#endif
         if (any_noise || __builtin_amdgcn_ballot_w64(!(ok0 & ok1)) != 0) return 2;
         q0 = t0 - urh_atanf_poly(t0);
         q1 = t1 - urh_atanf_poly(t1);
@@ -629,6 +675,28 @@ __global__ __launch_bounds__(kAfpBlock) void k_afp_demod(const RunArgs p) {
         }
     }
 }
+// Test hook: out[i] = number of (n, d) pairs (d in the fast-path range, |n/d| < 1) on which div_fast differs from
+// the IEEE division, over `reps` pseudo-random pairs per thread.
+__global__ void k_test_div(uint64_t seed, int reps, unsigned long long *mismatches) {
+    uint64_t s = seed + (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) * 0x9e3779b97f4a7c15ull;
+    unsigned long long bad = 0;
+    for (int i = 0; i < reps; ++i) {
+        s += 0x9e3779b97f4a7c15ull;
+        uint64_t z = s; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31;
+        const uint32_t a = (uint32_t)z, b = (uint32_t)(z >> 32);
+        // d: positive, exponent in [-40, 40); n: |n| <= |d| scaled by a random power of two down to 2^-30
+        const float d = __uint_as_float(((b % 80u + 87u) << 23) | (b >> 9));
+        const float f = __uint_as_float((a & 0x807fffffu) | 0x3f000000u);            // +-[0.5, 1)
+        const float n = f * d * __uint_as_float((127u - (a >> 23) % 31u) << 23);
+        float q2, q3;
+        div_fast2(n, d, d * 0.25f, n == 0.f ? 1.0f : n * 8.0f, q2, q3);   // second slot: another in-range pair when |n*8| is
+        const float q1 = n / d;
+        if (__float_as_uint(q1) != __float_as_uint(q2)) ++bad;
+        if (__float_as_uint(div_fast(n, d)) != __float_as_uint(q1)) ++bad;
+        (void)q3;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
 
 __global__ void k_test_atan2f(const float *y, const float *x, int64_t n, float *out) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
@@ -712,6 +780,10 @@ int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t
         case URHGPU_DT_U16: return launch_afp_2<URHGPU_DT_U16>(a, mod, grid, s);
         default: return URHGPU_ERR_DTYPE;
     }
+}
+
+void launch_test_div(uint64_t seed, int reps, unsigned long long *d_mismatches, hipStream_t s) {
+    hipLaunchKernelGGL(k_test_div, dim3(4096), dim3(256), 0, s, seed, reps, d_mismatches);
 }
 
 void launch_test_atan2f(const float *y, const float *x, int64_t n, float *out, hipStream_t s) {

@@ -1,10 +1,350 @@
-// filters.hip -- FIR / IIR / Costas-loop / magnitude kernels (rows 2, 3, 5, 6, 7 of SURVEY.md §8a).
+// filters.hip -- FIR / IIR / magnitude kernels (rows 2, 3, 6, 7 of SURVEY.md §8a) for gfx950.
+//
+//   k_fir              signal_functions.fir_filter   /root/reference/src/urh/cythonext/signal_functions.pyx:513-525
+//   k_iir_*            signal_functions.iir_filter   /root/reference/src/urh/cythonext/signal_functions.pyx:527-542
+//   k_magnitudes       util.get_magnitudes           /root/reference/src/urh/cythonext/util.pyx:128-136
+//   k_mag_chunk_*      the O(N) part of AutoInterpretation.detect_noise_level
+//                                                    /root/reference/src/urh/ainterpretation/AutoInterpretation.py:60-91
+//
+// Bit-exactness: -ffp-contract=off; every complex product is the 4-multiply / 2-add form the reference's
+// generated C++ evaluates (std::complex<float> operator*), with the C99 Annex G recovery (__mulsc3) when both
+// parts come out NaN; sums are accumulated in the reference's order.
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "common.hpp"
 #include "launchers.hpp"
 
 namespace urh {
+
+// ---- complex64 product exactly as GCC emits it for std::complex<float> / float _Complex --------------------
+__device__ __noinline__ float2 mulsc3_recover(float a, float b, float c, float d, float2 r) {
+    // libgcc __mulsc3 (C99 G.5.1): only reached when both parts are NaN
+    const float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
+    bool recalc = false;
+    if (isinf(a) || isinf(b)) {
+        a = copysignf(isinf(a) ? 1.f : 0.f, a); b = copysignf(isinf(b) ? 1.f : 0.f, b);
+        if (isnan(c)) c = copysignf(0.f, c);
+        if (isnan(d)) d = copysignf(0.f, d);
+        recalc = true;
+    }
+    if (isinf(c) || isinf(d)) {
+        c = copysignf(isinf(c) ? 1.f : 0.f, c); d = copysignf(isinf(d) ? 1.f : 0.f, d);
+        if (isnan(a)) a = copysignf(0.f, a);
+        if (isnan(b)) b = copysignf(0.f, b);
+        recalc = true;
+    }
+    if (!recalc && (isinf(ac) || isinf(bd) || isinf(ad) || isinf(bc))) {
+        if (isnan(a)) a = copysignf(0.f, a);
+        if (isnan(b)) b = copysignf(0.f, b);
+        if (isnan(c)) c = copysignf(0.f, c);
+        if (isnan(d)) d = copysignf(0.f, d);
+        recalc = true;
+    }
+    if (recalc) {
+        r.x = __builtin_inff() * (a * c - b * d);
+        r.y = __builtin_inff() * (a * d + b * c);
+    }
+    return r;
+}
+__device__ __forceinline__ float2 cmul(float2 x, float2 h) {
+    float2 r;
+    r.x = x.x * h.x - x.y * h.y;
+    r.y = x.x * h.y + x.y * h.x;
+    if (__builtin_expect((r.x != r.x) & (r.y != r.y), 0)) r = mulsc3_recover(x.x, x.y, h.x, h.y, r);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FIR: out[k] = sum over i = max(0, k-M+1) .. k (ascending) of x[i] * h[k-i], each term a rounded complex64
+// product, accumulated into a complex64 that starts at +0 (the reference's scatter loop on np.zeros).
+// Roofline: fp32 VALU, not HBM -- 8 non-fused flops per tap per sample against 16 B of traffic per sample
+// (M = 64: 512 flop / 16 B = 32 flop/B, above the fp32 ridge), so the layout serves the VALU: each lane
+// owns R consecutive outputs and slides a register window over the LDS-staged input, taps broadcast from LDS;
+// per tap and lane: one 8-byte LDS read of x, one broadcast read of h, R products.
+// A workgroup of 256 lanes produces kFirTile = 256 * R outputs from kFirTile + H staged inputs.
+// HEAD: this workgroup contains outputs k < M-1 of a capture without left halo (terms with i < 0 do not exist).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFirBlock = 256;
+constexpr int kFirR = 4;
+constexpr int kFirTile = kFirBlock * kFirR;
+
+struct FirArgs {
+    const float2 *x;         // n samples
+    const float2 *halo;      // m - 1 samples preceding x[0] (sharded captures) or nullptr (zero history)
+    const float2 *taps;      // m taps
+    float2 *out;
+    int64_t n;
+    int m;
+    int hist;                // staged history: multiple-of-R tap blocks, >= m - 1
+    int64_t tile0;           // first tile of this launch
+};
+
+template <bool HEAD>
+__global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    float2 *s_taps = (float2 *)s_raw;                       // [m]
+    float2 *s_x = s_taps + ((a.m + 1) & ~1);                // [hist + kFirTile], s_x[u] = x[base - hist + u]
+    const int t = threadIdx.x;
+    const int64_t base = (a.tile0 + blockIdx.x) * (int64_t)kFirTile;
+    for (int j = t; j < a.m; j += kFirBlock) s_taps[j] = a.taps[j];
+    const int total = a.hist + kFirTile;
+    for (int u = t; u < total; u += kFirBlock) {
+        const int64_t i = base - a.hist + u;
+        float2 v = make_float2(0.f, 0.f);
+        if (i >= 0) { if (i < a.n) v = a.x[i]; }
+        else if (a.halo != nullptr && i + (a.m - 1) >= 0) v = a.halo[i + (a.m - 1)];
+        s_x[u] = v;
+    }
+    __syncthreads();
+    constexpr int R = kFirR;
+    const int64_t k0 = base + (int64_t)R * t;               // my first output
+    if (k0 >= a.n) return;
+    float2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
+    const int jb_top = ((a.m - 1) / R) * R;
+    // W[u] = x[k0 - jb - (R-1) + u], u in [0, 2R-1); in LDS: index (R*t + hist) - jb - (R-1) + u
+    float2 W[2 * R - 1];
+    const int lds0 = R * t + a.hist - (R - 1);
+#pragma unroll
+    for (int u = 0; u < R - 1; ++u) W[u + R] = s_x[lds0 - jb_top - R + u + R];   // becomes W[u] after the first shift
+    for (int jb = jb_top; jb >= 0; jb -= R) {
+#pragma unroll
+        for (int u = 0; u < R - 1; ++u) W[u] = W[u + R];
+#pragma unroll
+        for (int u = R - 1; u < 2 * R - 1; ++u) W[u] = s_x[lds0 - jb + u];
+#pragma unroll
+        for (int tj = R - 1; tj >= 0; --tj) {
+            const int j = jb + tj;
+            if (j < a.m) {                                   // wave-uniform
+                const float2 h = s_taps[j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (HEAD && (k0 + r - j < 0)) continue;  // term with i < 0 does not exist
+                    const float2 p = cmul(W[r + (R - 1 - tj)], h);
+                    acc[r].x += p.x;
+                    acc[r].y += p.y;
+                }
+            }
+        }
+    }
+    if (k0 + R <= a.n) {
+        *(float4 *)(a.out + k0) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
+        *(float4 *)(a.out + k0 + 2) = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (k0 + r < a.n) a.out[k0 + r] = acc[r];
+    }
+}
+
+int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const float2 *halo, float2 *out, hipStream_t s) {
+    if (n <= 0) return URHGPU_OK;
+    if (m <= 0) { return hipMemsetAsync(out, 0, (size_t)n * 8, s) == hipSuccess ? URHGPU_OK : URHGPU_ERR_HIP; }
+    FirArgs a;
+    a.x = x; a.halo = halo; a.taps = taps; a.out = out; a.n = n; a.m = m;
+    a.hist = ((m - 1) / kFirR) * kFirR + kFirR - 1;
+    const size_t lds = (size_t)(((m + 1) & ~1) + a.hist + kFirTile) * 8;
+    if (lds > 150 * 1024) return URHGPU_ERR_UNSUPPORTED;       // m <= ~8900 taps
+    if (lds > 64 * 1024) {
+        if (hipFuncSetAttribute((const void *)k_fir<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_fir<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return URHGPU_ERR_HIP;
+    }
+    const int64_t tiles = (n + kFirTile - 1) / kFirTile;
+    // tiles that contain outputs k < m - 1 need the i >= 0 test unless a halo supplies the history
+    int64_t head_tiles = (halo == nullptr) ? std::min<int64_t>(tiles, ((int64_t)m - 1 + kFirTile - 1) / kFirTile) : 0;
+    if (head_tiles > 0) {
+        a.tile0 = 0;
+        hipLaunchKernelGGL(k_fir<true>, dim3((unsigned)head_tiles), dim3(kFirBlock), lds, s, a);
+    }
+    if (tiles > head_tiles) {
+        a.tile0 = head_tiles;
+        hipLaunchKernelGGL(k_fir<false>, dim3((unsigned)(tiles - head_tiles)), dim3(kFirBlock), lds, s, a);
+    }
+    return URHGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// IIR (signal_functions.pyx:527-542):  for n >= max(M, N+1):
+//   y[n] = (((0 + a0 x[n]) + a1 x[n-1]) + ...) + b0 y[n-1] + b1 y[n-2] ...   every product a complex128 multiply
+//   (a[j] + 0j) * complex128(x) rounded to complex64, every += a complex64 add.
+// The feed-forward part is a map (k_iir_ff); the feedback part is a serial recurrence with per-step rounding and
+// runs on ONE lane (k_iir_fb).  Lowest priority row: no production caller in the reference and no asserting test
+// (parity unpinned there; checked here against the oracle / the reference build).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 iir_term(double coef, float2 v) {
+    // (coef + 0j) * (v.x + v.y j) in complex128, rounded to complex64
+    const double re = coef * (double)v.x - 0.0 * (double)v.y;
+    const double im = coef * (double)v.y + 0.0 * (double)v.x;
+    return make_float2((float)re, (float)im);
+}
+
+__global__ void k_iir_ff(const double *a, int64_t M, const float2 *x, int64_t n, int64_t start, float2 *y) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float2 acc = make_float2(0.f, 0.f);
+        if (i >= start) {
+            for (int64_t j = 0; j < M; ++j) {
+                const float2 p = iir_term(a[j], x[i - j]);
+                acc.x += p.x; acc.y += p.y;
+            }
+        }
+        y[i] = acc;
+    }
+}
+
+__global__ void k_iir_fb(const double *b, int64_t N, int64_t n, int64_t start, float2 *y) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int64_t i = start; i < n; ++i) {
+        float2 acc = y[i];
+        for (int64_t k = 0; k < N; ++k) {
+            const float2 p = iir_term(b[k], y[i - 1 - k]);
+            acc.x += p.x; acc.y += p.y;
+        }
+        y[i] = acc;
+    }
+}
+
+int launch_iir(const double *a, int64_t M, const double *b, int64_t N, const float2 *x, int64_t n, float2 *y, hipStream_t s) {
+    if (n <= 0) return URHGPU_OK;
+    const int64_t start = std::max<int64_t>(M, N + 1);
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_iir_ff, dim3(grid), dim3(256), 0, s, a, M, x, n, start, y);
+    if (N > 0 && start < n) hipLaunchKernelGGL(k_iir_fb, dim3(1), dim3(64), 0, s, b, N, n, start, y);
+    return URHGPU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Magnitudes (util.pyx:128-136): float input -> (double) sqrtf(I*I + Q*Q) in fp32; integer input -> products and sum
+// in C `int` (wrapping, as the reference's generated code), sqrt in double.
+// ---------------------------------------------------------------------------------------------------------------
+template <int DT> struct MagLoad;
+template <> struct MagLoad<URHGPU_DT_F32> {
+    static __device__ __forceinline__ double mag(const void *p, int64_t i) {
+        const float2 v = ((const float2 *)p)[i];
+        return (double)__builtin_sqrtf(v.x * v.x + v.y * v.y);
+    }
+};
+template <class T2> __device__ __forceinline__ double int_mag(int re, int im) {
+    const int s = (int)((unsigned)(re * re) + (unsigned)(im * im));
+    return __builtin_sqrt((double)s);
+}
+template <> struct MagLoad<URHGPU_DT_I8> {
+    static __device__ __forceinline__ double mag(const void *p, int64_t i) { const char2 v = ((const char2 *)p)[i]; return int_mag<void>(v.x, v.y); }
+};
+template <> struct MagLoad<URHGPU_DT_U8> {
+    static __device__ __forceinline__ double mag(const void *p, int64_t i) { const uchar2 v = ((const uchar2 *)p)[i]; return int_mag<void>(v.x, v.y); }
+};
+template <> struct MagLoad<URHGPU_DT_I16> {
+    static __device__ __forceinline__ double mag(const void *p, int64_t i) { const short2 v = ((const short2 *)p)[i]; return int_mag<void>(v.x, v.y); }
+};
+template <> struct MagLoad<URHGPU_DT_U16> {
+    static __device__ __forceinline__ double mag(const void *p, int64_t i) {
+        const ushort2 v = ((const ushort2 *)p)[i];
+        // 65535^2 overflows C int: wrap like the reference (unsigned arithmetic, same two's-complement bits)
+        const int s = (int)((unsigned)v.x * (unsigned)v.x + (unsigned)v.y * (unsigned)v.y);
+        return __builtin_sqrt((double)s);
+    }
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_magnitudes(const void *iq, int64_t n, double *out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = MagLoad<DT>::mag(iq, i);
+}
+
+// Chunk statistics: chunk k (counted from the END of the capture) = samples [n - (k+1)*chunk, n - k*chunk).
+// Two deterministic stages: workgroup (slice, k) reduces one slice of chunk k to (sum, max); then one lane per
+// chunk adds the slices in order.  Sums are fp64 (the reference's np.mean is an fp64 pairwise sum: the fp32-cast
+// means agree unless an fp64 sum lands within an ulp of an fp32 rounding boundary).
+constexpr int kMagSlices = 32;
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_mag_chunk_partials(const void *iq, int64_t n, int64_t chunk, double *part_sum, double *part_max) {
+    __shared__ double s_sum[4], s_max[4];
+    const int64_t k = blockIdx.y;
+    const int64_t lo = n - (k + 1) * chunk, hi = lo + chunk;
+    const int64_t L = (chunk + kMagSlices - 1) / kMagSlices;
+    const int64_t a0 = lo + (int64_t)blockIdx.x * L;
+    const int64_t a1 = (a0 + L < hi) ? a0 + L : hi;
+    double sum = 0.0, mx = 0.0;
+    bool any_nan = false;
+    for (int64_t i = a0 + threadIdx.x; i < a1; i += 256) {
+        const double v = MagLoad<DT>::mag(iq, i);
+        sum += v;
+        if (v != v) any_nan = true; else mx = (v > mx) ? v : mx;
+    }
+    if (any_nan) mx = __builtin_nan("");
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        sum += __shfl_down(sum, o);
+        const double om = __shfl_down(mx, o);
+        mx = (om != om || mx != mx) ? __builtin_nan("") : ((om > mx) ? om : mx);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { s_sum[wave] = sum; s_max[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double ts = 0.0, tm = 0.0; bool nan = false;
+        for (int w = 0; w < 4; ++w) { ts += s_sum[w]; if (s_max[w] != s_max[w]) nan = true; else tm = (s_max[w] > tm) ? s_max[w] : tm; }
+        part_sum[k * kMagSlices + blockIdx.x] = ts;
+        part_max[k * kMagSlices + blockIdx.x] = nan ? __builtin_nan("") : tm;
+    }
+}
+
+__global__ void k_mag_chunk_finish(const double *part_sum, const double *part_max, int64_t n_chunks, double *d_sum, double *d_max) {
+    const int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (k >= n_chunks) return;
+    double ts = 0.0, tm = 0.0; bool nan = false;
+    for (int s = 0; s < kMagSlices; ++s) {
+        ts += part_sum[k * kMagSlices + s];
+        const double m = part_max[k * kMagSlices + s];
+        if (m != m) nan = true; else tm = (m > tm) ? m : tm;
+    }
+    d_sum[k] = ts;
+    d_max[k] = nan ? __builtin_nan("") : tm;
+}
+
+template <int DT>
+static void launch_mag_dt(const void *iq, int64_t n, double *out, int64_t chunk, int64_t n_chunks, double *ps, double *pm,
+                          double *d_sum, double *d_max, hipStream_t s) {
+    if (out) {
+        const int grid = (int)std::min<int64_t>((n + 255) / 256, 8192);
+        hipLaunchKernelGGL(k_magnitudes<DT>, dim3(grid), dim3(256), 0, s, iq, n, out);
+    } else {
+        hipLaunchKernelGGL(k_mag_chunk_partials<DT>, dim3(kMagSlices, (unsigned)n_chunks), dim3(256), 0, s, iq, n, chunk, ps, pm);
+        hipLaunchKernelGGL(k_mag_chunk_finish, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, s, ps, pm, n_chunks, d_sum, d_max);
+    }
+}
+
+static int launch_mag_any(int dtype, const void *iq, int64_t n, double *out, int64_t chunk, int64_t n_chunks, double *ps,
+                          double *pm, double *d_sum, double *d_max, hipStream_t s) {
+    switch (dtype) {
+        case URHGPU_DT_F32: launch_mag_dt<URHGPU_DT_F32>(iq, n, out, chunk, n_chunks, ps, pm, d_sum, d_max, s); return URHGPU_OK;
+        case URHGPU_DT_I8: launch_mag_dt<URHGPU_DT_I8>(iq, n, out, chunk, n_chunks, ps, pm, d_sum, d_max, s); return URHGPU_OK;
+        case URHGPU_DT_U8: launch_mag_dt<URHGPU_DT_U8>(iq, n, out, chunk, n_chunks, ps, pm, d_sum, d_max, s); return URHGPU_OK;
+        case URHGPU_DT_I16: launch_mag_dt<URHGPU_DT_I16>(iq, n, out, chunk, n_chunks, ps, pm, d_sum, d_max, s); return URHGPU_OK;
+        case URHGPU_DT_U16: launch_mag_dt<URHGPU_DT_U16>(iq, n, out, chunk, n_chunks, ps, pm, d_sum, d_max, s); return URHGPU_OK;
+        default: return URHGPU_ERR_DTYPE;
+    }
+}
+
+int launch_magnitudes(const void *iq, int dtype, int64_t n, double *out, hipStream_t s) {
+    if (n <= 0) return URHGPU_OK;
+    return launch_mag_any(dtype, iq, n, out, 0, 0, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+size_t mag_chunk_scratch_bytes(int64_t n_chunks) { return (size_t)n_chunks * kMagSlices * 16 + 512; }
+
+int launch_mag_chunk_stats(const void *iq, int dtype, int64_t n, int64_t chunk, int64_t n_chunks, double *d_sum, double *d_max,
+                           void *scratch, hipStream_t s) {
+    if (n_chunks <= 0) return URHGPU_OK;
+    if (chunk <= 0 || n_chunks * chunk > n || n_chunks > 65535) return URHGPU_ERR_ARG;
+    double *ps = (double *)scratch;
+    double *pm = ps + n_chunks * kMagSlices;
+    return launch_mag_any(dtype, iq, n, nullptr, chunk, n_chunks, ps, pm, d_sum, d_max, s);
+}
 
 int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad) {
     (void)ctx; (void)d_iq; (void)n; (void)p; (void)d_qad;

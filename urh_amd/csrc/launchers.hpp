@@ -32,6 +32,7 @@ struct RunArgs {
 int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s);
 int launch_runs_qad(const RunArgs &a, hipStream_t s);
 int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t s);
+void launch_test_div(uint64_t seed, int reps, unsigned long long *d_mismatches, hipStream_t s);
 void launch_test_atan2f(const float *y, const float *x, int64_t n, float *out, hipStream_t s);
 
 // ---- pulse_table.hip ---------------------------------------------------------------------------------
@@ -136,6 +137,12 @@ void launch_merge_fix(int64_t *rows, const int64_t *d_n_rows, const int64_t *d_a
 void launch_bits_extra(const int64_t *d_all, int rank, int world, int32_t *d_extra, hipStream_t s);
 
 // ---- filters.hip ---------------------------------------------------------------------------------------
+int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const float2 *halo, float2 *out, hipStream_t s);
+int launch_iir(const double *a, int64_t M, const double *b, int64_t N, const float2 *x, int64_t n, float2 *y, hipStream_t s);
+int launch_magnitudes(const void *iq, int dtype, int64_t n, double *out, hipStream_t s);
+size_t mag_chunk_scratch_bytes(int64_t n_chunks);
+int launch_mag_chunk_stats(const void *iq, int dtype, int64_t n, int64_t chunk, int64_t n_chunks, double *d_sum, double *d_max,
+                           void *scratch, hipStream_t s);
 int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad);
 
 }  // namespace urh
