@@ -60,6 +60,16 @@ __global__ __launch_bounds__(256) void k_ceiling_chunked(const float4 *in, float
         out[b0 + i] = make_float2(v.x + v.y, v.z + v.w);
     }
 }
+typedef float kv4 __attribute__((ext_vector_type(4)));
+typedef float kv2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_ceiling_chunked_nt(const kv4 *in, kv2 *out, int64_t pairs_per_block) {
+    const int64_t b0 = blockIdx.x * pairs_per_block;
+    for (int64_t i = threadIdx.x; i < pairs_per_block; i += 256) {
+        const kv4 v = __builtin_nontemporal_load(in + b0 + i);
+        const kv2 o = {v.x + v.y, v.z + v.w};
+        __builtin_nontemporal_store(o, out + b0 + i);
+    }
+}
 
 static float time_ms(hipStream_t s, int iters, void (*fn)(void *), void *arg) {
     hipEvent_t e0, e1;
@@ -123,6 +133,8 @@ int main(int argc, char **argv) {
     c.grid = (int)n_chunks;
     ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; hipLaunchKernelGGL(k_ceiling_chunked, dim3(c->grid), dim3(256), 0, c->s, c->in4, c->out2, c->n_pairs / c->grid); }, &c);
     printf("ceiling chunked (%lld wg)        %8.4f ms  %7.1f GB/s\n", (long long)n_chunks, ms, n * 12.0 / ms / 1e6);
+    ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; hipLaunchKernelGGL(k_ceiling_chunked_nt, dim3(c->grid), dim3(256), 0, c->s, (const kv4 *)c->in4, (kv2 *)c->out2, c->n_pairs / c->grid); }, &c);
+    printf("ceiling chunked nt (%lld wg)     %8.4f ms  %7.1f GB/s\n", (long long)n_chunks, ms, n * 12.0 / ms / 1e6);
     ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; LAUNCH(c->a, URHGPU_MOD_FSK, true, c->s); }, &c);
     printf("k_demod_runs FSK (qad written)  %8.4f ms  %7.1f GB/s (12 B/sample)\n", ms, n * 12.0 / ms / 1e6);
     ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; LAUNCH(c->a, URHGPU_MOD_FSK, false, c->s); }, &c);

@@ -158,7 +158,7 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
     e.rows = rows_stage; e.cap_rows = cap_rows; e.d_ts_carry = nullptr; e.is_ask = ask ? 1 : 0; e.sps = p->samples_per_symbol;
     URH_TRY(launch_emit_rows(e, pl.n_chunks, s));
-    if (ask) URH_TRY(launch_merge_rows_ask(rows_stage, d_n_stage, cap_rows, d_rows, cap_rows, d_n_rows, merge_scratch, s));
+    if (ask) URH_TRY(launch_merge_rows_ask(rows_stage, d_n_stage, cap_rows, d_rows, cap_rows, d_n_rows, merge_scratch, ctx->d_tickets, s));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }
@@ -239,6 +239,8 @@ int urhgpu_ctx_create(int device, urhgpu_ctx **out) {
     URH_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     URH_HIP(hipMalloc((void **)&ctx->d_counts, 16 * sizeof(int64_t)));
+    URH_HIP(hipMalloc((void **)&ctx->d_tickets, 8 * sizeof(int32_t)));
+    URH_HIP(hipMemset(ctx->d_tickets, 0, 8 * sizeof(int32_t)));
     URH_HIP(hipHostMalloc((void **)&ctx->h_counts, 16 * sizeof(int64_t)));
     *out = ctx;
     return URHGPU_OK;
@@ -253,6 +255,7 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     delete (ShardSession *)ctx->shard;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
+    if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -370,7 +373,7 @@ int urhgpu_grab_pulse_lens_dev(urhgpu_ctx *ctx, const float *d_qad, int64_t n, c
 static int ppseq_to_bits_inner(urhgpu_ctx *ctx, const int64_t *d_rows, const int64_t *d_n_rows, int64_t cap,
                                const urhgpu_params *p, const urhgpu_outputs *out, void *scratch) {
     BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts};
-    URH_TRY(launch_ppseq_to_bits(d_rows, d_n_rows, cap, bits_params(p), bo, scratch, ctx->stream));
+    URH_TRY(launch_ppseq_to_bits(d_rows, d_n_rows, cap, bits_params(p), bo, scratch, ctx->d_tickets, ctx->stream));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }
@@ -521,7 +524,7 @@ int urhgpu_shard_rows_dev(urhgpu_ctx *ctx, const void *d_summaries, int64_t *d_m
     ss->d_row_base = r.sc.out_off + rank;
     if (ask) {
         URH_TRY(launch_merge_rows_ask(ss->rows_stage, ss->d_n_stage, ss->out.cap_rows, ss->out.rows, ss->out.cap_rows,
-                                      ss->d_small + 3, ss->merge_scratch, s));
+                                      ss->d_small + 3, ss->merge_scratch, ctx->d_tickets, s));
         launch_merge_summary(ss->out.rows, ss->d_small + 3, d_merge, s);
     }
     URH_HIP(hipGetLastError());
@@ -543,7 +546,7 @@ int urhgpu_shard_bits_prepare_dev(urhgpu_ctx *ctx, const int64_t *d_merge_all, i
     BitsParams bp = bits_params(&ss->p);
     bp.d_row_base = ss->d_row_base; bp.d_ts_carry = ss->d_small; bp.d_absorbed = ask ? ss->d_small + 1 : nullptr;
     bp.d_extra = (const int32_t *)(ss->d_small + 2); bp.is_last_rank = (ss->rank == ss->world - 1) ? 1 : 0;
-    URH_TRY(launch_bits_prepare(ss->out.rows, d_n_rows, std::max<int64_t>(ss->out.cap_rows, 1), bp, ss->bits_scratch, d_flags, s));
+    URH_TRY(launch_bits_prepare(ss->out.rows, d_n_rows, std::max<int64_t>(ss->out.cap_rows, 1), bp, ss->bits_scratch, d_flags, ctx->d_tickets, s));
     URH_HIP(hipGetLastError());
     ss->phase = 3;
     return URHGPU_OK;
@@ -562,7 +565,7 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
     bp.d_extra = (const int32_t *)(ss->d_small + 2); bp.is_last_rank = (ss->rank == ss->world - 1) ? 1 : 0;
     const urhgpu_outputs &o = ss->out;
     BitsOut bo{o.bits, o.cap_bits, o.msg_off, o.pauses, o.cap_msg, o.pos, o.cap_pos, o.pos_off, o.counts};
-    URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, s));
+    URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, ctx->d_tickets, s));
     URH_HIP(hipGetLastError());
     ss->phase = 0;
     return URHGPU_OK;

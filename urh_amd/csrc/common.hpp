@@ -58,6 +58,7 @@ struct urhgpu_ctx {
     urh::Arena staging;      // device mirrors of host buffers for the host-pointer entry points
     int64_t *d_counts = nullptr;   // small device result block (8 x int64)
     int64_t *h_counts = nullptr;   // pinned host mirror
+    int32_t *d_tickets = nullptr;  // 8 zeroed ints: elections of the fused scan kernels (scan.hpp)
     // optional timing of the dominant kernel (demod + run segmentation) with HIP events on `stream`
     std::vector<hipEvent_t> prof_events;   // pairs: [2k] before, [2k+1] after
     int prof_used = 0;                     // pairs recorded since urhgpu_ctx_profile_begin

@@ -42,6 +42,15 @@ enum { SRC_IQ = 0, SRC_QAD = 1 };
 #ifndef URH_MINWAVES
 #define URH_MINWAVES 1
 #endif
+#ifndef URH_EXP
+#define URH_EXP 0         // timing experiments (tools/kbench only); 0 in the product
+#endif
+#ifndef URH_SPEC
+#define URH_SPEC 1        // branch-free speculative fast path per batch of rows (see spec_pair)
+#endif
+#ifndef URH_NT
+#define URH_NT 1          // non-temporal IQ loads / qad stores (streamed once): +8 % on the copy ceiling, tools/kbench
+#endif
 
 // ---- small device helpers ---------------------------------------------------------------------
 __device__ __forceinline__ float dpp_wave_shr1(float x, float lane0) {
@@ -56,7 +65,12 @@ template <int DT> struct Iq;
 template <> struct Iq<URHGPU_DT_F32> {
     static constexpr int kBytes = 8;
     static __device__ __forceinline__ void load2(const void *b, int64_t i, float &c0, float &d0, float &c1, float &d1) {
+#if URH_NT
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load((const v4f *)b + (i >> 1)); c0 = v.x; d0 = v.y; c1 = v.z; d1 = v.w;
+#else
         float4 v = ((const float4 *)b)[i >> 1]; c0 = v.x; d0 = v.y; c1 = v.z; d1 = v.w;
+#endif
     }
     static __device__ __forceinline__ void load1(const void *b, int64_t i, float &c, float &d) {
         float2 v = ((const float2 *)b)[i]; c = v.x; d = v.y;
@@ -284,9 +298,17 @@ __device__ __forceinline__ int demod_pair(const RowIn &r, float prev_c, float pr
         const bool ok0 = ((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (re0 > 0.0f);
         const bool ok1 = ((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (re1 > 0.0f);
 #endif
+#if URH_EXP == 2 || URH_EXP == 3     // timing experiment only (tools/kbench): no range test
+        if (any_noise) return 2;
+#else
         if (any_noise || __builtin_amdgcn_ballot_w64(!(ok0 & ok1)) != 0) return 2;
+#endif
+#if URH_EXP == 1 || URH_EXP == 3     // timing experiment only: no polynomial
+        q0 = t0; q1 = t1;
+#else
         q0 = t0 - urh_atanf_poly(t0);
         q1 = t1 - urh_atanf_poly(t1);
+#endif
         return 0;
     }
     if (MOD == URHGPU_MOD_ASK) {
@@ -299,6 +321,32 @@ __device__ __forceinline__ int demod_pair(const RowIn &r, float prev_c, float pr
     q0 = n0 ? p.noise_val : q0;
     q1 = n1 ? p.noise_val : q1;
     return 1;
+}
+
+// Branch-free speculative form of demod_pair's common case: computes the fast-path result of a lane's two
+// samples unconditionally and returns true when the lane needs anything else (a noise-gated sample, an FSK
+// quotient outside the fast range).  The caller ballots the flags of a whole batch of rows once and sends only
+// the flagged rows through demod_pair: the hot loop has no per-row branches and the rows' dependent chains interleave.
+template <int MOD>
+__device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float prev_d, const RunArgs &p, float &q0, float &q1) {
+    const float c0 = r.c0, d0 = r.d0, c1 = r.c1, d1 = r.d1;
+    const float mag0 = c0 * c0 + d0 * d0, mag1 = c1 * c1 + d1 * d1;
+    const bool n0 = mag0 <= p.noise_sqrd, n1 = mag1 <= p.noise_sqrd;
+    if (MOD == URHGPU_MOD_FSK) {
+        const float pc = dpp_wave_shr1(c1, prev_c), pd = dpp_wave_shr1(d1, prev_d);
+        const float re0 = pc * c0 + pd * d0, im0 = pc * d0 - pd * c0;
+        const float re1 = c0 * c1 + d0 * d1, im1 = c0 * d1 - d0 * c1;
+        float t0, t1;
+        div_fast2(im0, re0, im1, re1, t0, t1);
+        const bool ok0 = (int)((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re0) - kReLo < kReSpan);
+        const bool ok1 = (int)((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re1) - kReLo < kReSpan);
+        q0 = t0 - urh_atanf_poly(t0);
+        q1 = t1 - urh_atanf_poly(t1);
+        return n0 | n1 | !ok0 | !ok1;
+    }
+    q0 = __builtin_sqrtf(mag0) / p.max_magnitude;
+    q1 = __builtin_sqrtf(mag1) / p.max_magnitude;
+    return n0 | n1;
 }
 
 // The general FSK row (any operand class, any angle, noise gating).  Deliberately rolled up (one
@@ -433,6 +481,38 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
                 float q0[kBatch], q1[kBatch];
                 uint32_t general = 0, gated = 0;                        // per-row flags, wavefront-uniform
                 float pcs[kBatch], pds[kBatch];                         // seam operand of each row (uniform)
+#if URH_SPEC
+                if (SRC == SRC_IQ && MOD != URHGPU_MOD_OTHER) {
+                    bool flag[kBatch];
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) {
+                        pcs[j] = prev_c; pds[j] = prev_d;
+                        flag[j] = spec_pair<MOD>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
+                        if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
+                    }
+                    uint32_t bad = 0;
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) if (__builtin_amdgcn_ballot_w64(flag[j]) != 0) bad |= 1u << j;
+                    if (__builtin_expect(bad != 0, 0)) {
+#pragma unroll 1
+                        for (int j = 0; j < kBatch; ++j) {
+                            if (!((bad >> j) & 1u)) continue;
+                            RowIn r = cur[0]; float pc = pcs[0], pd = pds[0];
+#pragma unroll
+                            for (int k = 1; k < kBatch; ++k) if (j == k) { r = cur[k]; pc = pcs[k]; pd = pds[k]; }
+                            float g0 = 0.f, g1 = 0.f;
+                            const int kind = demod_pair<MOD>(r, pc, pd, p, g0, g1);
+                            if (kind == 2) general |= 1u << j;
+                            else {
+#pragma unroll
+                                for (int k = 0; k < kBatch; ++k) if (j == k) { q0[k] = g0; q1[k] = g1; }
+                            }
+                            if (kind != 0) gated |= 1u << j;
+                        }
+                    }
+                } else
+#endif
+                {
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) {
                     if (SRC == SRC_QAD) { q0[j] = cur[j].c0; q1[j] = cur[j].d0; gated |= 1u << j; continue; }
@@ -441,6 +521,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
                     if (k == 2) general |= 1u << j;
                     if (k != 0) gated |= 1u << j;
                     if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
+                }
                 }
                 if (MOD == URHGPU_MOD_FSK && SRC == SRC_IQ && general) {
 #pragma unroll 1
@@ -461,7 +542,12 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
                     if (SRC == SRC_IQ) {
                         if (j == 0 && rb == 0 && first_row) q0[0] = p.noise_val;        // result[0] = NOISE (:361)
                         if (WRITE_QAD) {
+#if URH_NT
+                            typedef float v2s __attribute__((ext_vector_type(2)));
+                            if (FULL || ta + off + 1 < a1) { const v2s qq = {q0[j], q1[j]}; __builtin_nontemporal_store(qq, (v2s *)(p.qad + ta + off)); }
+#else
                             if (FULL || ta + off + 1 < a1) *(float2 *)(p.qad + ta + off) = make_float2(q0[j], q1[j]);
+#endif
                             else if (ta + off < a1) p.qad[ta + off] = q0[j];
                         }
                     }

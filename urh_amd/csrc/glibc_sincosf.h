@@ -1,0 +1,112 @@
+// Bit-faithful fp32 sinf / cosf of glibc 2.35 (sysdeps/ieee754/flt-32/s_sincosf.h, s_sinf.c, s_cosf.c,
+// s_sincosf_data.c -- the ARM "optimized routines" algorithm), usable from HIP device code and host C/C++.
+//
+// WHY: the reference's Costas loop evaluates cosf(-phase) / sinf(-phase) per sample
+// (/root/reference/src/urh/cythonext/signal_functions.pyx:301; compiled as C++, GCC merges the pair into
+// sincosf, which computes the same two polynomials), and its output feeds back into the loop, so a 1-ulp
+// difference anywhere changes every later sample.  glibc's routines work in DOUBLE precision (range reduction by
+// one multiply-subtract with pi/2, degree-7/8 polynomials) and round once to float; they are not correctly
+// rounded.  x86-64 glibc selects at run time (ifunc) between a build without FMA (`__sinf_sse2`) and one compiled
+// with -mfma (`__sinf_fma`, chosen on every CPU with FMA+AVX2), in which GCC contracts every a + b*c into an fma:
+// URH_SINCOSF_FMA selects that evaluation (default 1: all hosts of interest have FMA).  The two differ in the
+// rounded float for about one input in 10^9.
+// Only |x| < 120 is restated (fast reduction): the Costas phase is kept within +-2*pi.  Larger arguments return
+// NaN through urh_sincosf_unsupported so that a misuse cannot go unnoticed.
+// Constants are the published ones of ARM optimized-routines (MIT licence) as shipped in glibc.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define URH_SC_HD __host__ __device__ __forceinline__
+#else
+#include <math.h>
+#define URH_SC_HD static inline
+#endif
+
+#ifndef URH_SINCOSF_FMA
+#define URH_SINCOSF_FMA 1
+#endif
+
+URH_SC_HD double urh_sc_madd(double a, double b, double c) {   // a + b * c as the selected libm build evaluates it
+#if URH_SINCOSF_FMA
+    return __builtin_fma(b, c, a);
+#else
+    return a + b * c;
+#endif
+}
+
+URH_SC_HD uint32_t urh_sc_abstop12(float x) {
+    union { float f; uint32_t u; } v; v.f = x;
+    return (v.u >> 20) & 0x7ff;
+}
+
+// polynomial table entry 0 / 1 (entry 1: cosine polynomial negated)
+URH_SC_HD float urh_sinf_poly(double x, double x2, int neg_cos, int n) {
+    const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = urh_sc_madd(s2c, x2, s3c);
+        const double x7 = x3 * x2;
+        const double s = urh_sc_madd(x, x3, s1c);
+        return (float)urh_sc_madd(s, x7, s1);
+    } else {
+        const double sg = neg_cos ? -1.0 : 1.0;
+        const double c0 = sg * 0x1p0, c1c = sg * -0x1.ffffffd0c621cp-2, c2c = sg * 0x1.55553e1068f19p-5,
+                     c3c = sg * -0x1.6c087e89a359dp-10, c4c = sg * 0x1.99343027bf8c3p-16;
+        const double x4 = x2 * x2;
+        const double c2 = urh_sc_madd(c3c, x2, c4c);
+        const double c1 = urh_sc_madd(c0, x2, c1c);
+        const double x6 = x4 * x2;
+        const double c = urh_sc_madd(c1, x4, c2c);
+        return (float)urh_sc_madd(c, x6, c2);
+    }
+}
+
+// reduce_fast (!TOINT_INTRINSICS, x86-64): quadrant from a 2^24-scaled float->int conversion
+URH_SC_HD double urh_sc_reduce_fast(double x, int *np) {
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double r = x * hpi_inv;
+    const int n = ((int32_t)r + 0x800000) >> 24;
+    *np = n;
+#if URH_SINCOSF_FMA
+    return __builtin_fma(-(double)n, hpi, x);
+#else
+    return x - (double)n * hpi;
+#endif
+}
+
+URH_SC_HD float urh_sincosf_unsupported(void) {
+    union { uint32_t u; float f; } v; v.u = 0x7fc00000u; return v.f;
+}
+
+URH_SC_HD float urh_sinf(float y) {
+    double x = y;
+    if (urh_sc_abstop12(y) < 0x3f4) {                       // |y| < pi/4 (abstop12(0x1.921FB6p-1f))
+        const double s = x * x;
+        if (urh_sc_abstop12(y) < 0x398) return y;           // |y| < 2^-12
+        return urh_sinf_poly(x, s, 0, 0);
+    }
+    if (urh_sc_abstop12(y) < 0x42f) {                       // |y| < 120
+        int n;
+        x = urh_sc_reduce_fast(x, &n);
+        const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;     // sign[] = {1, -1, -1, 1}
+        return urh_sinf_poly(x * s, x * x, (n & 2) != 0, n);
+    }
+    return urh_sincosf_unsupported();
+}
+
+URH_SC_HD float urh_cosf(float y) {
+    double x = y;
+    if (urh_sc_abstop12(y) < 0x3f4) {
+        const double x2 = x * x;
+        if (urh_sc_abstop12(y) < 0x398) return 1.0f;
+        return urh_sinf_poly(x, x2, 0, 1);
+    }
+    if (urh_sc_abstop12(y) < 0x42f) {
+        int n;
+        x = urh_sc_reduce_fast(x, &n);
+        const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        return urh_sinf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
+    }
+    return urh_sincosf_unsupported();
+}

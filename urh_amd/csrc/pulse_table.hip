@@ -40,10 +40,8 @@ ResolveScratch resolve_scratch_carve(void *mem, int64_t n_chunks) {
     return sc;
 }
 
-// R1: one thread per chunk.
-__global__ __launch_bounds__(256) void k_chunk_stable(const ResolveArgs a) {
-    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c >= a.n_chunks) return;
+// R1: per chunk.
+__device__ __forceinline__ void chunk_stable(const ResolveArgs &a, int64_t c) {
     ChunkInfo *ch = a.chunks;
     int ps = 0;
     const int64_t pend_pos = ch[c].pend_pos;
@@ -116,7 +114,7 @@ __device__ void block_scan_max_sum(const int32_t *in_max, int32_t *out_max, cons
 }
 
 // S1: prev_stable = exclusive last-valid scan of has_stable.
-__global__ __launch_bounds__(kResolveBlock) void k_scan_stable(const ResolveArgs a) {
+__device__ __forceinline__ void scan_stable(const ResolveArgs &a) {
     int32_t tm; int64_t ts;
     block_scan_max_sum<false>(a.sc.has_stable, a.sc.prev_stable, nullptr, nullptr, a.n_chunks, tm, ts);
     if (threadIdx.x == 0) a.aux->last_stable = tm;
@@ -124,10 +122,8 @@ __global__ __launch_bounds__(kResolveBlock) void k_scan_stable(const ResolveArgs
 
 __device__ __forceinline__ uint32_t chunk_last_stable_state(const ChunkInfo &ci) { return ci.pend_stable ? ci.pend_state : ci.last_state; }
 
-// R2: one thread per chunk: acceptance of the tentative first record / the pending run, counts.
-__global__ __launch_bounds__(256) void k_chunk_accept(const ResolveArgs a) {
-    const int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (c >= a.n_chunks) return;
+// R2: per chunk: acceptance of the tentative first record / the pending run, counts.
+__device__ __forceinline__ void chunk_accept(const ResolveArgs &a, int64_t c) {
     ChunkInfo *ch = a.chunks;
     const int32_t ip = a.sc.prev_stable[c];
     const uint32_t prev_state = (ip < 0) ? (a.local_pass ? 0xFFFFu : (uint32_t)ch[0].init_state) : chunk_last_stable_state(ch[ip]);
@@ -150,7 +146,7 @@ __device__ __forceinline__ void chunk_last_acc(const ChunkInfo &ci, int64_t &pos
 
 // S2: out_off = exclusive sum of out_cnt, prev_acc = exclusive last-valid scan of has_acc; totals and
 // the final row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487).
-__global__ __launch_bounds__(kResolveBlock) void k_scan_accept(const ResolveArgs a) {
+__device__ __forceinline__ void scan_accept(const ResolveArgs &a) {
     int32_t last_c; int64_t P;
     block_scan_max_sum<true>(a.sc.has_acc, a.sc.prev_acc, a.sc.out_cnt, a.sc.out_off, a.n_chunks, last_c, P);
     if (threadIdx.x == 0) {
@@ -198,6 +194,22 @@ __global__ __launch_bounds__(kResolveBlock) void k_scan_accept(const ResolveArgs
         *a.d_n_rows_needed = n_rows;
         *a.d_n_rows = (a.rows != nullptr && n_rows > a.cap_rows) ? a.cap_rows : n_rows;
     }
+}
+
+// The whole resolve stage as ONE single-workgroup launch (the table is small: ~16 K entries at 1 GiB): the four
+// phases are separated by workgroup barriers instead of kernel boundaries.
+__global__ __launch_bounds__(kResolveBlock) void k_resolve(const ResolveArgs a) {
+    if (threadIdx.x == 0) {
+        a.aux->first_nonlead = kAuxNone; a.aux->open_chunk = kAuxNone; a.aux->first_stable = kAuxNone; a.aux->last_stable = -1;
+    }
+    __syncthreads();
+    for (int64_t c = threadIdx.x; c < a.n_chunks; c += kResolveBlock) chunk_stable(a, c);
+    __syncthreads();
+    scan_stable(a);
+    __syncthreads();
+    for (int64_t c = threadIdx.x; c < a.n_chunks; c += kResolveBlock) chunk_accept(a, c);
+    __syncthreads();
+    scan_accept(a);
 }
 
 // =====================================================================================================
@@ -422,15 +434,19 @@ struct GroupStore {
     }
 };
 
-// counts = {n_rows, n_msg, n_bits, n_pos}; also terminates msg_off / pos_off
-__global__ void k_bits_counts(const int64_t *d_n_rows, const VecK<3> *grand, int64_t *msg_off, int64_t *pos_off,
-                              int64_t cap_msg, int64_t *counts) {
-    const int64_t n_rows = *d_n_rows;
-    VecK<3> g; g.zero();
-    if (n_rows > 0) g = *grand;
-    counts[0] = n_rows; counts[1] = g.v[0]; counts[2] = g.v[1]; counts[3] = g.v[2];
-    msg_off[0] = 0; pos_off[0] = 0;          // msg_off[m + 1] / pos_off[m + 1] = END of message m (GroupStore)
-}
+// Runs once after the group scan: counts = {n_rows, n_msg, n_bits, n_pos}; msg_off[0] = pos_off[0] = 0
+// (msg_off[m + 1] / pos_off[m + 1] = END of message m, written by GroupStore).
+struct BitsCountsFinal {
+    const int64_t *d_n_rows;
+    int64_t *msg_off, *pos_off, *counts;
+    __device__ void operator()(const VecK<3> &grand) const {
+        const int64_t n_rows = *d_n_rows;
+        VecK<3> g; g.zero();
+        if (n_rows > 0) g = grand;
+        counts[0] = n_rows; counts[1] = g.v[0]; counts[2] = g.v[1]; counts[3] = g.v[2];
+        msg_off[0] = 0; pos_off[0] = 0;
+    }
+};
 
 struct ExpandArgs {
     const int64_t *rows;
@@ -491,12 +507,7 @@ __global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
 // ---- host-side launchers ---------------------------------------------------------------------------
 int launch_resolve(const ResolveArgs &a, hipStream_t s) {
     if (a.n_chunks <= 0) return URHGPU_ERR_ARG;
-    const unsigned g = (unsigned)((a.n_chunks + 255) / 256);
-    if (hipMemsetAsync(a.aux, 0x7F, sizeof(ResolveAux), s) != hipSuccess) return URHGPU_ERR_HIP;
-    hipLaunchKernelGGL(k_chunk_stable, dim3(g), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_scan_stable, dim3(1), dim3(kResolveBlock), 0, s, a);
-    hipLaunchKernelGGL(k_chunk_accept, dim3(g), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_scan_accept, dim3(1), dim3(kResolveBlock), 0, s, a);
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(kResolveBlock), 0, s, a);
     return URHGPU_OK;
 }
 
@@ -514,7 +525,7 @@ size_t merge_scratch_bytes(int64_t cap) {
 
 // rows_in (d_n_in rows) -> rows_out (d_n_out rows); rows_in and rows_out must differ.
 int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t cap, int64_t *rows_out,
-                          int64_t cap_out, int64_t *d_n_out, void *scratch, hipStream_t s) {
+                          int64_t cap_out, int64_t *d_n_out, void *scratch, int32_t *tickets, hipStream_t s) {
     if (cap <= 0) return URHGPU_OK;
     const int64_t nb = scan_blocks(cap);
     char *p = (char *)scratch;
@@ -523,10 +534,9 @@ int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t
     int64_t *grp_end = (int64_t *)p;
     MergeLoad ld{rows_in};
     MergeStore st{rows_in, d_n_in, grp_state, grp_end};
-    hipLaunchKernelGGL((k_scan_reduce<2, MergeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld, partials);
-    hipLaunchKernelGGL((k_scan_partials<2>), dim3(1), dim3(kScanBlock), 0, s, d_n_in, partials, nb);
-    hipLaunchKernelGGL((k_scan_apply<2, MergeLoad, MergeStore>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld,
-                       partials, st);
+    hipLaunchKernelGGL((k_scan_reduce<2, MergeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld, partials, nb, tickets);
+    hipLaunchKernelGGL((k_scan_apply<2, MergeLoad, MergeStore, NoFinal>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld,
+                       partials, nb, st, NoFinal(), tickets + 1);
     int64_t fin_blocks = (cap + 255) / 256; if (fin_blocks > 4096) fin_blocks = 4096;
     hipLaunchKernelGGL(k_merge_finish, dim3((unsigned)fin_blocks), dim3(256), 0, s, partials + nb, grp_state, grp_end,
                        rows_out, cap_out, d_n_out);
@@ -563,45 +573,49 @@ BitsScratch carve_bits(void *scratch, int64_t cap_rows) {
 }
 }  // namespace
 
-// number of groups = total L rows + 1; flags = {long pause present, data before the first one, data after the last one}
-__global__ void k_group_count_flags(const int64_t *d_n_rows, const VecK<4> *grand, const GroupInfo *groups,
-                                    int64_t *d_n_groups, int64_t *d_flags) {
-    const int64_t n = *d_n_rows;
-    const int64_t n_l = (n > 0) ? grand->v[1] : 0;
-    *d_n_groups = (n > 0) ? n_l + 1 : 0;
-    if (d_flags) {
-        d_flags[0] = n_l > 0;
-        d_flags[1] = (n > 0) && groups[0].data_end > 0;
-        d_flags[2] = (n > 0) && (groups[n_l].data_end - (n_l ? groups[n_l - 1].data_end : 0) > 0);
+// Runs once after the row scan: number of groups = total L rows + 1;
+// flags = {long pause present, data before the first one, data after the last one}
+struct GroupCountFinal {
+    const int64_t *d_n_rows;
+    const GroupInfo *groups;
+    int64_t *d_n_groups;
+    int64_t *d_flags;
+    __device__ void operator()(const VecK<4> &grand) const {
+        const int64_t n = *d_n_rows;
+        const int64_t n_l = (n > 0) ? grand.v[1] : 0;
+        *d_n_groups = (n > 0) ? n_l + 1 : 0;
+        if (d_flags) {
+            d_flags[0] = n_l > 0;
+            d_flags[1] = (n > 0) && groups[0].data_end > 0;
+            d_flags[2] = (n > 0) && (groups[n_l].data_end - (n_l ? groups[n_l - 1].data_end : 0) > 0);
+        }
     }
-}
+};
 
 int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                        void *scratch, int64_t *d_flags, hipStream_t s) {
+                        void *scratch, int64_t *d_flags, int32_t *tickets, hipStream_t s) {
     if (cap_rows <= 0) cap_rows = 1;
     const BitsScratch b = carve_bits(scratch, cap_rows);
     BitsLoad ld{rows, d_n_rows, bp};
     BitsStore st{rows, d_n_rows, b.info, b.groups, bp.d_ts_carry, bp.d_absorbed};
-    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4);
-    hipLaunchKernelGGL((k_scan_partials<4>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, b.part4, b.nb);
-    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld,
-                       b.part4, st);
-    hipLaunchKernelGGL(k_group_count_flags, dim3(1), dim3(1), 0, s, d_n_rows, b.part4 + b.nb, b.groups, b.d_n_groups, d_flags);
+    GroupCountFinal fin{d_n_rows, b.groups, b.d_n_groups, d_flags};
+    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb, tickets);
+    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore, GroupCountFinal>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld,
+                       b.part4, b.nb, st, fin, tickets + 1);
     return URHGPU_OK;
 }
 
 int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                       const BitsOut &o, void *scratch, hipStream_t s) {
+                       const BitsOut &o, void *scratch, int32_t *tickets, hipStream_t s) {
     if (cap_rows <= 0) cap_rows = 1;
     const BitsScratch b = carve_bits(scratch, cap_rows);
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
-    hipLaunchKernelGGL((k_scan_reduce<3, GroupLoad>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s, b.d_n_groups, gl, b.part3);
-    hipLaunchKernelGGL((k_scan_partials<3>), dim3(1), dim3(kScanBlock), 0, s, b.d_n_groups, b.part3, b.nbg);
-    hipLaunchKernelGGL((k_scan_apply<3, GroupLoad, GroupStore>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s, b.d_n_groups,
-                       gl, b.part3, gs);
-    hipLaunchKernelGGL(k_bits_counts, dim3(1), dim3(1), 0, s, d_n_rows, b.part3 + b.nbg, o.msg_off, o.pos_off, o.cap_msg,
-                       o.counts);
+    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts};
+    hipLaunchKernelGGL((k_scan_reduce<3, GroupLoad>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s, b.d_n_groups, gl, b.part3, b.nbg,
+                       tickets + 2);
+    hipLaunchKernelGGL((k_scan_apply<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s,
+                       b.d_n_groups, gl, b.part3, b.nbg, gs, fin, tickets + 3);
     ExpandArgs ea{rows, d_n_rows, b.info, b.gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp};
     const int64_t eb = (cap_rows + 255) / 256;
     hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)eb), dim3(256), 0, s, ea);
@@ -609,9 +623,9 @@ int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap
 }
 
 int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                         const BitsOut &o, void *scratch, hipStream_t s) {
-    URH_TRY(launch_bits_prepare(rows, d_n_rows, cap_rows, bp, scratch, nullptr, s));
-    return launch_bits_finish(rows, d_n_rows, cap_rows, bp, o, scratch, s);
+                         const BitsOut &o, void *scratch, int32_t *tickets, hipStream_t s) {
+    URH_TRY(launch_bits_prepare(rows, d_n_rows, cap_rows, bp, scratch, nullptr, tickets, s));
+    return launch_bits_finish(rows, d_n_rows, cap_rows, bp, o, scratch, tickets, s);
 }
 
 // ---- sharded captures: the tiny cross-shard fix-ups (one thread each; world <= a few dozen) ---------------
