@@ -55,9 +55,9 @@ def test_device_atan2f_is_glibc_atan2f(oracle):
 def test_golden_host_api(sf, name):
     g = load_golden(name)
     mod, bps = g["modulation_type"], g["bits_per_symbol"]
-    if mod != "PSK":
-        qad = sf.afp_demod(g["iq"], g["noise_threshold"], mod, 2 ** bps, g["costas_loop_bandwidth"])
-        assert bits_equal(qad, g["qad"]), int((qad.view(np.uint32) != g["qad"].view(np.uint32)).sum())
+    qad = sf.afp_demod(g["iq"], g["noise_threshold"], mod, 2 ** bps, g["costas_loop_bandwidth"])
+    st = 1 if mod == "PSK" else 0             # the reference leaves result[0] of the Costas loop uninitialised
+    assert bits_equal(qad[st:], g["qad"][st:]), int((qad[st:].view(np.uint32) != g["qad"][st:].view(np.uint32)).sum())
     pp = sf.grab_pulse_lens(g["qad"], g["center"], g["tolerance"], mod, g["samples_per_symbol"], bps, g["center_spacing"])
     assert np.array_equal(pp, g["ppseq"])
     bits, off, pauses, pos, poff = sf.ppseq_to_bits_flat(g["ppseq"], g["samples_per_symbol"], bps, True, g["pause_threshold"])
@@ -68,7 +68,7 @@ def test_golden_host_api(sf, name):
         assert first == g["kat"] if g["kat_mode"] == "exact" else first.startswith(g["kat"])
 
 
-@pytest.mark.parametrize("name", [c for c in GOLDEN_CASES if not c.startswith("psk")])
+@pytest.mark.parametrize("name", GOLDEN_CASES)
 def test_golden_fused_device_path(pipe, name):
     import torch
     from urh_amd.pipeline import DemodParams
@@ -77,6 +77,11 @@ def test_golden_fused_device_path(pipe, name):
                     g["tolerance"], g["samples_per_symbol"], g["costas_loop_bandwidth"], g["pause_threshold"], True)
     iq = torch.from_numpy(g["iq"]).cuda()
     res = pipe.iq_to_bits(iq, p, want_qad=True)
+    if g["modulation_type"] == "PSK":
+        # the golden qad's element 0 is whatever np.empty held in the reference run; the table is compared against
+        # the oracle's (which segments the same signal with element 0 = -4, like the GPU path)
+        assert bits_equal(res.qad.cpu().numpy()[1:], g["qad"][1:])
+        return
     assert bits_equal(res.qad.cpu().numpy(), g["qad"])
     assert np.array_equal(res.ppseq(), g["ppseq"])
     bits, off, pauses, pos, poff = res.flat()
@@ -309,3 +314,39 @@ def test_fast_path_division_is_ieee_division():
     bad = C.c_uint64(123)
     _lib.check(_lib.load().urhgpu_test_fast_division_dev(ctx.handle, 7, 4096, C.byref(bad)))     # 4.3e9 pairs
     assert bad.value == 0
+
+
+@pytest.mark.parametrize("order", [2, 4])
+@pytest.mark.parametrize("dtype", [np.float32, np.int8, np.uint8, np.int16, np.uint16])
+def test_costas_equals_oracle(sf, pipe, oracle, order, dtype):
+    """PSK: the Costas loop (serial recurrence with glibc sinf / cosf) is bit-exact from sample 1 on; pulse table and
+    bits follow (config 5 of BASELINE.json at a size the oracle finishes in seconds)."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    rng = np.random.default_rng(order * 10 + np.dtype(dtype).itemsize)
+    n, sps = 120_000, 100
+    sym = rng.integers(0, order, n // sps + 1)
+    phases = (np.array([-135, -45, 45, 135]) if order == 4 else np.array([-90, 90]))[sym] * np.pi / 180
+    ph = np.repeat(phases, sps)[:n] + 2 * np.pi * 0.04 * np.arange(n)
+    iq = np.stack([np.cos(ph), np.sin(ph)], 1) + 0.1 * np.sqrt(0.5) * rng.standard_normal((n, 2))
+    iq[40_000:43_000] *= 0.01                                                  # a gap: noise-gated samples freeze the loop
+    if dtype == np.float32:
+        iq, noise = iq.astype(np.float32), 0.2
+    else:
+        info = np.iinfo(dtype)
+        scale, off = (info.max - info.min) / 2 * 0.7, (info.max + info.min + 1) / 2
+        iq = np.clip(np.round(iq * scale + off), info.min, info.max).astype(dtype)
+        noise = 0.0 if np.dtype(dtype).kind == "u" else 0.2 * scale               # unsigned: the offset dominates |x|
+    want = oracle.afp_demod(iq, noise, "PSK", order, 0.1)
+    got = sf.afp_demod(iq, noise, "PSK", order, 0.1)
+    assert bits_equal(got[1:], want[1:]), (order, np.dtype(dtype).name, int((got[1:] != want[1:]).sum()))
+    assert got[0] == -4.0
+    want[0] = -4.0
+    bps = 2 if order == 4 else 1
+    p = DemodParams("PSK", bps, noise, 0.0, 1.5 if order == 4 else 1.0, 5, sps, 0.1, 8, True)
+    pp = oracle.grab_pulse_lens(want, p.center, 5, "PSK", sps, bps, p.center_spacing)
+    fb = oracle.ppseq_to_bits_flat(pp, sps, bps, True, 8)
+    res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True)
+    assert bits_equal(res.qad.cpu().numpy(), want)
+    assert np.array_equal(res.ppseq(), pp)
+    assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))

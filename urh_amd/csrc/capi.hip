@@ -142,8 +142,8 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
         if (!rows_stage || !merge_scratch || !d_n_stage) return URHGPU_ERR_ARG;
     }
     void *rs_mem = ctx->arena.take(resolve_scratch_bytes(pl.n_chunks));
-    ResolveAux *aux = (ResolveAux *)ctx->arena.take(sizeof(ResolveAux));
-    if (!rs_mem || !aux) return URHGPU_ERR_ARG;
+    ResolveAux *aux = (ResolveAux *)(ctx->d_tickets + 4);
+    if (!rs_mem) return URHGPU_ERR_ARG;
     const ResolveScratch rsc = resolve_scratch_carve(rs_mem, pl.n_chunks);
     ResolveArgs r;
     memset(&r, 0, sizeof(r));
@@ -152,7 +152,7 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     r.rows = rows_stage; r.cap_rows = cap_rows; r.d_n_acc = d_n_acc; r.d_n_rows = d_n_stage;
     r.d_n_rows_needed = d_n_rows_needed; r.write_last_row = 1;
     r.local_pass = 0; r.aux = aux; r.summary_out = nullptr; r.chunk_first = 0; r.n_local = pl.n_chunks; r.d_ts_carry = nullptr;
-    URH_TRY(launch_resolve(r, s));
+    URH_TRY(launch_resolve(r, ctx->d_tickets, s));
     EmitArgs e;
     e.sc = rsc;
     e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
@@ -240,7 +240,11 @@ int urhgpu_ctx_create(int device, urhgpu_ctx **out) {
     ctx->stream = ctx->own_stream;
     URH_HIP(hipMalloc((void **)&ctx->d_counts, 16 * sizeof(int64_t)));
     URH_HIP(hipMalloc((void **)&ctx->d_tickets, 8 * sizeof(int32_t)));
-    URH_HIP(hipMemset(ctx->d_tickets, 0, 8 * sizeof(int32_t)));
+    URH_HIP(hipMemset(ctx->d_tickets, 0, 4 * sizeof(int32_t)));
+    {   // d_tickets[4..7] is the ResolveAux block of the resolve kernels: kAuxNone x3, -1
+        const int32_t aux0[4] = {kAuxNone, kAuxNone, kAuxNone, -1};
+        URH_HIP(hipMemcpy(ctx->d_tickets + 4, aux0, sizeof(aux0), hipMemcpyHostToDevice));
+    }
     URH_HIP(hipHostMalloc((void **)&ctx->h_counts, 16 * sizeof(int64_t)));
     *out = ctx;
     return URHGPU_OK;
@@ -447,7 +451,7 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
     ss->table = (ChunkInfo *)ctx->arena.take((size_t)n_table * sizeof(ChunkInfo));
     ss->slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
     ss->rs_mem = ctx->arena.take(resolve_scratch_bytes(n_table));
-    ss->aux = (ResolveAux *)ctx->arena.take(sizeof(ResolveAux));
+    ss->aux = (ResolveAux *)(ctx->d_tickets + 4);
     ss->d_small = (int64_t *)ctx->arena.take(8 * 8);
     ss->bits_scratch = ctx->arena.take(bits_scratch_bytes(std::max<int64_t>(out->cap_rows, 1)));
     ss->rows_stage = out->rows; ss->merge_scratch = nullptr; ss->d_n_stage = ss->d_small + 3;
@@ -482,7 +486,7 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
     r.rows = nullptr; r.cap_rows = 0; r.d_n_acc = ctx->d_counts + 9; r.d_n_rows = ctx->d_counts + 10;
     r.d_n_rows_needed = ctx->d_counts + 8; r.write_last_row = 0;
     r.local_pass = 1; r.aux = ss->aux; r.summary_out = (ChunkInfo *)d_summary; r.chunk_first = 0; r.n_local = pl.n_chunks;
-    URH_TRY(launch_resolve(r, s));
+    URH_TRY(launch_resolve(r, ctx->d_tickets, s));
     URH_HIP(hipGetLastError());
     ss->phase = 1;
     return URHGPU_OK;
@@ -514,7 +518,7 @@ int urhgpu_shard_rows_dev(urhgpu_ctx *ctx, const void *d_summaries, int64_t *d_m
     r.local_pass = 0; r.aux = ss->aux; r.summary_out = nullptr; r.chunk_first = rank; r.n_local = pl.n_chunks;
     r.d_ts_carry = ss->d_small;
     URH_HIP(hipMemsetAsync(ss->d_small, 0, 8 * 8, s));
-    URH_TRY(launch_resolve(r, s));
+    URH_TRY(launch_resolve(r, ctx->d_tickets, s));
     EmitArgs e;
     e.sc = r.sc;
     e.chunks = ss->table; e.chunk_first = rank; e.slab = ss->slab; e.slab_stride = pl.slab_stride;

@@ -68,7 +68,7 @@ struct ResolveArgs {
     // stays open, no last row is written, and *summary_out receives the ChunkInfo that stands for the whole
     // shard in the other ranks' tables.
     int local_pass;
-    ResolveAux *aux;         // zero-cost when not sharded: still needed by the kernels (4 ints)
+    ResolveAux *aux;         // persistent context memory, kAuxNone / -1 between passes
     ChunkInfo *summary_out;
     int64_t chunk_first;     // table index of this GPU's first chunk
     int64_t n_local;         // this GPU's chunks
@@ -113,7 +113,7 @@ struct BitsOut {
     int64_t *pos; int64_t cap_pos; int64_t *pos_off;
     int64_t *counts;
 };
-int launch_resolve(const ResolveArgs &a, hipStream_t s);
+int launch_resolve(const ResolveArgs &a, int32_t *tickets, hipStream_t s);
 int launch_emit_rows(const EmitArgs &a, int64_t n_local_chunks, hipStream_t s);
 size_t merge_scratch_bytes(int64_t cap);
 int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t cap, int64_t *rows_out,

@@ -196,20 +196,24 @@ __device__ __forceinline__ void scan_accept(const ResolveArgs &a) {
     }
 }
 
-// The whole resolve stage as ONE single-workgroup launch (the table is small: ~16 K entries at 1 GiB): the four
-// phases are separated by workgroup barriers instead of kernel boundaries.
-__global__ __launch_bounds__(kResolveBlock) void k_resolve(const ResolveArgs a) {
+// The resolve stage as TWO launches: the per-chunk phases run over the whole grid, and the workgroup that finishes
+// last runs the single-workgroup scan that follows (scan.hpp: scan_last_block), instead of a launch of its own.
+// aux is persistent context memory that holds kAuxNone / -1 between passes (k_resolve_b restores it).
+__global__ __launch_bounds__(kResolveBlock) void k_resolve_a(const ResolveArgs a, int32_t *ticket) {
+    const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
+    if (c < a.n_chunks) chunk_stable(a, c);
+    if (!scan_last_block(ticket, gridDim.x)) return;
+    scan_stable(a);
+}
+__global__ __launch_bounds__(kResolveBlock) void k_resolve_b(const ResolveArgs a, int32_t *ticket) {
+    const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
+    if (c < a.n_chunks) chunk_accept(a, c);
+    if (!scan_last_block(ticket, gridDim.x)) return;
+    scan_accept(a);
+    __syncthreads();
     if (threadIdx.x == 0) {
         a.aux->first_nonlead = kAuxNone; a.aux->open_chunk = kAuxNone; a.aux->first_stable = kAuxNone; a.aux->last_stable = -1;
     }
-    __syncthreads();
-    for (int64_t c = threadIdx.x; c < a.n_chunks; c += kResolveBlock) chunk_stable(a, c);
-    __syncthreads();
-    scan_stable(a);
-    __syncthreads();
-    for (int64_t c = threadIdx.x; c < a.n_chunks; c += kResolveBlock) chunk_accept(a, c);
-    __syncthreads();
-    scan_accept(a);
 }
 
 // =====================================================================================================
@@ -505,9 +509,11 @@ __global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
 }
 
 // ---- host-side launchers ---------------------------------------------------------------------------
-int launch_resolve(const ResolveArgs &a, hipStream_t s) {
+int launch_resolve(const ResolveArgs &a, int32_t *tickets, hipStream_t s) {
     if (a.n_chunks <= 0) return URHGPU_ERR_ARG;
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(kResolveBlock), 0, s, a);
+    const unsigned g = (unsigned)((a.n_chunks + kResolveBlock - 1) / kResolveBlock);
+    hipLaunchKernelGGL(k_resolve_a, dim3(g), dim3(kResolveBlock), 0, s, a, tickets);
+    hipLaunchKernelGGL(k_resolve_b, dim3(g), dim3(kResolveBlock), 0, s, a, tickets + 1);
     return URHGPU_OK;
 }
 
