@@ -222,6 +222,28 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all);
 int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, int64_t chunk,
                                      int64_t n_chunks, double *d_sum, double *d_max);
 
+/* ---- estimator passes: the O(N) parts of AutoInterpretation.estimate (src/urh/ainterpretation/AutoInterpretation.py:373-470);
+ * the decisions on the few hundred resulting values stay on the host (urh_amd/estimators.py). ------------------------- */
+
+/* auto_interpretation.segment_messages_from_magnitudes (src/urh/cythonext/auto_interpretation.pyx:55-111) as a pulse table:
+ * state 1 = |sample| > noise_threshold, 0 = below, switched after 10 consecutive samples (tolerance 9), row layout and
+ * length conventions of urhgpu_grab_pulse_lens_dev; the state machine starts in the state of sample 0.  The host turns
+ * the rows into (start, end) tuples.  float32 IQ only (URHGPU_ERR_UNSUPPORTED for the integer dtypes). */
+int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold,
+                            int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows);
+/* rect[rect > thr] (AutoInterpretation.py:227), order preserved; *d_count (device) = number kept. */
+int urhgpu_compact_gt_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float thr, float *d_out, int64_t *d_count);
+/* positions i >= 1 where (x[i] <= center) != (x[i-1] <= center), ascending (get_plateau_lengths,
+ * auto_interpretation.pyx:179-208); at most cap are stored, *d_count (device) = number found. */
+int urhgpu_edges_le_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float center, int64_t *d_idx, int64_t cap, int64_t *d_count);
+/* util.minmax (util.pyx:20-36) of a float32 array: d_out2 = {min, max}. */
+int urhgpu_minmax_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float *d_out2);
+/* numpy's pairwise float32 sum (what np.mean / np.var reduce with): mode 0 sum x[i], mode 1 sum (x[i] - mean)^2.
+ * Synchronous; *sum_out is a HOST float. */
+int urhgpu_pairwise_sum_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, float mean, float *sum_out);
+/* np.histogram(x, bins=edges) for ascending float64 edges: d_counts[n_edges - 1]. */
+int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const double *d_edges, int64_t n_edges, int64_t *d_counts);
+
 /* Test hook: the hot kernel's fast-path division (Newton + residual chain without scaling) against the IEEE
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);

@@ -350,3 +350,60 @@ def test_costas_equals_oracle(sf, pipe, oracle, order, dtype):
     assert bits_equal(res.qad.cpu().numpy(), want)
     assert np.array_equal(res.ppseq(), pp)
     assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
+
+
+# ---- estimators: segmentation, center, plateau lengths (rows 11-13) ----------------------------------------------
+def _bursty(n, seed, sps=50):
+    rng = np.random.default_rng(seed)
+    iq = synth_fsk(n, sps=sps, seed=seed, noise=0.02, pause_every=max(n // 4, 1), pause_len=n // 9)
+    # sprinkle short dropouts / spikes so that the 10-sample outlier tolerance matters
+    for _ in range(20):
+        a = int(rng.integers(0, n))
+        ln = int(rng.choice([1, 3, 9, 10, 11, 25]))
+        iq[a:a + ln] *= np.float32(rng.choice([0.001, 30.0]))
+    return iq
+
+
+def test_segment_messages_equals_oracle(pipe, oracle):
+    import torch
+    from urh_amd import estimators
+    for n, seed in ((1, 0), (9, 1), (10, 2), (11, 3), (500, 4), (70_001, 5), (200_000, 6), (262_144, 7)):
+        iq = _bursty(n, seed)
+        for nt in (0.3, 0.0, 5.0):
+            want = oracle.segment_messages_from_magnitudes(oracle.get_magnitudes(iq), nt)
+            got = estimators.segment_messages_dev(pipe, torch.from_numpy(iq).cuda(), nt)
+            assert got == [(int(a), int(b)) for a, b in want], (n, nt, got[:4], want[:4])
+
+
+def test_detect_center_equals_numpy(pipe, oracle):
+    """the GPU passes reproduce numpy's float32 pairwise np.var and np.histogram exactly -> identical center"""
+    import torch
+    from urh_amd import estimators
+    cases = []
+    for name in GOLDEN_CASES:
+        cases.append((name, load_golden(name)["qad"]))
+    for n, seed in ((100, 1), (4_000, 2), (131_072, 3), (1_000_003, 4)):
+        iq = synth_fsk(n, sps=100, seed=seed, noise=0.05, pause_every=max(n // 3, 1), pause_len=n // 20)
+        cases.append((f"fsk{n}", oracle.afp_demod(iq, 0.2, "FSK", 2)))
+        cases.append((f"ask{n}", oracle.afp_demod(iq, 0.0, "ASK", 2)))
+    for name, qad in cases:
+        want = oracle.detect_center(qad)
+        got = estimators.detect_center_dev(pipe, torch.from_numpy(np.ascontiguousarray(qad, np.float32)).cuda())
+        assert (want is None and got is None) or (want is not None and got is not None and float(want) == float(got)), (name, want, got)
+        if len(qad) > 5000:
+            want = oracle.detect_center(qad, max_size=3000)
+            got = estimators.detect_center_dev(pipe, torch.from_numpy(np.ascontiguousarray(qad, np.float32)).cuda(), max_size=3000)
+            assert (want is None and got is None) or float(want) == float(got), (name, "max_size", want, got)
+
+
+def test_plateau_lengths_equal_oracle(pipe, oracle):
+    import torch
+    from urh_amd import estimators
+    for n, seed in ((0, 0), (3, 1), (1000, 2), (60_000, 3), (150_001, 4)):
+        iq = synth_fsk(max(n, 4), sps=40, seed=seed, noise=0.1)[:n]
+        qad = oracle.afp_demod(iq, 0.0, "FSK", 2) if n else np.zeros(0, np.float32)
+        for center in (0.0, 0.05):
+            for pct in (25, 100):
+                want = oracle.get_plateau_lengths(qad, center, pct)
+                got = estimators.get_plateau_lengths_dev(pipe, torch.from_numpy(qad).cuda(), center, pct)
+                assert np.array_equal(want, got), (n, center, pct, want[:6], got[:6], len(want), len(got))

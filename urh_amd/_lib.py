@@ -81,6 +81,12 @@ PROTOTYPES = {
     "urhgpu_shard_bits_prepare_dev": (_i, [_vp, _vp, _vp]),
     "urhgpu_shard_bits_finish_dev": (_i, [_vp, _vp]),
     "urhgpu_magnitude_chunk_stats_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp]),
+    "urhgpu_segment_runs_dev": (_i, [_vp, _vp, _i, _i64, _f, _vp, _i64, _vp]),
+    "urhgpu_compact_gt_dev": (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
+    "urhgpu_edges_le_dev": (_i, [_vp, _vp, _i64, _f, _vp, _i64, _vp]),
+    "urhgpu_minmax_f32_dev": (_i, [_vp, _vp, _i64, _vp]),
+    "urhgpu_pairwise_sum_f32_dev": (_i, [_vp, _vp, _i64, _i, _f, C.POINTER(_f)]),
+    "urhgpu_histogram_f32_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "urhgpu_test_fast_division_dev": (_i, [_vp, C.c_uint64, _i, C.POINTER(C.c_uint64)]),
     "urhgpu_test_atan2f_dev": (_i, [_vp, _vp, _vp, _i64, _vp]),
 }

@@ -110,7 +110,7 @@ int dtype_bytes(int dtype) {
 // scratch must come from ctx->arena (already reserved by the caller).
 int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const urhgpu_params *p, float *d_qad,
              int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows, int64_t *d_n_rows_needed, int64_t *d_n_acc,
-             const Plan &pl) {
+             const Plan &pl, int seg_mode = 0) {
     hipStream_t s = ctx->stream;
     RunArgs a;
     memset(&a, 0, sizeof(a));
@@ -121,6 +121,11 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
     if (from_iq) URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
+    if (seg_mode) {
+        // message segmentation: state = (|sample| > noise threshold) with the 10-sample outlier tolerance.  Reuses the
+        // ASK arithmetic with max_magnitude 1 (q = sqrtf(I*I + Q*Q) exactly), no noise gating, threshold = noise level.
+        a.seg_mode = 1; a.max_magnitude = 1.0f; a.noise_sqrd = -1.0f; a.noise_val = __builtin_nanf("");
+    }
     ChunkInfo *chunks = (ChunkInfo *)ctx->arena.take((size_t)pl.n_chunks * sizeof(ChunkInfo));
     uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
     if (!chunks || !slab) return URHGPU_ERR_ARG;
@@ -131,7 +136,7 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     else URH_TRY(launch_runs_qad(a, s));
     if (prof) { URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], s)); ctx->prof_used += 1; }
 
-    const bool ask = (p->mod == URHGPU_MOD_ASK);
+    const bool ask = (p->mod == URHGPU_MOD_ASK) && !seg_mode;
     int64_t *rows_stage = d_rows;
     int64_t *d_n_stage = d_n_rows;
     void *merge_scratch = nullptr;
@@ -572,6 +577,81 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
     URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, ctx->d_tickets, s));
     URH_HIP(hipGetLastError());
     ss->phase = 0;
+    return URHGPU_OK;
+}
+
+// ---- estimator passes (device pointers; see include/urhgpu.h) ---------------------------------------------------
+namespace {
+__global__ void k_set_i64(int64_t *p, int64_t v) { *p = v; }
+}
+
+int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold,
+                            int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows) {
+    if (!ctx || n < 0 || !d_n_rows || cap_rows < 0) return URHGPU_ERR_ARG;
+    if (dtype != URHGPU_DT_F32) return dtype_bytes(dtype) ? URHGPU_ERR_UNSUPPORTED : URHGPU_ERR_DTYPE;
+    URH_HIP(hipSetDevice(ctx->device));
+    if (n == 0) { URH_HIP(hipMemsetAsync(d_n_rows, 0, 8, ctx->stream)); return URHGPU_OK; }
+    if (!d_iq || !d_rows || ((uintptr_t)d_iq & 15)) return URHGPU_ERR_ARG;
+    urhgpu_params p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = dtype; p.mod = URHGPU_MOD_ASK; p.bits_per_symbol = 1; p.center = noise_threshold; p.center_spacing = 0.f;
+    p.tolerance = 9;                                   // outlier_tolerance = 10 consecutive samples (auto_interpretation.pyx:72)
+    p.samples_per_symbol = 1;
+    const Plan pl = make_plan(ctx, n, p.tolerance);
+    URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, cap_rows, false, false)));
+    ctx->arena.reset();
+    return digitize(ctx, true, d_iq, n, &p, nullptr, d_rows, cap_rows, d_n_rows, ctx->d_counts + 8, ctx->d_counts + 9, pl, 1);
+}
+
+int urhgpu_compact_gt_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float thr, float *d_out, int64_t *d_count) {
+    if (!ctx || n < 0 || !d_count || (n > 0 && (!d_x || !d_out))) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(ctx->arena.reserve(compact_scratch_bytes(n) + 1024));
+    ctx->arena.reset();
+    void *scratch = ctx->arena.take(compact_scratch_bytes(n));
+    if (!scratch) return URHGPU_ERR_ARG;
+    hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, ctx->stream, ctx->d_counts + 11, n);
+    URH_TRY(launch_compact_gt(d_x, n, ctx->d_counts + 11, thr, d_out, d_count, scratch, ctx->d_tickets, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_edges_le_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float center, int64_t *d_idx, int64_t cap, int64_t *d_count) {
+    if (!ctx || n < 0 || cap < 0 || !d_count || (n > 0 && !d_x) || (cap > 0 && !d_idx)) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(ctx->arena.reserve(compact_scratch_bytes(n) + 1024));
+    ctx->arena.reset();
+    void *scratch = ctx->arena.take(compact_scratch_bytes(n));
+    if (!scratch) return URHGPU_ERR_ARG;
+    hipLaunchKernelGGL(k_set_i64, dim3(1), dim3(1), 0, ctx->stream, ctx->d_counts + 11, n);
+    URH_TRY(launch_compact_edges(d_x, n, ctx->d_counts + 11, center, d_idx, cap, d_count, scratch, ctx->d_tickets, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_minmax_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float *d_out2) {
+    if (!ctx || n <= 0 || !d_x || !d_out2) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(ctx->arena.reserve(minmax_scratch_bytes() + 1024));
+    ctx->arena.reset();
+    void *scratch = ctx->arena.take(minmax_scratch_bytes());
+    if (!scratch) return URHGPU_ERR_ARG;
+    URH_TRY(launch_minmax(d_x, n, d_out2, scratch, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_pairwise_sum_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, float mean, float *sum_out) {
+    if (!ctx || n < 0 || !sum_out || (n > 0 && !d_x) || (mode != 0 && mode != 1)) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    return pairwise_sum_f32(ctx, d_x, n, mode, mean, sum_out);
+}
+
+int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const double *d_edges, int64_t n_edges, int64_t *d_counts) {
+    if (!ctx || n < 0 || n_edges < 2 || n_edges > (1 << 30) || !d_edges || !d_counts || (n > 0 && !d_x)) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(launch_hist_edges(d_x, n, d_edges, (int)n_edges, d_counts, ctx->stream));
+    URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }
 

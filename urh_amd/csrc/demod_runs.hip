@@ -540,7 +540,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
                 for (int j = 0; j < kBatch; ++j) {
                     const int off = (rb + j) * kRowSamples + 2 * t;
                     if (SRC == SRC_IQ) {
-                        if (j == 0 && rb == 0 && first_row) q0[0] = p.noise_val;        // result[0] = NOISE (:361)
+                        if (j == 0 && rb == 0 && first_row && !p.seg_mode) q0[0] = p.noise_val;   // result[0] = NOISE (:361)
                         if (WRITE_QAD) {
 #if URH_NT
                             typedef float v2s __attribute__((ext_vector_type(2)));
@@ -717,6 +717,11 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
             if (SRC == SRC_QAD) first_is_noise = (((const float *)p.in)[0] == p.noise_val);
             else first_is_noise = true;                            // afp_demod: result[0] = NOISE
             init = first_is_noise ? kStPause : classify<ORDER2>(0.0f, p, false);   // literal 0.0: thresholds only
+            if (SRC == SRC_IQ && p.seg_mode) {                     // segmentation: the state of sample 0 itself
+                float c = 0.f, d = 0.f;
+                Iq<DT>::load1(p.in, 0, c, d);
+                init = classify<ORDER2>(demod_one<MOD>(0.f, 0.f, c, d, p), p);
+            }
         }
         ci.init_state = (uint16_t)init;
         ci.first_acc = 0; ci.pend_acc = 0; ci.pend_stable = 0; ci.pad = 0;

@@ -27,6 +27,8 @@ struct RunArgs {
     float max_magnitude;     // ASK normalisation
     int order;               // modulation order = 2^bits_per_symbol
     int tol;                 // tolerance
+    int seg_mode;            // 1: message segmentation on magnitudes (auto_interpretation.pyx:55-111): sample 0 is an
+                             // ordinary sample (no result[0] = NOISE) and the state machine starts in ITS state
     float thr[kMaxOrder - 1];
 };
 int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s);
@@ -144,6 +146,16 @@ int launch_magnitudes(const void *iq, int dtype, int64_t n, double *out, hipStre
 size_t mag_chunk_scratch_bytes(int64_t n_chunks);
 int launch_mag_chunk_stats(const void *iq, int dtype, int64_t n, int64_t chunk, int64_t n_chunks, double *d_sum, double *d_max,
                            void *scratch, hipStream_t s);
+// ---- estimators.hip ----------------------------------------------------------------------------------------
+size_t compact_scratch_bytes(int64_t n);
+int launch_compact_gt(const float *x, int64_t n, const int64_t *d_n, float thr, float *out, int64_t *d_count, void *scratch,
+                      int32_t *tickets, hipStream_t s);
+int launch_compact_edges(const float *x, int64_t n, const int64_t *d_n, float center, int64_t *out, int64_t cap, int64_t *d_count,
+                         void *scratch, int32_t *tickets, hipStream_t s);
+size_t minmax_scratch_bytes();
+int launch_minmax(const float *x, int64_t n, float *d_out2, void *scratch, hipStream_t s);
+int pairwise_sum_f32(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, float mean, float *out);
+int launch_hist_edges(const float *x, int64_t n, const double *d_edges, int n_edges, int64_t *d_counts, hipStream_t s);
 int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad);
 
 }  // namespace urh

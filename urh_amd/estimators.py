@@ -52,3 +52,194 @@ def detect_noise_level_dev(pipe, iq) -> float:
                                                             dtype_code(_torch_dtype(iq)), n, chunk, n_chunks,
                                                             C.c_void_p(sums.data_ptr()), C.c_void_p(maxs.data_ptr())))
     return noise_level_from_chunk_stats(sums.cpu().numpy(), maxs.cpu().numpy(), chunk)
+
+
+# ======================================================================================================================
+# Message segmentation, center, plateau lengths: O(N) passes on the GPU, decisions on the host
+# ======================================================================================================================
+def _dev_f32(pipe, x):
+    torch = pipe.torch
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 1 and x.is_contiguous()):
+        raise ValueError("expected a contiguous float32 1-D tensor on the GPU")
+    pipe.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+    return x
+
+
+def segment_messages_dev(pipe, iq, noise_threshold: float):
+    """auto_interpretation.segment_messages_from_magnitudes (auto_interpretation.pyx:55-111) for a float32 capture on
+    the GPU: list of (start, end).  The above/below-noise state machine with its 10-sample outlier tolerance is the
+    run segmentation of the hot kernel with tolerance 9 on |sample| (urhgpu_segment_runs_dev); the host walks the
+    resulting rows (one per state change) and applies the reference's index conventions."""
+    torch = pipe.torch
+    if iq.dtype == torch.complex64:
+        iq = torch.view_as_real(iq)
+    n = int(iq.shape[0])
+    if n == 0:
+        return []
+    pipe.ctx.set_stream(torch.cuda.current_stream(iq.device).cuda_stream)
+    cap = n // 10 + 2
+    rows = torch.empty((cap, 2), dtype=torch.int64, device=iq.device)
+    n_rows = torch.zeros(1, dtype=torch.int64, device=iq.device)
+    from .pipeline import _torch_dtype
+    _lib.check(_lib.load().urhgpu_segment_runs_dev(pipe.ctx.handle, C.c_void_p(iq.data_ptr()), dtype_code(_torch_dtype(iq)), n,
+                                                   float(noise_threshold), C.c_void_p(rows.data_ptr()), cap,
+                                                   C.c_void_p(n_rows.data_ptr())))
+    r = rows[:int(n_rows.item())].cpu().numpy()
+    tail = iq[max(0, n - 10):].cpu().numpy().astype(np.float32)
+    tail_mag = np.sqrt(tail[:, 0] * tail[:, 0] + tail[:, 1] * tail[:, 1])              # fp32, as get_magnitudes
+    return segments_from_rows(r, n, tail_mag > np.float32(noise_threshold))
+
+
+def segments_from_rows(rows: np.ndarray, n: int, tail_above: np.ndarray):
+    """rows: pulse table of the above(1)/below(0) states with tolerance 9 (row j: state BEFORE the j-th change, length);
+    tail_above: above-noise flags of the last <= 10 samples."""
+    result = []
+    state = int(rows[0, 0])                      # state of sample 0
+    start = 0
+    # run starts of the accepted state changes: r_1 = len_0 - 1, r_{k+1} = r_k + len_k
+    lens = rows[:, 1]
+    n_changes = len(rows) - 1
+    pos = int(lens[0]) - 1
+    for k in range(1, n_changes + 1):
+        new_state = int(rows[k, 0])
+        if new_state == 1:                       # -1 -> 1 after 10 samples above: start = i - conseq_above (:101-104)
+            start = pos - 1
+        else:                                    # 1 -> -1 after 10 samples below: (start, i - conseq_below) (:95-99)
+            result.append((start, pos - 1))
+        state = new_state
+        pos += int(lens[k]) if k < n_changes else 0
+    if state == 1:                               # :107-109
+        conseq_below = 0
+        for a in tail_above[::-1]:
+            if a:
+                break
+            conseq_below += 1
+        if start < n - conseq_below:
+            result.append((start, n - conseq_below))
+    return result
+
+
+def merge_message_segments_for_ook(segments: list):
+    """AutoInterpretation.merge_message_segments_for_ook (AutoInterpretation.py:107-148)."""
+    if len(segments) <= 1:
+        return segments
+    seg = np.asarray(segments, dtype=np.int64)
+    pauses = (seg[1:, 0] - seg[:-1, 1]).astype(np.uint64)
+    pulses = (seg[:, 1] - seg[:, 0]).astype(np.uint64)
+    min_pulse_length = min_without_outliers(pulses, z=1)
+    large = np.nonzero(pauses >= 8 * min_pulse_length)[0]
+    bounds = [0] + [int(i) + 1 for i in large] + [len(segments)]
+    result = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        begin = int(seg[a, 0])
+        length = int((seg[a:b, 1] - seg[a:b, 0]).sum()) + int((seg[a + 1:b, 0] - seg[a:b - 1, 1]).sum())
+        result.append((begin, begin + length))
+    return result
+
+
+def max_without_outliers(data: np.ndarray, z=3):
+    """AutoInterpretation.py:14-18"""
+    if len(data) == 0:
+        return None
+    return np.max(data[abs(data - np.mean(data)) <= z * np.std(data)])
+
+
+def min_without_outliers(data: np.ndarray, z=2):
+    """AutoInterpretation.py:21-25"""
+    if len(data) == 0:
+        return None
+    return np.min(data[abs(data - np.mean(data)) <= z * np.std(data)])
+
+
+def get_most_frequent_value(values: list):
+    """AutoInterpretation.py:28-47: most frequent value, ties -> the LAST of the tied values in first-seen order."""
+    if len(values) == 0:
+        return None
+    from collections import Counter
+    ranked = Counter(values).most_common()
+    top = ranked[0][1]
+    return [v for v, c in ranked if c == top][-1]
+
+
+def detect_center_dev(pipe, rect, max_size=None):
+    """AutoInterpretation.detect_center (AutoInterpretation.py:226-277) for a demodulated signal on the GPU.
+    GPU passes: compaction rect > -4, min / max, np.var (float32 pairwise sums in numpy's order), histogram over the
+    float64 edges np.arange(min, max + step, step); the peak picking over the bins is host work."""
+    torch = pipe.torch
+    x = _dev_f32(pipe, rect)
+    n = int(x.shape[0])
+    lib, h = _lib.load(), pipe.ctx.handle
+    kept = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
+    cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
+    _lib.check(lib.urhgpu_compact_gt_dev(h, C.c_void_p(x.data_ptr()), n, -4.0, C.c_void_p(kept.data_ptr()), C.c_void_p(cnt.data_ptr())))
+    k = int(cnt.item())
+    a, b = int(0.05 * k), int(0.95 * k)                                                # :231
+    r = kept[a:b]
+    if max_size is not None and len(r) > max_size:                                    # :233-234
+        r = r[0:max_size]
+    m = int(r.shape[0])
+    if m == 0:
+        return None                 # np.var of an empty slice is nan -> np.arange raises ValueError -> None (:246-248)
+    mm = torch.empty(2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.urhgpu_minmax_f32_dev(h, C.c_void_p(r.data_ptr()), m, C.c_void_p(mm.data_ptr())))
+    hist_min, hist_max = (float(v) for v in mm.cpu().numpy())
+    s = C.c_float(0.0)
+    _lib.check(lib.urhgpu_pairwise_sum_f32_dev(h, C.c_void_p(r.data_ptr()), m, 0, 0.0, C.byref(s)))
+    mean = np.float32(s.value) / np.float32(m)                                         # np.mean: float32 sum / float32 count
+    _lib.check(lib.urhgpu_pairwise_sum_f32_dev(h, C.c_void_p(r.data_ptr()), m, 1, float(mean), C.byref(s)))
+    hist_step = float(np.float32(s.value) / np.float32(m))                             # float(np.var(rect)) (:240)
+    try:
+        with np.errstate(all="ignore"):
+            edges = np.arange(hist_min, hist_max + hist_step, hist_step)             # :243-245
+        if len(edges) < 2:
+            # np.histogram with fewer than 2 edges raises ValueError -> None (:246-248)
+            return None
+    except (ZeroDivisionError, ValueError):
+        return None
+    d_edges = torch.from_numpy(np.ascontiguousarray(edges, dtype=np.float64)).to(x.device)
+    d_counts = torch.empty(len(edges) - 1, dtype=torch.int64, device=x.device)
+    _lib.check(lib.urhgpu_histogram_f32_dev(h, C.c_void_p(r.data_ptr()), m, C.c_void_p(d_edges.data_ptr()), len(edges),
+                                            C.c_void_p(d_counts.data_ptr())))
+    return center_from_histogram(d_counts.cpu().numpy(), edges)
+
+
+def center_from_histogram(y: np.ndarray, x: np.ndarray):
+    """The peak picking of detect_center (AutoInterpretation.py:250-277): up to two bins, most populated first, that are
+    strict maxima over +-(window-1) bins; the center is the mean of their left edges."""
+    num_values = 2
+    window_size = max(2, int(0.05 * len(y)) + 1)
+    levels = []
+    ny = len(y)
+    for index in np.argsort(y)[::-1]:
+        lo, hi = max(0, index - (window_size - 1)), min(ny, index + window_size)
+        around = np.concatenate([y[lo:index], y[index + 1:hi]])
+        # neighbours outside the histogram count as 0, so a bin with count 0 is never a strict maximum
+        if y[index] > 0 and (len(around) == 0 or y[index] > around.max()):
+            levels.append(x[index])
+        if len(levels) == num_values:
+            break
+    if len(levels) == 0:
+        return None
+    return np.mean(levels)
+
+
+def get_plateau_lengths_dev(pipe, rect, center, percentage=25) -> np.ndarray:
+    """auto_interpretation.get_plateau_lengths (auto_interpretation.pyx:179-208): lengths of the runs of
+    (rect <= center) that START before `percentage` % of the signal and end inside it, uint64."""
+    torch = pipe.torch
+    x = _dev_f32(pipe, rect)
+    n = int(x.shape[0])
+    if n == 0 or center is None:
+        return np.array([], dtype=np.uint64)
+    cap = n
+    idx = torch.empty(max(cap, 1), dtype=torch.int64, device=x.device)
+    cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
+    _lib.check(_lib.load().urhgpu_edges_le_dev(pipe.ctx.handle, C.c_void_p(x.data_ptr()), n, float(center), C.c_void_p(idx.data_ptr()),
+                                               cap, C.c_void_p(cnt.data_ptr())))
+    b = idx[:int(cnt.item())].cpu().numpy()                       # run boundaries B_0 < B_1 < ...
+    limit = (percentage * n) // 100                               # C integer division (cdivision)
+    # plateau k = [B_{k-1}, B_k) is appended at i = B_k if the sum appended so far (= B_{k-1}, or 0) is < limit
+    starts = np.concatenate([[0], b[:-1]]) if len(b) else np.zeros(0, np.int64)
+    keep = starts < limit
+    lengths = (b - starts)[keep]
+    return lengths.astype(np.uint64)
