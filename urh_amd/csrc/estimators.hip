@@ -108,15 +108,19 @@ int launch_minmax(const float *x, int64_t n, float *d_out2, void *scratch, hipSt
     return URHGPU_OK;
 }
 
-// ---- numpy's pairwise float32 summation (numpy/core/src/umath/loops_utils.h.src, *_pairwise_sum) ---------------
+// ---- numpy's float32 summation (np.add.reduce, what np.mean / np.var use) -------------------------------------------
+// np.add.reduce walks a contiguous array in chunks of the ufunc buffer size (8192 elements) and accumulates
+//     total = (((0 + pw(chunk 0)) + pw(chunk 1)) + ...)                       [verified against numpy 2.2 on this host]
+// where pw is the pairwise routine of numpy/core/src/umath/loops_utils.h.src (float32 accumulators):
 //   n < 8            : res = 0; res += a[i] in order
 //   n <= 128         : 8 accumulators r[j] = a[j]; r[j] += a[i + j] for i = 8, 16, ... < n - n % 8;
 //                      res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)); then the n % 8 tail in order
-//   n > 128          : n2 = n / 2; n2 -= n2 % 8; pairwise(a, n2) + pairwise(a + n2, n - n2)
-// np.mean / np.var of a float32 array reduce with exactly this routine (float32 accumulators), so reproducing
-// detect_center's bin width (float(np.var(rect))) bit for bit needs the same tree.  The leaves (<= 128 elements)
-// are evaluated one per thread on the GPU from a host-built leaf table; the tree above them (~n/100 adds) is
-// combined on the host in the same order.  mode 0: a[i] = x[i]; mode 1: a[i] = (x[i] - mean)^2 in float32.
+//   n > 128          : n2 = n / 2; n2 -= n2 % 8; pw(a, n2) + pw(a + n2, n - n2)
+// A full chunk is therefore a perfect binary tree over 64 leaves of 128 elements.  Reproducing detect_center's bin
+// width (float(np.var(rect))) bit for bit needs exactly this order: leaves are evaluated one per thread, each full
+// chunk's tree by one thread (k_pairwise_chunks), and the O(n / 8192) chunk totals plus the irregular last chunk
+// are accumulated on the host.  mode 0: a[i] = x[i]; mode 1: a[i] = (x[i] - mean)^2 in float32.
+constexpr int kPwChunk = 8192, kPwLeaf = 128, kPwLeavesPerChunk = kPwChunk / kPwLeaf;
 struct Leaf { int64_t off; int32_t len; int32_t pad; };
 
 __device__ __forceinline__ float pw_elem(const float *x, int64_t i, int mode, float mean) {
@@ -126,12 +130,14 @@ __device__ __forceinline__ float pw_elem(const float *x, int64_t i, int mode, fl
     return d * d;
 }
 
-__global__ __launch_bounds__(256) void k_pairwise_leaves(const float *x, const Leaf *leaves, int64_t n_leaves, int mode, float mean,
-                                                          float *sums) {
+// leaves [0, n_regular) are the 128-element leaves of the full chunks; leaves beyond come from `extra`
+__global__ __launch_bounds__(256) void k_pairwise_leaves(const float *x, int64_t n_regular, const Leaf *extra, int64_t n_extra,
+                                                          int mode, float mean, float *sums) {
     const int64_t k = blockIdx.x * 256ll + threadIdx.x;
-    if (k >= n_leaves) return;
-    const int64_t off = leaves[k].off;
-    const int n = leaves[k].len;
+    if (k >= n_regular + n_extra) return;
+    int64_t off = k * kPwLeaf;
+    int n = kPwLeaf;
+    if (k >= n_regular) { off = extra[k - n_regular].off; n = extra[k - n_regular].len; }
     float res;
     if (n < 8) {
         res = 0.f;
@@ -151,46 +157,66 @@ __global__ __launch_bounds__(256) void k_pairwise_leaves(const float *x, const L
     sums[k] = res;
 }
 
+// one thread per full chunk: perfect binary tree over its 64 leaf sums, in place order
+__global__ __launch_bounds__(64) void k_pairwise_chunks(const float *leaf_sums, int64_t n_chunks, float *chunk_sums) {
+    const int64_t c = blockIdx.x * 64ll + threadIdx.x;
+    if (c >= n_chunks) return;
+    float s[kPwLeavesPerChunk];
+#pragma unroll
+    for (int i = 0; i < kPwLeavesPerChunk; ++i) s[i] = leaf_sums[c * kPwLeavesPerChunk + i];
+#pragma unroll
+    for (int w = kPwLeavesPerChunk / 2; w >= 1; w >>= 1) {
+#pragma unroll
+        for (int i = 0; i < w; ++i) s[i] = s[2 * i] + s[2 * i + 1];
+    }
+    chunk_sums[c] = s[0];
+}
+
 static void build_leaves(int64_t off, int64_t n, std::vector<Leaf> &out) {
-    if (n <= 128) { out.push_back(Leaf{off, (int32_t)n, 0}); return; }
+    if (n <= kPwLeaf) { out.push_back(Leaf{off, (int32_t)n, 0}); return; }
     int64_t n2 = n / 2;
     n2 -= n2 % 8;
     build_leaves(off, n2, out);
     build_leaves(off + n2, n - n2, out);
 }
 static float combine_leaves(int64_t n, const float *sums, int64_t &next) {
-    if (n <= 128) return sums[next++];
+    if (n <= kPwLeaf) return sums[next++];
     int64_t n2 = n / 2;
     n2 -= n2 % 8;
-    const float a = combine_leaves(n2, sums, next);
-    const float b = combine_leaves(n - n2, sums, next);
+    volatile float a = combine_leaves(n2, sums, next);
+    volatile float b = combine_leaves(n - n2, sums, next);
     return a + b;
 }
 
-// Synchronous: builds the leaf table for n, runs the leaf kernel, combines on the host.  *out = 0 + pairwise(...)
-// (np.add.reduce starts from the identity 0).
+// Synchronous.  *out = np.add.reduce(a) for the float32 sequence a described above.
 int pairwise_sum_f32(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, float mean, float *out) {
     if (n <= 0) { *out = 0.f; return URHGPU_OK; }
-    std::vector<Leaf> leaves;
-    leaves.reserve((size_t)(n / 64 + 8));
-    build_leaves(0, n, leaves);
-    const int64_t nl = (int64_t)leaves.size();
-    const size_t need = ((size_t)nl * sizeof(Leaf) + 255) / 256 * 256 + (size_t)nl * 4 + 512;
+    const int64_t n_chunks = n / kPwChunk, rest = n % kPwChunk;
+    const int64_t n_regular = n_chunks * kPwLeavesPerChunk;
+    std::vector<Leaf> extra;
+    if (rest) build_leaves(n_chunks * kPwChunk, rest, extra);
+    const int64_t n_extra = (int64_t)extra.size(), nl = n_regular + n_extra;
+    const size_t need = (size_t)(n_extra + 1) * sizeof(Leaf) + (size_t)nl * 4 + (size_t)(n_chunks + 1) * 4 + 2048;
     URH_TRY(ctx->staging.reserve(need));
     ctx->staging.reset();
-    Leaf *d_leaves = (Leaf *)ctx->staging.take((size_t)nl * sizeof(Leaf));
+    Leaf *d_extra = (Leaf *)ctx->staging.take((size_t)(n_extra + 1) * sizeof(Leaf));
     float *d_sums = (float *)ctx->staging.take((size_t)nl * 4);
-    if (!d_leaves || !d_sums) return URHGPU_ERR_ARG;
+    float *d_chunk = (float *)ctx->staging.take((size_t)(n_chunks + 1) * 4);
+    if (!d_extra || !d_sums || !d_chunk) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
-    URH_HIP(hipMemcpyAsync(d_leaves, leaves.data(), (size_t)nl * sizeof(Leaf), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_pairwise_leaves, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, d_x, d_leaves, nl, mode, mean, d_sums);
+    if (n_extra) URH_HIP(hipMemcpyAsync(d_extra, extra.data(), (size_t)n_extra * sizeof(Leaf), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pairwise_leaves, dim3((unsigned)((nl + 255) / 256)), dim3(256), 0, s, d_x, n_regular, d_extra, n_extra, mode,
+                       mean, d_sums);
+    if (n_chunks) hipLaunchKernelGGL(k_pairwise_chunks, dim3((unsigned)((n_chunks + 63) / 64)), dim3(64), 0, s, d_sums, n_chunks, d_chunk);
     URH_HIP(hipGetLastError());
-    std::vector<float> sums((size_t)nl);
-    URH_HIP(hipMemcpyAsync(sums.data(), d_sums, (size_t)nl * 4, hipMemcpyDeviceToHost, s));
+    std::vector<float> chunk((size_t)n_chunks), tail((size_t)n_extra);
+    if (n_chunks) URH_HIP(hipMemcpyAsync(chunk.data(), d_chunk, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
+    if (n_extra) URH_HIP(hipMemcpyAsync(tail.data(), d_sums + n_regular, (size_t)n_extra * 4, hipMemcpyDeviceToHost, s));
     URH_HIP(hipStreamSynchronize(s));
-    int64_t next = 0;
-    volatile float total = combine_leaves(n, sums.data(), next);      // float32 adds, no excess precision
-    *out = 0.0f + total;
+    volatile float total = 0.0f;                                   // float32 adds, no excess precision
+    for (int64_t c = 0; c < n_chunks; ++c) total = total + chunk[(size_t)c];
+    if (rest) { int64_t next = 0; const float t = combine_leaves(rest, tail.data(), next); total = total + t; }
+    *out = total;
     return URHGPU_OK;
 }
 
