@@ -180,10 +180,12 @@ def ppseq_to_bits(ppseq, samples_per_symbol: int, bits_per_symbol: int, write_bi
 # numpy restatements of the Python-side estimators (AutoInterpretation.py)
 # ------------------------------------------------------------------------------------------------
 def minmax(arr):
-    """util.pyx:20-36"""
+    """util.pyx:20-36.  The Cython function returns its C `float` results as Python floats (doubles): detect_center's
+    bin edges np.arange(min, max + step, step) are therefore float64 -- returning numpy float32 scalars here would
+    make them float32 (NEP 50) and shift the detected center in the 6th digit."""
     if len(arr) == 0:
         return 0, 0
-    return arr.min(), arr.max()
+    return float(arr.min()), float(arr.max())
 
 
 def detect_noise_level(magnitudes) -> float:

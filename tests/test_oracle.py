@@ -109,3 +109,36 @@ def test_oracle_ppseq_to_bits_vs_reference_python(oracle):
             assert [list(x) for x in ref[0]] == [list(x) for x in got[0]]
             assert list(ref[1]) == list(got[1])
             assert [list(x) for x in ref[2]] == [list(x) for x in got[2]]
+
+
+def test_oracle_estimators_vs_reference_python(oracle):
+    """The numpy restatements of the estimators (detect_noise_level, detect_center, segment_messages_from_magnitudes,
+    get_plateau_lengths) against the reference's own AutoInterpretation / Cython code, on every golden capture and on
+    seeded synthetic input."""
+    import ref_python
+    import build_ref
+    if not (build_ref.built() and ref_python.available()):
+        pytest.skip("reference Python not available")
+    ref_python.setup()
+    from urh.ainterpretation import AutoInterpretation as AI
+    from urh.cythonext import auto_interpretation as c_ai
+    cases = [(name, load_golden(name)) for name in GOLDEN_CASES]
+    for name, g in cases:
+        mags = oracle.get_magnitudes(g["iq"])
+        assert AI.detect_noise_level(mags) == oracle.detect_noise_level(mags), name
+        a, b = AI.detect_center(g["qad"]), oracle.detect_center(g["qad"])
+        assert (a is None and b is None) or float(a) == float(b), (name, a, b)
+        nt = float(g["noise_threshold"]) or 0.01
+        m = mags[:60000]
+        assert [tuple(map(int, s)) for s in AI.segment_messages_from_magnitudes(m, nt)] == \
+            [tuple(map(int, s)) for s in oracle.segment_messages_from_magnitudes(m, nt)], name
+        if a is not None:
+            q = np.ascontiguousarray(g["qad"][:40000])
+            assert np.array_equal(np.asarray(c_ai.get_plateau_lengths(q, a, 25)), oracle.get_plateau_lengths(q, a, 25)), name
+    for n, seed in ((5000, 1), (100_003, 2)):
+        iq = synth_fsk(n, sps=50, seed=seed, noise=0.05, pause_every=n // 3, pause_len=n // 11)
+        qad = oracle.afp_demod(iq, 0.2, "FSK", 2)
+        a, b = AI.detect_center(qad), oracle.detect_center(qad)
+        assert (a is None and b is None) or float(a) == float(b), (n, a, b)
+        a, b = AI.detect_center(qad, max_size=3000), oracle.detect_center(qad, max_size=3000)
+        assert (a is None and b is None) or float(a) == float(b), (n, "max_size", a, b)
