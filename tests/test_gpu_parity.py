@@ -407,3 +407,26 @@ def test_plateau_lengths_equal_oracle(pipe, oracle):
                 want = oracle.get_plateau_lengths(qad, center, pct)
                 got = estimators.get_plateau_lengths_dev(pipe, torch.from_numpy(qad).cuda(), center, pct)
                 assert np.array_equal(want, got), (n, center, pct, want[:6], got[:6], len(want), len(got))
+
+
+def test_estimate_equals_reference_goldens(pipe):
+    """AutoInterpretation.estimate on the GPU vs what the real reference returned for the same captures
+    (tests/golden/estimates.json, made by tests/golden/make_estimate_golden.py): identical dict, floats included."""
+    import json
+    import os
+    import torch
+    from conftest import GOLDEN_DIR
+    from urh_amd import estimators
+    want = json.load(open(os.path.join(GOLDEN_DIR, "estimates.json")))
+    for key, w in want.items():
+        name, mod, how = key.split("|")
+        g = load_golden(name)
+        noise = None if how == "auto" else g["noise_threshold"]
+        got = estimators.estimate_dev(pipe, torch.from_numpy(g["iq"]).cuda(), noise=noise, modulation=mod)
+        if w is None:
+            assert got is None, (key, got)
+            continue
+        assert got is not None, key
+        assert got["modulation_type"] == w["modulation_type"] and int(got["bit_length"]) == w["bit_length"] \
+            and int(got["tolerance"]) == w["tolerance"], (key, got, w)
+        assert float(got["center"]) == w["center"] and float(got["noise"]) == w["noise"], (key, got, w)

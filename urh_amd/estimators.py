@@ -243,3 +243,167 @@ def get_plateau_lengths_dev(pipe, rect, center, percentage=25) -> np.ndarray:
     keep = starts < limit
     lengths = (b - starts)[keep]
     return lengths.astype(np.uint64)
+
+
+# ---- host decisions on plateau lengths (a few thousand integers per message) ---------------------------------------------
+def estimate_tolerance_from_plateau_lengths(plateau_lengths, relative_max=0.05):
+    """AutoInterpretation.py:280-298: the largest "tiny" plateau length, i.e. below 5 % of the outlier-free maximum."""
+    if len(plateau_lengths) <= 1:
+        return None
+    unique = np.unique(plateau_lengths)
+    limit = relative_max * max_without_outliers(unique, z=2)
+    if unique[0] > 1 and unique[0] >= limit:
+        return 0
+    result = 0
+    for value in unique:
+        if value > 1 and value >= limit:
+            break
+        result = value
+    return result
+
+
+def merge_plateaus(plateaus, tolerance, max_count=10000) -> np.ndarray:
+    """auto_interpretation.merge_plateaus (auto_interpretation.pyx:145-176): plateaus <= tolerance are glitches and are
+    merged with their neighbours (looking ahead over alternating glitches); at most max_count merged plateaus."""
+    p = np.asarray(plateaus, dtype=np.uint64)
+    n = len(p)
+    if n == 0:
+        return np.zeros(0, dtype=np.uint64)
+    tolerance = int(tolerance)
+    result = np.empty(n, dtype=np.uint64)
+    result[0] = 0 if int(p[0]) <= tolerance else p[0]
+    current, i = 0, 1
+    while i < n and current < max_count:
+        if int(p[i]) <= tolerance:
+            step = 2
+            while i + step < n and int(p[i + step]) <= tolerance:
+                step += 2
+            result[current] = p[i - 1:min(n, i + step)].sum(dtype=np.uint64)
+            i += step
+        else:
+            current += 1
+            result[current] = p[i]
+            i += 1
+    return result[:current + 1]
+
+
+def merge_plateau_lengths(plateau_lengths, tolerance=None):
+    """AutoInterpretation.py:301-310"""
+    if tolerance is None:
+        tolerance = estimate_tolerance_from_plateau_lengths(plateau_lengths)
+    if tolerance == 0 or tolerance is None:
+        return plateau_lengths
+    return merge_plateaus(plateau_lengths, tolerance, max_count=10000)
+
+
+def round_plateau_lengths(plateau_lengths):
+    """AutoInterpretation.py:313-326 (in place): round to the leading digits, e.g. 99 -> 100, 293 -> 300."""
+    digit_counts = [len(str(p)) for p in plateau_lengths]
+    n_digits = min(3, int(np.percentile(digit_counts, 50)))
+    f = 10 ** (n_digits - 1)
+    for i, plateau_len in enumerate(plateau_lengths):
+        plateau_lengths[i] = int(round(plateau_len / f)) * f
+
+
+def get_threshold_divisor_histogram(plateau_lengths, threshold=0.2) -> np.ndarray:
+    """auto_interpretation.get_threshold_divisor_histogram (auto_interpretation.pyx:113-143): histogram[min(x, y)] += 1
+    for every pair whose ratio max / min has a fractional part below `threshold` (float32 threshold, double ratio)."""
+    p = np.asarray(plateau_lengths, dtype=np.uint64)
+    hist = np.zeros(int(np.max(p)) + 1, dtype=np.uint64)
+    thr = float(np.float32(threshold))
+    pf = p.astype(np.float64)
+    for i in range(len(p) - 1):
+        x = p[i]
+        if x == 0:
+            continue
+        y = p[i + 1:]
+        yf = pf[i + 1:]
+        lo = np.minimum(x, y)
+        hi_f = np.maximum(pf[i], yf)
+        lo_f = np.minimum(pf[i], yf)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            frac = hi_f / lo_f - (np.maximum(x, y) // np.where(lo == 0, 1, lo)).astype(np.float64)
+        ok = (y != 0) & (frac < thr)
+        np.add.at(hist, lo[ok].astype(np.int64), 1)
+    return hist
+
+
+def get_bit_length_from_plateau_lengths(merged_plateau_lengths) -> int:
+    """AutoInterpretation.py:344-370"""
+    if len(merged_plateau_lengths) == 0:
+        return 0
+    if len(merged_plateau_lengths) == 1:
+        return int(merged_plateau_lengths[0])
+    round_plateau_lengths(merged_plateau_lengths)
+    histogram = get_threshold_divisor_histogram(merged_plateau_lengths)
+    if len(histogram) == 0:
+        return 0
+    sorted_indices = np.argsort(histogram)[::-1]
+    max_count = histogram[sorted_indices[0]]
+    result = sorted_indices[0]
+    for i in range(1, len(sorted_indices)):
+        if histogram[sorted_indices[i]] < 0.25 * max_count:
+            break
+        if sorted_indices[i] <= 0.5 * result:
+            result = sorted_indices[i]
+    return int(result)
+
+
+def estimate_dev(pipe, iq, noise: float = None, modulation: str = None):
+    """AutoInterpretation.estimate (AutoInterpretation.py:373-470) for a float32 capture resident on the GPU: every pass
+    over the samples (magnitude statistics, segmentation, demodulation, per-message center and plateau boundaries) runs
+    on the GPU, the per-message decisions on the host.  `modulation` must be given: detect_modulation (wavelet transform)
+    is not on this path yet."""
+    from .pipeline import DemodParams
+    torch = pipe.torch
+    if iq.dtype == torch.complex64:
+        iq = torch.view_as_real(iq)
+    if modulation is None:
+        raise NotImplementedError("automatic modulation detection is not part of the GPU path: pass modulation=")
+    noise = detect_noise_level_dev(pipe, iq) if noise is None else noise
+    message_indices = segment_messages_dev(pipe, iq, noise)
+    if modulation == "OOK":
+        message_indices = merge_message_segments_for_ook(message_indices)
+    if modulation in ("OOK", "ASK"):
+        mod = "ASK"
+    elif modulation in ("FSK", "PSK"):
+        mod = modulation
+    else:
+        raise ValueError("Unsupported Modulation")
+    data = pipe.afp_demod(iq, DemodParams(mod, 1, float(noise)))
+    centers, bit_lengths, tolerances = [], [], []
+    for start, end in message_indices:
+        msg = data[start:end]
+        center = detect_center_dev(pipe, msg)
+        if center is None:
+            continue
+        plateau_lengths = get_plateau_lengths_dev(pipe, msg, center, percentage=25)
+        tolerance = estimate_tolerance_from_plateau_lengths(plateau_lengths)
+        if tolerance is None:
+            tolerance = 0
+        else:
+            tolerances.append(tolerance)
+        merged_lengths = merge_plateau_lengths(plateau_lengths, tolerance=tolerance)
+        if len(merged_lengths) < 2:
+            continue
+        bit_length = get_bit_length_from_plateau_lengths(merged_lengths)
+        if bit_length > tolerance + 1:
+            centers.append(center)
+            bit_lengths.append(bit_length)
+    if modulation in ("OOK", "ASK"):
+        center = min_without_outliers(np.array(centers), z=2)
+        if center is None:
+            return None
+    elif len(centers) > 0:
+        center = np.mean(centers)
+    else:
+        return None
+    bit_length = get_most_frequent_value(bit_lengths)
+    if bit_length is None:
+        return None
+    try:
+        tolerance = np.percentile(tolerances, 50)
+    except IndexError:
+        tolerance = max(1, int(0.05 * bit_length))
+    return {"modulation_type": "ASK" if modulation == "OOK" else modulation, "bit_length": bit_length, "center": center,
+            "tolerance": int(tolerance), "noise": noise}
