@@ -434,3 +434,90 @@ def test_estimate_equals_reference_goldens(pipe):
         assert got["modulation_type"] == w["modulation_type"] and int(got["bit_length"]) == w["bit_length"] \
             and int(got["tolerance"]) == w["tolerance"], (key, got, w)
         assert float(got["center"]) == w["center"] and float(got["noise"]) == w["noise"], (key, got, w)
+
+
+# ---- BASELINE.json full-size configurations: size-independent properties -------------------------------------------------
+def test_full_size_fsk_1gib_properties(pipe):
+    """configs[1] at full size (1 GiB complex64 2-FSK @ 100 samples/symbol): the recovered bits equal the transmitted
+    bits (one message: the 76-sample gaps between segments are short pauses), the pulse-table lengths add up to the
+    capture, and the 8-way sharded pass (8 simulated ranks, 128 MiB each: configs[3] per-GPU logic) gives the same
+    rows / bits / positions / qad bit for bit."""
+    import torch
+    from test_sharding import run_threads
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.shard_engine import GpuShardEngine
+    from urh_amd.sharding import shard_bounds, stitch
+    from urh_amd.synth import fsk_capture
+    dev = torch.device("cuda", 0)
+    segs, sps, tol = 128, 100, 5
+    iq, tx = fsk_capture(segs, dev, seed=1234, sps=sps)
+    n = iq.shape[0]
+    assert n == 1 << 27
+    p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, tol, sps, 0.1, 8, True)
+    res = pipe.iq_to_bits(iq, p, want_qad=True)
+    res.check_capacity()
+    rows = res.ppseq()
+    bits, off, pauses, pos, poff = res.flat()
+    # lengths: first row r+1, last row n-1-r_last-tol => sum = n - tol
+    assert int(rows[:, 1].sum()) == n - tol
+    assert len(pauses) == 1 and off[-1] == len(bits)
+    # transmitted symbols: per segment 10485 symbols, then a 76-sample gap that demodulates to noise (random states)
+    nsym = tx.shape[1]
+    txb = tx.cpu().numpy()
+    got = bits
+    # align per segment through bit_sample_pos: bit k of the message starts at sample pos[k]
+    seg_of = pos[:len(bits)] // (1 << 20)
+    sym_of = (pos[:len(bits)] % (1 << 20) + sps // 2) // sps
+    ok = sym_of < nsym
+    errors = int((got[ok] != txb[seg_of[ok], sym_of[ok]]).sum())
+    assert ok.sum() > 0.999 * segs * nsym and errors < 1e-4 * ok.sum(), (int(ok.sum()), errors)
+    want = (rows, bits, off, pauses, pos, poff)
+    qad_sum = int(res.qad.view(torch.int32).to(torch.int64).sum().item())
+    world = 8
+    bounds = shard_bounds(n, world)
+    shards = [iq[a:b] for a, b in bounds]
+    out = run_threads(world, lambda r: GpuShardEngine(0), shards, bounds, n, p)
+    got_all = stitch(out)
+    for k, (a, b) in enumerate(zip(got_all, want)):
+        assert np.array_equal(a, b), (k, len(a), len(b))
+    assert sum(int(r.qad.view(torch.int32).to(torch.int64).sum().item()) for r in out) == qad_sum
+
+
+def test_config3_ook_fir_auto_noise_pipeline(pipe, sf, oracle):
+    """configs[2] (OOK + 64-tap FIR band-pass + automatic noise threshold) at a size the oracle finishes in seconds:
+    Signal.filter_range semantics (fir_filter), detect_noise_level, ASK demodulation and digitization, each stage and
+    the final bits identical to the oracle."""
+    import torch
+    from urh_amd import estimators
+    from urh_amd.pipeline import DemodParams
+    rng = np.random.default_rng(4321)
+    n, sps = 1 << 20, 100
+    chips = np.repeat(np.array([[1, 0], [0, 1]])[rng.integers(0, 2, n // sps // 2 + 1)].reshape(-1), sps)[:n]   # Manchester
+    env = chips.astype(np.float64)
+    env[:n // 8] = 0                                                        # leading noise-only stretch (for the estimator)
+    env[n // 2:n // 2 + 60_000] = 0                                         # a long pause: two messages
+    ph = 2 * np.pi * 0.04 * np.arange(n)
+    iq = (env[:, None] * np.stack([np.cos(ph), np.sin(ph)], 1) + 0.02 * rng.standard_normal((n, 2))).astype(np.float32)
+    m = 64
+    k = np.arange(m) - (m - 1) / 2
+    taps = (np.sinc(2 * 0.02 * k) * 2 * 0.02 * np.blackman(m) * np.exp(2j * np.pi * 0.04 * k)).astype(np.complex64)
+    x = iq.view(np.complex64).reshape(-1)
+    filt_want = oracle.fir_filter(x, taps)
+    filt = sf.fir_filter(x, taps)
+    assert cbits_equal(filt, filt_want)
+    fiq = np.ascontiguousarray(filt.view(np.float32).reshape(-1, 2))
+    noise_want = oracle.detect_noise_level(oracle.get_magnitudes(fiq))
+    d_fiq = torch.from_numpy(fiq).cuda()
+    noise = estimators.detect_noise_level_dev(pipe, d_fiq)
+    assert noise == noise_want and noise > 0
+    qad_want = oracle.afp_demod(fiq, noise, "ASK", 2)
+    center = float(oracle.detect_center(qad_want))
+    p = DemodParams("ASK", 1, noise, center, 1.0, 5, sps, 0.1, 8, True)
+    res = pipe.iq_to_bits(d_fiq, p, want_qad=True)
+    assert bits_equal(res.qad.cpu().numpy(), qad_want)
+    assert float(estimators.detect_center_dev(pipe, res.qad)) == center
+    pp = oracle.grab_pulse_lens(qad_want, center, 5, "ASK", sps, 1, 1.0)
+    assert np.array_equal(res.ppseq(), pp)
+    fb = oracle.ppseq_to_bits_flat(pp, sps, 1, True, 8)
+    assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
+    assert len(fb[2]) >= 2                                                 # at least two messages
