@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Per-stage timings of the secondary kernels at BASELINE sizes (developer tool; run on the GPU box):
+FIR (64 taps), magnitude chunk statistics, qad-only demodulation, Costas loop, estimator passes."""
+import ctypes as C
+import json
+import sys
+import time
+
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from urh_amd import _lib, estimators
+from urh_amd.pipeline import DemodParams, DevicePipeline
+from urh_amd.synth import fsk_capture
+
+dev = torch.device("cuda", 0)
+pipe = DevicePipeline(0)
+lib, h = _lib.load(), pipe.ctx.handle
+segs = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+iq, _ = fsk_capture(segs, dev, seed=1)
+n = iq.shape[0]
+out = {"n": n}
+
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+pipe.ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+taps = torch.from_numpy((np.random.default_rng(0).standard_normal((64, 2)) * 0.1).astype(np.float32)).to(dev)
+fout = torch.empty_like(iq)
+t = timed(lambda: _lib.check(lib.urhgpu_fir_filter_dev(h, C.c_void_p(iq.data_ptr()), n, C.c_void_p(taps.data_ptr()), 64, None,
+                                                        C.c_void_p(fout.data_ptr()))))
+out["fir64"] = {"ms": t * 1e3, "Msamples/s": n / t / 1e6, "GB/s(16B/sample)": 16 * n / t / 1e9, "GFLOP/s(512/sample)": 512 * n / t / 1e9}
+t = timed(lambda: estimators.detect_noise_level_dev(pipe, iq))
+out["detect_noise_level"] = {"ms": t * 1e3, "GB/s(8B/sample)": 8 * n / t / 1e9}
+p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100)
+t = timed(lambda: pipe.afp_demod(iq, p))
+out["afp_demod_fsk_qad_only"] = {"ms": t * 1e3, "GB/s(12B/sample)": 12 * n / t / 1e9}
+pa = DemodParams("ASK", 1, 0.02, 0.3, 1.0, 5, 100)
+t = timed(lambda: pipe.iq_to_bits(iq, pa, want_qad=True))
+out["iq_to_bits_ask"] = {"ms": t * 1e3, "Msamples/s": n / t / 1e6}
+t = timed(lambda: estimators.segment_messages_dev(pipe, iq, 0.3), reps=3)
+out["segment_messages"] = {"ms": t * 1e3, "GB/s(8B/sample)": 8 * n / t / 1e9}
+qad = pipe.afp_demod(iq, p)
+t = timed(lambda: estimators.detect_center_dev(pipe, qad), reps=3)
+out["detect_center"] = {"ms": t * 1e3, "GB/s(4B/sample)": 4 * n / t / 1e9}
+t = timed(lambda: estimators.get_plateau_lengths_dev(pipe, qad, 0.0), reps=3)
+out["get_plateau_lengths"] = {"ms": t * 1e3}
+m = min(n, 1 << 23)
+pp = DemodParams("PSK", 2, 0.0, 0.0, 1.5, 5, 100)
+t = timed(lambda: pipe.afp_demod(iq[:m], pp), reps=1)
+out["costas_order4"] = {"samples": m, "ms": t * 1e3, "Msamples/s": m / t / 1e6}
+print(json.dumps(out, indent=1))

@@ -93,10 +93,16 @@ __global__ __launch_bounds__(256) void k_minmax_partials(const float *x, int64_t
         part[2 * blockIdx.x] = mn; part[2 * blockIdx.x + 1] = mx;
     }
 }
-__global__ void k_minmax_finish(const float *part, int nblocks, float *out2) {
+__global__ __launch_bounds__(64) void k_minmax_finish(const float *part, int nblocks, float *out2) {
     float mn = part[0], mx = part[1];
-    for (int b = 1; b < nblocks; ++b) { if (part[2 * b] < mn) mn = part[2 * b]; if (part[2 * b + 1] > mx) mx = part[2 * b + 1]; }
-    out2[0] = mn; out2[1] = mx;
+    for (int b = threadIdx.x; b < nblocks; b += 64) { if (part[2 * b] < mn) mn = part[2 * b]; if (part[2 * b + 1] > mx) mx = part[2 * b + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float a = __shfl_down(mn, o), b = __shfl_down(mx, o);
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+    if (threadIdx.x == 0) { out2[0] = mn; out2[1] = mx; }
 }
 constexpr int kMinmaxBlocks = 1024;
 size_t minmax_scratch_bytes() { return (size_t)kMinmaxBlocks * 8 + 64; }
@@ -104,7 +110,7 @@ int launch_minmax(const float *x, int64_t n, float *d_out2, void *scratch, hipSt
     if (n <= 0) return URHGPU_ERR_ARG;
     const int grid = (int)std::min<int64_t>((n + 255) / 256, kMinmaxBlocks);
     hipLaunchKernelGGL(k_minmax_partials, dim3(grid), dim3(256), 0, s, x, n, (float *)scratch);
-    hipLaunchKernelGGL(k_minmax_finish, dim3(1), dim3(1), 0, s, (const float *)scratch, grid, d_out2);
+    hipLaunchKernelGGL(k_minmax_finish, dim3(1), dim3(64), 0, s, (const float *)scratch, grid, d_out2);
     return URHGPU_OK;
 }
 
@@ -224,27 +230,37 @@ int pairwise_sum_f32(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, flo
 // count[k] = #{x : e[k] <= x < e[k+1]}, the last bin closed on the right; x compared as float64 (numpy casts the data to
 // the common type).  Edges are staged in LDS when they fit (<= 8192 edges), found by binary search; integer counts
 // accumulate with atomics (order independent => exact).
-constexpr int kHistEdgesLds = 8192;
+constexpr int kHistEdgesLds = 4096;
 
 __global__ __launch_bounds__(256) void k_hist_edges(const float *x, int64_t n, const double *edges, int n_edges,
                                                      unsigned long long *counts) {
+    // edges and a private copy of the counts live in LDS when they fit: detect_center's histograms are sharply peaked
+    // (two symbol levels), so device-wide atomics on the few hot bins would serialise the whole pass
     __shared__ double s_e[kHistEdgesLds];
+    __shared__ unsigned int s_c[kHistEdgesLds];
     const bool in_lds = n_edges <= kHistEdgesLds;
-    if (in_lds) for (int k = threadIdx.x; k < n_edges; k += 256) s_e[k] = edges[k];
+    if (in_lds) for (int k = threadIdx.x; k < n_edges; k += 256) { s_e[k] = edges[k]; s_c[k] = 0u; }
     __syncthreads();
     const double *e = in_lds ? s_e : edges;
     const double e0 = e[0], eN = e[n_edges - 1];
-    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    // a workgroup owns a contiguous slice (so that its private counters cannot overflow 32 bits: slice < 2^32 samples)
+    const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t a0 = blockIdx.x * per, a1 = (a0 + per < n) ? a0 + per : n;
+    for (int64_t i = a0 + threadIdx.x; i < a1; i += 256) {
         const double v = (double)x[i];
         if (!(v >= e0) || !(v <= eN)) continue;          // outside (or NaN)
-        // largest k with e[k] <= v, clamped to the last bin
-        int lo = 0, hi = n_edges - 1;                    // invariant: e[lo] <= v, and (hi == n_edges-1 or e[hi] > v)
+        int lo = 0, hi = n_edges - 1;                    // invariant: e[lo] <= v; hi == n_edges-1 or e[hi] > v
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
             if (e[mid] <= v) lo = mid; else hi = mid;
         }
-        if (lo == n_edges - 1) lo = n_edges - 2;        // v == last edge: closed last bin
-        atomicAdd(&counts[lo], 1ull);
+        // lo <= n_edges - 2: v == last edge lands in the (closed) last bin
+        if (in_lds) atomicAdd(&s_c[lo], 1u); else atomicAdd(&counts[lo], 1ull);
+    }
+    if (in_lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < n_edges - 1; k += 256)
+            if (s_c[k]) atomicAdd(&counts[k], (unsigned long long)s_c[k]);
     }
 }
 
@@ -252,7 +268,7 @@ int launch_hist_edges(const float *x, int64_t n, const double *d_edges, int n_ed
     if (n_edges < 2) return URHGPU_ERR_ARG;
     if (hipMemsetAsync(d_counts, 0, (size_t)(n_edges - 1) * 8, s) != hipSuccess) return URHGPU_ERR_HIP;
     if (n <= 0) return URHGPU_OK;
-    const int grid = (int)std::min<int64_t>((n + 255) / 256, 2048);
+    const int grid = (int)std::min<int64_t>((n + 4095) / 4096, 2048);
     hipLaunchKernelGGL(k_hist_edges, dim3(grid), dim3(256), 0, s, x, n, d_edges, n_edges, (unsigned long long *)d_counts);
     return URHGPU_OK;
 }

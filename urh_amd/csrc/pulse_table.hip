@@ -443,7 +443,9 @@ struct GroupStore {
 struct BitsCountsFinal {
     const int64_t *d_n_rows;
     int64_t *msg_off, *pos_off, *counts;
+    int32_t *huge_count;
     __device__ void operator()(const VecK<3> &grand) const {
+        *huge_count = 0;
         const int64_t n_rows = *d_n_rows;
         VecK<3> g; g.zero();
         if (n_rows > 0) g = grand;
@@ -451,6 +453,10 @@ struct BitsCountsFinal {
         msg_off[0] = 0; pos_off[0] = 0;
     }
 };
+
+struct HugeRow { int64_t kb, ob, op, ts, type; };   // a row that expands to more than kHugeBits bits
+constexpr int64_t kHugeBits = 4096;
+constexpr int kHugeCap = 8192;
 
 struct ExpandArgs {
     const int64_t *rows;
@@ -462,6 +468,9 @@ struct ExpandArgs {
     int64_t *pos;
     int64_t cap_pos;
     BitsParams bp;
+    HugeRow *huge;           // work list for k_expand_huge (long constant stretches: one row, thousands of bits)
+    int32_t *huge_count;     // zero before k_expand_bits (BitsCountsFinal), consumed by k_expand_huge
+    int32_t huge_cap;
 };
 
 // one thread per row; rows with many bits are expanded cooperatively by the whole wavefront
@@ -500,10 +509,35 @@ __global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
         big &= big - 1;
         const int64_t kb_s = __shfl(kb, src), ob_s = __shfl(ob, src), op_s = __shfl(op, src), ts_s = __shfl(ts, src),
                       ty_s = __shfl(type, src);
+        if (kb_s > kHugeBits) {                              // too long for one wavefront: hand it to the whole grid
+            int slot = 0;
+            if (lane == 0) slot = atomicAdd(a.huge_count, 1);
+            slot = __shfl(slot, 0);
+            if (slot < a.huge_cap) {
+                if (lane == 0) a.huge[slot] = HugeRow{kb_s, ob_s, op_s, ts_s, ty_s};
+                continue;
+            }
+        }
         for (int64_t k = lane; k < kb_s; k += 64) {
             const uint8_t b = (ty_s < 0) ? 0 : (uint8_t)((ty_s >> (bps - 1 - (int)(k % bps))) & 1);
             if (ob_s + k < a.cap_bits) a.bits[ob_s + k] = b;
             if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
+        }
+    }
+}
+
+// rows of more than kHugeBits bits, spread over the whole grid
+__global__ __launch_bounds__(256) void k_expand_huge(const ExpandArgs a) {
+    int cnt = *a.huge_count;
+    if (cnt > a.huge_cap) cnt = a.huge_cap;
+    const int bps = (int)a.bp.bps;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int w = 0; w < cnt; ++w) {
+        const HugeRow r = a.huge[w];
+        for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < r.kb; k += stride) {
+            const uint8_t b = (r.type < 0) ? 0 : (uint8_t)((r.type >> (bps - 1 - (int)(k % bps))) & 1);
+            if (r.ob + k < a.cap_bits) a.bits[r.ob + k] = b;
+            if (a.bp.write_pos && r.op + k < a.cap_pos) a.pos[r.op + k] = r.ts + k * a.bp.samples_per_bit;
         }
     }
 }
@@ -554,12 +588,14 @@ size_t bits_scratch_bytes(int64_t cap_rows) {
     const int64_t cap_groups = cap_rows + 1;
     const int64_t nbg = scan_blocks(cap_groups);
     return (size_t)(nb + 1) * sizeof(VecK<4>) + (size_t)(nbg + 1) * sizeof(VecK<3>) + (size_t)cap_rows * sizeof(RowInfo) +
-           (size_t)cap_groups * (sizeof(GroupInfo) + sizeof(GroupOut)) + 64 + 8 * 256;
+           (size_t)cap_groups * (sizeof(GroupInfo) + sizeof(GroupOut)) + 64 + 8 * 256 + 64 + 256 +
+           (size_t)kHugeCap * sizeof(HugeRow) + 256;
 }
 
 namespace {
 struct BitsScratch {
     VecK<4> *part4; VecK<3> *part3; RowInfo *info; GroupInfo *groups; GroupOut *gout; int64_t *d_n_groups;
+    HugeRow *huge; int32_t *huge_count;
     int64_t nb, nbg;
 };
 BitsScratch carve_bits(void *scratch, int64_t cap_rows) {
@@ -575,6 +611,8 @@ BitsScratch carve_bits(void *scratch, int64_t cap_rows) {
     b.groups = (GroupInfo *)take((size_t)cap_groups * sizeof(GroupInfo));
     b.gout = (GroupOut *)take((size_t)cap_groups * sizeof(GroupOut));
     b.d_n_groups = (int64_t *)take(64);
+    b.huge_count = (int32_t *)take(64);
+    b.huge = (HugeRow *)take((size_t)kHugeCap * sizeof(HugeRow));
     return b;
 }
 }  // namespace
@@ -617,14 +655,15 @@ int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap
     const BitsScratch b = carve_bits(scratch, cap_rows);
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
-    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts};
+    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count};
     hipLaunchKernelGGL((k_scan_reduce<3, GroupLoad>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s, b.d_n_groups, gl, b.part3, b.nbg,
                        tickets + 2);
     hipLaunchKernelGGL((k_scan_apply<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, b.part3, b.nbg, gs, fin, tickets + 3);
-    ExpandArgs ea{rows, d_n_rows, b.info, b.gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp};
+    ExpandArgs ea{rows, d_n_rows, b.info, b.gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp, b.huge, b.huge_count, kHugeCap};
     const int64_t eb = (cap_rows + 255) / 256;
     hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)eb), dim3(256), 0, s, ea);
+    hipLaunchKernelGGL(k_expand_huge, dim3(512), dim3(256), 0, s, ea);
     return URHGPU_OK;
 }
 
