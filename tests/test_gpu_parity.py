@@ -521,3 +521,26 @@ def test_config3_ook_fir_auto_noise_pipeline(pipe, sf, oracle):
     fb = oracle.ppseq_to_bits_flat(pp, sps, 1, True, 8)
     assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
     assert len(fb[2]) >= 2                                                 # at least two messages
+
+
+@pytest.mark.parametrize("order", [2, 4])
+def test_costas_parallel_chain_large(sf, oracle, order):
+    """configs[4]-like PSK capture of 4 Mi samples (carrier 0.04 cycles/sample, AWGN, a long gated pause, an un-gated
+    noise-only stretch): the speculative chunk evaluation of the Costas loop is bit-exact, and most chunks resolve
+    through a matching candidate."""
+    from urh_amd import _lib
+    rng = np.random.default_rng(100 + order)
+    n, sps = 1 << 22, 100
+    sym = rng.integers(0, order, n // sps + 1)
+    phases = (np.array([-135, -45, 45, 135]) if order == 4 else np.array([-90, 90]))[sym] * np.pi / 180
+    ph = np.repeat(phases, sps)[:n] + 2 * np.pi * 0.04 * np.arange(n)
+    iq = np.stack([np.cos(ph), np.sin(ph)], 1) + 0.1 * np.sqrt(0.5) * rng.standard_normal((n, 2))
+    iq[1_000_000:1_300_000] *= 0.01                          # gated pause (below the noise threshold)
+    iq[2_000_000:2_050_000] = 0.5 * rng.standard_normal((50_000, 2))   # un-gated noise: the loop wanders
+    iq = iq.astype(np.float32)
+    want = oracle.afp_demod(iq, 0.2, "PSK", order, 0.1)
+    got = sf.afp_demod(iq, 0.2, "PSK", order, 0.1)
+    assert bits_equal(got[1:], want[1:]), int((got[1:] != want[1:]).sum())
+    stats = _lib.default_context().costas_stats()
+    assert sum(stats) == (n - 1 + 4095) // 4096 - 1
+    assert stats[0] > 0.8 * sum(stats), stats

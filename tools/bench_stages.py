@@ -53,8 +53,14 @@ t = timed(lambda: estimators.detect_center_dev(pipe, qad), reps=3)
 out["detect_center"] = {"ms": t * 1e3, "GB/s(4B/sample)": 4 * n / t / 1e9}
 t = timed(lambda: estimators.get_plateau_lengths_dev(pipe, qad, 0.0), reps=3)
 out["get_plateau_lengths"] = {"ms": t * 1e3}
-m = min(n, 1 << 23)
-pp = DemodParams("PSK", 2, 0.0, 0.0, 1.5, 5, 100)
-t = timed(lambda: pipe.afp_demod(iq[:m], pp), reps=1)
-out["costas_order4"] = {"samples": m, "ms": t * 1e3, "Msamples/s": m / t / 1e6}
+import math
+m = n
+k = torch.arange(m, device=dev, dtype=torch.float64)
+sym = torch.randint(0, 4, (m // 100 + 1,), device=dev).repeat_interleave(100)[:m]
+ph = (sym.to(torch.float64) * (math.pi / 2) - 3 * math.pi / 4) + 2 * math.pi * 0.04 * k
+psk = torch.stack([torch.cos(ph), torch.sin(ph)], 1).to(torch.float32) + 0.07 * torch.randn((m, 2), device=dev)
+del k, sym, ph
+pp = DemodParams("PSK", 2, 0.2, 0.0, 1.5, 5, 100)
+t = timed(lambda: pipe.afp_demod(psk, pp), reps=2)
+out["costas_order4"] = {"samples": m, "ms": t * 1e3, "Msamples/s": m / t / 1e6, "chunks(map,ckpt,serial)": pipe.ctx.costas_stats()}
 print(json.dumps(out, indent=1))

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "urhgpu_ctx_sync": (_i, [_vp]),
     "urhgpu_ctx_reserve": (_i, [_vp, _i64, _i]),
     "urhgpu_ctx_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.c_char_p, _i]),
+    "urhgpu_ctx_costas_stats": (_i, [_vp, C.POINTER(C.c_int32)]),
     "urhgpu_ctx_profile_begin": (_i, [_vp, _i]),
     "urhgpu_ctx_profile_end": (_i, [_vp, C.POINTER(C.c_float), _i, C.POINTER(_i)]),
     "urhgpu_get_magnitudes": (_i, [_vp, _vp, _i, _i64, _vp]),
@@ -188,6 +189,12 @@ class Context:
         n = C.c_int(0)
         check(load().urhgpu_ctx_profile_end(self._h, ms, cap, C.byref(n)))
         return [float(ms[i]) for i in range(min(n.value, cap))]
+
+    def costas_stats(self):
+        """(chunks matched by a candidate, chunks met at a checkpoint, chunks evaluated serially) of the last PSK pass"""
+        out = (C.c_int32 * 3)()
+        check(load().urhgpu_ctx_costas_stats(self._h, out))
+        return tuple(int(v) for v in out)
 
     def close(self):
         if self._h:

@@ -261,6 +261,7 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->arena.release();
     ctx->staging.release();
+    ctx->aux.release();
     delete (ShardSession *)ctx->shard;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -349,7 +350,14 @@ int urhgpu_afp_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urh
         return URHGPU_OK;
     }
     if (((uintptr_t)d_iq & 15) || ((uintptr_t)d_qad & 7)) return URHGPU_ERR_ARG;
-    if (p->mod == URHGPU_MOD_PSK) return launch_costas(ctx, d_iq, n, p, d_qad);
+    if (p->mod == URHGPU_MOD_PSK) {
+        URH_TRY(ctx->aux.reserve(costas_scratch_bytes(n) + 1024));
+        ctx->aux.reset();
+        void *scratch = ctx->aux.take(costas_scratch_bytes(n));
+        URH_TRY(launch_costas(ctx, d_iq, n, p, d_qad, scratch));
+        URH_HIP(hipGetLastError());
+        return URHGPU_OK;
+    }
     RunArgs a;
     memset(&a, 0, sizeof(a));
     a.in = d_iq; a.qad = d_qad; a.n = n; a.left_halo = nullptr;
@@ -652,6 +660,14 @@ int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const
     URH_HIP(hipSetDevice(ctx->device));
     URH_TRY(launch_hist_edges(d_x, n, d_edges, (int)n_edges, d_counts, ctx->stream));
     URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_costas_stats(urhgpu_ctx *ctx, int32_t *out3) {
+    if (!ctx || !out3) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(out3, ctx->h_counts + 12, 12);
     return URHGPU_OK;
 }
 

@@ -56,6 +56,7 @@ struct urhgpu_ctx {
     hipDeviceProp_t prop;
     urh::Arena arena;        // per-call scratch (tables, slabs, scan partials)
     urh::Arena staging;      // device mirrors of host buffers for the host-pointer entry points
+    urh::Arena aux;          // Costas candidate / checkpoint states (lives across the arena / staging users)
     int64_t *d_counts = nullptr;   // small device result block (8 x int64)
     int64_t *h_counts = nullptr;   // pinned host mirror
     int32_t *d_tickets = nullptr;  // 8 zeroed ints: elections of the fused scan kernels (scan.hpp)

@@ -1,0 +1,320 @@
+// costas.hip -- the Costas-loop PSK demodulator (row 5 of SURVEY.md §8a) for gfx950.
+//
+//   costa_demod   /root/reference/src/urh/cythonext/signal_functions.pyx:252-330
+//
+// The loop is a nonlinear recurrence over the whole capture: state (freq, phase) in float32, per step a noise gate,
+// sinf / cosf of the phase (glibc's, restated in glibc_sincosf.h), a complex product, a clamped error, two state
+// updates, a wrap into +-2*pi evaluated in double.  Every output must equal the serial evaluation bit for bit.
+//
+// Exact parallel evaluation (k_costas_spec / k_costas_map / k_costas_stitch / k_costas_final):
+//   * The capture is cut into chunks of kChunk samples.  Started from ANY state, the loop forgets that state: after
+//     some hundred un-gated samples two trajectories that lock onto the same phase ambiguity become bit-identical
+//     (measured on the reference).  The lock points are pi/2 (order 4) or pi (order 2) apart, each with a
+//     twin 2*pi away inside the +-2*pi wrap range.
+//   * k_costas_spec runs, for every chunk, one candidate per lock point: it starts kWarm un-gated samples before the
+//     chunk from phase 1.5 + k * (pi/2 | pi), freq 0, and records the candidate's state at the chunk start (S), at
+//     checkpoints inside the chunk (CP) and at its end (E).  Chunk 0's candidate 0 IS the true trajectory.
+//   * k_costas_map: for every chunk c and candidate k of chunk c-1, which candidate of chunk c starts (bitwise) in
+//     E[c-1][k]?  k_costas_stitch follows this map from chunk 0: as long as a candidate matches, the true state at
+//     the next chunk start is known without touching a sample.  Where nothing matches (acquisition, long gated
+//     stretches) it evaluates the chunk serially from the true state, leaving it as soon as the state equals a
+//     candidate's checkpoint.  Either way the TRUE state at every chunk start comes out.
+//   * k_costas_final re-evaluates every chunk from its true start state, in parallel, and writes the output.
+// The result is exact by construction (equality is tested on the state bits, never assumed); only the speed depends on
+// how quickly candidates converge.  Work: (K (kWarm + kChunk) + kChunk) steps per chunk instead of kChunk.
+// Loop orders other than 2 and 4 leave the output unwritten in the reference; they use the serial kernel.
+//
+// Bound: dependent-instruction latency, hidden by running one chunk-candidate per lane over the whole machine.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <math.h>
+
+#include "cmul.hpp"
+#include "common.hpp"
+#include "launchers.hpp"
+#include "glibc_sincosf.h"
+
+namespace urh {
+
+struct CostasArgs {
+    const void *iq; int64_t n; float *out;
+    float noise_sqrd, alpha, beta, scale, shift;
+    int loop_order;
+};
+struct CostasState { float freq, phase; };
+
+__device__ __forceinline__ float costas_clamp(float x) {      // :246-250
+    if (x < -1.0f) x = -1.0f;
+    else if (x > 1.0f) x = 1.0f;
+    return x;
+}
+
+template <int DT> struct CostasLoad;
+template <> struct CostasLoad<URHGPU_DT_F32> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { return ((const float2 *)p)[i]; } };
+template <> struct CostasLoad<URHGPU_DT_I8> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { const char2 v = ((const char2 *)p)[i]; return make_float2((float)v.x, (float)v.y); } };
+template <> struct CostasLoad<URHGPU_DT_U8> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { const uchar2 v = ((const uchar2 *)p)[i]; return make_float2((float)v.x, (float)v.y); } };
+template <> struct CostasLoad<URHGPU_DT_I16> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { const short2 v = ((const short2 *)p)[i]; return make_float2((float)v.x, (float)v.y); } };
+template <> struct CostasLoad<URHGPU_DT_U16> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { const ushort2 v = ((const ushort2 *)p)[i]; return make_float2((float)v.x, (float)v.y); } };
+
+__device__ __forceinline__ bool costas_gated(float2 sm, const CostasArgs &a) { return sm.x * sm.x + sm.y * sm.y <= a.noise_sqrd; }
+
+// One sample of the loop (:291-328): returns the output, updates the state.  err is only carried for loop orders
+// other than 2 / 4 (where it never changes); callers keep it.
+__device__ __forceinline__ float costas_step(float2 sm, CostasState &st, float &err, const CostasArgs &a) {
+    if (costas_gated(sm, a)) return -4.0f;                              // NOISE_FSK_PSK, state frozen (:293-295)
+    const double two_pi = 2 * 3.14159265358979323846;
+    const float real_float = (sm.x + a.shift) / a.scale, imag_float = (sm.y + a.shift) / a.scale;
+    const float2 cur = make_float2(real_float + 0.0f * imag_float, 1.0f * imag_float);   // re + imag_unit * im
+    const float sn = urh_sinf(-st.phase), cs = urh_cosf(-st.phase);
+    const float2 nco = make_float2(cs + 0.0f * sn, 1.0f * sn);
+    const float2 z = cmul(nco, cur);
+    if (a.loop_order == 2) {
+        err = z.y * z.x;
+    } else if (a.loop_order == 4) {
+        const float f1 = z.x > 0.0f ? 1.0f : -1.0f, f2 = z.y > 0.0f ? 1.0f : -1.0f;
+        err = f1 * z.y - f2 * z.x;
+    }
+    err = costas_clamp(err);
+    st.freq += a.beta * err;
+    st.phase += st.freq + a.alpha * err;
+    while ((double)st.phase > two_pi) st.phase = (float)((double)st.phase - two_pi);     // double compare / subtract (:318-321)
+    while ((double)st.phase < -two_pi) st.phase = (float)((double)st.phase + two_pi);
+    st.freq = costas_clamp(st.freq);
+    if (a.loop_order == 2) return z.x;
+    if (a.loop_order == 4) return (float)(2.0 * (double)z.x + (double)z.y);
+    return 0.0f;
+}
+
+// ---- serial evaluation: one wavefront, every lane the same recurrence, lane k keeps outputs k, k+64, ... of a tile ----
+constexpr int kCostasTile = 1024;
+
+template <int DT>
+__global__ __launch_bounds__(64) void k_costas(const CostasArgs a) {
+    __shared__ float2 s_x[kCostasTile];
+    const int lane = threadIdx.x;
+    CostasState st{0.0f, 1.5f};                                // :261
+    float err = 0.0f;
+    if (lane == 0 && a.n > 0) a.out[0] = -4.0f;                // reference: np.empty, never written (documented in urhgpu.h)
+    for (int64_t base = 0; base < a.n; base += kCostasTile) {
+        const int tv = (int)((a.n - base < kCostasTile) ? (a.n - base) : kCostasTile);
+        __syncthreads();
+        for (int u = lane; u < tv; u += 64) s_x[u] = CostasLoad<DT>::at(a.iq, base + u);
+        __syncthreads();
+        float mine[kCostasTile / 64];
+#pragma unroll 1
+        for (int g = 0; g < kCostasTile / 64; ++g) {
+            float keep = 0.0f;
+#pragma unroll 1
+            for (int u = 0; u < 64; ++u) {
+                const int k = g * 64 + u;
+                if (k >= tv || (base + k) == 0) continue;       // the loop starts at sample 1 (:289)
+                const float o = costas_step(s_x[k], st, err, a);
+                if (u == lane) keep = o;
+            }
+            mine[g] = keep;
+        }
+#pragma unroll 1
+        for (int g = 0; g < kCostasTile / 64; ++g) {
+            const int k = g * 64 + lane;
+            if (k < tv && base + k != 0) a.out[base + k] = mine[g];
+        }
+    }
+}
+
+// ---- speculative parallel evaluation ----------------------------------------------------------------------------------
+constexpr int kChunk = 4096;        // samples per chunk
+constexpr int kWarm = 1024;         // un-gated samples a candidate runs before its chunk
+constexpr int kWarmBack = 16384;    // ... looking back at most this many samples for them
+constexpr int kCkpt = 256;          // checkpoint spacing inside a chunk
+constexpr int kNumCkpt = kChunk / kCkpt;   // checkpoints at offsets kCkpt, 2 kCkpt, ... < kChunk  (index j = off / kCkpt - 1)
+constexpr int kMaxCand = 8;
+
+struct SpecBuffers {
+    CostasState *S;        // [n_chunks][K]  state at the chunk start (before its first sample)
+    CostasState *E;        // [n_chunks][K]  state after the chunk's last sample
+    CostasState *CP;       // [n_chunks][kNumCkpt][K] state after offset (j+1)*kCkpt samples of the chunk
+    uint32_t *map;         // [n_chunks] nibble k: candidate of this chunk that starts in E[c-1][k], 0xF none
+    CostasState *T;        // [n_chunks] TRUE state at the chunk start (written by the stitch)
+    int32_t *stats;        // [0] chunks resolved by the map, [1] by a checkpoint inside a serial run, [2] fully serial
+};
+
+__device__ __forceinline__ bool same_state(CostasState a, CostasState b) {
+    return __float_as_uint(a.freq) == __float_as_uint(b.freq) && __float_as_uint(a.phase) == __float_as_uint(b.phase);
+}
+__device__ __forceinline__ int64_t chunk_begin(int64_t c) { return 1 + c * (int64_t)kChunk; }   // sample 0 is not part of the loop
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K) {
+    const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
+    const int64_t c = gid / K;
+    const int k = (int)(gid % K);
+    if (c >= n_chunks) return;
+    const int64_t s0 = chunk_begin(c);
+    const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
+    // candidate k: phase 1.5 + (k - K/2) * (2*pi / (K/2)) ... spaced pi/2 (order 4, K = 8) or pi (order 2, K = 4); candidate K/2 is
+    // the reference's own initial state (phase 1.5)
+    const float spacing = (a.loop_order == 4) ? 1.57079632679489661923f : 3.14159265358979323846f;
+    CostasState st{0.0f, 1.5f + (float)(k - K / 2) * spacing};
+    float err = 0.0f;
+    int64_t p = s0;
+    if (c == 0) {
+        st = CostasState{0.0f, 1.5f};                       // every candidate of chunk 0 is the true trajectory
+    } else {
+        int ungated = 0;
+        while (p > 1 && ungated < kWarm && s0 - p < kWarmBack) {
+            --p;
+            if (!costas_gated(CostasLoad<DT>::at(a.iq, p), a)) ++ungated;
+        }
+        if (p == 1) st = CostasState{0.0f, 1.5f};           // reached the start of the capture: exact, not a guess
+        for (int64_t i = p; i < s0; ++i) costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
+    }
+    b.S[c * K + k] = st;
+    for (int64_t i = s0; i < e0; ++i) {
+        costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
+        const int off = (int)(i - s0) + 1;
+        if (off % kCkpt == 0 && off < kChunk) b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + k] = st;
+    }
+    b.E[c * K + k] = st;
+}
+
+__global__ __launch_bounds__(256) void k_costas_map(SpecBuffers b, int64_t n_chunks, int K) {
+    const int64_t c = blockIdx.x * 256ll + threadIdx.x;
+    if (c >= n_chunks) return;
+    uint32_t m = 0xFFFFFFFFu;
+    if (c > 0) {
+        for (int k = 0; k < K; ++k) {
+            const CostasState e = b.E[(c - 1) * K + k];
+            int hit = 0xF;
+            for (int q = 0; q < K; ++q) if (same_state(e, b.S[c * K + q])) { hit = q; break; }
+            m = (m & ~(0xFu << (4 * k))) | ((uint32_t)hit << (4 * k));
+        }
+    }
+    b.map[c] = m;
+}
+
+// One wavefront walks the chunks in order (every lane the same control flow; lanes < K compare checkpoints).
+template <int DT>
+__global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K) {
+    const int lane = threadIdx.x;
+    int cand = 0;                                   // chunk 0: candidate 0 is exact
+    CostasState T{0.0f, 1.5f};                      // true state at the start of the current chunk
+    int n_map = 0, n_ckpt = 0, n_serial = 0;
+    if (lane == 0) b.T[0] = T;
+    for (int64_t c = 1; c < n_chunks; ++c) {
+        // true state at the start of chunk c
+        if (cand >= 0) T = b.E[(c - 1) * K + cand];
+        if (lane == 0) b.T[c] = T;
+        // which candidate of chunk c is the true trajectory?
+        int next = -1;
+        if (cand >= 0) {
+            const uint32_t nib = (b.map[c] >> (4 * cand)) & 0xFu;
+            if (nib != 0xFu) next = (int)nib;
+        } else {
+            const bool hit = lane < K && same_state(T, b.S[c * K + lane]);
+            const unsigned long long m = __ballot(hit);
+            if (m) next = __builtin_ctzll(m);
+        }
+        if (next >= 0) { cand = next; ++n_map; continue; }
+        // no candidate starts in T: evaluate the chunk from T until the state meets a candidate at a checkpoint
+        const int64_t s0 = chunk_begin(c);
+        const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
+        float err = 0.0f;
+        CostasState st = T;
+        cand = -1;
+        for (int64_t i = s0; i < e0; ++i) {
+            costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
+            const int off = (int)(i - s0) + 1;
+            if (off % kCkpt == 0 && off < kChunk) {
+                const bool hit = lane < K && same_state(st, b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + lane]);
+                const unsigned long long m = __ballot(hit);
+                if (m) { cand = __builtin_ctzll(m); break; }
+            }
+        }
+        if (cand >= 0) ++n_ckpt;
+        else { ++n_serial; T = st; }                // T now holds the state at the END of chunk c (used as start of c+1)
+        if (cand < 0) {
+            // the next iteration takes T as the start state of chunk c+1 (cand < 0 path)
+        }
+    }
+    if (lane == 0) { b.stats[0] = n_map; b.stats[1] = n_ckpt; b.stats[2] = n_serial; }
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void k_costas_final(const CostasArgs a, SpecBuffers b, int64_t n_chunks) {
+    const int64_t c = blockIdx.x * 256ll + threadIdx.x;
+    if (c >= n_chunks) return;
+    if (c == 0 && a.n > 0) a.out[0] = -4.0f;        // reference: np.empty, never written (documented in urhgpu.h)
+    const int64_t s0 = chunk_begin(c);
+    const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
+    CostasState st = b.T[c];
+    float err = 0.0f;
+    for (int64_t i = s0; i < e0; ++i) a.out[i] = costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
+}
+
+size_t costas_scratch_bytes(int64_t n) {
+    const int64_t nc = (std::max<int64_t>(n - 1, 0) + kChunk - 1) / kChunk + 1;
+    return (size_t)nc * kMaxCand * sizeof(CostasState) * 2 + (size_t)nc * kNumCkpt * kMaxCand * sizeof(CostasState) +
+           (size_t)nc * 4 + (size_t)nc * sizeof(CostasState) + 64 + 8 * 256;
+}
+
+template <int DT>
+static int launch_costas_dt(const CostasArgs &a, void *scratch, int64_t *h_stats, urhgpu_ctx *ctx) {
+    hipStream_t s = ctx->stream;
+    const bool parallel = (a.loop_order == 2 || a.loop_order == 4) && a.n > 2 * kChunk && scratch != nullptr;
+    if (!parallel) {
+        hipLaunchKernelGGL(k_costas<DT>, dim3(1), dim3(64), 0, s, a);
+        return URHGPU_OK;
+    }
+    const int K = (a.loop_order == 4) ? 8 : 4;
+    const int64_t nc = (a.n - 1 + kChunk - 1) / kChunk;
+    char *p = (char *)scratch;
+    auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~size_t(255); return r; };
+    SpecBuffers b;
+    b.S = (CostasState *)take((size_t)nc * K * sizeof(CostasState));
+    b.E = (CostasState *)take((size_t)nc * K * sizeof(CostasState));
+    b.CP = (CostasState *)take((size_t)nc * kNumCkpt * K * sizeof(CostasState));
+    b.map = (uint32_t *)take((size_t)nc * 4);
+    b.T = (CostasState *)take((size_t)nc * sizeof(CostasState));
+    b.stats = (int32_t *)take(64);
+    hipLaunchKernelGGL(k_costas_spec<DT>, dim3((unsigned)((nc * K + 255) / 256)), dim3(256), 0, s, a, b, nc, K);
+    hipLaunchKernelGGL(k_costas_map, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, b, nc, K);
+    hipLaunchKernelGGL(k_costas_stitch<DT>, dim3(1), dim3(64), 0, s, a, b, nc, K);
+    hipLaunchKernelGGL(k_costas_final<DT>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, a, b, nc);
+    if (h_stats) {
+        URH_HIP(hipMemcpyAsync(ctx->h_counts + 12, b.stats, 12, hipMemcpyDeviceToHost, s));
+    }
+    return URHGPU_OK;
+}
+
+int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, void *scratch) {
+    CostasArgs a;
+    a.iq = d_iq; a.n = n; a.out = d_qad;
+    a.noise_sqrd = p->noise_threshold * p->noise_threshold;
+    // :253-254 as the reference's generated code evaluates them (damping = (float)(sqrt(2)/2), bandwidth*bandwidth a float product)
+    const float bandwidth = p->costas_loop_bandwidth;
+    const float damping = (float)(sqrt(2.0) / 2.0);
+    const double den = (1.0 + ((2.0 * (double)damping) * (double)bandwidth)) + (double)(bandwidth * bandwidth);
+    a.alpha = (float)(((4.0 * (double)damping) * (double)bandwidth) / den);
+    a.beta = (float)(((4.0 * (double)bandwidth) * (double)bandwidth) / den);
+    switch (p->dtype) {                                        // :267-283
+        case URHGPU_DT_I8: a.scale = 127.5f; a.shift = 0.5f; break;
+        case URHGPU_DT_U8: a.scale = 127.5f; a.shift = -127.5f; break;
+        case URHGPU_DT_I16: a.scale = 32767.5f; a.shift = 0.5f; break;
+        case URHGPU_DT_U16: a.scale = 65535.0f; a.shift = -32767.5f; break;
+        case URHGPU_DT_F32: a.scale = 1.0f; a.shift = 0.0f; break;
+        default: return URHGPU_ERR_DTYPE;
+    }
+    int order = p->mod_order > 0 ? p->mod_order : (1 << p->bits_per_symbol);
+    if (order > 4) order = 4;                                  // :285-287
+    a.loop_order = order;
+    switch (p->dtype) {
+        case URHGPU_DT_I8: return launch_costas_dt<URHGPU_DT_I8>(a, scratch, ctx->h_counts, ctx);
+        case URHGPU_DT_U8: return launch_costas_dt<URHGPU_DT_U8>(a, scratch, ctx->h_counts, ctx);
+        case URHGPU_DT_I16: return launch_costas_dt<URHGPU_DT_I16>(a, scratch, ctx->h_counts, ctx);
+        case URHGPU_DT_U16: return launch_costas_dt<URHGPU_DT_U16>(a, scratch, ctx->h_counts, ctx);
+        default: return launch_costas_dt<URHGPU_DT_F32>(a, scratch, ctx->h_counts, ctx);
+    }
+}
+
+}  // namespace urh

@@ -14,48 +14,11 @@
 #include <algorithm>
 #include <math.h>
 
+#include "cmul.hpp"
 #include "common.hpp"
 #include "launchers.hpp"
 
 namespace urh {
-
-// ---- complex64 product exactly as GCC emits it for std::complex<float> / float _Complex --------------------
-__device__ __noinline__ float2 mulsc3_recover(float a, float b, float c, float d, float2 r) {
-    // libgcc __mulsc3 (C99 G.5.1): only reached when both parts are NaN
-    const float ac = a * c, bd = b * d, ad = a * d, bc = b * c;
-    bool recalc = false;
-    if (isinf(a) || isinf(b)) {
-        a = copysignf(isinf(a) ? 1.f : 0.f, a); b = copysignf(isinf(b) ? 1.f : 0.f, b);
-        if (isnan(c)) c = copysignf(0.f, c);
-        if (isnan(d)) d = copysignf(0.f, d);
-        recalc = true;
-    }
-    if (isinf(c) || isinf(d)) {
-        c = copysignf(isinf(c) ? 1.f : 0.f, c); d = copysignf(isinf(d) ? 1.f : 0.f, d);
-        if (isnan(a)) a = copysignf(0.f, a);
-        if (isnan(b)) b = copysignf(0.f, b);
-        recalc = true;
-    }
-    if (!recalc && (isinf(ac) || isinf(bd) || isinf(ad) || isinf(bc))) {
-        if (isnan(a)) a = copysignf(0.f, a);
-        if (isnan(b)) b = copysignf(0.f, b);
-        if (isnan(c)) c = copysignf(0.f, c);
-        if (isnan(d)) d = copysignf(0.f, d);
-        recalc = true;
-    }
-    if (recalc) {
-        r.x = __builtin_inff() * (a * c - b * d);
-        r.y = __builtin_inff() * (a * d + b * c);
-    }
-    return r;
-}
-__device__ __forceinline__ float2 cmul(float2 x, float2 h) {
-    float2 r;
-    r.x = x.x * h.x - x.y * h.y;
-    r.y = x.x * h.y + x.y * h.x;
-    if (__builtin_expect((r.x != r.x) & (r.y != r.y), 0)) r = mulsc3_recover(x.x, x.y, h.x, h.y, r);
-    return r;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // FIR: out[k] = sum over i = max(0, k-M+1) .. k (ascending) of x[i] * h[k-i], each term a rounded complex64
@@ -345,129 +308,6 @@ int launch_mag_chunk_stats(const void *iq, int dtype, int64_t n, int64_t chunk, 
     double *ps = (double *)scratch;
     double *pm = ps + n_chunks * kMagSlices;
     return launch_mag_any(dtype, iq, n, nullptr, chunk, n_chunks, ps, pm, d_sum, d_max, s);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Costas loop (signal_functions.pyx:252-330): second-order PLL over the whole capture -- a nonlinear recurrence
-// (phase / frequency state, clamp, wrap, sinf / cosf) with per-step fp32 rounding.  v1 is the exact serial
-// evaluation: one wavefront per capture; the 64 lanes fetch a tile of samples coalesced into LDS, then every lane
-// evaluates the same recurrence (wave-uniform, no divergence) and lane k keeps the outputs k, k + 64, ... of the
-// tile so that the tile is stored coalesced.  Bound: dependent-instruction latency (~10^2 cycles per sample), far
-// below any roofline; stated as such in DESIGN.md.  sinf / cosf are glibc's (glibc_sincosf.h).
-// ---------------------------------------------------------------------------------------------------------------
-}  // namespace urh
-#include "glibc_sincosf.h"
-namespace urh {
-
-constexpr int kCostasTile = 1024;
-
-struct CostasArgs {
-    const void *iq; int64_t n; float *out;
-    float noise_sqrd, alpha, beta, scale, shift;
-    int loop_order;
-};
-
-__device__ __forceinline__ float costas_clamp(float x) {      // :246-250
-    if (x < -1.0f) x = -1.0f;
-    else if (x > 1.0f) x = 1.0f;
-    return x;
-}
-
-template <int DT> struct CostasLoad;
-template <> struct CostasLoad<URHGPU_DT_F32> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { return ((const float2 *)p)[i]; } };
-template <> struct CostasLoad<URHGPU_DT_I8> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { const char2 v = ((const char2 *)p)[i]; return make_float2((float)v.x, (float)v.y); } };
-template <> struct CostasLoad<URHGPU_DT_U8> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { const uchar2 v = ((const uchar2 *)p)[i]; return make_float2((float)v.x, (float)v.y); } };
-template <> struct CostasLoad<URHGPU_DT_I16> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { const short2 v = ((const short2 *)p)[i]; return make_float2((float)v.x, (float)v.y); } };
-template <> struct CostasLoad<URHGPU_DT_U16> { static __device__ __forceinline__ float2 at(const void *p, int64_t i) { const ushort2 v = ((const ushort2 *)p)[i]; return make_float2((float)v.x, (float)v.y); } };
-
-template <int DT>
-__global__ __launch_bounds__(64) void k_costas(const CostasArgs a) {
-    __shared__ float2 s_x[kCostasTile];
-    const int lane = threadIdx.x;
-    const double two_pi = 2 * 3.14159265358979323846;
-    float freq = 0.0f, err = 0.0f, phase = 1.5f;            // :261
-    if (lane == 0 && a.n > 0) a.out[0] = -4.0f;              // reference: np.empty, never written (documented in urhgpu.h)
-    for (int64_t base = 0; base < a.n; base += kCostasTile) {
-        const int tv = (int)((a.n - base < kCostasTile) ? (a.n - base) : kCostasTile);
-        __syncthreads();
-        for (int u = lane; u < tv; u += 64) s_x[u] = CostasLoad<DT>::at(a.iq, base + u);
-        __syncthreads();
-        float mine[kCostasTile / 64];
-#pragma unroll 1
-        for (int g = 0; g < kCostasTile / 64; ++g) {
-            float keep = 0.0f;
-#pragma unroll 1
-            for (int u = 0; u < 64; ++u) {
-                const int k = g * 64 + u;
-                if (k >= tv || (base + k) == 0) continue;           // the loop starts at sample 1 (:289)
-                const float2 sm = s_x[k];
-                float o;
-                if (sm.x * sm.x + sm.y * sm.y <= a.noise_sqrd) {
-                    o = -4.0f;                                      // NOISE_FSK_PSK, state frozen (:293-295)
-                } else {
-                    const float real_float = (sm.x + a.shift) / a.scale, imag_float = (sm.y + a.shift) / a.scale;
-                    const float2 cur = make_float2(real_float + 0.0f * imag_float, 1.0f * imag_float);   // re + imag_unit*im
-                    const float sn = urh_sinf(-phase), cs = urh_cosf(-phase);
-                    const float2 nco = make_float2(cs + 0.0f * sn, 1.0f * sn);
-                    const float2 z = cmul(nco, cur);
-                    if (a.loop_order == 2) {
-                        err = z.y * z.x;
-                    } else if (a.loop_order == 4) {
-                        const float f1 = z.x > 0.0f ? 1.0f : -1.0f, f2 = z.y > 0.0f ? 1.0f : -1.0f;
-                        err = f1 * z.y - f2 * z.x;
-                    }
-                    err = costas_clamp(err);
-                    freq += a.beta * err;
-                    phase += freq + a.alpha * err;
-                    while ((double)phase > two_pi) phase = (float)((double)phase - two_pi);      // double compare / subtract (:318-321)
-                    while ((double)phase < -two_pi) phase = (float)((double)phase + two_pi);
-                    freq = costas_clamp(freq);
-                    o = 0.0f;
-                    if (a.loop_order == 2) o = z.x;
-                    else if (a.loop_order == 4) o = (float)(2.0 * (double)z.x + (double)z.y);
-                }
-                if (u == lane) keep = o;
-            }
-            mine[g] = keep;
-        }
-#pragma unroll 1
-        for (int g = 0; g < kCostasTile / 64; ++g) {
-            const int k = g * 64 + lane;
-            if (k < tv && base + k != 0) a.out[base + k] = mine[g];
-        }
-    }
-}
-
-int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad) {
-    CostasArgs a;
-    a.iq = d_iq; a.n = n; a.out = d_qad;
-    a.noise_sqrd = p->noise_threshold * p->noise_threshold;
-    // :253-254 as the reference's generated code evaluates them (damping = (float)(sqrt(2)/2), bandwidth*bandwidth a float product)
-    const float bandwidth = p->costas_loop_bandwidth;
-    const float damping = (float)(sqrt(2.0) / 2.0);
-    const double den = (1.0 + ((2.0 * (double)damping) * (double)bandwidth)) + (double)(bandwidth * bandwidth);
-    a.alpha = (float)(((4.0 * (double)damping) * (double)bandwidth) / den);
-    a.beta = (float)(((4.0 * (double)bandwidth) * (double)bandwidth) / den);
-    switch (p->dtype) {                                        // :267-283
-        case URHGPU_DT_I8: a.scale = 127.5f; a.shift = 0.5f; break;
-        case URHGPU_DT_U8: a.scale = 127.5f; a.shift = -127.5f; break;
-        case URHGPU_DT_I16: a.scale = 32767.5f; a.shift = 0.5f; break;
-        case URHGPU_DT_U16: a.scale = 65535.0f; a.shift = -32767.5f; break;
-        case URHGPU_DT_F32: a.scale = 1.0f; a.shift = 0.0f; break;
-        default: return URHGPU_ERR_DTYPE;
-    }
-    int order = p->mod_order > 0 ? p->mod_order : (1 << p->bits_per_symbol);
-    if (order > 4) order = 4;                                  // :285-287
-    a.loop_order = order;
-    hipStream_t s = ctx->stream;
-    switch (p->dtype) {
-        case URHGPU_DT_I8: hipLaunchKernelGGL(k_costas<URHGPU_DT_I8>, dim3(1), dim3(64), 0, s, a); break;
-        case URHGPU_DT_U8: hipLaunchKernelGGL(k_costas<URHGPU_DT_U8>, dim3(1), dim3(64), 0, s, a); break;
-        case URHGPU_DT_I16: hipLaunchKernelGGL(k_costas<URHGPU_DT_I16>, dim3(1), dim3(64), 0, s, a); break;
-        case URHGPU_DT_U16: hipLaunchKernelGGL(k_costas<URHGPU_DT_U16>, dim3(1), dim3(64), 0, s, a); break;
-        default: hipLaunchKernelGGL(k_costas<URHGPU_DT_F32>, dim3(1), dim3(64), 0, s, a); break;
-    }
-    return URHGPU_OK;
 }
 
 }  // namespace urh

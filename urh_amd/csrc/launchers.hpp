@@ -156,6 +156,8 @@ size_t minmax_scratch_bytes();
 int launch_minmax(const float *x, int64_t n, float *d_out2, void *scratch, hipStream_t s);
 int pairwise_sum_f32(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, float mean, float *out);
 int launch_hist_edges(const float *x, int64_t n, const double *d_edges, int n_edges, int64_t *d_counts, hipStream_t s);
-int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad);
+// ---- costas.hip -----------------------------------------------------------------------------------------------
+size_t costas_scratch_bytes(int64_t n);
+int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, void *scratch);
 
 }  // namespace urh
