@@ -166,7 +166,32 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
             --p;
             if (!costas_gated(CostasLoad<DT>::at(a.iq, p), a)) ++ungated;
         }
-        if (p == 1) st = CostasState{0.0f, 1.5f};           // reached the start of the capture: exact, not a guess
+        if (p == 1) {
+            st = CostasState{0.0f, 1.5f};                   // reached the start of the capture: exact, not a guess
+        } else {
+            // Seed the candidate's frequency with the carrier offset of the warm-up stretch (M-th power of the
+            // differential phase: the PSK symbol steps are multiples of 2*pi/M and drop out).  A candidate that starts
+            // at freq 0 against an offset beyond the loop bandwidth needs thousands of samples to pull in; seeded, it
+            // locks within the warm-up.  Heuristic only: a wrong seed costs time (serial fallback), never exactness.
+            float ax = 0.0f, ay = 0.0f;
+            float2 prev = CostasLoad<DT>::at(a.iq, p);
+            bool prev_ok = !costas_gated(prev, a);
+            const int64_t wend = (p + 512 < s0) ? p + 512 : s0;
+            for (int64_t i = p + 1; i < wend; ++i) {
+                const float2 cur = CostasLoad<DT>::at(a.iq, i);
+                const bool ok = !costas_gated(cur, a);
+                if (ok && prev_ok) {
+                    const float cr = (cur.x + a.shift) / a.scale, ci = (cur.y + a.shift) / a.scale;
+                    const float pr = (prev.x + a.shift) / a.scale, pi = (prev.y + a.shift) / a.scale;
+                    float dx = cr * pr + ci * pi, dy = ci * pr - cr * pi;          // cur * conj(prev)
+                    float tx = dx * dx - dy * dy, ty = 2.0f * dx * dy;             // ^2
+                    if (a.loop_order == 4) { const float ux = tx * tx - ty * ty, uy = 2.0f * tx * ty; tx = ux; ty = uy; }
+                    ax += tx; ay += ty;
+                }
+                prev = cur; prev_ok = ok;
+            }
+            if (ax != 0.0f || ay != 0.0f) st.freq = costas_clamp(atan2f(ay, ax) / (float)a.loop_order);
+        }
         for (int64_t i = p; i < s0; ++i) costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
     }
     b.S[c * K + k] = st;
