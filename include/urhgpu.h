@@ -78,10 +78,12 @@ int urhgpu_ctx_reserve(urhgpu_ctx *ctx, int64_t n_samples, int tolerance);
 int urhgpu_ctx_info(urhgpu_ctx *ctx, int *compute_units, int *wavefront, int64_t *hbm_bytes, char *name, int name_cap);
 
 /* After a PSK demodulation (Costas loop) of more than 8192 samples: how the chunk chain of the exact parallel evaluation was
- * resolved -- out3 = {chunks whose true start state matched a speculative candidate, chunks evaluated serially until they
- * met a candidate's checkpoint, chunks evaluated serially to the end}.  Synchronises the stream.  Diagnostics only: the
- * output is exact in every case. */
-int urhgpu_ctx_costas_stats(urhgpu_ctx *ctx, int32_t *out3);
+ * resolved -- out4 = {chunks whose true start state matched a speculative candidate, chunks evaluated serially until they
+ * met a candidate's checkpoint, chunks evaluated serially to the end (or fully gated), re-speculation rounds}.
+ * Synchronises the stream.  Diagnostics only: the output is exact in every case.
+ * (The PSK path of urhgpu_afp_demod_dev / urhgpu_iq_to_bits_dev synchronises the stream itself: the host has to learn
+ * whether the chunk chain closed before it launches the final pass.) */
+int urhgpu_ctx_costas_stats(urhgpu_ctx *ctx, int32_t *out4);
 
 /* Time the dominant kernel (demod + run segmentation) of subsequent fused / grab_pulse_lens calls with
  * HIP events recorded on the context's stream: begin(max_records) arms up to max_records records

@@ -542,5 +542,6 @@ def test_costas_parallel_chain_large(sf, oracle, order):
     got = sf.afp_demod(iq, 0.2, "PSK", order, 0.1)
     assert bits_equal(got[1:], want[1:]), int((got[1:] != want[1:]).sum())
     stats = _lib.default_context().costas_stats()
-    assert sum(stats) == (n - 1 + 4095) // 4096 - 1
-    assert stats[0] > 0.8 * sum(stats), stats
+    assert sum(stats[:3]) == (n - 1 + 4095) // 4096 - 1
+    # the 300k-sample gated pause is 73 chunks that no candidate can match; everything else should
+    assert stats[0] > 0.85 * sum(stats[:3]), stats

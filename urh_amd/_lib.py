@@ -191,8 +191,8 @@ class Context:
         return [float(ms[i]) for i in range(min(n.value, cap))]
 
     def costas_stats(self):
-        """(chunks matched by a candidate, chunks met at a checkpoint, chunks evaluated serially) of the last PSK pass"""
-        out = (C.c_int32 * 3)()
+        """(chunks matched by a candidate, met at a checkpoint, evaluated serially, re-speculation rounds) of the last PSK pass"""
+        out = (C.c_int32 * 4)()
         check(load().urhgpu_ctx_costas_stats(self._h, out))
         return tuple(int(v) for v in out)
 

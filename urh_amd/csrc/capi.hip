@@ -250,7 +250,8 @@ int urhgpu_ctx_create(int device, urhgpu_ctx **out) {
         const int32_t aux0[4] = {kAuxNone, kAuxNone, kAuxNone, -1};
         URH_HIP(hipMemcpy(ctx->d_tickets + 4, aux0, sizeof(aux0), hipMemcpyHostToDevice));
     }
-    URH_HIP(hipHostMalloc((void **)&ctx->h_counts, 16 * sizeof(int64_t)));
+    URH_HIP(hipHostMalloc((void **)&ctx->h_counts, 32 * sizeof(int64_t)));
+    memset(ctx->h_counts, 0, 32 * sizeof(int64_t));
     *out = ctx;
     return URHGPU_OK;
 }
@@ -663,11 +664,12 @@ int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const
     return URHGPU_OK;
 }
 
-int urhgpu_ctx_costas_stats(urhgpu_ctx *ctx, int32_t *out3) {
-    if (!ctx || !out3) return URHGPU_ERR_ARG;
+int urhgpu_ctx_costas_stats(urhgpu_ctx *ctx, int32_t *out4) {
+    if (!ctx || !out4) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
     URH_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(out3, ctx->h_counts + 12, 12);
+    const int32_t *h = (const int32_t *)(ctx->h_counts + 12);
+    out4[0] = h[0]; out4[1] = h[1]; out4[2] = h[2]; out4[3] = h[4];
     return URHGPU_OK;
 }
 

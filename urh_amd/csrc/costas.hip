@@ -29,6 +29,7 @@
 
 #include <algorithm>
 #include <math.h>
+#include <string.h>
 
 #include "cmul.hpp"
 #include "common.hpp"
@@ -136,7 +137,10 @@ struct SpecBuffers {
     CostasState *CP;       // [n_chunks][kNumCkpt][K] state after offset (j+1)*kCkpt samples of the chunk
     uint32_t *map;         // [n_chunks] nibble k: candidate of this chunk that starts in E[c-1][k], 0xF none
     CostasState *T;        // [n_chunks] TRUE state at the chunk start (written by the stitch)
-    int32_t *stats;        // [0] chunks resolved by the map, [1] by a checkpoint inside a serial run, [2] fully serial
+    int32_t *ungated;      // [n_chunks] un-gated samples in the chunk
+    CostasState *resume;   // [1] true state at the start of chunk stats[3] when the stitch hands back to the host
+    int32_t *stats;        // [0] chunks resolved by the map, [1] by a checkpoint inside a serial run, [2] fully serial,
+                           // [3] chunk the stitch stopped in front of (n_chunks: finished), [4] re-speculation rounds
 };
 
 __device__ __forceinline__ bool same_state(CostasState a, CostasState b) {
@@ -144,16 +148,19 @@ __device__ __forceinline__ bool same_state(CostasState a, CostasState b) {
 }
 __device__ __forceinline__ int64_t chunk_begin(int64_t c) { return 1 + c * (int64_t)kChunk; }   // sample 0 is not part of the loop
 
+// Candidates of the chunks c >= c_from.  use_seed: all candidates start with freq = seed_freq (the true loop's own
+// frequency where the chain last broke) instead of the estimate from the data.
 template <int DT>
-__global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K) {
+__global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K, int64_t c_from,
+                                                      int use_seed, float seed_freq) {
     const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
-    const int64_t c = gid / K;
+    const int64_t c = c_from + gid / K;
     const int k = (int)(gid % K);
     if (c >= n_chunks) return;
     const int64_t s0 = chunk_begin(c);
     const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
-    // candidate k: phase 1.5 + (k - K/2) * (2*pi / (K/2)) ... spaced pi/2 (order 4, K = 8) or pi (order 2, K = 4); candidate K/2 is
-    // the reference's own initial state (phase 1.5)
+    // candidate k: phase 1.5 + (k - K/2) * spacing, spaced pi/2 (order 4, K = 8) or pi (order 2, K = 4): every lock point and its
+    // twin 2*pi away; candidate K/2 has the reference's own initial phase 1.5
     const float spacing = (a.loop_order == 4) ? 1.57079632679489661923f : 3.14159265358979323846f;
     CostasState st{0.0f, 1.5f + (float)(k - K / 2) * spacing};
     float err = 0.0f;
@@ -168,6 +175,8 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
         }
         if (p == 1) {
             st = CostasState{0.0f, 1.5f};                   // reached the start of the capture: exact, not a guess
+        } else if (use_seed) {
+            st.freq = seed_freq;
         } else {
             // Seed the candidate's frequency with the carrier offset of the warm-up stretch (M-th power of the
             // differential phase: the PSK symbol steps are multiples of 2*pi/M and drop out).  A candidate that starts
@@ -195,16 +204,20 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
         for (int64_t i = p; i < s0; ++i) costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
     }
     b.S[c * K + k] = st;
+    int ung = 0;
     for (int64_t i = s0; i < e0; ++i) {
-        costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
+        const float2 sm = CostasLoad<DT>::at(a.iq, i);
+        if (!costas_gated(sm, a)) ++ung;
+        costas_step(sm, st, err, a);
         const int off = (int)(i - s0) + 1;
         if (off % kCkpt == 0 && off < kChunk) b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + k] = st;
     }
     b.E[c * K + k] = st;
+    if (k == 0) b.ungated[c] = ung;
 }
 
-__global__ __launch_bounds__(256) void k_costas_map(SpecBuffers b, int64_t n_chunks, int K) {
-    const int64_t c = blockIdx.x * 256ll + threadIdx.x;
+__global__ __launch_bounds__(256) void k_costas_map(SpecBuffers b, int64_t n_chunks, int K, int64_t c_from) {
+    const int64_t c = c_from + blockIdx.x * 256ll + threadIdx.x;
     if (c >= n_chunks) return;
     uint32_t m = 0xFFFFFFFFu;
     if (c > 0) {
@@ -218,19 +231,23 @@ __global__ __launch_bounds__(256) void k_costas_map(SpecBuffers b, int64_t n_chu
     b.map[c] = m;
 }
 
-// One wavefront walks the chunks in order (every lane the same control flow; lanes < K compare checkpoints).
+// One wavefront walks the chunks c_from .. in order (every lane the same control flow; lanes < K compare candidates).
+// Entry: the true state at the start of chunk c_from is *b.resume (c_from == 1: chunk 0's end, taken from E[0][0]).
+// Exit: either all chunks are resolved, or -- when allow_break -- the chain broke for good (a chunk with plenty of
+// un-gated samples was evaluated serially to its end and met no candidate): stats[3] = the next chunk, *b.resume = its true
+// start state, and the host re-speculates the remaining chunks around that state's frequency.
 template <int DT>
-__global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K) {
+__global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K, int64_t c_from,
+                                                       int allow_break) {
     const int lane = threadIdx.x;
-    int cand = 0;                                   // chunk 0: candidate 0 is exact
-    CostasState T{0.0f, 1.5f};                      // true state at the start of the current chunk
+    int cand = -1;
+    CostasState T = *b.resume;                      // true state at the start of chunk c_from
+    if (c_from == 1) { cand = 0; if (lane == 0) b.T[0] = CostasState{0.0f, 1.5f}; }   // chunk 0: candidate 0 is exact
     int n_map = 0, n_ckpt = 0, n_serial = 0;
-    if (lane == 0) b.T[0] = T;
-    for (int64_t c = 1; c < n_chunks; ++c) {
-        // true state at the start of chunk c
+    int64_t stop_at = n_chunks;
+    for (int64_t c = c_from; c < n_chunks; ++c) {
         if (cand >= 0) T = b.E[(c - 1) * K + cand];
         if (lane == 0) b.T[c] = T;
-        // which candidate of chunk c is the true trajectory?
         int next = -1;
         if (cand >= 0) {
             const uint32_t nib = (b.map[c] >> (4 * cand)) & 0xFu;
@@ -241,12 +258,13 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
             if (m) next = __builtin_ctzll(m);
         }
         if (next >= 0) { cand = next; ++n_map; continue; }
+        cand = -1;
+        if (b.ungated[c] == 0) { ++n_serial; continue; }          // fully gated chunk: the state does not move
         // no candidate starts in T: evaluate the chunk from T until the state meets a candidate at a checkpoint
         const int64_t s0 = chunk_begin(c);
         const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
         float err = 0.0f;
         CostasState st = T;
-        cand = -1;
         for (int64_t i = s0; i < e0; ++i) {
             costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
             const int off = (int)(i - s0) + 1;
@@ -256,13 +274,15 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
                 if (m) { cand = __builtin_ctzll(m); break; }
             }
         }
-        if (cand >= 0) ++n_ckpt;
-        else { ++n_serial; T = st; }                // T now holds the state at the END of chunk c (used as start of c+1)
-        if (cand < 0) {
-            // the next iteration takes T as the start state of chunk c+1 (cand < 0 path)
-        }
+        if (cand >= 0) { ++n_ckpt; continue; }
+        ++n_serial;
+        T = st;                                     // the state at the END of chunk c = start of chunk c + 1
+        if (allow_break && b.ungated[c] >= kChunk / 2 && c + 1 < n_chunks) { stop_at = c + 1; break; }
     }
-    if (lane == 0) { b.stats[0] = n_map; b.stats[1] = n_ckpt; b.stats[2] = n_serial; }
+    if (lane == 0) {
+        b.stats[0] += n_map; b.stats[1] += n_ckpt; b.stats[2] += n_serial; b.stats[3] = (int32_t)stop_at;
+        *b.resume = T;
+    }
 }
 
 template <int DT>
@@ -280,15 +300,19 @@ __global__ __launch_bounds__(256) void k_costas_final(const CostasArgs a, SpecBu
 size_t costas_scratch_bytes(int64_t n) {
     const int64_t nc = (std::max<int64_t>(n - 1, 0) + kChunk - 1) / kChunk + 1;
     return (size_t)nc * kMaxCand * sizeof(CostasState) * 2 + (size_t)nc * kNumCkpt * kMaxCand * sizeof(CostasState) +
-           (size_t)nc * 4 + (size_t)nc * sizeof(CostasState) + 64 + 8 * 256;
+           (size_t)nc * 4 * 2 + (size_t)nc * sizeof(CostasState) + 64 + 64 + 10 * 256;
 }
 
+constexpr int kMaxRounds = 24;     // re-speculation rounds before the stitch stops handing back (and runs serially)
+
+// NOTE: synchronises the stream (at least once): the host has to learn whether the chunk chain closed.
 template <int DT>
-static int launch_costas_dt(const CostasArgs &a, void *scratch, int64_t *h_stats, urhgpu_ctx *ctx) {
+static int launch_costas_dt(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx) {
     hipStream_t s = ctx->stream;
     const bool parallel = (a.loop_order == 2 || a.loop_order == 4) && a.n > 2 * kChunk && scratch != nullptr;
     if (!parallel) {
         hipLaunchKernelGGL(k_costas<DT>, dim3(1), dim3(64), 0, s, a);
+        ctx->h_counts[12] = ctx->h_counts[13] = ctx->h_counts[14] = 0;
         return URHGPU_OK;
     }
     const int K = (a.loop_order == 4) ? 8 : 4;
@@ -301,14 +325,36 @@ static int launch_costas_dt(const CostasArgs &a, void *scratch, int64_t *h_stats
     b.CP = (CostasState *)take((size_t)nc * kNumCkpt * K * sizeof(CostasState));
     b.map = (uint32_t *)take((size_t)nc * 4);
     b.T = (CostasState *)take((size_t)nc * sizeof(CostasState));
+    b.ungated = (int32_t *)take((size_t)nc * 4);
+    b.resume = (CostasState *)take(64);
     b.stats = (int32_t *)take(64);
-    hipLaunchKernelGGL(k_costas_spec<DT>, dim3((unsigned)((nc * K + 255) / 256)), dim3(256), 0, s, a, b, nc, K);
-    hipLaunchKernelGGL(k_costas_map, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, b, nc, K);
-    hipLaunchKernelGGL(k_costas_stitch<DT>, dim3(1), dim3(64), 0, s, a, b, nc, K);
-    hipLaunchKernelGGL(k_costas_final<DT>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, a, b, nc);
-    if (h_stats) {
-        URH_HIP(hipMemcpyAsync(ctx->h_counts + 12, b.stats, 12, hipMemcpyDeviceToHost, s));
+    URH_HIP(hipMemsetAsync(b.stats, 0, 64, s));
+    URH_HIP(hipMemsetAsync(b.resume, 0, 64, s));
+    int64_t c_from = 0;
+    int use_seed = 0;
+    float seed_freq = 0.0f;
+    int32_t *h = (int32_t *)(ctx->h_counts + 12);            // pinned: stats[0..4], then the resume state
+    int rounds = 0;
+    for (int round = 0;; ++round) {
+        const int64_t todo = nc - c_from;
+        hipLaunchKernelGGL(k_costas_spec<DT>, dim3((unsigned)((todo * K + 255) / 256)), dim3(256), 0, s, a, b, nc, K, c_from, use_seed,
+                           seed_freq);
+        hipLaunchKernelGGL(k_costas_map, dim3((unsigned)((todo + 255) / 256)), dim3(256), 0, s, b, nc, K, std::max<int64_t>(c_from, 1));
+        hipLaunchKernelGGL(k_costas_stitch<DT>, dim3(1), dim3(64), 0, s, a, b, nc, K, std::max<int64_t>(c_from, 1),
+                           round < kMaxRounds ? 1 : 0);
+        URH_HIP(hipGetLastError());
+        URH_HIP(hipMemcpyAsync(h, b.stats, 20, hipMemcpyDeviceToHost, s));
+        URH_HIP(hipMemcpyAsync(h + 6, b.resume, 8, hipMemcpyDeviceToHost, s));
+        URH_HIP(hipStreamSynchronize(s));
+        const int64_t stop_at = h[3];
+        if (stop_at >= nc) break;
+        c_from = stop_at;
+        use_seed = 1;
+        memcpy(&seed_freq, h + 6, 4);                        // resume state: {freq, phase}
+        rounds = round + 1;
     }
+    h[4] = rounds;
+    hipLaunchKernelGGL(k_costas_final<DT>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, a, b, nc);
     return URHGPU_OK;
 }
 
@@ -334,11 +380,11 @@ int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_par
     if (order > 4) order = 4;                                  // :285-287
     a.loop_order = order;
     switch (p->dtype) {
-        case URHGPU_DT_I8: return launch_costas_dt<URHGPU_DT_I8>(a, scratch, ctx->h_counts, ctx);
-        case URHGPU_DT_U8: return launch_costas_dt<URHGPU_DT_U8>(a, scratch, ctx->h_counts, ctx);
-        case URHGPU_DT_I16: return launch_costas_dt<URHGPU_DT_I16>(a, scratch, ctx->h_counts, ctx);
-        case URHGPU_DT_U16: return launch_costas_dt<URHGPU_DT_U16>(a, scratch, ctx->h_counts, ctx);
-        default: return launch_costas_dt<URHGPU_DT_F32>(a, scratch, ctx->h_counts, ctx);
+        case URHGPU_DT_I8: return launch_costas_dt<URHGPU_DT_I8>(a, scratch, ctx);
+        case URHGPU_DT_U8: return launch_costas_dt<URHGPU_DT_U8>(a, scratch, ctx);
+        case URHGPU_DT_I16: return launch_costas_dt<URHGPU_DT_I16>(a, scratch, ctx);
+        case URHGPU_DT_U16: return launch_costas_dt<URHGPU_DT_U16>(a, scratch, ctx);
+        default: return launch_costas_dt<URHGPU_DT_F32>(a, scratch, ctx);
     }
 }
 
