@@ -102,7 +102,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # URH_BENCH_FORCE_SHARDED=1 (with torch.distributed.run --nproc-per-node 1) drives the sharded code path -- RCCL process
+    # group, all-gathers, urhgpu_shard_* phases -- on a single GPU: a smoke test of the N > 1 plumbing on a 1-GPU box.
+    force_sharded = os.environ.get("URH_BENCH_FORCE_SHARDED") == "1"
+    if world > 1 or force_sharded:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
@@ -111,7 +114,7 @@ def main():
     # rank r holds segments [r*segments, (r+1)*segments) of the world*segments-segment capture
     iq, tx_bits = fsk_capture(args.segments, dev, seed=1234, sps=sps, first_segment=rank * args.segments)
     n = iq.shape[0]
-    if world > 1:
+    if world > 1 or force_sharded:
         from urh_amd.shard_engine import GpuShardEngine
         from urh_amd.sharding import ShardedPipeline, TorchDistComm
         pipe = ShardedPipeline(GpuShardEngine(local_rank), TorchDistComm())
