@@ -545,3 +545,46 @@ def test_costas_parallel_chain_large(sf, oracle, order):
     assert sum(stats[:3]) == (n - 1 + 4095) // 4096 - 1
     # the 300k-sample gated pause is 73 chunks that no candidate can match; everything else should
     assert stats[0] > 0.85 * sum(stats[:3]), stats
+
+
+def test_sharded_fir_halo_then_bits(pipe, oracle):
+    """configs[3]-style: 4 simulated ranks, FIR with the left neighbour's 63-sample tail as history, then the sharded
+    IQ->bits pass on the filtered shards == one-pass oracle FIR + single-GPU pass."""
+    import threading
+    import torch
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.shard_engine import GpuShardEngine
+    from urh_amd.sharding import ShardedPipeline, ThreadComm, shard_bounds, stitch
+    rng = np.random.default_rng(9)
+    n, m, world = 400_000, 64, 4
+    iq = synth_fsk(n, sps=100, seed=77, noise=0.05, pause_every=n // 3, pause_len=n // 25)
+    taps = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64) * np.float32(0.05)
+    taps[m // 2] += 1
+    want_f = oracle.fir_filter(iq.view(np.complex64).reshape(-1), taps)
+    fiq = np.ascontiguousarray(want_f.view(np.float32).reshape(-1, 2))
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    single = pipe.iq_to_bits(torch.from_numpy(fiq).cuda(), p, want_qad=True)
+    want = (single.ppseq(),) + tuple(single.flat())
+    bounds = shard_bounds(n, world)
+    dev_iq, dev_taps = torch.from_numpy(iq).cuda(), torch.from_numpy(taps).cuda()
+    shared = ThreadComm.Shared(world)
+    out, filt, err = [None] * world, [None] * world, []
+
+    def work(r):
+        try:
+            sp = ShardedPipeline(GpuShardEngine(0), ThreadComm(shared, r))
+            a, b = bounds[r]
+            f = sp.fir_filter(dev_iq[a:b], dev_taps)
+            filt[r] = f.cpu().numpy()
+            out[r] = sp.iq_to_bits(f, p, want_qad=True, pos_base=a, n_total=n)
+        except BaseException as e:          # noqa: BLE001
+            err.append(e)
+            shared.barrier.abort()
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    if err:
+        raise err[0]
+    assert cbits_equal(np.concatenate(filt).view(np.complex64).reshape(-1), want_f)
+    for k, (a, b) in enumerate(zip(stitch(out), want)):
+        assert np.array_equal(a, b), k

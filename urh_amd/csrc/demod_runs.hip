@@ -342,6 +342,16 @@ __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float pr
         const bool ok1 = (int)((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re1) - kReLo < kReSpan);
         q0 = t0 - urh_atanf_poly(t0);
         q1 = t1 - urh_atanf_poly(t1);
+#if URH_EXP == 4      // timing experiment (tools/kbench): 24 extra plain VALU instructions per row
+        { float dummy = t0;
+#pragma unroll
+          for (int e = 0; e < 24; ++e) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
+          asm volatile("" :: "v"(dummy)); }
+#endif
+#if URH_EXP == 5      // timing experiment: 24 extra SALU instructions per row
+#pragma unroll
+          for (int e = 0; e < 24; ++e) asm volatile("s_nop 0");
+#endif
         return n0 | n1 | !ok0 | !ok1;
     }
     q0 = __builtin_sqrtf(mag0) / p.max_magnitude;

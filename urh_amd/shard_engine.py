@@ -58,6 +58,28 @@ class GpuShardEngine(DevicePipeline):
             iq_local = torch.view_as_real(iq_local)
         return iq_local[-2:].contiguous()                     # (2, 2): samples n-2, n-1
 
+    def fir_tail(self, iq_local, k):
+        torch = self.torch
+        if iq_local.dtype == torch.complex64:
+            iq_local = torch.view_as_real(iq_local)
+        return iq_local[-k:].contiguous()
+
+    def fir(self, iq_local, taps, left):
+        """complex64 FIR of this shard (float32 (N, 2) or complex64 (N,)) with `left` (the m-1 preceding samples) as history"""
+        torch = self.torch
+        x = torch.view_as_real(iq_local) if iq_local.dtype == torch.complex64 else iq_local
+        h = torch.view_as_real(taps) if taps.dtype == torch.complex64 else taps
+        if x.dtype != torch.float32 or h.dtype != torch.float32 or not x.is_contiguous():
+            raise ValueError("FIR needs contiguous float32 / complex64 samples and taps")
+        h = h.contiguous()
+        out = torch.empty_like(x)
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_fir_filter_dev(self.ctx.handle, C.c_void_p(x.data_ptr()), x.shape[0], C.c_void_p(h.data_ptr()),
+                                                     h.shape[0], C.c_void_p(left.data_ptr()) if left is not None else None,
+                                                     C.c_void_p(out.data_ptr())))
+        self._fir_keep = (x, h, left)
+        return out if iq_local.dtype != torch.complex64 else torch.view_as_complex(out)
+
     def runs(self, iq, left, pos_base, n_total, rank, world, p, want_qad):
         torch = self.torch
         if iq.dtype == torch.complex64:

@@ -99,6 +99,20 @@ class ShardedPipeline:
     def reserve(self, n_local, p):
         self.engine.reserve(n_local, p)
 
+    def fir_filter(self, iq_local, taps):
+        """Signal.filter_range semantics on a sharded capture (BASELINE.json configs[3], "FIR-halo exchange"): every rank
+        filters its shard with the m-1 samples that precede it -- the left neighbour's tail, one all-gather of
+        (m-1) * 8 bytes per rank -- as history; rank 0 starts from zero history like the reference's fir_filter
+        (signal_functions.pyx:513-525).  Returns the filtered shard (same shape as iq_local)."""
+        e, c = self.engine, self.comm
+        m = int(taps.shape[0])
+        if m <= 1 or self.world == 1:
+            return e.fir(iq_local, taps, None)
+        if int(iq_local.shape[0]) < m - 1:
+            raise ValueError("shard shorter than the filter history")
+        tails = c.all_gather(e.fir_tail(iq_local, m - 1))
+        return e.fir(iq_local, taps, tails[self.rank - 1] if self.rank > 0 else None)
+
     def iq_to_bits(self, iq_local, p, want_qad=True, pos_base=None, n_total=None):
         """iq_local: this rank's shard.  pos_base / n_total default to equal shards of len(iq_local)."""
         e, c = self.engine, self.comm
