@@ -588,3 +588,25 @@ def test_sharded_fir_halo_then_bits(pipe, oracle):
     assert cbits_equal(np.concatenate(filt).view(np.complex64).reshape(-1), want_f)
     for k, (a, b) in enumerate(zip(stitch(out), want)):
         assert np.array_equal(a, b), k
+
+
+def test_get_protocol_from_signal_goldens(pipe):
+    """ProtocolAnalyzer.get_protocol_from_signal (bits, pause, RSSI, timestamp, bit_sample_pos per message, ASK padding with
+    message_length_divisor) vs what the real reference put into its Message objects (tests/golden/messages.json)."""
+    import json
+    import os
+    import torch
+    from conftest import GOLDEN_DIR
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.protocol import get_protocol_from_signal_dev
+    want = json.load(open(os.path.join(GOLDEN_DIR, "messages.json")))
+    for key, msgs in want.items():
+        name, divisor = key.split("|")
+        g = load_golden(name)
+        p = DemodParams(g["modulation_type"], g["bits_per_symbol"], g["noise_threshold"], g["center"], g["center_spacing"],
+                        g["tolerance"], g["samples_per_symbol"], g["costas_loop_bandwidth"], g["pause_threshold"], True)
+        got = get_protocol_from_signal_dev(pipe, torch.from_numpy(g["iq"]).cuda(), p, message_length_divisor=int(divisor))
+        assert len(got) == len(msgs), key
+        for a, b in zip(got, msgs):
+            assert a.plain_bits_str == b["bits"] and a.pause == b["pause"] and list(a.bit_sample_pos) == b["pos"], key
+            assert a.rssi == b["rssi"] and a.timestamp == b["timestamp"], (key, a.rssi, b["rssi"])
