@@ -609,4 +609,6 @@ def test_get_protocol_from_signal_goldens(pipe):
         assert len(got) == len(msgs), key
         for a, b in zip(got, msgs):
             assert a.plain_bits_str == b["bits"] and a.pause == b["pause"] and list(a.bit_sample_pos) == b["pos"], key
-            assert a.rssi == b["rssi"] and a.timestamp == b["timestamp"], (key, a.rssi, b["rssi"])
+            assert a.rssi == b["rssi"], (key, a.rssi, b["rssi"])
+            if b["pos"][0] != 0:            # a message at sample 0 has timestamp 0, which urh's Message replaces by time.time()
+                assert a.timestamp == b["timestamp"], key
