@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--segments", type=int, default=128, help="2^20-sample segments per GPU (128 = 1 GiB complex64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bits-only", action="store_true", help="do not materialise qad (8 B/sample variant)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="run every step strictly after the previous one (default: consecutive steps are software-pipelined: "
+                         "the hot kernel of step i+1 overlaps the latency-bound tail of step i on a second stream)")
     args = ap.parse_args()
 
     import torch
@@ -117,9 +120,9 @@ def main():
     if world > 1 or force_sharded:
         from urh_amd.shard_engine import GpuShardEngine
         from urh_amd.sharding import ShardedPipeline, TorchDistComm
-        pipe = ShardedPipeline(GpuShardEngine(local_rank), TorchDistComm())
+        pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=not args.no_pipeline), TorchDistComm())
     else:
-        pipe = DevicePipeline(local_rank)
+        pipe = DevicePipeline(local_rank, pipelined=not args.no_pipeline)
     pipe.reserve(n, p)
     want_qad = not args.bits_only
 
@@ -128,7 +131,18 @@ def main():
 
     for _ in range(args.warmup):
         res = step()
+    pipe.ctx.join()
     torch.cuda.synchronize()
+    # latency of ONE step with nothing overlapped (reported next to the pipelined throughput)
+    lat = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t_l = time.perf_counter()
+        res = step()
+        pipe.ctx.join()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t_l)
+    latency_ms = min(lat) * 1e3
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -136,6 +150,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
+    pipe.ctx.join()                      # the stream waits for the last step's tail
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -169,7 +184,8 @@ def main():
                        if world == 1 else f"configs[3]-style: {world} GiB complex64 2-FSK sharded sample-contiguously over {world} GPUs",
                        "samples_per_gpu": n, "samples_per_symbol": sps, "tolerance": tol, "noise_sigma": 0.05,
                        "outputs": "qad+ppseq+bits+pauses+bit_sample_pos" if want_qad else "ppseq+bits+pauses+bit_sample_pos",
-                       "rows": counts[0], "messages": counts[1], "bits": counts[2]},
+                       "rows": counts[0], "messages": counts[1], "bits": counts[2],
+                       "steps_pipelined": not args.no_pipeline, "single_step_latency_ms": round(latency_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_demod_runs", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": n * bytes_per_sample,

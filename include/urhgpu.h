@@ -71,6 +71,14 @@ int urhgpu_ctx_set_stream(urhgpu_ctx *ctx, void *hip_stream);
 /* Go back to the context's private (non-blocking) stream. */
 int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx);
 int urhgpu_ctx_sync(urhgpu_ctx *ctx);
+/* Pipelined mode for back-to-back passes (streaming one capture after the other): urhgpu_iq_to_bits_dev then runs its
+ * hot kernel on the context's stream and everything after it (pulse table, bits: latency-bound kernels that leave the GPU
+ * nearly empty) on a second stream with alternating scratch, so that the NEXT pass's hot kernel overlaps this pass's tail.
+ * tail_stream: a hipStream_t of the caller (e.g. a torch stream) or NULL for a private one.  In this mode the outputs of a
+ * pass are complete only after urhgpu_ctx_join (the context's stream waits for the tail; the host does not block) or
+ * urhgpu_ctx_sync; every other entry point joins first.  enable = 0 switches back (synchronises). */
+int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
+int urhgpu_ctx_join(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no
  * allocation happens inside later calls (bench / steady state). */
 int urhgpu_ctx_reserve(urhgpu_ctx *ctx, int64_t n_samples, int tolerance);

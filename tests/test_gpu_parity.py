@@ -612,3 +612,35 @@ def test_get_protocol_from_signal_goldens(pipe):
             assert a.rssi == b["rssi"], (key, a.rssi, b["rssi"])
             if b["pos"][0] != 0:            # a message at sample 0 has timestamp 0, which urh's Message replaces by time.time()
                 assert a.timestamp == b["timestamp"], key
+
+
+def test_pipelined_passes_do_not_disturb_each_other(oracle):
+    """pipelined mode: a burst of back-to-back passes over alternating captures without any synchronisation in between;
+    the last two results (kept in separate output slots) are bit-exact, i.e. the hot kernel of pass i+1 did not disturb the
+    tail of pass i (alternating scratch) and the tails ran in order."""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    pp = DevicePipeline(0, pipelined=True)
+    n = 1 << 22
+    caps, wants = [], []
+    for seed, mod in ((1, "FSK"), (2, "ASK")):
+        iq = synth_fsk(n, sps=100, seed=seed, noise=0.05, pause_every=n // 3, pause_len=n // 17)
+        if mod == "ASK":
+            env = np.repeat(np.random.default_rng(seed).integers(0, 2, n // 100 + 1), 100)[:n]
+            iq = (iq * (0.05 + 0.95 * env)[:, None]).astype(np.float32)
+        p = DemodParams(mod, 1, 0.1, 0.0 if mod == "FSK" else 0.35, 1.0, 5, 100, 0.1, 8, True)
+        qad = oracle.afp_demod(iq, 0.1, mod, 2)
+        ppseq = oracle.grab_pulse_lens(qad, p.center, 5, mod, 100, 1, 1.0)
+        wants.append((qad, ppseq, oracle.ppseq_to_bits_flat(ppseq, 100, 1, True, 8)))
+        caps.append((torch.from_numpy(iq).cuda(), p))
+    results = [None, None]
+    for i in range(12):
+        iq, p = caps[i % 2]
+        results[i % 2] = pp.iq_to_bits(iq, p, want_qad=True, slot=i % 2)
+    for k in (0, 1):
+        qad, ppseq, flat = wants[k]
+        res = results[k]
+        assert np.array_equal(res.ppseq(), ppseq), k
+        assert all(np.array_equal(a, b) for a, b in zip(flat, res.flat())), k
+        assert bits_equal(res.qad.cpu().numpy(), qad), k
+    pp.ctx.set_pipelined(False)

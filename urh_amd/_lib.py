@@ -59,6 +59,8 @@ PROTOTYPES = {
     "urhgpu_ctx_set_stream": (_i, [_vp, _vp]),
     "urhgpu_ctx_use_private_stream": (_i, [_vp]),
     "urhgpu_ctx_sync": (_i, [_vp]),
+    "urhgpu_ctx_set_pipelined": (_i, [_vp, _i, _vp]),
+    "urhgpu_ctx_join": (_i, [_vp]),
     "urhgpu_ctx_reserve": (_i, [_vp, _i64, _i]),
     "urhgpu_ctx_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.c_char_p, _i]),
     "urhgpu_ctx_costas_stats": (_i, [_vp, C.POINTER(C.c_int32)]),
@@ -171,6 +173,13 @@ class Context:
 
     def sync(self):
         check(load().urhgpu_ctx_sync(self._h))
+
+    def set_pipelined(self, enable: bool, tail_stream_ptr=None):
+        """see urhgpu_ctx_set_pipelined (include/urhgpu.h): outputs of iq_to_bits are then complete after join() / sync()"""
+        check(load().urhgpu_ctx_set_pipelined(self._h, 1 if enable else 0, C.c_void_p(tail_stream_ptr or 0)))
+
+    def join(self):
+        check(load().urhgpu_ctx_join(self._h))
 
     def reserve(self, n_samples: int, tolerance: int):
         check(load().urhgpu_ctx_reserve(self._h, int(n_samples), int(tolerance)))

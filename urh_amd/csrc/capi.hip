@@ -110,7 +110,7 @@ int dtype_bytes(int dtype) {
 // scratch must come from ctx->arena (already reserved by the caller).
 int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const urhgpu_params *p, float *d_qad,
              int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows, int64_t *d_n_rows_needed, int64_t *d_n_acc,
-             const Plan &pl, int seg_mode = 0) {
+             const Plan &pl, int seg_mode = 0, hipStream_t s_tail = nullptr) {
     hipStream_t s = ctx->stream;
     RunArgs a;
     memset(&a, 0, sizeof(a));
@@ -135,6 +135,11 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     if (from_iq) URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, d_qad != nullptr, s));
     else URH_TRY(launch_runs_qad(a, s));
     if (prof) { URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], s)); ctx->prof_used += 1; }
+    if (s_tail) {                                   // pipelined: everything after the hot kernel goes to the tail stream
+        URH_HIP(hipEventRecord(ctx->ev_hot, s));
+        URH_HIP(hipStreamWaitEvent(s_tail, ctx->ev_hot, 0));
+        s = s_tail;
+    }
 
     const bool ask = (p->mod == URHGPU_MOD_ASK) && !seg_mode;
     int64_t *rows_stage = d_rows;
@@ -183,6 +188,7 @@ BitsParams bits_params(const urhgpu_params *p) {
 // carved from ctx->arena, which is not reset until the next pass begins.
 struct ShardSession {
     int phase = 0;                 // 1: runs done, 2: rows done, 3: bits prepared
+    bool piped = false;            // pipelined mode: phases after the hot kernel run on ctx->tail_stream
     int rank = 0, world = 1;
     int64_t n_local = 0, pos_base = 0, n_total = 0;
     urhgpu_params p;
@@ -197,6 +203,28 @@ struct ShardSession {
     int64_t *d_small = nullptr;    // [0] ts_carry, [1] absorbed, [2] extra (2 x int32), [3] n_rows (final)
     const int64_t *d_row_base = nullptr;
 };
+
+// pipelined mode: make the caller's stream wait for the tail of the last pass (no host blocking)
+int join_tail(urhgpu_ctx *ctx) {
+    if (ctx->tail_pending) {
+        URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->flip ^ 1], 0));
+        ctx->tail_pending = false;
+    }
+    return URHGPU_OK;
+}
+
+// pipelined mode: switch to the other scratch arena; the caller's stream first waits for the tail that used it last
+int begin_pipelined_pass(urhgpu_ctx *ctx) {
+    std::swap(ctx->arena, ctx->arena_alt);
+    URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->flip], 0));
+    return URHGPU_OK;
+}
+int end_pipelined_pass(urhgpu_ctx *ctx) {
+    URH_HIP(hipEventRecord(ctx->ev_tail[ctx->flip], ctx->tail_stream));
+    ctx->flip ^= 1;
+    ctx->tail_pending = true;
+    return URHGPU_OK;
+}
 
 ShardSession *session(urhgpu_ctx *ctx) {
     if (!ctx->shard) ctx->shard = new (std::nothrow) ShardSession();
@@ -263,6 +291,10 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     ctx->arena.release();
     ctx->staging.release();
     ctx->aux.release();
+    ctx->arena_alt.release();
+    if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
+    if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
+    if (ctx->ev_hot) { (void)hipEventDestroy(ctx->ev_hot); (void)hipEventDestroy(ctx->ev_tail[0]); (void)hipEventDestroy(ctx->ev_tail[1]); }
     delete (ShardSession *)ctx->shard;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -287,8 +319,34 @@ int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx) {
 
 int urhgpu_ctx_sync(urhgpu_ctx *ctx) {
     if (!ctx) return URHGPU_ERR_ARG;
+    if (ctx->tail_stream) URH_HIP(hipStreamSynchronize(ctx->tail_stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->tail_pending = false;
     return URHGPU_OK;
+}
+
+int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
+    if (!ctx) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(urhgpu_ctx_sync(ctx));
+    if (ctx->own_tail_stream && ctx->tail_stream) { (void)hipStreamDestroy(ctx->tail_stream); }
+    ctx->tail_stream = nullptr; ctx->own_tail_stream = false; ctx->pipelined = false;
+    if (!enable) return URHGPU_OK;
+    if (tail_stream) ctx->tail_stream = (hipStream_t)tail_stream;
+    else { URH_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking)); ctx->own_tail_stream = true; }
+    if (!ctx->ev_hot) {
+        URH_HIP(hipEventCreateWithFlags(&ctx->ev_hot, hipEventDisableTiming));
+        URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[0], hipEventDisableTiming));
+        URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[1], hipEventDisableTiming));
+    }
+    ctx->pipelined = true;
+    return URHGPU_OK;
+}
+
+int urhgpu_ctx_join(urhgpu_ctx *ctx) {
+    if (!ctx) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    return join_tail(ctx);
 }
 
 int urhgpu_ctx_info(urhgpu_ctx *ctx, int *compute_units, int *wavefront, int64_t *hbm_bytes, char *name, int name_cap) {
@@ -305,7 +363,9 @@ int urhgpu_ctx_reserve(urhgpu_ctx *ctx, int64_t n_samples, int tolerance) {
     URH_HIP(hipSetDevice(ctx->device));
     const Plan pl = make_plan(ctx, n_samples, tolerance);
     const int64_t cap_rows = n_samples / ((int64_t)tolerance + 1) + 2;
-    return ctx->arena.reserve(digitize_scratch_bytes(pl, cap_rows, true, true));
+    URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, cap_rows, true, true)));
+    if (ctx->pipelined) URH_TRY(ctx->arena_alt.reserve(digitize_scratch_bytes(pl, cap_rows, true, true)));
+    return URHGPU_OK;
 }
 
 int urhgpu_ctx_profile_begin(urhgpu_ctx *ctx, int max_records) {
@@ -346,6 +406,7 @@ int urhgpu_afp_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urh
     if (!ctx || !p || n < 0 || (n > 0 && (!d_iq || !d_qad))) return URHGPU_ERR_ARG;
     if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     if (n <= 2) {                                   // signal_functions.pyx:335-336
         if (n > 0) URH_HIP(hipMemsetAsync(d_qad, 0, (size_t)n * 4, ctx->stream));
         return URHGPU_OK;
@@ -376,6 +437,7 @@ int urhgpu_grab_pulse_lens_dev(urhgpu_ctx *ctx, const float *d_qad, int64_t n, c
                                int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows) {
     if (!ctx || !p || n < 0 || cap_rows < 0 || !d_n_rows) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     if (n == 0) {                                   // signal_functions.pyx:416-417
         URH_HIP(hipMemsetAsync(d_n_rows, 0, 8, ctx->stream));
         URH_HIP(hipMemsetAsync(ctx->d_counts, 0, 16 * 8, ctx->stream));
@@ -401,6 +463,7 @@ int urhgpu_ppseq_to_bits_dev(urhgpu_ctx *ctx, const int64_t *d_rows, const int64
     if (!ctx || !p || !out || !d_n_rows || cap_rows_hint < 0) return URHGPU_ERR_ARG;
     if (p->bits_per_symbol < 1 || p->samples_per_symbol < 1) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     const int64_t cap = std::max<int64_t>(cap_rows_hint, 1);
     URH_TRY(ctx->arena.reserve(bits_scratch_bytes(cap) + 4096));
     ctx->arena.reset();
@@ -417,10 +480,13 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
     URH_HIP(hipSetDevice(ctx->device));
     const Plan pl = make_plan(ctx, n, p->tolerance);
     const bool ask = (p->mod == URHGPU_MOD_ASK);
+    const bool fused = !(n <= 2 || p->mod == URHGPU_MOD_PSK);
+    const bool piped = ctx->pipelined && fused;
+    if (piped) URH_TRY(begin_pipelined_pass(ctx)); else URH_TRY(join_tail(ctx));
     URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, out->cap_rows, ask, true) + (out->qad ? 0 : align256((size_t)n * 4))));
     ctx->arena.reset();
     int64_t *d_n_rows = ctx->d_counts + 10;
-    if (n <= 2 || p->mod == URHGPU_MOD_PSK) {
+    if (!fused) {
         // no fused kernel: demodulate (zeros for n <= 2, Costas loop for PSK), then segment the qad
         float *qad = out->qad;
         if (!qad) { qad = (float *)ctx->arena.take((size_t)n * 4); if (!qad) return URHGPU_ERR_ARG; }
@@ -429,15 +495,21 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
                          ctx->d_counts + 9, pl));
     } else {
         URH_TRY(digitize(ctx, true, d_iq, n, p, out->qad, out->rows, out->cap_rows, d_n_rows, ctx->d_counts + 8,
-                         ctx->d_counts + 9, pl));
+                         ctx->d_counts + 9, pl, 0, piped ? ctx->tail_stream : nullptr));
     }
-    if (!out->bits || !out->msg_off || !out->pauses || !out->pos_off) return URHGPU_OK;   // pulse table only
-    const int64_t cap = std::max<int64_t>(out->cap_rows, 1);
-    void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
-    if (!scratch) return URHGPU_ERR_ARG;
-    return ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch);
+    int st = URHGPU_OK;
+    if (out->bits && out->msg_off && out->pauses && out->pos_off) {          // else: pulse table only
+        const int64_t cap = std::max<int64_t>(out->cap_rows, 1);
+        void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
+        if (!scratch) return URHGPU_ERR_ARG;
+        hipStream_t caller = ctx->stream;
+        if (piped) ctx->stream = ctx->tail_stream;
+        st = ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch);
+        ctx->stream = caller;
+    }
+    if (piped) URH_TRY(end_pipelined_pass(ctx));
+    return st;
 }
-
 
 // ---- sharded captures (one rank's phases; the all-gathers in between belong to the caller) --------------
 int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
@@ -454,6 +526,8 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
     ShardSession *ss = session(ctx);
     if (!ss) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
+    ss->piped = ctx->pipelined;
+    if (ss->piped) URH_TRY(begin_pipelined_pass(ctx)); else URH_TRY(join_tail(ctx));
     ss->phase = 0; ss->rank = rank; ss->world = world; ss->n_local = n_local; ss->pos_base = pos_base; ss->n_total = n_total;
     ss->p = *p; ss->out = *out;
     const Plan pl = make_plan(ctx, n_local, p->tolerance);
@@ -492,6 +566,11 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
     if (prof) URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used], s));
     URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s));
     if (prof) { URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], s)); ctx->prof_used += 1; }
+    if (ss->piped) {                                // everything after the hot kernel goes to the tail stream
+        URH_HIP(hipEventRecord(ctx->ev_hot, s));
+        URH_HIP(hipStreamWaitEvent(ctx->tail_stream, ctx->ev_hot, 0));
+        s = ctx->tail_stream;
+    }
     // local resolve pass: the shard on its own -> its summary
     ResolveArgs r;
     memset(&r, 0, sizeof(r));
@@ -511,7 +590,7 @@ int urhgpu_shard_rows_dev(urhgpu_ctx *ctx, const void *d_summaries, int64_t *d_m
     ShardSession *ss = (ShardSession *)ctx->shard;
     if (!ss || ss->phase != 1) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ss->piped ? ctx->tail_stream : ctx->stream;
     const int rank = ss->rank, world = ss->world;
     const Plan &pl = ss->pl;
     const bool ask = (ss->p.mod == URHGPU_MOD_ASK);
@@ -558,7 +637,7 @@ int urhgpu_shard_bits_prepare_dev(urhgpu_ctx *ctx, const int64_t *d_merge_all, i
     if (ask && !d_merge_all) return URHGPU_ERR_ARG;
     if (!ss->out.bits || !ss->out.msg_off || !ss->out.pauses || !ss->out.pos_off) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ss->piped ? ctx->tail_stream : ctx->stream;
     int64_t *d_n_rows = ss->d_small + 3;
     if (ask) launch_merge_fix(ss->out.rows, d_n_rows, d_merge_all, ss->rank, ss->world, ss->d_small + 1, s);
     BitsParams bp = bits_params(&ss->p);
@@ -575,7 +654,7 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
     ShardSession *ss = (ShardSession *)ctx->shard;
     if (!ss || ss->phase != 3) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ss->piped ? ctx->tail_stream : ctx->stream;
     const bool ask = (ss->p.mod == URHGPU_MOD_ASK);
     launch_bits_extra(d_flags_all, ss->rank, ss->world, (int32_t *)(ss->d_small + 2), s);
     BitsParams bp = bits_params(&ss->p);
@@ -586,6 +665,7 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
     URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, ctx->d_tickets, s));
     URH_HIP(hipGetLastError());
     ss->phase = 0;
+    if (ss->piped) URH_TRY(end_pipelined_pass(ctx));
     return URHGPU_OK;
 }
 
@@ -599,6 +679,7 @@ int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_
     if (!ctx || n < 0 || !d_n_rows || cap_rows < 0) return URHGPU_ERR_ARG;
     if (dtype != URHGPU_DT_F32) return dtype_bytes(dtype) ? URHGPU_ERR_UNSUPPORTED : URHGPU_ERR_DTYPE;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     if (n == 0) { URH_HIP(hipMemsetAsync(d_n_rows, 0, 8, ctx->stream)); return URHGPU_OK; }
     if (!d_iq || !d_rows || ((uintptr_t)d_iq & 15)) return URHGPU_ERR_ARG;
     urhgpu_params p;
@@ -615,6 +696,7 @@ int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_
 int urhgpu_compact_gt_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float thr, float *d_out, int64_t *d_count) {
     if (!ctx || n < 0 || !d_count || (n > 0 && (!d_x || !d_out))) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     URH_TRY(ctx->arena.reserve(compact_scratch_bytes(n) + 1024));
     ctx->arena.reset();
     void *scratch = ctx->arena.take(compact_scratch_bytes(n));
@@ -628,6 +710,7 @@ int urhgpu_compact_gt_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float th
 int urhgpu_edges_le_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float center, int64_t *d_idx, int64_t cap, int64_t *d_count) {
     if (!ctx || n < 0 || cap < 0 || !d_count || (n > 0 && !d_x) || (cap > 0 && !d_idx)) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     URH_TRY(ctx->arena.reserve(compact_scratch_bytes(n) + 1024));
     ctx->arena.reset();
     void *scratch = ctx->arena.take(compact_scratch_bytes(n));
@@ -641,6 +724,7 @@ int urhgpu_edges_le_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float cent
 int urhgpu_minmax_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float *d_out2) {
     if (!ctx || n <= 0 || !d_x || !d_out2) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     URH_TRY(ctx->arena.reserve(minmax_scratch_bytes() + 1024));
     ctx->arena.reset();
     void *scratch = ctx->arena.take(minmax_scratch_bytes());
@@ -653,12 +737,14 @@ int urhgpu_minmax_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float *d
 int urhgpu_pairwise_sum_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, float mean, float *sum_out) {
     if (!ctx || n < 0 || !sum_out || (n > 0 && !d_x) || (mode != 0 && mode != 1)) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     return pairwise_sum_f32(ctx, d_x, n, mode, mean, sum_out);
 }
 
 int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const double *d_edges, int64_t n_edges, int64_t *d_counts) {
     if (!ctx || n < 0 || n_edges < 2 || n_edges > (1 << 30) || !d_edges || !d_counts || (n > 0 && !d_x)) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     URH_TRY(launch_hist_edges(d_x, n, d_edges, (int)n_edges, d_counts, ctx->stream));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
@@ -813,6 +899,7 @@ int urhgpu_fir_filter_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const fl
     if (!ctx || n < 0 || m < 0 || (n > 0 && (!d_x || !d_out)) || (m > 0 && !d_taps)) return URHGPU_ERR_ARG;
     if (((uintptr_t)d_x & 7) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_taps & 7) || m > (int64_t)1 << 20) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     URH_TRY(launch_fir((const float2 *)d_x, n, (const float2 *)d_taps, (int)m, (const float2 *)d_left_halo, (float2 *)d_out, ctx->stream));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
@@ -880,6 +967,7 @@ int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *ctx, const void *d_iq, int dtyp
     if (dtype_bytes(dtype) == 0) return URHGPU_ERR_DTYPE;
     if (n_chunks == 0) return URHGPU_OK;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
     URH_TRY(ctx->arena.reserve(mag_chunk_scratch_bytes(n_chunks) + 1024));
     ctx->arena.reset();
     void *scratch = ctx->arena.take(mag_chunk_scratch_bytes(n_chunks));

@@ -65,4 +65,15 @@ struct urhgpu_ctx {
     int prof_used = 0;                     // pairs recorded since urhgpu_ctx_profile_begin
     bool prof_on = false;
     void *shard = nullptr;                 // state of a sharded pass between its phases (capi.hip: ShardSession)
+    // Pipelined mode (urhgpu_ctx_set_pipelined): the hot kernel of a pass runs on `stream`, everything after it on
+    // `tail_stream`, with two scratch arenas used alternately, so that the hot kernel of the NEXT pass overlaps the
+    // (latency-bound, nearly empty) tail of this one.  Outputs are complete after urhgpu_ctx_join / urhgpu_ctx_sync.
+    bool pipelined = false;
+    hipStream_t tail_stream = nullptr;
+    bool own_tail_stream = false;
+    urh::Arena arena_alt;
+    hipEvent_t ev_hot = nullptr;
+    hipEvent_t ev_tail[2] = {nullptr, nullptr};
+    int flip = 0;
+    bool tail_pending = false;
 };

@@ -66,16 +66,19 @@ def _torch_dtype(t):
 class BitsResult:
     """Device-resident outputs of one IQ->bits pass (torch tensors) + lazy host views."""
 
-    def __init__(self, qad, rows, bits, msg_off, pauses, pos, pos_off, counts, params):
+    def __init__(self, qad, rows, bits, msg_off, pauses, pos, pos_off, counts, params, ctx=None):
         self.qad, self.rows_buf, self.bits_buf = qad, rows, bits
         self.msg_off_buf, self.pauses_buf, self.pos_buf, self.pos_off_buf = msg_off, pauses, pos, pos_off
         self.counts = counts
         self.params = params
         self._host_counts = None
+        self._ctx = ctx
 
     def host_counts(self):
         """(n_rows, n_msg, n_bits, n_pos): one 32-byte D2H copy (synchronises)."""
         if self._host_counts is None:
+            if self._ctx is not None:
+                self._ctx.join()          # pipelined mode: the current stream waits for the tail of the pass
             c = self.counts.cpu().numpy()
             self._host_counts = tuple(int(x) for x in c[:4])
         return self._host_counts
@@ -119,7 +122,9 @@ class BitsResult:
 class DevicePipeline:
     """Owns a liburhgpu context bound to torch's current stream and the output buffers."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, pipelined=False):
+        """pipelined: back-to-back iq_to_bits passes overlap (the hot kernel of a pass runs while the tail of the previous
+        one finishes on a second stream, see urhgpu_ctx_set_pipelined); results synchronise when they are read."""
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -127,6 +132,18 @@ class DevicePipeline:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.ctx = _lib.Context(self.device.index)
         self._bufs = {}
+        self.tail_stream = None
+        if pipelined:
+            self.tail_stream = torch.cuda.Stream(self.device)
+            self.ctx.set_pipelined(True, self.tail_stream.cuda_stream)
+
+    def tail_context(self):
+        """torch stream context of the work that follows the hot kernel (pipelined mode), else a no-op context"""
+        import contextlib
+        return self.torch.cuda.stream(self.tail_stream) if self.tail_stream is not None else contextlib.nullcontext()
+
+    def join(self):
+        self.ctx.join()
 
     def _buf(self, name, shape, dtype):
         t = self._bufs.get(name)
@@ -150,8 +167,9 @@ class DevicePipeline:
     def reserve(self, n: int, p: DemodParams):
         self.ctx.reserve(n, p.tolerance)
 
-    def iq_to_bits(self, iq, p: DemodParams, want_qad=True, cap_rows=None) -> BitsResult:
-        """iq: torch tensor on this device, shape (N, 2) of int8/uint8/int16/uint16/float32, or complex64 (N,)."""
+    def iq_to_bits(self, iq, p: DemodParams, want_qad=True, cap_rows=None, slot=0) -> BitsResult:
+        """iq: torch tensor on this device, shape (N, 2) of int8/uint8/int16/uint16/float32, or complex64 (N,).
+        The result lives in buffers owned by the pipeline and is overwritten by the next pass with the same `slot`."""
         torch = self.torch
         if iq.dtype == torch.complex64:
             iq = torch.view_as_real(iq)
@@ -161,14 +179,15 @@ class DevicePipeline:
         n = iq.shape[0]
         cp = p.to_c(npdt)
         cap_rows, cap_bits, cap_msg, cap_pos = self.capacities(n, p, cap_rows)
-        qad = self._buf("qad", (n,), torch.float32) if want_qad else None
-        rows = self._buf("rows", (cap_rows, 2), torch.int64)
-        bits = self._buf("bits", (cap_bits,), torch.uint8)
-        msg_off = self._buf("msg_off", (cap_msg + 1,), torch.int64)
-        pauses = self._buf("pauses", (cap_msg,), torch.int64)
-        pos_off = self._buf("pos_off", (cap_msg + 1,), torch.int64)
-        pos = self._buf("pos", (cap_pos,), torch.int64) if p.write_bit_sample_pos else None
-        counts = self._buf("counts", (4,), torch.int64)
+        sfx = f"s{slot}:" if slot else ""
+        qad = self._buf(sfx + "qad", (n,), torch.float32) if want_qad else None
+        rows = self._buf(sfx + "rows", (cap_rows, 2), torch.int64)
+        bits = self._buf(sfx + "bits", (cap_bits,), torch.uint8)
+        msg_off = self._buf(sfx + "msg_off", (cap_msg + 1,), torch.int64)
+        pauses = self._buf(sfx + "pauses", (cap_msg,), torch.int64)
+        pos_off = self._buf(sfx + "pos_off", (cap_msg + 1,), torch.int64)
+        pos = self._buf(sfx + "pos", (cap_pos,), torch.int64) if p.write_bit_sample_pos else None
+        counts = self._buf(sfx + "counts", (4,), torch.int64)
         o = _lib.Outputs()
         o.qad = qad.data_ptr() if qad is not None else None
         o.rows = rows.data_ptr(); o.cap_rows = cap_rows
@@ -180,7 +199,7 @@ class DevicePipeline:
         o.counts = counts.data_ptr()
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(_lib.load().urhgpu_iq_to_bits_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, C.byref(cp), C.byref(o)))
-        return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p)
+        return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, self.ctx)
 
     def afp_demod(self, iq, p: DemodParams):
         torch = self.torch

@@ -12,14 +12,17 @@ from .pipeline import DevicePipeline, _torch_dtype
 class ShardResult:
     """This rank's piece of a sharded result (device tensors) + host views for `sharding.stitch`."""
 
-    def __init__(self, qad, rows, bits, msg_off, pauses, pos, pos_off, counts, params):
+    def __init__(self, qad, rows, bits, msg_off, pauses, pos, pos_off, counts, params, ctx=None):
         self.qad, self.rows_buf, self.bits_buf = qad, rows, bits
         self.msg_off_buf, self.pauses_buf, self.pos_buf, self.pos_off_buf = msg_off, pauses, pos, pos_off
         self.counts, self.params = counts, params
         self._host_counts = None
+        self._ctx = ctx
 
     def host_counts(self):
         if self._host_counts is None:
+            if self._ctx is not None:
+                self._ctx.join()
             self._host_counts = tuple(int(x) for x in self.counts.cpu().numpy()[:4])
         return self._host_counts
 
@@ -107,7 +110,7 @@ class GpuShardEngine(DevicePipeline):
         o.cap_pos = cap_pos if pos is not None else 0
         o.pos_off = pos_off.data_ptr()
         o.counts = counts.data_ptr()
-        self._res = ShardResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p)
+        self._res = ShardResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, self.ctx)
         self._ask = p.modulation_type == "ASK"
         self._keep = (iq, left)                                # keep the inputs alive until the pass is over
         summary = self._buf("summary", (9,), torch.int64)      # URHGPU_SHARD_SUMMARY_BYTES = 72

@@ -22,6 +22,8 @@ The orchestration below is engine-agnostic: `engine` is the GPU engine (urh_amd.
 HIP kernels behind the C ABI) in production; the CPU test-suite drives the same orchestration with the executable
 model of the kernels (tests/model_shard.py) over a world_size-2 gloo group.
 """
+import contextlib
+
 import numpy as np
 
 
@@ -126,10 +128,13 @@ class ShardedPipeline:
         halos = c.all_gather(e.tail(iq_local, p))
         left = halos[self.rank - 1] if self.rank > 0 else None
         summary = e.runs(iq_local, left, pos_base, n_total, self.rank, self.world, p, want_qad)
-        merge = e.rows(c.all_gather(summary))
-        merged_all = c.all_gather(merge) if merge is not None else None
-        flags = e.bits_prepare(merged_all)
-        return e.bits_finish(c.all_gather(flags))
+        # everything after the hot kernel (all-gathers included) is issued on the engine's tail stream when it is pipelined:
+        # the next pass's halo exchange and hot kernel then overlap this pass's latency-bound tail
+        with (e.tail_context() if hasattr(e, "tail_context") else contextlib.nullcontext()):
+            merge = e.rows(c.all_gather(summary))
+            merged_all = c.all_gather(merge) if merge is not None else None
+            flags = e.bits_prepare(merged_all)
+            return e.bits_finish(c.all_gather(flags))
 
 
 def stitch(pieces):
