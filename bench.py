@@ -87,7 +87,6 @@ def main():
     ap.add_argument("--segments", type=int, default=128, help="2^20-sample segments per GPU (128 = 1 GiB complex64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bits-only", action="store_true", help="do not materialise qad (8 B/sample variant)")
-    ap.add_argument("--tail-cus", type=int, default=0, help="compute units reserved for the tail stream (0 = 1/8 of the GPU)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="run every step strictly after the previous one (default: consecutive steps are software-pipelined: "
                          "the hot kernel of step i+1 overlaps the latency-bound tail of step i on a second stream)")
@@ -121,9 +120,9 @@ def main():
     if world > 1 or force_sharded:
         from urh_amd.shard_engine import GpuShardEngine
         from urh_amd.sharding import ShardedPipeline, TorchDistComm
-        pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=not args.no_pipeline, tail_cus=args.tail_cus), TorchDistComm())
+        pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=not args.no_pipeline), TorchDistComm())
     else:
-        pipe = DevicePipeline(local_rank, pipelined=not args.no_pipeline, tail_cus=args.tail_cus)
+        pipe = DevicePipeline(local_rank, pipelined=not args.no_pipeline)
     pipe.reserve(n, p)
     want_qad = not args.bits_only
 

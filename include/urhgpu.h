@@ -71,16 +71,13 @@ int urhgpu_ctx_set_stream(urhgpu_ctx *ctx, void *hip_stream);
 /* Go back to the context's private (non-blocking) stream. */
 int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx);
 int urhgpu_ctx_sync(urhgpu_ctx *ctx);
-/* Pipelined mode for back-to-back passes (streaming one capture after the other).  urhgpu_iq_to_bits_dev and the
- * urhgpu_shard_* phases then run the hot kernel on a stream restricted (CU mask) to all but `tail_cus` compute units and
- * everything after it -- pulse table, bits: latency-bound kernels of a few wavefronts -- on a second stream that owns the
- * remaining tail_cus CUs (0 = 1/8 of the GPU), with alternating scratch, so that the NEXT pass's hot kernel overlaps this
- * pass's tail instead of waiting ~0.13 ms for it.  Ordering: the hot stream waits for the work already queued on the
- * context's stream when the pass is called; the inputs and outputs of a pass are released / complete only after
- * urhgpu_ctx_join (the context's stream then waits for the pass; the host does not block) or urhgpu_ctx_sync.  Every other
- * entry point joins first.  enable = 0 switches back (synchronises).  urhgpu_ctx_streams returns the two hipStream_t. */
-int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, int tail_cus);
-int urhgpu_ctx_streams(urhgpu_ctx *ctx, void **hot_stream, void **tail_stream);
+/* Pipelined mode for back-to-back passes (streaming one capture after the other): urhgpu_iq_to_bits_dev then runs its
+ * hot kernel on the context's stream and everything after it (pulse table, bits: latency-bound kernels that leave the GPU
+ * nearly empty) on a second stream with alternating scratch, so that the NEXT pass's hot kernel overlaps this pass's tail.
+ * tail_stream: a hipStream_t of the caller (e.g. a torch stream) or NULL for a private one.  In this mode the outputs of a
+ * pass are complete only after urhgpu_ctx_join (the context's stream waits for the tail; the host does not block) or
+ * urhgpu_ctx_sync; every other entry point joins first.  enable = 0 switches back (synchronises). */
+int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
 int urhgpu_ctx_join(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no
  * allocation happens inside later calls (bench / steady state). */

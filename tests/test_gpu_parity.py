@@ -643,5 +643,4 @@ def test_pipelined_passes_do_not_disturb_each_other(oracle):
         assert np.array_equal(res.ppseq(), ppseq), k
         assert all(np.array_equal(a, b) for a, b in zip(flat, res.flat())), k
         assert bits_equal(res.qad.cpu().numpy(), qad), k
-    pp.tail_stream = None
     pp.ctx.set_pipelined(False)

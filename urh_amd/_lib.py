@@ -59,8 +59,7 @@ PROTOTYPES = {
     "urhgpu_ctx_set_stream": (_i, [_vp, _vp]),
     "urhgpu_ctx_use_private_stream": (_i, [_vp]),
     "urhgpu_ctx_sync": (_i, [_vp]),
-    "urhgpu_ctx_set_pipelined": (_i, [_vp, _i, _i]),
-    "urhgpu_ctx_streams": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp)]),
+    "urhgpu_ctx_set_pipelined": (_i, [_vp, _i, _vp]),
     "urhgpu_ctx_join": (_i, [_vp]),
     "urhgpu_ctx_reserve": (_i, [_vp, _i64, _i]),
     "urhgpu_ctx_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.c_char_p, _i]),
@@ -175,15 +174,9 @@ class Context:
     def sync(self):
         check(load().urhgpu_ctx_sync(self._h))
 
-    def set_pipelined(self, enable: bool, tail_cus: int = 0):
+    def set_pipelined(self, enable: bool, tail_stream_ptr=None):
         """see urhgpu_ctx_set_pipelined (include/urhgpu.h): outputs of iq_to_bits are then complete after join() / sync()"""
-        check(load().urhgpu_ctx_set_pipelined(self._h, 1 if enable else 0, int(tail_cus)))
-
-    def streams(self):
-        """(hot, tail) hipStream_t handles of the pipelined mode (0 when it is off)"""
-        hot, tail = C.c_void_p(), C.c_void_p()
-        check(load().urhgpu_ctx_streams(self._h, C.byref(hot), C.byref(tail)))
-        return hot.value or 0, tail.value or 0
+        check(load().urhgpu_ctx_set_pipelined(self._h, 1 if enable else 0, C.c_void_p(tail_stream_ptr or 0)))
 
     def join(self):
         check(load().urhgpu_ctx_join(self._h))

@@ -189,7 +189,6 @@ BitsParams bits_params(const urhgpu_params *p) {
 struct ShardSession {
     int phase = 0;                 // 1: runs done, 2: rows done, 3: bits prepared
     bool piped = false;            // pipelined mode: phases after the hot kernel run on ctx->tail_stream
-    hipStream_t caller = nullptr;
     int rank = 0, world = 1;
     int64_t n_local = 0, pos_base = 0, n_total = 0;
     urhgpu_params p;
@@ -214,19 +213,13 @@ int join_tail(urhgpu_ctx *ctx) {
     return URHGPU_OK;
 }
 
-// pipelined mode: switch to the other scratch arena; the hot stream waits for the caller's stream (inputs) and for the
-// tail that used this arena last.  Returns with ctx->stream == hot stream; *caller receives the caller's stream.
-int begin_pipelined_pass(urhgpu_ctx *ctx, hipStream_t *caller) {
-    *caller = ctx->stream;
+// pipelined mode: switch to the other scratch arena; the caller's stream first waits for the tail that used it last
+int begin_pipelined_pass(urhgpu_ctx *ctx) {
     std::swap(ctx->arena, ctx->arena_alt);
-    URH_HIP(hipEventRecord(ctx->ev_in, ctx->stream));
-    URH_HIP(hipStreamWaitEvent(ctx->hot_stream, ctx->ev_in, 0));
-    URH_HIP(hipStreamWaitEvent(ctx->hot_stream, ctx->ev_tail[ctx->flip], 0));
-    ctx->stream = ctx->hot_stream;
+    URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->flip], 0));
     return URHGPU_OK;
 }
-int end_pipelined_pass(urhgpu_ctx *ctx, hipStream_t caller) {
-    ctx->stream = caller;
+int end_pipelined_pass(urhgpu_ctx *ctx) {
     URH_HIP(hipEventRecord(ctx->ev_tail[ctx->flip], ctx->tail_stream));
     ctx->flip ^= 1;
     ctx->tail_pending = true;
@@ -299,9 +292,9 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     ctx->staging.release();
     ctx->aux.release();
     ctx->arena_alt.release();
-    if (ctx->tail_stream) { (void)hipStreamSynchronize(ctx->tail_stream); (void)hipStreamDestroy(ctx->tail_stream); }
-    if (ctx->hot_stream) { (void)hipStreamSynchronize(ctx->hot_stream); (void)hipStreamDestroy(ctx->hot_stream); }
-    if (ctx->ev_hot) { (void)hipEventDestroy(ctx->ev_hot); (void)hipEventDestroy(ctx->ev_in); (void)hipEventDestroy(ctx->ev_tail[0]); (void)hipEventDestroy(ctx->ev_tail[1]); }
+    if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
+    if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
+    if (ctx->ev_hot) { (void)hipEventDestroy(ctx->ev_hot); (void)hipEventDestroy(ctx->ev_tail[0]); (void)hipEventDestroy(ctx->ev_tail[1]); }
     delete (ShardSession *)ctx->shard;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -326,51 +319,27 @@ int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx) {
 
 int urhgpu_ctx_sync(urhgpu_ctx *ctx) {
     if (!ctx) return URHGPU_ERR_ARG;
-    if (ctx->hot_stream) URH_HIP(hipStreamSynchronize(ctx->hot_stream));
     if (ctx->tail_stream) URH_HIP(hipStreamSynchronize(ctx->tail_stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
     ctx->tail_pending = false;
     return URHGPU_OK;
 }
 
-int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, int tail_cus) {
-    if (!ctx || tail_cus < 0) return URHGPU_ERR_ARG;
+int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
+    if (!ctx) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
     URH_TRY(urhgpu_ctx_sync(ctx));
-    if (ctx->hot_stream) { (void)hipStreamDestroy(ctx->hot_stream); ctx->hot_stream = nullptr; }
-    if (ctx->tail_stream) { (void)hipStreamDestroy(ctx->tail_stream); ctx->tail_stream = nullptr; }
-    ctx->pipelined = false;
+    if (ctx->own_tail_stream && ctx->tail_stream) { (void)hipStreamDestroy(ctx->tail_stream); }
+    ctx->tail_stream = nullptr; ctx->own_tail_stream = false; ctx->pipelined = false;
     if (!enable) return URHGPU_OK;
-    // Partition the CUs: the tail's small kernels get `tail_cus` CUs of their own (they would otherwise starve behind the
-    // hot kernel, which fills every wave slot), the hot kernel gets the rest.
-    const int n_cu = ctx->prop.multiProcessorCount;
-    if (tail_cus == 0) tail_cus = n_cu / 8;
-    if (tail_cus >= n_cu) return URHGPU_ERR_ARG;
-    const int words = (n_cu + 31) / 32;
-    std::vector<uint32_t> mask_hot((size_t)words, 0u), mask_tail((size_t)words, 0u);
-    const int stride = n_cu / tail_cus;
-    int given = 0;
-    for (int cu = 0; cu < n_cu; ++cu) {
-        const bool tail = (cu % stride == 0) && given < tail_cus;
-        if (tail) ++given;
-        (tail ? mask_tail : mask_hot)[(size_t)cu / 32] |= 1u << (cu % 32);
-    }
-    URH_HIP(hipExtStreamCreateWithCUMask(&ctx->hot_stream, (uint32_t)words, mask_hot.data()));
-    URH_HIP(hipExtStreamCreateWithCUMask(&ctx->tail_stream, (uint32_t)words, mask_tail.data()));
+    if (tail_stream) ctx->tail_stream = (hipStream_t)tail_stream;
+    else { URH_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking)); ctx->own_tail_stream = true; }
     if (!ctx->ev_hot) {
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_hot, hipEventDisableTiming));
-        URH_HIP(hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[0], hipEventDisableTiming));
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[1], hipEventDisableTiming));
     }
     ctx->pipelined = true;
-    return URHGPU_OK;
-}
-
-int urhgpu_ctx_streams(urhgpu_ctx *ctx, void **hot, void **tail) {
-    if (!ctx) return URHGPU_ERR_ARG;
-    if (hot) *hot = (void *)ctx->hot_stream;
-    if (tail) *tail = (void *)ctx->tail_stream;
     return URHGPU_OK;
 }
 
@@ -513,8 +482,7 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
     const bool ask = (p->mod == URHGPU_MOD_ASK);
     const bool fused = !(n <= 2 || p->mod == URHGPU_MOD_PSK);
     const bool piped = ctx->pipelined && fused;
-    hipStream_t caller = ctx->stream;
-    if (piped) URH_TRY(begin_pipelined_pass(ctx, &caller)); else URH_TRY(join_tail(ctx));
+    if (piped) URH_TRY(begin_pipelined_pass(ctx)); else URH_TRY(join_tail(ctx));
     URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, out->cap_rows, ask, true) + (out->qad ? 0 : align256((size_t)n * 4))));
     ctx->arena.reset();
     int64_t *d_n_rows = ctx->d_counts + 10;
@@ -533,13 +501,13 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
     if (out->bits && out->msg_off && out->pauses && out->pos_off) {          // else: pulse table only
         const int64_t cap = std::max<int64_t>(out->cap_rows, 1);
         void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
-        if (!scratch) { ctx->stream = caller; return URHGPU_ERR_ARG; }
-        const hipStream_t keep = ctx->stream;
+        if (!scratch) return URHGPU_ERR_ARG;
+        hipStream_t caller = ctx->stream;
         if (piped) ctx->stream = ctx->tail_stream;
         st = ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch);
-        ctx->stream = keep;
+        ctx->stream = caller;
     }
-    if (piped) URH_TRY(end_pipelined_pass(ctx, caller));
+    if (piped) URH_TRY(end_pipelined_pass(ctx));
     return st;
 }
 
@@ -557,12 +525,9 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
     URH_HIP(hipSetDevice(ctx->device));
     ShardSession *ss = session(ctx);
     if (!ss) return URHGPU_ERR_ARG;
+    hipStream_t s = ctx->stream;
     ss->piped = ctx->pipelined;
-    hipStream_t caller = ctx->stream;
-    if (ss->piped) URH_TRY(begin_pipelined_pass(ctx, &caller)); else URH_TRY(join_tail(ctx));
-    hipStream_t s = ctx->stream;                    // pipelined: the hot stream
-    ctx->stream = caller;
-    ss->caller = caller;
+    if (ss->piped) URH_TRY(begin_pipelined_pass(ctx)); else URH_TRY(join_tail(ctx));
     ss->phase = 0; ss->rank = rank; ss->world = world; ss->n_local = n_local; ss->pos_base = pos_base; ss->n_total = n_total;
     ss->p = *p; ss->out = *out;
     const Plan pl = make_plan(ctx, n_local, p->tolerance);
@@ -700,7 +665,7 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
     URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, ctx->d_tickets, s));
     URH_HIP(hipGetLastError());
     ss->phase = 0;
-    if (ss->piped) URH_TRY(end_pipelined_pass(ctx, ss->caller));
+    if (ss->piped) URH_TRY(end_pipelined_pass(ctx));
     return URHGPU_OK;
 }
 

@@ -69,9 +69,8 @@ struct urhgpu_ctx {
     // `tail_stream`, with two scratch arenas used alternately, so that the hot kernel of the NEXT pass overlaps the
     // (latency-bound, nearly empty) tail of this one.  Outputs are complete after urhgpu_ctx_join / urhgpu_ctx_sync.
     bool pipelined = false;
-    hipStream_t hot_stream = nullptr;      // CU-masked: every CU except the ones reserved for the tail
-    hipStream_t tail_stream = nullptr;     // CU-masked: the reserved CUs
-    hipEvent_t ev_in = nullptr;            // caller's stream -> hot stream (inputs ready)
+    hipStream_t tail_stream = nullptr;
+    bool own_tail_stream = false;
     urh::Arena arena_alt;
     hipEvent_t ev_hot = nullptr;
     hipEvent_t ev_tail[2] = {nullptr, nullptr};

@@ -122,7 +122,7 @@ class BitsResult:
 class DevicePipeline:
     """Owns a liburhgpu context bound to torch's current stream and the output buffers."""
 
-    def __init__(self, device=None, pipelined=False, tail_cus=0):
+    def __init__(self, device=None, pipelined=False):
         """pipelined: back-to-back iq_to_bits passes overlap (the hot kernel of a pass runs while the tail of the previous
         one finishes on a second stream, see urhgpu_ctx_set_pipelined); results synchronise when they are read."""
         import torch
@@ -134,8 +134,8 @@ class DevicePipeline:
         self._bufs = {}
         self.tail_stream = None
         if pipelined:
-            self.ctx.set_pipelined(True, tail_cus)
-            self.tail_stream = torch.cuda.ExternalStream(self.ctx.streams()[1], device=self.device)
+            self.tail_stream = torch.cuda.Stream(self.device)
+            self.ctx.set_pipelined(True, self.tail_stream.cuda_stream)
 
     def tail_context(self):
         """torch stream context of the work that follows the hot kernel (pipelined mode), else a no-op context"""
