@@ -87,9 +87,11 @@ def main():
     ap.add_argument("--segments", type=int, default=128, help="2^20-sample segments per GPU (128 = 1 GiB complex64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bits-only", action="store_true", help="do not materialise qad (8 B/sample variant)")
-    ap.add_argument("--no-pipeline", action="store_true",
-                    help="run every step strictly after the previous one (default: consecutive steps are software-pipelined: "
-                         "the hot kernel of step i+1 overlaps the latency-bound tail of step i on a second stream)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="software-pipeline consecutive steps (hot kernel of step i+1 on the main stream while the tail of step i "
+                         "runs on a second stream).  Off by default: on MI355X the hot kernel's single-wavefront workgroups "
+                         "refill every wave slot they free, the tail's multi-wave workgroups starve until it ends, and nothing "
+                         "is gained (DESIGN.md, section 4)")
     args = ap.parse_args()
 
     import torch
@@ -120,9 +122,9 @@ def main():
     if world > 1 or force_sharded:
         from urh_amd.shard_engine import GpuShardEngine
         from urh_amd.sharding import ShardedPipeline, TorchDistComm
-        pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=not args.no_pipeline), TorchDistComm())
+        pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=args.pipeline), TorchDistComm())
     else:
-        pipe = DevicePipeline(local_rank, pipelined=not args.no_pipeline)
+        pipe = DevicePipeline(local_rank, pipelined=args.pipeline)
     pipe.reserve(n, p)
     want_qad = not args.bits_only
 
@@ -185,7 +187,7 @@ def main():
                        "samples_per_gpu": n, "samples_per_symbol": sps, "tolerance": tol, "noise_sigma": 0.05,
                        "outputs": "qad+ppseq+bits+pauses+bit_sample_pos" if want_qad else "ppseq+bits+pauses+bit_sample_pos",
                        "rows": counts[0], "messages": counts[1], "bits": counts[2],
-                       "steps_pipelined": not args.no_pipeline, "single_step_latency_ms": round(latency_ms, 4)},
+                       "steps_pipelined": args.pipeline, "single_step_latency_ms": round(latency_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": "k_demod_runs", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": n * bytes_per_sample,

@@ -76,7 +76,8 @@ int urhgpu_ctx_sync(urhgpu_ctx *ctx);
  * nearly empty) on a second stream with alternating scratch, so that the NEXT pass's hot kernel overlaps this pass's tail.
  * tail_stream: a hipStream_t of the caller (e.g. a torch stream) or NULL for a private one.  In this mode the outputs of a
  * pass are complete only after urhgpu_ctx_join (the context's stream waits for the tail; the host does not block) or
- * urhgpu_ctx_sync; every other entry point joins first.  enable = 0 switches back (synchronises). */
+ * urhgpu_ctx_sync; every other entry point joins first.  enable = 0 switches back (synchronises).
+ * Measured on MI355X: no gain -- the tail's workgroups starve behind the hot kernel's -- so nothing uses it by default. */
 int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
 int urhgpu_ctx_join(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no
