@@ -54,3 +54,23 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 txt = open(os.path.join(root, f)).read()
                 assert "urh_oracle" not in txt and "oracle/" not in txt.replace("tests/ compare against the oracle /", ""), f
+
+
+def test_argument_errors_without_gpu():
+    """status codes of the C ABI for calls that are rejected before any device work (include/urhgpu.h)"""
+    import ctypes as C
+    from urh_amd import _lib
+    lib = _lib.load()
+    assert lib.urhgpu_strerror(0) == b"ok" and lib.urhgpu_strerror(-2) == b"Unsupported dtype"
+    null = C.c_void_p(None)
+    n_rows = C.c_int64(0)
+    assert lib.urhgpu_afp_demod(null, null, 4, 10, 0.0, 1, 2, 0.1, 0.0, null) == _lib.ERR_ARG
+    assert lib.urhgpu_grab_pulse_lens(null, null, 10, 0.0, 5, 1, 100, 1, 0.1, 0.0, null, 0, C.byref(n_rows)) == _lib.ERR_ARG
+    assert lib.urhgpu_ctx_sync(null) == _lib.ERR_ARG
+    assert lib.urhgpu_fir_filter(null, null, 4, null, 2, null) == _lib.ERR_ARG
+    out = (C.c_float * 3)()
+    assert lib.urhgpu_get_center_thresholds(0.5, 0.25, 4, out) == 0 and list(out) == [0.25, 0.5, 0.75]
+    h = C.c_void_p()
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.urhgpu_ctx_create(0, C.byref(h)) == _lib.ERR_NO_DEVICE

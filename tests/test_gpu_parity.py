@@ -644,3 +644,32 @@ def test_pipelined_passes_do_not_disturb_each_other(oracle):
         assert all(np.array_equal(a, b) for a, b in zip(flat, res.flat())), k
         assert bits_equal(res.qad.cpu().numpy(), qad), k
     pp.ctx.set_pipelined(False)
+
+
+def test_error_codes_on_device(pipe, sf):
+    """argument / capacity / unsupported-parameter errors surface as the documented status codes and exceptions"""
+    import torch
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams
+    lib, h = _lib.load(), pipe.ctx.handle
+    iq = torch.from_numpy(synth_fsk(50_000, sps=20, seed=1, noise=0.05)).cuda()
+    # pulse table capacity too small: the device path clamps and reports through counts; the host API returns ERR_CAPACITY + size
+    qad = sf.afp_demod(iq.cpu().numpy(), 0.0, "FSK", 2)
+    rows = np.zeros((4, 2), np.int64)
+    n_rows = C.c_int64(0)
+    st = lib.urhgpu_grab_pulse_lens(h, qad.ctypes.data_as(C.c_void_p), len(qad), 0.0, 5, _lib.MOD_FSK, 20, 1, 0.1, 0.0,
+                                    rows.ctypes.data_as(C.c_void_p), 4, C.byref(n_rows))
+    assert st == _lib.ERR_CAPACITY and n_rows.value == len(sf.grab_pulse_lens(qad, 0.0, 5, "FSK", 20))
+    res = pipe.iq_to_bits(iq, DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 20), cap_rows=16)
+    with pytest.raises(_lib.UrhGpuError):
+        res.check_capacity()
+    with pytest.raises(_lib.UrhGpuError):                       # bits_per_symbol > 7
+        sf.grab_pulse_lens(qad, 0.0, 5, "FSK", 20, 8)
+    with pytest.raises(ValueError):                             # (N, 3) is not an IQ array
+        sf.afp_demod(np.zeros((10, 3), np.float32), 0.0, "FSK", 2)
+    with pytest.raises(OverflowError):
+        sf.grab_pulse_lens(qad, 0.0, 70000, "FSK", 20)
+    # misaligned device pointer
+    p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 20).to_c(np.float32)
+    out = torch.empty(100, dtype=torch.float32, device="cuda")
+    assert lib.urhgpu_afp_demod_dev(h, C.c_void_p(iq.data_ptr() + 8), 100, C.byref(p), C.c_void_p(out.data_ptr())) == _lib.ERR_ARG
