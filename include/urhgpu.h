@@ -167,8 +167,8 @@ typedef struct urhgpu_params {
 } urhgpu_params;
 
 /* Output descriptor of the fused path.  All pointers are DEVICE pointers owned by the caller; any
- * of qad / pos may be NULL (not materialised).  counts (device int64[4]) receives
- * {n_rows, n_msg, n_bits, n_pos}; the caller reads it back (32 bytes) when it needs the sizes.
+ * of qad / pos may be NULL (not materialised).  counts (device int64[5]) receives
+ * {n_rows, n_msg, n_bits, n_pos, n_rows_needed}; the caller reads it back (40 bytes) when it needs the sizes.
  * n_rows is clamped to cap_rows; a table that did not fit shows as n_rows == cap_rows. */
 typedef struct urhgpu_outputs {
     float *qad;            /* float32[n]  demodulated signal (Signal.qad) or NULL */
@@ -182,7 +182,7 @@ typedef struct urhgpu_outputs {
     int64_t *pos;          /* int64[cap_pos] or NULL */
     int64_t cap_pos;
     int64_t *pos_off;      /* int64[cap_msg+1] */
-    int64_t *counts;       /* int64[4] */
+    int64_t *counts;       /* int64[5]: {n_rows, n_msg, n_bits, n_pos, rows the table needed (> cap_rows: it was truncated)} */
 } urhgpu_outputs;
 
 /* afp_demod on device memory (ASK/FSK/OTHER: one streaming kernel; PSK: Costas loop). */

@@ -181,6 +181,7 @@ BitsParams bits_params(const urhgpu_params *p) {
     bp.samples_per_bit = (int64_t)((double)p->samples_per_symbol / (double)p->bits_per_symbol);   // int(sps / bps) :344
     bp.write_pos = p->write_bit_sample_pos ? 1 : 0;
     bp.d_row_base = nullptr; bp.d_ts_carry = nullptr; bp.d_absorbed = nullptr; bp.d_extra = nullptr; bp.is_last_rank = 1;
+    bp.d_rows_needed = nullptr;
     return bp;
 }
 
@@ -451,9 +452,12 @@ int urhgpu_grab_pulse_lens_dev(urhgpu_ctx *ctx, const float *d_qad, int64_t n, c
 }
 
 static int ppseq_to_bits_inner(urhgpu_ctx *ctx, const int64_t *d_rows, const int64_t *d_n_rows, int64_t cap,
-                               const urhgpu_params *p, const urhgpu_outputs *out, void *scratch) {
+                               const urhgpu_params *p, const urhgpu_outputs *out, void *scratch,
+                               const int64_t *d_rows_needed = nullptr) {
     BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts};
-    URH_TRY(launch_ppseq_to_bits(d_rows, d_n_rows, cap, bits_params(p), bo, scratch, ctx->d_tickets, ctx->stream));
+    BitsParams bp = bits_params(p);
+    bp.d_rows_needed = d_rows_needed;
+    URH_TRY(launch_ppseq_to_bits(d_rows, d_n_rows, cap, bp, bo, scratch, ctx->d_tickets, ctx->stream));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }
@@ -504,7 +508,7 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
         if (!scratch) return URHGPU_ERR_ARG;
         hipStream_t caller = ctx->stream;
         if (piped) ctx->stream = ctx->tail_stream;
-        st = ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch);
+        st = ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch, ctx->d_counts + 8);
         ctx->stream = caller;
     }
     if (piped) URH_TRY(end_pipelined_pass(ctx));
@@ -660,6 +664,7 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
     BitsParams bp = bits_params(&ss->p);
     bp.d_row_base = ss->d_row_base; bp.d_ts_carry = ss->d_small; bp.d_absorbed = ask ? ss->d_small + 1 : nullptr;
     bp.d_extra = (const int32_t *)(ss->d_small + 2); bp.is_last_rank = (ss->rank == ss->world - 1) ? 1 : 0;
+    bp.d_rows_needed = ctx->d_counts + 8;
     const urhgpu_outputs &o = ss->out;
     BitsOut bo{o.bits, o.cap_bits, o.msg_off, o.pauses, o.cap_msg, o.pos, o.cap_pos, o.pos_off, o.counts};
     URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, ctx->d_tickets, s));

@@ -107,6 +107,7 @@ struct BitsParams {
     const int64_t *d_absorbed;    // full length of the pause this GPU's only (absorbed) row belongs to, or -1
     const int32_t *d_extra;       // [0]: the group my first rows continue has data on earlier ranks, [1]: later ranks
     int is_last_rank;             // the capture ends on this GPU: the trailing group closes here
+    const int64_t *d_rows_needed; // un-clamped row count of the pulse table (-> counts[4]) or nullptr
 };
 constexpr int64_t kRowAbsorbed = -(int64_t(1) << 62);   // == URHGPU_ROW_ABSORBED
 struct BitsOut {

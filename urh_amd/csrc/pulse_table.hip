@@ -444,8 +444,10 @@ struct BitsCountsFinal {
     const int64_t *d_n_rows;
     int64_t *msg_off, *pos_off, *counts;
     int32_t *huge_count;
+    const int64_t *d_rows_needed;      // rows the pulse table needed before clamping to cap_rows (nullptr: unknown)
     __device__ void operator()(const VecK<3> &grand) const {
         *huge_count = 0;
+        counts[4] = d_rows_needed ? *d_rows_needed : *d_n_rows;
         const int64_t n_rows = *d_n_rows;
         VecK<3> g; g.zero();
         if (n_rows > 0) g = grand;
@@ -655,7 +657,7 @@ int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap
     const BitsScratch b = carve_bits(scratch, cap_rows);
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
-    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count};
+    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};
     hipLaunchKernelGGL((k_scan_reduce<3, GroupLoad>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s, b.d_n_groups, gl, b.part3, b.nbg,
                        tickets + 2);
     hipLaunchKernelGGL((k_scan_apply<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s,

@@ -81,13 +81,14 @@ class BitsResult:
                 self._ctx.join()          # pipelined mode: the current stream waits for the tail of the pass
             c = self.counts.cpu().numpy()
             self._host_counts = tuple(int(x) for x in c[:4])
+            self._rows_needed = int(c[4])
         return self._host_counts
 
     def check_capacity(self):
         n_rows, n_msg, n_bits, n_pos = self.host_counts()
-        if n_rows > self.rows_buf.shape[0] or n_msg > self.pauses_buf.shape[0] or n_bits > self.bits_buf.shape[0] \
+        if self._rows_needed > self.rows_buf.shape[0] or n_msg > self.pauses_buf.shape[0] or n_bits > self.bits_buf.shape[0] \
                 or (self.pos_buf is not None and n_pos > self.pos_buf.shape[0]):
-            raise _lib.UrhGpuError(_lib.ERR_CAPACITY, f"output capacity too small: rows={n_rows} msgs={n_msg} "
+            raise _lib.UrhGpuError(_lib.ERR_CAPACITY, f"output capacity too small: rows={self._rows_needed} msgs={n_msg} "
                                                       f"bits={n_bits} pos={n_pos}")
 
     def ppseq(self) -> np.ndarray:
@@ -187,7 +188,7 @@ class DevicePipeline:
         pauses = self._buf(sfx + "pauses", (cap_msg,), torch.int64)
         pos_off = self._buf(sfx + "pos_off", (cap_msg + 1,), torch.int64)
         pos = self._buf(sfx + "pos", (cap_pos,), torch.int64) if p.write_bit_sample_pos else None
-        counts = self._buf(sfx + "counts", (4,), torch.int64)
+        counts = self._buf(sfx + "counts", (5,), torch.int64)
         o = _lib.Outputs()
         o.qad = qad.data_ptr() if qad is not None else None
         o.rows = rows.data_ptr(); o.cap_rows = cap_rows
