@@ -45,29 +45,16 @@ struct FirArgs {
     int64_t tile0;           // first tile of this launch
 };
 
-template <bool HEAD>
-__global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    float2 *s_taps = (float2 *)s_raw;                       // [m]
-    float2 *s_x = s_taps + ((a.m + 1) & ~1);                // [hist + kFirTile], s_x[u] = x[base - hist + u]
-    const int t = threadIdx.x;
-    const int64_t base = (a.tile0 + blockIdx.x) * (int64_t)kFirTile;
-    for (int j = t; j < a.m; j += kFirBlock) s_taps[j] = a.taps[j];
-    const int total = a.hist + kFirTile;
-    for (int u = t; u < total; u += kFirBlock) {
-        const int64_t i = base - a.hist + u;
-        float2 v = make_float2(0.f, 0.f);
-        if (i >= 0) { if (i < a.n) v = a.x[i]; }
-        else if (a.halo != nullptr && i + (a.m - 1) >= 0) v = a.halo[i + (a.m - 1)];
-        s_x[u] = v;
-    }
-    __syncthreads();
+// The products of a tile can only come out as (NaN, NaN) -- the case the reference's complex multiply repairs with
+// __mulsc3 -- when an operand is non-finite or two products overflow.  While staging a tile the workgroup records the
+// largest |component| of its inputs and taps; if both stay below 2^60 every product and partial sum is finite (m < 2^20
+// terms of at most 2^121) and the per-product NaN test is skipped (wave-uniform branch): a third of the instructions.
+constexpr uint32_t kFirSafeBits = 0x5d800000u;   // 2^60
+
+template <bool HEAD, bool CHECKED>
+__device__ __forceinline__ void fir_accumulate(const FirArgs &a, const float2 *s_taps, const float2 *s_x, int t, int64_t k0,
+                                               float2 (&acc)[kFirR]) {
     constexpr int R = kFirR;
-    const int64_t k0 = base + (int64_t)R * t;               // my first output
-    if (k0 >= a.n) return;
-    float2 acc[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
     const int jb_top = ((a.m - 1) / R) * R;
     // W[u] = x[k0 - jb - (R-1) + u], u in [0, 2R-1); in LDS: index (R*t + hist) - jb - (R-1) + u
     float2 W[2 * R - 1];
@@ -87,13 +74,54 @@ __global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (HEAD && (k0 + r - j < 0)) continue;  // term with i < 0 does not exist
-                    const float2 p = cmul(W[r + (R - 1 - tj)], h);
+                    const float2 x = W[r + (R - 1 - tj)];
+                    float2 p;
+                    if (CHECKED) p = cmul(x, h);
+                    else { p.x = x.x * h.x - x.y * h.y; p.y = x.x * h.y + x.y * h.x; }
                     acc[r].x += p.x;
                     acc[r].y += p.y;
                 }
             }
         }
     }
+}
+
+template <bool HEAD>
+__global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ uint32_t s_maxbits;
+    float2 *s_taps = (float2 *)s_raw;                       // [m]
+    float2 *s_x = s_taps + ((a.m + 1) & ~1);                // [hist + kFirTile], s_x[u] = x[base - hist + u]
+    const int t = threadIdx.x;
+    const int64_t base = (a.tile0 + blockIdx.x) * (int64_t)kFirTile;
+    if (t == 0) s_maxbits = 0;
+    __syncthreads();
+    uint32_t mb = 0;                                        // largest |component| seen, as float bits (NaN / inf compare high)
+    for (int j = t; j < a.m; j += kFirBlock) {
+        const float2 h = a.taps[j];
+        s_taps[j] = h;
+        mb = max(mb, max(__float_as_uint(h.x) & 0x7fffffffu, __float_as_uint(h.y) & 0x7fffffffu));
+    }
+    const int total = a.hist + kFirTile;
+    for (int u = t; u < total; u += kFirBlock) {
+        const int64_t i = base - a.hist + u;
+        float2 v = make_float2(0.f, 0.f);
+        if (i >= 0) { if (i < a.n) v = a.x[i]; }
+        else if (a.halo != nullptr && i + (a.m - 1) >= 0) v = a.halo[i + (a.m - 1)];
+        s_x[u] = v;
+        mb = max(mb, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu));
+    }
+    atomicMax(&s_maxbits, mb);
+    __syncthreads();
+    const bool safe = s_maxbits < kFirSafeBits;
+    constexpr int R = kFirR;
+    const int64_t k0 = base + (int64_t)R * t;               // my first output
+    if (k0 >= a.n) return;
+    float2 acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
+    if (safe) fir_accumulate<HEAD, false>(a, s_taps, s_x, t, k0, acc);
+    else fir_accumulate<HEAD, true>(a, s_taps, s_x, t, k0, acc);
     if (k0 + R <= a.n) {
         *(float4 *)(a.out + k0) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
         *(float4 *)(a.out + k0 + 2) = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);

@@ -231,12 +231,17 @@ def get_plateau_lengths_dev(pipe, rect, center, percentage=25) -> np.ndarray:
     n = int(x.shape[0])
     if n == 0 or center is None:
         return np.array([], dtype=np.uint64)
-    cap = n
-    idx = torch.empty(max(cap, 1), dtype=torch.int64, device=x.device)
-    cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
-    _lib.check(_lib.load().urhgpu_edges_le_dev(pipe.ctx.handle, C.c_void_p(x.data_ptr()), n, float(center), C.c_void_p(idx.data_ptr()),
-                                               cap, C.c_void_p(cnt.data_ptr())))
-    b = idx[:int(cnt.item())].cpu().numpy()                       # run boundaries B_0 < B_1 < ...
+    cap = min(n, max(1 << 16, n // 16))                           # plenty for real signals; retried with the exact count if not
+    while True:
+        idx = torch.empty(max(cap, 1), dtype=torch.int64, device=x.device)
+        cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
+        _lib.check(_lib.load().urhgpu_edges_le_dev(pipe.ctx.handle, C.c_void_p(x.data_ptr()), n, float(center),
+                                                   C.c_void_p(idx.data_ptr()), cap, C.c_void_p(cnt.data_ptr())))
+        found = int(cnt.item())
+        if found <= cap:
+            break
+        cap = found
+    b = idx[:found].cpu().numpy()                                 # run boundaries B_0 < B_1 < ...
     limit = (percentage * n) // 100                               # C integer division (cdivision)
     # plateau k = [B_{k-1}, B_k) is appended at i = B_k if the sum appended so far (= B_{k-1}, or 0) is < limit
     starts = np.concatenate([[0], b[:-1]]) if len(b) else np.zeros(0, np.int64)
