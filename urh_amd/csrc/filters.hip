@@ -31,7 +31,7 @@ namespace urh {
 // HEAD: this workgroup contains outputs k < M-1 of a capture without left halo (terms with i < 0 do not exist).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kFirBlock = 256;
-constexpr int kFirR = 4;
+constexpr int kFirR = 8;
 constexpr int kFirTile = kFirBlock * kFirR;
 
 struct FirArgs {
@@ -70,7 +70,7 @@ __device__ __forceinline__ void fir_accumulate(const FirArgs &a, const float2 *s
         for (int tj = R - 1; tj >= 0; --tj) {
             const int j = jb + tj;
             if (j < a.m) {                                   // wave-uniform
-                const float2 h = s_taps[j];
+                const float2 h = a.taps[j];                  // wave-uniform address: a scalar load, no LDS traffic
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     if (HEAD && (k0 + r - j < 0)) continue;  // term with i < 0 does not exist
@@ -123,8 +123,8 @@ __global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
     if (safe) fir_accumulate<HEAD, false>(a, s_taps, s_x, t, k0, acc);
     else fir_accumulate<HEAD, true>(a, s_taps, s_x, t, k0, acc);
     if (k0 + R <= a.n) {
-        *(float4 *)(a.out + k0) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
-        *(float4 *)(a.out + k0 + 2) = make_float4(acc[2].x, acc[2].y, acc[3].x, acc[3].y);
+#pragma unroll
+        for (int r = 0; r < R; r += 2) *(float4 *)(a.out + k0 + r) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) if (k0 + r < a.n) a.out[k0 + r] = acc[r];
