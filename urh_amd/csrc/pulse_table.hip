@@ -325,7 +325,8 @@ struct BitsLoad {
     // i counts rows AFTER the skipped leading pause row? no: all rows; row 0 is neutralised when it is a pause
     __device__ VecK<4> operator()(int64_t i) const {
         VecK<4> v; v.zero();
-        const int64_t type = rows[2 * i], len = rows[2 * i + 1];
+        const longlong2 row = *(const longlong2 *)(rows + 2 * i);          // one 16-byte load
+        const int64_t type = row.x, len = row.y;
         v.v[2] = len;
         if (type == kRowAbsorbed) return v;              // merged into the previous GPU's last row: length only
         const bool global_row0 = (i == 0) && (bp.d_row_base == nullptr || *bp.d_row_base == 0);

@@ -9,7 +9,10 @@
 namespace urh {
 
 constexpr int kScanBlock = 256;
-constexpr int kScanItems = 8;
+#ifndef URH_SCAN_ITEMS
+#define URH_SCAN_ITEMS 8
+#endif
+constexpr int kScanItems = URH_SCAN_ITEMS;
 constexpr int kScanTile = kScanBlock * kScanItems;   // 2048 elements per workgroup
 
 template <int K> struct VecK {
