@@ -245,7 +245,7 @@ int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *ctx, const void *d_iq, int dtyp
 /* auto_interpretation.segment_messages_from_magnitudes (src/urh/cythonext/auto_interpretation.pyx:55-111) as a pulse table:
  * state 1 = |sample| > noise_threshold, 0 = below, switched after 10 consecutive samples (tolerance 9), row layout and
  * length conventions of urhgpu_grab_pulse_lens_dev; the state machine starts in the state of sample 0.  The host turns
- * the rows into (start, end) tuples.  float32 IQ only (URHGPU_ERR_UNSUPPORTED for the integer dtypes). */
+ * the rows into (start, end) tuples.  Integer captures: magnitudes as util.get_magnitudes computes them (C int sum, double sqrt). */
 int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold,
                             int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows);
 /* rect[rect > thr] (AutoInterpretation.py:227), order preserved; *d_count (device) = number kept. */

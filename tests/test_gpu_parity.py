@@ -375,6 +375,21 @@ def test_segment_messages_equals_oracle(pipe, oracle):
             assert got == [(int(a), int(b)) for a, b in want], (n, nt, got[:4], want[:4])
 
 
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16])
+def test_segment_messages_integer_captures(pipe, oracle, dtype):
+    import torch
+    from urh_amd import estimators
+    for n, seed in ((12, 1), (5_000, 2), (120_000, 3)):
+        iq = synth_fsk(n, sps=50, seed=seed, noise=0.02, pause_every=max(n // 4, 1), pause_len=n // 9, dtype=dtype)
+        if dtype == np.uint16:
+            iq[n // 2:n // 2 + 30] = 65535                         # C int overflow -> NaN magnitudes -> "not above"
+        mags = oracle.get_magnitudes(iq)
+        for nt in (float(np.nanmedian(mags)), 0.0, 1e9):
+            want = oracle.segment_messages_from_magnitudes(mags, nt)
+            got = estimators.segment_messages_dev(pipe, torch.from_numpy(iq).cuda(), nt)
+            assert got == [(int(a), int(b)) for a, b in want], (np.dtype(dtype).name, n, nt, got[:3], want[:3])
+
+
 def test_detect_center_equals_numpy(pipe, oracle):
     """the GPU passes reproduce numpy's float32 pairwise np.var and np.histogram exactly -> identical center"""
     import torch

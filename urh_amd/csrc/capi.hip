@@ -682,7 +682,7 @@ __global__ void k_set_i64(int64_t *p, int64_t v) { *p = v; }
 int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold,
                             int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows) {
     if (!ctx || n < 0 || !d_n_rows || cap_rows < 0) return URHGPU_ERR_ARG;
-    if (dtype != URHGPU_DT_F32) return dtype_bytes(dtype) ? URHGPU_ERR_UNSUPPORTED : URHGPU_ERR_DTYPE;
+    if (dtype_bytes(dtype) == 0) return URHGPU_ERR_DTYPE;
     URH_HIP(hipSetDevice(ctx->device));
     URH_TRY(join_tail(ctx));
     if (n == 0) { URH_HIP(hipMemsetAsync(d_n_rows, 0, 8, ctx->stream)); return URHGPU_OK; }

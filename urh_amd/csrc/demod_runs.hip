@@ -127,6 +127,17 @@ __device__ __forceinline__ void conj_mul(float a, float b, float c, float d, flo
     im = A * D + B * C;
 }
 
+// Message segmentation (seg_mode) on integer captures: util.get_magnitudes computes I*I + Q*Q in C `int` (wrapping) and
+// takes the DOUBLE square root (util.pyx:128-136), and segment_messages_from_magnitudes compares that double with the
+// float threshold (auto_interpretation.pyx:82).  The classification only needs "above" / "not above": return a value on
+// the right side of every threshold.  (c, d) hold the integer sample exactly (|value| < 2^16).
+__device__ __forceinline__ float seg_value_int(float c, float d, float threshold) {
+    const int re = (int)c, im = (int)d;
+    const int s = (int)((unsigned)(re * re) + (unsigned)(im * im));
+    const double m = __builtin_sqrt((double)s);
+    return (m > (double)threshold) ? 3.0e38f : -3.0e38f;
+}
+
 // atan2f for the common case (both operands finite, non-zero, exponents within 2^60 of each
 // other); everything else goes through the literal port in fdlibm_atan2f.h.
 __device__ __forceinline__ float atan2f_dev(float y, float x) {
@@ -229,8 +240,9 @@ __device__ __forceinline__ uint32_t classify(float q, const RunArgs &p, bool che
 }
 
 // Demodulate one sample.  (pc,pd) = previous IQ sample, (c,d) = this one.
-template <int MOD>
+template <int MOD, int DT = URHGPU_DT_F32>
 __device__ __forceinline__ float demod_one(float pc, float pd, float c, float d, const RunArgs &p) {
+    if (MOD == URHGPU_MOD_ASK && DT != URHGPU_DT_F32 && p.seg_mode) return seg_value_int(c, d, p.thr[0]);
     const float mag = c * c + d * d;
     if (mag <= p.noise_sqrd) return p.noise_val;
     if (MOD == URHGPU_MOD_ASK) return __builtin_sqrtf(mag) / p.max_magnitude;   // (double)sqrtf/(double) == fp32 div
@@ -327,7 +339,7 @@ __device__ __forceinline__ int demod_pair(const RowIn &r, float prev_c, float pr
 // samples unconditionally and returns true when the lane needs anything else (a noise-gated sample, an FSK
 // quotient outside the fast range).  The caller ballots the flags of a whole batch of rows once and sends only
 // the flagged rows through demod_pair: the hot loop has no per-row branches and the rows' dependent chains interleave.
-template <int MOD>
+template <int MOD, int DT = URHGPU_DT_F32>
 __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float prev_d, const RunArgs &p, float &q0, float &q1) {
     const float c0 = r.c0, d0 = r.d0, c1 = r.c1, d1 = r.d1;
     const float mag0 = c0 * c0 + d0 * d0, mag1 = c1 * c1 + d1 * d1;
@@ -353,6 +365,11 @@ __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float pr
           for (int e = 0; e < 24; ++e) asm volatile("s_nop 0");
 #endif
         return n0 | n1 | !ok0 | !ok1;
+    }
+    if (DT != URHGPU_DT_F32 && p.seg_mode) {
+        q0 = seg_value_int(c0, d0, p.thr[0]);
+        q1 = seg_value_int(c1, d1, p.thr[0]);
+        return false;
     }
     q0 = __builtin_sqrtf(mag0) / p.max_magnitude;
     q1 = __builtin_sqrtf(mag1) / p.max_magnitude;
@@ -454,7 +471,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
                 have = true;
             }
             if (have) {
-                const float q = is_global0 ? p.noise_val : demod_one<MOD>(pc, pd, prev_c, prev_d, p);
+                const float q = is_global0 ? p.noise_val : demod_one<MOD, DT>(pc, pd, prev_c, prev_d, p);
                 st = classify<ORDER2>(q, p);
             }
         }
@@ -497,7 +514,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
 #pragma unroll
                     for (int j = 0; j < kBatch; ++j) {
                         pcs[j] = prev_c; pds[j] = prev_d;
-                        flag[j] = spec_pair<MOD>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
+                        flag[j] = spec_pair<MOD, DT>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
                         if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
                     }
                     uint32_t bad = 0;
@@ -730,7 +747,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
             if (SRC == SRC_IQ && p.seg_mode) {                     // segmentation: the state of sample 0 itself
                 float c = 0.f, d = 0.f;
                 Iq<DT>::load1(p.in, 0, c, d);
-                init = classify<ORDER2>(demod_one<MOD>(0.f, 0.f, c, d, p), p);
+                init = classify<ORDER2>(demod_one<MOD, DT>(0.f, 0.f, c, d, p), p);
             }
         }
         ci.init_state = (uint16_t)init;

@@ -85,9 +85,15 @@ def segment_messages_dev(pipe, iq, noise_threshold: float):
                                                    float(noise_threshold), C.c_void_p(rows.data_ptr()), cap,
                                                    C.c_void_p(n_rows.data_ptr())))
     r = rows[:int(n_rows.item())].cpu().numpy()
-    tail = iq[max(0, n - 10):].cpu().numpy().astype(np.float32)
-    tail_mag = np.sqrt(tail[:, 0] * tail[:, 0] + tail[:, 1] * tail[:, 1])              # fp32, as get_magnitudes
-    return segments_from_rows(r, n, tail_mag > np.float32(noise_threshold))
+    tail = iq[max(0, n - 10):].cpu().numpy()
+    if tail.dtype == np.float32:
+        tail_mag = np.sqrt(tail[:, 0] * tail[:, 0] + tail[:, 1] * tail[:, 1]).astype(np.float64)   # fp32 sqrtf, as get_magnitudes
+    else:                                                                              # C int arithmetic (wrapping), double sqrt
+        a = tail.astype(np.int64)
+        s32 = ((a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        with np.errstate(invalid="ignore"):
+            tail_mag = np.sqrt(s32.astype(np.float64))
+    return segments_from_rows(r, n, tail_mag > float(np.float32(noise_threshold)))
 
 
 def segments_from_rows(rows: np.ndarray, n: int, tail_above: np.ndarray):
