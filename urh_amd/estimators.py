@@ -74,7 +74,7 @@ def segment_messages_dev(pipe, iq, noise_threshold: float):
     if iq.dtype == torch.complex64:
         iq = torch.view_as_real(iq)
     n = int(iq.shape[0])
-    if n == 0:
+    if n == 0 or math.isnan(float(noise_threshold)):        # nothing compares greater than NaN: never above the noise
         return []
     pipe.ctx.set_stream(torch.cuda.current_stream(iq.device).cuda_stream)
     cap = n // 10 + 2
