@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Run the REAL reference's AutoInterpretation.estimate (this container only) on the IQ of every float32 golden capture
-and store what it returns in tests/golden/estimates.json; the GPU test compares urh_amd.estimators.estimate_dev with it.
+(all dtypes) and store what it returns in tests/golden/estimates.json; the GPU test compares urh_amd.estimators.estimate_dev with it.
 
     python tests/golden/make_estimate_golden.py
 """
@@ -24,8 +24,6 @@ for f in sorted(os.listdir(HERE)):
         continue
     z = np.load(os.path.join(HERE, f))
     iq = z["iq"]
-    if iq.dtype != np.float32:
-        continue
     mod = str(z["modulation_type"])
     for m in ([mod, "OOK"] if mod == "ASK" else [mod]):
         for noise in (None, float(z["noise_threshold"])):
