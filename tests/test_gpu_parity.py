@@ -689,3 +689,21 @@ def test_error_codes_on_device(pipe, sf):
     p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 20).to_c(np.float32)
     out = torch.empty(100, dtype=torch.float32, device="cuda")
     assert lib.urhgpu_afp_demod_dev(h, C.c_void_p(iq.data_ptr() + 8), 100, C.byref(p), C.c_void_p(out.data_ptr())) == _lib.ERR_ARG
+
+
+def test_capacity_regrowth_on_noise_capture(pipe, oracle):
+    """a noise-only capture yields ~n/10 pulse-table rows, far beyond the default capacity of 4 rows per symbol:
+    iq_to_bits_checked notices and repeats the pass with enough room"""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    rng = np.random.default_rng(8)
+    n = 400_000
+    iq = (0.3 * rng.standard_normal((n, 2))).astype(np.float32)
+    p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 1, 1000, 0.1, 8, True)
+    qad = oracle.afp_demod(iq, 0.0, "FSK", 2)
+    pp = oracle.grab_pulse_lens(qad, 0.0, 1, "FSK", 1000, 1, 1.0)
+    assert len(pp) > 4 * (n // 1000) + 4096
+    res = pipe.iq_to_bits_checked(torch.from_numpy(iq).cuda(), p)
+    assert np.array_equal(res.ppseq(), pp)
+    fb = oracle.ppseq_to_bits_flat(pp, 1000, 1, True, 8)
+    assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))

@@ -202,6 +202,21 @@ class DevicePipeline:
         _lib.check(_lib.load().urhgpu_iq_to_bits_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, C.byref(cp), C.byref(o)))
         return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, self.ctx)
 
+    def iq_to_bits_checked(self, iq, p: DemodParams, want_qad=True) -> BitsResult:
+        """iq_to_bits with the output capacities verified (one 40-byte read-back) and, if the default capacities were
+        too small -- a capture that is mostly noise produces far more pulse-table rows than 4 per symbol --, one more
+        pass with what the first one reported."""
+        res = self.iq_to_bits(iq, p, want_qad)
+        n_rows, n_msg, n_bits, n_pos = res.host_counts()
+        need = res._rows_needed
+        if need > res.rows_buf.shape[0] or n_msg > res.pauses_buf.shape[0] or n_bits > res.bits_buf.shape[0] \
+                or (res.pos_buf is not None and n_pos > res.pos_buf.shape[0]):
+            n = iq.shape[0]
+            worst = n // (p.tolerance + 1) + 2
+            res = self.iq_to_bits(iq, p, want_qad, cap_rows=min(worst, max(2 * need, 4096)))
+            res.check_capacity()
+        return res
+
     def afp_demod(self, iq, p: DemodParams):
         torch = self.torch
         if iq.dtype == torch.complex64:

@@ -56,7 +56,7 @@ def get_protocol_from_signal_dev(pipe, iq, p, message_length_divisor=1, sample_r
     torch = pipe.torch
     if iq.dtype == torch.complex64:
         iq = torch.view_as_real(iq)
-    res = pipe.iq_to_bits(iq, p, want_qad=True)
+    res = pipe.iq_to_bits_checked(iq, p, want_qad=True)
     bit_data, pauses, bit_sample_pos = res.messages()
     sps = int(p.samples_per_symbol)
     if message_length_divisor > 1 and p.modulation_type == "ASK":
