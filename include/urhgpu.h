@@ -229,6 +229,10 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
 int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
                           int rank, int world, const void *d_left_halo, const urhgpu_params *p,
                           const urhgpu_outputs *out, void *d_summary);
+/* Optional: start the hot kernel BEFORE the halo has arrived -- every chunk but the first, which alone reads it -- so that
+ * the halo all-gather overlaps the kernel; urhgpu_shard_runs_dev (same arguments + the halo) then only adds the first chunk. */
+int urhgpu_shard_prelaunch_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
+                               int rank, int world, const urhgpu_params *p, const urhgpu_outputs *out);
 int urhgpu_shard_rows_dev(urhgpu_ctx *ctx, const void *d_summaries, int64_t *d_merge);
 int urhgpu_shard_bits_prepare_dev(urhgpu_ctx *ctx, const int64_t *d_merge_all, int64_t *d_flags);
 int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all);

@@ -80,6 +80,7 @@ PROTOTYPES = {
     "urhgpu_ppseq_to_bits_dev": (_i, [_vp, _vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
     "urhgpu_iq_to_bits_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
     "urhgpu_shard_runs_dev": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, _vp, C.POINTER(Params), C.POINTER(Outputs), _vp]),
+    "urhgpu_shard_prelaunch_dev": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, C.POINTER(Params), C.POINTER(Outputs)]),
     "urhgpu_shard_rows_dev": (_i, [_vp, _vp, _vp]),
     "urhgpu_shard_bits_prepare_dev": (_i, [_vp, _vp, _vp]),
     "urhgpu_shard_bits_finish_dev": (_i, [_vp, _vp]),

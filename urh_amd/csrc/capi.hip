@@ -190,6 +190,7 @@ BitsParams bits_params(const urhgpu_params *p) {
 struct ShardSession {
     int phase = 0;                 // 1: runs done, 2: rows done, 3: bits prepared
     bool piped = false;            // pipelined mode: phases after the hot kernel run on ctx->tail_stream
+    RunArgs run;                   // kernel arguments of the hot launch (kept for the deferred first chunk)
     int rank = 0, world = 1;
     int64_t n_local = 0, pos_base = 0, n_total = 0;
     urhgpu_params p;
@@ -516,22 +517,22 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
 }
 
 // ---- sharded captures (one rank's phases; the all-gathers in between belong to the caller) --------------
-int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
-                          int rank, int world, const void *d_left_halo, const urhgpu_params *p,
-                          const urhgpu_outputs *out, void *d_summary) {
-    if (!ctx || !p || !out || !d_iq || !d_summary || !out->rows || !out->counts) return URHGPU_ERR_ARG;
+// validation + scratch + kernel arguments of a shard pass; launches the chunks selected by `part` on the hot stream
+static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total, int rank, int world,
+                        const void *d_left_halo, const urhgpu_params *p, const urhgpu_outputs *out, int part) {
+    if (!ctx || !p || !out || !d_iq || !out->rows || !out->counts) return URHGPU_ERR_ARG;
     if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world || n_local < 2 || pos_base < 0 || pos_base + n_local > n_total)
         return URHGPU_ERR_ARG;
-    if ((rank == 0) != (d_left_halo == nullptr) || (rank == 0 && pos_base != 0)) return URHGPU_ERR_ARG;
+    if (rank == 0 && pos_base != 0) return URHGPU_ERR_ARG;
     if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
     if (p->mod == URHGPU_MOD_PSK) return URHGPU_ERR_UNSUPPORTED;      // the Costas loop does not shard
     if (((uintptr_t)d_iq & 15) || (out->qad && ((uintptr_t)out->qad & 7))) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
     ShardSession *ss = session(ctx);
     if (!ss) return URHGPU_ERR_ARG;
-    hipStream_t s = ctx->stream;
     ss->piped = ctx->pipelined;
     if (ss->piped) URH_TRY(begin_pipelined_pass(ctx)); else URH_TRY(join_tail(ctx));
+    hipStream_t s = ctx->stream;
     ss->phase = 0; ss->rank = rank; ss->world = world; ss->n_local = n_local; ss->pos_base = pos_base; ss->n_total = n_total;
     ss->p = *p; ss->out = *out;
     const Plan pl = make_plan(ctx, n_local, p->tolerance);
@@ -552,11 +553,10 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
         ss->merge_scratch = ctx->arena.take(merge_scratch_bytes(out->cap_rows));
         ss->d_n_stage = (int64_t *)ctx->arena.take(64);
     }
-    if (!ss->table || !ss->slab || !ss->rs_mem || !ss->aux || !ss->d_small || !ss->bits_scratch || !ss->rows_stage ||
+    if (!ss->table || !ss->slab || !ss->rs_mem || !ss->d_small || !ss->bits_scratch || !ss->rows_stage ||
         !ss->d_n_stage || (ask && !ss->merge_scratch))
         return URHGPU_ERR_ARG;
-    ChunkInfo *local = ss->table + rank;       // this rank's chunks sit at table[rank .. rank + n_chunks)
-    RunArgs a;
+    RunArgs &a = ss->run;
     memset(&a, 0, sizeof(a));
     URH_TRY(fill_thresholds(a, p));
     a.in = d_iq; a.qad = out->qad; a.left_halo = d_left_halo; a.n = n_local; a.pos_base = pos_base;
@@ -565,21 +565,59 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
-    a.chunks = local; a.slab = ss->slab;
+    a.chunks = ss->table + rank;               // this rank's chunks sit at table[rank .. rank + n_chunks)
+    a.slab = ss->slab;
+    a.launch_part = part;
+    if (part == 1 && rank > 0 && !a.left_halo) a.left_halo = d_iq;    // any non-null value: only chunk 0 reads the halo
     const bool prof = ctx->prof_on && (size_t)(2 * ctx->prof_used + 1) < ctx->prof_events.size();
     if (prof) URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used], s));
     URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s));
     if (prof) { URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], s)); ctx->prof_used += 1; }
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_shard_prelaunch_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
+                               int rank, int world, const urhgpu_params *p, const urhgpu_outputs *out) {
+    URH_TRY(shard_launch(ctx, d_iq, n_local, pos_base, n_total, rank, world, nullptr, p, out, rank > 0 ? 1 : 0));
+    ((ShardSession *)ctx->shard)->phase = -1;
+    return URHGPU_OK;
+}
+
+int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
+                          int rank, int world, const void *d_left_halo, const urhgpu_params *p,
+                          const urhgpu_outputs *out, void *d_summary) {
+    if (!ctx || !d_summary) return URHGPU_ERR_ARG;
+    if ((rank == 0) != (d_left_halo == nullptr)) return URHGPU_ERR_ARG;
+    ShardSession *ss = (ShardSession *)ctx->shard;
+    hipStream_t s;
+    if (ss && ss->phase == -1) {
+        // prelaunched: only the first chunk (it needs the halo) is still missing
+        if (ss->rank != rank || ss->world != world || ss->n_local != n_local || ss->run.in != d_iq) return URHGPU_ERR_ARG;
+        URH_HIP(hipSetDevice(ctx->device));
+        s = ctx->stream;
+        if (rank > 0) {
+            RunArgs a = ss->run;
+            a.left_halo = d_left_halo; a.launch_part = 2;
+            URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s));
+        }
+    } else {
+        URH_TRY(shard_launch(ctx, d_iq, n_local, pos_base, n_total, rank, world, d_left_halo, p, out, 0));
+        ss = (ShardSession *)ctx->shard;
+        s = ctx->stream;
+    }
     if (ss->piped) {                                // everything after the hot kernel goes to the tail stream
         URH_HIP(hipEventRecord(ctx->ev_hot, s));
         URH_HIP(hipStreamWaitEvent(ctx->tail_stream, ctx->ev_hot, 0));
         s = ctx->tail_stream;
     }
     // local resolve pass: the shard on its own -> its summary
+    const Plan &pl = ss->pl;
+    const int64_t n_table = pl.n_chunks + world - 1;
     ResolveArgs r;
     memset(&r, 0, sizeof(r));
     r.sc = resolve_scratch_carve(ss->rs_mem, n_table);
-    r.chunks = local; r.n_chunks = pl.n_chunks; r.n_total = n_local; r.tol = p->tolerance;
+    r.chunks = ss->table + rank; r.n_chunks = pl.n_chunks; r.n_total = n_local; r.tol = ss->p.tolerance;
     r.rows = nullptr; r.cap_rows = 0; r.d_n_acc = ctx->d_counts + 9; r.d_n_rows = ctx->d_counts + 10;
     r.d_n_rows_needed = ctx->d_counts + 8; r.write_last_row = 0;
     r.local_pass = 1; r.aux = ss->aux; r.summary_out = (ChunkInfo *)d_summary; r.chunk_first = 0; r.n_local = pl.n_chunks;

@@ -26,6 +26,8 @@
 // to LDS in sample order; in the run phase lane t owns 32 consecutive samples.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.hpp"
 #include "fdlibm_atan2f.h"
 #include "launchers.hpp"
@@ -826,13 +828,18 @@ __global__ void k_test_atan2f(const float *y, const float *x, int64_t n, float *
 // one launch over the whole tiles, one one-workgroup launch for the partial tile at the end.
 template <int SRC, int DT, int MOD, bool O2, bool WQ>
 static void launch_runs_4(RunArgs a, hipStream_t s) {
+    // a.launch_part: 0 = every chunk; 1 = every chunk but the first (it alone needs the left halo of a sharded capture,
+    // which may still be in flight); 2 = the first chunk only
+    const int part = a.launch_part;
     const int64_t n_full = (a.n / kTile) * kTile;
     const int64_t n_main = (n_full + a.chunk_len - 1) / a.chunk_len;
-    if (n_main > 0) {
-        a.range_begin = 0; a.range_end = n_full; a.chunk_base = 0;
-        hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)n_main), dim3(kBlock), 0, s, a);
+    const int64_t c_lo = (part == 1) ? 1 : 0, c_hi = (part == 2) ? std::min<int64_t>(n_main, 1) : n_main;
+    if (c_hi > c_lo) {
+        a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
+        hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock), 0, s, a);
     }
-    if (n_full < a.n) {
+    const bool tail_is_first = (n_main == 0);                 // a capture shorter than one tile: its only chunk
+    if (n_full < a.n && ((part == 0) || (part == 1 && !tail_is_first) || (part == 2 && tail_is_first))) {
         a.range_begin = n_full; a.range_end = a.n; a.chunk_base = n_main;
         hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, false>), dim3(1), dim3(kBlock), 0, s, a);
     }

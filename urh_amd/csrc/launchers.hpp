@@ -27,6 +27,7 @@ struct RunArgs {
     float max_magnitude;     // ASK normalisation
     int order;               // modulation order = 2^bits_per_symbol
     int tol;                 // tolerance
+    int launch_part;         // 0 all chunks, 1 all but the first, 2 the first only (launchers; see launch_runs_4)
     int seg_mode;            // 1: message segmentation on magnitudes (auto_interpretation.pyx:55-111): sample 0 is an
                              // ordinary sample (no result[0] = NOISE) and the state machine starts in ITS state
     float thr[kMaxOrder - 1];

@@ -85,7 +85,7 @@ class GpuShardEngine(DevicePipeline):
         self._fir_keep = (x, h, left)
         return out if iq_local.dtype != torch.complex64 else torch.view_as_complex(out)
 
-    def runs(self, iq, left, pos_base, n_total, rank, world, p, want_qad):
+    def _setup(self, iq, p, want_qad):
         torch = self.torch
         if iq.dtype == torch.complex64:
             iq = torch.view_as_real(iq)
@@ -114,9 +114,27 @@ class GpuShardEngine(DevicePipeline):
         o.counts = counts.data_ptr()
         self._res = ShardResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, self.ctx)
         self._ask = p.modulation_type == "ASK"
-        self._keep = (iq, left)                                # keep the inputs alive until the pass is over
-        summary = self._buf("summary", (9,), torch.int64)      # URHGPU_SHARD_SUMMARY_BYTES = 72
+        self._keep = (iq,)                                     # keep the inputs alive until the pass is over
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        return iq, n, cp, o
+
+    def runs_begin(self, iq, pos_base, n_total, rank, world, p, want_qad):
+        """start the hot kernel on every chunk but the first while the halo all-gather is still in flight"""
+        iq, n, cp, o = self._setup(iq, p, want_qad)
+        self._pre = (iq, n, cp, o)
+        _lib.check(_lib.load().urhgpu_shard_prelaunch_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, int(pos_base), int(n_total),
+                                                          int(rank), int(world), C.byref(cp), C.byref(o)))
+
+    def runs(self, iq, left, pos_base, n_total, rank, world, p, want_qad):
+        torch = self.torch
+        pre = getattr(self, "_pre", None)
+        if pre is not None:
+            iq, n, cp, o = pre
+            self._pre = None
+        else:
+            iq, n, cp, o = self._setup(iq, p, want_qad)
+        self._keep += (left,)
+        summary = self._buf("summary", (9,), torch.int64)      # URHGPU_SHARD_SUMMARY_BYTES = 72
         lh = C.c_void_p(left.data_ptr()) if left is not None else None
         _lib.check(_lib.load().urhgpu_shard_runs_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, int(pos_base), int(n_total),
                                                      int(rank), int(world), lh, C.byref(cp), C.byref(o),

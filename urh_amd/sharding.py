@@ -39,10 +39,19 @@ class TorchDistComm:
 
     def all_gather(self, t):
         """t: torch tensor (same shape/dtype on every rank) -> tensor [world, *t.shape] on t's device."""
+        return self.all_gather_start(t)()
+
+    def all_gather_start(self, t):
+        """Enqueue the all-gather and return a function that waits for it (stream-level on GPU tensors: the host does not
+        block) and returns the gathered tensor: work enqueued in between overlaps the collective."""
         import torch
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
-        return out
+        work = self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group, async_op=True)
+
+        def wait():
+            work.wait()
+            return out
+        return wait
 
 
 class ThreadComm:
@@ -58,6 +67,10 @@ class ThreadComm:
 
     def __init__(self, shared, rank):
         self.shared, self.rank, self.world = shared, rank, shared.world
+
+    def all_gather_start(self, t):
+        out = self.all_gather(t)
+        return lambda: out
 
     def all_gather(self, t):
         import torch
@@ -125,7 +138,10 @@ class ShardedPipeline:
             n_total = self.world * n_local
         if p.modulation_type == "PSK":
             raise ValueError("the Costas loop carries state across the whole capture: PSK does not shard")
-        halos = c.all_gather(e.tail(iq_local, p))
+        pending = c.all_gather_start(e.tail(iq_local, p))
+        if hasattr(e, "runs_begin"):               # the halo exchange overlaps the hot kernel (all chunks but the first)
+            e.runs_begin(iq_local, pos_base, n_total, self.rank, self.world, p, want_qad)
+        halos = pending()
         left = halos[self.rank - 1] if self.rank > 0 else None
         summary = e.runs(iq_local, left, pos_base, n_total, self.rank, self.world, p, want_qad)
         # everything after the hot kernel (all-gathers included) is issued on the engine's tail stream when it is pipelined:
