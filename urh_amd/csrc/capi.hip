@@ -206,6 +206,20 @@ struct ShardSession {
     const int64_t *d_row_base = nullptr;
 };
 
+// descriptor memory of the single-pass scans for pulse tables of up to cap_rows rows
+int scan_state(urhgpu_ctx *ctx, int64_t cap_rows, ScanState *out) {
+    const size_t need = bits_desc_bytes(cap_rows);
+    if (need > ctx->desc_cap) {
+        if (ctx->d_desc) { URH_HIP(hipFree(ctx->d_desc)); ctx->d_desc = nullptr; ctx->desc_cap = 0; }
+        const size_t want = (need + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+        URH_HIP(hipMalloc(&ctx->d_desc, want));
+        URH_HIP(hipMemset(ctx->d_desc, 0, want));
+        ctx->desc_cap = want;
+    }
+    out->tickets = ctx->d_tickets; out->desc = ctx->d_desc; out->desc_bytes = ctx->desc_cap; out->epoch = &ctx->scan_epoch;
+    return URHGPU_OK;
+}
+
 // pipelined mode: make the caller's stream wait for the tail of the last pass (no host blocking)
 int join_tail(urhgpu_ctx *ctx) {
     if (ctx->tail_pending) {
@@ -301,6 +315,7 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
+    if (ctx->d_desc) (void)hipFree(ctx->d_desc);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -458,7 +473,9 @@ static int ppseq_to_bits_inner(urhgpu_ctx *ctx, const int64_t *d_rows, const int
     BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts};
     BitsParams bp = bits_params(p);
     bp.d_rows_needed = d_rows_needed;
-    URH_TRY(launch_ppseq_to_bits(d_rows, d_n_rows, cap, bp, bo, scratch, ctx->d_tickets, ctx->stream));
+    ScanState ss;
+    URH_TRY(scan_state(ctx, cap, &ss));
+    URH_TRY(launch_ppseq_to_bits(d_rows, d_n_rows, cap, bp, bo, scratch, ss, ctx->stream));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }
@@ -685,7 +702,9 @@ int urhgpu_shard_bits_prepare_dev(urhgpu_ctx *ctx, const int64_t *d_merge_all, i
     BitsParams bp = bits_params(&ss->p);
     bp.d_row_base = ss->d_row_base; bp.d_ts_carry = ss->d_small; bp.d_absorbed = ask ? ss->d_small + 1 : nullptr;
     bp.d_extra = (const int32_t *)(ss->d_small + 2); bp.is_last_rank = (ss->rank == ss->world - 1) ? 1 : 0;
-    URH_TRY(launch_bits_prepare(ss->out.rows, d_n_rows, std::max<int64_t>(ss->out.cap_rows, 1), bp, ss->bits_scratch, d_flags, ctx->d_tickets, s));
+    ScanState sst;
+    URH_TRY(scan_state(ctx, std::max<int64_t>(ss->out.cap_rows, 1), &sst));
+    URH_TRY(launch_bits_prepare(ss->out.rows, d_n_rows, std::max<int64_t>(ss->out.cap_rows, 1), bp, ss->bits_scratch, d_flags, sst, s));
     URH_HIP(hipGetLastError());
     ss->phase = 3;
     return URHGPU_OK;
@@ -705,7 +724,9 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
     bp.d_rows_needed = ctx->d_counts + 8;
     const urhgpu_outputs &o = ss->out;
     BitsOut bo{o.bits, o.cap_bits, o.msg_off, o.pauses, o.cap_msg, o.pos, o.cap_pos, o.pos_off, o.counts};
-    URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, ctx->d_tickets, s));
+    ScanState sst;
+    URH_TRY(scan_state(ctx, std::max<int64_t>(o.cap_rows, 1), &sst));
+    URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, sst, s));
     URH_HIP(hipGetLastError());
     ss->phase = 0;
     if (ss->piped) URH_TRY(end_pipelined_pass(ctx));

@@ -60,6 +60,11 @@ struct urhgpu_ctx {
     int64_t *d_counts = nullptr;   // small device result block (8 x int64)
     int64_t *h_counts = nullptr;   // pinned host mirror
     int32_t *d_tickets = nullptr;  // 8 zeroed ints: elections of the fused scan kernels (scan.hpp)
+    void *d_desc = nullptr;        // descriptors of the single-pass scans: dedicated, zeroed when (re)allocated
+    size_t desc_cap = 0;
+    // pass counter carried by the descriptor flags; starts far above anything a count or a position can be, so that memory
+    // that held other values (another descriptor layout) can never look like a flag of the current pass
+    unsigned long long scan_epoch = 0x0ACE0FBA5E000000ull;
     // optional timing of the dominant kernel (demod + run segmentation) with HIP events on `stream`
     std::vector<hipEvent_t> prof_events;   // pairs: [2k] before, [2k+1] after
     int prof_used = 0;                     // pairs recorded since urhgpu_ctx_profile_begin

@@ -123,16 +123,25 @@ size_t merge_scratch_bytes(int64_t cap);
 int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t cap, int64_t *rows_out,
                           int64_t cap_out, int64_t *d_n_out, void *scratch, int32_t *tickets, hipStream_t s);
 size_t bits_scratch_bytes(int64_t cap_rows);
-// tickets: 4 persistent device ints, zero between launches ("last workgroup done" elections of the fused scans)
+// Persistent per-context state of the scan kernels (scan.hpp): 4 device ints that are zero between launches ("last
+// workgroup done" elections), and the descriptor array of the single-pass scans -- dedicated memory that is zeroed when it
+// is (re)allocated and only ever holds descriptors, whose flags carry the pass counter `*epoch`.
+struct ScanState {
+    int32_t *tickets;
+    void *desc;
+    size_t desc_bytes;
+    unsigned long long *epoch;
+};
+size_t bits_desc_bytes(int64_t cap_rows);
 int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                         const BitsOut &o, void *scratch, int32_t *tickets, hipStream_t s);
+                         const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
 // The same in two halves (sharded captures: the boundary flags are exchanged in between).
 //   prepare: per-row scan; d_flags (3 x int64) = {long pause present, data before the first one, data after the last one}
 //   finish : groups -> messages, expansion (bp.d_extra resolved from every rank's flags)
 int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                        void *scratch, int64_t *d_flags, int32_t *tickets, hipStream_t s);
+                        void *scratch, int64_t *d_flags, const ScanState &ss, hipStream_t s);
 int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                       const BitsOut &o, void *scratch, int32_t *tickets, hipStream_t s);
+                       const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
 // ASK, sharded: summary of the locally merged table {n_rows, first state, first length, last state, last length}
 void launch_merge_summary(const int64_t *rows, const int64_t *d_n_rows, int64_t *d_out5, hipStream_t s);
 // ASK, sharded: merge equal-state rows across shard boundaries (d_all: world x 5 int64)

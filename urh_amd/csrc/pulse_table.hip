@@ -639,30 +639,37 @@ struct GroupCountFinal {
     }
 };
 
-int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                        void *scratch, int64_t *d_flags, int32_t *tickets, hipStream_t s) {
+// descriptor memory of the two single-pass scans (rows: K = 4, groups: K = 3)
+size_t bits_desc_bytes(int64_t cap_rows) {
     if (cap_rows <= 0) cap_rows = 1;
+    return (((size_t)(scan_blocks(cap_rows) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)) + (size_t)(scan_blocks(cap_rows + 1) + 1) * sizeof(ScanDesc<3>) + 512;
+}
+
+int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                        void *scratch, int64_t *d_flags, const ScanState &ss, hipStream_t s) {
+    if (cap_rows <= 0) cap_rows = 1;
+    if (ss.desc_bytes < bits_desc_bytes(cap_rows)) return URHGPU_ERR_ARG;
     const BitsScratch b = carve_bits(scratch, cap_rows);
     BitsLoad ld{rows, d_n_rows, bp};
     BitsStore st{rows, d_n_rows, b.info, b.groups, bp.d_ts_carry, bp.d_absorbed};
     GroupCountFinal fin{d_n_rows, b.groups, b.d_n_groups, d_flags};
-    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb, tickets);
-    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore, GroupCountFinal>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld,
-                       b.part4, b.nb, st, fin, tickets + 1);
+    // the flags of a sharded pass read what every workgroup stored (groups[]): the workgroup that finishes last computes them
+    hipLaunchKernelGGL((k_scan_lookback<4, BitsLoad, BitsStore, GroupCountFinal>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows,
+                       ld, (ScanDesc<4> *)ss.desc, b.nb, st, fin, ++*ss.epoch, ss.tickets, d_flags ? 1 : 0);
     return URHGPU_OK;
 }
 
 int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                       const BitsOut &o, void *scratch, int32_t *tickets, hipStream_t s) {
+                       const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s) {
     if (cap_rows <= 0) cap_rows = 1;
+    if (ss.desc_bytes < bits_desc_bytes(cap_rows)) return URHGPU_ERR_ARG;
     const BitsScratch b = carve_bits(scratch, cap_rows);
+    ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(b.nb + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};
-    hipLaunchKernelGGL((k_scan_reduce<3, GroupLoad>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s, b.d_n_groups, gl, b.part3, b.nbg,
-                       tickets + 2);
-    hipLaunchKernelGGL((k_scan_apply<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s,
-                       b.d_n_groups, gl, b.part3, b.nbg, gs, fin, tickets + 3);
+    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s,
+                       b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandArgs ea{rows, d_n_rows, b.info, b.gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp, b.huge, b.huge_count, kHugeCap};
     const int64_t eb = (cap_rows + 255) / 256;
     hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)eb), dim3(256), 0, s, ea);
@@ -671,9 +678,9 @@ int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap
 }
 
 int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                         const BitsOut &o, void *scratch, int32_t *tickets, hipStream_t s) {
-    URH_TRY(launch_bits_prepare(rows, d_n_rows, cap_rows, bp, scratch, nullptr, tickets, s));
-    return launch_bits_finish(rows, d_n_rows, cap_rows, bp, o, scratch, tickets, s);
+                         const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s) {
+    URH_TRY(launch_bits_prepare(rows, d_n_rows, cap_rows, bp, scratch, nullptr, ss, s));
+    return launch_bits_finish(rows, d_n_rows, cap_rows, bp, o, scratch, ss, s);
 }
 
 // ---- sharded captures: the tiny cross-shard fix-ups (one thread each; world <= a few dozen) ---------------

@@ -162,6 +162,120 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t *d_n, L
     if (threadIdx.x == 0) fin(partials[nblocks_max]);
 }
 
+// ---- single-pass scan (decoupled look-back) -----------------------------------------------------------------------------
+// One launch instead of two: every workgroup publishes the total of its tile (AGGREGATE), then a wavefront looks back over
+// its predecessors -- 64 descriptors per step -- adding aggregates until it meets one that already carries its inclusive
+// prefix, publishes its own inclusive prefix (PREFIX) and finishes its tile.  Workgroups are dispatched in index order, so
+// a workgroup only ever waits for workgroups that are already running.  Descriptors are never reset: the flag carries the
+// pass number (`epoch`, a per-context counter), anything older reads as "not yet published".
+template <int K> struct ScanDesc {
+    VecK<K> agg;
+    VecK<K> incl;
+    unsigned long long flag;     // epoch << 2 | state (1 = aggregate valid, 2 = inclusive prefix valid)
+    unsigned long long pad;
+};
+constexpr unsigned long long kScanAgg = 1, kScanIncl = 2;
+constexpr int kScanSpinLimit = 1 << 24;    // a lost predecessor would otherwise hang the GPU: give up and poison the result
+
+template <int K>
+__device__ __forceinline__ VecK<K> wave_sum_vec(VecK<K> x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int k = 0; k < K; ++k) x.v[k] += __shfl_xor(x.v[k], o);
+    return x;
+}
+
+// exclusive prefix of workgroup b (the sum of the totals of workgroups 0 .. b-1); executed by wavefront 0 of the workgroup
+template <int K>
+__device__ __forceinline__ VecK<K> scan_look_back(ScanDesc<K> *desc, int64_t b, unsigned long long epoch) {
+    const int lane = threadIdx.x & 63;
+    VecK<K> prefix; prefix.zero();
+    int64_t top = b - 1;                                  // nearest predecessor not yet accounted for
+    int spins = 0;
+    while (top >= 0) {
+        const int64_t j = top - lane;
+        unsigned long long f = 0;
+        if (j >= 0) f = __hip_atomic_load(&desc[j].flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = (j < 0) || ((f >> 2) == epoch);
+        const bool has_incl = (j >= 0) && ready && ((f & 3) == kScanIncl);
+        const unsigned long long m_incl = __ballot(has_incl);
+        const unsigned long long m_not_ready = __ballot(!ready);
+        // lanes below the first inclusive prefix must all be published
+        const int first_incl = m_incl ? __builtin_ctzll(m_incl) : 64;
+        const unsigned long long need = (first_incl >= 63) ? ~0ull : ((2ull << first_incl) - 1ull);
+        if (m_not_ready & need) {
+            if (++spins > kScanSpinLimit) { prefix.v[0] = -(1ll << 60); return prefix; }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        __threadfence();                                  // acquire: the values behind the flags
+        VecK<K> mine; mine.zero();
+        if (j >= 0 && lane <= first_incl) mine = (lane == first_incl) ? desc[j].incl : desc[j].agg;
+        prefix.add(wave_sum_vec<K>(mine));
+        if (m_incl) break;
+        top -= 64;
+    }
+    return prefix;
+}
+
+// Load::operator()(int64 i) -> VecK<K>; Store::operator()(int64 i, const VecK<K>& value, const VecK<K>& excl_prefix);
+// Final::operator()(const VecK<K>& grand_total) runs once on one thread: by the last workgroup of the scan when it does not
+// depend on what the OTHER workgroups stored (elect == 0), else by the workgroup that finishes last (ticket election).
+template <int K, class Load, class Store, class Final>
+__global__ __launch_bounds__(kScanBlock) void k_scan_lookback(const int64_t *d_n, Load load, ScanDesc<K> *desc, int64_t nblocks_max,
+                                                               Store store, Final fin, unsigned long long epoch, int32_t *ticket,
+                                                               int elect) {
+    __shared__ VecK<K> s_wave[kScanBlock / 64];
+    __shared__ VecK<K> s_prefix;
+    const int64_t n = *d_n;
+    const int64_t nb = scan_active_blocks(n, nblocks_max);
+    const int64_t b = blockIdx.x;
+    if (b >= nb) return;
+    const int64_t base = b * kScanTile;
+    VecK<K> item[kScanItems];
+    VecK<K> acc; acc.zero();
+    const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        item[j].zero();
+        if (i0 + j < n) item[j] = load(i0 + j);
+        acc.add(item[j]);
+    }
+    VecK<K> total;
+    VecK<K> ex = block_excl_scan_vec<K>(acc, total, s_wave);
+    if (threadIdx.x < 64) {                               // wavefront 0 publishes and looks back
+        if (b > 0 && threadIdx.x == 0) {
+            desc[b].agg = total;
+            __threadfence();
+            __hip_atomic_store(&desc[b].flag, (epoch << 2) | kScanAgg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const VecK<K> prefix = scan_look_back<K>(desc, b, epoch);
+        if (threadIdx.x == 0) {
+            VecK<K> incl = prefix; incl.add(total);
+            desc[b].incl = incl;
+            __threadfence();
+            __hip_atomic_store(&desc[b].flag, (epoch << 2) | kScanIncl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = prefix;
+        }
+    }
+    __syncthreads();
+    const VecK<K> prefix = s_prefix;
+    ex.add(prefix);
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (i0 + j < n) store(i0 + j, item[j], ex);
+        ex.add(item[j]);
+    }
+    if (elect) {
+        if (!scan_last_block(ticket, nb)) return;
+        if (threadIdx.x == 0) fin(desc[nb - 1].incl);
+    } else if (b == nb - 1 && threadIdx.x == 0) {
+        VecK<K> grand = prefix; grand.add(total);
+        fin(grand);
+    }
+}
+
 struct NoFinal {
     template <class V> __device__ void operator()(const V &) const {}
 };
