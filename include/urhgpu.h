@@ -143,6 +143,23 @@ int urhgpu_fir_filter(urhgpu_ctx *ctx, const float *x, int64_t n, const float *t
 int urhgpu_fir_filter_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const float *d_taps, int64_t m,
                           const float *d_left_halo, float *d_out);
 
+/* Filter.apply_bandpass_filter (src/urh/signalprocessing/Filter.py:84-101; np.convolve(data, h, "same") at :98 and
+ * Filter.fft_convolve_1d at :70-82 are the same centred linear convolution): complex64 x[n] (*) complex128 taps[m],
+ *   out[i] = sum_{k=0}^{m-1} taps[k] * X(i + shift - k),  i in [0, n_out),  X = x extended by zeros,
+ * accumulated in complex128 (fp64 FMAs, taps ascending) -- the reference's summation order is numpy's (BLAS / FFT) and
+ * undefined, so this entry point is floating point with a tolerance, not bit-exact.  The caller designs the taps
+ * (Filter.py:103-131, O(m) on the host) and passes shift = (min(n, m) - 1) / 2, n_out = max(n, m) for "same".
+ * out: n_out complex128 values. */
+int urhgpu_bandpass(urhgpu_ctx *ctx, const float *x, int64_t n, const double *taps, int64_t m, int64_t shift,
+                    int64_t n_out, double *out);
+
+/* The same on device memory (asynchronous).  d_left / d_right: NULL or DEVICE pointers to n_left samples preceding d_x[0] /
+ * n_right samples following d_x[n-1] (sharded captures: the neighbours' edges) instead of zeros.  out_c64 != 0 writes
+ * complex64 (the cast of SignalFrame.py:1578-1580 fused into the store), else complex128. */
+int urhgpu_bandpass_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const double *d_taps, int64_t m, int64_t shift,
+                        int64_t n_out, const float *d_left, int64_t n_left, const float *d_right, int64_t n_right,
+                        void *d_out, int out_c64);
+
 /* signal_functions.iir_filter (:527-542). */
 int urhgpu_iir_filter(urhgpu_ctx *ctx, const double *a, int64_t na, const double *b, int64_t nb,
                       const float *x, int64_t n, float *out);

@@ -707,3 +707,64 @@ def test_capacity_regrowth_on_noise_capture(pipe, oracle):
     assert np.array_equal(res.ppseq(), pp)
     fb = oracle.ppseq_to_bits_flat(pp, 1000, 1, True, 8)
     assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
+
+
+# ---- row 6b: spectrogram band-pass (Filter.apply_bandpass_filter) -- floating point with the tolerance of
+# tests/test_bandpass_host.py: 2^-40 * sum|h| * max|x| in the reference's np.convolve regime, 2^-18 in its (single precision)
+# FFT regime -------------------------------------------------------------------------------------------------------------
+def test_bandpass_equals_reference_outputs():
+    from test_bandpass_host import golden_cases, tolerance
+    from urh_amd import filter as uf
+    for name, x, (lo, hi, bw), y in golden_cases():
+        got = uf.apply_bandpass_filter(x, lo, hi, bw)
+        assert got.dtype == np.complex128 and got.shape == y.shape, name
+        assert np.max(np.abs(got - y)) <= tolerance(x, uf.bandpass_taps(lo, hi, bw)), name
+
+
+def test_bandpass_kat():
+    """/root/reference/tests/test_filter.py:124-132: swapped band edges give the same result"""
+    from urh_amd import filter as uf
+    sig = (np.sin(2 * np.pi * 0.2 * np.arange(100)) + np.sin(2 * np.pi * 0.3 * np.arange(100))).astype(np.complex64)
+    assert np.array_equal(uf.apply_bandpass_filter(sig, 0.1, 0.2), uf.apply_bandpass_filter(sig, 0.2, 0.1))
+
+
+def test_bandpass_device_equals_model(pipe):
+    """device entry point on random captures: every tap-count residue of the register window, tile edges, complex128 and
+    fused complex64 output, and a capture cut in three with the neighbours' edges as halos (what a shard sees)"""
+    import torch
+    from test_bandpass_host import model_convolve
+    from urh_amd import filter as uf
+    rng = np.random.default_rng(8)
+    for n, m in [(1, 1), (5, 3), (1023, 7), (1024, 8), (1025, 9), (4097, 51), (20_000, 401), (3000, 4001), (70_000, 1001)]:
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        h = rng.standard_normal(m) + 1j * rng.standard_normal(m)
+        shift, n_out = (min(n, m) - 1) // 2, max(n, m)
+        want = model_convolve(x, h, shift, n_out)
+        tol = float(np.sum(np.abs(h)) * np.max(np.abs(x))) * 2.0 ** -40
+        d_x = torch.from_numpy(x).to(pipe.device)
+        got = uf.convolve_dev(pipe, d_x, h, shift, n_out, out_complex64=False).cpu().numpy()
+        assert np.max(np.abs(got - want)) <= tol, (n, m)
+        got32 = uf.convolve_dev(pipe, d_x, h, shift, n_out, out_complex64=True).cpu().numpy()
+        assert got32.dtype == np.complex64 and np.array_equal(got32, got.astype(np.complex64)), (n, m)
+    n, m = 50_000, 301
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    h = rng.standard_normal(m) + 1j * rng.standard_normal(m)
+    shift = (m - 1) // 2
+    d_x = torch.from_numpy(x).to(pipe.device)
+    whole = uf.convolve_dev(pipe, d_x, h, shift, n, out_complex64=False).cpu().numpy()
+    cuts = [0, 17_001, 33_333, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        left = d_x[max(0, a - (m - 1 - shift)):a]
+        right = d_x[b:min(n, b + shift)]
+        part = uf.convolve_dev(pipe, d_x[a:b].contiguous(), h, shift, b - a, out_complex64=False, left=left, right=right).cpu().numpy()
+        assert np.array_equal(part, whole[a:b]), (a, b)
+
+
+def test_bandpass_argument_errors(pipe):
+    import torch
+    from urh_amd import _lib, filter as uf
+    x = torch.zeros(100, dtype=torch.complex64, device=pipe.device)
+    with pytest.raises(_lib.UrhGpuError):
+        uf.convolve_dev(pipe, x, np.ones(40_000, dtype=np.complex128), 0, 100)        # more taps than the LDS window holds
+    with pytest.raises(ValueError):
+        uf.apply_bandpass_filter(np.zeros(0, np.complex64), 0.1, 0.2)

@@ -74,6 +74,8 @@ PROTOTYPES = {
     "urhgpu_ppseq_to_bits": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "urhgpu_fir_filter": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "urhgpu_fir_filter_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "urhgpu_bandpass": (_i, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
+    "urhgpu_bandpass_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i]),
     "urhgpu_iir_filter": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "urhgpu_afp_demod_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp]),
     "urhgpu_grab_pulse_lens_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp, _i64, _vp]),

@@ -986,6 +986,43 @@ int urhgpu_fir_filter(urhgpu_ctx *ctx, const float *x, int64_t n, const float *t
     return URHGPU_OK;
 }
 
+int urhgpu_bandpass_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const double *d_taps, int64_t m, int64_t shift,
+                        int64_t n_out, const float *d_left, int64_t n_left, const float *d_right, int64_t n_right, void *d_out,
+                        int out_c64) {
+    if (!ctx || n < 0 || m < 0 || n_out < 0 || n_left < 0 || n_right < 0 || (n > 0 && !d_x) || (m > 0 && !d_taps) ||
+        (n_out > 0 && !d_out))
+        return URHGPU_ERR_ARG;
+    if (((uintptr_t)d_x & 7) || ((uintptr_t)d_taps & 15) || ((uintptr_t)d_out & (out_c64 ? 7 : 15)) || ((uintptr_t)d_left & 7) ||
+        ((uintptr_t)d_right & 7) || m > (int64_t)1 << 20 || shift < -((int64_t)1 << 40) || shift > (int64_t)1 << 40)
+        return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(launch_bandpass((const float2 *)d_x, n, (const float2 *)d_left, n_left, (const float2 *)d_right, n_right,
+                            (const double2 *)d_taps, (int)m, shift, n_out, out_c64 ? nullptr : (double2 *)d_out,
+                            out_c64 ? (float2 *)d_out : nullptr, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_bandpass(urhgpu_ctx *ctx, const float *x, int64_t n, const double *taps, int64_t m, int64_t shift, int64_t n_out,
+                    double *out) {
+    if (!ctx || n < 0 || m < 0 || n_out < 0 || (n > 0 && !x) || (m > 0 && !taps) || (n_out > 0 && !out)) return URHGPU_ERR_ARG;
+    if (n_out == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(ctx->staging.reserve(align256((size_t)std::max<int64_t>(n, 1) * 8) + align256((size_t)std::max<int64_t>(m, 1) * 16) +
+                                 align256((size_t)n_out * 16) + 1024));
+    ctx->staging.reset();
+    void *d_x = nullptr, *d_t = nullptr;
+    URH_TRY(stage_in(ctx, x, (size_t)n * 8, &d_x));
+    URH_TRY(stage_in(ctx, taps, (size_t)m * 16, &d_t));
+    double *d_out = (double *)ctx->staging.take((size_t)n_out * 16);
+    if (!d_out) return URHGPU_ERR_ARG;
+    URH_TRY(urhgpu_bandpass_dev(ctx, (const float *)d_x, n, (const double *)d_t, m, shift, n_out, nullptr, 0, nullptr, 0, d_out, 0));
+    URH_HIP(hipMemcpyAsync(out, d_out, (size_t)n_out * 16, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
 int urhgpu_iir_filter(urhgpu_ctx *ctx, const double *a, int64_t na, const double *b, int64_t nb, const float *x, int64_t n,
                       float *out) {
     if (!ctx || n < 0 || na < 0 || nb < 0 || (n > 0 && (!x || !out)) || (na > 0 && !a) || (nb > 0 && !b)) return URHGPU_ERR_ARG;

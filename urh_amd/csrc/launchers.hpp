@@ -38,6 +38,10 @@ int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t
 void launch_test_div(uint64_t seed, int reps, unsigned long long *d_mismatches, hipStream_t s);
 void launch_test_atan2f(const float *y, const float *x, int64_t n, float *out, hipStream_t s);
 
+// ---- bandpass.hip ------------------------------------------------------------------------------------
+int launch_bandpass(const float2 *x, int64_t n, const float2 *left, int64_t n_left, const float2 *right, int64_t n_right,
+                    const double2 *taps, int m, int64_t shift, int64_t n_out, double2 *out128, float2 *out64, hipStream_t s);
+
 // ---- pulse_table.hip ---------------------------------------------------------------------------------
 // Scratch of the resolve stage: one entry per chunk (ints are chunk indices or -1).
 struct ResolveScratch {
