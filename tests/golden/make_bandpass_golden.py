@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run the REAL reference's Filter.apply_bandpass_filter (this container only) on the first samples of golden captures and
 on synthetic tones, in both of its regimes (np.convolve for short filters, FFT convolution for long ones), and store
-inputs, parameters and the complex128 results in tests/golden/bandpass.npz; the GPU test compares
+inputs, parameters and the complex128 results in tests/golden/filter/bandpass.npz; the GPU test compares
 urh_amd.filter.apply_bandpass_filter with it within the tolerance stated there.
 
     python tests/golden/make_bandpass_golden.py
@@ -37,5 +37,5 @@ for name, x, lo, hi, bw in [
     assert y.dtype == np.complex128
     cases.append((name, x, np.array([lo, hi, bw]), y))
     print(name, len(x), Filter.get_filter_length_from_bandwidth(bw), len(y))
-np.savez_compressed(os.path.join(HERE, "bandpass.npz"), names=np.array([c[0] for c in cases]),
+np.savez_compressed(os.path.join(HERE, "filter", "bandpass.npz"), names=np.array([c[0] for c in cases]),
                     **{f"x_{c[0]}": c[1] for c in cases}, **{f"p_{c[0]}": c[2] for c in cases}, **{f"y_{c[0]}": c[3] for c in cases})

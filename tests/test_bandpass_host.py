@@ -1,6 +1,6 @@
 """Host side of the spectrogram band-pass (urh_amd/filter.py, row 6b): tap design and result geometry against the
 reference's Filter (skipped where /root/reference is absent), and the centred-convolution formula the kernel evaluates
-against the committed outputs of the real reference (tests/golden/bandpass.npz).  No GPU involved."""
+against the committed outputs of the real reference (tests/golden/filter/bandpass.npz).  No GPU involved."""
 import os
 
 import numpy as np
@@ -8,7 +8,7 @@ import pytest
 
 from urh_amd import filter as f
 
-GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "bandpass.npz")
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "filter", "bandpass.npz")
 
 
 def model_convolve(x, h, shift, n_out, left=None, right=None):
