@@ -351,11 +351,19 @@ __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float pr
         const float re0 = pc * c0 + pd * d0, im0 = pc * d0 - pd * c0;
         const float re1 = c0 * c1 + d0 * d1, im1 = c0 * d1 - d0 * c1;
         float t0, t1;
+#if URH_EXP == 8                      // timing experiment: no division either
+        t0 = im0 * 0.125f; t1 = im1 * 0.125f;
+#else
         div_fast2(im0, re0, im1, re1, t0, t1);
+#endif
         const bool ok0 = (int)((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re0) - kReLo < kReSpan);
         const bool ok1 = (int)((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re1) - kReLo < kReSpan);
+#if URH_EXP == 6 || URH_EXP == 8      // timing experiment (tools/kbench): no polynomial in the speculative path
+        q0 = t0; q1 = t1;
+#else
         q0 = t0 - urh_atanf_poly(t0);
         q1 = t1 - urh_atanf_poly(t1);
+#endif
 #if URH_EXP == 4      // timing experiment (tools/kbench): 24 extra plain VALU instructions per row
         { float dummy = t0;
 #pragma unroll
@@ -593,6 +601,9 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
             }
         }
         __syncthreads();   // A: states complete
+#if URH_EXP == 7 || URH_EXP == 8      // timing experiment: no run phase
+        if (p.tol >= 0) continue;
+#endif
 
         // ================= phase 2: runs.  thread t owns samples [32t, 32t+32) of the tile ==============
         uint32_t bm = 0;
