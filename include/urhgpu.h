@@ -286,6 +286,11 @@ int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);
 
+/* Test hook: modulation order 2 (2-FSK, OOK, message segmentation) normally runs the bit-plane kernel
+ * (k_demod_runs_bp) and every other order the state-byte kernel (k_demod_runs); on != 0 routes order 2 through the
+ * state-byte kernel as well, so that tests can compare the two on the same input.  Process-wide. */
+int urhgpu_test_force_state_bytes(int on);
+
 /* Test hook: elementwise bit-faithful atan2f (the device port of glibc 2.35 atan2f), device pointers. */
 int urhgpu_test_atan2f_dev(urhgpu_ctx *ctx, const float *d_y, const float *d_x, int64_t n, float *d_out);
 

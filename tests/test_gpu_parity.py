@@ -182,6 +182,48 @@ def test_fused_equals_oracle_medium(pipe, oracle, mod):
 
 
 @pytest.mark.parametrize("mod", ["FSK", "ASK"])
+def test_bit_plane_kernel_equals_state_byte_kernel(pipe, oracle, mod):
+    """Modulation order 2 runs k_demod_runs_bp (bit planes, wavefronts sharing a chunk), every other order the
+    state-byte kernel: both on the same captures -- tolerances 0..64 and beyond (65: the state-byte kernel is the
+    only one), noise gating on and off, exact-zero samples, sizes that end in whole rows, partial rows, partial tiles --
+    must agree on everything, and with the oracle."""
+    import torch
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams
+    lib = _lib.load()
+    rng = np.random.default_rng(77 + len(mod))
+    try:
+        for n, dtype in ((1 << 18, np.float32), (262_144 + 8192 + 2048 + 130, np.float32), (70_001, np.int16), (8192 * 3, np.uint8)):
+            iq = synth_fsk(n, sps=50, seed=n % 89, noise=0.08, pause_every=n // 4, pause_len=n // 19, dtype=dtype)
+            scale = {np.float32: 1.0, np.int16: 32767.0, np.uint8: 127.0}[dtype]
+            if mod == "ASK":
+                env = np.repeat(rng.integers(0, 2, n // 50 + 1), 50)[:n]
+                iq = (iq.astype(np.float32) * (0.05 + 0.95 * env)[:, None]).astype(dtype)
+            if dtype == np.float32:
+                iq[rng.integers(0, n, 300)] = 0.0                       # exact zeros: NOISE even at threshold 0
+                iq[5000:5700] = 0.0
+            dev = torch.from_numpy(iq).cuda()
+            for tol in (0, 1, 2, 5, 6, 17, 63, 64, 65):
+                for noise in (0.0, 0.25 * scale):
+                    center = 0.0 if mod == "FSK" else 0.35
+                    p = DemodParams(mod, 1, noise, center, 1.0, tol, 50, 0.1, 8, True)
+                    got = []
+                    for force in (0, 1):
+                        lib.urhgpu_test_force_state_bytes(force)
+                        res = pipe.iq_to_bits(dev, p, want_qad=True, cap_rows=n // (tol + 1) + 2)
+                        got.append((res.qad.cpu().numpy().copy(), res.ppseq().copy()) + tuple(x.copy() for x in res.flat()))
+                    assert bits_equal(got[0][0], got[1][0]), (n, dtype, tol, noise)
+                    for k in range(1, len(got[0])):
+                        assert np.array_equal(got[0][k], got[1][k]), (n, dtype, tol, noise, k)
+                    if tol in (0, 5, 64) and n <= (1 << 18):
+                        qad = oracle.afp_demod(iq, noise, mod, 2)
+                        pp = oracle.grab_pulse_lens(qad, center, tol, mod, 50, 1, 1.0)
+                        assert bits_equal(got[0][0], qad) and np.array_equal(got[0][1], pp), (n, dtype, tol, noise)
+    finally:
+        lib.urhgpu_test_force_state_bytes(0)
+
+
+@pytest.mark.parametrize("mod", ["FSK", "ASK"])
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_equals_single_gpu(pipe, oracle, mod, world):
     """W simulated ranks (threads, one context each) on this GPU: the stitched sharded result equals the

@@ -71,6 +71,55 @@ __global__ __launch_bounds__(256) void k_ceiling_chunked_nt(const kv4 *in, kv2 *
     }
 }
 
+// one wavefront per chunk, rows of 1 KiB, software-pipelined NB rows ahead: the hot kernel's memory structure without its math
+template <int NB>
+__global__ __launch_bounds__(64) void k_ceiling_wave_nt(const kv4 *in, kv2 *out, int64_t pairs_per_block) {
+    const int64_t b0 = blockIdx.x * pairs_per_block;
+    kv4 cur[NB], nxt[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cur[j] = __builtin_nontemporal_load(in + b0 + j * 64 + threadIdx.x);
+#pragma unroll 1
+    for (int64_t i = 0; i < pairs_per_block; i += 64 * NB) {
+        if (i + 64 * NB < pairs_per_block) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) nxt[j] = __builtin_nontemporal_load(in + b0 + i + 64 * NB + j * 64 + threadIdx.x);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const kv2 o = {cur[j].x + cur[j].y, cur[j].z + cur[j].w};
+            __builtin_nontemporal_store(o, out + b0 + i + j * 64 + threadIdx.x);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) cur[j] = nxt[j];
+    }
+}
+// same with a per-chunk rotated start row (do concurrently running wavefronts collide on memory channels when they
+// all sit at the same offset of their 64 KiB chunk?)
+template <int NB>
+__global__ __launch_bounds__(64) void k_ceiling_wave_rot(const kv4 *in, kv2 *out, int64_t pairs_per_block, int mult) {
+    const int64_t b0 = blockIdx.x * pairs_per_block;
+    const int64_t steps = pairs_per_block / (64 * NB);
+    int64_t st = ((int64_t)blockIdx.x * mult) % steps;
+    kv4 cur[NB], nxt[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) cur[j] = __builtin_nontemporal_load(in + b0 + st * 64 * NB + j * 64 + threadIdx.x);
+#pragma unroll 1
+    for (int64_t k = 0; k < steps; ++k) {
+        int64_t sn = st + 1; if (sn == steps) sn = 0;
+        if (k + 1 < steps) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) nxt[j] = __builtin_nontemporal_load(in + b0 + sn * 64 * NB + j * 64 + threadIdx.x);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const kv2 o = {cur[j].x + cur[j].y, cur[j].z + cur[j].w};
+            __builtin_nontemporal_store(o, out + b0 + st * 64 * NB + j * 64 + threadIdx.x);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) cur[j] = nxt[j];
+        st = sn;
+    }
+}
 static float time_ms(hipStream_t s, int iters, void (*fn)(void *), void *arg) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -135,6 +184,17 @@ int main(int argc, char **argv) {
     printf("ceiling chunked (%lld wg)        %8.4f ms  %7.1f GB/s\n", (long long)n_chunks, ms, n * 12.0 / ms / 1e6);
     ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; hipLaunchKernelGGL(k_ceiling_chunked_nt, dim3(c->grid), dim3(256), 0, c->s, (const kv4 *)c->in4, (kv2 *)c->out2, c->n_pairs / c->grid); }, &c);
     printf("ceiling chunked nt (%lld wg)     %8.4f ms  %7.1f GB/s\n", (long long)n_chunks, ms, n * 12.0 / ms / 1e6);
+    ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; hipLaunchKernelGGL(k_ceiling_wave_nt<1>, dim3(c->grid), dim3(64), 0, c->s, (const kv4 *)c->in4, (kv2 *)c->out2, c->n_pairs / c->grid); }, &c);
+    printf("ceiling 1 wave/chunk nt, 1 row ahead    %8.4f ms  %7.1f GB/s\n", ms, n * 12.0 / ms / 1e6);
+    ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; hipLaunchKernelGGL(k_ceiling_wave_nt<2>, dim3(c->grid), dim3(64), 0, c->s, (const kv4 *)c->in4, (kv2 *)c->out2, c->n_pairs / c->grid); }, &c);
+    printf("ceiling 1 wave/chunk nt, 2 rows ahead   %8.4f ms  %7.1f GB/s\n", ms, n * 12.0 / ms / 1e6);
+    ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; hipLaunchKernelGGL(k_ceiling_wave_nt<4>, dim3(c->grid), dim3(64), 0, c->s, (const kv4 *)c->in4, (kv2 *)c->out2, c->n_pairs / c->grid); }, &c);
+    printf("ceiling 1 wave/chunk nt, 4 rows ahead   %8.4f ms  %7.1f GB/s\n", ms, n * 12.0 / ms / 1e6);
+    for (int mult : {1, 3, 5, 7, 11}) {
+        static int g_mult; g_mult = mult;
+        ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; hipLaunchKernelGGL(k_ceiling_wave_rot<2>, dim3(c->grid), dim3(64), 0, c->s, (const kv4 *)c->in4, (kv2 *)c->out2, c->n_pairs / c->grid, g_mult); }, &c);
+        printf("ceiling 1 wave/chunk nt, 2 rows ahead, start rotated x%-2d  %8.4f ms  %7.1f GB/s\n", mult, ms, n * 12.0 / ms / 1e6);
+    }
     ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; LAUNCH(c->a, URHGPU_MOD_FSK, true, c->s); }, &c);
     printf("k_demod_runs FSK (qad written)  %8.4f ms  %7.1f GB/s (12 B/sample)\n", ms, n * 12.0 / ms / 1e6);
     ms = time_ms(s, iters, [](void *p) { Ctx *c = (Ctx *)p; LAUNCH(c->a, URHGPU_MOD_FSK, false, c->s); }, &c);

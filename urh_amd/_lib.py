@@ -94,6 +94,7 @@ PROTOTYPES = {
     "urhgpu_pairwise_sum_f32_dev": (_i, [_vp, _vp, _i64, _i, _f, C.POINTER(_f)]),
     "urhgpu_histogram_f32_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "urhgpu_test_fast_division_dev": (_i, [_vp, C.c_uint64, _i, C.POINTER(C.c_uint64)]),
+    "urhgpu_test_force_state_bytes": (_i, [_i]),
     "urhgpu_test_atan2f_dev": (_i, [_vp, _vp, _vp, _i64, _vp]),
 }
 

@@ -46,7 +46,8 @@ Plan make_plan(const urhgpu_ctx *ctx, int64_t n, int tol) {
     // tile at the end of the capture is one more chunk (see launch_runs_4 in demod_runs.hip)
     const int64_t full_tiles = n / kTile;
     const int64_t target = (int64_t)ctx->prop.multiProcessorCount * 64;      // chunks (= wavefronts): ~2-3 rounds of the resident set
-    const int64_t tiles_per_chunk = std::max<int64_t>(1, (full_tiles + target - 1) / target);
+    // at most 4 tiles = 64 rows per chunk: the bit-plane kernel parks one row per lane (kBpMaxRows)
+    const int64_t tiles_per_chunk = std::min<int64_t>(4, std::max<int64_t>(1, (full_tiles + target - 1) / target));
     pl.chunk_len = tiles_per_chunk * kTile;
     pl.n_chunks = (full_tiles * kTile + pl.chunk_len - 1) / pl.chunk_len + ((n % kTile) ? 1 : 0);
     pl.slab_stride = pl.chunk_len / ((int64_t)tol + 1) + 2;
@@ -832,6 +833,11 @@ int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint
     URH_HIP(hipMemcpyAsync(ctx->h_counts, ctx->d_counts, 8, hipMemcpyDeviceToHost, ctx->stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
     *n_mismatch = (uint64_t)ctx->h_counts[0];
+    return URHGPU_OK;
+}
+
+int urhgpu_test_force_state_bytes(int on) {
+    urh::g_force_state_bytes = (on != 0);
     return URHGPU_OK;
 }
 

@@ -50,6 +50,12 @@ enum { SRC_IQ = 0, SRC_QAD = 1 };
 #ifndef URH_SPEC
 #define URH_SPEC 1        // branch-free speculative fast path per batch of rows (see spec_pair)
 #endif
+#ifndef URH_BITPLANE
+#define URH_BITPLANE 1     // order-2 work goes through k_demod_runs_bp (0: tools/kbench A/B builds)
+#endif
+#ifndef URH_WPB
+#define URH_WPB 4          // k_demod_runs_bp: wavefronts per chunk (1, 2, 4 or 8)
+#endif
 #ifndef URH_NT
 #define URH_NT 1          // non-temporal IQ loads / qad stores (streamed once): +8 % on the copy ceiling, tools/kbench
 #endif
@@ -404,6 +410,124 @@ __device__ __forceinline__ void fsk_row_general(const RowIn &r, float prev_c, fl
     q0 = out[0]; q1 = out[1];
 }
 
+// Demodulate one batch of NB rows (cur[j] = a lane's two samples of row j).  (prev_c, prev_d) is the IQ sample before
+// the batch (wavefront-uniform) and is advanced to the batch's last sample.  Returns the per-row "gated" flags (bit j:
+// some sample of row j may equal the NOISE sentinel, so the classification has to test for it).
+template <int SRC, int DT, int MOD, int NB>
+__device__ __forceinline__ uint32_t demod_batch(const RowIn (&cur)[NB], float &prev_c, float &prev_d, const RunArgs &p,
+                                                float (&q0)[NB], float (&q1)[NB]) {
+    constexpr int kBatch = NB;
+    uint32_t general = 0, gated = 0;                        // per-row flags, wavefront-uniform
+    float pcs[kBatch], pds[kBatch];                         // seam operand of each row (uniform)
+#if URH_SPEC
+    if (SRC == SRC_IQ && MOD != URHGPU_MOD_OTHER) {
+        bool flag[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            pcs[j] = prev_c; pds[j] = prev_d;
+            flag[j] = spec_pair<MOD, DT>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
+            if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
+        }
+        uint32_t bad = 0;
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) if (__builtin_amdgcn_ballot_w64(flag[j]) != 0) bad |= 1u << j;
+        if (__builtin_expect(bad != 0, 0)) {
+#pragma unroll 1
+            for (int j = 0; j < kBatch; ++j) {
+                if (!((bad >> j) & 1u)) continue;
+                RowIn r = cur[0]; float pc = pcs[0], pd = pds[0];
+#pragma unroll
+                for (int k = 1; k < kBatch; ++k) if (j == k) { r = cur[k]; pc = pcs[k]; pd = pds[k]; }
+                float g0 = 0.f, g1 = 0.f;
+                const int kind = demod_pair<MOD>(r, pc, pd, p, g0, g1);
+                if (kind == 2) general |= 1u << j;
+                else {
+#pragma unroll
+                    for (int k = 0; k < kBatch; ++k) if (j == k) { q0[k] = g0; q1[k] = g1; }
+                }
+                if (kind != 0) gated |= 1u << j;
+            }
+        }
+    } else
+#endif
+    {
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+        if (SRC == SRC_QAD) { q0[j] = cur[j].c0; q1[j] = cur[j].d0; gated |= 1u << j; continue; }
+        pcs[j] = prev_c; pds[j] = prev_d;
+        const int k = demod_pair<MOD>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
+        if (k == 2) general |= 1u << j;
+        if (k != 0) gated |= 1u << j;
+        if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
+    }
+    }
+    if (MOD == URHGPU_MOD_FSK && SRC == SRC_IQ && general) {
+#pragma unroll 1
+        for (int j = 0; j < kBatch; ++j) {
+            if (!((general >> j) & 1u)) continue;
+            RowIn r = cur[0]; float pc = pcs[0], pd = pds[0];
+#pragma unroll
+            for (int k = 1; k < kBatch; ++k) if (j == k) { r = cur[k]; pc = pcs[k]; pd = pds[k]; }
+            float g0, g1;
+            fsk_row_general(r, pc, pd, p, g0, g1);
+#pragma unroll
+            for (int k = 0; k < kBatch; ++k) if (j == k) { q0[k] = g0; q1[k] = g1; }
+        }
+    }
+    return gated;
+}
+
+// Chunk prologue: the state of sample a0-1 (kStNone when the capture starts at a0) and, for FSK, the IQ sample a0-1
+// itself (the seam operand of the chunk's first sample).  Wavefront-uniform loads.
+template <int SRC, int DT, int MOD, bool ORDER2>
+__device__ __forceinline__ uint32_t chunk_prologue(const RunArgs &p, int64_t a0, bool global_start, float &prev_c, float &prev_d) {
+    uint32_t st = kStNone;
+    if (SRC == SRC_QAD) {
+        const float *q = (const float *)p.in;
+        if (a0 > 0) st = classify<ORDER2>(q[a0 - 1], p);
+        else if (!global_start) st = classify<ORDER2>(((const float *)p.left_halo)[0], p);
+    } else {
+        // qad[a0-1] needs IQ[a0-1] and (FSK) IQ[a0-2]
+        float pc = 0, pd = 0;
+        bool have = false, is_global0 = false;
+        if (a0 >= 1) {
+            Iq<DT>::load1(p.in, a0 - 1, prev_c, prev_d);
+            have = true;
+            if (a0 >= 2) Iq<DT>::load1(p.in, a0 - 2, pc, pd);
+            else if (!global_start) Iq<DT>::load1(p.left_halo, 1, pc, pd);
+            else is_global0 = true;           // sample a0-1 is global sample 0 -> NOISE
+        } else if (!global_start) {
+            Iq<DT>::load1(p.left_halo, 1, prev_c, prev_d);
+            Iq<DT>::load1(p.left_halo, 0, pc, pd);
+            have = true;
+        }
+        if (have) {
+            const float q = is_global0 ? p.noise_val : demod_one<MOD, DT>(pc, pd, prev_c, prev_d, p);
+            st = classify<ORDER2>(q, p);
+        }
+    }
+    return st;
+}
+
+// initial cur_state of the reference state machine (signal_functions.pyx:421-429), kept in chunk 0's ChunkInfo:
+// PAUSE if samples[0] == NOISE else the state of the literal 0.0
+template <int SRC, int DT, int MOD, bool ORDER2>
+__device__ __forceinline__ uint32_t chunk_init_state(const RunArgs &p, int64_t chunk) {
+    uint32_t init = 0;
+    if (chunk == 0) {
+        bool first_is_noise;
+        if (SRC == SRC_QAD) first_is_noise = (((const float *)p.in)[0] == p.noise_val);
+        else first_is_noise = true;                            // afp_demod: result[0] = NOISE
+        init = first_is_noise ? kStPause : classify<ORDER2>(0.0f, p, false);   // literal 0.0: thresholds only
+        if (SRC == SRC_IQ && p.seg_mode) {                     // segmentation: the state of sample 0 itself
+            float c = 0.f, d = 0.f;
+            Iq<DT>::load1(p.in, 0, c, d);
+            init = classify<ORDER2>(demod_one<MOD, DT>(0.f, 0.f, c, d, p), p);
+        }
+    }
+    return init;
+}
+
 // Block-wide helpers --------------------------------------------------------------------------------
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
@@ -460,31 +584,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
     // sample a0-1, initial carries ------------------------------------------------------------------
     float prev_c = 0.f, prev_d = 0.f;          // IQ sample a0-1: seam operand of the chunk's first sample
     {
-        uint32_t st = kStNone;
-        if (SRC == SRC_QAD) {
-            const float *q = (const float *)p.in;
-            if (a0 > 0) st = classify<ORDER2>(q[a0 - 1], p);
-            else if (!global_start) st = classify<ORDER2>(((const float *)p.left_halo)[0], p);
-        } else {
-            // qad[a0-1] needs IQ[a0-1] and (FSK) IQ[a0-2]
-            float pc = 0, pd = 0;
-            bool have = false, is_global0 = false;
-            if (a0 >= 1) {
-                Iq<DT>::load1(p.in, a0 - 1, prev_c, prev_d);
-                have = true;
-                if (a0 >= 2) Iq<DT>::load1(p.in, a0 - 2, pc, pd);
-                else if (!global_start) Iq<DT>::load1(p.left_halo, 1, pc, pd);
-                else is_global0 = true;           // sample a0-1 is global sample 0 -> NOISE
-            } else if (!global_start) {
-                Iq<DT>::load1(p.left_halo, 1, prev_c, prev_d);
-                Iq<DT>::load1(p.left_halo, 0, pc, pd);
-                have = true;
-            }
-            if (have) {
-                const float q = is_global0 ? p.noise_val : demod_one<MOD, DT>(pc, pd, prev_c, prev_d, p);
-                st = classify<ORDER2>(q, p);
-            }
-        }
+        const uint32_t st = chunk_prologue<SRC, DT, MOD, ORDER2>(p, a0, global_start, prev_c, prev_d);
         if (t == 0) {
             s_prev_state8 = st;
             s_pend_pos = -1; s_pend_state = 0; s_lead = -1; s_carry_last = 0xFFFFu; s_first_state = 0xFFFFu; s_count = 0; s_last_pos = 0;
@@ -516,63 +616,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
                     if (have_cur) load_rows<SRC, DT, FULL>(p, ta + kTile, 0, t, a1, nxt);
                 }
                 float q0[kBatch], q1[kBatch];
-                uint32_t general = 0, gated = 0;                        // per-row flags, wavefront-uniform
-                float pcs[kBatch], pds[kBatch];                         // seam operand of each row (uniform)
-#if URH_SPEC
-                if (SRC == SRC_IQ && MOD != URHGPU_MOD_OTHER) {
-                    bool flag[kBatch];
-#pragma unroll
-                    for (int j = 0; j < kBatch; ++j) {
-                        pcs[j] = prev_c; pds[j] = prev_d;
-                        flag[j] = spec_pair<MOD, DT>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
-                        if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
-                    }
-                    uint32_t bad = 0;
-#pragma unroll
-                    for (int j = 0; j < kBatch; ++j) if (__builtin_amdgcn_ballot_w64(flag[j]) != 0) bad |= 1u << j;
-                    if (__builtin_expect(bad != 0, 0)) {
-#pragma unroll 1
-                        for (int j = 0; j < kBatch; ++j) {
-                            if (!((bad >> j) & 1u)) continue;
-                            RowIn r = cur[0]; float pc = pcs[0], pd = pds[0];
-#pragma unroll
-                            for (int k = 1; k < kBatch; ++k) if (j == k) { r = cur[k]; pc = pcs[k]; pd = pds[k]; }
-                            float g0 = 0.f, g1 = 0.f;
-                            const int kind = demod_pair<MOD>(r, pc, pd, p, g0, g1);
-                            if (kind == 2) general |= 1u << j;
-                            else {
-#pragma unroll
-                                for (int k = 0; k < kBatch; ++k) if (j == k) { q0[k] = g0; q1[k] = g1; }
-                            }
-                            if (kind != 0) gated |= 1u << j;
-                        }
-                    }
-                } else
-#endif
-                {
-#pragma unroll
-                for (int j = 0; j < kBatch; ++j) {
-                    if (SRC == SRC_QAD) { q0[j] = cur[j].c0; q1[j] = cur[j].d0; gated |= 1u << j; continue; }
-                    pcs[j] = prev_c; pds[j] = prev_d;
-                    const int k = demod_pair<MOD>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
-                    if (k == 2) general |= 1u << j;
-                    if (k != 0) gated |= 1u << j;
-                    if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
-                }
-                }
-                if (MOD == URHGPU_MOD_FSK && SRC == SRC_IQ && general) {
-#pragma unroll 1
-                    for (int j = 0; j < kBatch; ++j) {
-                        if (!((general >> j) & 1u)) continue;
-                        RowIn r = cur[0]; float pc = pcs[0], pd = pds[0];
-#pragma unroll
-                        for (int k = 1; k < kBatch; ++k) if (j == k) { r = cur[k]; pc = pcs[k]; pd = pds[k]; }
-                        float g0, g1;
-                        fsk_row_general(r, pc, pd, p, g0, g1);
-#pragma unroll
-                        for (int k = 0; k < kBatch; ++k) if (j == k) { q0[k] = g0; q1[k] = g1; }
-                    }
-                }
+                const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1);
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) {
                     const int off = (rb + j) * kRowSamples + 2 * t;
@@ -749,21 +793,256 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
         ci.last_state = (uint16_t)s_carry_last;
         ci.pend_state = (uint16_t)s_pend_state;
         ci.last_pos = (int64_t)s_last_pos;
-        // initial cur_state of the reference state machine (signal_functions.pyx:421-429):
-        // PAUSE if samples[0] == NOISE else the state of the literal 0.0
-        uint32_t init = 0;
-        if (chunk == 0) {
-            bool first_is_noise;
-            if (SRC == SRC_QAD) first_is_noise = (((const float *)p.in)[0] == p.noise_val);
-            else first_is_noise = true;                            // afp_demod: result[0] = NOISE
-            init = first_is_noise ? kStPause : classify<ORDER2>(0.0f, p, false);   // literal 0.0: thresholds only
-            if (SRC == SRC_IQ && p.seg_mode) {                     // segmentation: the state of sample 0 itself
-                float c = 0.f, d = 0.f;
-                Iq<DT>::load1(p.in, 0, c, d);
-                init = classify<ORDER2>(demod_one<MOD, DT>(0.f, 0.f, c, d, p), p);
+        const uint32_t init = chunk_init_state<SRC, DT, MOD, ORDER2>(p, chunk);
+        ci.init_state = (uint16_t)init;
+        ci.first_acc = 0; ci.pend_acc = 0; ci.pend_stable = 0; ci.pad = 0;
+        p.chunks[chunk] = ci;
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// k_demod_runs_bp<SRC, DT, MOD, WRITE_QAD> -- the hot kernel for modulation order 2 (2-FSK, OOK, message
+// segmentation: the states are {PAUSE, 1, 2}), whole rows only, tolerance <= kBpMaxTol, chunks of at most 64 rows.
+//
+// Same contract as k_demod_runs (qad, slab records, ChunkInfo) with the run phase done on BIT PLANES instead of state
+// bytes in LDS: the per-sample states of a row are two compare masks per sample parity (v_cmp writes them as 64-bit
+// wavefront masks: B = "q <= threshold", P = "q == NOISE", lane t <-> samples 2t / 2t+1), parked in lane r of four
+// registers for row r.  After the chunk's last row, lane r analyses row r with 64-bit logic:
+//   boundary masks  D_even = B_e ^ (B_o << 1 | carry), D_odd = B_e ^ B_o            (either plane)
+//   stable runs     a boundary is the start of a stable run iff no boundary follows within `tol` samples: OR of
+//                   shifted copies of the 128-bit (this row : next row) boundary masks, log2(tol) steps
+//   accepted runs   walk the (few) stable bits of the row, compare with the state of the stable run before it
+//                   (ballot + shuffle over rows), wave prefix sum of the counts, write the records
+// No LDS, no per-boundary loops over the noise-induced (unstable) boundaries, ~6 VALU instructions per row instead
+// of ~45, and the state classification is the v_cmp itself.
+// -----------------------------------------------------------------------------------------------------
+constexpr int kBpMaxTol = 64;
+constexpr int kBpMaxRows = 64;
+
+struct M128 { uint64_t lo, hi; };
+__device__ __forceinline__ M128 m_shr(M128 x, int s) { return M128{(x.lo >> s) | (x.hi << (64 - s)), x.hi >> s}; }   // 0 < s < 64
+__device__ __forceinline__ M128 m_or(M128 a, M128 b) { return M128{a.lo | b.lo, a.hi | b.hi}; }
+// OR of (x >> j) for j in [0, k), 1 <= k <= 64 (wavefront-uniform k)
+__device__ __forceinline__ M128 m_smear(M128 x, int k) {
+    int have = 1;
+    while (2 * have <= k) { x = m_or(x, m_shr(x, have)); have *= 2; }
+    if (have < k) x = m_or(x, m_shr(x, k - have));
+    return x;
+}
+__device__ __forceinline__ int bp_first(uint64_t e, uint64_t o) {     // lowest sample offset set in (even, odd) masks; 256 if none
+    const int pe = e ? 2 * __builtin_ctzll(e) : 256, po = o ? 2 * __builtin_ctzll(o) + 1 : 256;
+    return pe < po ? pe : po;
+}
+__device__ __forceinline__ int bp_last(uint64_t e, uint64_t o) {      // highest sample offset set; -1 if none
+    const int pe = e ? 2 * (63 - __builtin_clzll(e)) : -1, po = o ? 2 * (63 - __builtin_clzll(o)) + 1 : -1;
+    return pe > po ? pe : po;
+}
+
+// value -> lane `row` of a register that holds one word per row (value and row are wavefront-uniform): v_writelane_b32.
+// This clang has no __builtin_amdgcn_writelane; the LLVM intrinsic is reached through its assembler name.
+extern "C" __device__ int urh_llvm_writelane_i32(int value, int lane, int old) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t put_lane(uint32_t value, int row, uint32_t old) {
+    return (uint32_t)urh_llvm_writelane_i32((int)value, row, (int)old);
+}
+
+template <int SRC, int DT, int MOD, bool WRITE_QAD>
+__global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArgs p) {
+    // One workgroup per chunk, URH_WPB wavefronts: wavefront w streams the w-th share of the chunk's rows on its own
+    // (no barrier inside the streaming phase), so that the wavefronts resident on the chip cover a NARROW window of
+    // the capture (DRAM page locality: a wavefront per 16 KiB measured 8 % faster than a wavefront per 64 KiB on a
+    // pure copy of this shape) while the per-chunk work (prologue, run phase, ChunkInfo) is paid once per 64 rows.
+    constexpr int W = URH_WPB;
+    __shared__ uint32_t s_planes[W > 1 ? 8 : 1][W > 1 ? 64 : 1];
+    const int lane = threadIdx.x & 63;
+    const int w = (W > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;     // wavefront-uniform
+    const int64_t chunk = p.chunk_base + blockIdx.x;
+    const int64_t a0 = p.range_begin + (int64_t)blockIdx.x * p.chunk_len;
+    const int64_t a1 = (a0 + p.chunk_len < p.range_end) ? a0 + p.chunk_len : p.range_end;
+    const int nr = (int)((a1 - a0) / kRowSamples);            // whole rows in this chunk: 16, 32, 48 or 64
+    const int R = nr / W;                                     // rows of this wavefront: [w R, w R + R)
+    const int r0 = w * R;
+    uint64_t *slab = p.slab + chunk * p.slab_stride;
+    const bool global_start = (p.left_halo == nullptr);
+    const bool first_row = (a0 == 0) && global_start && (w == 0);   // this wavefront holds sample 0 of the capture
+
+    // the first batch of rows is requested before the prologue's (dependent, wavefront-uniform) loads: their latency overlaps
+    constexpr int kBatch = URH_KBATCH;
+    RowIn cur[kBatch], nxt[kBatch];
+    load_rows<SRC, DT, true>(p, a0, r0, lane, a1, cur);
+
+    float prev_c = 0.f, prev_d = 0.f;                         // IQ sample before my first row (FSK seam operand)
+    uint32_t st_before = kStNone;                             // state of sample a0-1: wavefront 0 (it runs phase 2)
+    if (w == 0) st_before = chunk_prologue<SRC, DT, MOD, true>(p, a0, global_start, prev_c, prev_d);
+    else if (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK) Iq<DT>::load1(p.in, a0 + (int64_t)r0 * kRowSamples - 1, prev_c, prev_d);
+
+    // ================= phase 1: demodulate, one compare mask per plane and parity, parked in lane `row` ==============
+    uint32_t be_lo = 0, be_hi = 0, bo_lo = 0, bo_hi = 0, pe_lo = 0, pe_hi = 0, po_lo = 0, po_hi = 0;
+#pragma unroll 1
+    for (int rb = r0; rb < r0 + R; rb += kBatch) {
+        if (rb + kBatch < r0 + R) load_rows<SRC, DT, true>(p, a0, rb + kBatch, lane, a1, nxt);
+        float q0[kBatch], q1[kBatch];
+        const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1);
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+            const int off = (rb + j) * kRowSamples + 2 * lane;
+            const bool row0 = (j == 0) && (rb == 0) && first_row;
+            if (SRC == SRC_IQ) {
+                if (row0 && lane == 0 && !p.seg_mode) q0[0] = p.noise_val;            // result[0] = NOISE (:361)
+                if (WRITE_QAD) {
+#if URH_NT
+                    typedef float v2s __attribute__((ext_vector_type(2)));
+                    const v2s qq = {q0[j], q1[j]};
+                    __builtin_nontemporal_store(qq, (v2s *)(p.qad + a0 + off));
+#else
+                    *(float2 *)(p.qad + a0 + off) = make_float2(q0[j], q1[j]);
+#endif
+                }
+            }
+            uint64_t Be = __builtin_amdgcn_ballot_w64(q0[j] <= p.thr[0]), Bo = __builtin_amdgcn_ballot_w64(q1[j] <= p.thr[0]);
+            const int row = rb + j;
+            if (((gated >> j) & 1u) || row0) {                 // wavefront-uniform: some sample may be the NOISE sentinel
+                const uint64_t Pe = __builtin_amdgcn_ballot_w64(q0[j] == p.noise_val), Po = __builtin_amdgcn_ballot_w64(q1[j] == p.noise_val);
+                Be &= ~Pe; Bo &= ~Po;
+                pe_lo = put_lane((uint32_t)Pe, row, pe_lo); pe_hi = put_lane((uint32_t)(Pe >> 32), row, pe_hi);
+                po_lo = put_lane((uint32_t)Po, row, po_lo); po_hi = put_lane((uint32_t)(Po >> 32), row, po_hi);
+            }
+            be_lo = put_lane((uint32_t)Be, row, be_lo); be_hi = put_lane((uint32_t)(Be >> 32), row, be_hi);
+            bo_lo = put_lane((uint32_t)Bo, row, bo_lo); bo_hi = put_lane((uint32_t)(Bo >> 32), row, bo_hi);
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) cur[j] = nxt[j];
+    }
+
+    // the chunk's planes come together in wavefront 0 (lane r <- row r)
+    if (W > 1) {
+        if (w != 0) {
+            if (lane >= r0 && lane < r0 + R) {
+                s_planes[0][lane] = be_lo; s_planes[1][lane] = be_hi; s_planes[2][lane] = bo_lo; s_planes[3][lane] = bo_hi;
+                s_planes[4][lane] = pe_lo; s_planes[5][lane] = pe_hi; s_planes[6][lane] = po_lo; s_planes[7][lane] = po_hi;
             }
         }
-        ci.init_state = (uint16_t)init;
+        __syncthreads();
+        if (w != 0) return;
+        if (lane >= R) {
+            be_lo = s_planes[0][lane]; be_hi = s_planes[1][lane]; bo_lo = s_planes[2][lane]; bo_hi = s_planes[3][lane];
+            pe_lo = s_planes[4][lane]; pe_hi = s_planes[5][lane]; po_lo = s_planes[6][lane]; po_hi = s_planes[7][lane];
+        }
+    }
+
+    // ================= phase 2: lane r owns row r (samples [128 r, 128 r + 128) of the chunk) =====================
+    const uint64_t Be = ((uint64_t)be_hi << 32) | be_lo, Bo = ((uint64_t)bo_hi << 32) | bo_lo;
+    const uint64_t Pe = ((uint64_t)pe_hi << 32) | pe_lo, Po = ((uint64_t)po_hi << 32) | po_lo;
+    auto state_at = [&](int pos) -> uint32_t {                 // state byte of sample `pos` of my row
+        const int idx = pos >> 1;
+        const uint64_t P = (pos & 1) ? Po : Pe, B = (pos & 1) ? Bo : Be;
+        return ((P >> idx) & 1) ? kStPause : (((B >> idx) & 1) ? 1u : 2u);
+    };
+    // boundaries: sample differs from the one before it
+    uint64_t De, Do;
+    {
+        uint32_t upB = __shfl_up(bo_hi, 1) >> 31, upP = __shfl_up(po_hi, 1) >> 31;      // last sample of the row above
+        if (lane == 0) { upB = (st_before == 1u); upP = (st_before == kStPause); }
+        De = (Be ^ ((Bo << 1) | upB)) | (Pe ^ ((Po << 1) | upP));
+        if (lane == 0 && st_before == kStNone) De |= 1ull;     // the capture starts here: its first sample starts a run
+        Do = (Be ^ Bo) | (Pe ^ Po);
+        if (lane >= nr) { De = 0; Do = 0; }
+    }
+    // stable runs: no boundary within the next `tol` samples (the chunk end counts as one: what it cuts short is
+    // either truly unstable or the chunk's pending run)
+    uint64_t Se = De, So = Do;
+    if (p.tol > 0) {
+        uint64_t Ne = __shfl_down((unsigned long long)De, 1), No = __shfl_down((unsigned long long)Do, 1);
+        if (lane >= nr - 1) { Ne = (lane == nr - 1) ? 1ull : 0ull; No = 0; }
+        const int ke = p.tol >> 1, ko = (p.tol + 1) >> 1;     // samples p+1..p+tol: ke / ko of each parity
+        const M128 Xe{De, Ne}, Xo{Do, No};
+        M128 e_ke{0, 0}, o_ke{0, 0}, e_ko = Xe, o_ko = Xo;
+        if (ke > 0) {
+            e_ke = m_smear(Xe, ke); o_ke = m_smear(Xo, ke);
+            e_ko = e_ke; o_ko = o_ke;
+            if (ko > ke) { e_ko = m_or(e_ke, m_shr(Xe, ke)); o_ko = m_or(o_ke, m_shr(Xo, ke)); }
+        }
+        const uint64_t near_e = o_ko.lo | m_shr(e_ke, 1).lo;           // after an even sample: odd idx t..t+ko-1, even idx t+1..t+ke
+        const uint64_t near_o = m_shr(e_ko, 1).lo | m_shr(o_ke, 1).lo; // after an odd sample: even idx t+1..t+ko, odd idx t+1..t+ke
+        Se = De & ~near_e; So = Do & ~near_o;
+    }
+    // chunk-level facts: lead (offset of the first boundary), the pending run (last boundary within tol of the end)
+    int64_t lead = a1 - a0;
+    {
+        const uint64_t bm = __builtin_amdgcn_ballot_w64((De | Do) != 0);
+        if (bm) {
+            const int fl = __builtin_ctzll(bm);
+            lead = (int64_t)fl * kRowSamples + __builtin_amdgcn_readlane(bp_first(De, Do), fl);
+        }
+    }
+    int64_t pend_pos = -1; uint32_t pend_state = 0;
+    {
+        const int lp = bp_last(De, Do);
+        const uint32_t ls = state_at(lp < 0 ? 0 : lp);
+        const int lpu = __builtin_amdgcn_readlane(lp, nr - 1);
+        const uint32_t lsu = __builtin_amdgcn_readlane(ls, nr - 1);
+        if (lpu >= 0 && kRowSamples - lpu <= p.tol) { pend_pos = a0 + (int64_t)(nr - 1) * kRowSamples + lpu; pend_state = lsu; }
+    }
+    // accepted runs: stable runs whose state differs from the stable run before them
+    const bool has = (Se | So) != 0;
+    const int hp = bp_last(Se, So);
+    const uint32_t my_last = has ? state_at(hp) : 0xFFFFu;
+    const uint64_t hm = __builtin_amdgcn_ballot_w64(has);
+    uint32_t prev;
+    {
+        const uint64_t lower = hm & ((1ull << lane) - 1ull);
+        const int src = lower ? 63 - __builtin_clzll(lower) : 0;
+        const uint32_t from_lane = __shfl(my_last, src);
+        prev = lower ? from_lane : 0xFFFFu;
+    }
+    uint64_t ae = 0, ao = 0;
+    int cnt = 0, last_acc = -1;
+    uint32_t first_acc_state = 0;
+    {
+        uint64_t se = Se, so = So;
+        while (se | so) {
+            const int pos = bp_first(se, so);
+            const uint32_t st = state_at(pos);
+            if (st != prev) {
+                if (cnt == 0) first_acc_state = st;
+                if (pos & 1) ao |= 1ull << (pos >> 1); else ae |= 1ull << (pos >> 1);
+                ++cnt; last_acc = pos;
+            }
+            prev = st;
+            if (pos & 1) so &= so - 1; else se &= se - 1;
+        }
+    }
+    const int incl = wave_incl_scan(cnt, lane);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    {
+        int o = incl - cnt;
+        const int64_t base = p.pos_base + a0 + (int64_t)lane * kRowSamples;
+        while (ae | ao) {
+            const int pos = bp_first(ae, ao);
+            slab[o++] = rec_make(base + pos, state_at(pos));
+            if (pos & 1) ao &= ao - 1; else ae &= ae - 1;
+        }
+    }
+    const uint64_t am = __builtin_amdgcn_ballot_w64(cnt > 0);
+    uint32_t first_state = 0xFFFFu; int64_t last_pos = 0;
+    if (am) {
+        const int fl = __builtin_ctzll(am), ll = 63 - __builtin_clzll(am);
+        first_state = __builtin_amdgcn_readlane(first_acc_state, fl);
+        last_pos = p.pos_base + a0 + (int64_t)ll * kRowSamples + __builtin_amdgcn_readlane(last_acc, ll);
+    }
+    const uint32_t last_state = hm ? (uint32_t)__builtin_amdgcn_readlane(my_last, 63 - __builtin_clzll(hm)) : 0xFFFFu;
+
+    if (lane == 0) {
+        ChunkInfo ci;
+        ci.pend_pos = (pend_pos >= 0) ? pend_pos + p.pos_base : -1;
+        ci.start = p.pos_base + a0;
+        ci.len = a1 - a0;
+        ci.lead = lead;
+        ci.cnt = total;
+        ci.first_state = (uint16_t)first_state;
+        ci.last_state = (uint16_t)last_state;
+        ci.pend_state = (uint16_t)pend_state;
+        ci.last_pos = last_pos;
+        ci.init_state = (uint16_t)chunk_init_state<SRC, DT, MOD, true>(p, chunk);
         ci.first_acc = 0; ci.pend_acc = 0; ci.pend_stable = 0; ci.pad = 0;
         p.chunks[chunk] = ci;
     }
@@ -835,6 +1114,9 @@ __global__ void k_test_atan2f(const float *y, const float *x, int64_t n, float *
 }
 
 // ---- host-side launchers ---------------------------------------------------------------------------
+// test hook (urhgpu_test_force_state_bytes): route order-2 work through the state-byte kernel as well
+bool g_force_state_bytes = false;
+
 // `a` describes the whole capture (a.n samples, chunk table / slab for n_main + has_tail chunks):
 // one launch over the whole tiles, one one-workgroup launch for the partial tile at the end.
 template <int SRC, int DT, int MOD, bool O2, bool WQ>
@@ -847,7 +1129,11 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
     const int64_t c_lo = (part == 1) ? 1 : 0, c_hi = (part == 2) ? std::min<int64_t>(n_main, 1) : n_main;
     if (c_hi > c_lo) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
-        hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock), 0, s, a);
+        // order 2 (states PAUSE/1/2): the bit-plane kernel; anything else: the state-byte kernel
+        if (URH_BITPLANE && O2 && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes)
+            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * URH_WPB), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock), 0, s, a);
     }
     const bool tail_is_first = (n_main == 0);                 // a capture shorter than one tile: its only chunk
     if (n_full < a.n && ((part == 0) || (part == 1 && !tail_is_first) || (part == 2 && tail_is_first))) {

@@ -32,6 +32,7 @@ struct RunArgs {
                              // ordinary sample (no result[0] = NOISE) and the state machine starts in ITS state
     float thr[kMaxOrder - 1];
 };
+extern bool g_force_state_bytes;   // test hook: order 2 through the state-byte kernel too
 int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s);
 int launch_runs_qad(const RunArgs &a, hipStream_t s);
 int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t s);
