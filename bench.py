@@ -10,7 +10,7 @@ bit_sample_pos, everything left in device memory.  Workload at N=1: BASELINE.jso
 1 GiB sample-contiguous shard of one N-GiB capture (weak scaling, configs[3] at N=8).
 
 Prints ONE JSON line on rank 0 (see the driver contract) with two extra objects:
-  roofline      the dominant kernel (k_demod_runs: demodulation + run segmentation) against HBM peak;
+  roofline      the dominant kernel (k_demod_runs_bp: demodulation + run segmentation) against HBM peak;
                 achieved = algorithmic bytes (12 B/sample) / mean kernel time measured with HIP events
                 on the launch stream inside the timed region
   cpu_baseline  the reference's own Cython kernels (oracle/_ref, built from /root/reference) when they
@@ -175,7 +175,7 @@ def main():
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         bytes_per_sample = ALGO_BYTES_PER_SAMPLE if want_qad else 8
         achieved = (n * bytes_per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, traffic_src = (pmc_traffic("k_demod_runs<0, 4, 1, true, true, true>") if want_qad and n == 128 * SEG
+        traffic, traffic_src = (pmc_traffic("k_demod_runs_bp<0, 4, 1, true>") if want_qad and n == 128 * SEG
                                 else (None, None))
         out = {
             "metric": "Msamples/s IQ->bits (1 GiB complex64 2-FSK per GPU, qad materialised)",
@@ -188,7 +188,7 @@ def main():
                        "outputs": "qad+ppseq+bits+pauses+bit_sample_pos" if want_qad else "ppseq+bits+pauses+bit_sample_pos",
                        "rows": counts[0], "messages": counts[1], "bits": counts[2],
                        "steps_pipelined": args.pipeline, "single_step_latency_ms": round(latency_ms, 4)},
-            "roofline": {"bound": "hbm", "kernel": "k_demod_runs", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_demod_runs_bp", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": n * bytes_per_sample,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_sample": bytes_per_sample,
