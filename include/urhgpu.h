@@ -286,6 +286,23 @@ int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);
 
+/* signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK (GFSK / OQPSK: URHGPU_ERR_UNSUPPORTED),
+ * n_msgs messages rendered back to back by one launch (URH modulates message by message, Modulator.py:215-255):
+ * message m has bits[bit_off[m] .. bit_off[m+1]), is followed by pause[m] zero samples and starts at sample index start[m]
+ * (the time origin of its carrier).  parameters: 2^bits_per_symbol amplitudes / frequencies / phases as the reference takes
+ * them.  dtype: URHGPU_DT_F32 / _I8 / _I16 (get_numpy_dtype, :46-54; anything else URHGPU_ERR_DTYPE).  All pointers are HOST
+ * pointers except d_out (device, (cap_samples, 2) of dtype); *total_samples = sum over m of
+ * (n_bits_m / bits_per_symbol) * samples_per_symbol + pause[m]; more than cap_samples: URHGPU_ERR_CAPACITY, nothing written.
+ * Asynchronous on the context's stream. */
+int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit_off, const uint32_t *pause, const uint32_t *start,
+                        int n_msgs, uint32_t samples_per_symbol, int mod, const float *parameters, int bits_per_symbol,
+                        float carrier_amplitude, float carrier_frequency, float carrier_phase, float sample_rate, int dtype,
+                        void *d_out, int64_t cap_samples, int64_t *total_samples);
+/* One message, host output: exactly modulate_c's signature; out holds ((num_bits / bits_per_symbol) * samples_per_symbol + pause, 2). */
+int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint32_t samples_per_symbol, int mod,
+                    const float *parameters, int bits_per_symbol, float carrier_amplitude, float carrier_frequency,
+                    float carrier_phase, float sample_rate, uint32_t pause, uint32_t start, int dtype, void *out);
+
 /* Test hook: modulation order 2 (2-FSK, OOK, message segmentation) normally runs the bit-plane kernel
  * (k_demod_runs_bp) and every other order the state-byte kernel (k_demod_runs); on != 0 routes order 2 through the
  * state-byte kernel as well, so that tests can compare the two on the same input.  Process-wide. */

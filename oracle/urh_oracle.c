@@ -365,3 +365,62 @@ int64_t orc_ppseq_to_bits(const int64_t *ppseq, int64_t nrows, int64_t samples_p
 void orc_atan2f_array(const float *y, const float *x, int64_t n, float *out) {
     for (int64_t i = 0; i < n; i++) out[i] = atan2f(y[i], x[i]);
 }
+
+/* ---- modulate_c  (signal_functions.pyx:56-177; rows of SURVEY.md §8f rank 2) --------------------------------
+ * ASK / FSK / PSK.  (GFSK goes through numpy's float32 convolve and OQPSK is marked "does not work correctly"
+ * in the reference, :179-180; neither is restated.)  Types as in the generated C++:
+ *   t             = (float)(i + start) / sample_rate                                         (:160)
+ *   current_arg   = (float)((((2.0*M_PI) * f) * t + phi) + phase_correction)   in double      (:164)
+ *   out           = (iq)(a * cosf(current_arg)), (iq)(a * sinf(current_arg))                  (:165-166)
+ *   FSK phase corrections (:121-137): serial over the symbols,
+ *     t = (float)((s_i*sps + start) - 1) / sample_rate;  pc[s] = (float)fmod(pc[s-1] + ((2.0*M_PI)*(f_prev - f))*t, 2.0*M_PI)
+ * out: total_symbols*sps + pause samples (x2), zero where nothing is written.  Returns the sample count, -1 on an
+ * unsupported modulation.  dt: DT_I8 / DT_I16 / DT_F32 (get_numpy_dtype, :46-54). */
+static uint64_t bits_to_number(const uint8_t *bits, int64_t start, int64_t end) {   /* util.pyx:50-61 */
+    uint64_t r = 0;
+    for (int64_t i = start; i < end; ++i) r = (r << 1) + bits[i];
+    return r;
+}
+static void store_iq(void *out, int dt, int64_t idx, float v) {
+    if (dt == DT_F32) ((float *)out)[idx] = v;
+    else if (dt == DT_I8) ((int8_t *)out)[idx] = (int8_t)v;
+    else ((int16_t *)out)[idx] = (int16_t)v;
+}
+int64_t orc_modulate(const uint8_t *bits, int64_t num_bits, uint32_t sps, int mod, const float *parameters,
+                     int bits_per_symbol, float carrier_amplitude, float carrier_frequency, float carrier_phase,
+                     float sample_rate, uint32_t pause, uint32_t start, int dt, void *out) {
+    if (mod != MOD_ASK && mod != MOD_FSK && mod != MOD_PSK) return -1;
+    const uint32_t total_symbols = (uint32_t)(num_bits / bits_per_symbol);
+    const int64_t total_samples = (int64_t)total_symbols * sps + pause;
+    const int esz = dt == DT_F32 ? 4 : (dt == DT_I8 ? 1 : 2);
+    memset(out, 0, (size_t)total_samples * 2 * esz);
+    if (num_bits == 0) return total_samples;
+    float *pc = NULL;
+    if (mod == MOD_FSK && total_symbols > 0) {
+        pc = (float *)malloc((size_t)total_symbols * sizeof(float));
+        pc[0] = 0.0f;
+        for (int64_t s = 1; s < total_symbols; ++s) {
+            const float f = parameters[bits_to_number(bits, s * bits_per_symbol, (s + 1) * bits_per_symbol)];
+            const float fp = parameters[bits_to_number(bits, (s - 1) * bits_per_symbol, s * bits_per_symbol)];
+            if (f != fp) {
+                const float t = ((float)(((s * (int64_t)sps) + (int64_t)start) - 1)) / sample_rate;
+                pc[s] = (float)fmod(pc[s - 1] + (((2.0 * M_PI) * (fp - f)) * t), 2.0 * M_PI);
+            } else pc[s] = pc[s - 1];
+        }
+    }
+    for (int64_t s = 0; s < total_symbols; ++s) {
+        const uint64_t index = bits_to_number(bits, s * bits_per_symbol, (s + 1) * bits_per_symbol);
+        float a = carrier_amplitude, f = carrier_frequency, phi = carrier_phase, corr = 0;
+        if (mod == MOD_ASK) { a = parameters[index]; if (a == 0) continue; }
+        else if (mod == MOD_FSK) { f = parameters[index]; corr = pc[s]; }
+        else phi = parameters[index];
+        for (int64_t i = s * (int64_t)sps; i < (s + 1) * (int64_t)sps; ++i) {
+            const float t = ((float)(i + (int64_t)start)) / sample_rate;
+            const float arg = (float)(((((2.0 * M_PI) * f) * t) + phi) + corr);
+            store_iq(out, dt, 2 * i, a * cosf(arg));
+            store_iq(out, dt, 2 * i + 1, a * sinf(arg));
+        }
+    }
+    free(pc);
+    return total_samples;
+}

@@ -41,6 +41,7 @@ def lib():
         _lib.orc_grab_pulse_lens.restype = C.c_int64
         _lib.orc_ppseq_to_bits.restype = C.c_int64
         _lib.orc_afp_demod.restype = C.c_int
+        _lib.orc_modulate.restype = C.c_int64
     return _lib
 
 
@@ -290,3 +291,25 @@ def get_plateau_lengths(rect_data, center, percentage=25) -> np.ndarray:
             state = new_state
             plateau_length = 1
     return np.array(result, dtype=np.uint64)
+
+
+def modulate_c(bits, samples_per_symbol: int, modulation_type: str, parameters, bits_per_symbol: int,
+               carrier_amplitude: float, carrier_frequency: float, carrier_phase: float, sample_rate: float,
+               pause: int, start: int, dtype=np.float32, gauss_bt: float = 0.5, filter_width: float = 1.0) -> np.ndarray:
+    """signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK."""
+    mod = modulation_type.upper()
+    if mod not in MOD_CODES:
+        raise NotImplementedError(modulation_type)
+    dt = np.dtype(dtype)
+    if dt not in (np.dtype(np.int8), np.dtype(np.int16), np.dtype(np.float32)):
+        raise ValueError("Unsupported dtype for modulation {}".format(dtype))
+    b = np.ascontiguousarray(np.frombuffer(bytes(bytearray(bits)), dtype=np.uint8) if not isinstance(bits, np.ndarray) else bits, dtype=np.uint8)
+    par = np.ascontiguousarray(parameters, dtype=np.float32)
+    total = (len(b) // bits_per_symbol) * samples_per_symbol + pause
+    out = np.zeros((total, 2), dtype=dt)
+    k = lib().orc_modulate(b.ctypes.data_as(C.c_void_p), C.c_int64(len(b)), C.c_uint32(samples_per_symbol), MOD_CODES[mod],
+                           par.ctypes.data_as(C.c_void_p), C.c_int(bits_per_symbol), C.c_float(carrier_amplitude),
+                           C.c_float(carrier_frequency), C.c_float(carrier_phase), C.c_float(sample_rate), C.c_uint32(pause),
+                           C.c_uint32(start), DT_CODES[dt], out.ctypes.data_as(C.c_void_p))
+    assert k == total
+    return out

@@ -1,0 +1,52 @@
+"""urh_amd/csrc/glibc_sincosf.h (the restatement the Costas and modulation kernels use) is bit-identical to the host
+libm's sinf / cosf -- the functions the reference calls (signal_functions.pyx:165-166, :301) -- on small, medium and
+large (reduce_large) arguments.  The FMA build of glibc (selected by ifunc on every host with FMA + AVX2) contracts
+a + b*c: when the host has no FMA the header's non-FMA evaluation is compared instead."""
+import os
+import subprocess
+import tempfile
+
+from conftest import ROOT
+
+SRC = r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <string.h>
+#include <stdint.h>
+#define URH_SINCOSF_FMA %d
+#include "%s"
+static inline uint64_t sm(uint64_t *s){ uint64_t z=(*s+=0x9e3779b97f4a7c15ULL); z=(z^(z>>30))*0xbf58476d1ce4e5b9ULL; z=(z^(z>>27))*0x94d049bb133111ebULL; return z^(z>>31);}
+static inline float u2f(uint32_t u){ float f; memcpy(&f,&u,4); return f; }
+int main(int argc,char**argv){ long n=atol(argv[1]); long bad=0;
+  #pragma omp parallel for reduction(+:bad)
+  for(long t=0;t<64;t++){ uint64_t s=1234+t*7919;
+    for(long i=0;i<n/64;i++){ uint64_t r=sm(&s); uint32_t a=(uint32_t)r, b=(uint32_t)(r>>32); float x; int mode=i&3;
+      if(mode==0) x=u2f(a);                                              /* any bit pattern */
+      else if(mode==1) x=((int32_t)a)/2147483648.0f*130.0f;              /* around the fast / large switch */
+      else if(mode==2) x=((int32_t)a)/2147483648.0f*2.0e5f;              /* the carrier arguments of modulate_c */
+      else x=u2f((a&0x807fffffu)|(((b>>7)%%60+120)<<23));               /* 2^-7 .. 2^52 */
+      float r1=sinf(x), r2=urh_sinf(x); if(memcmp(&r1,&r2,4)!=0 && !(r1!=r1 && r2!=r2)) bad++;
+      float q1=cosf(x), q2=urh_cosf(x); if(memcmp(&q1,&q2,4)!=0 && !(q1!=q1 && q2!=q2)) bad++; }}
+  printf("%%ld\n",bad); return 0; }
+'''
+
+
+def host_has_fma():
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return True
+    return " fma " in flags and " avx2 " in flags
+
+
+def test_port_equals_libm():
+    hdr = os.path.join(ROOT, "urh_amd", "csrc", "glibc_sincosf.h")
+    fma = 1 if host_has_fma() else 0
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "chk.c")
+        open(c, "w").write(SRC % (fma, hdr))
+        exe = os.path.join(d, "chk")
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp"] + (["-mfma"] if fma else []) + [c, "-o", exe, "-lm"])
+        out = subprocess.check_output([exe, "64000000"]).decode().strip()
+    assert out == "0", f"{out} mismatches against libm"

@@ -836,6 +836,81 @@ int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint
     return URHGPU_OK;
 }
 
+static int stage_in(urhgpu_ctx *ctx, const void *host, size_t bytes, void **dev);
+
+int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit_off, const uint32_t *pause, const uint32_t *start,
+                        int n_msgs, uint32_t samples_per_symbol, int mod, const float *parameters, int bits_per_symbol,
+                        float carrier_amplitude, float carrier_frequency, float carrier_phase, float sample_rate, int dtype,
+                        void *d_out, int64_t cap_samples, int64_t *total_samples) {
+    if (!ctx || n_msgs < 0 || !total_samples || (n_msgs > 0 && (!bit_off || !pause || !start || !parameters))) return URHGPU_ERR_ARG;
+    if (mod != URHGPU_MOD_ASK && mod != URHGPU_MOD_FSK && mod != URHGPU_MOD_PSK) return URHGPU_ERR_UNSUPPORTED;
+    if (dtype != URHGPU_DT_F32 && dtype != URHGPU_DT_I8 && dtype != URHGPU_DT_I16) return URHGPU_ERR_DTYPE;
+    if (bits_per_symbol < 1 || bits_per_symbol > 16 || samples_per_symbol == 0 || n_msgs > 65535) return URHGPU_ERR_UNSUPPORTED;
+    std::vector<ModMsg> msgs((size_t)n_msgs);
+    int64_t total = 0, total_sym = 0, max_samples = 0;
+    for (int m = 0; m < n_msgs; ++m) {
+        const int64_t nb = bit_off[m + 1] - bit_off[m];
+        if (nb < 0) return URHGPU_ERR_ARG;
+        ModMsg &g = msgs[(size_t)m];
+        g.bit_off = bit_off[m]; g.n_sym = nb / bits_per_symbol; g.sym_off = total_sym; g.out_off = total;
+        g.pause = pause[m]; g.start = start[m];
+        const int64_t ns = g.n_sym * (int64_t)samples_per_symbol + pause[m];
+        total += ns; total_sym += g.n_sym;
+        max_samples = std::max(max_samples, ns);
+    }
+    *total_samples = total;
+    if (total > cap_samples) return URHGPU_ERR_CAPACITY;
+    if (total == 0) return URHGPU_OK;
+    if (!d_out || !bits) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    const int64_t n_bits = bit_off[n_msgs];
+    const size_t n_par = (size_t)1 << bits_per_symbol;
+    URH_TRY(ctx->staging.reserve(align256((size_t)std::max<int64_t>(n_bits, 1)) + align256(msgs.size() * sizeof(ModMsg)) +
+                                 align256(n_par * 4) + align256((size_t)std::max<int64_t>(total_sym, 1) * 4) + 2048));
+    ctx->staging.reset();
+    void *d_bits = nullptr, *d_msgs = nullptr, *d_par = nullptr;
+    URH_TRY(stage_in(ctx, bits, (size_t)n_bits, &d_bits));
+    URH_TRY(stage_in(ctx, msgs.data(), msgs.size() * sizeof(ModMsg), &d_msgs));
+    URH_TRY(stage_in(ctx, parameters, n_par * 4, &d_par));
+    float *d_phase = (float *)ctx->staging.take((size_t)std::max<int64_t>(total_sym, 1) * 4);
+    if (!d_phase) return URHGPU_ERR_ARG;
+    ModArgs a;
+    a.bits = (const uint8_t *)d_bits; a.msgs = (const ModMsg *)d_msgs; a.params = (const float *)d_par; a.phase = d_phase;
+    a.out = d_out; a.n_msgs = n_msgs; a.mod = mod; a.dtype = dtype; a.bps = bits_per_symbol; a.sps = samples_per_symbol;
+    a.carrier_amplitude = carrier_amplitude; a.carrier_frequency = carrier_frequency; a.carrier_phase = carrier_phase;
+    a.sample_rate = sample_rate;
+    URH_TRY(launch_modulate(a, max_samples, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint32_t samples_per_symbol, int mod,
+                    const float *parameters, int bits_per_symbol, float carrier_amplitude, float carrier_frequency,
+                    float carrier_phase, float sample_rate, uint32_t pause, uint32_t start, int dtype, void *out) {
+    if (!ctx || num_bits < 0 || bits_per_symbol < 1) return URHGPU_ERR_ARG;
+    if (dtype != URHGPU_DT_F32 && dtype != URHGPU_DT_I8 && dtype != URHGPU_DT_I16) return URHGPU_ERR_DTYPE;
+    const int64_t total = (num_bits / bits_per_symbol) * (int64_t)samples_per_symbol + pause;
+    if (total == 0) return URHGPU_OK;
+    if (!out) return URHGPU_ERR_ARG;
+    const size_t bytes = (size_t)total * 2 * (dtype == URHGPU_DT_F32 ? 4 : (dtype == URHGPU_DT_I8 ? 1 : 2));
+    if (num_bits == 0) { memset(out, 0, bytes); return URHGPU_OK; }             // np.zeros, :104-106
+    URH_HIP(hipSetDevice(ctx->device));
+    void *d_out = nullptr;                                 // not from the staging arena: urhgpu_modulate_dev resets it
+    URH_HIP(hipMalloc(&d_out, bytes));
+    const int64_t off[2] = {0, num_bits};
+    int64_t got = 0;
+    int st = urhgpu_modulate_dev(ctx, bits, off, &pause, &start, 1, samples_per_symbol, mod, parameters, bits_per_symbol,
+                                 carrier_amplitude, carrier_frequency, carrier_phase, sample_rate, dtype, d_out, total, &got);
+    if (st == URHGPU_OK) {
+        hipError_t e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = urh::hip_fail(e, "modulate D2H", __FILE__, __LINE__);
+    }
+    (void)hipFree(d_out);
+    return st;
+}
+
 int urhgpu_test_force_state_bytes(int on) {
     urh::g_force_state_bytes = (on != 0);
     return URHGPU_OK;

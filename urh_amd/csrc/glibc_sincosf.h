@@ -10,8 +10,10 @@
 // with -mfma (`__sinf_fma`, chosen on every CPU with FMA+AVX2), in which GCC contracts every a + b*c into an fma:
 // URH_SINCOSF_FMA selects that evaluation (default 1: all hosts of interest have FMA).  The two differ in the
 // rounded float for about one input in 10^9.
-// Only |x| < 120 is restated (fast reduction): the Costas phase is kept within +-2*pi.  Larger arguments return
-// NaN through urh_sincosf_unsupported so that a misuse cannot go unnoticed.
+// |x| < 120 takes the fast reduction (the Costas phase is kept within +-2*pi); larger finite arguments -- the carrier
+// argument 2*pi*f*t of modulate_c (signal_functions.pyx:159-166) reaches 10^5 rad -- take glibc's reduce_large: a
+// 32x96-bit fixed-point multiply with 4/pi (table __inv_pio4: 4/pi in 8-bit steps, recomputed here from pi with integer
+// arithmetic and checked against the host libm by tests/test_sincosf_port.py).  inf / NaN return NaN.
 // Constants are the published ones of ARM optimized-routines (MIT licence) as shipped in glibc.
 #pragma once
 #include <stdint.h>
@@ -75,8 +77,30 @@ URH_SC_HD double urh_sc_reduce_fast(double x, int *np) {
 #endif
 }
 
-URH_SC_HD float urh_sincosf_unsupported(void) {
+URH_SC_HD float urh_sincosf_invalid(void) {
     union { uint32_t u; float f; } v; v.u = 0x7fc00000u; return v.f;
+}
+
+// reduce_large: xi = bits of a float with |x| >= 2; returns x mod pi/2 in [-pi/4, pi/4] and the quadrant
+URH_SC_HD double urh_sc_reduce_large(uint32_t xi, int *np) {
+    const uint32_t inv_pio4[24] = {0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529,
+                                   0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1, 0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0,
+                                   0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041};
+    const double pi63 = 0x1.921FB54442D18p-62;             // 2 pi * 2^-64
+    const uint32_t *arr = &inv_pio4[(xi >> 26) & 15];
+    const int shift = (xi >> 23) & 7;
+    uint64_t n, res0, res1, res2;
+    xi = (xi & 0xffffff) | 0x800000;
+    xi <<= shift;
+    res0 = (uint32_t)(xi * arr[0]);                        // 32-bit product (the reference multiplies two uint32_t)
+    res1 = (uint64_t)xi * arr[4];
+    res2 = (uint64_t)xi * arr[8];
+    res0 = (res2 >> 32) | (res0 << 32);
+    res0 += res1;
+    n = (res0 + (1ULL << 61)) >> 62;
+    res0 -= n << 62;
+    *np = (int)n;
+    return (double)(int64_t)res0 * pi63;
 }
 
 URH_SC_HD float urh_sinf(float y) {
@@ -92,7 +116,16 @@ URH_SC_HD float urh_sinf(float y) {
         const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;     // sign[] = {1, -1, -1, 1}
         return urh_sinf_poly(x * s, x * x, (n & 2) != 0, n);
     }
-    return urh_sincosf_unsupported();
+    if (urh_sc_abstop12(y) < 0x7f8) {                       // finite
+        union { float f; uint32_t u; } v; v.f = y;
+        const int sign = (int)(v.u >> 31);
+        int n;
+        x = urh_sc_reduce_large(v.u, &n);
+        const int k = (n + sign) & 3;
+        const double s = (k == 1 || k == 2) ? -1.0 : 1.0;
+        return urh_sinf_poly(x * s, x * x, (k & 2) != 0, n);
+    }
+    return urh_sincosf_invalid();
 }
 
 URH_SC_HD float urh_cosf(float y) {
@@ -108,5 +141,12 @@ URH_SC_HD float urh_cosf(float y) {
         const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
         return urh_sinf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
     }
-    return urh_sincosf_unsupported();
+    if (urh_sc_abstop12(y) < 0x7f8) {
+        union { float f; uint32_t u; } v; v.f = y;
+        int n;
+        x = urh_sc_reduce_large(v.u, &n);                   // cosine is even: the sign of y is ignored
+        const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+        return urh_sinf_poly(x * s, x * x, (n & 2) != 0, n ^ 1);
+    }
+    return urh_sincosf_invalid();
 }

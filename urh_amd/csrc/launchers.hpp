@@ -39,6 +39,27 @@ int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t
 void launch_test_div(uint64_t seed, int reps, unsigned long long *d_mismatches, hipStream_t s);
 void launch_test_atan2f(const float *y, const float *x, int64_t n, float *out, hipStream_t s);
 
+// ---- modulate.hip ------------------------------------------------------------------------------------
+struct ModMsg {              // one message of a modulate batch
+    int64_t bit_off;         // first bit in bits[]
+    int64_t n_sym;           // symbols (= bits // bits_per_symbol)
+    int64_t sym_off;         // first entry in phase[] (FSK)
+    int64_t out_off;         // first output sample
+    uint32_t pause;          // silent samples after the symbols
+    uint32_t start;          // sample index of the message's first sample (time origin of the carrier)
+};
+struct ModArgs {
+    const uint8_t *bits;     // device: all messages' bits back to back
+    const ModMsg *msgs;      // device
+    const float *params;     // device: 2^bits_per_symbol amplitudes / frequencies / phases
+    float *phase;            // device scratch: one float per symbol (FSK)
+    void *out;               // device: (total samples, 2) of dtype
+    int n_msgs, mod, dtype, bps;
+    uint32_t sps;
+    float carrier_amplitude, carrier_frequency, carrier_phase, sample_rate;
+};
+int launch_modulate(const ModArgs &a, int64_t max_samples, hipStream_t s);
+
 // ---- bandpass.hip ------------------------------------------------------------------------------------
 int launch_bandpass(const float2 *x, int64_t n, const float2 *left, int64_t n_left, const float2 *right, int64_t n_right,
                     const double2 *taps, int m, int64_t shift, int64_t n_out, double2 *out128, float2 *out64, hipStream_t s);

@@ -176,3 +176,88 @@ def iir_filter(a, b, signal, ctx=None) -> np.ndarray:
     ctx = ctx or _lib.default_context()
     _lib.check(_lib.load().urhgpu_iir_filter(ctx.handle, _vp(a), len(a), _vp(b), len(b), _vp(x), len(x), _vp(out)))
     return out
+
+
+def _bits_u8(bits) -> np.ndarray:
+    if isinstance(bits, np.ndarray):
+        return np.ascontiguousarray(bits, dtype=np.uint8)
+    if isinstance(bits, str):
+        return np.frombuffer(bytes(map(int, bits)), dtype=np.uint8).copy()
+    return np.frombuffer(bytes(bytearray(bits)), dtype=np.uint8).copy()
+
+
+_MOD_DTYPES = {np.dtype(np.int8): _lib.DT_I8, np.dtype(np.int16): _lib.DT_I16, np.dtype(np.float32): _lib.DT_F32}
+
+
+def _modulation_code(modulation_type: str) -> int:
+    m = modulation_type.lower()                      # the reference compares lower-case names (:111-115)
+    if m in ("ask", "fsk", "psk"):
+        return _MOD[m.upper()]
+    if m in ("gfsk", "oqpsk"):
+        raise NotImplementedError(f"{modulation_type}: only ASK / FSK / PSK are generated on the GPU")
+    raise AssertionError(modulation_type)            # `assert is_fsk or is_ask or ...` (:117)
+
+
+def modulate_c(bits, samples_per_symbol: int, modulation_type: str, parameters, bits_per_symbol: int,
+               carrier_amplitude: float, carrier_frequency: float, carrier_phase: float, sample_rate: float,
+               pause: int, start: int, dtype=np.float32, gauss_bt: float = 0.5, filter_width: float = 1.0,
+               ctx=None) -> np.ndarray:
+    """signal_functions.modulate_c (signal_functions.pyx:56-177): bits -> (N, 2) IQ samples of `dtype`
+    (np.float32 / np.int8 / np.int16), N = len(bits) // bits_per_symbol * samples_per_symbol + pause."""
+    dt = np.dtype(dtype)
+    if dt not in _MOD_DTYPES:
+        raise ValueError("Unsupported dtype for modulation {}".format(dtype))
+    b = _bits_u8(bits)
+    total = (len(b) // int(bits_per_symbol)) * int(samples_per_symbol) + int(pause)
+    out = np.zeros((total, 2), dtype=dt)
+    if len(b) == 0 or total == 0:
+        return out
+    mod = _modulation_code(modulation_type)
+    par = np.ascontiguousarray(parameters, dtype=np.float32)
+    if len(par) < (1 << int(bits_per_symbol)):
+        raise IndexError("parameters shorter than 2**bits_per_symbol")
+    ctx = ctx or _lib.default_context()
+    _lib.check(_lib.load().urhgpu_modulate(ctx.handle, _vp(b), len(b), int(samples_per_symbol), mod, _vp(par),
+                                           int(bits_per_symbol), float(carrier_amplitude), float(carrier_frequency),
+                                           float(carrier_phase), float(sample_rate), int(pause), int(start),
+                                           _MOD_DTYPES[dt], _vp(out)))
+    return out
+
+
+def modulate_messages_dev(messages, samples_per_symbol: int, modulation_type: str, parameters, bits_per_symbol: int,
+                          carrier_amplitude: float, carrier_frequency: float, carrier_phase: float, sample_rate: float,
+                          pauses, starts=None, dtype=np.float32, device=None, ctx=None):
+    """Many messages rendered back to back by one launch, result left in HBM: a torch tensor (N, 2) of `dtype`.
+    messages: sequence of bit sequences; pauses[m] silent samples follow message m; starts[m] is the sample index of
+    its first sample (default: consecutive, as ProtocolAnalyzerContainer.modulate places them)."""
+    import torch
+    dt = np.dtype(dtype)
+    if dt not in _MOD_DTYPES:
+        raise ValueError("Unsupported dtype for modulation {}".format(dtype))
+    mod = _modulation_code(modulation_type)
+    bl = [_bits_u8(m) for m in messages]
+    off = np.zeros(len(bl) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(x) for x in bl])
+    allbits = np.concatenate(bl) if bl else np.zeros(0, np.uint8)
+    pa = np.ascontiguousarray(pauses, dtype=np.uint32)
+    lens = np.array([(len(x) // int(bits_per_symbol)) * int(samples_per_symbol) for x in bl], dtype=np.int64) + pa
+    if starts is None:
+        st = np.zeros(len(bl), dtype=np.int64)
+        st[1:] = np.cumsum(lens)[:-1]
+    else:
+        st = np.asarray(starts, dtype=np.int64)
+    st = np.ascontiguousarray(st, dtype=np.uint32)
+    total = int(lens.sum())
+    par = np.ascontiguousarray(parameters, dtype=np.float32)
+    ctx = ctx or _lib.default_context()
+    tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.int8): torch.int8, np.dtype(np.int16): torch.int16}[dt]
+    out = torch.empty((total, 2), dtype=tdt, device=device if device is not None else torch.device("cuda", ctx.device))
+    ctx.set_stream(torch.cuda.current_stream(out.device).cuda_stream)
+    got = C.c_int64(0)
+    _lib.check(_lib.load().urhgpu_modulate_dev(ctx.handle, _vp(allbits), _vp(off), _vp(pa), _vp(st), len(bl),
+                                               int(samples_per_symbol), mod, _vp(par), int(bits_per_symbol),
+                                               float(carrier_amplitude), float(carrier_frequency), float(carrier_phase),
+                                               float(sample_rate), _MOD_DTYPES[dt], C.c_void_p(out.data_ptr()), total,
+                                               C.byref(got)))
+    assert got.value == total
+    return out
