@@ -303,6 +303,16 @@ int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint
                     const float *parameters, int bits_per_symbol, float carrier_amplitude, float carrier_frequency,
                     float carrier_phase, float sample_rate, uint32_t pause, uint32_t start, int dtype, void *out);
 
+/* path_creator.create_path's pass over the samples (path_creator.pyx:46-66): 1-D samples of dtype (the five IQ sample
+ * types), stretches of samples_per_pixel samples from `start` (the last one ends at `end`); values[2k] / values[2k+1] =
+ * minimum / maximum of stretch k exactly as the reference's sequential scan finds them (NaN and signed-zero behaviour
+ * included).  values holds 2 * ceil((end - start) / samples_per_pixel) elements of dtype.  _dev: device pointers,
+ * asynchronous; the host form takes the whole array (n samples) and returns when values is filled. */
+int urhgpu_path_minmax_dev(urhgpu_ctx *ctx, const void *d_samples, int dtype, int64_t start, int64_t end,
+                           int64_t samples_per_pixel, void *d_values);
+int urhgpu_path_minmax(urhgpu_ctx *ctx, const void *samples, int dtype, int64_t n, int64_t start, int64_t end,
+                       int64_t samples_per_pixel, void *values);
+
 /* Test hook: modulation order 2 (2-FSK, OOK, message segmentation) normally runs the bit-plane kernel
  * (k_demod_runs_bp) and every other order the state-byte kernel (k_demod_runs); on != 0 routes order 2 through the
  * state-byte kernel as well, so that tests can compare the two on the same input.  Process-wide. */

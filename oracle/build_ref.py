@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF_ROOT = os.environ.get("URH_REFERENCE", "/root/reference")
 OUT = os.path.join(HERE, "_ref")
 PKG = os.path.join(OUT, "urh", "cythonext")
-MODULES = ["util", "signal_functions", "auto_interpretation"]
+MODULES = ["util", "signal_functions", "auto_interpretation", "path_creator"]   # path_creator imports only under ref_python.setup() (PyQt6 stub)
 
 DIRECTIVES = {
     "language_level": 3,

@@ -1,3 +1,3 @@
-from ._dummy import (Dummy, QDir, QObject, QSettings, module_getattr, pyqtSignal, pyqtSlot)
+from ._dummy import (Dummy, QByteArray, QDataStream, QDir, QObject, QSettings, module_getattr, pyqtSignal, pyqtSlot)
 
 __getattr__ = module_getattr({})

@@ -114,6 +114,44 @@ class QSettings(Dummy):
         return ""
 
 
+class QByteArray(bytearray):
+    """Enough of QByteArray for path_creator.array_to_QPath (path_creator.pyx:101-129): a resizable byte buffer that
+    numpy can map (np.frombuffer) and QDataStream can hand to a QPainterPath."""
+
+    def resize(self, n):
+        if n < len(self):
+            del self[n:]
+        else:
+            self.extend(b"\0" * (n - len(self)))
+
+    def replace(self, pos, length, data):
+        self[pos:pos + length] = bytes(data)
+
+
+class QPainterPath:
+    """Keeps the serialised form QDataStream delivered (numVerts, then (type, x, y) per vertex, big endian)."""
+
+    def __init__(self, *a, **k):
+        self.serialised = b""
+
+    def vertices(self):
+        import numpy as np
+        if not self.serialised:
+            return np.zeros(0), np.zeros(0)
+        n = int.from_bytes(self.serialised[:4], "big", signed=True)
+        arr = np.frombuffer(self.serialised, dtype=[("c", ">i4"), ("x", ">f8"), ("y", ">f8")], count=n, offset=4)
+        return arr["x"].astype(np.float64), arr["y"].astype(np.float64)
+
+
+class QDataStream:
+    def __init__(self, buffer=None, *a, **k):
+        self.buffer = buffer
+
+    def __rshift__(self, path):
+        path.serialised = bytes(self.buffer)
+        return self
+
+
 def module_getattr(known):
     def __getattr__(name):
         if name.startswith("__"):

@@ -35,13 +35,5 @@ def setup():
             d = os.path.join(base, sub) if sub else base
             if os.path.isdir(d) and d not in pkg.__path__:
                 pkg.__path__.append(d)
-    # path_creator (plot decimation) needs a real PyQt6 and is off the hot path: inert placeholder.
-    import types
-    for name in ("path_creator",):
-        full = "urh.cythonext." + name
-        if full not in sys.modules:
-            mod = types.ModuleType(full)
-            sys.modules[full] = mod
-            setattr(ce, name, mod)
     import urh
     return urh

@@ -313,3 +313,41 @@ def modulate_c(bits, samples_per_symbol: int, modulation_type: str, parameters, 
                            C.c_uint32(start), DT_CODES[dt], out.ctypes.data_as(C.c_void_p))
     assert k == total
     return out
+
+
+def create_path_arrays(samples, start: int, end: int, subpath_ranges=None, pixels_on_path: int = 5000):
+    """path_creator.create_path (path_creator.pyx:19-82) up to the point where it hands (x, values) slices to
+    array_to_QPath: per-pixel minimum / maximum of samples[start:end] (:46-66), or the samples themselves when there is
+    at most one sample per pixel (:67-70), cut into the requested sub-paths (:76-81).  Returns [(x int64, values)]."""
+    samples = np.ascontiguousarray(samples)
+    num_samples = end - start
+    subpath_ranges = [(start, end)] if subpath_ranges is None else subpath_ranges
+    spp = (abs(num_samples) // pixels_on_path) * (1 if num_samples >= 0 else -1)   # C division of two long long (:38)
+    if spp > 1:
+        rng = np.arange(start, end, spp, dtype=np.int64)
+        values = np.zeros(2 * len(rng), dtype=samples.dtype)
+        scale_factor = float(np.float32(num_samples / (2.0 * len(rng))))      # cdef float
+        for k, i in enumerate(rng):
+            chunk = samples[i:min(i + spp, end)]
+            mn = mx = chunk[0]
+            for v in chunk[1:]:                      # :56-61 (a NaN never wins a comparison)
+                if v < mn:
+                    mn = v
+                elif v > mx:
+                    mx = v
+            values[2 * k], values[2 * k + 1] = mn, mx
+        x = np.repeat(rng, 2)
+    else:
+        x = np.arange(start, end, dtype=np.int64)
+        values = samples[start:end]
+        scale_factor = 1.0
+    if scale_factor == 0:
+        scale_factor = 1
+    out = []
+    for r in subpath_ranges:
+        s0 = ((((r[0] - start) / scale_factor) * scale_factor) - 2 * scale_factor) / scale_factor
+        s0 = int(max(0, math.floor(s0)))
+        s1 = ((((r[1] - start) / scale_factor) * scale_factor) + 2 * scale_factor) / scale_factor
+        s1 = int(max(0, math.ceil(s1)))
+        out.append((x[s0:s1], values[s0:s1]))
+    return out

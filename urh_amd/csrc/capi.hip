@@ -911,6 +911,45 @@ int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint
     return st;
 }
 
+static int plot_elem_bytes(int dtype) {
+    switch (dtype) {
+        case URHGPU_DT_I8: case URHGPU_DT_U8: return 1;
+        case URHGPU_DT_I16: case URHGPU_DT_U16: return 2;
+        case URHGPU_DT_F32: return 4;
+        default: return 0;
+    }
+}
+
+int urhgpu_path_minmax_dev(urhgpu_ctx *ctx, const void *d_samples, int dtype, int64_t start, int64_t end,
+                           int64_t samples_per_pixel, void *d_values) {
+    if (!ctx || !d_samples || !d_values || start < 0 || end <= start || samples_per_pixel < 1) return URHGPU_ERR_ARG;
+    if (!plot_elem_bytes(dtype)) return URHGPU_ERR_DTYPE;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(launch_path_minmax(d_samples, dtype, start, end, samples_per_pixel, d_values, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_path_minmax(urhgpu_ctx *ctx, const void *samples, int dtype, int64_t n, int64_t start, int64_t end,
+                       int64_t samples_per_pixel, void *values) {
+    if (!ctx || !samples || !values || start < 0 || end <= start || end > n || samples_per_pixel < 1) return URHGPU_ERR_ARG;
+    const int eb = plot_elem_bytes(dtype);
+    if (!eb) return URHGPU_ERR_DTYPE;
+    const int64_t pixels = (end - start + samples_per_pixel - 1) / samples_per_pixel;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(ctx->staging.reserve(align256((size_t)(end - start) * eb) + align256((size_t)pixels * 2 * eb) + 1024));
+    ctx->staging.reset();
+    void *d_in = nullptr;
+    URH_TRY(stage_in(ctx, (const char *)samples + (size_t)start * eb, (size_t)(end - start) * eb, &d_in));
+    void *d_val = ctx->staging.take((size_t)pixels * 2 * eb);
+    if (!d_val) return URHGPU_ERR_ARG;
+    URH_TRY(urhgpu_path_minmax_dev(ctx, d_in, dtype, 0, end - start, samples_per_pixel, d_val));
+    URH_HIP(hipMemcpyAsync(values, d_val, (size_t)pixels * 2 * eb, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
 int urhgpu_test_force_state_bytes(int on) {
     urh::g_force_state_bytes = (on != 0);
     return URHGPU_OK;

@@ -60,6 +60,9 @@ struct ModArgs {
 };
 int launch_modulate(const ModArgs &a, int64_t max_samples, hipStream_t s);
 
+// ---- plot.hip ----------------------------------------------------------------------------------------
+int launch_path_minmax(const void *samples, int dtype, int64_t start, int64_t end, int64_t spp, void *values, hipStream_t s);
+
 // ---- bandpass.hip ------------------------------------------------------------------------------------
 int launch_bandpass(const float2 *x, int64_t n, const float2 *left, int64_t n_left, const float2 *right, int64_t n_right,
                     const double2 *taps, int m, int64_t shift, int64_t n_out, double2 *out128, float2 *out64, hipStream_t s);
