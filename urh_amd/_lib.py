@@ -133,11 +133,12 @@ def load():
     global _lib
     with _lock:
         if _lib is None:
-            if not os.path.exists(LIB_PATH):
-                raise UrhGpuError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: build it with `python -m urh_amd.build` "
+            path = os.environ.get("URHGPU_LIB", LIB_PATH)      # A/B builds (python -m urh_amd.build --tag ...)
+            if not os.path.exists(path):
+                raise UrhGpuError(ERR_NO_DEVICE, f"{path} is missing: build it with `python -m urh_amd.build` "
                                                  "(there is no CPU fallback)")
             _share_torch_hip_runtime()
-            lib = C.CDLL(LIB_PATH)
+            lib = C.CDLL(path)
             for name, (res, args) in PROTOTYPES.items():
                 fn = getattr(lib, name)          # AttributeError if the symbol is not exported
                 fn.restype = res

@@ -26,15 +26,17 @@ def _newest_source() -> float:
     return t
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_source():
-        return LIB
+def build(force: bool = False, verbose: bool = False, extra_flags=(), lib: str = LIB, tag: str = "") -> str:
+    """extra_flags / lib / tag: A/B builds of tuning knobs (-DURH_...) into a differently named library that
+    URHGPU_LIB=<path> makes urh_amd._lib load (developer tooling; the product is the default build)."""
+    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest_source():
+        return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(CSRC, src.replace(".hip", tag + ".o"))
+        cmd = [hipcc, *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
@@ -42,10 +44,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src, pr in procs:
         if pr.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m urh_amd.build [--force] [--tag NAME -DURH_X=1 ...]  (tagged: urh_amd/liburhgpu_NAME.so)
+    argv = sys.argv[1:]
+    tag = argv[argv.index("--tag") + 1] if "--tag" in argv else ""
+    flags = [a for a in argv if a.startswith("-D")]
+    if tag:
+        print(build(force=True, verbose=True, extra_flags=flags, lib=os.path.join(HERE, f"liburhgpu_{tag}.so"), tag="_" + tag))
+    else:
+        print(build(force="--force" in argv, verbose=True, extra_flags=flags))

@@ -28,6 +28,8 @@ void Arena::release() {
 
 }  // namespace urh
 
+#include <stdlib.h>
+
 #include "launchers.hpp"
 
 using namespace urh;
@@ -121,6 +123,7 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     a.noise_sqrd = p->noise_threshold * p->noise_threshold;
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
+    a.lds_pad = ctx->pipelined ? ctx->hot_lds_pad : 0;
     if (from_iq) URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     if (seg_mode) {
         // message segmentation: state = (|sample| > noise threshold) with the 10-sample outlier tolerance.  Reuses the
@@ -358,6 +361,10 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[1], hipEventDisableTiming));
     }
     ctx->pipelined = true;
+    {   // experiment knob: URH_HOT_LDS_KB=<KiB of dynamic LDS per hot workgroup> (0 / unset: the default below)
+        const char *e = getenv("URH_HOT_LDS_KB");
+        ctx->hot_lds_pad = (e ? atoi(e) : 21) * 1024;
+    }
     return URHGPU_OK;
 }
 
@@ -582,6 +589,7 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     a.noise_sqrd = p->noise_threshold * p->noise_threshold;
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
+    a.lds_pad = ctx->pipelined ? ctx->hot_lds_pad : 0;
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     a.chunks = ss->table + rank;               // this rank's chunks sit at table[rank .. rank + n_chunks)
     a.slab = ss->slab;

@@ -74,6 +74,7 @@ struct urhgpu_ctx {
     // `tail_stream`, with two scratch arenas used alternately, so that the hot kernel of the NEXT pass overlaps the
     // (latency-bound, nearly empty) tail of this one.  Outputs are complete after urhgpu_ctx_join / urhgpu_ctx_sync.
     bool pipelined = false;
+    int hot_lds_pad = 0;           // pipelined mode: dynamic LDS bytes added to every hot-kernel workgroup (see RunArgs::lds_pad)
     hipStream_t tail_stream = nullptr;
     bool own_tail_stream = false;
     urh::Arena arena_alt;

@@ -1131,7 +1131,7 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
         // order 2 (states PAUSE/1/2): the bit-plane kernel; anything else: the state-byte kernel
         if (URH_BITPLANE && O2 && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes)
-            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * URH_WPB), 0, s, a);
+            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * URH_WPB), (size_t)a.lds_pad, s, a);
         else
             hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock), 0, s, a);
     }

@@ -30,6 +30,8 @@ struct RunArgs {
     int launch_part;         // 0 all chunks, 1 all but the first, 2 the first only (launchers; see launch_runs_4)
     int seg_mode;            // 1: message segmentation on magnitudes (auto_interpretation.pyx:55-111): sample 0 is an
                              // ordinary sample (no result[0] = NOISE) and the state machine starts in ITS state
+    int lds_pad;             // extra dynamic LDS bytes per workgroup of k_demod_runs_bp: caps its workgroups per CU so that
+                             // wave slots stay free for the tail of the previous pass (pipelined mode)
     float thr[kMaxOrder - 1];
 };
 extern bool g_force_state_bytes;   // test hook: order 2 through the state-byte kernel too
@@ -76,6 +78,9 @@ struct ResolveScratch {
     int32_t *prev_acc;       // last chunk before c that contributes an accepted run, or -1
     int64_t *out_cnt;        // accepted runs contributed by chunk c
     int64_t *out_off;        // index of chunk c's first accepted run in the global accepted sequence
+    int32_t *blk_stable;     // per resolve workgroup: last chunk with a stable run (or -1)
+    int32_t *blk_acc;        // per resolve workgroup: last chunk that contributes an accepted run (or -1)
+    int64_t *blk_cnt;        // per resolve workgroup: accepted runs
 };
 size_t resolve_scratch_bytes(int64_t n_chunks);
 ResolveScratch resolve_scratch_carve(void *mem, int64_t n_chunks);

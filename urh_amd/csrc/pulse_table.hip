@@ -23,13 +23,24 @@ namespace urh {
 // Two per-chunk kernels (one thread per chunk, any grid) separated by two single-workgroup scans
 // over small int arrays: "last chunk before me that has X" is an exclusive max-scan of (c if X else -1).
 // =====================================================================================================
-constexpr int kResolveBlock = 1024;
+#ifndef URH_RESOLVE_BLOCK
+#define URH_RESOLVE_BLOCK 1024
+#endif
+#ifndef URH_RESOLVE_ITEMS
+#define URH_RESOLVE_ITEMS 4
+#endif
+constexpr int kResolveBlock = URH_RESOLVE_BLOCK;
 
-size_t resolve_scratch_bytes(int64_t n_chunks) { return (size_t)n_chunks * (4 * 4 + 2 * 8) + 6 * 256; }
+__host__ __device__ static inline int64_t resolve_blocks(int64_t n_chunks) { return (n_chunks + kResolveBlock - 1) / kResolveBlock; }
+
+size_t resolve_scratch_bytes(int64_t n_chunks) {
+    return (size_t)n_chunks * (4 * 4 + 2 * 8) + (size_t)(resolve_blocks(n_chunks) + 1) * (4 + 4 + 8) + 10 * 256;
+}
 
 ResolveScratch resolve_scratch_carve(void *mem, int64_t n_chunks) {
     char *p = (char *)mem;
     auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~size_t(255); return r; };
+    const int64_t nb = resolve_blocks(n_chunks) + 1;
     ResolveScratch sc;
     sc.out_cnt = (int64_t *)take((size_t)n_chunks * 8);
     sc.out_off = (int64_t *)take((size_t)n_chunks * 8);
@@ -37,11 +48,14 @@ ResolveScratch resolve_scratch_carve(void *mem, int64_t n_chunks) {
     sc.prev_stable = (int32_t *)take((size_t)n_chunks * 4);
     sc.has_acc = (int32_t *)take((size_t)n_chunks * 4);
     sc.prev_acc = (int32_t *)take((size_t)n_chunks * 4);
+    sc.blk_stable = (int32_t *)take((size_t)nb * 4);
+    sc.blk_acc = (int32_t *)take((size_t)nb * 4);
+    sc.blk_cnt = (int64_t *)take((size_t)nb * 8);
     return sc;
 }
 
 // R1: per chunk.
-__device__ __forceinline__ void chunk_stable(const ResolveArgs &a, int64_t c) {
+__device__ __forceinline__ int32_t chunk_stable(const ResolveArgs &a, int64_t c) {
     ChunkInfo *ch = a.chunks;
     int ps = 0;
     const int64_t pend_pos = ch[c].pend_pos;
@@ -58,74 +72,60 @@ __device__ __forceinline__ void chunk_stable(const ResolveArgs &a, int64_t c) {
     }
     ch[c].pend_stable = ps;
     const bool has = ps || ch[c].cnt > 0;
-    a.sc.has_stable[c] = has ? (int32_t)c : -1;
     if (has) atomicMin(&a.aux->first_stable, (int32_t)c);
     if (ch[c].lead < ch[c].len) atomicMin(&a.aux->first_nonlead, (int32_t)c);
+    return has ? (int32_t)c : -1;
 }
 
-// Single-workgroup exclusive scans over n <= 2^31 ints: out_max[i] = max(in_max[0..i)) (or -1);
-// optionally out_sum[i] = sum(in_sum[0..i)).  Returns (via shared) the inclusive totals.
+// Exclusive scans inside ONE workgroup, one element per thread: ex_m = max of the elements before mine (or -1),
+// ex_s = their sum; tot_* = over the whole workgroup.  The scans over the whole table are two-level: every workgroup
+// scans its own kResolveBlock chunks and publishes its totals (blk_*), and whoever needs a global value adds the
+// totals of the workgroups before it (a handful: 16 for a 1 GiB capture) -- no workgroup ever walks the whole table.
 template <bool WITH_SUM>
-__device__ void block_scan_max_sum(const int32_t *in_max, int32_t *out_max, const int64_t *in_sum, int64_t *out_sum, int64_t n,
-                                   int32_t &total_max, int64_t &total_sum) {
+__device__ __forceinline__ void block_local_scan(int32_t m, int64_t v, int32_t &ex_m, int64_t &ex_s, int32_t &tot_m, int64_t &tot_s) {
     __shared__ int32_t s_m[kResolveBlock / 64];
     __shared__ int64_t s_s[kResolveBlock / 64];
-    __shared__ int32_t s_cm;
-    __shared__ int64_t s_cs;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    constexpr int kItems = 4;
-    if (t == 0) { s_cm = -1; s_cs = 0; }
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += (int64_t)kResolveBlock * kItems) {
-        const int64_t i0 = base + (int64_t)t * kItems;
-        int32_t m[kItems]; int64_t v[kItems];
-        int32_t mm = -1; int64_t ss = 0;
+    int32_t im = m; int64_t is = v;
 #pragma unroll
-        for (int j = 0; j < kItems; ++j) {
-            m[j] = (i0 + j < n) ? in_max[i0 + j] : -1;
-            v[j] = (WITH_SUM && i0 + j < n) ? in_sum[i0 + j] : 0;
-            mm = max(mm, m[j]); ss += v[j];
-        }
-        // inclusive scan across the workgroup (wave shuffles, then wave totals)
-        int32_t im = mm; int64_t is = ss;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int32_t um = __shfl_up(im, o); const int64_t us = WITH_SUM ? __shfl_up(is, o) : 0;
-            if (lane >= o) { im = max(im, um); is += us; }
-        }
-        if (lane == 63) { s_m[wave] = im; s_s[wave] = is; }
-        __syncthreads();
-        int32_t bm = s_cm; int64_t bs = s_cs;                 // carry from earlier rounds + earlier waves
-        for (int w = 0; w < wave; ++w) { bm = max(bm, s_m[w]); bs += s_s[w]; }
-        // exclusive prefix of this thread
-        int32_t em = __shfl_up(im, 1); int64_t es = WITH_SUM ? __shfl_up(is, 1) : 0;
-        if (lane == 0) { em = -1; es = 0; }
-        em = max(em, bm); es += bs;
-#pragma unroll
-        for (int j = 0; j < kItems; ++j) {
-            if (i0 + j < n) { out_max[i0 + j] = em; if (WITH_SUM) out_sum[i0 + j] = es; }
-            em = max(em, m[j]); es += v[j];
-        }
-        __syncthreads();
-        if (t == kResolveBlock - 1) { s_cm = em; s_cs = es; }   // inclusive total so far (last thread has seen everything)
-        __syncthreads();
+    for (int o = 1; o < 64; o <<= 1) {
+        const int32_t um = __shfl_up(im, o); const int64_t us = WITH_SUM ? __shfl_up(is, o) : 0;
+        if (lane >= o) { im = max(im, um); is += us; }
     }
-    total_max = s_cm; total_sum = s_cs;
+    __syncthreads();                                       // s_m / s_s may still be read by a previous call
+    if (lane == 63) { s_m[wave] = im; s_s[wave] = is; }
+    __syncthreads();
+    int32_t bm = -1, tm = -1; int64_t bs = 0, ts = 0;
+    for (int w = 0; w < kResolveBlock / 64; ++w) {
+        if (w < wave) { bm = max(bm, s_m[w]); bs += s_s[w]; }
+        tm = max(tm, s_m[w]); ts += s_s[w];
+    }
+    int32_t em = __shfl_up(im, 1); int64_t es = WITH_SUM ? __shfl_up(is, 1) : 0;
+    if (lane == 0) { em = -1; es = 0; }
+    ex_m = max(em, bm); ex_s = es + bs; tot_m = tm; tot_s = ts;
 }
 
-// S1: prev_stable = exclusive last-valid scan of has_stable.
-__device__ __forceinline__ void scan_stable(const ResolveArgs &a) {
-    int32_t tm; int64_t ts;
-    block_scan_max_sum<false>(a.sc.has_stable, a.sc.prev_stable, nullptr, nullptr, a.n_chunks, tm, ts);
-    if (threadIdx.x == 0) a.aux->last_stable = tm;
+// max / sum of the totals of the workgroups before workgroup b (every thread gets the result)
+template <bool WITH_SUM>
+__device__ __forceinline__ void blocks_before(const int32_t *blk_m, const int64_t *blk_s, int64_t b, int32_t &pm, int64_t &ps) {
+    __shared__ int32_t s_pm;
+    __shared__ int64_t s_ps;
+    if (threadIdx.x < 64) {
+        int32_t m = -1; int64_t v = 0;
+        for (int64_t u = threadIdx.x; u < b; u += 64) { m = max(m, blk_m[u]); if (WITH_SUM) v += blk_s[u]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { m = max(m, __shfl_down(m, o)); if (WITH_SUM) v += __shfl_down(v, o); }
+        if (threadIdx.x == 0) { s_pm = m; s_ps = v; }
+    }
+    __syncthreads();
+    pm = s_pm; ps = s_ps;
 }
 
 __device__ __forceinline__ uint32_t chunk_last_stable_state(const ChunkInfo &ci) { return ci.pend_stable ? ci.pend_state : ci.last_state; }
 
 // R2: per chunk: acceptance of the tentative first record / the pending run, counts.
-__device__ __forceinline__ void chunk_accept(const ResolveArgs &a, int64_t c) {
+__device__ __forceinline__ void chunk_accept(const ResolveArgs &a, int64_t c, int32_t ip, int64_t &out_cnt, int32_t &has_acc) {
     ChunkInfo *ch = a.chunks;
-    const int32_t ip = a.sc.prev_stable[c];
     const uint32_t prev_state = (ip < 0) ? (a.local_pass ? 0xFFFFu : (uint32_t)ch[0].init_state) : chunk_last_stable_state(ch[ip]);
     const int cnt = ch[c].cnt;
     const int ps = ch[c].pend_stable;
@@ -134,8 +134,8 @@ __device__ __forceinline__ void chunk_accept(const ResolveArgs &a, int64_t c) {
     const int pend_acc = ps && (ch[c].pend_state != before_pend);
     ch[c].first_acc = first_acc;
     ch[c].pend_acc = pend_acc;
-    a.sc.out_cnt[c] = (cnt > 0 ? cnt - 1 + first_acc : 0) + pend_acc;
-    a.sc.has_acc[c] = (pend_acc || cnt >= 2 || (cnt == 1 && first_acc)) ? (int32_t)c : -1;
+    out_cnt = (cnt > 0 ? cnt - 1 + first_acc : 0) + pend_acc;
+    has_acc = (pend_acc || cnt >= 2 || (cnt == 1 && first_acc)) ? (int32_t)c : -1;
 }
 
 // position / state of the last accepted run of chunk ci (which contributes at least one)
@@ -144,12 +144,19 @@ __device__ __forceinline__ void chunk_last_acc(const ChunkInfo &ci, int64_t &pos
     else { pos = ci.last_pos; state = ci.last_state; }
 }
 
-// S2: out_off = exclusive sum of out_cnt, prev_acc = exclusive last-valid scan of has_acc; totals and
-// the final row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487).
-__device__ __forceinline__ void scan_accept(const ResolveArgs &a) {
-    int32_t last_c; int64_t P;
-    block_scan_max_sum<true>(a.sc.has_acc, a.sc.prev_acc, a.sc.out_cnt, a.sc.out_off, a.n_chunks, last_c, P);
-    if (threadIdx.x == 0) {
+// Totals and the final row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487): one thread,
+// from the workgroup totals.  out_off values it needs are rebuilt from the workgroup-local offsets (sc.out_cnt).
+__device__ __forceinline__ void resolve_finish(const ResolveArgs &a) {
+    const int64_t nb = resolve_blocks(a.n_chunks);
+    int32_t last_c = -1, last_stable = -1; int64_t P = 0;
+    for (int64_t u = 0; u < nb; ++u) { last_c = max(last_c, a.sc.blk_acc[u]); last_stable = max(last_stable, a.sc.blk_stable[u]); P += a.sc.blk_cnt[u]; }
+    a.aux->last_stable = last_stable;
+    auto global_off = [&](int64_t c) {                     // out_off[c] without waiting for the other workgroups of this launch
+        int64_t o = a.sc.out_cnt[c];
+        for (int64_t u = 0; u < c / kResolveBlock; ++u) o += a.sc.blk_cnt[u];
+        return o;
+    };
+    {
         *a.d_n_acc = P;
         if (a.local_pass) {
             // the ChunkInfo that stands for this whole shard in the other ranks' tables
@@ -176,8 +183,8 @@ __device__ __forceinline__ void scan_accept(const ResolveArgs &a) {
             return;
         }
         // this GPU's rows are global rows [row_base, row_end) (+ the table's last row on the last GPU)
-        const int64_t row_base = a.sc.out_off[a.chunk_first];
-        const int64_t row_end = (a.chunk_first + a.n_local < a.n_chunks) ? a.sc.out_off[a.chunk_first + a.n_local] : P;
+        const int64_t row_base = global_off(a.chunk_first);
+        const int64_t row_end = (a.chunk_first + a.n_local < a.n_chunks) ? global_off(a.chunk_first + a.n_local) : P;
         int64_t n_rows = row_end - row_base;
         if (P < a.n_total && a.write_last_row) {
             const int64_t o = P - row_base;
@@ -196,22 +203,38 @@ __device__ __forceinline__ void scan_accept(const ResolveArgs &a) {
     }
 }
 
-// The resolve stage as TWO launches: the per-chunk phases run over the whole grid, and the workgroup that finishes
-// last runs the single-workgroup scan that follows (scan.hpp: scan_last_block), instead of a launch of its own.
-// aux is persistent context memory that holds kAuxNone / -1 between passes (k_resolve_b restores it).
-__global__ __launch_bounds__(kResolveBlock) void k_resolve_a(const ResolveArgs a, int32_t *ticket) {
+// The resolve stage as three launches over the table, kResolveBlock chunks per workgroup, no workgroup waiting for another:
+//   k_resolve_a  per chunk: does its trailing short run turn stable?  workgroup-local "last chunk with a stable run before me"
+//   k_resolve_b  per chunk: acceptance of its first / pending run, counts; workgroup-local offsets and "last chunk that
+//                contributes an accepted run before me"
+//   k_resolve_c  adds the totals of the workgroups before: out_off, prev_acc; thread 0 of workgroup 0: totals, last row
+// aux is persistent context memory that holds kAuxNone / -1 between passes (k_resolve_c restores it).
+__global__ __launch_bounds__(kResolveBlock) void k_resolve_a(const ResolveArgs a) {
     const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
-    if (c < a.n_chunks) chunk_stable(a, c);
-    if (!scan_last_block(ticket, gridDim.x)) return;
-    scan_stable(a);
+    const int32_t hs = (c < a.n_chunks) ? chunk_stable(a, c) : -1;
+    int32_t ex, tot; int64_t d0, d1;
+    block_local_scan<false>(hs, 0, ex, d0, tot, d1);
+    if (c < a.n_chunks) a.sc.prev_stable[c] = ex;
+    if (threadIdx.x == 0) a.sc.blk_stable[blockIdx.x] = tot;
 }
-__global__ __launch_bounds__(kResolveBlock) void k_resolve_b(const ResolveArgs a, int32_t *ticket) {
+__global__ __launch_bounds__(kResolveBlock) void k_resolve_b(const ResolveArgs a) {
     const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
-    if (c < a.n_chunks) chunk_accept(a, c);
-    if (!scan_last_block(ticket, gridDim.x)) return;
-    scan_accept(a);
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    int32_t pm; int64_t dummy;
+    blocks_before<false>(a.sc.blk_stable, nullptr, blockIdx.x, pm, dummy);
+    int64_t cnt = 0; int32_t ha = -1;
+    if (c < a.n_chunks) chunk_accept(a, c, max(a.sc.prev_stable[c], pm), cnt, ha);
+    int32_t ex_m, tot_m; int64_t ex_s, tot_s;
+    block_local_scan<true>(ha, cnt, ex_m, ex_s, tot_m, tot_s);
+    if (c < a.n_chunks) { a.sc.out_cnt[c] = ex_s; a.sc.has_acc[c] = ex_m; }     // workgroup-local exclusive values
+    if (threadIdx.x == 0) { a.sc.blk_acc[blockIdx.x] = tot_m; a.sc.blk_cnt[blockIdx.x] = tot_s; }
+}
+__global__ __launch_bounds__(kResolveBlock) void k_resolve_c(const ResolveArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
+    int32_t pm; int64_t ps;
+    blocks_before<true>(a.sc.blk_acc, a.sc.blk_cnt, blockIdx.x, pm, ps);
+    if (c < a.n_chunks) { a.sc.out_off[c] = a.sc.out_cnt[c] + ps; a.sc.prev_acc[c] = max(a.sc.has_acc[c], pm); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        resolve_finish(a);
         a.aux->first_nonlead = kAuxNone; a.aux->open_chunk = kAuxNone; a.aux->first_stable = kAuxNone; a.aux->last_stable = -1;
     }
 }
@@ -549,8 +572,10 @@ __global__ __launch_bounds__(256) void k_expand_huge(const ExpandArgs a) {
 int launch_resolve(const ResolveArgs &a, int32_t *tickets, hipStream_t s) {
     if (a.n_chunks <= 0) return URHGPU_ERR_ARG;
     const unsigned g = (unsigned)((a.n_chunks + kResolveBlock - 1) / kResolveBlock);
-    hipLaunchKernelGGL(k_resolve_a, dim3(g), dim3(kResolveBlock), 0, s, a, tickets);
-    hipLaunchKernelGGL(k_resolve_b, dim3(g), dim3(kResolveBlock), 0, s, a, tickets + 1);
+    (void)tickets;
+    hipLaunchKernelGGL(k_resolve_a, dim3(g), dim3(kResolveBlock), 0, s, a);
+    hipLaunchKernelGGL(k_resolve_b, dim3(g), dim3(kResolveBlock), 0, s, a);
+    hipLaunchKernelGGL(k_resolve_c, dim3(g), dim3(kResolveBlock), 0, s, a);
     return URHGPU_OK;
 }
 
