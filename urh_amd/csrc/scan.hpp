@@ -108,13 +108,27 @@ __device__ __forceinline__ void scan_partials_body(VecK<K> *partials, int64_t nb
     if (threadIdx.x == 0) partials[nblocks_max] = *s_carry;
 }
 
-// Pass 1: per-workgroup totals; the last workgroup to finish turns them into exclusive prefixes.
-// Load::operator()(int64 i) -> VecK<K> (only called for i < n).
+// Up to kScanDirect active workgroups the scan is two-level without a pass over the totals: every workgroup of pass 2
+// adds up the totals of the workgroups before it (the pulse-table stages: a few hundred workgroups).  Beyond that (stream
+// compaction over a whole capture: tens of thousands of workgroups) the last workgroup of pass 1 scans the totals.
+constexpr int64_t kScanDirect = 1024;
+
+// Sum of partials[0 .. count) by the whole workgroup (every thread gets it).
+template <int K>
+__device__ __forceinline__ VecK<K> block_sum_partials(const VecK<K> *partials, int64_t count, VecK<K> *s_wave) {
+    VecK<K> acc; acc.zero();
+    for (int64_t u = threadIdx.x; u < count; u += kScanBlock) acc.add(partials[u]);
+    VecK<K> total;
+    block_excl_scan_vec<K>(acc, total, s_wave);
+    return total;
+}
+
+// Pass 1: per-workgroup totals (partials[b]); with more than kScanDirect workgroups the last one to finish turns them into
+// exclusive prefixes.  Load::operator()(int64 i) -> VecK<K> (only called for i < n).
 template <int K, class Load>
 __global__ __launch_bounds__(kScanBlock) void k_scan_reduce(const int64_t *d_n, Load load, VecK<K> *partials, int64_t nblocks_max,
                                                              int32_t *ticket) {
     __shared__ VecK<K> s_wave[kScanBlock / 64];
-    __shared__ VecK<K> s_carry;
     const int64_t n = *d_n;
     const int64_t nb = scan_active_blocks(n, nblocks_max);
     if ((int64_t)blockIdx.x >= nb) return;
@@ -127,14 +141,17 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_reduce(const int64_t *d_n, 
     VecK<K> total;
     block_excl_scan_vec<K>(acc, total, s_wave);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
+    if (nb <= kScanDirect) return;
+    __shared__ VecK<K> s_carry;
     if (!scan_last_block(ticket, nb)) return;
     scan_partials_body<K>(partials, nb, nblocks_max, s_wave, &s_carry);
 }
 
 // Pass 2: the scan proper.  Store::operator()(int64 i, const VecK<K>& value, const VecK<K>& excl_prefix);
-// Final::operator()(const VecK<K>& grand_total) runs once, on one thread, after every element has been stored.
+// Final::operator()(const VecK<K>& grand_total) runs once, on one thread, after every element has been stored; the grand
+// total is also left in partials[nblocks_max].
 template <int K, class Load, class Store, class Final>
-__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t *d_n, Load load, const VecK<K> *partials, int64_t nblocks_max,
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t *d_n, Load load, VecK<K> *partials, int64_t nblocks_max,
                                                             Store store, Final fin, int32_t *ticket) {
     __shared__ VecK<K> s_wave[kScanBlock / 64];
     const int64_t n = *d_n;
@@ -150,16 +167,22 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t *d_n, L
         if (i0 + j < n) item[j] = load(i0 + j);
         acc.add(item[j]);
     }
+    VecK<K> before;
+    if (nb <= kScanDirect) before = block_sum_partials<K>(partials, blockIdx.x, s_wave);
+    else before = partials[blockIdx.x];
     VecK<K> total;
     VecK<K> ex = block_excl_scan_vec<K>(acc, total, s_wave);
-    ex.add(partials[blockIdx.x]);
+    ex.add(before);
 #pragma unroll
     for (int j = 0; j < kScanItems; ++j) {
         if (i0 + j < n) store(i0 + j, item[j], ex);
         ex.add(item[j]);
     }
     if (!scan_last_block(ticket, nb)) return;
-    if (threadIdx.x == 0) fin(partials[nblocks_max]);
+    if (nb <= kScanDirect) {
+        const VecK<K> grand = block_sum_partials<K>(partials, nb, s_wave);
+        if (threadIdx.x == 0) { partials[nblocks_max] = grand; fin(grand); }
+    } else if (threadIdx.x == 0) fin(partials[nblocks_max]);
 }
 
 // ---- single-pass scan (decoupled look-back) -----------------------------------------------------------------------------
