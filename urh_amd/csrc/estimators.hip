@@ -55,6 +55,7 @@ int launch_compact_gt(const float *x, int64_t n, const int64_t *d_n, float thr, 
     hipLaunchKernelGGL((k_scan_reduce<1, GtLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb, tickets);
     hipLaunchKernelGGL((k_scan_apply<1, GtLoad, GtStore, CountFinal>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb,
                        GtStore{x, out}, CountFinal{d_count}, tickets + 1);
+    hipLaunchKernelGGL((k_scan_finish<1, CountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n, part, nb, CountFinal{d_count});
     return URHGPU_OK;
 }
 
@@ -66,6 +67,7 @@ int launch_compact_edges(const float *x, int64_t n, const int64_t *d_n, float ce
     hipLaunchKernelGGL((k_scan_reduce<1, EdgeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb, tickets);
     hipLaunchKernelGGL((k_scan_apply<1, EdgeLoad, EdgeStore, CountFinal>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb,
                        EdgeStore{out, cap}, CountFinal{d_count}, tickets + 1);
+    hipLaunchKernelGGL((k_scan_finish<1, CountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n, part, nb, CountFinal{d_count});
     return URHGPU_OK;
 }
 

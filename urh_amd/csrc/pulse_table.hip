@@ -605,6 +605,7 @@ int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t
     hipLaunchKernelGGL((k_scan_reduce<2, MergeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld, partials, nb, tickets);
     hipLaunchKernelGGL((k_scan_apply<2, MergeLoad, MergeStore, NoFinal>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld,
                        partials, nb, st, NoFinal(), tickets + 1);
+    hipLaunchKernelGGL((k_scan_finish<2, NoFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_in, partials, nb, NoFinal());
     int64_t fin_blocks = (cap + 255) / 256; if (fin_blocks > 4096) fin_blocks = 4096;
     hipLaunchKernelGGL(k_merge_finish, dim3((unsigned)fin_blocks), dim3(256), 0, s, partials + nb, grp_state, grp_end,
                        rows_out, cap_out, d_n_out);
@@ -683,6 +684,7 @@ int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t ca
     hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb, ss.tickets);
     hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore, GroupCountFinal>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld,
                        b.part4, b.nb, st, fin, ss.tickets + 1);
+    hipLaunchKernelGGL((k_scan_finish<4, GroupCountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, b.part4, b.nb, fin);
     return URHGPU_OK;
 }
 
