@@ -10,7 +10,7 @@ namespace urh {
 
 constexpr int kScanBlock = 256;
 #ifndef URH_SCAN_ITEMS
-#define URH_SCAN_ITEMS 8
+#define URH_SCAN_ITEMS 4
 #endif
 constexpr int kScanItems = URH_SCAN_ITEMS;
 constexpr int kScanTile = kScanBlock * kScanItems;   // 2048 elements per workgroup
