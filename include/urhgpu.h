@@ -313,6 +313,20 @@ int urhgpu_path_minmax_dev(urhgpu_ctx *ctx, const void *d_samples, int dtype, in
 int urhgpu_path_minmax(urhgpu_ctx *ctx, const void *samples, int dtype, int64_t n, int64_t start, int64_t end,
                        int64_t samples_per_pixel, void *values);
 
+/* Spectrogram.stft + __calculate_spectrogram (Spectrogram.py:94-116, :158-164; util.arr2decibel, util.pyx:38-48) on device
+ * memory: d_x complex64[n]; frames = max(1, (n - window_size) / hop + 1) frames of window_size samples (a power of two,
+ * 8 .. 4096; samples at or beyond n read as zero: the reference's zero padding of captures shorter than one window),
+ * d_window float64[window_size] (np.hanning by default), d_twiddles complex128[window_size / 2] = exp(-2 pi i m / window_size).
+ * Exactly one output: d_stft complex128[frames * window_size] (the stft, divided by window_size) or d_db float32[frames *
+ * window_size] (fftshift along frequency, complex64, 10 log10 |.|^2, fliplr).  Double-precision FFT like numpy's; floating
+ * point, not bit-exact.  Asynchronous. */
+int urhgpu_spectrogram_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, int window_size, int64_t hop, int64_t frames,
+                           const double *d_window, const double *d_twiddles, double *d_stft, float *d_db);
+/* Spectrogram.apply_bgra_lookup (Spectrogram.py:196-210, normalize=True): d_db float32 (frames, window_size) ->
+ * d_image uint32 BGRA (window_size, frames) through d_colormap[n_colors]. */
+int urhgpu_bgra_lookup_dev(urhgpu_ctx *ctx, const float *d_db, int64_t frames, int window_size, const uint32_t *d_colormap,
+                           int n_colors, float data_min, float data_max, uint32_t *d_image);
+
 /* Test hook: modulation order 2 (2-FSK, OOK, message segmentation) normally runs the bit-plane kernel
  * (k_demod_runs_bp) and every other order the state-byte kernel (k_demod_runs); on != 0 routes order 2 through the
  * state-byte kernel as well, so that tests can compare the two on the same input.  Process-wide. */

@@ -919,6 +919,28 @@ int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint
     return st;
 }
 
+int urhgpu_spectrogram_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, int window_size, int64_t hop, int64_t frames,
+                           const double *d_window, const double *d_twiddles, double *d_stft, float *d_db) {
+    if (!ctx || !d_x || n < 0 || !d_window || !d_twiddles || ((d_stft != nullptr) == (d_db != nullptr))) return URHGPU_ERR_ARG;
+    if (((uintptr_t)d_x & 7) || ((uintptr_t)d_twiddles & 15) || ((uintptr_t)d_stft & 15)) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(launch_stft((const float2 *)d_x, n, window_size, hop, frames, d_window, (const double2 *)d_twiddles, (double2 *)d_stft, d_db,
+                        ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_bgra_lookup_dev(urhgpu_ctx *ctx, const float *d_db, int64_t frames, int window_size, const uint32_t *d_colormap,
+                           int n_colors, float data_min, float data_max, uint32_t *d_image) {
+    if (!ctx || !d_db || !d_colormap || !d_image || frames < 0 || window_size < 1) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(launch_bgra_lookup(d_db, frames, window_size, d_colormap, n_colors, data_min, data_max, d_image, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
 static int plot_elem_bytes(int dtype) {
     switch (dtype) {
         case URHGPU_DT_I8: case URHGPU_DT_U8: return 1;

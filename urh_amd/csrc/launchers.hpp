@@ -62,6 +62,12 @@ struct ModArgs {
 };
 int launch_modulate(const ModArgs &a, int64_t max_samples, hipStream_t s);
 
+// ---- spectrogram.hip ---------------------------------------------------------------------------------
+int launch_stft(const float2 *x, int64_t n, int ws, int64_t hop, int64_t frames, const double *window, const double2 *tw,
+                double2 *out_c128, float *out_db, hipStream_t s);
+int launch_bgra_lookup(const float *data, int64_t frames, int ws, const uint32_t *colormap, int n_colors, float dmin, float dmax,
+                       uint32_t *image, hipStream_t s);
+
 // ---- plot.hip ----------------------------------------------------------------------------------------
 int launch_path_minmax(const void *samples, int dtype, int64_t start, int64_t end, int64_t spp, void *values, hipStream_t s);
 
