@@ -107,6 +107,20 @@ def test_afp_demod_sizes_and_dtypes(sf, oracle, mod):
                 assert bits_equal(got, want), (mod, np.dtype(dtype).name, n, noise, int((got != want).sum()))
 
 
+@pytest.mark.parametrize("mod", ["FSK", "ASK", "QAM"])
+def test_afp_demod_streaming_kernel_and_remainder(sf, oracle, mod):
+    """urhgpu_afp_demod sends whole 8192-sample chunks through the hot kernel's streaming structure (no run phase) and the
+    remainder through k_afp_demod: sizes either side of the chunk size, every sample type."""
+    for dtype in (np.float32, np.int8, np.uint16):
+        for n in (8191, 8192, 8193, 8192 * 3 + 1, 8192 * 5 + 4099, 100_000):
+            iq = synth_fsk(n, sps=25, seed=n + 1, noise=0.1, pause_every=3000, pause_len=400, dtype=dtype)
+            scale = 1.0 if dtype == np.float32 else float(np.abs(iq.astype(np.float64)).max())
+            for noise in (0.0, 0.4 * scale):
+                want = oracle.afp_demod(iq, noise, mod, 2)
+                got = sf.afp_demod(iq, noise, mod, 2)
+                assert bits_equal(got, want), (mod, np.dtype(dtype).name, n, noise, int((got != want).sum()))
+
+
 def test_afp_demod_signed_zero_and_nonfinite(sf, oracle):
     vals = np.array([0.0, -0.0, 1.0, -1.0, 1e-40, -1e-40, 1e-30, 3e38, -3e38, 0.5, -0.25], dtype=np.float32)
     rng = np.random.default_rng(5)

@@ -63,4 +63,20 @@ del k, sym, ph
 pp = DemodParams("PSK", 2, 0.2, 0.0, 1.5, 5, 100)
 t = timed(lambda: pipe.afp_demod(psk, pp), reps=2)
 out["costas_order4"] = {"samples": m, "ms": t * 1e3, "Msamples/s": m / t / 1e6, "chunks(map,ckpt,serial)": pipe.ctx.costas_stats()}
+del psk
+# ---- the steps either side of the path ----
+from urh_amd import signal_functions as sf
+from urh_amd.path_creator import create_path_arrays
+from urh_amd.spectrogram import Spectrogram
+rng = np.random.default_rng(5)
+msgs = [rng.integers(0, 2, 10485).astype(np.uint8) for _ in range(segs)]
+t = timed(lambda: sf.modulate_messages_dev(msgs, 100, "FSK", [-20e3, 20e3], 1, 1.0, 40e3, 0.0, 1e6, [76] * segs, [0] * segs), reps=3)
+out["modulate_fsk_%d_messages" % segs] = {"ms": t * 1e3, "Msamples/s": n / t / 1e6, "GB/s(8B/sample written)": 8 * n / t / 1e9,
+                                           "note": "includes the host-side staging of the bits"}
+t = timed(lambda: create_path_arrays(qad, 0, n), reps=3)
+out["path_minmax_qad"] = {"ms": t * 1e3, "GB/s(4B/sample)": 4 * n / t / 1e9}
+spec = Spectrogram(iq[: n // 4])
+t = timed(lambda: spec.calculate_spectrogram(device=True), reps=3)
+out["spectrogram_db_1024_quarter"] = {"samples": n // 4, "ms": t * 1e3, "Msamples/s": n / 4 / t / 1e6,
+                                       "GB/s(16B read + 8B written per sample)": 24 * (n // 4) / t / 1e9}
 print(json.dumps(out, indent=1))

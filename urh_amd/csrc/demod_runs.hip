@@ -845,7 +845,8 @@ __device__ __forceinline__ uint32_t put_lane(uint32_t value, int row, uint32_t o
     return (uint32_t)urh_llvm_writelane_i32((int)value, row, (int)old);
 }
 
-template <int SRC, int DT, int MOD, bool WRITE_QAD>
+// RUNS = false: demodulation only (urhgpu_afp_demod[_dev], Signal.qad): the same streaming structure without the planes
+template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true>
 __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArgs p) {
     // One workgroup per chunk, URH_WPB wavefronts: wavefront w streams the w-th share of the chunk's rows on its own
     // (no barrier inside the streaming phase), so that the wavefronts resident on the chip cover a NARROW window of
@@ -861,7 +862,7 @@ __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArg
     const int nr = (int)((a1 - a0) / kRowSamples);            // whole rows in this chunk: 16, 32, 48 or 64
     const int R = nr / W;                                     // rows of this wavefront: [w R, w R + R)
     const int r0 = w * R;
-    uint64_t *slab = p.slab + chunk * p.slab_stride;
+    uint64_t *slab = RUNS ? p.slab + chunk * p.slab_stride : nullptr;
     const bool global_start = (p.left_halo == nullptr);
     const bool first_row = (a0 == 0) && global_start && (w == 0);   // this wavefront holds sample 0 of the capture
 
@@ -872,8 +873,12 @@ __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArg
 
     float prev_c = 0.f, prev_d = 0.f;                         // IQ sample before my first row (FSK seam operand)
     uint32_t st_before = kStNone;                             // state of sample a0-1: wavefront 0 (it runs phase 2)
-    if (w == 0) st_before = chunk_prologue<SRC, DT, MOD, true>(p, a0, global_start, prev_c, prev_d);
-    else if (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK) Iq<DT>::load1(p.in, a0 + (int64_t)r0 * kRowSamples - 1, prev_c, prev_d);
+    if (w == 0 && RUNS) st_before = chunk_prologue<SRC, DT, MOD, true>(p, a0, global_start, prev_c, prev_d);
+    else if (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK) {
+        const int64_t before = a0 + (int64_t)r0 * kRowSamples - 1;
+        if (before >= 0) Iq<DT>::load1(p.in, before, prev_c, prev_d);
+        else if (!global_start) Iq<DT>::load1(p.left_halo, 1, prev_c, prev_d);
+    }
 
     // ================= phase 1: demodulate, one compare mask per plane and parity, parked in lane `row` ==============
     uint32_t be_lo = 0, be_hi = 0, bo_lo = 0, bo_hi = 0, pe_lo = 0, pe_hi = 0, po_lo = 0, po_hi = 0;
@@ -898,6 +903,7 @@ __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArg
 #endif
                 }
             }
+            if (!RUNS) continue;
             uint64_t Be = __builtin_amdgcn_ballot_w64(q0[j] <= p.thr[0]), Bo = __builtin_amdgcn_ballot_w64(q1[j] <= p.thr[0]);
             const int row = rb + j;
             if (((gated >> j) & 1u) || row0) {                 // wavefront-uniform: some sample may be the NOISE sentinel
@@ -913,6 +919,7 @@ __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArg
         for (int j = 0; j < kBatch; ++j) cur[j] = nxt[j];
     }
 
+    if (!RUNS) return;
     // the chunk's planes come together in wavefront 0 (lane r <- row r)
     if (W > 1) {
         if (w != 0) {
@@ -1182,13 +1189,35 @@ int launch_runs_qad(const RunArgs &a, hipStream_t s) {
     return URHGPU_OK;
 }
 
+template <int DT, int MOD>
+static void launch_afp_3(const RunArgs &a0, int grid, hipStream_t s) {
+    // whole chunks of 64 rows through the streaming structure of the hot kernel, the remainder through k_afp_demod
+    RunArgs a = a0;
+    const int64_t chunk = (int64_t)kBpMaxRows * kRowSamples;
+    const int64_t n_main = (a.n / chunk) * chunk;
+    if (n_main > 0) {
+        a.chunk_len = chunk; a.range_begin = 0; a.range_end = n_main; a.chunk_base = 0;
+        hipLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, DT, MOD, true, false>), dim3((unsigned)(n_main / chunk)), dim3(kBlock * URH_WPB), 0, s, a);
+    }
+    if (n_main < a.n) {
+        RunArgs t = a0;
+        if (n_main > 0) {
+            t.in = (const char *)a0.in + (size_t)n_main * Iq<DT>::kBytes;
+            t.left_halo = (const char *)a0.in + (size_t)(n_main - 2) * Iq<DT>::kBytes;
+            t.qad = a0.qad + n_main;
+            t.n = a0.n - n_main;
+        }
+        const int g = (int)std::min<int64_t>(grid, (t.n + kAfpRow - 1) / kAfpRow);
+        hipLaunchKernelGGL((k_afp_demod<DT, MOD>), dim3(g), dim3(kAfpBlock), 0, s, t);
+    }
+}
+
 template <int DT>
 static int launch_afp_2(const RunArgs &a, int mod, int grid, hipStream_t s) {
-    dim3 g(grid), b(kAfpBlock);
     switch (mod) {
-        case URHGPU_MOD_ASK: hipLaunchKernelGGL((k_afp_demod<DT, URHGPU_MOD_ASK>), g, b, 0, s, a); return URHGPU_OK;
-        case URHGPU_MOD_FSK: hipLaunchKernelGGL((k_afp_demod<DT, URHGPU_MOD_FSK>), g, b, 0, s, a); return URHGPU_OK;
-        case URHGPU_MOD_OTHER: hipLaunchKernelGGL((k_afp_demod<DT, URHGPU_MOD_OTHER>), g, b, 0, s, a); return URHGPU_OK;
+        case URHGPU_MOD_ASK: launch_afp_3<DT, URHGPU_MOD_ASK>(a, grid, s); return URHGPU_OK;
+        case URHGPU_MOD_FSK: launch_afp_3<DT, URHGPU_MOD_FSK>(a, grid, s); return URHGPU_OK;
+        case URHGPU_MOD_OTHER: launch_afp_3<DT, URHGPU_MOD_OTHER>(a, grid, s); return URHGPU_OK;
         default: return URHGPU_ERR_ARG;
     }
 }
