@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Run the REAL reference's AutoInterpretation.estimate (this container only) on the IQ of every float32 golden capture
-(all dtypes) and store what it returns in tests/golden/estimates.json; the GPU test compares urh_amd.estimators.estimate_dev with it.
+(all dtypes) and store what it returns in tests/golden/estimates.json; the GPU test compares urh_amd.estimators.estimate_dev with it
+(`detect`: modulation=None, i.e. detect_modulation_for_messages decides).
 
     python tests/golden/make_estimate_golden.py
 """
@@ -25,10 +26,10 @@ for f in sorted(os.listdir(HERE)):
     z = np.load(os.path.join(HERE, f))
     iq = z["iq"]
     mod = str(z["modulation_type"])
-    for m in ([mod, "OOK"] if mod == "ASK" else [mod]):
+    for m in ([mod, "OOK", None] if mod == "ASK" else [mod, None]):
         for noise in (None, float(z["noise_threshold"])):
             r = AI.estimate(iq, noise=noise, modulation=m)
-            key = f"{f[:-4]}|{m}|{'auto' if noise is None else 'given'}"
+            key = f"{f[:-4]}|{m if m is not None else 'detect'}|{'auto' if noise is None else 'given'}"
             out[key] = None if r is None else {k: (float(v) if k in ("center", "noise") else (int(v) if k != "modulation_type" else v))
                                                for k, v in r.items()}
             print(key, out[key])

@@ -69,3 +69,48 @@ def test_segment_and_value_helpers_equal_reference(ref):
         for fn in ("max_without_outliers", "min_without_outliers"):
             x, y = getattr(AI, fn)(d), getattr(e, fn)(d)
             assert (x is None and y is None) or x == y
+
+
+def test_median_filter_equals_reference(ref):
+    AI, c_ai = ref
+    rng = np.random.default_rng(4)
+    for n in (0, 1, 2, 5, 10, 11, 12, 100, 1000):
+        x = rng.standard_normal(n) * rng.choice([1e-3, 1.0, 1e6])
+        for k in (1, 2, 3, 11, 12):
+            want = c_ai.median_filter(x, k=k)
+            got = e.median_filter(x, k=k)
+            assert got.dtype == want.dtype and np.array_equal(got, want), (n, k)
+
+
+def test_detect_modulation_equals_reference(ref):
+    """AutoInterpretation.detect_modulation on every message the reference segments out of the golden captures, plus
+    synthetic ASK / PSK / noise messages: the same label."""
+    import os
+    from conftest import GOLDEN_DIR
+    AI, c_ai = ref
+    from urh.signalprocessing.IQArray import IQArray
+    n_checked = 0
+    for f in sorted(os.listdir(GOLDEN_DIR)):
+        if not f.endswith(".npz"):
+            continue
+        z = np.load(os.path.join(GOLDEN_DIR, f))
+        if "iq" not in z:
+            continue
+        iq = z["iq"]
+        arr = IQArray(iq)
+        noise = AI.detect_noise_level(arr.magnitudes)
+        segs = AI.segment_messages_from_magnitudes(arr.magnitudes, noise_threshold=noise)
+        cplx = arr.as_complex64()
+        assert np.array_equal(e._as_complex64(iq).view(np.uint32), cplx.view(np.uint32)), f
+        for start, end in segs[:100]:
+            assert e.detect_modulation(cplx[start:end]) == AI.detect_modulation(cplx[start:end]), (f, start, end)
+            n_checked += 1
+    rng = np.random.default_rng(12)
+    t = np.arange(4096)
+    for msg in (np.exp(2j * np.pi * 0.05 * t) * np.repeat(rng.integers(1, 3, 64), 64),
+                np.exp(2j * np.pi * 0.05 * t + 1j * np.pi * np.repeat(rng.integers(0, 2, 64), 64)),
+                rng.standard_normal(4096) + 1j * rng.standard_normal(4096), np.zeros(100), np.ones(3)):
+        msg = (msg + 0.01 * (rng.standard_normal(len(msg)) + 1j * rng.standard_normal(len(msg))) * (np.abs(msg) > 0)).astype(np.complex64)
+        assert e.detect_modulation(msg) == AI.detect_modulation(msg)
+        n_checked += 1
+    assert n_checked > 20

@@ -360,19 +360,136 @@ def get_bit_length_from_plateau_lengths(merged_plateau_lengths) -> int:
     return int(result)
 
 
+# ---- modulation detection (host, like the reference: numpy on the first 100 messages) -----------------------------
+def median_filter(data, k: int = 3) -> np.ndarray:
+    """auto_interpretation.median_filter (auto_interpretation.pyx:213-240): float32 result; the window of sample i is
+    data[i : i + k] cut at the end of the array (`start` is computed and ignored, :233-238), values rounded to float32
+    before the sort, result = sorted[k' // 2]."""
+    x = np.asarray(data, dtype=np.float64).astype(np.float32)
+    n = len(x)
+    out = np.zeros(n, dtype=np.float32)
+    if n == 0:
+        return out
+    k = int(k)
+    full = n - k + 1
+    if full > 0:
+        win = np.lib.stride_tricks.sliding_window_view(x, k)
+        out[:full] = np.sort(win, axis=1)[:, k // 2]
+    for i in range(max(full, 0), n):
+        w = np.sort(x[i:n])
+        out[i] = w[len(w) // 2]
+    return out
+
+
+def normalized_haar_wavelet(omega, scale):
+    """Wavelet.normalized_haar_wavelet (Wavelet.py:7-12)"""
+    omega_cpy = omega[:] / scale
+    omega_cpy[0] = 1.0
+    return (1j * np.square(-1 + np.exp(0.5j * omega))) / omega_cpy
+
+
+def cwt_haar(x: np.ndarray, scale=10):
+    """Wavelet.cwt_haar (Wavelet.py:15-43)"""
+    next_power_two = 2 ** int(np.log2(len(x)))
+    x = x[0:next_power_two]
+    num_data = len(x)
+    x_hat = np.fft.fft(x)
+    f = 2.0 * np.pi / num_data
+    omega = f * np.concatenate((np.arange(0, num_data // 2), np.arange(num_data // 2, num_data) * -1))
+    psi_hat = np.sqrt(2.0 * np.pi * scale) * normalized_haar_wavelet(scale * omega, scale)
+    W = np.fft.ifft(x_hat * psi_hat)
+    return W[2 * scale:-2 * scale]
+
+
+def detect_modulation(data: np.ndarray, wavelet_scale=4, median_filter_order=11):
+    """AutoInterpretation.detect_modulation (AutoInterpretation.py:150-205) for ONE message (complex64 samples on the host)."""
+    n_data = len(data)
+    data = data[np.abs(data) > 0]
+    if len(data) == 0:
+        return None
+    if n_data - len(data) > 3:
+        return "OOK"
+    data = data / np.abs(np.max(data))
+    mag_wavlt = np.abs(cwt_haar(data, scale=wavelet_scale))
+    if len(mag_wavlt) == 0:
+        return None
+    norm_mag_wavlt = np.abs(cwt_haar(data / np.abs(data), scale=wavelet_scale))
+    var_mag = np.var(mag_wavlt)
+    var_norm_mag = np.var(norm_mag_wavlt)
+    var_filtered_mag = np.var(median_filter(mag_wavlt, k=median_filter_order))
+    var_filtered_norm_mag = np.var(median_filter(norm_mag_wavlt, k=median_filter_order))
+    if all(v < 0.15 for v in (var_mag, var_norm_mag, var_filtered_mag, var_filtered_norm_mag)):
+        return "OOK"
+    if var_mag > 1.5 * var_norm_mag:
+        return "ASK"
+    if var_mag > 10 * var_filtered_mag:
+        return "PSK"
+    fft = np.fft.fft(data[0:2 ** int(np.log2(len(data)))])
+    fft = np.abs(np.fft.fftshift(fft))
+    ten_greatest_indices = np.argsort(fft)[::-1][0:10]
+    greatest_index = ten_greatest_indices[0]
+    min_distance = 10
+    min_freq = 100
+    if any(abs(i - greatest_index) >= min_distance and fft[i] >= min_freq for i in ten_greatest_indices):
+        return "FSK"
+    return "OOK"
+
+
+def most_common(values: list):
+    """AutoInterpretation.most_common (:50-57): ties go to the value that appears first"""
+    from collections import Counter
+    counter = Counter(values)
+    return max(values, key=counter.get)
+
+
+def _as_complex64(iq_host: np.ndarray) -> np.ndarray:
+    """IQArray.as_complex64 (IQArray.py:92-93) = convert_to(np.float32) (:127-185) viewed as complex64: integer captures are
+    scaled with the reference's float32 operations (multiply by 1/128 or 1/32768, unsigned types then add -1)."""
+    a = iq_host
+    if a.dtype == np.float32:
+        f = a
+    elif a.dtype == np.uint8:
+        f = np.add(np.multiply(a, 1 / 128, dtype=np.float32), -1.0, dtype=np.float32)
+    elif a.dtype == np.int8:
+        f = np.multiply(a, 1 / 128, dtype=np.float32)
+    elif a.dtype == np.uint16:
+        f = np.add(np.multiply(a, 1 / 32768, dtype=np.float32), -1.0, dtype=np.float32)
+    elif a.dtype == np.int16:
+        f = np.multiply(a, 1 / 32768, dtype=np.float32)
+    else:
+        raise ValueError("Unsupported dtype")
+    return np.ascontiguousarray(f).flatten(order="C").view(np.complex64)
+
+
+def detect_modulation_for_messages_dev(iq, message_indices: list):
+    """AutoInterpretation.detect_modulation_for_messages (:208-223): the first 100 messages are copied to the host (a message is
+    a few thousand samples) and classified there, exactly as the reference does with numpy."""
+    max_messages = 100
+    mods = []
+    for start, end in message_indices[0:max_messages]:
+        mod = detect_modulation(_as_complex64(iq[start:end].cpu().numpy()))
+        if mod is not None:
+            mods.append(mod)
+    if len(mods) == 0:
+        return None
+    return most_common(mods)
+
+
 def estimate_dev(pipe, iq, noise: float = None, modulation: str = None):
     """AutoInterpretation.estimate (AutoInterpretation.py:373-470) for a float32 capture resident on the GPU: every pass
     over the samples (magnitude statistics, segmentation, demodulation, per-message center and plateau boundaries) runs
-    on the GPU, the per-message decisions on the host.  `modulation` must be given: detect_modulation (wavelet transform)
-    is not on this path yet."""
+    on the GPU, the per-message decisions -- including detect_modulation on the first 100 messages, numpy like the
+    reference -- on the host."""
     from .pipeline import DemodParams
     torch = pipe.torch
     if iq.dtype == torch.complex64:
         iq = torch.view_as_real(iq)
-    if modulation is None:
-        raise NotImplementedError("automatic modulation detection is not part of the GPU path: pass modulation=")
     noise = detect_noise_level_dev(pipe, iq) if noise is None else noise
     message_indices = segment_messages_dev(pipe, iq, noise)
+    if modulation is None:
+        modulation = detect_modulation_for_messages_dev(iq, message_indices)
+        if modulation is None:
+            return None
     if modulation == "OOK":
         message_indices = merge_message_segments_for_ook(message_indices)
     if modulation in ("OOK", "ASK"):
