@@ -195,6 +195,39 @@ def test_fused_equals_oracle_medium(pipe, oracle, mod):
         assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
 
 
+def test_fused_randomised_vs_oracle(pipe, oracle):
+    """Differential fuzz of the fused device path against the oracle: random sizes (chunk and row boundaries fall anywhere in
+    runs and pauses), tolerances, samples per symbol, noise gates, centers, sample types; everything bit-exact."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    rng = np.random.default_rng(2026)
+    for it in range(160):
+        n = int(rng.choice([rng.integers(3, 300), rng.integers(300, 9000), rng.integers(9000, 70_000)]))
+        sps = int(rng.choice([1, 2, 5, 17, 100, 333]))
+        dtype = [np.float32, np.float32, np.int8, np.uint8, np.int16, np.uint16][it % 6]
+        mod = "FSK" if it % 2 == 0 else "ASK"
+        pe = int(rng.choice([0, max(n // 3, 1), 2500]))
+        iq = synth_fsk(n, sps=sps, seed=it, noise=float(rng.choice([0.0, 0.02, 0.3])), pause_every=pe,
+                       pause_len=int(rng.choice([1, 7, 130, 2100])) if pe else 0, dtype=dtype)
+        scale = 1.0 if dtype == np.float32 else float(np.abs(iq.astype(np.float64)).max())
+        if mod == "ASK":
+            env = np.repeat(rng.integers(0, 2, n // sps + 1), sps)[:n]
+            iq = (iq.astype(np.float32) * (0.05 + 0.95 * env)[:, None]).astype(dtype)
+        tol = int(rng.choice([0, 1, 2, 5, 9, 64, 200]))
+        noise = float(rng.choice([0.0, 0.2, 0.6])) * scale
+        center = float(rng.choice([0.0, 0.1, -0.2])) if mod == "FSK" else float(rng.choice([0.05, 0.35, 0.8]))
+        pt = int(rng.choice([0, 1, 8]))
+        p = DemodParams(mod, 1, noise, center, 1.0, tol, sps, 0.1, pt, True)
+        qad = oracle.afp_demod(iq, noise, mod, 2)
+        pp = oracle.grab_pulse_lens(qad, center, tol, mod, sps, 1, 1.0)
+        fb = oracle.ppseq_to_bits_flat(pp, sps, 1, True, pt)
+        res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True, cap_rows=n // (tol + 1) + 2)
+        ctxt = (it, n, sps, np.dtype(dtype).name, mod, tol, noise, center, pt)
+        assert bits_equal(res.qad.cpu().numpy(), qad), ctxt
+        assert np.array_equal(res.ppseq(), pp), ctxt
+        assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat())), ctxt
+
+
 @pytest.mark.parametrize("mod", ["FSK", "ASK"])
 def test_bit_plane_kernel_equals_state_byte_kernel(pipe, oracle, mod):
     """Modulation order 2 runs k_demod_runs_bp (bit planes, wavefronts sharing a chunk), every other order the
