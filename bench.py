@@ -175,7 +175,7 @@ def main():
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         bytes_per_sample = ALGO_BYTES_PER_SAMPLE if want_qad else 8
         achieved = (n * bytes_per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, traffic_src = (pmc_traffic("k_demod_runs_bp<0, 4, 1, true>") if want_qad and n == 128 * SEG
+        traffic, traffic_src = (pmc_traffic("k_demod_runs_bp<0, 4, 1, true") if want_qad and n == 128 * SEG
                                 else (None, None))
         out = {
             "metric": "Msamples/s IQ->bits (1 GiB complex64 2-FSK per GPU, qad materialised)",
