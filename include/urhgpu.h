@@ -303,6 +303,10 @@ int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint
                     const float *parameters, int bits_per_symbol, float carrier_amplitude, float carrier_frequency,
                     float carrier_phase, float sample_rate, uint32_t pause, uint32_t start, int dtype, void *out);
 
+/* IQArray.convert_to (IQArray.py:127-203) on device memory: n VALUES (two per IQ sample) of src_dtype -> dst_dtype, any
+ * pair of different URHGPU_DT_* codes, with the reference's wrapping / truncating numpy semantics.  Asynchronous. */
+int urhgpu_convert_dev(urhgpu_ctx *ctx, const void *d_src, int src_dtype, void *d_dst, int dst_dtype, int64_t n);
+
 /* path_creator.create_path's pass over the samples (path_creator.pyx:46-66): 1-D samples of dtype (the five IQ sample
  * types), stretches of samples_per_pixel samples from `start` (the last one ends at `end`); values[2k] / values[2k+1] =
  * minimum / maximum of stretch k exactly as the reference's sequential scan finds them (NaN and signed-zero behaviour

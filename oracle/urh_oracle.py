@@ -351,3 +351,56 @@ def create_path_arrays(samples, start: int, end: int, subpath_ranges=None, pixel
         s1 = int(max(0, math.ceil(s1)))
         out.append((x[s0:s1], values[s0:s1]))
     return out
+
+
+def convert_to(data: np.ndarray, target_dtype) -> np.ndarray:
+    """IQArray.convert_to (IQArray.py:127-203), the numpy expressions of the reference one to one."""
+    target_dtype = np.dtype(target_dtype).type
+    if target_dtype == data.dtype:
+        return data
+    if data.dtype == np.uint8:
+        if target_dtype == np.int8:
+            return np.add(data, -128, dtype=np.int8, casting="unsafe")
+        elif target_dtype == np.int16:
+            return np.add(data, -128, dtype=np.int16, casting="unsafe") << 8
+        elif target_dtype == np.uint16:
+            return data.astype(np.uint16) << 8
+        elif target_dtype == np.float32:
+            return np.add(np.multiply(data, 1 / 128, dtype=np.float32), -1.0, dtype=np.float32)
+    if data.dtype == np.int8:
+        if target_dtype == np.uint8:
+            return np.add(data, 128, dtype=np.uint8, casting="unsafe")
+        elif target_dtype == np.int16:
+            return data.astype(np.int16) << 8
+        elif target_dtype == np.uint16:
+            return np.add(data, 128, dtype=np.uint16, casting="unsafe") << 8
+        elif target_dtype == np.float32:
+            return np.multiply(data, 1 / 128, dtype=np.float32)
+    if data.dtype == np.uint16:
+        if target_dtype == np.int8:
+            return (np.add(data, -32768, dtype=np.int16, casting="unsafe") >> 8).astype(np.int8)
+        elif target_dtype == np.uint8:
+            return (data >> 8).astype(np.uint8)
+        elif target_dtype == np.int16:
+            return np.add(data, -32768, dtype=np.int16, casting="unsafe")
+        elif target_dtype == np.float32:
+            return np.add(np.multiply(data, 1 / 32768, dtype=np.float32), -1.0, dtype=np.float32)
+    if data.dtype == np.int16:
+        if target_dtype == np.int8:
+            return (data >> 8).astype(np.int8)
+        elif target_dtype == np.uint8:
+            return (np.add(data, 32768, dtype=np.uint16, casting="unsafe") >> 8).astype(np.uint8)
+        elif target_dtype == np.uint16:
+            return np.add(data, 32768, dtype=np.uint16, casting="unsafe")
+        elif target_dtype == np.float32:
+            return np.multiply(data, 1 / 32768, dtype=np.float32)
+    if data.dtype == np.float32:
+        if target_dtype == np.int8:
+            return np.multiply(data, 127, dtype=np.float32).astype(np.int8)
+        elif target_dtype == np.uint8:
+            return np.multiply(np.add(data, 1.0, dtype=np.float32), 127, dtype=np.float32).astype(np.uint8)
+        elif target_dtype == np.int16:
+            return np.multiply(data, 32767, dtype=np.float32).astype(np.int16)
+        elif target_dtype == np.uint16:
+            return np.multiply(np.add(data, 1.0, dtype=np.float32), 32767, dtype=np.float32).astype(np.uint16)
+    raise ValueError("Data type {} not supported".format(target_dtype))

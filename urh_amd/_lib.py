@@ -98,6 +98,7 @@ PROTOTYPES = {
     "urhgpu_modulate": (_i, [_vp, _vp, _i64, C.c_uint32, _i, _vp, _i, _f, _f, _f, _f, C.c_uint32, C.c_uint32, _i, _vp]),
     "urhgpu_spectrogram_dev": (_i, [_vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "urhgpu_bgra_lookup_dev": (_i, [_vp, _vp, _i64, _i, _vp, _i, _f, _f, _vp]),
+    "urhgpu_convert_dev": (_i, [_vp, _vp, _i, _vp, _i, _i64]),
     "urhgpu_path_minmax_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp]),
     "urhgpu_path_minmax": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _vp]),
     "urhgpu_test_force_state_bytes": (_i, [_i]),

@@ -47,7 +47,7 @@ Plan make_plan(const urhgpu_ctx *ctx, int64_t n, int tol) {
     // whole tiles are grouped into chunks of tiles_per_chunk tiles (one workgroup each); a partial
     // tile at the end of the capture is one more chunk (see launch_runs_4 in demod_runs.hip)
     const int64_t full_tiles = n / kTile;
-    const int64_t target = (int64_t)ctx->prop.multiProcessorCount * 64;      // chunks (= wavefronts): ~2-3 rounds of the resident set
+    const int64_t target = (int64_t)ctx->prop.multiProcessorCount * 16;      // chunks (four wavefronts each in the bit-plane kernel): ~2 rounds of the resident set
     // at most 4 tiles = 64 rows per chunk: the bit-plane kernel parks one row per lane (kBpMaxRows)
     const int64_t tiles_per_chunk = std::min<int64_t>(4, std::max<int64_t>(1, (full_tiles + target - 1) / target));
     pl.chunk_len = tiles_per_chunk * kTile;
@@ -937,6 +937,16 @@ int urhgpu_bgra_lookup_dev(urhgpu_ctx *ctx, const float *d_db, int64_t frames, i
     URH_HIP(hipSetDevice(ctx->device));
     URH_TRY(join_tail(ctx));
     URH_TRY(launch_bgra_lookup(d_db, frames, window_size, d_colormap, n_colors, data_min, data_max, d_image, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_convert_dev(urhgpu_ctx *ctx, const void *d_src, int src_dtype, void *d_dst, int dst_dtype, int64_t n) {
+    if (!ctx || n < 0 || (n > 0 && (!d_src || !d_dst))) return URHGPU_ERR_ARG;
+    if (src_dtype == dst_dtype) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(launch_convert(d_src, src_dtype, d_dst, dst_dtype, n, ctx->stream));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }

@@ -68,6 +68,9 @@ int launch_stft(const float2 *x, int64_t n, int ws, int64_t hop, int64_t frames,
 int launch_bgra_lookup(const float *data, int64_t frames, int ws, const uint32_t *colormap, int n_colors, float dmin, float dmax,
                        uint32_t *image, hipStream_t s);
 
+// ---- convert.hip -------------------------------------------------------------------------------------
+int launch_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, hipStream_t s);
+
 // ---- plot.hip ----------------------------------------------------------------------------------------
 int launch_path_minmax(const void *samples, int dtype, int64_t start, int64_t end, int64_t spp, void *values, hipStream_t s);
 
