@@ -24,7 +24,7 @@ namespace urh {
 // over small int arrays: "last chunk before me that has X" is an exclusive max-scan of (c if X else -1).
 // =====================================================================================================
 #ifndef URH_RESOLVE_BLOCK
-#define URH_RESOLVE_BLOCK 1024
+#define URH_RESOLVE_BLOCK 256
 #endif
 #ifndef URH_RESOLVE_ITEMS
 #define URH_RESOLVE_ITEMS 4
@@ -110,6 +110,7 @@ template <bool WITH_SUM>
 __device__ __forceinline__ void blocks_before(const int32_t *blk_m, const int64_t *blk_s, int64_t b, int32_t &pm, int64_t &ps) {
     __shared__ int32_t s_pm;
     __shared__ int64_t s_ps;
+    __syncthreads();                                       // a previous call's result may still be read
     if (threadIdx.x < 64) {
         int32_t m = -1; int64_t v = 0;
         for (int64_t u = threadIdx.x; u < b; u += 64) { m = max(m, blk_m[u]); if (WITH_SUM) v += blk_s[u]; }
@@ -146,16 +147,18 @@ __device__ __forceinline__ void chunk_last_acc(const ChunkInfo &ci, int64_t &pos
 
 // Totals and the final row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487): one thread,
 // from the workgroup totals.  out_off values it needs are rebuilt from the workgroup-local offsets (sc.out_cnt).
-__device__ __forceinline__ void resolve_finish(const ResolveArgs &a) {
-    const int64_t nb = resolve_blocks(a.n_chunks);
-    int32_t last_c = -1, last_stable = -1; int64_t P = 0;
-    for (int64_t u = 0; u < nb; ++u) { last_c = max(last_c, a.sc.blk_acc[u]); last_stable = max(last_stable, a.sc.blk_stable[u]); P += a.sc.blk_cnt[u]; }
-    a.aux->last_stable = last_stable;
-    auto global_off = [&](int64_t c) {                     // out_off[c] without waiting for the other workgroups of this launch
-        int64_t o = a.sc.out_cnt[c];
-        for (int64_t u = 0; u < c / kResolveBlock; ++u) o += a.sc.blk_cnt[u];
-        return o;
-    };
+struct ResolveTotals {       // sums / maxima over the workgroup totals, computed by the whole of workgroup 0 (k_resolve_c)
+    int32_t last_c, last_stable;
+    int64_t P;               // accepted runs in the whole table
+    int64_t before_first;    // accepted runs in the resolve workgroups before the one that holds chunk_first
+    int64_t before_end;      //   ... before the one that holds chunk_first + n_local
+};
+
+__device__ __forceinline__ void resolve_finish(const ResolveArgs &a, const ResolveTotals &t) {
+    const int32_t last_c = t.last_c;
+    const int64_t P = t.P;
+    a.aux->last_stable = t.last_stable;
+    auto global_off = [&](int64_t c, int64_t before) { return a.sc.out_cnt[c] + before; };   // out_off[c] from the local offset
     {
         *a.d_n_acc = P;
         if (a.local_pass) {
@@ -183,8 +186,8 @@ __device__ __forceinline__ void resolve_finish(const ResolveArgs &a) {
             return;
         }
         // this GPU's rows are global rows [row_base, row_end) (+ the table's last row on the last GPU)
-        const int64_t row_base = global_off(a.chunk_first);
-        const int64_t row_end = (a.chunk_first + a.n_local < a.n_chunks) ? global_off(a.chunk_first + a.n_local) : P;
+        const int64_t row_base = global_off(a.chunk_first, t.before_first);
+        const int64_t row_end = (a.chunk_first + a.n_local < a.n_chunks) ? global_off(a.chunk_first + a.n_local, t.before_end) : P;
         int64_t n_rows = row_end - row_base;
         if (P < a.n_total && a.write_last_row) {
             const int64_t o = P - row_base;
@@ -233,9 +236,20 @@ __global__ __launch_bounds__(kResolveBlock) void k_resolve_c(const ResolveArgs a
     int32_t pm; int64_t ps;
     blocks_before<true>(a.sc.blk_acc, a.sc.blk_cnt, blockIdx.x, pm, ps);
     if (c < a.n_chunks) { a.sc.out_off[c] = a.sc.out_cnt[c] + ps; a.sc.prev_acc[c] = max(a.sc.has_acc[c], pm); }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        resolve_finish(a);
-        a.aux->first_nonlead = kAuxNone; a.aux->open_chunk = kAuxNone; a.aux->first_stable = kAuxNone; a.aux->last_stable = -1;
+    if (blockIdx.x == 0) {                                 // totals, last row: workgroup 0 sums the workgroup totals together
+        const int64_t nb = resolve_blocks(a.n_chunks);
+        ResolveTotals t;
+        int64_t dummy;
+        blocks_before<true>(a.sc.blk_acc, a.sc.blk_cnt, nb, t.last_c, t.P);
+        blocks_before<false>(a.sc.blk_stable, nullptr, nb, t.last_stable, dummy);
+        int32_t dm;
+        blocks_before<true>(a.sc.blk_acc, a.sc.blk_cnt, a.chunk_first / kResolveBlock, dm, t.before_first);
+        const int64_t ce = (a.chunk_first + a.n_local < a.n_chunks) ? a.chunk_first + a.n_local : 0;
+        blocks_before<true>(a.sc.blk_acc, a.sc.blk_cnt, ce / kResolveBlock, dm, t.before_end);
+        if (threadIdx.x == 0) {
+            resolve_finish(a, t);
+            a.aux->first_nonlead = kAuxNone; a.aux->open_chunk = kAuxNone; a.aux->first_stable = kAuxNone; a.aux->last_stable = -1;
+        }
     }
 }
 
