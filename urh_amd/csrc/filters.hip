@@ -51,6 +51,38 @@ struct FirArgs {
 // terms of at most 2^121) and the per-product NaN test is skipped (wave-uniform branch): a third of the instructions.
 constexpr uint32_t kFirSafeBits = 0x5d800000u;   // 2^60
 
+typedef float fir_v2f __attribute__((ext_vector_type(2)));
+
+// LDS layout of the staged input: one pad element after every 8 samples.  Lane t reads at 8 t + c (c uniform): without the
+// pad that is a 64-byte lane stride -- every 8-byte read of a wavefront lands in 2 of the 32 banks; with it the stride is
+// 72 bytes and the 32 lanes of a half-wavefront cover all banks once.
+__device__ __forceinline__ int fir_pad(int i) { return i + (i >> 3); }
+
+// Two complex multiply-accumulates accA += xA * h, accB += xB * h with the reference's operation sequence
+// (re = fl(fl(x.re h.re) - fl(x.im h.im)), im = fl(fl(x.re h.im) + fl(x.im h.re)), then the two rounded adds into acc) as
+// FOUR packed instructions per product instead of the six the compiler emits for the C++ form (it computes t1 - t2 and
+// t1 + t2 separately and keeps half of each, because it does not mix neg_lo / neg_hi):
+//   t1 = (x.re h.re, x.re h.im)          v_pk_mul  x low half broadcast
+//   t2 = (x.im h.im, x.im h.re)          v_pk_mul  x high half broadcast, h halves swapped by op_sel
+//   p  = (t1.lo - t2.lo, t1.hi + t2.hi)  v_pk_add  neg_lo on t2 only
+//   acc += p                             v_pk_add
+// The two products are interleaved so that no instruction reads the result of the one right before it (a dependent
+// packed operation needs one wait state on gfx950; the assembler does not add it inside an asm block).
+__device__ __forceinline__ void fir_cmac2(fir_v2f &accA, fir_v2f &accB, fir_v2f xA, fir_v2f xB, fir_v2f h) {
+    fir_v2f t1a, t2a, t1b, t2b;
+    asm volatile(
+        "v_pk_mul_f32 %2, %6, %8 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %6, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %4, %7, %8 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %5, %7, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %2, %2, %3 neg_lo:[0,1] neg_hi:[0,0]\n\t"
+        "v_pk_add_f32 %4, %4, %5 neg_lo:[0,1] neg_hi:[0,0]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\t"
+        "v_pk_add_f32 %1, %1, %4"
+        : "+v"(accA), "+v"(accB), "=&v"(t1a), "=&v"(t2a), "=&v"(t1b), "=&v"(t2b)
+        : "v"(xA), "v"(xB), "v"(h));
+}
+
 template <bool HEAD, bool CHECKED>
 __device__ __forceinline__ void fir_accumulate(const FirArgs &a, const float2 *s_taps, const float2 *s_x, int t, int64_t k0,
                                                float2 (&acc)[kFirR]) {
@@ -60,12 +92,29 @@ __device__ __forceinline__ void fir_accumulate(const FirArgs &a, const float2 *s
     float2 W[2 * R - 1];
     const int lds0 = R * t + a.hist - (R - 1);
 #pragma unroll
-    for (int u = 0; u < R - 1; ++u) W[u + R] = s_x[lds0 - jb_top - R + u + R];   // becomes W[u] after the first shift
+    for (int u = 0; u < R - 1; ++u) W[u + R] = s_x[fir_pad(lds0 - jb_top - R + u + R)];   // becomes W[u] after the first shift
     for (int jb = jb_top; jb >= 0; jb -= R) {
 #pragma unroll
         for (int u = 0; u < R - 1; ++u) W[u] = W[u + R];
 #pragma unroll
-        for (int u = R - 1; u < 2 * R - 1; ++u) W[u] = s_x[lds0 - jb + u];
+        for (int u = R - 1; u < 2 * R - 1; ++u) W[u] = s_x[fir_pad(lds0 - jb + u)];
+        if (!HEAD && !CHECKED && jb + R <= a.m) {            // a full block of taps, finite operands: the packed fast path
+            float2 hb[R];
+#pragma unroll
+            for (int tj = 0; tj < R; ++tj) hb[tj] = s_taps[jb + tj];             // LDS broadcast reads (the taps are staged once per tile)
+#pragma unroll
+            for (int tj = R - 1; tj >= 0; --tj) {
+                const fir_v2f h = {hb[tj].x, hb[tj].y};
+#pragma unroll
+                for (int r = 0; r < R; r += 2) {
+                    fir_v2f aA = {acc[r].x, acc[r].y}, aB = {acc[r + 1].x, acc[r + 1].y};
+                    const float2 xa = W[r + (R - 1 - tj)], xb = W[r + 1 + (R - 1 - tj)];
+                    fir_cmac2(aA, aB, fir_v2f{xa.x, xa.y}, fir_v2f{xb.x, xb.y}, h);
+                    acc[r] = make_float2(aA.x, aA.y); acc[r + 1] = make_float2(aB.x, aB.y);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int tj = R - 1; tj >= 0; --tj) {
             const int j = jb + tj;
@@ -108,7 +157,7 @@ __global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
         float2 v = make_float2(0.f, 0.f);
         if (i >= 0) { if (i < a.n) v = a.x[i]; }
         else if (a.halo != nullptr && i + (a.m - 1) >= 0) v = a.halo[i + (a.m - 1)];
-        s_x[u] = v;
+        s_x[fir_pad(u)] = v;
         mb = max(mb, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu));
     }
     atomicMax(&s_maxbits, mb);
@@ -137,7 +186,7 @@ int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const floa
     FirArgs a;
     a.x = x; a.halo = halo; a.taps = taps; a.out = out; a.n = n; a.m = m;
     a.hist = ((m - 1) / kFirR) * kFirR + kFirR - 1;
-    const size_t lds = (size_t)(((m + 1) & ~1) + a.hist + kFirTile) * 8;
+    const size_t lds = (size_t)(((m + 1) & ~1) + (a.hist + kFirTile) + ((a.hist + kFirTile) >> 3) + 1) * 8;
     if (lds > 150 * 1024) return URHGPU_ERR_UNSUPPORTED;       // m <= ~8900 taps
     if (lds > 64 * 1024) {
         if (hipFuncSetAttribute((const void *)k_fir<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
