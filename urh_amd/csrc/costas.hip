@@ -137,6 +137,7 @@ struct SpecBuffers {
     CostasState *CP;       // [n_chunks][kNumCkpt][K] state after offset (j+1)*kCkpt samples of the chunk
     uint32_t *map;         // [n_chunks] nibble k: candidate of this chunk that starts in E[c-1][k], 0xF none
     CostasState *T;        // [n_chunks] TRUE state at the chunk start (written by the stitch)
+    int32_t *gidx;         // [n_chunks] candidate whose trajectory IS the true one over the whole chunk, or -1 (written by the stitch)
     int32_t *ungated;      // [n_chunks] un-gated samples in the chunk
     CostasState *resume;   // [1] true state at the start of chunk stats[3] when the stitch hands back to the host
     int32_t *stats;        // [0] chunks resolved by the map, [1] by a checkpoint inside a serial run, [2] fully serial,
@@ -205,6 +206,8 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
     }
     b.S[c * K + k] = st;
     int ung = 0;
+    // (fetching the samples 16 at a time as k_costas_final does was measured 8 % slower here: the candidates of a chunk
+    // share their loads, this kernel is bound by the arithmetic of the recurrence)
     for (int64_t i = s0; i < e0; ++i) {
         const float2 sm = CostasLoad<DT>::at(a.iq, i);
         if (!costas_gated(sm, a)) ++ung;
@@ -231,7 +234,24 @@ __global__ __launch_bounds__(256) void k_costas_map(SpecBuffers b, int64_t n_chu
     b.map[c] = m;
 }
 
-// One wavefront walks the chunks c_from .. in order (every lane the same control flow; lanes < K compare candidates).
+// Composition of two chunk maps (8 nibbles: candidate of the previous chunk -> candidate of this chunk, 0xF = none):
+// (later o earlier)[k] = later[earlier[k]], none stays none.
+__device__ __forceinline__ uint32_t map_compose(uint32_t later, uint32_t earlier) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t mid = (earlier >> (4 * k)) & 0xFu;
+        const uint32_t v = (mid == 0xFu) ? 0xFu : ((later >> (4 * mid)) & 0xFu);
+        r |= v << (4 * k);
+    }
+    return r;
+}
+
+// One wavefront walks the chunks c_from .. in order.  While a candidate carries the true trajectory the walk is a
+// composition of the chunk maps, evaluated 64 chunks at a time by a wavefront prefix "scan" with map_compose (the serial
+// walk -- two dependent global loads per chunk -- took 10.9 ms for the 32 767 chunks of a 1 GiB capture).  Where the maps
+// end (acquisition, long gated stretches) the chunk is handled as before: compare the true state with the chunk's
+// candidates, else evaluate it serially from the true state until it meets a candidate at a checkpoint.
 // Entry: the true state at the start of chunk c_from is *b.resume (c_from == 1: chunk 0's end, taken from E[0][0]).
 // Exit: either all chunks are resolved, or -- when allow_break -- the chain broke for good (a chunk with plenty of
 // un-gated samples was evaluated serially to its end and met no candidate): stats[3] = the next chunk, *b.resume = its true
@@ -240,26 +260,56 @@ template <int DT>
 __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K, int64_t c_from,
                                                        int allow_break) {
     const int lane = threadIdx.x;
-    int cand = -1;
-    CostasState T = *b.resume;                      // true state at the start of chunk c_from
-    if (c_from == 1) { cand = 0; if (lane == 0) b.T[0] = CostasState{0.0f, 1.5f}; }   // chunk 0: candidate 0 is exact
+    int cand = -1;                                  // candidate of chunk c - 1 that is the true trajectory, or -1
+    CostasState T = *b.resume;                      // true state at the start of chunk c (valid while cand < 0)
+    if (c_from == 1) { cand = 0; if (lane == 0) { b.T[0] = CostasState{0.0f, 1.5f}; b.gidx[0] = 0; } }   // chunk 0: every candidate is exact
     int n_map = 0, n_ckpt = 0, n_serial = 0;
     int64_t stop_at = n_chunks;
-    for (int64_t c = c_from; c < n_chunks; ++c) {
-        if (cand >= 0) T = b.E[(c - 1) * K + cand];
-        if (lane == 0) b.T[c] = T;
-        int next = -1;
-        if (cand >= 0) {
-            const uint32_t nib = (b.map[c] >> (4 * cand)) & 0xFu;
-            if (nib != 0xFu) next = (int)nib;
-        } else {
+    int64_t c = c_from;
+    bool map_failed = false;                        // chunk c: the map already said that no candidate starts in T
+    while (c < n_chunks) {
+        while (cand >= 0 && c < n_chunks) {         // ---- fast-forward over up to 64 chunks
+            const int64_t cc = c + lane;
+            uint32_t P = (cc < n_chunks) ? b.map[cc] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(P, o);
+                if (lane >= o) P = map_compose(P, u);
+            }
+            const uint32_t g = (P >> (4 * cand)) & 0xFu;             // candidate of chunk cc on the true trajectory
+            uint32_t gp = __shfl_up(g, 1);
+            if (lane == 0) gp = (uint32_t)cand;                      // ... of the chunk before cc
+            const bool reach = (gp != 0xFu) && (cc < n_chunks);      // the true state at the start of chunk cc is E[cc - 1][gp]
+            CostasState Tl = T;
+            if (reach) { Tl = b.E[(cc - 1) * K + gp]; b.T[cc] = Tl; b.gidx[cc] = (g == 0xFu) ? -1 : (int32_t)g; }
+            const unsigned long long fail = __ballot(reach && g == 0xFu);
+            if (fail == 0) {
+                const unsigned long long inr = __ballot(cc < n_chunks);
+                const int last = 63 - __builtin_clzll(inr);
+                cand = (int)__shfl(g, last);
+                n_map += last + 1; c += last + 1;
+                continue;
+            }
+            const int t = __builtin_ctzll(fail);
+            n_map += t;
+            T.freq = __shfl(Tl.freq, t); T.phase = __shfl(Tl.phase, t);
+            c += t; cand = -1; map_failed = true;
+        }
+        if (c >= n_chunks) break;
+        // ---- chunk c without a carrying candidate: T is the true state at its start
+        if (!map_failed) {
+            if (lane == 0) { b.T[c] = T; b.gidx[c] = -1; }
             const bool hit = lane < K && same_state(T, b.S[c * K + lane]);
             const unsigned long long m = __ballot(hit);
-            if (m) next = __builtin_ctzll(m);
+            if (m) {
+                cand = __builtin_ctzll(m);
+                if (lane == 0) b.gidx[c] = cand;
+                ++n_map; ++c;
+                continue;
+            }
         }
-        if (next >= 0) { cand = next; ++n_map; continue; }
-        cand = -1;
-        if (b.ungated[c] == 0) { ++n_serial; continue; }          // fully gated chunk: the state does not move
+        map_failed = false;
+        if (b.ungated[c] == 0) { ++n_serial; ++c; continue; }     // fully gated chunk: the state does not move
         // no candidate starts in T: evaluate the chunk from T until the state meets a candidate at a checkpoint
         const int64_t s0 = chunk_begin(c);
         const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
@@ -274,10 +324,11 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
                 if (m) { cand = __builtin_ctzll(m); break; }
             }
         }
-        if (cand >= 0) { ++n_ckpt; continue; }
+        if (cand >= 0) { ++n_ckpt; ++c; continue; }     // gidx[c] stays -1: only part of the chunk lies on the candidate
         ++n_serial;
         T = st;                                     // the state at the END of chunk c = start of chunk c + 1
         if (allow_break && b.ungated[c] >= kChunk / 2 && c + 1 < n_chunks) { stop_at = c + 1; break; }
+        ++c;
     }
     if (lane == 0) {
         b.stats[0] += n_map; b.stats[1] += n_ckpt; b.stats[2] += n_serial; b.stats[3] = (int32_t)stop_at;
@@ -285,22 +336,55 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
     }
 }
 
+// Output pass: every chunk from its TRUE start state.  A chunk that lies on a candidate's trajectory from its first
+// sample (gidx >= 0) is evaluated by kNumCkpt lanes, each from the candidate's checkpoint state (bitwise the true state
+// there); any other chunk by one lane from T[c].
 template <int DT>
-__global__ __launch_bounds__(256) void k_costas_final(const CostasArgs a, SpecBuffers b, int64_t n_chunks) {
-    const int64_t c = blockIdx.x * 256ll + threadIdx.x;
+__global__ __launch_bounds__(256) void k_costas_final(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K) {
+    const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
+    const int64_t c = gid / kNumCkpt;
+    const int j = (int)(gid % kNumCkpt);            // segment j = samples [j kCkpt, (j + 1) kCkpt) of the chunk
     if (c >= n_chunks) return;
-    if (c == 0 && a.n > 0) a.out[0] = -4.0f;        // reference: np.empty, never written (documented in urhgpu.h)
+    if (gid == 0 && a.n > 0) a.out[0] = -4.0f;      // reference: np.empty, never written (documented in urhgpu.h)
     const int64_t s0 = chunk_begin(c);
     const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
+    const int g = b.gidx[c];
+    int64_t i0 = s0, i1 = e0;
     CostasState st = b.T[c];
+    if (g >= 0) {
+        i0 = s0 + (int64_t)j * kCkpt;
+        i1 = (i0 + kCkpt < e0) ? i0 + kCkpt : e0;
+        if (j > 0) st = b.CP[(c * kNumCkpt + (j - 1)) * K + g];
+    } else if (j != 0) return;
     float err = 0.0f;
-    for (int64_t i = s0; i < e0; ++i) a.out[i] = costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
+    // 16 samples (one 128-byte line of complex64) per round: the lanes of a wavefront are 2 KiB apart, so every line a lane
+    // touches is fetched for that lane alone -- ask for all of it at once instead of 16 times 8 bytes
+    constexpr int kTileF = 16;
+    int64_t i = i0;
+    for (; i + kTileF <= i1; i += kTileF) {
+        float2 x[kTileF];
+#pragma unroll
+        for (int u = 0; u < kTileF; ++u) x[u] = CostasLoad<DT>::at(a.iq, i + u);
+        float o[kTileF];
+#pragma unroll 1
+        for (int u = 0; u < kTileF; ++u) {
+            float2 xv = x[0];
+#pragma unroll
+            for (int q = 1; q < kTileF; ++q) if (u == q) xv = x[q];
+            const float ov = costas_step(xv, st, err, a);
+#pragma unroll
+            for (int q = 0; q < kTileF; ++q) if (u == q) o[q] = ov;
+        }
+#pragma unroll
+        for (int u = 0; u < kTileF; ++u) a.out[i + u] = o[u];
+    }
+    for (; i < i1; ++i) a.out[i] = costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
 }
 
 size_t costas_scratch_bytes(int64_t n) {
     const int64_t nc = (std::max<int64_t>(n - 1, 0) + kChunk - 1) / kChunk + 1;
     return (size_t)nc * kMaxCand * sizeof(CostasState) * 2 + (size_t)nc * kNumCkpt * kMaxCand * sizeof(CostasState) +
-           (size_t)nc * 4 * 2 + (size_t)nc * sizeof(CostasState) + 64 + 64 + 10 * 256;
+           (size_t)nc * 4 * 3 + (size_t)nc * sizeof(CostasState) + 64 + 64 + 12 * 256;
 }
 
 constexpr int kMaxRounds = 24;     // re-speculation rounds before the stitch stops handing back (and runs serially)
@@ -326,6 +410,7 @@ static int launch_costas_dt(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx)
     b.map = (uint32_t *)take((size_t)nc * 4);
     b.T = (CostasState *)take((size_t)nc * sizeof(CostasState));
     b.ungated = (int32_t *)take((size_t)nc * 4);
+    b.gidx = (int32_t *)take((size_t)nc * 4);
     b.resume = (CostasState *)take(64);
     b.stats = (int32_t *)take(64);
     URH_HIP(hipMemsetAsync(b.stats, 0, 64, s));
@@ -354,7 +439,7 @@ static int launch_costas_dt(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx)
         rounds = round + 1;
     }
     h[4] = rounds;
-    hipLaunchKernelGGL(k_costas_final<DT>, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, a, b, nc);
+    hipLaunchKernelGGL(k_costas_final<DT>, dim3((unsigned)((nc * kNumCkpt + 255) / 256)), dim3(256), 0, s, a, b, nc, K);
     return URHGPU_OK;
 }
 
