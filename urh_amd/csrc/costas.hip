@@ -62,10 +62,12 @@ __device__ __forceinline__ bool costas_gated(float2 sm, const CostasArgs &a) { r
 
 // One sample of the loop (:291-328): returns the output, updates the state.  err is only carried for loop orders
 // other than 2 / 4 (where it never changes); callers keep it.
+// UNIT: float32 captures (shift 0, scale 1): (x + 0.0f) / 1.0f == x + 0.0f for every x, the two IEEE divisions are dropped.
+template <bool UNIT = false>
 __device__ __forceinline__ float costas_step(float2 sm, CostasState &st, float &err, const CostasArgs &a) {
     if (costas_gated(sm, a)) return -4.0f;                              // NOISE_FSK_PSK, state frozen (:293-295)
     const double two_pi = 2 * 3.14159265358979323846;
-    const float real_float = (sm.x + a.shift) / a.scale, imag_float = (sm.y + a.shift) / a.scale;
+    const float real_float = UNIT ? sm.x + 0.0f : (sm.x + a.shift) / a.scale, imag_float = UNIT ? sm.y + 0.0f : (sm.y + a.shift) / a.scale;
     const float2 cur = make_float2(real_float + 0.0f * imag_float, 1.0f * imag_float);   // re + imag_unit * im
     const float sn = urh_sinf(-st.phase), cs = urh_cosf(-st.phase);
     const float2 nco = make_float2(cs + 0.0f * sn, 1.0f * sn);
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(64) void k_costas(const CostasArgs a) {
             for (int u = 0; u < 64; ++u) {
                 const int k = g * 64 + u;
                 if (k >= tv || (base + k) == 0) continue;       // the loop starts at sample 1 (:289)
-                const float o = costas_step(s_x[k], st, err, a);
+                const float o = costas_step<DT == URHGPU_DT_F32>(s_x[k], st, err, a);
                 if (u == lane) keep = o;
             }
             mine[g] = keep;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
             }
             if (ax != 0.0f || ay != 0.0f) st.freq = costas_clamp(atan2f(ay, ax) / (float)a.loop_order);
         }
-        for (int64_t i = p; i < s0; ++i) costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
+        for (int64_t i = p; i < s0; ++i) costas_step<DT == URHGPU_DT_F32>(CostasLoad<DT>::at(a.iq, i), st, err, a);
     }
     b.S[c * K + k] = st;
     int ung = 0;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
     for (int64_t i = s0; i < e0; ++i) {
         const float2 sm = CostasLoad<DT>::at(a.iq, i);
         if (!costas_gated(sm, a)) ++ung;
-        costas_step(sm, st, err, a);
+        costas_step<DT == URHGPU_DT_F32>(sm, st, err, a);
         const int off = (int)(i - s0) + 1;
         if (off % kCkpt == 0 && off < kChunk) b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + k] = st;
     }
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
         float err = 0.0f;
         CostasState st = T;
         for (int64_t i = s0; i < e0; ++i) {
-            costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
+            costas_step<DT == URHGPU_DT_F32>(CostasLoad<DT>::at(a.iq, i), st, err, a);
             const int off = (int)(i - s0) + 1;
             if (off % kCkpt == 0 && off < kChunk) {
                 const bool hit = lane < K && same_state(st, b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + lane]);
@@ -371,14 +373,14 @@ __global__ __launch_bounds__(256) void k_costas_final(const CostasArgs a, SpecBu
             float2 xv = x[0];
 #pragma unroll
             for (int q = 1; q < kTileF; ++q) if (u == q) xv = x[q];
-            const float ov = costas_step(xv, st, err, a);
+            const float ov = costas_step<DT == URHGPU_DT_F32>(xv, st, err, a);
 #pragma unroll
             for (int q = 0; q < kTileF; ++q) if (u == q) o[q] = ov;
         }
 #pragma unroll
         for (int u = 0; u < kTileF; ++u) a.out[i + u] = o[u];
     }
-    for (; i < i1; ++i) a.out[i] = costas_step(CostasLoad<DT>::at(a.iq, i), st, err, a);
+    for (; i < i1; ++i) a.out[i] = costas_step<DT == URHGPU_DT_F32>(CostasLoad<DT>::at(a.iq, i), st, err, a);
 }
 
 size_t costas_scratch_bytes(int64_t n) {
