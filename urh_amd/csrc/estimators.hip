@@ -52,10 +52,12 @@ int launch_compact_gt(const float *x, int64_t n, const int64_t *d_n, float thr, 
     const int64_t nb = std::max<int64_t>((n + kScanTile - 1) / kScanTile, 1);
     VecK<1> *part = (VecK<1> *)scratch;
     GtLoad ld{x, thr};
-    hipLaunchKernelGGL((k_scan_reduce<1, GtLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb, tickets);
-    hipLaunchKernelGGL((k_scan_apply<1, GtLoad, GtStore, CountFinal>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb,
-                       GtStore{x, out}, CountFinal{d_count}, tickets + 1);
-    hipLaunchKernelGGL((k_scan_finish<1, CountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n, part, nb, CountFinal{d_count});
+    (void)tickets;
+    hipLaunchKernelGGL((k_scan_reduce<1, GtLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb);
+    if (nb > kScanDirect) hipLaunchKernelGGL((k_scan_partials<1>), dim3(1), dim3(kScanPartialsBlock), 0, s, d_n, part, nb, kScanDirect);
+    hipLaunchKernelGGL((k_scan_apply<1, GtLoad, GtStore>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb, GtStore{x, out},
+                       kScanDirect);
+    hipLaunchKernelGGL((k_scan_finish<1, CountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n, part, nb, CountFinal{d_count}, kScanDirect);
     return URHGPU_OK;
 }
 
@@ -64,10 +66,12 @@ int launch_compact_edges(const float *x, int64_t n, const int64_t *d_n, float ce
     const int64_t nb = std::max<int64_t>((n + kScanTile - 1) / kScanTile, 1);
     VecK<1> *part = (VecK<1> *)scratch;
     EdgeLoad ld{x, center};
-    hipLaunchKernelGGL((k_scan_reduce<1, EdgeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb, tickets);
-    hipLaunchKernelGGL((k_scan_apply<1, EdgeLoad, EdgeStore, CountFinal>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb,
-                       EdgeStore{out, cap}, CountFinal{d_count}, tickets + 1);
-    hipLaunchKernelGGL((k_scan_finish<1, CountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n, part, nb, CountFinal{d_count});
+    (void)tickets;
+    hipLaunchKernelGGL((k_scan_reduce<1, EdgeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb);
+    if (nb > kScanDirect) hipLaunchKernelGGL((k_scan_partials<1>), dim3(1), dim3(kScanPartialsBlock), 0, s, d_n, part, nb, kScanDirect);
+    hipLaunchKernelGGL((k_scan_apply<1, EdgeLoad, EdgeStore>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n, ld, part, nb,
+                       EdgeStore{out, cap}, kScanDirect);
+    hipLaunchKernelGGL((k_scan_finish<1, CountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n, part, nb, CountFinal{d_count}, kScanDirect);
     return URHGPU_OK;
 }
 

@@ -616,10 +616,11 @@ int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t
     int64_t *grp_end = (int64_t *)p;
     MergeLoad ld{rows_in};
     MergeStore st{rows_in, d_n_in, grp_state, grp_end};
-    hipLaunchKernelGGL((k_scan_reduce<2, MergeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld, partials, nb, tickets);
-    hipLaunchKernelGGL((k_scan_apply<2, MergeLoad, MergeStore, NoFinal>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld,
-                       partials, nb, st, NoFinal(), tickets + 1);
-    hipLaunchKernelGGL((k_scan_finish<2, NoFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_in, partials, nb, NoFinal());
+    (void)tickets;
+    hipLaunchKernelGGL((k_scan_reduce<2, MergeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld, partials, nb);
+    hipLaunchKernelGGL((k_scan_apply<2, MergeLoad, MergeStore>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld, partials, nb, st,
+                       kScanAlwaysDirect);
+    hipLaunchKernelGGL((k_scan_finish<2, NoFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_in, partials, nb, NoFinal(), kScanAlwaysDirect);
     int64_t fin_blocks = (cap + 255) / 256; if (fin_blocks > 4096) fin_blocks = 4096;
     hipLaunchKernelGGL(k_merge_finish, dim3((unsigned)fin_blocks), dim3(256), 0, s, partials + nb, grp_state, grp_end,
                        rows_out, cap_out, d_n_out);
@@ -695,10 +696,10 @@ int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t ca
     GroupCountFinal fin{d_n_rows, b.groups, b.d_n_groups, d_flags};
     // Two passes for the rows: a single-pass look-back scan over hundreds of workgroups measured 54 us against 48 us for
     // this pair -- every look-back hop is a round trip through memory between XCDs (their L2s are not coherent).
-    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb, ss.tickets);
-    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore, GroupCountFinal>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld,
-                       b.part4, b.nb, st, fin, ss.tickets + 1);
-    hipLaunchKernelGGL((k_scan_finish<4, GroupCountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, b.part4, b.nb, fin);
+    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb);
+    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb, st,
+                       kScanAlwaysDirect);
+    hipLaunchKernelGGL((k_scan_finish<4, GroupCountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, b.part4, b.nb, fin, kScanAlwaysDirect);
     return URHGPU_OK;
 }
 

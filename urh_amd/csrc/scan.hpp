@@ -88,30 +88,17 @@ __device__ __forceinline__ bool scan_last_block(int32_t *ticket, int64_t nb) {
     return last;
 }
 
-// Exclusive scan of the workgroup totals by ONE workgroup; writes the grand total to partials[nblocks_max].
-template <int K>
-__device__ __forceinline__ void scan_partials_body(VecK<K> *partials, int64_t nb, int64_t nblocks_max, VecK<K> *s_wave, VecK<K> *s_carry) {
-    if (threadIdx.x == 0) s_carry->zero();
-    __syncthreads();
-    for (int64_t b0 = 0; b0 < nb; b0 += kScanBlock) {
-        const int64_t b = b0 + threadIdx.x;
-        VecK<K> mine; mine.zero();
-        if (b < nb) mine = partials[b];
-        VecK<K> total;
-        VecK<K> ex = block_excl_scan_vec<K>(mine, total, s_wave);
-        ex.add(*s_carry);
-        if (b < nb) partials[b] = ex;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry->add(total);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) partials[nblocks_max] = *s_carry;
-}
-
-// Up to kScanDirect active workgroups the scan is two-level without a pass over the totals: every workgroup of pass 2
-// adds up the totals of the workgroups before it (the pulse-table stages: a few hundred workgroups).  Beyond that (stream
-// compaction over a whole capture: tens of thousands of workgroups) the last workgroup of pass 1 scans the totals.
-constexpr int64_t kScanDirect = 1024;
+// Three small kernels make a device-wide scan; none of them elects a "last workgroup" (an election costs every workgroup a
+// device-scope fence and an atomic on ONE address: 131 072 workgroups compacting a 1 GiB capture spent 10 ms in it):
+//   k_scan_reduce    per-workgroup totals -> partials[b]
+//   k_scan_partials  ONE workgroup, only when more than `direct_max` workgroups are active: partials -> exclusive prefixes,
+//                    grand total -> partials[nblocks_max]
+//   k_scan_apply     the scan proper; with at most `direct_max` active workgroups every workgroup adds up the totals of the
+//                    workgroups before it itself (the pulse-table stages: a few hundred workgroups, direct_max = "always")
+//   k_scan_finish    ONE workgroup: grand total, Final
+constexpr int64_t kScanAlwaysDirect = INT64_MAX;
+constexpr int64_t kScanDirect = 1024;      // stream compaction over a whole capture: beyond this many workgroups use k_scan_partials
+constexpr int kScanPartialsBlock = 1024;
 
 // Sum of partials[0 .. count) by the whole workgroup (every thread gets it).
 template <int K>
@@ -123,11 +110,9 @@ __device__ __forceinline__ VecK<K> block_sum_partials(const VecK<K> *partials, i
     return total;
 }
 
-// Pass 1: per-workgroup totals (partials[b]); with more than kScanDirect workgroups the last one to finish turns them into
-// exclusive prefixes.  Load::operator()(int64 i) -> VecK<K> (only called for i < n).
+// Load::operator()(int64 i) -> VecK<K> (only called for i < n).
 template <int K, class Load>
-__global__ __launch_bounds__(kScanBlock) void k_scan_reduce(const int64_t *d_n, Load load, VecK<K> *partials, int64_t nblocks_max,
-                                                             int32_t *ticket) {
+__global__ __launch_bounds__(kScanBlock) void k_scan_reduce(const int64_t *d_n, Load load, VecK<K> *partials, int64_t nblocks_max) {
     __shared__ VecK<K> s_wave[kScanBlock / 64];
     const int64_t n = *d_n;
     const int64_t nb = scan_active_blocks(n, nblocks_max);
@@ -141,18 +126,44 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_reduce(const int64_t *d_n, 
     VecK<K> total;
     block_excl_scan_vec<K>(acc, total, s_wave);
     if (threadIdx.x == 0) partials[blockIdx.x] = total;
-    if (nb <= kScanDirect) return;
-    __shared__ VecK<K> s_carry;
-    if (!scan_last_block(ticket, nb)) return;
-    scan_partials_body<K>(partials, nb, nblocks_max, s_wave, &s_carry);
 }
 
-// Pass 2: the scan proper.  Store::operator()(int64 i, const VecK<K>& value, const VecK<K>& excl_prefix);
-// Final::operator()(const VecK<K>& grand_total) runs once, on one thread, after every element has been stored; the grand
-// total is also left in partials[nblocks_max].
-template <int K, class Load, class Store, class Final>
-__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t *d_n, Load load, VecK<K> *partials, int64_t nblocks_max,
-                                                            Store store, Final fin, int32_t *ticket) {
+// ONE workgroup of kScanPartialsBlock threads, 8 totals per thread and round.
+template <int K>
+__global__ __launch_bounds__(kScanPartialsBlock) void k_scan_partials(const int64_t *d_n, VecK<K> *partials, int64_t nblocks_max, int64_t direct_max) {
+    constexpr int kPer = 8, kW = kScanPartialsBlock / 64;
+    __shared__ VecK<K> s_w[kW];
+    __shared__ VecK<K> s_carry;
+    const int64_t nb = scan_active_blocks(*d_n, nblocks_max);
+    if (nb <= direct_max) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry.zero();
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < nb; b0 += (int64_t)kScanPartialsBlock * kPer) {
+        const int64_t i0 = b0 + (int64_t)threadIdx.x * kPer;
+        VecK<K> item[kPer], acc; acc.zero();
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { item[j].zero(); if (i0 + j < nb) item[j] = partials[i0 + j]; acc.add(item[j]); }
+        VecK<K> incl = wave_incl_scan_vec<K>(acc, lane);
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        VecK<K> ex = s_carry, total; total.zero();
+        for (int w = 0; w < kW; ++w) { if (w < wave) ex.add(s_w[w]); total.add(s_w[w]); }
+#pragma unroll
+        for (int k = 0; k < K; ++k) ex.v[k] += incl.v[k] - acc.v[k];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) { if (i0 + j < nb) partials[i0 + j] = ex; ex.add(item[j]); }
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry.add(total);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[nblocks_max] = s_carry;
+}
+
+// Store::operator()(int64 i, const VecK<K>& value, const VecK<K>& excl_prefix)
+template <int K, class Load, class Store>
+__global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t *d_n, Load load, const VecK<K> *partials, int64_t nblocks_max,
+                                                            Store store, int64_t direct_max) {
     __shared__ VecK<K> s_wave[kScanBlock / 64];
     const int64_t n = *d_n;
     const int64_t nb = scan_active_blocks(n, nblocks_max);
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t *d_n, L
         acc.add(item[j]);
     }
     VecK<K> before;
-    if (nb <= kScanDirect) before = block_sum_partials<K>(partials, blockIdx.x, s_wave);
+    if (nb <= direct_max) before = block_sum_partials<K>(partials, blockIdx.x, s_wave);
     else before = partials[blockIdx.x];
     VecK<K> total;
     VecK<K> ex = block_excl_scan_vec<K>(acc, total, s_wave);
@@ -178,20 +189,18 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t *d_n, L
         if (i0 + j < n) store(i0 + j, item[j], ex);
         ex.add(item[j]);
     }
-    // two-level case: the epilogue is k_scan_finish (a last-workgroup election here costs every workgroup a device-scope
-    // fence behind megabytes of freshly written rows: measured 36 us for 327 workgroups against 4 us for the extra launch)
-    if (nb <= kScanDirect) return;
-    if (!scan_last_block(ticket, nb)) return;
-    if (threadIdx.x == 0) fin(partials[nblocks_max]);
 }
 
-// Epilogue of the two-level case (launch with ONE workgroup right after k_scan_apply): grand total, Final.
+// Final::operator()(const VecK<K>& grand_total) runs once, on one thread, after every element has been stored; the grand
+// total is also left in partials[nblocks_max].  Launch with ONE workgroup right after k_scan_apply.
 template <int K, class Final>
-__global__ __launch_bounds__(kScanBlock) void k_scan_finish(const int64_t *d_n, VecK<K> *partials, int64_t nblocks_max, Final fin) {
+__global__ __launch_bounds__(kScanBlock) void k_scan_finish(const int64_t *d_n, VecK<K> *partials, int64_t nblocks_max, Final fin,
+                                                             int64_t direct_max) {
     __shared__ VecK<K> s_wave[kScanBlock / 64];
     const int64_t nb = scan_active_blocks(*d_n, nblocks_max);
-    if (nb > kScanDirect) return;                          // k_scan_apply has done it
-    const VecK<K> grand = block_sum_partials<K>(partials, nb, s_wave);
+    VecK<K> grand;
+    if (nb <= direct_max) grand = block_sum_partials<K>(partials, nb, s_wave);
+    else grand = partials[nblocks_max];
     if (threadIdx.x == 0) { partials[nblocks_max] = grand; fin(grand); }
 }
 
