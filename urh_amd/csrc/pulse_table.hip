@@ -72,8 +72,10 @@ __device__ __forceinline__ int32_t chunk_stable(const ResolveArgs &a, int64_t c)
     }
     ch[c].pend_stable = ps;
     const bool has = ps || ch[c].cnt > 0;
-    if (has) atomicMin(&a.aux->first_stable, (int32_t)c);
-    if (ch[c].lead < ch[c].len) atomicMin(&a.aux->first_nonlead, (int32_t)c);
+    if (a.local_pass) {                                     // only the shard summary needs them (resolve_finish)
+        if (has) atomicMin(&a.aux->first_stable, (int32_t)c);
+        if (ch[c].lead < ch[c].len) atomicMin(&a.aux->first_nonlead, (int32_t)c);
+    }
     return has ? (int32_t)c : -1;
 }
 
