@@ -166,12 +166,11 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     r.rows = rows_stage; r.cap_rows = cap_rows; r.d_n_acc = d_n_acc; r.d_n_rows = d_n_stage;
     r.d_n_rows_needed = d_n_rows_needed; r.write_last_row = 1;
     r.local_pass = 0; r.aux = aux; r.summary_out = nullptr; r.chunk_first = 0; r.n_local = pl.n_chunks; r.d_ts_carry = nullptr;
-    URH_TRY(launch_resolve(r, ctx->d_tickets, s));
     EmitArgs e;
     e.sc = rsc;
     e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
     e.rows = rows_stage; e.cap_rows = cap_rows; e.d_ts_carry = nullptr; e.is_ask = ask ? 1 : 0; e.sps = p->samples_per_symbol;
-    URH_TRY(launch_emit_rows(e, pl.n_chunks, s));
+    URH_TRY(launch_resolve_emit_single(r, e, s));
     if (ask) URH_TRY(launch_merge_rows_ask(rows_stage, d_n_stage, cap_rows, d_rows, cap_rows, d_n_rows, merge_scratch, ctx->d_tickets, s));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;

@@ -161,6 +161,7 @@ struct BitsOut {
     int64_t *counts;
 };
 int launch_resolve(const ResolveArgs &a, int32_t *tickets, hipStream_t s);
+int launch_resolve_emit_single(const ResolveArgs &r, const EmitArgs &e, hipStream_t s);
 int launch_emit_rows(const EmitArgs &a, int64_t n_local_chunks, hipStream_t s);
 size_t merge_scratch_bytes(int64_t cap);
 int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t cap, int64_t *rows_out,

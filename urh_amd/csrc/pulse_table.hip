@@ -260,18 +260,14 @@ __global__ __launch_bounds__(kResolveBlock) void k_resolve_c(const ResolveArgs a
 //   row g = (state of accepted run g-1, start_g - start_{g-1}); row 0 = (init state, start_0 + 1)
 //   ASK: pause rows shorter than samples_per_symbol are relabelled 0 (signal_functions.pyx:471-473).
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_emit_rows(const EmitArgs a) {
-    const int64_t c = a.chunk_first + blockIdx.x;
+__device__ __forceinline__ void emit_chunk_rows(const EmitArgs &a, int64_t c, int64_t out_off, int64_t row_base, int32_t ip) {
     const ChunkInfo ci = a.chunks[c];
-    const uint64_t *slab = a.slab + (int64_t)blockIdx.x * a.slab_stride;
+    const uint64_t *slab = a.slab + (c - a.chunk_first) * a.slab_stride;
     const int skip = (ci.cnt > 0 && !ci.first_acc) ? 1 : 0;
     const int64_t from_slab = (ci.cnt > 0) ? ci.cnt - skip : 0;
     const int64_t total = from_slab + ci.pend_acc;
     if (total == 0) return;
-    const int64_t out_off = a.sc.out_off[c];
-    const int64_t row_base = a.sc.out_off[a.chunk_first];
     int64_t prev_pos = -1; uint32_t prev_state = a.chunks[0].init_state;   // before the very first accepted run
-    const int32_t ip = a.sc.prev_acc[c];
     if (ip >= 0) chunk_last_acc(a.chunks[ip], prev_pos, prev_state);
     for (int64_t j = threadIdx.x; j < total; j += blockDim.x) {
         int64_t pos;
@@ -287,6 +283,40 @@ __global__ __launch_bounds__(64) void k_emit_rows(const EmitArgs a) {
         const int64_t o = g - row_base;
         if (o >= 0 && o < a.cap_rows) { a.rows[2 * o] = state; a.rows[2 * o + 1] = len; }
         if (o == 0 && a.d_ts_carry) *a.d_ts_carry = (g == 0) ? 0 : ppos + 1;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_emit_rows(const EmitArgs a) {
+    const int64_t c = a.chunk_first + blockIdx.x;
+    emit_chunk_rows(a, c, a.sc.out_off[c], a.sc.out_off[a.chunk_first], a.sc.prev_acc[c]);
+}
+
+// Single-GPU captures (the table holds this GPU's chunks only, starting at row 0): k_resolve_c folded into the row pass --
+// every chunk's wavefront adds up the totals of the resolve workgroups before its own (at most a few hundred values from L2),
+// workgroup 0 also writes the totals and the table's last row.  One launch less on the latency chain of the tail.
+__global__ __launch_bounds__(64) void k_emit_rows_fused(const EmitArgs a, const ResolveArgs r) {
+    const int64_t c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int64_t b = c / kResolveBlock;
+    int32_t pm = -1; int64_t ps = 0;
+    for (int64_t u = lane; u < b; u += 64) { pm = max(pm, r.sc.blk_acc[u]); ps += r.sc.blk_cnt[u]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { pm = max(pm, __shfl_xor(pm, o)); ps += __shfl_xor(ps, o); }
+    emit_chunk_rows(a, c, r.sc.out_cnt[c] + ps, 0, max(r.sc.has_acc[c], pm));
+    if (c == 0) {
+        const int64_t nb = resolve_blocks(r.n_chunks);
+        ResolveTotals t;
+        t.last_c = -1; t.last_stable = -1; t.P = 0; t.before_first = 0; t.before_end = 0;
+        for (int64_t u = lane; u < nb; u += 64) { t.last_c = max(t.last_c, r.sc.blk_acc[u]); t.last_stable = max(t.last_stable, r.sc.blk_stable[u]); t.P += r.sc.blk_cnt[u]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            t.last_c = max(t.last_c, __shfl_xor(t.last_c, o)); t.last_stable = max(t.last_stable, __shfl_xor(t.last_stable, o));
+            t.P += __shfl_xor(t.P, o);
+        }
+        if (lane == 0) {
+            resolve_finish(r, t);
+            r.aux->first_nonlead = kAuxNone; r.aux->open_chunk = kAuxNone; r.aux->first_stable = kAuxNone; r.aux->last_stable = -1;
+        }
     }
 }
 
@@ -592,6 +622,16 @@ int launch_resolve(const ResolveArgs &a, int32_t *tickets, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve_a, dim3(g), dim3(kResolveBlock), 0, s, a);
     hipLaunchKernelGGL(k_resolve_b, dim3(g), dim3(kResolveBlock), 0, s, a);
     hipLaunchKernelGGL(k_resolve_c, dim3(g), dim3(kResolveBlock), 0, s, a);
+    return URHGPU_OK;
+}
+
+// resolve + rows of a single-GPU capture: k_resolve_a, k_resolve_b, k_emit_rows_fused
+int launch_resolve_emit_single(const ResolveArgs &r, const EmitArgs &e, hipStream_t s) {
+    if (r.n_chunks <= 0 || r.local_pass || r.chunk_first != 0 || r.n_local != r.n_chunks || e.chunk_first != 0) return URHGPU_ERR_ARG;
+    const unsigned g = (unsigned)((r.n_chunks + kResolveBlock - 1) / kResolveBlock);
+    hipLaunchKernelGGL(k_resolve_a, dim3(g), dim3(kResolveBlock), 0, s, r);
+    hipLaunchKernelGGL(k_resolve_b, dim3(g), dim3(kResolveBlock), 0, s, r);
+    hipLaunchKernelGGL(k_emit_rows_fused, dim3((unsigned)r.n_chunks), dim3(64), 0, s, e, r);
     return URHGPU_OK;
 }
 
