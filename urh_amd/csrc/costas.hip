@@ -139,6 +139,9 @@ struct SpecBuffers {
     CostasState *CP;       // [n_chunks][kNumCkpt][K] state after offset (j+1)*kCkpt samples of the chunk
     uint32_t *map;         // [n_chunks] nibble k: candidate of this chunk that starts in E[c-1][k], 0xF none
     CostasState *T;        // [n_chunks] TRUE state at the chunk start (written by the stitch)
+    int32_t *run_list;     // [n_chunks * K] chunk * K + candidate of every DISTINCT candidate (k_costas_spec appends, k_costas_run consumes)
+    int32_t *run_count;    // [1] entries in run_list
+    uint8_t *is_rep;       // [n_chunks][K] 1: the candidate runs (no lower-numbered candidate of the chunk starts in the same state)
     int32_t *gidx;         // [n_chunks] candidate whose trajectory IS the true one over the whole chunk, or -1 (written by the stitch)
     int32_t *ungated;      // [n_chunks] un-gated samples in the chunk
     CostasState *resume;   // [1] true state at the start of chunk stats[3] when the stitch hands back to the host
@@ -161,7 +164,6 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
     const int k = (int)(gid % K);
     if (c >= n_chunks) return;
     const int64_t s0 = chunk_begin(c);
-    const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
     // candidate k: phase 1.5 + (k - K/2) * spacing, spaced pi/2 (order 4, K = 8) or pi (order 2, K = 4): every lock point and its
     // twin 2*pi away; candidate K/2 has the reference's own initial phase 1.5
     const float spacing = (a.loop_order == 4) ? 1.57079632679489661923f : 3.14159265358979323846f;
@@ -207,9 +209,39 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
         for (int64_t i = p; i < s0; ++i) costas_step<DT == URHGPU_DT_F32>(CostasLoad<DT>::at(a.iq, i), st, err, a);
     }
     b.S[c * K + k] = st;
+    // Candidates that have met during the warm-up -- the twins 2*pi apart do as soon as a carrier offset has wrapped the
+    // phase once, every candidate of chunk 0 is the true trajectory -- would repeat each other sample for sample: only
+    // the lowest-numbered one of every distinct start state runs the chunk (k_costas_run, lanes packed densely).
+    const int lane = threadIdx.x & 63, base = lane - k;              // the chunk's K candidates are adjacent lanes of one wavefront
+    bool dup = false;
+    for (int j = 0; j < K; ++j) {
+        CostasState o;
+        o.freq = __shfl(st.freq, base + j); o.phase = __shfl(st.phase, base + j);
+        if (j < k && same_state(o, st)) dup = true;
+    }
+    b.is_rep[c * K + k] = dup ? 0 : 1;
+    const unsigned long long m = __ballot(!dup);
+    int pos = 0;
+    if (lane == __builtin_ctzll(m)) pos = atomicAdd(b.run_count, __builtin_popcountll(m));
+    pos = __shfl(pos, __builtin_ctzll(m));
+    if (!dup) b.run_list[pos + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = (int32_t)(c * K + k);
+}
+
+// The chunk itself, one lane per distinct candidate: checkpoints, end state, un-gated sample count.
+template <int DT>
+__global__ __launch_bounds__(256) void k_costas_run(const CostasArgs a, SpecBuffers b, int K) {
+    const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
+    if (gid >= *b.run_count) return;
+    const int64_t ck = b.run_list[gid];
+    const int64_t c = ck / K;
+    const int k = (int)(ck % K);
+    const int64_t s0 = chunk_begin(c);
+    const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
+    CostasState st = b.S[ck];
+    float err = 0.0f;
     int ung = 0;
-    // (fetching the samples 16 at a time as k_costas_final does was measured 8 % slower here: the candidates of a chunk
-    // share their loads, this kernel is bound by the arithmetic of the recurrence)
+    // (fetching the samples 16 at a time as k_costas_final does was measured 7 % slower here, with or without the duplicates:
+    // the kernel is bound by the dependent arithmetic of the recurrence, ~150 instructions per step)
     for (int64_t i = s0; i < e0; ++i) {
         const float2 sm = CostasLoad<DT>::at(a.iq, i);
         if (!costas_gated(sm, a)) ++ung;
@@ -217,7 +249,7 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
         const int off = (int)(i - s0) + 1;
         if (off % kCkpt == 0 && off < kChunk) b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + k] = st;
     }
-    b.E[c * K + k] = st;
+    b.E[ck] = st;
     if (k == 0) b.ungated[c] = ung;
 }
 
@@ -227,9 +259,11 @@ __global__ __launch_bounds__(256) void k_costas_map(SpecBuffers b, int64_t n_chu
     uint32_t m = 0xFFFFFFFFu;
     if (c > 0) {
         for (int k = 0; k < K; ++k) {
-            const CostasState e = b.E[(c - 1) * K + k];
             int hit = 0xF;
-            for (int q = 0; q < K; ++q) if (same_state(e, b.S[c * K + q])) { hit = q; break; }
+            if (b.is_rep[(c - 1) * K + k]) {                 // a duplicate did not run: no end state (it is never the carrying candidate)
+                const CostasState e = b.E[(c - 1) * K + k];
+                for (int q = 0; q < K; ++q) if (same_state(e, b.S[c * K + q])) { hit = q; break; }
+            }
             m = (m & ~(0xFu << (4 * k))) | ((uint32_t)hit << (4 * k));
         }
     }
@@ -321,7 +355,7 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
             costas_step<DT == URHGPU_DT_F32>(CostasLoad<DT>::at(a.iq, i), st, err, a);
             const int off = (int)(i - s0) + 1;
             if (off % kCkpt == 0 && off < kChunk) {
-                const bool hit = lane < K && same_state(st, b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + lane]);
+                const bool hit = lane < K && b.is_rep[c * K + lane] && same_state(st, b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + lane]);
                 const unsigned long long m = __ballot(hit);
                 if (m) { cand = __builtin_ctzll(m); break; }
             }
@@ -386,7 +420,7 @@ __global__ __launch_bounds__(256) void k_costas_final(const CostasArgs a, SpecBu
 size_t costas_scratch_bytes(int64_t n) {
     const int64_t nc = (std::max<int64_t>(n - 1, 0) + kChunk - 1) / kChunk + 1;
     return (size_t)nc * kMaxCand * sizeof(CostasState) * 2 + (size_t)nc * kNumCkpt * kMaxCand * sizeof(CostasState) +
-           (size_t)nc * 4 * 3 + (size_t)nc * sizeof(CostasState) + 64 + 64 + 12 * 256;
+           (size_t)nc * 4 * 3 + (size_t)nc * sizeof(CostasState) + (size_t)nc * kMaxCand * 5 + 3 * 64 + 16 * 256;
 }
 
 constexpr int kMaxRounds = 24;     // re-speculation rounds before the stitch stops handing back (and runs serially)
@@ -413,6 +447,9 @@ static int launch_costas_dt(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx)
     b.T = (CostasState *)take((size_t)nc * sizeof(CostasState));
     b.ungated = (int32_t *)take((size_t)nc * 4);
     b.gidx = (int32_t *)take((size_t)nc * 4);
+    b.run_list = (int32_t *)take((size_t)nc * K * 4);
+    b.is_rep = (uint8_t *)take((size_t)nc * K);
+    b.run_count = (int32_t *)take(64);
     b.resume = (CostasState *)take(64);
     b.stats = (int32_t *)take(64);
     URH_HIP(hipMemsetAsync(b.stats, 0, 64, s));
@@ -424,8 +461,10 @@ static int launch_costas_dt(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx)
     int rounds = 0;
     for (int round = 0;; ++round) {
         const int64_t todo = nc - c_from;
+        URH_HIP(hipMemsetAsync(b.run_count, 0, 4, s));
         hipLaunchKernelGGL(k_costas_spec<DT>, dim3((unsigned)((todo * K + 255) / 256)), dim3(256), 0, s, a, b, nc, K, c_from, use_seed,
                            seed_freq);
+        hipLaunchKernelGGL(k_costas_run<DT>, dim3((unsigned)((todo * K + 255) / 256)), dim3(256), 0, s, a, b, K);
         hipLaunchKernelGGL(k_costas_map, dim3((unsigned)((todo + 255) / 256)), dim3(256), 0, s, b, nc, K, std::max<int64_t>(c_from, 1));
         hipLaunchKernelGGL(k_costas_stitch<DT>, dim3(1), dim3(64), 0, s, a, b, nc, K, std::max<int64_t>(c_from, 1),
                            round < kMaxRounds ? 1 : 0);
