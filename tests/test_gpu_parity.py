@@ -200,8 +200,9 @@ def test_fused_randomised_vs_oracle(pipe, oracle):
     runs and pauses), tolerances, samples per symbol, noise gates, centers, sample types; everything bit-exact."""
     import torch
     from urh_amd.pipeline import DemodParams
-    rng = np.random.default_rng(2026)
-    for it in range(160):
+    import os
+    rng = np.random.default_rng(int(os.environ.get("URH_FUZZ_SEED", "2026")))     # URH_FUZZ_SEED: more rounds by hand
+    for it in range(int(os.environ.get("URH_FUZZ_CASES", "160"))):
         n = int(rng.choice([rng.integers(3, 300), rng.integers(300, 9000), rng.integers(9000, 70_000)]))
         sps = int(rng.choice([1, 2, 5, 17, 100, 333]))
         dtype = [np.float32, np.float32, np.int8, np.uint8, np.int16, np.uint16][it % 6]
