@@ -726,6 +726,57 @@ def test_get_protocol_from_signal_goldens(pipe):
                 assert a.timestamp == b["timestamp"], key
 
 
+@pytest.mark.parametrize("mod", ["FSK", "ASK"])
+def test_sharded_pipelined_passes(pipe, mod):
+    """The sharded path in pipelined mode (bench.py uses it for --gpus N > 1: the exchange-laden tail of a pass overlaps the hot
+    kernel of the next one): three back-to-back passes per rank over two alternating captures, two simulated ranks with
+    persistent pipelined engines; every pass equals the single-GPU result."""
+    import threading
+    import torch
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.shard_engine import GpuShardEngine
+    from urh_amd.sharding import ShardedPipeline, ThreadComm, shard_bounds, stitch
+    world = 2
+    caps = []
+    for seed, n in ((5, 700_001), (6, 524_288)):
+        iq = synth_fsk(n, sps=50, seed=seed, noise=0.05, pause_every=n // 4, pause_len=n // 31)
+        if mod == "ASK":
+            env = np.repeat(np.random.default_rng(seed).integers(0, 2, n // 50 + 1), 50)[:n]
+            iq = (iq * (0.05 + 0.95 * env)[:, None]).astype(np.float32)
+        p = DemodParams(mod, 1, 0.2, 0.0 if mod == "FSK" else 0.35, 1.0, 3, 50, 0.1, 8, True)
+        dev = torch.from_numpy(iq).cuda()
+        single = pipe.iq_to_bits(dev, p, want_qad=True)
+        want = (single.ppseq().copy(),) + tuple(x.copy() for x in single.flat())
+        caps.append((dev, p, want, single.qad.cpu().numpy().copy(), shard_bounds(n, world), n))
+    shared = ThreadComm.Shared(world)
+    results, err = [[None] * world for _ in range(3)], []
+
+    def work(r):
+        try:
+            sp = ShardedPipeline(GpuShardEngine(0, pipelined=True), ThreadComm(shared, r))
+            for it in range(3):
+                dev, p, _, _, bounds, n = caps[it % 2]
+                a, b = bounds[r]
+                res = sp.iq_to_bits(dev[a:b], p, want_qad=True, pos_base=a, n_total=n)
+                results[it][r] = (res.piece(), res.qad.cpu().numpy().copy())
+        except BaseException as e:          # noqa: BLE001 -- re-raised in the main thread
+            err.append(e)
+            shared.barrier.abort()
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if err:
+        raise err[0]
+    for it in range(3):
+        _, _, want, want_qad, _, _ = caps[it % 2]
+        got = stitch([results[it][r][0] for r in range(world)])
+        for k, (x, y) in enumerate(zip(got, want)):
+            assert np.array_equal(x, y), (mod, it, k, len(x), len(y))
+        assert bits_equal(np.concatenate([results[it][r][1] for r in range(world)]), want_qad), (mod, it)
+
+
 def test_pipelined_passes_do_not_disturb_each_other(oracle):
     """pipelined mode: a burst of back-to-back passes over alternating captures without any synchronisation in between;
     the last two results (kept in separate output slots) are bit-exact, i.e. the hot kernel of pass i+1 did not disturb the
