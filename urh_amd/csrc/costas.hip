@@ -284,7 +284,7 @@ __device__ __forceinline__ uint32_t map_compose(uint32_t later, uint32_t earlier
 }
 
 // One wavefront walks the chunks c_from .. in order.  While a candidate carries the true trajectory the walk is a
-// composition of the chunk maps, evaluated 64 chunks at a time by a wavefront prefix "scan" with map_compose (the serial
+// composition of the chunk maps, evaluated 256 chunks at a time (4 per lane) by a wavefront prefix "scan" with map_compose (the serial
 // walk -- two dependent global loads per chunk -- took 10.9 ms for the 32 767 chunks of a 1 GiB capture).  Where the maps
 // end (acquisition, long gated stretches) the chunk is handled as before: compare the true state with the chunk's
 // candidates, else evaluate it serially from the true state until it meets a candidate at a checkpoint.
@@ -304,32 +304,60 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
     int64_t c = c_from;
     bool map_failed = false;                        // chunk c: the map already said that no candidate starts in T
     while (c < n_chunks) {
-        while (cand >= 0 && c < n_chunks) {         // ---- fast-forward over up to 64 chunks
-            const int64_t cc = c + lane;
-            uint32_t P = (cc < n_chunks) ? b.map[cc] : 0xFFFFFFFFu;
+        while (cand >= 0 && c < n_chunks) {         // ---- fast-forward over up to 256 chunks: 4 consecutive chunks per lane
+            constexpr int Q = 4;
+            const int64_t cc0 = c + (int64_t)Q * lane;
+            uint32_t L[Q];                                            // L[q] = map[cc0 + q] o ... o map[cc0]
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const uint32_t m = (cc0 + q < n_chunks) ? b.map[cc0 + q] : 0xFFFFFFFFu;
+                L[q] = q ? map_compose(m, L[q - 1]) : m;
+            }
+            uint32_t P = L[Q - 1];                                    // inclusive prefix composition over the lanes
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t u = __shfl_up(P, o);
                 if (lane >= o) P = map_compose(P, u);
             }
-            const uint32_t g = (P >> (4 * cand)) & 0xFu;             // candidate of chunk cc on the true trajectory
-            uint32_t gp = __shfl_up(g, 1);
-            if (lane == 0) gp = (uint32_t)cand;                      // ... of the chunk before cc
-            const bool reach = (gp != 0xFu) && (cc < n_chunks);      // the true state at the start of chunk cc is E[cc - 1][gp]
-            CostasState Tl = T;
-            if (reach) { Tl = b.E[(cc - 1) * K + gp]; b.T[cc] = Tl; b.gidx[cc] = (g == 0xFu) ? -1 : (int32_t)g; }
-            const unsigned long long fail = __ballot(reach && g == 0xFu);
+            uint32_t X = __shfl_up(P, 1);                             // everything before my first chunk
+            if (lane == 0) X = 0x76543210u;                           // identity
+            uint32_t g[Q], gp[Q];
+#pragma unroll
+            for (int q = 0; q < Q; ++q) g[q] = (map_compose(L[q], X) >> (4 * cand)) & 0xFu;   // candidate of chunk cc0 + q on the true trajectory
+            gp[0] = __shfl_up(g[Q - 1], 1);
+            if (lane == 0) gp[0] = (uint32_t)cand;
+#pragma unroll
+            for (int q = 1; q < Q; ++q) gp[q] = g[q - 1];
+            CostasState Tl[Q];
+            int firstq = Q;                                           // my first chunk where the chain ends
+#pragma unroll
+            for (int q = Q - 1; q >= 0; --q) {
+                const int64_t cc = cc0 + q;
+                const bool reach = (gp[q] != 0xFu) && (cc < n_chunks);   // the true state at the start of chunk cc is E[cc - 1][gp]
+                Tl[q] = T;
+                if (reach) { Tl[q] = b.E[(cc - 1) * K + gp[q]]; b.T[cc] = Tl[q]; b.gidx[cc] = (g[q] == 0xFu) ? -1 : (int32_t)g[q]; }
+                if (reach && g[q] == 0xFu) firstq = q;
+            }
+            const unsigned long long fail = __ballot(firstq < Q);
             if (fail == 0) {
-                const unsigned long long inr = __ballot(cc < n_chunks);
-                const int last = 63 - __builtin_clzll(inr);
-                cand = (int)__shfl(g, last);
-                n_map += last + 1; c += last + 1;
+                const int64_t left = n_chunks - c;
+                const int total = (int)(left < 64 * Q ? left : 64 * Q);
+                const int ll = (total - 1) / Q, lq = (total - 1) % Q;
+                uint32_t gl = g[0];
+#pragma unroll
+                for (int q = 1; q < Q; ++q) if (lq == q) gl = g[q];
+                cand = (int)__shfl(gl, ll);
+                n_map += total; c += total;
                 continue;
             }
             const int t = __builtin_ctzll(fail);
-            n_map += t;
-            T.freq = __shfl(Tl.freq, t); T.phase = __shfl(Tl.phase, t);
-            c += t; cand = -1; map_failed = true;
+            const int qf = __shfl(firstq, t);
+            CostasState Ts = Tl[0];
+#pragma unroll
+            for (int q = 1; q < Q; ++q) if (qf == q) Ts = Tl[q];
+            T.freq = __shfl(Ts.freq, t); T.phase = __shfl(Ts.phase, t);
+            n_map += Q * t + qf;
+            c += Q * t + qf; cand = -1; map_failed = true;
         }
         if (c >= n_chunks) break;
         // ---- chunk c without a carrying candidate: T is the true state at its start
