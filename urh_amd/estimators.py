@@ -237,18 +237,25 @@ def get_plateau_lengths_dev(pipe, rect, center, percentage=25) -> np.ndarray:
     n = int(x.shape[0])
     if n == 0 or center is None:
         return np.array([], dtype=np.uint64)
-    cap = min(n, max(1 << 16, n // 16))                           # plenty for real signals; retried with the exact count if not
-    while True:
-        idx = torch.empty(max(cap, 1), dtype=torch.int64, device=x.device)
-        cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
-        _lib.check(_lib.load().urhgpu_edges_le_dev(pipe.ctx.handle, C.c_void_p(x.data_ptr()), n, float(center),
-                                                   C.c_void_p(idx.data_ptr()), cap, C.c_void_p(cnt.data_ptr())))
-        found = int(cnt.item())
-        if found <= cap:
-            break
-        cap = found
-    b = idx[:found].cpu().numpy()                                 # run boundaries B_0 < B_1 < ...
     limit = (percentage * n) // 100                               # C integer division (cdivision)
+    # only the plateaus that START before `limit` count: all boundaries below it and the first one at or beyond it.  The
+    # boundary pass runs over a window that is extended until it holds such a boundary (or the whole signal).
+    w = min(n, limit + (1 << 16))
+    while True:
+        cap = min(w, max(1 << 16, w // 16))                       # plenty for real signals; retried with the exact count if not
+        while True:
+            idx = torch.empty(max(cap, 1), dtype=torch.int64, device=x.device)
+            cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
+            _lib.check(_lib.load().urhgpu_edges_le_dev(pipe.ctx.handle, C.c_void_p(x.data_ptr()), w, float(center),
+                                                       C.c_void_p(idx.data_ptr()), cap, C.c_void_p(cnt.data_ptr())))
+            found = int(cnt.item())
+            if found <= cap:
+                break
+            cap = found
+        b = idx[:found].cpu().numpy()                             # run boundaries B_0 < B_1 < ...
+        if w == n or (found and b[-1] >= limit):
+            break
+        w = min(n, 2 * w)
     # plateau k = [B_{k-1}, B_k) is appended at i = B_k if the sum appended so far (= B_{k-1}, or 0) is < limit
     starts = np.concatenate([[0], b[:-1]]) if len(b) else np.zeros(0, np.int64)
     keep = starts < limit
