@@ -218,20 +218,73 @@ def test_fused_randomised_vs_oracle(pipe, oracle):
         noise = float(rng.choice([0.0, 0.2, 0.6])) * scale
         center = float(rng.choice([0.0, 0.1, -0.2])) if mod == "FSK" else float(rng.choice([0.05, 0.35, 0.8]))
         pt = int(rng.choice([0, 1, 8]))
-        p = DemodParams(mod, 1, noise, center, 1.0, tol, sps, 0.1, pt, True)
+        bps, spacing = (2, float(rng.choice([0.05, 0.3]))) if it % 5 == 3 else (1, 1.0)     # order 4: three thresholds
+        p = DemodParams(mod, bps, noise, center, spacing, tol, sps, 0.1, pt, True)
         qad = oracle.afp_demod(iq, noise, mod, 2)
-        pp = oracle.grab_pulse_lens(qad, center, tol, mod, sps, 1, 1.0)
-        fb = oracle.ppseq_to_bits_flat(pp, sps, 1, True, pt)
+        pp = oracle.grab_pulse_lens(qad, center, tol, mod, sps, bps, spacing)
+        fb = oracle.ppseq_to_bits_flat(pp, sps, bps, True, pt)
         res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True, cap_rows=n // (tol + 1) + 2)
-        ctxt = (it, n, sps, np.dtype(dtype).name, mod, tol, noise, center, pt)
+        ctxt = (it, n, sps, np.dtype(dtype).name, mod, tol, noise, center, pt, bps, spacing)
         assert bits_equal(res.qad.cpu().numpy(), qad), ctxt
         assert np.array_equal(res.ppseq(), pp), ctxt
         assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat())), ctxt
 
 
+def _four_level(n, sps, seed, mod, noise=0.03):
+    """4-FSK (four frequency steps) or 4-ASK (four amplitudes) capture with silent gaps, float32 [n, 2]."""
+    rng = np.random.default_rng(seed)
+    sym = np.repeat(rng.integers(0, 4, n // sps + 1), sps)[:n]
+    if mod == "FSK":
+        ph = np.cumsum(np.array([-0.6, -0.2, 0.2, 0.6])[sym])
+        amp = np.ones(n)
+    else:
+        ph = 0.01 * np.arange(n)
+        amp = np.array([0.2, 0.45, 0.7, 0.95])[sym]
+    iq = np.stack([amp * np.cos(ph), amp * np.sin(ph)], 1) + noise * rng.standard_normal((n, 2))
+    for a in range(n // 5, n, n // 4):
+        iq[a:a + n // 21] *= 0.01
+    return iq.astype(np.float32)
+
+
+@pytest.mark.parametrize("mod", ["FSK", "ASK"])
+def test_bit_plane_kernel_order4_equals_state_byte_kernel(pipe, oracle, mod):
+    """Modulation order 4 (three thresholds, states 1..4 as two bit planes + PAUSE) on the bit-plane kernel vs the state-byte
+    kernel vs the oracle: four-level captures, tolerances either side of the plane kernel's limit, noise gate on and off."""
+    import torch
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams
+    lib = _lib.load()
+    center, spacing = (0.0, 0.4) if mod == "FSK" else (0.4, 0.17)          # ASK magnitudes are scaled by 1 / sqrt(2)
+    try:
+        for n, sps in ((1 << 18, 40), (262_144 + 8192 + 2048 + 130, 25), (70_001, 100), (777, 5)):
+            iq = _four_level(n, sps, n % 83, mod)
+            iq[np.random.default_rng(n).integers(0, n, 50)] = 0.0
+            dev = torch.from_numpy(iq).cuda()
+            for tol in (0, 1, 5, 6, 33, 64, 65):
+                for noise in (0.0, 0.1):
+                    p = DemodParams(mod, 2, noise, center, spacing, tol, sps, 0.1, 8, True)
+                    got = []
+                    for force in (0, 1):
+                        lib.urhgpu_test_force_state_bytes(force)
+                        res = pipe.iq_to_bits(dev, p, want_qad=True, cap_rows=n // (tol + 1) + 2)
+                        got.append((res.qad.cpu().numpy().copy(), res.ppseq().copy()) + tuple(x.copy() for x in res.flat()))
+                    assert bits_equal(got[0][0], got[1][0]), (n, tol, noise)
+                    for k in range(1, len(got[0])):
+                        assert np.array_equal(got[0][k], got[1][k]), (n, tol, noise, k)
+                    if tol in (0, 5, 64):
+                        qad = oracle.afp_demod(iq, noise, mod, 4)
+                        pp = oracle.grab_pulse_lens(qad, center, tol, mod, sps, 2, spacing)
+                        fb = oracle.ppseq_to_bits_flat(pp, sps, 2, True, 8)
+                        assert bits_equal(got[0][0], qad) and np.array_equal(got[0][1], pp), (n, tol, noise)
+                        assert n < 1000 or len(set(pp[:, 0].tolist())) >= 4, "all four levels should occur"
+                        assert all(np.array_equal(a, b) for a, b in zip(fb, got[0][2:])), (n, tol, noise)
+    finally:
+        lib.urhgpu_test_force_state_bytes(0)
+
+
 @pytest.mark.parametrize("mod", ["FSK", "ASK"])
 def test_bit_plane_kernel_equals_state_byte_kernel(pipe, oracle, mod):
-    """Modulation order 2 runs k_demod_runs_bp (bit planes, wavefronts sharing a chunk), every other order the
+    """Modulation orders 2 and 4 run k_demod_runs_bp (bit planes, wavefronts sharing a chunk), every other order the
     state-byte kernel: both on the same captures -- tolerances 0..64 and beyond (65: the state-byte kernel is the
     only one), noise gating on and off, exact-zero samples, sizes that end in whole rows, partial rows, partial tiles --
     must agree on everything, and with the oracle."""

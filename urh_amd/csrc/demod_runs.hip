@@ -846,14 +846,16 @@ __device__ __forceinline__ uint32_t put_lane(uint32_t value, int row, uint32_t o
 }
 
 // RUNS = false: demodulation only (urhgpu_afp_demod[_dev], Signal.qad): the same streaming structure without the planes
-template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true>
+// NPL: bit planes of the state besides PAUSE: 1 for modulation order 2 (plane = "q <= threshold": state 1, else 2), 2 for
+// order 4 (planes = the two bits of state - 1, from the three threshold masks).
+template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1>
 __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArgs p) {
     // One workgroup per chunk, URH_WPB wavefronts: wavefront w streams the w-th share of the chunk's rows on its own
     // (no barrier inside the streaming phase), so that the wavefronts resident on the chip cover a NARROW window of
     // the capture (DRAM page locality: a wavefront per 16 KiB measured 8 % faster than a wavefront per 64 KiB on a
     // pure copy of this shape) while the per-chunk work (prologue, run phase, ChunkInfo) is paid once per 64 rows.
     constexpr int W = URH_WPB;
-    __shared__ uint32_t s_planes[W > 1 ? 8 : 1][W > 1 ? 64 : 1];
+    __shared__ uint32_t s_planes[W > 1 ? (NPL + 1) * 4 : 1][W > 1 ? 64 : 1];
     const int lane = threadIdx.x & 63;
     const int w = (W > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;     // wavefront-uniform
     const int64_t chunk = p.chunk_base + blockIdx.x;
@@ -873,7 +875,7 @@ __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArg
 
     float prev_c = 0.f, prev_d = 0.f;                         // IQ sample before my first row (FSK seam operand)
     uint32_t st_before = kStNone;                             // state of sample a0-1: wavefront 0 (it runs phase 2)
-    if (w == 0 && RUNS) st_before = chunk_prologue<SRC, DT, MOD, true>(p, a0, global_start, prev_c, prev_d);
+    if (w == 0 && RUNS) st_before = chunk_prologue<SRC, DT, MOD, NPL == 1>(p, a0, global_start, prev_c, prev_d);
     else if (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK) {
         const int64_t before = a0 + (int64_t)r0 * kRowSamples - 1;
         if (before >= 0) Iq<DT>::load1(p.in, before, prev_c, prev_d);
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArg
     }
 
     // ================= phase 1: demodulate, one compare mask per plane and parity, parked in lane `row` ==============
-    uint32_t be_lo = 0, be_hi = 0, bo_lo = 0, bo_hi = 0, pe_lo = 0, pe_hi = 0, po_lo = 0, po_hi = 0;
+    uint32_t pl[NPL + 1][2][2] = {};                          // [state planes ..., PAUSE][even, odd samples][low, high word]: lane r <- row r
 #pragma unroll 1
     for (int rb = r0; rb < r0 + R; rb += kBatch) {
         if (rb + kBatch < r0 + R) load_rows<SRC, DT, true>(p, a0, rb + kBatch, lane, a1, nxt);
@@ -904,16 +906,36 @@ __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArg
                 }
             }
             if (!RUNS) continue;
-            uint64_t Be = __builtin_amdgcn_ballot_w64(q0[j] <= p.thr[0]), Bo = __builtin_amdgcn_ballot_w64(q1[j] <= p.thr[0]);
+            uint64_t X[NPL][2];                                // [plane][parity]
+            if (NPL == 1) {
+                X[0][0] = __builtin_amdgcn_ballot_w64(q0[j] <= p.thr[0]); X[0][1] = __builtin_amdgcn_ballot_w64(q1[j] <= p.thr[0]);
+            } else {
+                // order 4: state - 1 = the first k with q <= thr[k], else 3 (signal_functions.pyx:438-442), as two bits
+                const float qq[2] = {q0[j], q1[j]};
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    const uint64_t m0 = __builtin_amdgcn_ballot_w64(qq[par] <= p.thr[0]), m1 = __builtin_amdgcn_ballot_w64(qq[par] <= p.thr[1]),
+                                   m2 = __builtin_amdgcn_ballot_w64(qq[par] <= p.thr[2]);
+                    X[NPL - 1][par] = ~m0 & ~m1;               // bit 1
+                    X[0][par] = ~m0 & (m1 | ~m2);              // bit 0
+                }
+            }
             const int row = rb + j;
             if (((gated >> j) & 1u) || row0) {                 // wavefront-uniform: some sample may be the NOISE sentinel
                 const uint64_t Pe = __builtin_amdgcn_ballot_w64(q0[j] == p.noise_val), Po = __builtin_amdgcn_ballot_w64(q1[j] == p.noise_val);
-                Be &= ~Pe; Bo &= ~Po;
-                pe_lo = put_lane((uint32_t)Pe, row, pe_lo); pe_hi = put_lane((uint32_t)(Pe >> 32), row, pe_hi);
-                po_lo = put_lane((uint32_t)Po, row, po_lo); po_hi = put_lane((uint32_t)(Po >> 32), row, po_hi);
+#pragma unroll
+                for (int k = 0; k < NPL; ++k) { X[k][0] &= ~Pe; X[k][1] &= ~Po; }
+                pl[NPL][0][0] = put_lane((uint32_t)Pe, row, pl[NPL][0][0]); pl[NPL][0][1] = put_lane((uint32_t)(Pe >> 32), row, pl[NPL][0][1]);
+                pl[NPL][1][0] = put_lane((uint32_t)Po, row, pl[NPL][1][0]); pl[NPL][1][1] = put_lane((uint32_t)(Po >> 32), row, pl[NPL][1][1]);
             }
-            be_lo = put_lane((uint32_t)Be, row, be_lo); be_hi = put_lane((uint32_t)(Be >> 32), row, be_hi);
-            bo_lo = put_lane((uint32_t)Bo, row, bo_lo); bo_hi = put_lane((uint32_t)(Bo >> 32), row, bo_hi);
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+#pragma unroll
+                for (int par = 0; par < 2; ++par) {
+                    pl[k][par][0] = put_lane((uint32_t)X[k][par], row, pl[k][par][0]);
+                    pl[k][par][1] = put_lane((uint32_t)(X[k][par] >> 32), row, pl[k][par][1]);
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) cur[j] = nxt[j];
@@ -924,34 +946,51 @@ __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArg
     if (W > 1) {
         if (w != 0) {
             if (lane >= r0 && lane < r0 + R) {
-                s_planes[0][lane] = be_lo; s_planes[1][lane] = be_hi; s_planes[2][lane] = bo_lo; s_planes[3][lane] = bo_hi;
-                s_planes[4][lane] = pe_lo; s_planes[5][lane] = pe_hi; s_planes[6][lane] = po_lo; s_planes[7][lane] = po_hi;
+#pragma unroll
+                for (int k = 0; k <= NPL; ++k) {
+                    s_planes[4 * k + 0][lane] = pl[k][0][0]; s_planes[4 * k + 1][lane] = pl[k][0][1];
+                    s_planes[4 * k + 2][lane] = pl[k][1][0]; s_planes[4 * k + 3][lane] = pl[k][1][1];
+                }
             }
         }
         __syncthreads();
         if (w != 0) return;
         if (lane >= R) {
-            be_lo = s_planes[0][lane]; be_hi = s_planes[1][lane]; bo_lo = s_planes[2][lane]; bo_hi = s_planes[3][lane];
-            pe_lo = s_planes[4][lane]; pe_hi = s_planes[5][lane]; po_lo = s_planes[6][lane]; po_hi = s_planes[7][lane];
+#pragma unroll
+            for (int k = 0; k <= NPL; ++k) {
+                pl[k][0][0] = s_planes[4 * k + 0][lane]; pl[k][0][1] = s_planes[4 * k + 1][lane];
+                pl[k][1][0] = s_planes[4 * k + 2][lane]; pl[k][1][1] = s_planes[4 * k + 3][lane];
+            }
         }
     }
 
     // ================= phase 2: lane r owns row r (samples [128 r, 128 r + 128) of the chunk) =====================
-    const uint64_t Be = ((uint64_t)be_hi << 32) | be_lo, Bo = ((uint64_t)bo_hi << 32) | bo_lo;
-    const uint64_t Pe = ((uint64_t)pe_hi << 32) | pe_lo, Po = ((uint64_t)po_hi << 32) | po_lo;
+    uint64_t XE[NPL + 1], XO[NPL + 1];                         // planes of my row: even / odd samples
+#pragma unroll
+    for (int k = 0; k <= NPL; ++k) { XE[k] = ((uint64_t)pl[k][0][1] << 32) | pl[k][0][0]; XO[k] = ((uint64_t)pl[k][1][1] << 32) | pl[k][1][0]; }
     auto state_at = [&](int pos) -> uint32_t {                 // state byte of sample `pos` of my row
         const int idx = pos >> 1;
-        const uint64_t P = (pos & 1) ? Po : Pe, B = (pos & 1) ? Bo : Be;
-        return ((P >> idx) & 1) ? kStPause : (((B >> idx) & 1) ? 1u : 2u);
+        if ((((pos & 1) ? XO[NPL] : XE[NPL]) >> idx) & 1) return kStPause;
+        const uint32_t b0 = (uint32_t)((((pos & 1) ? XO[0] : XE[0]) >> idx) & 1);
+        if (NPL == 1) return b0 ? 1u : 2u;
+        const uint32_t b1 = (uint32_t)((((pos & 1) ? XO[NPL - 1] : XE[NPL - 1]) >> idx) & 1);
+        return 1u + b0 + 2u * b1;
     };
-    // boundaries: sample differs from the one before it
-    uint64_t De, Do;
+    // boundaries: sample differs from the one before it (in any plane)
+    uint64_t De = 0, Do = 0;
     {
-        uint32_t upB = __shfl_up(bo_hi, 1) >> 31, upP = __shfl_up(po_hi, 1) >> 31;      // last sample of the row above
-        if (lane == 0) { upB = (st_before == 1u); upP = (st_before == kStPause); }
-        De = (Be ^ ((Bo << 1) | upB)) | (Pe ^ ((Po << 1) | upP));
+#pragma unroll
+        for (int k = 0; k <= NPL; ++k) {
+            uint32_t up = __shfl_up(pl[k][1][1], 1) >> 31;     // last sample of the row above
+            if (lane == 0) {
+                if (k == NPL) up = (st_before == kStPause);
+                else if (NPL == 1) up = (st_before == 1u);
+                else up = (st_before >= 1u && st_before <= 4u) ? (((st_before - 1u) >> k) & 1u) : 0u;
+            }
+            De |= XE[k] ^ ((XO[k] << 1) | up);
+            Do |= XE[k] ^ XO[k];
+        }
         if (lane == 0 && st_before == kStNone) De |= 1ull;     // the capture starts here: its first sample starts a run
-        Do = (Be ^ Bo) | (Pe ^ Po);
         if (lane >= nr) { De = 0; Do = 0; }
     }
     // stable runs: no boundary within the next `tol` samples (the chunk end counts as one: what it cuts short is
@@ -1049,7 +1088,7 @@ __global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArg
         ci.last_state = (uint16_t)last_state;
         ci.pend_state = (uint16_t)pend_state;
         ci.last_pos = last_pos;
-        ci.init_state = (uint16_t)chunk_init_state<SRC, DT, MOD, true>(p, chunk);
+        ci.init_state = (uint16_t)chunk_init_state<SRC, DT, MOD, NPL == 1>(p, chunk);
         ci.first_acc = 0; ci.pend_acc = 0; ci.pend_stable = 0; ci.pad = 0;
         p.chunks[chunk] = ci;
     }
@@ -1136,9 +1175,12 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
     const int64_t c_lo = (part == 1) ? 1 : 0, c_hi = (part == 2) ? std::min<int64_t>(n_main, 1) : n_main;
     if (c_hi > c_lo) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
-        // order 2 (states PAUSE/1/2): the bit-plane kernel; anything else: the state-byte kernel
-        if (URH_BITPLANE && O2 && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes)
+        // orders 2 and 4: the bit-plane kernel; anything else: the state-byte kernel
+        const bool planes_ok = URH_BITPLANE && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes;
+        if (planes_ok && O2)
             hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * URH_WPB), (size_t)a.lds_pad, s, a);
+        else if (planes_ok && a.order == 4)
+            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 2>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * URH_WPB), (size_t)a.lds_pad, s, a);
         else
             hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock), 0, s, a);
     }
