@@ -53,6 +53,7 @@ extern "C" {
 #define URHGPU_MOD_FSK 1
 #define URHGPU_MOD_PSK 2
 #define URHGPU_MOD_OTHER 3 /* "OQPSK"/"QAM"/...: no demod branch in afp_demod (result stays 0) */
+#define URHGPU_MOD_OQPSK 4 /* urhgpu_modulate* only: get_oqpsk_bits + PSK + half-symbol blanking (signal_functions.pyx:118-121, 165-169) */
 
 typedef struct urhgpu_ctx urhgpu_ctx;
 
@@ -286,7 +287,7 @@ int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);
 
-/* signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK (GFSK / OQPSK: URHGPU_ERR_UNSUPPORTED),
+/* signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK / OQPSK (URHGPU_MOD_OQPSK: bits_per_symbol must be 2; GFSK: not provided),
  * n_msgs messages rendered back to back by one launch (URH modulates message by message, Modulator.py:215-255):
  * message m has bits[bit_off[m] .. bit_off[m+1]), is followed by pause[m] zero samples and starts at sample index start[m]
  * (the time origin of its carrier).  parameters: 2^bits_per_symbol amplitudes / frequencies / phases as the reference takes

@@ -26,7 +26,8 @@
 /* dtype codes shared with include/urhgpu.h */
 enum { DT_I8 = 0, DT_U8 = 1, DT_I16 = 2, DT_U16 = 3, DT_F32 = 4 };
 /* modulation codes shared with include/urhgpu.h */
-enum { MOD_ASK = 0, MOD_FSK = 1, MOD_PSK = 2, MOD_OTHER = 3 /* e.g. "QAM", "OQPSK": no demod branch */ };
+enum { MOD_ASK = 0, MOD_FSK = 1, MOD_PSK = 2, MOD_OTHER = 3 /* e.g. "QAM", "OQPSK": no demod branch */,
+       MOD_OQPSK = 4 /* orc_modulate only */ };
 
 #define PAUSE_STATE (-1)
 
@@ -389,12 +390,22 @@ static void store_iq(void *out, int dt, int64_t idx, float v) {
 int64_t orc_modulate(const uint8_t *bits, int64_t num_bits, uint32_t sps, int mod, const float *parameters,
                      int bits_per_symbol, float carrier_amplitude, float carrier_frequency, float carrier_phase,
                      float sample_rate, uint32_t pause, uint32_t start, int dt, void *out) {
-    if (mod != MOD_ASK && mod != MOD_FSK && mod != MOD_PSK) return -1;
+    const int is_oqpsk = (mod == MOD_OQPSK);
+    if (mod != MOD_ASK && mod != MOD_FSK && mod != MOD_PSK && !is_oqpsk) return -1;
+    if (is_oqpsk && bits_per_symbol != 2) return -2;                           /* assert bits_per_symbol == 2 (:120) */
     const uint32_t total_symbols = (uint32_t)(num_bits / bits_per_symbol);
     const int64_t total_samples = (int64_t)total_symbols * sps + pause;
     const int esz = dt == DT_F32 ? 4 : (dt == DT_I8 ? 1 : 2);
     memset(out, 0, (size_t)total_samples * 2 * esz);
     if (num_bits == 0) return total_samples;
+    uint8_t *oq = NULL;
+    if (is_oqpsk) {                                                            /* get_oqpsk_bits (:179-194), literally */
+        oq = (uint8_t *)calloc((size_t)num_bits + 2, 1);
+        oq[0] = bits[0];
+        oq[num_bits + 1] = bits[num_bits - 1];
+        for (int64_t i = 2; i < num_bits - 2; i += 2) { oq[i] = bits[i]; oq[i + 1] = bits[i - 1]; }
+        bits = oq;
+    }
     float *pc = NULL;
     if (mod == MOD_FSK && total_symbols > 0) {
         pc = (float *)malloc((size_t)total_symbols * sizeof(float));
@@ -421,6 +432,15 @@ int64_t orc_modulate(const uint8_t *bits, int64_t num_bits, uint32_t sps, int mo
             store_iq(out, dt, 2 * i + 1, a * sinf(arg));
         }
     }
+    if (is_oqpsk) {                                                            /* :165-169; negative indices wrap around (Cython default) */
+        for (int64_t i = 0; i < (int64_t)sps; ++i)
+            if (i < total_samples) store_iq(out, dt, 2 * i + 1, 0.0f);
+        for (int64_t i = total_samples - pause - sps; i < total_samples - pause; ++i) {
+            const int64_t k = i < 0 ? i + total_samples : i;
+            if (k >= 0 && k < total_samples) store_iq(out, dt, 2 * k, 0.0f);
+        }
+    }
     free(pc);
+    free(oq);
     return total_samples;
 }

@@ -296,10 +296,13 @@ def get_plateau_lengths(rect_data, center, percentage=25) -> np.ndarray:
 def modulate_c(bits, samples_per_symbol: int, modulation_type: str, parameters, bits_per_symbol: int,
                carrier_amplitude: float, carrier_frequency: float, carrier_phase: float, sample_rate: float,
                pause: int, start: int, dtype=np.float32, gauss_bt: float = 0.5, filter_width: float = 1.0) -> np.ndarray:
-    """signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK."""
+    """signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK / OQPSK."""
     mod = modulation_type.upper()
-    if mod not in MOD_CODES:
+    codes = dict(MOD_CODES, OQPSK=4)
+    if mod not in codes:
         raise NotImplementedError(modulation_type)
+    if mod == "OQPSK":
+        assert bits_per_symbol == 2
     dt = np.dtype(dtype)
     if dt not in (np.dtype(np.int8), np.dtype(np.int16), np.dtype(np.float32)):
         raise ValueError("Unsupported dtype for modulation {}".format(dtype))
@@ -307,7 +310,7 @@ def modulate_c(bits, samples_per_symbol: int, modulation_type: str, parameters, 
     par = np.ascontiguousarray(parameters, dtype=np.float32)
     total = (len(b) // bits_per_symbol) * samples_per_symbol + pause
     out = np.zeros((total, 2), dtype=dt)
-    k = lib().orc_modulate(b.ctypes.data_as(C.c_void_p), C.c_int64(len(b)), C.c_uint32(samples_per_symbol), MOD_CODES[mod],
+    k = lib().orc_modulate(b.ctypes.data_as(C.c_void_p), C.c_int64(len(b)), C.c_uint32(samples_per_symbol), codes[mod],
                            par.ctypes.data_as(C.c_void_p), C.c_int(bits_per_symbol), C.c_float(carrier_amplitude),
                            C.c_float(carrier_frequency), C.c_float(carrier_phase), C.c_float(sample_rate), C.c_uint32(pause),
                            C.c_uint32(start), DT_CODES[dt], out.ctypes.data_as(C.c_void_p))

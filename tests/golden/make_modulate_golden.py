@@ -26,6 +26,8 @@ CASES = [
     ("ask4_i8", "ASK", [0.0, 42.0, 85.0, 127.0], 2, 25, 300, 0, 999, "int8", 127.0),
     ("psk2_f32", "PSK", [-np.pi / 2, np.pi / 2], 1, 8, 96, 10, 0, "float32", 1.0),
     ("psk4_f32", "PSK", list(np.array([-135.0, -45.0, 45.0, 135.0]) * np.pi / 180), 2, 100, 200, 76, 50_000, "float32", 1.0),
+    ("oqpsk_f32", "OQPSK", list(np.array([-135.0, -45.0, 45.0, 135.0]) * np.pi / 180), 2, 100, 200, 76, 0, "float32", 1.0),
+    ("oqpsk_i8_odd", "OQPSK", list(np.array([-135.0, -45.0, 45.0, 135.0]) * np.pi / 180), 2, 10, 31, 5, 777, "int8", 100.0),
 ]
 
 

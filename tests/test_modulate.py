@@ -29,7 +29,7 @@ def random_cases(seed, n):
     rng = np.random.default_rng(seed)
     mods = [("FSK", [-20e3, 20e3], 1), ("FSK", [-30e3, -10e3, 10e3, 30e3], 2), ("ASK", [0.0, 1.0], 1), ("ASK", [0.0, 0.3, 0.6, 1.0], 2),
             ("PSK", [-np.pi / 2, np.pi / 2], 1), ("PSK", list(np.array([-135.0, -45.0, 45.0, 135.0]) * np.pi / 180), 2),
-            ("FSK", list(np.linspace(-35e3, 35e3, 8)), 3)]
+            ("FSK", list(np.linspace(-35e3, 35e3, 8)), 3), ("OQPSK", list(np.array([-135.0, -45.0, 45.0, 135.0]) * np.pi / 180), 2)]
     for k in range(n):
         mod, par, bps = mods[k % len(mods)]
         dtype = (np.float32, np.int8, np.int16)[(k // len(mods)) % 3]
@@ -39,6 +39,8 @@ def random_cases(seed, n):
         sps = int(rng.choice([1, 7, 8, 100, 333]))
         nb = int(rng.integers(0, 700)) * bps + int(rng.integers(0, bps))        # trailing bits that fill no symbol are ignored
         pause = int(rng.choice([0, 1, 76, 5000]))
+        if mod == "OQPSK" and nb < 2 and pause < sps:
+            pause = sps                                         # the reference's blanking loops index past the array otherwise
         start = int(rng.choice([0, 17, 123_456, 16_777_217, 3_000_000_000]))
         bits = rng.integers(0, 2, nb).astype(np.uint8)
         yield (bits, sps, mod, np.array(par, np.float32), bps, amp, 40e3, float(rng.uniform(-3, 3)), float(rng.choice([1e6, 2e6, 250e3])),
@@ -50,7 +52,7 @@ def test_oracle_equals_reference_goldens(oracle):
     for name, args, want in golden_cases():
         assert same(oracle.modulate_c(*args), want), name
         n += 1
-    assert n == 7
+    assert n == 9
 
 
 def test_oracle_equals_real_reference_random(oracle):
@@ -58,7 +60,7 @@ def test_oracle_equals_real_reference_random(oracle):
     if not build_ref.built():
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     sf, _, _ = build_ref.import_ref()
-    for args in random_cases(5, 84):
+    for args in random_cases(5, 96):
         bits, sps, mod, par = args[:4]
         ref = sf.modulate_c(array.array("B", bits.tolist()), sps, mod, array.array("f", par.tolist()), *args[4:])
         assert same(oracle.modulate_c(*args), ref), args[1:]
@@ -69,7 +71,7 @@ def test_gpu_modulate_equals_goldens_and_oracle(oracle):
     from urh_amd import signal_functions as sf
     for name, args, want in golden_cases():
         assert same(sf.modulate_c(*args), want), name
-    for args in random_cases(11, 126):
+    for args in random_cases(11, 144):
         assert same(sf.modulate_c(*args), oracle.modulate_c(*args)), args[1:]
 
 
@@ -81,14 +83,16 @@ def test_gpu_modulate_long_message_and_batch(oracle):
     rng = np.random.default_rng(3)
     msgs = [rng.integers(0, 2, n).astype(np.uint8) for n in (10485, 0, 1, 2000, 5000)]
     pauses = [76, 10, 0, 300, 48576]
-    for mod, par, dtype in (("FSK", [-20e3, 20e3], np.float32), ("ASK", [0.0, 100.0], np.int8), ("PSK", [-1.0, 2.0], np.int16)):
+    for mod, par, dtype in (("FSK", [-20e3, 20e3], np.float32), ("ASK", [0.0, 100.0], np.int8), ("PSK", [-1.0, 2.0], np.int16),
+                            ("OQPSK", [-2.0, -1.0, 1.0, 2.0], np.float32)):
         amp = {np.float32: 1.0, np.int8: 127.0, np.int16: 32767.0}[dtype]
+        bps = 2 if mod == "OQPSK" else 1
         for starts in (None, [0, 5, 5, 1 << 24, 77]):
-            got = sf.modulate_messages_dev(msgs, 100, mod, par, 1, amp, 40e3, 0.1, 1e6, pauses, starts, dtype).cpu().numpy()
+            got = sf.modulate_messages_dev(msgs, 100, mod, par, bps, amp, 40e3, 0.1, 1e6, pauses, starts, dtype).cpu().numpy()
             off = 0
             for k, (m, p) in enumerate(zip(msgs, pauses)):
                 st = off if starts is None else starts[k]
-                want = oracle.modulate_c(m, 100, mod, np.array(par, np.float32), 1, amp, 40e3, 0.1, 1e6, p, st, dtype)
+                want = oracle.modulate_c(m, 100, mod, np.array(par, np.float32), bps, amp, 40e3, 0.1, 1e6, p, st, dtype)
                 assert same(got[off:off + len(want)], want), (mod, dtype, k)
                 off += len(want)
             assert off == len(got)
@@ -117,5 +121,7 @@ def test_gpu_modulate_errors_and_edges():
         sf.modulate_c([1, 0], 10, "FSK", [-1.0, 1.0], 1, 1.0, 0.0, 0.0, 1e6, 0, 0, dtype=np.uint8)
     with pytest.raises(NotImplementedError):
         sf.modulate_c([1, 0], 10, "GFSK", [-1.0, 1.0], 1, 1.0, 0.0, 0.0, 1e6, 0, 0)
+    with pytest.raises(AssertionError):
+        sf.modulate_c([1, 0], 10, "OQPSK", [-1.0, 1.0], 1, 1.0, 0.0, 0.0, 1e6, 0, 0)          # bits_per_symbol must be 2
     with pytest.raises(AssertionError):
         sf.modulate_c([1, 0], 10, "QAM", [-1.0, 1.0], 1, 1.0, 0.0, 0.0, 1e6, 0, 0)

@@ -850,7 +850,9 @@ int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit
                         float carrier_amplitude, float carrier_frequency, float carrier_phase, float sample_rate, int dtype,
                         void *d_out, int64_t cap_samples, int64_t *total_samples) {
     if (!ctx || n_msgs < 0 || !total_samples || (n_msgs > 0 && (!bit_off || !pause || !start || !parameters))) return URHGPU_ERR_ARG;
-    if (mod != URHGPU_MOD_ASK && mod != URHGPU_MOD_FSK && mod != URHGPU_MOD_PSK) return URHGPU_ERR_UNSUPPORTED;
+    const bool oqpsk = (mod == URHGPU_MOD_OQPSK);
+    if (mod != URHGPU_MOD_ASK && mod != URHGPU_MOD_FSK && mod != URHGPU_MOD_PSK && !oqpsk) return URHGPU_ERR_UNSUPPORTED;
+    if (oqpsk && bits_per_symbol != 2) return URHGPU_ERR_ARG;                    // assert bits_per_symbol == 2 (:120)
     if (dtype != URHGPU_DT_F32 && dtype != URHGPU_DT_I8 && dtype != URHGPU_DT_I16) return URHGPU_ERR_DTYPE;
     if (bits_per_symbol < 1 || bits_per_symbol > 16 || samples_per_symbol == 0 || n_msgs > 65535) return URHGPU_ERR_UNSUPPORTED;
     std::vector<ModMsg> msgs((size_t)n_msgs);
@@ -877,6 +879,21 @@ int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit
                                  align256(n_par * 4) + align256((size_t)std::max<int64_t>(total_sym, 1) * 4) + 2048));
     ctx->staging.reset();
     void *d_bits = nullptr, *d_msgs = nullptr, *d_par = nullptr;
+    std::vector<uint8_t> oq;
+    if (oqpsk) {
+        // get_oqpsk_bits (:179-194) per message: even bits stay, odd bits are delayed by one symbol; of the num_bits + 2
+        // bits it returns the symbol loop reads the first 2 * n_sym (total_symbols is taken from the original length)
+        oq.assign((size_t)n_bits, 0);
+        for (int m = 0; m < n_msgs; ++m) {
+            const uint8_t *b = bits + bit_off[m];
+            uint8_t *r = oq.data() + bit_off[m];
+            const int64_t nb = bit_off[m + 1] - bit_off[m];
+            if (nb == 0) continue;
+            r[0] = b[0];
+            for (int64_t i = 2; i < nb - 2; i += 2) { r[i] = b[i]; r[i + 1] = b[i - 1]; }
+        }
+        bits = oq.data();
+    }
     URH_TRY(stage_in(ctx, bits, (size_t)n_bits, &d_bits));
     URH_TRY(stage_in(ctx, msgs.data(), msgs.size() * sizeof(ModMsg), &d_msgs));
     URH_TRY(stage_in(ctx, parameters, n_par * 4, &d_par));
@@ -884,7 +901,7 @@ int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit
     if (!d_phase) return URHGPU_ERR_ARG;
     ModArgs a;
     a.bits = (const uint8_t *)d_bits; a.msgs = (const ModMsg *)d_msgs; a.params = (const float *)d_par; a.phase = d_phase;
-    a.out = d_out; a.n_msgs = n_msgs; a.mod = mod; a.dtype = dtype; a.bps = bits_per_symbol; a.sps = samples_per_symbol;
+    a.out = d_out; a.n_msgs = n_msgs; a.mod = oqpsk ? URHGPU_MOD_PSK : mod; a.oqpsk = oqpsk ? 1 : 0; a.dtype = dtype; a.bps = bits_per_symbol; a.sps = samples_per_symbol;
     a.carrier_amplitude = carrier_amplitude; a.carrier_frequency = carrier_frequency; a.carrier_phase = carrier_phase;
     a.sample_rate = sample_rate;
     URH_TRY(launch_modulate(a, max_samples, ctx->stream));

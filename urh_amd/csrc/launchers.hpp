@@ -57,6 +57,7 @@ struct ModArgs {
     float *phase;            // device scratch: one float per symbol (FSK)
     void *out;               // device: (total samples, 2) of dtype
     int n_msgs, mod, dtype, bps;
+    int oqpsk;               // mod == PSK on re-ordered bits, first symbol's Q and last symbol's I blanked
     uint32_t sps;
     float carrier_amplitude, carrier_frequency, carrier_phase, sample_rate;
 };

@@ -1,5 +1,5 @@
 // modulate.hip -- signal_functions.modulate_c on the GPU (the generator on the other side of the IQ->bits path)
-//   /root/reference/src/urh/cythonext/signal_functions.pyx:56-177   (ASK, FSK, PSK)
+//   /root/reference/src/urh/cythonext/signal_functions.pyx:56-177   (ASK, FSK, PSK, OQPSK)
 //
 // Batched: URH modulates message by message (Modulator.modulate, ProtocolAnalyzerContainer.modulate), every message
 // with its own bits / pause / start sample; one launch renders any number of messages back to back.
@@ -87,6 +87,11 @@ __global__ __launch_bounds__(256) void k_modulate(const ModArgs a) {
                 const float arg = (float)(((((two_pi) * (double)f) * (double)t) + (double)phi) + (double)corr);
                 o.x = mod_cast<T>(amp * urh_cosf(arg));
                 o.y = mod_cast<T>(amp * urh_sinf(arg));
+            }
+            // OQPSK (:165-169): Q of the first symbol and I of the last one are blanked
+            if (MOD == URHGPU_MOD_PSK && a.oqpsk) {
+                if (i < (int64_t)a.sps) o.y = (T)0;
+                if (i >= n_data - (int64_t)a.sps) o.x = (T)0;
             }
         }
         out[i] = o;

@@ -193,8 +193,10 @@ def _modulation_code(modulation_type: str) -> int:
     m = modulation_type.lower()                      # the reference compares lower-case names (:111-115)
     if m in ("ask", "fsk", "psk"):
         return _MOD[m.upper()]
-    if m in ("gfsk", "oqpsk"):
-        raise NotImplementedError(f"{modulation_type}: only ASK / FSK / PSK are generated on the GPU")
+    if m == "oqpsk":
+        return 4                                     # URHGPU_MOD_OQPSK
+    if m == "gfsk":
+        raise NotImplementedError("GFSK: numpy's float32 convolution (BLAS sdot, host dependent) is not reproduced on the GPU")
     raise AssertionError(modulation_type)            # `assert is_fsk or is_ask or ...` (:117)
 
 
@@ -213,6 +215,7 @@ def modulate_c(bits, samples_per_symbol: int, modulation_type: str, parameters, 
     if len(b) == 0 or total == 0:
         return out
     mod = _modulation_code(modulation_type)
+    assert mod != 4 or int(bits_per_symbol) == 2     # :120
     par = np.ascontiguousarray(parameters, dtype=np.float32)
     if len(par) < (1 << int(bits_per_symbol)):
         raise IndexError("parameters shorter than 2**bits_per_symbol")
@@ -235,6 +238,7 @@ def modulate_messages_dev(messages, samples_per_symbol: int, modulation_type: st
     if dt not in _MOD_DTYPES:
         raise ValueError("Unsupported dtype for modulation {}".format(dtype))
     mod = _modulation_code(modulation_type)
+    assert mod != 4 or int(bits_per_symbol) == 2     # :120
     bl = [_bits_u8(m) for m in messages]
     off = np.zeros(len(bl) + 1, dtype=np.int64)
     off[1:] = np.cumsum([len(x) for x in bl])
