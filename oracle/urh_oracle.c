@@ -264,7 +264,8 @@ void orc_fir_filter(const float *x, int64_t N, const float *taps, int64_t M, flo
 
 /* signal_functions.pyx:527-542 iir_filter.  As generated: the product (a[j]+0j)*complex128(x) is a
  * full complex128 multiply, ROUNDED to complex64, then accumulated with a complex64 `+=`.
- * PARITY UNPINNED in the reference (no asserting test); pinned here against the oracle/_ref build. */
+ * No asserting test in the reference; pinned on the real function run here (oracle/_ref) and on its committed outputs
+ * (tests/golden/filter/fir_iir.npz). */
 void orc_iir_filter(const double *a, int64_t M, const double *b, int64_t N, const float *sig, int64_t len,
                     float *out) {
     for (int64_t i = 0; i < 2 * len; i++) out[i] = 0.0f;

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, load_golden, synth_fsk
+from conftest import GOLDEN_CASES, ROOT, load_golden, synth_fsk
 
 pytestmark = pytest.mark.gpu
 
@@ -418,6 +418,18 @@ def test_iir_equals_oracle(sf, oracle):
     for na, nb in ((1, 0), (3, 2), (2, 4), (5, 5)):
         a, b = rng.standard_normal(na) * 0.3, rng.standard_normal(nb) * 0.2
         assert cbits_equal(sf.iir_filter(a, b, x), oracle.iir_filter(a, b, x)), (na, nb)
+
+
+def test_filters_equal_reference_goldens(sf):
+    """The real reference's fir_filter / iir_filter outputs (tests/golden/filter/fir_iir.npz) through the C ABI."""
+    import os
+    g = np.load(os.path.join(ROOT, "tests", "golden", "filter", "fir_iir.npz"))
+    for name in (str(n) for n in g["names"]):
+        if name.startswith("iir"):
+            got = sf.iir_filter(g[name + "_a"], g[name + "_b"], g[name + "_x"])
+        else:
+            got = sf.fir_filter(g[name + "_x"], g[name + "_h"])
+        assert cbits_equal(got, g[name + "_y"]), name
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.int8, np.uint8, np.int16, np.uint16])

@@ -86,6 +86,26 @@ def test_oracle_filters_vs_real_reference(oracle):
     assert np.array_equal(np.asarray(sf.iir_filter(a, b, x)).view(np.uint32), oracle.iir_filter(a, b, x).view(np.uint32))
 
 
+def _filter_goldens():
+    import os
+    from conftest import ROOT
+    g = np.load(os.path.join(ROOT, "tests", "golden", "filter", "fir_iir.npz"))
+    return g, [str(n) for n in g["names"]]
+
+
+def test_oracle_filters_equal_reference_goldens(oracle):
+    """fir_filter / iir_filter outputs of the real reference (tests/golden/make_filter_golden.py): the committed vectors are
+    the pin for iir_filter, which the reference's own tests never assert on."""
+    g, names = _filter_goldens()
+    assert len(names) == 9
+    for name in names:
+        if name.startswith("iir"):
+            got = oracle.iir_filter(g[name + "_a"], g[name + "_b"], g[name + "_x"])
+        else:
+            got = oracle.fir_filter(g[name + "_x"], g[name + "_h"])
+        assert np.array_equal(got.view(np.uint32), g[name + "_y"].view(np.uint32)), name
+
+
 def test_oracle_ppseq_to_bits_vs_reference_python(oracle):
     """_ppseq_to_bits against the reference's own Python (needs /root/reference + the PyQt6 stub)."""
     import ref_python
