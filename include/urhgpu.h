@@ -287,7 +287,7 @@ int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);
 
-/* signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK / OQPSK (URHGPU_MOD_OQPSK: bits_per_symbol must be 2; GFSK: not provided),
+/* signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK / OQPSK (URHGPU_MOD_OQPSK: bits_per_symbol must be 2; GFSK: urhgpu_modulate_gfsk*),
  * n_msgs messages rendered back to back by one launch (URH modulates message by message, Modulator.py:215-255):
  * message m has bits[bit_off[m] .. bit_off[m+1]), is followed by pause[m] zero samples and starts at sample index start[m]
  * (the time origin of its carrier).  parameters: 2^bits_per_symbol amplitudes / frequencies / phases as the reference takes
@@ -303,6 +303,22 @@ int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit
 int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint32_t samples_per_symbol, int mod,
                     const float *parameters, int bits_per_symbol, float carrier_amplitude, float carrier_frequency,
                     float carrier_phase, float sample_rate, uint32_t pause, uint32_t start, int dtype, void *out);
+
+/* modulate_c(..., "GFSK", ...) (signal_functions.pyx:118-125, 156-163, 196-228).  gauss_fir: the n_taps Gaussian taps of
+ * gauss_fir (:230-243), which the reference computes with numpy (host; urh_amd.signal_functions.gauss_fir restates it).
+ * The per-sample symbol frequencies are convolved with the taps ("same" mode), every output an exactly accumulated dot product
+ * rounded once to float32; the reference takes this value from numpy's float32 BLAS dot product, whose summation order (and last
+ * bit) depends on the host CPU.  frequencies (HOST, optional): the filtered frequencies, one float per data sample of every
+ * message back to back (e.g. numpy's convolution, for the reference's bits on this host) -- used instead of the device
+ * convolution.  The phase recurrence (:219-226, numpy's float32 arange restated) and the carrier are evaluated exactly as
+ * the reference does.  A message with fewer bits than one symbol: URHGPU_ERR_ARG (ZeroDivisionError in the reference, :201). */
+int urhgpu_modulate_gfsk_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit_off, const uint32_t *pause, const uint32_t *start,
+                             int n_msgs, uint32_t samples_per_symbol, const float *parameters, int bits_per_symbol,
+                             float carrier_amplitude, float carrier_phase, float sample_rate, int dtype, const float *gauss_fir,
+                             int n_taps, const float *frequencies, void *d_out, int64_t cap_samples, int64_t *total_samples);
+int urhgpu_modulate_gfsk(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint32_t samples_per_symbol, const float *parameters,
+                         int bits_per_symbol, float carrier_amplitude, float carrier_phase, float sample_rate, uint32_t pause,
+                         uint32_t start, int dtype, const float *gauss_fir, int n_taps, const float *frequencies, void *out);
 
 /* IQArray.convert_to (IQArray.py:127-203) on device memory: n VALUES (two per IQ sample) of src_dtype -> dst_dtype, any
  * pair of different URHGPU_DT_* codes, with the reference's wrapping / truncating numpy semantics.  Asynchronous. */

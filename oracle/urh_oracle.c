@@ -445,3 +445,72 @@ int64_t orc_modulate(const uint8_t *bits, int64_t num_bits, uint32_t sps, int mo
     free(oq);
     return total_samples;
 }
+
+/* signal_functions.pyx:196-228 get_gauss_filtered_freqs_phases + the GFSK branch of __modulate (:118-125, :156-163).
+ *   frequencies[i] = parameters[symbol(i)]                       float32, one value per sample
+ *   t              = np.arange(start, start + n, dtype=float32) / sample_rate
+ *                    numpy fills an arange as buf[0] = start, buf[1] = start + 1 (each rounded to float32), then
+ *                    buf[i] = buf[0] + i * (buf[1] - buf[0]) in float32; the division is a float32 division
+ *   frequencies    = np.convolve(frequencies, gfir, "same")      (or convolve(gfir, frequencies, "same")[:n] when the
+ *                    filter is the longer one).  numpy evaluates every output as a float32 BLAS dot product whose summation
+ *                    order depends on the host's sdot kernel: THIS STEP IS NOT BIT-REPRODUCIBLE ACROSS HOSTS in the
+ *                    reference.  Restated as the exactly-summed (double) dot product rounded once to float32; compared
+ *                    with the real reference under a tolerance (tests/test_modulate.py), the device kernel equals this
+ *                    restatement bit for bit.
+ *   phases[0] = phi;  phases[i+1] = (float)(((2.0*M_PI) * t[i]) * (double)(f[i] - f[i+1]) + phases[i])   (f[i]-f[i+1] in float32)
+ *   sample i: t' = (float)(i + start) / sample_rate;  arg = (float)((2.0*M_PI*f[i])*t' + phases[i] + 0);  a*cosf(arg), a*sinf(arg)
+ * gfir (gauss_fir, :230-243) is computed by the caller with numpy, exactly as the reference does.
+ * freq_in (optional): the filtered frequencies (n floats), used instead of the convolution above -- e.g. numpy's on this host.
+ * freq_out / phase_out (optional): the two columns, n floats each.  Returns the sample count; -3: no whole symbol. */
+static float arange_f32(uint32_t start, int64_t i) {
+    const float s0 = (float)(double)start, s1 = (float)((double)start + 1.0);
+    if (i == 0) return s0;
+    if (i == 1) return s1;
+    const float delta = s1 - s0;
+    const float prod = (float)i * delta;
+    return s0 + prod;
+}
+int64_t orc_modulate_gfsk(const uint8_t *bits, int64_t num_bits, uint32_t sps, const float *parameters, int bits_per_symbol,
+                          float carrier_amplitude, float carrier_phase, float sample_rate, uint32_t pause, uint32_t start,
+                          const float *gfir, int64_t n_taps, const float *freq_in, int dt, void *out, float *freq_out,
+                          float *phase_out) {
+    const uint32_t total_symbols = (uint32_t)(num_bits / bits_per_symbol);
+    const int64_t total_samples = (int64_t)total_symbols * sps + pause;
+    const int esz = dt == DT_F32 ? 4 : (dt == DT_I8 ? 1 : 2);
+    memset(out, 0, (size_t)total_samples * 2 * esz);
+    if (num_bits == 0) return total_samples;
+    if (total_symbols == 0) return -3;                               /* len(bits) // num_symbols: ZeroDivisionError (:201) */
+    const int bps = (int)(num_bits / total_symbols);                 /* :201 (re-derived; equals bits_per_symbol when it divides) */
+    const int64_t n = (int64_t)total_symbols * sps, m = n_taps;
+    float *raw = (float *)malloc(sizeof(float) * (size_t)n), *f = (float *)malloc(sizeof(float) * (size_t)n);
+    float *ph = (float *)malloc(sizeof(float) * (size_t)n);
+    for (int64_t s = 0; s < total_symbols; ++s) {
+        const float v = parameters[bits_to_number(bits, s * bps, (s + 1) * bps)];
+        for (int64_t i = s * (int64_t)sps; i < (s + 1) * (int64_t)sps; ++i) raw[i] = v;
+    }
+    const int64_t off = (n >= m) ? (m - 1) / 2 : (n - 1) / 2;        /* "same": centred on the longer operand */
+    for (int64_t i = 0; i < n; ++i) {
+        if (freq_in) { f[i] = freq_in[i]; continue; }
+        const int64_t k = i + off;
+        const int64_t lo = k - m + 1 > 0 ? k - m + 1 : 0, hi = k < n - 1 ? k : n - 1;
+        double acc = 0.0;
+        for (int64_t j = lo; j <= hi; ++j) acc += (double)raw[j] * (double)gfir[k - j];
+        f[i] = (float)acc;
+    }
+    ph[0] = carrier_phase;
+    for (int64_t i = 0; i + 1 < n; ++i) {
+        const float t = arange_f32(start, i) / sample_rate;
+        const float df = f[i] - f[i + 1];
+        ph[i + 1] = (float)((((2.0 * M_PI) * (double)t) * (double)df) + (double)ph[i]);
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        const float t = ((float)(i + (int64_t)start)) / sample_rate;
+        const float arg = (float)(((((2.0 * M_PI) * f[i]) * t) + ph[i]) + 0.0f);
+        store_iq(out, dt, 2 * i, carrier_amplitude * cosf(arg));
+        store_iq(out, dt, 2 * i + 1, carrier_amplitude * sinf(arg));
+    }
+    if (freq_out) memcpy(freq_out, f, sizeof(float) * (size_t)n);
+    if (phase_out) memcpy(phase_out, ph, sizeof(float) * (size_t)n);
+    free(raw); free(f); free(ph);
+    return total_samples;
+}

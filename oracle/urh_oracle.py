@@ -318,6 +318,45 @@ def modulate_c(bits, samples_per_symbol: int, modulation_type: str, parameters, 
     return out
 
 
+def gauss_fir(sample_rate: float, samples_per_symbol: int, bt: float = 0.5, filter_width: float = 1.0) -> np.ndarray:
+    """signal_functions.gauss_fir (signal_functions.pyx:230-243): the same numpy expression (sample_rate, bt, filter_width
+    arrive as C floats there, i.e. as Python floats holding float32 values)."""
+    bt, filter_width, sample_rate = float(np.float32(bt)), float(np.float32(filter_width)), float(np.float32(sample_rate))
+    k = np.arange(-int(filter_width * samples_per_symbol), int(filter_width * samples_per_symbol) + 1, dtype=np.float32)
+    ts = float(np.float32(samples_per_symbol / sample_rate))          # cdef float ts
+    h = (np.sqrt((2 * np.pi) / (np.log(2))) * bt / ts * np.exp(
+        -(((np.sqrt(2) * np.pi) / np.sqrt(np.log(2)) * bt * k / samples_per_symbol) ** 2))).astype(np.float32)
+    return h / h.sum()
+
+
+def modulate_gfsk(bits, samples_per_symbol: int, parameters, bits_per_symbol: int, carrier_amplitude: float,
+                  carrier_phase: float, sample_rate: float, pause: int, start: int, dtype=np.float32, gauss_bt: float = 0.5,
+                  filter_width: float = 1.0, return_freqs_phases: bool = False, frequencies=None):
+    """modulate_c(..., "GFSK", ...) (signal_functions.pyx:118-125, 156-163, 196-228); see orc_modulate_gfsk for what is and
+    what is not bit-reproducible in the reference.  frequencies: the filtered frequencies to use instead of the restated
+    convolution (numpy's, for the reference's bits on this host)."""
+    dt = np.dtype(dtype)
+    b = np.ascontiguousarray(np.frombuffer(bytes(bytearray(bits)), dtype=np.uint8) if not isinstance(bits, np.ndarray) else bits, dtype=np.uint8)
+    par = np.ascontiguousarray(parameters, dtype=np.float32)
+    g = np.ascontiguousarray(gauss_fir(sample_rate, samples_per_symbol, gauss_bt, filter_width), dtype=np.float32)
+    n = (len(b) // bits_per_symbol) * samples_per_symbol
+    out = np.zeros((n + pause, 2), dtype=dt)
+    fr, ph = np.zeros(max(n, 1), np.float32), np.zeros(max(n, 1), np.float32)
+    fin = None if frequencies is None else np.ascontiguousarray(frequencies, dtype=np.float32)
+    assert fin is None or len(fin) == n
+    f = lib().orc_modulate_gfsk
+    f.restype = C.c_int64
+    k = f(b.ctypes.data_as(C.c_void_p), C.c_int64(len(b)), C.c_uint32(samples_per_symbol), par.ctypes.data_as(C.c_void_p),
+          C.c_int(bits_per_symbol), C.c_float(carrier_amplitude), C.c_float(carrier_phase), C.c_float(sample_rate), C.c_uint32(pause),
+          C.c_uint32(start), g.ctypes.data_as(C.c_void_p), C.c_int64(len(g)),
+          fin.ctypes.data_as(C.c_void_p) if fin is not None else None, DT_CODES[dt], out.ctypes.data_as(C.c_void_p),
+          fr.ctypes.data_as(C.c_void_p), ph.ctypes.data_as(C.c_void_p))
+    if k == -3:
+        raise ZeroDivisionError("integer division or modulo by zero")
+    assert k == n + pause
+    return (out, fr[:n], ph[:n]) if return_freqs_phases else out
+
+
 def create_path_arrays(samples, start: int, end: int, subpath_ranges=None, pixels_on_path: int = 5000):
     """path_creator.create_path (path_creator.pyx:19-82) up to the point where it hands (x, values) slices to
     array_to_QPath: per-pixel minimum / maximum of samples[start:end] (:46-66), or the samples themselves when there is

@@ -96,6 +96,8 @@ PROTOTYPES = {
     "urhgpu_test_fast_division_dev": (_i, [_vp, C.c_uint64, _i, C.POINTER(C.c_uint64)]),
     "urhgpu_modulate_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_uint32, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _i64, C.POINTER(_i64)]),
     "urhgpu_modulate": (_i, [_vp, _vp, _i64, C.c_uint32, _i, _vp, _i, _f, _f, _f, _f, C.c_uint32, C.c_uint32, _i, _vp]),
+    "urhgpu_modulate_gfsk_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_uint32, _vp, _i, _f, _f, _f, _i, _vp, _i, _vp, _vp, _i64, C.POINTER(_i64)]),
+    "urhgpu_modulate_gfsk": (_i, [_vp, _vp, _i64, C.c_uint32, _vp, _i, _f, _f, _f, C.c_uint32, C.c_uint32, _i, _vp, _i, _vp, _vp]),
     "urhgpu_spectrogram_dev": (_i, [_vp, _vp, _i64, _i, _i64, _i64, _vp, _vp, _vp, _vp]),
     "urhgpu_bgra_lookup_dev": (_i, [_vp, _vp, _i64, _i, _vp, _i, _f, _f, _vp]),
     "urhgpu_convert_dev": (_i, [_vp, _vp, _i, _vp, _i, _i64]),

@@ -845,13 +845,18 @@ int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint
 
 static int stage_in(urhgpu_ctx *ctx, const void *host, size_t bytes, void **dev);
 
-int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit_off, const uint32_t *pause, const uint32_t *start,
-                        int n_msgs, uint32_t samples_per_symbol, int mod, const float *parameters, int bits_per_symbol,
-                        float carrier_amplitude, float carrier_frequency, float carrier_phase, float sample_rate, int dtype,
-                        void *d_out, int64_t cap_samples, int64_t *total_samples) {
+// mod: URHGPU_MOD_ASK / _FSK / _PSK / _OQPSK, or urh::kModGfsk with the Gaussian taps (and optionally the caller's filtered
+// frequencies, one float per data sample of every message, back to back)
+static int modulate_common(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit_off, const uint32_t *pause, const uint32_t *start,
+                           int n_msgs, uint32_t samples_per_symbol, int mod, const float *parameters, int bits_per_symbol,
+                           float carrier_amplitude, float carrier_frequency, float carrier_phase, float sample_rate, int dtype,
+                           const float *gauss_fir, int n_taps, const float *frequencies,
+                           void *d_out, int64_t cap_samples, int64_t *total_samples) {
+    const bool gfsk = (mod == urh::kModGfsk);
+    if (gfsk && (!gauss_fir || n_taps < 1)) return URHGPU_ERR_ARG;
     if (!ctx || n_msgs < 0 || !total_samples || (n_msgs > 0 && (!bit_off || !pause || !start || !parameters))) return URHGPU_ERR_ARG;
     const bool oqpsk = (mod == URHGPU_MOD_OQPSK);
-    if (mod != URHGPU_MOD_ASK && mod != URHGPU_MOD_FSK && mod != URHGPU_MOD_PSK && !oqpsk) return URHGPU_ERR_UNSUPPORTED;
+    if (mod != URHGPU_MOD_ASK && mod != URHGPU_MOD_FSK && mod != URHGPU_MOD_PSK && !oqpsk && !gfsk) return URHGPU_ERR_UNSUPPORTED;
     if (oqpsk && bits_per_symbol != 2) return URHGPU_ERR_ARG;                    // assert bits_per_symbol == 2 (:120)
     if (dtype != URHGPU_DT_F32 && dtype != URHGPU_DT_I8 && dtype != URHGPU_DT_I16) return URHGPU_ERR_DTYPE;
     if (bits_per_symbol < 1 || bits_per_symbol > 16 || samples_per_symbol == 0 || n_msgs > 65535) return URHGPU_ERR_UNSUPPORTED;
@@ -860,6 +865,10 @@ int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit
     for (int m = 0; m < n_msgs; ++m) {
         const int64_t nb = bit_off[m + 1] - bit_off[m];
         if (nb < 0) return URHGPU_ERR_ARG;
+        // GFSK re-derives bits_per_symbol as len(bits) // num_symbols (:201): no whole symbol -> ZeroDivisionError there;
+        // a message shorter than bits_per_symbol symbols can derive a larger value: not supported
+        if (gfsk && nb > 0 && (nb / bits_per_symbol == 0 || nb / (nb / bits_per_symbol) != bits_per_symbol))
+            return nb / bits_per_symbol == 0 ? URHGPU_ERR_ARG : URHGPU_ERR_UNSUPPORTED;
         ModMsg &g = msgs[(size_t)m];
         g.bit_off = bit_off[m]; g.n_sym = nb / bits_per_symbol; g.sym_off = total_sym; g.out_off = total;
         g.pause = pause[m]; g.start = start[m];
@@ -876,7 +885,8 @@ int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit
     const int64_t n_bits = bit_off[n_msgs];
     const size_t n_par = (size_t)1 << bits_per_symbol;
     URH_TRY(ctx->staging.reserve(align256((size_t)std::max<int64_t>(n_bits, 1)) + align256(msgs.size() * sizeof(ModMsg)) +
-                                 align256(n_par * 4) + align256((size_t)std::max<int64_t>(total_sym, 1) * 4) + 2048));
+                                 align256(n_par * 4) + align256((size_t)std::max<int64_t>(total_sym, 1) * 4) + 2048 +
+                                 (gfsk ? align256((size_t)n_taps * 4) + 2 * align256((size_t)std::max<int64_t>(total_sym, 1) * samples_per_symbol * 4) : 0)));
     ctx->staging.reset();
     void *d_bits = nullptr, *d_msgs = nullptr, *d_par = nullptr;
     std::vector<uint8_t> oq;
@@ -904,14 +914,49 @@ int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit
     a.out = d_out; a.n_msgs = n_msgs; a.mod = oqpsk ? URHGPU_MOD_PSK : mod; a.oqpsk = oqpsk ? 1 : 0; a.dtype = dtype; a.bps = bits_per_symbol; a.sps = samples_per_symbol;
     a.carrier_amplitude = carrier_amplitude; a.carrier_frequency = carrier_frequency; a.carrier_phase = carrier_phase;
     a.sample_rate = sample_rate;
+    a.taps = nullptr; a.n_taps = 0; a.freq_given = 0; a.gf_freq = a.gf_phase = nullptr;
+    if (gfsk) {
+        const size_t n_data = (size_t)total_sym * samples_per_symbol;
+        void *d_taps = nullptr;
+        URH_TRY(stage_in(ctx, gauss_fir, (size_t)n_taps * 4, &d_taps));
+        a.taps = (const float *)d_taps; a.n_taps = n_taps;
+        if (frequencies && n_data) {
+            void *d_f = nullptr;
+            URH_TRY(stage_in(ctx, frequencies, n_data * 4, &d_f));
+            a.gf_freq = (float *)d_f; a.freq_given = 1;
+        } else {
+            a.gf_freq = (float *)ctx->staging.take(std::max<size_t>(n_data, 1) * 4);
+        }
+        a.gf_phase = (float *)ctx->staging.take(std::max<size_t>(n_data, 1) * 4);
+        if (!a.gf_freq || !a.gf_phase) return URHGPU_ERR_ARG;
+    }
     URH_TRY(launch_modulate(a, max_samples, ctx->stream));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }
 
-int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint32_t samples_per_symbol, int mod,
-                    const float *parameters, int bits_per_symbol, float carrier_amplitude, float carrier_frequency,
-                    float carrier_phase, float sample_rate, uint32_t pause, uint32_t start, int dtype, void *out) {
+int urhgpu_modulate_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit_off, const uint32_t *pause, const uint32_t *start,
+                        int n_msgs, uint32_t samples_per_symbol, int mod, const float *parameters, int bits_per_symbol,
+                        float carrier_amplitude, float carrier_frequency, float carrier_phase, float sample_rate, int dtype,
+                        void *d_out, int64_t cap_samples, int64_t *total_samples) {
+    if (mod == urh::kModGfsk) return URHGPU_ERR_UNSUPPORTED;
+    return modulate_common(ctx, bits, bit_off, pause, start, n_msgs, samples_per_symbol, mod, parameters, bits_per_symbol, carrier_amplitude,
+                           carrier_frequency, carrier_phase, sample_rate, dtype, nullptr, 0, nullptr, d_out, cap_samples, total_samples);
+}
+
+int urhgpu_modulate_gfsk_dev(urhgpu_ctx *ctx, const uint8_t *bits, const int64_t *bit_off, const uint32_t *pause, const uint32_t *start,
+                             int n_msgs, uint32_t samples_per_symbol, const float *parameters, int bits_per_symbol,
+                             float carrier_amplitude, float carrier_phase, float sample_rate, int dtype, const float *gauss_fir,
+                             int n_taps, const float *frequencies, void *d_out, int64_t cap_samples, int64_t *total_samples) {
+    return modulate_common(ctx, bits, bit_off, pause, start, n_msgs, samples_per_symbol, urh::kModGfsk, parameters, bits_per_symbol,
+                           carrier_amplitude, 0.0f, carrier_phase, sample_rate, dtype, gauss_fir, n_taps, frequencies, d_out, cap_samples,
+                           total_samples);
+}
+
+static int modulate_one(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint32_t samples_per_symbol, int mod,
+                        const float *parameters, int bits_per_symbol, float carrier_amplitude, float carrier_frequency,
+                        float carrier_phase, float sample_rate, uint32_t pause, uint32_t start, int dtype, const float *gauss_fir,
+                        int n_taps, const float *frequencies, void *out) {
     if (!ctx || num_bits < 0 || bits_per_symbol < 1) return URHGPU_ERR_ARG;
     if (dtype != URHGPU_DT_F32 && dtype != URHGPU_DT_I8 && dtype != URHGPU_DT_I16) return URHGPU_ERR_DTYPE;
     const int64_t total = (num_bits / bits_per_symbol) * (int64_t)samples_per_symbol + pause;
@@ -924,8 +969,9 @@ int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint
     URH_HIP(hipMalloc(&d_out, bytes));
     const int64_t off[2] = {0, num_bits};
     int64_t got = 0;
-    int st = urhgpu_modulate_dev(ctx, bits, off, &pause, &start, 1, samples_per_symbol, mod, parameters, bits_per_symbol,
-                                 carrier_amplitude, carrier_frequency, carrier_phase, sample_rate, dtype, d_out, total, &got);
+    int st = modulate_common(ctx, bits, off, &pause, &start, 1, samples_per_symbol, mod, parameters, bits_per_symbol,
+                             carrier_amplitude, carrier_frequency, carrier_phase, sample_rate, dtype, gauss_fir, n_taps, frequencies,
+                             d_out, total, &got);
     if (st == URHGPU_OK) {
         hipError_t e = hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -933,6 +979,21 @@ int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint
     }
     (void)hipFree(d_out);
     return st;
+}
+
+int urhgpu_modulate(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint32_t samples_per_symbol, int mod,
+                    const float *parameters, int bits_per_symbol, float carrier_amplitude, float carrier_frequency,
+                    float carrier_phase, float sample_rate, uint32_t pause, uint32_t start, int dtype, void *out) {
+    if (mod == urh::kModGfsk) return URHGPU_ERR_UNSUPPORTED;
+    return modulate_one(ctx, bits, num_bits, samples_per_symbol, mod, parameters, bits_per_symbol, carrier_amplitude, carrier_frequency,
+                        carrier_phase, sample_rate, pause, start, dtype, nullptr, 0, nullptr, out);
+}
+
+int urhgpu_modulate_gfsk(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits, uint32_t samples_per_symbol, const float *parameters,
+                         int bits_per_symbol, float carrier_amplitude, float carrier_phase, float sample_rate, uint32_t pause,
+                         uint32_t start, int dtype, const float *gauss_fir, int n_taps, const float *frequencies, void *out) {
+    return modulate_one(ctx, bits, num_bits, samples_per_symbol, urh::kModGfsk, parameters, bits_per_symbol, carrier_amplitude, 0.0f,
+                        carrier_phase, sample_rate, pause, start, dtype, gauss_fir, n_taps, frequencies, out);
 }
 
 int urhgpu_spectrogram_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, int window_size, int64_t hop, int64_t frames,

@@ -50,6 +50,7 @@ struct ModMsg {              // one message of a modulate batch
     uint32_t pause;          // silent samples after the symbols
     uint32_t start;          // sample index of the message's first sample (time origin of the carrier)
 };
+constexpr int kModGfsk = 5;  // internal to launch_modulate (public entry: urhgpu_modulate_gfsk*)
 struct ModArgs {
     const uint8_t *bits;     // device: all messages' bits back to back
     const ModMsg *msgs;      // device
@@ -58,6 +59,11 @@ struct ModArgs {
     void *out;               // device: (total samples, 2) of dtype
     int n_msgs, mod, dtype, bps;
     int oqpsk;               // mod == PSK on re-ordered bits, first symbol's Q and last symbol's I blanked
+    // GFSK (mod == kModGfsk): Gaussian-filtered frequency and phase per data sample (entry sym_off * sps + i of message m)
+    const float *taps;       // device: gauss_fir, n_taps floats
+    int n_taps;
+    int freq_given;          // gf_freq already holds the filtered frequencies (caller's convolution)
+    float *gf_freq, *gf_phase;
     uint32_t sps;
     float carrier_amplitude, carrier_frequency, carrier_phase, sample_rate;
 };

@@ -1,5 +1,5 @@
 // modulate.hip -- signal_functions.modulate_c on the GPU (the generator on the other side of the IQ->bits path)
-//   /root/reference/src/urh/cythonext/signal_functions.pyx:56-177   (ASK, FSK, PSK, OQPSK)
+//   /root/reference/src/urh/cythonext/signal_functions.pyx:56-177   (ASK, FSK, PSK, OQPSK), :196-228 (GFSK)
 //
 // Batched: URH modulates message by message (Modulator.modulate, ProtocolAnalyzerContainer.modulate), every message
 // with its own bits / pause / start sample; one launch renders any number of messages back to back.
@@ -11,6 +11,12 @@
 //                 float, glibc's sinf / cosf (glibc_sincosf.h: the argument reaches 10^5 rad, so the large-argument
 //                 reduction is on the path), amplitude, C cast to the sample type.  Pauses and zero-amplitude ASK
 //                 symbols are written as zeros (the reference starts from np.zeros).
+//   k_gfsk_freq   GFSK: the per-sample symbol frequencies convolved with the Gaussian taps ("same" mode), every output an
+//                 exactly accumulated (fp64) dot product rounded once to float32.  The reference gets this value from
+//                 numpy's float32 BLAS dot, whose summation order is a property of the host CPU: callers who need the
+//                 reference's bits on their host pass numpy's convolution in (freq_given) and this kernel is skipped;
+//   k_gfsk_phase  GFSK: phases[i+1] = (float)(2 pi t[i] (f[i] - f[i+1]) + phases[i]) -- a float rounding in every step, one
+//                 wavefront per message walks its samples (t = numpy's float32 arange, restated);
 // Roofline: the sample kernel writes 8 B (complex64) per sample against ~100 fp64 operations: HBM write bandwidth and
 // the fp64 vector rate are about level; the phase kernel is latency (one dependent fmod per symbol per message).
 #include <hip/hip_runtime.h>
@@ -51,6 +57,67 @@ __global__ void k_mod_phase(const ModArgs a) {
     }
 }
 
+// GFSK, :196-217: one thread per data sample, grid.y = message
+__global__ __launch_bounds__(256) void k_gfsk_freq(const ModArgs a) {
+    const ModMsg g = a.msgs[blockIdx.y];
+    const uint8_t *bits = a.bits + g.bit_off;
+    const int64_t n = g.n_sym * (int64_t)a.sps, m = a.n_taps;
+    float *f = a.gf_freq + g.sym_off * (int64_t)a.sps;
+    const int64_t off = (n >= m) ? (m - 1) / 2 : (n - 1) / 2;                  // "same": centred on the longer operand
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = i + off;
+        const int64_t lo = k - m + 1 > 0 ? k - m + 1 : 0, hi = k < n - 1 ? k : n - 1;
+        int64_t sym = lo / a.sps;
+        uint32_t left = (uint32_t)((sym + 1) * (int64_t)a.sps - lo);           // samples of this symbol from lo on
+        float val = a.params[mod_symbol_index(bits, sym, a.bps)];
+        double acc = 0.0;
+        for (int64_t j = lo; j <= hi; ++j) {
+            acc += (double)val * (double)a.taps[k - j];
+            if (--left == 0 && j < hi) { ++sym; left = a.sps; val = a.params[mod_symbol_index(bits, sym, a.bps)]; }
+        }
+        f[i] = (float)acc;
+    }
+}
+
+// GFSK, :219-226: one wavefront per message.  Step i (phases[i] -> phases[i+1]) needs d_i = (2 pi t[i]) * (f[i] - f[i+1]) -- 64
+// lanes evaluate 64 of them at once (division, products, coalesced loads) -- and then the one thing that is serial: the
+// float rounding of the running sum, done uniformly in all lanes with d_i read from lane i (add, two conversions per step).
+__device__ __forceinline__ double gfsk_readlane(double v, int k) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+__global__ __launch_bounds__(64) void k_gfsk_phase(const ModArgs a) {
+    const ModMsg g = a.msgs[blockIdx.x];
+    const int lane = threadIdx.x;
+    const int64_t n = g.n_sym * (int64_t)a.sps;
+    if (n <= 0) return;
+    const float *__restrict__ f = a.gf_freq + g.sym_off * (int64_t)a.sps;
+    float *__restrict__ ph = a.gf_phase + g.sym_off * (int64_t)a.sps;
+    const double two_pi = 2.0 * 3.14159265358979323846;
+    // np.arange(start, start + n, dtype=float32): buf[0] = start, buf[1] = start + 1, buf[i] = buf[0] + i * (buf[1] - buf[0])
+    const float s0 = (float)(double)g.start, s1 = (float)((double)g.start + 1.0), delta = s1 - s0;
+    float cur = a.carrier_phase;
+    if (lane == 0) ph[0] = cur;
+    for (int64_t base = 0; base + 1 < n; base += 64) {
+        const int64_t i = base + lane;
+        double d = 0.0;
+        if (i + 1 < n) {
+            const float prod = (float)i * delta;
+            const float ti = (i == 0) ? s0 : ((i == 1) ? s1 : s0 + prod);
+            const float t = ti / a.sample_rate;
+            const float df = f[i] - f[i + 1];
+            d = (two_pi * (double)t) * (double)df;
+        }
+        float mine = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 64; ++k) {
+            cur = (float)(gfsk_readlane(d, k) + (double)cur);
+            if (lane == k) mine = cur;
+        }
+        if (i + 1 < n) ph[i + 1] = mine;
+    }
+}
+
 template <typename T> __device__ __forceinline__ T mod_cast(float v);
 template <> __device__ __forceinline__ float mod_cast<float>(float v) { return v; }
 // (char)float / (short)float as x86-64 evaluates them: truncating conversion to int32, low bits kept
@@ -81,6 +148,7 @@ __global__ __launch_bounds__(256) void k_modulate(const ModArgs a) {
             float amp = a.carrier_amplitude, f = a.carrier_frequency, phi = a.carrier_phase, corr = 0.0f;
             if (MOD == URHGPU_MOD_ASK) amp = a.params[index];
             else if (MOD == URHGPU_MOD_FSK) { f = a.params[index]; corr = a.phase[g.sym_off + s]; }
+            else if (MOD == kModGfsk) { f = a.gf_freq[g.sym_off * (int64_t)a.sps + i]; phi = a.gf_phase[g.sym_off * (int64_t)a.sps + i]; }
             else phi = a.params[index];
             if (!(MOD == URHGPU_MOD_ASK && amp == 0.0f)) {
                 const float t = ((float)(i + (int64_t)g.start)) / a.sample_rate;
@@ -108,6 +176,7 @@ static int launch_mod_t(const ModArgs &a, int64_t max_samples, hipStream_t s) {
         case URHGPU_MOD_ASK: hipLaunchKernelGGL((k_modulate<T, URHGPU_MOD_ASK>), grid, block, 0, s, a); return URHGPU_OK;
         case URHGPU_MOD_FSK: hipLaunchKernelGGL((k_modulate<T, URHGPU_MOD_FSK>), grid, block, 0, s, a); return URHGPU_OK;
         case URHGPU_MOD_PSK: hipLaunchKernelGGL((k_modulate<T, URHGPU_MOD_PSK>), grid, block, 0, s, a); return URHGPU_OK;
+        case kModGfsk: hipLaunchKernelGGL((k_modulate<T, kModGfsk>), grid, block, 0, s, a); return URHGPU_OK;
         default: return URHGPU_ERR_UNSUPPORTED;
     }
 }
@@ -116,6 +185,14 @@ int launch_modulate(const ModArgs &a, int64_t max_samples, hipStream_t s) {
     if (a.n_msgs <= 0) return URHGPU_OK;
     if (a.n_msgs > 65535) return URHGPU_ERR_ARG;
     if (a.mod == URHGPU_MOD_FSK) hipLaunchKernelGGL(k_mod_phase, dim3((unsigned)((a.n_msgs + 63) / 64)), dim3(64), 0, s, a);
+    if (a.mod == kModGfsk) {
+        if (!a.freq_given) {
+            int64_t gx = (max_samples + 255) / 256;
+            gx = gx > 16384 ? 16384 : (gx < 1 ? 1 : gx);
+            hipLaunchKernelGGL(k_gfsk_freq, dim3((unsigned)gx, (unsigned)a.n_msgs), dim3(256), 0, s, a);
+        }
+        hipLaunchKernelGGL(k_gfsk_phase, dim3((unsigned)a.n_msgs), dim3(64), 0, s, a);
+    }
     switch (a.dtype) {
         case URHGPU_DT_F32: return launch_mod_t<float>(a, max_samples, s);
         case URHGPU_DT_I8: return launch_mod_t<int8_t>(a, max_samples, s);

@@ -196,30 +196,90 @@ def _modulation_code(modulation_type: str) -> int:
     if m == "oqpsk":
         return 4                                     # URHGPU_MOD_OQPSK
     if m == "gfsk":
-        raise NotImplementedError("GFSK: numpy's float32 convolution (BLAS sdot, host dependent) is not reproduced on the GPU")
+        return 5                                     # urhgpu_modulate_gfsk*
     raise AssertionError(modulation_type)            # `assert is_fsk or is_ask or ...` (:117)
+
+
+def gauss_fir(sample_rate: float, samples_per_symbol: int, bt: float = 0.5, filter_width: float = 1.0) -> np.ndarray:
+    """signal_functions.gauss_fir (signal_functions.pyx:230-243): the Gaussian taps, evaluated with numpy on the host as
+    the reference does (its arguments are C floats there: Python floats holding float32 values)."""
+    bt, filter_width, sample_rate = float(np.float32(bt)), float(np.float32(filter_width)), float(np.float32(sample_rate))
+    half = int(filter_width * samples_per_symbol)
+    k = np.arange(-half, half + 1, dtype=np.float32)
+    ts = float(np.float32(samples_per_symbol / sample_rate))                               # symbol time (cdef float)
+    h = (np.sqrt((2 * np.pi) / (np.log(2))) * bt / ts * np.exp(
+        -(((np.sqrt(2) * np.pi) / np.sqrt(np.log(2)) * bt * k / samples_per_symbol) ** 2))).astype(np.float32)
+    return h / h.sum()
+
+
+def gfsk_frequencies_numpy(bits, parameters, samples_per_symbol: int, bits_per_symbol: int, gfir) -> np.ndarray:
+    """The Gaussian-filtered per-sample frequencies as the reference computes them ON THIS HOST: numpy's float32
+    convolution (signal_functions.pyx:203-217).  Pass the result as `gfsk_frequencies` to modulate_c to get the reference's
+    bits (numpy's BLAS dot product decides the last bit of every frequency, and the phase recurrence amplifies it)."""
+    b = _bits_u8(bits)
+    n_sym = len(b) // int(bits_per_symbol)
+    par = np.ascontiguousarray(parameters, dtype=np.float32)
+    sym = b[:n_sym * bits_per_symbol].reshape(n_sym, bits_per_symbol).astype(np.int64)
+    index = (sym << np.arange(bits_per_symbol - 1, -1, -1)).sum(axis=1)
+    raw = np.repeat(par[index], int(samples_per_symbol)).astype(np.float32)
+    gfir = np.ascontiguousarray(gfir, dtype=np.float32)
+    if len(raw) >= len(gfir):
+        return np.convolve(raw, gfir, mode="same")
+    return np.convolve(gfir, raw, mode="same")[:len(raw)]
+
+
+def _modulate_gfsk(b, samples_per_symbol, par, bits_per_symbol, carrier_amplitude, carrier_phase, sample_rate, pause, start, dt,
+                   gauss_bt, filter_width, gfsk_frequencies, out, ctx):
+    if len(b) // int(bits_per_symbol) == 0:
+        raise ZeroDivisionError("integer division or modulo by zero")                     # len(bits) // num_symbols (:201)
+    gfir = np.ascontiguousarray(gauss_fir(sample_rate, samples_per_symbol, gauss_bt, filter_width), dtype=np.float32)
+    freqs = None
+    if isinstance(gfsk_frequencies, str):
+        if gfsk_frequencies != "numpy":
+            raise ValueError("gfsk_frequencies: None (device convolution), 'numpy' or an array")
+        freqs = gfsk_frequencies_numpy(b, par, samples_per_symbol, bits_per_symbol, gfir)
+    elif gfsk_frequencies is not None:
+        freqs = gfsk_frequencies
+    if freqs is not None:
+        freqs = np.ascontiguousarray(freqs, dtype=np.float32)
+        if len(freqs) != (len(b) // int(bits_per_symbol)) * int(samples_per_symbol):
+            raise ValueError("gfsk_frequencies: one value per data sample expected")
+    _lib.check(_lib.load().urhgpu_modulate_gfsk(ctx.handle, _vp(b), len(b), int(samples_per_symbol), _vp(par), int(bits_per_symbol),
+                                                float(carrier_amplitude), float(carrier_phase), float(sample_rate), int(pause),
+                                                int(start), _MOD_DTYPES[dt], _vp(gfir), len(gfir),
+                                                _vp(freqs) if freqs is not None else None, _vp(out)))
+    return out
 
 
 def modulate_c(bits, samples_per_symbol: int, modulation_type: str, parameters, bits_per_symbol: int,
                carrier_amplitude: float, carrier_frequency: float, carrier_phase: float, sample_rate: float,
                pause: int, start: int, dtype=np.float32, gauss_bt: float = 0.5, filter_width: float = 1.0,
-               ctx=None) -> np.ndarray:
+               ctx=None, gfsk_frequencies=None) -> np.ndarray:
     """signal_functions.modulate_c (signal_functions.pyx:56-177): bits -> (N, 2) IQ samples of `dtype`
-    (np.float32 / np.int8 / np.int16), N = len(bits) // bits_per_symbol * samples_per_symbol + pause."""
+    (np.float32 / np.int8 / np.int16), N = len(bits) // bits_per_symbol * samples_per_symbol + pause.
+    GFSK: gfsk_frequencies=None convolves on the GPU (exactly accumulated dot products), "numpy" takes the Gaussian-filtered
+    frequencies from numpy's convolution on the host like the reference (see gfsk_frequencies_numpy)."""
     dt = np.dtype(dtype)
     if dt not in _MOD_DTYPES:
         raise ValueError("Unsupported dtype for modulation {}".format(dtype))
     b = _bits_u8(bits)
     total = (len(b) // int(bits_per_symbol)) * int(samples_per_symbol) + int(pause)
     out = np.zeros((total, 2), dtype=dt)
-    if len(b) == 0 or total == 0:
-        return out
+    if len(b) == 0:
+        return out                                   # :104-106
     mod = _modulation_code(modulation_type)
+    if mod == 5 and len(b) // int(bits_per_symbol) == 0:
+        raise ZeroDivisionError("integer division or modulo by zero")                     # len(bits) // num_symbols (:201)
+    if total == 0:
+        return out
     assert mod != 4 or int(bits_per_symbol) == 2     # :120
     par = np.ascontiguousarray(parameters, dtype=np.float32)
     if len(par) < (1 << int(bits_per_symbol)):
         raise IndexError("parameters shorter than 2**bits_per_symbol")
     ctx = ctx or _lib.default_context()
+    if mod == 5:
+        return _modulate_gfsk(b, samples_per_symbol, par, bits_per_symbol, carrier_amplitude, carrier_phase, sample_rate, pause,
+                              start, dt, gauss_bt, filter_width, gfsk_frequencies, out, ctx)
     _lib.check(_lib.load().urhgpu_modulate(ctx.handle, _vp(b), len(b), int(samples_per_symbol), mod, _vp(par),
                                            int(bits_per_symbol), float(carrier_amplitude), float(carrier_frequency),
                                            float(carrier_phase), float(sample_rate), int(pause), int(start),
@@ -229,7 +289,8 @@ def modulate_c(bits, samples_per_symbol: int, modulation_type: str, parameters, 
 
 def modulate_messages_dev(messages, samples_per_symbol: int, modulation_type: str, parameters, bits_per_symbol: int,
                           carrier_amplitude: float, carrier_frequency: float, carrier_phase: float, sample_rate: float,
-                          pauses, starts=None, dtype=np.float32, device=None, ctx=None):
+                          pauses, starts=None, dtype=np.float32, device=None, ctx=None, gauss_bt: float = 0.5,
+                          filter_width: float = 1.0):
     """Many messages rendered back to back by one launch, result left in HBM: a torch tensor (N, 2) of `dtype`.
     messages: sequence of bit sequences; pauses[m] silent samples follow message m; starts[m] is the sample index of
     its first sample (default: consecutive, as ProtocolAnalyzerContainer.modulate places them)."""
@@ -258,6 +319,15 @@ def modulate_messages_dev(messages, samples_per_symbol: int, modulation_type: st
     out = torch.empty((total, 2), dtype=tdt, device=device if device is not None else torch.device("cuda", ctx.device))
     ctx.set_stream(torch.cuda.current_stream(out.device).cuda_stream)
     got = C.c_int64(0)
+    if mod == 5:
+        gfir = np.ascontiguousarray(gauss_fir(sample_rate, samples_per_symbol, gauss_bt, filter_width), dtype=np.float32)
+        _lib.check(_lib.load().urhgpu_modulate_gfsk_dev(ctx.handle, _vp(allbits), _vp(off), _vp(pa), _vp(st), len(bl),
+                                                        int(samples_per_symbol), _vp(par), int(bits_per_symbol),
+                                                        float(carrier_amplitude), float(carrier_phase), float(sample_rate),
+                                                        _MOD_DTYPES[dt], _vp(gfir), len(gfir), None, C.c_void_p(out.data_ptr()),
+                                                        total, C.byref(got)))
+        assert got.value == total
+        return out
     _lib.check(_lib.load().urhgpu_modulate_dev(ctx.handle, _vp(allbits), _vp(off), _vp(pa), _vp(st), len(bl),
                                                int(samples_per_symbol), mod, _vp(par), int(bits_per_symbol),
                                                float(carrier_amplitude), float(carrier_frequency), float(carrier_phase),
