@@ -56,6 +56,9 @@ enum { SRC_IQ = 0, SRC_QAD = 1 };
 #ifndef URH_WPB
 #define URH_WPB 4          // k_demod_runs_bp: wavefronts per chunk (1, 2, 4 or 8)
 #endif
+#ifndef URH_ASK_WPB
+#define URH_ASK_WPB 8      // ... when it demodulates ASK (magnitudes: little per-wavefront start-up work, measured faster with 8)
+#endif
 #ifndef URH_NT
 #define URH_NT 1          // non-temporal IQ loads / qad stores (streamed once): +8 % on the copy ceiling, tools/kbench
 #endif
@@ -848,13 +851,15 @@ __device__ __forceinline__ uint32_t put_lane(uint32_t value, int row, uint32_t o
 // RUNS = false: demodulation only (urhgpu_afp_demod[_dev], Signal.qad): the same streaming structure without the planes
 // NPL: bit planes of the state besides PAUSE: 1 for modulation order 2 (plane = "q <= threshold": state 1, else 2), 2 for
 // order 4 (planes = the two bits of state - 1, from the three threshold masks).
+template <int SRC, int MOD> constexpr int bp_waves() { return (SRC == SRC_IQ && MOD == URHGPU_MOD_ASK) ? URH_ASK_WPB : URH_WPB; }
+
 template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1>
-__global__ __launch_bounds__(kBlock * URH_WPB) void k_demod_runs_bp(const RunArgs p) {
+__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) void k_demod_runs_bp(const RunArgs p) {
     // One workgroup per chunk, URH_WPB wavefronts: wavefront w streams the w-th share of the chunk's rows on its own
     // (no barrier inside the streaming phase), so that the wavefronts resident on the chip cover a NARROW window of
     // the capture (DRAM page locality: a wavefront per 16 KiB measured 8 % faster than a wavefront per 64 KiB on a
     // pure copy of this shape) while the per-chunk work (prologue, run phase, ChunkInfo) is paid once per 64 rows.
-    constexpr int W = URH_WPB;
+    constexpr int W = bp_waves<SRC, MOD>();
     __shared__ uint32_t s_planes[W > 1 ? (NPL + 1) * 4 : 1][W > 1 ? 64 : 1];
     const int lane = threadIdx.x & 63;
     const int w = (W > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;     // wavefront-uniform
@@ -1178,9 +1183,9 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
         // orders 2 and 4: the bit-plane kernel; anything else: the state-byte kernel
         const bool planes_ok = URH_BITPLANE && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes;
         if (planes_ok && O2)
-            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * URH_WPB), (size_t)a.lds_pad, s, a);
+            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
         else if (planes_ok && a.order == 4)
-            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 2>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * URH_WPB), (size_t)a.lds_pad, s, a);
+            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 2>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
         else
             hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock), 0, s, a);
     }
@@ -1239,7 +1244,7 @@ static void launch_afp_3(const RunArgs &a0, int grid, hipStream_t s) {
     const int64_t n_main = (a.n / chunk) * chunk;
     if (n_main > 0) {
         a.chunk_len = chunk; a.range_begin = 0; a.range_end = n_main; a.chunk_base = 0;
-        hipLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, DT, MOD, true, false>), dim3((unsigned)(n_main / chunk)), dim3(kBlock * URH_WPB), 0, s, a);
+        hipLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, DT, MOD, true, false>), dim3((unsigned)(n_main / chunk)), dim3(kBlock * bp_waves<SRC_IQ, MOD>()), 0, s, a);
     }
     if (n_main < a.n) {
         RunArgs t = a0;
