@@ -420,6 +420,29 @@ def test_iir_equals_oracle(sf, oracle):
         assert cbits_equal(sf.iir_filter(a, b, x), oracle.iir_filter(a, b, x)), (na, nb)
 
 
+@pytest.mark.parametrize("bps", [1, 2])
+def test_many_huge_rows_expand(pipe, oracle, bps):
+    """300 constant stretches of 4 500-9 000 symbols each (rows of more than 4096 bits go to k_expand_huge's work list, more
+    rows than its grid has row slots), one sample per symbol, short breaks in between: bits and bit_sample_pos vs the oracle."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    rng = np.random.default_rng(90 + bps)
+    amp = np.concatenate([np.concatenate([np.full(int(rng.integers(4500, 9000)), 0.8 if bps == 1 else float(rng.choice([0.55, 0.8]))),
+                                          np.full(int(rng.integers(1, 4)), 0.05)]) for _ in range(300)])
+    n = len(amp)
+    ph = 0.01 * np.arange(n)
+    iq = (np.stack([amp * np.cos(ph), amp * np.sin(ph)], 1) + 0.002 * rng.standard_normal((n, 2))).astype(np.float32)
+    center, spacing = (0.25, 1.0) if bps == 1 else (0.3, 0.17)          # ASK magnitudes are scaled by 1 / sqrt(2)
+    p = DemodParams("ASK", bps, 0.0, center, spacing, 0, 1, 0.1, 8, True)
+    qad = oracle.afp_demod(iq, 0.0, "ASK", 1 << bps)
+    pp = oracle.grab_pulse_lens(qad, center, 0, "ASK", 1, bps, spacing)
+    assert (pp[:, 1] > 4096).sum() >= 290
+    fb = oracle.ppseq_to_bits_flat(pp, 1, bps, True, 8)
+    res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True, cap_rows=n + 2)
+    assert np.array_equal(res.ppseq(), pp)
+    assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
+
+
 def test_filters_equal_reference_goldens(sf):
     """The real reference's fir_filter / iir_filter outputs (tests/golden/filter/fir_iir.npz) through the C ABI."""
     import os

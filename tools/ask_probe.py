@@ -28,3 +28,10 @@ print("afp_demod ASK        %.4f ms" % timed(lambda: pipe.afp_demod(iq, pa)))
 print("segment_messages     %.4f ms" % timed(lambda: estimators.segment_messages_dev(pipe, iq, 0.3), 5))
 pf = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100)
 print("iq_to_bits FSK       %.4f ms" % timed(lambda: pipe.iq_to_bits(iq, pf, want_qad=True)))
+# modulation order 4 on the same capture (three thresholds): bit-plane kernel vs the state-byte kernel
+from urh_amd import _lib
+p4 = DemodParams("FSK", 2, 0.0, 0.0, 0.4, 5, 100)
+for force in (0, 1):
+    _lib.load().urhgpu_test_force_state_bytes(force)
+    print("iq_to_bits FSK order 4, %s  %.4f ms" % ("state bytes" if force else "bit planes ", timed(lambda: pipe.iq_to_bits(iq, p4, want_qad=True))))
+_lib.load().urhgpu_test_force_state_bytes(0)

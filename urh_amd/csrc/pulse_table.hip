@@ -549,8 +549,8 @@ struct ExpandArgs {
 __global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
     const int64_t n = *a.d_n_rows;
     const int lane = threadIdx.x & 63;
-    const int64_t wave_base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane;
-    if (wave_base >= n) return;
+    // the grid is sized for a typical row count, not for the table's capacity (empty workgroups are not free): stride loop
+    for (int64_t wave_base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) - lane; wave_base < n; wave_base += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = wave_base + lane;
     int64_t kb = 0, ob = 0, op = 0, ts = 0, type = 0;
     if (i < n) {
@@ -596,18 +596,24 @@ __global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
             if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
         }
     }
+    }
 }
 
-// rows of more than kHugeBits bits, spread over the whole grid
+// rows of more than kHugeBits bits: blockIdx.y strides over the work list, the blocks along x share one row -- a capture
+// that is one long constant stretch per message (an unmodulated carrier: one row per message, thousands of bits each) keeps
+// every row's blocks busy at once instead of walking the list row by row
+constexpr unsigned kHugeGridX = 64, kHugeGridY = 64;
+constexpr int64_t kExpandMaxBlocks = 4096;     // k_expand_bits: 2^20 rows per sweep
 __global__ __launch_bounds__(256) void k_expand_huge(const ExpandArgs a) {
     int cnt = *a.huge_count;
     if (cnt > a.huge_cap) cnt = a.huge_cap;
     const int bps = (int)a.bp.bps;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int w = 0; w < cnt; ++w) {
+    for (int w = blockIdx.y; w < cnt; w += gridDim.y) {
         const HugeRow r = a.huge[w];
         for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < r.kb; k += stride) {
-            const uint8_t b = (r.type < 0) ? 0 : (uint8_t)((r.type >> (bps - 1 - (int)(k % bps))) & 1);
+            const int sh = (bps == 1) ? 0 : bps - 1 - (int)(k % bps);
+            const uint8_t b = (r.type < 0) ? 0 : (uint8_t)((r.type >> sh) & 1);
             if (r.ob + k < a.cap_bits) a.bits[r.ob + k] = b;
             if (a.bp.write_pos && r.op + k < a.cap_pos) a.pos[r.op + k] = r.ts + k * a.bp.samples_per_bit;
         }
@@ -758,9 +764,9 @@ int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap
     hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandArgs ea{rows, d_n_rows, b.info, b.gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp, b.huge, b.huge_count, kHugeCap};
-    const int64_t eb = (cap_rows + 255) / 256;
+    const int64_t eb = std::min<int64_t>((cap_rows + 255) / 256, kExpandMaxBlocks);
     hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)eb), dim3(256), 0, s, ea);
-    hipLaunchKernelGGL(k_expand_huge, dim3(512), dim3(256), 0, s, ea);
+    hipLaunchKernelGGL(k_expand_huge, dim3(kHugeGridX, kHugeGridY), dim3(256), 0, s, ea);
     return URHGPU_OK;
 }
 
