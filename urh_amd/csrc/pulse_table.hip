@@ -391,6 +391,8 @@ struct BitsLoad {
     const int64_t *rows;
     const int64_t *d_n_rows;
     BitsParams bp;
+    int64_t *d_n_groups0;    // single-GPU: the group count is written by BitsStore at the last row; zero rows -> zero groups
+    __device__ void on_start(int64_t n) const { if (d_n_groups0 && n <= 0) *d_n_groups0 = 0; }
     // i counts rows AFTER the skipped leading pause row? no: all rows; row 0 is neutralised when it is a pause
     __device__ VecK<4> operator()(int64_t i) const {
         VecK<4> v; v.zero();
@@ -419,6 +421,7 @@ struct BitsStore {
     GroupInfo *groups;
     const int64_t *d_ts_carry;   // sharded captures: total_samples before this GPU's first row (nullptr: 0)
     const int64_t *d_absorbed;
+    int64_t *d_n_groups;         // single-GPU: number of groups = long pauses + 1 (sharded: GroupCountFinal, with the flags)
     __device__ void operator()(int64_t i, const VecK<4> &val, const VecK<4> &ex) const {
         const int64_t n = *d_n_rows;
         const int64_t ts0 = d_ts_carry ? *d_ts_carry : 0;
@@ -437,6 +440,7 @@ struct BitsStore {
             if (rows[2 * i] == kRowAbsorbed && d_absorbed && *d_absorbed >= 0) g.pause = *d_absorbed;
             g.closed = 0; g.pad = 0;
             groups[ex.v[1] + val.v[1]] = g;
+            if (d_n_groups) *d_n_groups = ex.v[1] + val.v[1] + 1;
         }
     }
 };
@@ -739,15 +743,19 @@ int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t ca
     if (cap_rows <= 0) cap_rows = 1;
     if (ss.desc_bytes < bits_desc_bytes(cap_rows)) return URHGPU_ERR_ARG;
     const BitsScratch b = carve_bits(scratch, cap_rows);
-    BitsLoad ld{rows, d_n_rows, bp};
-    BitsStore st{rows, d_n_rows, b.info, b.groups, bp.d_ts_carry, bp.d_absorbed};
+    // a capture on one GPU needs no flags for its neighbours: the group count comes out of the row scan itself (last row) and
+    // the one-workgroup epilogue launch is dropped
+    const bool single = (d_flags == nullptr);
+    BitsLoad ld{rows, d_n_rows, bp, single ? b.d_n_groups : nullptr};
+    BitsStore st{rows, d_n_rows, b.info, b.groups, bp.d_ts_carry, bp.d_absorbed, single ? b.d_n_groups : nullptr};
     GroupCountFinal fin{d_n_rows, b.groups, b.d_n_groups, d_flags};
     // Two passes for the rows: a single-pass look-back scan over hundreds of workgroups measured 54 us against 48 us for
     // this pair -- every look-back hop is a round trip through memory between XCDs (their L2s are not coherent).
     hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb);
     hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb, st,
                        kScanAlwaysDirect);
-    hipLaunchKernelGGL((k_scan_finish<4, GroupCountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, b.part4, b.nb, fin, kScanAlwaysDirect);
+    if (!single)
+        hipLaunchKernelGGL((k_scan_finish<4, GroupCountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, b.part4, b.nb, fin, kScanAlwaysDirect);
     return URHGPU_OK;
 }
 

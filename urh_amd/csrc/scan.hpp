@@ -110,11 +110,16 @@ __device__ __forceinline__ VecK<K> block_sum_partials(const VecK<K> *partials, i
     return total;
 }
 
+// Optional Load::on_start(n): called once (workgroup 0, thread 0) before anything else, whatever n is.
+template <class Load> __device__ __forceinline__ auto scan_on_start(const Load &l, int64_t n, int) -> decltype(l.on_start(n), void()) { l.on_start(n); }
+template <class Load> __device__ __forceinline__ void scan_on_start(const Load &, int64_t, long) {}
+
 // Load::operator()(int64 i) -> VecK<K> (only called for i < n).
 template <int K, class Load>
 __global__ __launch_bounds__(kScanBlock) void k_scan_reduce(const int64_t *d_n, Load load, VecK<K> *partials, int64_t nblocks_max) {
     __shared__ VecK<K> s_wave[kScanBlock / 64];
     const int64_t n = *d_n;
+    if (blockIdx.x == 0 && threadIdx.x == 0) scan_on_start(load, n, 0);
     const int64_t nb = scan_active_blocks(n, nblocks_max);
     if ((int64_t)blockIdx.x >= nb) return;
     const int64_t base = (int64_t)blockIdx.x * kScanTile;
