@@ -420,6 +420,36 @@ def test_iir_equals_oracle(sf, oracle):
         assert cbits_equal(sf.iir_filter(a, b, x), oracle.iir_filter(a, b, x)), (na, nb)
 
 
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16])
+def test_integer_capture_exact_zero_cross_products(pipe, oracle, dtype):
+    """Integer samples make the FSK cross product I0*Q1 - Q0*I1 an exact integer that is often exactly zero (and, with zero
+    components, a zero whose sign depends on how the reference multiplies): small amplitudes, so that zeros of every kind
+    are frequent; qad bit for bit (signed zeros included), pulse table, bits."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    rng = np.random.default_rng(7)
+    zero_frac = 0.0
+    for amp, n in ((3, 200_003), (9, 262_144), (40, 300_000)):
+        ph = np.cumsum(rng.choice([-0.13, 0.13], n // 50 + 1).repeat(50)[:n])
+        x = np.stack([amp * np.cos(ph), amp * np.sin(ph)], 1) + 0.3 * rng.standard_normal((n, 2))
+        off = 128 if dtype == np.uint8 else 0
+        info = np.iinfo(dtype)
+        iq = np.clip(np.round(x) + off, info.min, info.max).astype(dtype)
+        iq[1000:1100] = off                                              # a stretch of exact zeros (uint8: of the offset)
+        for noise in (0.0, 1.5):
+            p = DemodParams("FSK", 1, noise, 0.0, 1.0, 2, 50, 0.1, 8, True)
+            qad = oracle.afp_demod(iq, noise, "FSK", 2)
+            pp = oracle.grab_pulse_lens(qad, 0.0, 2, "FSK", 50, 1, 1.0)
+            fb = oracle.ppseq_to_bits_flat(pp, 50, 1, True, 8)
+            res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True, cap_rows=n // 3 + 2)
+            got = res.qad.cpu().numpy()
+            assert bits_equal(got, qad), (amp, noise, int((got.view(np.uint32) != qad.view(np.uint32)).sum()))
+            assert np.array_equal(res.ppseq(), pp)
+            assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
+            zero_frac = max(zero_frac, float((qad[2:] == 0).mean()))
+    assert dtype == np.uint8 or zero_frac > 1e-3                         # the case is actually exercised
+
+
 @pytest.mark.parametrize("bps", [1, 2])
 def test_many_huge_rows_expand(pipe, oracle, bps):
     """300 constant stretches of 4 500-9 000 symbols each (rows of more than 4096 bits go to k_expand_huge's work list, more

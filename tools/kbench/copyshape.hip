@@ -20,7 +20,8 @@ __global__ void k_copy(const float *in, float *out, int rows_per_wave) {
     constexpr int NB = 2;
     float cur[NB][IN], nxt[NB][IN];
     auto ld = [&](float (&r)[IN], const float *p) {
-        if (IN == 2) { const v2 t = __builtin_nontemporal_load((const v2 *)p); r[0] = t.x; r[1] = t.y; }
+        if (IN == 1) { r[0] = __builtin_nontemporal_load(p); }
+        else if (IN == 2) { const v2 t = __builtin_nontemporal_load((const v2 *)p); r[0] = t.x; r[1] = t.y; }
         else {
 #pragma unroll
             for (int q = 0; q < IN / 4; ++q) { const v4 t = __builtin_nontemporal_load((const v4 *)p + q); r[4 * q] = t.x; r[4 * q + 1] = t.y; r[4 * q + 2] = t.z; r[4 * q + 3] = t.w; }
@@ -38,7 +39,7 @@ __global__ void k_copy(const float *in, float *out, int rows_per_wave) {
         for (int j = 0; j < NB; ++j) {
             float o[OUT];
 #pragma unroll
-            for (int q = 0; q < OUT; ++q) o[q] = cur[j][q * (IN / OUT)] + cur[j][q * (IN / OUT) + (IN / OUT) - 1];
+            for (int q = 0; q < OUT; ++q) o[q] = (IN >= OUT) ? cur[j][q * (IN / OUT)] + cur[j][q * (IN / OUT) + (IN / OUT) - 1] : cur[j][0] + (float)q;
             float *p = dst + (int64_t)(r + j) * 64 * OUT;
             if (OUT == 2) { const v2 t = {o[0], o[1]}; __builtin_nontemporal_store(t, (v2 *)p); }
             else { const v4 t = {o[0], o[1], o[2], o[3]}; __builtin_nontemporal_store(t, (v4 *)p); }
@@ -63,7 +64,7 @@ static int run(const char *what, const float *in, float *out, int64_t n_samples,
     for (int it = 0; it < iters; ++it) hipLaunchKernelGGL((k_copy<IN, OUT>), dim3((unsigned)(waves / W)), dim3(64 * W), 0, s, in, out, rows_per_wave);
     CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
-    const double bytes = (double)n_samples * 4 * (in_dw_per_sample + 1);
+    const double bytes = (double)n_samples * 4 * ((double)IN / OUT + 1);
     printf("%-62s W=%d  %7.4f ms  %7.1f GB/s\n", what, W, ms, bytes / ms / 1e6);
     return 0;
 }
@@ -79,11 +80,14 @@ int main() {
             run<8, 4>("complex64, lane = 4 samples (2 x 16 B load, 16 B store)", in, out, n, 2, 4, s);
             run<2, 2>("complex int16, lane = 2 samples (8 B load, 8 B store)", in, out, n, 1, 4, s);
             run<4, 4>("complex int16, lane = 4 samples (16 B load, 16 B store)", in, out, n, 1, 4, s);
+            run<1, 2>("complex int8, lane = 2 samples (4 B load, 8 B store)", in, out, n, 1, 4, s);
+            run<2, 4>("complex int8, lane = 4 samples (8 B load, 16 B store)", in, out, n, 1, 4, s);
         } else {
             run<4, 2>("complex64, lane = 2 samples (16 B load, 8 B store)", in, out, n, 2, 8, s);
             run<8, 4>("complex64, lane = 4 samples (2 x 16 B load, 16 B store)", in, out, n, 2, 8, s);
             run<2, 2>("complex int16, lane = 2 samples (8 B load, 8 B store)", in, out, n, 1, 8, s);
             run<4, 4>("complex int16, lane = 4 samples (16 B load, 16 B store)", in, out, n, 1, 8, s);
+            run<1, 2>("complex int8, lane = 2 samples (4 B load, 8 B store)", in, out, n, 1, 8, s);
         }
     }
     return 0;

@@ -365,14 +365,28 @@ __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float pr
 #else
         div_fast2(im0, re0, im1, re1, t0, t1);
 #endif
-        const bool ok0 = (int)((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re0) - kReLo < kReSpan);
-        const bool ok1 = (int)((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re1) - kReLo < kReSpan);
+        const bool rw0 = (__float_as_uint(re0) - kReLo < kReSpan), rw1 = (__float_as_uint(re1) - kReLo < kReSpan);
+        bool ok0 = (int)((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)rw0;
+        bool ok1 = (int)((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)rw1;
 #if URH_EXP == 6 || URH_EXP == 8      // timing experiment (tools/kbench): no polynomial in the speculative path
         q0 = t0; q1 = t1;
 #else
         q0 = t0 - urh_atanf_poly(t0);
         q1 = t1 - urh_atanf_poly(t1);
 #endif
+        if (DT != URHGPU_DT_F32) {
+            // Integer captures: the cross product of two integer samples is an exact integer and EXACTLY zero about once
+            // in 700 samples at 8 bits -- one row in six would leave the fast path.  atan2f(+-0, re > 0) = +-0 (fdlibm:
+            // "atan(+-0, +anything) = +-0"), the sign being that of the reference's product (conj_mul: its zeros are signed
+            // differently from the plain product's).
+            const bool z0 = (im0 == 0.0f) & rw0, z1 = (im1 == 0.0f) & rw1;
+            if (__builtin_amdgcn_ballot_w64(z0 | z1) != 0) {           // wavefront-uniform
+                float re_r, im_r;
+                conj_mul(pc, pd, c0, d0, re_r, im_r); q0 = z0 ? im_r : q0;
+                conj_mul(c0, d0, c1, d1, re_r, im_r); q1 = z1 ? im_r : q1;
+            }
+            ok0 |= z0; ok1 |= z1;
+        }
 #if URH_EXP == 4      // timing experiment (tools/kbench): 24 extra plain VALU instructions per row
         { float dummy = t0;
 #pragma unroll
