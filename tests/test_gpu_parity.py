@@ -420,11 +420,12 @@ def test_iir_equals_oracle(sf, oracle):
         assert cbits_equal(sf.iir_filter(a, b, x), oracle.iir_filter(a, b, x)), (na, nb)
 
 
-@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16])
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.float32])
 def test_integer_capture_exact_zero_cross_products(pipe, oracle, dtype):
     """Integer samples make the FSK cross product I0*Q1 - Q0*I1 an exact integer that is often exactly zero (and, with zero
     components, a zero whose sign depends on how the reference multiplies): small amplitudes, so that zeros of every kind
-    are frequent; qad bit for bit (signed zeros included), pulse table, bits."""
+    are frequent; qad bit for bit (signed zeros included), pulse table, bits.  float32: the same integers divided by 128, a
+    complex64 recording of an 8-bit receiver."""
     import torch
     from urh_amd.pipeline import DemodParams
     rng = np.random.default_rng(7)
@@ -433,10 +434,13 @@ def test_integer_capture_exact_zero_cross_products(pipe, oracle, dtype):
         ph = np.cumsum(rng.choice([-0.13, 0.13], n // 50 + 1).repeat(50)[:n])
         x = np.stack([amp * np.cos(ph), amp * np.sin(ph)], 1) + 0.3 * rng.standard_normal((n, 2))
         off = 128 if dtype == np.uint8 else 0
-        info = np.iinfo(dtype)
-        iq = np.clip(np.round(x) + off, info.min, info.max).astype(dtype)
+        if dtype == np.float32:
+            iq = (np.clip(np.round(x), -128, 127) / 128.0).astype(np.float32)
+        else:
+            info = np.iinfo(dtype)
+            iq = np.clip(np.round(x) + off, info.min, info.max).astype(dtype)
         iq[1000:1100] = off                                              # a stretch of exact zeros (uint8: of the offset)
-        for noise in (0.0, 1.5):
+        for noise in (0.0, 1.5 / 128 if dtype == np.float32 else 1.5):
             p = DemodParams("FSK", 1, noise, 0.0, 1.0, 2, 50, 0.1, 8, True)
             qad = oracle.afp_demod(iq, noise, "FSK", 2)
             pp = oracle.grab_pulse_lens(qad, 0.0, 2, "FSK", 50, 1, 1.0)

@@ -374,9 +374,10 @@ __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float pr
         q0 = t0 - urh_atanf_poly(t0);
         q1 = t1 - urh_atanf_poly(t1);
 #endif
-        if (DT != URHGPU_DT_F32) {
-            // Integer captures: the cross product of two integer samples is an exact integer and EXACTLY zero about once
-            // in 700 samples at 8 bits -- one row in six would leave the fast path.  atan2f(+-0, re > 0) = +-0 (fdlibm:
+        {
+            // Integer captures (and float captures recorded from 8-bit receivers: multiples of 2^-7): the cross product of
+            // two such samples is exact and EXACTLY zero about once in 700 samples at 8 bits -- one row in six would leave
+            // the fast path.  atan2f(+-0, re > 0) = +-0 (fdlibm:
             // "atan(+-0, +anything) = +-0"), the sign being that of the reference's product (conj_mul: its zeros are signed
             // differently from the plain product's).
             const bool z0 = (im0 == 0.0f) & rw0, z1 = (im1 == 0.0f) & rw1;
