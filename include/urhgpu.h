@@ -96,8 +96,11 @@ int urhgpu_ctx_info(urhgpu_ctx *ctx, int *compute_units, int *wavefront, int64_t
 int urhgpu_ctx_costas_stats(urhgpu_ctx *ctx, int32_t *out4);
 
 /* Time the dominant kernel (demod + run segmentation) of subsequent fused / grab_pulse_lens calls with
- * HIP events recorded on the context's stream: begin(max_records) arms up to max_records records
- * (one per call); end() synchronises the stream and returns the per-call durations in ms. */
+ * HIP events on the context's stream: begin(max_records) arms up to max_records records (one per call); end()
+ * synchronises the stream and returns the per-call durations in ms.  The bit-plane kernel's dispatch carries the start /
+ * stop events itself (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps, the duration rocprofv3 reports);
+ * hot launches made of several kernels are bracketed by events recorded before and after them (environment
+ * URH_PROFILE_BRACKET=1: always report the bracket, which reads 3-5 % longer than the kernel runs). */
 int urhgpu_ctx_profile_begin(urhgpu_ctx *ctx, int max_records);
 int urhgpu_ctx_profile_end(urhgpu_ctx *ctx, float *ms_out, int cap, int *n_records);
 

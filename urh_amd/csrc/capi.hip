@@ -111,6 +111,27 @@ int dtype_bytes(int dtype) {
 // Core of grab_pulse_lens / the fused path: run-segmentation kernel (IQ or qad source), resolve,
 // emit rows, optional ASK merge.  On return d_rows / d_n_rows hold the final pulse table.
 // scratch must come from ctx->arena (already reserved by the caller).
+// One profile record = four events: [4k], [4k+1] bracket the hot launch on the stream (what is reported for launches made of
+// several kernels); [4k+2], [4k+3] are attached to the bit-plane kernel's dispatch (its own begin / end timestamps)
+bool prof_begin_record(urhgpu_ctx *ctx, hipStream_t s) {
+    const bool prof = ctx->prof_on && (size_t)(4 * ctx->prof_used + 3) < ctx->prof_events.size();
+    if (!prof) return false;
+    if (hipEventRecord(ctx->prof_events[4 * ctx->prof_used], s) != hipSuccess) return false;
+    g_hot_events.start = ctx->prof_events[4 * ctx->prof_used + 2];
+    g_hot_events.stop = ctx->prof_events[4 * ctx->prof_used + 3];
+    g_hot_events.used = false;
+    return true;
+}
+int prof_end_record(urhgpu_ctx *ctx, hipStream_t s) {
+    const bool used = g_hot_events.used;
+    g_hot_events = HotEvents();
+    URH_HIP(hipEventRecord(ctx->prof_events[4 * ctx->prof_used + 1], s));
+    if ((size_t)ctx->prof_used >= ctx->prof_dispatch.size()) ctx->prof_dispatch.resize((size_t)ctx->prof_used + 1);
+    ctx->prof_dispatch[(size_t)ctx->prof_used] = used;
+    ctx->prof_used += 1;
+    return URHGPU_OK;
+}
+
 int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const urhgpu_params *p, float *d_qad,
              int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows, int64_t *d_n_rows_needed, int64_t *d_n_acc,
              const Plan &pl, int seg_mode = 0, hipStream_t s_tail = nullptr) {
@@ -134,11 +155,10 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
     if (!chunks || !slab) return URHGPU_ERR_ARG;
     a.chunks = chunks; a.slab = slab;
-    const bool prof = ctx->prof_on && (size_t)(2 * ctx->prof_used + 1) < ctx->prof_events.size();
-    if (prof) URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used], s));
+    const bool prof = prof_begin_record(ctx, s);
     if (from_iq) URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, d_qad != nullptr, s));
     else URH_TRY(launch_runs_qad(a, s));
-    if (prof) { URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], s)); ctx->prof_used += 1; }
+    if (prof) URH_TRY(prof_end_record(ctx, s));
     if (s_tail) {                                   // pipelined: everything after the hot kernel goes to the tail stream
         URH_HIP(hipEventRecord(ctx->ev_hot, s));
         URH_HIP(hipStreamWaitEvent(s_tail, ctx->ev_hot, 0));
@@ -395,7 +415,7 @@ int urhgpu_ctx_reserve(urhgpu_ctx *ctx, int64_t n_samples, int tolerance) {
 int urhgpu_ctx_profile_begin(urhgpu_ctx *ctx, int max_records) {
     if (!ctx || max_records < 0) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
-    while ((int)ctx->prof_events.size() < 2 * max_records) {
+    while ((int)ctx->prof_events.size() < 4 * max_records) {
         hipEvent_t e;
         URH_HIP(hipEventCreate(&e));
         ctx->prof_events.push_back(e);
@@ -412,8 +432,11 @@ int urhgpu_ctx_profile_end(urhgpu_ctx *ctx, float *ms_out, int cap, int *n_recor
     ctx->prof_on = false;
     const int n = ctx->prof_used;
     *n_records = n;
-    for (int k = 0; k < n && k < cap; ++k)
-        URH_HIP(hipEventElapsedTime(&ms_out[k], ctx->prof_events[2 * k], ctx->prof_events[2 * k + 1]));
+    const bool bracket = getenv("URH_PROFILE_BRACKET") != nullptr;   // report the stream-level bracket instead (comparison)
+    for (int k = 0; k < n && k < cap; ++k) {
+        const int base = 4 * k + ((ctx->prof_dispatch[(size_t)k] && !bracket) ? 2 : 0);
+        URH_HIP(hipEventElapsedTime(&ms_out[k], ctx->prof_events[base], ctx->prof_events[base + 1]));
+    }
     return URHGPU_OK;
 }
 
@@ -594,10 +617,9 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     a.slab = ss->slab;
     a.launch_part = part;
     if (part == 1 && rank > 0 && !a.left_halo) a.left_halo = d_iq;    // any non-null value: only chunk 0 reads the halo
-    const bool prof = ctx->prof_on && (size_t)(2 * ctx->prof_used + 1) < ctx->prof_events.size();
-    if (prof) URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used], s));
+    const bool prof = prof_begin_record(ctx, s);
     URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s));
-    if (prof) { URH_HIP(hipEventRecord(ctx->prof_events[2 * ctx->prof_used + 1], s)); ctx->prof_used += 1; }
+    if (prof) URH_TRY(prof_end_record(ctx, s));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }

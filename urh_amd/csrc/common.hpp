@@ -66,7 +66,8 @@ struct urhgpu_ctx {
     // that held other values (another descriptor layout) can never look like a flag of the current pass
     unsigned long long scan_epoch = 0x0ACE0FBA5E000000ull;
     // optional timing of the dominant kernel (demod + run segmentation) with HIP events on `stream`
-    std::vector<hipEvent_t> prof_events;   // pairs: [2k] before, [2k+1] after
+    std::vector<hipEvent_t> prof_events;   // four per record: [4k], [4k+1] around the hot launch; [4k+2], [4k+3] attached to the dispatch
+    std::vector<bool> prof_dispatch;       // record k: the dispatch-attached pair was used
     int prof_used = 0;                     // pairs recorded since urhgpu_ctx_profile_begin
     bool prof_on = false;
     void *shard = nullptr;                 // state of a sharded pass between its phases (capi.hip: ShardSession)

@@ -25,6 +25,7 @@
 // previous row, carried in registers (v_readlane) from row to row and tile to tile.  State bytes go
 // to LDS in sample order; in the run phase lane t owns 32 consecutive samples.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 
@@ -1182,6 +1183,7 @@ __global__ void k_test_atan2f(const float *y, const float *x, int64_t n, float *
 // ---- host-side launchers ---------------------------------------------------------------------------
 // test hook (urhgpu_test_force_state_bytes): route order-2 work through the state-byte kernel as well
 bool g_force_state_bytes = false;
+thread_local HotEvents g_hot_events;
 
 // `a` describes the whole capture (a.n samples, chunk table / slab for n_main + has_tail chunks):
 // one launch over the whole tiles, one one-workgroup launch for the partial tile at the end.
@@ -1197,7 +1199,11 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
         // orders 2 and 4: the bit-plane kernel; anything else: the state-byte kernel
         const bool planes_ok = URH_BITPLANE && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes;
-        if (planes_ok && O2)
+        if (planes_ok && O2 && g_hot_events.start && !g_hot_events.used) {
+            hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
+                                  (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
+            g_hot_events.used = true;
+        } else if (planes_ok && O2)
             hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
         else if (planes_ok && a.order == 4)
             hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 2>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
