@@ -454,6 +454,35 @@ def test_integer_capture_exact_zero_cross_products(pipe, oracle, dtype):
     assert dtype == np.uint8 or zero_frac > 1e-3                         # the case is actually exercised
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.int16, np.int8])
+def test_wide_deviation_reduced_argument_path(pipe, oracle, dtype):
+    """Phase steps around and beyond atan(7/16) per sample (wide FSK deviations, noise): rows whose lanes need fdlibm's first two
+    argument reductions (7/16 <= |im/re| < 1) are evaluated without the general atan2f; steps up to pi/4 and beyond (general
+    path), mixed in one capture, qad bit for bit against the oracle."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    rng = np.random.default_rng(17)
+    n = 400_000
+    for step, sigma in ((0.30, 0.05), (0.42, 0.02), (0.55, 0.05), (0.70, 0.03), (0.80, 0.08), (1.30, 0.05)):
+        ph = np.cumsum(rng.choice([-step, step], n // 40 + 1).repeat(40)[:n])
+        x = np.stack([np.cos(ph), np.sin(ph)], 1) + sigma * rng.standard_normal((n, 2))
+        x[100_000:100_500] *= 0.0                                        # exact zeros
+        if dtype == np.float32:
+            iq = x.astype(np.float32)
+            iq[200_000:200_064, 0] = 1.0; iq[200_000:200_064, 1] = np.linspace(-1.2, 1.2, 64, dtype=np.float32)   # |im/re| sweeps
+        else:
+            amp = 0.6 * np.iinfo(dtype).max
+            iq = np.clip(np.round(x * amp), np.iinfo(dtype).min, np.iinfo(dtype).max).astype(dtype)
+        for noise in (0.0, 0.3 if dtype == np.float32 else 0.3 * 0.6 * np.iinfo(dtype).max):
+            p = DemodParams("FSK", 1, noise, 0.0, 1.0, 3, 40, 0.1, 8, True)
+            qad = oracle.afp_demod(iq, noise, "FSK", 2)
+            pp = oracle.grab_pulse_lens(qad, 0.0, 3, "FSK", 40, 1, 1.0)
+            res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True, cap_rows=n // 4 + 2)
+            got = res.qad.cpu().numpy()
+            assert bits_equal(got, qad), (step, sigma, noise, int((got.view(np.uint32) != qad.view(np.uint32)).sum()))
+            assert np.array_equal(res.ppseq(), pp), (step, sigma, noise)
+
+
 @pytest.mark.parametrize("bps", [1, 2])
 def test_many_huge_rows_expand(pipe, oracle, bps):
     """300 constant stretches of 4 500-9 000 symbols each (rows of more than 4096 bits go to k_expand_huge's work list, more

@@ -216,6 +216,19 @@ __device__ __forceinline__ float div_fast(float n, float d) {
     return n / d;
 #endif
 }
+// fdlibm atanf's first two argument reductions (s_atanf.c): 7/16 <= ax < 11/16: atan(1/2) + atan((2 ax - 1) / (2 + ax));
+// 11/16 <= ax < 19/16 (used below 1 only): atan(1) + atan((ax - 1) / (ax + 1)).  Lanes that are not `mid` get (t, 1): the
+// division then returns t itself.  kAtanMid*: "0.4375 <= ax < 1" as one unsigned compare.
+constexpr uint32_t kAtanMidLo = 0x3ee00000u, kAtanMidSpan = 0x3f800000u - 0x3ee00000u;
+__device__ __forceinline__ void atan_reduce(float ax, bool mid, float t, float &num, float &den, float &hi, float &lo) {
+    const bool low = ax < 0.6875f;
+    const float n_lo = 2.0f * ax - 1.0f, d_lo = 2.0f + ax, n_hi = ax - 1.0f, d_hi = ax + 1.0f;
+    num = mid ? (low ? n_lo : n_hi) : t;
+    den = mid ? (low ? d_lo : d_hi) : 1.0f;
+    hi = low ? 4.6364760399e-01f : 7.8539812565e-01f;
+    lo = low ? 5.0121582440e-09f : 3.7748947079e-08f;
+}
+
 // two quotients at once: the fma chain as 2-vectors (v_pk_fma_f32 / v_pk_mul_f32)
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void div_fast2(float n0, float d0, float n1, float d1, float &q0, float &q1) {
@@ -231,6 +244,29 @@ __device__ __forceinline__ void div_fast2(float n0, float d0, float n1, float d1
     q0 = q.x; q1 = q.y;
 }
 
+
+// The FSK pair of a lane when some lane of the row needs an argument reduction (mdX: 0.4375 <= |tX| < 1) or has an exactly
+// zero cross product (zrX); every lane's denominator is in the fast division's window.  Lanes in the plain fast range come
+// out as t - poly(t) like everywhere else.
+__device__ __forceinline__ void fsk_reduced(float pc, float pd, float c0, float d0, float c1, float d1, float t0, float t1,
+                                            bool md0, bool md1, bool zr0, bool zr1, float &q0, float &q1) {
+    float n0v, d0v, h0, l0, n1v, d1v, h1, l1;
+    atan_reduce(__uint_as_float(__float_as_uint(t0) & 0x7fffffffu), md0, t0, n0v, d0v, h0, l0);
+    atan_reduce(__uint_as_float(__float_as_uint(t1) & 0x7fffffffu), md1, t1, n1v, d1v, h1, l1);
+    float u0, u1;
+    div_fast2(n0v, d0v, n1v, d1v, u0, u1);           // lanes in the fast range: t / 1 = t exactly
+    const float p0 = urh_atanf_poly(u0), p1 = urh_atanf_poly(u1);
+    const float z0 = h0 - ((p0 - l0) - u0), z1 = h1 - ((p1 - l1) - u1);
+    q0 = md0 ? __uint_as_float(__float_as_uint(z0) | (__float_as_uint(t0) & 0x80000000u)) : t0 - p0;
+    q1 = md1 ? __uint_as_float(__float_as_uint(z1) | (__float_as_uint(t1) & 0x80000000u)) : t1 - p1;
+    if (__builtin_amdgcn_ballot_w64(zr0 | zr1) != 0) {
+        // atan2f(+-0, re > 0) = +-0 (fdlibm: "atan(+-0, +anything) = +-0"), the sign being that of the reference's product
+        // (conj_mul: its zeros are signed differently from the plain product's)
+        float re_r, im_r;
+        conj_mul(pc, pd, c0, d0, re_r, im_r); q0 = zr0 ? im_r : q0;
+        conj_mul(c0, d0, c1, d1, re_r, im_r); q1 = zr1 ? im_r : q1;
+    }
+}
 
 __device__ __forceinline__ float atan2f_small(float r, float y, float x) {
     // r = |y/x| in [2^-29, 0.4375)
@@ -315,8 +351,19 @@ __device__ __forceinline__ int demod_pair(const RowIn &r, float prev_c, float pr
 #if URH_FASTDIV
         float t0, t1;
         div_fast2(im0, re0, im1, re1, t0, t1);
-        const bool ok0 = (int)((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re0) - kReLo < kReSpan);
-        const bool ok1 = (int)((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)(__float_as_uint(re1) - kReLo < kReSpan);
+        // This function re-does the rows the speculative pass flagged.  Besides the fast range it accepts, still without a
+        // branch per lane, 0.4375 <= |im/re| < 1 (phase steps up to pi/4: wide deviations, noisy samples) -- fdlibm's first
+        // two argument reductions, one more division -- and exact zeros (see spec_pair).
+        const uint32_t a0 = __float_as_uint(t0) & 0x7fffffffu, a1 = __float_as_uint(t1) & 0x7fffffffu;
+        const bool rw0 = (__float_as_uint(re0) - kReLo < kReSpan), rw1 = (__float_as_uint(re1) - kReLo < kReSpan);
+        const bool md0 = (a0 - kAtanMidLo < kAtanMidSpan), md1 = (a1 - kAtanMidLo < kAtanMidSpan);
+        const bool zr0 = (im0 == 0.0f), zr1 = (im1 == 0.0f);
+        const bool ok0 = (int)((a0 - kAtanLo < kAtanSpan) | md0 | zr0) & (int)rw0;
+        const bool ok1 = (int)((a1 - kAtanLo < kAtanSpan) | md1 | zr1) & (int)rw1;
+        if (!any_noise && __builtin_amdgcn_ballot_w64(!(ok0 & ok1)) == 0 && __builtin_amdgcn_ballot_w64(md0 | md1 | zr0 | zr1) != 0) {
+            fsk_reduced(pc, pd, c0, d0, c1, d1, t0, t1, md0, md1, zr0, zr1, q0, q1);
+            return 0;
+        }
 #else
         const float t0 = im0 / re0, t1 = im1 / re1;
         const bool ok0 = ((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (re0 > 0.0f);
@@ -378,9 +425,10 @@ __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float pr
         {
             // Integer captures (and float captures recorded from 8-bit receivers: multiples of 2^-7): the cross product of
             // two such samples is exact and EXACTLY zero about once in 700 samples at 8 bits -- one row in six would leave
-            // the fast path.  atan2f(+-0, re > 0) = +-0 (fdlibm:
-            // "atan(+-0, +anything) = +-0"), the sign being that of the reference's product (conj_mul: its zeros are signed
-            // differently from the plain product's).
+            // the fast path.  atan2f(+-0, re > 0) = +-0 (fdlibm: "atan(+-0, +anything) = +-0"), the sign being that of the
+            // reference's product (conj_mul: its zeros are signed differently from the plain product's).
+            // (Lanes that need an argument reduction are NOT settled here but when the flagged row is re-done, demod_pair:
+            // testing for them in this pass costs the rows that need nothing 1 % (complex64) to 9 % (int8).)
             const bool z0 = (im0 == 0.0f) & rw0, z1 = (im1 == 0.0f) & rw1;
             if (__builtin_amdgcn_ballot_w64(z0 | z1) != 0) {           // wavefront-uniform
                 float re_r, im_r;
