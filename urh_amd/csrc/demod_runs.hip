@@ -482,22 +482,35 @@ __device__ __forceinline__ void fsk_row_general(const RowIn &r, float prev_c, fl
 // some sample of row j may equal the NOISE sentinel, so the classification has to test for it).
 template <int SRC, int DT, int MOD, int NB>
 __device__ __forceinline__ uint32_t demod_batch(const RowIn (&cur)[NB], float &prev_c, float &prev_d, const RunArgs &p,
-                                                float (&q0)[NB], float (&q1)[NB]) {
+                                                float (&q0)[NB], float (&q1)[NB], uint32_t &hint) {
     constexpr int kBatch = NB;
     uint32_t general = 0, gated = 0;                        // per-row flags, wavefront-uniform
     float pcs[kBatch], pds[kBatch];                         // seam operand of each row (uniform)
 #if URH_SPEC
     if (SRC == SRC_IQ && MOD != URHGPU_MOD_OTHER) {
-        bool flag[kBatch];
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-            pcs[j] = prev_c; pds[j] = prev_d;
-            flag[j] = spec_pair<MOD, DT>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
-            if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
-        }
         uint32_t bad = 0;
+        if (MOD == URHGPU_MOD_FSK && hint != 0) {
+            // the speculative pass has just been failing (wide deviation, noise): the next few batches skip it and take the
+            // re-do of flagged rows directly (wavefront-uniform; `hint` counts down to the next speculative attempt)
+            --hint;
+            bad = (1u << kBatch) - 1u;
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) if (__builtin_amdgcn_ballot_w64(flag[j]) != 0) bad |= 1u << j;
+            for (int j = 0; j < kBatch; ++j) {
+                pcs[j] = prev_c; pds[j] = prev_d;
+                prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1);
+            }
+        } else {
+            bool flag[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                pcs[j] = prev_c; pds[j] = prev_d;
+                flag[j] = spec_pair<MOD, DT>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
+                if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) if (__builtin_amdgcn_ballot_w64(flag[j]) != 0) bad |= 1u << j;
+            if (MOD == URHGPU_MOD_FSK && bad == (1u << kBatch) - 1u) hint = 7;       // every row of the batch: likely to go on
+        }
         if (__builtin_expect(bad != 0, 0)) {
 #pragma unroll 1
             for (int j = 0; j < kBatch; ++j) {
@@ -662,6 +675,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
     constexpr int kBatch = URH_KBATCH;   // rows (16-byte loads per thread) in flight per batch
     RowIn cur[kBatch], nxt[kBatch];
     bool have_cur = false;         // cur[] already holds rows 0..kBatch-1 of the tile about to start (uniform)
+    uint32_t spec_hint = 0;        // demod_batch: batches left that skip the speculative pass
     for (int64_t ta = a0; ta < a1; ta += kTile) {
         const int tv = (int)((a1 - ta < kTile) ? (a1 - ta) : kTile);     // valid samples in this tile
         if (t == 0) {
@@ -683,7 +697,7 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
                     if (have_cur) load_rows<SRC, DT, FULL>(p, ta + kTile, 0, t, a1, nxt);
                 }
                 float q0[kBatch], q1[kBatch];
-                const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1);
+                const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1, spec_hint);
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) {
                     const int off = (rb + j) * kRowSamples + 2 * t;
@@ -952,12 +966,13 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) void k_demod_runs_
     }
 
     // ================= phase 1: demodulate, one compare mask per plane and parity, parked in lane `row` ==============
+    uint32_t spec_hint = 0;                                    // demod_batch: batches left that skip the speculative pass
     uint32_t pl[NPL + 1][2][2] = {};                          // [state planes ..., PAUSE][even, odd samples][low, high word]: lane r <- row r
 #pragma unroll 1
     for (int rb = r0; rb < r0 + R; rb += kBatch) {
         if (rb + kBatch < r0 + R) load_rows<SRC, DT, true>(p, a0, rb + kBatch, lane, a1, nxt);
         float q0[kBatch], q1[kBatch];
-        const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1);
+        const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1, spec_hint);
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             const int off = (rb + j) * kRowSamples + 2 * lane;
