@@ -36,12 +36,12 @@ def oracle():
     return urh_oracle
 
 
-def synth_fsk(n, sps=100, seed=0, noise=0.05, pause_every=0, pause_len=0, dtype=np.float32):
-    """Small seeded 2-FSK capture (continuous phase, +-20 kHz @ 1 MS/s) with AWGN and optional silent gaps."""
+def synth_fsk(n, sps=100, seed=0, noise=0.05, pause_every=0, pause_len=0, dtype=np.float32, deviation_hz=20e3):
+    """Small seeded 2-FSK capture (continuous phase, +-deviation_hz @ 1 MS/s) with AWGN and optional silent gaps."""
     rng = np.random.default_rng(seed)
     nsym = n // sps + 1
     bits = rng.integers(0, 2, nsym)
-    f = np.repeat(np.where(bits == 1, 20e3, -20e3), sps)[:n]
+    f = np.repeat(np.where(bits == 1, deviation_hz, -deviation_hz), sps)[:n]
     phase = np.cumsum(2 * np.pi * f / 1e6)
     iq = np.stack([np.cos(phase), np.sin(phase)], axis=1)
     if pause_every:

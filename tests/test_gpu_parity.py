@@ -208,8 +208,9 @@ def test_fused_randomised_vs_oracle(pipe, oracle):
         dtype = [np.float32, np.float32, np.int8, np.uint8, np.int16, np.uint16][it % 6]
         mod = "FSK" if it % 2 == 0 else "ASK"
         pe = int(rng.choice([0, max(n // 3, 1), 2500]))
+        dev_hz = (20e3, 20e3, 60e3, 90e3, 140e3, 260e3)[(it // 6) % 6]     # phase steps 0.13 ... 1.6 rad per sample
         iq = synth_fsk(n, sps=sps, seed=it, noise=float(rng.choice([0.0, 0.02, 0.3])), pause_every=pe,
-                       pause_len=int(rng.choice([1, 7, 130, 2100])) if pe else 0, dtype=dtype)
+                       pause_len=int(rng.choice([1, 7, 130, 2100])) if pe else 0, dtype=dtype, deviation_hz=dev_hz)
         scale = 1.0 if dtype == np.float32 else float(np.abs(iq.astype(np.float64)).max())
         if mod == "ASK":
             env = np.repeat(rng.integers(0, 2, n // sps + 1), sps)[:n]
