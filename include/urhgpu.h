@@ -356,6 +356,12 @@ int urhgpu_bgra_lookup_dev(urhgpu_ctx *ctx, const float *d_db, int64_t frames, i
  * state-byte kernel as well, so that tests can compare the two on the same input.  Process-wide. */
 int urhgpu_test_force_state_bytes(int on);
 
+/* Test hook: the chunk plan normally depends on the capture size (1 tile = 16 rows of 128 samples per chunk below
+ * about 8 M samples, 4 tiles = 64 rows -- every lane of the run phase populated, four wavefronts exchanging bit planes
+ * through LDS -- above about 25 M).  tiles = 1..4 forces that many tiles per chunk for every size, so that small
+ * captures the oracle finishes in seconds exercise the plan the 1 GiB benchmark runs; 0 restores the default.  Process-wide. */
+int urhgpu_test_force_tiles_per_chunk(int tiles);
+
 /* Test hook: elementwise bit-faithful atan2f (the device port of glibc 2.35 atan2f), device pointers. */
 int urhgpu_test_atan2f_dev(urhgpu_ctx *ctx, const float *d_y, const float *d_x, int64_t n, float *d_out);
 

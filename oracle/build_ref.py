@@ -87,6 +87,56 @@ def build(force: bool = False) -> bool:
     return built()
 
 
+# Python side of the reference (Signal, ProtocolAnalyzer, AutoInterpretation, ...) and the captures its own demodulation tests
+# read: STAGED into the git-ignored oracle/_ref/ (never into history) so that the GPU box -- where /root/reference does not
+# exist -- can run the reference's classes with this library patched in underneath (tests/test_reference_dropin.py) and
+# bench.py can time the reference's own end-to-end Python path as the CPU baseline.
+PYSRC = os.path.join(OUT, "pysrc")
+REFTESTS = os.path.join(OUT, "reftests")
+STAGED_TESTS = ["test_demodulations.py", "utils_testing.py", "__init__.py"]
+STAGED_DATA = ["ask.complex", "ask_short.complex", "fsk.complex", "psk_gen_noisy.complex", "steckdose_anlernen.complex",
+               "two_participants.complex16s", "unaveraged.coco", "enocean.complex", "homematic.complex32s", "pwm.complex16s"]
+
+
+def staged() -> bool:
+    return os.path.exists(os.path.join(PYSRC, "urh", "signalprocessing", "Signal.py")) and \
+        os.path.exists(os.path.join(REFTESTS, "tests", "test_demodulations.py"))
+
+
+def stage_python(force: bool = False) -> bool:
+    if staged() and not force:
+        return True
+    if not ref_available():
+        return staged()
+    src = os.path.join(REF_ROOT, "src", "urh")
+    for root, dirs, files in os.walk(src):
+        dirs[:] = [d for d in dirs if d != "__pycache__"]
+        rel = os.path.relpath(root, src)
+        for f in files:
+            if f.endswith(".py"):
+                dst = os.path.join(PYSRC, "urh", rel, f)
+                os.makedirs(os.path.dirname(dst), exist_ok=True)
+                shutil.copyfile(os.path.join(root, f), dst)
+    tdst = os.path.join(REFTESTS, "tests")
+    os.makedirs(os.path.join(tdst, "data"), exist_ok=True)
+    for f in STAGED_TESTS:
+        a = os.path.join(REF_ROOT, "tests", f)
+        if os.path.exists(a):
+            shutil.copyfile(a, os.path.join(tdst, f))
+    for f in STAGED_DATA:
+        a = os.path.join(REF_ROOT, "tests", "data", f)
+        if os.path.exists(a):
+            shutil.copyfile(a, os.path.join(tdst, "data", f))
+    return staged()
+
+
+def python_src_root():
+    """Directory holding the reference's `urh` Python package: the reference tree itself where it exists, else the staged copy."""
+    if ref_available():
+        return os.path.join(REF_ROOT, "src")
+    return PYSRC if staged() else None
+
+
 def import_ref():
     """Import the built reference modules (signal_functions, util, auto_interpretation)."""
     if not built():
@@ -99,5 +149,5 @@ def import_ref():
 
 if __name__ == "__main__":
     ok = build(force="--force" in sys.argv)
-    print("oracle/_ref built:", ok)
+    print("oracle/_ref built:", ok, " python sources staged:", stage_python(force="--force" in sys.argv))
     sys.exit(0 if ok else 1)

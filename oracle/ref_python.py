@@ -1,6 +1,8 @@
 """Import the reference's own Python classes (Signal, ProtocolAnalyzer, AutoInterpretation, ...)
-on top of the oracle/_ref Cython build.  Works ONLY where /root/reference exists (this build
-container); used by tests/golden/make_golden.py and by `-m "not gpu"` tests that pin the oracle.
+on top of the oracle/_ref Cython build.  Where /root/reference exists (this build container) the
+sources are read from there; elsewhere (the GPU box) from the copy oracle/build_ref.py staged into
+the git-ignored oracle/_ref/pysrc.  Used by tests/golden/make_*.py, by the tests that pin the oracle,
+by tests/test_reference_dropin.py and by bench.py's cpu_baseline leg.
 TEST INFRASTRUCTURE ONLY."""
 import os
 import sys
@@ -10,8 +12,9 @@ REF_ROOT = os.environ.get("URH_REFERENCE", "/root/reference")
 
 
 def available() -> bool:
+    sys.path.insert(0, HERE) if HERE not in sys.path else None
     import build_ref  # noqa
-    return os.path.isdir(os.path.join(REF_ROOT, "src", "urh")) and build_ref.built()
+    return build_ref.built() and build_ref.python_src_root() is not None
 
 
 def setup():
@@ -22,7 +25,9 @@ def setup():
     if not build_ref.build():
         raise RuntimeError("reference build unavailable")
     stub = os.path.join(HERE, "pyqt6_stub")
-    src = os.path.join(REF_ROOT, "src")
+    src = build_ref.python_src_root()
+    if src is None:
+        raise RuntimeError("reference Python sources unavailable (neither /root/reference nor oracle/_ref/pysrc)")
     for p in (src, stub):
         if p not in sys.path:
             sys.path.insert(0, p)

@@ -195,15 +195,18 @@ def test_fused_equals_oracle_medium(pipe, oracle, mod):
         assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
 
 
-def test_fused_randomised_vs_oracle(pipe, oracle):
+def test_fused_randomised_vs_oracle(pipe, oracle, cases=None, big=False):
     """Differential fuzz of the fused device path against the oracle: random sizes (chunk and row boundaries fall anywhere in
-    runs and pauses), tolerances, samples per symbol, noise gates, centers, sample types; everything bit-exact."""
+    runs and pauses), tolerances, samples per symbol, noise gates, centers, sample types; everything bit-exact.
+    big: sizes up to 600 000 samples (dozens of 64-row chunks under a forced chunk plan)."""
     import torch
     from urh_amd.pipeline import DemodParams
     import os
-    rng = np.random.default_rng(int(os.environ.get("URH_FUZZ_SEED", "2026")))     # URH_FUZZ_SEED: more rounds by hand
-    for it in range(int(os.environ.get("URH_FUZZ_CASES", "160"))):
+    rng = np.random.default_rng(int(os.environ.get("URH_FUZZ_SEED", "2026")) + (7 if big else 0))     # URH_FUZZ_SEED: more rounds by hand
+    for it in range(int(os.environ.get("URH_FUZZ_CASES", "160")) if cases is None else cases):
         n = int(rng.choice([rng.integers(3, 300), rng.integers(300, 9000), rng.integers(9000, 70_000)]))
+        if big:
+            n = int(rng.choice([n, rng.integers(70_000, 600_000), 8192 * int(rng.integers(1, 40)) + int(rng.choice([0, 1, 127, 128, 2047, 2048, 4097]))]))
         sps = int(rng.choice([1, 2, 5, 17, 100, 333]))
         dtype = [np.float32, np.float32, np.int8, np.uint8, np.int16, np.uint16][it % 6]
         mod = "FSK" if it % 2 == 0 else "ASK"
@@ -229,6 +232,29 @@ def test_fused_randomised_vs_oracle(pipe, oracle):
         assert bits_equal(res.qad.cpu().numpy(), qad), ctxt
         assert np.array_equal(res.ppseq(), pp), ctxt
         assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat())), ctxt
+
+
+@pytest.mark.parametrize("tiles", [2, 4])
+def test_forced_chunk_plan_vs_oracle(pipe, oracle, tiles):
+    """The 1 GiB benchmark runs chunks of 4 tiles = 64 rows (every lane of the run phase populated, four wavefronts per chunk
+    exchanging bit planes through LDS); captures the oracle finishes in seconds would get 1-tile chunks.  Forcing the plan
+    (urhgpu_test_force_tiles_per_chunk) puts the benchmark's kernel configuration under the full differential suite: the
+    randomised fuzz (all dtypes, orders 2 and 4, tolerances, noise gates), the medium captures, the order-4 comparison and the
+    bit-plane / state-byte comparison -- all against the oracle, bit-exact."""
+    from urh_amd import _lib
+    lib = _lib.load()
+    assert lib.urhgpu_test_force_tiles_per_chunk(tiles) == 0
+    try:
+        test_fused_randomised_vs_oracle(pipe, oracle, cases=150, big=True)
+        for mod in ("FSK", "ASK"):
+            test_fused_equals_oracle_medium(pipe, oracle, mod)
+            test_bit_plane_kernel_order4_equals_state_byte_kernel(pipe, oracle, mod)
+            test_bit_plane_kernel_equals_state_byte_kernel(pipe, oracle, mod)
+        test_integer_capture_exact_zero_cross_products(pipe, oracle, np.int8)
+        test_wide_deviation_reduced_argument_path(pipe, oracle, np.float32)
+    finally:
+        lib.urhgpu_test_force_tiles_per_chunk(0)
+    assert lib.urhgpu_test_force_tiles_per_chunk(5) == _lib.ERR_ARG
 
 
 def _four_level(n, sps, seed, mod, noise=0.03):
@@ -745,6 +771,89 @@ def test_full_size_fsk_1gib_properties(pipe):
     for k, (a, b) in enumerate(zip(got_all, want)):
         assert np.array_equal(a, b), (k, len(a), len(b))
     assert sum(int(r.qad.view(torch.int32).to(torch.int64).sum().item()) for r in out) == qad_sum
+
+
+def test_spec_capture_bytes_equal_reference_generator(pipe, oracle):
+    """urh_amd.synth.spec_fsk_capture builds SURVEY §8(d) config 2's capture byte for byte: two segments through the GPU generator
+    equal the same segments through the oracle's modulate_c (and the real reference's, where oracle/_ref is built) + numpy AWGN."""
+    import array
+    import build_ref
+    from urh_amd.synth import spec_fsk_bits, spec_fsk_capture
+    iq, bits = spec_fsk_capture(2, "cuda:0", first_segment=5)
+    got = iq.cpu().numpy()
+    gens = [oracle.modulate_c]
+    if build_ref.built():
+        gens.append(build_ref.import_ref()[0].modulate_c)
+    for gen in gens:
+        for j, k in enumerate((5, 6)):
+            b = np.random.default_rng(1234 + k).integers(0, 2, 10485)
+            assert np.array_equal(b, bits[j]) and np.array_equal(b, spec_fsk_bits(k))
+            seg = np.asarray(gen(array.array("B", b.tolist()), 100, "FSK", array.array("f", [-20e3, 20e3]), 1, 1.0, 40e3, 0.0, 1e6, 76, 0),
+                             dtype=np.float32)
+            assert seg.shape == (1 << 20, 2)
+            want = seg + np.float32(0.05) * np.random.default_rng(5678 + k).standard_normal((1 << 20, 2)).astype(np.float32)
+            assert want.dtype == np.float32
+            assert np.array_equal(got[j << 20:(j + 1) << 20].view(np.uint32), want.view(np.uint32)), (gen, k)
+
+
+def full_size_reference(iq_host, p, oracle):
+    """qad / pulse table / flat bits of the CPU side for a full-size capture: the REAL reference's Cython functions (oracle/_ref)
+    when they are built -- afp_demod is an OpenMP prange --, else the C restatement; the tail (pure Python in the reference, a
+    minute at this size) is the C restatement, which tests/test_oracle.py pins against the reference's Python."""
+    import build_ref
+    order = 2 ** p.bits_per_symbol
+    if build_ref.built():
+        sfr = build_ref.import_ref()[0]
+        qad = np.asarray(sfr.afp_demod(iq_host, p.noise_threshold, p.modulation_type, order, p.costas_loop_bandwidth))
+        pp = np.asarray(sfr.grab_pulse_lens(qad, p.center, p.tolerance, p.modulation_type, p.samples_per_symbol, p.bits_per_symbol,
+                                            p.center_spacing))
+    else:
+        qad = oracle.afp_demod(iq_host, p.noise_threshold, p.modulation_type, order, p.costas_loop_bandwidth)
+        pp = oracle.grab_pulse_lens(qad, p.center, p.tolerance, p.modulation_type, p.samples_per_symbol, p.bits_per_symbol, p.center_spacing)
+    flat = oracle.ppseq_to_bits_flat(pp, p.samples_per_symbol, p.bits_per_symbol, True, p.pause_threshold)
+    return qad, pp, flat
+
+
+@pytest.mark.parametrize("variant", ["2", "2b"])
+def test_full_size_fsk_1gib_bit_exact(pipe, oracle, variant):
+    """BASELINE.json configs[1] at FULL size on the bytes SURVEY §8(d) config 2 specifies (variant 2b: bursty, 2 076-sample gaps,
+    noise threshold 0.2, 128 messages): the float32 demodulated signal (uint32 view), the pulse table, the bits, pauses,
+    message offsets and bit_sample_pos of the 2^27-sample capture equal the reference's, element for element."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.synth import spec_fsk_capture
+    segs = 128
+    if variant == "2":
+        iq, tx = spec_fsk_capture(segs, "cuda:0")
+        p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    else:
+        iq, tx = spec_fsk_capture(segs, "cuda:0", seg_len=1 << 20, sps=100, n_symbols=10465)
+        p = DemodParams("FSK", 1, 0.2, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    n = iq.shape[0]
+    assert n == 1 << 27
+    res = pipe.iq_to_bits_checked(iq, p, want_qad=True)
+    rows = res.ppseq()
+    got_flat = res.flat()
+    got_qad = res.qad.cpu().numpy()
+    host = iq.cpu().numpy()
+    del iq
+    qad, pp, flat = full_size_reference(host, p, oracle)
+    assert int((got_qad.view(np.uint32) != qad.view(np.uint32)).sum()) == 0
+    assert np.array_equal(rows, pp), (len(rows), len(pp))
+    for k, (a, b) in enumerate(zip(got_flat, flat)):
+        assert np.array_equal(a, b), (k, len(a), len(b))
+    n_msg = len(flat[2])
+    assert n_msg == (1 if variant == "2" else 128), n_msg
+    # sanity vs the transmitter: bit k of a message starts at sample pos[k]
+    bits, off, pauses, pos, poff = got_flat
+    errors = total = 0
+    for m in range(n_msg):
+        bp = pos[poff[m]:poff[m] + (off[m + 1] - off[m])]
+        seg_of, sym_of = bp // (1 << 20), (bp % (1 << 20) + 50) // 100
+        ok = sym_of < tx.shape[1]
+        errors += int((bits[off[m]:off[m + 1]][ok] != tx[seg_of[ok], sym_of[ok]]).sum())
+        total += int(ok.sum())
+    assert total > 0.99 * tx.size and errors < 1e-3 * total, (total, errors)
 
 
 def test_config3_ook_fir_auto_noise_pipeline(pipe, sf, oracle):

@@ -1,10 +1,13 @@
 """Pin the oracle: against the committed golden vectors (produced by the real reference, see
 tests/golden/make_golden.py), against the reference's own known-answer bit strings, and -- where the
 oracle/_ref build of the real Cython modules is present -- against the reference itself on random input."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_CASES, load_golden, synth_fsk
+from conftest import GOLDEN_CASES, ROOT, load_golden, synth_fsk
 
 
 @pytest.mark.parametrize("name", GOLDEN_CASES)
@@ -162,3 +165,18 @@ def test_oracle_estimators_vs_reference_python(oracle):
         assert (a is None and b is None) or float(a) == float(b), (n, a, b)
         a, b = AI.detect_center(qad, max_size=3000), oracle.detect_center(qad, max_size=3000)
         assert (a is None and b is None) or float(a) == float(b), (n, "max_size", a, b)
+
+
+def test_config1_reference_plumbing_cpu():
+    """BASELINE.json configs[0]: the reference's own tests/test_demodulations.py on the compiled Cython
+    path, CPU only -- the same driver tests/test_reference_dropin.py runs on the GPU box with liburhgpu.so patched in."""
+    import json
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_driver.py"), "--no-patch"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    if out.get("unavailable"):
+        pytest.skip("oracle/_ref not built")
+    assert out["ran"] == 7 and out["failures"] == 0 and out["errors"] == 0, out["details"]
+    assert out["calls"]["afp_demod"] >= 8 and out["calls"]["grab_pulse_lens"] >= 8

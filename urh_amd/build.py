@@ -22,7 +22,8 @@ def _newest_source() -> float:
     t = 0.0
     for root in (CSRC, os.path.join(HERE, "..", "include")):
         for f in os.listdir(root):
-            t = max(t, os.path.getmtime(os.path.join(root, f)))
+            if f.endswith((".hip", ".hpp", ".h")):
+                t = max(t, os.path.getmtime(os.path.join(root, f)))
     return t
 
 
@@ -41,9 +42,9 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), lib: str =
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
         objs.append(obj)
-    for src, pr in procs:
-        if pr.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {src}")
+    failed = [src for src, pr in procs if pr.wait() != 0]     # every job is waited for before raising
+    if failed:
+        raise RuntimeError(f"hipcc failed on {', '.join(failed)}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     subprocess.check_call(cmd)
     return lib

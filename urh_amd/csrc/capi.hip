@@ -42,6 +42,18 @@ struct Plan {                 // how a capture of n samples is cut into chunks
     int64_t slab_stride;
 };
 
+// test hook (urhgpu_test_force_tiles_per_chunk): 0 = size-dependent choice below, 1..4 = that many tiles per chunk
+int g_force_tiles_per_chunk = 0;
+
+// Argument checks shared by every entry point that cuts a capture into chunks or turns rows into bits.  The reference
+// takes `tolerance` as uint16 (OverflowError outside 0..65535, signal_functions.pyx:392) and divides by
+// samples_per_symbol (ZeroDivisionError, ProtocolAnalyzer.py:353); here both are URHGPU_ERR_ARG before anything is launched.
+int check_params(const urhgpu_params *p, bool need_sps) {
+    if (p->tolerance < 0 || p->tolerance > 65535) return URHGPU_ERR_ARG;
+    if (need_sps && (p->samples_per_symbol < 1 || p->bits_per_symbol < 1)) return URHGPU_ERR_ARG;
+    return URHGPU_OK;
+}
+
 Plan make_plan(const urhgpu_ctx *ctx, int64_t n, int tol) {
     Plan pl;
     // whole tiles are grouped into chunks of tiles_per_chunk tiles (one workgroup each); a partial
@@ -49,7 +61,8 @@ Plan make_plan(const urhgpu_ctx *ctx, int64_t n, int tol) {
     const int64_t full_tiles = n / kTile;
     const int64_t target = (int64_t)ctx->prop.multiProcessorCount * 16;      // chunks (four wavefronts each in the bit-plane kernel): ~2 rounds of the resident set
     // at most 4 tiles = 64 rows per chunk: the bit-plane kernel parks one row per lane (kBpMaxRows)
-    const int64_t tiles_per_chunk = std::min<int64_t>(4, std::max<int64_t>(1, (full_tiles + target - 1) / target));
+    int64_t tiles_per_chunk = std::min<int64_t>(4, std::max<int64_t>(1, (full_tiles + target - 1) / target));
+    if (g_force_tiles_per_chunk >= 1 && g_force_tiles_per_chunk <= 4) tiles_per_chunk = g_force_tiles_per_chunk;
     pl.chunk_len = tiles_per_chunk * kTile;
     pl.n_chunks = (full_tiles * kTile + pl.chunk_len - 1) / pl.chunk_len + ((n % kTile) ? 1 : 0);
     pl.slab_stride = pl.chunk_len / ((int64_t)tol + 1) + 2;
@@ -483,6 +496,7 @@ int urhgpu_afp_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urh
 int urhgpu_grab_pulse_lens_dev(urhgpu_ctx *ctx, const float *d_qad, int64_t n, const urhgpu_params *p,
                                int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows) {
     if (!ctx || !p || n < 0 || cap_rows < 0 || !d_n_rows) return URHGPU_ERR_ARG;
+    URH_TRY(check_params(p, false));
     URH_HIP(hipSetDevice(ctx->device));
     URH_TRY(join_tail(ctx));
     if (n == 0) {                                   // signal_functions.pyx:416-417
@@ -528,6 +542,7 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
                           const urhgpu_outputs *out) {
     if (!ctx || !p || !out || n <= 0 || !d_iq || !out->rows || !out->counts) return URHGPU_ERR_ARG;
     if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
+    URH_TRY(check_params(p, out->bits != nullptr));
     if (((uintptr_t)d_iq & 15) || (out->qad && ((uintptr_t)out->qad & 7))) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
     const Plan pl = make_plan(ctx, n, p->tolerance);
@@ -572,6 +587,7 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
         return URHGPU_ERR_ARG;
     if (rank == 0 && pos_base != 0) return URHGPU_ERR_ARG;
     if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
+    URH_TRY(check_params(p, true));
     if (p->mod == URHGPU_MOD_PSK) return URHGPU_ERR_UNSUPPORTED;      // the Costas loop does not shard
     if (((uintptr_t)d_iq & 15) || (out->qad && ((uintptr_t)out->qad & 7))) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
@@ -1091,6 +1107,12 @@ int urhgpu_path_minmax(urhgpu_ctx *ctx, const void *samples, int dtype, int64_t 
 
 int urhgpu_test_force_state_bytes(int on) {
     urh::g_force_state_bytes = (on != 0);
+    return URHGPU_OK;
+}
+
+int urhgpu_test_force_tiles_per_chunk(int tiles) {
+    if (tiles < 0 || tiles > 4) return URHGPU_ERR_ARG;
+    g_force_tiles_per_chunk = tiles;
     return URHGPU_OK;
 }
 

@@ -33,6 +33,14 @@ class DemodParams:
 
     def to_c(self, dtype) -> _lib.Params:
         mod, sentinel = mod_code(self.modulation_type)
+        # the reference's own failures for these inputs: `uint16 tolerance` (signal_functions.pyx:392) raises
+        # OverflowError, `n / samples_per_symbol` (ProtocolAnalyzer.py:353) ZeroDivisionError
+        if not 0 <= int(self.tolerance) <= 65535:
+            raise OverflowError("tolerance must fit an unsigned 16-bit integer")
+        if int(self.samples_per_symbol) < 1:
+            raise ZeroDivisionError("samples_per_symbol must be at least 1")
+        if int(self.bits_per_symbol) < 1:
+            raise ValueError("bits_per_symbol must be at least 1")
         p = _lib.Params()
         p.dtype = dtype_code(dtype)
         p.mod = mod
@@ -92,6 +100,7 @@ class BitsResult:
                                                       f"bits={n_bits} pos={n_pos}")
 
     def ppseq(self) -> np.ndarray:
+        self.check_capacity()             # an overflowing table is clamped to cap_rows on the device: never hand that out
         n_rows = self.host_counts()[0]
         return self.rows_buf[:n_rows].cpu().numpy()
 

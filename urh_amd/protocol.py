@@ -58,6 +58,12 @@ def get_protocol_from_signal_dev(pipe, iq, p, message_length_divisor=1, sample_r
         iq = torch.view_as_real(iq)
     res = pipe.iq_to_bits_checked(iq, p, want_qad=True)
     bit_data, pauses, bit_sample_pos = res.messages()
+    return messages_from_bits(pipe, iq, p, bit_data, pauses, bit_sample_pos, message_length_divisor, sample_rate, timestamp)
+
+
+def messages_from_bits(pipe, iq, p, bit_data, pauses, bit_sample_pos, message_length_divisor=1, sample_rate=1e6, timestamp=0.0):
+    """The per-message part of get_protocol_from_signal (:256-283) for bits that are already on the host."""
+    torch = pipe.torch
     sps = int(p.samples_per_symbol)
     if message_length_divisor > 1 and p.modulation_type == "ASK":
         ensure_message_length_multiple(bit_data, sps, pauses, bit_sample_pos, int(message_length_divisor))

@@ -46,7 +46,9 @@ class TorchDistComm:
         block) and returns the gathered tensor: work enqueued in between overlaps the collective."""
         import torch
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        work = self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group, async_op=True)
+        # gathered as raw bytes: halos of uint16 captures are torch.uint16 tensors, which the nccl / gloo backends do not all take
+        work = self.dist.all_gather_into_tensor(out.view(-1).view(torch.uint8), t.contiguous().view(-1).view(torch.uint8),
+                                                group=self.group, async_op=True)
 
         def wait():
             work.wait()

@@ -1,0 +1,338 @@
+"""`Signal`-level shim: what the reference's `Signal` object promises about the demodulated signal, for a capture that lives in HBM.
+
+Mirrors the behaviour (not the Qt plumbing) of /root/reference/src/urh/signalprocessing/Signal.py:
+
+  * `qad` is computed lazily and cached (:421-431); captures that are already demodulated (mono WAV, Flipper `.sub`) bypass
+    the demodulator -- their "qad" is the real part of the samples (:424-427);
+  * `quad_demod()` returns `zeros(2)` when the noise threshold is at or above the largest possible magnitude of the sample
+    type (:474-484), otherwise `afp_demod(iq, noise_threshold, modulation_type, 2 ** bits_per_symbol, costas_loop_bandwidth)`;
+  * changing modulation_type / bits_per_symbol / costas_loop_bandwidth / noise_threshold drops the cache (:259, :273, :355, :391);
+    center, center_spacing, tolerance, samples_per_symbol, pause_threshold do not (they only steer the slicing);
+  * edits keep the cache consistent: insert -> dropped (:613-617), delete / crop -> sliced (:619-643), mute -> zeroed
+    (:631-636), filter_range -> the range re-demodulated in place (:645-655).
+
+Design difference: the capture and the cache are torch tensors on the GPU and one fused pass (urhgpu_iq_to_bits_dev) yields the
+demodulated signal TOGETHER with the pulse table and the bits, so `get_protocol()` after a parameter change costs one pass
+over the samples, not three.  Nothing here computes on the host: every entry point ends in liburhgpu.so and raises without it.
+"""
+import numpy as np
+
+from . import _lib
+from .pipeline import DemodParams, DevicePipeline, _torch_dtype
+
+_DEMOD_KEYS = ("modulation_type", "bits_per_symbol", "costas_loop_bandwidth", "noise_threshold")
+_SLICE_KEYS = ("center", "center_spacing", "tolerance", "samples_per_symbol", "pause_threshold", "message_length_divisor")
+
+
+def _limits(np_dtype):
+    """IQArray.min_max_for_dtype (IQArray.py:246-250)"""
+    dt = np.dtype(np_dtype)
+    if dt.kind in "fc":
+        return -1, 1
+    info = np.iinfo(dt)
+    return info.min, info.max
+
+
+class Signal:
+    MODULATION_TYPES = ("ASK", "FSK", "PSK", "QAM")
+
+    def __init__(self, iq=None, name="Signal", modulation="FSK", sample_rate=1e6, timestamp=0.0, pipe=None,
+                 already_demodulated=False, device=None):
+        """iq: (N, 2) numpy array / torch tensor of int8, uint8, int16, uint16 or float32, or complex64 (N,); uploaded once."""
+        self.pipe = pipe or DevicePipeline(device)
+        self.name = name
+        self.sample_rate = float(sample_rate)
+        self.timestamp = float(timestamp)
+        self.already_demodulated = bool(already_demodulated)
+        self._par = dict(modulation_type=modulation or "FSK", bits_per_symbol=1, costas_loop_bandwidth=0.1, noise_threshold=0,
+                         center=0, center_spacing=1, tolerance=5, samples_per_symbol=100, pause_threshold=8,
+                         message_length_divisor=1)
+        self._qad = None
+        self._bits = None            # BitsResult of the pass that produced _qad (valid for the slicing parameters in _bits_key)
+        self._bits_key = None
+        self.changed = False
+        self.demod_passes = 0        # passes over the samples so far (tests watch the cache through it)
+        self._iq = None
+        if iq is not None:
+            self.iq = iq
+
+    # ---- samples --------------------------------------------------------------------------------------------------
+    @classmethod
+    def from_file(cls, filename, **kw):
+        """IQArray.from_file by extension (IQArray.py:205-227); mono WAV / .sub are not read here (already_demodulated inputs
+        are handed over as arrays)."""
+        from .iq_array import from_file
+        s = cls(None, **kw)
+        s.iq = from_file(filename, device=s.pipe.device)
+        return s
+
+    @property
+    def iq(self):
+        return self._iq
+
+    @iq.setter
+    def iq(self, value):
+        torch = self.pipe.torch
+        if isinstance(value, np.ndarray):
+            if value.dtype == np.complex64:
+                value = value.view(np.float32).reshape(-1, 2)
+            value = torch.from_numpy(np.ascontiguousarray(value))
+        if value.dtype == torch.complex64:
+            value = torch.view_as_real(value)
+        if value.dim() == 1:                      # IQArray.convert_array_to_iq: flat interleaved, odd tail dropped (:229-243)
+            value = value[: value.numel() // 2 * 2].reshape(-1, 2)
+        _torch_dtype(value)                        # ValueError("Unsupported dtype") as the Cython signatures give
+        self._iq = value.to(self.pipe.device).contiguous()
+        self._drop_cache()
+
+    @property
+    def num_samples(self):
+        return 0 if self._iq is None else int(self._iq.shape[0])
+
+    @property
+    def dtype(self):
+        return _torch_dtype(self._iq)
+
+    @property
+    def max_magnitude(self):                       # Signal.py:407-410
+        lo, hi = _limits(self.dtype)
+        return (2 * max(lo ** 2, hi ** 2)) ** 0.5
+
+    @property
+    def max_amplitude(self):                       # :412-415
+        lo, hi = _limits(self.dtype)
+        return 0.5 * (hi - lo)
+
+    @property
+    def noise_threshold_relative(self):
+        return self.noise_threshold / self.max_magnitude
+
+    @noise_threshold_relative.setter
+    def noise_threshold_relative(self, value):
+        self.noise_threshold = value * self.max_magnitude
+
+    @property
+    def modulation_order(self):
+        return 2 ** self.bits_per_symbol
+
+    # ---- parameters: one generic accessor pair, the key decides what a change invalidates ----------------------------
+    def __getattr__(self, key):
+        par = self.__dict__.get("_par")
+        if par is not None and key in par:
+            return par[key]
+        raise AttributeError(key)
+
+    def __setattr__(self, key, value):
+        par = self.__dict__.get("_par")
+        if par is not None and key in par:
+            if key == "bits_per_symbol":
+                value = int(value)
+            if par[key] != value:
+                par[key] = value
+                if key in _DEMOD_KEYS:
+                    self._drop_cache()
+            return
+        object.__setattr__(self, key, value)
+
+    def params(self) -> DemodParams:
+        p = self._par
+        return DemodParams(p["modulation_type"], int(p["bits_per_symbol"]), float(p["noise_threshold"]), float(p["center"]),
+                           float(p["center_spacing"]), int(p["tolerance"]), int(p["samples_per_symbol"]),
+                           float(p["costas_loop_bandwidth"]), int(p["pause_threshold"]), True)
+
+    def _drop_cache(self):
+        self._qad = None
+        self._bits = None
+        self._bits_key = None
+
+    def _slice_key(self):
+        return tuple(self._par[k] for k in _SLICE_KEYS[:5])
+
+    # ---- demodulated signal -------------------------------------------------------------------------------------------
+    @property
+    def real_plot_data(self):
+        return self._iq[:, 0] if self._iq is not None else self.pipe.torch.zeros(0, dtype=self.pipe.torch.float32, device=self.pipe.device)
+
+    def quad_demod(self):
+        """Signal.quad_demod (:474-484): a fresh demodulation (device tensor), or zeros(2) when everything is below the noise gate."""
+        torch = self.pipe.torch
+        if not (self.noise_threshold < self.max_magnitude):
+            return torch.zeros(2, dtype=torch.float32, device=self.pipe.device)
+        self.demod_passes += 1
+        return self.pipe.afp_demod(self._iq, self.params())
+
+    @property
+    def qad(self):
+        """Signal.qad (:421-431): cached; already-demodulated captures hand back their real part."""
+        if self._qad is None:
+            torch = self.pipe.torch
+            if self.already_demodulated:
+                self._qad = self.real_plot_data.contiguous()
+            elif not (self.noise_threshold < self.max_magnitude) or self.num_samples <= 2 or self.modulation_type not in ("ASK", "FSK"):
+                self._qad = self.quad_demod()
+            else:
+                # ASK / FSK: the fused pass gives qad AND the pulse table / bits for the current slicing parameters
+                self.demod_passes += 1
+                res = self.pipe.iq_to_bits_checked(self._iq, self.params(), want_qad=True)
+                self._qad = res.qad.clone()          # the pipeline's buffers are reused by the next pass
+                self._bits, self._bits_key = self._detach(res), self._slice_key()
+        return self._qad
+
+    @staticmethod
+    def _detach(res):
+        """host copies of the compact outputs (the pipeline's output buffers are overwritten by the next pass)"""
+        return (res.ppseq().copy(),) + tuple(x.copy() for x in res.flat())
+
+    def qad_host(self) -> np.ndarray:
+        return self.qad.cpu().numpy()
+
+    # ---- digitisation ---------------------------------------------------------------------------------------------------
+    def _digitize(self):
+        """(ppseq, bits, msg_off, pauses, pos, pos_off) for the current parameters; re-slices the cached qad when only slicing
+        parameters changed (grab_pulse_lens + _ppseq_to_bits on the device, no new demodulation)."""
+        import ctypes as C
+        q = self.qad
+        if self._bits is not None and self._bits_key == self._slice_key():
+            return self._bits
+        torch = self.pipe.torch
+        if q.dtype != torch.float32:
+            raise ValueError("Buffer dtype mismatch, expected 'float' (grab_pulse_lens takes float[::1])")
+        p = self.params()
+        n = int(q.shape[0])
+        if n == 0:
+            z = np.zeros(0, np.int64)
+            return (np.zeros((0, 2), np.int64), np.zeros(0, np.uint8), np.zeros(1, np.int64), z, z, np.zeros(1, np.int64))
+        pipe = self.pipe
+        cp = p.to_c(np.float32)
+        cap_rows = n // (p.tolerance + 1) + 2
+        cap_rows, cap_bits, cap_msg, cap_pos = pipe.capacities(n, p, cap_rows)
+        rows = pipe._buf("sig:rows", (cap_rows, 2), torch.int64)
+        n_rows = pipe._buf("sig:n_rows", (1,), torch.int64)
+        pipe.ctx.set_stream(torch.cuda.current_stream(pipe.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_grab_pulse_lens_dev(pipe.ctx.handle, C.c_void_p(q.data_ptr()), n, C.byref(cp),
+                                                          C.c_void_p(rows.data_ptr()), cap_rows, C.c_void_p(n_rows.data_ptr())))
+        o = _lib.Outputs()
+        bits = pipe._buf("sig:bits", (cap_bits,), torch.uint8)
+        msg_off = pipe._buf("sig:msg_off", (cap_msg + 1,), torch.int64)
+        pauses = pipe._buf("sig:pauses", (cap_msg,), torch.int64)
+        pos_off = pipe._buf("sig:pos_off", (cap_msg + 1,), torch.int64)
+        pos = pipe._buf("sig:pos", (cap_pos,), torch.int64)
+        counts = pipe._buf("sig:counts", (5,), torch.int64)
+        o.qad = None
+        o.rows = rows.data_ptr(); o.cap_rows = cap_rows
+        o.bits = bits.data_ptr(); o.cap_bits = cap_bits
+        o.msg_off = msg_off.data_ptr(); o.pauses = pauses.data_ptr(); o.cap_msg = cap_msg
+        o.pos = pos.data_ptr(); o.cap_pos = cap_pos; o.pos_off = pos_off.data_ptr(); o.counts = counts.data_ptr()
+        _lib.check(_lib.load().urhgpu_ppseq_to_bits_dev(pipe.ctx.handle, C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr()),
+                                                        cap_rows, C.byref(cp), C.byref(o)))
+        c = counts.cpu().numpy()
+        nr = int(n_rows.cpu().numpy()[0])
+        n_msg, n_bits, n_pos = int(c[1]), int(c[2]), int(c[3])
+        if n_msg > cap_msg or n_bits > cap_bits or n_pos > cap_pos:
+            raise _lib.UrhGpuError(_lib.ERR_CAPACITY, "output capacity too small")
+        out = (rows[:nr].cpu().numpy(), bits[:n_bits].cpu().numpy(), msg_off[:n_msg + 1].cpu().numpy(), pauses[:n_msg].cpu().numpy(),
+               pos[:n_pos].cpu().numpy(), pos_off[:n_msg + 1].cpu().numpy())
+        self._bits, self._bits_key = out, self._slice_key()
+        return out
+
+    def ppseq(self) -> np.ndarray:
+        """signal_functions.grab_pulse_lens(signal.qad, center, tolerance, modulation_type, samples_per_symbol, bits_per_symbol,
+        center_spacing) as ProtocolAnalyzer.get_protocol_from_signal calls it (ProtocolAnalyzer.py:236-244)."""
+        return self._digitize()[0]
+
+    def bits(self):
+        """(bit_data, pauses, bit_sample_pos) exactly as ProtocolAnalyzer._ppseq_to_bits returns them (:323-414)."""
+        import array
+        _, b, off, pauses, pos, poff = self._digitize()
+        data = [array.array("B", b[off[i]:off[i + 1]].tobytes()) for i in range(len(pauses))]
+        return data, array.array("L", pauses.tolist()), [array.array("L", pos[poff[i]:poff[i + 1]].tolist()) for i in range(len(pauses))]
+
+    def plain_bits_str(self):
+        return ["".join(map(str, m)) for m in self.bits()[0]]
+
+    def get_protocol(self):
+        """ProtocolAnalyzer.get_protocol_from_signal (:227-287): MessageData per message (bits, pause, RSSI, timestamp, positions)."""
+        from .protocol import messages_from_bits
+        data, pauses, bsp = self.bits()
+        return messages_from_bits(self.pipe, self._iq, self.params(), data, pauses, bsp, int(self.message_length_divisor),
+                                  self.sample_rate, self.timestamp)
+
+    # ---- parameter estimation -----------------------------------------------------------------------------------------------
+    def auto_detect(self, detect_modulation=True, detect_noise=False) -> bool:
+        """Signal.auto_detect (:537-577): AutoInterpretation.estimate on the device-resident capture, parameters applied as the
+        reference applies them (noise and modulation only when asked for; center, tolerance, samples_per_symbol always)."""
+        from .estimators import estimate_dev
+        modulation = None if detect_modulation else ("OOK" if self.bits_per_symbol == 1 and self.modulation_type == "ASK"
+                                                     else self.modulation_type)
+        est = estimate_dev(self.pipe, self._iq, noise=None if detect_noise else self.noise_threshold, modulation=modulation)
+        if est is None:
+            return False
+        if detect_noise:
+            self.noise_threshold = est["noise"]
+        if detect_modulation:
+            self.modulation_type = est["modulation_type"]
+        self.center = est["center"]
+        self.tolerance = est["tolerance"]
+        self.samples_per_symbol = est["bit_length"]
+        return True
+
+    # ---- edits ------------------------------------------------------------------------------------------------------------
+    def _after_edit(self):
+        self._bits = None
+        self._bits_key = None
+        self.changed = True
+
+    def insert_data(self, index: int, data):
+        torch = self.pipe.torch
+        d = torch.from_numpy(np.ascontiguousarray(data)).to(self.pipe.device) if isinstance(data, np.ndarray) else data
+        self._iq = torch.cat([self._iq[:index], d.to(self._iq.dtype).reshape(-1, 2), self._iq[index:]]).contiguous()
+        self._qad = None
+        self._after_edit()
+
+    def delete_range(self, start: int, end: int):
+        torch = self.pipe.torch
+        self._iq = torch.cat([self._iq[:start], self._iq[end:]]).contiguous()
+        if self._qad is not None:
+            self._qad = torch.cat([self._qad[:start], self._qad[end:]]).contiguous()
+        self._after_edit()
+
+    def mute_range(self, start: int, end: int):
+        self._iq[start:end] = 0
+        if self._qad is not None:
+            self._qad[start:end] = 0
+        self._after_edit()
+
+    def crop_to_range(self, start: int, end: int):
+        self._iq = self._iq[start:end].contiguous()
+        if self._qad is not None:
+            self._qad = self._qad[start:end].contiguous()
+        self._after_edit()
+
+    def filter_range(self, start: int, end: int, taps):
+        """Signal.filter_range (:645-655) with Filter.work's FIR branch (Filter.py:31-46): the range is filtered on its own (zero
+        history), written back in the capture's sample type, and qad[start:end] becomes afp_demod of the filtered range ALONE
+        (so its first sample is the NOISE value, as in the reference)."""
+        import ctypes as C
+        torch = self.pipe.torch
+        _ = self.qad                                  # the reference indexes self._qad: it must exist
+        seg = self._iq[start:end]
+        n = int(seg.shape[0])
+        if n == 0:
+            return
+        from .iq_array import convert_to
+        x = convert_to(seg.clone(), np.float32, self.pipe.ctx)          # a copy: 16-byte aligned whatever `start` is
+        h = np.ascontiguousarray(taps, dtype=np.complex64)
+        d_h = torch.from_numpy(h.view(np.float32).copy()).to(self.pipe.device)
+        y = torch.empty_like(x)
+        self.pipe.ctx.set_stream(torch.cuda.current_stream(self.pipe.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_fir_filter_dev(self.pipe.ctx.handle, C.c_void_p(x.data_ptr()), n, C.c_void_p(d_h.data_ptr()),
+                                                     len(h), None, C.c_void_p(y.data_ptr())))
+        if seg.dtype != torch.float32:
+            y = convert_to(y, self.dtype, self.pipe.ctx)
+        self._iq[start:end] = y
+        if self._qad.shape[0] == self.num_samples:        # (a zeros(2) cache cannot take the range: the reference raises there too)
+            self.demod_passes += 1
+            self._qad[start:end] = self.pipe.afp_demod(self._iq[start:end].clone(), self.params())
+        else:
+            raise ValueError("could not broadcast the demodulated range into a cache of shape ({},)".format(int(self._qad.shape[0])))
+        self._after_edit()
