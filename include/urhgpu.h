@@ -356,6 +356,11 @@ int urhgpu_bgra_lookup_dev(urhgpu_ctx *ctx, const float *d_db, int64_t frames, i
  * state-byte kernel as well, so that tests can compare the two on the same input.  Process-wide. */
 int urhgpu_test_force_state_bytes(int on);
 
+/* Test hook: single-GPU captures of every modulation but ASK go from chunk records to bits through the five-launch "tile"
+ * tail; on != 0 routes them through the generic tail (the one ASK and sharded captures use) so that tests can compare the two
+ * on the same input.  Process-wide. */
+int urhgpu_test_force_generic_tail(int on);
+
 /* Test hook: the chunk plan normally depends on the capture size (1 tile = 16 rows of 128 samples per chunk below
  * about 8 M samples, 4 tiles = 64 rows -- every lane of the run phase populated, four wavefronts exchanging bit planes
  * through LDS -- above about 25 M).  tiles = 1..4 forces that many tiles per chunk for every size, so that small

@@ -533,6 +533,53 @@ def test_many_huge_rows_expand(pipe, oracle, bps):
     assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
 
 
+@pytest.mark.parametrize("bps,stretches", [(1, 300), (2, 300), (1, 9000)])
+def test_tile_tail_huge_rows_fsk(pipe, oracle, bps, stretches):
+    """The tile tail's own huge-row path (rows of more than 4096 bits are listed while the rows are written and expanded by extra
+    workgroups of the expansion launch): constant-frequency stretches of 4 500-9 000 symbols at one sample per symbol, 2-FSK and
+    4-FSK, against the oracle; 9 000 stretches overflow the 8 192-entry list (every wavefront then expands its own rows)."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    rng = np.random.default_rng(190 + bps + stretches)
+    lo, hi = (4500, 9000) if stretches < 1000 else (4200, 4700)
+    steps = [-0.5, 0.5] if bps == 1 else [-0.6, -0.2, 0.2, 0.6]
+    L = len(steps)
+    f = np.concatenate([np.concatenate([np.full(int(rng.integers(lo, hi)), steps[k % L]), np.full(int(rng.integers(1, 4)), steps[(k + L // 2 + (L == 2)) % L])])
+                        for k in range(stretches)])
+    n = len(f)
+    ph = np.cumsum(f)
+    iq = (np.stack([np.cos(ph), np.sin(ph)], 1) + 0.002 * rng.standard_normal((n, 2))).astype(np.float32)
+    center, spacing = (0.0, 1.0) if bps == 1 else (0.0, 0.4)
+    p = DemodParams("FSK", bps, 0.0, center, spacing, 0, 1, 0.1, 8, True)
+    qad = oracle.afp_demod(iq, 0.0, "FSK", 1 << bps)
+    pp = oracle.grab_pulse_lens(qad, center, 0, "FSK", 1, bps, spacing)
+    assert (pp[:, 1] * bps > 4096).sum() >= 0.95 * stretches
+    fb = oracle.ppseq_to_bits_flat(pp, 1, bps, True, 8)
+    dev = torch.from_numpy(iq).cuda()
+    for _ in range(3):                              # consecutive passes alternate the two huge-row counters
+        res = pipe.iq_to_bits(dev, p, want_qad=True, cap_rows=n + 2)
+        assert np.array_equal(res.ppseq(), pp)
+        assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
+    # a rows-only pass in between must not disturb the counters
+    from urh_amd import signal_functions as sf
+    assert np.array_equal(sf.grab_pulse_lens(qad, center, 0, "FSK", 1, bps, spacing), pp)
+    res = pipe.iq_to_bits(dev, p, want_qad=False, cap_rows=n + 2)
+    assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat()))
+
+
+def test_generic_tail_still_equals_oracle(pipe, oracle):
+    """Single-GPU FSK captures normally take the tile tail; the generic tail (ASK, sharded captures) stays covered for them too:
+    the same fuzz and medium captures with the tile tail switched off."""
+    from urh_amd import _lib
+    lib = _lib.load()
+    lib.urhgpu_test_force_generic_tail(1)
+    try:
+        test_fused_randomised_vs_oracle(pipe, oracle, cases=120)
+        test_fused_equals_oracle_medium(pipe, oracle, "FSK")
+    finally:
+        lib.urhgpu_test_force_generic_tail(0)
+
+
 def test_filters_equal_reference_goldens(sf):
     """The real reference's fir_filter / iir_filter outputs (tests/golden/filter/fir_iir.npz) through the C ABI."""
     import os

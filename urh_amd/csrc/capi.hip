@@ -42,6 +42,9 @@ struct Plan {                 // how a capture of n samples is cut into chunks
     int64_t slab_stride;
 };
 
+// test hook (urhgpu_test_force_generic_tail): 0 routes single-GPU non-ASK captures through the generic 8-launch tail as well
+bool g_tile_tail = true;
+
 // test hook (urhgpu_test_force_tiles_per_chunk): 0 = size-dependent choice below, 1..4 = that many tiles per chunk
 int g_force_tiles_per_chunk = 0;
 
@@ -78,6 +81,7 @@ size_t digitize_scratch_bytes(const Plan &pl, int64_t cap_rows, bool ask, bool b
     b += align256((size_t)(pl.n_chunks + kMaxWorld) * sizeof(ChunkInfo));
     b += align256((size_t)pl.n_chunks * pl.slab_stride * 8);
     b += align256(resolve_scratch_bytes(pl.n_chunks + kMaxWorld)) + 2 * 256;
+    b += align256(tile_tail_bytes(pl.n_chunks)) + 256;
     if (ask) b += align256((size_t)cap_rows * 16) + align256(merge_scratch_bytes(cap_rows));
     if (bits) b += align256(bits_scratch_bytes(cap_rows));
     b += 4096;
@@ -147,8 +151,10 @@ int prof_end_record(urhgpu_ctx *ctx, hipStream_t s) {
 
 int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const urhgpu_params *p, float *d_qad,
              int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows, int64_t *d_n_rows_needed, int64_t *d_n_acc,
-             const Plan &pl, int seg_mode = 0, hipStream_t s_tail = nullptr) {
+             const Plan &pl, int seg_mode = 0, hipStream_t s_tail = nullptr, const BitsParams *tile_bp = nullptr,
+             TileTailMem *tile_out = nullptr) {
     hipStream_t s = ctx->stream;
+    if (tile_out) tile_out->mem = nullptr;
     RunArgs a;
     memset(&a, 0, sizeof(a));
     URH_TRY(fill_thresholds(a, p));
@@ -203,6 +209,17 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     e.sc = rsc;
     e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
     e.rows = rows_stage; e.cap_rows = cap_rows; e.d_ts_carry = nullptr; e.is_ask = ask ? 1 : 0; e.sps = p->samples_per_symbol;
+    if (!ask && g_tile_tail) {
+        // tile tail: one composed scan instead of three, rows + their bit aggregates in one pass (pulse_table.hip)
+        TileTailMem tm;
+        tm.mem = ctx->arena.take(tile_tail_bytes(pl.n_chunks));
+        tm.n_chunks = pl.n_chunks; tm.huge_count = ctx->d_tickets + 8; tm.parity = tile_out ? (ctx->tile_parity ^= 1) : ctx->tile_parity;   // only passes that expand bits consume a counter
+        if (!tm.mem) return URHGPU_ERR_ARG;
+        URH_TRY(launch_tile_rows(r, e, tm, tile_out ? tile_bp : nullptr, s));
+        if (tile_out) *tile_out = tm;
+        URH_HIP(hipGetLastError());
+        return URHGPU_OK;
+    }
     URH_TRY(launch_resolve_emit_single(r, e, s));
     if (ask) URH_TRY(launch_merge_rows_ask(rows_stage, d_n_stage, cap_rows, d_rows, cap_rows, d_n_rows, merge_scratch, ctx->d_tickets, s));
     URH_HIP(hipGetLastError());
@@ -324,8 +341,8 @@ int urhgpu_ctx_create(int device, urhgpu_ctx **out) {
     URH_HIP(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     URH_HIP(hipMalloc((void **)&ctx->d_counts, 16 * sizeof(int64_t)));
-    URH_HIP(hipMalloc((void **)&ctx->d_tickets, 8 * sizeof(int32_t)));
-    URH_HIP(hipMemset(ctx->d_tickets, 0, 4 * sizeof(int32_t)));
+    URH_HIP(hipMalloc((void **)&ctx->d_tickets, 16 * sizeof(int32_t)));     // [0..3] elections, [4..7] ResolveAux, [8..9] tile tail's huge-row counters
+    URH_HIP(hipMemset(ctx->d_tickets, 0, 16 * sizeof(int32_t)));
     {   // d_tickets[4..7] is the ResolveAux block of the resolve kernels: kAuxNone x3, -1
         const int32_t aux0[4] = {kAuxNone, kAuxNone, kAuxNone, -1};
         URH_HIP(hipMemcpy(ctx->d_tickets + 4, aux0, sizeof(aux0), hipMemcpyHostToDevice));
@@ -553,25 +570,39 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
     URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, out->cap_rows, ask, true) + (out->qad ? 0 : align256((size_t)n * 4))));
     ctx->arena.reset();
     int64_t *d_n_rows = ctx->d_counts + 10;
+    const bool want_bits = out->bits && out->msg_off && out->pauses && out->pos_off;
+    BitsParams tile_bp = bits_params(p);
+    tile_bp.d_rows_needed = ctx->d_counts + 8;
+    TileTailMem tile;
+    tile.mem = nullptr;
     if (!fused) {
         // no fused kernel: demodulate (zeros for n <= 2, Costas loop for PSK), then segment the qad
         float *qad = out->qad;
         if (!qad) { qad = (float *)ctx->arena.take((size_t)n * 4); if (!qad) return URHGPU_ERR_ARG; }
         URH_TRY(urhgpu_afp_demod_dev(ctx, d_iq, n, p, qad));
         URH_TRY(digitize(ctx, false, qad, n, p, nullptr, out->rows, out->cap_rows, d_n_rows, ctx->d_counts + 8,
-                         ctx->d_counts + 9, pl));
+                         ctx->d_counts + 9, pl, 0, nullptr, want_bits ? &tile_bp : nullptr, want_bits ? &tile : nullptr));
     } else {
         URH_TRY(digitize(ctx, true, d_iq, n, p, out->qad, out->rows, out->cap_rows, d_n_rows, ctx->d_counts + 8,
-                         ctx->d_counts + 9, pl, 0, piped ? ctx->tail_stream : nullptr));
+                         ctx->d_counts + 9, pl, 0, piped ? ctx->tail_stream : nullptr, want_bits ? &tile_bp : nullptr,
+                         want_bits ? &tile : nullptr));
     }
     int st = URHGPU_OK;
-    if (out->bits && out->msg_off && out->pauses && out->pos_off) {          // else: pulse table only
+    if (want_bits) {                                                         // else: pulse table only
         const int64_t cap = std::max<int64_t>(out->cap_rows, 1);
         void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
         if (!scratch) return URHGPU_ERR_ARG;
         hipStream_t caller = ctx->stream;
         if (piped) ctx->stream = ctx->tail_stream;
-        st = ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch, ctx->d_counts + 8);
+        if (tile.mem) {
+            BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts};
+            ScanState ss;
+            st = scan_state(ctx, std::max<int64_t>(cap, pl.n_chunks + 1), &ss);
+            if (st == URHGPU_OK) st = launch_tile_bits(tile, out->rows, d_n_rows, cap, tile_bp, bo, scratch, ss, ctx->stream);
+            if (st == URHGPU_OK && hipGetLastError() != hipSuccess) st = URHGPU_ERR_HIP;
+        } else {
+            st = ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch, ctx->d_counts + 8);
+        }
         ctx->stream = caller;
     }
     if (piped) URH_TRY(end_pipelined_pass(ctx));
@@ -1107,6 +1138,11 @@ int urhgpu_path_minmax(urhgpu_ctx *ctx, const void *samples, int dtype, int64_t 
 
 int urhgpu_test_force_state_bytes(int on) {
     urh::g_force_state_bytes = (on != 0);
+    return URHGPU_OK;
+}
+
+int urhgpu_test_force_generic_tail(int on) {
+    g_tile_tail = (on == 0);
     return URHGPU_OK;
 }
 

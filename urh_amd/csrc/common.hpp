@@ -83,4 +83,5 @@ struct urhgpu_ctx {
     hipEvent_t ev_tail[2] = {nullptr, nullptr};
     int flip = 0;
     bool tail_pending = false;
+    int tile_parity = 0;           // which of the two huge-row counters (d_tickets[8..9]) the current pass appends to
 };

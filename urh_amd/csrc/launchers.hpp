@@ -197,6 +197,17 @@ int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t ca
                         void *scratch, int64_t *d_flags, const ScanState &ss, hipStream_t s);
 int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
                        const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
+// Tile tail (single GPU, not ASK): resolve + rows in two launches, bits in three more; see pulse_table.hip.
+struct TileTailMem {
+    void *mem;               // tile_tail_bytes(n_chunks) of scratch that lives from launch_tile_rows to launch_tile_bits
+    int64_t n_chunks;
+    int32_t *huge_count;     // 2 persistent ints of the context, zero between passes
+    int parity;              // which of the two this pass uses (alternates)
+};
+size_t tile_tail_bytes(int64_t n_chunks);
+int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams *bp, hipStream_t s);
+int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                     const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
 // ASK, sharded: summary of the locally merged table {n_rows, first state, first length, last state, last length}
 void launch_merge_summary(const int64_t *rows, const int64_t *d_n_rows, int64_t *d_out5, hipStream_t s);
 // ASK, sharded: merge equal-state rows across shard boundaries (d_all: world x 5 int64)

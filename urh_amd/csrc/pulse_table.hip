@@ -624,6 +624,432 @@ __global__ __launch_bounds__(256) void k_expand_huge(const ExpandArgs a) {
     }
 }
 
+
+// =====================================================================================================
+// Single-GPU tail for everything but ASK ("tile" tail): five launches from chunk records to bits.
+//
+//   k_resolve_one      per chunk: does its trailing short run turn stable (chunk_stable)?  Then ONE scan instead of the three
+//                      dependent ones above: what a chunk does to the pulse table is a function of the stable state it is entered
+//                      with, and these functions compose associatively (ResElem), so a single prefix composition yields, per
+//                      chunk, the stable state before it, the number of accepted runs before it and the last accepted run
+//                      before it.  Workgroup-local exclusive prefixes + one total per workgroup (no workgroup waits for another).
+//   k_emit_rows_tiles  one wavefront per chunk: folds the workgroup totals before its own (a few dozen 32-byte values), writes
+//                      the chunk's rows and -- the rows being in registers anyway -- what they contribute to _ppseq_to_bits
+//                      (bits, long pauses, samples, data rows: a VecK<4> per chunk, the chunk being a TILE of the row table);
+//                      one more wavefront writes the totals, the table's last row and the last (one-row) tile.
+//   tile scan          k_scan_lookback<4> over the 16 K tile aggregates (a handful of workgroups): exclusive prefix per tile; the
+//                      few tiles that hold a long pause (or the table's last row) are walked for their GroupInfo.
+//   group scan         k_scan_lookback<3> as in the generic path.
+//   k_expand_tiles     one wavefront per tile: re-reads its rows (16 B each), a wave scan places every row's bits and positions;
+//                      rows longer than kHugeBits bits were listed by k_emit_rows_tiles and are expanded by extra workgroups of
+//                      the same launch.
+// Against the generic path (resolve a / b, rows, row-scan reduce + apply, group scan, expand, expand-huge: 8 launches, two of them
+// passes over a 24-byte-per-row side table with 1.3 wavefronts per SIMD) this drops the RowInfo table, three launches and every
+// under-occupied pass.  ASK (rows merge across chunks after the short-pause rule) and sharded captures keep the generic path.
+// =====================================================================================================
+struct ResElem {             // effect of a stretch of chunks on the reference's state machine, as a function of the entry state
+    int64_t cnt;             // accepted runs, not counting the conditional first one
+    int64_t first_pos;       // position of the first stable run (meaningful while nothing else has been accepted)
+    int64_t la_pos;          // last run that is accepted whatever the entry state
+    uint64_t meta;           // first_state | last_state << 16 | la_state << 32 | has << 48 | la_valid << 49
+    __device__ __forceinline__ bool has() const { return (meta >> 48) & 1; }
+    __device__ __forceinline__ bool la_valid() const { return (meta >> 49) & 1; }
+    __device__ __forceinline__ uint32_t first_state() const { return (uint32_t)(meta & 0xFFFF); }
+    __device__ __forceinline__ uint32_t last_state() const { return (uint32_t)((meta >> 16) & 0xFFFF); }
+    __device__ __forceinline__ uint32_t la_state() const { return (uint32_t)((meta >> 32) & 0xFFFF); }
+};
+__device__ __forceinline__ ResElem res_identity() { ResElem e; e.cnt = 0; e.first_pos = -1; e.la_pos = -1; e.meta = 0; return e; }
+__device__ __forceinline__ ResElem res_make(uint32_t first_state, int64_t first_pos, uint32_t last_state, int64_t cnt, bool la_valid,
+                                            int64_t la_pos, uint32_t la_state) {
+    ResElem e;
+    e.cnt = cnt; e.first_pos = first_pos; e.la_pos = la_pos;
+    e.meta = (uint64_t)(first_state & 0xFFFF) | ((uint64_t)(last_state & 0xFFFF) << 16) | ((uint64_t)(la_state & 0xFFFF) << 32) |
+             (1ull << 48) | ((uint64_t)(la_valid ? 1 : 0) << 49);
+    return e;
+}
+// a, then b
+__device__ __forceinline__ ResElem res_combine(const ResElem &a, const ResElem &b) {
+    if (!a.has()) return b;
+    if (!b.has()) return a;
+    const bool acc = b.first_state() != a.last_state();        // b's first stable run switches the state machine
+    if (b.la_valid()) return res_make(a.first_state(), a.first_pos, b.last_state(), a.cnt + b.cnt + (acc ? 1 : 0), true, b.la_pos, b.la_state());
+    if (acc) return res_make(a.first_state(), a.first_pos, b.last_state(), a.cnt + b.cnt + 1, true, b.first_pos, b.first_state());
+    return res_make(a.first_state(), a.first_pos, b.last_state(), a.cnt + b.cnt, a.la_valid(), a.la_pos, a.la_state());
+}
+__device__ __forceinline__ ResElem res_shfl_up(const ResElem &x, int o) {
+    ResElem r;
+    r.cnt = __shfl_up(x.cnt, o); r.first_pos = __shfl_up(x.first_pos, o); r.la_pos = __shfl_up(x.la_pos, o);
+    r.meta = (uint64_t)__shfl_up((long long)x.meta, o);
+    return r;
+}
+__device__ __forceinline__ ResElem res_shfl(const ResElem &x, int src) {
+    ResElem r;
+    r.cnt = __shfl(x.cnt, src); r.first_pos = __shfl(x.first_pos, src); r.la_pos = __shfl(x.la_pos, src);
+    r.meta = (uint64_t)__shfl((long long)x.meta, src);
+    return r;
+}
+__device__ __forceinline__ ResElem res_wave_incl_scan(ResElem x, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const ResElem u = res_shfl_up(x, o);
+        if (lane >= o) x = res_combine(u, x);
+    }
+    return x;
+}
+// the stable runs of one chunk as an element (after chunk_stable has settled its pending run)
+__device__ __forceinline__ ResElem res_of_chunk(const ChunkInfo &ci, int pend_stable) {
+    const int cnt = ci.cnt;
+    const bool pend_in = pend_stable && (cnt == 0 || ci.pend_state != ci.last_state);   // the pending run is a further stable run
+    const int k = cnt + (pend_in ? 1 : 0);
+    if (k == 0) return res_identity();
+    const uint32_t first_state = cnt > 0 ? ci.first_state : ci.pend_state;
+    const int64_t last_pos = pend_in ? ci.pend_pos : ci.last_pos;
+    const uint32_t last_state = pend_in ? ci.pend_state : ci.last_state;
+    // k == 1: the only stable run IS the first one (cnt == 1: last_pos is record 0's position)
+    return res_make(first_state, k == 1 ? last_pos : -1, last_state, k - 1, k >= 2, last_pos, last_state);
+}
+
+struct TileTail {            // scratch of the tile tail (carved from the context's arena)
+    ResElem *ploc;           // [n_chunks] exclusive prefix inside the chunk's resolve workgroup
+    ResElem *btot;           // [resolve workgroups] totals
+    VecK<4> *agg;            // [n_chunks + 1] per tile: (bits, long pauses, samples, data rows) of its rows
+    VecK<4> *excl;           // [n_chunks + 1] exclusive prefix of agg (tile scan)
+    int64_t *tile_off;       // [n_chunks + 1] first row of the tile
+    int32_t *tile_cnt;       // [n_chunks + 1] rows in the tile
+    int64_t *d_n_tiles;      // = n_chunks + 1 (device copy for the scan kernel)
+    int32_t *huge_count;     // [2] persistent, alternating by pass parity; zero between uses
+    int parity;
+    int want_bits;
+};
+
+__global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs a, const TileTail ft) {
+    __shared__ ResElem s_w[kResolveBlock / 64];
+    const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    ResElem e = res_identity();
+    if (c < a.n_chunks) {
+        (void)chunk_stable(a, c);                                   // writes ch[c].pend_stable
+        e = res_of_chunk(a.chunks[c], a.chunks[c].pend_stable);
+    }
+    const ResElem incl = res_wave_incl_scan(e, lane);
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    ResElem base = res_identity(), tot = res_identity();
+#pragma unroll
+    for (int w = 0; w < kResolveBlock / 64; ++w) {
+        if (w < wave) base = res_combine(base, s_w[w]);
+        tot = res_combine(tot, s_w[w]);
+    }
+    ResElem ex = res_shfl_up(incl, 1);
+    if (lane == 0) ex = res_identity();
+    ex = res_combine(base, ex);
+    if (c < a.n_chunks) ft.ploc[c] = ex;
+    if (t == 0) ft.btot[blockIdx.x] = tot;
+}
+
+// composition of btot[0 .. count) by one wavefront, in order (every lane gets it)
+__device__ __forceinline__ ResElem res_fold_blocks(const ResElem *btot, int64_t count, int lane) {
+    ResElem carry = res_identity();
+    for (int64_t u0 = 0; u0 < count; u0 += 64) {
+        ResElem x = res_identity();
+        if (u0 + lane < count) x = btot[u0 + lane];
+        x = res_wave_incl_scan(x, lane);
+        carry = res_combine(carry, res_shfl(x, 63));
+    }
+    return carry;
+}
+
+// What one row contributes to _ppseq_to_bits (ProtocolAnalyzer.py:346-401): v[0] bits, v[1] long pause, v[2] samples, v[3] data row
+__device__ __forceinline__ VecK<4> row_value(int64_t type, int64_t len, bool global_row0, const BitsParams &bp) {
+    VecK<4> v; v.zero();
+    v.v[2] = len;
+    if (type == kRowAbsorbed) return v;
+    if (global_row0 && type == -1) return v;             // "Starts with Pause" (:346-348): only seeds total_samples
+    const int64_t ns = num_symbols_of(len, bp.sps);
+    if (type == -1) {
+        if (ns <= bp.pause_threshold || bp.pause_threshold == 0) v.v[0] = (ns > 0) ? ns * bp.bps : 0;
+        else v.v[1] = 1;
+    } else {
+        v.v[0] = (ns > 0) ? ns * bp.bps : 0;
+        v.v[3] = (ns > 0) ? 1 : 0;
+    }
+    return v;
+}
+
+struct HugeRef { int64_t tile, row; };                   // a row of more than kHugeBits bits, found while the rows were emitted
+
+struct EmitTileArgs {
+    EmitArgs e;
+    ResolveArgs r;
+    TileTail ft;
+    BitsParams bp;
+    HugeRef *huge;
+    int32_t huge_cap;
+};
+
+__global__ __launch_bounds__(64) void k_emit_rows_tiles(const EmitTileArgs g) {
+    const EmitArgs &a = g.e;
+    const ResolveArgs &r = g.r;
+    const int64_t c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t init_state = a.chunks[0].init_state;
+    const ResElem init = res_make(init_state, -1, init_state, 0, false, -1, 0);
+    if (c == r.n_chunks) {
+        // totals, the table's last row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487), last tile
+        const ResElem tot = res_combine(init, res_fold_blocks(g.ft.btot, resolve_blocks(r.n_chunks), lane));
+        if (lane == 0) {
+            const int64_t P = tot.cnt;
+            *r.d_n_acc = P;
+            int64_t n_rows = P;
+            VecK<4> v; v.zero();
+            int32_t tcnt = 0;
+            if (P < r.n_total && r.write_last_row) {
+                n_rows = P + 1;
+                tcnt = 1;
+                const int64_t fpos = tot.la_valid() ? tot.la_pos : -1;
+                const uint32_t fstate = tot.la_valid() ? tot.la_state() : init_state;
+                const int64_t len = (P == 0) ? (r.n_total - r.tol) : (r.n_total - 1 - fpos - r.tol);
+                if (r.rows != nullptr && P < r.cap_rows) { r.rows[2 * P] = (int64_t)fstate - 1; r.rows[2 * P + 1] = len; }
+                if (g.ft.want_bits) {
+                    v = row_value((int64_t)fstate - 1, len, P == 0, g.bp);
+                    if (v.v[0] > kHugeBits) {
+                        const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
+                        if (slot < g.huge_cap) g.huge[slot] = HugeRef{c, P};
+                    }
+                }
+            }
+            *r.d_n_rows_needed = n_rows;
+            *r.d_n_rows = (r.rows != nullptr && n_rows > r.cap_rows) ? r.cap_rows : n_rows;
+            g.ft.agg[c] = v; g.ft.tile_off[c] = P; g.ft.tile_cnt[c] = tcnt;
+            *g.ft.d_n_tiles = r.n_chunks + 1;
+        }
+        return;
+    }
+    // state machine before this chunk: init, the resolve workgroups before mine, the chunks before me in my workgroup
+    ResElem pre = res_combine(init, res_fold_blocks(g.ft.btot, c / kResolveBlock, lane));
+    pre = res_combine(pre, g.ft.ploc[c]);
+    const ChunkInfo ci = a.chunks[c];
+    const uint32_t prev_state = pre.last_state();
+    const int first_acc = (ci.cnt > 0) && (ci.first_state != prev_state);
+    const uint32_t before_pend = (ci.cnt > 0) ? ci.last_state : prev_state;
+    const int pend_acc = ci.pend_stable && (ci.pend_state != before_pend);
+    const int skip = (ci.cnt > 0 && !first_acc) ? 1 : 0;
+    const int64_t from_slab = (ci.cnt > 0) ? ci.cnt - skip : 0;
+    const int64_t total = from_slab + pend_acc;
+    const int64_t out_off = pre.cnt;
+    VecK<4> acc; acc.zero();
+    if (total > 0) {
+        const uint64_t *slab = a.slab + c * a.slab_stride;
+        const int64_t prev_pos = pre.la_valid() ? pre.la_pos : -1;
+        const uint32_t prev_st = pre.la_valid() ? pre.la_state() : init_state;
+        for (int64_t j = lane; j < total; j += 64) {
+            const int64_t pos = (j < from_slab) ? rec_pos(slab[j + skip]) : ci.pend_pos;
+            int64_t ppos; uint32_t pst;
+            if (j == 0) { ppos = prev_pos; pst = prev_st; }
+            else { const uint64_t rr = slab[j - 1 + skip]; ppos = rec_pos(rr); pst = rec_state(rr); }
+            const int64_t gi = out_off + j;
+            const int64_t len = (gi == 0) ? pos + 1 : pos - ppos;
+            const int64_t state = (int64_t)pst - 1;
+            if (gi < a.cap_rows) *(longlong2 *)(a.rows + 2 * gi) = longlong2{(long long)state, (long long)len};
+            if (g.ft.want_bits) {
+                const VecK<4> v = row_value(state, len, gi == 0, g.bp);
+                acc.add(v);
+                if (v.v[0] > kHugeBits) {
+                    const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
+                    if (slot < g.huge_cap) g.huge[slot] = HugeRef{c, gi};
+                }
+            }
+        }
+    }
+    if (g.ft.want_bits) acc = wave_sum_vec<4>(acc);
+    if (lane == 0) { g.ft.agg[c] = acc; g.ft.tile_off[c] = out_off; g.ft.tile_cnt[c] = (int32_t)total; }
+}
+
+// ---- tile scan: exclusive prefix per tile; GroupInfo of the tiles that hold a long pause or the table's last row -------
+struct TileAggLoad {
+    const VecK<4> *agg;
+    __device__ VecK<4> operator()(int64_t t) const { return agg[t]; }
+};
+struct TileStore {
+    const int64_t *rows;
+    const int64_t *d_n_rows;
+    const int64_t *tile_off;
+    const int32_t *tile_cnt;
+    VecK<4> *excl;
+    GroupInfo *groups;
+    int64_t cap_groups;
+    BitsParams bp;
+    __device__ void operator()(int64_t t, const VecK<4> &val, const VecK<4> &ex) const {
+        excl[t] = ex;
+        const int64_t n = *d_n_rows;
+        const int64_t off = tile_off[t];
+        int64_t end = off + tile_cnt[t];
+        if (end > n) end = n;
+        if (end <= off) return;
+        if (val.v[1] == 0 && end != n) return;              // no long pause here and not the table's last row
+        VecK<4> run = ex;
+        for (int64_t i = off; i < end; ++i) {
+            const int64_t type = rows[2 * i], len = rows[2 * i + 1];
+            const VecK<4> v = row_value(type, len, i == 0, bp);
+            if (v.v[1] && run.v[1] < cap_groups) {          // long pause: closes group run.v[1]
+                GroupInfo gi;
+                gi.bits_end = run.v[0]; gi.data_end = run.v[3]; gi.ts_close = run.v[2]; gi.pause = len; gi.closed = 1; gi.pad = 0;
+                groups[run.v[1]] = gi;
+            }
+            if (i + 1 == n && run.v[1] + v.v[1] < cap_groups) {   // trailing group
+                GroupInfo gi;
+                gi.bits_end = run.v[0] + v.v[0]; gi.data_end = run.v[3] + v.v[3]; gi.ts_close = run.v[2] + v.v[2];
+                gi.pause = (type == -1) ? len : 0;          // :411
+                gi.closed = 0; gi.pad = 0;
+                groups[run.v[1] + v.v[1]] = gi;
+            }
+            run.add(v);
+        }
+    }
+};
+struct TileGroupCount {
+    const int64_t *d_n_rows;
+    int64_t *d_n_groups;
+    int64_t cap_groups;
+    __device__ void operator()(const VecK<4> &grand) const {
+        const int64_t n = *d_n_rows;
+        int64_t g = (n > 0) ? grand.v[1] + 1 : 0;
+        if (g > cap_groups) g = cap_groups;
+        *d_n_groups = g;
+    }
+};
+
+struct ExpandTileArgs {
+    const int64_t *rows;
+    const int64_t *d_n_rows;
+    const VecK<4> *excl;
+    const int64_t *tile_off;
+    const int32_t *tile_cnt;
+    const GroupOut *gout;
+    const int64_t *d_n_groups;
+    uint8_t *bits; int64_t cap_bits;
+    int64_t *pos; int64_t cap_pos;
+    BitsParams bp;
+    const HugeRef *huge;
+    int32_t *huge_count;     // [2]
+    int32_t huge_cap;
+    int parity;
+    int64_t n_tiles;
+};
+constexpr unsigned kHugeBlocksX = 16, kHugeBlocksY = 16;
+
+// one wavefront per tile; workgroups beyond the tiles expand the listed huge rows, kHugeBlocksX workgroups per row
+__global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = *a.d_n_rows;
+    const int bps = (int)a.bp.bps;
+    const int64_t tile_blocks = (a.n_tiles + 3) / 4;
+    if ((int64_t)blockIdx.x >= tile_blocks) {
+        // ---- huge rows ----
+        const int64_t hb = (int64_t)blockIdx.x - tile_blocks;
+        const int hx = (int)(hb % kHugeBlocksX), hy = (int)(hb / kHugeBlocksX);
+        if (hb == 0 && threadIdx.x == 0) a.huge_count[a.parity ^ 1] = 0;       // the other parity's counter: free for the next pass
+        int cnt = a.huge_count[a.parity];
+        if (cnt > a.huge_cap) cnt = 0;                      // list overflowed: the tiles' own wavefronts expand every row
+        __shared__ int64_t s_h[5];
+        for (int w = hy; w < cnt; w += kHugeBlocksY) {
+            const HugeRef h = a.huge[w];
+            __syncthreads();
+            if (wave == 0) {
+                // prefix of the row inside its tile: walk the tile's rows before it, 64 at a time
+                VecK<4> run = a.excl[h.tile];
+                const int64_t off = a.tile_off[h.tile];
+                for (int64_t i0 = off; i0 <= h.row; i0 += 64) {
+                    const int64_t i = i0 + lane;
+                    VecK<4> v; v.zero();
+                    if (i < h.row && i < n) v = row_value(a.rows[2 * i], a.rows[2 * i + 1], i == 0, a.bp);
+                    run.add(wave_sum_vec<4>(v));
+                }
+                if (lane == 0) {
+                    int64_t kb = 0, ob = 0, op = 0, ty = 0;
+                    if (h.row < n && run.v[1] < *a.d_n_groups) {
+                        const GroupOut go = a.gout[run.v[1]];
+                        if (go.is_msg) {
+                            ty = a.rows[2 * h.row];
+                            kb = row_value(ty, a.rows[2 * h.row + 1], h.row == 0, a.bp).v[0];
+                            ob = go.out_bits + (run.v[0] - go.bits_start);
+                            op = go.out_pos + (run.v[0] - go.bits_start);
+                        }
+                    }
+                    s_h[0] = kb; s_h[1] = ob; s_h[2] = op; s_h[3] = run.v[2]; s_h[4] = ty;
+                }
+            }
+            __syncthreads();
+            const int64_t kb = s_h[0], ob = s_h[1], op = s_h[2], ts = s_h[3], ty = s_h[4];
+            for (int64_t k = (int64_t)hx * blockDim.x + threadIdx.x; k < kb; k += (int64_t)kHugeBlocksX * blockDim.x) {
+                const int sh = (bps == 1) ? 0 : bps - 1 - (int)(k % bps);
+                const uint8_t b = (ty < 0) ? 0 : (uint8_t)((ty >> sh) & 1);
+                if (ob + k < a.cap_bits) a.bits[ob + k] = b;
+                if (a.bp.write_pos && op + k < a.cap_pos) a.pos[op + k] = ts + k * a.bp.samples_per_bit;
+            }
+        }
+        return;
+    }
+    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
+    if (t >= a.n_tiles) return;
+    const int64_t off = a.tile_off[t];
+    int64_t end = off + a.tile_cnt[t];
+    if (end > n) end = n;
+    if (end <= off) return;
+    VecK<4> run = a.excl[t];
+    const int64_t n_groups = *a.d_n_groups;
+    const int64_t own_limit = (a.huge_count[a.parity] > a.huge_cap) ? INT64_MAX : kHugeBits;   // longer rows are on the list
+    for (int64_t i0 = off; i0 < end; i0 += 64) {
+        const int64_t i = i0 + lane;
+        VecK<4> v; v.zero();
+        int64_t type = 0;
+        if (i < end) {
+            const longlong2 row = *(const longlong2 *)(a.rows + 2 * i);
+            type = row.x;
+            v = row_value(type, row.y, i == 0, a.bp);
+        }
+        const VecK<4> incl = wave_incl_scan_vec<4>(v, lane);
+        int64_t kb = 0, ob = 0, op = 0, ts = 0;
+        if (i < end && v.v[0] > 0 && v.v[0] <= own_limit) {
+            const int64_t grp = run.v[1] + incl.v[1] - v.v[1];
+            if (grp < n_groups) {
+                const GroupOut go = a.gout[grp];
+                if (go.is_msg) {
+                    const int64_t bit_prefix = run.v[0] + incl.v[0] - v.v[0];
+                    kb = v.v[0];
+                    ob = go.out_bits + (bit_prefix - go.bits_start);
+                    op = go.out_pos + (bit_prefix - go.bits_start);
+                    ts = run.v[2] + incl.v[2] - v.v[2];
+                }
+            }
+        }
+        constexpr int kShort = 16;
+        if (kb > 0 && kb <= kShort) {
+            for (int64_t k = 0; k < kb; ++k) {
+                const uint8_t b = (type < 0) ? 0 : (uint8_t)((type >> (bps - 1 - (int)(k % bps))) & 1);
+                if (ob + k < a.cap_bits) a.bits[ob + k] = b;
+                if (a.bp.write_pos && op + k < a.cap_pos) a.pos[op + k] = ts + k * a.bp.samples_per_bit;
+            }
+        }
+        unsigned long long big = __ballot(kb > kShort);
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const int64_t kb_s = __shfl(kb, src), ob_s = __shfl(ob, src), op_s = __shfl(op, src), ts_s = __shfl(ts, src),
+                          ty_s = __shfl(type, src);
+            for (int64_t k = lane; k < kb_s; k += 64) {
+                const uint8_t b = (ty_s < 0) ? 0 : (uint8_t)((ty_s >> (bps - 1 - (int)(k % bps))) & 1);
+                if (ob_s + k < a.cap_bits) a.bits[ob_s + k] = b;
+                if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
+            }
+        }
+        VecK<4> tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tot.v[k] = __shfl(incl.v[k], 63);
+        run.add(tot);
+    }
+}
+
 // ---- host-side launchers ---------------------------------------------------------------------------
 int launch_resolve(const ResolveArgs &a, int32_t *tickets, hipStream_t s) {
     if (a.n_chunks <= 0) return URHGPU_ERR_ARG;
@@ -782,6 +1208,80 @@ int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t c
                          const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s) {
     URH_TRY(launch_bits_prepare(rows, d_n_rows, cap_rows, bp, scratch, nullptr, ss, s));
     return launch_bits_finish(rows, d_n_rows, cap_rows, bp, o, scratch, ss, s);
+}
+
+
+// ---- tile tail: host side ----------------------------------------------------------------------------------------------
+namespace {
+constexpr int kTileHugeCap = 8192;
+struct TileCarve { TileTail ft; HugeRef *huge; };
+TileCarve carve_tile(const TileTailMem &m) {
+    TileCarve tc;
+    char *p = (char *)m.mem;
+    auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~size_t(255); return r; };
+    const int64_t nt = m.n_chunks + 1;
+    tc.ft.ploc = (ResElem *)take((size_t)m.n_chunks * sizeof(ResElem));
+    tc.ft.btot = (ResElem *)take((size_t)(resolve_blocks(m.n_chunks) + 1) * sizeof(ResElem));
+    tc.ft.agg = (VecK<4> *)take((size_t)nt * sizeof(VecK<4>));
+    tc.ft.excl = (VecK<4> *)take((size_t)nt * sizeof(VecK<4>));
+    tc.ft.tile_off = (int64_t *)take((size_t)nt * 8);
+    tc.ft.tile_cnt = (int32_t *)take((size_t)nt * 4);
+    tc.ft.d_n_tiles = (int64_t *)take(64);
+    tc.huge = (HugeRef *)take((size_t)kTileHugeCap * sizeof(HugeRef));
+    tc.ft.huge_count = m.huge_count;
+    tc.ft.parity = m.parity;
+    tc.ft.want_bits = 0;
+    return tc;
+}
+}  // namespace
+
+size_t tile_tail_bytes(int64_t n_chunks) {
+    const int64_t nt = n_chunks + 1;
+    return (size_t)n_chunks * sizeof(ResElem) + (size_t)(resolve_blocks(n_chunks) + 1) * sizeof(ResElem) + (size_t)nt * (2 * sizeof(VecK<4>) + 12) +
+           64 + (size_t)kTileHugeCap * sizeof(HugeRef) + 10 * 256;
+}
+
+// resolve + rows (+ per-tile bit aggregates when bp != nullptr) of a single-GPU, non-ASK capture: two launches
+int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams *bp, hipStream_t s) {
+    if (r.n_chunks <= 0 || r.local_pass || r.chunk_first != 0 || r.n_local != r.n_chunks || e.chunk_first != 0 || e.is_ask) return URHGPU_ERR_ARG;
+    TileCarve tc = carve_tile(m);
+    EmitTileArgs g;
+    g.e = e; g.r = r; g.ft = tc.ft; g.huge = tc.huge; g.huge_cap = kTileHugeCap;
+    memset(&g.bp, 0, sizeof(g.bp));
+    if (bp) { g.bp = *bp; g.ft.want_bits = 1; }
+    const unsigned gb = (unsigned)resolve_blocks(r.n_chunks);
+    hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft);
+    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)(r.n_chunks + 1)), dim3(64), 0, s, g);
+    return URHGPU_OK;
+}
+
+// bits / pauses / bit_sample_pos from the tiles launch_tile_rows left behind: tile scan, group scan, expansion
+int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                     const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s) {
+    if (cap_rows <= 0) cap_rows = 1;
+    const int64_t nt = m.n_chunks + 1;
+    if (ss.desc_bytes < bits_desc_bytes(std::max(cap_rows, nt))) return URHGPU_ERR_ARG;
+    const TileCarve tc = carve_tile(m);
+    const BitsScratch b = carve_bits(scratch, cap_rows);
+    const int64_t cap_groups = cap_rows + 1;
+    const int64_t nbt = scan_blocks(nt);
+    ScanDesc<4> *desc4 = (ScanDesc<4> *)ss.desc;
+    ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(scan_blocks(std::max(cap_rows, nt)) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
+    TileAggLoad tl{tc.ft.agg};
+    TileStore ts{rows, d_n_rows, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, bp};
+    TileGroupCount tf{d_n_rows, b.d_n_groups, cap_groups};
+    hipLaunchKernelGGL((k_scan_lookback<4, TileAggLoad, TileStore, TileGroupCount>), dim3((unsigned)nbt), dim3(kScanBlock), 0, s,
+                       tc.ft.d_n_tiles, tl, desc4, nbt, ts, tf, ++*ss.epoch, ss.tickets + 2, 0);
+    GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
+    GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
+    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};
+    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s,
+                       b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
+    ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, b.d_n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
+                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt};
+    const unsigned tile_blocks = (unsigned)((nt + 3) / 4);
+    hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(256), 0, s, ea);
+    return URHGPU_OK;
 }
 
 // ---- sharded captures: the tiny cross-shard fix-ups (one thread each; world <= a few dozen) ---------------
