@@ -215,6 +215,15 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
         tm.mem = ctx->arena.take(tile_tail_bytes(pl.n_chunks));
         tm.n_chunks = pl.n_chunks; tm.huge_count = ctx->d_tickets + 8; tm.parity = tile_out ? (ctx->tile_parity ^= 1) : ctx->tile_parity;   // only passes that expand bits consume a counter
         if (!tm.mem) return URHGPU_ERR_ARG;
+        const size_t rd = tile_rdesc_bytes(pl.n_chunks);
+        if (rd > ctx->rdesc_cap) {
+            if (ctx->d_rdesc) { URH_HIP(hipFree(ctx->d_rdesc)); ctx->d_rdesc = nullptr; ctx->rdesc_cap = 0; }
+            const size_t want = (rd + 65535) & ~size_t(65535);
+            URH_HIP(hipMalloc(&ctx->d_rdesc, want));
+            URH_HIP(hipMemset(ctx->d_rdesc, 0, want));
+            ctx->rdesc_cap = want;
+        }
+        tm.rdesc = ctx->d_rdesc; tm.epoch = ++ctx->scan_epoch;
         URH_TRY(launch_tile_rows(r, e, tm, tile_out ? tile_bp : nullptr, s));
         if (tile_out) *tile_out = tm;
         URH_HIP(hipGetLastError());
@@ -369,6 +378,7 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
     if (ctx->d_tickets) (void)hipFree(ctx->d_tickets);
     if (ctx->d_desc) (void)hipFree(ctx->d_desc);
+    if (ctx->d_rdesc) (void)hipFree(ctx->d_rdesc);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -597,7 +607,7 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
         if (tile.mem) {
             BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts};
             ScanState ss;
-            st = scan_state(ctx, std::max<int64_t>(cap, pl.n_chunks + 1), &ss);
+            st = scan_state(ctx, tile_desc_cap(cap, pl.n_chunks), &ss);
             if (st == URHGPU_OK) st = launch_tile_bits(tile, out->rows, d_n_rows, cap, tile_bp, bo, scratch, ss, ctx->stream);
             if (st == URHGPU_OK && hipGetLastError() != hipSuccess) st = URHGPU_ERR_HIP;
         } else {

@@ -62,6 +62,8 @@ struct urhgpu_ctx {
     int32_t *d_tickets = nullptr;  // 8 zeroed ints: elections of the fused scan kernels (scan.hpp)
     void *d_desc = nullptr;        // descriptors of the single-pass scans: dedicated, zeroed when (re)allocated
     size_t desc_cap = 0;
+    void *d_rdesc = nullptr;       // look-back descriptors of the tile tail's resolve scan (same regime)
+    size_t rdesc_cap = 0;
     // pass counter carried by the descriptor flags; starts far above anything a count or a position can be, so that memory
     // that held other values (another descriptor layout) can never look like a flag of the current pass
     unsigned long long scan_epoch = 0x0ACE0FBA5E000000ull;

@@ -203,8 +203,12 @@ struct TileTailMem {
     int64_t n_chunks;
     int32_t *huge_count;     // 2 persistent ints of the context, zero between passes
     int parity;              // which of the two this pass uses (alternates)
+    void *rdesc;             // tile_rdesc_bytes(n_chunks) of persistent, initially zeroed memory: look-back descriptors of the resolve scan
+    unsigned long long epoch; // pass counter carried by their flags (never repeats on a context)
 };
+size_t tile_rdesc_bytes(int64_t n_chunks);
 size_t tile_tail_bytes(int64_t n_chunks);
+int64_t tile_desc_cap(int64_t cap_rows, int64_t n_chunks);
 int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams *bp, hipStream_t s);
 int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
                      const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);

@@ -364,7 +364,15 @@ __global__ void k_merge_finish(const VecK<2> *grand_total, const int64_t *grp_st
 //   groups   : stretches of rows between L rows; a group with at least one D row is a message.
 // =====================================================================================================
 __device__ __forceinline__ int64_t num_symbols_of(int64_t num_samples, int64_t sps) {
-    // int(n / sps) (+1 when the fractional part exceeds 0.5), in double like the Python source (:353-358)
+    // int(n / sps) (+1 when the fractional part exceeds 0.5), in double like the Python source (:353-358).
+    // Below 2^32 the double quotient's floor and the sign of (fraction - 0.5) are those of the exact quotient (the nearest
+    // quotients to an integer or to a half differ from it by >= 1 / (2 sps) > 2^-33, against a rounding error < 2^-52 * 2^32):
+    // integer form q + (2 r > sps), one 32-bit division.
+    if ((((uint64_t)num_samples | (uint64_t)sps) >> 32) == 0) {
+        const uint32_t n32 = (uint32_t)num_samples, s32 = (uint32_t)sps;
+        const uint32_t q = n32 / s32, r = n32 - q * s32;
+        return (int64_t)q + ((2ull * r > s32) ? 1 : 0);
+    }
     const double f = (double)num_samples / (double)sps;
     int64_t k = (int64_t)f;
     if (f - (double)k > 0.5) k += 1;
@@ -667,19 +675,33 @@ __device__ __forceinline__ ResElem res_make(uint32_t first_state, int64_t first_
              (1ull << 48) | ((uint64_t)(la_valid ? 1 : 0) << 49);
     return e;
 }
-// a, then b
+// a, then b.  Written as per-field selects: returning one of several structs makes the compiler build them in scratch memory.
 __device__ __forceinline__ ResElem res_combine(const ResElem &a, const ResElem &b) {
-    if (!a.has()) return b;
-    if (!b.has()) return a;
+    const bool ah = a.has(), bh = b.has();
     const bool acc = b.first_state() != a.last_state();        // b's first stable run switches the state machine
-    if (b.la_valid()) return res_make(a.first_state(), a.first_pos, b.last_state(), a.cnt + b.cnt + (acc ? 1 : 0), true, b.la_pos, b.la_state());
-    if (acc) return res_make(a.first_state(), a.first_pos, b.last_state(), a.cnt + b.cnt + 1, true, b.first_pos, b.first_state());
-    return res_make(a.first_state(), a.first_pos, b.last_state(), a.cnt + b.cnt, a.la_valid(), a.la_pos, a.la_state());
+    const bool blv = b.la_valid();
+    const int64_t both_cnt = a.cnt + b.cnt + (acc ? 1 : 0);
+    const int64_t both_la_pos = blv ? b.la_pos : (acc ? b.first_pos : a.la_pos);
+    const uint64_t both_la_state = blv ? b.la_state() : (acc ? b.first_state() : a.la_state());
+    const uint64_t both_lav = (blv || acc || a.la_valid()) ? 1 : 0;
+    const uint64_t both_meta = (uint64_t)a.first_state() | ((uint64_t)b.last_state() << 16) | (both_la_state << 32) | (1ull << 48) | (both_lav << 49);
+    ResElem r;
+    r.cnt = !ah ? b.cnt : (!bh ? a.cnt : both_cnt);
+    r.first_pos = !ah ? b.first_pos : a.first_pos;
+    r.la_pos = !ah ? b.la_pos : (!bh ? a.la_pos : both_la_pos);
+    r.meta = !ah ? b.meta : (!bh ? a.meta : both_meta);
+    return r;
 }
 __device__ __forceinline__ ResElem res_shfl_up(const ResElem &x, int o) {
     ResElem r;
     r.cnt = __shfl_up(x.cnt, o); r.first_pos = __shfl_up(x.first_pos, o); r.la_pos = __shfl_up(x.la_pos, o);
     r.meta = (uint64_t)__shfl_up((long long)x.meta, o);
+    return r;
+}
+__device__ __forceinline__ ResElem res_shfl_down(const ResElem &x, int o) {
+    ResElem r;
+    r.cnt = __shfl_down(x.cnt, o); r.first_pos = __shfl_down(x.first_pos, o); r.la_pos = __shfl_down(x.la_pos, o);
+    r.meta = (uint64_t)__shfl_down((long long)x.meta, o);
     return r;
 }
 __device__ __forceinline__ ResElem res_shfl(const ResElem &x, int src) {
@@ -697,14 +719,14 @@ __device__ __forceinline__ ResElem res_wave_incl_scan(ResElem x, int lane) {
     return x;
 }
 // the stable runs of one chunk as an element (after chunk_stable has settled its pending run)
-__device__ __forceinline__ ResElem res_of_chunk(const ChunkInfo &ci, int pend_stable) {
-    const int cnt = ci.cnt;
-    const bool pend_in = pend_stable && (cnt == 0 || ci.pend_state != ci.last_state);   // the pending run is a further stable run
+__device__ __forceinline__ ResElem res_of_chunk(int cnt, uint32_t c_first_state, uint32_t c_last_state, uint32_t c_pend_state, int64_t c_last_pos,
+                                                int64_t c_pend_pos, int pend_stable) {
+    const bool pend_in = pend_stable && (cnt == 0 || c_pend_state != c_last_state);   // the pending run is a further stable run
     const int k = cnt + (pend_in ? 1 : 0);
     if (k == 0) return res_identity();
-    const uint32_t first_state = cnt > 0 ? ci.first_state : ci.pend_state;
-    const int64_t last_pos = pend_in ? ci.pend_pos : ci.last_pos;
-    const uint32_t last_state = pend_in ? ci.pend_state : ci.last_state;
+    const uint32_t first_state = cnt > 0 ? c_first_state : c_pend_state;
+    const int64_t last_pos = pend_in ? c_pend_pos : c_last_pos;
+    const uint32_t last_state = pend_in ? c_pend_state : c_last_state;
     // k == 1: the only stable run IS the first one (cnt == 1: last_pos is record 0's position)
     return res_make(first_state, k == 1 ? last_pos : -1, last_state, k - 1, k >= 2, last_pos, last_state);
 }
@@ -720,16 +742,39 @@ struct TileTail {            // scratch of the tile tail (carved from the contex
     int32_t *huge_count;     // [2] persistent, alternating by pass parity; zero between uses
     int parity;
     int want_bits;
+    GranDesc *rdesc;         // look-back descriptors of k_resolve_one (persistent, tagged with the pass number)
+    unsigned long long epoch;
 };
 
+// The kernels below are latency chains of a few memory round trips on a nearly idle chip, not bandwidth: every load whose
+// address does not depend on loaded data is issued BEFORE the first use of any of them (measured: the same kernels written in
+// natural order spent 9 us per wavefront in 5 serialised round trips).
 __global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs a, const TileTail ft) {
     __shared__ ResElem s_w[kResolveBlock / 64];
     const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     ResElem e = res_identity();
     if (c < a.n_chunks) {
-        (void)chunk_stable(a, c);                                   // writes ch[c].pend_stable
-        e = res_of_chunk(a.chunks[c], a.chunks[c].pend_stable);
+        ChunkInfo *ch = a.chunks + c;
+        // everything of this chunk, and -- speculatively -- the next chunk's leading stretch, in one round trip
+        const int64_t pend_pos = ch->pend_pos, start = ch->start, len = ch->len, last_pos = ch->last_pos;
+        const int cnt = ch->cnt;
+        const uint32_t first_state = ch->first_state, last_state = ch->last_state, pend_state = ch->pend_state;
+        const bool has_next = c + 1 < a.n_chunks;
+        int64_t lead = has_next ? ch[1].lead : 0, nlen = has_next ? ch[1].len : 1;
+        // does the trailing short run grow past `tol` in the following chunks (chunk_stable, single-GPU form)
+        int ps = 0;
+        if (pend_pos >= 0) {
+            int64_t run = start + len - pend_pos;
+            for (int64_t u = c + 1; run <= a.tol && u < a.n_chunks; ++u) {
+                if (u > c + 1) { lead = a.chunks[u].lead; nlen = a.chunks[u].len; }
+                run += lead;
+                if (lead < nlen) break;
+            }
+            ps = run > a.tol;
+        }
+        ch->pend_stable = ps;
+        e = res_of_chunk(cnt, first_state, last_state, pend_state, last_pos, pend_pos, ps);
     }
     const ResElem incl = res_wave_incl_scan(e, lane);
     if (lane == 63) s_w[wave] = incl;
@@ -743,16 +788,16 @@ __global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs
     ResElem ex = res_shfl_up(incl, 1);
     if (lane == 0) ex = res_identity();
     ex = res_combine(base, ex);
-    if (c < a.n_chunks) ft.ploc[c] = ex;
-    if (t == 0) ft.btot[blockIdx.x] = tot;
+    if (c < a.n_chunks) ft.ploc[c] = ex;                  // exclusive prefix inside this workgroup
+    if (t == 0) ft.btot[blockIdx.x] = tot;                // consumers compose the totals of the workgroups before theirs
 }
 
-// composition of btot[0 .. count) by one wavefront, in order (every lane gets it)
-__device__ __forceinline__ ResElem res_fold_blocks(const ResElem *btot, int64_t count, int lane) {
+// composition of btot[0 .. count) by one wavefront, in order (every lane gets it); `first` = btot[lane] already loaded
+__device__ __forceinline__ ResElem res_fold_blocks(const ResElem *btot, int64_t count, int lane, ResElem first) {
     ResElem carry = res_identity();
     for (int64_t u0 = 0; u0 < count; u0 += 64) {
-        ResElem x = res_identity();
-        if (u0 + lane < count) x = btot[u0 + lane];
+        ResElem x = first;
+        if (u0 > 0) { x = res_identity(); if (u0 + lane < count) x = btot[u0 + lane]; }
         x = res_wave_incl_scan(x, lane);
         carry = res_combine(carry, res_shfl(x, 63));
     }
@@ -777,6 +822,7 @@ __device__ __forceinline__ VecK<4> row_value(int64_t type, int64_t len, bool glo
 }
 
 struct HugeRef { int64_t tile, row; };                   // a row of more than kHugeBits bits, found while the rows were emitted
+constexpr int kEmitWaves = 8;                           // chunks per workgroup of k_emit_rows_tiles (one wavefront each)
 
 struct EmitTileArgs {
     EmitArgs e;
@@ -787,18 +833,51 @@ struct EmitTileArgs {
     int32_t huge_cap;
 };
 
-__global__ __launch_bounds__(64) void k_emit_rows_tiles(const EmitTileArgs g) {
+__global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitTileArgs g) {
     const EmitArgs &a = g.e;
     const ResolveArgs &r = g.r;
-    const int64_t c = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int64_t c = (int64_t)blockIdx.x * kEmitWaves + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const bool is_chunk = c < r.n_chunks;
+    const bool idle = c > r.n_chunks;                     // wavefronts beyond the last tile only take part in the barrier
+    // ---- one round trip: everything this wavefront reads ----
+    // resolve workgroups composed on the left: the same for every chunk of this workgroup (kResolveBlock % kEmitWaves == 0) except
+    // for the totals wavefront, which takes them all.  Wavefront 0 composes them for the others (a look-back inside k_resolve_one
+    // that would hand every chunk its global prefix costs 5 us there; every wavefront composing for itself 11 us here).
+    static_assert(kResolveBlock % kEmitWaves == 0, "chunks of one emit workgroup share their resolve workgroup");
+    __shared__ ResElem s_fold;
+    const int wave = threadIdx.x >> 6;
+    const int64_t n_before = is_chunk ? c / kResolveBlock : resolve_blocks(r.n_chunks);
     const uint32_t init_state = a.chunks[0].init_state;
+    ResElem first = res_identity();
+    const bool totals = c == r.n_chunks;
+    const bool folds = (wave == 0 && is_chunk) || totals;
+    if (folds && lane < n_before) first = g.ft.btot[lane];
+    ResElem pl = res_identity();
+    int cnt = 0, pend_stable = 0;
+    uint32_t c_first = 0, c_last = 0, c_pend = 0;
+    int64_t pend_pos = -1;
+    uint64_t rec = 0;
+    const uint64_t *slab = a.slab + c * a.slab_stride;
+    if (is_chunk) {
+        pl = g.ft.ploc[c];
+        const ChunkInfo *ch = a.chunks + c;
+        cnt = ch->cnt; pend_stable = ch->pend_stable; c_first = ch->first_state; c_last = ch->last_state; c_pend = ch->pend_state;
+        pend_pos = ch->pend_pos;
+        if (lane < a.slab_stride) rec = slab[lane];                  // speculative: the first 64 records (those beyond cnt are ignored)
+    }
     const ResElem init = res_make(init_state, -1, init_state, 0, false, -1, 0);
-    if (c == r.n_chunks) {
+    ResElem fold = res_identity();
+    if (folds) fold = res_fold_blocks(g.ft.btot, n_before, lane, first);
+    if (wave == 0 && lane == 0) s_fold = fold;          // (a totals wavefront in slot 0 has no chunk wavefronts behind it)
+    __syncthreads();
+    if (idle) return;
+    if (is_chunk) fold = s_fold;
+    const ResElem pre = res_combine(res_combine(init, fold), pl);      // state machine before this chunk (totals wavefront: at the end)
+    if (!is_chunk) {
         // totals, the table's last row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487), last tile
-        const ResElem tot = res_combine(init, res_fold_blocks(g.ft.btot, resolve_blocks(r.n_chunks), lane));
         if (lane == 0) {
-            const int64_t P = tot.cnt;
+            const int64_t P = pre.cnt;
             *r.d_n_acc = P;
             int64_t n_rows = P;
             VecK<4> v; v.zero();
@@ -806,58 +885,60 @@ __global__ __launch_bounds__(64) void k_emit_rows_tiles(const EmitTileArgs g) {
             if (P < r.n_total && r.write_last_row) {
                 n_rows = P + 1;
                 tcnt = 1;
-                const int64_t fpos = tot.la_valid() ? tot.la_pos : -1;
-                const uint32_t fstate = tot.la_valid() ? tot.la_state() : init_state;
+                const int64_t fpos = pre.la_valid() ? pre.la_pos : -1;
+                const uint32_t fstate = pre.la_valid() ? pre.la_state() : init_state;
                 const int64_t len = (P == 0) ? (r.n_total - r.tol) : (r.n_total - 1 - fpos - r.tol);
                 if (r.rows != nullptr && P < r.cap_rows) { r.rows[2 * P] = (int64_t)fstate - 1; r.rows[2 * P + 1] = len; }
                 if (g.ft.want_bits) {
                     v = row_value((int64_t)fstate - 1, len, P == 0, g.bp);
                     if (v.v[0] > kHugeBits) {
                         const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
-                        if (slot < g.huge_cap) g.huge[slot] = HugeRef{c, P};
+                        if (slot < g.huge_cap) { g.huge[slot].tile = c; g.huge[slot].row = P; }
                     }
                 }
             }
             *r.d_n_rows_needed = n_rows;
             *r.d_n_rows = (r.rows != nullptr && n_rows > r.cap_rows) ? r.cap_rows : n_rows;
             g.ft.agg[c] = v; g.ft.tile_off[c] = P; g.ft.tile_cnt[c] = tcnt;
-            *g.ft.d_n_tiles = r.n_chunks + 1;
         }
         return;
     }
-    // state machine before this chunk: init, the resolve workgroups before mine, the chunks before me in my workgroup
-    ResElem pre = res_combine(init, res_fold_blocks(g.ft.btot, c / kResolveBlock, lane));
-    pre = res_combine(pre, g.ft.ploc[c]);
-    const ChunkInfo ci = a.chunks[c];
     const uint32_t prev_state = pre.last_state();
-    const int first_acc = (ci.cnt > 0) && (ci.first_state != prev_state);
-    const uint32_t before_pend = (ci.cnt > 0) ? ci.last_state : prev_state;
-    const int pend_acc = ci.pend_stable && (ci.pend_state != before_pend);
-    const int skip = (ci.cnt > 0 && !first_acc) ? 1 : 0;
-    const int64_t from_slab = (ci.cnt > 0) ? ci.cnt - skip : 0;
+    const int first_acc = (cnt > 0) && (c_first != prev_state);
+    const uint32_t before_pend = (cnt > 0) ? c_last : prev_state;
+    const int pend_acc = pend_stable && (c_pend != before_pend);
+    const int skip = (cnt > 0 && !first_acc) ? 1 : 0;
+    const int64_t from_slab = (cnt > 0) ? cnt - skip : 0;
     const int64_t total = from_slab + pend_acc;
     const int64_t out_off = pre.cnt;
+    const int64_t prev_pos = pre.la_valid() ? pre.la_pos : -1;
+    const uint32_t prev_st = pre.la_valid() ? pre.la_state() : init_state;
     VecK<4> acc; acc.zero();
-    if (total > 0) {
-        const uint64_t *slab = a.slab + c * a.slab_stride;
-        const int64_t prev_pos = pre.la_valid() ? pre.la_pos : -1;
-        const uint32_t prev_st = pre.la_valid() ? pre.la_state() : init_state;
-        for (int64_t j = lane; j < total; j += 64) {
-            const int64_t pos = (j < from_slab) ? rec_pos(slab[j + skip]) : ci.pend_pos;
-            int64_t ppos; uint32_t pst;
+    const bool in_regs = cnt <= 64;                      // every record this chunk has is in `rec`
+    // record of row j's run (j + skip) and of the run before it, from the neighbours' registers
+    const uint64_t rec_j = skip ? (uint64_t)__shfl_down((long long)rec, 1) : rec;
+    const uint64_t rec_p = (uint64_t)__shfl_up((long long)rec_j, 1);
+    for (int64_t j = lane; j < total; j += 64) {
+        int64_t pos, ppos; uint32_t pst;
+        if (in_regs && j < 64) {
+            pos = (j < from_slab) ? rec_pos(rec_j) : pend_pos;
+            if (j == 0) { ppos = prev_pos; pst = prev_st; }
+            else { ppos = rec_pos(rec_p); pst = rec_state(rec_p); }
+        } else {
+            pos = (j < from_slab) ? rec_pos(slab[j + skip]) : pend_pos;
             if (j == 0) { ppos = prev_pos; pst = prev_st; }
             else { const uint64_t rr = slab[j - 1 + skip]; ppos = rec_pos(rr); pst = rec_state(rr); }
-            const int64_t gi = out_off + j;
-            const int64_t len = (gi == 0) ? pos + 1 : pos - ppos;
-            const int64_t state = (int64_t)pst - 1;
-            if (gi < a.cap_rows) *(longlong2 *)(a.rows + 2 * gi) = longlong2{(long long)state, (long long)len};
-            if (g.ft.want_bits) {
-                const VecK<4> v = row_value(state, len, gi == 0, g.bp);
-                acc.add(v);
-                if (v.v[0] > kHugeBits) {
-                    const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
-                    if (slot < g.huge_cap) g.huge[slot] = HugeRef{c, gi};
-                }
+        }
+        const int64_t gi = out_off + j;
+        const int64_t len = (gi == 0) ? pos + 1 : pos - ppos;
+        const int64_t state = (int64_t)pst - 1;
+        if (gi < a.cap_rows) *(longlong2 *)(a.rows + 2 * gi) = longlong2{(long long)state, (long long)len};
+        if (g.ft.want_bits) {
+            const VecK<4> v = row_value(state, len, gi == 0, g.bp);
+            acc.add(v);
+            if (v.v[0] > kHugeBits) {
+                const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
+                if (slot < g.huge_cap) { g.huge[slot].tile = c; g.huge[slot].row = gi; }
             }
         }
     }
@@ -865,59 +946,108 @@ __global__ __launch_bounds__(64) void k_emit_rows_tiles(const EmitTileArgs g) {
     if (lane == 0) { g.ft.agg[c] = acc; g.ft.tile_off[c] = out_off; g.ft.tile_cnt[c] = (int32_t)total; }
 }
 
-// ---- tile scan: exclusive prefix per tile; GroupInfo of the tiles that hold a long pause or the table's last row -------
-struct TileAggLoad {
-    const VecK<4> *agg;
-    __device__ VecK<4> operator()(int64_t t) const { return agg[t]; }
-};
-struct TileStore {
+// ---- tile scan: exclusive prefix per tile (one thread per tile, look-back across the few dozen workgroups); the tiles that hold a
+// long pause or the table's last row are then walked, one wavefront each, for their GroupInfo -----------------------------------
+struct TileScanArgs {
     const int64_t *rows;
     const int64_t *d_n_rows;
+    const VecK<4> *agg;
     const int64_t *tile_off;
     const int32_t *tile_cnt;
     VecK<4> *excl;
     GroupInfo *groups;
     int64_t cap_groups;
+    int64_t *d_n_groups;
+    int64_t n_tiles;
     BitsParams bp;
-    __device__ void operator()(int64_t t, const VecK<4> &val, const VecK<4> &ex) const {
-        excl[t] = ex;
-        const int64_t n = *d_n_rows;
-        const int64_t off = tile_off[t];
-        int64_t end = off + tile_cnt[t];
-        if (end > n) end = n;
-        if (end <= off) return;
-        if (val.v[1] == 0 && end != n) return;              // no long pause here and not the table's last row
-        VecK<4> run = ex;
-        for (int64_t i = off; i < end; ++i) {
-            const int64_t type = rows[2 * i], len = rows[2 * i + 1];
-            const VecK<4> v = row_value(type, len, i == 0, bp);
-            if (v.v[1] && run.v[1] < cap_groups) {          // long pause: closes group run.v[1]
-                GroupInfo gi;
-                gi.bits_end = run.v[0]; gi.data_end = run.v[3]; gi.ts_close = run.v[2]; gi.pause = len; gi.closed = 1; gi.pad = 0;
-                groups[run.v[1]] = gi;
+    GranDesc *desc;
+    unsigned long long epoch;
+};
+__global__ __launch_bounds__(kScanBlock) void k_tile_scan(const TileScanArgs a) {
+    __shared__ VecK<4> s_wave[kScanBlock / 64];
+    __shared__ VecK<4> s_prefix;
+    __shared__ VecK<4> s_ex[kScanBlock];                 // listed tiles: prefix, first row, end
+    __shared__ int64_t s_off[kScanBlock], s_end[kScanBlock];
+    __shared__ int s_count;
+    const int64_t b = blockIdx.x, nb = gridDim.x;
+    const int64_t t = b * kScanBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // one round trip
+    const int64_t n = *a.d_n_rows;
+    VecK<4> mine; mine.zero();
+    int64_t off = 0; int32_t cnt = 0;
+    if (t < a.n_tiles) { mine = a.agg[t]; off = a.tile_off[t]; cnt = a.tile_cnt[t]; }
+    if (threadIdx.x == 0) s_count = 0;
+    VecK<4> total;
+    VecK<4> ex = block_excl_scan_vec<4>(mine, total, s_wave);
+    if (threadIdx.x < 64) {                               // wavefront 0 publishes and looks back
+        const uint32_t tag = (uint32_t)a.epoch;
+        if (threadIdx.x == 0) gran_store(a.desc[b].agg, total, tag);
+        VecK<4> zero; zero.zero();
+        bool ok;
+        const VecK<4> prefix = gran_look_back<VecK<4>>(a.desc, b, tag, zero,
+                                                         [](const VecK<4> &l, const VecK<4> &r) { VecK<4> x = l; x.add(r); return x; },
+                                                         [](const VecK<4> &x, int o) { VecK<4> r; for (int k = 0; k < 4; ++k) r.v[k] = __shfl_down(x.v[k], o); return r; },
+                                                         [](const VecK<4> &x) { VecK<4> r; for (int k = 0; k < 4; ++k) r.v[k] = __shfl(x.v[k], 0); return r; },
+                                                         lane, ok);
+        if (threadIdx.x == 0) {
+            VecK<4> incl = prefix; incl.add(total);
+            gran_store(a.desc[b].incl, incl, tag);
+            s_prefix = prefix;
+            if (b == nb - 1) {                            // number of groups = long pauses + 1
+                int64_t g = (n > 0) ? incl.v[1] + 1 : 0;
+                if (g > a.cap_groups) g = a.cap_groups;
+                *a.d_n_groups = g;
             }
-            if (i + 1 == n && run.v[1] + v.v[1] < cap_groups) {   // trailing group
-                GroupInfo gi;
-                gi.bits_end = run.v[0] + v.v[0]; gi.data_end = run.v[3] + v.v[3]; gi.ts_close = run.v[2] + v.v[2];
-                gi.pause = (type == -1) ? len : 0;          // :411
-                gi.closed = 0; gi.pad = 0;
-                groups[run.v[1] + v.v[1]] = gi;
-            }
-            run.add(v);
         }
     }
-};
-struct TileGroupCount {
-    const int64_t *d_n_rows;
-    int64_t *d_n_groups;
-    int64_t cap_groups;
-    __device__ void operator()(const VecK<4> &grand) const {
-        const int64_t n = *d_n_rows;
-        int64_t g = (n > 0) ? grand.v[1] + 1 : 0;
-        if (g > cap_groups) g = cap_groups;
-        *d_n_groups = g;
+    __syncthreads();
+    ex.add(s_prefix);
+    int64_t end = off + cnt;
+    if (end > n) end = n;
+    if (t < a.n_tiles) {
+        a.excl[t] = ex;
+        if (end > off && (mine.v[1] > 0 || end == n)) {
+            const int slot = atomicAdd(&s_count, 1);
+            s_ex[slot] = ex; s_off[slot] = off; s_end[slot] = end;
+        }
     }
-};
+    __syncthreads();
+    const int n_list = s_count;
+    for (int w = wave; w < n_list; w += kScanBlock / 64) {
+        // walk the listed tile's rows 64 at a time
+        const int64_t o = s_off[w], e = s_end[w];
+        VecK<4> run = s_ex[w];
+        for (int64_t i0 = o; i0 < e; i0 += 64) {
+            const int64_t i = i0 + lane;
+            VecK<4> v; v.zero();
+            int64_t type = 0, len = 0;
+            if (i < e) {
+                const longlong2 row = *(const longlong2 *)(a.rows + 2 * i);
+                type = row.x; len = row.y;
+                v = row_value(type, len, i == 0, a.bp);
+            }
+            const VecK<4> incl = wave_incl_scan_vec<4>(v, lane);
+            VecK<4> before = run;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) before.v[k] += incl.v[k] - v.v[k];
+            if (i < e && v.v[1] && before.v[1] < a.cap_groups) {          // long pause: closes group before.v[1]
+                GroupInfo gi;
+                gi.bits_end = before.v[0]; gi.data_end = before.v[3]; gi.ts_close = before.v[2]; gi.pause = len; gi.closed = 1; gi.pad = 0;
+                a.groups[before.v[1]] = gi;
+            }
+            if (i < e && i + 1 == n && before.v[1] + v.v[1] < a.cap_groups) {   // trailing group
+                GroupInfo gi;
+                gi.bits_end = before.v[0] + v.v[0]; gi.data_end = before.v[3] + v.v[3]; gi.ts_close = before.v[2] + v.v[2];
+                gi.pause = (type == -1) ? len : 0;          // :411
+                gi.closed = 0; gi.pad = 0;
+                a.groups[before.v[1] + v.v[1]] = gi;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) run.v[k] += __shfl(incl.v[k], 63);
+        }
+    }
+}
 
 struct ExpandTileArgs {
     const int64_t *rows;
@@ -941,11 +1071,11 @@ constexpr unsigned kHugeBlocksX = 16, kHugeBlocksY = 16;
 // one wavefront per tile; workgroups beyond the tiles expand the listed huge rows, kHugeBlocksX workgroups per row
 __global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n = *a.d_n_rows;
     const int bps = (int)a.bp.bps;
     const int64_t tile_blocks = (a.n_tiles + 3) / 4;
     if ((int64_t)blockIdx.x >= tile_blocks) {
         // ---- huge rows ----
+        const int64_t n = *a.d_n_rows;
         const int64_t hb = (int64_t)blockIdx.x - tile_blocks;
         const int hx = (int)(hb % kHugeBlocksX), hy = (int)(hb / kHugeBlocksX);
         if (hb == 0 && threadIdx.x == 0) a.huge_count[a.parity ^ 1] = 0;       // the other parity's counter: free for the next pass
@@ -992,19 +1122,29 @@ __global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
     }
     const int64_t t = (int64_t)blockIdx.x * 4 + wave;
     if (t >= a.n_tiles) return;
+    // ---- round trip 1: everything that does not depend on loaded data ----
+    const int64_t n = *a.d_n_rows;
+    const int64_t n_groups = *a.d_n_groups;
+    const int hc = a.huge_count[a.parity];
     const int64_t off = a.tile_off[t];
-    int64_t end = off + a.tile_cnt[t];
+    const int32_t tcnt = a.tile_cnt[t];
+    VecK<4> run = a.excl[t];
+    int64_t end = off + tcnt;
     if (end > n) end = n;
     if (end <= off) return;
-    VecK<4> run = a.excl[t];
-    const int64_t n_groups = *a.d_n_groups;
-    const int64_t own_limit = (a.huge_count[a.parity] > a.huge_cap) ? INT64_MAX : kHugeBits;   // longer rows are on the list
+    const int64_t own_limit = (hc > a.huge_cap) ? INT64_MAX : kHugeBits;   // longer rows are on the list
+    // ---- round trip 2: the rows, and the group the tile starts in (nearly every row of the tile belongs to it) ----
+    const int64_t g0 = run.v[1];
+    GroupOut go0; go0.bits_start = 0; go0.out_bits = 0; go0.out_pos = 0; go0.is_msg = 0; go0.pad = 0;
+    longlong2 row0 = longlong2{0, 0};
+    if (off + lane < end) row0 = *(const longlong2 *)(a.rows + 2 * (off + lane));
+    if (g0 < n_groups) go0 = a.gout[g0];
     for (int64_t i0 = off; i0 < end; i0 += 64) {
         const int64_t i = i0 + lane;
         VecK<4> v; v.zero();
         int64_t type = 0;
         if (i < end) {
-            const longlong2 row = *(const longlong2 *)(a.rows + 2 * i);
+            const longlong2 row = (i0 == off) ? row0 : *(const longlong2 *)(a.rows + 2 * i);
             type = row.x;
             v = row_value(type, row.y, i == 0, a.bp);
         }
@@ -1013,7 +1153,8 @@ __global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
         if (i < end && v.v[0] > 0 && v.v[0] <= own_limit) {
             const int64_t grp = run.v[1] + incl.v[1] - v.v[1];
             if (grp < n_groups) {
-                const GroupOut go = a.gout[grp];
+                GroupOut go = go0;
+                if (grp != g0) go = a.gout[grp];
                 if (go.is_msg) {
                     const int64_t bit_prefix = run.v[0] + incl.v[0] - v.v[0];
                     kb = v.v[0];
@@ -1043,10 +1184,8 @@ __global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
                 if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
             }
         }
-        VecK<4> tot;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) tot.v[k] = __shfl(incl.v[k], 63);
-        run.add(tot);
+        for (int k = 0; k < 4; ++k) run.v[k] += __shfl(incl.v[k], 63);
     }
 }
 
@@ -1231,9 +1370,18 @@ TileCarve carve_tile(const TileTailMem &m) {
     tc.ft.huge_count = m.huge_count;
     tc.ft.parity = m.parity;
     tc.ft.want_bits = 0;
+    tc.ft.rdesc = (GranDesc *)m.rdesc;
+    tc.ft.epoch = m.epoch;
     return tc;
 }
 }  // namespace
+
+// the tile scan runs one workgroup per 256 tiles: descriptor memory sized (bits_desc_bytes) for this many "rows" holds them
+int64_t tile_desc_cap(int64_t cap_rows, int64_t n_chunks) { return std::max<int64_t>(cap_rows, 8 * (n_chunks + 2) + kScanTile); }
+
+size_t tile_rdesc_bytes(int64_t n_chunks) {        // resolve scan + tile scan descriptors
+    return (size_t)(resolve_blocks(n_chunks) + 2 + (n_chunks + 1 + kScanBlock - 1) / kScanBlock + 2) * sizeof(GranDesc);
+}
 
 size_t tile_tail_bytes(int64_t n_chunks) {
     const int64_t nt = n_chunks + 1;
@@ -1251,7 +1399,7 @@ int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem 
     if (bp) { g.bp = *bp; g.ft.want_bits = 1; }
     const unsigned gb = (unsigned)resolve_blocks(r.n_chunks);
     hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft);
-    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)(r.n_chunks + 1)), dim3(64), 0, s, g);
+    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((r.n_chunks + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
     return URHGPU_OK;
 }
 
@@ -1260,18 +1408,17 @@ int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d
                      const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s) {
     if (cap_rows <= 0) cap_rows = 1;
     const int64_t nt = m.n_chunks + 1;
-    if (ss.desc_bytes < bits_desc_bytes(std::max(cap_rows, nt))) return URHGPU_ERR_ARG;
+    const int64_t cap_desc = tile_desc_cap(cap_rows, m.n_chunks);
+    if (ss.desc_bytes < bits_desc_bytes(cap_desc)) return URHGPU_ERR_ARG;
     const TileCarve tc = carve_tile(m);
     const BitsScratch b = carve_bits(scratch, cap_rows);
     const int64_t cap_groups = cap_rows + 1;
-    const int64_t nbt = scan_blocks(nt);
-    ScanDesc<4> *desc4 = (ScanDesc<4> *)ss.desc;
-    ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(scan_blocks(std::max(cap_rows, nt)) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
-    TileAggLoad tl{tc.ft.agg};
-    TileStore ts{rows, d_n_rows, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, bp};
-    TileGroupCount tf{d_n_rows, b.d_n_groups, cap_groups};
-    hipLaunchKernelGGL((k_scan_lookback<4, TileAggLoad, TileStore, TileGroupCount>), dim3((unsigned)nbt), dim3(kScanBlock), 0, s,
-                       tc.ft.d_n_tiles, tl, desc4, nbt, ts, tf, ++*ss.epoch, ss.tickets + 2, 0);
+    ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(scan_blocks(cap_desc) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
+    GranDesc *tdesc = (GranDesc *)m.rdesc + resolve_blocks(m.n_chunks) + 2;
+    TileScanArgs ta{rows, d_n_rows, tc.ft.agg, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, b.d_n_groups, nt, bp, tdesc,
+                    m.epoch};
+    const unsigned nb_ts = (unsigned)((nt + kScanBlock - 1) / kScanBlock);
+    hipLaunchKernelGGL(k_tile_scan, dim3(nb_ts), dim3(kScanBlock), 0, s, ta);
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};

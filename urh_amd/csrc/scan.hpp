@@ -323,6 +323,79 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_lookback(const int64_t *d_n
     }
 }
 
+
+// ---- look-back on data-tagged granules ----------------------------------------------------------------------------------
+// The descriptor of a workgroup is 2 x 8 granules of 8 bytes {32 bits of payload, 32-bit pass tag}, each written by ONE
+// write-through (agent-scope relaxed atomic = sc1) store and polled with sc1 loads: a granule whose tag is the current pass's
+// carries valid payload -- no flag, no fence, no ordering between the granules (MI355X_MICROARCH.md, persistent-kernel price
+// list: a fenced flag hand-off costs 2 x 3.5 us of __threadfence, a granule hand-off about 1 us).  Memory must be zero
+// (or hold older tags) before first use; tags never repeat on a context within 2^32 passes.
+struct GranDesc { unsigned long long agg[8]; unsigned long long incl[8]; };
+static_assert(sizeof(GranDesc) == 128, "GranDesc");
+
+template <class T> __device__ __forceinline__ void gran_store(unsigned long long *g, const T &x, uint32_t tag) {
+    static_assert(sizeof(T) == 32, "granule payload is 8 x 32 bits");
+    uint32_t w[8];
+    __builtin_memcpy(w, &x, 32);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        __hip_atomic_store(g + k, ((unsigned long long)tag << 32) | w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T> __device__ __forceinline__ bool gran_load(const unsigned long long *g, T &x, uint32_t tag) {
+    uint32_t w[8];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned long long v = __hip_atomic_load(g + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        w[k] = (uint32_t)v;
+        ok &= (uint32_t)(v >> 32) == tag;
+    }
+    __builtin_memcpy(&x, w, 32);
+    return ok;
+}
+
+// Ordered composition of the totals of workgroups 0 .. b-1, executed by ONE wavefront (every lane gets the result).
+// comb(left, right) may be non-commutative; shfl_down(x, o) moves a T across lanes.  Lane l of a window looks at workgroup
+// top - l; a descending-lane suffix composition keeps the workgroups in order.  `ok` is cleared when a predecessor never shows up.
+template <class T, class Comb, class ShflDown, class Shfl0>
+__device__ __forceinline__ T gran_look_back(GranDesc *desc, int64_t b, uint32_t tag, const T &identity, Comb comb, ShflDown shfl_down,
+                                            Shfl0 shfl0, int lane, bool &ok) {
+    T carry = identity;
+    int64_t top = b - 1;
+    int spins = 0;
+    ok = true;
+    while (top >= 0) {
+        const int64_t j = top - lane;
+        T vi = identity, va = identity;
+        bool has_incl = false, has_agg = false;
+        if (j >= 0) {
+            has_incl = gran_load(desc[j].incl, vi, tag);
+            if (!has_incl) has_agg = gran_load(desc[j].agg, va, tag);
+        }
+        const bool ready = (j < 0) || has_incl || has_agg;
+        const unsigned long long m_incl = __ballot(has_incl);
+        const unsigned long long m_not_ready = __ballot(!ready);
+        const int first_incl = m_incl ? __builtin_ctzll(m_incl) : 64;
+        const unsigned long long need = (first_incl >= 63) ? ~0ull : ((2ull << first_incl) - 1ull);
+        if (m_not_ready & need) {
+            if (++spins > kScanSpinLimit) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        T mine = identity;
+        if (j >= 0 && lane <= first_incl) mine = (lane == first_incl) ? vi : va;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const T u = shfl_down(mine, o);                   // workgroups further to the left
+            if (lane + o < 64) mine = comb(u, mine);
+        }
+        carry = comb(shfl0(mine), carry);
+        if (m_incl) break;
+        top -= 64;
+    }
+    return carry;
+}
+
 struct NoFinal {
     template <class V> __device__ void operator()(const V &) const {}
 };
