@@ -22,7 +22,8 @@ Prints ONE JSON line on rank 0 (see the driver contract) with extra objects:
                 2^27-sample capture compared element for element with the CPU reference on the same bytes
   cpu_baseline  the reference's own path on this box's host cores (oracle/_ref = the reference's Cython modules compiled
                 from /root/reference, plus its pure-Python tail when the staged sources are present), else the C port
-  extra         other BASELINE configurations at full size (--extra): configs[2] OOK+FIR+auto noise, configs[4] 4-PSK Costas
+  extra         the other single-GPU BASELINE configurations at full size with their own parity records (--no-extra skips them):
+                configs[2] OOK + 64-tap FIR + auto noise + estimate, configs[4] 4-PSK Costas + auto center
 """
 import argparse
 import json
@@ -201,8 +202,230 @@ def parity_record(res, ref_out, tx_bits, kind):
     return rec
 
 
+def _timed(torch, fn, reps=3):
+    """(result, best wall time in ms) of fn() with the GPU drained before and after"""
+    best, out = None, None
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) * 1e3
+        best = dt if best is None else min(best, dt)
+    return out, best
+
+
+def _ref_modules():
+    """(signal_functions, util, auto_interpretation Cython modules, AutoInterpretation python module or None) of the real reference"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import build_ref
+    import ref_python
+    if not build_ref.built():
+        return None
+    sf, util, ai = build_ref.import_ref()
+    AI = IQArray = None
+    if ref_python.available():
+        try:
+            ref_python.setup()
+            from urh.ainterpretation import AutoInterpretation as AI
+            from urh.signalprocessing.IQArray import IQArray
+        except Exception:           # noqa: BLE001
+            AI = IQArray = None
+    return sf, util, ai, AI, IQArray
+
+
+def extra_config3(pipe, dev, args):
+    """BASELINE.json configs[2] at full size: 1 GiB OOK capture -> 64-tap complex FIR (Signal.filter_range
+    semantics) -> get_magnitudes + detect_noise_level -> AutoInterpretation.estimate(noise, "OOK") -> afp_demod("ASK") -> pulse
+    table -> bits, every stage compared with the real reference on the same bytes."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from urh_amd import _lib, estimators
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.synth import spec_fir_taps, spec_ook_capture
+    iq, chips = spec_ook_capture(args.segments, dev)
+    n = iq.shape[0]
+    taps = spec_fir_taps()
+    d_taps = torch.from_numpy(taps.view(np.float32).copy()).to(dev)
+    filt = torch.empty_like(iq)
+    lib, h = _lib.load(), pipe.ctx.handle
+
+    def fir():
+        pipe.ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.urhgpu_fir_filter_dev(h, C.c_void_p(iq.data_ptr()), n, C.c_void_p(d_taps.data_ptr()), len(taps), None,
+                                             C.c_void_p(filt.data_ptr())))
+    _, t_fir = _timed(torch, fir)
+    noise, t_noise = _timed(torch, lambda: estimators.detect_noise_level_dev(pipe, filt))
+    est, t_est = _timed(torch, lambda: estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK"), reps=2)
+    center = float(est["center"]) if est else 0.0
+    p = DemodParams("ASK", 1, float(noise), center, 1.0, 5, 100, 0.1, 8, True)
+    res, t_bits = _timed(torch, lambda: pipe.iq_to_bits_checked(filt, p, want_qad=True))
+    total_ms = t_fir + t_noise + t_est + t_bits
+    rec = {"workload": "configs[2]: 1 GiB OOK (Manchester, 124 messages) + 64-tap complex FIR + auto noise threshold + estimate + bits",
+           "samples": n, "ms": round(total_ms, 3),
+           "stages_ms": {"fir_filter": round(t_fir, 3), "detect_noise_level": round(t_noise, 3), "estimate": round(t_est, 3),
+                         "iq_to_bits_ask": round(t_bits, 3)},
+           "estimated": {k: (float(v) if not isinstance(v, str) else v) for k, v in (est or {}).items()},
+           "roofline": {"algorithmic_bytes_per_sample": 28,
+                        "hbm_frac": round(28 * n / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "fir_valu_frac": round(512.0 * n / (t_fir * 1e-3) / 78.6e12, 4),
+                        "note": "28 B/sample = FIR 8 + 8, demodulation 8 + 4 (SURVEY 8(d) config 3); the FIR is bound by un-fused fp32 VALU "
+                                "(512 flop per sample against 78.6 TFLOP/s of non-FMA packed fp32), not by HBM"},
+           "messages": res.host_counts()[1], "bits": res.host_counts()[2]}
+    mods = None if args.no_cpu_baseline else _ref_modules()
+    if mods:
+        sf, util, ai, AI, IQArray = mods
+        host = iq.cpu().numpy()
+        x = host.view(np.complex64).reshape(-1)
+        t0 = time.perf_counter()
+        ref_f = np.asarray(sf.fir_filter(x, taps))
+        t1 = time.perf_counter()
+        ref_f2 = np.ascontiguousarray(ref_f).view(np.float32).reshape(-1, 2)
+        got_f = filt.cpu().numpy()
+        par = {"fir_mismatches": int((got_f.view(np.uint32) != ref_f2.view(np.uint32)).sum())}
+        del got_f
+        mags = np.asarray(util.get_magnitudes(ref_f2))
+        cpu = {"fir_filter_s": round(t1 - t0, 2)}
+        if AI is not None:
+            t2 = time.perf_counter()
+            ref_noise = AI.detect_noise_level(mags)
+            t3 = time.perf_counter()
+            ref_est = AI.estimate(IQArray(ref_f2), noise=ref_noise, modulation="OOK")
+            t4 = time.perf_counter()
+            cpu.update({"detect_noise_level_s": round(t3 - t2, 2), "estimate_s": round(t4 - t3, 2)})
+            par["noise_equal"] = bool(float(ref_noise) == float(noise))
+            par["estimate_equal"] = bool(ref_est is not None and est is not None and all(
+                (ref_est[k] == est[k]) if isinstance(ref_est[k], str) else (float(ref_est[k]) == float(est[k])) for k in ref_est))
+            par["reference_estimate"] = {k: (float(v) if not isinstance(v, str) else v) for k, v in (ref_est or {}).items()}
+        del mags
+        t5 = time.perf_counter()
+        ref_qad = np.asarray(sf.afp_demod(ref_f2, p.noise_threshold, "ASK", 2))
+        ref_pp = np.asarray(sf.grab_pulse_lens(ref_qad, p.center, 5, "ASK", 100, 1, 1.0))
+        t6 = time.perf_counter()
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import urh_oracle as oracle
+        ref_flat = oracle.ppseq_to_bits_flat(ref_pp, 100, 1, True, 8)
+        cpu["afp_demod_plus_grab_pulse_lens_s"] = round(t6 - t5, 2)
+        par["qad_mismatches"] = int((res.qad.cpu().numpy().view(np.uint32) != ref_qad.view(np.uint32)).sum())
+        par["rows_equal"] = bool(np.array_equal(res.ppseq(), ref_pp))
+        par["bits_pauses_positions_equal"] = bool(all(np.array_equal(a, b) for a, b in zip(res.flat(), ref_flat)))
+        # against the transmitter: every message carries the 10 000 chips of its segment
+        bits, off = res.flat()[0], res.flat()[1]
+        ok_msgs = sum(1 for m in range(len(off) - 1) if off[m + 1] - off[m] >= 10000 and np.array_equal(bits[off[m]:off[m] + 10000], chips[4 + m])
+                      ) if len(off) - 1 <= chips.shape[0] - 4 else 0
+        par["messages_equal_transmitted_chips"] = int(ok_msgs)
+        par["bit_exact"] = bool(par["fir_mismatches"] == 0 and par["qad_mismatches"] == 0 and par["rows_equal"] and
+                                par["bits_pauses_positions_equal"] and par.get("noise_equal", True) and par.get("estimate_equal", True))
+        rec["parity"] = par
+        cpu_total = sum(v for v in cpu.values())
+        rec["cpu_baseline"] = {"kind": "reference", "stages": cpu, "value": round(n / cpu_total / 1e6, 2), "unit": "Msamples/s",
+                               "cores": os.cpu_count() or 1,
+                               "sample": f"all {n} samples: the reference's Cython fir_filter / afp_demod / grab_pulse_lens and its Python "
+                                         "detect_noise_level / estimate"}
+    rec["value"] = round(n / (total_ms * 1e-3) / 1e6, 1)
+    rec["unit"] = "Msamples/s"
+    return rec
+
+
+def extra_config5(pipe, dev, args):
+    """BASELINE.json configs[4] at full size: 1 GiB 4-PSK, Costas loop (order 4) + auto center detection.
+    Run (i) as named: center = detect_center(qad); run (ii) center = 0, center_spacing = 1.5 as the reference's own 4-PSK test."""
+    import numpy as np
+    import torch
+    from urh_amd import estimators
+    from urh_amd.signal import Signal
+    from urh_amd.synth import spec_psk_capture
+    iq, tx = spec_psk_capture(args.segments, dev)
+    n = iq.shape[0]
+    sig = Signal(iq, modulation="PSK", pipe=pipe)
+    del iq
+    sig.bits_per_symbol = 2
+    sig.noise_threshold = 0.2
+    sig.center_spacing = 1.5
+    sig.costas_loop_bandwidth = 0.1
+
+    def costas():
+        sig._drop_cache()
+        return sig.qad
+    qad, t_costas = _timed(torch, costas)
+    stats = pipe.ctx.costas_stats()
+    center, t_center = _timed(torch, lambda: estimators.detect_center_dev(pipe, qad))
+    out = {}
+    for tag, c in (("i_auto_center", center), ("ii_center_0", 0.0)):
+        sig.center = float(c) if c is not None else 0.0
+
+        def slice_bits():
+            sig._bits = None
+            return sig._digitize()
+        dig, t_dig = _timed(torch, slice_bits)
+        out[tag] = (dig, t_dig, sig.center)
+    total_i = t_costas + t_center + out["i_auto_center"][1]
+    total_ii = t_costas + out["ii_center_0"][1]
+    rec = {"workload": "configs[4]: 1 GiB 4-PSK, Costas loop (order 4, bandwidth 0.1) + detect_center + bits",
+           "samples": n, "ms": round(total_i, 3), "ms_center_0": round(total_ii, 3),
+           "stages_ms": {"costas_demod": round(t_costas, 3), "detect_center": round(t_center, 3),
+                         "grab_pulse_lens_plus_bits_auto_center": round(out["i_auto_center"][1], 3),
+                         "grab_pulse_lens_plus_bits_center_0": round(out["ii_center_0"][1], 3)},
+           "center_detected": None if center is None else float(center),
+           "costas_chunks": {"matched_by_a_candidate": stats[0], "met_at_a_checkpoint": stats[1], "evaluated_serially": stats[2],
+                             "respeculation_rounds": stats[3],
+                             "speculative_hit_rate": round(stats[0] / max(1, stats[0] + stats[1] + stats[2]), 5)},
+           "roofline": {"algorithmic_bytes_per_sample": 24, "hbm_frac": round(24 * n / (total_i * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "bound by the dependent arithmetic of the loop recurrence (SURVEY 8(d) config 5), not by a roofline"},
+           "rows_auto_center": int(len(out["i_auto_center"][0][0])), "rows_center_0": int(len(out["ii_center_0"][0][0]))}
+    mods = None if args.no_cpu_baseline else _ref_modules()
+    if mods:
+        sf, util, ai, AI, IQArray = mods
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import urh_oracle as oracle
+        host = sig.iq.cpu().numpy()
+        t0 = time.perf_counter()
+        ref_qad = np.asarray(sf.afp_demod(host, 0.2, "PSK", 4, 0.1)).copy()
+        t1 = time.perf_counter()
+        got_qad = qad.cpu().numpy()
+        par = {"qad_mismatches_from_index_1": int((got_qad[1:].view(np.uint32) != ref_qad[1:].view(np.uint32)).sum())}
+        ref_qad[0] = got_qad[0]          # the reference leaves element 0 uninitialised (np.empty): give both slicers the same value
+        cpu = {"costas_afp_demod_s": round(t1 - t0, 2)}
+        ref_center = None
+        if AI is not None:
+            t2 = time.perf_counter()
+            ref_center = AI.detect_center(ref_qad)
+            cpu["detect_center_s"] = round(time.perf_counter() - t2, 2)
+            par["center_equal"] = bool((ref_center is None and center is None) or (ref_center is not None and center is not None and
+                                                                                   float(ref_center) == float(center)))
+            par["reference_center"] = None if ref_center is None else float(ref_center)
+        t3 = time.perf_counter()
+        for tag in ("i_auto_center", "ii_center_0"):
+            dig, _, c = out[tag]
+            ref_pp = np.asarray(sf.grab_pulse_lens(ref_qad, c, 5, "PSK", 100, 2, 1.5))
+            ref_flat = oracle.ppseq_to_bits_flat(ref_pp, 100, 2, True, 8)
+            par[tag + "_rows_equal"] = bool(np.array_equal(dig[0], ref_pp))
+            par[tag + "_bits_pauses_positions_equal"] = bool(all(np.array_equal(a, b) for a, b in zip(dig[1:], ref_flat)))
+        cpu["grab_pulse_lens_x2_s"] = round(time.perf_counter() - t3, 2)
+        par["bit_exact"] = bool(par["qad_mismatches_from_index_1"] == 0 and par.get("center_equal", True) and
+                                all(v for k, v in par.items() if k.endswith("_equal")))
+        rec["parity"] = par
+        rec["cpu_baseline"] = {"kind": "reference", "stages": cpu, "value": round(n / (cpu["costas_afp_demod_s"] + cpu.get("detect_center_s", 0) +
+                                                                                     cpu["grab_pulse_lens_x2_s"] / 2) / 1e6, 2),
+                               "unit": "Msamples/s", "cores": os.cpu_count() or 1,
+                               "sample": f"all {n} samples: the reference's Cython costa_demod (serial) / grab_pulse_lens and Python detect_center"}
+    rec["value"] = round(n / (total_i * 1e-3) / 1e6, 1)
+    rec["unit"] = "Msamples/s"
+    return rec
+
+
 def run_extras(pipe, dev, args):
-    return []
+    out = []
+    for fn in (extra_config3, extra_config5):
+        try:
+            import torch
+            torch.cuda.empty_cache()
+            out.append(fn(pipe, dev, args))
+        except Exception as e:           # noqa: BLE001  (an extra must not take the headline line down)
+            import traceback
+            out.append({"workload": fn.__name__, "error": repr(e)[:300], "trace": traceback.format_exc()[-600:]})
+    return out
 
 
 def self_launch(args):
@@ -228,7 +451,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU reference (then no parity record either)")
     ap.add_argument("--bits-only", action="store_true", help="do not materialise qad (8 B/sample variant)")
     ap.add_argument("--torch-capture", action="store_true", help="round-1 capture (torch RNG, clean fp64 phase ramp) instead of the §8(d) bytes")
-    ap.add_argument("--extra", action="store_true", help="also run configs[2] and configs[4] at full size (adds about a minute)")
+    ap.add_argument("--no-extra", action="store_true", help="skip configs[2] and configs[4] at full size (they add about a minute)")
     ap.add_argument("--fir-halo", action="store_true", help="N > 1: prepend the 64-tap FIR with halo exchange (configs[3] 'FIR-halo' variant)")
     ap.add_argument("--pipeline", action="store_true",
                     help="software-pipeline consecutive steps (hot kernel of step i+1 on the main stream while the tail of step i "
@@ -319,7 +542,7 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    pipe.ctx.profile_begin(args.steps)
+    pipe.ctx.profile_begin(0 if os.environ.get("URH_BENCH_NO_PROFILE") else args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -405,7 +628,7 @@ def main():
             out["cpu_baseline"] = rec
             out["parity"] = parity_record(res, ref_out, tx_bits, rec["kind"])
             del host, ref_out
-        if args.extra and world == 1 and not force_sharded:
+        if not args.no_extra and world == 1 and not force_sharded:
             del iq
             out["extra"] = run_extras(pipe, dev, args)
         print(json.dumps(out))

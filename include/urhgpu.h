@@ -286,6 +286,26 @@ int urhgpu_pairwise_sum_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, in
 /* np.histogram(x, bins=edges) for ascending float64 edges: d_counts[n_edges - 1]. */
 int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const double *d_edges, int64_t n_edges, int64_t *d_counts);
 
+/* AutoInterpretation.estimate's per-message statistics for ALL messages of a capture in one go (AutoInterpretation.py:392-446 walks
+ * them one by one: detect_center :226-277 and get_plateau_lengths, auto_interpretation.pyx:179-208).  d_x: the demodulated signal
+ * (device, float32[n]); ranges: HOST int64[n_msgs][2] = (start, end) of every message.  Synchronous; host outputs.
+ *
+ * urhgpu_msg_center_stats: per message rect = x[start:end][x > -4] trimmed to [int(0.05 k), int(0.95 k)), then
+ * out_stats[m] = {kept k, trimmed length, min, max, float32 mean, float32 np.var (the bin width), n_edges, first edge} and
+ * out_hist[m][0 .. n_edges - 2] = np.histogram(rect, bins = np.arange(min, max + var, var)); n_edges == 0: no histogram (empty
+ * message, zero or NaN variance, fewer than two edges -> detect_center returns None); n_edges - 1 > max_bins: the histogram does not
+ * fit the pool (the caller takes that message through urhgpu_histogram_f32_dev).  out_stats: double[n_msgs][8], out_hist:
+ * int64[n_msgs][max_bins]. */
+int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins,
+                            double *out_stats, int64_t *out_hist);
+/* urhgpu_msg_plateaus: get_plateau_lengths(x[start:end], centers[m], percentage) for every message with a center (NaN: none,
+ * no plateaus): out_len[out_off[m] .. |out_off[m + 1]|) (uint64, back to back; out_off[0] = 0).  Boundaries are searched in the
+ * first percentage % + extra_window samples of a message; when that window holds no boundary at or beyond the percentage mark the
+ * message's end offset comes back as -(end + 1) and the caller repeats it with a larger window.  More than cap_total lengths:
+ * URHGPU_ERR_CAPACITY with the needed total in out_off[n_msgs].  Messages longer than 2^31 - 1 samples: URHGPU_ERR_UNSUPPORTED. */
+int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
+                        int percentage, int64_t extra_window, int64_t *out_off, uint64_t *out_len, int64_t cap_total);
+
 /* Test hook: the hot kernel's fast-path division (Newton + residual chain without scaling) against the IEEE
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);

@@ -740,6 +740,40 @@ def test_plateau_lengths_equal_oracle(pipe, oracle):
                 assert np.array_equal(want, got), (n, center, pct, want[:6], got[:6], len(want), len(got))
 
 
+def test_batched_message_statistics_equal_oracle(pipe, oracle):
+    """urhgpu_msg_center_stats / urhgpu_msg_plateaus (all messages of a capture in one pass each) against the oracle's detect_center
+    and get_plateau_lengths message by message: message sizes from 0 to 300 000 samples (partial tiles, partial pairwise chunks),
+    noise-gated stretches inside messages, a constant message (zero variance -> no center), an all-noise message."""
+    import torch
+    from urh_amd import estimators
+    rng = np.random.default_rng(404)
+    n = 1_500_000
+    qad = (np.repeat(rng.integers(0, 2, n // 50 + 1), 50)[:n] * 1.1 - 0.55 + 0.08 * rng.standard_normal(n)).astype(np.float32)
+    qad[rng.integers(0, n, 20_000)] = -4.0                         # noise-gated samples sprinkled in
+    qad[400_000:400_700] = -4.0
+    bounds = [(0, 0), (5, 9), (10, 137), (200, 8392), (9000, 9000 + 8192), (20_000, 20_000 + 16_384 + 77), (50_000, 350_000),
+              (360_000, 500_001), (600_000, 600_050), (700_000, 900_123), (1_000_000, 1_000_000 + 4096), (1_100_000, 1_499_999)]
+    qad[600_000:600_050] = 0.25                                    # constant: zero variance
+    qad[1_000_000:1_000_000 + 4096] = -4.0                         # all noise: nothing kept
+    dev = torch.from_numpy(qad).cuda()
+    centers = estimators.centers_batched(pipe, dev, bounds)
+    for (a, b), c in zip(bounds, centers):
+        want = oracle.detect_center(qad[a:b]) if b > a else None
+        assert (c is None and want is None) or (c is not None and want is not None and float(c) == float(want)), ((a, b), c, want)
+    assert sum(c is not None for c in centers) >= 6
+    use = [c if c is not None else (0.1 if i % 2 else None) for i, c in enumerate(centers)]
+    plats = estimators.plateau_lengths_batched(pipe, dev, bounds, use)
+    for (a, b), c, got in zip(bounds, use, plats):
+        want = oracle.get_plateau_lengths(qad[a:b], c, 25) if c is not None else np.zeros(0, np.uint64)
+        assert np.array_equal(np.asarray(got, dtype=np.uint64), np.asarray(want, dtype=np.uint64)), ((a, b), c, len(got), len(want))
+    # a long plateau beyond the first search window (25 % + 65 536 samples): the batched pass reports it, the caller repeats it
+    flat = np.full(600_000, 0.5, np.float32)
+    flat[:10_000] = np.where((np.arange(10_000) // 100) % 2 == 0, 0.5, -0.5)
+    flat[590_000:] = -0.5
+    got = estimators.plateau_lengths_batched(pipe, torch.from_numpy(flat).cuda(), [(0, 600_000)], [0.0])[0]
+    assert np.array_equal(np.asarray(got, np.uint64), oracle.get_plateau_lengths(flat, 0.0, 25))
+
+
 def test_estimate_equals_reference_goldens(pipe):
     """AutoInterpretation.estimate on the GPU vs what the real reference returned for the same captures
     (tests/golden/estimates.json, made by tests/golden/make_estimate_golden.py): identical dict, floats included."""

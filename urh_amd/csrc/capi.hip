@@ -133,7 +133,9 @@ int dtype_bytes(int dtype) {
 bool prof_begin_record(urhgpu_ctx *ctx, hipStream_t s) {
     const bool prof = ctx->prof_on && (size_t)(4 * ctx->prof_used + 3) < ctx->prof_events.size();
     if (!prof) return false;
-    if (hipEventRecord(ctx->prof_events[4 * ctx->prof_used], s) != hipSuccess) return false;
+    // the stream-level bracket costs two more barrier packets around the hot launch (about 10 us of bubbles per pass): only
+    // on request (URH_PROFILE_BRACKET, comparison of the two timings); the dispatch-attached pair costs nothing extra
+    if (ctx->prof_bracket && hipEventRecord(ctx->prof_events[4 * ctx->prof_used], s) != hipSuccess) return false;
     g_hot_events.start = ctx->prof_events[4 * ctx->prof_used + 2];
     g_hot_events.stop = ctx->prof_events[4 * ctx->prof_used + 3];
     g_hot_events.used = false;
@@ -142,7 +144,8 @@ bool prof_begin_record(urhgpu_ctx *ctx, hipStream_t s) {
 int prof_end_record(urhgpu_ctx *ctx, hipStream_t s) {
     const bool used = g_hot_events.used;
     g_hot_events = HotEvents();
-    URH_HIP(hipEventRecord(ctx->prof_events[4 * ctx->prof_used + 1], s));
+    if (ctx->prof_bracket) URH_HIP(hipEventRecord(ctx->prof_events[4 * ctx->prof_used + 1], s));
+    else if (!used) return URHGPU_OK;             // a launch made of several kernels (state-byte path): no record without the bracket
     if ((size_t)ctx->prof_used >= ctx->prof_dispatch.size()) ctx->prof_dispatch.resize((size_t)ctx->prof_used + 1);
     ctx->prof_dispatch[(size_t)ctx->prof_used] = used;
     ctx->prof_used += 1;
@@ -462,6 +465,7 @@ int urhgpu_ctx_profile_begin(urhgpu_ctx *ctx, int max_records) {
     }
     ctx->prof_used = 0;
     ctx->prof_on = max_records > 0;
+    ctx->prof_bracket = getenv("URH_PROFILE_BRACKET") != nullptr;
     return URHGPU_OK;
 }
 
@@ -472,7 +476,7 @@ int urhgpu_ctx_profile_end(urhgpu_ctx *ctx, float *ms_out, int cap, int *n_recor
     ctx->prof_on = false;
     const int n = ctx->prof_used;
     *n_records = n;
-    const bool bracket = getenv("URH_PROFILE_BRACKET") != nullptr;   // report the stream-level bracket instead (comparison)
+    const bool bracket = ctx->prof_bracket;                          // report the stream-level bracket instead (comparison)
     for (int k = 0; k < n && k < cap; ++k) {
         const int base = 4 * k + ((ctx->prof_dispatch[(size_t)k] && !bracket) ? 2 : 0);
         URH_HIP(hipEventElapsedTime(&ms_out[k], ctx->prof_events[base], ctx->prof_events[base + 1]));

@@ -72,6 +72,7 @@ struct urhgpu_ctx {
     std::vector<bool> prof_dispatch;       // record k: the dispatch-attached pair was used
     int prof_used = 0;                     // pairs recorded since urhgpu_ctx_profile_begin
     bool prof_on = false;
+    bool prof_bracket = false;             // also bracket the hot launch with stream-level events (URH_PROFILE_BRACKET)
     void *shard = nullptr;                 // state of a sharded pass between its phases (capi.hip: ShardSession)
     // Pipelined mode (urhgpu_ctx_set_pipelined): the hot kernel of a pass runs on `stream`, everything after it on
     // `tail_stream`, with two scratch arenas used alternately, so that the hot kernel of the NEXT pass overlaps the

@@ -1,0 +1,564 @@
+// msg_estimators.hip -- AutoInterpretation.estimate's per-message statistics for ALL messages of a capture at once.
+//
+// The reference (src/urh/ainterpretation/AutoInterpretation.py:373-471) walks the messages one by one: detect_center
+// (:226-277: noise removal, 5 % trim, min / max, np.var, np.histogram) and get_plateau_lengths
+// (cythonext/auto_interpretation.pyx:179-208) per message.  Doing the same on the GPU message by message costs a dozen
+// launches and several read-backs per message (seconds for a hundred messages).  Here every stage is ONE launch over a tile
+// table that covers all messages, results stay in device memory between the stages, and the host reads back twice per capture:
+//   urhgpu_msg_center_stats   kept count, trimmed length, min, max, mean, variance and the histogram of every message
+//   urhgpu_msg_plateaus       plateau lengths of every message for the centers the host picked from those histograms
+// The arithmetic is the reference's: float32 sums in numpy's pairwise order (see estimators.hip), float64 bin edges
+// first + i * delta as np.arange fills them, np.histogram's half-open bins with the last one closed.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <math.h>
+#include <vector>
+
+#include "common.hpp"
+#include "launchers.hpp"
+
+namespace urh {
+
+constexpr int kMeTile = 4096;                 // samples per tile: 256 threads x 16 consecutive samples
+constexpr int kMeBlock = 256;
+constexpr int kMePer = kMeTile / kMeBlock;
+constexpr int kPwChunkM = 8192, kPwLeafM = 128, kLeavesPerTile = kMeTile / kPwLeafM;    // numpy's pairwise summation geometry
+
+struct MsgTile { int32_t msg; int32_t idx; };           // tile `idx` of message `msg`
+
+struct MsgState {            // one per message, device resident between the stages (host mirror: same layout)
+    int64_t start, end;      // sample range in the demodulated signal
+    int64_t first_tile;      // index of its first tile in the tile table
+    int64_t kept;            // samples > -4 (AutoInterpretation.py:227)
+    int64_t a, L;            // trimmed range [a, a + L) of the kept samples (:231)
+    float mn, mx;            // util.minmax of the trimmed samples (:236)
+    float mean, var;         // float32 np.mean / np.var (:240)
+    double e0, delta;        // bin edges e0 + i * delta (np.arange(min, max + step, step), :243)
+    int64_t n_edges;         // 0: no histogram (empty, zero / NaN variance, fewer than 2 edges); > max_bins + 1: too many for the pool
+    int64_t n_plateaus;      // urhgpu_msg_plateaus: plateaus found, -1: the window did not reach the 25 % mark
+    int64_t edge_cnt;        // boundaries found in the window
+    int64_t window;          // samples of the message searched for boundaries
+    double center;           // center handed to urhgpu_msg_plateaus (NaN: none)
+};
+
+// ---- stage 1: stable compaction of x > -4 per message into kept[start + j] ----------------------------------------------
+__global__ __launch_bounds__(kMeBlock) void k_me_count(const float *x, const MsgState *st, const MsgTile *tiles, int32_t *tile_cnt) {
+    __shared__ int s_w[kMeBlock / 64];
+    const MsgTile t = tiles[blockIdx.x];
+    const int64_t base = st[t.msg].start + (int64_t)t.idx * kMeTile, end = st[t.msg].end;
+    int c = 0;
+    const int64_t i0 = base + (int64_t)threadIdx.x * kMePer;
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) if (i0 + j < end && x[i0 + j] > -4.0f) ++c;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// sum of v[0 .. n) by the whole workgroup (every thread gets it)
+__device__ __forceinline__ int64_t block_sum_i32(const int32_t *v, int64_t n) {
+    __shared__ int64_t s_p[kMeBlock / 64];
+    int64_t acc = 0;
+    for (int64_t u = threadIdx.x; u < n; u += kMeBlock) acc += v[u];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    return s_p[0] + s_p[1] + s_p[2] + s_p[3];
+}
+
+__global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgState *st, const MsgTile *tiles, const int32_t *tile_cnt,
+                                                          float *kept) {
+    __shared__ int s_w[kMeBlock / 64];
+    const MsgTile t = tiles[blockIdx.x];
+    const MsgState m = st[t.msg];
+    const int64_t before = block_sum_i32(tile_cnt + m.first_tile, t.idx);        // kept samples in the message's earlier tiles
+    const int64_t base = m.start + (int64_t)t.idx * kMeTile;
+    const int64_t i0 = base + (int64_t)threadIdx.x * kMePer;
+    float v[kMePer];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) { v[j] = (i0 + j < m.end) ? x[i0 + j] : -5.0f; if (v[j] > -4.0f) ++c; }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kMeBlock / 64; ++w) { if (w < wave) wbase += s_w[w]; total += s_w[w]; }
+    int64_t o = m.start + before + wbase + incl - c;
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) if (v[j] > -4.0f) kept[o++] = v[j];
+    if (threadIdx.x == 0 && base + kMeTile >= m.end) st[t.msg].kept = before + total;      // the message's last tile
+}
+
+// ---- stage 2: trim, pairwise-summation geometry -------------------------------------------------------------------------
+__global__ void k_me_trim(MsgState *st, int n_msgs) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_msgs) return;
+    const int64_t k = st[m].kept;
+    const int64_t a = (int64_t)(0.05 * (double)k), b = (int64_t)(0.95 * (double)k);     // int(0.05 * len), int(0.95 * len) (:231)
+    st[m].a = a;
+    st[m].L = b > a ? b - a : 0;
+}
+
+// ---- stage 3: min / max (util.minmax: seeded with element 0, `<` / `>` folds -- NaN never replaces a value) ----------------
+__global__ __launch_bounds__(kMeBlock) void k_me_minmax(const float *kept, const MsgState *st, const MsgTile *tiles, float2 *tile_mm) {
+    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
+    const MsgTile t = tiles[blockIdx.x];
+    const MsgState m = st[t.msg];
+    if (m.L <= 0) return;
+    const float *r = kept + m.start + m.a;
+    float mn = r[0], mx = r[0];
+    const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
+    for (int j = 0; j < kMePer; ++j) {
+        const int64_t i = i0 + (int64_t)j * kMeBlock;
+        if (i < m.L) { const float v = r[i]; if (v < mn) mn = v; if (v > mx) mx = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kMeBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
+        tile_mm[blockIdx.x] = float2{mn, mx};
+    }
+}
+__global__ __launch_bounds__(64) void k_me_minmax_fin(MsgState *st, const float2 *tile_mm, const float *kept) {
+    const int m = blockIdx.x;
+    MsgState s = st[m];
+    if (s.L <= 0) return;
+    const int64_t nt = (s.L + kMeTile - 1) / kMeTile;
+    float mn = kept[s.start + s.a], mx = mn;
+    for (int64_t u = threadIdx.x; u < nt; u += 64) {
+        const float2 p = tile_mm[s.first_tile + u];
+        if (p.x < mn) mn = p.x;
+        if (p.y > mx) mx = p.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+    if (threadIdx.x == 0) { st[m].mn = mn; st[m].mx = mx; }
+}
+
+// ---- stage 4: numpy's float32 pairwise sums (np.mean, np.var) ---------------------------------------------------------------
+// see estimators.hip for the order: chunks of 8192 accumulated left to right, a full chunk = perfect binary tree over 64 leaves
+// of 128 elements, a leaf = 8 strided accumulators combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); the irregular last chunk is
+// split recursively (n2 = n/2 rounded down to a multiple of 8).
+__device__ __forceinline__ float me_elem(const float *r, int64_t i, int mode, float mean) {
+    const float v = r[i];
+    if (mode == 0) return v;
+    const float d = v - mean;
+    return d * d;
+}
+// leaf sums of the FULL chunks: 8 threads per leaf (one per accumulator), 32 leaves per tile
+__global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *kept, const MsgState *st, const MsgTile *tiles, int mode, float *leaf_sums) {
+    const MsgTile t = tiles[blockIdx.x];
+    const MsgState m = st[t.msg];
+    const int64_t n_full_leaves = (m.L / kPwChunkM) * (kPwChunkM / kPwLeafM);
+    const int64_t leaf = (int64_t)t.idx * kLeavesPerTile + (threadIdx.x >> 3);
+    const int j = threadIdx.x & 7;
+    float acc = 0.f;
+    const bool live = leaf < n_full_leaves;
+    if (live) {
+        const float *r = kept + m.start + m.a + leaf * kPwLeafM;
+        acc = me_elem(r, j, mode, m.mean);
+#pragma unroll
+        for (int i = 8; i < kPwLeafM; i += 8) acc += me_elem(r, i + j, mode, m.mean);
+    }
+    // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) across the 8 lanes of the leaf
+    acc = acc + __shfl_down(acc, 1);
+    acc = acc + __shfl_down(acc, 2);
+    acc = acc + __shfl_down(acc, 4);
+    if (live && j == 0) leaf_sums[m.first_tile * kLeavesPerTile + leaf] = acc;
+}
+// one wavefront per message: chunk trees, the left-to-right accumulation of the chunk sums, the irregular rest, the result
+__device__ float me_rest_sum(const float *r, int64_t n, int mode, float mean) {     // pw(a, n) for n < 8192, one thread, explicit stack
+    // iterative post-order evaluation of the recursion: stack of (offset, length, state)
+    struct Frame { int32_t off, len; float left; int32_t state; };
+    Frame stack[16];
+    int sp = 0;
+    stack[0] = Frame{0, (int32_t)n, 0.f, 0};
+    float ret = 0.f;
+    while (sp >= 0) {
+        Frame &f = stack[sp];
+        if (f.len <= kPwLeafM) {
+            const float *a = r + f.off;
+            const int len = f.len;
+            float res;
+            if (len < 8) {
+                res = 0.f;
+                for (int i = 0; i < len; ++i) res += me_elem(a, i, mode, mean);
+            } else {
+                float q[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) q[j] = me_elem(a, j, mode, mean);
+                int i;
+                for (i = 8; i < len - (len % 8); i += 8) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) q[j] += me_elem(a, i + j, mode, mean);
+                }
+                res = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+                for (; i < len; ++i) res += me_elem(a, i, mode, mean);
+            }
+            ret = res;
+            --sp;
+            continue;
+        }
+        int32_t n2 = f.len / 2;
+        n2 -= n2 % 8;
+        if (f.state == 0) { f.state = 1; stack[sp + 1] = Frame{f.off, n2, 0.f, 0}; ++sp; }
+        else if (f.state == 1) { f.left = ret; f.state = 2; stack[sp + 1] = Frame{f.off + n2, f.len - n2, 0.f, 0}; ++sp; }
+        else { ret = f.left + ret; --sp; }
+    }
+    return ret;
+}
+__global__ __launch_bounds__(64) void k_me_sum_fin(const float *kept, MsgState *st, const float *leaf_sums, int mode) {
+    __shared__ float s_chunk[64];
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const MsgState s = st[m];
+    if (s.L <= 0) return;
+    const int64_t n_chunks = s.L / kPwChunkM, rest = s.L % kPwChunkM;
+    const float *ls = leaf_sums + s.first_tile * kLeavesPerTile;
+    float total = 0.f;
+    // chunk c: lane i holds leaf 64 c + i; tree s[i] = s[2i] + s[2i+1] level by level
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += 64) {
+        const int64_t nc = (n_chunks - c0 < 64) ? n_chunks - c0 : 64;
+        for (int64_t c = 0; c < nc; ++c) {
+            float v = ls[(c0 + c) * 64 + lane];
+            v = v + __shfl_down(v, 1);
+            v = v + __shfl_down(v, 2);
+            v = v + __shfl_down(v, 4);
+            v = v + __shfl_down(v, 8);
+            v = v + __shfl_down(v, 16);
+            v = v + __shfl_down(v, 32);
+            if (lane == 0) s_chunk[c] = v;
+        }
+        __syncthreads();
+        if (lane == 0) for (int64_t c = 0; c < nc; ++c) total = total + s_chunk[c];      // total = ((0 + c0) + c1) + ...
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (rest) total = total + me_rest_sum(kept + s.start + s.a + n_chunks * kPwChunkM, rest, mode, s.mean);
+        const float res = total / (float)s.L;                   // float32 sum / float32 count
+        if (mode == 0) st[m].mean = res; else st[m].var = res;
+    }
+}
+
+// ---- stage 5: bin edges (np.arange(min, max + step, step) in float64) and histogram ---------------------------------------
+__global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_msgs) return;
+    MsgState s = st[m];
+    int64_t ne = 0;
+    double e0 = 0, delta = 0;
+    if (s.L > 0) {
+        const double step = (double)s.var, start = (double)s.mn, stop = (double)s.mx + step;
+        // np.arange: length = ceil((stop - start) / step); step == 0 -> ZeroDivisionError, NaN -> ValueError: no histogram (:246-248)
+        if (step == step && step != 0.0 && start == start && stop == stop) {
+            const double q = (stop - start) / step;
+            if (q == q && q < 9.0e15) {
+                double len = ceil(q);
+                if (len < 0) len = 0;
+                ne = (int64_t)len;
+                e0 = start;
+                delta = (start + step) - start;               // np.arange fills first + i * (second - first)
+            }
+        }
+        if (ne < 2) ne = 0;                                    // np.histogram needs at least two edges (ValueError -> None)
+    }
+    st[m].n_edges = ne; st[m].e0 = e0; st[m].delta = delta;
+    (void)max_bins;
+}
+__device__ __forceinline__ double me_edge(const MsgState &s, int64_t i) { return s.e0 + (double)i * s.delta; }
+
+__global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *kept, const MsgState *st, const MsgTile *tiles, int64_t max_bins,
+                                                       unsigned int *counts) {
+    const MsgTile t = tiles[blockIdx.x];
+    const MsgState m = st[t.msg];
+    if (m.L <= 0 || m.n_edges < 2 || m.n_edges - 1 > max_bins) return;
+    const int64_t nb = m.n_edges - 1;
+    const double e0 = m.e0, eN = me_edge(m, nb);
+    const float *r = kept + m.start + m.a;
+    unsigned int *out = counts + (int64_t)t.msg * max_bins;
+    const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
+    for (int j = 0; j < kMePer; ++j) {
+        const int64_t i = i0 + (int64_t)j * kMeBlock;
+        if (i >= m.L) break;
+        const double v = (double)r[i];
+        if (!(v >= e0) || !(v <= eN)) continue;                // outside (or NaN)
+        int64_t k = (m.delta > 0.0) ? (int64_t)((v - e0) / m.delta) : 0;
+        if (k < 0) k = 0;
+        if (k > nb - 1) k = nb - 1;
+        while (k > 0 && me_edge(m, k) > v) --k;                // exact edge arithmetic decides (the guess is within one bin)
+        while (k < nb - 1 && me_edge(m, k + 1) <= v) ++k;      // last bin closed on the right
+        atomicAdd(&out[k], 1u);
+    }
+}
+
+// ---- plateaus: boundaries of (x <= center) per message, first 25 % (get_plateau_lengths) -----------------------------------
+__global__ __launch_bounds__(kMeBlock) void k_me_edge_count(const float *x, const MsgState *st, const MsgTile *tiles, int32_t *tile_cnt) {
+    __shared__ int s_w[kMeBlock / 64];
+    const MsgTile t = tiles[blockIdx.x];
+    const MsgState m = st[t.msg];
+    int c = 0;
+    if (m.center == m.center) {
+        const float cen = (float)m.center;
+        const int64_t lo = (int64_t)t.idx * kMeTile + (int64_t)threadIdx.x * kMePer;
+#pragma unroll
+        for (int j = 0; j < kMePer; ++j) {
+            const int64_t i = lo + j;                          // position inside the message
+            if (i >= 1 && i < m.window && ((x[m.start + i] <= cen) != (x[m.start + i - 1] <= cen))) ++c;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ __launch_bounds__(kMeBlock) void k_me_edge_compact(const float *x, MsgState *st, const MsgTile *tiles, const int32_t *tile_cnt,
+                                                               int32_t *edges /* positions inside the message, region = message start */) {
+    __shared__ int s_w[kMeBlock / 64];
+    const MsgTile t = tiles[blockIdx.x];
+    const MsgState m = st[t.msg];
+    if (!(m.center == m.center)) { if (threadIdx.x == 0 && t.idx == 0) st[t.msg].edge_cnt = 0; return; }
+    const int64_t before = block_sum_i32(tile_cnt + m.first_tile, t.idx);
+    const float cen = (float)m.center;
+    const int64_t lo = (int64_t)t.idx * kMeTile + (int64_t)threadIdx.x * kMePer;
+    bool e[kMePer];
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) {
+        const int64_t i = lo + j;
+        e[j] = i >= 1 && i < m.window && ((x[m.start + i] <= cen) != (x[m.start + i - 1] <= cen));
+        if (e[j]) ++c;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kMeBlock / 64; ++w) { if (w < wave) wbase += s_w[w]; total += s_w[w]; }
+    int64_t o = m.start + before + wbase + incl - c;
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) if (e[j]) edges[o++] = (int32_t)(lo + j);
+    const int64_t last_tile = (m.window + kMeTile - 1) / kMeTile - 1;
+    if (threadIdx.x == 0 && t.idx == last_tile) st[t.msg].edge_cnt = before + total;
+}
+// plateau k = [B_{k-1}, B_k) (B_{-1} = 0) counts while the plateaus appended before it sum to less than limit = 25 * len / 100
+// (C integer division): lengths[k] = B_k - B_{k-1} for B_{k-1} < limit.  In place: edges[] becomes lengths[].
+__global__ __launch_bounds__(64) void k_me_plateaus(MsgState *st, int32_t *edges, int percentage) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    const MsgState s = st[m];
+    if (!(s.center == s.center)) { if (lane == 0) st[m].n_plateaus = 0; return; }
+    const int64_t len = s.end - s.start, limit = ((int64_t)percentage * len) / 100;
+    int32_t *b = edges + s.start;
+    const int64_t found = s.edge_cnt;
+    // is the window enough?  it is when it is the whole message, or holds a boundary at or beyond the limit
+    const bool enough = (s.window >= len) || (found > 0 && (int64_t)b[found - 1] >= limit);
+    // number of plateaus kept: those whose start B_{k-1} < limit, i.e. k = 0 (start 0, kept iff limit > 0 ... the reference's
+    // loop appends plateau 0 at the first boundary whenever it gets there: current_sum = 0 < limit unless limit == 0)
+    int64_t keep = 0;
+    for (int64_t k0 = 0; k0 < found; k0 += 64) {
+        const int64_t k = k0 + lane;
+        bool kept = false;
+        if (k < found) { const int64_t startk = k ? (int64_t)b[k - 1] : 0; kept = startk < limit; }
+        keep += __popcll(__ballot(kept));
+    }
+    // lengths in place, back to front would overwrite what is still needed: go front to back keeping the previous boundary
+    int64_t prev_last = 0;
+    for (int64_t k0 = 0; k0 < keep; k0 += 64) {
+        const int64_t k = k0 + lane;
+        int32_t cur = 0, prev = 0;
+        if (k < keep) { cur = b[k]; prev = k ? ((k == k0) ? (int32_t)prev_last : b[k - 1]) : 0; }
+        const int32_t last = __shfl(cur, 63);
+        __syncthreads();
+        if (k < keep) b[k] = cur - prev;
+        prev_last = last;
+        __syncthreads();
+    }
+    if (lane == 0) st[m].n_plateaus = enough ? keep : -1;
+}
+
+// lengths of every message, back to back, as uint64 (what get_plateau_lengths returns)
+__global__ __launch_bounds__(64) void k_me_gather(const MsgState *st, const int32_t *lengths, const int64_t *out_begin, uint64_t *out) {
+    const int m = blockIdx.x;
+    const int64_t k = st[m].n_plateaus, o = out_begin[m];
+    const int32_t *src = lengths + st[m].start;
+    for (int64_t i = threadIdx.x; i < k; i += 64) out[o + i] = (uint64_t)(uint32_t)src[i];
+}
+
+}  // namespace urh
+
+using namespace urh;
+
+namespace {
+
+struct MsgBatch {
+    std::vector<MsgState> host;
+    std::vector<MsgTile> tiles;
+    MsgState *d_state = nullptr;
+    MsgTile *d_tiles = nullptr;
+    int64_t n_tiles = 0;
+};
+
+// tile table over [start, start + span_m) of every message; span = whole message (window = nullptr) or the given windows
+int build_batch(urhgpu_ctx *ctx, const int64_t *ranges, int n_msgs, int64_t n, const int64_t *windows, MsgBatch &b) {
+    b.host.resize((size_t)n_msgs);
+    b.tiles.clear();
+    for (int m = 0; m < n_msgs; ++m) {
+        const int64_t s = ranges[2 * m], e = ranges[2 * m + 1];
+        if (s < 0 || e < s || e > n) return URHGPU_ERR_ARG;
+        MsgState st;
+        memset(&st, 0, sizeof(st));
+        st.start = s; st.end = e; st.first_tile = (int64_t)b.tiles.size();
+        st.center = __builtin_nan("");
+        const int64_t span = windows ? windows[m] : e - s;
+        st.window = span;
+        const int64_t nt = (std::max<int64_t>(span, 1) + kMeTile - 1) / kMeTile;
+        if (nt > INT32_MAX) return URHGPU_ERR_UNSUPPORTED;
+        for (int64_t j = 0; j < nt; ++j) b.tiles.push_back(MsgTile{m, (int32_t)j});
+        b.host[(size_t)m] = st;
+    }
+    b.n_tiles = (int64_t)b.tiles.size();
+    return URHGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins,
+                            double *out_stats, int64_t *out_hist) {
+    if (!ctx || n < 0 || n_msgs < 0 || max_bins < 1 || (n_msgs > 0 && (!ranges || !out_stats || !out_hist || !d_x))) return URHGPU_ERR_ARG;
+    if (n_msgs == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    MsgBatch b;
+    URH_TRY(build_batch(ctx, ranges, n_msgs, n, nullptr, b));
+    // scratch: state, tiles, per-tile counts / min-max, leaf sums, the compacted samples, the histogram pool
+    const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)b.n_tiles * (sizeof(MsgTile) + 4 + 8 + kLeavesPerTile * 4) +
+                        (size_t)n * 4 + (size_t)n_msgs * (size_t)max_bins * 4 + 16 * 256;
+    URH_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
+    MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
+    int32_t *d_cnt = (int32_t *)ctx->arena.take((size_t)b.n_tiles * 4);
+    float2 *d_mm = (float2 *)ctx->arena.take((size_t)b.n_tiles * 8);
+    float *d_leaf = (float *)ctx->arena.take((size_t)b.n_tiles * kLeavesPerTile * 4);
+    float *d_kept = (float *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
+    unsigned int *d_hist = (unsigned int *)ctx->arena.take((size_t)n_msgs * (size_t)max_bins * 4);
+    if (!d_st || !d_tiles || !d_cnt || !d_mm || !d_leaf || !d_kept || !d_hist) return URHGPU_ERR_ARG;
+    hipStream_t s = ctx->stream;
+    URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
+    URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
+    URH_HIP(hipMemsetAsync(d_hist, 0, (size_t)n_msgs * (size_t)max_bins * 4, s));
+    const unsigned gt = (unsigned)b.n_tiles, gm = (unsigned)((n_msgs + 63) / 64);
+    hipLaunchKernelGGL(k_me_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
+    hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_kept);
+    hipLaunchKernelGGL(k_me_trim, dim3(gm), dim3(64), 0, s, d_st, n_msgs);
+    hipLaunchKernelGGL(k_me_minmax, dim3(gt), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles, d_mm);
+    hipLaunchKernelGGL(k_me_minmax_fin, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_mm, d_kept);
+    for (int mode = 0; mode < 2; ++mode) {
+        hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles, mode, d_leaf);
+        hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(64), 0, s, d_kept, d_st, d_leaf, mode);
+    }
+    hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins);
+    hipLaunchKernelGGL(k_me_hist, dim3(gt), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles, max_bins, d_hist);
+    URH_HIP(hipGetLastError());
+    std::vector<unsigned int> hist((size_t)n_msgs * (size_t)max_bins);
+    URH_HIP(hipMemcpyAsync(b.host.data(), d_st, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost, s));
+    URH_HIP(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
+    URH_HIP(hipStreamSynchronize(s));
+    for (int m = 0; m < n_msgs; ++m) {
+        const MsgState &st = b.host[(size_t)m];
+        double *o = out_stats + 8 * (size_t)m;
+        o[0] = (double)st.kept; o[1] = (double)st.L; o[2] = (double)st.mn; o[3] = (double)st.mx; o[4] = (double)st.mean; o[5] = (double)st.var;
+        o[6] = (double)st.n_edges; o[7] = st.e0;
+        int64_t *h = out_hist + (size_t)m * (size_t)max_bins;
+        const int64_t nb = (st.n_edges >= 2 && st.n_edges - 1 <= max_bins) ? st.n_edges - 1 : 0;
+        for (int64_t k = 0; k < max_bins; ++k) h[k] = (k < nb) ? (int64_t)hist[(size_t)m * (size_t)max_bins + (size_t)k] : 0;
+    }
+    return URHGPU_OK;
+}
+
+int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
+                        int percentage, int64_t extra_window, int64_t *out_off, uint64_t *out_len, int64_t cap_total) {
+    if (!ctx || n < 0 || n_msgs < 0 || percentage < 0 || extra_window < 0 || cap_total < 0 ||
+        (n_msgs > 0 && (!ranges || !centers || !out_off || !d_x)))
+        return URHGPU_ERR_ARG;
+    if (out_off) out_off[0] = 0;
+    if (n_msgs == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    // boundaries are searched in [0, 25 % + extra_window) of every message; a message whose window holds no boundary at or
+    // beyond the 25 % mark comes back with count -1 (the caller repeats it with a larger window)
+    std::vector<int64_t> windows((size_t)n_msgs);
+    for (int m = 0; m < n_msgs; ++m) {
+        const int64_t len = ranges[2 * m + 1] - ranges[2 * m];
+        if (len > INT32_MAX) return URHGPU_ERR_UNSUPPORTED;       // positions inside a message are 32-bit
+        const int64_t limit = ((int64_t)percentage * len) / 100;
+        windows[(size_t)m] = std::min<int64_t>(len, limit + extra_window);
+    }
+    MsgBatch b;
+    URH_TRY(build_batch(ctx, ranges, n_msgs, n, windows.data(), b));
+    for (int m = 0; m < n_msgs; ++m) b.host[(size_t)m].center = centers[m];
+    const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)b.n_tiles * (sizeof(MsgTile) + 4) + (size_t)std::max<int64_t>(n, 1) * 4 + 8 * 256;
+    URH_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
+    MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
+    int32_t *d_cnt = (int32_t *)ctx->arena.take((size_t)b.n_tiles * 4);
+    int32_t *d_edges = (int32_t *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
+    if (!d_st || !d_tiles || !d_cnt || !d_edges) return URHGPU_ERR_ARG;
+    hipStream_t s = ctx->stream;
+    URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
+    URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
+    const unsigned gt = (unsigned)b.n_tiles;
+    hipLaunchKernelGGL(k_me_edge_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
+    hipLaunchKernelGGL(k_me_edge_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_edges);
+    hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
+    URH_HIP(hipGetLastError());
+    URH_HIP(hipMemcpyAsync(b.host.data(), d_st, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost, s));
+    URH_HIP(hipStreamSynchronize(s));
+    // end offsets; a message whose window was too small has no plateaus here and is marked -(end + 1)
+    std::vector<int64_t> begin((size_t)n_msgs);
+    int64_t total = 0;
+    for (int m = 0; m < n_msgs; ++m) {
+        const int64_t k = b.host[(size_t)m].n_plateaus;
+        begin[(size_t)m] = total;
+        total += (k > 0) ? k : 0;
+        out_off[m + 1] = (k < 0) ? -(total + 1) : total;
+    }
+    if (total > cap_total) { out_off[n_msgs] = total; return URHGPU_ERR_CAPACITY; }
+    if (total > 0) {
+        URH_TRY(ctx->staging.reserve((size_t)n_msgs * 8 + (size_t)total * 8 + 1024));
+        ctx->staging.reset();
+        int64_t *d_begin = (int64_t *)ctx->staging.take((size_t)n_msgs * 8);
+        uint64_t *d_out = (uint64_t *)ctx->staging.take((size_t)total * 8);
+        if (!d_begin || !d_out) return URHGPU_ERR_ARG;
+        URH_HIP(hipMemcpyAsync(d_begin, begin.data(), (size_t)n_msgs * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_me_gather, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, d_begin, d_out);
+        URH_HIP(hipGetLastError());
+        URH_HIP(hipMemcpyAsync(out_len, d_out, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+        URH_HIP(hipStreamSynchronize(s));
+    }
+    return URHGPU_OK;
+}
+
+}  // extern "C"

@@ -325,24 +325,25 @@ def round_plateau_lengths(plateau_lengths):
 
 def get_threshold_divisor_histogram(plateau_lengths, threshold=0.2) -> np.ndarray:
     """auto_interpretation.get_threshold_divisor_histogram (auto_interpretation.pyx:113-143): histogram[min(x, y)] += 1
-    for every pair whose ratio max / min has a fractional part below `threshold` (float32 threshold, double ratio)."""
+    for every pair (i < j) whose ratio max / min has a fractional part below `threshold` (float32 threshold, double ratio).
+
+    The reference walks all P^2 / 2 pairs; the outcome of a pair depends on its two VALUES only, and after
+    round_plateau_lengths there are few distinct ones, so the histogram is assembled from the value multiset:
+    c_a * c_b pairs for distinct values a < b that pass the test, c_a * (c_a - 1) / 2 pairs of equal values (ratio 1)."""
     p = np.asarray(plateau_lengths, dtype=np.uint64)
     hist = np.zeros(int(np.max(p)) + 1, dtype=np.uint64)
+    vals, counts = np.unique(p[p != 0], return_counts=True)
+    if len(vals) == 0:
+        return hist
     thr = float(np.float32(threshold))
-    pf = p.astype(np.float64)
-    for i in range(len(p) - 1):
-        x = p[i]
-        if x == 0:
-            continue
-        y = p[i + 1:]
-        yf = pf[i + 1:]
-        lo = np.minimum(x, y)
-        hi_f = np.maximum(pf[i], yf)
-        lo_f = np.minimum(pf[i], yf)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            frac = hi_f / lo_f - (np.maximum(x, y) // np.where(lo == 0, 1, lo)).astype(np.float64)
-        ok = (y != 0) & (frac < thr)
-        np.add.at(hist, lo[ok].astype(np.int64), 1)
+    c = counts.astype(np.uint64)
+    hist[vals.astype(np.int64)] += c * (c - np.uint64(1)) // np.uint64(2)
+    if len(vals) > 1:
+        lo = vals[:, None]                                     # vals ascending: row a < column b above the diagonal
+        hi = vals[None, :]
+        frac = hi.astype(np.float64) / lo.astype(np.float64) - (hi // lo).astype(np.float64)
+        ok = np.triu(frac < thr, k=1)
+        hist[vals.astype(np.int64)] += (ok * c[None, :]).sum(axis=1, dtype=np.uint64) * c
     return hist
 
 
@@ -482,11 +483,89 @@ def detect_modulation_for_messages_dev(iq, message_indices: list):
     return most_common(mods)
 
 
+def centers_batched(pipe, data, message_indices, max_bins: int = 4096):
+    """detect_center (AutoInterpretation.py:226-277) of every message: the statistics and histograms of ALL messages come from
+    one batched device pass (urhgpu_msg_center_stats, one read-back); picking the peaks of a few dozen bins per message is
+    host work.  A message whose histogram has more than max_bins bins (a nearly constant signal: tiny variance) goes through
+    the single-message path.  Returns a list with a float or None per message."""
+    x = _dev_f32(pipe, data)
+    n_msgs = len(message_indices)
+    if n_msgs == 0:
+        return []
+    ranges = np.ascontiguousarray(message_indices, dtype=np.int64).reshape(-1, 2)
+    stats = np.zeros((n_msgs, 8), dtype=np.float64)
+    hist = np.zeros((n_msgs, max_bins), dtype=np.int64)
+    _lib.check(_lib.load().urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
+                                                   n_msgs, max_bins, stats.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p)))
+    centers = []
+    for m in range(n_msgs):
+        n_edges = int(stats[m, 6])
+        if n_edges < 2:
+            centers.append(None)
+        elif n_edges - 1 > max_bins:
+            centers.append(detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])]))
+        else:
+            hist_min, hist_max, step = float(stats[m, 2]), float(stats[m, 3]), float(stats[m, 5])
+            with np.errstate(all="ignore"):
+                edges = np.arange(hist_min, hist_max + step, step)              # the same edges the device binned with
+            if len(edges) != n_edges or edges[0] != stats[m, 7]:                # cannot happen; never bin against other edges silently
+                centers.append(detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])]))
+            else:
+                centers.append(center_from_histogram(hist[m, :n_edges - 1], edges))
+    return centers
+
+
+def plateau_lengths_batched(pipe, data, message_indices, centers, percentage: int = 25):
+    """get_plateau_lengths (auto_interpretation.pyx:179-208) of every message that has a center: one batched device pass
+    (urhgpu_msg_plateaus), one read-back.  Returns a list of uint64 arrays (empty for messages without a center)."""
+    x = _dev_f32(pipe, data)
+    n_msgs = len(message_indices)
+    if n_msgs == 0:
+        return []
+    ranges = np.ascontiguousarray(message_indices, dtype=np.int64).reshape(-1, 2)
+    cen = np.array([np.nan if c is None else float(np.float32(c)) for c in centers], dtype=np.float64)
+    off = np.zeros(n_msgs + 1, dtype=np.int64)
+    cap = int(max(1 << 16, (ranges[:, 1] - ranges[:, 0]).sum() // 64))
+    lib = _lib.load()
+    while True:
+        lens = np.zeros(cap, dtype=np.uint64)
+        st = lib.urhgpu_msg_plateaus(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
+                                     cen.ctypes.data_as(C.c_void_p), n_msgs, int(percentage), 1 << 16, off.ctypes.data_as(C.c_void_p),
+                                     lens.ctypes.data_as(C.c_void_p), cap)
+        if st == _lib.ERR_CAPACITY:
+            cap = int(off[n_msgs])
+            continue
+        _lib.check(st)
+        break
+    out = []
+    begin = 0
+    for m in range(n_msgs):
+        end = int(off[m + 1])
+        if end < 0:                                # no boundary beyond the 25 % mark inside the first window: single-message path
+            end = -end - 1
+            out.append(get_plateau_lengths_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], centers[m], percentage))
+        else:
+            out.append(lens[begin:end].copy())
+        begin = end
+    return out
+
+
+def bit_length_of_message(plateau_lengths):
+    """(tolerance or None, bit_length or None) of one message from its plateau lengths: glitch tolerance, merged plateaus,
+    divisor histogram (AutoInterpretation.py:416-433)."""
+    tolerance = estimate_tolerance_from_plateau_lengths(plateau_lengths)
+    merged = merge_plateau_lengths(plateau_lengths, tolerance=0 if tolerance is None else tolerance)
+    if len(merged) < 2:
+        return tolerance, None
+    return tolerance, get_bit_length_from_plateau_lengths(merged)
+
+
 def estimate_dev(pipe, iq, noise: float = None, modulation: str = None):
-    """AutoInterpretation.estimate (AutoInterpretation.py:373-470) for a float32 capture resident on the GPU: every pass
-    over the samples (magnitude statistics, segmentation, demodulation, per-message center and plateau boundaries) runs
-    on the GPU, the per-message decisions -- including detect_modulation on the first 100 messages, numpy like the
-    reference -- on the host."""
+    """AutoInterpretation.estimate (AutoInterpretation.py:373-470) for a float32 capture resident on the GPU.  Device passes over
+    the samples: magnitude statistics, segmentation, demodulation, then TWO batched passes over all messages (center statistics +
+    histograms; plateau boundaries for the chosen centers).  The host sees a histogram of a few dozen bins and a few thousand
+    plateau lengths per message and takes the decisions the reference takes (peak picking, tolerance, merged plateaus, divisor
+    histogram from the multiset of rounded lengths), plus detect_modulation on the first 100 messages like the reference."""
     from .pipeline import DemodParams
     torch = pipe.torch
     if iq.dtype == torch.complex64:
@@ -506,23 +585,16 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None):
     else:
         raise ValueError("Unsupported Modulation")
     data = pipe.afp_demod(iq, DemodParams(mod, 1, float(noise)))
+    all_centers = centers_batched(pipe, data, message_indices)
+    all_plateaus = plateau_lengths_batched(pipe, data, message_indices, all_centers)
     centers, bit_lengths, tolerances = [], [], []
-    for start, end in message_indices:
-        msg = data[start:end]
-        center = detect_center_dev(pipe, msg)
+    for center, plateau_lengths in zip(all_centers, all_plateaus):
         if center is None:
             continue
-        plateau_lengths = get_plateau_lengths_dev(pipe, msg, center, percentage=25)
-        tolerance = estimate_tolerance_from_plateau_lengths(plateau_lengths)
-        if tolerance is None:
-            tolerance = 0
-        else:
+        tolerance, bit_length = bit_length_of_message(plateau_lengths)
+        if tolerance is not None:
             tolerances.append(tolerance)
-        merged_lengths = merge_plateau_lengths(plateau_lengths, tolerance=tolerance)
-        if len(merged_lengths) < 2:
-            continue
-        bit_length = get_bit_length_from_plateau_lengths(merged_lengths)
-        if bit_length > tolerance + 1:
+        if bit_length is not None and bit_length > (tolerance or 0) + 1:
             centers.append(center)
             bit_lengths.append(bit_length)
     if modulation in ("OOK", "ASK"):
