@@ -257,7 +257,9 @@ def extra_config3(pipe, dev, args):
                                              C.c_void_p(filt.data_ptr())))
     _, t_fir = _timed(torch, fir)
     noise, t_noise = _timed(torch, lambda: estimators.detect_noise_level_dev(pipe, filt))
-    est, t_est = _timed(torch, lambda: estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK"), reps=2)
+    est, t_est = _timed(torch, lambda: estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK"), reps=3)
+    est_stages = {}
+    estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK", timings=est_stages)
     center = float(est["center"]) if est else 0.0
     p = DemodParams("ASK", 1, float(noise), center, 1.0, 5, 100, 0.1, 8, True)
     res, t_bits = _timed(torch, lambda: pipe.iq_to_bits_checked(filt, p, want_qad=True))
@@ -266,6 +268,7 @@ def extra_config3(pipe, dev, args):
            "samples": n, "ms": round(total_ms, 3),
            "stages_ms": {"fir_filter": round(t_fir, 3), "detect_noise_level": round(t_noise, 3), "estimate": round(t_est, 3),
                          "iq_to_bits_ask": round(t_bits, 3)},
+           "estimate_stages_ms": est_stages,
            "estimated": {k: (float(v) if not isinstance(v, str) else v) for k, v in (est or {}).items()},
            "roofline": {"algorithmic_bytes_per_sample": 28,
                         "hbm_frac": round(28 * n / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -310,10 +313,17 @@ def extra_config3(pipe, dev, args):
         par["qad_mismatches"] = int((res.qad.cpu().numpy().view(np.uint32) != ref_qad.view(np.uint32)).sum())
         par["rows_equal"] = bool(np.array_equal(res.ppseq(), ref_pp))
         par["bits_pauses_positions_equal"] = bool(all(np.array_equal(a, b) for a, b in zip(res.flat(), ref_flat)))
-        # against the transmitter: every message carries the 10 000 chips of its segment
+        # against the transmitter (sanity, not the parity criterion): message m carries the chips of segment 4 + m from its first
+        # "1" chip on (leading and trailing "0" chips of an OOK message are indistinguishable from the pause around it)
         bits, off = res.flat()[0], res.flat()[1]
-        ok_msgs = sum(1 for m in range(len(off) - 1) if off[m + 1] - off[m] >= 10000 and np.array_equal(bits[off[m]:off[m] + 10000], chips[4 + m])
-                      ) if len(off) - 1 <= chips.shape[0] - 4 else 0
+        ok_msgs = 0
+        if len(off) - 1 <= chips.shape[0] - 4:
+            for m in range(len(off) - 1):
+                c = chips[4 + m]
+                lead = int(np.argmax(c))
+                got = bits[off[m]:off[m + 1]]
+                L = min(len(got), len(c) - lead)
+                ok_msgs += int(L >= 9900 and np.array_equal(got[:L], c[lead:lead + L]))
         par["messages_equal_transmitted_chips"] = int(ok_msgs)
         par["bit_exact"] = bool(par["fir_mismatches"] == 0 and par["qad_mismatches"] == 0 and par["rows_equal"] and
                                 par["bits_pauses_positions_equal"] and par.get("noise_equal", True) and par.get("estimate_equal", True))

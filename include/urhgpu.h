@@ -306,6 +306,10 @@ int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const 
 int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
                         int percentage, int64_t extra_window, int64_t *out_off, uint64_t *out_len, int64_t cap_total);
 
+/* auto_interpretation.merge_plateaus (auto_interpretation.pyx:145-176): host arrays, host arithmetic (sequential, a few thousand
+ * values); out needs room for n values, *n_out = number of merged plateaus. */
+int urhgpu_merge_plateaus(const uint64_t *plateaus, int64_t n, uint64_t tolerance, uint64_t max_count, uint64_t *out, int64_t *n_out);
+
 /* Test hook: the hot kernel's fast-path division (Newton + residual chain without scaling) against the IEEE
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);

@@ -186,48 +186,31 @@ __global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *kept, const
     if (live && j == 0) leaf_sums[m.first_tile * kLeavesPerTile + leaf] = acc;
 }
 // one wavefront per message: chunk trees, the left-to-right accumulation of the chunk sums, the irregular rest, the result
-__device__ float me_rest_sum(const float *r, int64_t n, int mode, float mean) {     // pw(a, n) for n < 8192, one thread, explicit stack
-    // iterative post-order evaluation of the recursion: stack of (offset, length, state)
-    struct Frame { int32_t off, len; float left; int32_t state; };
-    Frame stack[16];
-    int sp = 0;
-    stack[0] = Frame{0, (int32_t)n, 0.f, 0};
-    float ret = 0.f;
-    while (sp >= 0) {
-        Frame &f = stack[sp];
-        if (f.len <= kPwLeafM) {
-            const float *a = r + f.off;
-            const int len = f.len;
-            float res;
-            if (len < 8) {
-                res = 0.f;
-                for (int i = 0; i < len; ++i) res += me_elem(a, i, mode, mean);
-            } else {
-                float q[8];
+__device__ __forceinline__ float me_leaf_sum(const float *a, int len, int mode, float mean) {      // pw(a, len) for len <= 128
+    float res;
+    if (len < 8) {
+        res = 0.f;
+        for (int i = 0; i < len; ++i) res += me_elem(a, i, mode, mean);
+    } else {
+        float q[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) q[j] = me_elem(a, j, mode, mean);
-                int i;
-                for (i = 8; i < len - (len % 8); i += 8) {
+        for (int j = 0; j < 8; ++j) q[j] = me_elem(a, j, mode, mean);
+        int i;
+        for (i = 8; i < len - (len % 8); i += 8) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) q[j] += me_elem(a, i + j, mode, mean);
-                }
-                res = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-                for (; i < len; ++i) res += me_elem(a, i, mode, mean);
-            }
-            ret = res;
-            --sp;
-            continue;
+            for (int j = 0; j < 8; ++j) q[j] += me_elem(a, i + j, mode, mean);
         }
-        int32_t n2 = f.len / 2;
-        n2 -= n2 % 8;
-        if (f.state == 0) { f.state = 1; stack[sp + 1] = Frame{f.off, n2, 0.f, 0}; ++sp; }
-        else if (f.state == 1) { f.left = ret; f.state = 2; stack[sp + 1] = Frame{f.off + n2, f.len - n2, 0.f, 0}; ++sp; }
-        else { ret = f.left + ret; --sp; }
+        res = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+        for (; i < len; ++i) res += me_elem(a, i, mode, mean);
     }
-    return ret;
+    return res;
 }
+constexpr int kMeRestLeaves = 256;            // a rest of < 8192 elements splits into at most 128 leaves
 __global__ __launch_bounds__(64) void k_me_sum_fin(const float *kept, MsgState *st, const float *leaf_sums, int mode) {
     __shared__ float s_chunk[64];
+    __shared__ int s_off[kMeRestLeaves], s_len[kMeRestLeaves];
+    __shared__ float s_sum[kMeRestLeaves];
+    __shared__ int s_nleaf;
     const int m = blockIdx.x, lane = threadIdx.x;
     const MsgState s = st[m];
     if (s.L <= 0) return;
@@ -251,8 +234,48 @@ __global__ __launch_bounds__(64) void k_me_sum_fin(const float *kept, MsgState *
         if (lane == 0) for (int64_t c = 0; c < nc; ++c) total = total + s_chunk[c];      // total = ((0 + c0) + c1) + ...
         __syncthreads();
     }
+    // the irregular last chunk: pw(a, n) = pw(a, n2) + pw(a + n2, n - n2), n2 = n / 2 rounded down to a multiple of 8, down to
+    // leaves of <= 128 elements.  Lane 0 lists the leaves (left to right), the lanes sum them, lane 0 combines along the same tree.
+    struct Frame { int32_t off, len, state; float left; };
     if (lane == 0) {
-        if (rest) total = total + me_rest_sum(kept + s.start + s.a + n_chunks * kPwChunkM, rest, mode, s.mean);
+        int nl = 0;
+        if (rest) {
+            Frame stack[16];
+            int sp = 0;
+            stack[0] = Frame{0, (int32_t)rest, 0, 0.f};
+            while (sp >= 0) {
+                Frame &f = stack[sp];
+                if (f.len <= kPwLeafM) { s_off[nl] = f.off; s_len[nl] = f.len; ++nl; --sp; continue; }
+                int32_t n2 = f.len / 2;
+                n2 -= n2 % 8;
+                if (f.state == 0) { f.state = 1; stack[sp + 1] = Frame{f.off, n2, 0, 0.f}; ++sp; }
+                else if (f.state == 1) { f.state = 2; stack[sp + 1] = Frame{f.off + n2, f.len - n2, 0, 0.f}; ++sp; }
+                else --sp;
+            }
+        }
+        s_nleaf = nl;
+    }
+    __syncthreads();
+    const float *ra = kept + s.start + s.a + n_chunks * kPwChunkM;
+    for (int k = lane; k < s_nleaf; k += 64) s_sum[k] = me_leaf_sum(ra + s_off[k], s_len[k], mode, s.mean);
+    __syncthreads();
+    if (lane == 0) {
+        if (rest) {
+            Frame stack[16];
+            int sp = 0, next = 0;
+            float ret = 0.f;
+            stack[0] = Frame{0, (int32_t)rest, 0, 0.f};
+            while (sp >= 0) {
+                Frame &f = stack[sp];
+                if (f.len <= kPwLeafM) { ret = s_sum[next++]; --sp; continue; }
+                int32_t n2 = f.len / 2;
+                n2 -= n2 % 8;
+                if (f.state == 0) { f.state = 1; stack[sp + 1] = Frame{f.off, n2, 0, 0.f}; ++sp; }
+                else if (f.state == 1) { f.left = ret; f.state = 2; stack[sp + 1] = Frame{f.off + n2, f.len - n2, 0, 0.f}; ++sp; }
+                else { ret = f.left + ret; --sp; }
+            }
+            total = total + ret;
+        }
         const float res = total / (float)s.L;                   // float32 sum / float32 count
         if (mode == 0) st[m].mean = res; else st[m].var = res;
     }
@@ -285,18 +308,28 @@ __global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins) {
 }
 __device__ __forceinline__ double me_edge(const MsgState &s, int64_t i) { return s.e0 + (double)i * s.delta; }
 
+constexpr int kMeHistLds = 4096;             // bins kept in LDS per workgroup (the pool's max_bins is at most this)
 __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *kept, const MsgState *st, const MsgTile *tiles, int64_t max_bins,
                                                        unsigned int *counts) {
+    // demodulated signals sit on two or four levels: nearly every sample of a message lands in a handful of bins.  Counting
+    // straight into device memory serialises the whole pass on those few addresses (40 ms for a 1 GiB capture); a thread counts
+    // runs of equal bins in a register, the workgroup in LDS, and only the non-empty bins of a tile reach device memory.
+    __shared__ unsigned int s_c[kMeHistLds];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
     if (m.L <= 0 || m.n_edges < 2 || m.n_edges - 1 > max_bins) return;
     const int64_t nb = m.n_edges - 1;
+    const bool in_lds = nb <= kMeHistLds;
+    if (in_lds) for (int k = threadIdx.x; k < nb; k += kMeBlock) s_c[k] = 0u;
+    __syncthreads();
     const double e0 = m.e0, eN = me_edge(m, nb);
     const float *r = kept + m.start + m.a;
     unsigned int *out = counts + (int64_t)t.msg * max_bins;
-    const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
+    const int64_t i0 = (int64_t)t.idx * kMeTile + (int64_t)threadIdx.x * kMePer;      // 16 consecutive samples per thread
+    int64_t run_bin = -1;
+    unsigned int run = 0;
     for (int j = 0; j < kMePer; ++j) {
-        const int64_t i = i0 + (int64_t)j * kMeBlock;
+        const int64_t i = i0 + j;
         if (i >= m.L) break;
         const double v = (double)r[i];
         if (!(v >= e0) || !(v <= eN)) continue;                // outside (or NaN)
@@ -305,7 +338,14 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *kept, const M
         if (k > nb - 1) k = nb - 1;
         while (k > 0 && me_edge(m, k) > v) --k;                // exact edge arithmetic decides (the guess is within one bin)
         while (k < nb - 1 && me_edge(m, k + 1) <= v) ++k;      // last bin closed on the right
-        atomicAdd(&out[k], 1u);
+        if (k == run_bin) { ++run; continue; }
+        if (run) { if (in_lds) atomicAdd(&s_c[run_bin], run); else atomicAdd(&out[run_bin], run); }
+        run_bin = k; run = 1;
+    }
+    if (run) { if (in_lds) atomicAdd(&s_c[run_bin], run); else atomicAdd(&out[run_bin], run); }
+    if (in_lds) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < nb; k += kMeBlock) if (s_c[k]) atomicAdd(&out[k], s_c[k]);
     }
 }
 
@@ -558,6 +598,33 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
         URH_HIP(hipMemcpyAsync(out_len, d_out, (size_t)total * 8, hipMemcpyDeviceToHost, s));
         URH_HIP(hipStreamSynchronize(s));
     }
+    return URHGPU_OK;
+}
+
+// auto_interpretation.merge_plateaus (auto_interpretation.pyx:145-176) on the host: plateaus of at most `tolerance` samples are
+// glitches and merge with their neighbours; a run of alternating glitches (67, 1, 10, 1, 21) merges as a whole.  Sequential by
+// nature (what a merge swallows decides where the next one starts) and a few thousand elements long: native host code, as the
+// reference's is.  out: n entries of room; *n_out = merged plateaus (at most max_count + 1).
+int urhgpu_merge_plateaus(const uint64_t *plateaus, int64_t n, uint64_t tolerance, uint64_t max_count, uint64_t *out, int64_t *n_out) {
+    if (n < 0 || !n_out || (n > 0 && (!plateaus || !out))) return URHGPU_ERR_ARG;
+    if (n == 0) { *n_out = 0; return URHGPU_OK; }
+    uint64_t cur = 0;
+    out[0] = plateaus[0] <= tolerance ? 0 : plateaus[0];
+    int64_t i = 1;
+    while (i < n && cur < max_count) {
+        if (plateaus[i] <= tolerance) {
+            int64_t span = 2;                                   // the glitch and the plateau after it ...
+            while (i + span < n && plateaus[i + span] <= tolerance) span += 2;     // ... and further alternating glitches
+            const int64_t stop = std::min<int64_t>(n, i + span);
+            uint64_t sum = 0;
+            for (int64_t j = i - 1; j < stop; ++j) sum += plateaus[j];
+            out[cur] = sum;
+            i += span;
+        } else {
+            out[++cur] = plateaus[i++];
+        }
+    }
+    *n_out = (int64_t)cur + 1;
     return URHGPU_OK;
 }
 

@@ -65,7 +65,7 @@ def _dev_f32(pipe, x):
     return x
 
 
-def segment_messages_dev(pipe, iq, noise_threshold: float):
+def segment_messages_dev(pipe, iq, noise_threshold: float, as_array: bool = False):
     """auto_interpretation.segment_messages_from_magnitudes (auto_interpretation.pyx:55-111) for a float32 capture on
     the GPU: list of (start, end).  The above/below-noise state machine with its 10-sample outlier tolerance is the
     run segmentation of the hot kernel with tolerance 9 on |sample| (urhgpu_segment_runs_dev); the host walks the
@@ -75,7 +75,7 @@ def segment_messages_dev(pipe, iq, noise_threshold: float):
         iq = torch.view_as_real(iq)
     n = int(iq.shape[0])
     if n == 0 or math.isnan(float(noise_threshold)):        # nothing compares greater than NaN: never above the noise
-        return []
+        return np.zeros((0, 2), np.int64) if as_array else []
     pipe.ctx.set_stream(torch.cuda.current_stream(iq.device).cuda_stream)
     cap = n // 10 + 2
     rows = torch.empty((cap, 2), dtype=torch.int64, device=iq.device)
@@ -93,54 +93,60 @@ def segment_messages_dev(pipe, iq, noise_threshold: float):
         s32 = ((a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
         with np.errstate(invalid="ignore"):
             tail_mag = np.sqrt(s32.astype(np.float64))
-    return segments_from_rows(r, n, tail_mag > float(np.float32(noise_threshold)))
+    seg = _segments_array(r, n, tail_mag > float(np.float32(noise_threshold)))
+    return seg if as_array else _as_tuples(seg)
 
 
 def segments_from_rows(rows: np.ndarray, n: int, tail_above: np.ndarray):
     """rows: pulse table of the above(1)/below(0) states with tolerance 9 (row j: state BEFORE the j-th change, length);
-    tail_above: above-noise flags of the last <= 10 samples."""
-    result = []
-    state = int(rows[0, 0])                      # state of sample 0
-    start = 0
-    # run starts of the accepted state changes: r_1 = len_0 - 1, r_{k+1} = r_k + len_k
-    lens = rows[:, 1]
+    tail_above: above-noise flags of the last <= 10 samples.  Returns the reference's list of (start, end) tuples.
+
+    Change k (k >= 1) happens at sample pos_k = len_0 - 1 + len_1 + ... + len_{k-1} (the run that triggered it started 10 samples
+    earlier); a change to "above" opens a message at pos_k - 1 (auto_interpretation.pyx:101-104), a change to "below" closes the open
+    one at pos_k - 1 (:95-99).  States alternate, so opens and closes pair up in order -- all of it array arithmetic."""
+    return _as_tuples(_segments_array(rows, n, tail_above))
+
+
+def _as_tuples(seg: np.ndarray):
+    return list(zip(seg[:, 0].tolist(), seg[:, 1].tolist()))
+
+
+def _segments_array(rows: np.ndarray, n: int, tail_above: np.ndarray) -> np.ndarray:
+    """segments_from_rows as an int64 (K, 2) array (an OOK capture has one segment per pulse: hundreds of thousands)"""
+    rows = np.asarray(rows, dtype=np.int64)
+    states, lens = rows[:, 0], rows[:, 1]
     n_changes = len(rows) - 1
-    pos = int(lens[0]) - 1
-    for k in range(1, n_changes + 1):
-        new_state = int(rows[k, 0])
-        if new_state == 1:                       # -1 -> 1 after 10 samples above: start = i - conseq_above (:101-104)
-            start = pos - 1
-        else:                                    # 1 -> -1 after 10 samples below: (start, i - conseq_below) (:95-99)
-            result.append((start, pos - 1))
-        state = new_state
-        pos += int(lens[k]) if k < n_changes else 0
-    if state == 1:                               # :107-109
-        conseq_below = 0
-        for a in tail_above[::-1]:
-            if a:
-                break
-            conseq_below += 1
+    pos = lens[0] - 1 + np.concatenate([[0], np.cumsum(lens[1:n_changes])]) if n_changes > 0 else np.zeros(0, np.int64)
+    new_states = states[1:]
+    opens = pos[new_states == 1] - 1
+    closes = pos[new_states != 1] - 1
+    if int(states[0]) == 1:                          # the capture starts above the noise: a message is open from sample 0
+        opens = np.concatenate([[0], opens])
+    seg = np.stack([opens[:len(closes)], closes], axis=1).astype(np.int64).reshape(-1, 2)
+    if int(states[-1]) == 1:                         # still above at the end (:107-109): closes where the trailing below-run starts
+        start = int(opens[-1]) if len(opens) else 0
+        below = np.asarray(tail_above)[::-1]
+        conseq_below = int(np.argmax(below)) if below.any() else len(below)
         if start < n - conseq_below:
-            result.append((start, n - conseq_below))
-    return result
+            seg = np.concatenate([seg, np.array([[start, n - conseq_below]], dtype=np.int64)])
+    return seg
 
 
 def merge_message_segments_for_ook(segments: list):
-    """AutoInterpretation.merge_message_segments_for_ook (AutoInterpretation.py:107-148)."""
+    """AutoInterpretation.merge_message_segments_for_ook (AutoInterpretation.py:107-148): OOK pulses separated by pauses shorter
+    than 8 x the (outlier-free) minimum pulse length belong to one message.  A merged message starts at its first pulse and is as
+    long as its pulses and inner pauses together -- which telescopes to "ends where its last pulse ends"."""
     if len(segments) <= 1:
         return segments
-    seg = np.asarray(segments, dtype=np.int64)
+    seg = np.asarray(segments, dtype=np.int64).reshape(-1, 2)
     pauses = (seg[1:, 0] - seg[:-1, 1]).astype(np.uint64)
     pulses = (seg[:, 1] - seg[:, 0]).astype(np.uint64)
     min_pulse_length = min_without_outliers(pulses, z=1)
-    large = np.nonzero(pauses >= 8 * min_pulse_length)[0]
-    bounds = [0] + [int(i) + 1 for i in large] + [len(segments)]
-    result = []
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        begin = int(seg[a, 0])
-        length = int((seg[a:b, 1] - seg[a:b, 0]).sum()) + int((seg[a + 1:b, 0] - seg[a:b - 1, 1]).sum())
-        result.append((begin, begin + length))
-    return result
+    cut = np.nonzero(pauses >= 8 * min_pulse_length)[0] + 1           # a new message starts after every long pause
+    first = np.concatenate([[0], cut])
+    last = np.concatenate([cut, [len(seg)]]) - 1
+    merged = np.stack([seg[first, 0], seg[last, 1]], axis=1)
+    return merged if isinstance(segments, np.ndarray) else _as_tuples(merged)
 
 
 def max_without_outliers(data: np.ndarray, z=3):
@@ -282,27 +288,14 @@ def estimate_tolerance_from_plateau_lengths(plateau_lengths, relative_max=0.05):
 
 def merge_plateaus(plateaus, tolerance, max_count=10000) -> np.ndarray:
     """auto_interpretation.merge_plateaus (auto_interpretation.pyx:145-176): plateaus <= tolerance are glitches and are
-    merged with their neighbours (looking ahead over alternating glitches); at most max_count merged plateaus."""
-    p = np.asarray(plateaus, dtype=np.uint64)
-    n = len(p)
-    if n == 0:
-        return np.zeros(0, dtype=np.uint64)
-    tolerance = int(tolerance)
-    result = np.empty(n, dtype=np.uint64)
-    result[0] = 0 if int(p[0]) <= tolerance else p[0]
-    current, i = 0, 1
-    while i < n and current < max_count:
-        if int(p[i]) <= tolerance:
-            step = 2
-            while i + step < n and int(p[i + step]) <= tolerance:
-                step += 2
-            result[current] = p[i - 1:min(n, i + step)].sum(dtype=np.uint64)
-            i += step
-        else:
-            current += 1
-            result[current] = p[i]
-            i += 1
-    return result[:current + 1]
+    merged with their neighbours (looking ahead over alternating glitches); at most max_count merged plateaus.
+    Sequential host arithmetic on a few thousand values: native code in the library (urhgpu_merge_plateaus), like the reference's."""
+    p = np.ascontiguousarray(plateaus, dtype=np.uint64)
+    out = np.empty(len(p), dtype=np.uint64)
+    n_out = C.c_int64(0)
+    _lib.check(_lib.load().urhgpu_merge_plateaus(p.ctypes.data_as(C.c_void_p), len(p), int(tolerance), int(max_count),
+                                                 out.ctypes.data_as(C.c_void_p), C.byref(n_out)))
+    return out[:n_out.value]
 
 
 def merge_plateau_lengths(plateau_lengths, tolerance=None):
@@ -315,12 +308,16 @@ def merge_plateau_lengths(plateau_lengths, tolerance=None):
 
 
 def round_plateau_lengths(plateau_lengths):
-    """AutoInterpretation.py:313-326 (in place): round to the leading digits, e.g. 99 -> 100, 293 -> 300."""
-    digit_counts = [len(str(p)) for p in plateau_lengths]
+    """AutoInterpretation.py:313-326 (in place): round to the leading digits, e.g. 99 -> 100, 293 -> 300.  The number of kept
+    digits is the median decimal length (at most 3); int(round(p / f)) * f with Python's round = half-to-even on the double quotient."""
+    p = np.asarray(plateau_lengths, dtype=np.uint64)
+    digit_counts = np.searchsorted(_POW10, p, side="right") + 1                 # len(str(p))
     n_digits = min(3, int(np.percentile(digit_counts, 50)))
     f = 10 ** (n_digits - 1)
-    for i, plateau_len in enumerate(plateau_lengths):
-        plateau_lengths[i] = int(round(plateau_len / f)) * f
+    plateau_lengths[:] = (np.rint(p / f).astype(np.uint64) * np.uint64(f)).astype(np.asarray(plateau_lengths).dtype)
+
+
+_POW10 = np.array([10 ** k for k in range(1, 20)], dtype=np.uint64)
 
 
 def get_threshold_divisor_histogram(plateau_lengths, threshold=0.2) -> np.ndarray:
@@ -560,20 +557,31 @@ def bit_length_of_message(plateau_lengths):
     return tolerance, get_bit_length_from_plateau_lengths(merged)
 
 
-def estimate_dev(pipe, iq, noise: float = None, modulation: str = None):
+def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings: dict = None):
     """AutoInterpretation.estimate (AutoInterpretation.py:373-470) for a float32 capture resident on the GPU.  Device passes over
     the samples: magnitude statistics, segmentation, demodulation, then TWO batched passes over all messages (center statistics +
     histograms; plateau boundaries for the chosen centers).  The host sees a histogram of a few dozen bins and a few thousand
     plateau lengths per message and takes the decisions the reference takes (peak picking, tolerance, merged plateaus, divisor
     histogram from the multiset of rounded lengths), plus detect_modulation on the first 100 messages like the reference."""
     from .pipeline import DemodParams
+    import time
     torch = pipe.torch
+    t_last = [time.perf_counter()]
+
+    def lap(name):                                   # stage wall times for bench.py's breakdown (timings given: synchronises)
+        if timings is not None:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            timings[name] = round((now - t_last[0]) * 1e3, 3)
+            t_last[0] = now
     if iq.dtype == torch.complex64:
         iq = torch.view_as_real(iq)
     noise = detect_noise_level_dev(pipe, iq) if noise is None else noise
-    message_indices = segment_messages_dev(pipe, iq, noise)
+    lap("noise_ms")
+    message_indices = segment_messages_dev(pipe, iq, noise, as_array=True)    # (K, 2) array: one row per OOK pulse before merging
+    lap("segment_messages_ms")
     if modulation is None:
-        modulation = detect_modulation_for_messages_dev(iq, message_indices)
+        modulation = detect_modulation_for_messages_dev(iq, message_indices[:100].tolist())
         if modulation is None:
             return None
     if modulation == "OOK":
@@ -584,9 +592,13 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None):
         mod = modulation
     else:
         raise ValueError("Unsupported Modulation")
+    lap("modulation_and_merge_ms")
     data = pipe.afp_demod(iq, DemodParams(mod, 1, float(noise)))
+    lap("afp_demod_ms")
     all_centers = centers_batched(pipe, data, message_indices)
+    lap("centers_ms")
     all_plateaus = plateau_lengths_batched(pipe, data, message_indices, all_centers)
+    lap("plateaus_ms")
     centers, bit_lengths, tolerances = [], [], []
     for center, plateau_lengths in zip(all_centers, all_plateaus):
         if center is None:
@@ -597,6 +609,7 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None):
         if bit_length is not None and bit_length > (tolerance or 0) + 1:
             centers.append(center)
             bit_lengths.append(bit_length)
+    lap("bit_lengths_host_ms")
     if modulation in ("OOK", "ASK"):
         center = min_without_outliers(np.array(centers), z=2)
         if center is None:
