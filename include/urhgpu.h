@@ -146,6 +146,11 @@ int urhgpu_fir_filter(urhgpu_ctx *ctx, const float *x, int64_t n, const float *t
  * to the m - 1 samples that precede d_x[0] (sharded captures: the left neighbour's tail). */
 int urhgpu_fir_filter_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const float *d_taps, int64_t m,
                           const float *d_left_halo, float *d_out);
+/* The same with the magnitude chunk statistics of the OUTPUT fused into the filter's epilogue (Signal.filter_range followed by
+ * detect_noise_level, AutoInterpretation.py:60-91, in one pass over the samples): d_sum[k] / d_max[k] (device, float64) for chunk k
+ * counted from the end, as urhgpu_magnitude_chunk_stats_dev computes them on a float32 capture. */
+int urhgpu_fir_filter_stats_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const float *d_taps, int64_t m, const float *d_left_halo,
+                                float *d_out, int64_t chunk, int64_t n_chunks, double *d_sum, double *d_max);
 
 /* Filter.apply_bandpass_filter (src/urh/signalprocessing/Filter.py:84-101; np.convolve(data, h, "same") at :98 and
  * Filter.fft_convolve_1d at :70-82 are the same centred linear convolution): complex64 x[n] (*) complex128 taps[m],

@@ -1001,6 +1001,28 @@ def test_costas_parallel_chain_large(sf, oracle, order):
     assert stats[0] > 0.85 * sum(stats[:3]), stats
 
 
+def test_fir_with_fused_noise_statistics(pipe, oracle):
+    """urhgpu_fir_filter_stats_dev: the filtered samples are those of urhgpu_fir_filter_dev bit for bit, and the noise threshold from
+    the fused chunk statistics equals detect_noise_level on the filtered signal (oracle), for sizes whose 1 % chunks cut tiles anywhere,
+    a capture with a left halo, and one too small for the fused path (chunk < one tile)."""
+    import torch
+    from urh_amd import estimators
+    from urh_amd.synth import spec_fir_taps
+    taps = spec_fir_taps()
+    rng = np.random.default_rng(31)
+    for n in (1_000_003, 409_600, 204_799, 2_500_000, 150_000):
+        env = np.repeat(rng.integers(0, 2, n // 5000 + 1), 5000)[:n]
+        env[: n // 10] = 0                                      # a noise-only stretch so that the estimator does not return 0
+        x = ((0.9 * env + 0.02 * rng.standard_normal(n)) * np.exp(2j * np.pi * 0.04 * np.arange(n)) + 0.02j * rng.standard_normal(n)).astype(np.complex64)
+        dev = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).cuda()
+        filt, noise = estimators.fir_filter_detect_noise_dev(pipe, dev, taps)
+        want_f = oracle.fir_filter(x, taps)
+        assert np.array_equal(filt.cpu().numpy().reshape(-1).view(np.uint32), want_f.view(np.uint32)), n
+        want_noise = oracle.detect_noise_level(oracle.get_magnitudes(want_f.view(np.float32).reshape(-1, 2)))
+        assert float(noise) == float(want_noise), (n, noise, want_noise)
+        assert n < 2_000_000 or noise > 0
+
+
 def test_sharded_fir_halo_then_bits(pipe, oracle):
     """configs[3]-style: 4 simulated ranks, FIR with the left neighbour's 63-sample tail as history, then the sharded
     IQ->bits pass on the filtered shards == one-pass oracle FIR + single-GPU pass."""

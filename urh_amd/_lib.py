@@ -74,6 +74,7 @@ PROTOTYPES = {
     "urhgpu_ppseq_to_bits": (_i, [_vp, _vp, _i64, _i64, _i, _i, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _vp]),
     "urhgpu_fir_filter": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "urhgpu_fir_filter_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "urhgpu_fir_filter_stats_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
     "urhgpu_bandpass": (_i, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     "urhgpu_bandpass_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _i]),
     "urhgpu_iir_filter": (_i, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),

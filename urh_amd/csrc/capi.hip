@@ -1300,6 +1300,27 @@ int urhgpu_fir_filter_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const fl
     return URHGPU_OK;
 }
 
+int urhgpu_fir_filter_stats_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const float *d_taps, int64_t m, const float *d_left_halo,
+                                float *d_out, int64_t chunk, int64_t n_chunks, double *d_sum, double *d_max) {
+    if (!ctx || n <= 0 || m <= 0 || !d_x || !d_out || !d_taps || chunk <= 0 || n_chunks <= 0 || !d_sum || !d_max) return URHGPU_ERR_ARG;
+    if (((uintptr_t)d_x & 7) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_taps & 7) || m > (int64_t)1 << 20) return URHGPU_ERR_ARG;
+    if (n_chunks * chunk > n || n_chunks > 65535) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    if (chunk < 2048) {          // a tile of outputs would meet more than two chunks: the filter, then the separate statistics pass
+        URH_TRY(urhgpu_fir_filter_dev(ctx, d_x, n, d_taps, m, d_left_halo, d_out));
+        return urhgpu_magnitude_chunk_stats_dev(ctx, d_out, URHGPU_DT_F32, n, chunk, n_chunks, d_sum, d_max);
+    }
+    URH_TRY(ctx->arena.reserve(fir_stats_scratch_bytes(n) + 1024));
+    ctx->arena.reset();
+    void *scratch = ctx->arena.take(fir_stats_scratch_bytes(n));
+    if (!scratch) return URHGPU_ERR_ARG;
+    URH_TRY(launch_fir((const float2 *)d_x, n, (const float2 *)d_taps, (int)m, (const float2 *)d_left_halo, (float2 *)d_out, ctx->stream,
+                       chunk, n_chunks, d_sum, d_max, scratch));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
 int urhgpu_fir_filter(urhgpu_ctx *ctx, const float *x, int64_t n, const float *taps, int64_t m, float *out) {
     if (!ctx || n < 0 || m < 0 || (n > 0 && (!x || !out)) || (m > 0 && !taps)) return URHGPU_ERR_ARG;
     if (n == 0) return URHGPU_OK;

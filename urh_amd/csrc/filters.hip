@@ -43,6 +43,10 @@ struct FirArgs {
     int m;
     int hist;                // staged history: multiple-of-R tap blocks, >= m - 1
     int64_t tile0;           // first tile of this launch
+    // fused magnitude chunk statistics of the OUTPUT (detect_noise_level's O(N) part, AutoInterpretation.py:60-91): chunk k counted
+    // from the end = outputs [n - (k+1) chunk, n - k chunk); a tile of 2048 outputs meets at most two chunks (chunk >= kFirTile)
+    int64_t chunk, n_chunks; // 0: no statistics
+    double *tile_stats;      // [tiles][4] = {sum, max} of the tile's outputs in its first chunk and in the next one
 };
 
 // The products of a tile can only come out as (NaN, NaN) -- the case the reference's complex multiply repairs with
@@ -135,10 +139,14 @@ __device__ __forceinline__ void fir_accumulate(const FirArgs &a, const float2 *s
     }
 }
 
-template <bool HEAD>
+// NaN-propagating maximum (np.max of a chunk that holds a NaN is NaN)
+__device__ __forceinline__ double fir_nanmax(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : ((b > a) ? b : a); }
+
+template <bool HEAD, bool STATS>
 __global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
     __shared__ uint32_t s_maxbits;
+    __shared__ double s_st[kFirBlock / 64][4];
     float2 *s_taps = (float2 *)s_raw;                       // [m]
     float2 *s_x = s_taps + ((a.m + 1) & ~1);                // [hist + kFirTile], s_x[u] = x[base - hist + u]
     const int t = threadIdx.x;
@@ -165,32 +173,93 @@ __global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
     const bool safe = s_maxbits < kFirSafeBits;
     constexpr int R = kFirR;
     const int64_t k0 = base + (int64_t)R * t;               // my first output
-    if (k0 >= a.n) return;
+    if (!STATS && k0 >= a.n) return;
     float2 acc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) acc[r] = make_float2(0.f, 0.f);
-    if (safe) fir_accumulate<HEAD, false>(a, s_taps, s_x, t, k0, acc);
-    else fir_accumulate<HEAD, true>(a, s_taps, s_x, t, k0, acc);
-    if (k0 + R <= a.n) {
+    if (k0 < a.n) {
+        if (safe) fir_accumulate<HEAD, false>(a, s_taps, s_x, t, k0, acc);
+        else fir_accumulate<HEAD, true>(a, s_taps, s_x, t, k0, acc);
+        if (k0 + R <= a.n) {
 #pragma unroll
-        for (int r = 0; r < R; r += 2) *(float4 *)(a.out + k0 + r) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
-    } else {
+            for (int r = 0; r < R; r += 2) *(float4 *)(a.out + k0 + r) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
+        } else {
 #pragma unroll
-        for (int r = 0; r < R; ++r) if (k0 + r < a.n) a.out[k0 + r] = acc[r];
+            for (int r = 0; r < R; ++r) if (k0 + r < a.n) a.out[k0 + r] = acc[r];
+        }
+    }
+    if (STATS) {
+        // magnitudes of the outputs as util.get_magnitudes computes them (float sqrtf, stored as double), summed per chunk
+        const int64_t rem = a.n - a.n_chunks * a.chunk;                  // outputs before `rem` belong to no chunk
+        const int64_t i0 = (base > rem) ? base : rem;                    // first output of the tile that counts
+        const int64_t kfirst = (i0 < a.n) ? (a.n - 1 - i0) / a.chunk : 0;
+        const int64_t split = a.n - kfirst * a.chunk;                    // outputs at or beyond it are in chunk kfirst - 1
+        double sum0 = 0.0, sum1 = 0.0, mx0 = 0.0, mx1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = k0 + r;
+            if (i >= rem && i < a.n) {
+                const double mg = (double)__builtin_sqrtf(acc[r].x * acc[r].x + acc[r].y * acc[r].y);
+                if (i < split) { sum0 += mg; mx0 = fir_nanmax(mx0, mg); } else { sum1 += mg; mx1 = fir_nanmax(mx1, mg); }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sum0 += __shfl_down(sum0, o); sum1 += __shfl_down(sum1, o);
+            mx0 = fir_nanmax(mx0, __shfl_down(mx0, o)); mx1 = fir_nanmax(mx1, __shfl_down(mx1, o));
+        }
+        if ((t & 63) == 0) { s_st[t >> 6][0] = sum0; s_st[t >> 6][1] = mx0; s_st[t >> 6][2] = sum1; s_st[t >> 6][3] = mx1; }
+        __syncthreads();
+        if (t == 0) {
+            double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+            for (int w = 0; w < kFirBlock / 64; ++w) { o0 += s_st[w][0]; o1 = fir_nanmax(o1, s_st[w][1]); o2 += s_st[w][2]; o3 = fir_nanmax(o3, s_st[w][3]); }
+            double *dst = a.tile_stats + 4 * (a.tile0 + blockIdx.x);
+            dst[0] = o0; dst[1] = o1; dst[2] = o2; dst[3] = o3;
+        }
     }
 }
 
-int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const float2 *halo, float2 *out, hipStream_t s) {
+// chunk k = outputs [lo, hi): the tiles that meet it, added in tile order by one wavefront (lane-strided, then a fixed tree)
+__global__ __launch_bounds__(64) void k_fir_stats_finish(const double *tile_stats, int64_t n, int64_t chunk, int64_t n_chunks, double *d_sum,
+                                                          double *d_max) {
+    const int64_t k = blockIdx.x;
+    const int64_t lo = n - (k + 1) * chunk, hi = lo + chunk, rem = n - n_chunks * chunk;
+    const int64_t t0 = lo / kFirTile, t1 = (hi - 1) / kFirTile;
+    double sum = 0.0, mx = 0.0;
+    for (int64_t tl = t0 + threadIdx.x; tl <= t1; tl += 64) {
+        const int64_t base = tl * kFirTile;
+        const int64_t i0 = (base > rem) ? base : rem;
+        const int64_t kfirst = (n - 1 - i0) / chunk;                     // the tile's slot 0 chunk; slot 1 is kfirst - 1
+        const int slot = (int)(kfirst - k);
+        if (slot == 0 || slot == 1) { sum += tile_stats[4 * tl + 2 * slot]; mx = fir_nanmax(mx, tile_stats[4 * tl + 2 * slot + 1]); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); mx = fir_nanmax(mx, __shfl_down(mx, o)); }
+    if (threadIdx.x == 0) { d_sum[k] = sum; d_max[k] = mx; }
+}
+
+size_t fir_stats_scratch_bytes(int64_t n) { return (size_t)((n + kFirTile - 1) / kFirTile + 1) * 4 * sizeof(double); }
+
+// stats: chunk > 0 asks for the magnitude chunk statistics of the output (chunk >= kFirTile, n_chunks * chunk <= n), written to
+// d_sum / d_max[n_chunks]; tile_scratch: fir_stats_scratch_bytes(n)
+int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const float2 *halo, float2 *out, hipStream_t s, int64_t chunk,
+               int64_t n_chunks, double *d_sum, double *d_max, void *tile_scratch) {
     if (n <= 0) return URHGPU_OK;
-    if (m <= 0) { return hipMemsetAsync(out, 0, (size_t)n * 8, s) == hipSuccess ? URHGPU_OK : URHGPU_ERR_HIP; }
+    const bool stats = chunk > 0 && n_chunks > 0;
+    if (stats && (chunk < kFirTile || n_chunks * chunk > n || !d_sum || !d_max || !tile_scratch)) return URHGPU_ERR_ARG;
+    if (m <= 0 && !stats) { return hipMemsetAsync(out, 0, (size_t)n * 8, s) == hipSuccess ? URHGPU_OK : URHGPU_ERR_HIP; }
+    if (m <= 0) return URHGPU_ERR_UNSUPPORTED;
     FirArgs a;
     a.x = x; a.halo = halo; a.taps = taps; a.out = out; a.n = n; a.m = m;
+    a.chunk = stats ? chunk : 0; a.n_chunks = stats ? n_chunks : 0; a.tile_stats = (double *)tile_scratch;
     a.hist = ((m - 1) / kFirR) * kFirR + kFirR - 1;
     const size_t lds = (size_t)(((m + 1) & ~1) + (a.hist + kFirTile) + ((a.hist + kFirTile) >> 3) + 1) * 8;
     if (lds > 150 * 1024) return URHGPU_ERR_UNSUPPORTED;       // m <= ~8900 taps
     if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void *)k_fir<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)k_fir<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute((const void *)k_fir<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_fir<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_fir<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void *)k_fir<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return URHGPU_ERR_HIP;
     }
     const int64_t tiles = (n + kFirTile - 1) / kFirTile;
@@ -198,12 +267,15 @@ int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const floa
     int64_t head_tiles = (halo == nullptr) ? std::min<int64_t>(tiles, ((int64_t)m - 1 + kFirTile - 1) / kFirTile) : 0;
     if (head_tiles > 0) {
         a.tile0 = 0;
-        hipLaunchKernelGGL(k_fir<true>, dim3((unsigned)head_tiles), dim3(kFirBlock), lds, s, a);
+        if (stats) hipLaunchKernelGGL((k_fir<true, true>), dim3((unsigned)head_tiles), dim3(kFirBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_fir<true, false>), dim3((unsigned)head_tiles), dim3(kFirBlock), lds, s, a);
     }
     if (tiles > head_tiles) {
         a.tile0 = head_tiles;
-        hipLaunchKernelGGL(k_fir<false>, dim3((unsigned)(tiles - head_tiles)), dim3(kFirBlock), lds, s, a);
+        if (stats) hipLaunchKernelGGL((k_fir<false, true>), dim3((unsigned)(tiles - head_tiles)), dim3(kFirBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_fir<false, false>), dim3((unsigned)(tiles - head_tiles)), dim3(kFirBlock), lds, s, a);
     }
+    if (stats) hipLaunchKernelGGL(k_fir_stats_finish, dim3((unsigned)n_chunks), dim3(64), 0, s, (const double *)tile_scratch, n, chunk, n_chunks, d_sum, d_max);
     return URHGPU_OK;
 }
 

@@ -58,25 +58,41 @@ __global__ __launch_bounds__(kMeBlock) void k_me_count(const float *x, const Msg
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
 
-// sum of v[0 .. n) by the whole workgroup (every thread gets it)
-__device__ __forceinline__ int64_t block_sum_i32(const int32_t *v, int64_t n) {
-    __shared__ int64_t s_p[kMeBlock / 64];
-    int64_t acc = 0;
-    for (int64_t u = threadIdx.x; u < n; u += kMeBlock) acc += v[u];
+// exclusive prefix of the per-tile counts over the whole tile table (ONE workgroup: the table has n / 4096 entries); a tile's
+// offset inside its message is pre[tile] - pre[message's first tile] -- no workgroup re-adds the counts of the tiles before it
+// (a capture that is ONE message of 2^27 samples has 32 768 tiles)
+constexpr int kMeScanBlock = 1024;
+__global__ __launch_bounds__(kMeScanBlock) void k_me_tile_scan(const int32_t *cnt, int64_t n_tiles, int64_t *pre) {
+    __shared__ int64_t s_w[kMeScanBlock / 64];
+    __shared__ int64_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t b0 = 0; b0 < n_tiles; b0 += kMeScanBlock) {
+        const int64_t i = b0 + threadIdx.x;
+        const int64_t v = (i < n_tiles) ? cnt[i] : 0;
+        int64_t incl = v;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    return s_p[0] + s_p[1] + s_p[2] + s_p[3];
+        for (int o = 1; o < 64; o <<= 1) { const int64_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+        if (lane == 63) s_w[wave] = incl;
+        __syncthreads();
+        int64_t base = s_carry, total = 0;
+#pragma unroll
+        for (int w = 0; w < kMeScanBlock / 64; ++w) { if (w < wave) base += s_w[w]; total += s_w[w]; }
+        if (i < n_tiles) pre[i] = base + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry += total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pre[n_tiles] = s_carry;
 }
 
-__global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgState *st, const MsgTile *tiles, const int32_t *tile_cnt,
+__global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgState *st, const MsgTile *tiles, const int64_t *tile_pre,
                                                           float *kept) {
     __shared__ int s_w[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
-    const int64_t before = block_sum_i32(tile_cnt + m.first_tile, t.idx);        // kept samples in the message's earlier tiles
+    const int64_t before = tile_pre[blockIdx.x] - tile_pre[m.first_tile];       // kept samples in the message's earlier tiles
     const int64_t base = m.start + (int64_t)t.idx * kMeTile;
     const int64_t i0 = base + (int64_t)threadIdx.x * kMePer;
     float v[kMePer];
@@ -185,7 +201,24 @@ __global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *kept, const
     acc = acc + __shfl_down(acc, 4);
     if (live && j == 0) leaf_sums[m.first_tile * kLeavesPerTile + leaf] = acc;
 }
-// one wavefront per message: chunk trees, the left-to-right accumulation of the chunk sums, the irregular rest, the result
+// full chunks: perfect binary tree over the 64 leaf sums of a chunk, one wavefront per chunk (a chunk = two tiles: the even tile's
+// workgroup does it).  chunk_sums[first_tile / 2 + message-local chunk] (first_tile counts tiles of the earlier messages).
+__global__ __launch_bounds__(64) void k_me_chunk_trees(const MsgState *st, const MsgTile *tiles, const float *leaf_sums, float *chunk_sums) {
+    const MsgTile t = tiles[blockIdx.x];
+    if (t.idx & 1) return;
+    const MsgState m = st[t.msg];
+    const int64_t c = t.idx >> 1;
+    if (c >= m.L / kPwChunkM) return;
+    float v = leaf_sums[m.first_tile * kLeavesPerTile + c * 64 + threadIdx.x];
+    v = v + __shfl_down(v, 1);                // s[i] = s[2i] + s[2i+1], level by level
+    v = v + __shfl_down(v, 2);
+    v = v + __shfl_down(v, 4);
+    v = v + __shfl_down(v, 8);
+    v = v + __shfl_down(v, 16);
+    v = v + __shfl_down(v, 32);
+    if (threadIdx.x == 0) chunk_sums[m.first_tile + c] = v;       // first_tile + c: distinct per (message, chunk), within the tile count
+}
+// one wavefront per message: the left-to-right accumulation of the chunk sums, the irregular rest, the result
 __device__ __forceinline__ float me_leaf_sum(const float *a, int len, int mode, float mean) {      // pw(a, len) for len <= 128
     float res;
     if (len < 8) {
@@ -206,7 +239,7 @@ __device__ __forceinline__ float me_leaf_sum(const float *a, int len, int mode, 
     return res;
 }
 constexpr int kMeRestLeaves = 256;            // a rest of < 8192 elements splits into at most 128 leaves
-__global__ __launch_bounds__(64) void k_me_sum_fin(const float *kept, MsgState *st, const float *leaf_sums, int mode) {
+__global__ __launch_bounds__(64) void k_me_sum_fin(const float *kept, MsgState *st, const float *chunk_sums, int mode) {
     __shared__ float s_chunk[64];
     __shared__ int s_off[kMeRestLeaves], s_len[kMeRestLeaves];
     __shared__ float s_sum[kMeRestLeaves];
@@ -215,21 +248,11 @@ __global__ __launch_bounds__(64) void k_me_sum_fin(const float *kept, MsgState *
     const MsgState s = st[m];
     if (s.L <= 0) return;
     const int64_t n_chunks = s.L / kPwChunkM, rest = s.L % kPwChunkM;
-    const float *ls = leaf_sums + s.first_tile * kLeavesPerTile;
+    const float *cs = chunk_sums + s.first_tile;
     float total = 0.f;
-    // chunk c: lane i holds leaf 64 c + i; tree s[i] = s[2i] + s[2i+1] level by level
     for (int64_t c0 = 0; c0 < n_chunks; c0 += 64) {
         const int64_t nc = (n_chunks - c0 < 64) ? n_chunks - c0 : 64;
-        for (int64_t c = 0; c < nc; ++c) {
-            float v = ls[(c0 + c) * 64 + lane];
-            v = v + __shfl_down(v, 1);
-            v = v + __shfl_down(v, 2);
-            v = v + __shfl_down(v, 4);
-            v = v + __shfl_down(v, 8);
-            v = v + __shfl_down(v, 16);
-            v = v + __shfl_down(v, 32);
-            if (lane == 0) s_chunk[c] = v;
-        }
+        if (lane < nc) s_chunk[lane] = cs[c0 + lane];
         __syncthreads();
         if (lane == 0) for (int64_t c = 0; c < nc; ++c) total = total + s_chunk[c];      // total = ((0 + c0) + c1) + ...
         __syncthreads();
@@ -370,13 +393,13 @@ __global__ __launch_bounds__(kMeBlock) void k_me_edge_count(const float *x, cons
     __syncthreads();
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
 }
-__global__ __launch_bounds__(kMeBlock) void k_me_edge_compact(const float *x, MsgState *st, const MsgTile *tiles, const int32_t *tile_cnt,
+__global__ __launch_bounds__(kMeBlock) void k_me_edge_compact(const float *x, MsgState *st, const MsgTile *tiles, const int64_t *tile_pre,
                                                                int32_t *edges /* positions inside the message, region = message start */) {
     __shared__ int s_w[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
     if (!(m.center == m.center)) { if (threadIdx.x == 0 && t.idx == 0) st[t.msg].edge_cnt = 0; return; }
-    const int64_t before = block_sum_i32(tile_cnt + m.first_tile, t.idx);
+    const int64_t before = tile_pre[blockIdx.x] - tile_pre[m.first_tile];
     const float cen = (float)m.center;
     const int64_t lo = (int64_t)t.idx * kMeTile + (int64_t)threadIdx.x * kMePer;
     bool e[kMePer];
@@ -493,31 +516,35 @@ int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const 
     MsgBatch b;
     URH_TRY(build_batch(ctx, ranges, n_msgs, n, nullptr, b));
     // scratch: state, tiles, per-tile counts / min-max, leaf sums, the compacted samples, the histogram pool
-    const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)b.n_tiles * (sizeof(MsgTile) + 4 + 8 + kLeavesPerTile * 4) +
+    const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)(b.n_tiles + 1) * (sizeof(MsgTile) + 4 + 8 + 8 + 4 + kLeavesPerTile * 4) +
                         (size_t)n * 4 + (size_t)n_msgs * (size_t)max_bins * 4 + 16 * 256;
     URH_TRY(ctx->arena.reserve(need));
     ctx->arena.reset();
     MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
     MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
     int32_t *d_cnt = (int32_t *)ctx->arena.take((size_t)b.n_tiles * 4);
+    int64_t *d_pre = (int64_t *)ctx->arena.take((size_t)(b.n_tiles + 1) * 8);
     float2 *d_mm = (float2 *)ctx->arena.take((size_t)b.n_tiles * 8);
     float *d_leaf = (float *)ctx->arena.take((size_t)b.n_tiles * kLeavesPerTile * 4);
+    float *d_chunk = (float *)ctx->arena.take((size_t)(b.n_tiles + 1) * 4);
     float *d_kept = (float *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
     unsigned int *d_hist = (unsigned int *)ctx->arena.take((size_t)n_msgs * (size_t)max_bins * 4);
-    if (!d_st || !d_tiles || !d_cnt || !d_mm || !d_leaf || !d_kept || !d_hist) return URHGPU_ERR_ARG;
+    if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_mm || !d_leaf || !d_chunk || !d_kept || !d_hist) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
     URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
     URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
     URH_HIP(hipMemsetAsync(d_hist, 0, (size_t)n_msgs * (size_t)max_bins * 4, s));
     const unsigned gt = (unsigned)b.n_tiles, gm = (unsigned)((n_msgs + 63) / 64);
     hipLaunchKernelGGL(k_me_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
-    hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_kept);
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
+    hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_kept);
     hipLaunchKernelGGL(k_me_trim, dim3(gm), dim3(64), 0, s, d_st, n_msgs);
     hipLaunchKernelGGL(k_me_minmax, dim3(gt), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles, d_mm);
     hipLaunchKernelGGL(k_me_minmax_fin, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_mm, d_kept);
     for (int mode = 0; mode < 2; ++mode) {
         hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles, mode, d_leaf);
-        hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(64), 0, s, d_kept, d_st, d_leaf, mode);
+        hipLaunchKernelGGL(k_me_chunk_trees, dim3(gt), dim3(64), 0, s, d_st, d_tiles, d_leaf, d_chunk);
+        hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(64), 0, s, d_kept, d_st, d_chunk, mode);
     }
     hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins);
     hipLaunchKernelGGL(k_me_hist, dim3(gt), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles, max_bins, d_hist);
@@ -558,20 +585,22 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
     MsgBatch b;
     URH_TRY(build_batch(ctx, ranges, n_msgs, n, windows.data(), b));
     for (int m = 0; m < n_msgs; ++m) b.host[(size_t)m].center = centers[m];
-    const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)b.n_tiles * (sizeof(MsgTile) + 4) + (size_t)std::max<int64_t>(n, 1) * 4 + 8 * 256;
+    const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)(b.n_tiles + 1) * (sizeof(MsgTile) + 4 + 8) + (size_t)std::max<int64_t>(n, 1) * 4 + 8 * 256;
     URH_TRY(ctx->arena.reserve(need));
     ctx->arena.reset();
     MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
     MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
     int32_t *d_cnt = (int32_t *)ctx->arena.take((size_t)b.n_tiles * 4);
+    int64_t *d_pre = (int64_t *)ctx->arena.take((size_t)(b.n_tiles + 1) * 8);
     int32_t *d_edges = (int32_t *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
-    if (!d_st || !d_tiles || !d_cnt || !d_edges) return URHGPU_ERR_ARG;
+    if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_edges) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
     URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
     URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
     const unsigned gt = (unsigned)b.n_tiles;
     hipLaunchKernelGGL(k_me_edge_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
-    hipLaunchKernelGGL(k_me_edge_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_edges);
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
+    hipLaunchKernelGGL(k_me_edge_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_edges);
     hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
     URH_HIP(hipGetLastError());
     URH_HIP(hipMemcpyAsync(b.host.data(), d_st, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost, s));

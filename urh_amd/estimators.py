@@ -54,6 +54,36 @@ def detect_noise_level_dev(pipe, iq) -> float:
     return noise_level_from_chunk_stats(sums.cpu().numpy(), maxs.cpu().numpy(), chunk)
 
 
+def fir_filter_detect_noise_dev(pipe, iq, taps, left=None):
+    """Signal.filter_range over the whole capture followed by detect_noise_level (Signal.py:645-655, AutoInterpretation.py:60-91) in
+    ONE pass over the samples: the magnitude chunk statistics of the filtered signal come out of the FIR kernel's epilogue
+    (urhgpu_fir_filter_stats_dev).  iq: float32 (N, 2) or complex64 (N,) on the GPU; taps: complex64 (numpy or device).
+    Returns (filtered capture, same shape / dtype as iq; noise threshold)."""
+    torch = pipe.torch
+    x = torch.view_as_real(iq) if iq.dtype == torch.complex64 else iq
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise ValueError("FIR needs contiguous float32 / complex64 samples")
+    if isinstance(taps, np.ndarray):
+        taps = torch.from_numpy(np.ascontiguousarray(taps, dtype=np.complex64).view(np.float32).copy()).to(x.device)
+    h = (torch.view_as_real(taps) if taps.dtype == torch.complex64 else taps).contiguous()
+    n, m = int(x.shape[0]), int(h.shape[0])
+    out = torch.empty_like(x)
+    chunk, n_chunks = noise_chunks(n) if n > 3 else (0, 0)
+    pipe.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+    lib, hdl = _lib.load(), pipe.ctx.handle
+    lp = C.c_void_p(left.data_ptr()) if left is not None else None
+    if n_chunks == 0 or m == 0:
+        _lib.check(lib.urhgpu_fir_filter_dev(hdl, C.c_void_p(x.data_ptr()), n, C.c_void_p(h.data_ptr()), m, lp, C.c_void_p(out.data_ptr())))
+        noise = detect_noise_level_dev(pipe, out)
+    else:
+        sums = torch.empty(n_chunks, dtype=torch.float64, device=x.device)
+        maxs = torch.empty(n_chunks, dtype=torch.float64, device=x.device)
+        _lib.check(lib.urhgpu_fir_filter_stats_dev(hdl, C.c_void_p(x.data_ptr()), n, C.c_void_p(h.data_ptr()), m, lp, C.c_void_p(out.data_ptr()),
+                                                   chunk, n_chunks, C.c_void_p(sums.data_ptr()), C.c_void_p(maxs.data_ptr())))
+        noise = noise_level_from_chunk_stats(sums.cpu().numpy(), maxs.cpu().numpy(), chunk)
+    return (out if iq.dtype != torch.complex64 else torch.view_as_complex(out)), noise
+
+
 # ======================================================================================================================
 # Message segmentation, center, plateau lengths: O(N) passes on the GPU, decisions on the host
 # ======================================================================================================================
@@ -173,13 +203,16 @@ def get_most_frequent_value(values: list):
     return [v for v, c in ranked if c == top][-1]
 
 
-def detect_center_dev(pipe, rect, max_size=None):
+def detect_center_dev(pipe, rect, max_size=None, _single=False):
     """AutoInterpretation.detect_center (AutoInterpretation.py:226-277) for a demodulated signal on the GPU.
     GPU passes: compaction rect > -4, min / max, np.var (float32 pairwise sums in numpy's order), histogram over the
     float64 edges np.arange(min, max + step, step); the peak picking over the bins is host work."""
     torch = pipe.torch
     x = _dev_f32(pipe, rect)
     n = int(x.shape[0])
+    if max_size is None and n > 0 and not _single:
+        # one "message": the batched pass (one read-back instead of five), unless its histogram does not fit the pool
+        return centers_batched(pipe, x, [(0, n)])[0]
     lib, h = _lib.load(), pipe.ctx.handle
     kept = torch.empty(max(n, 1), dtype=torch.float32, device=x.device)
     cnt = torch.zeros(1, dtype=torch.int64, device=x.device)
@@ -500,13 +533,13 @@ def centers_batched(pipe, data, message_indices, max_bins: int = 4096):
         if n_edges < 2:
             centers.append(None)
         elif n_edges - 1 > max_bins:
-            centers.append(detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])]))
+            centers.append(detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True))
         else:
             hist_min, hist_max, step = float(stats[m, 2]), float(stats[m, 3]), float(stats[m, 5])
             with np.errstate(all="ignore"):
                 edges = np.arange(hist_min, hist_max + step, step)              # the same edges the device binned with
             if len(edges) != n_edges or edges[0] != stats[m, 7]:                # cannot happen; never bin against other edges silently
-                centers.append(detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])]))
+                centers.append(detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True))
             else:
                 centers.append(center_from_histogram(hist[m, :n_edges - 1], edges))
     return centers
