@@ -65,7 +65,7 @@ def fir_filter_detect_noise_dev(pipe, iq, taps, left=None):
         raise ValueError("FIR needs contiguous float32 / complex64 samples")
     if isinstance(taps, np.ndarray):
         taps = torch.from_numpy(np.ascontiguousarray(taps, dtype=np.complex64).view(np.float32).copy()).to(x.device)
-    h = (torch.view_as_real(taps) if taps.dtype == torch.complex64 else taps).contiguous()
+    h = (torch.view_as_real(taps) if taps.dtype == torch.complex64 else taps).contiguous().reshape(-1, 2)
     n, m = int(x.shape[0]), int(h.shape[0])
     out = torch.empty_like(x)
     chunk, n_chunks = noise_chunks(n) if n > 3 else (0, 0)
