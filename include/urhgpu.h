@@ -315,6 +315,13 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
  * values); out needs room for n values, *n_out = number of merged plateaus. */
 int urhgpu_merge_plateaus(const uint64_t *plateaus, int64_t n, uint64_t tolerance, uint64_t max_count, uint64_t *out, int64_t *n_out);
 
+/* The per-message decisions of AutoInterpretation.estimate after get_plateau_lengths (AutoInterpretation.py:416-433; tolerance :280-298,
+ * merge_plateaus, round_plateau_lengths :313-326, divisor histogram, bit length :344-370) for every message in one call, host
+ * arithmetic on the lengths urhgpu_msg_plateaus returned (same `off` convention).  tol_out[m]: tolerance or -1 (None);
+ * bitlen_out[m]: bit length, -1 (fewer than two merged plateaus: no vote) or -2 (the reference's result depends on numpy's order of
+ * equal counts: decide that message with numpy). */
+int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs, int64_t *tol_out, int64_t *bitlen_out);
+
 /* Test hook: the hot kernel's fast-path division (Newton + residual chain without scaling) against the IEEE
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);

@@ -1141,6 +1141,20 @@ def test_sharded_pipelined_passes(pipe, mod):
         assert bits_equal(np.concatenate([results[it][r][1] for r in range(world)]), want_qad), (mod, it)
 
 
+def test_pinned_host_copy_equals_pageable(pipe):
+    """BitsResult.to_host_pinned (asynchronous copies into pinned buffers, one synchronisation) returns what ppseq() / flat() return"""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    iq = synth_fsk(700_000, sps=100, seed=5, noise=0.05, pause_every=200_000, pause_len=9000)
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    pool = {}
+    for _ in range(2):
+        res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True)
+        got = res.to_host_pinned(pool)
+        want = (res.ppseq(),) + res.flat()
+        assert len(got) == 6 and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
 def test_pipelined_passes_do_not_disturb_each_other(oracle):
     """pipelined mode: a burst of back-to-back passes over alternating captures without any synchronisation in between;
     the last two results (kept in separate output slots) are bit-exact, i.e. the hot kernel of pass i+1 did not disturb the

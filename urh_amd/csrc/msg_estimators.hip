@@ -658,3 +658,140 @@ int urhgpu_merge_plateaus(const uint64_t *plateaus, int64_t n, uint64_t toleranc
 }
 
 }  // extern "C"
+
+// ---- per-message decisions on plateau lengths: host arithmetic on a few thousand integers, all messages in one call -------------
+namespace {
+
+// numpy's float64 summation (np.add.reduce): chunks of 8192 accumulated left to right, pairwise inside a chunk
+double np_pairwise_f64(const double *a, int64_t n) {
+    if (n < 8) { double r = 0.0; for (int64_t i = 0; i < n; ++i) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int64_t i;
+        for (i = 8; i < n - (n % 8); i += 8) for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    }
+    int64_t n2 = n / 2;
+    n2 -= n2 % 8;
+    const double x = np_pairwise_f64(a, n2), y = np_pairwise_f64(a + n2, n - n2);
+    return x + y;
+}
+double np_sum_f64(const double *a, int64_t n) {
+    double total = 0.0;
+    for (int64_t c = 0; c < n; c += 8192) total += np_pairwise_f64(a + c, std::min<int64_t>(8192, n - c));
+    return total;
+}
+
+// AutoInterpretation.estimate_tolerance_from_plateau_lengths (AutoInterpretation.py:280-298); -1: None, -2: undefined in the reference
+int64_t tolerance_of(const std::vector<uint64_t> &p) {
+    if (p.size() <= 1) return -1;
+    std::vector<uint64_t> u(p);
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+    const int64_t n = (int64_t)u.size();
+    std::vector<double> d((size_t)n);
+    for (int64_t i = 0; i < n; ++i) d[(size_t)i] = (double)u[(size_t)i];
+    const double mean = np_sum_f64(d.data(), n) / (double)n;
+    std::vector<double> sq((size_t)n);
+    for (int64_t i = 0; i < n; ++i) { const double x = d[(size_t)i] - mean; sq[(size_t)i] = x * x; }
+    const double sd = sqrt(np_sum_f64(sq.data(), n) / (double)n);
+    bool any = false; uint64_t maximum = 0;                     // max_without_outliers(unique, z=2) (:14-18)
+    for (int64_t i = 0; i < n; ++i)
+        if (fabs(d[(size_t)i] - mean) <= 2.0 * sd) { any = true; if (u[(size_t)i] > maximum) maximum = u[(size_t)i]; }
+    if (!any) return -2;
+    const double limit = 0.05 * (double)maximum;
+    if (u[0] > 1 && (double)u[0] >= limit) return 0;
+    uint64_t result = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (u[(size_t)i] > 1 && (double)u[(size_t)i] >= limit) break;
+        result = u[(size_t)i];
+    }
+    return (int64_t)result;
+}
+
+int digits_of(uint64_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
+
+// get_bit_length_from_plateau_lengths (:344-370) on the merged lengths (rounded in place); -2: the outcome depends on how
+// np.argsort orders equal counts (the caller repeats that message in numpy)
+int64_t bit_length_of(std::vector<uint64_t> &m) {
+    if (m.empty()) return 0;
+    if (m.size() == 1) return (int64_t)m[0];
+    // round_plateau_lengths (:313-326): keep the median number of digits (at most 3); int(round(p / f)) * f, round = half to even
+    std::vector<int> dc(m.size());
+    for (size_t i = 0; i < m.size(); ++i) dc[i] = digits_of(m[i]);
+    std::sort(dc.begin(), dc.end());
+    const double idx = 0.5 * (double)(dc.size() - 1);
+    const size_t lo = (size_t)floor(idx), hi = (size_t)ceil(idx);
+    const double med = (double)dc[lo] + ((double)dc[hi] - (double)dc[lo]) * (idx - (double)lo);
+    const int n_digits = std::min(3, (int)med);
+    double f = 1.0;
+    for (int k = 1; k < n_digits; ++k) f *= 10.0;
+    for (auto &v : m) v = (uint64_t)nearbyint((double)v / f) * (uint64_t)f;
+    // get_threshold_divisor_histogram (auto_interpretation.pyx:113-143) from the multiset of values
+    std::vector<uint64_t> vals(m);
+    std::sort(vals.begin(), vals.end());
+    std::vector<std::pair<uint64_t, uint64_t>> vc;              // (value, count), value != 0, ascending
+    for (size_t i = 0; i < vals.size();) {
+        size_t j = i;
+        while (j < vals.size() && vals[j] == vals[i]) ++j;
+        if (vals[i] != 0) vc.push_back({vals[i], (uint64_t)(j - i)});
+        i = j;
+    }
+    const double thr = (double)0.2f;
+    std::vector<std::pair<uint64_t, uint64_t>> hist;            // (count, index) for the non-zero entries
+    for (size_t a = 0; a < vc.size(); ++a) {
+        uint64_t c = vc[a].second * (vc[a].second - 1) / 2;      // pairs of equal values: ratio 1
+        for (size_t b = a + 1; b < vc.size(); ++b) {
+            const uint64_t mn = vc[a].first, mx = vc[b].first;
+            if ((double)mx / (double)mn - (double)(mx / mn) < thr) c += vc[a].second * vc[b].second;
+        }
+        if (c) hist.push_back({c, vc[a].first});
+    }
+    if (hist.empty()) return -2;                                // all counts zero: argsort's order of equal elements decides
+    std::sort(hist.begin(), hist.end(), [](const std::pair<uint64_t, uint64_t> &x, const std::pair<uint64_t, uint64_t> &y) { return x.first > y.first; });
+    const uint64_t max_count = hist[0].first;
+    int64_t result = (int64_t)hist[0].second;
+    for (size_t i = 1; i < hist.size(); ++i) {
+        if ((double)hist[i].first < 0.25 * (double)max_count) break;
+        if (hist[i].first == hist[i - 1].first) return -2;      // equal counts among the candidates
+        if ((double)hist[i].second <= 0.5 * (double)result) result = (int64_t)hist[i].second;
+    }
+    if (hist.size() > 1 && hist[1].first == max_count) return -2;
+    return result;
+}
+
+}  // namespace
+
+extern "C" {
+
+// The per-message part of AutoInterpretation.estimate after get_plateau_lengths (AutoInterpretation.py:416-433) for every message:
+// lens[|off[m]| .. |off[m + 1]|) are message m's plateau lengths (off as urhgpu_msg_plateaus returns it).  tol_out[m]: the estimated
+// tolerance, -1 = None; bitlen_out[m]: the bit length, -1 = fewer than two merged plateaus (the message does not vote), -2 = the
+// reference's result depends on numpy's ordering of equal histogram counts (decide that message with numpy).  Host arithmetic.
+int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs, int64_t *tol_out, int64_t *bitlen_out) {
+    if (n_msgs < 0 || (n_msgs > 0 && (!off || !tol_out || !bitlen_out))) return URHGPU_ERR_ARG;
+    for (int m = 0; m < n_msgs; ++m) {
+        const int64_t a = off[m] < 0 ? -off[m] - 1 : off[m], b = off[m + 1] < 0 ? -off[m + 1] - 1 : off[m + 1];
+        if (b < a || (b > a && !lens)) return URHGPU_ERR_ARG;
+        std::vector<uint64_t> p(lens + a, lens + b);
+        const int64_t tol = tolerance_of(p);
+        tol_out[m] = tol;
+        if (tol == -2) { bitlen_out[m] = -2; continue; }
+        std::vector<uint64_t> merged;
+        if (tol > 0) {
+            merged.resize(p.size());
+            int64_t k = 0;
+            if (!p.empty()) URH_TRY(urhgpu_merge_plateaus(p.data(), (int64_t)p.size(), (uint64_t)tol, 10000, merged.data(), &k));
+            merged.resize((size_t)k);
+        } else {
+            merged = p;
+        }
+        bitlen_out[m] = merged.size() < 2 ? -1 : bit_length_of(merged);
+    }
+    return URHGPU_OK;
+}
+
+}  // extern "C"

@@ -590,6 +590,29 @@ def bit_length_of_message(plateau_lengths):
     return tolerance, get_bit_length_from_plateau_lengths(merged)
 
 
+def bit_lengths_batched(all_plateaus):
+    """[(tolerance or None, bit_length or None)] for every message from its plateau lengths: the native batch call
+    (urhgpu_msg_bit_lengths: tolerance, merged plateaus, rounded lengths, divisor histogram from the value multiset, decision); a
+    message whose decision hangs on how np.argsort orders equal counts is repeated in numpy (bit_length_of_message)."""
+    n_msgs = len(all_plateaus)
+    if n_msgs == 0:
+        return []
+    off = np.zeros(n_msgs + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(p) for p in all_plateaus])
+    lens = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.uint64) for p in all_plateaus]) if off[-1] else np.zeros(1, np.uint64))
+    tol = np.zeros(n_msgs, dtype=np.int64)
+    bl = np.zeros(n_msgs, dtype=np.int64)
+    _lib.check(_lib.load().urhgpu_msg_bit_lengths(lens.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), n_msgs,
+                                                  tol.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p)))
+    out = []
+    for m in range(n_msgs):
+        if bl[m] == -2 or tol[m] == -2:
+            out.append(bit_length_of_message(np.array(all_plateaus[m], dtype=np.uint64)))
+        else:
+            out.append((None if tol[m] < 0 else int(tol[m]), None if bl[m] < 0 else int(bl[m])))
+    return out
+
+
 def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings: dict = None):
     """AutoInterpretation.estimate (AutoInterpretation.py:373-470) for a float32 capture resident on the GPU.  Device passes over
     the samples: magnitude statistics, segmentation, demodulation, then TWO batched passes over all messages (center statistics +
@@ -632,11 +655,11 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
     lap("centers_ms")
     all_plateaus = plateau_lengths_batched(pipe, data, message_indices, all_centers)
     lap("plateaus_ms")
+    decisions = bit_lengths_batched(all_plateaus)
     centers, bit_lengths, tolerances = [], [], []
-    for center, plateau_lengths in zip(all_centers, all_plateaus):
+    for center, (tolerance, bit_length) in zip(all_centers, decisions):
         if center is None:
             continue
-        tolerance, bit_length = bit_length_of_message(plateau_lengths)
         if tolerance is not None:
             tolerances.append(tolerance)
         if bit_length is not None and bit_length > (tolerance or 0) + 1:
