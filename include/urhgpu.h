@@ -315,6 +315,16 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
  * values); out needs room for n values, *n_out = number of merged plateaus. */
 int urhgpu_merge_plateaus(const uint64_t *plateaus, int64_t n, uint64_t tolerance, uint64_t max_count, uint64_t *out, int64_t *n_out);
 
+/* AutoInterpretation.detect_modulation (AutoInterpretation.py:150-205; Wavelet.cwt_haar, Wavelet.py:15-43; median_filter,
+ * auto_interpretation.pyx:213-240) for n_msgs messages of a complex64 capture on the device (d_iq: float32 pairs; ranges: HOST
+ * int64[n_msgs][2]): labels_out[m] = 0 none, 1 OOK, 2 ASK, 3 FSK, 4 PSK; vars_out (or NULL): double[n_msgs][4] = the variances of
+ * |CWT|, |CWT of the unit-magnitude samples| and of both after the median filter (NaN when the decision fell before them).
+ * Floating-point classifier (double-precision radix-2 FFTs here, single-precision pocketfft forward transforms in the
+ * reference): the label is the parity criterion.  wavelet_scale 4 and median_filter_order 11 are the reference's defaults.
+ * Synchronous. */
+int urhgpu_detect_modulation_dev(urhgpu_ctx *ctx, const float *d_iq, int64_t n, const int64_t *ranges, int n_msgs, int wavelet_scale,
+                                 int median_filter_order, int *labels_out, double *vars_out);
+
 /* The per-message decisions of AutoInterpretation.estimate after get_plateau_lengths (AutoInterpretation.py:416-433; tolerance :280-298,
  * merge_plateaus, round_plateau_lengths :313-326, divisor histogram, bit length :344-370) for every message in one call, host
  * arithmetic on the lengths urhgpu_msg_plateaus returned (same `off` convention).  tol_out[m]: tolerance or -1 (None);

@@ -774,6 +774,79 @@ def test_batched_message_statistics_equal_oracle(pipe, oracle):
     assert np.array_equal(np.asarray(got, np.uint64), oracle.get_plateau_lengths(flat, 0.0, 25))
 
 
+def test_detect_modulation_on_device(pipe):
+    """urhgpu_detect_modulation_dev against detect_modulation in numpy (and the real reference's, where staged): same label for every
+    message, variances within 1e-4 relative (double-precision radix-2 FFTs here, numpy's single-precision forward transforms there):
+    synthetic OOK / ASK / FSK / PSK / noise messages on both transform paths (<= 2048 points in LDS, longer through HBM), messages with
+    zeros, tiny and empty ones; the messages of the golden captures."""
+    import torch
+    import ref_python
+    from urh_amd import estimators
+    ref_dm = None
+    if ref_python.available():
+        ref_python.setup()
+        from urh.ainterpretation import AutoInterpretation as AI
+        ref_dm = AI.detect_modulation
+    rng = np.random.default_rng(2024)
+    msgs = []
+
+    def tone(n, kind):
+        t = np.arange(n)
+        sym = np.repeat(rng.integers(0, 2, n // 40 + 1), 40)[:n]
+        if kind == "FSK":
+            x = np.exp(1j * np.cumsum(np.where(sym == 1, 0.25, -0.25)))
+        elif kind == "ASK":
+            x = (0.3 + 0.7 * sym) * np.exp(1j * 0.2 * t)
+        elif kind == "PSK":
+            x = np.exp(1j * (0.2 * t + np.pi * sym))
+        elif kind == "OOK1":
+            x = np.exp(1j * 0.2 * t)                       # one unmodulated pulse
+        else:
+            x = np.zeros(n, complex)
+        return (x + 0.02 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    for kind in ("FSK", "ASK", "PSK", "OOK1", "noise"):
+        for n in (300, 1500, 2048, 2049, 5000, 70_000):
+            msgs.append(tone(n, kind))
+    z = tone(4000, "FSK"); z[100:110] = 0; msgs.append(z)           # more than 3 zeros: OOK
+    z = tone(4000, "FSK"); z[7] = 0; msgs.append(z)                 # up to 3 zeros are only dropped
+    msgs += [tone(10, "FSK"), tone(17, "ASK"), np.zeros(50, np.complex64), np.zeros(0, np.complex64), tone(33, "PSK")]
+    capture = np.concatenate(msgs)
+    bounds, o = [], 0
+    for mm in msgs:
+        bounds.append((o, o + len(mm))); o += len(mm)
+    dev = torch.from_numpy(capture.view(np.float32).reshape(-1, 2)).cuda()
+    labels, variances = estimators.detect_modulation_dev(pipe, dev, bounds, return_variances=True)
+    seen = set()
+    for k, (mm, lab) in enumerate(zip(msgs, labels)):
+        want = estimators.detect_modulation(mm.copy())
+        assert lab == want, (k, len(mm), lab, want, variances[k])
+        if ref_dm is not None:
+            assert lab == ref_dm(mm.copy()), (k, len(mm))
+        seen.add(lab)
+    assert {"FSK", "ASK", "PSK", "OOK", None} <= seen, seen
+    # variances against numpy on one long and one short message
+    for k in (5, 1):
+        d = msgs[k][np.abs(msgs[k]) > 0]
+        d = d / np.abs(np.max(d))
+        w1 = np.abs(estimators.cwt_haar(d, scale=4)); w2 = np.abs(estimators.cwt_haar(d / np.abs(d), scale=4))
+        want = [np.var(w1), np.var(w2), np.var(estimators.median_filter(w1, 11)), np.var(estimators.median_filter(w2, 11))]
+        assert np.allclose(variances[k], want, rtol=1e-4, atol=1e-9), (k, variances[k], want)
+    # the golden captures: every message, device label == numpy label
+    from urh_amd.pipeline import DevicePipeline
+    for name in GOLDEN_CASES:
+        g = load_golden(name)
+        iq = g["iq"]
+        if iq.dtype != np.float32:
+            continue
+        d = torch.from_numpy(iq).cuda()
+        segs = estimators.segment_messages_dev(pipe, d, g["noise_threshold"])[:100]
+        if not segs:
+            continue
+        got = estimators.detect_modulation_dev(pipe, d, segs)
+        cplx = iq.view(np.complex64).reshape(-1)
+        assert got == [estimators.detect_modulation(cplx[a:b].copy()) for a, b in segs], name
+
+
 def test_estimate_equals_reference_goldens(pipe):
     """AutoInterpretation.estimate on the GPU vs what the real reference returned for the same captures
     (tests/golden/estimates.json, made by tests/golden/make_estimate_golden.py): identical dict, floats included."""

@@ -499,15 +499,43 @@ def _as_complex64(iq_host: np.ndarray) -> np.ndarray:
     return np.ascontiguousarray(f).flatten(order="C").view(np.complex64)
 
 
-def detect_modulation_for_messages_dev(iq, message_indices: list):
-    """AutoInterpretation.detect_modulation_for_messages (:208-223): the first 100 messages are copied to the host (a message is
-    a few thousand samples) and classified there, exactly as the reference does with numpy."""
+_MOD_LABELS = (None, "OOK", "ASK", "FSK", "PSK")
+
+
+def detect_modulation_dev(pipe, iq, message_indices, wavelet_scale=4, median_filter_order=11, return_variances=False):
+    """AutoInterpretation.detect_modulation (:150-205) for every given message of a capture on the GPU (float32 (N, 2) or complex64):
+    compaction, Haar wavelet transforms through double-precision FFTs, median filter, variances and spectrum peaks on the device
+    (urhgpu_detect_modulation_dev); returns the list of labels ("OOK" / "ASK" / "FSK" / "PSK" / None)."""
+    torch = pipe.torch
+    x = torch.view_as_real(iq) if iq.dtype == torch.complex64 else iq
+    if x.dtype != torch.float32:
+        from .iq_array import convert_to
+        x = convert_to(x, np.float32, pipe.ctx)                   # IQArray.as_complex64 (IQArray.py:92-93)
+    x = x.contiguous()
+    ranges = np.ascontiguousarray(message_indices, dtype=np.int64).reshape(-1, 2)
+    n_msgs = len(ranges)
+    labels = np.zeros(max(n_msgs, 1), dtype=np.int32)
+    variances = np.zeros((max(n_msgs, 1), 4), dtype=np.float64)
+    pipe.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+    _lib.check(_lib.load().urhgpu_detect_modulation_dev(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]),
+                                                        ranges.ctypes.data_as(C.c_void_p), n_msgs, int(wavelet_scale), int(median_filter_order),
+                                                        labels.ctypes.data_as(C.c_void_p), variances.ctypes.data_as(C.c_void_p)))
+    out = [_MOD_LABELS[int(v)] for v in labels[:n_msgs]]
+    return (out, variances[:n_msgs]) if return_variances else out
+
+
+def detect_modulation_for_messages_dev(iq, message_indices: list, pipe=None):
+    """AutoInterpretation.detect_modulation_for_messages (:208-223): the most common label of the first 100 messages.  With a
+    pipeline the messages are classified on the GPU; without one they are copied to the host and classified with numpy."""
     max_messages = 100
-    mods = []
-    for start, end in message_indices[0:max_messages]:
-        mod = detect_modulation(_as_complex64(iq[start:end].cpu().numpy()))
-        if mod is not None:
-            mods.append(mod)
+    if pipe is not None:
+        mods = [m for m in detect_modulation_dev(pipe, iq, list(message_indices[0:max_messages])) if m is not None]
+    else:
+        mods = []
+        for start, end in message_indices[0:max_messages]:
+            mod = detect_modulation(_as_complex64(iq[start:end].cpu().numpy()))
+            if mod is not None:
+                mods.append(mod)
     if len(mods) == 0:
         return None
     return most_common(mods)
@@ -637,7 +665,7 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
     message_indices = segment_messages_dev(pipe, iq, noise, as_array=True)    # (K, 2) array: one row per OOK pulse before merging
     lap("segment_messages_ms")
     if modulation is None:
-        modulation = detect_modulation_for_messages_dev(iq, message_indices[:100].tolist())
+        modulation = detect_modulation_for_messages_dev(iq, message_indices[:100].tolist(), pipe=pipe)
         if modulation is None:
             return None
     if modulation == "OOK":
