@@ -143,7 +143,9 @@ int urhgpu_ppseq_to_bits(urhgpu_ctx *ctx, const int64_t *rows, int64_t n_rows, i
 int urhgpu_fir_filter(urhgpu_ctx *ctx, const float *x, int64_t n, const float *taps, int64_t m, float *out);
 
 /* The same on device memory (asynchronous).  d_left_halo: NULL = zero history (the reference), or DEVICE pointer
- * to the m - 1 samples that precede d_x[0] (sharded captures: the left neighbour's tail). */
+ * to the m - 1 samples that precede d_x[0] (sharded captures: the left neighbour's tail).
+ * Limits (URHGPU_ERR_UNSUPPORTED beyond them, nothing is computed): the taps and one tile of input are staged in LDS, which
+ * holds about 8 900 taps; bits_per_symbol <= 7 (modulation order <= 128) in every entry point that slices. */
 int urhgpu_fir_filter_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const float *d_taps, int64_t m,
                           const float *d_left_halo, float *d_out);
 /* The same with the magnitude chunk statistics of the OUTPUT fused into the filter's epilogue (Signal.filter_range followed by

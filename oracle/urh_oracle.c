@@ -6,13 +6,13 @@
  * (urh_amd/) never imports, links or calls anything under oracle/.
  *
  * Every function follows the reference file:line it cites, statement by statement, in plain
- * single-threaded C.  Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/build_oracle.py);
+ * single-threaded C.  Build: gcc -O2 -ffp-contract=off -fPIC -shared (see urh_oracle.build() in oracle/urh_oracle.py);
  * -ffp-contract=off because the reference's x86-64 build contains no FMA instructions
  * (SURVEY.md appendix).  libm functions are the host glibc ones, exactly as in the reference
  * (atan2f / sqrtf / sinf / cosf: the Cython module is compiled as C++, so `atan2(float,float)` and
  * `sqrt(float)` bind to the float overloads).
  *
- * Parity pin: tests/test_oracle_vs_ref.py checks every function here against the real reference
+ * Parity pin: tests/test_oracle.py checks every function here against the real reference
  * build (oracle/_ref, built by oracle/build_ref.py from /root/reference) and against the golden
  * vectors under tests/golden/ (made by tests/golden/make_golden.py from the reference's own
  * Python + Cython code and its tests' known answers).

@@ -16,14 +16,15 @@
 //   * the conj(prev)*cur product follows the exact operation sequence the reference's generated
 //     C++ performs (including the 0*x terms that decide signed zeros, see conj_mul()).
 //
-// Layout: one wavefront (a 64-thread workgroup) owns a whole chunk, so there is no barrier and no
-// cross-wavefront dependency anywhere in the kernel: each wavefront is its own software pipeline
-// and the SIMD scheduler interleaves wavefronts that are in different phases.  Inside a tile (2048
-// samples) load row r covers 128 consecutive samples, lane t owns samples 2t, 2t+1 of the row (one
-// 16-byte load, lane-contiguous => 1 KiB per wavefront instruction).  The previous sample of a
-// lane's first sample comes from lane t-1 by DPP wave_shr:1; lane 0 takes the last sample of the
-// previous row, carried in registers (v_readlane) from row to row and tile to tile.  State bytes go
-// to LDS in sample order; in the run phase lane t owns 32 consecutive samples.
+// Layout.  A row = 128 consecutive samples = one 1 KiB wavefront-wide load: lane t owns samples 2t, 2t+1 (one 16-byte load,
+// lane-contiguous).  The previous sample of a lane's first sample comes from lane t-1 by DPP wave_shr:1; lane 0 takes the last
+// sample of the previous row, carried in SGPRs (v_readlane) from row to row.
+//   k_demod_runs_bp  (modulation orders 2 and 4, tolerance <= 64: the 1 GiB benchmark): a chunk is up to 64 rows shared by FOUR
+//                    wavefronts (ASK: eight) of one workgroup, each streaming its own 16 rows with no barrier; the states are BIT
+//                    PLANES -- the classification IS the v_cmp: 64-bit wavefront masks parked in lane r of a few registers for row
+//                    r -- which meet in wavefront 0 through 2 KiB of LDS, where lane r analyses row r with 64-bit logic.
+//   k_demod_runs     (every other order, tolerance > 64, the partial last tile): one wavefront per chunk walks tiles of 2048
+//                    samples, state bytes in LDS in sample order, lane t owning 32 consecutive samples in the run phase.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -44,9 +45,6 @@ enum { SRC_IQ = 0, SRC_QAD = 1 };
 #endif
 #ifndef URH_MINWAVES
 #define URH_MINWAVES 1
-#endif
-#ifndef URH_EXP
-#define URH_EXP 0         // timing experiments (tools/kbench only); 0 in the product
 #endif
 #ifndef URH_SPEC
 #define URH_SPEC 1        // branch-free speculative fast path per batch of rows (see spec_pair)
@@ -369,17 +367,9 @@ __device__ __forceinline__ int demod_pair(const RowIn &r, float prev_c, float pr
         const bool ok0 = ((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (re0 > 0.0f);
         const bool ok1 = ((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (re1 > 0.0f);
 #endif
-#if URH_EXP == 2 || URH_EXP == 3     // timing experiment only (tools/kbench): no range test
-        if (any_noise) return 2;
-#else
         if (any_noise || __builtin_amdgcn_ballot_w64(!(ok0 & ok1)) != 0) return 2;
-#endif
-#if URH_EXP == 1 || URH_EXP == 3     // timing experiment only: no polynomial
-        q0 = t0; q1 = t1;
-#else
         q0 = t0 - urh_atanf_poly(t0);
         q1 = t1 - urh_atanf_poly(t1);
-#endif
         return 0;
     }
     if (MOD == URHGPU_MOD_ASK) {
@@ -408,20 +398,12 @@ __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float pr
         const float re0 = pc * c0 + pd * d0, im0 = pc * d0 - pd * c0;
         const float re1 = c0 * c1 + d0 * d1, im1 = c0 * d1 - d0 * c1;
         float t0, t1;
-#if URH_EXP == 8                      // timing experiment: no division either
-        t0 = im0 * 0.125f; t1 = im1 * 0.125f;
-#else
         div_fast2(im0, re0, im1, re1, t0, t1);
-#endif
         const bool rw0 = (__float_as_uint(re0) - kReLo < kReSpan), rw1 = (__float_as_uint(re1) - kReLo < kReSpan);
         bool ok0 = (int)((__float_as_uint(t0) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)rw0;
         bool ok1 = (int)((__float_as_uint(t1) & 0x7fffffffu) - kAtanLo < kAtanSpan) & (int)rw1;
-#if URH_EXP == 6 || URH_EXP == 8      // timing experiment (tools/kbench): no polynomial in the speculative path
-        q0 = t0; q1 = t1;
-#else
         q0 = t0 - urh_atanf_poly(t0);
         q1 = t1 - urh_atanf_poly(t1);
-#endif
         {
             // Integer captures (and float captures recorded from 8-bit receivers: multiples of 2^-7): the cross product of
             // two such samples is exact and EXACTLY zero about once in 700 samples at 8 bits -- one row in six would leave
@@ -437,16 +419,6 @@ __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float pr
             }
             ok0 |= z0; ok1 |= z1;
         }
-#if URH_EXP == 4      // timing experiment (tools/kbench): 24 extra plain VALU instructions per row
-        { float dummy = t0;
-#pragma unroll
-          for (int e = 0; e < 24; ++e) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
-          asm volatile("" :: "v"(dummy)); }
-#endif
-#if URH_EXP == 5      // timing experiment: 24 extra SALU instructions per row
-#pragma unroll
-          for (int e = 0; e < 24; ++e) asm volatile("s_nop 0");
-#endif
         return n0 | n1 | !ok0 | !ok1;
     }
     if (DT != URHGPU_DT_F32 && p.seg_mode) {
@@ -726,9 +698,6 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
             }
         }
         __syncthreads();   // A: states complete
-#if URH_EXP == 7 || URH_EXP == 8      // timing experiment: no run phase
-        if (p.tol >= 0) continue;
-#endif
 
         // ================= phase 2: runs.  thread t owns samples [32t, 32t+32) of the tile ==============
         uint32_t bm = 0;

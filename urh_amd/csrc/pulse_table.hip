@@ -382,8 +382,9 @@ __device__ __forceinline__ int64_t num_symbols_of(int64_t num_samples, int64_t s
 struct RowInfo {             // per-row scan results kept for the expansion kernel
     int64_t bit_prefix;      // bits before this row (all rows, kept or not)
     int64_t ts_prefix;       // total_samples before this row
+    int64_t kbits;           // bits this row contributes (0 for L rows); 64 bits: one sample per symbol on a multi-GiB capture
     int32_t group;           // long pauses before this row
-    int32_t kbits;           // bits this row contributes (0 for L rows)
+    int32_t pad;
 };
 
 struct GroupInfo {
@@ -434,7 +435,7 @@ struct BitsStore {
         const int64_t n = *d_n_rows;
         const int64_t ts0 = d_ts_carry ? *d_ts_carry : 0;
         RowInfo ri;
-        ri.bit_prefix = ex.v[0]; ri.ts_prefix = ts0 + ex.v[2]; ri.group = (int32_t)ex.v[1]; ri.kbits = (int32_t)val.v[0];
+        ri.bit_prefix = ex.v[0]; ri.ts_prefix = ts0 + ex.v[2]; ri.group = (int32_t)ex.v[1]; ri.kbits = val.v[0]; ri.pad = 0;
         info[i] = ri;
         if (val.v[1]) {                                   // L row closes group ex.v[1]
             GroupInfo g;
