@@ -914,7 +914,11 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
     const int64_t out_off = pre.cnt;
     const int64_t prev_pos = pre.la_valid() ? pre.la_pos : -1;
     const uint32_t prev_st = pre.la_valid() ? pre.la_state() : init_state;
-    VecK<4> acc; acc.zero();
+    // what the chunk's rows contribute to _ppseq_to_bits: bits (64-bit sum), long pauses and data rows (two 32-bit counts in one
+    // word); the samples need no sum at all -- row lengths telescope: sum = (position of the chunk's last accepted run) - prev_pos
+    int64_t acc_bits = 0;
+    uint64_t acc_ld = 0;
+    int64_t my_last_pos = 0;
     const bool in_regs = cnt <= 64;                      // every record this chunk has is in `rec`
     // record of row j's run (j + skip) and of the run before it, from the neighbours' registers
     const uint64_t rec_j = skip ? (uint64_t)__shfl_down((long long)rec, 1) : rec;
@@ -930,20 +934,29 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
             if (j == 0) { ppos = prev_pos; pst = prev_st; }
             else { const uint64_t rr = slab[j - 1 + skip]; ppos = rec_pos(rr); pst = rec_state(rr); }
         }
+        my_last_pos = pos;
         const int64_t gi = out_off + j;
         const int64_t len = (gi == 0) ? pos + 1 : pos - ppos;
         const int64_t state = (int64_t)pst - 1;
         if (gi < a.cap_rows) *(longlong2 *)(a.rows + 2 * gi) = longlong2{(long long)state, (long long)len};
         if (g.ft.want_bits) {
             const VecK<4> v = row_value(state, len, gi == 0, g.bp);
-            acc.add(v);
+            acc_bits += v.v[0];
+            acc_ld += (uint64_t)v.v[1] | ((uint64_t)v.v[3] << 32);
             if (v.v[0] > kHugeBits) {
                 const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
                 if (slot < g.huge_cap) { g.huge[slot].tile = c; g.huge[slot].row = gi; }
             }
         }
     }
-    if (g.ft.want_bits) acc = wave_sum_vec<4>(acc);
+    VecK<4> acc; acc.zero();
+    if (g.ft.want_bits && total > 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { acc_bits += __shfl_xor(acc_bits, o); acc_ld += (uint64_t)__shfl_xor((long long)acc_ld, o); }
+        const int64_t last_pos = __shfl(my_last_pos, (int)((total - 1) & 63));       // the lane that wrote the chunk's last row
+        acc.v[0] = acc_bits; acc.v[1] = (int64_t)(acc_ld & 0xFFFFFFFFull); acc.v[3] = (int64_t)(acc_ld >> 32);
+        acc.v[2] = last_pos - prev_pos;                  // (prev_pos = -1 before the table's first row: its length is position + 1)
+    }
     if (lane == 0) { g.ft.agg[c] = acc; g.ft.tile_off[c] = out_off; g.ft.tile_cnt[c] = (int32_t)total; }
 }
 
@@ -1149,19 +1162,27 @@ __global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
             type = row.x;
             v = row_value(type, row.y, i == 0, a.bp);
         }
-        const VecK<4> incl = wave_incl_scan_vec<4>(v, lane);
+        // inclusive wave scans of what the expansion needs: bits and samples (64-bit), long pauses (32-bit: a tile has few rows)
+        int64_t in_bits = v.v[0], in_ts = v.v[2];
+        int in_l = (int)v.v[1];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int64_t ub = __shfl_up(in_bits, o), ut = __shfl_up(in_ts, o);
+            const int ul = __shfl_up(in_l, o);
+            if (lane >= o) { in_bits += ub; in_ts += ut; in_l += ul; }
+        }
         int64_t kb = 0, ob = 0, op = 0, ts = 0;
         if (i < end && v.v[0] > 0 && v.v[0] <= own_limit) {
-            const int64_t grp = run.v[1] + incl.v[1] - v.v[1];
+            const int64_t grp = run.v[1] + in_l - v.v[1];
             if (grp < n_groups) {
                 GroupOut go = go0;
                 if (grp != g0) go = a.gout[grp];
                 if (go.is_msg) {
-                    const int64_t bit_prefix = run.v[0] + incl.v[0] - v.v[0];
+                    const int64_t bit_prefix = run.v[0] + in_bits - v.v[0];
                     kb = v.v[0];
                     ob = go.out_bits + (bit_prefix - go.bits_start);
                     op = go.out_pos + (bit_prefix - go.bits_start);
-                    ts = run.v[2] + incl.v[2] - v.v[2];
+                    ts = run.v[2] + in_ts - v.v[2];
                 }
             }
         }
@@ -1185,8 +1206,7 @@ __global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
                 if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
             }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) run.v[k] += __shfl(incl.v[k], 63);
+        run.v[0] += __shfl(in_bits, 63); run.v[1] += __shfl(in_l, 63); run.v[2] += __shfl(in_ts, 63);
     }
 }
 
