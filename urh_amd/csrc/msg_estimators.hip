@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <math.h>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -720,12 +721,12 @@ int64_t bit_length_of(std::vector<uint64_t> &m) {
     if (m.empty()) return 0;
     if (m.size() == 1) return (int64_t)m[0];
     // round_plateau_lengths (:313-326): keep the median number of digits (at most 3); int(round(p / f)) * f, round = half to even
-    std::vector<int> dc(m.size());
-    for (size_t i = 0; i < m.size(); ++i) dc[i] = digits_of(m[i]);
-    std::sort(dc.begin(), dc.end());
-    const double idx = 0.5 * (double)(dc.size() - 1);
+    size_t dhist[24] = {0};
+    for (size_t i = 0; i < m.size(); ++i) ++dhist[digits_of(m[i])];
+    auto kth = [&](size_t k) { size_t c = 0; for (int d = 0; d < 24; ++d) { c += dhist[d]; if (k < c) return d; } return 23; };   // k-th smallest digit count
+    const double idx = 0.5 * (double)(m.size() - 1);
     const size_t lo = (size_t)floor(idx), hi = (size_t)ceil(idx);
-    const double med = (double)dc[lo] + ((double)dc[hi] - (double)dc[lo]) * (idx - (double)lo);
+    const double med = (double)kth(lo) + ((double)kth(hi) - (double)kth(lo)) * (idx - (double)lo);
     const int n_digits = std::min(3, (int)med);
     double f = 1.0;
     for (int k = 1; k < n_digits; ++k) f *= 10.0;
@@ -776,20 +777,32 @@ int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs,
     for (int m = 0; m < n_msgs; ++m) {
         const int64_t a = off[m] < 0 ? -off[m] - 1 : off[m], b = off[m + 1] < 0 ? -off[m + 1] - 1 : off[m + 1];
         if (b < a || (b > a && !lens)) return URHGPU_ERR_ARG;
+    }
+    auto one = [&](int m) {
+        const int64_t a = off[m] < 0 ? -off[m] - 1 : off[m], b = off[m + 1] < 0 ? -off[m + 1] - 1 : off[m + 1];
         std::vector<uint64_t> p(lens + a, lens + b);
         const int64_t tol = tolerance_of(p);
         tol_out[m] = tol;
-        if (tol == -2) { bitlen_out[m] = -2; continue; }
+        if (tol == -2) { bitlen_out[m] = -2; return; }
         std::vector<uint64_t> merged;
         if (tol > 0) {
             merged.resize(p.size());
             int64_t k = 0;
-            if (!p.empty()) URH_TRY(urhgpu_merge_plateaus(p.data(), (int64_t)p.size(), (uint64_t)tol, 10000, merged.data(), &k));
+            if (!p.empty()) (void)urhgpu_merge_plateaus(p.data(), (int64_t)p.size(), (uint64_t)tol, 10000, merged.data(), &k);
             merged.resize((size_t)k);
         } else {
-            merged = p;
+            merged.swap(p);
         }
         bitlen_out[m] = merged.size() < 2 ? -1 : bit_length_of(merged);
+    };
+    // the messages are independent: a few host threads when there are many of them (a sort of a few thousand values each)
+    const int n_threads = std::min<int>(16, std::min<int>(n_msgs / 8, (int)std::max(1u, std::thread::hardware_concurrency())));
+    if (n_threads <= 1) {
+        for (int m = 0; m < n_msgs; ++m) one(m);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < n_threads; ++t) pool.emplace_back([&, t]() { for (int m = t; m < n_msgs; m += n_threads) one(m); });
+        for (auto &th : pool) th.join();
     }
     return URHGPU_OK;
 }
