@@ -539,6 +539,15 @@ struct BitsCountsFinal {
     }
 };
 
+// bit k of a row that repeats the symbol `type` (bits_per_symbol bits, most significant first): number_to_bits(state) * n (:390-392).
+// k % bps in 32 bits where k fits (a 64-bit remainder is a 50-instruction sequence per bit); bps == 1: always bit 0.
+__device__ __forceinline__ uint8_t symbol_bit(int64_t type, int64_t k, int bps) {
+    if (type < 0) return 0;
+    if (bps == 1) return (uint8_t)(type & 1);
+    const int r = (k < 0x7fffffff) ? (int)((uint32_t)k % (uint32_t)bps) : (int)(k % bps);
+    return (uint8_t)((type >> (bps - 1 - r)) & 1);
+}
+
 struct HugeRow { int64_t kb, ob, op, ts, type; };   // a row that expands to more than kHugeBits bits
 constexpr int64_t kHugeBits = 4096;
 constexpr int kHugeCap = 8192;
@@ -583,7 +592,7 @@ __global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
     constexpr int kShort = 16;
     if (kb > 0 && kb <= kShort) {
         for (int64_t k = 0; k < kb; ++k) {
-            const uint8_t b = (type < 0) ? 0 : (uint8_t)((type >> (bps - 1 - (int)(k % bps))) & 1);
+            const uint8_t b = symbol_bit(type, k, bps);
             if (ob + k < a.cap_bits) a.bits[ob + k] = b;
             if (a.bp.write_pos && op + k < a.cap_pos) a.pos[op + k] = ts + k * a.bp.samples_per_bit;
         }
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(256) void k_expand_bits(const ExpandArgs a) {
             }
         }
         for (int64_t k = lane; k < kb_s; k += 64) {
-            const uint8_t b = (ty_s < 0) ? 0 : (uint8_t)((ty_s >> (bps - 1 - (int)(k % bps))) & 1);
+            const uint8_t b = symbol_bit(ty_s, k, bps);
             if (ob_s + k < a.cap_bits) a.bits[ob_s + k] = b;
             if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
         }
@@ -1188,10 +1197,19 @@ __global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
         }
         constexpr int kShort = 16;
         if (kb > 0 && kb <= kShort) {
-            for (int64_t k = 0; k < kb; ++k) {
-                const uint8_t b = (type < 0) ? 0 : (uint8_t)((type >> (bps - 1 - (int)(k % bps))) & 1);
-                if (ob + k < a.cap_bits) a.bits[ob + k] = b;
-                if (a.bp.write_pos && op + k < a.cap_pos) a.pos[op + k] = ts + k * a.bp.samples_per_bit;
+            // a few bits per row (the common case): capacity checks hoisted out of the loop, positions by repeated addition
+            const int nb = (ob + kb <= a.cap_bits) ? (int)kb : (int)((a.cap_bits > ob) ? a.cap_bits - ob : 0);
+            const int np = !a.bp.write_pos ? 0 : ((op + kb <= a.cap_pos) ? (int)kb : (int)((a.cap_pos > op) ? a.cap_pos - op : 0));
+            uint8_t *bp8 = a.bits + ob;
+            int64_t *pp = a.pos + op;
+            int64_t tsk = ts;
+            int sh = bps - 1;
+            for (int k = 0; k < (int)kb; ++k) {
+                const uint8_t b = (type < 0) ? 0 : (uint8_t)((type >> sh) & 1);
+                sh = (sh == 0) ? bps - 1 : sh - 1;
+                if (k < nb) bp8[k] = b;
+                if (k < np) pp[k] = tsk;
+                tsk += a.bp.samples_per_bit;
             }
         }
         unsigned long long big = __ballot(kb > kShort);
@@ -1201,7 +1219,7 @@ __global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
             const int64_t kb_s = __shfl(kb, src), ob_s = __shfl(ob, src), op_s = __shfl(op, src), ts_s = __shfl(ts, src),
                           ty_s = __shfl(type, src);
             for (int64_t k = lane; k < kb_s; k += 64) {
-                const uint8_t b = (ty_s < 0) ? 0 : (uint8_t)((ty_s >> (bps - 1 - (int)(k % bps))) & 1);
+                const uint8_t b = symbol_bit(ty_s, k, bps);
                 if (ob_s + k < a.cap_bits) a.bits[ob_s + k] = b;
                 if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
             }
