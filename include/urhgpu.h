@@ -280,6 +280,15 @@ int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *ctx, const void *d_iq, int dtyp
  * the rows into (start, end) tuples.  Integer captures: magnitudes as util.get_magnitudes computes them (C int sum, double sqrt). */
 int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold,
                             int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows);
+/* segment_messages_from_magnitudes (auto_interpretation.pyx:55-111) and -- when n_merged_out is not NULL --
+ * merge_message_segments_for_ook (AutoInterpretation.py:107-148) entirely on the device: state table (urhgpu_segment_runs_dev),
+ * prefix sum -> (start, end) of every segment, outlier-free minimum pulse length, cuts at pauses >= 8 x that.  Only ranges cross
+ * PCIe: seg_out = HOST int64[cap_seg_out][2] receives the first min(*n_seg_out, cap_seg_out) segments (AutoInterpretation.estimate
+ * looks at the first 100 to tell the modulation), merged_out likewise the merged messages.  *merge_ambiguous = 1: a pulse length
+ * lies within 1e-9 of the outlier bound mean +- std, where the order of the floating-point sum of squares decides -- the caller
+ * then fetches every segment and takes that decision in numpy's order.  Synchronous. */
+int urhgpu_message_ranges_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold, int64_t *seg_out, int64_t cap_seg_out,
+                              int64_t *n_seg_out, int64_t *merged_out, int64_t cap_merged_out, int64_t *n_merged_out, int *merge_ambiguous);
 /* rect[rect > thr] (AutoInterpretation.py:227), order preserved; *d_count (device) = number kept. */
 int urhgpu_compact_gt_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float thr, float *d_out, int64_t *d_count);
 /* positions i >= 1 where (x[i] <= center) != (x[i-1] <= center), ascending (get_plateau_lengths,

@@ -269,6 +269,27 @@ def segment_messages_from_magnitudes(magnitudes, noise_threshold: float):
     return result
 
 
+def merge_message_segments_for_ook(segments: list):
+    """AutoInterpretation.merge_message_segments_for_ook (AutoInterpretation.py:107-148), with min_without_outliers(z=1) (:21-25)
+    inlined: OOK pulses whose separating pause is shorter than 8 x the minimum pulse within one standard deviation of the mean
+    belong to the same message."""
+    if len(segments) <= 1:
+        return segments
+    pulses = np.array([b - a for a, b in segments], dtype=np.uint64)
+    pauses = np.array([segments[i + 1][0] - segments[i][1] for i in range(len(segments) - 1)], dtype=np.uint64)
+    inliers = pulses[abs(pulses - np.mean(pulses)) <= 1 * np.std(pulses)]
+    long_pause = pauses >= 8 * np.min(inliers)
+    result = []
+    first = 0
+    for i in range(len(segments)):
+        if i == len(segments) - 1 or long_pause[i]:                    # message = segments first..i
+            length = sum(segments[j][1] - segments[j][0] for j in range(first, i + 1))
+            length += sum(segments[j][0] - segments[j - 1][1] for j in range(first + 1, i + 1))
+            result.append((segments[first][0], segments[first][0] + length))
+            first = i + 1
+    return result
+
+
 def get_plateau_lengths(rect_data, center, percentage=25) -> np.ndarray:
     """auto_interpretation.pyx:179-208 (pure-Python loop: small inputs only)."""
     n = len(rect_data)

@@ -63,6 +63,9 @@ def test_segment_and_value_helpers_equal_reference(ref):
         a = AI.merge_message_segments_for_ook(list(segs2))
         b = e.merge_message_segments_for_ook(list(segs2))
         assert [tuple(map(int, x)) for x in a] == [tuple(map(int, x)) for x in b], (it, segs2)
+        from oracle import urh_oracle
+        c = urh_oracle.merge_message_segments_for_ook(list(segs2))
+        assert [tuple(map(int, x)) for x in a] == [tuple(map(int, x)) for x in c], (it, segs2)
         vals = [int(v) for v in rng.integers(0, 6, int(rng.integers(0, 12)))]
         assert AI.get_most_frequent_value(list(vals)) == e.get_most_frequent_value(list(vals)), vals
         d = rng.standard_normal(int(rng.integers(0, 20)))

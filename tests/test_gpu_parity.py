@@ -679,6 +679,50 @@ def _bursty(n, seed, sps=50):
     return iq
 
 
+def _check_message_ranges(pipe, oracle, iq, nt, want_segments, caps=(4096, 65536)):
+    """the device-resident segmentation + OOK merge against the oracle's segments and the reference's merge of them"""
+    import torch
+    from urh_amd import estimators
+    want = [(int(a), int(b)) for a, b in want_segments]
+    seg, n_seg, mrg, n_mrg, amb = estimators.message_ranges_dev(pipe, torch.from_numpy(iq).cuda(), nt, cap_seg=caps[0], cap_merged=caps[1])
+    assert n_seg == len(want) and [tuple(r) for r in seg.tolist()] == want[:caps[0]], (len(iq), nt, n_seg, len(want), seg[:3], want[:3])
+    want_m = oracle.merge_message_segments_for_ook(list(want))
+    if not amb:
+        assert n_mrg == len(want_m) and [tuple(r) for r in mrg.tolist()] == [(int(a), int(b)) for a, b in want_m][:caps[1]], \
+            (len(iq), nt, n_mrg, len(want_m), mrg[:3], want_m[:3])
+    seg2, n2, none, _, _ = estimators.message_ranges_dev(pipe, torch.from_numpy(iq).cuda(), nt, merge=False, cap_seg=3)
+    assert none is None and n2 == len(want) and [tuple(r) for r in seg2.tolist()] == want[:3]
+    return amb
+
+
+def test_message_ranges_ook_bursts(pipe, oracle):
+    """OOK captures: one segment per pulse, merged into bursts on the device (AutoInterpretation.py:107-148)"""
+    def synth_ook_bursts(n, sps, seed):
+        rng = np.random.default_rng(seed)
+        env = np.zeros(n, np.float32)
+        pos = int(rng.integers(0, 5 * sps))
+        while pos < n:
+            bits = rng.integers(0, 2, int(rng.integers(16, 200)))
+            bits[0] = 1
+            sym = np.repeat(bits, sps).astype(np.float32)
+            # pulse-width jitter: pulses of 1..3 symbols whose lengths spread around the mean
+            env[pos:pos + len(sym)] = sym[:max(0, n - pos)]
+            pos += len(sym) + int(rng.integers(20, 400)) * sps
+        ph = rng.uniform(0, 2 * np.pi)
+        t = np.arange(n, dtype=np.float64)
+        c = np.exp(1j * (2 * np.pi * 0.01 * t + ph))
+        iq = (env * c).astype(np.complex64) + (0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+        return np.ascontiguousarray(iq.view(np.float32).reshape(-1, 2))
+    n_amb = 0
+    for n, seed, sps in ((40_000, 1, 20), (300_000, 2, 50), (2_000_000, 3, 25), (1_500_000, 4, 100)):
+        iq = synth_ook_bursts(n, sps=sps, seed=seed)
+        for nt in (0.1, 0.3):
+            want = oracle.segment_messages_from_magnitudes(oracle.get_magnitudes(iq), nt)
+            assert len(want) > 10
+            n_amb += _check_message_ranges(pipe, oracle, iq, nt, want, caps=(100, 50_000))
+    assert n_amb == 0                                   # the test captures are not borderline: the device decided all of them
+
+
 def test_segment_messages_equals_oracle(pipe, oracle):
     import torch
     from urh_amd import estimators
@@ -688,6 +732,7 @@ def test_segment_messages_equals_oracle(pipe, oracle):
             want = oracle.segment_messages_from_magnitudes(oracle.get_magnitudes(iq), nt)
             got = estimators.segment_messages_dev(pipe, torch.from_numpy(iq).cuda(), nt)
             assert got == [(int(a), int(b)) for a, b in want], (n, nt, got[:4], want[:4])
+            _check_message_ranges(pipe, oracle, iq, nt, want)
 
 
 @pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16])
@@ -704,6 +749,7 @@ def test_segment_messages_integer_captures(pipe, oracle, dtype):
             want = oracle.segment_messages_from_magnitudes(mags, nt)
             got = estimators.segment_messages_dev(pipe, torch.from_numpy(iq).cuda(), nt)
             assert got == [(int(a), int(b)) for a, b in want], (np.dtype(dtype).name, n, nt, got[:3], want[:3])
+            _check_message_ranges(pipe, oracle, iq, nt, want)
 
 
 def test_detect_center_equals_numpy(pipe, oracle):

@@ -89,6 +89,7 @@ PROTOTYPES = {
     "urhgpu_shard_bits_finish_dev": (_i, [_vp, _vp]),
     "urhgpu_magnitude_chunk_stats_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp]),
     "urhgpu_segment_runs_dev": (_i, [_vp, _vp, _i, _i64, _f, _vp, _i64, _vp]),
+    "urhgpu_message_ranges_dev": (_i, [_vp, _vp, _i, _i64, _f, _vp, _i64, C.POINTER(_i64), _vp, _i64, C.POINTER(_i64), C.POINTER(_i)]),
     "urhgpu_compact_gt_dev": (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     "urhgpu_edges_le_dev": (_i, [_vp, _vp, _i64, _f, _vp, _i64, _vp]),
     "urhgpu_minmax_f32_dev": (_i, [_vp, _vp, _i64, _vp]),

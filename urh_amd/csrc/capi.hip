@@ -848,6 +848,55 @@ int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_
     return digitize(ctx, true, d_iq, n, &p, nullptr, d_rows, cap_rows, d_n_rows, ctx->d_counts + 8, ctx->d_counts + 9, pl, 1);
 }
 
+int urhgpu_message_ranges_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold, int64_t *seg_out, int64_t cap_seg_out,
+                              int64_t *n_seg_out, int64_t *merged_out, int64_t cap_merged_out, int64_t *n_merged_out, int *merge_ambiguous) {
+    if (!ctx || n < 0 || !n_seg_out || cap_seg_out < 0 || cap_merged_out < 0 || (cap_seg_out > 0 && !seg_out) || (cap_merged_out > 0 && !merged_out))
+        return URHGPU_ERR_ARG;
+    if (dtype_bytes(dtype) == 0) return URHGPU_ERR_DTYPE;
+    const bool merge = n_merged_out != nullptr;
+    *n_seg_out = 0;
+    if (merge) *n_merged_out = 0;
+    if (merge_ambiguous) *merge_ambiguous = 0;
+    if (n == 0 || noise_threshold != noise_threshold) return URHGPU_OK;      // nothing compares greater than NaN: never above the noise
+    URH_HIP(hipSetDevice(ctx->device));
+    // the state table, the segment table and the message table live in the staging arena for the duration of the call
+    const int64_t cap_rows = n / 10 + 2;                   // a state change needs 10 samples in the new state
+    const int64_t cap_seg = cap_rows / 2 + 2;
+    const size_t need = (size_t)cap_rows * 16 + 2 * (size_t)cap_seg * 16 + seg_scratch_bytes(cap_rows, cap_seg) + seg_ctl_bytes() + 16 * 256;
+    URH_TRY(ctx->staging.reserve(need));
+    ctx->staging.reset();
+    int64_t *d_rows = (int64_t *)ctx->staging.take((size_t)cap_rows * 16);
+    int64_t *d_seg = (int64_t *)ctx->staging.take((size_t)cap_seg * 16);
+    int64_t *d_msgs = (int64_t *)ctx->staging.take((size_t)cap_seg * 16);
+    void *scratch = ctx->staging.take(seg_scratch_bytes(cap_rows, cap_seg));
+    SegCtl *d_ctl = (SegCtl *)ctx->staging.take(seg_ctl_bytes());
+    int64_t *d_n_rows = (int64_t *)ctx->staging.take(64);
+    if (!d_rows || !d_seg || !d_msgs || !scratch || !d_ctl || !d_n_rows) return URHGPU_ERR_ARG;
+    URH_TRY(urhgpu_segment_runs_dev(ctx, d_iq, dtype, n, noise_threshold, d_rows, cap_rows, d_n_rows));
+    URH_TRY(launch_message_ranges(d_rows, d_n_rows, cap_rows, d_iq, dtype, n, noise_threshold, merge ? 1 : 0, d_seg, d_msgs, cap_seg, d_ctl, scratch,
+                                  ctx->stream));
+    URH_HIP(hipGetLastError());
+    std::vector<char> ctl(seg_ctl_bytes());
+    URH_HIP(hipMemcpyAsync(ctl.data(), d_ctl, ctl.size(), hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t n_seg = 0, n_msgs = 0;
+    int ambiguous = 0;
+    seg_ctl_read(ctl.data(), &n_seg, &n_msgs, &ambiguous);
+    if (n_seg > cap_seg) return URHGPU_ERR_CAPACITY;       // cannot happen (a segment needs two state changes)
+    *n_seg_out = n_seg;
+    const int64_t take = std::min(n_seg, cap_seg_out);
+    if (take > 0) URH_HIP(hipMemcpyAsync(seg_out, d_seg, (size_t)take * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (merge) {
+        const bool merged = n_seg > 1;                     // AutoInterpretation.py:108: one segment is returned as it is
+        *n_merged_out = merged ? n_msgs : n_seg;
+        if (merge_ambiguous) *merge_ambiguous = merged ? ambiguous : 0;
+        const int64_t take_m = std::min(*n_merged_out, cap_merged_out);
+        if (take_m > 0) URH_HIP(hipMemcpyAsync(merged_out, merged ? d_msgs : d_seg, (size_t)take_m * 16, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
 int urhgpu_compact_gt_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float thr, float *d_out, int64_t *d_count) {
     if (!ctx || n < 0 || !d_count || (n > 0 && (!d_x || !d_out))) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));

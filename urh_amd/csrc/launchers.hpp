@@ -239,6 +239,13 @@ size_t minmax_scratch_bytes();
 int launch_minmax(const float *x, int64_t n, float *d_out2, void *scratch, hipStream_t s);
 int pairwise_sum_f32(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, float mean, float *out);
 int launch_hist_edges(const float *x, int64_t n, const double *d_edges, int n_edges, int64_t *d_counts, hipStream_t s);
+// ---- msg_ranges.hip ------------------------------------------------------------------------------------------
+struct SegCtl;
+int launch_message_ranges(const int64_t *d_rows, const int64_t *d_n_rows, int64_t cap_rows, const void *d_iq, int dtype, int64_t n, float thr,
+                          int ook_merge, int64_t *d_seg, int64_t *d_msgs, int64_t cap, SegCtl *d_ctl, void *scratch, hipStream_t s);
+size_t seg_scratch_bytes(int64_t cap_rows, int64_t cap);
+size_t seg_ctl_bytes();
+void seg_ctl_read(const void *host_copy, int64_t *n_seg, int64_t *n_msgs, int *ambiguous);
 // ---- costas.hip -----------------------------------------------------------------------------------------------
 size_t costas_scratch_bytes(int64_t n);
 int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, void *scratch);

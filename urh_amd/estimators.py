@@ -127,6 +127,27 @@ def segment_messages_dev(pipe, iq, noise_threshold: float, as_array: bool = Fals
     return seg if as_array else _as_tuples(seg)
 
 
+def message_ranges_dev(pipe, iq, noise_threshold: float, merge: bool = True, cap_seg: int = 4096, cap_merged: int = 65536):
+    """Segmentation and (optionally) the OOK merge without the per-pulse table leaving the GPU (urhgpu_message_ranges_dev).
+    Returns (segments[:cap_seg], n_segments, merged[:cap_merged] or None, n_merged, ambiguous): (K, 2) int64 arrays as
+    segment_messages_dev(as_array=True) / merge_message_segments_for_ook give them, truncated to the capacities."""
+    torch = pipe.torch
+    if iq.dtype == torch.complex64:
+        iq = torch.view_as_real(iq)
+    n = int(iq.shape[0])
+    pipe.ctx.set_stream(torch.cuda.current_stream(iq.device).cuda_stream)
+    from .pipeline import _torch_dtype
+    seg = np.empty((cap_seg, 2), np.int64)
+    mrg = np.empty((cap_merged, 2), np.int64) if merge else None
+    n_seg, n_mrg, amb = C.c_int64(0), C.c_int64(0), C.c_int(0)
+    _lib.check(_lib.load().urhgpu_message_ranges_dev(
+        pipe.ctx.handle, C.c_void_p(iq.data_ptr()), dtype_code(_torch_dtype(iq)), n, float(noise_threshold),
+        seg.ctypes.data_as(C.c_void_p), cap_seg, C.byref(n_seg),
+        mrg.ctypes.data_as(C.c_void_p) if merge else None, cap_merged if merge else 0, C.byref(n_mrg) if merge else None, C.byref(amb)))
+    return (seg[:min(n_seg.value, cap_seg)], n_seg.value, mrg[:min(n_mrg.value, cap_merged)] if merge else None, n_mrg.value,
+            bool(amb.value))
+
+
 def segments_from_rows(rows: np.ndarray, n: int, tail_above: np.ndarray):
     """rows: pulse table of the above(1)/below(0) states with tolerance 9 (row j: state BEFORE the j-th change, length);
     tail_above: above-noise flags of the last <= 10 samples.  Returns the reference's list of (start, end) tuples.
@@ -662,14 +683,25 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
         iq = torch.view_as_real(iq)
     noise = detect_noise_level_dev(pipe, iq) if noise is None else noise
     lap("noise_ms")
-    message_indices = segment_messages_dev(pipe, iq, noise, as_array=True)    # (K, 2) array: one row per OOK pulse before merging
+    # one row per OOK pulse before merging: hundreds of thousands, which stay on the GPU -- the host gets the first segments
+    # (modulation detection looks at 100) and the merged messages
+    segments, n_segments, merged, n_merged, ambiguous = message_ranges_dev(pipe, iq, noise)
     lap("segment_messages_ms")
     if modulation is None:
-        modulation = detect_modulation_for_messages_dev(iq, message_indices[:100].tolist(), pipe=pipe)
+        modulation = detect_modulation_for_messages_dev(iq, segments[:100].tolist(), pipe=pipe)
         if modulation is None:
             return None
     if modulation == "OOK":
-        message_indices = merge_message_segments_for_ook(message_indices)
+        if ambiguous:                                # a pulse length within rounding of mean +- std: decide in numpy's summation order
+            message_indices = merge_message_segments_for_ook(segment_messages_dev(pipe, iq, noise, as_array=True))
+        elif n_merged > len(merged):
+            message_indices = message_ranges_dev(pipe, iq, noise, cap_seg=1, cap_merged=n_merged)[2]
+        else:
+            message_indices = merged
+    elif n_segments > len(segments):
+        message_indices = message_ranges_dev(pipe, iq, noise, merge=False, cap_seg=n_segments)[0]
+    else:
+        message_indices = segments
     if modulation in ("OOK", "ASK"):
         mod = "ASK"
     elif modulation in ("FSK", "PSK"):
