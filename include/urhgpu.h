@@ -311,9 +311,12 @@ int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const
  * out_hist[m][0 .. n_edges - 2] = np.histogram(rect, bins = np.arange(min, max + var, var)); n_edges == 0: no histogram (empty
  * message, zero or NaN variance, fewer than two edges -> detect_center returns None); n_edges - 1 > max_bins: the histogram does not
  * fit the pool (the caller takes that message through urhgpu_histogram_f32_dev).  out_stats: double[n_msgs][8], out_hist:
- * int64[n_msgs][max_bins]. */
+ * int64[n_msgs][max_bins] or NULL (the histograms stay on the device).
+ * The peak picking (AutoInterpretation.py:250-277) happens on the device too: out_flag[m] = 1: out_center[m] is detect_center's
+ * result; 0: None; 2: too many bins (see above); 3: the second and third most populated peaks hold the same count, so the result
+ * depends on how np.argsort orders equal keys -- the caller asks again with out_hist and lets numpy decide.  Both may be NULL. */
 int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins,
-                            double *out_stats, int64_t *out_hist);
+                            double *out_stats, int64_t *out_hist, double *out_center, int32_t *out_flag);
 /* urhgpu_msg_plateaus: get_plateau_lengths(x[start:end], centers[m], percentage) for every message with a center (NaN: none,
  * no plateaus): out_len[out_off[m] .. |out_off[m + 1]|) (uint64, back to back; out_off[0] = 0).  Boundaries are searched in the
  * first percentage % + extra_window samples of a message; when that window holds no boundary at or beyond the percentage mark the

@@ -820,6 +820,38 @@ def test_batched_message_statistics_equal_oracle(pipe, oracle):
     assert np.array_equal(np.asarray(got, np.uint64), oracle.get_plateau_lengths(flat, 0.0, 25))
 
 
+def test_batched_centers_dense_messages_and_tied_peaks(pipe, oracle):
+    """messages without noise-gated samples are not compacted (the statistics read the capture itself); a histogram whose second and
+    third peak hold the same count is handed to numpy (np.argsort's order of equal keys decides in the reference)"""
+    import torch
+    from urh_amd import estimators
+    rng = np.random.default_rng(7)
+    n = 700_000
+    qad = (np.repeat(rng.integers(0, 2, n // 40 + 1), 40)[:n] * 0.9 + 0.05 + 0.03 * rng.standard_normal(n)).astype(np.float32)
+    qad[300_000:300_100] = -4.0                                      # one gated stretch: that message alone is compacted
+    qad[650_000:650_010] = np.nan
+    tied = np.zeros(40_000, np.float32)
+    tied[50::100] = 10.0
+    tied[51::100] = 20.0
+    qad[400_000:440_000] = tied
+    bounds = [(0, 100_000), (100_003, 250_001), (250_001, 350_000), (400_000, 440_000), (450_000, 450_001), (460_000, 700_000)]
+    dev = torch.from_numpy(qad).cuda()
+    centers = estimators.centers_batched(pipe, dev, bounds)
+    for (a, b), c in zip(bounds, centers):
+        want = oracle.detect_center(qad[a:b])
+        assert (c is None and want is None) or (c is not None and want is not None and float(c) == float(want)), ((a, b), c, want)
+    assert sum(c is not None for c in centers) >= 5
+    # the tied message really went through the tie path
+    import ctypes as C
+    from urh_amd import _lib
+    ranges = np.array(bounds, np.int64)
+    stats, cen, flag = np.zeros((len(bounds), 8)), np.zeros(len(bounds)), np.zeros(len(bounds), np.int32)
+    _lib.check(_lib.load().urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(dev.data_ptr()), n, ranges.ctypes.data_as(C.c_void_p), len(bounds),
+                                                   4096, stats.ctypes.data_as(C.c_void_p), None, cen.ctypes.data_as(C.c_void_p),
+                                                   flag.ctypes.data_as(C.c_void_p)))
+    assert flag.tolist() == [1, 1, 1, 3, 0, 1] and stats[0, 0] == 100_000 and stats[2, 0] == 99_999 - 100
+
+
 def test_detect_modulation_on_device(pipe):
     """urhgpu_detect_modulation_dev against detect_modulation in numpy (and the real reference's, where staged): same label for every
     message, variances within 1e-4 relative (double-precision radix-2 FFTs here, numpy's single-precision forward transforms there):

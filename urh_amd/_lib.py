@@ -95,7 +95,7 @@ PROTOTYPES = {
     "urhgpu_minmax_f32_dev": (_i, [_vp, _vp, _i64, _vp]),
     "urhgpu_pairwise_sum_f32_dev": (_i, [_vp, _vp, _i64, _i, _f, C.POINTER(_f)]),
     "urhgpu_histogram_f32_dev": (_i, [_vp, _vp, _i64, _vp, _i64, _vp]),
-    "urhgpu_msg_center_stats": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _vp, _vp]),
+    "urhgpu_msg_center_stats": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _vp, _vp, _vp, _vp]),
     "urhgpu_msg_plateaus": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64]),
     "urhgpu_detect_modulation_dev": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp]),
     "urhgpu_msg_bit_lengths": (_i, [_vp, _vp, _i, _vp, _vp]),

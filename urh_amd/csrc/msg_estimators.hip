@@ -13,7 +13,12 @@
 
 #include <algorithm>
 #include <math.h>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "common.hpp"
@@ -41,17 +46,44 @@ struct MsgState {            // one per message, device resident between the sta
     int64_t edge_cnt;        // boundaries found in the window
     int64_t window;          // samples of the message searched for boundaries
     double center;           // center handed to urhgpu_msg_plateaus (NaN: none)
+    double peak_center;      // urhgpu_msg_center_stats: center picked from the histogram (k_me_peaks)
+    int64_t peak_flag;       // 0 none, 1 peak_center valid, 2 more bins than the pool holds, 3 equally populated peaks compete for a slot
 };
+
+// Tile geometry: thread `tid` of a tile looks at samples j * 256 + tid (j = 0..15): every load instruction of a wavefront reads 256
+// consecutive bytes.  Order-preserving work (the compaction, the boundary lists) ranks a sample by (row j, wavefront, lane) from
+// ballots.  (16 consecutive samples per thread -- the first version -- made every load touch 32 cache lines: 1.9 TB/s.)
+__device__ __forceinline__ unsigned long long me_lanes_below() { return (1ull << (threadIdx.x & 63)) - 1ull; }
+// exclusive prefix of the 64 cells (row j, wavefront w) of a tile in s_cell[j * 4 + w] (in place), total returned to all threads
+__device__ __forceinline__ int me_cell_scan(int *s_cell, int *s_total) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int v = s_cell[threadIdx.x];
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if ((int)threadIdx.x >= o) incl += u; }
+        s_cell[threadIdx.x] = incl - v;
+        if (threadIdx.x == 63) *s_total = incl;
+    }
+    __syncthreads();
+    return *s_total;
+}
+// samples of a message after the x > -4 filter: the capture itself when nothing was filtered (ASK magnitudes: always)
+__device__ __forceinline__ const float *me_src(const float *x, const float *kept, const MsgState &m) {
+    return (m.kept == m.end - m.start) ? x + m.start : kept + m.start;
+}
 
 // ---- stage 1: stable compaction of x > -4 per message into kept[start + j] ----------------------------------------------
 __global__ __launch_bounds__(kMeBlock) void k_me_count(const float *x, const MsgState *st, const MsgTile *tiles, int32_t *tile_cnt) {
     __shared__ int s_w[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const int64_t base = st[t.msg].start + (int64_t)t.idx * kMeTile, end = st[t.msg].end;
-    int c = 0;
-    const int64_t i0 = base + (int64_t)threadIdx.x * kMePer;
+    float v[kMePer];
 #pragma unroll
-    for (int j = 0; j < kMePer; ++j) if (i0 + j < end && x[i0 + j] > -4.0f) ++c;
+    for (int j = 0; j < kMePer; ++j) { const int64_t i = base + j * kMeBlock + threadIdx.x; v[j] = (i < end) ? x[i] : -5.0f; }
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) c += (v[j] > -4.0f) ? 1 : 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
@@ -90,29 +122,31 @@ __global__ __launch_bounds__(kMeScanBlock) void k_me_tile_scan(const int32_t *cn
 
 __global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgState *st, const MsgTile *tiles, const int64_t *tile_pre,
                                                           float *kept) {
-    __shared__ int s_w[kMeBlock / 64];
+    __shared__ int s_cell[kMePer * (kMeBlock / 64)];
+    __shared__ int s_total;
     const MsgTile t = tiles[blockIdx.x];
-    const MsgState m = st[t.msg];
-    const int64_t before = tile_pre[blockIdx.x] - tile_pre[m.first_tile];       // kept samples in the message's earlier tiles
-    const int64_t base = m.start + (int64_t)t.idx * kMeTile;
-    const int64_t i0 = base + (int64_t)threadIdx.x * kMePer;
+    const int64_t start = st[t.msg].start, end = st[t.msg].end, first_tile = st[t.msg].first_tile;
+    const int64_t len = end - start, n_tiles = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
+    const int64_t kept_total = tile_pre[first_tile + n_tiles] - tile_pre[first_tile];
+    if (threadIdx.x == 0 && t.idx == n_tiles - 1) st[t.msg].kept = kept_total;
+    if (kept_total == len) return;                           // nothing filtered: the later stages read the capture (me_src)
+    const int64_t before = tile_pre[blockIdx.x] - tile_pre[first_tile];         // kept samples in the message's earlier tiles
+    const int64_t base = start + (int64_t)t.idx * kMeTile;
+    const int wave = threadIdx.x >> 6;
     float v[kMePer];
-    int c = 0;
+    unsigned long long bal[kMePer];
 #pragma unroll
-    for (int j = 0; j < kMePer; ++j) { v[j] = (i0 + j < m.end) ? x[i0 + j] : -5.0f; if (v[j] > -4.0f) ++c; }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = c;
+    for (int j = 0; j < kMePer; ++j) { const int64_t i = base + j * kMeBlock + threadIdx.x; v[j] = (i < end) ? x[i] : -5.0f; }
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    int wbase = 0, total = 0;
+    for (int j = 0; j < kMePer; ++j) {
+        bal[j] = __ballot(v[j] > -4.0f);
+        if ((threadIdx.x & 63) == 0) s_cell[j * (kMeBlock / 64) + wave] = __popcll(bal[j]);
+    }
+    me_cell_scan(s_cell, &s_total);
+    const unsigned long long below = me_lanes_below();
 #pragma unroll
-    for (int w = 0; w < kMeBlock / 64; ++w) { if (w < wave) wbase += s_w[w]; total += s_w[w]; }
-    int64_t o = m.start + before + wbase + incl - c;
-#pragma unroll
-    for (int j = 0; j < kMePer; ++j) if (v[j] > -4.0f) kept[o++] = v[j];
-    if (threadIdx.x == 0 && base + kMeTile >= m.end) st[t.msg].kept = before + total;      // the message's last tile
+    for (int j = 0; j < kMePer; ++j)
+        if (v[j] > -4.0f) kept[start + before + s_cell[j * (kMeBlock / 64) + wave] + __popcll(bal[j] & below)] = v[j];
 }
 
 // ---- stage 2: trim, pairwise-summation geometry -------------------------------------------------------------------------
@@ -126,18 +160,20 @@ __global__ void k_me_trim(MsgState *st, int n_msgs) {
 }
 
 // ---- stage 3: min / max (util.minmax: seeded with element 0, `<` / `>` folds -- NaN never replaces a value) ----------------
-__global__ __launch_bounds__(kMeBlock) void k_me_minmax(const float *kept, const MsgState *st, const MsgTile *tiles, float2 *tile_mm) {
+__global__ __launch_bounds__(kMeBlock) void k_me_minmax(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, float2 *tile_mm) {
     __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
-    if (m.L <= 0) return;
-    const float *r = kept + m.start + m.a;
-    float mn = r[0], mx = r[0];
+    if (m.L <= 0 || (int64_t)t.idx * kMeTile >= m.L) return;
+    const float *r = me_src(x, kept, m) + m.a;
     const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
-    for (int j = 0; j < kMePer; ++j) {
-        const int64_t i = i0 + (int64_t)j * kMeBlock;
-        if (i < m.L) { const float v = r[i]; if (v < mn) mn = v; if (v > mx) mx = v; }
-    }
+    const float first = r[0];                                // the seed of every partial fold: a NaN there stays (as in util.minmax)
+    float v[kMePer];
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) { const int64_t i = i0 + (int64_t)j * kMeBlock; v[j] = (i < m.L) ? r[i] : first; }
+    float mn = first, mx = first;
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) { if (v[j] < mn) mn = v[j]; if (v[j] > mx) mx = v[j]; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const float a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
@@ -151,12 +187,12 @@ __global__ __launch_bounds__(kMeBlock) void k_me_minmax(const float *kept, const
         tile_mm[blockIdx.x] = float2{mn, mx};
     }
 }
-__global__ __launch_bounds__(64) void k_me_minmax_fin(MsgState *st, const float2 *tile_mm, const float *kept) {
+__global__ __launch_bounds__(64) void k_me_minmax_fin(MsgState *st, const float2 *tile_mm, const float *x, const float *kept) {
     const int m = blockIdx.x;
     MsgState s = st[m];
     if (s.L <= 0) return;
     const int64_t nt = (s.L + kMeTile - 1) / kMeTile;
-    float mn = kept[s.start + s.a], mx = mn;
+    float mn = me_src(x, kept, s)[s.a], mx = mn;
     for (int64_t u = threadIdx.x; u < nt; u += 64) {
         const float2 p = tile_mm[s.first_tile + u];
         if (p.x < mn) mn = p.x;
@@ -182,7 +218,8 @@ __device__ __forceinline__ float me_elem(const float *r, int64_t i, int mode, fl
     return d * d;
 }
 // leaf sums of the FULL chunks: 8 threads per leaf (one per accumulator), 32 leaves per tile
-__global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *kept, const MsgState *st, const MsgTile *tiles, int mode, float *leaf_sums) {
+__global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int mode,
+                                                         float *leaf_sums) {
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
     const int64_t n_full_leaves = (m.L / kPwChunkM) * (kPwChunkM / kPwLeafM);
@@ -191,7 +228,7 @@ __global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *kept, const
     float acc = 0.f;
     const bool live = leaf < n_full_leaves;
     if (live) {
-        const float *r = kept + m.start + m.a + leaf * kPwLeafM;
+        const float *r = me_src(x, kept, m) + m.a + leaf * kPwLeafM;
         acc = me_elem(r, j, mode, m.mean);
 #pragma unroll
         for (int i = 8; i < kPwLeafM; i += 8) acc += me_elem(r, i + j, mode, m.mean);
@@ -239,67 +276,69 @@ __device__ __forceinline__ float me_leaf_sum(const float *a, int len, int mode, 
     }
     return res;
 }
-constexpr int kMeRestLeaves = 256;            // a rest of < 8192 elements splits into at most 128 leaves
-__global__ __launch_bounds__(64) void k_me_sum_fin(const float *kept, MsgState *st, const float *chunk_sums, int mode) {
+// The irregular rest (< 8192 elements) is a tree whose leaves hold 64..128 elements each, so every leaf contains a multiple of 64
+// within its first 64 elements: the thread that owns that multiple owns the leaf.  It finds the leaf by walking down from the
+// root (registers only), sums it, and the tree is combined level by level from the deepest one up -- the node values live in LDS at
+// the slot of the node's leftmost leaf, and the owner of that leaf adds the right child (left + right, as pw() does).
+constexpr int kMeRestSlots = kPwChunkM / 64, kMeRestDepth = 9;
+__global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, const float *kept, MsgState *st, const float *chunk_sums, int mode) {
     __shared__ float s_chunk[64];
-    __shared__ int s_off[kMeRestLeaves], s_len[kMeRestLeaves];
-    __shared__ float s_sum[kMeRestLeaves];
-    __shared__ int s_nleaf;
-    const int m = blockIdx.x, lane = threadIdx.x;
+    __shared__ float s_val[kMeRestSlots + 1];
+    const int m = blockIdx.x, tid = threadIdx.x;
     const MsgState s = st[m];
     if (s.L <= 0) return;
-    const int64_t n_chunks = s.L / kPwChunkM, rest = s.L % kPwChunkM;
+    const int64_t n_chunks = s.L / kPwChunkM;
+    const int rest = (int)(s.L % kPwChunkM);
     const float *cs = chunk_sums + s.first_tile;
     float total = 0.f;
     for (int64_t c0 = 0; c0 < n_chunks; c0 += 64) {
         const int64_t nc = (n_chunks - c0 < 64) ? n_chunks - c0 : 64;
-        if (lane < nc) s_chunk[lane] = cs[c0 + lane];
+        if (tid < nc) s_chunk[tid] = cs[c0 + tid];
         __syncthreads();
-        if (lane == 0) for (int64_t c = 0; c < nc; ++c) total = total + s_chunk[c];      // total = ((0 + c0) + c1) + ...
+        if (tid == 0) for (int64_t c = 0; c < nc; ++c) total = total + s_chunk[c];      // total = ((0 + c0) + c1) + ...
         __syncthreads();
     }
-    // the irregular last chunk: pw(a, n) = pw(a, n2) + pw(a + n2, n - n2), n2 = n / 2 rounded down to a multiple of 8, down to
-    // leaves of <= 128 elements.  Lane 0 lists the leaves (left to right), the lanes sum them, lane 0 combines along the same tree.
-    struct Frame { int32_t off, len, state; float left; };
-    if (lane == 0) {
-        int nl = 0;
-        if (rest) {
-            Frame stack[16];
-            int sp = 0;
-            stack[0] = Frame{0, (int32_t)rest, 0, 0.f};
-            while (sp >= 0) {
-                Frame &f = stack[sp];
-                if (f.len <= kPwLeafM) { s_off[nl] = f.off; s_len[nl] = f.len; ++nl; --sp; continue; }
-                int32_t n2 = f.len / 2;
+    // pw(a, n) = pw(a, n2) + pw(a + n2, n - n2), n2 = n / 2 rounded down to a multiple of 8, down to leaves of <= 128 elements
+    const int e = tid * 64;                                  // this thread's element
+    int off[kMeRestDepth], len[kMeRestDepth];
+    int depth = 0, leaf_o = -1;                              // depth / offset of the leaf that holds e
+    bool owner = false;
+    if (e < rest) {
+        int o = 0, l = rest;
+#pragma unroll
+        for (int d = 0; d < kMeRestDepth; ++d) {
+            off[d] = o; len[d] = l;
+            if (l > kPwLeafM) {
+                int n2 = l / 2;
                 n2 -= n2 % 8;
-                if (f.state == 0) { f.state = 1; stack[sp + 1] = Frame{f.off, n2, 0, 0.f}; ++sp; }
-                else if (f.state == 1) { f.state = 2; stack[sp + 1] = Frame{f.off + n2, f.len - n2, 0, 0.f}; ++sp; }
-                else --sp;
+                if (e < o + n2) l = n2; else { o += n2; l -= n2; }
+                depth = d + 1;
             }
         }
-        s_nleaf = nl;
+        owner = (e - o) < 64;                                // the first multiple of 64 inside the leaf [o, o + l)
+        leaf_o = o;
+        if (owner) s_val[tid] = me_leaf_sum(me_src(x, kept, s) + s.a + n_chunks * kPwChunkM + o, l, mode, s.mean);
+        // (off / len at depths beyond the leaf repeat the leaf)
     }
     __syncthreads();
-    const float *ra = kept + s.start + s.a + n_chunks * kPwChunkM;
-    for (int k = lane; k < s_nleaf; k += 64) s_sum[k] = me_leaf_sum(ra + s_off[k], s_len[k], mode, s.mean);
-    __syncthreads();
-    if (lane == 0) {
-        if (rest) {
-            Frame stack[16];
-            int sp = 0, next = 0;
-            float ret = 0.f;
-            stack[0] = Frame{0, (int32_t)rest, 0, 0.f};
-            while (sp >= 0) {
-                Frame &f = stack[sp];
-                if (f.len <= kPwLeafM) { ret = s_sum[next++]; --sp; continue; }
-                int32_t n2 = f.len / 2;
-                n2 -= n2 % 8;
-                if (f.state == 0) { f.state = 1; stack[sp + 1] = Frame{f.off, n2, 0, 0.f}; ++sp; }
-                else if (f.state == 1) { f.left = ret; f.state = 2; stack[sp + 1] = Frame{f.off + n2, f.len - n2, 0, 0.f}; ++sp; }
-                else { ret = f.left + ret; --sp; }
-            }
-            total = total + ret;
+#pragma unroll
+    for (int d = kMeRestDepth - 2; d >= 0; --d) {
+        // the node at depth d on this thread's path is internal when the leaf lies deeper; this thread combines it when its leaf is
+        // the node's leftmost one (same offset)
+        float right = 0.f;
+        bool act = false;
+        if (owner && d < depth) {
+            const int o = off[d], l = len[d];
+            int n2 = l / 2;
+            n2 -= n2 % 8;
+            if (leaf_o == o) { act = true; right = s_val[(o + n2 + 63) / 64]; }
         }
+        __syncthreads();
+        if (act) s_val[tid] = s_val[tid] + right;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (rest) total = total + s_val[0];
         const float res = total / (float)s.L;                   // float32 sum / float32 count
         if (mode == 0) st[m].mean = res; else st[m].var = res;
     }
@@ -333,60 +372,181 @@ __global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins) {
 __device__ __forceinline__ double me_edge(const MsgState &s, int64_t i) { return s.e0 + (double)i * s.delta; }
 
 constexpr int kMeHistLds = 4096;             // bins kept in LDS per workgroup (the pool's max_bins is at most this)
-__global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *kept, const MsgState *st, const MsgTile *tiles, int64_t max_bins,
+constexpr int kMeEdgeLds = 2048;             // edges kept in LDS (histograms with more bins evaluate the edges per sample)
+__device__ __forceinline__ double me_edge32(const MsgState &s, int i) { return s.e0 + (double)i * s.delta; }
+__global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int64_t max_bins,
                                                        unsigned int *counts) {
     // demodulated signals sit on two or four levels: nearly every sample of a message lands in a handful of bins.  Counting
-    // straight into device memory serialises the whole pass on those few addresses (40 ms for a 1 GiB capture); a thread counts
-    // runs of equal bins in a register, the workgroup in LDS, and only the non-empty bins of a tile reach device memory.
+    // straight into device memory serialises the whole pass on those few addresses (40 ms for a 1 GiB capture).  A wavefront
+    // counts the lanes that share a bin with one ballot per distinct bin (one to three rounds per 64 samples), the workgroup
+    // accumulates in LDS, and only the non-empty bins of a tile reach device memory.
+    // The pass is bound by instruction issue, not by HBM: the bin is guessed in float32 and checked against the exact float64
+    // edges, which come from an LDS table (evaluating first + i * delta per sample costs two conversions and four float64 operations
+    // per edge).
     __shared__ unsigned int s_c[kMeHistLds];
+    __shared__ double s_e[kMeEdgeLds + 2];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
-    if (m.L <= 0 || m.n_edges < 2 || m.n_edges - 1 > max_bins) return;
-    const int64_t nb = m.n_edges - 1;
-    const bool in_lds = nb <= kMeHistLds;
+    if (m.L <= 0 || m.n_edges < 2 || m.n_edges - 1 > max_bins || m.n_edges - 1 > INT32_MAX - 1 || (int64_t)t.idx * kMeTile >= m.L) return;
+    const int nb = (int)(m.n_edges - 1);
+    const bool in_lds = nb <= kMeHistLds, table = nb + 1 <= kMeEdgeLds;
     if (in_lds) for (int k = threadIdx.x; k < nb; k += kMeBlock) s_c[k] = 0u;
+    if (table) for (int k = threadIdx.x; k <= nb; k += kMeBlock) s_e[k] = me_edge32(m, k);
     __syncthreads();
-    const double e0 = m.e0, eN = me_edge(m, nb);
-    const float *r = kept + m.start + m.a;
+    const double e0 = m.e0, eN = me_edge32(m, nb);
+    const float e0f = (float)e0, invf = (m.delta > 0.0) ? (float)(1.0 / m.delta) : 0.f;
+    const float *r = me_src(x, kept, m) + m.a;
     unsigned int *out = counts + (int64_t)t.msg * max_bins;
-    const int64_t i0 = (int64_t)t.idx * kMeTile + (int64_t)threadIdx.x * kMePer;      // 16 consecutive samples per thread
-    int64_t run_bin = -1;
-    unsigned int run = 0;
-    for (int j = 0; j < kMePer; ++j) {
-        const int64_t i = i0 + j;
-        if (i >= m.L) break;
-        const double v = (double)r[i];
-        if (!(v >= e0) || !(v <= eN)) continue;                // outside (or NaN)
-        int64_t k = (m.delta > 0.0) ? (int64_t)((v - e0) / m.delta) : 0;
-        if (k < 0) k = 0;
-        if (k > nb - 1) k = nb - 1;
-        while (k > 0 && me_edge(m, k) > v) --k;                // exact edge arithmetic decides (the guess is within one bin)
-        while (k < nb - 1 && me_edge(m, k + 1) <= v) ++k;      // last bin closed on the right
-        if (k == run_bin) { ++run; continue; }
-        if (run) { if (in_lds) atomicAdd(&s_c[run_bin], run); else atomicAdd(&out[run_bin], run); }
-        run_bin = k; run = 1;
+    const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    float val[kMePer];
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) { const int64_t i = i0 + (int64_t)j * kMeBlock; val[j] = (i < m.L) ? r[i] : __builtin_nanf(""); }
+    int bin[kMePer];
+    if (table) {
+        // straight-line code for all 16 rows (their LDS reads overlap): guess, one step either way, check.  The float32 guess is off by
+        // far less than one bin for <= 2047 bins (3 roundings of 2^-24 each), so the check never fails -- if it ever does, the exact
+        // search below repairs it.  (A float32-only fast path for samples far from every edge was tried: slower, the rows that need
+        // the float64 edges anyway pay for both.)
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < kMePer; ++j) {
+            const double v = (double)val[j];
+            const bool in = v >= e0 && v <= eN;                // inside (and not NaN)
+            const float g = (val[j] - e0f) * invf;
+            int k = (g >= 0.f) ? ((g < (float)(nb - 1)) ? (int)g : nb - 1) : 0;
+            k = in ? k : 0;
+            const double lo = s_e[k], hi = s_e[k + 1];
+            k += (v >= hi && k < nb - 1) ? 1 : ((v < lo && k > 0) ? -1 : 0);
+            const double lo2 = s_e[k], hi2 = s_e[k + 1];
+            bad |= in && !(v >= lo2 && (v < hi2 || k == nb - 1));
+            bin[j] = in ? k : -1;
+        }
+        if (__any(bad)) {
+#pragma unroll
+            for (int j = 0; j < kMePer; ++j) {
+                const double v = (double)val[j];
+                int k = bin[j];
+                if (k >= 0) {
+                    while (k > 0 && s_e[k] > v) --k;
+                    while (k < nb - 1 && s_e[k + 1] <= v) ++k;
+                    bin[j] = k;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kMePer; ++j) {
+            const double v = (double)val[j];
+            int k = -1;
+            if (v >= e0 && v <= eN) {
+                const float g = (val[j] - e0f) * invf;         // a guess; the exact edge arithmetic decides
+                k = (g >= 0.f) ? ((g < (float)(nb - 1)) ? (int)g : nb - 1) : 0;
+                while (k > 0 && me_edge32(m, k) > v) --k;
+                while (k < nb - 1 && me_edge32(m, k + 1) <= v) ++k;      // last bin closed on the right
+            }
+            bin[j] = k;
+        }
     }
-    if (run) { if (in_lds) atomicAdd(&s_c[run_bin], run); else atomicAdd(&out[run_bin], run); }
+    // count: a bin first seen in row j is counted over rows j..15 at once (a demodulated signal has two or three bins per wavefront)
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) {
+        unsigned long long todo = __ballot(bin[j] >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int kl = __shfl(bin[j], leader);
+            unsigned int cnt = 0;
+#pragma unroll
+            for (int q = j; q < kMePer; ++q) {
+                const bool same = bin[q] == kl;
+                cnt += (unsigned)__popcll(__ballot(same));
+                bin[q] = same ? -1 : bin[q];
+            }
+            if (lane == leader) { if (in_lds) atomicAdd(&s_c[kl], cnt); else atomicAdd(&out[kl], cnt); }
+            todo = __ballot(bin[j] >= 0);
+        }
+    }
     if (in_lds) {
         __syncthreads();
         for (int k = threadIdx.x; k < nb; k += kMeBlock) if (s_c[k]) atomicAdd(&out[k], s_c[k]);
     }
 }
 
+// ---- stage 6: the peak picking of detect_center (AutoInterpretation.py:250-277) ---------------------------------------------
+// Up to two bins, most populated first, that are strict maxima over +-(window - 1) bins (bins outside the histogram count as 0);
+// the center is the mean of their left edges.  Two strict maxima are at least `window` bins apart: at most 21 candidates.  The
+// reference walks the bins in np.argsort order, which leaves the order of equally populated bins to the sort implementation: that
+// matters only when the second and third candidate tie -- reported as flag 3, decided by the caller with numpy itself.
+__global__ __launch_bounds__(kMeBlock) void k_me_peaks(MsgState *st, const unsigned int *counts, int64_t max_bins) {
+    __shared__ int s_n;
+    __shared__ int s_idx[64];
+    __shared__ unsigned int s_cnt[64];
+    const int m = blockIdx.x;
+    const MsgState s = st[m];
+    if (s.n_edges < 2) { if (threadIdx.x == 0) { st[m].peak_flag = 0; st[m].peak_center = 0.0; } return; }
+    if (s.n_edges - 1 > max_bins) { if (threadIdx.x == 0) { st[m].peak_flag = 2; st[m].peak_center = 0.0; } return; }
+    const int nb = (int)(s.n_edges - 1);
+    const unsigned int *y = counts + (int64_t)m * max_bins;
+    int w = (int)(0.05 * (double)nb) + 1;
+    if (w < 2) w = 2;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += kMeBlock) {
+        const unsigned int yi = y[i];
+        bool ok = yi > 0u;
+        for (int d = 1; d < w && ok; ++d) {
+            const unsigned int l = (i - d >= 0) ? y[i - d] : 0u, r = (i + d < nb) ? y[i + d] : 0u;
+            ok = yi > l && yi > r;
+        }
+        if (ok) { const int q = atomicAdd(&s_n, 1); if (q < 64) { s_idx[q] = i; s_cnt[q] = yi; } }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nc = s_n < 64 ? s_n : 64;
+        int best[3] = {-1, -1, -1};                            // the three most populated candidates (ties: lower bin first -- only
+        for (int q = 0; q < nc; ++q) {                         // used to see whether a tie matters)
+            int c = q;
+            for (int r = 0; r < 3; ++r) {
+                if (c < 0) break;
+                if (best[r] < 0 || s_cnt[c] > s_cnt[best[r]] || (s_cnt[c] == s_cnt[best[r]] && s_idx[c] < s_idx[best[r]])) { const int tmp = best[r]; best[r] = c; c = tmp; }
+            }
+        }
+        int64_t flag = 0;
+        double center = 0.0;
+        if (nc == 1) { flag = 1; center = me_edge(s, s_idx[best[0]]) / 1.0; }
+        else if (nc >= 2) {
+            if (nc >= 3 && s_cnt[best[1]] == s_cnt[best[2]]) flag = 3;
+            else { flag = 1; center = (me_edge(s, s_idx[best[0]]) + me_edge(s, s_idx[best[1]])) / 2.0; }
+        }
+        st[m].peak_flag = flag; st[m].peak_center = center;
+    }
+}
+
 // ---- plateaus: boundaries of (x <= center) per message, first 25 % (get_plateau_lengths) -----------------------------------
+__device__ __forceinline__ void me_edge_flags(const float *x, const MsgState &m, const MsgTile &t, bool (&e)[kMePer]) {
+    const float cen = (float)m.center;
+    const float *r = x + m.start;
+    float cur[kMePer], prev[kMePer];
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) {
+        const int64_t i = (int64_t)t.idx * kMeTile + j * kMeBlock + threadIdx.x;          // position inside the message
+        const bool in = i >= 1 && i < m.window;
+        cur[j] = in ? r[i] : 0.f;
+        prev[j] = in ? r[i - 1] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < kMePer; ++j) e[j] = (cur[j] <= cen) != (prev[j] <= cen);
+}
 __global__ __launch_bounds__(kMeBlock) void k_me_edge_count(const float *x, const MsgState *st, const MsgTile *tiles, int32_t *tile_cnt) {
     __shared__ int s_w[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
     int c = 0;
     if (m.center == m.center) {
-        const float cen = (float)m.center;
-        const int64_t lo = (int64_t)t.idx * kMeTile + (int64_t)threadIdx.x * kMePer;
+        bool e[kMePer];
+        me_edge_flags(x, m, t, e);
 #pragma unroll
-        for (int j = 0; j < kMePer; ++j) {
-            const int64_t i = lo + j;                          // position inside the message
-            if (i >= 1 && i < m.window && ((x[m.start + i] <= cen) != (x[m.start + i - 1] <= cen))) ++c;
-        }
+        for (int j = 0; j < kMePer; ++j) c += e[j] ? 1 : 0;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
@@ -396,33 +556,27 @@ __global__ __launch_bounds__(kMeBlock) void k_me_edge_count(const float *x, cons
 }
 __global__ __launch_bounds__(kMeBlock) void k_me_edge_compact(const float *x, MsgState *st, const MsgTile *tiles, const int64_t *tile_pre,
                                                                int32_t *edges /* positions inside the message, region = message start */) {
-    __shared__ int s_w[kMeBlock / 64];
+    __shared__ int s_cell[kMePer * (kMeBlock / 64)];
+    __shared__ int s_total;
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
     if (!(m.center == m.center)) { if (threadIdx.x == 0 && t.idx == 0) st[t.msg].edge_cnt = 0; return; }
     const int64_t before = tile_pre[blockIdx.x] - tile_pre[m.first_tile];
-    const float cen = (float)m.center;
-    const int64_t lo = (int64_t)t.idx * kMeTile + (int64_t)threadIdx.x * kMePer;
+    const int wave = threadIdx.x >> 6;
     bool e[kMePer];
-    int c = 0;
+    me_edge_flags(x, m, t, e);
+    unsigned long long bal[kMePer];
 #pragma unroll
     for (int j = 0; j < kMePer; ++j) {
-        const int64_t i = lo + j;
-        e[j] = i >= 1 && i < m.window && ((x[m.start + i] <= cen) != (x[m.start + i - 1] <= cen));
-        if (e[j]) ++c;
+        bal[j] = __ballot(e[j]);
+        if ((threadIdx.x & 63) == 0) s_cell[j * (kMeBlock / 64) + wave] = __popcll(bal[j]);
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int incl = c;
+    const int total = me_cell_scan(s_cell, &s_total);
+    const unsigned long long below = me_lanes_below();
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    int wbase = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < kMeBlock / 64; ++w) { if (w < wave) wbase += s_w[w]; total += s_w[w]; }
-    int64_t o = m.start + before + wbase + incl - c;
-#pragma unroll
-    for (int j = 0; j < kMePer; ++j) if (e[j]) edges[o++] = (int32_t)(lo + j);
+    for (int j = 0; j < kMePer; ++j)
+        if (e[j]) edges[m.start + before + s_cell[j * (kMeBlock / 64) + wave] + __popcll(bal[j] & below)] =
+                      (int32_t)((int64_t)t.idx * kMeTile + j * kMeBlock + threadIdx.x);
     const int64_t last_tile = (m.window + kMeTile - 1) / kMeTile - 1;
     if (threadIdx.x == 0 && t.idx == last_tile) st[t.msg].edge_cnt = before + total;
 }
@@ -510,8 +664,8 @@ int build_batch(urhgpu_ctx *ctx, const int64_t *ranges, int n_msgs, int64_t n, c
 extern "C" {
 
 int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins,
-                            double *out_stats, int64_t *out_hist) {
-    if (!ctx || n < 0 || n_msgs < 0 || max_bins < 1 || (n_msgs > 0 && (!ranges || !out_stats || !out_hist || !d_x))) return URHGPU_ERR_ARG;
+                            double *out_stats, int64_t *out_hist, double *out_center, int32_t *out_flag) {
+    if (!ctx || n < 0 || n_msgs < 0 || max_bins < 1 || (n_msgs > 0 && (!ranges || !out_stats || !d_x))) return URHGPU_ERR_ARG;
     if (n_msgs == 0) return URHGPU_OK;
     URH_HIP(hipSetDevice(ctx->device));
     MsgBatch b;
@@ -540,28 +694,36 @@ int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const 
     hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
     hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_kept);
     hipLaunchKernelGGL(k_me_trim, dim3(gm), dim3(64), 0, s, d_st, n_msgs);
-    hipLaunchKernelGGL(k_me_minmax, dim3(gt), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles, d_mm);
-    hipLaunchKernelGGL(k_me_minmax_fin, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_mm, d_kept);
+    hipLaunchKernelGGL(k_me_minmax, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, d_mm);
+    hipLaunchKernelGGL(k_me_minmax_fin, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_mm, d_x, d_kept);
     for (int mode = 0; mode < 2; ++mode) {
-        hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles, mode, d_leaf);
+        hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, mode, d_leaf);
         hipLaunchKernelGGL(k_me_chunk_trees, dim3(gt), dim3(64), 0, s, d_st, d_tiles, d_leaf, d_chunk);
-        hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(64), 0, s, d_kept, d_st, d_chunk, mode);
+        hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeRestSlots), 0, s, d_x, d_kept, d_st, d_chunk, mode);
     }
     hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins);
-    hipLaunchKernelGGL(k_me_hist, dim3(gt), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles, max_bins, d_hist);
+    hipLaunchKernelGGL(k_me_hist, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, max_bins, d_hist);
+    hipLaunchKernelGGL(k_me_peaks, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_hist, max_bins);
     URH_HIP(hipGetLastError());
-    std::vector<unsigned int> hist((size_t)n_msgs * (size_t)max_bins);
+    std::vector<unsigned int> hist;
     URH_HIP(hipMemcpyAsync(b.host.data(), d_st, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost, s));
-    URH_HIP(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
+    if (out_hist) {                                          // the histograms themselves: only a caller that has to break a tie wants them
+        hist.resize((size_t)n_msgs * (size_t)max_bins);
+        URH_HIP(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
+    }
     URH_HIP(hipStreamSynchronize(s));
     for (int m = 0; m < n_msgs; ++m) {
         const MsgState &st = b.host[(size_t)m];
         double *o = out_stats + 8 * (size_t)m;
         o[0] = (double)st.kept; o[1] = (double)st.L; o[2] = (double)st.mn; o[3] = (double)st.mx; o[4] = (double)st.mean; o[5] = (double)st.var;
         o[6] = (double)st.n_edges; o[7] = st.e0;
-        int64_t *h = out_hist + (size_t)m * (size_t)max_bins;
-        const int64_t nb = (st.n_edges >= 2 && st.n_edges - 1 <= max_bins) ? st.n_edges - 1 : 0;
-        for (int64_t k = 0; k < max_bins; ++k) h[k] = (k < nb) ? (int64_t)hist[(size_t)m * (size_t)max_bins + (size_t)k] : 0;
+        if (out_center) out_center[m] = st.peak_center;
+        if (out_flag) out_flag[m] = (int32_t)st.peak_flag;
+        if (out_hist) {
+            int64_t *h = out_hist + (size_t)m * (size_t)max_bins;
+            const int64_t nb = (st.n_edges >= 2 && st.n_edges - 1 <= max_bins) ? st.n_edges - 1 : 0;
+            for (int64_t k = 0; k < max_bins; ++k) h[k] = (k < nb) ? (int64_t)hist[(size_t)m * (size_t)max_bins + (size_t)k] : 0;
+        }
     }
     return URHGPU_OK;
 }
@@ -766,6 +928,59 @@ int64_t bit_length_of(std::vector<uint64_t> &m) {
 
 }  // namespace
 
+// A small pool of host threads that lives as long as the process (creating 16 threads per call cost more than the work they did).
+// Jobs are indices 0 .. n - 1 handed out by an atomic counter; the caller works too and returns when all are done.
+namespace {
+struct HostPool {
+    std::mutex mu;
+    std::condition_variable wake, done;
+    std::vector<std::thread> threads;
+    const std::function<void(int)> *fn = nullptr;
+    std::atomic<int> next{0};
+    int n = 0, generation = 0, active = 0;
+    pid_t owner = 0;                          // a forked child has none of the threads: it builds its own pool
+};
+HostPool *g_pool = nullptr;                   // never destroyed: its threads may outlive static destruction
+std::mutex g_pool_call;                       // one batch at a time
+
+void host_pool_worker(HostPool *p) {
+    int seen = 0;
+    for (;;) {
+        const std::function<void(int)> *fn;
+        int n;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->wake.wait(lk, [&] { return p->generation != seen; });
+            seen = p->generation;
+            fn = p->fn; n = p->n;
+        }
+        for (int i; (i = p->next.fetch_add(1)) < n;) (*fn)(i);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            if (--p->active == 0) p->done.notify_one();
+        }
+    }
+}
+
+void host_pool_run(int n, int want_threads, const std::function<void(int)> &fn) {
+    const int hw = (int)std::max(1u, std::thread::hardware_concurrency());
+    const int helpers = std::min(std::min(want_threads, hw) - 1, n - 1);
+    if (helpers <= 0) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::lock_guard<std::mutex> call(g_pool_call);
+    if (!g_pool || g_pool->owner != getpid()) { g_pool = new HostPool(); g_pool->owner = getpid(); }
+    HostPool *p = g_pool;
+    while ((int)p->threads.size() < helpers) { p->threads.emplace_back(host_pool_worker, p); p->threads.back().detach(); }
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->fn = &fn; p->n = n; p->next.store(0); p->active = (int)p->threads.size(); ++p->generation;
+    }
+    p->wake.notify_all();
+    for (int i; (i = p->next.fetch_add(1)) < n;) fn(i);
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->done.wait(lk, [&] { return p->active == 0; });
+}
+}  // namespace
+
 extern "C" {
 
 // The per-message part of AutoInterpretation.estimate after get_plateau_lengths (AutoInterpretation.py:416-433) for every message:
@@ -796,14 +1011,7 @@ int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs,
         bitlen_out[m] = merged.size() < 2 ? -1 : bit_length_of(merged);
     };
     // the messages are independent: a few host threads when there are many of them (a sort of a few thousand values each)
-    const int n_threads = std::min<int>(16, std::min<int>(n_msgs / 8, (int)std::max(1u, std::thread::hardware_concurrency())));
-    if (n_threads <= 1) {
-        for (int m = 0; m < n_msgs; ++m) one(m);
-    } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t) pool.emplace_back([&, t]() { for (int m = t; m < n_msgs; m += n_threads) one(m); });
-        for (auto &th : pool) th.join();
-    }
+    host_pool_run(n_msgs, n_msgs >= 16 ? 24 : 1, one);
     return URHGPU_OK;
 }
 

@@ -227,7 +227,7 @@ def get_most_frequent_value(values: list):
 def detect_center_dev(pipe, rect, max_size=None, _single=False):
     """AutoInterpretation.detect_center (AutoInterpretation.py:226-277) for a demodulated signal on the GPU.
     GPU passes: compaction rect > -4, min / max, np.var (float32 pairwise sums in numpy's order), histogram over the
-    float64 edges np.arange(min, max + step, step); the peak picking over the bins is host work."""
+    float64 edges np.arange(min, max + step, step), peak picking over the bins."""
     torch = pipe.torch
     x = _dev_f32(pipe, rect)
     n = int(x.shape[0])
@@ -563,35 +563,60 @@ def detect_modulation_for_messages_dev(iq, message_indices: list, pipe=None):
 
 
 def centers_batched(pipe, data, message_indices, max_bins: int = 4096):
-    """detect_center (AutoInterpretation.py:226-277) of every message: the statistics and histograms of ALL messages come from
-    one batched device pass (urhgpu_msg_center_stats, one read-back); picking the peaks of a few dozen bins per message is
-    host work.  A message whose histogram has more than max_bins bins (a nearly constant signal: tiny variance) goes through
-    the single-message path.  Returns a list with a float or None per message."""
+    """detect_center (AutoInterpretation.py:226-277) of every message in one batched device pass (urhgpu_msg_center_stats):
+    statistics, histograms and the peak picking; one read-back of a few numbers per message.  A message whose histogram has more
+    than max_bins bins (a nearly constant signal: tiny variance) goes through the single-message path; one whose result depends on
+    np.argsort's order of equal counts is decided by numpy on its histogram.  Returns a list with a float or None per message."""
     x = _dev_f32(pipe, data)
     n_msgs = len(message_indices)
     if n_msgs == 0:
         return []
     ranges = np.ascontiguousarray(message_indices, dtype=np.int64).reshape(-1, 2)
     stats = np.zeros((n_msgs, 8), dtype=np.float64)
-    hist = np.zeros((n_msgs, max_bins), dtype=np.int64)
-    _lib.check(_lib.load().urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
-                                                   n_msgs, max_bins, stats.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p)))
-    centers = []
-    for m in range(n_msgs):
+    cen = np.zeros(n_msgs, dtype=np.float64)
+    flag = np.zeros(n_msgs, dtype=np.int32)
+    lib = _lib.load()
+    _lib.check(lib.urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
+                                           n_msgs, max_bins, stats.ctypes.data_as(C.c_void_p), None, cen.ctypes.data_as(C.c_void_p),
+                                           flag.ctypes.data_as(C.c_void_p)))
+    centers = [np.float64(c) if f == 1 else None for c, f in zip(cen.tolist(), flag.tolist())]
+    hist = None
+    for m in np.nonzero(flag >= 2)[0].tolist():
+        if flag[m] == 2:
+            centers[m] = detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True)
+            continue
+        if hist is None:                             # equally populated peaks: fetch the histograms, np.argsort decides
+            hist = np.zeros((n_msgs, max_bins), dtype=np.int64)
+            _lib.check(lib.urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
+                                                   n_msgs, max_bins, stats.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p), None, None))
         n_edges = int(stats[m, 6])
-        if n_edges < 2:
-            centers.append(None)
-        elif n_edges - 1 > max_bins:
-            centers.append(detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True))
+        hist_min, hist_max, step = float(stats[m, 2]), float(stats[m, 3]), float(stats[m, 5])
+        with np.errstate(all="ignore"):
+            edges = np.arange(hist_min, hist_max + step, step)                  # the same edges the device binned with
+        if len(edges) != n_edges or edges[0] != stats[m, 7]:                    # cannot happen; never bin against other edges silently
+            centers[m] = detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True)
         else:
-            hist_min, hist_max, step = float(stats[m, 2]), float(stats[m, 3]), float(stats[m, 5])
-            with np.errstate(all="ignore"):
-                edges = np.arange(hist_min, hist_max + step, step)              # the same edges the device binned with
-            if len(edges) != n_edges or edges[0] != stats[m, 7]:                # cannot happen; never bin against other edges silently
-                centers.append(detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True))
-            else:
-                centers.append(center_from_histogram(hist[m, :n_edges - 1], edges))
+            centers[m] = center_from_histogram(hist[m, :n_edges - 1], edges)
     return centers
+
+
+def _plateaus_raw(pipe, x, ranges, cen, percentage):
+    """urhgpu_msg_plateaus: (lens, off) -- message m's plateau lengths are lens[|off[m]| : |off[m + 1]|), a negative end offset
+    -(end + 1) marks a message whose first search window held no boundary beyond the percentage mark."""
+    n_msgs = len(ranges)
+    off = np.zeros(n_msgs + 1, dtype=np.int64)
+    cap = int(max(1 << 16, (ranges[:, 1] - ranges[:, 0]).sum() // 64))
+    lib = _lib.load()
+    while True:
+        lens = np.empty(cap, dtype=np.uint64)
+        st = lib.urhgpu_msg_plateaus(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
+                                     cen.ctypes.data_as(C.c_void_p), n_msgs, int(percentage), 1 << 16, off.ctypes.data_as(C.c_void_p),
+                                     lens.ctypes.data_as(C.c_void_p), cap)
+        if st == _lib.ERR_CAPACITY:
+            cap = int(off[n_msgs])
+            continue
+        _lib.check(st)
+        return lens, off
 
 
 def plateau_lengths_batched(pipe, data, message_indices, centers, percentage: int = 25):
@@ -603,19 +628,7 @@ def plateau_lengths_batched(pipe, data, message_indices, centers, percentage: in
         return []
     ranges = np.ascontiguousarray(message_indices, dtype=np.int64).reshape(-1, 2)
     cen = np.array([np.nan if c is None else float(np.float32(c)) for c in centers], dtype=np.float64)
-    off = np.zeros(n_msgs + 1, dtype=np.int64)
-    cap = int(max(1 << 16, (ranges[:, 1] - ranges[:, 0]).sum() // 64))
-    lib = _lib.load()
-    while True:
-        lens = np.zeros(cap, dtype=np.uint64)
-        st = lib.urhgpu_msg_plateaus(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
-                                     cen.ctypes.data_as(C.c_void_p), n_msgs, int(percentage), 1 << 16, off.ctypes.data_as(C.c_void_p),
-                                     lens.ctypes.data_as(C.c_void_p), cap)
-        if st == _lib.ERR_CAPACITY:
-            cap = int(off[n_msgs])
-            continue
-        _lib.check(st)
-        break
+    lens, off = _plateaus_raw(pipe, x, ranges, cen, percentage)
     out = []
     begin = 0
     for m in range(n_msgs):
@@ -639,6 +652,21 @@ def bit_length_of_message(plateau_lengths):
     return tolerance, get_bit_length_from_plateau_lengths(merged)
 
 
+def _bit_lengths_raw(lens, off, plateaus_of):
+    """urhgpu_msg_bit_lengths on the (lens, off) layout of _plateaus_raw; plateaus_of(m): message m's plateau lengths (for the
+    messages numpy has to decide)."""
+    n_msgs = len(off) - 1
+    tol = np.zeros(n_msgs, dtype=np.int64)
+    bl = np.zeros(n_msgs, dtype=np.int64)
+    lens = lens if len(lens) else np.zeros(1, np.uint64)
+    _lib.check(_lib.load().urhgpu_msg_bit_lengths(lens.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), n_msgs,
+                                                  tol.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p)))
+    out = [(None if t < 0 else t, None if b < 0 else b) for t, b in zip(tol.tolist(), bl.tolist())]
+    for m in np.nonzero((bl == -2) | (tol == -2))[0].tolist():
+        out[m] = bit_length_of_message(np.array(plateaus_of(m), dtype=np.uint64))
+    return out
+
+
 def bit_lengths_batched(all_plateaus):
     """[(tolerance or None, bit_length or None)] for every message from its plateau lengths: the native batch call
     (urhgpu_msg_bit_lengths: tolerance, merged plateaus, rounded lengths, divisor histogram from the value multiset, decision); a
@@ -649,17 +677,7 @@ def bit_lengths_batched(all_plateaus):
     off = np.zeros(n_msgs + 1, dtype=np.int64)
     off[1:] = np.cumsum([len(p) for p in all_plateaus])
     lens = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.uint64) for p in all_plateaus]) if off[-1] else np.zeros(1, np.uint64))
-    tol = np.zeros(n_msgs, dtype=np.int64)
-    bl = np.zeros(n_msgs, dtype=np.int64)
-    _lib.check(_lib.load().urhgpu_msg_bit_lengths(lens.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), n_msgs,
-                                                  tol.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p)))
-    out = []
-    for m in range(n_msgs):
-        if bl[m] == -2 or tol[m] == -2:
-            out.append(bit_length_of_message(np.array(all_plateaus[m], dtype=np.uint64)))
-        else:
-            out.append((None if tol[m] < 0 else int(tol[m]), None if bl[m] < 0 else int(bl[m])))
-    return out
+    return _bit_lengths_raw(lens, off, lambda m: all_plateaus[m])
 
 
 def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings: dict = None):
@@ -713,9 +731,16 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
     lap("afp_demod_ms")
     all_centers = centers_batched(pipe, data, message_indices)
     lap("centers_ms")
-    all_plateaus = plateau_lengths_batched(pipe, data, message_indices, all_centers)
-    lap("plateaus_ms")
-    decisions = bit_lengths_batched(all_plateaus)
+    ranges = np.ascontiguousarray(message_indices, dtype=np.int64).reshape(-1, 2)
+    cen = np.array([np.nan if c is None else float(np.float32(c)) for c in all_centers], dtype=np.float64)
+    lens, off = _plateaus_raw(pipe, _dev_f32(pipe, data), ranges, cen, 25) if len(ranges) else (np.zeros(1, np.uint64), np.zeros(1, np.int64))
+    if (off < 0).any():                              # a message whose first plateau outlasts the search window: the per-message path
+        all_plateaus = plateau_lengths_batched(pipe, data, message_indices, all_centers)
+        lap("plateaus_ms")
+        decisions = bit_lengths_batched(all_plateaus)
+    else:
+        lap("plateaus_ms")
+        decisions = _bit_lengths_raw(lens, off, lambda m: lens[int(off[m]):int(off[m + 1])])
     centers, bit_lengths, tolerances = [], [], []
     for center, (tolerance, bit_length) in zip(all_centers, decisions):
         if center is None:
