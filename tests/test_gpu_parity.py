@@ -418,6 +418,17 @@ def test_fir_equals_oracle(sf, oracle):
     h = (vals[rng.integers(0, 7, 9)] + 1j * vals[rng.integers(0, 7, 9)]).astype(np.complex64)
     assert cbits_equal(sf.fir_filter(x, h), oracle.fir_filter(x, h))
     assert len(sf.fir_filter(np.zeros(0, np.complex64), h)) == 0
+    # a capture whose tiles mostly take the fast kernel while a few are handed to the checked one (non-finite / huge samples), leading
+    # negative zeros in front (the zero-history identity), a partial last tile
+    for m in (7, 64, 100):
+        x = (rng.standard_normal(20_001) + 1j * rng.standard_normal(20_001)).astype(np.complex64)
+        x[:5] = np.array([-0.0, 0.0, -0.0 - 0.0j, 1e-30, -0.0], dtype=np.complex64)
+        x[7000] = np.inf
+        x[15_000] = np.float32(1e25)
+        x[19_990] = np.nan
+        h = (rng.standard_normal(m) + 1j * rng.standard_normal(m)).astype(np.complex64)
+        h[m // 2] = np.complex64(-0.0)
+        assert cbits_equal(sf.fir_filter(x, h), oracle.fir_filter(x, h)), m
 
 
 def test_fir_with_left_halo_equals_one_pass(pipe, oracle):

@@ -1344,7 +1344,11 @@ int urhgpu_fir_filter_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const fl
     if (((uintptr_t)d_x & 7) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_taps & 7) || m > (int64_t)1 << 20) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
     URH_TRY(join_tail(ctx));
-    URH_TRY(launch_fir((const float2 *)d_x, n, (const float2 *)d_taps, (int)m, (const float2 *)d_left_halo, (float2 *)d_out, ctx->stream));
+    URH_TRY(ctx->arena.reserve(fir_work_bytes(n, (int)m) + 1024));
+    ctx->arena.reset();
+    void *work = ctx->arena.take(fir_work_bytes(n, (int)m));
+    if (!work) return URHGPU_ERR_ARG;
+    URH_TRY(launch_fir((const float2 *)d_x, n, (const float2 *)d_taps, (int)m, (const float2 *)d_left_halo, (float2 *)d_out, ctx->stream, work));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }
@@ -1360,11 +1364,12 @@ int urhgpu_fir_filter_stats_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, co
         URH_TRY(urhgpu_fir_filter_dev(ctx, d_x, n, d_taps, m, d_left_halo, d_out));
         return urhgpu_magnitude_chunk_stats_dev(ctx, d_out, URHGPU_DT_F32, n, chunk, n_chunks, d_sum, d_max);
     }
-    URH_TRY(ctx->arena.reserve(fir_stats_scratch_bytes(n) + 1024));
+    URH_TRY(ctx->arena.reserve(fir_stats_scratch_bytes(n) + fir_work_bytes(n, (int)m) + 2048));
     ctx->arena.reset();
     void *scratch = ctx->arena.take(fir_stats_scratch_bytes(n));
-    if (!scratch) return URHGPU_ERR_ARG;
-    URH_TRY(launch_fir((const float2 *)d_x, n, (const float2 *)d_taps, (int)m, (const float2 *)d_left_halo, (float2 *)d_out, ctx->stream,
+    void *work = ctx->arena.take(fir_work_bytes(n, (int)m));
+    if (!scratch || !work) return URHGPU_ERR_ARG;
+    URH_TRY(launch_fir((const float2 *)d_x, n, (const float2 *)d_taps, (int)m, (const float2 *)d_left_halo, (float2 *)d_out, ctx->stream, work,
                        chunk, n_chunks, d_sum, d_max, scratch));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <math.h>
+#include <utility>
 
 #include "cmul.hpp"
 #include "common.hpp"
@@ -47,6 +48,10 @@ struct FirArgs {
     // from the end = outputs [n - (k+1) chunk, n - k chunk); a tile of 2048 outputs meets at most two chunks (chunk >= kFirTile)
     int64_t chunk, n_chunks; // 0: no statistics
     double *tile_stats;      // [tiles][4] = {sum, max} of the tile's outputs in its first chunk and in the next one
+    // k_fir_fast: taps padded with zeros to a multiple of 8 (+ 8), the list of tiles it left to k_fir (non-finite / huge operands)
+    const float2 *taps_pad;
+    int *redo;               // redo[0] = count, redo[1 + i] = tile
+    const int *tile_list;    // k_fir: nullptr = tiles tile0 + blockIdx.x; else the redo list
 };
 
 // The products of a tile can only come out as (NaN, NaN) -- the case the reference's complex multiply repairs with
@@ -143,14 +148,11 @@ __device__ __forceinline__ void fir_accumulate(const FirArgs &a, const float2 *s
 __device__ __forceinline__ double fir_nanmax(double a, double b) { return (a != a || b != b) ? __builtin_nan("") : ((b > a) ? b : a); }
 
 template <bool HEAD, bool STATS>
-__global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
-    __shared__ uint32_t s_maxbits;
-    __shared__ double s_st[kFirBlock / 64][4];
+__device__ __forceinline__ void fir_tile(const FirArgs &a, const int64_t tile, unsigned char *s_raw, uint32_t &s_maxbits, double (*s_st)[4]) {
     float2 *s_taps = (float2 *)s_raw;                       // [m]
     float2 *s_x = s_taps + ((a.m + 1) & ~1);                // [hist + kFirTile], s_x[u] = x[base - hist + u]
     const int t = threadIdx.x;
-    const int64_t base = (a.tile0 + blockIdx.x) * (int64_t)kFirTile;
+    const int64_t base = tile * (int64_t)kFirTile;
     if (t == 0) s_maxbits = 0;
     __syncthreads();
     uint32_t mb = 0;                                        // largest |component| seen, as float bits (NaN / inf compare high)
@@ -213,10 +215,191 @@ __global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
         if (t == 0) {
             double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
             for (int w = 0; w < kFirBlock / 64; ++w) { o0 += s_st[w][0]; o1 = fir_nanmax(o1, s_st[w][1]); o2 += s_st[w][2]; o3 = fir_nanmax(o3, s_st[w][3]); }
-            double *dst = a.tile_stats + 4 * (a.tile0 + blockIdx.x);
+            double *dst = a.tile_stats + 4 * tile;
             dst[0] = o0; dst[1] = o1; dst[2] = o2; dst[3] = o3;
         }
     }
+}
+
+template <bool HEAD, bool STATS>
+__global__ __launch_bounds__(kFirBlock) void k_fir(const FirArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ uint32_t s_maxbits;
+    __shared__ double s_st[kFirBlock / 64][4];
+    if (a.tile_list == nullptr) { fir_tile<HEAD, STATS>(a, a.tile0 + blockIdx.x, s_raw, s_maxbits, s_st); return; }
+    const int count = a.tile_list[0];                       // the tiles k_fir_fast handed back
+    for (int i = blockIdx.x; i < count; i += gridDim.x) {
+        fir_tile<HEAD, STATS>(a, a.tile_list[1 + i], s_raw, s_maxbits, s_st);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// k_fir_fast: the interior tiles (every output has its full history, the tile lies inside the capture) whose operands are finite
+// and below 2^60 -- all of a real capture.  Same arithmetic, arranged for the VALU:
+//   * LDS rows of 8 samples + 1 pad; lane t's outputs k0 .. k0 + 7 start a row, so the 8 samples a tap block needs (x[k0 - jb ..
+//     k0 - jb + 7]) are ONE row: a base register that moves one row per block and constant offsets (no address arithmetic);
+//   * taps from scalar registers (s_load from a zero-padded copy; v_pk_mul_f32 takes the SGPR pair directly): no LDS traffic, no
+//     VGPRs for them; a zero tap adds +-0 to an accumulator that is never -0: the padding above tap m - 1 changes nothing;
+//   * two row buffers in ping-pong: a block first issues the MACs that use the older row, then reloads that buffer with the NEXT
+//     block's row and issues the MACs that use the newer row while the load is in flight; no register moves;
+//   * tiles with a non-finite or huge operand are not computed here: their index goes to a list that k_fir works off afterwards
+//     (keeping the NaN-recovery path out of this kernel halves its register count);
+//   * the first outputs of a capture without halo (k < m - 1: terms with i < 0 do not exist) are computed against a zero history:
+//     a zero sample times a finite tap is +-0, and adding +-0 to an accumulator that started at +0 and is never -0 (a sum that
+//     cancels exactly rounds to +0) leaves it as it is -- the same identity that lets the taps be padded.
+// Order of the terms of one output: tap index descending (= sample index ascending), exactly as in fir_accumulate.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fir_cmac2s(fir_v2f &accA, fir_v2f &accB, fir_v2f xA, fir_v2f xB, fir_v2f hA, fir_v2f hB) {
+    fir_v2f t1a, t2a, t1b, t2b;
+    asm volatile(
+        "v_pk_mul_f32 %2, %6, %8 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %3, %6, %8 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %4, %7, %9 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %5, %7, %9 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+        "v_pk_add_f32 %2, %2, %3 neg_lo:[0,1] neg_hi:[0,0]\n\t"
+        "v_pk_add_f32 %4, %4, %5 neg_lo:[0,1] neg_hi:[0,0]\n\t"
+        "v_pk_add_f32 %0, %0, %2\n\t"
+        "v_pk_add_f32 %1, %1, %4"
+        : "+v"(accA), "+v"(accB), "=&v"(t1a), "=&v"(t2a), "=&v"(t1b), "=&v"(t2b)
+        : "v"(xA), "v"(xB), "s"(hA), "s"(hB));
+}
+// the MACs of one tap block in issue order: phase 1 (older row): tj = 7..1, r = 0..tj-1 (28); phase 2 (newer row): tj = 7..0, r = tj..7 (36)
+struct FirMac { int r, tj, u; };
+__host__ __device__ constexpr FirMac fir_mac1(int idx) {       // idx in [0, 28): sample = old[u]
+    int tj = 7;
+    while (idx >= tj) { idx -= tj; --tj; }
+    return FirMac{idx, tj, idx + 8 - tj};
+}
+__host__ __device__ constexpr FirMac fir_mac2(int idx) {       // idx in [0, 36): sample = nw[u]
+    int tj = 7;
+    while (idx >= 8 - tj) { idx -= 8 - tj; --tj; }
+    return FirMac{tj + idx, tj, idx};
+}
+__device__ __forceinline__ void fir_load_row(fir_v2f (&w)[8], const float2 *row) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { const float2 v = row[c]; w[c] = fir_v2f{v.x, v.y}; }
+}
+// (the indices must be compile-time constants: a register array indexed at run time goes through s_set_gpr_idx / scratch)
+template <int I>
+__device__ __forceinline__ void fir_pair1(fir_v2f (&acc)[8], const fir_v2f (&old)[8], const fir_v2f (&h)[8]) {
+    constexpr FirMac a = fir_mac1(I), b = fir_mac1(I + 1);
+    fir_cmac2s(acc[a.r], acc[b.r], old[a.u], old[b.u], h[a.tj], h[b.tj]);
+}
+template <int I>
+__device__ __forceinline__ void fir_pair2(fir_v2f (&acc)[8], const fir_v2f (&nw)[8], const fir_v2f (&h)[8]) {
+    constexpr FirMac a = fir_mac2(I), b = fir_mac2(I + 1);
+    fir_cmac2s(acc[a.r], acc[b.r], nw[a.u], nw[b.u], h[a.tj], h[b.tj]);
+}
+template <int... P>
+__device__ __forceinline__ void fir_phase1(fir_v2f (&acc)[8], const fir_v2f (&old)[8], const fir_v2f (&h)[8], std::integer_sequence<int, P...>) {
+    (fir_pair1<2 * P>(acc, old, h), ...);
+}
+template <int... P>
+__device__ __forceinline__ void fir_phase2(fir_v2f (&acc)[8], const fir_v2f (&nw)[8], const fir_v2f (&h)[8], std::integer_sequence<int, P...>) {
+    (fir_pair2<2 * P>(acc, nw, h), ...);
+}
+// one block of 8 taps: acc[r] += sum over tj = 7..0 of W(r, tj) * h[tj]; `old` is reloaded with *next_row between the phases
+__device__ __forceinline__ void fir_block(fir_v2f (&acc)[8], fir_v2f (&old)[8], const fir_v2f (&nw)[8], const float2 *taps8, const float2 *next_row) {
+    // uniform address in the constant address space: scalar loads (a plain global load after a barrier is never scalarised)
+    typedef const __attribute__((address_space(4))) float *fir_cptr;
+    const fir_cptr tc = (fir_cptr)(uintptr_t)taps8;
+    fir_v2f h[8];
+#pragma unroll
+    for (int tj = 0; tj < 8; ++tj) h[tj] = fir_v2f{tc[2 * tj], tc[2 * tj + 1]};
+    fir_phase1(acc, old, h, std::make_integer_sequence<int, 14>{});
+    if (next_row) fir_load_row(old, next_row);
+    fir_phase2(acc, nw, h, std::make_integer_sequence<int, 18>{});
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kFirBlock) void k_fir_fast(const FirArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ uint32_t s_maxbits;
+    __shared__ double s_st[kFirBlock / 64][4];
+    constexpr int R = kFirR;
+    float2 *s_x = (float2 *)s_raw;                          // rows of 9: s_x[fir_pad(u)] = x[base - hist + u], hist a multiple of 8
+    const int t = threadIdx.x;
+    const int64_t tile = a.tile0 + blockIdx.x;
+    const int64_t base = tile * (int64_t)kFirTile;
+    const int jb_top = ((a.m - 1) / R) * R, hist = jb_top + R;
+    if (t == 0) s_maxbits = 0;
+    __syncthreads();
+    uint32_t mb = 0;
+    for (int j = t; j < a.m; j += kFirBlock) {
+        const float2 h = a.taps[j];
+        mb = max(mb, max(__float_as_uint(h.x) & 0x7fffffffu, __float_as_uint(h.y) & 0x7fffffffu));
+    }
+    const int total = hist + kFirTile;
+    for (int u = t; u < total; u += kFirBlock) {
+        const int64_t i = base - hist + u;
+        float2 v = make_float2(0.f, 0.f);
+        if (i >= 0) { if (i < a.n) v = a.x[i]; }
+        else if (a.halo != nullptr && i + (a.m - 1) >= 0) v = a.halo[i + (a.m - 1)];     // no halo: zero history (see above)
+        s_x[fir_pad(u)] = v;
+        mb = max(mb, max(__float_as_uint(v.x) & 0x7fffffffu, __float_as_uint(v.y) & 0x7fffffffu));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, o));
+    if ((t & 63) == 0) atomicMax(&s_maxbits, mb);
+    __syncthreads();
+    if (s_maxbits >= kFirSafeBits) {                        // workgroup-uniform: k_fir's checked arithmetic does this tile
+        if (t == 0) a.redo[1 + atomicAdd(&a.redo[0], 1)] = (int)tile;
+        return;
+    }
+    const int64_t k0 = base + (int64_t)R * t;               // my first output
+    fir_v2f acc[R], wa[R], wb[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = fir_v2f{0.f, 0.f};
+    // row of x[k0 - j .. k0 - j + 7] (j a multiple of 8): t + (hist - j) / 8
+    const float2 *row0 = s_x + (t + hist / R) * (R + 1);
+    fir_load_row(wa, row0 - (jb_top / R + 1) * (R + 1));    // the row before the top block's (its samples 1..7 are the window's head)
+    fir_load_row(wb, row0 - (jb_top / R) * (R + 1));
+    int jb = jb_top;
+    for (; jb >= R; jb -= 2 * R) {                          // two blocks per trip: (old, new) = (wa, wb), then (wb, wa)
+        fir_block(acc, wa, wb, a.taps_pad + jb, row0 - (jb / R - 1) * (R + 1));
+        fir_block(acc, wb, wa, a.taps_pad + jb - R, (jb >= 2 * R) ? row0 - (jb / R - 2) * (R + 1) : nullptr);
+    }
+    if (jb == 0) fir_block(acc, wa, wb, a.taps_pad, nullptr);
+    if (k0 + R <= a.n) {
+#pragma unroll
+        for (int r = 0; r < R; r += 2) *(float4 *)(a.out + k0 + r) = make_float4(acc[r].x, acc[r].y, acc[r + 1].x, acc[r + 1].y);
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) if (k0 + r < a.n) a.out[k0 + r] = make_float2(acc[r].x, acc[r].y);
+    }
+    if (STATS) {
+        const int64_t rem = a.n - a.n_chunks * a.chunk;                  // outputs before `rem` belong to no chunk
+        const int64_t i0 = (base > rem) ? base : rem;                    // first output of the tile that counts
+        const int64_t kfirst = (i0 < a.n) ? (a.n - 1 - i0) / a.chunk : 0;
+        const int64_t split = a.n - kfirst * a.chunk;                    // outputs at or beyond it are in chunk kfirst - 1
+        double sum0 = 0.0, sum1 = 0.0, mx0 = 0.0, mx1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int64_t i = k0 + r;
+            if (i >= rem && i < a.n) {
+                const double mg = (double)__builtin_sqrtf(acc[r].x * acc[r].x + acc[r].y * acc[r].y);
+                if (i < split) { sum0 += mg; mx0 = fir_nanmax(mx0, mg); } else { sum1 += mg; mx1 = fir_nanmax(mx1, mg); }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sum0 += __shfl_down(sum0, o); sum1 += __shfl_down(sum1, o);
+            mx0 = fir_nanmax(mx0, __shfl_down(mx0, o)); mx1 = fir_nanmax(mx1, __shfl_down(mx1, o));
+        }
+        if ((t & 63) == 0) { s_st[t >> 6][0] = sum0; s_st[t >> 6][1] = mx0; s_st[t >> 6][2] = sum1; s_st[t >> 6][3] = mx1; }
+        __syncthreads();
+        if (t == 0) {
+            double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+            for (int w = 0; w < kFirBlock / 64; ++w) { o0 += s_st[w][0]; o1 = fir_nanmax(o1, s_st[w][1]); o2 += s_st[w][2]; o3 = fir_nanmax(o3, s_st[w][3]); }
+            double *dst = a.tile_stats + 4 * tile;
+            dst[0] = o0; dst[1] = o1; dst[2] = o2; dst[3] = o3;
+        }
+    }
+}
+__global__ void k_fir_prepare(const float2 *taps, int m, int m_pad, float2 *taps_pad, int *redo) {
+    for (int j = threadIdx.x; j < m_pad; j += blockDim.x) taps_pad[j] = (j < m) ? taps[j] : make_float2(0.f, 0.f);
+    if (threadIdx.x == 0) redo[0] = 0;
 }
 
 // chunk k = outputs [lo, hi): the tiles that meet it, added in tile order by one wavefront (lane-strided, then a fixed tree)
@@ -239,10 +422,18 @@ __global__ __launch_bounds__(64) void k_fir_stats_finish(const double *tile_stat
 }
 
 size_t fir_stats_scratch_bytes(int64_t n) { return (size_t)((n + kFirTile - 1) / kFirTile + 1) * 4 * sizeof(double); }
+// work area of launch_fir: the zero-padded taps and the list of tiles handed from k_fir_fast to k_fir
+size_t fir_work_bytes(int64_t n, int m) { return (size_t)(m + 2 * kFirR) * sizeof(float2) + (size_t)((n + kFirTile - 1) / kFirTile + 2) * sizeof(int) + 256; }
+
+template <class K>
+static int fir_lds_attr(K kern, size_t lds) {
+    if (lds <= 64 * 1024) return URHGPU_OK;
+    return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess ? URHGPU_OK : URHGPU_ERR_HIP;
+}
 
 // stats: chunk > 0 asks for the magnitude chunk statistics of the output (chunk >= kFirTile, n_chunks * chunk <= n), written to
-// d_sum / d_max[n_chunks]; tile_scratch: fir_stats_scratch_bytes(n)
-int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const float2 *halo, float2 *out, hipStream_t s, int64_t chunk,
+// d_sum / d_max[n_chunks]; tile_scratch: fir_stats_scratch_bytes(n); work: fir_work_bytes(n, m) (nullptr: every tile through k_fir)
+int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const float2 *halo, float2 *out, hipStream_t s, void *work, int64_t chunk,
                int64_t n_chunks, double *d_sum, double *d_max, void *tile_scratch) {
     if (n <= 0) return URHGPU_OK;
     const bool stats = chunk > 0 && n_chunks > 0;
@@ -252,28 +443,45 @@ int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const floa
     FirArgs a;
     a.x = x; a.halo = halo; a.taps = taps; a.out = out; a.n = n; a.m = m;
     a.chunk = stats ? chunk : 0; a.n_chunks = stats ? n_chunks : 0; a.tile_stats = (double *)tile_scratch;
+    a.taps_pad = nullptr; a.redo = nullptr; a.tile_list = nullptr;
     a.hist = ((m - 1) / kFirR) * kFirR + kFirR - 1;
     const size_t lds = (size_t)(((m + 1) & ~1) + (a.hist + kFirTile) + ((a.hist + kFirTile) >> 3) + 1) * 8;
     if (lds > 150 * 1024) return URHGPU_ERR_UNSUPPORTED;       // m <= ~8900 taps
-    if (lds > 64 * 1024) {
-        if (hipFuncSetAttribute((const void *)k_fir<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)k_fir<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)k_fir<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void *)k_fir<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return URHGPU_ERR_HIP;
-    }
+    URH_TRY(fir_lds_attr(k_fir<true, false>, lds)); URH_TRY(fir_lds_attr(k_fir<false, false>, lds));
+    URH_TRY(fir_lds_attr(k_fir<true, true>, lds)); URH_TRY(fir_lds_attr(k_fir<false, true>, lds));
     const int64_t tiles = (n + kFirTile - 1) / kFirTile;
-    // tiles that contain outputs k < m - 1 need the i >= 0 test unless a halo supplies the history
-    int64_t head_tiles = (halo == nullptr) ? std::min<int64_t>(tiles, ((int64_t)m - 1 + kFirTile - 1) / kFirTile) : 0;
-    if (head_tiles > 0) {
-        a.tile0 = 0;
-        if (stats) hipLaunchKernelGGL((k_fir<true, true>), dim3((unsigned)head_tiles), dim3(kFirBlock), lds, s, a);
-        else hipLaunchKernelGGL((k_fir<true, false>), dim3((unsigned)head_tiles), dim3(kFirBlock), lds, s, a);
-    }
-    if (tiles > head_tiles) {
-        a.tile0 = head_tiles;
-        if (stats) hipLaunchKernelGGL((k_fir<false, true>), dim3((unsigned)(tiles - head_tiles)), dim3(kFirBlock), lds, s, a);
-        else hipLaunchKernelGGL((k_fir<false, false>), dim3((unsigned)(tiles - head_tiles)), dim3(kFirBlock), lds, s, a);
+    if (tiles >= INT32_MAX) return URHGPU_ERR_UNSUPPORTED;
+    if (work != nullptr) {
+        // k_fir_fast everywhere, then k_fir for the tiles it handed back (with the i >= 0 test when there is no halo)
+        const int m_pad = ((m - 1) / kFirR) * kFirR + kFirR, hist8 = m_pad;
+        const size_t lds_fast = (size_t)((hist8 + kFirTile) / kFirR) * (kFirR + 1) * 8;
+        URH_TRY(fir_lds_attr(k_fir_fast<false>, lds_fast)); URH_TRY(fir_lds_attr(k_fir_fast<true>, lds_fast));
+        float2 *taps_pad = (float2 *)work;
+        int *redo = (int *)((char *)work + (((size_t)(m + 2 * kFirR) * sizeof(float2) + 255) & ~size_t(255)));
+        hipLaunchKernelGGL(k_fir_prepare, dim3(1), dim3(256), 0, s, taps, m, m_pad, taps_pad, redo);
+        a.tile0 = 0; a.taps_pad = taps_pad; a.redo = redo;
+        if (stats) hipLaunchKernelGGL((k_fir_fast<true>), dim3((unsigned)tiles), dim3(kFirBlock), lds_fast, s, a);
+        else hipLaunchKernelGGL((k_fir_fast<false>), dim3((unsigned)tiles), dim3(kFirBlock), lds_fast, s, a);
+        a.tile_list = redo;
+        const unsigned gr = (unsigned)std::min<int64_t>(tiles, 1024);       // grid-stride over the list (normally empty)
+        const bool head = halo == nullptr;
+        if (head && stats) hipLaunchKernelGGL((k_fir<true, true>), dim3(gr), dim3(kFirBlock), lds, s, a);
+        else if (head) hipLaunchKernelGGL((k_fir<true, false>), dim3(gr), dim3(kFirBlock), lds, s, a);
+        else if (stats) hipLaunchKernelGGL((k_fir<false, true>), dim3(gr), dim3(kFirBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_fir<false, false>), dim3(gr), dim3(kFirBlock), lds, s, a);
+    } else {
+        // tiles that contain outputs k < m - 1 need the i >= 0 test unless a halo supplies the history
+        const int64_t head_tiles = (halo == nullptr) ? std::min<int64_t>(tiles, ((int64_t)m - 1 + kFirTile - 1) / kFirTile) : 0;
+        if (head_tiles > 0) {
+            a.tile0 = 0;
+            if (stats) hipLaunchKernelGGL((k_fir<true, true>), dim3((unsigned)head_tiles), dim3(kFirBlock), lds, s, a);
+            else hipLaunchKernelGGL((k_fir<true, false>), dim3((unsigned)head_tiles), dim3(kFirBlock), lds, s, a);
+        }
+        if (tiles > head_tiles) {
+            a.tile0 = head_tiles;
+            if (stats) hipLaunchKernelGGL((k_fir<false, true>), dim3((unsigned)(tiles - head_tiles)), dim3(kFirBlock), lds, s, a);
+            else hipLaunchKernelGGL((k_fir<false, false>), dim3((unsigned)(tiles - head_tiles)), dim3(kFirBlock), lds, s, a);
+        }
     }
     if (stats) hipLaunchKernelGGL(k_fir_stats_finish, dim3((unsigned)n_chunks), dim3(64), 0, s, (const double *)tile_scratch, n, chunk, n_chunks, d_sum, d_max);
     return URHGPU_OK;

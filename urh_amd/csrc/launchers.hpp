@@ -222,8 +222,9 @@ void launch_bits_extra(const int64_t *d_all, int rank, int world, int32_t *d_ext
 
 // ---- filters.hip ---------------------------------------------------------------------------------------
 size_t fir_stats_scratch_bytes(int64_t n);
-int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const float2 *halo, float2 *out, hipStream_t s, int64_t chunk = 0,
-               int64_t n_chunks = 0, double *d_sum = nullptr, double *d_max = nullptr, void *tile_scratch = nullptr);
+size_t fir_work_bytes(int64_t n, int m);
+int launch_fir(const float2 *x, int64_t n, const float2 *taps, int m, const float2 *halo, float2 *out, hipStream_t s, void *work = nullptr,
+               int64_t chunk = 0, int64_t n_chunks = 0, double *d_sum = nullptr, double *d_max = nullptr, void *tile_scratch = nullptr);
 int launch_iir(const double *a, int64_t M, const double *b, int64_t N, const float2 *x, int64_t n, float2 *y, hipStream_t s);
 int launch_magnitudes(const void *iq, int dtype, int64_t n, double *out, hipStream_t s);
 size_t mag_chunk_scratch_bytes(int64_t n_chunks);
