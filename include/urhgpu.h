@@ -349,6 +349,9 @@ int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs,
 /* Test hook: the hot kernel's fast-path division (Newton + residual chain without scaling) against the IEEE
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);
+/* Test hook: the branch-free sinf / cosf pair of the Costas loop (glibc_sincosf.h: urh_sincosf_fast) against the branchy restatement
+ * of glibc's sinf and cosf for EVERY float with |y| < 120; *n_mismatch = arguments where either result differs in a bit. */
+int urhgpu_test_sincosf_fast_dev(urhgpu_ctx *ctx, uint64_t *n_mismatch);
 
 /* signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK / OQPSK (URHGPU_MOD_OQPSK: bits_per_symbol must be 2; GFSK: urhgpu_modulate_gfsk*),
  * n_msgs messages rendered back to back by one launch (URH modulates message by message, Modulator.py:215-255):

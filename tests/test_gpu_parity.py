@@ -863,6 +863,16 @@ def test_batched_centers_dense_messages_and_tied_peaks(pipe, oracle):
     assert flag.tolist() == [1, 1, 1, 3, 0, 1] and stats[0, 0] == 100_000 and stats[2, 0] == 99_999 - 100
 
 
+def test_branch_free_sincosf_equals_branchy_for_every_float_below_120(pipe):
+    """glibc_sincosf.h: urh_sincosf_fast (what the Costas loop evaluates per sample) against urh_sinf / urh_cosf -- which
+    tests/test_sincosf_port.py pins to the host libm -- on all 2.25e9 floats with |y| < 120"""
+    import ctypes as C
+    from urh_amd import _lib
+    bad = C.c_uint64(123)
+    _lib.check(_lib.load().urhgpu_test_sincosf_fast_dev(pipe.ctx.handle, C.byref(bad)))
+    assert bad.value == 0
+
+
 def test_detect_modulation_on_device(pipe):
     """urhgpu_detect_modulation_dev against detect_modulation in numpy (and the real reference's, where staged): same label for every
     message, variances within 1e-4 relative (double-precision radix-2 FFTs here, numpy's single-precision forward transforms there):
@@ -1161,6 +1171,25 @@ def test_costas_parallel_chain_large(sf, oracle, order):
     assert sum(stats[:3]) == (n - 1 + 4095) // 4096 - 1
     # the 300k-sample gated pause is 73 chunks that no candidate can match; everything else should
     assert stats[0] > 0.85 * sum(stats[:3]), stats
+
+
+@pytest.mark.parametrize("bandwidth", [0.05, 0.1, 0.25])
+def test_costas_warm_up_follows_loop_bandwidth(sf, oracle, bandwidth):
+    """the candidates' warm-up length is derived from the loop bandwidth (512 samples at the default 0.1): still bit-exact, and on a
+    noisy capture (SNR 10 dB) with a carrier offset practically every chunk is carried by a candidate"""
+    from urh_amd import _lib
+    for order, offset in ((4, 0.013), (2, -0.006)):
+        rng = np.random.default_rng(int(bandwidth * 1000) + order)
+        n, sps = 1 << 20, 64
+        sym = rng.integers(0, order, n // sps + 1)
+        phases = (np.array([-135, -45, 45, 135]) if order == 4 else np.array([-90, 90]))[sym] * np.pi / 180
+        ph = np.repeat(phases, sps)[:n] + 2 * np.pi * offset * np.arange(n)
+        iq = (np.stack([np.cos(ph), np.sin(ph)], 1) + 0.316 * np.sqrt(0.5) * rng.standard_normal((n, 2))).astype(np.float32)
+        want = oracle.afp_demod(iq, 0.05, "PSK", order, bandwidth)
+        got = sf.afp_demod(iq, 0.05, "PSK", order, bandwidth)
+        assert bits_equal(got[1:], want[1:]), (order, int((got[1:] != want[1:]).sum()))
+        stats = _lib.default_context().costas_stats()
+        assert stats[0] >= 0.97 * sum(stats[:3]), (bandwidth, order, stats)
 
 
 def test_fir_with_fused_noise_statistics(pipe, oracle):

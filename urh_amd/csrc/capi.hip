@@ -975,6 +975,18 @@ int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint
     return URHGPU_OK;
 }
 
+int urhgpu_test_sincosf_fast_dev(urhgpu_ctx *ctx, uint64_t *n_mismatch) {
+    if (!ctx || !n_mismatch) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_HIP(hipMemsetAsync(ctx->d_counts, 0, 8, ctx->stream));
+    launch_test_sincosf_fast((unsigned long long *)ctx->d_counts, ctx->stream);
+    URH_HIP(hipGetLastError());
+    URH_HIP(hipMemcpyAsync(ctx->h_counts, ctx->d_counts, 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    *n_mismatch = (uint64_t)ctx->h_counts[0];
+    return URHGPU_OK;
+}
+
 static int stage_in(urhgpu_ctx *ctx, const void *host, size_t bytes, void **dev);
 
 // mod: URHGPU_MOD_ASK / _FSK / _PSK / _OQPSK, or urh::kModGfsk with the Gaussian taps (and optionally the caller's filtered

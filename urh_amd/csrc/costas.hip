@@ -11,7 +11,7 @@
 //     some hundred un-gated samples two trajectories that lock onto the same phase ambiguity become bit-identical
 //     (measured on the reference).  The lock points are pi/2 (order 4) or pi (order 2) apart, each with a
 //     twin 2*pi away inside the +-2*pi wrap range.
-//   * k_costas_spec runs, for every chunk, one candidate per lock point: it starts kWarm un-gated samples before the
+//   * k_costas_spec runs, for every chunk, one candidate per lock point: it starts `warm` un-gated samples before the
 //     chunk from phase 1.5 + k * (pi/2 | pi), freq 0, and records the candidate's state at the chunk start (S), at
 //     checkpoints inside the chunk (CP) and at its end (E).  Chunk 0's candidate 0 IS the true trajectory.
 //   * k_costas_map: for every chunk c and candidate k of chunk c-1, which candidate of chunk c starts (bitwise) in
@@ -21,7 +21,7 @@
 //     candidate's checkpoint.  Either way the TRUE state at every chunk start comes out.
 //   * k_costas_final re-evaluates every chunk from its true start state, in parallel, and writes the output.
 // The result is exact by construction (equality is tested on the state bits, never assumed); only the speed depends on
-// how quickly candidates converge.  Work: (K (kWarm + kChunk) + kChunk) steps per chunk instead of kChunk.
+// how quickly candidates converge.  Work: (K warm + D kChunk + kChunk) steps per chunk instead of kChunk (D <= K distinct candidates).
 // Loop orders other than 2 and 4 leave the output unwritten in the reference; they use the serial kernel.
 //
 // Bound: dependent-instruction latency, hidden by running one chunk-candidate per lane over the whole machine.
@@ -42,6 +42,7 @@ struct CostasArgs {
     const void *iq; int64_t n; float *out;
     float noise_sqrd, alpha, beta, scale, shift;
     int loop_order;
+    int warm;                // un-gated samples a candidate runs before its chunk (from the loop bandwidth, see launch_costas)
 };
 struct CostasState { float freq, phase; };
 
@@ -69,7 +70,9 @@ __device__ __forceinline__ float costas_step(float2 sm, CostasState &st, float &
     const double two_pi = 2 * 3.14159265358979323846;
     const float real_float = UNIT ? sm.x + 0.0f : (sm.x + a.shift) / a.scale, imag_float = UNIT ? sm.y + 0.0f : (sm.y + a.shift) / a.scale;
     const float2 cur = make_float2(real_float + 0.0f * imag_float, 1.0f * imag_float);   // re + imag_unit * im
-    const float sn = urh_sinf(-st.phase), cs = urh_cosf(-st.phase);
+    float sn, cs;
+    if (urh_sc_abstop12(st.phase) < 0x42f) urh_sincosf_fast(-st.phase, &sn, &cs);        // |phase| < 120: always (the loop keeps it within +-2 pi)
+    else { sn = urh_sinf(-st.phase); cs = urh_cosf(-st.phase); }
     const float2 nco = make_float2(cs + 0.0f * sn, 1.0f * sn);
     const float2 z = cmul(nco, cur);
     if (a.loop_order == 2) {
@@ -127,8 +130,7 @@ __global__ __launch_bounds__(64) void k_costas(const CostasArgs a) {
 
 // ---- speculative parallel evaluation ----------------------------------------------------------------------------------
 constexpr int kChunk = 4096;        // samples per chunk
-constexpr int kWarm = 1024;         // un-gated samples a candidate runs before its chunk
-constexpr int kWarmBack = 16384;    // ... looking back at most this many samples for them
+constexpr int kWarmBackFactor = 16; // a candidate looks back at most 16 x its warm-up length for un-gated samples
 constexpr int kCkpt = 256;          // checkpoint spacing inside a chunk
 constexpr int kNumCkpt = kChunk / kCkpt;   // checkpoints at offsets kCkpt, 2 kCkpt, ... < kChunk  (index j = off / kCkpt - 1)
 constexpr int kMaxCand = 8;
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
         st = CostasState{0.0f, 1.5f};                       // every candidate of chunk 0 is the true trajectory
     } else {
         int ungated = 0;
-        while (p > 1 && ungated < kWarm && s0 - p < kWarmBack) {
+        while (p > 1 && ungated < a.warm && s0 - p < (int64_t)kWarmBackFactor * a.warm) {
             --p;
             if (!costas_gated(CostasLoad<DT>::at(a.iq, p), a)) ++ungated;
         }
@@ -530,6 +532,16 @@ int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_par
         case URHGPU_DT_F32: a.scale = 1.0f; a.shift = 0.0f; break;
         default: return URHGPU_ERR_DTYPE;
     }
+    // Warm-up: two trajectories in the same lock class contract by about (1 - alpha) per sample once the seeded frequency is close;
+    // from a phase error of order 1 down to the last float bit takes ~ 18 / alpha samples (130 at the default bandwidth 0.1), the
+    // pull-in before that a few loop time constants: 40 / bandwidth samples, rounded up to a power of two, covers both with margin
+    // (512 at 0.1; it was a fixed 1024).  Too short a warm-up only costs time: unmatched chunks are re-speculated / run serially.
+    {
+        const double want = 40.0 / std::max(1e-3, std::min(1.0, (double)fabsf(bandwidth)));
+        int w = 256;
+        while (w < want && w < 8192) w *= 2;
+        a.warm = w;
+    }
     int order = p->mod_order > 0 ? p->mod_order : (1 << p->bits_per_symbol);
     if (order > 4) order = 4;                                  // :285-287
     a.loop_order = order;
@@ -540,6 +552,22 @@ int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_par
         case URHGPU_DT_U16: return launch_costas_dt<URHGPU_DT_U16>(a, scratch, ctx);
         default: return launch_costas_dt<URHGPU_DT_F32>(a, scratch, ctx);
     }
+}
+
+// every float with |y| < 120 (bit patterns 0 .. 0x42f00000, both signs): urh_sincosf_fast against urh_sinf / urh_cosf
+__global__ __launch_bounds__(256) void k_test_sincosf_fast(unsigned long long *mismatches) {
+    unsigned long long bad = 0;
+    for (uint64_t u = blockIdx.x * 256ull + threadIdx.x; u < 2ull * 0x42f00000ull; u += (uint64_t)gridDim.x * 256ull) {
+        const uint32_t bits = (u < 0x42f00000ull) ? (uint32_t)u : ((uint32_t)(u - 0x42f00000ull) | 0x80000000u);
+        const float y = __uint_as_float(bits);
+        float sn, cs;
+        urh_sincosf_fast(y, &sn, &cs);
+        if (__float_as_uint(sn) != __float_as_uint(urh_sinf(y)) || __float_as_uint(cs) != __float_as_uint(urh_cosf(y))) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+void launch_test_sincosf_fast(unsigned long long *d_mismatches, hipStream_t s) {
+    hipLaunchKernelGGL(k_test_sincosf_fast, dim3(256 * 32), dim3(256), 0, s, d_mismatches);
 }
 
 }  // namespace urh

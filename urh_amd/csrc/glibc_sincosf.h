@@ -150,3 +150,38 @@ URH_SC_HD float urh_cosf(float y) {
     }
     return urh_sincosf_invalid();
 }
+
+// sinf(y) and cosf(y) together, without branches, for |y| < 120 -- bit for bit what urh_sinf / urh_cosf return:
+//   * |y| < 0.75 (their first branch) is the fast reduction with quadrant 0: r = y * (2/pi) 2^24 stays below 2^23 in magnitude, so
+//     n = 0 and y - 0 * (pi/2) = y exactly; the sign is +1: the same polynomial on the same argument;
+//   * |y| < 2^-12, where they return y and 1.0f without evaluating anything: the sine polynomial is y (1 - y^2/6 + ...) with
+//     y^2/6 < 2^-26.5 -- less than half an ulp even just below a power of two -- and rounds to y; the cosine polynomial is
+//     1 - y^2/2 + ... > 1 - 2^-25, closer to 1 than to the float below it; y = -0 is returned as it is.  (tests/test_gpu_parity.py
+//     compares EVERY float below 120.)
+//   * both results are the sine polynomial A of (x s) and the cosine polynomial B (negated in quadrants 2, 3 -- negating every
+//     coefficient negates the result exactly): sin = n even ? A : B, cos = n even ? B : A.
+// The Costas loop evaluates the pair once per sample and lane; with the branches every wavefront walked through all four of them.
+URH_SC_HD void urh_sincosf_fast(float y, float *sn, float *cs) {
+    const double s1c = -0x1.555545995a603p-3, s2c = 0x1.1107605230bc4p-7, s3c = -0x1.994eb3774cf24p-13;
+    const double c0 = 0x1p0, c1c = -0x1.ffffffd0c621cp-2, c2c = 0x1.55553e1068f19p-5, c3c = -0x1.6c087e89a359dp-10, c4c = 0x1.99343027bf8c3p-16;
+    int n;
+    const double xr = urh_sc_reduce_fast((double)y, &n);
+    const double sg = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
+    const double x = xr * sg, x2 = xr * xr;
+    // sine polynomial (urh_sinf_poly, n even)
+    const double x3 = x * x2;
+    const double s1 = urh_sc_madd(s2c, x2, s3c);
+    const double x7 = x3 * x2;
+    const double sp = urh_sc_madd(x, x3, s1c);
+    const float A = (float)urh_sc_madd(sp, x7, s1);
+    // cosine polynomial (n odd), entry 1 of the table = every coefficient negated
+    const double x4 = x2 * x2;
+    const double c2 = urh_sc_madd(c3c, x2, c4c);
+    const double c1 = urh_sc_madd(c0, x2, c1c);
+    const double x6 = x4 * x2;
+    const double cc = urh_sc_madd(c1, x4, c2c);
+    const float B0 = (float)urh_sc_madd(cc, x6, c2);
+    const float B = (n & 2) ? -B0 : B0;
+    *sn = (y == 0.0f) ? y : ((n & 1) ? B : A);             // sinf(-0) = -0 (the polynomial's x + x^3 c turns it into +0)
+    *cs = (n & 1) ? A : B;
+}

@@ -43,6 +43,7 @@ int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, h
 int launch_runs_qad(const RunArgs &a, hipStream_t s);
 int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t s);
 void launch_test_div(uint64_t seed, int reps, unsigned long long *d_mismatches, hipStream_t s);
+void launch_test_sincosf_fast(unsigned long long *d_mismatches, hipStream_t s);
 void launch_test_atan2f(const float *y, const float *x, int64_t n, float *out, hipStream_t s);
 
 // ---- modulate.hip ------------------------------------------------------------------------------------
