@@ -46,10 +46,10 @@ struct CostasArgs {
 };
 struct CostasState { float freq, phase; };
 
-__device__ __forceinline__ float costas_clamp(float x) {      // :246-250
-    if (x < -1.0f) x = -1.0f;
-    else if (x > 1.0f) x = 1.0f;
-    return x;
+__device__ __forceinline__ float costas_clamp(float x) {      // :246-250 (NaN passes through: both comparisons are false)
+    float r = (x > 1.0f) ? 1.0f : x;
+    r = (x < -1.0f) ? -1.0f : r;
+    return r;
 }
 
 template <int DT> struct CostasLoad;
@@ -64,8 +64,11 @@ __device__ __forceinline__ bool costas_gated(float2 sm, const CostasArgs &a) { r
 // One sample of the loop (:291-328): returns the output, updates the state.  err is only carried for loop orders
 // other than 2 / 4 (where it never changes); callers keep it.
 // UNIT: float32 captures (shift 0, scale 1): (x + 0.0f) / 1.0f == x + 0.0f for every x, the two IEEE divisions are dropped.
-template <bool UNIT = false>
+// ORDER: 2 / 4 = the loop order as a compile-time constant (the speculative kernels: five wave-uniform branches less per step);
+// 0 = read a.loop_order.
+template <bool UNIT = false, int ORDER = 0>
 __device__ __forceinline__ float costas_step(float2 sm, CostasState &st, float &err, const CostasArgs &a) {
+    const int loop_order = ORDER ? ORDER : a.loop_order;
     if (costas_gated(sm, a)) return -4.0f;                              // NOISE_FSK_PSK, state frozen (:293-295)
     const double two_pi = 2 * 3.14159265358979323846;
     const float real_float = UNIT ? sm.x + 0.0f : (sm.x + a.shift) / a.scale, imag_float = UNIT ? sm.y + 0.0f : (sm.y + a.shift) / a.scale;
@@ -75,9 +78,9 @@ __device__ __forceinline__ float costas_step(float2 sm, CostasState &st, float &
     else { sn = urh_sinf(-st.phase); cs = urh_cosf(-st.phase); }
     const float2 nco = make_float2(cs + 0.0f * sn, 1.0f * sn);
     const float2 z = cmul(nco, cur);
-    if (a.loop_order == 2) {
+    if (loop_order == 2) {
         err = z.y * z.x;
-    } else if (a.loop_order == 4) {
+    } else if (loop_order == 4) {
         const float f1 = z.x > 0.0f ? 1.0f : -1.0f, f2 = z.y > 0.0f ? 1.0f : -1.0f;
         err = f1 * z.y - f2 * z.x;
     }
@@ -87,8 +90,8 @@ __device__ __forceinline__ float costas_step(float2 sm, CostasState &st, float &
     while ((double)st.phase > two_pi) st.phase = (float)((double)st.phase - two_pi);     // double compare / subtract (:318-321)
     while ((double)st.phase < -two_pi) st.phase = (float)((double)st.phase + two_pi);
     st.freq = costas_clamp(st.freq);
-    if (a.loop_order == 2) return z.x;
-    if (a.loop_order == 4) return (float)(2.0 * (double)z.x + (double)z.y);
+    if (loop_order == 2) return z.x;
+    if (loop_order == 4) return (float)(2.0 * (double)z.x + (double)z.y);
     return 0.0f;
 }
 
@@ -158,7 +161,7 @@ __device__ __forceinline__ int64_t chunk_begin(int64_t c) { return 1 + c * (int6
 
 // Candidates of the chunks c >= c_from.  use_seed: all candidates start with freq = seed_freq (the true loop's own
 // frequency where the chain last broke) instead of the estimate from the data.
-template <int DT>
+template <int DT, int ORDER>
 __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K, int64_t c_from,
                                                       int use_seed, float seed_freq) {
     const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
@@ -176,9 +179,19 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
         st = CostasState{0.0f, 1.5f};                       // every candidate of chunk 0 is the true trajectory
     } else {
         int ungated = 0;
-        while (p > 1 && ungated < a.warm && s0 - p < (int64_t)kWarmBackFactor * a.warm) {
-            --p;
-            if (!costas_gated(CostasLoad<DT>::at(a.iq, p), a)) ++ungated;
+        const int64_t back = (int64_t)kWarmBackFactor * a.warm;
+        // walk back until `warm` un-gated samples lie between p and the chunk -- eight samples per round trip to memory
+        while (p > 1 && ungated < a.warm && s0 - p < back) {
+            float2 g[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[j] = CostasLoad<DT>::at(a.iq, (p - 1 - j >= 1) ? p - 1 - j : 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (p > 1 && ungated < a.warm && s0 - p < back) {
+                    --p;
+                    if (!costas_gated(g[j], a)) ++ungated;
+                }
+            }
         }
         if (p == 1) {
             st = CostasState{0.0f, 1.5f};                   // reached the start of the capture: exact, not a guess
@@ -193,22 +206,44 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
             float2 prev = CostasLoad<DT>::at(a.iq, p);
             bool prev_ok = !costas_gated(prev, a);
             const int64_t wend = (p + 512 < s0) ? p + 512 : s0;
-            for (int64_t i = p + 1; i < wend; ++i) {
-                const float2 cur = CostasLoad<DT>::at(a.iq, i);
-                const bool ok = !costas_gated(cur, a);
-                if (ok && prev_ok) {
-                    const float cr = (cur.x + a.shift) / a.scale, ci = (cur.y + a.shift) / a.scale;
-                    const float pr = (prev.x + a.shift) / a.scale, pi = (prev.y + a.shift) / a.scale;
-                    float dx = cr * pr + ci * pi, dy = ci * pr - cr * pi;          // cur * conj(prev)
-                    float tx = dx * dx - dy * dy, ty = 2.0f * dx * dy;             // ^2
-                    if (a.loop_order == 4) { const float ux = tx * tx - ty * ty, uy = 2.0f * tx * ty; tx = ux; ty = uy; }
-                    ax += tx; ay += ty;
+            for (int64_t i0 = p + 1; i0 < wend; i0 += 8) {
+                float2 g[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = CostasLoad<DT>::at(a.iq, (i0 + j < wend) ? i0 + j : wend - 1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (i0 + j < wend) {
+                        const float2 cur = g[j];
+                        const bool ok = !costas_gated(cur, a);
+                        if (ok && prev_ok) {
+                            const float cr = (cur.x + a.shift) / a.scale, ci = (cur.y + a.shift) / a.scale;
+                            const float pr = (prev.x + a.shift) / a.scale, pi = (prev.y + a.shift) / a.scale;
+                            float dx = cr * pr + ci * pi, dy = ci * pr - cr * pi;          // cur * conj(prev)
+                            float tx = dx * dx - dy * dy, ty = 2.0f * dx * dy;             // ^2
+                            if (a.loop_order == 4) { const float ux = tx * tx - ty * ty, uy = 2.0f * tx * ty; tx = ux; ty = uy; }
+                            ax += tx; ay += ty;
+                        }
+                        prev = cur; prev_ok = ok;
+                    }
                 }
-                prev = cur; prev_ok = ok;
             }
             if (ax != 0.0f || ay != 0.0f) st.freq = costas_clamp(atan2f(ay, ax) / (float)a.loop_order);
         }
-        for (int64_t i = p; i < s0; ++i) costas_step<DT == URHGPU_DT_F32>(CostasLoad<DT>::at(a.iq, i), st, err, a);
+        {
+            constexpr int PF = 4;                               // as in k_costas_run: the next four samples are on their way
+            float2 cur[PF];
+#pragma unroll
+            for (int j = 0; j < PF; ++j) cur[j] = CostasLoad<DT>::at(a.iq, (p + j < s0) ? p + j : s0 - 1);
+            for (int64_t i = p; i < s0; i += PF) {
+                float2 nxt[PF];
+#pragma unroll
+                for (int j = 0; j < PF; ++j) { const int64_t q = i + PF + j; nxt[j] = CostasLoad<DT>::at(a.iq, (q < s0) ? q : s0 - 1); }
+#pragma unroll
+                for (int j = 0; j < PF; ++j) if (i + j < s0) costas_step<DT == URHGPU_DT_F32, ORDER>(cur[j], st, err, a);
+#pragma unroll
+                for (int j = 0; j < PF; ++j) cur[j] = nxt[j];
+            }
+        }
     }
     b.S[c * K + k] = st;
     // Candidates that have met during the warm-up -- the twins 2*pi apart do as soon as a carrier offset has wrapped the
@@ -230,7 +265,7 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
 }
 
 // The chunk itself, one lane per distinct candidate: checkpoints, end state, un-gated sample count.
-template <int DT>
+template <int DT, int ORDER>
 __global__ __launch_bounds__(256) void k_costas_run(const CostasArgs a, SpecBuffers b, int K) {
     const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
     if (gid >= *b.run_count) return;
@@ -242,14 +277,28 @@ __global__ __launch_bounds__(256) void k_costas_run(const CostasArgs a, SpecBuff
     CostasState st = b.S[ck];
     float err = 0.0f;
     int ung = 0;
-    // (fetching the samples 16 at a time as k_costas_final does was measured 7 % slower here, with or without the duplicates:
-    // the kernel is bound by the dependent arithmetic of the recurrence, ~150 instructions per step)
-    for (int64_t i = s0; i < e0; ++i) {
-        const float2 sm = CostasLoad<DT>::at(a.iq, i);
-        if (!costas_gated(sm, a)) ++ung;
-        costas_step<DT == URHGPU_DT_F32>(sm, st, err, a);
-        const int off = (int)(i - s0) + 1;
-        if (off % kCkpt == 0 && off < kChunk) b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + k] = st;
+    // The samples of the NEXT four steps are requested before the current four are evaluated: a step is ~130 dependent instructions,
+    // and with two wavefronts per SIMD (one lane per distinct candidate) nothing else hides the latency of its own load -- half of
+    // the wave cycles were spent in s_waitcnt before.
+    constexpr int PF = 4;
+    float2 cur[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) cur[j] = CostasLoad<DT>::at(a.iq, (s0 + j < e0) ? s0 + j : e0 - 1);
+    for (int64_t i = s0; i < e0; i += PF) {
+        float2 nxt[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) { const int64_t q = i + PF + j; nxt[j] = CostasLoad<DT>::at(a.iq, (q < e0) ? q : e0 - 1); }
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            if (i + j < e0) {
+                if (!costas_gated(cur[j], a)) ++ung;
+                costas_step<DT == URHGPU_DT_F32, ORDER>(cur[j], st, err, a);
+                const int off = (int)(i + j - s0) + 1;
+                if (off % kCkpt == 0 && off < kChunk) b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + k] = st;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PF; ++j) cur[j] = nxt[j];
     }
     b.E[ck] = st;
     if (k == 0) b.ungated[c] = ung;
@@ -294,7 +343,7 @@ __device__ __forceinline__ uint32_t map_compose(uint32_t later, uint32_t earlier
 // Exit: either all chunks are resolved, or -- when allow_break -- the chain broke for good (a chunk with plenty of
 // un-gated samples was evaluated serially to its end and met no candidate): stats[3] = the next chunk, *b.resume = its true
 // start state, and the host re-speculates the remaining chunks around that state's frequency.
-template <int DT>
+template <int DT, int ORDER>
 __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K, int64_t c_from,
                                                        int allow_break) {
     const int lane = threadIdx.x;
@@ -382,7 +431,7 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
         float err = 0.0f;
         CostasState st = T;
         for (int64_t i = s0; i < e0; ++i) {
-            costas_step<DT == URHGPU_DT_F32>(CostasLoad<DT>::at(a.iq, i), st, err, a);
+            costas_step<DT == URHGPU_DT_F32, ORDER>(CostasLoad<DT>::at(a.iq, i), st, err, a);
             const int off = (int)(i - s0) + 1;
             if (off % kCkpt == 0 && off < kChunk) {
                 const bool hit = lane < K && b.is_rep[c * K + lane] && same_state(st, b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + lane]);
@@ -405,7 +454,7 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
 // Output pass: every chunk from its TRUE start state.  A chunk that lies on a candidate's trajectory from its first
 // sample (gidx >= 0) is evaluated by kNumCkpt lanes, each from the candidate's checkpoint state (bitwise the true state
 // there); any other chunk by one lane from T[c].
-template <int DT>
+template <int DT, int ORDER>
 __global__ __launch_bounds__(256) void k_costas_final(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K) {
     const int64_t gid = blockIdx.x * 256ll + threadIdx.x;
     const int64_t c = gid / kNumCkpt;
@@ -437,14 +486,14 @@ __global__ __launch_bounds__(256) void k_costas_final(const CostasArgs a, SpecBu
             float2 xv = x[0];
 #pragma unroll
             for (int q = 1; q < kTileF; ++q) if (u == q) xv = x[q];
-            const float ov = costas_step<DT == URHGPU_DT_F32>(xv, st, err, a);
+            const float ov = costas_step<DT == URHGPU_DT_F32, ORDER>(xv, st, err, a);
 #pragma unroll
             for (int q = 0; q < kTileF; ++q) if (u == q) o[q] = ov;
         }
 #pragma unroll
         for (int u = 0; u < kTileF; ++u) a.out[i + u] = o[u];
     }
-    for (; i < i1; ++i) a.out[i] = costas_step<DT == URHGPU_DT_F32>(CostasLoad<DT>::at(a.iq, i), st, err, a);
+    for (; i < i1; ++i) a.out[i] = costas_step<DT == URHGPU_DT_F32, ORDER>(CostasLoad<DT>::at(a.iq, i), st, err, a);
 }
 
 size_t costas_scratch_bytes(int64_t n) {
@@ -456,15 +505,23 @@ size_t costas_scratch_bytes(int64_t n) {
 constexpr int kMaxRounds = 24;     // re-speculation rounds before the stitch stops handing back (and runs serially)
 
 // NOTE: synchronises the stream (at least once): the host has to learn whether the chunk chain closed.
+template <int DT, int ORDER>
+static int launch_costas_spec(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx);
+
 template <int DT>
 static int launch_costas_dt(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx) {
-    hipStream_t s = ctx->stream;
     const bool parallel = (a.loop_order == 2 || a.loop_order == 4) && a.n > 2 * kChunk && scratch != nullptr;
     if (!parallel) {
-        hipLaunchKernelGGL(k_costas<DT>, dim3(1), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(k_costas<DT>, dim3(1), dim3(64), 0, ctx->stream, a);
         ctx->h_counts[12] = ctx->h_counts[13] = ctx->h_counts[14] = 0;
         return URHGPU_OK;
     }
+    return a.loop_order == 4 ? launch_costas_spec<DT, 4>(a, scratch, ctx) : launch_costas_spec<DT, 2>(a, scratch, ctx);
+}
+
+template <int DT, int ORDER>
+static int launch_costas_spec(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx) {
+    hipStream_t s = ctx->stream;
     const int K = (a.loop_order == 4) ? 8 : 4;
     const int64_t nc = (a.n - 1 + kChunk - 1) / kChunk;
     char *p = (char *)scratch;
@@ -492,11 +549,11 @@ static int launch_costas_dt(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx)
     for (int round = 0;; ++round) {
         const int64_t todo = nc - c_from;
         URH_HIP(hipMemsetAsync(b.run_count, 0, 4, s));
-        hipLaunchKernelGGL(k_costas_spec<DT>, dim3((unsigned)((todo * K + 255) / 256)), dim3(256), 0, s, a, b, nc, K, c_from, use_seed,
+        hipLaunchKernelGGL((k_costas_spec<DT, ORDER>), dim3((unsigned)((todo * K + 255) / 256)), dim3(256), 0, s, a, b, nc, K, c_from, use_seed,
                            seed_freq);
-        hipLaunchKernelGGL(k_costas_run<DT>, dim3((unsigned)((todo * K + 255) / 256)), dim3(256), 0, s, a, b, K);
+        hipLaunchKernelGGL((k_costas_run<DT, ORDER>), dim3((unsigned)((todo * K + 255) / 256)), dim3(256), 0, s, a, b, K);
         hipLaunchKernelGGL(k_costas_map, dim3((unsigned)((todo + 255) / 256)), dim3(256), 0, s, b, nc, K, std::max<int64_t>(c_from, 1));
-        hipLaunchKernelGGL(k_costas_stitch<DT>, dim3(1), dim3(64), 0, s, a, b, nc, K, std::max<int64_t>(c_from, 1),
+        hipLaunchKernelGGL((k_costas_stitch<DT, ORDER>), dim3(1), dim3(64), 0, s, a, b, nc, K, std::max<int64_t>(c_from, 1),
                            round < kMaxRounds ? 1 : 0);
         URH_HIP(hipGetLastError());
         URH_HIP(hipMemcpyAsync(h, b.stats, 20, hipMemcpyDeviceToHost, s));
@@ -510,7 +567,7 @@ static int launch_costas_dt(const CostasArgs &a, void *scratch, urhgpu_ctx *ctx)
         rounds = round + 1;
     }
     h[4] = rounds;
-    hipLaunchKernelGGL(k_costas_final<DT>, dim3((unsigned)((nc * kNumCkpt + 255) / 256)), dim3(256), 0, s, a, b, nc, K);
+    hipLaunchKernelGGL((k_costas_final<DT, ORDER>), dim3((unsigned)((nc * kNumCkpt + 255) / 256)), dim3(256), 0, s, a, b, nc, K);
     return URHGPU_OK;
 }
 
