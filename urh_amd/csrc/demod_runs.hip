@@ -266,6 +266,39 @@ __device__ __forceinline__ void fsk_reduced(float pc, float pd, float c0, float 
     }
 }
 
+// The FSK pair of a lane in a row where some lane's phase step lies beyond pi/4 (|im/re| >= 1: wide deviations, low sample rates)
+// or in the backward half-plane (re < 0: beyond pi/2) -- every lane regular: |re| in the fast division's window, 2^-29 <= |im/re|
+// < 2^25, nothing gated.  fdlibm's atan2f without a branch: t = |im| / |re|, one of atanf's four argument reductions (or none)
+// chosen by selects, the division of the reduced argument, the polynomial, hi - ((p - lo) - u), then the quadrant: pi - (z - pi_lo) for re < 0, the sign
+// of im on top (a - b == -(b - a) exactly: cases 1 and 3 of e_atan2f.c are the negations of 0 and 2).  Before, such a row went
+// through the rolled-up general code, sample by sample: 0.62 - 0.68 ms per GiB at deviations of +-100 kHz and more (1 MS/s).
+__device__ __forceinline__ void atan_reduce_full(float ax, float &num, float &den, float &hi, float &lo, bool &direct) {
+    const uint32_t ir = __float_as_uint(ax);
+    direct = ir < 0x3ee00000u;                                         // < 0.4375
+    const bool r0 = ir < 0x3f300000u, r1 = ir < 0x3f980000u, r2 = ir < 0x401c0000u;      // < 11/16, < 19/16, < 39/16
+    const float n0 = 2.0f * ax - 1.0f, d0 = 2.0f + ax, n1 = ax - 1.0f, d1 = ax + 1.0f, n2 = ax - 1.5f, d2 = 1.0f + 1.5f * ax;
+    num = direct ? ax : (r0 ? n0 : (r1 ? n1 : (r2 ? n2 : -1.0f)));
+    den = direct ? 1.0f : (r0 ? d0 : (r1 ? d1 : (r2 ? d2 : ax)));
+    hi = r0 ? 4.6364760399e-01f : (r1 ? 7.8539812565e-01f : (r2 ? 9.8279368877e-01f : 1.5707962513e+00f));
+    lo = r0 ? 5.0121582440e-09f : (r1 ? 3.7748947079e-08f : (r2 ? 3.4473217170e-08f : 7.5497894159e-08f));
+}
+constexpr uint32_t kAtanExtSpan = 0x4c000000u - 0x31000000u;          // 2^-29 <= t < 2^25 as one unsigned compare (with kAtanLo)
+// t0 / t1 = |im / re| (the caller's signed quotients with the sign bit masked off: every step of the division is sign-symmetric)
+__device__ __forceinline__ void fsk_extended(float re0, float im0, float re1, float im1, float t0, float t1, float &q0, float &q1) {
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    float n0, d0, h0, l0, n1, d1, h1, l1;
+    bool dir0, dir1;
+    atan_reduce_full(t0, n0, d0, h0, l0, dir0);
+    atan_reduce_full(t1, n1, d1, h1, l1, dir1);
+    float u0, u1;
+    div_fast2(n0, d0, n1, d1, u0, u1);                                 // denominators in [1, 2^25), |quotients| < 1; direct: t / 1 = t
+    const float p0 = urh_atanf_poly(u0), p1 = urh_atanf_poly(u1);
+    const float z0 = dir0 ? u0 - p0 : h0 - ((p0 - l0) - u0), z1 = dir1 ? u1 - p1 : h1 - ((p1 - l1) - u1);
+    const float b0 = (__float_as_int(re0) < 0) ? pi - (z0 - pi_lo) : z0, b1 = (__float_as_int(re1) < 0) ? pi - (z1 - pi_lo) : z1;
+    q0 = __uint_as_float((__float_as_uint(b0) & 0x7fffffffu) | (__float_as_uint(im0) & 0x80000000u));
+    q1 = __uint_as_float((__float_as_uint(b1) & 0x7fffffffu) | (__float_as_uint(im1) & 0x80000000u));
+}
+
 __device__ __forceinline__ float atan2f_small(float r, float y, float x) {
     // r = |y/x| in [2^-29, 0.4375)
     const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
@@ -325,9 +358,9 @@ __device__ __forceinline__ void load_rows(const RunArgs &p, int64_t ta, int rb, 
 
 // Demodulate a lane's two consecutive samples (q0, q1); all 64 lanes are active.  (prev_c, prev_d)
 // is the sample before lane 0's first sample (wavefront-uniform).
-// Returns 0 when q0/q1 are final and NO sample of the row is noise-gated (the fast path: states
-// follow from the thresholds alone), 1 when q0/q1 are final but some sample is gated, 2 (FSK only)
-// when some lane needs the general code: q0/q1 are then NOT valid and the caller redoes the row with
+// Returns 0 (or 3: the same, computed by the extended any-angle form) when q0/q1 are final and NO sample of the row is
+// noise-gated (the fast path: states follow from the thresholds alone), 1 when q0/q1 are final but some sample is gated,
+// 2 (FSK only) when some lane needs the general code: q0/q1 are then NOT valid and the caller redoes the row with
 // fsk_row_general().
 template <int MOD>
 __device__ __forceinline__ int demod_pair(const RowIn &r, float prev_c, float prev_d, const RunArgs &p, float &q0, float &q1) {
@@ -361,6 +394,15 @@ __device__ __forceinline__ int demod_pair(const RowIn &r, float prev_c, float pr
         if (!any_noise && __builtin_amdgcn_ballot_w64(!(ok0 & ok1)) == 0 && __builtin_amdgcn_ballot_w64(md0 | md1 | zr0 | zr1) != 0) {
             fsk_reduced(pc, pd, c0, d0, c1, d1, t0, t1, md0, md1, zr0, zr1, q0, q1);
             return 0;
+        }
+        {
+            // any angle: |re| in the division's window (either sign), 2^-29 <= |im/re| < 2^25 (t's sign bit is masked off: a0 / a1)
+            const bool ew0 = ((__float_as_uint(re0) & 0x7fffffffu) - kReLo < kReSpan), ew1 = ((__float_as_uint(re1) & 0x7fffffffu) - kReLo < kReSpan);
+            const bool ex0 = (int)(a0 - kAtanLo < kAtanExtSpan) & (int)ew0, ex1 = (int)(a1 - kAtanLo < kAtanExtSpan) & (int)ew1;
+            if (!any_noise && __builtin_amdgcn_ballot_w64(!(ex0 & ex1)) == 0) {
+                fsk_extended(re0, im0, re1, im1, __uint_as_float(a0), __uint_as_float(a1), q0, q1);
+                return 3;                                    // as 0, through the extended form (demod_batch counts these)
+            }
         }
 #else
         const float t0 = im0 / re0, t1 = im1 / re1;
@@ -431,6 +473,26 @@ __device__ __forceinline__ bool spec_pair(const RowIn &r, float prev_c, float pr
     return n0 | n1;
 }
 
+// The wide-deviation form of spec_pair: the branch-free extended atan2f (fsk_extended) for a lane's two samples, whatever the angle;
+// true when the lane needs something else (a gated sample, |re| outside the division's window, |im/re| outside [2^-29, 2^25) --
+// which includes an exactly zero cross product).  For lanes inside spec_pair's range the result is the same bits: there the
+// reduction is "none", u = |t|, and t - poly(t) is odd in t.
+__device__ __forceinline__ bool ext_pair(const RowIn &r, float prev_c, float prev_d, const RunArgs &p, float &q0, float &q1) {
+    const float c0 = r.c0, d0 = r.d0, c1 = r.c1, d1 = r.d1;
+    const float mag0 = c0 * c0 + d0 * d0, mag1 = c1 * c1 + d1 * d1;
+    const bool n0 = mag0 <= p.noise_sqrd, n1 = mag1 <= p.noise_sqrd;
+    const float pc = dpp_wave_shr1(c1, prev_c), pd = dpp_wave_shr1(d1, prev_d);
+    const float re0 = pc * c0 + pd * d0, im0 = pc * d0 - pd * c0;
+    const float re1 = c0 * c1 + d0 * d1, im1 = c0 * d1 - d0 * c1;
+    float t0, t1;
+    div_fast2(im0, re0, im1, re1, t0, t1);
+    const uint32_t a0 = __float_as_uint(t0) & 0x7fffffffu, a1 = __float_as_uint(t1) & 0x7fffffffu;
+    const bool ew0 = ((__float_as_uint(re0) & 0x7fffffffu) - kReLo < kReSpan), ew1 = ((__float_as_uint(re1) & 0x7fffffffu) - kReLo < kReSpan);
+    const bool ex0 = (int)(a0 - kAtanLo < kAtanExtSpan) & (int)ew0, ex1 = (int)(a1 - kAtanLo < kAtanExtSpan) & (int)ew1;
+    fsk_extended(re0, im0, re1, im1, __uint_as_float(a0), __uint_as_float(a1), q0, q1);
+    return n0 | n1 | !ex0 | !ex1;
+}
+
 // The general FSK row (any operand class, any angle, noise gating).  Deliberately rolled up (one
 // copy of the general atan2f per kernel) so that the hot loop stays small in the instruction cache.
 __device__ __forceinline__ void fsk_row_general(const RowIn &r, float prev_c, float prev_d, const RunArgs &p, float &q0, float &q1) {
@@ -461,15 +523,32 @@ __device__ __forceinline__ uint32_t demod_batch(const RowIn (&cur)[NB], float &p
 #if URH_SPEC
     if (SRC == SRC_IQ && MOD != URHGPU_MOD_OTHER) {
         uint32_t bad = 0;
+        uint32_t form = 0;
         if (MOD == URHGPU_MOD_FSK && hint != 0) {
-            // the speculative pass has just been failing (wide deviation, noise): the next few batches skip it and take the
-            // re-do of flagged rows directly (wavefront-uniform; `hint` counts down to the next speculative attempt)
-            --hint;
-            bad = (1u << kBatch) - 1u;
+            // The narrow speculative pass has just been failing for every row (wide deviation, noise): the next batches skip it.
+            // Form 1: every row goes straight to the re-do below (demod_pair: narrow / middle / extended form, row by row, rolled
+            // up); when most rows of a batch needed the extended form there -- phase steps beyond pi/4 -- form 2: the extended form
+            // for every row, unrolled like the narrow pass.  hint = form << 4 | batches left until the next narrow attempt
+            // (wavefront-uniform); form 2 steps down to one batch of form 1.
+            form = hint >> 4;
+            hint = ((hint & 15u) > 1u) ? hint - 1u : ((form == 2u) ? ((1u << 4) | 1u) : 0u);
+            if (form == 1u) {
+                bad = (1u << kBatch) - 1u;
 #pragma unroll
-            for (int j = 0; j < kBatch; ++j) {
-                pcs[j] = prev_c; pds[j] = prev_d;
-                prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1);
+                for (int j = 0; j < kBatch; ++j) {
+                    pcs[j] = prev_c; pds[j] = prev_d;
+                    prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1);
+                }
+            } else {
+                bool flag[kBatch];
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) {
+                    pcs[j] = prev_c; pds[j] = prev_d;
+                    flag[j] = ext_pair(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
+                    prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1);
+                }
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) if (__builtin_amdgcn_ballot_w64(flag[j]) != 0) bad |= 1u << j;
             }
         } else {
             bool flag[kBatch];
@@ -481,9 +560,13 @@ __device__ __forceinline__ uint32_t demod_batch(const RowIn (&cur)[NB], float &p
             }
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) if (__builtin_amdgcn_ballot_w64(flag[j]) != 0) bad |= 1u << j;
-            if (MOD == URHGPU_MOD_FSK && bad == (1u << kBatch) - 1u) hint = 7;       // every row of the batch: likely to go on
+            // every row of the batch: likely to go on.  (Switching as soon as a quarter of the rows are flagged was measured: deviations
+            // of 50 - 70 kHz, where a minority of rows holds a sample beyond 0.4375, went from 0.45 to 0.49 ms -- the extended form
+            // costs every row about three times the narrow one.)
+            if (MOD == URHGPU_MOD_FSK && bad == (1u << kBatch) - 1u) hint = (1u << 4) | 7u;
         }
         if (__builtin_expect(bad != 0, 0)) {
+            int n_ext = 0;
 #pragma unroll 1
             for (int j = 0; j < kBatch; ++j) {
                 if (!((bad >> j) & 1u)) continue;
@@ -491,7 +574,8 @@ __device__ __forceinline__ uint32_t demod_batch(const RowIn (&cur)[NB], float &p
 #pragma unroll
                 for (int k = 1; k < kBatch; ++k) if (j == k) { r = cur[k]; pc = pcs[k]; pd = pds[k]; }
                 float g0 = 0.f, g1 = 0.f;
-                const int kind = demod_pair<MOD>(r, pc, pd, p, g0, g1);
+                int kind = demod_pair<MOD>(r, pc, pd, p, g0, g1);
+                if (kind == 3) { kind = 0; ++n_ext; }
                 if (kind == 2) general |= 1u << j;
                 else {
 #pragma unroll
@@ -499,6 +583,7 @@ __device__ __forceinline__ uint32_t demod_batch(const RowIn (&cur)[NB], float &p
                 }
                 if (kind != 0) gated |= 1u << j;
             }
+            if (MOD == URHGPU_MOD_FSK && form == 1u && 2 * n_ext >= kBatch) hint = (2u << 4) | 7u;
         }
     } else
 #endif
@@ -509,7 +594,7 @@ __device__ __forceinline__ uint32_t demod_batch(const RowIn (&cur)[NB], float &p
         pcs[j] = prev_c; pds[j] = prev_d;
         const int k = demod_pair<MOD>(cur[j], prev_c, prev_d, p, q0[j], q1[j]);
         if (k == 2) general |= 1u << j;
-        if (k != 0) gated |= 1u << j;
+        if (k != 0 && k != 3) gated |= 1u << j;
         if (MOD == URHGPU_MOD_FSK) { prev_c = lane63(cur[j].c1); prev_d = lane63(cur[j].d1); }
     }
     }
@@ -1184,7 +1269,7 @@ __global__ __launch_bounds__(kAfpBlock) void k_afp_demod(const RunArgs p) {
         }
     }
 }
-// Test hook: out[i] = number of (n, d) pairs (d in the fast-path range, |n/d| < 1) on which div_fast differs from
+// Test hook: out[i] = number of (n, d) pairs (d in the fast-path range, 2^-31 <= |n/d| < 2^26) on which div_fast differs from
 // the IEEE division, over `reps` pseudo-random pairs per thread.
 __global__ void k_test_div(uint64_t seed, int reps, unsigned long long *mismatches) {
     uint64_t s = seed + (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) * 0x9e3779b97f4a7c15ull;
@@ -1193,10 +1278,11 @@ __global__ void k_test_div(uint64_t seed, int reps, unsigned long long *mismatch
         s += 0x9e3779b97f4a7c15ull;
         uint64_t z = s; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; z ^= z >> 31;
         const uint32_t a = (uint32_t)z, b = (uint32_t)(z >> 32);
-        // d: positive, exponent in [-40, 40); n: |n| <= |d| scaled by a random power of two down to 2^-30
+        // d: positive, exponent in [-40, 40); n: |d| scaled by +-[0.5, 1) and a random power of two from 2^-30 to 2^26 (the extended
+        // path divides by |re| whatever the quotient: phase steps beyond pi/4 have |im/re| >= 1)
         const float d = __uint_as_float(((b % 80u + 87u) << 23) | (b >> 9));
         const float f = __uint_as_float((a & 0x807fffffu) | 0x3f000000u);            // +-[0.5, 1)
-        const float n = f * d * __uint_as_float((127u - (a >> 23) % 31u) << 23);
+        const float n = f * d * __uint_as_float((97u + (a >> 23) % 57u) << 23);
         float q2, q3;
         div_fast2(n, d, d * 0.25f, n == 0.f ? 1.0f : n * 8.0f, q2, q3);   // second slot: another in-range pair when |n*8| is
         const float q1 = n / d;
