@@ -370,18 +370,24 @@ def extra_config5(pipe, dev, args):
     for tag, c in (("i_auto_center", center), ("ii_center_0", 0.0)):
         sig.center = float(c) if c is not None else 0.0
 
-        def slice_bits():
+        def slice_bits():                          # outputs left in HBM, as in the headline step
+            return sig._digitize_dev(sig.qad, sig.params())
+        _, t_dev = _timed(torch, slice_bits)
+
+        def slice_bits_host():                     # ... and with the pulse table / bits / positions copied to the host
             sig._bits = None
             return sig._digitize()
-        dig, t_dig = _timed(torch, slice_bits)
-        out[tag] = (dig, t_dig, sig.center)
+        dig, t_dig = _timed(torch, slice_bits_host)
+        out[tag] = (dig, t_dev, sig.center, t_dig)
     total_i = t_costas + t_center + out["i_auto_center"][1]
     total_ii = t_costas + out["ii_center_0"][1]
     rec = {"workload": "configs[4]: 1 GiB 4-PSK, Costas loop (order 4, bandwidth 0.1) + detect_center + bits",
            "samples": n, "ms": round(total_i, 3), "ms_center_0": round(total_ii, 3),
            "stages_ms": {"costas_demod": round(t_costas, 3), "detect_center": round(t_center, 3),
                          "grab_pulse_lens_plus_bits_auto_center": round(out["i_auto_center"][1], 3),
-                         "grab_pulse_lens_plus_bits_center_0": round(out["ii_center_0"][1], 3)},
+                         "grab_pulse_lens_plus_bits_center_0": round(out["ii_center_0"][1], 3),
+                         "grab_pulse_lens_plus_bits_plus_d2h_auto_center": round(out["i_auto_center"][3], 3),
+                         "grab_pulse_lens_plus_bits_plus_d2h_center_0": round(out["ii_center_0"][3], 3)},
            "center_detected": None if center is None else float(center),
            "costas_chunks": {"matched_by_a_candidate": stats[0], "met_at_a_checkpoint": stats[1], "evaluated_serially": stats[2],
                              "respeculation_rounds": stats[3],
@@ -412,7 +418,7 @@ def extra_config5(pipe, dev, args):
             par["reference_center"] = None if ref_center is None else float(ref_center)
         t3 = time.perf_counter()
         for tag in ("i_auto_center", "ii_center_0"):
-            dig, _, c = out[tag]
+            dig, _, c, _ = out[tag]
             ref_pp = np.asarray(sf.grab_pulse_lens(ref_qad, c, 5, "PSK", 100, 2, 1.5))
             ref_flat = oracle.ppseq_to_bits_flat(ref_pp, 100, 2, True, 8)
             par[tag + "_rows_equal"] = bool(np.array_equal(dig[0], ref_pp))

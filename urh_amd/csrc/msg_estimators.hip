@@ -187,13 +187,15 @@ __global__ __launch_bounds__(kMeBlock) void k_me_minmax(const float *x, const fl
         tile_mm[blockIdx.x] = float2{mn, mx};
     }
 }
-__global__ __launch_bounds__(64) void k_me_minmax_fin(MsgState *st, const float2 *tile_mm, const float *x, const float *kept) {
+constexpr int kMeFinBlock = 1024;            // one message can be the whole capture: 32 768 tiles
+__global__ __launch_bounds__(kMeFinBlock) void k_me_minmax_fin(MsgState *st, const float2 *tile_mm, const float *x, const float *kept) {
+    __shared__ float s_mn[kMeFinBlock / 64], s_mx[kMeFinBlock / 64];
     const int m = blockIdx.x;
     MsgState s = st[m];
     if (s.L <= 0) return;
     const int64_t nt = (s.L + kMeTile - 1) / kMeTile;
     float mn = me_src(x, kept, s)[s.a], mx = mn;
-    for (int64_t u = threadIdx.x; u < nt; u += 64) {
+    for (int64_t u = threadIdx.x; u < nt; u += kMeFinBlock) {
         const float2 p = tile_mm[s.first_tile + u];
         if (p.x < mn) mn = p.x;
         if (p.y > mx) mx = p.y;
@@ -204,7 +206,12 @@ __global__ __launch_bounds__(64) void k_me_minmax_fin(MsgState *st, const float2
         if (a < mn) mn = a;
         if (b > mx) mx = b;
     }
-    if (threadIdx.x == 0) { st[m].mn = mn; st[m].mx = mx; }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kMeFinBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
+        st[m].mn = mn; st[m].mx = mx;
+    }
 }
 
 // ---- stage 4: numpy's float32 pairwise sums (np.mean, np.var) ---------------------------------------------------------------
@@ -282,7 +289,6 @@ __device__ __forceinline__ float me_leaf_sum(const float *a, int len, int mode, 
 // the slot of the node's leftmost leaf, and the owner of that leaf adds the right child (left + right, as pw() does).
 constexpr int kMeRestSlots = kPwChunkM / 64, kMeRestDepth = 9;
 __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, const float *kept, MsgState *st, const float *chunk_sums, int mode) {
-    __shared__ float s_chunk[64];
     __shared__ float s_val[kMeRestSlots + 1];
     const int m = blockIdx.x, tid = threadIdx.x;
     const MsgState s = st[m];
@@ -290,13 +296,23 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
     const int64_t n_chunks = s.L / kPwChunkM;
     const int rest = (int)(s.L % kPwChunkM);
     const float *cs = chunk_sums + s.first_tile;
+    // total = ((0 + c0) + c1) + ...: strictly sequential float adds (16 384 of them when the capture is one message).  Wavefront 0
+    // holds 64 chunk sums in its lanes and adds them through v_readlane (the next 64 are already loaded): a dependent add every few
+    // cycles instead of an LDS round trip per term.
     float total = 0.f;
-    for (int64_t c0 = 0; c0 < n_chunks; c0 += 64) {
-        const int64_t nc = (n_chunks - c0 < 64) ? n_chunks - c0 : 64;
-        if (tid < nc) s_chunk[tid] = cs[c0 + tid];
-        __syncthreads();
-        if (tid == 0) for (int64_t c = 0; c < nc; ++c) total = total + s_chunk[c];      // total = ((0 + c0) + c1) + ...
-        __syncthreads();
+    if (tid < 64) {
+        float v = (tid < n_chunks) ? cs[tid] : 0.f;
+        for (int64_t c0 = 0; c0 < n_chunks; c0 += 64) {
+            const float nxt = (c0 + 64 + tid < n_chunks) ? cs[c0 + 64 + tid] : 0.f;
+            const int nc = (int)((n_chunks - c0 < 64) ? n_chunks - c0 : 64);
+            if (nc == 64) {
+#pragma unroll
+                for (int c = 0; c < 64; ++c) total = total + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c));
+            } else {
+                for (int c = 0; c < nc; ++c) total = total + __shfl(v, c);
+            }
+            v = nxt;
+        }
     }
     // pw(a, n) = pw(a, n2) + pw(a + n2, n - n2), n2 = n / 2 rounded down to a multiple of 8, down to leaves of <= 128 elements
     const int e = tid * 64;                                  // this thread's element
@@ -695,7 +711,7 @@ int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const 
     hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_kept);
     hipLaunchKernelGGL(k_me_trim, dim3(gm), dim3(64), 0, s, d_st, n_msgs);
     hipLaunchKernelGGL(k_me_minmax, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, d_mm);
-    hipLaunchKernelGGL(k_me_minmax_fin, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_mm, d_x, d_kept);
+    hipLaunchKernelGGL(k_me_minmax_fin, dim3((unsigned)n_msgs), dim3(kMeFinBlock), 0, s, d_st, d_mm, d_x, d_kept);
     for (int mode = 0; mode < 2; ++mode) {
         hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, mode, d_leaf);
         hipLaunchKernelGGL(k_me_chunk_trees, dim3(gt), dim3(64), 0, s, d_st, d_tiles, d_leaf, d_chunk);

@@ -202,6 +202,23 @@ class Signal:
         if n == 0:
             z = np.zeros(0, np.int64)
             return (np.zeros((0, 2), np.int64), np.zeros(0, np.uint8), np.zeros(1, np.int64), z, z, np.zeros(1, np.int64))
+        rows, n_rows, bits, msg_off, pauses, pos, pos_off, counts, (cap_msg, cap_bits, cap_pos) = self._digitize_dev(q, p)
+        c = counts.cpu().numpy()
+        nr = int(n_rows.cpu().numpy()[0])
+        n_msg, n_bits, n_pos = int(c[1]), int(c[2]), int(c[3])
+        if n_msg > cap_msg or n_bits > cap_bits or n_pos > cap_pos:
+            raise _lib.UrhGpuError(_lib.ERR_CAPACITY, "output capacity too small")
+        out = (rows[:nr].cpu().numpy(), bits[:n_bits].cpu().numpy(), msg_off[:n_msg + 1].cpu().numpy(), pauses[:n_msg].cpu().numpy(),
+               pos[:n_pos].cpu().numpy(), pos_off[:n_msg + 1].cpu().numpy())
+        self._bits, self._bits_key = out, self._slice_key()
+        return out
+
+    def _digitize_dev(self, q, p):
+        """The device part of _digitize: grab_pulse_lens + _ppseq_to_bits on the cached qad, outputs left in the pipeline's buffers
+        (no host synchronisation): (rows, n_rows, bits, msg_off, pauses, pos, pos_off, counts, (cap_msg, cap_bits, cap_pos))."""
+        import ctypes as C
+        torch = self.pipe.torch
+        n = int(q.shape[0])
         pipe = self.pipe
         cp = p.to_c(np.float32)
         cap_rows = n // (p.tolerance + 1) + 2
@@ -225,15 +242,7 @@ class Signal:
         o.pos = pos.data_ptr(); o.cap_pos = cap_pos; o.pos_off = pos_off.data_ptr(); o.counts = counts.data_ptr()
         _lib.check(_lib.load().urhgpu_ppseq_to_bits_dev(pipe.ctx.handle, C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr()),
                                                         cap_rows, C.byref(cp), C.byref(o)))
-        c = counts.cpu().numpy()
-        nr = int(n_rows.cpu().numpy()[0])
-        n_msg, n_bits, n_pos = int(c[1]), int(c[2]), int(c[3])
-        if n_msg > cap_msg or n_bits > cap_bits or n_pos > cap_pos:
-            raise _lib.UrhGpuError(_lib.ERR_CAPACITY, "output capacity too small")
-        out = (rows[:nr].cpu().numpy(), bits[:n_bits].cpu().numpy(), msg_off[:n_msg + 1].cpu().numpy(), pauses[:n_msg].cpu().numpy(),
-               pos[:n_pos].cpu().numpy(), pos_off[:n_msg + 1].cpu().numpy())
-        self._bits, self._bits_key = out, self._slice_key()
-        return out
+        return rows, n_rows, bits, msg_off, pauses, pos, pos_off, counts, (cap_msg, cap_bits, cap_pos)
 
     def ppseq(self) -> np.ndarray:
         """signal_functions.grab_pulse_lens(signal.qad, center, tolerance, modulation_type, samples_per_symbol, bits_per_symbol,
