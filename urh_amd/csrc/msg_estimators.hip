@@ -390,31 +390,52 @@ __device__ __forceinline__ double me_edge(const MsgState &s, int64_t i) { return
 constexpr int kMeHistLds = 4096;             // bins kept in LDS per workgroup (the pool's max_bins is at most this)
 constexpr int kMeEdgeLds = 2048;             // edges kept in LDS (histograms with more bins evaluate the edges per sample)
 __device__ __forceinline__ double me_edge32(const MsgState &s, int i) { return s.e0 + (double)i * s.delta; }
-__global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int64_t max_bins,
-                                                       unsigned int *counts) {
+constexpr int kMeHistGroup = 8;              // consecutive tiles per workgroup: one flush of the LDS counters per message and group
+__global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int64_t n_tiles,
+                                                       int64_t max_bins, unsigned int *counts) {
     // demodulated signals sit on two or four levels: nearly every sample of a message lands in a handful of bins.  Counting
     // straight into device memory serialises the whole pass on those few addresses (40 ms for a 1 GiB capture).  A wavefront
     // counts the lanes that share a bin with one ballot per distinct bin (one to three rounds per 64 samples), the workgroup
     // accumulates in LDS, and only the non-empty bins of a tile reach device memory.
     // The pass is bound by instruction issue, not by HBM: the bin is guessed in float32 and checked against the exact float64
     // edges, which come from an LDS table (evaluating first + i * delta per sample costs two conversions and four float64 operations
-    // per edge).
+    // per edge).  A workgroup walks kMeHistGroup consecutive tiles and flushes its LDS counters when the message changes or at the end
+    // (a capture that is ONE message had 32 768 workgroups adding their counters to the same few words of device memory: 371 us).
     __shared__ unsigned int s_c[kMeHistLds];
     __shared__ double s_e[kMeEdgeLds + 2];
-    const MsgTile t = tiles[blockIdx.x];
-    const MsgState m = st[t.msg];
-    if (m.L <= 0 || m.n_edges < 2 || m.n_edges - 1 > max_bins || m.n_edges - 1 > INT32_MAX - 1 || (int64_t)t.idx * kMeTile >= m.L) return;
-    const int nb = (int)(m.n_edges - 1);
-    const bool in_lds = nb <= kMeHistLds, table = nb + 1 <= kMeEdgeLds;
-    if (in_lds) for (int k = threadIdx.x; k < nb; k += kMeBlock) s_c[k] = 0u;
-    if (table) for (int k = threadIdx.x; k <= nb; k += kMeBlock) s_e[k] = me_edge32(m, k);
-    __syncthreads();
+    const int64_t tile0 = (int64_t)blockIdx.x * kMeHistGroup, tile1 = (tile0 + kMeHistGroup < n_tiles) ? tile0 + kMeHistGroup : n_tiles;
+    int cur_msg = -1, nb = 0;
+    bool valid = false, in_lds = false, table = false;
+    MsgState m = st[0];
+    unsigned int *out = counts;
+    const int lane = threadIdx.x & 63;
+    for (int64_t tix = tile0; tix <= tile1; ++tix) {
+    const bool last = tix == tile1;
+    MsgTile t = tiles[last ? tile1 - 1 : tix];
+    if (last || t.msg != cur_msg) {                            // (workgroup-uniform)
+        if (valid && in_lds) {                                 // flush the message's counters
+            __syncthreads();
+            for (int k = threadIdx.x; k < nb; k += kMeBlock) if (s_c[k]) atomicAdd(&out[k], s_c[k]);
+            __syncthreads();
+        }
+        if (last) break;
+        cur_msg = t.msg;
+        m = st[t.msg];
+        valid = !(m.L <= 0 || m.n_edges < 2 || m.n_edges - 1 > max_bins || m.n_edges - 1 > INT32_MAX - 1);
+        nb = valid ? (int)(m.n_edges - 1) : 0;
+        in_lds = nb <= kMeHistLds; table = nb + 1 <= kMeEdgeLds;
+        out = counts + (int64_t)t.msg * max_bins;
+        if (valid) {
+            if (in_lds) for (int k = threadIdx.x; k < nb; k += kMeBlock) s_c[k] = 0u;
+            if (table) for (int k = threadIdx.x; k <= nb; k += kMeBlock) s_e[k] = me_edge32(m, k);
+            __syncthreads();
+        }
+    }
+    if (!valid || (int64_t)t.idx * kMeTile >= m.L) continue;
     const double e0 = m.e0, eN = me_edge32(m, nb);
     const float e0f = (float)e0, invf = (m.delta > 0.0) ? (float)(1.0 / m.delta) : 0.f;
     const float *r = me_src(x, kept, m) + m.a;
-    unsigned int *out = counts + (int64_t)t.msg * max_bins;
     const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
-    const int lane = threadIdx.x & 63;
     float val[kMePer];
 #pragma unroll
     for (int j = 0; j < kMePer; ++j) { const int64_t i = i0 + (int64_t)j * kMeBlock; val[j] = (i < m.L) ? r[i] : __builtin_nanf(""); }
@@ -482,9 +503,6 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
             todo = __ballot(bin[j] >= 0);
         }
     }
-    if (in_lds) {
-        __syncthreads();
-        for (int k = threadIdx.x; k < nb; k += kMeBlock) if (s_c[k]) atomicAdd(&out[k], s_c[k]);
     }
 }
 
@@ -718,7 +736,8 @@ int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const 
         hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeRestSlots), 0, s, d_x, d_kept, d_st, d_chunk, mode);
     }
     hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins);
-    hipLaunchKernelGGL(k_me_hist, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, max_bins, d_hist);
+    hipLaunchKernelGGL(k_me_hist, dim3((unsigned)((b.n_tiles + kMeHistGroup - 1) / kMeHistGroup)), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, b.n_tiles,
+                       max_bins, d_hist);
     hipLaunchKernelGGL(k_me_peaks, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_hist, max_bins);
     URH_HIP(hipGetLastError());
     std::vector<unsigned int> hist;
