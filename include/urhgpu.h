@@ -345,6 +345,13 @@ int urhgpu_detect_modulation_dev(urhgpu_ctx *ctx, const float *d_iq, int64_t n, 
  * bitlen_out[m]: bit length, -1 (fewer than two merged plateaus: no vote) or -2 (the reference's result depends on numpy's order of
  * equal counts: decide that message with numpy). */
 int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs, int64_t *tol_out, int64_t *bitlen_out);
+/* The two halves around np.argsort for a message urhgpu_msg_bit_lengths reported as -2 (equal counts in the divisor histogram: the
+ * reference's result is whatever order np.argsort gives equal keys).  urhgpu_msg_divisor_histogram: tolerance, merged and rounded
+ * plateaus (AutoInterpretation.py:280-326), then the dense uint64 histogram the reference sorts (auto_interpretation.pyx:113-143):
+ * *hist_len = max value + 1 (cap = 0 only asks for it), -1 = fewer than two merged plateaus.  urhgpu_bit_length_from_order: the
+ * selection loop of get_bit_length_from_plateau_lengths (AutoInterpretation.py:358-370) over order_desc = np.argsort(hist)[::-1]. */
+int urhgpu_msg_divisor_histogram(const uint64_t *lens, int64_t n, uint64_t *hist_out, int64_t cap, int64_t *hist_len, int64_t *tol_out);
+int urhgpu_bit_length_from_order(const uint64_t *hist, const int64_t *order_desc, int64_t len, int64_t *bitlen_out);
 
 /* Test hook: the hot kernel's fast-path division (Newton + residual chain without scaling) against the IEEE
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */

@@ -1,9 +1,12 @@
-"""Host-side decision logic of urh_amd/estimators.py (no GPU involved) against the reference's own functions
-(/root/reference: AutoInterpretation.py, auto_interpretation.pyx) on randomised plateau lengths / segments.
-Needs the oracle/_ref build; skipped where /root/reference is absent."""
+"""Host-side decision logic (no GPU involved) against the reference's own functions (/root/reference: AutoInterpretation.py,
+auto_interpretation.pyx) on randomised plateau lengths / segments: the library's native per-message decisions
+(urhgpu_msg_bit_lengths and the two halves around np.argsort), the array-form helpers of urh_amd/estimators.py, and the numpy
+restatements the gpu tests use as their comparison (tests/numpy_estimators.py).  Needs the oracle/_ref build; skipped where
+/root/reference is absent."""
 import numpy as np
 import pytest
 
+import numpy_estimators as ne
 from urh_amd import estimators as e
 
 
@@ -34,18 +37,39 @@ def test_plateau_logic_equals_reference(ref):
     for it in range(400):
         p = _plateaus(rng)
         tol_ref = AI.estimate_tolerance_from_plateau_lengths(p)
-        tol = e.estimate_tolerance_from_plateau_lengths(p)
+        tol = ne.estimate_tolerance_from_plateau_lengths(p)
         assert (tol_ref is None and tol is None) or int(tol_ref) == int(tol), (it, tol_ref, tol)
         for t in (0, 1, 3, 5, None):
             a = AI.merge_plateau_lengths(p.copy(), tolerance=t)
-            b = e.merge_plateau_lengths(p.copy(), tolerance=t)
+            b = ne.merge_plateau_lengths(p.copy(), tolerance=t)
             assert np.array_equal(np.asarray(a), np.asarray(b)), (it, t)
         if len(p):
-            assert np.array_equal(np.asarray(c_ai.get_threshold_divisor_histogram(p.copy())), e.get_threshold_divisor_histogram(p.copy())), it
+            assert np.array_equal(np.asarray(c_ai.get_threshold_divisor_histogram(p.copy())), ne.get_threshold_divisor_histogram(p.copy())), it
             assert np.array_equal(np.asarray(c_ai.merge_plateaus(p.copy(), 2, 50)), e.merge_plateaus(p.copy(), 2, 50)), it
         a, b = p.copy(), p.copy()
-        assert AI.get_bit_length_from_plateau_lengths(a) == e.get_bit_length_from_plateau_lengths(b), it
+        assert AI.get_bit_length_from_plateau_lengths(a) == ne.get_bit_length_from_plateau_lengths(b), it
         assert np.array_equal(a, b)                              # rounded in place the same way
+        # the product: the per-message chain of AutoInterpretation.estimate (:416-433) natively, ties through np.argsort
+        merged = AI.merge_plateau_lengths(p.copy(), tolerance=0 if tol_ref is None else tol_ref)
+        want_len = AI.get_bit_length_from_plateau_lengths(np.array(merged, dtype=np.uint64)) if len(merged) >= 2 else None
+        got_tol, got_len = e.bit_length_of_message(p.copy())
+        assert (tol_ref is None and got_tol is None) or int(tol_ref) == int(got_tol), (it, tol_ref, got_tol)
+        assert (want_len is None and got_len is None) or int(want_len) == int(got_len), (it, want_len, got_len)
+        got_tol2, got_len2 = e._bit_length_with_numpy_order(p.copy())      # the tie path gives the same on every message
+        assert (got_tol2, got_len2) == (got_tol, got_len), it
+
+
+def test_peaks_center_equals_reference_walk(ref):
+    """estimators.peaks_center (array form, used where np.argsort has to break a tie) against the reference's loop over
+    np.argsort(y)[::-1] (AutoInterpretation.py:250-277, restated in numpy_estimators.center_from_histogram)"""
+    rng = np.random.default_rng(5)
+    for it in range(500):
+        nb = int(rng.integers(1, 120))
+        y = rng.integers(0, int(rng.choice([2, 5, 1000])), nb)
+        edges = np.cumsum(rng.random(nb + 1))
+        want = ne.center_from_histogram(y, edges)
+        got = e.peaks_center(y, edges)
+        assert (want is None and got is None) or float(want) == float(got), (it, y.tolist())
 
 
 def test_segment_and_value_helpers_equal_reference(ref):
@@ -69,9 +93,10 @@ def test_segment_and_value_helpers_equal_reference(ref):
         vals = [int(v) for v in rng.integers(0, 6, int(rng.integers(0, 12)))]
         assert AI.get_most_frequent_value(list(vals)) == e.get_most_frequent_value(list(vals)), vals
         d = rng.standard_normal(int(rng.integers(0, 20)))
-        for fn in ("max_without_outliers", "min_without_outliers"):
-            x, y = getattr(AI, fn)(d), getattr(e, fn)(d)
-            assert (x is None and y is None) or x == y
+        for fn, red, z in (("max_without_outliers", np.max, 3), ("min_without_outliers", np.min, 2)):
+            x = getattr(AI, fn)(d)
+            inl = e._inliers(d, z)
+            assert (x is None and len(inl) == 0) or x == red(inl)
 
 
 def test_median_filter_equals_reference(ref):
@@ -81,7 +106,7 @@ def test_median_filter_equals_reference(ref):
         x = rng.standard_normal(n) * rng.choice([1e-3, 1.0, 1e6])
         for k in (1, 2, 3, 11, 12):
             want = c_ai.median_filter(x, k=k)
-            got = e.median_filter(x, k=k)
+            got = ne.median_filter(x, k=k)
             assert got.dtype == want.dtype and np.array_equal(got, want), (n, k)
 
 
@@ -104,9 +129,9 @@ def test_detect_modulation_equals_reference(ref):
         noise = AI.detect_noise_level(arr.magnitudes)
         segs = AI.segment_messages_from_magnitudes(arr.magnitudes, noise_threshold=noise)
         cplx = arr.as_complex64()
-        assert np.array_equal(e._as_complex64(iq).view(np.uint32), cplx.view(np.uint32)), f
+        assert np.array_equal(ne._as_complex64(iq).view(np.uint32), cplx.view(np.uint32)), f
         for start, end in segs[:100]:
-            assert e.detect_modulation(cplx[start:end]) == AI.detect_modulation(cplx[start:end]), (f, start, end)
+            assert ne.detect_modulation(cplx[start:end]) == AI.detect_modulation(cplx[start:end]), (f, start, end)
             n_checked += 1
     rng = np.random.default_rng(12)
     t = np.arange(4096)
@@ -114,6 +139,6 @@ def test_detect_modulation_equals_reference(ref):
                 np.exp(2j * np.pi * 0.05 * t + 1j * np.pi * np.repeat(rng.integers(0, 2, 64), 64)),
                 rng.standard_normal(4096) + 1j * rng.standard_normal(4096), np.zeros(100), np.ones(3)):
         msg = (msg + 0.01 * (rng.standard_normal(len(msg)) + 1j * rng.standard_normal(len(msg))) * (np.abs(msg) > 0)).astype(np.complex64)
-        assert e.detect_modulation(msg) == AI.detect_modulation(msg)
+        assert ne.detect_modulation(msg) == AI.detect_modulation(msg)
         n_checked += 1
     assert n_checked > 20

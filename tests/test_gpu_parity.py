@@ -880,6 +880,7 @@ def test_detect_modulation_on_device(pipe):
     zeros, tiny and empty ones; the messages of the golden captures."""
     import torch
     import ref_python
+    import numpy_estimators
     from urh_amd import estimators
     ref_dm = None
     if ref_python.available():
@@ -917,7 +918,7 @@ def test_detect_modulation_on_device(pipe):
     labels, variances = estimators.detect_modulation_dev(pipe, dev, bounds, return_variances=True)
     seen = set()
     for k, (mm, lab) in enumerate(zip(msgs, labels)):
-        want = estimators.detect_modulation(mm.copy())
+        want = numpy_estimators.detect_modulation(mm.copy())
         assert lab == want, (k, len(mm), lab, want, variances[k])
         if ref_dm is not None:
             assert lab == ref_dm(mm.copy()), (k, len(mm))
@@ -927,8 +928,8 @@ def test_detect_modulation_on_device(pipe):
     for k in (5, 1):
         d = msgs[k][np.abs(msgs[k]) > 0]
         d = d / np.abs(np.max(d))
-        w1 = np.abs(estimators.cwt_haar(d, scale=4)); w2 = np.abs(estimators.cwt_haar(d / np.abs(d), scale=4))
-        want = [np.var(w1), np.var(w2), np.var(estimators.median_filter(w1, 11)), np.var(estimators.median_filter(w2, 11))]
+        w1 = np.abs(numpy_estimators.cwt_haar(d, scale=4)); w2 = np.abs(numpy_estimators.cwt_haar(d / np.abs(d), scale=4))
+        want = [np.var(w1), np.var(w2), np.var(numpy_estimators.median_filter(w1, 11)), np.var(numpy_estimators.median_filter(w2, 11))]
         assert np.allclose(variances[k], want, rtol=1e-4, atol=1e-9), (k, variances[k], want)
     # the golden captures: every message, device label == numpy label
     from urh_amd.pipeline import DevicePipeline
@@ -943,7 +944,7 @@ def test_detect_modulation_on_device(pipe):
             continue
         got = estimators.detect_modulation_dev(pipe, d, segs)
         cplx = iq.view(np.complex64).reshape(-1)
-        assert got == [estimators.detect_modulation(cplx[a:b].copy()) for a, b in segs], name
+        assert got == [numpy_estimators.detect_modulation(cplx[a:b].copy()) for a, b in segs], name
 
 
 def test_estimate_equals_reference_goldens(pipe):

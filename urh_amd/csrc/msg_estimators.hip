@@ -912,12 +912,8 @@ int64_t tolerance_of(const std::vector<uint64_t> &p) {
 
 int digits_of(uint64_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
 
-// get_bit_length_from_plateau_lengths (:344-370) on the merged lengths (rounded in place); -2: the outcome depends on how
-// np.argsort orders equal counts (the caller repeats that message in numpy)
-int64_t bit_length_of(std::vector<uint64_t> &m) {
-    if (m.empty()) return 0;
-    if (m.size() == 1) return (int64_t)m[0];
-    // round_plateau_lengths (:313-326): keep the median number of digits (at most 3); int(round(p / f)) * f, round = half to even
+// round_plateau_lengths (:313-326, in place): keep the median number of digits (at most 3); int(round(p / f)) * f, round = half to even
+void round_lengths(std::vector<uint64_t> &m) {
     size_t dhist[24] = {0};
     for (size_t i = 0; i < m.size(); ++i) ++dhist[digits_of(m[i])];
     auto kth = [&](size_t k) { size_t c = 0; for (int d = 0; d < 24; ++d) { c += dhist[d]; if (k < c) return d; } return 23; };   // k-th smallest digit count
@@ -928,7 +924,10 @@ int64_t bit_length_of(std::vector<uint64_t> &m) {
     double f = 1.0;
     for (int k = 1; k < n_digits; ++k) f *= 10.0;
     for (auto &v : m) v = (uint64_t)nearbyint((double)v / f) * (uint64_t)f;
-    // get_threshold_divisor_histogram (auto_interpretation.pyx:113-143) from the multiset of values
+}
+
+// get_threshold_divisor_histogram (auto_interpretation.pyx:113-143) from the multiset of values: the non-zero entries as (count, index)
+void divisor_histogram(const std::vector<uint64_t> &m, std::vector<std::pair<uint64_t, uint64_t>> &hist) {
     std::vector<uint64_t> vals(m);
     std::sort(vals.begin(), vals.end());
     std::vector<std::pair<uint64_t, uint64_t>> vc;              // (value, count), value != 0, ascending
@@ -939,7 +938,7 @@ int64_t bit_length_of(std::vector<uint64_t> &m) {
         i = j;
     }
     const double thr = (double)0.2f;
-    std::vector<std::pair<uint64_t, uint64_t>> hist;            // (count, index) for the non-zero entries
+    hist.clear();
     for (size_t a = 0; a < vc.size(); ++a) {
         uint64_t c = vc[a].second * (vc[a].second - 1) / 2;      // pairs of equal values: ratio 1
         for (size_t b = a + 1; b < vc.size(); ++b) {
@@ -948,6 +947,16 @@ int64_t bit_length_of(std::vector<uint64_t> &m) {
         }
         if (c) hist.push_back({c, vc[a].first});
     }
+}
+
+// get_bit_length_from_plateau_lengths (:344-370) on the merged lengths (rounded in place); -2: the outcome depends on how
+// np.argsort orders equal counts (the caller lets numpy order the histogram: urhgpu_msg_divisor_histogram / urhgpu_bit_length_from_order)
+int64_t bit_length_of(std::vector<uint64_t> &m) {
+    if (m.empty()) return 0;
+    if (m.size() == 1) return (int64_t)m[0];
+    round_lengths(m);
+    std::vector<std::pair<uint64_t, uint64_t>> hist;
+    divisor_histogram(m, hist);
     if (hist.empty()) return -2;                                // all counts zero: argsort's order of equal elements decides
     std::sort(hist.begin(), hist.end(), [](const std::pair<uint64_t, uint64_t> &x, const std::pair<uint64_t, uint64_t> &y) { return x.first > y.first; });
     const uint64_t max_count = hist[0].first;
@@ -959,6 +968,23 @@ int64_t bit_length_of(std::vector<uint64_t> &m) {
     }
     if (hist.size() > 1 && hist[1].first == max_count) return -2;
     return result;
+}
+
+// tolerance + merged plateaus of one message (AutoInterpretation.py:416-420); false: the tolerance is undefined
+bool merged_lengths(const uint64_t *lens, int64_t n, int64_t *tol_out, std::vector<uint64_t> &merged) {
+    std::vector<uint64_t> p(lens, lens + n);
+    const int64_t tol = tolerance_of(p);
+    *tol_out = tol;
+    if (tol == -2) return false;
+    if (tol > 0) {
+        merged.resize(p.size());
+        int64_t k = 0;
+        if (!p.empty()) (void)urhgpu_merge_plateaus(p.data(), (int64_t)p.size(), (uint64_t)tol, 10000, merged.data(), &k);
+        merged.resize((size_t)k);
+    } else {
+        merged.swap(p);
+    }
+    return true;
 }
 
 }  // namespace
@@ -1030,23 +1056,49 @@ int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs,
     }
     auto one = [&](int m) {
         const int64_t a = off[m] < 0 ? -off[m] - 1 : off[m], b = off[m + 1] < 0 ? -off[m + 1] - 1 : off[m + 1];
-        std::vector<uint64_t> p(lens + a, lens + b);
-        const int64_t tol = tolerance_of(p);
-        tol_out[m] = tol;
-        if (tol == -2) { bitlen_out[m] = -2; return; }
         std::vector<uint64_t> merged;
-        if (tol > 0) {
-            merged.resize(p.size());
-            int64_t k = 0;
-            if (!p.empty()) (void)urhgpu_merge_plateaus(p.data(), (int64_t)p.size(), (uint64_t)tol, 10000, merged.data(), &k);
-            merged.resize((size_t)k);
-        } else {
-            merged.swap(p);
-        }
+        if (!merged_lengths(lens + a, b - a, &tol_out[m], merged)) { bitlen_out[m] = -2; return; }
         bitlen_out[m] = merged.size() < 2 ? -1 : bit_length_of(merged);
     };
     // the messages are independent: a few host threads when there are many of them (a sort of a few thousand values each)
     host_pool_run(n_msgs, n_msgs >= 16 ? 24 : 1, one);
+    return URHGPU_OK;
+}
+
+// The two halves around np.argsort for a message whose bit length urhgpu_msg_bit_lengths could not decide (-2: equal counts in the
+// divisor histogram, where the reference's result is whatever order np.argsort gives equal keys).
+//   urhgpu_msg_divisor_histogram: tolerance, merged and rounded plateaus, then the DENSE histogram the reference sorts
+//     (uint64[max value + 1], auto_interpretation.pyx:113-143).  *hist_len = its length (call with cap = 0 to ask), -1 = fewer than
+//     two merged plateaus (no histogram in the reference either).
+//   urhgpu_bit_length_from_order: the selection loop of get_bit_length_from_plateau_lengths (AutoInterpretation.py:358-370) for the
+//     caller's order (= np.argsort(hist)[::-1]).
+int urhgpu_msg_divisor_histogram(const uint64_t *lens, int64_t n, uint64_t *hist_out, int64_t cap, int64_t *hist_len, int64_t *tol_out) {
+    if (n < 0 || !hist_len || !tol_out || (n > 0 && !lens) || cap < 0 || (cap > 0 && !hist_out)) return URHGPU_ERR_ARG;
+    std::vector<uint64_t> merged;
+    if (!merged_lengths(lens, n, tol_out, merged)) return URHGPU_ERR_UNSUPPORTED;
+    if (merged.size() < 2) { *hist_len = -1; return URHGPU_OK; }
+    round_lengths(merged);
+    const uint64_t mx = *std::max_element(merged.begin(), merged.end());
+    *hist_len = (int64_t)mx + 1;
+    if (cap < *hist_len) return cap == 0 ? URHGPU_OK : URHGPU_ERR_CAPACITY;
+    std::vector<std::pair<uint64_t, uint64_t>> hist;
+    divisor_histogram(merged, hist);
+    std::fill(hist_out, hist_out + *hist_len, 0ull);
+    for (const auto &e : hist) hist_out[e.second] = e.first;
+    return URHGPU_OK;
+}
+
+int urhgpu_bit_length_from_order(const uint64_t *hist, const int64_t *order_desc, int64_t len, int64_t *bitlen_out) {
+    if (len < 0 || !bitlen_out || (len > 0 && (!hist || !order_desc))) return URHGPU_ERR_ARG;
+    if (len == 0) { *bitlen_out = 0; return URHGPU_OK; }
+    for (int64_t i = 0; i < len; ++i) if (order_desc[i] < 0 || order_desc[i] >= len) return URHGPU_ERR_ARG;
+    const uint64_t max_count = hist[order_desc[0]];
+    int64_t result = order_desc[0];
+    for (int64_t i = 1; i < len; ++i) {
+        if ((double)hist[order_desc[i]] < 0.25 * (double)max_count) break;
+        if ((double)order_desc[i] <= 0.5 * (double)result) result = order_desc[i];
+    }
+    *bitlen_out = result;
     return URHGPU_OK;
 }
 

@@ -192,7 +192,7 @@ def merge_message_segments_for_ook(segments: list):
     seg = np.asarray(segments, dtype=np.int64).reshape(-1, 2)
     pauses = (seg[1:, 0] - seg[:-1, 1]).astype(np.uint64)
     pulses = (seg[:, 1] - seg[:, 0]).astype(np.uint64)
-    min_pulse_length = min_without_outliers(pulses, z=1)
+    min_pulse_length = _inliers(pulses, 1).min()
     cut = np.nonzero(pauses >= 8 * min_pulse_length)[0] + 1           # a new message starts after every long pause
     first = np.concatenate([[0], cut])
     last = np.concatenate([cut, [len(seg)]]) - 1
@@ -200,18 +200,10 @@ def merge_message_segments_for_ook(segments: list):
     return merged if isinstance(segments, np.ndarray) else _as_tuples(merged)
 
 
-def max_without_outliers(data: np.ndarray, z=3):
-    """AutoInterpretation.py:14-18"""
-    if len(data) == 0:
-        return None
-    return np.max(data[abs(data - np.mean(data)) <= z * np.std(data)])
-
-
-def min_without_outliers(data: np.ndarray, z=2):
-    """AutoInterpretation.py:21-25"""
-    if len(data) == 0:
-        return None
-    return np.min(data[abs(data - np.mean(data)) <= z * np.std(data)])
+def _inliers(data: np.ndarray, z: float) -> np.ndarray:
+    """the values within z standard deviations of the mean (what max_ / min_without_outliers reduce over, AutoInterpretation.py:14-25)"""
+    data = np.asarray(data)
+    return data[np.abs(data - data.mean()) <= z * data.std()] if len(data) else data
 
 
 def get_most_frequent_value(values: list):
@@ -266,27 +258,28 @@ def detect_center_dev(pipe, rect, max_size=None, _single=False):
     d_counts = torch.empty(len(edges) - 1, dtype=torch.int64, device=x.device)
     _lib.check(lib.urhgpu_histogram_f32_dev(h, C.c_void_p(r.data_ptr()), m, C.c_void_p(d_edges.data_ptr()), len(edges),
                                             C.c_void_p(d_counts.data_ptr())))
-    return center_from_histogram(d_counts.cpu().numpy(), edges)
+    return peaks_center(d_counts.cpu().numpy(), edges)
 
 
-def center_from_histogram(y: np.ndarray, x: np.ndarray):
-    """The peak picking of detect_center (AutoInterpretation.py:250-277): up to two bins, most populated first, that are
-    strict maxima over +-(window-1) bins; the center is the mean of their left edges."""
-    num_values = 2
-    window_size = max(2, int(0.05 * len(y)) + 1)
-    levels = []
-    ny = len(y)
-    for index in np.argsort(y)[::-1]:
-        lo, hi = max(0, index - (window_size - 1)), min(ny, index + window_size)
-        around = np.concatenate([y[lo:index], y[index + 1:hi]])
-        # neighbours outside the histogram count as 0, so a bin with count 0 is never a strict maximum
-        if y[index] > 0 and (len(around) == 0 or y[index] > around.max()):
-            levels.append(x[index])
-        if len(levels) == num_values:
-            break
-    if len(levels) == 0:
+def peaks_center(counts: np.ndarray, edges: np.ndarray):
+    """detect_center's pick (AutoInterpretation.py:250-277) from a histogram: the two most populated bins that are strict maxima
+    over +-(window - 1) bins (bins outside the histogram count as 0), mean of their left edges; None without such a bin.  Written
+    on whole arrays: peak mask from shifted comparisons, candidates taken in the order np.argsort gives the bins (the reference's
+    walk order, which is what decides between equally populated peaks)."""
+    y = np.asarray(counts, dtype=np.int64)
+    nb = len(y)
+    if nb == 0:
         return None
-    return np.mean(levels)
+    reach = max(2, int(0.05 * nb) + 1) - 1
+    padded = np.concatenate([np.zeros(reach, np.int64), y, np.zeros(reach, np.int64)])
+    peak = y > 0
+    for d in range(1, reach + 1):
+        peak &= (y > padded[reach - d:reach - d + nb]) & (y > padded[reach + d:reach + d + nb])
+    if not peak.any():
+        return None
+    walk = np.argsort(counts)[::-1]
+    chosen = walk[peak[walk]][:2]
+    return np.mean(np.asarray(edges)[chosen])
 
 
 def get_plateau_lengths_dev(pipe, rect, center, percentage=25) -> np.ndarray:
@@ -324,22 +317,6 @@ def get_plateau_lengths_dev(pipe, rect, center, percentage=25) -> np.ndarray:
 
 
 # ---- host decisions on plateau lengths (a few thousand integers per message) ---------------------------------------------
-def estimate_tolerance_from_plateau_lengths(plateau_lengths, relative_max=0.05):
-    """AutoInterpretation.py:280-298: the largest "tiny" plateau length, i.e. below 5 % of the outlier-free maximum."""
-    if len(plateau_lengths) <= 1:
-        return None
-    unique = np.unique(plateau_lengths)
-    limit = relative_max * max_without_outliers(unique, z=2)
-    if unique[0] > 1 and unique[0] >= limit:
-        return 0
-    result = 0
-    for value in unique:
-        if value > 1 and value >= limit:
-            break
-        result = value
-    return result
-
-
 def merge_plateaus(plateaus, tolerance, max_count=10000) -> np.ndarray:
     """auto_interpretation.merge_plateaus (auto_interpretation.pyx:145-176): plateaus <= tolerance are glitches and are
     merged with their neighbours (looking ahead over alternating glitches); at most max_count merged plateaus.
@@ -350,174 +327,6 @@ def merge_plateaus(plateaus, tolerance, max_count=10000) -> np.ndarray:
     _lib.check(_lib.load().urhgpu_merge_plateaus(p.ctypes.data_as(C.c_void_p), len(p), int(tolerance), int(max_count),
                                                  out.ctypes.data_as(C.c_void_p), C.byref(n_out)))
     return out[:n_out.value]
-
-
-def merge_plateau_lengths(plateau_lengths, tolerance=None):
-    """AutoInterpretation.py:301-310"""
-    if tolerance is None:
-        tolerance = estimate_tolerance_from_plateau_lengths(plateau_lengths)
-    if tolerance == 0 or tolerance is None:
-        return plateau_lengths
-    return merge_plateaus(plateau_lengths, tolerance, max_count=10000)
-
-
-def round_plateau_lengths(plateau_lengths):
-    """AutoInterpretation.py:313-326 (in place): round to the leading digits, e.g. 99 -> 100, 293 -> 300.  The number of kept
-    digits is the median decimal length (at most 3); int(round(p / f)) * f with Python's round = half-to-even on the double quotient."""
-    p = np.asarray(plateau_lengths, dtype=np.uint64)
-    digit_counts = np.searchsorted(_POW10, p, side="right") + 1                 # len(str(p))
-    n_digits = min(3, int(np.percentile(digit_counts, 50)))
-    f = 10 ** (n_digits - 1)
-    plateau_lengths[:] = (np.rint(p / f).astype(np.uint64) * np.uint64(f)).astype(np.asarray(plateau_lengths).dtype)
-
-
-_POW10 = np.array([10 ** k for k in range(1, 20)], dtype=np.uint64)
-
-
-def get_threshold_divisor_histogram(plateau_lengths, threshold=0.2) -> np.ndarray:
-    """auto_interpretation.get_threshold_divisor_histogram (auto_interpretation.pyx:113-143): histogram[min(x, y)] += 1
-    for every pair (i < j) whose ratio max / min has a fractional part below `threshold` (float32 threshold, double ratio).
-
-    The reference walks all P^2 / 2 pairs; the outcome of a pair depends on its two VALUES only, and after
-    round_plateau_lengths there are few distinct ones, so the histogram is assembled from the value multiset:
-    c_a * c_b pairs for distinct values a < b that pass the test, c_a * (c_a - 1) / 2 pairs of equal values (ratio 1)."""
-    p = np.asarray(plateau_lengths, dtype=np.uint64)
-    hist = np.zeros(int(np.max(p)) + 1, dtype=np.uint64)
-    vals, counts = np.unique(p[p != 0], return_counts=True)
-    if len(vals) == 0:
-        return hist
-    thr = float(np.float32(threshold))
-    c = counts.astype(np.uint64)
-    hist[vals.astype(np.int64)] += c * (c - np.uint64(1)) // np.uint64(2)
-    if len(vals) > 1:
-        lo = vals[:, None]                                     # vals ascending: row a < column b above the diagonal
-        hi = vals[None, :]
-        frac = hi.astype(np.float64) / lo.astype(np.float64) - (hi // lo).astype(np.float64)
-        ok = np.triu(frac < thr, k=1)
-        hist[vals.astype(np.int64)] += (ok * c[None, :]).sum(axis=1, dtype=np.uint64) * c
-    return hist
-
-
-def get_bit_length_from_plateau_lengths(merged_plateau_lengths) -> int:
-    """AutoInterpretation.py:344-370"""
-    if len(merged_plateau_lengths) == 0:
-        return 0
-    if len(merged_plateau_lengths) == 1:
-        return int(merged_plateau_lengths[0])
-    round_plateau_lengths(merged_plateau_lengths)
-    histogram = get_threshold_divisor_histogram(merged_plateau_lengths)
-    if len(histogram) == 0:
-        return 0
-    sorted_indices = np.argsort(histogram)[::-1]
-    max_count = histogram[sorted_indices[0]]
-    result = sorted_indices[0]
-    for i in range(1, len(sorted_indices)):
-        if histogram[sorted_indices[i]] < 0.25 * max_count:
-            break
-        if sorted_indices[i] <= 0.5 * result:
-            result = sorted_indices[i]
-    return int(result)
-
-
-# ---- modulation detection (host, like the reference: numpy on the first 100 messages) -----------------------------
-def median_filter(data, k: int = 3) -> np.ndarray:
-    """auto_interpretation.median_filter (auto_interpretation.pyx:213-240): float32 result; the window of sample i is
-    data[i : i + k] cut at the end of the array (`start` is computed and ignored, :233-238), values rounded to float32
-    before the sort, result = sorted[k' // 2]."""
-    x = np.asarray(data, dtype=np.float64).astype(np.float32)
-    n = len(x)
-    out = np.zeros(n, dtype=np.float32)
-    if n == 0:
-        return out
-    k = int(k)
-    full = n - k + 1
-    if full > 0:
-        win = np.lib.stride_tricks.sliding_window_view(x, k)
-        out[:full] = np.sort(win, axis=1)[:, k // 2]
-    for i in range(max(full, 0), n):
-        w = np.sort(x[i:n])
-        out[i] = w[len(w) // 2]
-    return out
-
-
-def normalized_haar_wavelet(omega, scale):
-    """Wavelet.normalized_haar_wavelet (Wavelet.py:7-12)"""
-    omega_cpy = omega[:] / scale
-    omega_cpy[0] = 1.0
-    return (1j * np.square(-1 + np.exp(0.5j * omega))) / omega_cpy
-
-
-def cwt_haar(x: np.ndarray, scale=10):
-    """Wavelet.cwt_haar (Wavelet.py:15-43)"""
-    next_power_two = 2 ** int(np.log2(len(x)))
-    x = x[0:next_power_two]
-    num_data = len(x)
-    x_hat = np.fft.fft(x)
-    f = 2.0 * np.pi / num_data
-    omega = f * np.concatenate((np.arange(0, num_data // 2), np.arange(num_data // 2, num_data) * -1))
-    psi_hat = np.sqrt(2.0 * np.pi * scale) * normalized_haar_wavelet(scale * omega, scale)
-    W = np.fft.ifft(x_hat * psi_hat)
-    return W[2 * scale:-2 * scale]
-
-
-def detect_modulation(data: np.ndarray, wavelet_scale=4, median_filter_order=11):
-    """AutoInterpretation.detect_modulation (AutoInterpretation.py:150-205) for ONE message (complex64 samples on the host)."""
-    n_data = len(data)
-    data = data[np.abs(data) > 0]
-    if len(data) == 0:
-        return None
-    if n_data - len(data) > 3:
-        return "OOK"
-    data = data / np.abs(np.max(data))
-    mag_wavlt = np.abs(cwt_haar(data, scale=wavelet_scale))
-    if len(mag_wavlt) == 0:
-        return None
-    norm_mag_wavlt = np.abs(cwt_haar(data / np.abs(data), scale=wavelet_scale))
-    var_mag = np.var(mag_wavlt)
-    var_norm_mag = np.var(norm_mag_wavlt)
-    var_filtered_mag = np.var(median_filter(mag_wavlt, k=median_filter_order))
-    var_filtered_norm_mag = np.var(median_filter(norm_mag_wavlt, k=median_filter_order))
-    if all(v < 0.15 for v in (var_mag, var_norm_mag, var_filtered_mag, var_filtered_norm_mag)):
-        return "OOK"
-    if var_mag > 1.5 * var_norm_mag:
-        return "ASK"
-    if var_mag > 10 * var_filtered_mag:
-        return "PSK"
-    fft = np.fft.fft(data[0:2 ** int(np.log2(len(data)))])
-    fft = np.abs(np.fft.fftshift(fft))
-    ten_greatest_indices = np.argsort(fft)[::-1][0:10]
-    greatest_index = ten_greatest_indices[0]
-    min_distance = 10
-    min_freq = 100
-    if any(abs(i - greatest_index) >= min_distance and fft[i] >= min_freq for i in ten_greatest_indices):
-        return "FSK"
-    return "OOK"
-
-
-def most_common(values: list):
-    """AutoInterpretation.most_common (:50-57): ties go to the value that appears first"""
-    from collections import Counter
-    counter = Counter(values)
-    return max(values, key=counter.get)
-
-
-def _as_complex64(iq_host: np.ndarray) -> np.ndarray:
-    """IQArray.as_complex64 (IQArray.py:92-93) = convert_to(np.float32) (:127-185) viewed as complex64: integer captures are
-    scaled with the reference's float32 operations (multiply by 1/128 or 1/32768, unsigned types then add -1)."""
-    a = iq_host
-    if a.dtype == np.float32:
-        f = a
-    elif a.dtype == np.uint8:
-        f = np.add(np.multiply(a, 1 / 128, dtype=np.float32), -1.0, dtype=np.float32)
-    elif a.dtype == np.int8:
-        f = np.multiply(a, 1 / 128, dtype=np.float32)
-    elif a.dtype == np.uint16:
-        f = np.add(np.multiply(a, 1 / 32768, dtype=np.float32), -1.0, dtype=np.float32)
-    elif a.dtype == np.int16:
-        f = np.multiply(a, 1 / 32768, dtype=np.float32)
-    else:
-        raise ValueError("Unsupported dtype")
-    return np.ascontiguousarray(f).flatten(order="C").view(np.complex64)
 
 
 _MOD_LABELS = (None, "OOK", "ASK", "FSK", "PSK")
@@ -546,20 +355,20 @@ def detect_modulation_dev(pipe, iq, message_indices, wavelet_scale=4, median_fil
 
 
 def detect_modulation_for_messages_dev(iq, message_indices: list, pipe=None):
-    """AutoInterpretation.detect_modulation_for_messages (:208-223): the most common label of the first 100 messages.  With a
-    pipeline the messages are classified on the GPU; without one they are copied to the host and classified with numpy."""
-    max_messages = 100
-    if pipe is not None:
-        mods = [m for m in detect_modulation_dev(pipe, iq, list(message_indices[0:max_messages])) if m is not None]
-    else:
-        mods = []
-        for start, end in message_indices[0:max_messages]:
-            mod = detect_modulation(_as_complex64(iq[start:end].cpu().numpy()))
-            if mod is not None:
-                mods.append(mod)
-    if len(mods) == 0:
+    """AutoInterpretation.detect_modulation_for_messages (:208-223): the most common label of the first 100 messages, classified on
+    the GPU (urhgpu_detect_modulation_dev); among equally common labels the one that occurs first wins, as max() over the list does
+    in the reference (:50-57)."""
+    if pipe is None:
+        from .pipeline import DevicePipeline
+        pipe = DevicePipeline(iq.device.index)
+    labels = [m for m in detect_modulation_dev(pipe, iq, list(message_indices[0:100])) if m is not None]
+    if not labels:
         return None
-    return most_common(mods)
+    votes = {}
+    for position, label in enumerate(labels):
+        count, first = votes.get(label, (0, position))
+        votes[label] = (count + 1, first)
+    return min(votes, key=lambda label: (-votes[label][0], votes[label][1]))
 
 
 def centers_batched(pipe, data, message_indices, max_bins: int = 4096):
@@ -596,7 +405,7 @@ def centers_batched(pipe, data, message_indices, max_bins: int = 4096):
         if len(edges) != n_edges or edges[0] != stats[m, 7]:                    # cannot happen; never bin against other edges silently
             centers[m] = detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True)
         else:
-            centers[m] = center_from_histogram(hist[m, :n_edges - 1], edges)
+            centers[m] = peaks_center(hist[m, :n_edges - 1], edges)
     return centers
 
 
@@ -642,14 +451,30 @@ def plateau_lengths_batched(pipe, data, message_indices, centers, percentage: in
     return out
 
 
+def _bit_length_with_numpy_order(plateau_lengths):
+    """(tolerance or None, bit_length or None) of a message whose divisor histogram holds equal counts: the library builds the
+    histogram (urhgpu_msg_divisor_histogram), numpy orders it -- the reference's result is whatever np.argsort does with equal keys --
+    and the library applies the selection rule to that order (urhgpu_bit_length_from_order)."""
+    lib = _lib.load()
+    p = np.ascontiguousarray(plateau_lengths, dtype=np.uint64)
+    hist_len, tol = C.c_int64(0), C.c_int64(0)
+    _lib.check(lib.urhgpu_msg_divisor_histogram(p.ctypes.data_as(C.c_void_p), len(p), None, 0, C.byref(hist_len), C.byref(tol)))
+    tolerance = None if tol.value < 0 else tol.value
+    if hist_len.value < 0:
+        return tolerance, None
+    hist = np.zeros(hist_len.value, dtype=np.uint64)
+    _lib.check(lib.urhgpu_msg_divisor_histogram(p.ctypes.data_as(C.c_void_p), len(p), hist.ctypes.data_as(C.c_void_p), len(hist),
+                                                C.byref(hist_len), C.byref(tol)))
+    order = np.ascontiguousarray(np.argsort(hist)[::-1], dtype=np.int64)
+    out = C.c_int64(0)
+    _lib.check(lib.urhgpu_bit_length_from_order(hist.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p), len(hist), C.byref(out)))
+    return tolerance, out.value
+
+
 def bit_length_of_message(plateau_lengths):
     """(tolerance or None, bit_length or None) of one message from its plateau lengths: glitch tolerance, merged plateaus,
     divisor histogram (AutoInterpretation.py:416-433)."""
-    tolerance = estimate_tolerance_from_plateau_lengths(plateau_lengths)
-    merged = merge_plateau_lengths(plateau_lengths, tolerance=0 if tolerance is None else tolerance)
-    if len(merged) < 2:
-        return tolerance, None
-    return tolerance, get_bit_length_from_plateau_lengths(merged)
+    return bit_lengths_batched([np.asarray(plateau_lengths, dtype=np.uint64)])[0]
 
 
 def _bit_lengths_raw(lens, off, plateaus_of):
@@ -663,14 +488,14 @@ def _bit_lengths_raw(lens, off, plateaus_of):
                                                   tol.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p)))
     out = [(None if t < 0 else t, None if b < 0 else b) for t, b in zip(tol.tolist(), bl.tolist())]
     for m in np.nonzero((bl == -2) | (tol == -2))[0].tolist():
-        out[m] = bit_length_of_message(np.array(plateaus_of(m), dtype=np.uint64))
+        out[m] = _bit_length_with_numpy_order(np.array(plateaus_of(m), dtype=np.uint64))
     return out
 
 
 def bit_lengths_batched(all_plateaus):
     """[(tolerance or None, bit_length or None)] for every message from its plateau lengths: the native batch call
     (urhgpu_msg_bit_lengths: tolerance, merged plateaus, rounded lengths, divisor histogram from the value multiset, decision); a
-    message whose decision hangs on how np.argsort orders equal counts is repeated in numpy (bit_length_of_message)."""
+    message whose decision hangs on how np.argsort orders equal counts gets its histogram ordered by numpy (_bit_length_with_numpy_order)."""
     n_msgs = len(all_plateaus)
     if n_msgs == 0:
         return []
@@ -741,30 +566,25 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
     else:
         lap("plateaus_ms")
         decisions = _bit_lengths_raw(lens, off, lambda m: lens[int(off[m]):int(off[m + 1])])
-    centers, bit_lengths, tolerances = [], [], []
-    for center, (tolerance, bit_length) in zip(all_centers, decisions):
-        if center is None:
-            continue
-        if tolerance is not None:
-            tolerances.append(tolerance)
-        if bit_length is not None and bit_length > (tolerance or 0) + 1:
-            centers.append(center)
-            bit_lengths.append(bit_length)
+    # the votes (AutoInterpretation.py:407-470) on arrays: a message with a center contributes its tolerance; it votes for a center and
+    # a bit length when its merged plateaus gave a bit length above tolerance + 1
+    has_center = np.array([c is not None for c in all_centers], dtype=bool)
+    center_of = np.array([np.nan if c is None else c for c in all_centers], dtype=np.float64)
+    tol_of = np.array([-1 if t is None else t for t, _ in decisions], dtype=np.int64)
+    len_of = np.array([-1 if b is None else b for _, b in decisions], dtype=np.int64)
+    tolerances = tol_of[has_center & (tol_of >= 0)]
+    votes = has_center & (len_of >= 0) & (len_of > np.maximum(tol_of, 0) + 1)
     lap("bit_lengths_host_ms")
+    if not votes.any():
+        return None
     if modulation in ("OOK", "ASK"):
-        center = min_without_outliers(np.array(centers), z=2)
-        if center is None:
-            return None
-    elif len(centers) > 0:
-        center = np.mean(centers)
+        center = _inliers(center_of[votes], 2).min()         # min_without_outliers(centers, z=2)
     else:
-        return None
-    bit_length = get_most_frequent_value(bit_lengths)
-    if bit_length is None:
-        return None
+        center = np.mean(center_of[votes])
+    bit_length = get_most_frequent_value(len_of[votes].tolist())
     try:
-        tolerance = np.percentile(tolerances, 50)
-    except IndexError:
+        tolerance = np.percentile(tolerances.tolist(), 50)
+    except IndexError:                                   # no message had a tolerance (older numpy raises on an empty list)
         tolerance = max(1, int(0.05 * bit_length))
     return {"modulation_type": "ASK" if modulation == "OOK" else modulation, "bit_length": bit_length, "center": center,
             "tolerance": int(tolerance), "noise": noise}
