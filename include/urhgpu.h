@@ -359,6 +359,9 @@ int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint
 /* Test hook: the branch-free sinf / cosf pair of the Costas loop (glibc_sincosf.h: urh_sincosf_fast) against the branchy restatement
  * of glibc's sinf and cosf for EVERY float with |y| < 120; *n_mismatch = arguments where either result differs in a bit. */
 int urhgpu_test_sincosf_fast_dev(urhgpu_ctx *ctx, uint64_t *n_mismatch);
+/* Test hook: urhgpu_message_ranges_dev reports every OOK merge as borderline (*merge_ambiguous = 1), so that the caller's numpy
+ * route for that case can be exercised; returns the previous setting. */
+int urhgpu_test_force_merge_ambiguous(int on);
 
 /* signal_functions.modulate_c (signal_functions.pyx:56-177) for ASK / FSK / PSK / OQPSK (URHGPU_MOD_OQPSK: bits_per_symbol must be 2; GFSK: urhgpu_modulate_gfsk*),
  * n_msgs messages rendered back to back by one launch (URH modulates message by message, Modulator.py:215-255):

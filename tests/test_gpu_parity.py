@@ -734,6 +734,34 @@ def test_message_ranges_ook_bursts(pipe, oracle):
     assert n_amb == 0                                   # the test captures are not borderline: the device decided all of them
 
 
+def test_estimate_takes_the_numpy_merge_when_the_device_merge_is_borderline(pipe):
+    """a pulse length within rounding of mean +- std makes urhgpu_message_ranges_dev hand the OOK merge to numpy: forced here, the
+    estimate must come out the same"""
+    import torch
+    from urh_amd import _lib, estimators
+    rng = np.random.default_rng(3)
+    n, sps = 600_000, 40
+    env = np.zeros(n, np.float32)
+    pos = 3000
+    while pos < n - 20_000:
+        bits = rng.integers(0, 2, 120); bits[0] = 1
+        sym = np.repeat(bits, sps).astype(np.float32)
+        env[pos:pos + len(sym)] = sym
+        pos += len(sym) + int(rng.integers(40, 200)) * sps
+    iq = (env * np.exp(2j * np.pi * 0.01 * np.arange(n))).astype(np.complex64) + \
+        (0.01 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))).astype(np.complex64)
+    dev = torch.from_numpy(np.ascontiguousarray(iq.view(np.float32).reshape(-1, 2))).cuda()
+    want = estimators.estimate_dev(pipe, dev, noise=0.1, modulation="OOK")
+    lib = _lib.load()
+    lib.urhgpu_test_force_merge_ambiguous(1)
+    try:
+        assert estimators.message_ranges_dev(pipe, dev, 0.1)[4] is True
+        got = estimators.estimate_dev(pipe, dev, noise=0.1, modulation="OOK")
+    finally:
+        lib.urhgpu_test_force_merge_ambiguous(0)
+    assert want is not None and got == want, (want, got)
+
+
 def test_segment_messages_equals_oracle(pipe, oracle):
     import torch
     from urh_amd import estimators
@@ -1213,6 +1241,17 @@ def test_fir_with_fused_noise_statistics(pipe, oracle):
         want_noise = oracle.detect_noise_level(oracle.get_magnitudes(want_f.view(np.float32).reshape(-1, 2)))
         assert float(noise) == float(want_noise), (n, noise, want_noise)
         assert n < 2_000_000 or noise > 0
+    # tiles with a huge sample go through the checked kernel (k_fir_fast hands them back), statistics epilogue included
+    n = 500_000
+    x = ((0.5 + 0.02 * rng.standard_normal(n)) * np.exp(2j * np.pi * 0.03 * np.arange(n))).astype(np.complex64)
+    x[: n // 10] *= 0.01
+    x[123_456] = np.float32(3e24)
+    x[400_000] = np.complex64(-2e22j)
+    dev = torch.from_numpy(x.view(np.float32).reshape(-1, 2)).cuda()
+    filt, noise = estimators.fir_filter_detect_noise_dev(pipe, dev, taps)
+    want_f = oracle.fir_filter(x, taps)
+    assert np.array_equal(filt.cpu().numpy().reshape(-1).view(np.uint32), want_f.view(np.uint32))
+    assert float(noise) == float(oracle.detect_noise_level(oracle.get_magnitudes(want_f.view(np.float32).reshape(-1, 2))))
 
 
 def test_sharded_fir_halo_then_bits(pipe, oracle):

@@ -104,6 +104,7 @@ PROTOTYPES = {
     "urhgpu_merge_plateaus": (_i, [_vp, _i64, C.c_uint64, C.c_uint64, _vp, C.POINTER(_i64)]),
     "urhgpu_test_fast_division_dev": (_i, [_vp, C.c_uint64, _i, C.POINTER(C.c_uint64)]),
     "urhgpu_test_sincosf_fast_dev": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "urhgpu_test_force_merge_ambiguous": (_i, [_i]),
     "urhgpu_modulate_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_uint32, _i, _vp, _i, _f, _f, _f, _f, _i, _vp, _i64, C.POINTER(_i64)]),
     "urhgpu_modulate": (_i, [_vp, _vp, _i64, C.c_uint32, _i, _vp, _i, _f, _f, _f, _f, C.c_uint32, C.c_uint32, _i, _vp]),
     "urhgpu_modulate_gfsk_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, C.c_uint32, _vp, _i, _f, _f, _f, _i, _vp, _i, _vp, _vp, _i64, C.POINTER(_i64)]),

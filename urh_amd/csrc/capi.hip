@@ -975,6 +975,12 @@ int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint
     return URHGPU_OK;
 }
 
+int urhgpu_test_force_merge_ambiguous(int on) {
+    const int was = urh::g_force_merge_ambiguous ? 1 : 0;
+    urh::g_force_merge_ambiguous = on != 0;
+    return was;
+}
+
 int urhgpu_test_sincosf_fast_dev(urhgpu_ctx *ctx, uint64_t *n_mismatch) {
     if (!ctx || !n_mismatch) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));

@@ -243,6 +243,7 @@ int pairwise_sum_f32(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, flo
 int launch_hist_edges(const float *x, int64_t n, const double *d_edges, int n_edges, int64_t *d_counts, hipStream_t s);
 // ---- msg_ranges.hip ------------------------------------------------------------------------------------------
 struct SegCtl;
+extern bool g_force_merge_ambiguous;    // test hook
 int launch_message_ranges(const int64_t *d_rows, const int64_t *d_n_rows, int64_t cap_rows, const void *d_iq, int dtype, int64_t n, float thr,
                           int ook_merge, int64_t *d_seg, int64_t *d_msgs, int64_t cap, SegCtl *d_ctl, void *scratch, hipStream_t s);
 size_t seg_scratch_bytes(int64_t cap_rows, int64_t cap);

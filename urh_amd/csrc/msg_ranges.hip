@@ -21,6 +21,8 @@
 
 namespace urh {
 
+bool g_force_merge_ambiguous = false;        // test hook (urhgpu_test_force_merge_ambiguous): report every OOK merge as borderline
+
 struct SegCtl {              // device control block
     int64_t n_seg;           // complete segments
     int64_t n_msgs;          // after the OOK merge (or n_seg)
@@ -214,7 +216,7 @@ size_t seg_scratch_bytes(int64_t cap_rows, int64_t cap) {
 size_t seg_ctl_bytes() { return sizeof(SegCtl); }
 void seg_ctl_read(const void *host_copy, int64_t *n_seg, int64_t *n_msgs, int *ambiguous) {
     const SegCtl *c = (const SegCtl *)host_copy;
-    *n_seg = c->n_seg; *n_msgs = c->n_msgs; *ambiguous = c->ambiguous;
+    *n_seg = c->n_seg; *n_msgs = c->n_msgs; *ambiguous = c->ambiguous | (g_force_merge_ambiguous ? 1 : 0);
 }
 
 }  // namespace urh
