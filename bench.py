@@ -580,7 +580,7 @@ def main():
         pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=args.pipeline), TorchDistComm())
         if args.fir_halo:
             from urh_amd.synth import spec_fir_taps
-            fir_taps = torch.from_numpy(spec_fir_taps().view("float32").copy()).to(dev)
+            fir_taps = torch.from_numpy(spec_fir_taps().view("float32").reshape(-1, 2).copy()).to(dev)     # (64, 2): 64 complex taps
     else:
         pipe = DevicePipeline(local_rank, pipelined=args.pipeline)
     pipe.reserve(n, p)

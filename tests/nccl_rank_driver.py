@@ -35,7 +35,7 @@ def main():
         pipe = ShardedPipeline(GpuShardEngine(local, pipelined=pipelined), TorchDistComm())
         assert pipe.world == world and pipe.rank == rank
         p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
-        d_taps = torch.from_numpy(taps.view(np.float32).copy()).to(dev)
+        d_taps = torch.from_numpy(taps.view(np.float32).reshape(-1, 2).copy()).to(dev)
         for _ in range(3 if pipelined else 1):
             filt = pipe.fir_filter(shard, d_taps)
             res = pipe.iq_to_bits(filt, p, want_qad=True, pos_base=a, n_total=n)

@@ -76,6 +76,8 @@ class GpuShardEngine(DevicePipeline):
         h = torch.view_as_real(taps) if taps.dtype == torch.complex64 else taps
         if x.dtype != torch.float32 or h.dtype != torch.float32 or not x.is_contiguous():
             raise ValueError("FIR needs contiguous float32 / complex64 samples and taps")
+        if h.dim() != 2 or h.shape[1] != 2:
+            raise ValueError("taps: complex64 (m,) or float32 (m, 2)")          # a flat float32 vector would be read as twice the taps
         h = h.contiguous()
         out = torch.empty_like(x)
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)

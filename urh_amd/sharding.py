@@ -122,7 +122,7 @@ class ShardedPipeline:
         (m-1) * 8 bytes per rank -- as history; rank 0 starts from zero history like the reference's fir_filter
         (signal_functions.pyx:513-525).  Returns the filtered shard (same shape as iq_local)."""
         e, c = self.engine, self.comm
-        m = int(taps.shape[0])
+        m = int(taps.shape[0])                     # complex64 (m,) or float32 (m, 2): rows = taps
         if m <= 1 or self.world == 1:
             return e.fir(iq_local, taps, None)
         if int(iq_local.shape[0]) < m - 1:
