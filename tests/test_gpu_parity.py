@@ -889,6 +889,13 @@ def test_batched_centers_dense_messages_and_tied_peaks(pipe, oracle):
                                                    4096, stats.ctypes.data_as(C.c_void_p), None, cen.ctypes.data_as(C.c_void_p),
                                                    flag.ctypes.data_as(C.c_void_p)))
     assert flag.tolist() == [1, 1, 1, 3, 0, 1] and stats[0, 0] == 100_000 and stats[2, 0] == 99_999 - 100
+    # a nearly constant message: variance 1e-8 over a range of 4e-4 -> 40 000 bins, more than the pool holds (flag 2): that message
+    # goes through the single-message path
+    flat = (1.0 + 1e-4 * rng.standard_normal(50_000)).astype(np.float32)
+    both = np.concatenate([qad[:100_000], flat])
+    got = estimators.centers_batched(pipe, torch.from_numpy(both).cuda(), [(0, 100_000), (100_000, 150_000)])
+    want = [oracle.detect_center(both[:100_000]), oracle.detect_center(flat)]
+    assert all((g is None and w is None) or float(g) == float(w) for g, w in zip(got, want)), (got, want)
 
 
 def test_branch_free_sincosf_equals_branchy_for_every_float_below_120(pipe):
