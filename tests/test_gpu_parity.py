@@ -1498,7 +1498,9 @@ def test_bandpass_device_equals_model(pipe):
     from test_bandpass_host import model_convolve
     from urh_amd import filter as uf
     rng = np.random.default_rng(8)
-    for n, m in [(1, 1), (5, 3), (1023, 7), (1024, 8), (1025, 9), (4097, 51), (20_000, 401), (3000, 4001), (70_000, 1001)]:
+    # (from 128 taps and 4096 outputs on: overlap-save through the LDS FFT, 4096 points up to 1025 taps, 8192 up to 4097)
+    for n, m in [(1, 1), (5, 3), (1023, 7), (1024, 8), (1025, 9), (4097, 51), (4096, 127), (4096, 128), (20_000, 401), (3000, 4001), (70_000, 1001),
+                 (30_000, 1025), (30_000, 1026), (60_000, 4001), (50_000, 4097), (20_000, 4098)]:
         x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
         h = rng.standard_normal(m) + 1j * rng.standard_normal(m)
         shift, n_out = (min(n, m) - 1) // 2, max(n, m)
@@ -1516,6 +1518,16 @@ def test_bandpass_device_equals_model(pipe):
     d_x = torch.from_numpy(x).to(pipe.device)
     whole = uf.convolve_dev(pipe, d_x, h, shift, n, out_complex64=False).cpu().numpy()
     cuts = [0, 17_001, 33_333, n]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        left = d_x[max(0, a - (m - 1 - shift)):a]
+        right = d_x[b:min(n, b + shift)]
+        part = uf.convolve_dev(pipe, d_x[a:b].contiguous(), h, shift, b - a, out_complex64=False, left=left, right=right).cpu().numpy()
+        # (the shards' FFT blocks start elsewhere than the whole capture's: equal to rounding, not bit for bit)
+        assert np.max(np.abs(part - whole[a:b])) <= float(np.sum(np.abs(h)) * np.max(np.abs(x))) * 2.0 ** -40, (a, b)
+    m = 51                                                     # the direct form (short filters) is position independent: bit for bit
+    h = rng.standard_normal(m) + 1j * rng.standard_normal(m)
+    shift = (m - 1) // 2
+    whole = uf.convolve_dev(pipe, d_x, h, shift, n, out_complex64=False).cpu().numpy()
     for a, b in zip(cuts[:-1], cuts[1:]):
         left = d_x[max(0, a - (m - 1 - shift)):a]
         right = d_x[b:min(n, b + shift)]

@@ -1421,9 +1421,12 @@ int urhgpu_bandpass_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const doub
         return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
     URH_TRY(join_tail(ctx));
+    URH_TRY(ctx->arena.reserve(bandpass_fft_work_bytes() + 1024));
+    ctx->arena.reset();
+    void *work = ctx->arena.take(bandpass_fft_work_bytes());
     URH_TRY(launch_bandpass((const float2 *)d_x, n, (const float2 *)d_left, n_left, (const float2 *)d_right, n_right,
                             (const double2 *)d_taps, (int)m, shift, n_out, out_c64 ? nullptr : (double2 *)d_out,
-                            out_c64 ? (float2 *)d_out : nullptr, ctx->stream));
+                            out_c64 ? (float2 *)d_out : nullptr, ctx->stream, work));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }

@@ -88,7 +88,9 @@ int launch_path_minmax(const void *samples, int dtype, int64_t start, int64_t en
 
 // ---- bandpass.hip ------------------------------------------------------------------------------------
 int launch_bandpass(const float2 *x, int64_t n, const float2 *left, int64_t n_left, const float2 *right, int64_t n_right,
-                    const double2 *taps, int m, int64_t shift, int64_t n_out, double2 *out128, float2 *out64, hipStream_t s);
+                    const double2 *taps, int m, int64_t shift, int64_t n_out, double2 *out128, float2 *out64, hipStream_t s,
+                    void *work = nullptr);
+size_t bandpass_fft_work_bytes();
 
 // ---- pulse_table.hip ---------------------------------------------------------------------------------
 // Scratch of the resolve stage: one entry per chunk (ints are chunk indices or -1).
