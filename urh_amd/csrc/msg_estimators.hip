@@ -306,8 +306,12 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
             const float nxt = (c0 + 64 + tid < n_chunks) ? cs[c0 + 64 + tid] : 0.f;
             const int nc = (int)((n_chunks - c0 < 64) ? n_chunks - c0 : 64);
             if (nc == 64) {
+                // all 64 terms into scalar registers first, then the dependent adds back to back
+                float sv[64];
 #pragma unroll
-                for (int c = 0; c < 64; ++c) total = total + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c));
+                for (int c = 0; c < 64; ++c) sv[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c));
+#pragma unroll
+                for (int c = 0; c < 64; ++c) total = total + sv[c];
             } else {
                 for (int c = 0; c < nc; ++c) total = total + __shfl(v, c);
             }
