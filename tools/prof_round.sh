@@ -12,6 +12,6 @@ tools/prof_cmd.sh ${TAG}_costas python $R/tools/costas_only.py > /dev/null 2>&1
 tools/prof_estimate.sh $TAG > gpurun_out/${TAG}_estimate.txt 2>&1
 python tools/deviation_probe.py 2>/dev/null | grep deviation > gpurun_out/${TAG}_deviation.txt
 python tools/dtype_probe.py 2>/dev/null | grep "ms/step" > gpurun_out/${TAG}_dtypes.txt
-(cd tools/kbench && timeout 120 ./vbench) > gpurun_out/${TAG}_vbench.txt 2>&1
+(cd tools/kbench && ([ -x vbench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 vbench.hip -o vbench) && timeout 120 ./vbench) > gpurun_out/${TAG}_vbench.txt 2>&1
 python bench.py --steps 50 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 ls gpurun_out | head -40
