@@ -13,6 +13,6 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD S
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU GRBM_GUI_ACTIVE SQ_INSTS_SMEM" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $set --kernel-include-regex "k_emit_rows_tiles|k_expand_tiles|k_resolve_one|k_scan_lookback" --output-format csv -d $OUT/pmc$i -o b -- python $R/bench.py $ARGS > $OUT/pmc$i.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $set --kernel-include-regex "k_emit_rows_tiles|k_expand_tiles|k_resolve_one|k_scan_lookback|k_tile_scan" --output-format csv -d $OUT/pmc$i -o b -- python $R/bench.py $ARGS > $OUT/pmc$i.log 2>&1
 done
 python $R/tools/pmc_summary.py $OUT | grep -v "^==" | awk '{print}' | sed 's/  */ /g' | sort | head -150

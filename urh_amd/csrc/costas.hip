@@ -343,40 +343,50 @@ __device__ __forceinline__ uint32_t map_compose(uint32_t later, uint32_t earlier
 // Exit: either all chunks are resolved, or -- when allow_break -- the chain broke for good (a chunk with plenty of
 // un-gated samples was evaluated serially to its end and met no candidate): stats[3] = the next chunk, *b.resume = its true
 // start state, and the host re-speculates the remaining chunks around that state's frequency.
+constexpr int kStitchBlock = 1024;              // 16 wavefronts: the fast-forward composes 4096 chunk maps per round
 template <int DT, int ORDER>
-__global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K, int64_t c_from,
-                                                       int allow_break) {
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(kStitchBlock) void k_costas_stitch(const CostasArgs a, SpecBuffers b, int64_t n_chunks, int K, int64_t c_from,
+                                                                 int allow_break) {
+    __shared__ uint32_t s_wp[kStitchBlock / 64];    // per-wavefront composition of its chunk maps
+    __shared__ int s_fail, s_cand, s_flags;         // first position where the chain ends; broadcast slots
+    __shared__ CostasState s_T;
+    __shared__ long long s_c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int cand = -1;                                  // candidate of chunk c - 1 that is the true trajectory, or -1
     CostasState T = *b.resume;                      // true state at the start of chunk c (valid while cand < 0)
-    if (c_from == 1) { cand = 0; if (lane == 0) { b.T[0] = CostasState{0.0f, 1.5f}; b.gidx[0] = 0; } }   // chunk 0: every candidate is exact
-    int n_map = 0, n_ckpt = 0, n_serial = 0;
+    if (c_from == 1) { cand = 0; if (tid == 0) { b.T[0] = CostasState{0.0f, 1.5f}; b.gidx[0] = 0; } }   // chunk 0: every candidate is exact
+    int n_map = 0, n_ckpt = 0, n_serial = 0;        // (kept identically by every thread in the fast-forward, by wavefront 0 below)
     int64_t stop_at = n_chunks;
     int64_t c = c_from;
     bool map_failed = false;                        // chunk c: the map already said that no candidate starts in T
-    while (c < n_chunks) {
-        while (cand >= 0 && c < n_chunks) {         // ---- fast-forward over up to 1024 chunks: 16 consecutive chunks per lane
-            constexpr int Q = 16;                                     // (4: 128 rounds of ~3 us for a 1 GiB capture; 16: 32 rounds of ~4.5 us)
-            const int64_t cc0 = c + (int64_t)Q * lane;
+    bool stop = false;
+    while (c < n_chunks && !stop) {
+        while (cand >= 0 && c < n_chunks) {         // ---- fast-forward over up to 4096 chunks: 4 consecutive chunks per thread
+            constexpr int Q = 4;
+            if (tid == 0) s_fail = 0x7fffffff;
+            const int64_t cc0 = c + (int64_t)Q * tid;
             uint32_t L[Q];                                            // L[q] = map[cc0 + q] o ... o map[cc0]
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const uint32_t m = (cc0 + q < n_chunks) ? b.map[cc0 + q] : 0xFFFFFFFFu;
                 L[q] = q ? map_compose(m, L[q - 1]) : m;
             }
-            uint32_t P = L[Q - 1];                                    // inclusive prefix composition over the lanes
+            uint32_t P = L[Q - 1];                                    // inclusive prefix composition over the lanes of the wavefront
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const uint32_t u = __shfl_up(P, o);
                 if (lane >= o) P = map_compose(P, u);
             }
-            uint32_t X = __shfl_up(P, 1);                             // everything before my first chunk
-            if (lane == 0) X = 0x76543210u;                           // identity
+            if (lane == 63) s_wp[wave] = P;
+            __syncthreads();
+            uint32_t X = 0x76543210u;                                 // everything before my first chunk: the wavefronts before mine ...
+            for (int w = 0; w < wave; ++w) X = map_compose(s_wp[w], X);
+            const uint32_t before = __shfl_up(P, 1);                  // ... then the lanes before me
+            if (lane != 0) X = map_compose(before, X);
             uint32_t g[Q], gp[Q];
 #pragma unroll
             for (int q = 0; q < Q; ++q) g[q] = (map_compose(L[q], X) >> (4 * cand)) & 0xFu;   // candidate of chunk cc0 + q on the true trajectory
-            gp[0] = __shfl_up(g[Q - 1], 1);
-            if (lane == 0) gp[0] = (uint32_t)cand;
+            gp[0] = (X >> (4 * cand)) & 0xFu;
 #pragma unroll
             for (int q = 1; q < Q; ++q) gp[q] = g[q - 1];
             CostasState Tl[Q];
@@ -389,63 +399,79 @@ __global__ __launch_bounds__(64) void k_costas_stitch(const CostasArgs a, SpecBu
                 if (reach) { Tl[q] = b.E[(cc - 1) * K + gp[q]]; b.T[cc] = Tl[q]; b.gidx[cc] = (g[q] == 0xFu) ? -1 : (int32_t)g[q]; }
                 if (reach && g[q] == 0xFu) firstq = q;
             }
-            const unsigned long long fail = __ballot(firstq < Q);
-            if (fail == 0) {
-                const int64_t left = n_chunks - c;
-                const int total = (int)(left < 64 * Q ? left : 64 * Q);
-                const int ll = (total - 1) / Q, lq = (total - 1) % Q;
+            if (firstq < Q) atomicMin(&s_fail, tid * Q + firstq);
+            __syncthreads();
+            const int fail = s_fail;
+            const int64_t left = n_chunks - c;
+            const int total = (int)(left < (int64_t)kStitchBlock * Q ? left : (int64_t)kStitchBlock * Q);
+            const int pos = (fail == 0x7fffffff) ? total - 1 : fail;      // the chunk whose thread has the hand-over value
+            if (tid == pos / Q) {
+                const int qq = pos % Q;
                 uint32_t gl = g[0];
+                CostasState Ts = Tl[0];
 #pragma unroll
-                for (int q = 1; q < Q; ++q) if (lq == q) gl = g[q];
-                cand = (int)__shfl(gl, ll);
-                n_map += total; c += total;
-                continue;
+                for (int q = 1; q < Q; ++q) if (qq == q) { gl = g[q]; Ts = Tl[q]; }
+                s_cand = (int)gl; s_T = Ts;
             }
-            const int t = __builtin_ctzll(fail);
-            const int qf = __shfl(firstq, t);
-            CostasState Ts = Tl[0];
-#pragma unroll
-            for (int q = 1; q < Q; ++q) if (qf == q) Ts = Tl[q];
-            T.freq = __shfl(Ts.freq, t); T.phase = __shfl(Ts.phase, t);
-            n_map += Q * t + qf;
-            c += Q * t + qf; cand = -1; map_failed = true;
+            __syncthreads();
+            if (fail == 0x7fffffff) {
+                cand = s_cand;
+                n_map += total; c += total;
+            } else {
+                T = s_T;
+                n_map += fail; c += fail; cand = -1; map_failed = true;
+            }
+            __syncthreads();                                          // (s_fail / s_cand / s_T are rewritten by the next round)
         }
         if (c >= n_chunks) break;
-        // ---- chunk c without a carrying candidate: T is the true state at its start
-        if (!map_failed) {
-            if (lane == 0) { b.T[c] = T; b.gidx[c] = -1; }
-            const bool hit = lane < K && same_state(T, b.S[c * K + lane]);
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-                cand = __builtin_ctzll(m);
-                if (lane == 0) b.gidx[c] = cand;
-                ++n_map; ++c;
-                continue;
-            }
-        }
-        map_failed = false;
-        if (b.ungated[c] == 0) { ++n_serial; ++c; continue; }     // fully gated chunk: the state does not move
-        // no candidate starts in T: evaluate the chunk from T until the state meets a candidate at a checkpoint
-        const int64_t s0 = chunk_begin(c);
-        const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
-        float err = 0.0f;
-        CostasState st = T;
-        for (int64_t i = s0; i < e0; ++i) {
-            costas_step<DT == URHGPU_DT_F32, ORDER>(CostasLoad<DT>::at(a.iq, i), st, err, a);
-            const int off = (int)(i - s0) + 1;
-            if (off % kCkpt == 0 && off < kChunk) {
-                const bool hit = lane < K && b.is_rep[c * K + lane] && same_state(st, b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + lane]);
+        // ---- chunk c without a carrying candidate: T is the true state at its start.  One wavefront's work; the others wait.
+        if (wave == 0) {
+            bool done = false;
+            if (!map_failed) {
+                if (lane == 0) { b.T[c] = T; b.gidx[c] = -1; }
+                const bool hit = lane < K && same_state(T, b.S[c * K + lane]);
                 const unsigned long long m = __ballot(hit);
-                if (m) { cand = __builtin_ctzll(m); break; }
+                if (m) {
+                    cand = __builtin_ctzll(m);
+                    if (lane == 0) b.gidx[c] = cand;
+                    ++n_map; ++c;
+                    done = true;
+                }
             }
+            if (!done) {
+                map_failed = false;
+                if (b.ungated[c] == 0) { ++n_serial; ++c; done = true; }     // fully gated chunk: the state does not move
+            }
+            if (!done) {
+                // no candidate starts in T: evaluate the chunk from T until the state meets a candidate at a checkpoint
+                const int64_t s0 = chunk_begin(c);
+                const int64_t e0 = (s0 + kChunk < a.n) ? s0 + kChunk : a.n;
+                float err = 0.0f;
+                CostasState st = T;
+                for (int64_t i = s0; i < e0; ++i) {
+                    costas_step<DT == URHGPU_DT_F32, ORDER>(CostasLoad<DT>::at(a.iq, i), st, err, a);
+                    const int off = (int)(i - s0) + 1;
+                    if (off % kCkpt == 0 && off < kChunk) {
+                        const bool hit = lane < K && b.is_rep[c * K + lane] && same_state(st, b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + lane]);
+                        const unsigned long long m = __ballot(hit);
+                        if (m) { cand = __builtin_ctzll(m); break; }
+                    }
+                }
+                if (cand >= 0) { ++n_ckpt; ++c; }       // gidx[c] stays -1: only part of the chunk lies on the candidate
+                else {
+                    ++n_serial;
+                    T = st;                             // the state at the END of chunk c = start of chunk c + 1
+                    if (allow_break && b.ungated[c] >= kChunk / 2 && c + 1 < n_chunks) { stop_at = c + 1; stop = true; }
+                    else ++c;
+                }
+            }
+            if (lane == 0) { s_c = c; s_cand = cand; s_T = T; s_flags = (map_failed ? 1 : 0) | (stop ? 2 : 0); }
         }
-        if (cand >= 0) { ++n_ckpt; ++c; continue; }     // gidx[c] stays -1: only part of the chunk lies on the candidate
-        ++n_serial;
-        T = st;                                     // the state at the END of chunk c = start of chunk c + 1
-        if (allow_break && b.ungated[c] >= kChunk / 2 && c + 1 < n_chunks) { stop_at = c + 1; break; }
-        ++c;
+        __syncthreads();
+        c = s_c; cand = s_cand; T = s_T; map_failed = (s_flags & 1) != 0; stop = (s_flags & 2) != 0;
+        __syncthreads();
     }
-    if (lane == 0) {
+    if (tid == 0) {
         b.stats[0] += n_map; b.stats[1] += n_ckpt; b.stats[2] += n_serial; b.stats[3] = (int32_t)stop_at;
         *b.resume = T;
     }
@@ -553,7 +579,7 @@ static int launch_costas_spec(const CostasArgs &a, void *scratch, urhgpu_ctx *ct
                            seed_freq);
         hipLaunchKernelGGL((k_costas_run<DT, ORDER>), dim3((unsigned)((todo * K + 255) / 256)), dim3(256), 0, s, a, b, K);
         hipLaunchKernelGGL(k_costas_map, dim3((unsigned)((todo + 255) / 256)), dim3(256), 0, s, b, nc, K, std::max<int64_t>(c_from, 1));
-        hipLaunchKernelGGL((k_costas_stitch<DT, ORDER>), dim3(1), dim3(64), 0, s, a, b, nc, K, std::max<int64_t>(c_from, 1),
+        hipLaunchKernelGGL((k_costas_stitch<DT, ORDER>), dim3(1), dim3(kStitchBlock), 0, s, a, b, nc, K, std::max<int64_t>(c_from, 1),
                            round < kMaxRounds ? 1 : 0);
         URH_HIP(hipGetLastError());
         URH_HIP(hipMemcpyAsync(h, b.stats, 20, hipMemcpyDeviceToHost, s));
