@@ -96,28 +96,39 @@ __global__ __launch_bounds__(kMeBlock) void k_me_count(const float *x, const Msg
 // (a capture that is ONE message of 2^27 samples has 32 768 tiles)
 constexpr int kMeScanBlock = 1024;
 __global__ __launch_bounds__(kMeScanBlock) void k_me_tile_scan(const int32_t *cnt, int64_t n_tiles, int64_t *pre) {
+    // every wavefront owns a contiguous stretch of the table and reads it 64 entries at a time (coalesced): first its sum, then --
+    // after ONE exchange of the 16 sums -- a running wavefront scan over the stretch.  (The first version walked the whole table
+    // 1024 entries at a time: 32 rounds of three barriers each for a 1 GiB capture, 31 us.)
     __shared__ int64_t s_w[kMeScanBlock / 64];
-    __shared__ int64_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
+    constexpr int kW = kMeScanBlock / 64;
+    const int64_t per = ((n_tiles + kW - 1) / kW + 63) / 64 * 64;
+    const int64_t lo = (int64_t)wave * per, hi = (lo + per < n_tiles) ? lo + per : n_tiles;
+    int64_t mine = 0;
+#pragma unroll 4
+    for (int64_t i = lo + lane; i < hi; i += 64) mine += cnt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if (lane == 0) s_w[wave] = mine;
     __syncthreads();
-    for (int64_t b0 = 0; b0 < n_tiles; b0 += kMeScanBlock) {
-        const int64_t i = b0 + threadIdx.x;
-        const int64_t v = (i < n_tiles) ? cnt[i] : 0;
-        int64_t incl = v;
+    int64_t run = 0, total = 0;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int64_t u = __shfl_up(incl, o); if (lane >= o) incl += u; }
-        if (lane == 63) s_w[wave] = incl;
-        __syncthreads();
-        int64_t base = s_carry, total = 0;
+    for (int w = 0; w < kW; ++w) { if (w < wave) run += s_w[w]; total += s_w[w]; }
+    for (int64_t i0 = lo; i0 < hi; i0 += 4 * 64) {           // four loads in flight per round
+        int v[4];                                             // (a tile holds at most 4096 samples: 64 of them sum in 32 bits)
 #pragma unroll
-        for (int w = 0; w < kMeScanBlock / 64; ++w) { if (w < wave) base += s_w[w]; total += s_w[w]; }
-        if (i < n_tiles) pre[i] = base + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry += total;
-        __syncthreads();
+        for (int j = 0; j < 4; ++j) { const int64_t i = i0 + j * 64 + lane; v[j] = (i < hi) ? cnt[i] : 0; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t i = i0 + j * 64 + lane;
+            int incl = v[j];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(incl, o); if (lane >= o) incl += u; }
+            if (i < hi) pre[i] = run + (int64_t)(incl - v[j]);
+            run += (int64_t)__shfl(incl, 63);
+        }
     }
-    if (threadIdx.x == 0) pre[n_tiles] = s_carry;
+    if (threadIdx.x == 0) pre[n_tiles] = total;
 }
 
 __global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgState *st, const MsgTile *tiles, const int64_t *tile_pre,
