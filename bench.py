@@ -527,6 +527,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU reference (then no parity record either)")
     ap.add_argument("--bits-only", action="store_true", help="do not materialise qad (8 B/sample variant)")
     ap.add_argument("--torch-capture", action="store_true", help="round-1 capture (torch RNG, clean fp64 phase ramp) instead of the §8(d) bytes")
+    ap.add_argument("--no-d2h", action="store_true", help="skip the D2H-inclusive measurements (profiling runs: their passes overlap copies)")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[2] and configs[4] at full size (they add about a minute)")
     ap.add_argument("--fir-halo", action="store_true", help="N > 1: prepend the 64-tap FIR with halo exchange (configs[3] 'FIR-halo' variant)")
     ap.add_argument("--pipeline", action="store_true",
@@ -606,7 +607,7 @@ def main():
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t_l)
     d2h_bytes = None
-    if not sharded:
+    if not sharded and not args.no_d2h:
         pinned = {}
         for _ in range(6):
             torch.cuda.synchronize()

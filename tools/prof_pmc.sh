@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-pipeline $*"   # --no-pipeline: no extra pipelined passes in the trace
+ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-d2h --no-pipeline $*"   # --no-pipeline: no extra pipelined passes in the trace
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o b -- python $R/bench.py $ARGS > $OUT/stats.log 2>&1
 i=0
 for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \

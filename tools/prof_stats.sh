@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/stats_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-pipeline "$@" > $OUT/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o b -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra --no-d2h --no-pipeline "$@" > $OUT/log.txt 2>&1
 python - <<PY
 import csv, glob
 for f in glob.glob("$OUT/**/*kernel_stats.csv", recursive=True):
