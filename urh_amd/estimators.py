@@ -1,7 +1,18 @@
-"""Parameter estimators of the IQ->bits path (reference: src/urh/ainterpretation/AutoInterpretation.py) with the
-O(N) passes on the GPU and the O(100)-element decisions on the host.
+"""Parameter estimators of the IQ->bits path (reference: src/urh/ainterpretation/AutoInterpretation.py,
+src/urh/cythonext/auto_interpretation.pyx) for a capture that lives in HBM.
 
-detect_noise_level  AutoInterpretation.py:60-91   (+ util.get_magnitudes, util.pyx:128-136)
+Everything proportional to the capture, to the number of pulses or to the number of plateaus runs in liburhgpu.so: the passes over
+the samples (magnitude statistics, segmentation, per-message center statistics, plateau boundaries, modulation features) as kernels
+batched over all messages, the per-message integer decisions (tolerance, merged plateaus, divisor histogram, bit length) as native
+host arithmetic on a thread pool.  What is left here is glue on a handful of numbers per message -- and numpy as the arbiter
+wherever the reference's result is whatever numpy does with equal keys (np.argsort) or a borderline floating-point sum.
+
+  detect_noise_level                         AutoInterpretation.py:60-91   (+ util.get_magnitudes, util.pyx:128-136)
+  segment_messages / merge_..._for_ook       auto_interpretation.pyx:55-111, AutoInterpretation.py:107-148
+  detect_center, get_plateau_lengths         AutoInterpretation.py:226-277, auto_interpretation.pyx:179-208
+  tolerance / merge / round / bit length     AutoInterpretation.py:280-370, auto_interpretation.pyx:113-176
+  detect_modulation(_for_messages)           AutoInterpretation.py:150-223
+  estimate                                   AutoInterpretation.py:373-470
 """
 import ctypes as C
 import math
@@ -85,7 +96,7 @@ def fir_filter_detect_noise_dev(pipe, iq, taps, left=None):
 
 
 # ======================================================================================================================
-# Message segmentation, center, plateau lengths: O(N) passes on the GPU, decisions on the host
+# Message segmentation, center, plateau lengths
 # ======================================================================================================================
 def _dev_f32(pipe, x):
     torch = pipe.torch
@@ -98,8 +109,9 @@ def _dev_f32(pipe, x):
 def segment_messages_dev(pipe, iq, noise_threshold: float, as_array: bool = False):
     """auto_interpretation.segment_messages_from_magnitudes (auto_interpretation.pyx:55-111) for a float32 capture on
     the GPU: list of (start, end).  The above/below-noise state machine with its 10-sample outlier tolerance is the
-    run segmentation of the hot kernel with tolerance 9 on |sample| (urhgpu_segment_runs_dev); the host walks the
-    resulting rows (one per state change) and applies the reference's index conventions."""
+    run segmentation of the hot kernel with tolerance 9 on |sample| (urhgpu_segment_runs_dev); this entry point reads the rows back
+    (one per state change) and applies the reference's index conventions on arrays -- estimate_dev uses message_ranges_dev, which
+    keeps them on the device."""
     torch = pipe.torch
     if iq.dtype == torch.complex64:
         iq = torch.view_as_real(iq)
@@ -506,11 +518,10 @@ def bit_lengths_batched(all_plateaus):
 
 
 def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings: dict = None):
-    """AutoInterpretation.estimate (AutoInterpretation.py:373-470) for a float32 capture resident on the GPU.  Device passes over
-    the samples: magnitude statistics, segmentation, demodulation, then TWO batched passes over all messages (center statistics +
-    histograms; plateau boundaries for the chosen centers).  The host sees a histogram of a few dozen bins and a few thousand
-    plateau lengths per message and takes the decisions the reference takes (peak picking, tolerance, merged plateaus, divisor
-    histogram from the multiset of rounded lengths), plus detect_modulation on the first 100 messages like the reference."""
+    """AutoInterpretation.estimate (AutoInterpretation.py:373-470) for a float32 capture resident on the GPU: noise threshold,
+    message ranges (segmentation + OOK merge on the device), modulation vote over the first 100 messages (device), demodulation, then
+    three batched calls over ALL messages -- center statistics with peak picking, plateau boundaries, bit-length decisions -- and the
+    vote over the messages.  Per capture the host sees a few numbers per message."""
     from .pipeline import DemodParams
     import time
     torch = pipe.torch
