@@ -95,6 +95,54 @@ __device__ __forceinline__ float costas_step(float2 sm, CostasState &st, float &
     return 0.0f;
 }
 
+// The same step as straight-line code (the speculative kernels; loop order 2 or 4): the gate, the two wraps and the clamps are
+// selects; what cannot happen in a healthy loop (|phase| beyond 2 pi on entry, a product with two NaN parts) is collected in ONE flag,
+// tested once at the end, and sends the whole wavefront through costas_step from the saved state.  Measured effect: small (candidate
+// pass 1.97 -> 1.91 ms): nearly every one of a step's ~94 instructions depends on the one before it, a dependent VALU operation
+// issues every ~9.5 cycles whatever its type (tools/kbench/lbench.hip: fp32, fp64, conversions alike), and two trajectories per SIMD
+// lane cannot fill the gaps -- the pass sits at 94 x 9.5 cycles x 4096 steps.  One wrap is enough when
+// |phase| <= 2 pi on entry: |freq'| <= 1 + beta, |alpha err| <= alpha, alpha + beta < 4 for every bandwidth, so |phase'| < 2 pi + 5 < 4 pi.
+template <bool UNIT, int ORDER>
+__device__ __forceinline__ float costas_step_bf(float2 sm, CostasState &st, float &err, const CostasArgs &a) {
+    static_assert(ORDER == 2 || ORDER == 4, "the serial kernel handles the other orders");
+    const double two_pi = 2 * 3.14159265358979323846;
+    const CostasState old = st;
+    const float old_err = err;
+    const bool gated = costas_gated(sm, a);
+    const float real_float = UNIT ? sm.x + 0.0f : (sm.x + a.shift) / a.scale, imag_float = UNIT ? sm.y + 0.0f : (sm.y + a.shift) / a.scale;
+    const float2 cur = make_float2(real_float + 0.0f * imag_float, 1.0f * imag_float);   // re + imag_unit * im
+    const bool in_range = __builtin_fabsf(old.phase) <= __uint_as_float(0x40C90FDBu);   // the float next above 2 pi (NaN: false)
+    float sn, cs;
+    urh_sincosf_fast(-old.phase, &sn, &cs);
+    const float2 nco = make_float2(cs + 0.0f * sn, 1.0f * sn);
+    float2 z;
+    z.x = nco.x * cur.x - nco.y * cur.y;                     // cmul() without its NaN-recovery branch
+    z.y = nco.x * cur.y + nco.y * cur.x;
+    const bool rare = !gated && (!in_range || ((z.x != z.x) & (z.y != z.y)));
+    float e;
+    if (ORDER == 2) e = z.y * z.x;
+    else {
+        const float f1 = z.x > 0.0f ? 1.0f : -1.0f, f2 = z.y > 0.0f ? 1.0f : -1.0f;
+        e = f1 * z.y - f2 * z.x;
+    }
+    e = costas_clamp(e);
+    float freq = old.freq + a.beta * e;
+    float phase = old.phase + (freq + a.alpha * e);
+    const double d = (double)phase;
+    const float wrapped_down = (float)(d - two_pi), wrapped_up = (float)(d + two_pi);
+    phase = (d > two_pi) ? wrapped_down : ((d < -two_pi) ? wrapped_up : phase);
+    freq = costas_clamp(freq);
+    const float out = (ORDER == 2) ? z.x : (float)(2.0 * (double)z.x + (double)z.y);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(rare) != 0, 0)) {      // wavefront-uniform; never in a healthy loop
+        st = old; err = old_err;
+        return costas_step<UNIT, ORDER>(sm, st, err, a);
+    }
+    st.freq = gated ? old.freq : freq;
+    st.phase = gated ? old.phase : phase;
+    err = gated ? old_err : e;
+    return gated ? -4.0f : out;
+}
+
 // ---- serial evaluation: one wavefront, every lane the same recurrence, lane k keeps outputs k, k+64, ... of a tile ----
 constexpr int kCostasTile = 1024;
 
@@ -239,7 +287,7 @@ __global__ __launch_bounds__(256) void k_costas_spec(const CostasArgs a, SpecBuf
 #pragma unroll
                 for (int j = 0; j < PF; ++j) { const int64_t q = i + PF + j; nxt[j] = CostasLoad<DT>::at(a.iq, (q < s0) ? q : s0 - 1); }
 #pragma unroll
-                for (int j = 0; j < PF; ++j) if (i + j < s0) costas_step<DT == URHGPU_DT_F32, ORDER>(cur[j], st, err, a);
+                for (int j = 0; j < PF; ++j) if (i + j < s0) costas_step_bf<DT == URHGPU_DT_F32, ORDER>(cur[j], st, err, a);
 #pragma unroll
                 for (int j = 0; j < PF; ++j) cur[j] = nxt[j];
             }
@@ -292,7 +340,7 @@ __global__ __launch_bounds__(256) void k_costas_run(const CostasArgs a, SpecBuff
         for (int j = 0; j < PF; ++j) {
             if (i + j < e0) {
                 if (!costas_gated(cur[j], a)) ++ung;
-                costas_step<DT == URHGPU_DT_F32, ORDER>(cur[j], st, err, a);
+                costas_step_bf<DT == URHGPU_DT_F32, ORDER>(cur[j], st, err, a);
                 const int off = (int)(i + j - s0) + 1;
                 if (off % kCkpt == 0 && off < kChunk) b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + k] = st;
             }
@@ -449,7 +497,7 @@ __global__ __launch_bounds__(kStitchBlock) void k_costas_stitch(const CostasArgs
                 float err = 0.0f;
                 CostasState st = T;
                 for (int64_t i = s0; i < e0; ++i) {
-                    costas_step<DT == URHGPU_DT_F32, ORDER>(CostasLoad<DT>::at(a.iq, i), st, err, a);
+                    costas_step_bf<DT == URHGPU_DT_F32, ORDER>(CostasLoad<DT>::at(a.iq, i), st, err, a);
                     const int off = (int)(i - s0) + 1;
                     if (off % kCkpt == 0 && off < kChunk) {
                         const bool hit = lane < K && b.is_rep[c * K + lane] && same_state(st, b.CP[(c * kNumCkpt + (off / kCkpt - 1)) * K + lane]);
@@ -512,14 +560,14 @@ __global__ __launch_bounds__(256) void k_costas_final(const CostasArgs a, SpecBu
             float2 xv = x[0];
 #pragma unroll
             for (int q = 1; q < kTileF; ++q) if (u == q) xv = x[q];
-            const float ov = costas_step<DT == URHGPU_DT_F32, ORDER>(xv, st, err, a);
+            const float ov = costas_step_bf<DT == URHGPU_DT_F32, ORDER>(xv, st, err, a);
 #pragma unroll
             for (int q = 0; q < kTileF; ++q) if (u == q) o[q] = ov;
         }
 #pragma unroll
         for (int u = 0; u < kTileF; ++u) a.out[i + u] = o[u];
     }
-    for (; i < i1; ++i) a.out[i] = costas_step<DT == URHGPU_DT_F32, ORDER>(CostasLoad<DT>::at(a.iq, i), st, err, a);
+    for (; i < i1; ++i) a.out[i] = costas_step_bf<DT == URHGPU_DT_F32, ORDER>(CostasLoad<DT>::at(a.iq, i), st, err, a);
 }
 
 size_t costas_scratch_bytes(int64_t n) {
