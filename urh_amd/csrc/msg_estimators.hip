@@ -313,16 +313,19 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
     float total = 0.f;
     if (tid < 64) {
         float v = (tid < n_chunks) ? cs[tid] : 0.f;
+        float sv[64];                                        // the 64 terms of the current round, in scalar registers
+#pragma unroll
+        for (int c = 0; c < 64; ++c) sv[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c));
         for (int64_t c0 = 0; c0 < n_chunks; c0 += 64) {
             const float nxt = (c0 + 64 + tid < n_chunks) ? cs[c0 + 64 + tid] : 0.f;
             const int nc = (int)((n_chunks - c0 < 64) ? n_chunks - c0 : 64);
             if (nc == 64) {
-                // all 64 terms into scalar registers first, then the dependent adds back to back
-                float sv[64];
+                // a dependent add issues every ~9.5 cycles: the next round's v_readlane's go into the gaps
 #pragma unroll
-                for (int c = 0; c < 64; ++c) sv[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c));
-#pragma unroll
-                for (int c = 0; c < 64; ++c) total = total + sv[c];
+                for (int c = 0; c < 64; ++c) {
+                    total = total + sv[c];
+                    sv[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nxt), c));
+                }
             } else {
                 for (int c = 0; c < nc; ++c) total = total + __shfl(v, c);
             }
