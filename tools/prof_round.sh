@@ -15,3 +15,6 @@ python tools/dtype_probe.py 2>/dev/null | grep "ms/step" > gpurun_out/${TAG}_dty
 (cd tools/kbench && ([ -x vbench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 vbench.hip -o vbench) && timeout 120 ./vbench) > gpurun_out/${TAG}_vbench.txt 2>&1
 python bench.py --steps 50 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 ls gpurun_out | head -40
+# the default command (pipelined passes): kernel stats of what the driver's bench line times
+OUTP=$R/gpurun_out/stats_${TAG}_pipelined; mkdir -p $OUTP
+(cd /tmp && TMPDIR=/tmp timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUTP -o b -- python $R/bench.py --steps 100 --warmup 3 --no-cpu-baseline --no-extra --no-d2h --no-reference-loop > $OUTP/log.txt 2>&1)

@@ -288,21 +288,25 @@ int scan_state(urhgpu_ctx *ctx, int64_t cap_rows, ScanState *out) {
 // pipelined mode: make the caller's stream wait for the tail of the last pass (no host blocking)
 int join_tail(urhgpu_ctx *ctx) {
     if (ctx->tail_pending) {
-        URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->flip ^ 1], 0));
+        URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[(ctx->flip + 2) % 3], 0));       // the pass recorded last
         ctx->tail_pending = false;
     }
     return URHGPU_OK;
 }
 
-// pipelined mode: switch to the other scratch arena; the caller's stream first waits for the tail that used it last
+// pipelined mode: rotate to the scratch arena used three passes ago; the caller's stream first waits for the tail that used it.
+// (Two arenas made the hot kernel of pass i + 2 wait for the tail of pass i -- whose row kernel, starved of wave slots by the hot kernel
+// of pass i + 1, only finishes right after it: the passes ran back to back again.  With three the hot kernels follow each other and
+// the tails trail one pass behind.)
 int begin_pipelined_pass(urhgpu_ctx *ctx) {
     std::swap(ctx->arena, ctx->arena_alt);
+    std::swap(ctx->arena_alt, ctx->arena_alt2);
     URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->flip], 0));
     return URHGPU_OK;
 }
 int end_pipelined_pass(urhgpu_ctx *ctx) {
     URH_HIP(hipEventRecord(ctx->ev_tail[ctx->flip], ctx->tail_stream));
-    ctx->flip ^= 1;
+    ctx->flip = (ctx->flip + 1) % 3;
     ctx->tail_pending = true;
     return URHGPU_OK;
 }
@@ -373,9 +377,10 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     ctx->staging.release();
     ctx->aux.release();
     ctx->arena_alt.release();
+    ctx->arena_alt2.release();
     if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
-    if (ctx->ev_hot) { (void)hipEventDestroy(ctx->ev_hot); (void)hipEventDestroy(ctx->ev_tail[0]); (void)hipEventDestroy(ctx->ev_tail[1]); }
+    if (ctx->ev_hot) { (void)hipEventDestroy(ctx->ev_hot); (void)hipEventDestroy(ctx->ev_tail[0]); (void)hipEventDestroy(ctx->ev_tail[1]); (void)hipEventDestroy(ctx->ev_tail[2]); }
     delete (ShardSession *)ctx->shard;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->d_counts) (void)hipFree(ctx->d_counts);
@@ -416,16 +421,28 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
     ctx->tail_stream = nullptr; ctx->own_tail_stream = false; ctx->pipelined = false;
     if (!enable) return URHGPU_OK;
     if (tail_stream) ctx->tail_stream = (hipStream_t)tail_stream;
-    else { URH_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking)); ctx->own_tail_stream = true; }
+    else {
+        // experiment knob: URH_TAIL_PRIORITY=1 creates the tail stream at the device's highest priority
+        const char *pe = getenv("URH_TAIL_PRIORITY");
+        if (pe && atoi(pe) != 0) {
+            int lo = 0, hi = 0;
+            URH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            URH_HIP(hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, hi));
+        } else {
+            URH_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
+        }
+        ctx->own_tail_stream = true;
+    }
     if (!ctx->ev_hot) {
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_hot, hipEventDisableTiming));
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[0], hipEventDisableTiming));
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[1], hipEventDisableTiming));
+        URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[2], hipEventDisableTiming));
     }
     ctx->pipelined = true;
     {   // experiment knob: URH_HOT_LDS_KB=<KiB of dynamic LDS per hot workgroup> (0 / unset: the default below)
         const char *e = getenv("URH_HOT_LDS_KB");
-        ctx->hot_lds_pad = (e ? atoi(e) : 21) * 1024;
+        ctx->hot_lds_pad = (e ? atoi(e) : 0) * 1024;       // (21 KiB was the default while the row kernel had 8-wavefront workgroups)
     }
     return URHGPU_OK;
 }
@@ -451,7 +468,10 @@ int urhgpu_ctx_reserve(urhgpu_ctx *ctx, int64_t n_samples, int tolerance) {
     const Plan pl = make_plan(ctx, n_samples, tolerance);
     const int64_t cap_rows = n_samples / ((int64_t)tolerance + 1) + 2;
     URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, cap_rows, true, true)));
-    if (ctx->pipelined) URH_TRY(ctx->arena_alt.reserve(digitize_scratch_bytes(pl, cap_rows, true, true)));
+    if (ctx->pipelined) {
+        URH_TRY(ctx->arena_alt.reserve(digitize_scratch_bytes(pl, cap_rows, true, true)));
+        URH_TRY(ctx->arena_alt2.reserve(digitize_scratch_bytes(pl, cap_rows, true, true)));
+    }
     return URHGPU_OK;
 }
 

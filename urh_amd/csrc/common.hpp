@@ -76,14 +76,14 @@ struct urhgpu_ctx {
     void *shard = nullptr;                 // state of a sharded pass between its phases (capi.hip: ShardSession)
     // Pipelined mode (urhgpu_ctx_set_pipelined): the hot kernel of a pass runs on `stream`, everything after it on
     // `tail_stream`, with two scratch arenas used alternately, so that the hot kernel of the NEXT pass overlaps the
-    // (latency-bound, nearly empty) tail of this one.  Outputs are complete after urhgpu_ctx_join / urhgpu_ctx_sync.
+    // (latency-bound, nearly empty) tail of this one -- and, with three arenas, of the one before.  Outputs are complete after urhgpu_ctx_join / urhgpu_ctx_sync.
     bool pipelined = false;
     int hot_lds_pad = 0;           // pipelined mode: dynamic LDS bytes added to every hot-kernel workgroup (see RunArgs::lds_pad)
     hipStream_t tail_stream = nullptr;
     bool own_tail_stream = false;
-    urh::Arena arena_alt;
+    urh::Arena arena_alt, arena_alt2;   // three scratch arenas in rotation: the hot kernel of pass i + 2 does not wait for the tail of pass i
     hipEvent_t ev_hot = nullptr;
-    hipEvent_t ev_tail[2] = {nullptr, nullptr};
+    hipEvent_t ev_tail[3] = {nullptr, nullptr, nullptr};
     int flip = 0;
     bool tail_pending = false;
     int tile_parity = 0;           // which of the two huge-row counters (d_tickets[8..9]) the current pass appends to

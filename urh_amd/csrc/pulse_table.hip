@@ -832,7 +832,10 @@ __device__ __forceinline__ VecK<4> row_value(int64_t type, int64_t len, bool glo
 }
 
 struct HugeRef { int64_t tile, row; };                   // a row of more than kHugeBits bits, found while the rows were emitted
-constexpr int kEmitWaves = 8;                           // chunks per workgroup of k_emit_rows_tiles (one wavefront each)
+// chunks per workgroup of k_emit_rows_tiles (one wavefront each).  Four, not eight: beside the next pass's hot kernel (pipelined passes)
+// a workgroup needs one free wave slot per SIMD, which retiring hot workgroups (four wavefronts) leave; eight-wavefront workgroups were
+// starved until the hot kernel had drained (the row kernel then took that kernel's whole 290 us).
+constexpr int kEmitWaves = 4;
 
 struct EmitTileArgs {
     EmitArgs e;
