@@ -1393,14 +1393,15 @@ def test_pinned_host_copy_equals_pageable(pipe):
         assert len(got) == 6 and all(np.array_equal(a, b) for a, b in zip(got, want))
 
 
-def test_pipelined_passes_do_not_disturb_each_other(oracle):
+@pytest.mark.parametrize("n", [1 << 22, (1 << 22) + 777])
+def test_pipelined_passes_do_not_disturb_each_other(oracle, n):
     """pipelined mode: a burst of back-to-back passes over alternating captures without any synchronisation in between;
     the last two results (kept in separate output slots) are bit-exact, i.e. the hot kernel of pass i+1 did not disturb the
-    tail of pass i (alternating scratch) and the tails ran in order."""
+    tail of pass i (alternating scratch) and the tails ran in order.  Whole tiles: the tail stream waits for the hot dispatch's own
+    completion signal; with a partial tile at the end (a second, one-workgroup launch) for an event recorded behind both."""
     import torch
     from urh_amd.pipeline import DemodParams, DevicePipeline
     pp = DevicePipeline(0, pipelined=True)
-    n = 1 << 22
     caps, wants = [], []
     for seed, mod in ((1, "FSK"), (2, "ASK")):
         iq = synth_fsk(n, sps=100, seed=seed, noise=0.05, pause_every=n // 3, pause_len=n // 17)
@@ -1423,6 +1424,33 @@ def test_pipelined_passes_do_not_disturb_each_other(oracle):
         assert all(np.array_equal(a, b) for a, b in zip(flat, res.flat())), k
         assert bits_equal(res.qad.cpu().numpy(), qad), k
     pp.ctx.set_pipelined(False)
+
+
+@pytest.mark.parametrize("case", ["rows", "groups"])
+def test_scans_loop_over_more_tiles_than_their_grid(pipe, oracle, case):
+    """The pulse-table scans run on a bounded grid (scan.hpp scan_grid: 512 workgroups of 2048 elements) and loop beyond it:
+    a capture with more than 2^20 pulse-table rows ("rows": 4 samples per symbol) and one with more than 2^20 messages
+    ("groups": six-sample bursts, four-sample gaps, one sample per symbol, pause threshold 2) -- rows, bits, pauses and bit
+    positions identical to the oracle."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    n = 3 << 22
+    if case == "rows":
+        iq = synth_fsk(n, sps=4, seed=11, noise=0.02, deviation_hz=200e3)
+        p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 1, 4, 0.1, 8, True)
+    else:
+        iq = synth_fsk(n, sps=1, seed=12, noise=0.01, deviation_hz=200e3)
+        iq[(np.arange(n) % 10) >= 6] *= np.float32(0.01)
+        p = DemodParams("FSK", 1, 0.3, 0.0, 1.0, 1, 1, 0.1, 2, True)
+    qad = oracle.afp_demod(iq, p.noise_threshold, "FSK", 2)
+    ppseq = oracle.grab_pulse_lens(qad, 0.0, 1, "FSK", p.samples_per_symbol, 1, 1.0)
+    flat = oracle.ppseq_to_bits_flat(ppseq, p.samples_per_symbol, 1, True, p.pause_threshold)
+    assert len(ppseq) > (1 << 20) and (case == "rows" or len(flat[2]) > (1 << 20))
+    res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True)
+    res.check_capacity()
+    assert np.array_equal(res.ppseq(), ppseq)
+    assert all(np.array_equal(a, b) for a, b in zip(flat, res.flat()))
+    assert bits_equal(res.qad.cpu().numpy(), qad)
 
 
 def test_error_codes_on_device(pipe, sf):

@@ -178,12 +178,21 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     if (!chunks || !slab) return URHGPU_ERR_ARG;
     a.chunks = chunks; a.slab = slab;
     const bool prof = prof_begin_record(ctx, s);
+    // pipelined: the tail stream waits for the completion signal of the hot dispatch itself where one launch covers the capture (no
+    // partial tile at the end) -- an event recorded behind it is one more barrier packet between two hot kernels
+    hipEvent_t hot_done = nullptr;
+    if (s_tail && from_iq && ctx->hot_stop_event && n % kTile == 0) {
+        if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot; }
+        hot_done = g_hot_events.stop;
+    }
     if (from_iq) URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, d_qad != nullptr, s));
     else URH_TRY(launch_runs_qad(a, s));
+    if (hot_done && !g_hot_events.used) hot_done = nullptr;          // the launch did not take the events (state-byte kernel)
     if (prof) URH_TRY(prof_end_record(ctx, s));
+    else g_hot_events = HotEvents();
     if (s_tail) {                                   // pipelined: everything after the hot kernel goes to the tail stream
-        URH_HIP(hipEventRecord(ctx->ev_hot, s));
-        URH_HIP(hipStreamWaitEvent(s_tail, ctx->ev_hot, 0));
+        if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot, s)); hot_done = ctx->ev_hot; }
+        URH_HIP(hipStreamWaitEvent(s_tail, hot_done, 0));
         s = s_tail;
     }
 
@@ -443,6 +452,8 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
     {   // experiment knob: URH_HOT_LDS_KB=<KiB of dynamic LDS per hot workgroup> (0 / unset: the default below)
         const char *e = getenv("URH_HOT_LDS_KB");
         ctx->hot_lds_pad = (e ? atoi(e) : 0) * 1024;       // (21 KiB was the default while the row kernel had 8-wavefront workgroups)
+        const char *se = getenv("URH_HOT_STOP_EVENT");     // 0: record an event behind the hot kernel instead (comparison)
+        ctx->hot_stop_event = se ? atoi(se) != 0 : true;
     }
     return URHGPU_OK;
 }

@@ -1341,7 +1341,7 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
         // orders 2 and 4: the bit-plane kernel; anything else: the state-byte kernel
         const bool planes_ok = URH_BITPLANE && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes;
-        if (planes_ok && O2 && g_hot_events.start && !g_hot_events.used) {
+        if (planes_ok && O2 && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
             hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
                                   (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
             g_hot_events.used = true;

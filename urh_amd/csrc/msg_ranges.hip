@@ -178,9 +178,9 @@ int launch_message_ranges(const int64_t *d_rows, const int64_t *d_n_rows, int64_
     double *dpart = (double *)((char *)scratch + (((size_t)(nb + 2) * sizeof(VecK<1>) + 255) & ~size_t(255)));
     int64_t *d_nseg = (int64_t *)(dpart + 1024);
     SegLoad ld{d_rows};
-    hipLaunchKernelGGL((k_scan_reduce<1, SegLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_rows, ld, part, nb);
+    hipLaunchKernelGGL((k_scan_reduce<1, SegLoad>), dim3(scan_grid(nb)), dim3(kScanBlock), 0, s, d_n_rows, ld, part, nb);
     if (nb > kScanDirect) hipLaunchKernelGGL((k_scan_partials<1>), dim3(1), dim3(kScanPartialsBlock), 0, s, d_n_rows, part, nb, kScanDirect);
-    hipLaunchKernelGGL((k_scan_apply<1, SegLoad, SegStore>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_rows, ld, part, nb, SegStore{d_rows, d_seg, cap},
+    hipLaunchKernelGGL((k_scan_apply<1, SegLoad, SegStore>), dim3(scan_grid(nb)), dim3(kScanBlock), 0, s, d_n_rows, ld, part, nb, SegStore{d_rows, d_seg, cap},
                        kScanDirect);
     switch (dtype) {
         case URHGPU_DT_F32: launch_seg_finish<URHGPU_DT_F32>(d_rows, d_n_rows, d_iq, n, thr, d_seg, cap, d_ctl, s); break;
@@ -201,9 +201,9 @@ int launch_message_ranges(const int64_t *d_rows, const int64_t *d_n_rows, int64_
     const int64_t nbs = std::max<int64_t>((cap + kScanTile - 1) / kScanTile, 1);
     VecK<1> *part2 = part;                                   // the first scan is done
     CutLoad cl{d_seg, d_ctl};
-    hipLaunchKernelGGL((k_scan_reduce<1, CutLoad>), dim3((unsigned)nbs), dim3(kScanBlock), 0, s, d_nseg, cl, part2, nbs);
+    hipLaunchKernelGGL((k_scan_reduce<1, CutLoad>), dim3(scan_grid(nbs)), dim3(kScanBlock), 0, s, d_nseg, cl, part2, nbs);
     if (nbs > kScanDirect) hipLaunchKernelGGL((k_scan_partials<1>), dim3(1), dim3(kScanPartialsBlock), 0, s, d_nseg, part2, nbs, kScanDirect);
-    hipLaunchKernelGGL((k_scan_apply<1, CutLoad, CutStore>), dim3((unsigned)nbs), dim3(kScanBlock), 0, s, d_nseg, cl, part2, nbs,
+    hipLaunchKernelGGL((k_scan_apply<1, CutLoad, CutStore>), dim3(scan_grid(nbs)), dim3(kScanBlock), 0, s, d_nseg, cl, part2, nbs,
                        CutStore{d_seg, d_ctl, d_msgs, cap}, kScanDirect);
     hipLaunchKernelGGL((k_scan_finish<1, CutFinal>), dim3(1), dim3(kScanBlock), 0, s, d_nseg, part2, nbs, CutFinal{d_ctl}, kScanDirect);
     return URHGPU_OK;

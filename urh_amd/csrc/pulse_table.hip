@@ -1276,8 +1276,8 @@ int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t
     MergeLoad ld{rows_in};
     MergeStore st{rows_in, d_n_in, grp_state, grp_end};
     (void)tickets;
-    hipLaunchKernelGGL((k_scan_reduce<2, MergeLoad>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld, partials, nb);
-    hipLaunchKernelGGL((k_scan_apply<2, MergeLoad, MergeStore>), dim3((unsigned)nb), dim3(kScanBlock), 0, s, d_n_in, ld, partials, nb, st,
+    hipLaunchKernelGGL((k_scan_reduce<2, MergeLoad>), dim3(scan_grid(nb)), dim3(kScanBlock), 0, s, d_n_in, ld, partials, nb);
+    hipLaunchKernelGGL((k_scan_apply<2, MergeLoad, MergeStore>), dim3(scan_grid(nb)), dim3(kScanBlock), 0, s, d_n_in, ld, partials, nb, st,
                        kScanAlwaysDirect);
     hipLaunchKernelGGL((k_scan_finish<2, NoFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_in, partials, nb, NoFinal(), kScanAlwaysDirect);
     int64_t fin_blocks = (cap + 255) / 256; if (fin_blocks > 4096) fin_blocks = 4096;
@@ -1358,8 +1358,8 @@ int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t ca
     GroupCountFinal fin{d_n_rows, b.groups, b.d_n_groups, d_flags};
     // Two passes for the rows: a single-pass look-back scan over hundreds of workgroups measured 54 us against 48 us for
     // this pair -- every look-back hop is a round trip through memory between XCDs (their L2s are not coherent).
-    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb);
-    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore>), dim3((unsigned)b.nb), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb, st,
+    hipLaunchKernelGGL((k_scan_reduce<4, BitsLoad>), dim3(scan_grid(b.nb)), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb);
+    hipLaunchKernelGGL((k_scan_apply<4, BitsLoad, BitsStore>), dim3(scan_grid(b.nb)), dim3(kScanBlock), 0, s, d_n_rows, ld, b.part4, b.nb, st,
                        kScanAlwaysDirect);
     if (!single)
         hipLaunchKernelGGL((k_scan_finish<4, GroupCountFinal>), dim3(1), dim3(kScanBlock), 0, s, d_n_rows, b.part4, b.nb, fin, kScanAlwaysDirect);
@@ -1376,7 +1376,7 @@ int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};
     // the groups (usually a handful: one workgroup) go through the single-pass look-back scan: one launch instead of two
-    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s,
+    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandArgs ea{rows, d_n_rows, b.info, b.gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp, b.huge, b.huge_count, kHugeCap};
     const int64_t eb = std::min<int64_t>((cap_rows + 255) / 256, kExpandMaxBlocks);
@@ -1464,7 +1464,7 @@ int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};
-    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3((unsigned)b.nbg), dim3(kScanBlock), 0, s,
+    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, b.d_n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
                       bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt};

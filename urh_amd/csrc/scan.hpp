@@ -70,6 +70,13 @@ __device__ __forceinline__ int64_t scan_active_blocks(int64_t n, int64_t nblocks
     return nb < 1 ? 1 : nb;
 }
 
+// Launch grid for a scan whose element count is usually far below the host-side bound (pulse tables: rows <= samples / (tol + 1),
+// in practice a few percent of that): at most kScanGridMax workgroups, each looping over the active tiles with stride gridDim.x.
+// Surplus workgroups still cost a dispatch each -- beside a running hot kernel (pipelined passes) thousands of them wait for wave
+// slots one retiring workgroup at a time: the group scan "ran" for 60-240 us there.
+constexpr int64_t kScanGridMax = 512;
+inline unsigned scan_grid(int64_t nblocks_max) { return (unsigned)(nblocks_max < kScanGridMax ? (nblocks_max < 1 ? 1 : nblocks_max) : kScanGridMax); }
+
 // "Last workgroup done" election: every participating workgroup calls this after its global writes; exactly one
 // call (the last to arrive) returns true, with all the other workgroups' writes visible.  *ticket must be 0 before
 // the launch and is 0 again afterwards.
@@ -121,16 +128,17 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_reduce(const int64_t *d_n, 
     const int64_t n = *d_n;
     if (blockIdx.x == 0 && threadIdx.x == 0) scan_on_start(load, n, 0);
     const int64_t nb = scan_active_blocks(n, nblocks_max);
-    if ((int64_t)blockIdx.x >= nb) return;
-    const int64_t base = (int64_t)blockIdx.x * kScanTile;
-    VecK<K> acc; acc.zero();
-    const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {             // the grid may be smaller than nblocks_max (scan_grid)
+        const int64_t base = b * kScanTile;
+        VecK<K> acc; acc.zero();
+        const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j)
-        if (i0 + j < n) acc.add(load(i0 + j));
-    VecK<K> total;
-    block_excl_scan_vec<K>(acc, total, s_wave);
-    if (threadIdx.x == 0) partials[blockIdx.x] = total;
+        for (int j = 0; j < kScanItems; ++j)
+            if (i0 + j < n) acc.add(load(i0 + j));
+        VecK<K> total;
+        block_excl_scan_vec<K>(acc, total, s_wave);
+        if (threadIdx.x == 0) partials[b] = total;
+    }
 }
 
 // ONE workgroup of kScanPartialsBlock threads, 8 totals per thread and round.
@@ -172,27 +180,28 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_apply(const int64_t *d_n, L
     __shared__ VecK<K> s_wave[kScanBlock / 64];
     const int64_t n = *d_n;
     const int64_t nb = scan_active_blocks(n, nblocks_max);
-    if ((int64_t)blockIdx.x >= nb) return;
-    const int64_t base = (int64_t)blockIdx.x * kScanTile;
-    VecK<K> item[kScanItems];
-    VecK<K> acc; acc.zero();
-    const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int64_t base = b * kScanTile;
+        VecK<K> item[kScanItems];
+        VecK<K> acc; acc.zero();
+        const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        item[j].zero();
-        if (i0 + j < n) item[j] = load(i0 + j);
-        acc.add(item[j]);
-    }
-    VecK<K> before;
-    if (nb <= direct_max) before = block_sum_partials<K>(partials, blockIdx.x, s_wave);
-    else before = partials[blockIdx.x];
-    VecK<K> total;
-    VecK<K> ex = block_excl_scan_vec<K>(acc, total, s_wave);
-    ex.add(before);
+        for (int j = 0; j < kScanItems; ++j) {
+            item[j].zero();
+            if (i0 + j < n) item[j] = load(i0 + j);
+            acc.add(item[j]);
+        }
+        VecK<K> before;
+        if (nb <= direct_max) before = block_sum_partials<K>(partials, b, s_wave);
+        else before = partials[b];
+        VecK<K> total;
+        VecK<K> ex = block_excl_scan_vec<K>(acc, total, s_wave);
+        ex.add(before);
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        if (i0 + j < n) store(i0 + j, item[j], ex);
-        ex.add(item[j]);
+        for (int j = 0; j < kScanItems; ++j) {
+            if (i0 + j < n) store(i0 + j, item[j], ex);
+            ex.add(item[j]);
+        }
     }
 }
 
@@ -277,49 +286,51 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_lookback(const int64_t *d_n
     __shared__ VecK<K> s_prefix;
     const int64_t n = *d_n;
     const int64_t nb = scan_active_blocks(n, nblocks_max);
-    const int64_t b = blockIdx.x;
-    if (b >= nb) return;
-    const int64_t base = b * kScanTile;
-    VecK<K> item[kScanItems];
-    VecK<K> acc; acc.zero();
-    const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
+    // The grid may be smaller than nblocks_max (scan_grid): workgroup w then takes tiles w, w + G, ...  A tile still only waits
+    // for tiles below it, and those belong to workgroups that are running or will be dispatched whatever this one does.
+    for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const int64_t base = b * kScanTile;
+        VecK<K> item[kScanItems];
+        VecK<K> acc; acc.zero();
+        const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        item[j].zero();
-        if (i0 + j < n) item[j] = load(i0 + j);
-        acc.add(item[j]);
-    }
-    VecK<K> total;
-    VecK<K> ex = block_excl_scan_vec<K>(acc, total, s_wave);
-    if (threadIdx.x < 64) {                               // wavefront 0 publishes and looks back
-        if (b > 0 && threadIdx.x == 0) {
-            desc[b].agg = total;
-            __threadfence();
-            __hip_atomic_store(&desc[b].flag, (epoch << 2) | kScanAgg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int j = 0; j < kScanItems; ++j) {
+            item[j].zero();
+            if (i0 + j < n) item[j] = load(i0 + j);
+            acc.add(item[j]);
         }
-        const VecK<K> prefix = scan_look_back<K>(desc, b, epoch);
-        if (threadIdx.x == 0) {
-            VecK<K> incl = prefix; incl.add(total);
-            desc[b].incl = incl;
-            __threadfence();
-            __hip_atomic_store(&desc[b].flag, (epoch << 2) | kScanIncl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_prefix = prefix;
+        VecK<K> total;
+        VecK<K> ex = block_excl_scan_vec<K>(acc, total, s_wave);
+        if (threadIdx.x < 64) {                               // wavefront 0 publishes and looks back
+            if (b > 0 && threadIdx.x == 0) {
+                desc[b].agg = total;
+                __threadfence();
+                __hip_atomic_store(&desc[b].flag, (epoch << 2) | kScanAgg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const VecK<K> prefix = scan_look_back<K>(desc, b, epoch);
+            if (threadIdx.x == 0) {
+                VecK<K> incl = prefix; incl.add(total);
+                desc[b].incl = incl;
+                __threadfence();
+                __hip_atomic_store(&desc[b].flag, (epoch << 2) | kScanIncl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_prefix = prefix;
+            }
         }
-    }
-    __syncthreads();
-    const VecK<K> prefix = s_prefix;
-    ex.add(prefix);
+        __syncthreads();
+        const VecK<K> prefix = s_prefix;
+        ex.add(prefix);
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
-        if (i0 + j < n) store(i0 + j, item[j], ex);
-        ex.add(item[j]);
-    }
-    if (elect) {
-        if (!scan_last_block(ticket, nb)) return;
-        if (threadIdx.x == 0) fin(desc[nb - 1].incl);
-    } else if (b == nb - 1 && threadIdx.x == 0) {
-        VecK<K> grand = prefix; grand.add(total);
-        fin(grand);
+        for (int j = 0; j < kScanItems; ++j) {
+            if (i0 + j < n) store(i0 + j, item[j], ex);
+            ex.add(item[j]);
+        }
+        if (elect) {
+            if (scan_last_block(ticket, nb) && threadIdx.x == 0) fin(desc[nb - 1].incl);
+        } else if (b == nb - 1 && threadIdx.x == 0) {
+            VecK<K> grand = prefix; grand.add(total);
+            fin(grand);
+        }
+        __syncthreads();                                      // s_prefix / s_wave are reused by the next tile
     }
 }
 
