@@ -261,7 +261,10 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
                           int rank, int world, const void *d_left_halo, const urhgpu_params *p,
                           const urhgpu_outputs *out, void *d_summary);
 /* Optional: start the hot kernel BEFORE the halo has arrived -- every chunk but the first, which alone reads it -- so that
- * the halo all-gather overlaps the kernel; urhgpu_shard_runs_dev (same arguments + the halo) then only adds the first chunk. */
+ * the halo all-gather overlaps the kernel; urhgpu_shard_runs_dev (same arguments + the halo) then only adds the first chunk.
+ * On a pipelined context (urhgpu_ctx_set_pipelined) that first chunk and every later phase run on the TAIL stream: d_left_halo
+ * must be ready in tail-stream order (make the tail stream, not the context's stream, wait for the halo exchange), and the
+ * context's stream never waits for a collective. */
 int urhgpu_shard_prelaunch_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
                                int rank, int world, const urhgpu_params *p, const urhgpu_outputs *out);
 int urhgpu_shard_rows_dev(urhgpu_ctx *ctx, const void *d_summaries, int64_t *d_merge);

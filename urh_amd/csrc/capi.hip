@@ -185,8 +185,10 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
         if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot; }
         hot_done = g_hot_events.stop;
     }
-    if (from_iq) URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, d_qad != nullptr, s));
-    else URH_TRY(launch_runs_qad(a, s));
+    {
+        const int st = from_iq ? launch_demod_runs_iq(a, p->dtype, p->mod, d_qad != nullptr, s) : launch_runs_qad(a, s);
+        if (st != URHGPU_OK) { g_hot_events = HotEvents(); return st; }
+    }
     if (hot_done && !g_hot_events.used) hot_done = nullptr;          // the launch did not take the events (state-byte kernel)
     if (prof) URH_TRY(prof_end_record(ctx, s));
     else g_hot_events = HotEvents();
@@ -710,8 +712,25 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     a.launch_part = part;
     if (part == 1 && rank > 0 && !a.left_halo) a.left_halo = d_iq;    // any non-null value: only chunk 0 reads the halo
     const bool prof = prof_begin_record(ctx, s);
-    URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s));
+    hipEvent_t hot_done = nullptr;                 // pipelined: what the tail stream waits for (see digitize)
+    if (ss->piped && ctx->hot_stop_event && n_local % kTile == 0) {
+        if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot; }
+        hot_done = g_hot_events.stop;
+    }
+    {
+        const int st = launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s);
+        if (st != URHGPU_OK) { g_hot_events = HotEvents(); return st; }
+    }
+    if (hot_done && !g_hot_events.used) hot_done = nullptr;
     if (prof) URH_TRY(prof_end_record(ctx, s));
+    else g_hot_events = HotEvents();
+    if (ss->piped) {
+        // Everything after this launch goes to the tail stream -- also the first chunk of a prelaunched pass, which waits for the
+        // halo exchange: the caller's stream never waits for a collective (the exchanges of one communicator run in issue order,
+        // so the halo of pass i + 1 queues behind the last exchange of pass i's tail).
+        if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot, s)); hot_done = ctx->ev_hot; }
+        URH_HIP(hipStreamWaitEvent(ctx->tail_stream, hot_done, 0));
+    }
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }
@@ -734,7 +753,7 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
         // prelaunched: only the first chunk (it needs the halo) is still missing
         if (ss->rank != rank || ss->world != world || ss->n_local != n_local || ss->run.in != d_iq) return URHGPU_ERR_ARG;
         URH_HIP(hipSetDevice(ctx->device));
-        s = ctx->stream;
+        s = ss->piped ? ctx->tail_stream : ctx->stream;
         if (rank > 0) {
             RunArgs a = ss->run;
             a.left_halo = d_left_halo; a.launch_part = 2;
@@ -743,12 +762,7 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
     } else {
         URH_TRY(shard_launch(ctx, d_iq, n_local, pos_base, n_total, rank, world, d_left_halo, p, out, 0));
         ss = (ShardSession *)ctx->shard;
-        s = ctx->stream;
-    }
-    if (ss->piped) {                                // everything after the hot kernel goes to the tail stream
-        URH_HIP(hipEventRecord(ctx->ev_hot, s));
-        URH_HIP(hipStreamWaitEvent(ctx->tail_stream, ctx->ev_hot, 0));
-        s = ctx->tail_stream;
+        s = ss->piped ? ctx->tail_stream : ctx->stream;      // pipelined: shard_launch made the tail stream wait for the hot kernel
     }
     // local resolve pass: the shard on its own -> its summary
     const Plan &pl = ss->pl;

@@ -136,6 +136,8 @@ class GpuShardEngine(DevicePipeline):
         else:
             iq, n, cp, o = self._setup(iq, p, want_qad)
         self._keep += (left,)
+        if left is not None and getattr(self, "tail_stream", None) is not None:
+            left.record_stream(self.tail_stream)                # gathered under the caller's stream, read by the first chunk on the tail stream
         summary = self._buf("summary", (9,), torch.int64)      # URHGPU_SHARD_SUMMARY_BYTES = 72
         lh = C.c_void_p(left.data_ptr()) if left is not None else None
         _lib.check(_lib.load().urhgpu_shard_runs_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, int(pos_base), int(n_total),

@@ -143,12 +143,14 @@ class ShardedPipeline:
         pending = c.all_gather_start(e.tail(iq_local, p))
         if hasattr(e, "runs_begin"):               # the halo exchange overlaps the hot kernel (all chunks but the first)
             e.runs_begin(iq_local, pos_base, n_total, self.rank, self.world, p, want_qad)
-        halos = pending()
-        left = halos[self.rank - 1] if self.rank > 0 else None
-        summary = e.runs(iq_local, left, pos_base, n_total, self.rank, self.world, p, want_qad)
-        # everything after the hot kernel (all-gathers included) is issued on the engine's tail stream when it is pipelined:
-        # the next pass's halo exchange and hot kernel then overlap this pass's latency-bound tail
+        # Everything after the hot kernel -- the wait for the halo, the first chunk, the all-gathers -- is issued on the engine's tail
+        # stream when it is pipelined: the next pass's hot kernel then overlaps this pass's latency-bound tail, and the hot stream
+        # never waits for a collective (the exchanges of one process group run in issue order: the halo of pass i + 1 sits behind the
+        # last exchange of pass i's tail, so a hot stream that waited for its halo would run in lock-step with the tails).
         with (e.tail_context() if hasattr(e, "tail_context") else contextlib.nullcontext()):
+            halos = pending()
+            left = halos[self.rank - 1] if self.rank > 0 else None
+            summary = e.runs(iq_local, left, pos_base, n_total, self.rank, self.world, p, want_qad)
             merge = e.rows(c.all_gather(summary))
             merged_all = c.all_gather(merge) if merge is not None else None
             flags = e.bits_prepare(merged_all)
