@@ -706,6 +706,17 @@ def _check_message_ranges(pipe, oracle, iq, nt, want_segments, caps=(4096, 65536
     return amb
 
 
+def test_message_ranges_beyond_the_scan_grid(pipe, oracle):
+    """more than 2^20 segments: the segment / cut scans (msg_ranges.hip) loop over their tiles on a bounded grid (scan.hpp scan_grid)"""
+    n = 1 << 25
+    rng = np.random.default_rng(77)
+    env = ((np.arange(n) % 28) < 14).astype(np.float32)
+    iq = np.ascontiguousarray((env[:, None] * np.array([0.6, 0.5], np.float32) + 0.01 * rng.standard_normal((n, 2))).astype(np.float32))
+    want = oracle.segment_messages_from_magnitudes(oracle.get_magnitudes(iq), 0.2)
+    assert len(want) > (1 << 20)
+    _check_message_ranges(pipe, oracle, iq, 0.2, want, caps=(1 << 21, 1 << 21))
+
+
 def test_message_ranges_ook_bursts(pipe, oracle):
     """OOK captures: one segment per pulse, merged into bursts on the device (AutoInterpretation.py:107-148)"""
     def synth_ook_bursts(n, sps, seed):
@@ -1426,7 +1437,7 @@ def test_pipelined_passes_do_not_disturb_each_other(oracle, n):
     pp.ctx.set_pipelined(False)
 
 
-@pytest.mark.parametrize("case", ["rows", "groups"])
+@pytest.mark.parametrize("case", ["rows", "groups", "ask"])
 def test_scans_loop_over_more_tiles_than_their_grid(pipe, oracle, case):
     """The pulse-table scans run on a bounded grid (scan.hpp scan_grid: 512 workgroups of 2048 elements) and loop beyond it:
     a capture with more than 2^20 pulse-table rows ("rows": 4 samples per symbol) and one with more than 2^20 messages
@@ -1438,14 +1449,20 @@ def test_scans_loop_over_more_tiles_than_their_grid(pipe, oracle, case):
     if case == "rows":
         iq = synth_fsk(n, sps=4, seed=11, noise=0.02, deviation_hz=200e3)
         p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 1, 4, 0.1, 8, True)
+    elif case == "ask":                          # the ASK row merge (scan over the un-merged table) beyond its grid as well
+        iq = synth_fsk(n, sps=4, seed=13, noise=0.01)
+        env = np.repeat(np.random.default_rng(13).integers(0, 2, n // 4 + 1), 4)[:n]
+        iq = (iq * (0.2 + 0.8 * env)[:, None]).astype(np.float32)
+        p = DemodParams("ASK", 1, 0.0, 0.42, 1.0, 1, 4, 0.1, 8, True)
     else:
         iq = synth_fsk(n, sps=1, seed=12, noise=0.01, deviation_hz=200e3)
         iq[(np.arange(n) % 10) >= 6] *= np.float32(0.01)
         p = DemodParams("FSK", 1, 0.3, 0.0, 1.0, 1, 1, 0.1, 2, True)
-    qad = oracle.afp_demod(iq, p.noise_threshold, "FSK", 2)
-    ppseq = oracle.grab_pulse_lens(qad, 0.0, 1, "FSK", p.samples_per_symbol, 1, 1.0)
+    mod = p.modulation_type
+    qad = oracle.afp_demod(iq, p.noise_threshold, mod, 2)
+    ppseq = oracle.grab_pulse_lens(qad, p.center, 1, mod, p.samples_per_symbol, 1, 1.0)
     flat = oracle.ppseq_to_bits_flat(ppseq, p.samples_per_symbol, 1, True, p.pause_threshold)
-    assert len(ppseq) > (1 << 20) and (case == "rows" or len(flat[2]) > (1 << 20))
+    assert len(ppseq) > (1 << 20) and (case != "groups" or len(flat[2]) > (1 << 20))
     res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True)
     res.check_capacity()
     assert np.array_equal(res.ppseq(), ppseq)
