@@ -1008,8 +1008,14 @@ __device__ __forceinline__ uint32_t put_lane(uint32_t value, int row, uint32_t o
 // order 4 (planes = the two bits of state - 1, from the three threshold masks).
 template <int SRC, int MOD> constexpr int bp_waves() { return (SRC == SRC_IQ && MOD == URHGPU_MOD_ASK) ? URH_ASK_WPB : URH_WPB; }
 
+// A/B build knob (python -m urh_amd.build --tag w8 -DURH_BP_WAVES_PER_EU=8): occupancy the compiler has to reach for this kernel
+#ifdef URH_BP_WAVES_PER_EU
+#define URH_BP_OCC __attribute__((amdgpu_waves_per_eu(URH_BP_WAVES_PER_EU, URH_BP_WAVES_PER_EU)))
+#else
+#define URH_BP_OCC
+#endif
 template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1>
-__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) void k_demod_runs_bp(const RunArgs p) {
+__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_demod_runs_bp(const RunArgs p) {
     // One workgroup per chunk, URH_WPB wavefronts: wavefront w streams the w-th share of the chunk's rows on its own
     // (no barrier inside the streaming phase), so that the wavefronts resident on the chip cover a NARROW window of
     // the capture (DRAM page locality: a wavefront per 16 KiB measured 8 % faster than a wavefront per 64 KiB on a
