@@ -79,6 +79,9 @@ int urhgpu_ctx_sync(urhgpu_ctx *ctx);
  * pass are complete only after urhgpu_ctx_join (the context's stream waits for the tail; the host does not block) or
  * urhgpu_ctx_sync; every other entry point joins first.  enable = 0 switches back (synchronises).
  * Measured on MI355X: 0.30 ms per 1 GiB pass against 0.34 ms one after the other; bench.py times this mode.
+ * A caller that runs more than two passes ahead of the GPU is held back on the HOST at the start of the next pass until the tail
+ * that last used the pass's scratch arena has finished (bounded run-ahead; URH_ARENA_WAIT=stream makes the context's stream wait
+ * instead and keeps the host asynchronous, at the price of one more barrier packet between two hot kernels).
  * Environment knobs read here (experiments; defaults are what is measured): URH_HOT_STOP_EVENT=0 (record an event behind the hot
  * kernel instead of waiting on its dispatch's completion signal), URH_HOT_LDS_KB=<n> (dynamic LDS per hot workgroup: fewer of them
  * per CU), URH_TAIL_PRIORITY=1 (private tail stream at the highest priority). */

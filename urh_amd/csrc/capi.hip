@@ -312,7 +312,18 @@ int join_tail(urhgpu_ctx *ctx) {
 int begin_pipelined_pass(urhgpu_ctx *ctx) {
     std::swap(ctx->arena, ctx->arena_alt);
     std::swap(ctx->arena_alt, ctx->arena_alt2);
-    URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->flip], 0));
+    // Has the tail that last used this arena finished?  A caller that runs more than two passes ahead of the GPU (a tight loop of
+    // passes) is held back HERE, on the host, until it has (bounded run-ahead; the GPU still has the previous hot kernel queued
+    // behind the running one): a stream-level wait would put one more barrier packet between two hot kernels (about 4 us of the
+    // gap).  URH_ARENA_WAIT=stream keeps the host asynchronous and makes the stream wait instead.
+    const hipError_t q = hipEventQuery(ctx->ev_tail[ctx->flip]);
+    if (q == hipErrorNotReady) {
+        (void)hipGetLastError();                   // "not ready" is an answer, not an error: keep it out of the sticky last-error slot
+        if (ctx->arena_wait_on_stream) URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->flip], 0));
+        else URH_HIP(hipEventSynchronize(ctx->ev_tail[ctx->flip]));
+    } else if (q != hipSuccess) {
+        URH_HIP(q);
+    }
     return URHGPU_OK;
 }
 int end_pipelined_pass(urhgpu_ctx *ctx) {
@@ -456,6 +467,8 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
         ctx->hot_lds_pad = (e ? atoi(e) : 0) * 1024;       // (21 KiB was the default while the row kernel had 8-wavefront workgroups)
         const char *se = getenv("URH_HOT_STOP_EVENT");     // 0: record an event behind the hot kernel instead (comparison)
         ctx->hot_stop_event = se ? atoi(se) != 0 : true;
+        const char *aw = getenv("URH_ARENA_WAIT");         // "stream": never hold the host back (see begin_pipelined_pass)
+        ctx->arena_wait_on_stream = aw && strcmp(aw, "stream") == 0;
     }
     return URHGPU_OK;
 }

@@ -79,7 +79,9 @@ struct urhgpu_ctx {
     // (latency-bound, nearly empty) tail of this one -- and, with three arenas, of the one before.  Outputs are complete after urhgpu_ctx_join / urhgpu_ctx_sync.
     bool pipelined = false;
     int hot_lds_pad = 0;           // pipelined mode: dynamic LDS bytes added to every hot-kernel workgroup (see RunArgs::lds_pad)
-    bool hot_stop_event = true;    // pipelined mode: the tail waits for the hot dispatch's own completion signal (URH_HOT_STOP_EVENT)
+    bool hot_stop_event = true;
+    bool arena_wait_on_stream = false;   // pipelined mode: arena reuse guarded by a stream wait instead of bounded host run-ahead (URH_ARENA_WAIT=stream)
+      // pipelined mode: the tail waits for the hot dispatch's own completion signal (URH_HOT_STOP_EVENT)
     hipStream_t tail_stream = nullptr;
     bool own_tail_stream = false;
     urh::Arena arena_alt, arena_alt2;   // three scratch arenas in rotation: the hot kernel of pass i + 2 does not wait for the tail of pass i
