@@ -84,7 +84,7 @@ int urhgpu_ctx_sync(urhgpu_ctx *ctx);
  * instead and keeps the host asynchronous, at the price of one more barrier packet between two hot kernels).
  * Environment knobs read here (experiments; defaults are what is measured): URH_HOT_STOP_EVENT=0 (record an event behind the hot
  * kernel instead of waiting on its dispatch's completion signal), URH_HOT_LDS_KB=<n> (dynamic LDS per hot workgroup: fewer of them
- * per CU), URH_TAIL_PRIORITY=1 (private tail stream at the highest priority). */
+ * per CU; default 0, and 33 for the urhgpu_shard_* passes, whose longer tail needs the room), URH_TAIL_PRIORITY=1 (private tail stream at the highest priority). */
 int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
 int urhgpu_ctx_join(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no

@@ -465,6 +465,11 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
     {   // experiment knob: URH_HOT_LDS_KB=<KiB of dynamic LDS per hot workgroup> (0 / unset: the default below)
         const char *e = getenv("URH_HOT_LDS_KB");
         ctx->hot_lds_pad = (e ? atoi(e) : 0) * 1024;       // (21 KiB was the default while the row kernel had 8-wavefront workgroups)
+        // Sharded passes: their tail is the generic one with three exchanges in it -- 0.18 ms on an idle machine, 0.38 ms beside hot
+        // workgroups that fill every SIMD's register file, which made the tail the bound of the pass (0.365-0.40 ms).  33 KiB per hot
+        // workgroup = four of them per CU: the hot kernel takes 0.31 ms and the tail keeps up (0.317 ms per pass; 21 / 27 KiB = 6 / 5
+        // per CU: 0.36 / 0.34; 38 KiB and more = 3: 0.34-0.42; tools/sharded_two_engines.py under URH_HOT_LDS_KB).
+        ctx->hot_lds_pad_sharded = (e ? atoi(e) : 33) * 1024;
         const char *se = getenv("URH_HOT_STOP_EVENT");     // 0: record an event behind the hot kernel instead (comparison)
         ctx->hot_stop_event = se ? atoi(se) != 0 : true;
         const char *aw = getenv("URH_ARENA_WAIT");         // "stream": never hold the host back (see begin_pipelined_pass)
@@ -718,7 +723,7 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     a.noise_sqrd = p->noise_threshold * p->noise_threshold;
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
-    a.lds_pad = ctx->pipelined ? ctx->hot_lds_pad : 0;
+    a.lds_pad = ctx->pipelined ? ctx->hot_lds_pad_sharded : 0;
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     a.chunks = ss->table + rank;               // this rank's chunks sit at table[rank .. rank + n_chunks)
     a.slab = ss->slab;
