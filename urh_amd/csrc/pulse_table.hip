@@ -1258,6 +1258,9 @@ int launch_emit_rows(const EmitArgs &a, int64_t n_local_chunks, hipStream_t s) {
 }
 
 static inline int64_t scan_blocks(int64_t cap) { return (cap + kScanTile - 1) / kScanTile; }
+// the group scan runs one element per thread (k_scan_lookback<..., kGroupItems>)
+constexpr int kGroupItems = 1;
+static inline int64_t group_scan_blocks(int64_t cap) { return (cap + kScanBlock * kGroupItems - 1) / (kScanBlock * kGroupItems); }
 
 // scratch bytes needed by merge_rows_ask for up to cap rows
 size_t merge_scratch_bytes(int64_t cap) {
@@ -1289,7 +1292,7 @@ int launch_merge_rows_ask(const int64_t *rows_in, const int64_t *d_n_in, int64_t
 size_t bits_scratch_bytes(int64_t cap_rows) {
     const int64_t nb = scan_blocks(cap_rows);
     const int64_t cap_groups = cap_rows + 1;
-    const int64_t nbg = scan_blocks(cap_groups);
+    const int64_t nbg = group_scan_blocks(cap_groups);
     return (size_t)(nb + 1) * sizeof(VecK<4>) + (size_t)(nbg + 1) * sizeof(VecK<3>) + (size_t)cap_rows * sizeof(RowInfo) +
            (size_t)cap_groups * (sizeof(GroupInfo) + sizeof(GroupOut)) + 64 + 8 * 256 + 64 + 256 +
            (size_t)kHugeCap * sizeof(HugeRow) + 256;
@@ -1305,7 +1308,7 @@ BitsScratch carve_bits(void *scratch, int64_t cap_rows) {
     BitsScratch b;
     b.nb = scan_blocks(cap_rows);
     const int64_t cap_groups = cap_rows + 1;
-    b.nbg = scan_blocks(cap_groups);
+    b.nbg = group_scan_blocks(cap_groups);
     char *p = (char *)scratch;
     auto take = [&](size_t bytes) { char *r = p; p += (bytes + 255) & ~size_t(255); return r; };
     b.part4 = (VecK<4> *)take((size_t)(b.nb + 1) * sizeof(VecK<4>));
@@ -1342,7 +1345,7 @@ struct GroupCountFinal {
 // descriptor memory of the two single-pass scans (rows: K = 4, groups: K = 3)
 size_t bits_desc_bytes(int64_t cap_rows) {
     if (cap_rows <= 0) cap_rows = 1;
-    return (((size_t)(scan_blocks(cap_rows) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)) + (size_t)(scan_blocks(cap_rows + 1) + 1) * sizeof(ScanDesc<3>) + 512;
+    return (((size_t)(scan_blocks(cap_rows) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)) + (size_t)(group_scan_blocks(cap_rows + 1) + 1) * sizeof(ScanDesc<3>) + 512;
 }
 
 int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
@@ -1376,7 +1379,7 @@ int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};
     // the groups (usually a handful: one workgroup) go through the single-pass look-back scan: one launch instead of two
-    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
+    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandArgs ea{rows, d_n_rows, b.info, b.gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp, b.huge, b.huge_count, kHugeCap};
     const int64_t eb = std::min<int64_t>((cap_rows + 255) / 256, kExpandMaxBlocks);
@@ -1464,7 +1467,7 @@ int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};
-    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
+    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, b.d_n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
                       bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt};

@@ -278,23 +278,29 @@ __device__ __forceinline__ VecK<K> scan_look_back(ScanDesc<K> *desc, int64_t b, 
 // Load::operator()(int64 i) -> VecK<K>; Store::operator()(int64 i, const VecK<K>& value, const VecK<K>& excl_prefix);
 // Final::operator()(const VecK<K>& grand_total) runs once on one thread: by the last workgroup of the scan when it does not
 // depend on what the OTHER workgroups stored (elect == 0), else by the workgroup that finishes last (ticket election).
-template <int K, class Load, class Store, class Final>
-__global__ __launch_bounds__(kScanBlock) void k_scan_lookback(const int64_t *d_n, Load load, ScanDesc<K> *desc, int64_t nblocks_max,
+// ITEMS: elements per thread (tile = kScanBlock * ITEMS elements).  Scans over a handful of elements whose Load / Store are heavy (the
+// group scan: 105 VGPRs at four items) take one: the kernel then fits beside the hot kernel of the next pass (see scan_grid).
+// At least six waves per SIMD = at most 80 VGPRs: what one retiring hot workgroup (72 + the 8 it never had) leaves free on a SIMD.
+template <int K, class Load, class Store, class Final, int ITEMS = kScanItems>
+__global__ __launch_bounds__(kScanBlock) __attribute__((amdgpu_waves_per_eu(6))) void k_scan_lookback(const int64_t *d_n, Load load, ScanDesc<K> *desc, int64_t nblocks_max,
                                                                Store store, Final fin, unsigned long long epoch, int32_t *ticket,
                                                                int elect) {
     __shared__ VecK<K> s_wave[kScanBlock / 64];
     __shared__ VecK<K> s_prefix;
     const int64_t n = *d_n;
-    const int64_t nb = scan_active_blocks(n, nblocks_max);
+    constexpr int64_t kTileElems = (int64_t)kScanBlock * ITEMS;
+    int64_t nb = (n + kTileElems - 1) / kTileElems;          // scan_active_blocks for this tile size
+    if (nb > nblocks_max) nb = nblocks_max;
+    if (nb < 1) nb = 1;
     // The grid may be smaller than nblocks_max (scan_grid): workgroup w then takes tiles w, w + G, ...  A tile still only waits
     // for tiles below it, and those belong to workgroups that are running or will be dispatched whatever this one does.
     for (int64_t b = blockIdx.x; b < nb; b += gridDim.x) {
-        const int64_t base = b * kScanTile;
-        VecK<K> item[kScanItems];
+        const int64_t base = b * kTileElems;
+        VecK<K> item[ITEMS];
         VecK<K> acc; acc.zero();
-        const int64_t i0 = base + (int64_t)threadIdx.x * kScanItems;
+        const int64_t i0 = base + (int64_t)threadIdx.x * ITEMS;
 #pragma unroll
-        for (int j = 0; j < kScanItems; ++j) {
+        for (int j = 0; j < ITEMS; ++j) {
             item[j].zero();
             if (i0 + j < n) item[j] = load(i0 + j);
             acc.add(item[j]);
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(kScanBlock) void k_scan_lookback(const int64_t *d_n
         const VecK<K> prefix = s_prefix;
         ex.add(prefix);
 #pragma unroll
-        for (int j = 0; j < kScanItems; ++j) {
+        for (int j = 0; j < ITEMS; ++j) {
             if (i0 + j < n) store(i0 + j, item[j], ex);
             ex.add(item[j]);
         }
