@@ -549,6 +549,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
 
+    # Exactly ONE line on stdout: libraries write there too (RCCL prints a five-line version banner through C stdio, which lands
+    # behind the JSON line when the process exits), so file descriptor 1 is pointed at stderr for the rest of the run and the line
+    # goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from urh_amd.pipeline import DemodParams, DevicePipeline
     from urh_amd.synth import fsk_capture, spec_fsk_capture
@@ -755,7 +762,7 @@ def main():
             pipe.ctx.join()
             torch.cuda.synchronize()
             out["extra"] = run_extras(DevicePipeline(local_rank, pipelined=False), dev, args)     # stage by stage: nothing overlapped
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
         dist.destroy_process_group()
 
