@@ -74,3 +74,15 @@ def test_argument_errors_without_gpu():
     import torch
     if not torch.cuda.is_available():
         assert lib.urhgpu_ctx_create(0, C.byref(h)) == _lib.ERR_NO_DEVICE
+
+
+def test_environment_knobs_of_the_library_are_documented_in_the_header():
+    """every getenv() of the library (experiment knobs of the pipelined mode, profiling) is described in include/urhgpu.h"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for f in glob.glob(os.path.join(root, "urh_amd", "csrc", "*.h*")):
+        names |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(f).read()))
+    header = open(os.path.join(root, "include", "urhgpu.h")).read()
+    assert names and not [n for n in sorted(names) if n not in header]
