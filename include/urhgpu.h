@@ -323,7 +323,10 @@ int urhgpu_histogram_f32_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const
  * int64[n_msgs][max_bins] or NULL (the histograms stay on the device).
  * The peak picking (AutoInterpretation.py:250-277) happens on the device too: out_flag[m] = 1: out_center[m] is detect_center's
  * result; 0: None; 2: too many bins (see above); 3: the second and third most populated peaks hold the same count, so the result
- * depends on how np.argsort orders equal keys -- the caller asks again with out_hist and lets numpy decide.  Both may be NULL. */
+ * depends on how np.argsort orders equal keys -- the caller asks again with out_hist, for THOSE messages only, and lets numpy decide.
+ * Both may be NULL.  ranges must be ascending and disjoint (start[m] >= end[m - 1]; URHGPU_ERR_ARG otherwise): per-message scratch
+ * lives at [start, end) of capture-sized arrays.  The histogram pool is bounded: messages are processed in batches of at most
+ * 64 MiB / (4 max_bins) (16 384 at max_bins = 4096), whatever n_msgs is. */
 int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins,
                             double *out_stats, int64_t *out_hist, double *out_center, int32_t *out_flag);
 /* urhgpu_msg_plateaus: get_plateau_lengths(x[start:end], centers[m], percentage) for every message with a center (NaN: none,
@@ -408,6 +411,11 @@ int urhgpu_modulate_gfsk(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits,
 /* IQArray.convert_to (IQArray.py:127-203) on device memory: n VALUES (two per IQ sample) of src_dtype -> dst_dtype, any
  * pair of different URHGPU_DT_* codes, with the reference's wrapping / truncating numpy semantics.  Asynchronous. */
 int urhgpu_convert_dev(urhgpu_ctx *ctx, const void *d_src, int src_dtype, void *d_dst, int dst_dtype, int64_t n);
+/* The plain numpy cast between float32 and one of the four integer sample types (no IQArray scaling): what Filter.apply_fir_filter
+ * does to an integer capture before filtering (`tmp.real = input_signal[0::2]`, Filter.py:37-41: the raw values as float32) and what
+ * IQArray.__setitem__ does with the filtered complex64 range (`self.real[key] = value.real`, IQArray.py:31-33: truncation toward zero
+ * through int32, low bits kept).  Exactly one of the two dtypes is URHGPU_DT_F32.  Asynchronous. */
+int urhgpu_astype_dev(urhgpu_ctx *ctx, const void *d_src, int src_dtype, void *d_dst, int dst_dtype, int64_t n);
 
 /* path_creator.create_path's pass over the samples (path_creator.pyx:46-66): 1-D samples of dtype (the five IQ sample
  * types), stretches of samples_per_pixel samples from `start` (the last one ends at `end`); values[2k] / values[2k+1] =

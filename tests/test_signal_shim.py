@@ -152,6 +152,65 @@ def test_edits_and_filter_range(pipe, oracle):
     assert sig._qad is None and sig.num_samples == 80_007
 
 
+@pytest.mark.parametrize("dtype", [np.int8, np.uint8, np.int16, np.uint16])
+def test_filter_range_on_integer_captures(pipe, oracle, dtype):
+    """Signal.filter_range on integer captures: the reference filters the RAW integer values as complex64 (Filter.py:37-41) and
+    writes them back with numpy's truncating cast (IQArray.__setitem__, IQArray.py:31-33) -- no IQArray scaling either way.
+    Against the real Signal / Filter objects where oracle/_ref holds them, else against the same steps in numpy."""
+    import ref_python
+    from urh_amd.signal import Signal
+    iq = synth_fsk(60_000, sps=100, seed=21, noise=0.03, dtype=dtype)
+    taps = (np.hanning(17) / np.hanning(17).sum() * 0.9).astype(np.complex64)
+    a, b = 10_001, 41_234
+    mine = Signal(iq, pipe=pipe)
+    mine.noise_threshold = 3.0
+    _ = mine.qad
+    mine.filter_range(a, b, taps)
+    if ref_python.available():
+        ref_python.setup()
+        from urh.signalprocessing.Filter import Filter
+        from urh.signalprocessing.IQArray import IQArray
+        from urh.signalprocessing.Signal import Signal as RefSignal
+        ref = RefSignal("")
+        ref.iq_array = IQArray(iq.copy())
+        ref.noise_threshold = 3.0
+        _ = ref.qad
+        ref.filter_range(a, b, Filter(list(taps)))
+        want_iq, want_qad = ref.iq_array.data, np.asarray(ref.qad)
+    else:
+        seg = np.empty(b - a, np.complex64)
+        seg.real, seg.imag = iq[a:b, 0], iq[a:b, 1]
+        f = oracle.fir_filter(seg, taps)
+        want_iq = iq.copy()
+        want_iq[a:b, 0], want_iq[a:b, 1] = f.real, f.imag
+        want_qad = oracle.afp_demod(iq, np.float32(3.0), "FSK", 2)
+        want_qad[a:b] = oracle.afp_demod(np.ascontiguousarray(want_iq[a:b]), np.float32(3.0), "FSK", 2)
+    assert np.array_equal(mine.iq.cpu().numpy(), want_iq)
+    assert np.array_equal(u32(mine.qad_host()), u32(want_qad))
+
+
+def test_qad_survives_bad_slicing_parameters(pipe, oracle):
+    """The reference's qad depends on the demodulation parameters only (Signal.py:421-431): samples_per_symbol = 0 or a tolerance
+    outside uint16 make grab_pulse_lens / _ppseq_to_bits fail, not the qad; delete_range leaves a zeros(2) cache alone (:619-629)."""
+    from urh_amd.signal import Signal
+    iq = synth_fsk(20_000, sps=100, seed=5, noise=0.02)
+    sig = Signal(iq, pipe=pipe)
+    sig.samples_per_symbol = 0
+    assert np.array_equal(u32(sig.qad_host()), u32(oracle.afp_demod(iq, 0.0, "FSK", 2)))
+    with pytest.raises(ZeroDivisionError):
+        sig.bits()
+    sig2 = Signal(iq, pipe=pipe)
+    sig2.tolerance = 70_000
+    assert np.array_equal(u32(sig2.qad_host()), u32(oracle.afp_demod(iq, 0.0, "FSK", 2)))
+    with pytest.raises(OverflowError):
+        sig2.ppseq()
+    sig3 = Signal(iq, pipe=pipe)
+    sig3.noise_threshold = sig3.max_magnitude
+    assert sig3.qad_host().shape == (2,)
+    sig3.delete_range(100, 200)
+    assert sig3.num_samples == 19_900 and sig3.qad_host().shape == (2,)
+
+
 def test_against_the_real_reference_signal_object(pipe):
     """The same sequence of parameter changes on the real reference's Signal + ProtocolAnalyzer (staged under oracle/_ref) and on
     urh_amd.signal.Signal: qad and bit strings equal after every step."""

@@ -1,11 +1,10 @@
 #!/bin/bash
-# Build kbench variants: kbench_b<KBATCH>w<MINWAVES>[_v0]
+# Build kbench variants: kbench_b<KBATCH>w<MINWAVES>
 set -e
 cd "$(dirname "$0")"
 FLAGS="$XFLAGS --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -I../../urh_amd/csrc -Wno-unused-function"
 for v in "$@"; do
   b=${v%%w*}; b=${b#b}; w=${v##*w}; w=${w%%_*}
-  if [[ "$v" == v0 ]]; then /opt/rocm/bin/hipcc $FLAGS -DKBENCH_V0 kbench.hip -o kbench_v0 & continue; fi
   /opt/rocm/bin/hipcc $FLAGS -DURH_KBATCH=$b -DURH_MINWAVES=$w kbench.hip -o kbench_$v$SUFFIX &
 done
 wait

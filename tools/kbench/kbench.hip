@@ -1,7 +1,7 @@
 // kbench.hip -- stand-alone A/B timing harness for the hot kernel (developer tool, not part of the product).
 //   build: tools/kbench/build.sh     run (GPU box): tools/kbench/kbench_<variant> [log2_samples] [tiles_per_chunk]
-// Times k_demod_runs (current source, compiled with -DURH_KBATCH / -DURH_MINWAVES variants) against the
-// round-1 v0 kernel and a copy-shaped ceiling kernel on a device-generated 2-FSK capture, and checks that
+// Times k_demod_runs (current source, compiled with -DURH_KBATCH / -DURH_MINWAVES variants) against
+// a copy-shaped ceiling kernel on a device-generated 2-FSK capture, and checks that
 // both kernels produce identical qad / chunk records (full-size parity between kernel generations).
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -10,15 +10,8 @@
 #include <string.h>
 #include <vector>
 
-#ifdef KBENCH_V0
-#include "demod_runs_v0.hip"      // the round-1 v0 kernel, kept for A/B timing and full-size parity
-#define URH_KBATCH 4
-#define URH_MINWAVES 1
-#define LAUNCH(a, mod, wq, s) urh::launch_demod_runs_iq(a, URHGPU_DT_F32, mod, c->n_chunks, wq, s)
-#else
 #include "../../urh_amd/csrc/demod_runs.hip"
 #define LAUNCH(a, mod, wq, s) urh::launch_demod_runs_iq(a, URHGPU_DT_F32, mod, wq, s)
-#endif
 
 namespace urh { thread_local char g_hip_err[256] = ""; }
 

@@ -26,6 +26,17 @@ void Arena::release() {
     if (base) { (void)hipFree(base); base = nullptr; cap = 0; used = 0; }
 }
 
+// pipelined mode: make the caller's stream wait for the tail of the last pass (no host blocking).  Every entry point that takes
+// scratch from ctx->arena or launches on ctx->stream calls this first: on a pipelined context the arena is the one the last pass's
+// tail may still be working in.
+int join_tail(urhgpu_ctx *ctx) {
+    if (ctx->tail_pending) {
+        URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[(ctx->flip + 2) % 3], 0));       // the pass recorded last
+        ctx->tail_pending = false;
+    }
+    return URHGPU_OK;
+}
+
 }  // namespace urh
 
 #include <stdlib.h>
@@ -296,14 +307,7 @@ int scan_state(urhgpu_ctx *ctx, int64_t cap_rows, ScanState *out) {
     return URHGPU_OK;
 }
 
-// pipelined mode: make the caller's stream wait for the tail of the last pass (no host blocking)
-int join_tail(urhgpu_ctx *ctx) {
-    if (ctx->tail_pending) {
-        URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[(ctx->flip + 2) % 3], 0));       // the pass recorded last
-        ctx->tail_pending = false;
-    }
-    return URHGPU_OK;
-}
+using urh::join_tail;
 
 // pipelined mode: rotate to the scratch arena used three passes ago; the caller's stream first waits for the tail that used it.
 // (Two arenas made the hot kernel of pass i + 2 wait for the tail of pass i -- whose row kernel, starved of wave slots by the hot kernel
@@ -1237,6 +1241,16 @@ int urhgpu_convert_dev(urhgpu_ctx *ctx, const void *d_src, int src_dtype, void *
     URH_HIP(hipSetDevice(ctx->device));
     URH_TRY(join_tail(ctx));
     URH_TRY(launch_convert(d_src, src_dtype, d_dst, dst_dtype, n, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
+int urhgpu_astype_dev(urhgpu_ctx *ctx, const void *d_src, int src_dtype, void *d_dst, int dst_dtype, int64_t n) {
+    if (!ctx || n < 0 || (n > 0 && (!d_src || !d_dst))) return URHGPU_ERR_ARG;
+    if (src_dtype == dst_dtype) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(launch_astype(d_src, src_dtype, d_dst, dst_dtype, n, ctx->stream));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }

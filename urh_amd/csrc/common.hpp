@@ -92,3 +92,7 @@ struct urhgpu_ctx {
     bool tail_pending = false;
     int tile_parity = 0;           // which of the two huge-row counters (d_tickets[8..9]) the current pass appends to
 };
+
+namespace urh {
+int join_tail(urhgpu_ctx *ctx);    // capi.hip: the caller's stream waits for the tail of the last pipelined pass
+}

@@ -78,6 +78,47 @@ template <> int conv_from<float>(const void *src, int d, void *dst, int64_t n, h
                  URH_CONV_CASE(float, URHGPU_DT_U16, uint16_t) default: return URHGPU_ERR_DTYPE; }
 }
 
+// ---- plain numpy casts (ndarray.astype / assignment into an array of another type, no IQArray scaling) -------------------
+// integer -> float32 is exact; float32 -> integer is the C cast as x86-64 evaluates it (truncation toward zero through
+// int32, low bits kept) -- what `IQArray.__setitem__` does with a filtered complex64 range (IQArray.py:31-33).
+template <typename S, typename D> struct Cast { static __device__ D f(S v) { return (D)v; } };
+template <typename D> struct Cast<float, D> { static __device__ D f(float v) { return (D)cvt_trunc_i32(v); } };
+template <> struct Cast<float, float> { static __device__ float f(float v) { return v; } };
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void k_astype(const S *src, D *dst, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = Cast<S, D>::f(src[i]);
+}
+template <typename S, typename D>
+static int astype_launch(const void *src, void *dst, int64_t n, hipStream_t s) {
+    int64_t g = (n + 255) / 256; if (g > 65536) g = 65536;
+    hipLaunchKernelGGL((k_astype<S, D>), dim3((unsigned)g), dim3(256), 0, s, (const S *)src, (D *)dst, n);
+    return URHGPU_OK;
+}
+// one side is float32 (the filters' working type), the other one of the four integer sample types
+int launch_astype(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, hipStream_t s) {
+    if (n <= 0) return URHGPU_OK;
+    if (dst_dtype == URHGPU_DT_F32) {
+        switch (src_dtype) {
+            case URHGPU_DT_I8: return astype_launch<int8_t, float>(src, dst, n, s);
+            case URHGPU_DT_U8: return astype_launch<uint8_t, float>(src, dst, n, s);
+            case URHGPU_DT_I16: return astype_launch<int16_t, float>(src, dst, n, s);
+            case URHGPU_DT_U16: return astype_launch<uint16_t, float>(src, dst, n, s);
+            default: return URHGPU_ERR_DTYPE;
+        }
+    }
+    if (src_dtype == URHGPU_DT_F32) {
+        switch (dst_dtype) {
+            case URHGPU_DT_I8: return astype_launch<float, int8_t>(src, dst, n, s);
+            case URHGPU_DT_U8: return astype_launch<float, uint8_t>(src, dst, n, s);
+            case URHGPU_DT_I16: return astype_launch<float, int16_t>(src, dst, n, s);
+            case URHGPU_DT_U16: return astype_launch<float, uint16_t>(src, dst, n, s);
+            default: return URHGPU_ERR_DTYPE;
+        }
+    }
+    return URHGPU_ERR_DTYPE;
+}
+
 // n = number of VALUES (2 per IQ sample); src_dtype != dst_dtype
 int launch_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, hipStream_t s) {
     if (n <= 0) return URHGPU_OK;

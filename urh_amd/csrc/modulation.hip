@@ -318,6 +318,7 @@ int urhgpu_detect_modulation_dev(urhgpu_ctx *ctx, const float *d_iq, int64_t n, 
         (n_msgs > 0 && (!ranges || !labels_out || !d_iq)))
         return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));                               // pipelined context: the arena below may still serve the last pass's tail
     hipStream_t s = ctx->stream;
     int64_t max_len = 0;
     for (int m = 0; m < n_msgs; ++m) {

@@ -696,6 +696,9 @@ int build_batch(urhgpu_ctx *ctx, const int64_t *ranges, int n_msgs, int64_t n, c
     for (int m = 0; m < n_msgs; ++m) {
         const int64_t s = ranges[2 * m], e = ranges[2 * m + 1];
         if (s < 0 || e < s || e > n) return URHGPU_ERR_ARG;
+        // per-message scratch (compacted samples, boundary lists) lives at [start, end) of capture-sized arrays: messages must be
+        // ascending and disjoint, as segmentation delivers them -- overlapping ranges would race on it silently
+        if (m > 0 && s < ranges[2 * m - 1]) return URHGPU_ERR_ARG;
         MsgState st;
         memset(&st, 0, sizeof(st));
         st.start = s; st.end = e; st.first_tile = (int64_t)b.tiles.size();
@@ -715,11 +718,9 @@ int build_batch(urhgpu_ctx *ctx, const int64_t *ranges, int n_msgs, int64_t n, c
 
 extern "C" {
 
-int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins,
-                            double *out_stats, int64_t *out_hist, double *out_center, int32_t *out_flag) {
-    if (!ctx || n < 0 || n_msgs < 0 || max_bins < 1 || (n_msgs > 0 && (!ranges || !out_stats || !d_x))) return URHGPU_ERR_ARG;
-    if (n_msgs == 0) return URHGPU_OK;
-    URH_HIP(hipSetDevice(ctx->device));
+// one batch of urhgpu_msg_center_stats: at most kCenterBatchBytes of histogram pool (see below)
+static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins,
+                              double *out_stats, int64_t *out_hist, double *out_center, int32_t *out_flag) {
     MsgBatch b;
     URH_TRY(build_batch(ctx, ranges, n_msgs, n, nullptr, b));
     // scratch: state, tiles, per-tile counts / min-max, leaf sums, the compacted samples, the histogram pool
@@ -781,6 +782,27 @@ int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const 
     return URHGPU_OK;
 }
 
+// The histogram pool holds max_bins counters per message and is cleared for every call: a capture cut into 10^5 .. 10^6 segments (a
+// bursty capture whose modulation is not OOK, so nothing was merged) would ask for gigabytes of it at once.  The messages are
+// therefore taken in batches whose pool stays below kCenterBatchBytes; the compacted samples (indexed by message start) are shared.
+constexpr size_t kCenterBatchBytes = size_t(64) << 20;
+
+int urhgpu_msg_center_stats(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins,
+                            double *out_stats, int64_t *out_hist, double *out_center, int32_t *out_flag) {
+    if (!ctx || n < 0 || n_msgs < 0 || max_bins < 1 || (n_msgs > 0 && (!ranges || !out_stats || !d_x))) return URHGPU_ERR_ARG;
+    if (n_msgs == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));                               // pipelined context: the arena below may still serve the last pass's tail
+    const int64_t per = std::max<int64_t>(1, (int64_t)(kCenterBatchBytes / ((size_t)max_bins * 4)));
+    for (int64_t m0 = 0; m0 < n_msgs; m0 += per) {
+        const int nb = (int)std::min<int64_t>(per, n_msgs - m0);
+        URH_TRY(center_stats_batch(ctx, d_x, n, ranges + 2 * m0, nb, max_bins, out_stats + 8 * m0,
+                                   out_hist ? out_hist + (size_t)m0 * (size_t)max_bins : nullptr, out_center ? out_center + m0 : nullptr,
+                                   out_flag ? out_flag + m0 : nullptr));
+    }
+    return URHGPU_OK;
+}
+
 int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
                         int percentage, int64_t extra_window, int64_t *out_off, uint64_t *out_len, int64_t cap_total) {
     if (!ctx || n < 0 || n_msgs < 0 || percentage < 0 || extra_window < 0 || cap_total < 0 ||
@@ -798,6 +820,7 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
         const int64_t limit = ((int64_t)percentage * len) / 100;
         windows[(size_t)m] = std::min<int64_t>(len, limit + extra_window);
     }
+    URH_TRY(join_tail(ctx));                               // pipelined context: the arena below may still serve the last pass's tail
     MsgBatch b;
     URH_TRY(build_batch(ctx, ranges, n_msgs, n, windows.data(), b));
     for (int m = 0; m < n_msgs; ++m) b.host[(size_t)m].center = centers[m];

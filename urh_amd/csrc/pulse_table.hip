@@ -763,6 +763,9 @@ __global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs
     __shared__ ResElem s_w[kResolveBlock / 64];
     const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // this pass's huge-row counter starts at zero whatever an earlier pass of the same parity left behind (one that failed between
+    // its row and its expansion launches never reached the kernel that clears the counter for its successor)
+    if (c == 0 && ft.want_bits) ft.huge_count[ft.parity] = 0;
     ResElem e = res_identity();
     if (c < a.n_chunks) {
         ChunkInfo *ch = a.chunks + c;

@@ -401,24 +401,31 @@ def centers_batched(pipe, data, message_indices, max_bins: int = 4096):
                                            n_msgs, max_bins, stats.ctypes.data_as(C.c_void_p), None, cen.ctypes.data_as(C.c_void_p),
                                            flag.ctypes.data_as(C.c_void_p)))
     centers = [np.float64(c) if f == 1 else None for c, f in zip(cen.tolist(), flag.tolist())]
-    hist = None
-    for m in np.nonzero(flag >= 2)[0].tolist():
-        if flag[m] == 2:
-            centers[m] = detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True)
-            continue
-        if hist is None:                             # equally populated peaks: fetch the histograms, np.argsort decides
-            hist = np.zeros((n_msgs, max_bins), dtype=np.int64)
-            _lib.check(lib.urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
-                                                   n_msgs, max_bins, stats.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p), None, None))
-        n_edges = int(stats[m, 6])
-        hist_min, hist_max, step = float(stats[m, 2]), float(stats[m, 3]), float(stats[m, 5])
-        with np.errstate(all="ignore"):
-            edges = np.arange(hist_min, hist_max + step, step)                  # the same edges the device binned with
-        if len(edges) != n_edges or edges[0] != stats[m, 7]:                    # cannot happen; never bin against other edges silently
-            centers[m] = detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True)
-        else:
-            centers[m] = peaks_center(hist[m, :n_edges - 1], edges)
+    for m in np.nonzero(flag == 2)[0].tolist():      # more bins than the pool holds (a nearly constant message): the single-message path
+        centers[m] = detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True)
+    ties = np.nonzero(flag == 3)[0]
+    # equally populated peaks: np.argsort's order of equal keys decides.  Only THOSE messages' histograms are fetched, a bounded
+    # number at a time (a capture can hold 10^5 .. 10^6 messages; max_bins int64 counters each on the host)
+    for t0 in range(0, len(ties), _TIE_BATCH):
+        tie = ties[t0:t0 + _TIE_BATCH]
+        tr = np.ascontiguousarray(ranges[tie])
+        tstats = np.zeros((len(tie), 8), dtype=np.float64)
+        hist = np.zeros((len(tie), max_bins), dtype=np.int64)
+        _lib.check(lib.urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), tr.ctypes.data_as(C.c_void_p),
+                                               len(tie), max_bins, tstats.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p), None, None))
+        for k, m in enumerate(tie.tolist()):
+            n_edges = int(tstats[k, 6])
+            hist_min, hist_max, step = float(tstats[k, 2]), float(tstats[k, 3]), float(tstats[k, 5])
+            with np.errstate(all="ignore"):
+                edges = np.arange(hist_min, hist_max + step, step)                  # the same edges the device binned with
+            if len(edges) != n_edges or edges[0] != tstats[k, 7]:                   # cannot happen; never bin against other edges silently
+                centers[m] = detect_center_dev(pipe, x[int(ranges[m, 0]):int(ranges[m, 1])], _single=True)
+            else:
+                centers[m] = peaks_center(hist[k, :n_edges - 1], edges)
     return centers
+
+
+_TIE_BATCH = 1024
 
 
 def _plateaus_raw(pipe, x, ranges, cen, percentage):

@@ -45,6 +45,23 @@ def convert_to(data, target_dtype, ctx=None):
     return out
 
 
+def astype(data, target_dtype, ctx=None):
+    """numpy's plain cast (no IQArray scaling) between float32 and an integer sample type, on the device: the raw integer values
+    as float32 (Filter.apply_fir_filter, Filter.py:37-41) / the truncating write-back of IQArray.__setitem__ (IQArray.py:31-33)."""
+    import torch
+    target = np.dtype(target_dtype)
+    t = data.contiguous()
+    src = _torch_np_dtype(t)
+    if src == target:
+        return t
+    out = torch.empty(t.shape, dtype=_torch_dtype_for(target), device=t.device)
+    ctx = ctx or _lib.default_context()
+    ctx.set_stream(torch.cuda.current_stream(t.device).cuda_stream)
+    _lib.check(_lib.load().urhgpu_astype_dev(ctx.handle, C.c_void_p(t.data_ptr()), _DT[src], C.c_void_p(out.data_ptr()), _DT[target],
+                                             t.numel()))
+    return out
+
+
 def as_complex64(data, ctx=None):
     """IQArray.as_complex64 (:92-93): float32 conversion viewed as complex64 (N,)."""
     import torch

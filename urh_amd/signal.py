@@ -172,10 +172,23 @@ class Signal:
                 self._qad = self.quad_demod()
             else:
                 # ASK / FSK: the fused pass gives qad AND the pulse table / bits for the current slicing parameters
-                self.demod_passes += 1
-                res = self.pipe.iq_to_bits_checked(self._iq, self.params(), want_qad=True)
-                self._qad = res.qad.clone()          # the pipeline's buffers are reused by the next pass
-                self._bits, self._bits_key = self._detach(res), self._slice_key()
+                # (the reference's qad depends on the demodulation parameters only: slicing parameters the fused pass cannot take
+                # -- samples_per_symbol < 1, tolerance outside uint16, a pulse table beyond the output capacity -- must not make
+                # the qad fail; they raise where the reference raises, in ppseq() / bits())
+                res = None
+                try:
+                    res = self.pipe.iq_to_bits_checked(self._iq, self.params(), want_qad=True)
+                except (ZeroDivisionError, OverflowError, ValueError):
+                    pass
+                except _lib.UrhGpuError as e:
+                    if e.status not in (_lib.ERR_CAPACITY, _lib.ERR_ARG, _lib.ERR_UNSUPPORTED):
+                        raise
+                if res is None:
+                    self._qad = self.quad_demod()
+                else:
+                    self.demod_passes += 1
+                    self._qad = res.qad.clone()          # the pipeline's buffers are reused by the next pass
+                    self._bits, self._bits_key = self._detach(res), self._slice_key()
         return self._qad
 
     @staticmethod
@@ -300,8 +313,11 @@ class Signal:
 
     def delete_range(self, start: int, end: int):
         torch = self.pipe.torch
+        n_before = self.num_samples
         self._iq = torch.cat([self._iq[:start], self._iq[end:]]).contiguous()
-        if self._qad is not None:
+        # the reference indexes the cache with a mask of num_samples entries: a zeros(2) cache (noise threshold at the sample
+        # type's maximum) does not take it -- IndexError, logged, cache kept as it is (Signal.py:619-629)
+        if self._qad is not None and int(self._qad.shape[0]) == n_before:
             self._qad = torch.cat([self._qad[:start], self._qad[end:]]).contiguous()
         self._after_edit()
 
@@ -328,8 +344,10 @@ class Signal:
         n = int(seg.shape[0])
         if n == 0:
             return
-        from .iq_array import convert_to
-        x = convert_to(seg.clone(), np.float32, self.pipe.ctx)          # a copy: 16-byte aligned whatever `start` is
+        # the RAW sample values as float32 (Filter.apply_fir_filter, Filter.py:37-41: no IQArray scaling), filtered, and written
+        # back with numpy's truncating cast (IQArray.__setitem__, IQArray.py:31-33)
+        from .iq_array import astype
+        x = astype(seg.clone(), np.float32, self.pipe.ctx)              # a copy: 16-byte aligned whatever `start` is
         h = np.ascontiguousarray(taps, dtype=np.complex64)
         d_h = torch.from_numpy(h.view(np.float32).copy()).to(self.pipe.device)
         y = torch.empty_like(x)
@@ -337,7 +355,7 @@ class Signal:
         _lib.check(_lib.load().urhgpu_fir_filter_dev(self.pipe.ctx.handle, C.c_void_p(x.data_ptr()), n, C.c_void_p(d_h.data_ptr()),
                                                      len(h), None, C.c_void_p(y.data_ptr())))
         if seg.dtype != torch.float32:
-            y = convert_to(y, self.dtype, self.pipe.ctx)
+            y = astype(y, self.dtype, self.pipe.ctx)
         self._iq[start:end] = y
         if self._qad.shape[0] == self.num_samples:        # (a zeros(2) cache cannot take the range: the reference raises there too)
             self.demod_passes += 1
