@@ -365,6 +365,27 @@ int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs,
 int urhgpu_msg_divisor_histogram(const uint64_t *lens, int64_t n, uint64_t *hist_out, int64_t cap, int64_t *hist_len, int64_t *tol_out);
 int urhgpu_bit_length_from_order(const uint64_t *hist, const int64_t *order_desc, int64_t len, int64_t *bitlen_out);
 
+/* ---- host-array forms of the reference's remaining `util` / `auto_interpretation` functions on the path (the signatures
+ * AutoInterpretation.py:8-10 imports by name; urh_amd/util.py and urh_amd/auto_interpretation.py bind them) --------------------- */
+/* util.minmax (src/urh/cythonext/util.pyx:20-36): arr = n values of dtype (the fused `iq` element types); out2 = {min, max} in the
+ * same type; n == 0: {0, 0}.  The reference's comparisons (a NaN never replaces min / max unless it is element 0). */
+int urhgpu_minmax(urhgpu_ctx *ctx, const void *arr, int dtype, int64_t n, void *out2);
+/* auto_interpretation.segment_messages_from_magnitudes (src/urh/cythonext/auto_interpretation.pyx:55-111) on caller-supplied
+ * magnitudes (float32, or float64 as util.get_magnitudes returns them: is_f64): seg_out = int64[cap_seg][2] (start, end) tuples,
+ * *n_seg their number (also on URHGPU_ERR_CAPACITY).  At most n / 20 + 3 segments exist. */
+int urhgpu_segment_messages(urhgpu_ctx *ctx, const void *magnitudes, int is_f64, int64_t n, float noise_threshold, int64_t *seg_out,
+                            int64_t cap_seg, int64_t *n_seg);
+/* auto_interpretation.get_plateau_lengths (auto_interpretation.pyx:179-208): rect_data float32[n] (host) -> out uint64[cap], *n_out
+ * lengths (also on URHGPU_ERR_CAPACITY). */
+int urhgpu_get_plateau_lengths(urhgpu_ctx *ctx, const float *rect_data, int64_t n, float center, int percentage, uint64_t *out, int64_t cap,
+                               int64_t *n_out);
+/* auto_interpretation.get_threshold_divisor_histogram (auto_interpretation.pyx:113-143): dense uint64[max(lens) + 1]; cap = 0 only
+ * asks for *hist_len.  Host arithmetic (sorting the multiset of values instead of the reference's P^2 / 2 pair loop). */
+int urhgpu_threshold_divisor_histogram(const uint64_t *lens, int64_t n, float threshold, uint64_t *hist_out, int64_t cap, int64_t *hist_len);
+/* auto_interpretation.median_filter (auto_interpretation.pyx:227-240): out[i] = sorted(float(data[i : min(i + k, n)]))[k' / 2];
+ * k <= 64 (URHGPU_ERR_UNSUPPORTED beyond; the reference's callers use 3 .. 11). */
+int urhgpu_median_filter(urhgpu_ctx *ctx, const double *data, int64_t n, unsigned int k, float *out);
+
 /* Test hook: the hot kernel's fast-path division (Newton + residual chain without scaling) against the IEEE
  * division on 2^20 * reps pseudo-random operand pairs from the range the fast path accepts; *n_mismatch must be 0. */
 int urhgpu_test_fast_division_dev(urhgpu_ctx *ctx, uint64_t seed, int reps, uint64_t *n_mismatch);

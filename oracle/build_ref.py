@@ -93,14 +93,28 @@ def build(force: bool = False) -> bool:
 # bench.py can time the reference's own end-to-end Python path as the CPU baseline.
 PYSRC = os.path.join(OUT, "pysrc")
 REFTESTS = os.path.join(OUT, "reftests")
-STAGED_TESTS = ["test_demodulations.py", "utils_testing.py", "__init__.py"]
-STAGED_DATA = ["ask.complex", "ask_short.complex", "fsk.complex", "psk_gen_noisy.complex", "steckdose_anlernen.complex",
-               "two_participants.complex16s", "unaveraged.coco", "enocean.complex", "homematic.complex32s", "pwm.complex16s"]
+# the reference's headless hot-path tests (SURVEY.md probe table): staged next to the captures they read, with ONE textual change
+# made on the staged copy: `from tests.test_util import get_path_for_data_file` -> `from tests.utils_testing import ...`
+# (tests/test_util.py:8 imports the GUI QtTestCase, which needs a display; utils_testing.py holds the function itself)
+STAGED_TESTS = ["test_demodulations.py", "utils_testing.py", "__init__.py", "test_protocol_analyzer.py", "test_iq_array.py",
+                "test_modulator.py"]
+STAGED_TEST_DIRS = ["auto_interpretation"]
 
 
 def staged() -> bool:
     return os.path.exists(os.path.join(PYSRC, "urh", "signalprocessing", "Signal.py")) and \
-        os.path.exists(os.path.join(REFTESTS, "tests", "test_demodulations.py"))
+        os.path.exists(os.path.join(REFTESTS, "tests", "test_demodulations.py")) and \
+        os.path.exists(os.path.join(REFTESTS, "tests", "auto_interpretation", "test_center_detection.py")) and \
+        os.path.exists(os.path.join(REFTESTS, "tests", "data", "xavax.coco"))
+
+
+def _stage_test_file(src: str, dst: str):
+    with open(src, "r", encoding="utf-8") as f:
+        text = f.read()
+    text = text.replace("from tests.test_util import get_path_for_data_file", "from tests.utils_testing import get_path_for_data_file")
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    with open(dst, "w", encoding="utf-8") as f:
+        f.write(text)
 
 
 def stage_python(force: bool = False) -> bool:
@@ -122,10 +136,15 @@ def stage_python(force: bool = False) -> bool:
     for f in STAGED_TESTS:
         a = os.path.join(REF_ROOT, "tests", f)
         if os.path.exists(a):
-            shutil.copyfile(a, os.path.join(tdst, f))
-    for f in STAGED_DATA:
-        a = os.path.join(REF_ROOT, "tests", "data", f)
-        if os.path.exists(a):
+            _stage_test_file(a, os.path.join(tdst, f))
+    for d in STAGED_TEST_DIRS:
+        for f in sorted(os.listdir(os.path.join(REF_ROOT, "tests", d))):
+            if f.endswith(".py"):
+                _stage_test_file(os.path.join(REF_ROOT, "tests", d, f), os.path.join(tdst, d, f))
+    ddir = os.path.join(REF_ROOT, "tests", "data")
+    for f in sorted(os.listdir(ddir)):                     # every capture the staged tests read (18 MB in all)
+        a = os.path.join(ddir, f)
+        if os.path.isfile(a):
             shutil.copyfile(a, os.path.join(tdst, "data", f))
     return staged()
 

@@ -14,18 +14,42 @@ from conftest import ROOT, synth_fsk
 pytestmark = pytest.mark.gpu
 
 
-def test_reference_test_demodulations_on_gpu_functions():
-    """/root/reference/tests/test_demodulations.py (:14-27 ASK, :29-40 ASK tol 0, :42-53 FSK exact 177 bits, :55-72 modulate ->
-    demodulate, :74-87 PSK, :89-120 4-PSK clean + noisy, :122-135 4-FSK), unmodified, with afp_demod / grab_pulse_lens /
-    get_center_thresholds / modulate_c coming from liburhgpu.so."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_driver.py")], capture_output=True, text=True, timeout=900)
+def _run_driver(*args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_driver.py"), *args], capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stderr[-4000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     if out.get("unavailable"):
         pytest.skip("oracle/_ref (compiled reference + staged Python sources) is not present on this box")
-    assert out["ran"] == 7 and out["failures"] == 0 and out["errors"] == 0, out["details"]
+    return out
+
+
+def test_reference_test_demodulations_on_gpu_functions():
+    """/root/reference/tests/test_demodulations.py (:14-27 ASK, :29-40 ASK tol 0, :42-53 FSK exact 177 bits, :55-72 modulate ->
+    demodulate, :74-87 PSK, :89-120 4-PSK clean + noisy, :122-135 4-FSK), unmodified, with afp_demod / grab_pulse_lens /
+    get_center_thresholds / modulate_c coming from liburhgpu.so."""
+    out = _run_driver("test_demodulations")
+    rec = out["per_module"]["tests.test_demodulations"]
+    assert rec["ran"] == 7 and rec["failures"] == 0 and rec["errors"] == 0, out["details"]
     # the GPU functions did the work: every test demodulates and slices, three of them modulate
-    assert out["calls"]["afp_demod"] >= 8 and out["calls"]["grab_pulse_lens"] >= 8 and out["calls"]["modulate_c"] >= 3, out["calls"]
+    c = out["calls"]
+    assert c["signal_functions.afp_demod"] >= 8 and c["signal_functions.grab_pulse_lens"] >= 8 and c["signal_functions.modulate_c"] >= 3, c
+
+
+def test_reference_hot_path_tests_on_gpu_functions():
+    """The reference's other headless hot-path tests (SURVEY.md probe table), unmodified but for the import of
+    get_path_for_data_file, with urh.cythonext.signal_functions / auto_interpretation / util rebound to liburhgpu.so:
+    tests/auto_interpretation/*.py (AutoInterpretation.estimate, detect_center, detect_noise_level, segmentation, OOK merge, bit
+    length, tolerance, modulation detection on the reference's captures), tests/test_protocol_analyzer.py:11-61,
+    tests/test_iq_array.py, tests/test_modulator.py, and the FIR known-answer test of tests/test_filter.py:20-31."""
+    out = _run_driver()
+    assert out["failures"] == 0 and out["errors"] == 0, "\n".join(out["details"])[-6000:]
+    assert out["ran"] == 75 and out["skipped"] == 0, out["per_module"]
+    c = out["calls"]
+    for key in ("signal_functions.afp_demod", "signal_functions.grab_pulse_lens", "signal_functions.fir_filter", "signal_functions.modulate_c",
+                "auto_interpretation.segment_messages_from_magnitudes", "auto_interpretation.get_threshold_divisor_histogram",
+                "auto_interpretation.merge_plateaus", "auto_interpretation.get_plateau_lengths", "auto_interpretation.median_filter",
+                "util.minmax", "util.get_magnitudes"):
+        assert c[key] > 0, (key, c)
 
 
 def _thread_job(k, out, errs):

@@ -1566,6 +1566,134 @@ int urhgpu_get_magnitudes(urhgpu_ctx *ctx, const void *iq, int dtype, int64_t n,
     return URHGPU_OK;
 }
 
+// ---- host-array forms of the reference's util / auto_interpretation functions on the path (urh_amd/util.py, auto_interpretation.py) ----
+static int value_bytes(int dtype) {
+    switch (dtype) {
+        case URHGPU_DT_I8: case URHGPU_DT_U8: return 1;
+        case URHGPU_DT_I16: case URHGPU_DT_U16: return 2;
+        case URHGPU_DT_F32: return 4;
+        default: return 0;
+    }
+}
+
+int urhgpu_minmax(urhgpu_ctx *ctx, const void *arr, int dtype, int64_t n, void *out2) {
+    if (!ctx || n < 0 || !out2 || (n > 0 && !arr)) return URHGPU_ERR_ARG;
+    const int vb = value_bytes(dtype);
+    if (vb == 0) return URHGPU_ERR_DTYPE;
+    if (n == 0) { memset(out2, 0, 2 * (size_t)vb); return URHGPU_OK; }              // util.pyx:22-23: (0, 0)
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(ctx->staging.reserve(align256((size_t)n * vb) + align256(minmax_scratch_bytes()) + 1024));
+    ctx->staging.reset();
+    void *d_in = nullptr;
+    URH_TRY(stage_in(ctx, arr, (size_t)n * vb, &d_in));
+    void *scratch = ctx->staging.take(minmax_scratch_bytes());
+    void *d_out = ctx->staging.take(64);
+    if (!scratch || !d_out) return URHGPU_ERR_ARG;
+    URH_TRY(launch_minmax_any(d_in, dtype, n, d_out, scratch, ctx->stream));
+    URH_HIP(hipGetLastError());
+    URH_HIP(hipMemcpyAsync(out2, d_out, 2 * (size_t)vb, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
+int urhgpu_segment_messages(urhgpu_ctx *ctx, const void *magnitudes, int is_f64, int64_t n, float noise_threshold, int64_t *seg_out,
+                            int64_t cap_seg, int64_t *n_seg) {
+    if (!ctx || n < 0 || !n_seg || cap_seg < 0 || (n > 0 && !magnitudes) || (cap_seg > 0 && !seg_out)) return URHGPU_ERR_ARG;
+    *n_seg = 0;
+    if (n == 0 || noise_threshold != noise_threshold) return URHGPU_OK;           // nothing compares greater than NaN
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    const size_t eb = is_f64 ? 8 : 4;
+    const int64_t cap_rows = n / 10 + 2, cap = cap_rows / 2 + 2;
+    // magnitudes and flags live in the aux arena (urhgpu_segment_runs' digitize uses the main one), tables in the staging arena
+    URH_TRY(ctx->aux.reserve(align256((size_t)n * eb) + align256((size_t)n * 4) + 1024));
+    ctx->aux.reset();
+    void *d_mag = ctx->aux.take((size_t)n * eb);
+    float *d_flags = (float *)ctx->aux.take((size_t)n * 4);
+    URH_TRY(ctx->staging.reserve((size_t)cap_rows * 16 + 2 * (size_t)cap * 16 + seg_scratch_bytes(cap_rows, cap) + seg_ctl_bytes() + 16 * 256));
+    ctx->staging.reset();
+    int64_t *d_rows = (int64_t *)ctx->staging.take((size_t)cap_rows * 16);
+    int64_t *d_seg = (int64_t *)ctx->staging.take((size_t)cap * 16);
+    int64_t *d_msgs = (int64_t *)ctx->staging.take((size_t)cap * 16);
+    void *scratch = ctx->staging.take(seg_scratch_bytes(cap_rows, cap));
+    SegCtl *d_ctl = (SegCtl *)ctx->staging.take(seg_ctl_bytes());
+    int64_t *d_n_rows = (int64_t *)ctx->staging.take(64);
+    if (!d_mag || !d_flags || !d_rows || !d_seg || !d_msgs || !scratch || !d_ctl || !d_n_rows) return URHGPU_ERR_ARG;
+    URH_HIP(hipMemcpyAsync(d_mag, magnitudes, (size_t)n * eb, hipMemcpyHostToDevice, ctx->stream));
+    URH_TRY(launch_above_flags(d_mag, is_f64, n, noise_threshold, d_flags, ctx->stream));
+    urhgpu_params p;
+    memset(&p, 0, sizeof(p));
+    p.dtype = URHGPU_DT_F32; p.mod = URHGPU_MOD_ASK; p.bits_per_symbol = 1; p.center = 0.5f; p.center_spacing = 0.f;
+    p.tolerance = 9;                                   // outlier_tolerance = 10 consecutive samples (auto_interpretation.pyx:72)
+    p.samples_per_symbol = 1;
+    const Plan pl = make_plan(ctx, n, p.tolerance);
+    URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, cap_rows, false, false)));
+    ctx->arena.reset();
+    URH_TRY(digitize(ctx, false, d_flags, n, &p, nullptr, d_rows, cap_rows, d_n_rows, ctx->d_counts + 8, ctx->d_counts + 9, pl, 1));
+    URH_TRY(launch_message_ranges(d_rows, d_n_rows, cap_rows, d_flags, kDtAboveFlags, n, 0.5f, 0, d_seg, d_msgs, cap, d_ctl, scratch, ctx->stream));
+    URH_HIP(hipGetLastError());
+    std::vector<char> ctl(seg_ctl_bytes());
+    URH_HIP(hipMemcpyAsync(ctl.data(), d_ctl, ctl.size(), hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t ns = 0, nm = 0;
+    int amb = 0;
+    seg_ctl_read(ctl.data(), &ns, &nm, &amb);
+    *n_seg = ns;
+    if (ns > cap_seg) return URHGPU_ERR_CAPACITY;
+    if (ns > 0) {
+        URH_HIP(hipMemcpyAsync(seg_out, d_seg, (size_t)ns * 16, hipMemcpyDeviceToHost, ctx->stream));
+        URH_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return URHGPU_OK;
+}
+
+int urhgpu_get_plateau_lengths(urhgpu_ctx *ctx, const float *rect_data, int64_t n, float center, int percentage, uint64_t *out, int64_t cap,
+                               int64_t *n_out) {
+    if (!ctx || n < 0 || !n_out || cap < 0 || percentage < 0 || (n > 0 && !rect_data) || (cap > 0 && !out)) return URHGPU_ERR_ARG;
+    *n_out = 0;
+    if (n == 0) return URHGPU_OK;                              // auto_interpretation.pyx:180-181
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(ctx->aux.reserve(align256((size_t)n * 4) + 1024));
+    ctx->aux.reset();
+    float *d_x = (float *)ctx->aux.take((size_t)n * 4);
+    if (!d_x) return URHGPU_ERR_ARG;
+    URH_HIP(hipMemcpyAsync(d_x, rect_data, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    const int64_t range[2] = {0, n};
+    const double c = (double)center;
+    int64_t off[2] = {0, 0};
+    // boundaries are searched in the first percentage % + a window that doubles until it holds one beyond the mark (or the signal ends)
+    for (int64_t extra = int64_t(1) << 16;; extra *= 2) {
+        const int st = urhgpu_msg_plateaus(ctx, d_x, n, range, &c, 1, percentage, extra, off, out, cap);
+        if (st == URHGPU_ERR_CAPACITY) { *n_out = off[1]; return st; }
+        URH_TRY(st);
+        if (off[1] >= 0) break;
+        if (extra >= n) { off[1] = -off[1] - 1; break; }
+    }
+    *n_out = off[1];
+    return URHGPU_OK;
+}
+
+int urhgpu_median_filter(urhgpu_ctx *ctx, const double *data, int64_t n, unsigned int k, float *out) {
+    if (!ctx || n < 0 || (n > 0 && (!data || !out))) return URHGPU_ERR_ARG;
+    if (k < 1 || k > 64) return URHGPU_ERR_UNSUPPORTED;
+    if (n == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(ctx->staging.reserve(align256((size_t)n * 8) + align256((size_t)n * 4) + 1024));
+    ctx->staging.reset();
+    void *d_in = nullptr;
+    URH_TRY(stage_in(ctx, data, (size_t)n * 8, &d_in));
+    float *d_out = (float *)ctx->staging.take((size_t)n * 4);
+    if (!d_out) return URHGPU_ERR_ARG;
+    URH_TRY(launch_median_filter((const double *)d_in, n, (int)k, d_out, ctx->stream));
+    URH_HIP(hipGetLastError());
+    URH_HIP(hipMemcpyAsync(out, d_out, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
 int urhgpu_magnitude_chunk_stats_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, int64_t chunk, int64_t n_chunks,
                                      double *d_sum, double *d_max) {
     if (!ctx || n < 0 || n_chunks < 0 || (n_chunks > 0 && (!d_iq || !d_sum || !d_max))) return URHGPU_ERR_ARG;

@@ -678,7 +678,8 @@ __device__ __forceinline__ uint32_t chunk_init_state(const RunArgs &p, int64_t c
         if (SRC == SRC_QAD) first_is_noise = (((const float *)p.in)[0] == p.noise_val);
         else first_is_noise = true;                            // afp_demod: result[0] = NOISE
         init = first_is_noise ? kStPause : classify<ORDER2>(0.0f, p, false);   // literal 0.0: thresholds only
-        if (SRC == SRC_IQ && p.seg_mode) {                     // segmentation: the state of sample 0 itself
+        if (SRC == SRC_QAD && p.seg_mode) init = classify<ORDER2>(((const float *)p.in)[0], p);   // segmentation: the state of sample 0 itself
+        if (SRC == SRC_IQ && p.seg_mode) {
             float c = 0.f, d = 0.f;
             Iq<DT>::load1(p.in, 0, c, d);
             init = classify<ORDER2>(demod_one<MOD, DT>(0.f, 0.f, c, d, p), p);

@@ -110,7 +110,102 @@ __global__ __launch_bounds__(64) void k_minmax_finish(const float *part, int nbl
     }
     if (threadIdx.x == 0) { out2[0] = mn; out2[1] = mx; }
 }
+// ---- util.minmax for every element type of the fused `iq` type (util.pyx:20-36), same comparisons and NaN behaviour ----------
+template <typename T>
+__global__ __launch_bounds__(256) void k_minmax_partials_t(const T *x, int64_t n, T *part /*[2*grid]*/) {
+    __shared__ T s_min[4], s_max[4];
+    T mn = x[0], mx = x[0];
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const T v = x[i];
+        if (v < mn) mn = v;
+        if (v > mx) mx = v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T a = (T)__shfl_down((float)mn, o), b = (T)__shfl_down((float)mx, o);       // every element type is exact in float32
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+    if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = mn; s_max[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { if (s_min[w] < mn) mn = s_min[w]; if (s_max[w] > mx) mx = s_max[w]; }
+        part[2 * blockIdx.x] = mn; part[2 * blockIdx.x + 1] = mx;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(64) void k_minmax_finish_t(const T *part, int nblocks, T *out2) {
+    T mn = part[0], mx = part[1];
+    for (int b = threadIdx.x; b < nblocks; b += 64) { if (part[2 * b] < mn) mn = part[2 * b]; if (part[2 * b + 1] > mx) mx = part[2 * b + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T a = (T)__shfl_down((float)mn, o), b = (T)__shfl_down((float)mx, o);
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+    if (threadIdx.x == 0) { out2[0] = mn; out2[1] = mx; }
+}
 constexpr int kMinmaxBlocks = 1024;
+template <typename T>
+static int minmax_launch_t(const void *x, int64_t n, void *d_out2, void *scratch, hipStream_t s) {
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, kMinmaxBlocks);
+    hipLaunchKernelGGL(k_minmax_partials_t<T>, dim3(grid), dim3(256), 0, s, (const T *)x, n, (T *)scratch);
+    hipLaunchKernelGGL(k_minmax_finish_t<T>, dim3(1), dim3(64), 0, s, (const T *)scratch, grid, (T *)d_out2);
+    return URHGPU_OK;
+}
+// d_out2: {min, max} in the element type
+int launch_minmax_any(const void *x, int dtype, int64_t n, void *d_out2, void *scratch, hipStream_t s) {
+    if (n <= 0) return URHGPU_ERR_ARG;
+    switch (dtype) {
+        case URHGPU_DT_I8: return minmax_launch_t<int8_t>(x, n, d_out2, scratch, s);
+        case URHGPU_DT_U8: return minmax_launch_t<uint8_t>(x, n, d_out2, scratch, s);
+        case URHGPU_DT_I16: return minmax_launch_t<int16_t>(x, n, d_out2, scratch, s);
+        case URHGPU_DT_U16: return minmax_launch_t<uint16_t>(x, n, d_out2, scratch, s);
+        case URHGPU_DT_F32: return minmax_launch_t<float>(x, n, d_out2, scratch, s);
+        default: return URHGPU_ERR_DTYPE;
+    }
+}
+
+// ---- segment_messages_from_magnitudes on caller-supplied magnitudes (auto_interpretation.pyx:55-111): the comparison
+// `magnitudes[i] > noise_threshold` (float or double magnitude against a C float) as a 0 / 1 float, which the run segmentation
+// then slices at 0.5 ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_above_flags(const T *mag, int64_t n, float thr, float *flags) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) flags[i] = ((double)mag[i] > (double)thr) ? 1.0f : 0.0f;
+}
+int launch_above_flags(const void *mag, int is_f64, int64_t n, float thr, float *flags, hipStream_t s) {
+    if (n <= 0) return URHGPU_OK;
+    const unsigned g = (unsigned)std::min<int64_t>((n + 255) / 256, 65536);
+    if (is_f64) hipLaunchKernelGGL(k_above_flags<double>, dim3(g), dim3(256), 0, s, (const double *)mag, n, thr, flags);
+    else hipLaunchKernelGGL(k_above_flags<float>, dim3(g), dim3(256), 0, s, (const float *)mag, n, thr, flags);
+    return URHGPU_OK;
+}
+
+// ---- auto_interpretation.median_filter (auto_interpretation.pyx:213-240): window data[i : i + k] cut at the end of the array, the
+// values rounded to float, sorted, element k' / 2 ---------------------------------------------------------------------------------
+constexpr int kMedianMaxK = 64;
+__global__ __launch_bounds__(256) void k_median_filter(const double *data, int64_t n, int k, float *out) {
+    const int64_t i = blockIdx.x * 256ll + threadIdx.x;
+    if (i >= n) return;
+    int kk = k;
+    if (i + kk > n) kk = (int)(n - i);
+    float buf[kMedianMaxK];
+    for (int j = 0; j < kk; ++j) buf[j] = (float)data[i + j];
+    for (int a = 1; a < kk; ++a) {                          // insertion sort (std::sort's result on floats; NaN-free data)
+        const float v = buf[a];
+        int b = a - 1;
+        while (b >= 0 && buf[b] > v) { buf[b + 1] = buf[b]; --b; }
+        buf[b + 1] = v;
+    }
+    out[i] = buf[kk / 2];
+}
+int launch_median_filter(const double *data, int64_t n, int k, float *out, hipStream_t s) {
+    if (k < 1 || k > kMedianMaxK) return URHGPU_ERR_UNSUPPORTED;
+    if (n <= 0) return URHGPU_OK;
+    hipLaunchKernelGGL(k_median_filter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, data, n, k, out);
+    return URHGPU_OK;
+}
+
 size_t minmax_scratch_bytes() { return (size_t)kMinmaxBlocks * 8 + 64; }
 int launch_minmax(const float *x, int64_t n, float *d_out2, void *scratch, hipStream_t s) {
     if (n <= 0) return URHGPU_ERR_ARG;

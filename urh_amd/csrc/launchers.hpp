@@ -242,6 +242,10 @@ int launch_compact_edges(const float *x, int64_t n, const int64_t *d_n, float ce
                          void *scratch, int32_t *tickets, hipStream_t s);
 size_t minmax_scratch_bytes();
 int launch_minmax(const float *x, int64_t n, float *d_out2, void *scratch, hipStream_t s);
+int launch_minmax_any(const void *x, int dtype, int64_t n, void *d_out2, void *scratch, hipStream_t s);
+int launch_above_flags(const void *mag, int is_f64, int64_t n, float thr, float *flags, hipStream_t s);
+int launch_median_filter(const double *data, int64_t n, int k, float *out, hipStream_t s);
+constexpr int kDtAboveFlags = 100;       // launch_message_ranges: `d_iq` is a float32 array of 0 / 1 above-noise flags (launch_above_flags)
 int pairwise_sum_f32(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, float mean, float *out);
 int launch_hist_edges(const float *x, int64_t n, const double *d_edges, int n_edges, int64_t *d_counts, hipStream_t s);
 // ---- msg_ranges.hip ------------------------------------------------------------------------------------------

@@ -968,7 +968,7 @@ void round_lengths(std::vector<uint64_t> &m) {
 }
 
 // get_threshold_divisor_histogram (auto_interpretation.pyx:113-143) from the multiset of values: the non-zero entries as (count, index)
-void divisor_histogram(const std::vector<uint64_t> &m, std::vector<std::pair<uint64_t, uint64_t>> &hist) {
+void divisor_histogram(const std::vector<uint64_t> &m, std::vector<std::pair<uint64_t, uint64_t>> &hist, float threshold = 0.2f) {
     std::vector<uint64_t> vals(m);
     std::sort(vals.begin(), vals.end());
     std::vector<std::pair<uint64_t, uint64_t>> vc;              // (value, count), value != 0, ascending
@@ -978,10 +978,10 @@ void divisor_histogram(const std::vector<uint64_t> &m, std::vector<std::pair<uin
         if (vals[i] != 0) vc.push_back({vals[i], (uint64_t)(j - i)});
         i = j;
     }
-    const double thr = (double)0.2f;
+    const double thr = (double)threshold;
     hist.clear();
     for (size_t a = 0; a < vc.size(); ++a) {
-        uint64_t c = vc[a].second * (vc[a].second - 1) / 2;      // pairs of equal values: ratio 1
+        uint64_t c = (0.0 < thr) ? vc[a].second * (vc[a].second - 1) / 2 : 0;      // pairs of equal values: ratio 1, fraction 0
         for (size_t b = a + 1; b < vc.size(); ++b) {
             const uint64_t mn = vc[a].first, mx = vc[b].first;
             if ((double)mx / (double)mn - (double)(mx / mn) < thr) c += vc[a].second * vc[b].second;
@@ -1124,6 +1124,22 @@ int urhgpu_msg_divisor_histogram(const uint64_t *lens, int64_t n, uint64_t *hist
     if (cap < *hist_len) return cap == 0 ? URHGPU_OK : URHGPU_ERR_CAPACITY;
     std::vector<std::pair<uint64_t, uint64_t>> hist;
     divisor_histogram(merged, hist);
+    std::fill(hist_out, hist_out + *hist_len, 0ull);
+    for (const auto &e : hist) hist_out[e.second] = e.first;
+    return URHGPU_OK;
+}
+
+// auto_interpretation.get_threshold_divisor_histogram (auto_interpretation.pyx:113-143) itself: the DENSE histogram uint64[max + 1]
+// (the P^2 / 2 pair test evaluated on the multiset of values).  cap = 0 only asks for *hist_len.  Host arithmetic.
+int urhgpu_threshold_divisor_histogram(const uint64_t *lens, int64_t n, float threshold, uint64_t *hist_out, int64_t cap, int64_t *hist_len) {
+    if (n <= 0 || !lens || !hist_len || cap < 0 || (cap > 0 && !hist_out)) return URHGPU_ERR_ARG;       // np.max of an empty array raises in the reference
+    const uint64_t mx = *std::max_element(lens, lens + n);
+    if (mx >= (uint64_t)1 << 40) return URHGPU_ERR_UNSUPPORTED;
+    *hist_len = (int64_t)mx + 1;
+    if (cap < *hist_len) return cap == 0 ? URHGPU_OK : URHGPU_ERR_CAPACITY;
+    std::vector<uint64_t> m(lens, lens + n);
+    std::vector<std::pair<uint64_t, uint64_t>> hist;
+    divisor_histogram(m, hist, threshold);
     std::fill(hist_out, hist_out + *hist_len, 0ull);
     for (const auto &e : hist) hist_out[e.second] = e.first;
     return URHGPU_OK;

@@ -71,6 +71,8 @@ template <> __device__ bool seg_above<URHGPU_DT_U16>(const void *iq, int64_t i, 
     return __builtin_sqrt((double)s) > (double)thr;
 }
 
+template <> __device__ bool seg_above<kDtAboveFlags>(const void *iq, int64_t i, float) { return ((const float *)iq)[i] > 0.5f; }
+
 // number of complete segments; the trailing one of a capture that ends above the noise
 template <int DT>
 __global__ void k_seg_finish(const int64_t *rows, const int64_t *d_n_rows, const void *iq, int64_t n, float thr, int64_t *seg, int64_t cap,
@@ -188,6 +190,7 @@ int launch_message_ranges(const int64_t *d_rows, const int64_t *d_n_rows, int64_
         case URHGPU_DT_U8: launch_seg_finish<URHGPU_DT_U8>(d_rows, d_n_rows, d_iq, n, thr, d_seg, cap, d_ctl, s); break;
         case URHGPU_DT_I16: launch_seg_finish<URHGPU_DT_I16>(d_rows, d_n_rows, d_iq, n, thr, d_seg, cap, d_ctl, s); break;
         case URHGPU_DT_U16: launch_seg_finish<URHGPU_DT_U16>(d_rows, d_n_rows, d_iq, n, thr, d_seg, cap, d_ctl, s); break;
+        case kDtAboveFlags: launch_seg_finish<kDtAboveFlags>(d_rows, d_n_rows, d_iq, n, thr, d_seg, cap, d_ctl, s); break;
         default: return URHGPU_ERR_DTYPE;
     }
     if (!ook_merge) return URHGPU_OK;

@@ -19,9 +19,19 @@ def get_magnitudes(arr, ctx=None) -> np.ndarray:
     return out
 
 
-def minmax(arr):
-    """util.minmax (util.pyx:20-36): (min, max) of a small host array -- host arithmetic, as in the callers here."""
-    if len(arr) == 0:
-        return 0, 0
+def minmax(arr, ctx=None):
+    """util.minmax (util.pyx:20-36): (min, max) of a 1-D array of one of the fused `iq` element types (int8 / uint8 / int16 / uint16 /
+    float32), as Python scalars; (0, 0) for an empty array.  detect_center calls it on a whole message (AutoInterpretation.py:236), so
+    it is a pass over the samples: one reduction kernel with the reference's comparisons (urhgpu_minmax)."""
     a = np.asarray(arr)
-    return a.min(), a.max()
+    if a.ndim != 1:
+        raise ValueError("Buffer has wrong number of dimensions (expected 1, got {})".format(a.ndim))
+    if a.dtype not in _DT:
+        raise TypeError("No matching signature found")                  # what the fused-type dispatch raises
+    if len(a) == 0:
+        return 0, 0
+    a = np.ascontiguousarray(a)
+    out = np.zeros(2, dtype=a.dtype)
+    ctx = ctx or _lib.default_context()
+    _lib.check(_lib.load().urhgpu_minmax(ctx.handle, _vp(a), _DT[a.dtype], len(a), _vp(out)))
+    return out[0].item(), out[1].item()
