@@ -217,7 +217,29 @@ typedef struct urhgpu_outputs {
     int64_t cap_pos;
     int64_t *pos_off;      /* int64[cap_msg+1] */
     int64_t *counts;       /* int64[5]: {n_rows, n_msg, n_bits, n_pos, rows the table needed (> cap_rows: it was truncated)} */
+    /* Optional compact mirror of the results for the trip over PCIe (NULL: not produced): one contiguous blob written by one more
+     * kernel at the end of the pass -- see "compact result blob" below.  cap_blob >= urhgpu_blob_capacity(...). */
+    void *blob;            /* device, 16-byte aligned */
+    int64_t cap_blob;
 } urhgpu_outputs;
+
+/* ---- compact result blob ---------------------------------------------------------------------------------------------------
+ * The wide outputs above mirror the reference's Python objects (grab_pulse_lens' int64 [state, length] rows, one byte per bit,
+ * int64 bit_sample_pos): 22.8 MB per GiB of 2-FSK capture at 100 samples per symbol -- 0.5 ms of PCIe, more than the device pass.
+ * The blob holds the same information in 8.9 MB (3.5 MB without positions); every section starts 16-byte aligned:
+ *   int64 header[16] = {URHGPU_BLOB_MAGIC, n_rows, n_msg, n_bits, n_pos, rows_needed, total_bytes (negative: the blob was too small),
+ *                       has_pos, off_pauses, off_msg_off, off_pos_off, off_row_state, off_bits, off_row_len, off_pos32, truncated}
+ *   int64 pauses[n_msg]; int64 msg_off[n_msg + 1] (bit offsets); int64 pos_off[n_msg + 1];
+ *   int8  row_state[n_rows]   (-1 = pause; grab_pulse_lens' column 0)
+ *   uint8 bits[(n_bits + 7) / 8]   eight bits per byte, most significant first (numpy.packbits / unpackbits order)
+ *   int32 row_len[n_rows]     (grab_pulse_lens' column 1; captures of up to 2^31 - 1 samples)
+ *   uint32 pos32[n_pos]       (bit_sample_pos; absent when the pass wrote no positions)
+ * truncated != 0: a capacity was exceeded (rows_needed > cap_rows, or more messages / bits / positions than fit): the sections hold
+ * what fitted, the caller repeats the pass with larger capacities.  The counts come first (40 bytes from `counts`), then ONE copy of
+ * total_bytes moves everything; urhgpu_stream_* below does that overlapped with the following passes. */
+#define URHGPU_BLOB_MAGIC INT64_C(0x55524842424C4F42) /* "URHBBLOB" */
+#define URHGPU_BLOB_HEADER_BYTES 128
+int64_t urhgpu_blob_capacity(int64_t cap_rows, int64_t cap_bits, int64_t cap_msg, int64_t cap_pos, int has_pos);
 
 /* afp_demod on device memory (ASK/FSK/OTHER: one streaming kernel; PSK: Costas loop). */
 int urhgpu_afp_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad);
@@ -237,6 +259,40 @@ int urhgpu_ppseq_to_bits_dev(urhgpu_ctx *ctx, const int64_t *d_rows, const int64
  * Sharded captures use the urhgpu_shard_* phases below instead. */
 int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p,
                           const urhgpu_outputs *out);
+
+/* ---- a stream of captures, results on the host -------------------------------------------------------------------------------
+ * SURVEY.md §8(d)'s window for this path ends with the compact outputs ON THE HOST.  For capture after capture (the reference's live
+ * mode is such a consumer: ProtocolSniffer.py:161-202) three things overlap: the hot kernel of pass i, the tail of pass i - 1 (second
+ * stream, urhgpu_ctx_set_pipelined: the stream switches the context to that mode) and the D2H copy of pass i - 2's blob (copy engine,
+ * pinned memory owned by the stream).  Three output slots rotate.
+ *   urhgpu_stream_create   n_max: largest capture (samples, < 2^31); p: demodulation + slicing parameters of every pass (ASK / FSK /
+ *                          OTHER; PSK synchronises with the host inside the Costas loop: URHGPU_ERR_UNSUPPORTED); want_qad: the
+ *                          demodulated signal is materialised (stays in HBM: urhgpu_host_result::d_qad); want_pos: bit_sample_pos
+ *                          is produced and shipped; cap_rows: 0 = the default (urhgpu_stream_capacities), else the pulse-table capacity.
+ *   urhgpu_stream_push     queue pass i on d_iq (device; must stay valid until the pass has run) and return WITHOUT waiting for it;
+ *                          *ready receives the result of pass i - 3 (seq = -1: none yet), valid until the push after next.
+ *   urhgpu_stream_flush    wait for every outstanding pass; out3 receives up to three results, oldest first.
+ * The pointers of a result are pinned host memory owned by the stream. */
+typedef struct urhgpu_stream urhgpu_stream;
+typedef struct urhgpu_host_result {
+    int64_t seq;                 /* index of the push this result belongs to */
+    int64_t n_samples;
+    int64_t n_rows, n_msg, n_bits, n_pos, rows_needed;
+    int64_t blob_bytes;          /* bytes that crossed PCIe for this pass (+ 40 for the counts) */
+    int truncated;               /* see "compact result blob" */
+    const int32_t *row_len;      /* pulse table: grab_pulse_lens' [state, length] columns */
+    const int8_t *row_state;
+    const uint8_t *bits_packed;  /* numpy.unpackbits(bits_packed)[msg_off[m] : msg_off[m + 1]] = message m */
+    const int64_t *msg_off, *pauses, *pos_off;
+    const uint32_t *pos32;       /* bit_sample_pos or NULL */
+    const void *blob;            /* the whole blob (header first) */
+    const float *d_qad;          /* DEVICE: the pass's demodulated signal (overwritten three pushes later) or NULL */
+} urhgpu_host_result;
+int urhgpu_stream_capacities(int64_t n_max, const urhgpu_params *p, int64_t *cap_rows, int64_t *cap_bits, int64_t *cap_msg, int64_t *cap_pos);
+int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p, int want_qad, int want_pos, int64_t cap_rows, urhgpu_stream **out);
+int urhgpu_stream_destroy(urhgpu_stream *st);
+int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_host_result *ready);
+int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out);
 
 /* ---- sharded captures: one long capture split sample-contiguously over the GPUs of a node ------------------
  * (there is no reference counterpart: the reference processes a capture in one process.)

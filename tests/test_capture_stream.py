@@ -1,0 +1,89 @@
+"""urhgpu_stream_* (capture after capture, compact results on the host; include/urhgpu.h) against the oracle: every pass of a stream of
+DIFFERENT captures -- sizes, pauses, modulations, bits per symbol -- comes back with the pulse table, bits, pauses, offsets and
+bit_sample_pos the reference computes for that capture, whatever was in flight around it (hot kernel of the next pass, tail of this
+one, copy of the previous one)."""
+import numpy as np
+import pytest
+
+from conftest import synth_fsk
+
+pytestmark = pytest.mark.gpu
+
+
+def _captures(mod, bps, k, n_max, rng):
+    out = []
+    for i in range(k):
+        n = int(rng.choice([n_max, n_max - 777, n_max // 2 + 13, 4096 * 3, 70_001]))
+        iq = synth_fsk(n, sps=100, seed=100 + i, noise=0.04, pause_every=max(n // (2 + i % 3), 5000), pause_len=n // 19 + 901)
+        if mod == "ASK":
+            env = np.repeat(np.random.default_rng(i).integers(0, 2 ** bps, n // 100 + 1), 100)[:n] / (2 ** bps - 1)
+            iq = (iq * (0.05 + 0.95 * env)[:, None]).astype(np.float32)
+        out.append(iq)
+    return out
+
+
+@pytest.mark.parametrize("mod,bps,want_pos", [("FSK", 1, True), ("FSK", 1, False), ("ASK", 1, True), ("FSK", 2, True)])
+def test_stream_of_different_captures_equals_oracle(oracle, mod, bps, want_pos):
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    rng = np.random.default_rng(7)
+    n_max = (1 << 21) + 4096
+    pipe = DevicePipeline(0, pipelined=True)
+    center = 0.0 if mod == "FSK" else 0.4
+    spacing = 1.0 if bps == 1 else 0.03
+    p = DemodParams(mod, bps, 0.1, center, spacing, 5, 100, 0.1, 8, want_pos)
+    caps = _captures(mod, bps, 9, n_max, rng)
+    dev = [torch.from_numpy(c).cuda() for c in caps]
+    st = pipe.stream(n_max, p, want_qad=True, want_pos=want_pos)
+    got = {}
+
+    def keep(r):
+        if r is not None:
+            r.check()
+            got[r.seq] = (r.ppseq(), r.bits(), r.msg_off.copy(), r.pauses.copy(), r.bit_sample_pos(), r.pos_off.copy(), r.blob_bytes, r.n_samples)
+    for d in dev:
+        keep(st.push(d))
+    for r in st.flush():
+        keep(r)
+    assert sorted(got) == list(range(len(caps)))
+    for i, iq in enumerate(caps):
+        qad = oracle.afp_demod(iq, 0.1, mod, 2 ** bps)
+        pp = oracle.grab_pulse_lens(qad, center, 5, mod, 100, bps, spacing)
+        bits, off, pauses, pos, poff = oracle.ppseq_to_bits_flat(pp, 100, bps, want_pos, 8)
+        g = got[i]
+        assert g[7] == len(iq)
+        assert np.array_equal(g[0], pp), i
+        assert np.array_equal(g[1], bits) and np.array_equal(g[2], off) and np.array_equal(g[3], pauses), i
+        if want_pos:
+            assert np.array_equal(g[4], pos) and np.array_equal(g[5], poff), i
+        else:
+            assert len(g[4]) == 0
+        # what crossed PCIe: 5 B per row, 1 bit per bit, 4 B per position, 24 B per message (+ header and alignment)
+        assert g[6] <= 5 * len(pp) + len(bits) // 8 + 4 * len(pos) * (1 if want_pos else 0) + 24 * len(pauses) + 512, (i, g[6])
+    st.close()
+    # the pipeline is usable as before afterwards
+    res = pipe.iq_to_bits(dev[0], p, want_qad=True)
+    assert np.array_equal(res.ppseq(), got[0][0])
+
+
+def test_stream_reports_a_truncated_pulse_table(oracle):
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    n = 1 << 20
+    iq = (0.3 * np.random.default_rng(1).standard_normal((n, 2))).astype(np.float32)        # noise only: a row every few samples
+    p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 1, 100, 0.1, 8, True)
+    pipe = DevicePipeline(0)
+    st = pipe.stream(n, p)
+    d = torch.from_numpy(iq).cuda()
+    assert st.push(d) is None
+    (r,) = st.flush()
+    pp = oracle.grab_pulse_lens(oracle.afp_demod(iq, 0.0, "FSK", 2), 0.0, 1, "FSK", 100, 1, 1.0)
+    assert r.truncated and r.rows_needed == len(pp)
+    with pytest.raises(Exception):
+        r.check()
+    st.close()
+    st = pipe.stream(n, p, cap_rows=r.rows_needed + 8)
+    st.push(d)
+    (r,) = st.flush()
+    assert not r.truncated and np.array_equal(r.ppseq(), pp)
+    st.close()

@@ -44,6 +44,19 @@ class Outputs(C.Structure):
         ("msg_off", C.c_void_p), ("pauses", C.c_void_p), ("cap_msg", C.c_int64),
         ("pos", C.c_void_p), ("cap_pos", C.c_int64), ("pos_off", C.c_void_p),
         ("counts", C.c_void_p),
+        ("blob", C.c_void_p), ("cap_blob", C.c_int64),
+    ]
+
+
+class HostResult(C.Structure):
+    """struct urhgpu_host_result (include/urhgpu.h); pointers are pinned host memory owned by the stream"""
+    _fields_ = [
+        ("seq", C.c_int64), ("n_samples", C.c_int64),
+        ("n_rows", C.c_int64), ("n_msg", C.c_int64), ("n_bits", C.c_int64), ("n_pos", C.c_int64), ("rows_needed", C.c_int64),
+        ("blob_bytes", C.c_int64), ("truncated", C.c_int),
+        ("row_len", C.c_void_p), ("row_state", C.c_void_p), ("bits_packed", C.c_void_p),
+        ("msg_off", C.c_void_p), ("pauses", C.c_void_p), ("pos_off", C.c_void_p), ("pos32", C.c_void_p),
+        ("blob", C.c_void_p), ("d_qad", C.c_void_p),
     ]
 
 
@@ -82,6 +95,12 @@ PROTOTYPES = {
     "urhgpu_grab_pulse_lens_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp, _i64, _vp]),
     "urhgpu_ppseq_to_bits_dev": (_i, [_vp, _vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
     "urhgpu_iq_to_bits_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
+    "urhgpu_blob_capacity": (_i64, [_i64, _i64, _i64, _i64, _i]),
+    "urhgpu_stream_capacities": (_i, [_i64, C.POINTER(Params), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "urhgpu_stream_create": (_i, [_vp, _i64, C.POINTER(Params), _i, _i, _i64, C.POINTER(_vp)]),
+    "urhgpu_stream_destroy": (_i, [_vp]),
+    "urhgpu_stream_push": (_i, [_vp, _vp, _i64, C.POINTER(HostResult)]),
+    "urhgpu_stream_flush": (_i, [_vp, C.POINTER(HostResult), C.POINTER(_i)]),
     "urhgpu_shard_runs_dev": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, _vp, C.POINTER(Params), C.POINTER(Outputs), _vp]),
     "urhgpu_shard_prelaunch_dev": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, C.POINTER(Params), C.POINTER(Outputs)]),
     "urhgpu_shard_rows_dev": (_i, [_vp, _vp, _vp]),

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "compact.hpp"
 #include "runs.hpp"
 
 namespace urh {
@@ -621,7 +622,12 @@ int urhgpu_ppseq_to_bits_dev(urhgpu_ctx *ctx, const int64_t *d_rows, const int64
     ctx->arena.reset();
     void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
     if (!scratch) return URHGPU_ERR_ARG;
-    return ppseq_to_bits_inner(ctx, d_rows, d_n_rows, cap, p, out, scratch);
+    URH_TRY(ppseq_to_bits_inner(ctx, d_rows, d_n_rows, cap, p, out, scratch));
+    if (out->blob) {                                       // compact mirror: out->rows must then be the table d_rows (and cap_rows its capacity)
+        if (out->rows != d_rows) return URHGPU_ERR_ARG;
+        URH_TRY(launch_pack_blob(out, p->write_bit_sample_pos, ctx->stream));
+    }
+    return URHGPU_OK;
 }
 
 int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p,
@@ -672,10 +678,18 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
         } else {
             st = ppseq_to_bits_inner(ctx, out->rows, d_n_rows, cap, p, out, scratch, ctx->d_counts + 8);
         }
+        if (st == URHGPU_OK && out->blob) st = launch_pack_blob(out, p->write_bit_sample_pos, ctx->stream);     // compact mirror (compact.hip)
         ctx->stream = caller;
+    } else if (out->blob) {
+        st = URHGPU_ERR_ARG;                               // the blob mirrors the bit outputs: all of them must be given
     }
     if (piped) URH_TRY(end_pipelined_pass(ctx));
     return st;
+}
+
+int64_t urhgpu_blob_capacity(int64_t cap_rows, int64_t cap_bits, int64_t cap_msg, int64_t cap_pos, int has_pos) {
+    if (cap_rows < 0 || cap_bits < 0 || cap_msg < 0 || cap_pos < 0) return 0;
+    return urh::blob_capacity(cap_rows, cap_bits, cap_msg, cap_pos, has_pos ? 1 : 0);
 }
 
 // ---- sharded captures (one rank's phases; the all-gathers in between belong to the caller) --------------

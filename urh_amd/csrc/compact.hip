@@ -1,0 +1,87 @@
+// compact.hip -- the compact form of one pass's results, for the trip over PCIe (the timing window ends with the
+// compact outputs on the host).  The wide device outputs mirror the reference's Python objects (int64 [state, length] rows as
+// grab_pulse_lens returns them, one byte per bit, int64 positions: 22.8 MB per GiB of 2-FSK capture -- 0.5 ms of PCIe, more than
+// the whole device pass); the blob holds the same information in 8.9 MB (3.5 MB without bit_sample_pos):
+//   header   int64[16]  {magic, n_rows, n_msg, n_bits, n_pos, rows_needed, total_bytes, has_pos, section offsets ...}
+//   pauses   int64[n_msg]        msg_off  int64[n_msg + 1]  (bit offsets)        pos_off  int64[n_msg + 1]
+//   row_state int8[n_rows]       (state -1 = pause; modulation orders up to 128)
+//   bits     uint8[(n_bits + 7) / 8]   eight bits per byte, most significant first (numpy.packbits order), messages back to back
+//   row_len  int32[n_rows]       (a row is at most the capture: < 2^31 samples)
+//   pos32    uint32[n_pos]       bit_sample_pos (absolute sample positions; omitted when the pass did not write positions)
+// One kernel after the pass's last kernel: every section's offset follows from the counts, so ONE contiguous copy of
+// header.total_bytes moves everything (the host learns the counts from a 40-byte copy first).
+#include <hip/hip_runtime.h>
+
+#include "common.hpp"
+#include "compact.hpp"
+#include "launchers.hpp"
+
+namespace urh {
+
+struct PackArgs {
+    const int64_t *rows; const uint8_t *bits; const int64_t *msg_off, *pauses, *pos_off, *pos; const int64_t *counts;
+    int64_t cap_rows, cap_bits, cap_msg, cap_pos;
+    int has_pos;
+    char *blob; int64_t cap_blob;
+};
+
+__global__ __launch_bounds__(256) void k_pack_blob(const PackArgs a) {
+    const BlobLayout L = blob_layout(a.counts, a.cap_rows, a.cap_bits, a.cap_msg, a.cap_pos, a.has_pos);
+    const int64_t gtid = blockIdx.x * 256ll + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    int64_t *hdr = (int64_t *)a.blob;
+    const bool fits = L.total <= a.cap_blob;
+    if (gtid == 0) {
+        hdr[0] = URHGPU_BLOB_MAGIC; hdr[1] = L.n_rows; hdr[2] = L.n_msg; hdr[3] = L.n_bits; hdr[4] = L.n_pos; hdr[5] = a.counts[4];
+        hdr[6] = fits ? L.total : -L.total; hdr[7] = a.has_pos;
+        hdr[8] = L.off_pauses; hdr[9] = L.off_msg_off; hdr[10] = L.off_pos_off; hdr[11] = L.off_row_state; hdr[12] = L.off_bits;
+        hdr[13] = L.off_row_len; hdr[14] = L.off_pos32;
+        hdr[15] = (a.counts[1] > a.cap_msg || a.counts[2] > a.cap_bits || (a.has_pos && a.counts[3] > a.cap_pos) || a.counts[4] > a.cap_rows) ? 1 : 0;   // truncated
+    }
+    if (!fits) return;                                     // (cannot happen with a blob of blob_capacity bytes)
+    // bits: eight bytes in, one byte out; the bits beyond n_bits of the last byte are zero
+    {
+        const int64_t nb = (L.n_bits + 7) / 8;
+        uint8_t *out = (uint8_t *)(a.blob + L.off_bits);
+        const unsigned long long *in = (const unsigned long long *)a.bits;       // 8-byte aligned (checked by the launcher)
+        for (int64_t j = gtid; j < nb; j += stride) {
+            unsigned long long w;
+            if (8 * j + 8 <= L.n_bits) w = in[j];
+            else { w = 0; for (int k = 0; k < 8 && 8 * j + k < L.n_bits; ++k) w |= (unsigned long long)a.bits[8 * j + k] << (8 * k); }
+            out[j] = (uint8_t)(((w & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
+        }
+    }
+    {
+        int32_t *len = (int32_t *)(a.blob + L.off_row_len);
+        int8_t *st = (int8_t *)(a.blob + L.off_row_state);
+        for (int64_t i = gtid; i < L.n_rows; i += stride) {
+            const longlong2 r = *(const longlong2 *)(a.rows + 2 * i);
+            st[i] = (int8_t)r.x; len[i] = (int32_t)r.y;
+        }
+    }
+    if (a.has_pos) {
+        uint32_t *p32 = (uint32_t *)(a.blob + L.off_pos32);
+        for (int64_t i = gtid; i < L.n_pos; i += stride) p32[i] = (uint32_t)a.pos[i];
+    }
+    {
+        int64_t *pa = (int64_t *)(a.blob + L.off_pauses), *mo = (int64_t *)(a.blob + L.off_msg_off), *po = (int64_t *)(a.blob + L.off_pos_off);
+        for (int64_t i = gtid; i <= L.n_msg; i += stride) {
+            if (i < L.n_msg) pa[i] = a.pauses[i];
+            mo[i] = a.msg_off[i]; po[i] = a.pos_off[i];
+        }
+    }
+}
+
+int launch_pack_blob(const urhgpu_outputs *o, int write_pos, hipStream_t s) {
+    if (!o->blob) return URHGPU_OK;
+    if (!o->rows || !o->bits || !o->msg_off || !o->pauses || !o->pos_off || !o->counts) return URHGPU_ERR_ARG;
+    if (((uintptr_t)o->bits & 7) || ((uintptr_t)o->blob & 15) || ((uintptr_t)o->rows & 15)) return URHGPU_ERR_ARG;
+    const int has_pos = (write_pos && o->pos) ? 1 : 0;
+    if (o->cap_blob < blob_capacity(o->cap_rows, o->cap_bits, o->cap_msg, o->cap_pos, has_pos)) return URHGPU_ERR_CAPACITY;
+    PackArgs a{o->rows, o->bits, o->msg_off, o->pauses, o->pos_off, o->pos, o->counts, o->cap_rows, o->cap_bits, o->cap_msg, o->cap_pos, has_pos,
+               (char *)o->blob, o->cap_blob};
+    // sized for a typical result (a few million elements), stride loops for the rest: the counts are only known on the device
+    hipLaunchKernelGGL(k_pack_blob, dim3(2048), dim3(256), 0, s, a);
+    return URHGPU_OK;
+}
+
+}  // namespace urh

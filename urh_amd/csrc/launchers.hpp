@@ -256,6 +256,8 @@ int launch_message_ranges(const int64_t *d_rows, const int64_t *d_n_rows, int64_
 size_t seg_scratch_bytes(int64_t cap_rows, int64_t cap);
 size_t seg_ctl_bytes();
 void seg_ctl_read(const void *host_copy, int64_t *n_seg, int64_t *n_msgs, int *ambiguous);
+// ---- compact.hip --------------------------------------------------------------------------------------------------
+int launch_pack_blob(const urhgpu_outputs *o, int write_pos, hipStream_t s);
 // ---- costas.hip -----------------------------------------------------------------------------------------------
 size_t costas_scratch_bytes(int64_t n);
 int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, void *scratch);

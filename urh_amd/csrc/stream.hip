@@ -1,0 +1,214 @@
+// stream.hip -- a stream of captures, results on the host (include/urhgpu.h: urhgpu_stream_*).
+//
+// SURVEY §8(d)'s window for the IQ -> bits path is "IQ resident in HBM ... compact outputs on the host".  One capture at a time that is
+// hot kernel + tail + copy, strictly one after the other (0.44 + 0.4 ms per GiB in round 2).  A consumer that processes capture
+// after capture -- the reference's own live mode is one (ProtocolSniffer.py:161-202) -- lets three things overlap:
+//     hot kernel of pass i      | tail of pass i - 1 (second stream, urhgpu_ctx_set_pipelined) | D2H of pass i - 2 (copy engine)
+// Three output slots rotate; the compact blob (compact.hip) makes the copy ONE hipMemcpyAsync of 9 MB per GiB (3.5 MB without
+// bit_sample_pos) into pinned memory, which hides under the 0.29 ms hot kernel.  The host blocks only on the tail of the pass before
+// last -- finished by the time the hot kernel before this one ends --, so the GPU always has the next hot kernel queued.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <new>
+
+#include "common.hpp"
+#include "compact.hpp"
+#include "launchers.hpp"
+
+using namespace urh;
+
+struct urhgpu_stream {
+    urhgpu_ctx *ctx = nullptr;
+    urhgpu_params p;
+    int want_qad = 0, want_pos = 0;
+    int64_t n_max = 0, cap_rows = 0, cap_bits = 0, cap_msg = 0, cap_pos = 0, cap_blob = 0;
+    struct Slot {
+        void *dev = nullptr;               // one allocation: qad | rows | bits | msg_off | pauses | pos_off | pos | counts | blob
+        urhgpu_outputs out;
+        char *h_blob = nullptr;            // pinned
+        int64_t *h_counts = nullptr;       // pinned int64[8]
+        hipEvent_t ev_tail = nullptr, ev_copy = nullptr;
+        int64_t seq = -1, n = 0;
+        int state = 0;                     // 0 free, 1 pass launched (tail pending), 2 copy issued, 3 result handed out
+    } slot[3];
+    hipStream_t copy_stream = nullptr;
+    int64_t seq = 0;
+    bool was_pipelined = false;
+};
+
+namespace {
+
+size_t a256(size_t x) { return (x + 255) & ~size_t(255); }
+
+void fill_result(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r) {
+    memset(r, 0, sizeof(*r));
+    r->seq = s.seq;
+    const int64_t *hdr = (const int64_t *)s.h_blob;
+    r->n_samples = s.n;
+    r->n_rows = hdr[1]; r->n_msg = hdr[2]; r->n_bits = hdr[3]; r->n_pos = hdr[4]; r->rows_needed = hdr[5];
+    r->blob_bytes = hdr[6] < 0 ? -hdr[6] : hdr[6];
+    r->truncated = (int)hdr[15];
+    r->pauses = (const int64_t *)(s.h_blob + hdr[8]);
+    r->msg_off = (const int64_t *)(s.h_blob + hdr[9]);
+    r->pos_off = (const int64_t *)(s.h_blob + hdr[10]);
+    r->row_state = (const int8_t *)(s.h_blob + hdr[11]);
+    r->bits_packed = (const uint8_t *)(s.h_blob + hdr[12]);
+    r->row_len = (const int32_t *)(s.h_blob + hdr[13]);
+    r->pos32 = hdr[7] ? (const uint32_t *)(s.h_blob + hdr[14]) : nullptr;
+    r->blob = s.h_blob;
+    r->d_qad = s.out.qad;
+    (void)st;
+}
+
+// the host waits for the tail of the slot's pass, sizes the blob from the counts and queues its copy
+int issue_copy(urhgpu_stream *st, urhgpu_stream::Slot &s) {
+    if (s.state != 1) return URHGPU_OK;
+    URH_HIP(hipEventSynchronize(s.ev_tail));
+    const BlobLayout L = blob_layout(s.h_counts, st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
+    if (L.total > st->cap_blob) return URHGPU_ERR_CAPACITY;
+    URH_HIP(hipMemcpyAsync(s.h_blob, s.out.blob, (size_t)L.total, hipMemcpyDeviceToHost, st->copy_stream));
+    URH_HIP(hipEventRecord(s.ev_copy, st->copy_stream));
+    s.state = 2;
+    return URHGPU_OK;
+}
+
+int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r) {
+    if (s.state == 1) URH_TRY(issue_copy(st, s));
+    if (s.state != 2) return URHGPU_ERR_ARG;
+    URH_HIP(hipEventSynchronize(s.ev_copy));
+    if (((const int64_t *)s.h_blob)[0] != URHGPU_BLOB_MAGIC) return URHGPU_ERR_ARG;
+    fill_result(st, s, r);
+    s.state = 3;
+    return URHGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int urhgpu_stream_capacities(int64_t n_max, const urhgpu_params *p, int64_t *cap_rows, int64_t *cap_bits, int64_t *cap_msg, int64_t *cap_pos) {
+    if (!p || n_max <= 0 || p->samples_per_symbol < 1 || p->bits_per_symbol < 1 || p->tolerance < 0) return URHGPU_ERR_ARG;
+    const int64_t sps = (int64_t)p->samples_per_symbol;
+    // accepted runs cannot be denser than one per (tolerance + 1) samples; the default assumes at most ~4 per symbol (a capture
+    // that is mostly noise needs more: urhgpu_host_result::truncated says so and rows_needed by how much)
+    const int64_t rows = std::min<int64_t>(n_max / ((int64_t)p->tolerance + 1) + 2, std::max<int64_t>(4096, 4 * (n_max / sps) + 4096));
+    const int64_t bits = (n_max / sps + 2 * rows / 8 + 64) * (int64_t)p->bits_per_symbol + rows;
+    const int64_t msg = std::max<int64_t>(64, rows / 4);
+    if (cap_rows) *cap_rows = rows;
+    if (cap_bits) *cap_bits = bits;
+    if (cap_msg) *cap_msg = msg;
+    if (cap_pos) *cap_pos = bits + 2 * msg + 2;
+    return URHGPU_OK;
+}
+
+int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p, int want_qad, int want_pos, int64_t cap_rows, urhgpu_stream **out) {
+    if (!ctx || !p || !out || n_max <= 0 || n_max > INT32_MAX) return URHGPU_ERR_ARG;      // int32 row lengths, uint32 positions
+    if (p->mod == URHGPU_MOD_PSK) return URHGPU_ERR_UNSUPPORTED;                       // the Costas path synchronises with the host
+    URH_HIP(hipSetDevice(ctx->device));
+    urhgpu_stream *st = new (std::nothrow) urhgpu_stream();
+    if (!st) return URHGPU_ERR_ARG;
+    st->ctx = ctx; st->p = *p; st->want_qad = want_qad ? 1 : 0; st->want_pos = want_pos ? 1 : 0; st->n_max = n_max;
+    st->p.write_bit_sample_pos = st->want_pos;
+    int status = urhgpu_stream_capacities(n_max, p, &st->cap_rows, &st->cap_bits, &st->cap_msg, &st->cap_pos);
+    if (status != URHGPU_OK) { delete st; return status; }
+    if (cap_rows > 0) {                                    // the caller knows better (a retry after urhgpu_host_result::truncated)
+        st->cap_rows = cap_rows;
+        st->cap_bits = (n_max / (int64_t)p->samples_per_symbol + 2 * cap_rows / 8 + 64) * (int64_t)p->bits_per_symbol + cap_rows;
+        st->cap_msg = std::max<int64_t>(64, cap_rows / 4);
+        st->cap_pos = st->cap_bits + 2 * st->cap_msg + 2;
+    }
+    st->cap_blob = blob_capacity(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
+    st->was_pipelined = ctx->pipelined;
+    if (!ctx->pipelined) { status = urhgpu_ctx_set_pipelined(ctx, 1, nullptr); if (status != URHGPU_OK) { delete st; return status; } }
+    status = urhgpu_ctx_reserve(ctx, n_max, p->tolerance);
+    if (status != URHGPU_OK) { urhgpu_stream_destroy(st); return status; }
+    if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess) { urhgpu_stream_destroy(st); return URHGPU_ERR_HIP; }
+    const size_t b_qad = st->want_qad ? a256((size_t)n_max * 4) : 0, b_rows = a256((size_t)st->cap_rows * 16), b_bits = a256((size_t)st->cap_bits),
+                 b_off = a256((size_t)(st->cap_msg + 1) * 8), b_pos = st->want_pos ? a256((size_t)st->cap_pos * 8) : 0, b_blob = a256((size_t)st->cap_blob);
+    for (auto &s : st->slot) {
+        memset(&s.out, 0, sizeof(s.out));
+        if (hipMalloc(&s.dev, b_qad + b_rows + b_bits + 3 * b_off + b_pos + 256 + b_blob) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_blob, (size_t)st->cap_blob) != hipSuccess || hipHostMalloc((void **)&s.h_counts, 64) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_tail, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_copy, hipEventDisableTiming) != hipSuccess) {
+            urhgpu_stream_destroy(st);
+            return URHGPU_ERR_HIP;
+        }
+        char *d = (char *)s.dev;
+        if (st->want_qad) { s.out.qad = (float *)d; d += b_qad; }
+        s.out.rows = (int64_t *)d; d += b_rows; s.out.cap_rows = st->cap_rows;
+        s.out.bits = (uint8_t *)d; d += b_bits; s.out.cap_bits = st->cap_bits;
+        s.out.msg_off = (int64_t *)d; d += b_off;
+        s.out.pauses = (int64_t *)d; d += b_off; s.out.cap_msg = st->cap_msg;
+        s.out.pos_off = (int64_t *)d; d += b_off;
+        if (st->want_pos) { s.out.pos = (int64_t *)d; d += b_pos; s.out.cap_pos = st->cap_pos; }
+        s.out.counts = (int64_t *)d; d += 256;
+        s.out.blob = d; s.out.cap_blob = st->cap_blob;
+        memset(s.h_counts, 0, 64);
+    }
+    *out = st;
+    return URHGPU_OK;
+}
+
+int urhgpu_stream_destroy(urhgpu_stream *st) {
+    if (!st) return URHGPU_OK;
+    (void)hipSetDevice(st->ctx->device);
+    (void)urhgpu_ctx_sync(st->ctx);
+    if (st->copy_stream) { (void)hipStreamSynchronize(st->copy_stream); (void)hipStreamDestroy(st->copy_stream); }
+    for (auto &s : st->slot) {
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.h_blob) (void)hipHostFree(s.h_blob);
+        if (s.h_counts) (void)hipHostFree(s.h_counts);
+        if (s.ev_tail) (void)hipEventDestroy(s.ev_tail);
+        if (s.ev_copy) (void)hipEventDestroy(s.ev_copy);
+    }
+    if (!st->was_pipelined) (void)urhgpu_ctx_set_pipelined(st->ctx, 0, nullptr);
+    delete st;
+    return URHGPU_OK;
+}
+
+int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_host_result *ready) {
+    if (!st || !d_iq || n <= 2 || n > st->n_max) return URHGPU_ERR_ARG;
+    urhgpu_ctx *ctx = st->ctx;
+    URH_HIP(hipSetDevice(ctx->device));
+    const int64_t i = st->seq;
+    urhgpu_stream::Slot &s = st->slot[i % 3];
+    if (ready) { memset(ready, 0, sizeof(*ready)); ready->seq = -1; }
+    // the slot's previous pass (i - 3): its copy was queued two pushes ago; hand the result out now (valid until push i + 2)
+    if (s.state == 1 || s.state == 2) {
+        urhgpu_host_result r;
+        URH_TRY(finish_copy(st, s, &r));
+        if (ready) *ready = r;
+    }
+    // ...and nothing of this pass may be written into the slot's device buffers before that copy has read them
+    if (s.state == 3) URH_HIP(hipStreamWaitEvent(ctx->tail_stream, s.ev_copy, 0));
+    s.state = 0;
+    URH_TRY(urhgpu_iq_to_bits_dev(ctx, d_iq, n, &st->p, &s.out));
+    URH_HIP(hipMemcpyAsync(s.h_counts, s.out.counts, 40, hipMemcpyDeviceToHost, ctx->tail_stream));
+    URH_HIP(hipEventRecord(s.ev_tail, ctx->tail_stream));
+    s.state = 1; s.seq = i; s.n = n;
+    st->seq = i + 1;
+    // the pass before last: its tail ran beside the previous hot kernel and is done (or about to be): size and queue its copy
+    if (i >= 2) URH_TRY(issue_copy(st, st->slot[(i - 2) % 3]));
+    return URHGPU_OK;
+}
+
+int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out) {
+    if (!st || !out3 || !n_out) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(st->ctx->device));
+    *n_out = 0;
+    // oldest first
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int a, int b) { return st->slot[a].seq < st->slot[b].seq; });
+    for (int k = 0; k < 3; ++k) {
+        urhgpu_stream::Slot &s = st->slot[order[k]];
+        if (s.state == 1 || s.state == 2) {
+            URH_TRY(finish_copy(st, s, &out3[*n_out]));
+            *n_out += 1;
+        }
+    }
+    return URHGPU_OK;
+}
+
+}  // extern "C"

@@ -31,7 +31,12 @@ class DemodParams:
     pause_threshold: int = 8
     write_bit_sample_pos: bool = True
 
-    def to_c(self, dtype) -> _lib.Params:
+    def to_c(self, dtype, demod_only: bool = False) -> _lib.Params:
+        """demod_only: for afp_demod alone -- the slicing parameters (tolerance, samples_per_symbol, bits_per_symbol as a symbol
+        width) play no part there and must not make it fail (the reference's qad depends on the demodulation parameters only)."""
+        if demod_only:
+            from dataclasses import replace
+            return replace(self, tolerance=0, samples_per_symbol=1, bits_per_symbol=max(1, int(self.bits_per_symbol))).to_c(dtype)
         mod, sentinel = mod_code(self.modulation_type)
         # the reference's own failures for these inputs: `uint16 tolerance` (signal_functions.pyx:392) raises
         # OverflowError, `n / samples_per_symbol` (ProtocolAnalyzer.py:353) ZeroDivisionError
@@ -157,6 +162,97 @@ class BitsResult:
         return ["".join(map(str, d)) for d in data]
 
 
+class HostBits:
+    """One pass's results ON THE HOST, from the compact blob (include/urhgpu.h "compact result blob"): numpy views of pinned memory
+    owned by the stream -- valid until the push after next; copy what has to live longer.  The accessors widen to the reference's own
+    shapes and types: ppseq() is grab_pulse_lens' int64 (P, 2), bits() one byte per bit, bit_sample_pos() int64."""
+
+    def __init__(self, r: "_lib.HostResult", params):
+        self.seq, self.n_samples = int(r.seq), int(r.n_samples)
+        self.n_rows, self.n_msg, self.n_bits, self.n_pos = int(r.n_rows), int(r.n_msg), int(r.n_bits), int(r.n_pos)
+        self.rows_needed, self.truncated, self.blob_bytes = int(r.rows_needed), bool(r.truncated), int(r.blob_bytes)
+        self.params = params
+        self.d_qad_ptr = r.d_qad
+
+        def view(ptr, count, dtype):
+            if not ptr or count <= 0:
+                return np.zeros(0, dtype)
+            nbytes = count * np.dtype(dtype).itemsize
+            return np.frombuffer((C.c_ubyte * nbytes).from_address(ptr), dtype=dtype, count=count)
+        self.row_len = view(r.row_len, self.n_rows, np.int32)
+        self.row_state = view(r.row_state, self.n_rows, np.int8)
+        self.bits_packed = view(r.bits_packed, (self.n_bits + 7) // 8, np.uint8)
+        self.msg_off = view(r.msg_off, self.n_msg + 1, np.int64)
+        self.pauses = view(r.pauses, self.n_msg, np.int64)
+        self.pos_off = view(r.pos_off, self.n_msg + 1, np.int64)
+        self.pos32 = view(r.pos32, self.n_pos, np.uint32) if r.pos32 else None
+
+    def check(self):
+        if self.truncated:
+            raise _lib.UrhGpuError(_lib.ERR_CAPACITY, f"output capacity too small: the pulse table needs {self.rows_needed} rows")
+        return self
+
+    def ppseq(self) -> np.ndarray:
+        out = np.empty((self.n_rows, 2), np.int64)
+        out[:, 0] = self.row_state
+        out[:, 1] = self.row_len
+        return out
+
+    def bits(self) -> np.ndarray:
+        return np.unpackbits(self.bits_packed, count=self.n_bits) if self.n_bits else np.zeros(0, np.uint8)
+
+    def bit_sample_pos(self) -> np.ndarray:
+        return self.pos32.astype(np.int64) if self.pos32 is not None else np.zeros(0, np.int64)
+
+    def flat(self):
+        """(bits u8, msg_off i64, pauses i64, pos i64, pos_off i64): what BitsResult.flat() gives"""
+        return self.bits(), self.msg_off.copy(), self.pauses.copy(), self.bit_sample_pos(), self.pos_off.copy()
+
+
+class CaptureStream:
+    """Capture after capture with the results on the host (urhgpu_stream_*): push() queues a pass and returns at once with the result
+    of the pass pushed three calls earlier (or None); flush() waits for the rest.  The hot kernel of pass i, the tail of pass i - 1
+    and the D2H copy of pass i - 2's compact blob overlap."""
+
+    def __init__(self, pipe: "DevicePipeline", n_max: int, p: DemodParams, want_qad=True, want_pos=True, dtype=np.float32, cap_rows=0):
+        self.pipe, self.params = pipe, p
+        self._cp = p.to_c(dtype)
+        h = C.c_void_p()
+        pipe.ctx.set_stream(pipe.torch.cuda.current_stream(pipe.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_stream_create(pipe.ctx.handle, int(n_max), C.byref(self._cp), 1 if want_qad else 0,
+                                                    1 if want_pos else 0, int(cap_rows), C.byref(h)))
+        self._h = h
+        self._dtype = np.dtype(dtype)
+
+    def push(self, iq):
+        torch = self.pipe.torch
+        if iq.dtype == torch.complex64:
+            iq = torch.view_as_real(iq)
+        if _torch_dtype(iq) != self._dtype or not iq.is_contiguous():
+            raise ValueError("the stream was created for contiguous (N, 2) captures of " + str(self._dtype))
+        r = _lib.HostResult()
+        self.pipe.ctx.set_stream(torch.cuda.current_stream(self.pipe.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_stream_push(self._h, C.c_void_p(iq.data_ptr()), int(iq.shape[0]), C.byref(r)))
+        return HostBits(r, self.params) if r.seq >= 0 else None
+
+    def flush(self):
+        arr = (_lib.HostResult * 3)()
+        n = C.c_int(0)
+        _lib.check(_lib.load().urhgpu_stream_flush(self._h, arr, C.byref(n)))
+        return [HostBits(arr[k], self.params) for k in range(n.value)]
+
+    def close(self):
+        if self._h:
+            _lib.load().urhgpu_stream_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class DevicePipeline:
     """Owns a liburhgpu context bound to torch's current stream and the output buffers."""
 
@@ -204,6 +300,10 @@ class DevicePipeline:
 
     def reserve(self, n: int, p: DemodParams):
         self.ctx.reserve(n, p.tolerance)
+
+    def stream(self, n_max: int, p: DemodParams, want_qad=True, want_pos=True, dtype=np.float32, cap_rows=0) -> CaptureStream:
+        """a CaptureStream on this pipeline's context (which it switches to pipelined passes)"""
+        return CaptureStream(self, n_max, p, want_qad, want_pos, dtype, cap_rows)
 
     def iq_to_bits(self, iq, p: DemodParams, want_qad=True, cap_rows=None, slot=0) -> BitsResult:
         """iq: torch tensor on this device, shape (N, 2) of int8/uint8/int16/uint16/float32, or complex64 (N,).
@@ -261,7 +361,7 @@ class DevicePipeline:
         npdt = _torch_dtype(iq)
         n = iq.shape[0]
         qad = torch.empty(n, dtype=torch.float32, device=self.device)
-        cp = p.to_c(npdt)
+        cp = p.to_c(npdt, demod_only=True)
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(_lib.load().urhgpu_afp_demod_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, C.byref(cp),
                                                     C.c_void_p(qad.data_ptr())))
