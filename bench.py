@@ -4,8 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 A "step" is one full pass of the hot path over one synthetic capture that is already resident in HBM:
-IQ (complex64) -> demodulated signal (Signal.qad, materialised) -> pulse table -> bits / pauses /
-bit_sample_pos, everything left in device memory.  Workload at N=1: BASELINE.json configs[1]
+IQ (complex64) -> demodulated signal (Signal.qad, materialised, stays in HBM) -> pulse table -> bits / pauses /
+bit_sample_pos -> D2H copy of those compact outputs into pinned host memory (SURVEY.md §8(d)'s timing window).  At N=1 the steps
+run through urhgpu_stream_* (urh_amd.pipeline.CaptureStream): the hot kernel of step i, the tail of step i - 1 and the copy of
+step i - 2 overlap, and `value` counts K steps INCLUDING the copies of all K (the timed region ends after the last copy);
+the device-only figure of the same steps is config.device_only_ms_per_step.  Workload at N=1: BASELINE.json configs[1]
 ("1 GiB synthetic complex64 2-FSK @ 100 samples/symbol, single MI355X") on the bytes SURVEY.md §8(d) config 2
 specifies (128 segments of 2^20 samples: numpy-seeded bits through modulate_c + numpy-seeded AWGN, see
 urh_amd/synth.py:spec_fsk_capture); for N>1 every rank holds a 1 GiB sample-contiguous shard of one N-GiB capture
@@ -43,7 +46,8 @@ ALGO_BYTES_PER_SAMPLE = 12       # 8 B complex64 read + 4 B float32 qad write (S
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of the dominant kernel from the newest committed PMC summary under profiles/
     (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, corrected as tools/prof_collect.py documents); the counters
-    cannot be collected inside this process, so this is the figure of the profiled run of the SAME command."""
+    cannot be collected inside this process, so this is the figure of the profiled run of the SAME command -- the record names the
+    file (profiles/rNN...: the round it was collected in) so that a stale figure is recognisable as such."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_fsk_1gib_pmc.json")))
     for f in reversed(files):
@@ -53,8 +57,29 @@ def pmc_traffic(kernel_substr):
             continue
         for name, rec in d.items():
             if kernel_substr in name and "hbm_traffic_bytes_per_launch" in rec:
-                return int(rec["hbm_traffic_bytes_per_launch"]["total"]), os.path.basename(f)
+                return int(rec["hbm_traffic_bytes_per_launch"]["total"]), "profiles/" + os.path.basename(f) + " (a separate rocprofv3 --pmc run of this command)"
     return None, None
+
+
+def copy_ceiling(torch, pipe, iq, n):
+    """What a pure copy gets out of the HBM on THIS box, measured now (urhgpu_bench_copy_ceiling_dev): the hot kernel's access shape
+    without its arithmetic (8 B in + 4 B out per sample) and the guide's plain float4 copy."""
+    import ctypes as C
+    from urh_amd import _lib
+    out = torch.empty(n, dtype=torch.float32, device=iq.device)
+    rec = {}
+    lib, h = _lib.load(), pipe.ctx.handle
+    pipe.ctx.set_stream(torch.cuda.current_stream(iq.device).cuda_stream)
+    for shape, name, bytes_per in ((0, "hot_kernel_shape", 12), (1, "plain_float4", 8)):
+        ms = C.c_float(0.0)
+        best = None
+        for _ in range(3):                           # each call: 3 warm-up + 40 timed launches
+            _lib.check(lib.urhgpu_bench_copy_ceiling_dev(h, C.c_void_p(iq.data_ptr()), C.c_void_p(out.data_ptr()), n, shape, 40, C.byref(ms)))
+            best = ms.value if best is None else min(best, ms.value)
+        rec[name + "_ms"] = round(best, 4)
+        rec[name + "_gbs"] = round(n * bytes_per / (best * 1e-3) / 1e9, 1)
+    del out
+    return rec
 
 
 def cpu_model():
@@ -169,16 +194,21 @@ def cpu_reference(iq_host, p, want_outputs=True):
     return rec, (qad, pp, flat)
 
 
-def parity_record(res, ref_out, tx_bits, kind):
-    """Element-for-element comparison of the last timed step's device outputs with the CPU reference's on the same bytes."""
+def parity_record(res, ref_out, tx_bits, kind, got_qad=None):
+    """Element-for-element comparison of the last timed step's outputs with the CPU reference's on the same bytes.  res: the step's
+    HostBits (what arrived in pinned host memory through the compact blob) or a device-resident BitsResult; got_qad: the step's
+    demodulated signal (host copy)."""
     import numpy as np
     qad, pp, flat = ref_out
-    got_qad = res.qad.cpu().numpy() if res.qad is not None else None
+    if got_qad is None and getattr(res, "qad", None) is not None:
+        got_qad = res.qad.cpu().numpy()
     rows = res.ppseq()
     got = res.flat()
     names = ("bits", "msg_off", "pauses", "bit_sample_pos", "pos_off")
     rec = {"against": "oracle/_ref (the reference's Cython afp_demod + grab_pulse_lens; tail: C port pinned on the reference's Python)"
-           if kind == "reference" else "oracle/ C restatement", "samples": int(len(qad))}
+           if kind == "reference" else "oracle/ C restatement", "samples": int(len(qad)),
+           "outputs_compared": "the LAST timed step's: host copies that arrived through the compact blob (pulse table, bits, pauses, offsets, "
+                               "bit_sample_pos) + its qad read back from HBM"}
     if got_qad is not None:
         rec["qad_mismatches"] = int((got_qad.view(np.uint32) != qad.view(np.uint32)).sum())
     rec["rows"] = int(len(pp))
@@ -202,11 +232,12 @@ def parity_record(res, ref_out, tx_bits, kind):
     return rec
 
 
-def _timed(torch, fn, reps=3, ramp_ms=30.0):
-    """(result, best wall time in ms) of fn() with the GPU drained before and after.  The part needs about 30 ms of sustained load to
-    reach its clocks (tools/ramp_probe.py) and falls back within half a second of idling -- the host-side parity
-    checks between the stages are much longer than that --, so fn() is first repeated for ramp_ms, as the headline loop does."""
-    best, out = None, None
+def _timed(torch, fn, reps=5, ramp_ms=30.0):
+    """(result, MEDIAN wall time in ms over `reps`) of fn() with the GPU drained before and after.  The part needs about 30 ms of
+    sustained load to reach its clocks (tools/ramp_probe.py) and falls back within half a second of idling -- the
+    host-side parity checks between the stages are much longer than that --, so fn() is first repeated for ramp_ms, as the headline
+    loop does."""
+    times, out = [], None
     t_ramp = time.perf_counter()
     while ramp_ms > 0 and (time.perf_counter() - t_ramp) * 1e3 < ramp_ms:
         out = fn()
@@ -216,9 +247,9 @@ def _timed(torch, fn, reps=3, ramp_ms=30.0):
         t0 = time.perf_counter()
         out = fn()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) * 1e3
-        best = dt if best is None else min(best, dt)
-    return out, best
+        times.append((time.perf_counter() - t0) * 1e3)
+    times.sort()
+    return out, times[len(times) // 2]
 
 
 def _ref_modules():
@@ -267,7 +298,7 @@ def extra_config3(pipe, dev, args):
     (filt, noise), t_fir_noise = _timed(torch, lambda: estimators.fir_filter_detect_noise_dev(pipe, iq, d_taps))
     fused_equal = bool(torch.equal(filt, filt_u) and float(noise) == float(noise_u))
     del filt_u
-    est, t_est = _timed(torch, lambda: estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK"), reps=3)
+    est, t_est = _timed(torch, lambda: estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK"))
     est_stages = {}
     estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK", timings=est_stages)
     center = float(est["center"]) if est else 0.0
@@ -276,7 +307,7 @@ def extra_config3(pipe, dev, args):
     total_ms = t_fir_noise + t_est + t_bits
     rec = {"workload": "configs[2]: 1 GiB OOK (Manchester, 124 messages) + 64-tap complex FIR + auto noise threshold + estimate + bits",
            "samples": n, "ms": round(total_ms, 3),
-           "timing": "every stage: best of 3 wall times (GPU drained before and after) following 30 ms of repeats of the same stage (clock ramp)",
+           "timing": "every stage: median of 5 wall times (GPU drained before and after) following 30 ms of repeats of the same stage (clock ramp)",
            "stages_ms": {"fir_filter_with_fused_noise_statistics": round(t_fir_noise, 3), "estimate": round(t_est, 3),
                          "iq_to_bits_ask": round(t_bits, 3)},
            "unfused_ms": {"fir_filter": round(t_fir, 3), "detect_noise_level": round(t_noise, 3), "fused_result_equal": fused_equal},
@@ -390,7 +421,7 @@ def extra_config5(pipe, dev, args):
     total_ii = t_costas + out["ii_center_0"][1]
     rec = {"workload": "configs[4]: 1 GiB 4-PSK, Costas loop (order 4, bandwidth 0.1) + detect_center + bits",
            "samples": n, "ms": round(total_i, 3), "ms_center_0": round(total_ii, 3),
-           "timing": "every stage: best of 3 wall times (GPU drained before and after) following 30 ms of repeats of the same stage (clock ramp)",
+           "timing": "every stage: median of 5 wall times (GPU drained before and after) following 30 ms of repeats of the same stage (clock ramp)",
            "stages_ms": {"costas_demod": round(t_costas, 3), "detect_center": round(t_center, 3),
                          "grab_pulse_lens_plus_bits_auto_center": round(out["i_auto_center"][1], 3),
                          "grab_pulse_lens_plus_bits_center_0": round(out["ii_center_0"][1], 3),
@@ -442,62 +473,6 @@ def extra_config5(pipe, dev, args):
     rec["value"] = round(n / (total_i * 1e-3) / 1e6, 1)
     rec["unit"] = "Msamples/s"
     return rec
-
-
-def overlapped_d2h_steps(torch, pipe, x, p, want_qad, steps):
-    """Steady state of a consumer that wants every step's compact outputs on the host: steps alternate between two sets of output
-    buffers; while step i + 1 runs, the host reads step i's counts (40 bytes) and queues the copies of its pulse table, bits,
-    offsets, pauses and bit_sample_pos into pinned memory on a second stream.  Returns ms per step (copies of the last step
-    included)."""
-    copy_stream = torch.cuda.Stream()
-    main = torch.cuda.current_stream()
-    res = [None, None]
-    counts_host = [torch.zeros(5, dtype=torch.int64).pin_memory() for _ in range(2)]
-    pinned = [{}, {}]
-    ev_step = [torch.cuda.Event(), torch.cuda.Event()]
-    ev_copy = [None, None]
-
-    def launch(i):
-        s = i & 1
-        if ev_copy[s] is not None:
-            main.wait_event(ev_copy[s])                      # the buffers of step i - 2 have been read
-        res[s] = pipe.iq_to_bits(x, p, want_qad=want_qad, slot=s)
-        pipe.ctx.join()                                  # pipelined context: this stream waits for the pass's tail (no host blocking)
-        counts_host[s].copy_(res[s].counts, non_blocking=True)
-        ev_step[s].record(main)
-
-    def drain(i):
-        s = i & 1
-        ev_step[s].synchronize()
-        n_rows, n_msg, n_bits, n_pos = (int(v) for v in counts_host[s][:4])
-        r = res[s]
-        with torch.cuda.stream(copy_stream):
-            for name, src, count in (("rows", r.rows_buf, n_rows), ("bits", r.bits_buf, n_bits), ("msg_off", r.msg_off_buf, n_msg + 1),
-                                     ("pauses", r.pauses_buf, n_msg), ("pos", r.pos_buf, n_pos), ("pos_off", r.pos_off_buf, n_msg + 1)):
-                if src is None or count == 0:
-                    continue
-                buf = pinned[s].get(name)
-                if buf is None or buf.shape[0] < count:
-                    buf = torch.empty((max(count, 1024),) + tuple(src.shape[1:]), dtype=src.dtype, pin_memory=True)
-                    pinned[s][name] = buf
-                buf[:count].copy_(src[:count], non_blocking=True)
-            ev_copy[s] = torch.cuda.Event()
-            ev_copy[s].record(copy_stream)
-
-    for i in range(3):                                       # allocate the pinned buffers, warm up
-        launch(i)
-        drain(i)
-    copy_stream.synchronize()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    launch(0)
-    for i in range(1, steps):
-        launch(i)
-        drain(i - 1)
-    drain(steps - 1)
-    copy_stream.synchronize()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
 
 
 def run_extras(pipe, dev, args):
@@ -613,10 +588,9 @@ def main():
         res = step()
     pipe.ctx.join()
     torch.cuda.synchronize()
-    # latency of ONE step with nothing overlapped, and the same plus the D2H copy of the compact outputs (pulse table, bits,
-    # pauses, offsets, bit_sample_pos -- SURVEY 8(d)'s timing window; qad stays in HBM)
+    # latency of ONE step with nothing overlapped (device only), and the same plus the D2H copy of the WIDE outputs (int64 pulse table,
+    # one byte per bit, int64 bit_sample_pos -- the round-2 format, kept for comparison; qad stays in HBM)
     lat, lat_d2h = [], []
-    d2h_overlapped_ms = None
     for _ in range(5):
         torch.cuda.synchronize()
         t_l = time.perf_counter()
@@ -624,7 +598,8 @@ def main():
         pipe.ctx.join()
         torch.cuda.synchronize()
         lat.append(time.perf_counter() - t_l)
-    d2h_bytes = None
+    d2h_bytes_wide = None
+    use_stream = not sharded and args.pipeline and not args.no_d2h
     if not sharded and not args.no_d2h:
         pinned = {}
         for _ in range(6):
@@ -634,58 +609,132 @@ def main():
             host_out = res.to_host_pinned(pinned)           # pulse table, bits, offsets, pauses, bit_sample_pos in pinned host memory
             lat_d2h.append(time.perf_counter() - t_l)
         lat_d2h = lat_d2h[1:]                               # the first call allocates the pinned buffers
-        d2h_bytes = int(sum(x.nbytes for x in host_out))
-        d2h_overlapped_ms = overlapped_d2h_steps(torch, pipe, iq, p, want_qad, max(8, args.steps // 2))
+        d2h_bytes_wide = int(sum(x.nbytes for x in host_out))
+        del pinned, host_out
     latency_ms = min(lat) * 1e3
-    # The part takes some 30 ms of sustained load to reach its clocks (tools/ramp_probe.py: 0.34 -> 0.30 ms per pipelined pass over
-    # the first ~100 passes, and again after half a second of idling): untimed passes until the step time has settled, then the
-    # timed K steps.  (Sharded runs: a fixed count, every rank takes part in every pass's exchanges.)
-    ramp_passes = 0
-    if not os.environ.get("URH_BENCH_NO_RAMP"):
-        best = None
+
+    def ramp(run10):
+        """The part takes some 30 ms of sustained load to reach its clocks (tools/ramp_probe.py: 0.34 -> 0.30 ms per pipelined pass over
+        the first ~100 passes, and again after half a second of idling): untimed passes until the step time has settled.  (Sharded runs:
+        a fixed count, every rank takes part in every pass's exchanges.)"""
+        passes, best = 0, None
+        if os.environ.get("URH_BENCH_NO_RAMP"):
+            return 0
         for g in range(20):
             torch.cuda.synchronize()
             t_r = time.perf_counter()
-            for _ in range(10):
-                res = step()
-            pipe.ctx.join()
+            run10()
             torch.cuda.synchronize()
             cur = time.perf_counter() - t_r
-            ramp_passes += 10
+            passes += 10
             if not sharded and g >= 5 and best is not None and cur > 0.99 * best:
                 break
             if sharded and g >= 9:
                 break
             best = cur if best is None else min(best, cur)
+        return passes
+
+    def device_steps(k):
+        r = None
+        for _ in range(k):
+            r = step()
+        pipe.ctx.join()                      # the stream waits for the last step's tail
+        return r
+
+    # ---- the headline (N = 1): K steps through the capture stream, D2H of every step's compact outputs included ---------------------
+    stream_rec = {}
+    last_host = None
+    headline_dt = None
+    kernel_ms = []
+    ramp_passes = 0
+    if use_stream:
+        st = pipe.stream(n, p, want_qad=want_qad, want_pos=True)
+
+        def stream_steps(k):
+            out = []
+            for _ in range(k):
+                r = st.push(iq)
+                if r is not None:
+                    out.append(r)
+            return out + st.flush()
+        one = []
+        for _ in range(5):                                   # ONE capture start to finish: pass + its copy, nothing to overlap with
+            torch.cuda.synchronize()
+            t_l = time.perf_counter()
+            stream_steps(1)
+            one.append(time.perf_counter() - t_l)
+        ramp_passes = ramp(lambda: stream_steps(10))
+        torch.cuda.synchronize()
+        pipe.ctx.profile_begin(0 if os.environ.get("URH_BENCH_NO_PROFILE") else args.steps)
+        t0 = time.perf_counter()
+        results = stream_steps(args.steps)                   # K pushes, then the copies still in flight: ends with the last byte on the host
+        torch.cuda.synchronize()
+        headline_dt = time.perf_counter() - t0
+        kernel_ms = pipe.ctx.profile_end()
+        assert len(results) == args.steps and [r.seq for r in results[-3:]] == sorted(r.seq for r in results[-3:])
+        last_host = results[-1].check()
+        stream_rec = {"single_capture_incl_compact_d2h_ms": round(min(one) * 1e3, 4), "d2h_bytes_per_step": last_host.blob_bytes + 40,
+                      "d2h_format": "compact blob: int32 length + int8 state per pulse-table row, packed bits, uint32 bit_sample_pos, "
+                                    "int64 pauses / offsets (include/urhgpu.h)"}
+        # the last timed step's outputs for the parity record: host copies of the blob's sections + its qad read back from HBM
+        import numpy as np
+        from urh_amd import _lib as _ulib
+        import ctypes as C
+        host_copy = {"ppseq": last_host.ppseq(), "flat": last_host.flat(), "counts": (last_host.n_rows, last_host.n_msg, last_host.n_bits, last_host.n_pos)}
+        qad_host = None
+        if want_qad and last_host.d_qad_ptr:
+            qad_host = np.empty(n, np.float32)
+            _ulib.check(_ulib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(last_host.d_qad_ptr), qad_host.ctypes.data_as(C.c_void_p), n * 4))
+        st.close()
+        # the same without bit_sample_pos (the reference makes them optional: write_bit_sample_pos, ProtocolAnalyzer.py:323, 396-401)
+        from dataclasses import replace
+        st = pipe.stream(n, replace(p, write_bit_sample_pos=False), want_qad=want_qad, want_pos=False)
+        ramp(lambda: stream_steps(10))
+        torch.cuda.synchronize()
+        t_np = time.perf_counter()
+        r_np = stream_steps(args.steps)
+        torch.cuda.synchronize()
+        stream_rec["ms_per_step_without_positions"] = round((time.perf_counter() - t_np) / args.steps * 1e3, 4)
+        stream_rec["d2h_bytes_per_step_without_positions"] = r_np[-1].blob_bytes + 40
+        st.close()
+        del st, results, r_np
+
+    # ---- device only (outputs left in HBM): what round 2 reported as the headline; the timed region of sharded runs ------------------
+    rp_dev = ramp(lambda: device_steps(10))
+    if not use_stream:
+        ramp_passes = rp_dev
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    pipe.ctx.profile_begin(0 if os.environ.get("URH_BENCH_NO_PROFILE") else args.steps)
+    pipe.ctx.profile_begin(0 if (os.environ.get("URH_BENCH_NO_PROFILE") or use_stream) else args.steps)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    pipe.ctx.join()                      # the stream waits for the last step's tail
+    res = device_steps(args.steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    kernel_ms = pipe.ctx.profile_end()
+    if not use_stream:
+        kernel_ms = pipe.ctx.profile_end()
+    else:
+        pipe.ctx.profile_end()
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    device_only_ms = dt / args.steps * 1e3
+    if headline_dt is None:
+        headline_dt = dt
 
     counts = res.host_counts()
     res.check_capacity()
+    if use_stream:
+        assert tuple(host_copy["counts"]) == tuple(counts), (host_copy["counts"], counts)
 
-    # The roofline record of the line comes from the timed region itself (the hot kernel shares the machine with the previous pass's
-    # tail there).  For reference the N = 1 line also carries the same K steps run one after the other, nothing overlapped: step time
+    # For reference the N = 1 line also carries the same K steps run one after the other, nothing overlapped: step time
     # and the hot kernel's duration when it has the machine to itself.
-    pipelined_ms = None
     alone_ms, alone_kernel_ms = None, None
-    if not sharded and args.pipeline:
-        pipelined_ms = dt / args.steps * 1e3
+    ceiling = None
     if not sharded and args.pipeline and not args.no_reference_loop:
         pipe.ctx.join()
         torch.cuda.synchronize()
@@ -703,6 +752,8 @@ def main():
         alone_kernel_ms = sum(ka) / len(ka) if ka else None
         assert rp.host_counts() == counts
         res = rp
+    if not sharded and n % 8192 == 0:
+        ceiling = copy_ceiling(torch, pipe, iq, n)
 
     ranks_info = None
     if dist:
@@ -713,16 +764,19 @@ def main():
 
     if rank == 0:
         total_samples = n * world
-        ms_per_step = dt / args.steps * 1e3
-        value = total_samples * args.steps / dt / 1e6
+        ms_per_step = headline_dt / args.steps * 1e3
+        value = total_samples * args.steps / headline_dt / 1e6
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         bytes_per_sample = ALGO_BYTES_PER_SAMPLE if want_qad else 8
         achieved = (n * bytes_per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_src = (pmc_traffic("k_demod_runs_bp<0, 4, 1, true") if want_qad and n == 128 * SEG
                                 else (None, None))
-        e2e_frac = n * bytes_per_sample / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+        def frac_of(ms):
+            return round(n * bytes_per_sample / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None
         out = {
-            "metric": "Msamples/s IQ->bits (1 GiB complex64 2-FSK per GPU, qad materialised)",
+            "metric": "Msamples/s IQ->bits (1 GiB complex64 2-FSK per GPU, qad materialised"
+                      + (", compact outputs copied to the host)" if use_stream else ")"),
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -730,38 +784,57 @@ def main():
                        if world == 1 else f"configs[3]-style: {world} GiB complex64 2-FSK sharded sample-contiguously over {world} GPUs"
                        + (" with the 64-tap FIR (63-sample halo exchange) in front" if fir_taps is not None else ""),
                        "capture": capture,
+                       "timed_region": ("K steps through urhgpu_stream_*: IQ resident in HBM -> qad (HBM) + pulse table + bits + pauses + bit_sample_pos -> "
+                                        "compact blob -> pinned host memory; hot kernel of step i, tail of step i - 1 and D2H copy of step i - 2 overlap; "
+                                        "the region ends when the last step's copy has arrived (SURVEY 8(d) window)") if use_stream else
+                                       "K device-resident steps (outputs left in HBM)",
                        "samples_per_gpu": n, "samples_per_symbol": sps, "tolerance": tol, "noise_sigma": 0.05,
                        "outputs": "qad+ppseq+bits+pauses+bit_sample_pos" if want_qad else "ppseq+bits+pauses+bit_sample_pos",
                        "rows": counts[0], "messages": counts[1], "bits": counts[2],
                        "steps_pipelined": args.pipeline, "clock_ramp_passes_before_timing": ramp_passes,
+                       "device_only_ms_per_step": round(device_only_ms, 4),
                        "single_step_latency_ms": round(latency_ms, 4),
-                       "single_step_plus_d2h_ms": round(min(lat_d2h) * 1e3, 4) if lat_d2h else None, "d2h_bytes": d2h_bytes,
-                       "ms_per_step_with_d2h_overlapped": round(d2h_overlapped_ms, 4) if d2h_overlapped_ms else None,
-                       "pipelined_ms_per_step": round(pipelined_ms, 4) if pipelined_ms is not None else None,
+                       "single_step_plus_wide_d2h_ms": round(min(lat_d2h) * 1e3, 4) if lat_d2h else None, "wide_d2h_bytes": d2h_bytes_wide,
+                       **stream_rec,
                        "unpipelined_ms_per_step": round(alone_ms, 4) if alone_ms is not None else None,
                        "rccl_world_size": world if dist else None, "ranks": ranks_info},
             "roofline": {"bound": "hbm", "kernel": "k_demod_runs_bp", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": n * bytes_per_sample,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_sample": bytes_per_sample,
+                         "kernel_timing": "HIP events attached to the kernel's dispatch, inside the timed region (beside the previous step's tail and the copy before that)",
                          "kernel_ms_unshared": round(alone_kernel_ms, 4) if alone_kernel_ms else None,
-                         "frac_unshared": round(n * bytes_per_sample / (alone_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if alone_kernel_ms else None,
-                         "end_to_end_frac": round(e2e_frac, 4),
-                         "end_to_end_plus_d2h_frac": round(n * bytes_per_sample / min(lat_d2h) / 1e9 / HBM_PEAK_GBS, 4) if lat_d2h else None,
-                         "end_to_end_d2h_overlapped_frac": round(n * bytes_per_sample / (d2h_overlapped_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                         if d2h_overlapped_ms else None},
+                         "frac_unshared": frac_of(alone_kernel_ms),
+                         "copy_ceiling": ceiling,
+                         "copy_ceiling_gbs": ceiling["hot_kernel_shape_gbs"] if ceiling else None,
+                         "frac_of_copy_ceiling": round(achieved / ceiling["hot_kernel_shape_gbs"], 4) if ceiling else None,
+                         "end_to_end_frac": frac_of(ms_per_step),
+                         "end_to_end_device_only_frac": frac_of(device_only_ms),
+                         "end_to_end_single_capture_frac": frac_of(stream_rec.get("single_capture_incl_compact_d2h_ms"))},
         }
         if not args.no_cpu_baseline and world == 1 and not force_sharded:
             host = iq.cpu().numpy()
             rec, ref_out = cpu_reference(host, p)
             out["cpu_baseline"] = rec
-            out["parity"] = parity_record(res, ref_out, tx_bits, rec["kind"])
+            if use_stream:
+                class _Last:                                 # the host copies taken right after the timed region
+                    qad = None
+                    ppseq = staticmethod(lambda: host_copy["ppseq"])
+                    flat = staticmethod(lambda: host_copy["flat"])
+                out["parity"] = parity_record(_Last, ref_out, tx_bits, rec["kind"], got_qad=qad_host)
+            else:
+                out["parity"] = parity_record(res, ref_out, tx_bits, rec["kind"])
+            out["config"]["parity_bit_exact"] = out["parity"]["bit_exact"]
             del host, ref_out
         if not args.no_extra and world == 1 and not force_sharded:
             del iq
             pipe.ctx.join()
             torch.cuda.synchronize()
             out["extra"] = run_extras(DevicePipeline(local_rank, pipelined=False), dev, args)     # stage by stage: nothing overlapped
+            # the driver keeps `config` and `roofline`: the other configurations' verdicts and times in short form there
+            for key, ex in zip(("configs2_ook_fir", "configs4_psk_costas"), out["extra"]):
+                out["config"][key] = {"ms": ex.get("ms"), "Msamples_per_s": ex.get("value"),
+                                      "bit_exact": (ex.get("parity") or {}).get("bit_exact"), "error": ex.get("error")}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
         dist.destroy_process_group()

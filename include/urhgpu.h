@@ -221,6 +221,10 @@ typedef struct urhgpu_outputs {
      * kernel at the end of the pass -- see "compact result blob" below.  cap_blob >= urhgpu_blob_capacity(...). */
     void *blob;            /* device, 16-byte aligned */
     int64_t cap_blob;
+    /* Optional: pinned HOST memory (hipHostMalloc / torch pin_memory; device-accessible) that receives the five counts as well, stored
+     * by the kernel that finalises them -- valid once the pass has completed (an event recorded behind it).  Saves the 40-byte D2H copy
+     * a streaming consumer would otherwise queue behind every pass (a copy packet costs the tail chain about 13 us). */
+    int64_t *h_counts;
 } urhgpu_outputs;
 
 /* ---- compact result blob ---------------------------------------------------------------------------------------------------
@@ -517,6 +521,15 @@ int urhgpu_spectrogram_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, int win
  * d_image uint32 BGRA (window_size, frames) through d_colormap[n_colors]. */
 int urhgpu_bgra_lookup_dev(urhgpu_ctx *ctx, const float *d_db, int64_t frames, int window_size, const uint32_t *d_colormap,
                            int n_colors, float data_min, float data_max, uint32_t *d_image);
+
+/* Measurement hook (bench.py, SURVEY.md 8(d) "also measure an on-box copy-kernel ceiling and report both denominators"): a PURE COPY
+ * on this GPU, timed with events over `reps` launches.  shape 0: the hot kernel's access structure without its arithmetic (one
+ * workgroup of four wavefronts per 8192 samples, 16-byte non-temporal loads two rows ahead, 8-byte non-temporal stores: 8 B in + 4 B
+ * out per sample, d_in float32[2 n], d_out float32[n]); shape 1: a plain grid-stride float4 copy of n float32 values (4 B in + 4 B
+ * out per value).  n_samples a multiple of 8192.  Synchronous. */
+int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_out, int64_t n_samples, int shape, int reps, float *ms_per_copy);
+/* Synchronous device -> host copy after urhgpu_ctx_sync (for callers that hold raw device pointers, e.g. urhgpu_host_result::d_qad). */
+int urhgpu_memcpy_to_host(urhgpu_ctx *ctx, const void *d_src, void *host_dst, int64_t bytes);
 
 /* Test hook: modulation order 2 (2-FSK, OOK, message segmentation) normally runs the bit-plane kernel
  * (k_demod_runs_bp) and every other order the state-byte kernel (k_demod_runs); on != 0 routes order 2 through the

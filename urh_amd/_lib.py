@@ -44,7 +44,7 @@ class Outputs(C.Structure):
         ("msg_off", C.c_void_p), ("pauses", C.c_void_p), ("cap_msg", C.c_int64),
         ("pos", C.c_void_p), ("cap_pos", C.c_int64), ("pos_off", C.c_void_p),
         ("counts", C.c_void_p),
-        ("blob", C.c_void_p), ("cap_blob", C.c_int64),
+        ("blob", C.c_void_p), ("cap_blob", C.c_int64), ("h_counts", C.c_void_p),
     ]
 
 
@@ -139,6 +139,8 @@ PROTOTYPES = {
     "urhgpu_astype_dev": (_i, [_vp, _vp, _i, _vp, _i, _i64]),
     "urhgpu_path_minmax_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp]),
     "urhgpu_path_minmax": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _vp]),
+    "urhgpu_bench_copy_ceiling_dev": (_i, [_vp, _vp, _vp, _i64, _i, _i, C.POINTER(_f)]),
+    "urhgpu_memcpy_to_host": (_i, [_vp, _vp, _vp, _i64]),
     "urhgpu_test_force_state_bytes": (_i, [_i]),
     "urhgpu_test_force_tiles_per_chunk": (_i, [_i]),
     "urhgpu_test_force_generic_tail": (_i, [_i]),

@@ -601,7 +601,7 @@ int urhgpu_grab_pulse_lens_dev(urhgpu_ctx *ctx, const float *d_qad, int64_t n, c
 static int ppseq_to_bits_inner(urhgpu_ctx *ctx, const int64_t *d_rows, const int64_t *d_n_rows, int64_t cap,
                                const urhgpu_params *p, const urhgpu_outputs *out, void *scratch,
                                const int64_t *d_rows_needed = nullptr) {
-    BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts};
+    BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts, out->h_counts};
     BitsParams bp = bits_params(p);
     bp.d_rows_needed = d_rows_needed;
     ScanState ss;
@@ -670,7 +670,7 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
         hipStream_t caller = ctx->stream;
         if (piped) ctx->stream = ctx->tail_stream;
         if (tile.mem) {
-            BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts};
+            BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts, out->h_counts};
             ScanState ss;
             st = scan_state(ctx, tile_desc_cap(cap, pl.n_chunks), &ss);
             if (st == URHGPU_OK) st = launch_tile_bits(tile, out->rows, d_n_rows, cap, tile_bp, bo, scratch, ss, ctx->stream);
@@ -1305,6 +1305,34 @@ int urhgpu_path_minmax(urhgpu_ctx *ctx, const void *samples, int dtype, int64_t 
     URH_TRY(urhgpu_path_minmax_dev(ctx, d_in, dtype, 0, end - start, samples_per_pixel, d_val));
     URH_HIP(hipMemcpyAsync(values, d_val, (size_t)pixels * 2 * eb, hipMemcpyDeviceToHost, ctx->stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
+int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_out, int64_t n_samples, int shape, int reps, float *ms_per_copy) {
+    if (!ctx || !d_in || !d_out || !ms_per_copy || n_samples < 8192 || n_samples % 8192 || reps < 1 || (shape != 0 && shape != 1)) return URHGPU_ERR_ARG;
+    if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    hipEvent_t e0, e1;
+    URH_HIP(hipEventCreate(&e0));
+    URH_HIP(hipEventCreate(&e1));
+    for (int k = 0; k < 3; ++k) launch_copy_shape(d_in, d_out, n_samples, shape, ctx->stream);
+    URH_HIP(hipEventRecord(e0, ctx->stream));
+    for (int k = 0; k < reps; ++k) launch_copy_shape(d_in, d_out, n_samples, shape, ctx->stream);
+    URH_HIP(hipEventRecord(e1, ctx->stream));
+    URH_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    URH_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_per_copy = ms / (float)reps;
+    return URHGPU_OK;
+}
+
+int urhgpu_memcpy_to_host(urhgpu_ctx *ctx, const void *d_src, void *host_dst, int64_t bytes) {
+    if (!ctx || bytes < 0 || (bytes > 0 && (!d_src || !host_dst))) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(urhgpu_ctx_sync(ctx));
+    if (bytes) URH_HIP(hipMemcpy(host_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
     return URHGPU_OK;
 }
 

@@ -9,6 +9,15 @@
 
 #include "../../include/urhgpu.h"
 
+// Wavefronts of the tail kernels (pulse table, bits, compact blob) run beside the NEXT pass's hot kernel, seven of whose wavefronts
+// share every SIMD with them: the tail's wavefronts ask for the highest issue priority (s_setprio 3), so that their few hundred
+// instructions are not queued behind seven streaming wavefronts' -- the tail chain, not the hot kernel, set the period of
+// pipelined passes (rocprofv3 timeline, round 3).  -DURH_TAIL_PRIO_LEVEL=0: A/B.
+#ifndef URH_TAIL_PRIO_LEVEL
+#define URH_TAIL_PRIO_LEVEL 3
+#endif
+#define URH_TAIL_PRIO() __builtin_amdgcn_s_setprio(URH_TAIL_PRIO_LEVEL)
+
 namespace urh {
 
 extern thread_local char g_hip_err[256];

@@ -26,6 +26,7 @@ struct PackArgs {
 };
 
 __global__ __launch_bounds__(256) void k_pack_blob(const PackArgs a) {
+    URH_TAIL_PRIO();
     const BlobLayout L = blob_layout(a.counts, a.cap_rows, a.cap_bits, a.cap_msg, a.cap_pos, a.has_pos);
     const int64_t gtid = blockIdx.x * 256ll + threadIdx.x, stride = (int64_t)gridDim.x * 256;
     int64_t *hdr = (int64_t *)a.blob;
@@ -80,8 +81,45 @@ int launch_pack_blob(const urhgpu_outputs *o, int write_pos, hipStream_t s) {
     PackArgs a{o->rows, o->bits, o->msg_off, o->pauses, o->pos_off, o->pos, o->counts, o->cap_rows, o->cap_bits, o->cap_msg, o->cap_pos, has_pos,
                (char *)o->blob, o->cap_blob};
     // sized for a typical result (a few million elements), stride loops for the rest: the counts are only known on the device
-    hipLaunchKernelGGL(k_pack_blob, dim3(2048), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_pack_blob, dim3(512), dim3(256), 0, s, a);
     return URHGPU_OK;
+}
+
+// ---- measurement hook: what a PURE COPY with the hot kernel's access shape gets out of the HBM on this box (bench.py reports it
+// next to the 8 TB/s spec figure, SURVEY 8(d): "report both denominators") -------------------------------------------------------
+// shape 0: one workgroup of four wavefronts per 8192 samples, every wavefront streams its own 2048 samples (16 KiB in, 8 KiB out),
+//          lane = 2 consecutive samples per row (16-byte non-temporal load, 8-byte non-temporal store), loads two rows ahead -- the
+//          structure of k_demod_runs_bp without its arithmetic;  shape 1: the plain grid-stride float4 copy of the guide.
+typedef float cp_v4 __attribute__((ext_vector_type(4)));
+typedef float cp_v2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void k_copy_shape(const float *in, float *out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const float *src = in + wave * 16 * 256 + lane * 4;
+    float *dst = out + wave * 16 * 128 + lane * 2;
+    cp_v4 cur[2], nxt[2];
+    cur[0] = __builtin_nontemporal_load((const cp_v4 *)src);
+    cur[1] = __builtin_nontemporal_load((const cp_v4 *)(src + 256));
+#pragma unroll 1
+    for (int r = 0; r < 16; r += 2) {
+        if (r + 2 < 16) {
+            nxt[0] = __builtin_nontemporal_load((const cp_v4 *)(src + (int64_t)(r + 2) * 256));
+            nxt[1] = __builtin_nontemporal_load((const cp_v4 *)(src + (int64_t)(r + 3) * 256));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const cp_v2 t = {cur[j].x + cur[j].y, cur[j].z + cur[j].w};
+            __builtin_nontemporal_store(t, (cp_v2 *)(dst + (int64_t)(r + j) * 128));
+        }
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+    }
+}
+__global__ __launch_bounds__(256) void k_copy_plain(const cp_v4 *in, cp_v4 *out, int64_t n4) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) out[i] = in[i];
+}
+void launch_copy_shape(const float *in, float *out, int64_t n_samples, int shape, hipStream_t s) {
+    if (shape == 0) hipLaunchKernelGGL(k_copy_shape, dim3((unsigned)(n_samples / 8192)), dim3(256), 0, s, in, out);
+    else hipLaunchKernelGGL(k_copy_plain, dim3(256 * 20), dim3(256), 0, s, (const cp_v4 *)in, (cp_v4 *)out, n_samples / 4);
 }
 
 }  // namespace urh

@@ -174,6 +174,7 @@ struct BitsOut {
     int64_t *msg_off; int64_t *pauses; int64_t cap_msg;
     int64_t *pos; int64_t cap_pos; int64_t *pos_off;
     int64_t *counts;
+    int64_t *h_counts = nullptr;   // optional second destination of the counts: pinned HOST memory (zero-copy store), see urhgpu_outputs::h_counts
 };
 int launch_resolve(const ResolveArgs &a, int32_t *tickets, hipStream_t s);
 int launch_resolve_emit_single(const ResolveArgs &r, const EmitArgs &e, hipStream_t s);
@@ -258,6 +259,7 @@ size_t seg_ctl_bytes();
 void seg_ctl_read(const void *host_copy, int64_t *n_seg, int64_t *n_msgs, int *ambiguous);
 // ---- compact.hip --------------------------------------------------------------------------------------------------
 int launch_pack_blob(const urhgpu_outputs *o, int write_pos, hipStream_t s);
+void launch_copy_shape(const float *in, float *out, int64_t n_samples, int shape, hipStream_t s);
 // ---- costas.hip -----------------------------------------------------------------------------------------------
 size_t costas_scratch_bytes(int64_t n);
 int launch_costas(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, void *scratch);

@@ -528,13 +528,16 @@ struct BitsCountsFinal {
     int64_t *msg_off, *pos_off, *counts;
     int32_t *huge_count;
     const int64_t *d_rows_needed;      // rows the pulse table needed before clamping to cap_rows (nullptr: unknown)
+    int64_t *h_counts;                 // pinned host memory that receives the counts as well (nullptr: none)
     __device__ void operator()(const VecK<3> &grand) const {
         *huge_count = 0;
-        counts[4] = d_rows_needed ? *d_rows_needed : *d_n_rows;
+        const int64_t needed = d_rows_needed ? *d_rows_needed : *d_n_rows;
+        counts[4] = needed;
         const int64_t n_rows = *d_n_rows;
         VecK<3> g; g.zero();
         if (n_rows > 0) g = grand;
         counts[0] = n_rows; counts[1] = g.v[0]; counts[2] = g.v[1]; counts[3] = g.v[2];
+        if (h_counts) { h_counts[0] = n_rows; h_counts[1] = g.v[0]; h_counts[2] = g.v[1]; h_counts[3] = g.v[2]; h_counts[4] = needed; }
         msg_off[0] = 0; pos_off[0] = 0;
     }
 };
@@ -760,6 +763,7 @@ struct TileTail {            // scratch of the tile tail (carved from the contex
 // address does not depend on loaded data is issued BEFORE the first use of any of them (measured: the same kernels written in
 // natural order spent 9 us per wavefront in 5 serialised round trips).
 __global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs a, const TileTail ft) {
+    URH_TAIL_PRIO();
     __shared__ ResElem s_w[kResolveBlock / 64];
     const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -835,10 +839,35 @@ __device__ __forceinline__ VecK<4> row_value(int64_t type, int64_t len, bool glo
 }
 
 struct HugeRef { int64_t tile, row; };                   // a row of more than kHugeBits bits, found while the rows were emitted
-// chunks per workgroup of k_emit_rows_tiles (one wavefront each).  Four, not eight: beside the next pass's hot kernel (pipelined passes)
+// Wavefronts per workgroup of k_emit_rows_tiles / k_expand_tiles.  Four, not eight: beside the next pass's hot kernel (pipelined passes)
 // a workgroup needs one free wave slot per SIMD, which retiring hot workgroups (four wavefronts) leave; eight-wavefront workgroups were
 // starved until the hot kernel had drained (the row kernel then took that kernel's whole 290 us).
 constexpr int kEmitWaves = 4;
+// Consecutive chunks (tiles) per wavefront.  Beside a hot kernel that fills every SIMD's register file, a workgroup of the tail
+// starts only when a hot workgroup retires (rocprofv3 timeline of round 3: one chunk per wavefront = 4096 workgroups took 110 us
+// beside the hot kernel against 18 us on an idle machine -- the kernel was bound by the number of workgroups that had to find a
+// slot, not by its work).  kTailCPW chunks per wavefront: the per-chunk metadata of all of them arrives in ONE round trip (lane j holds
+// chunk j's), the records of the next chunk are requested before the current one is processed.  Measured (tools/r3_ab.sh, round 3):
+// 1 / 4 / 8 / 16 chunks per wavefront give 0.319 / 0.311 / 0.311 / 0.311 ms per pipelined step with D2H, but 0.402 / 0.402 / 0.406 /
+// 0.444 ms for ONE capture on an idle machine (fewer wavefronts = less parallelism there): four.
+#ifndef URH_TAIL_CPW
+#define URH_TAIL_CPW 4
+#endif
+constexpr int kTailCPW = URH_TAIL_CPW;
+// -DURH_TAIL_CAP80: at most 80 VGPRs (six wavefronts per SIMD) for the tail kernels that need more -- what ONE retiring hot wavefront
+// (72 + the 8 it never had) leaves free on a SIMD; costs spills (A/B knob)
+#ifdef URH_TAIL_CAP80
+#define URH_TAIL_OCC __attribute__((amdgpu_waves_per_eu(6)))
+#else
+#define URH_TAIL_OCC
+#endif
+static_assert(kResolveBlock % kTailCPW == 0 && kTailCPW <= 64, "the chunks of one wavefront share their resolve workgroup");
+
+__device__ __forceinline__ int64_t lane_bcast(int64_t v, int src) {          // src wave-uniform
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, src), hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 struct EmitTileArgs {
     EmitArgs e;
@@ -849,49 +878,44 @@ struct EmitTileArgs {
     int32_t huge_cap;
 };
 
+__host__ __device__ static inline int64_t tail_waves(int64_t n_items) { return (n_items + kTailCPW - 1) / kTailCPW; }
+
 __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitTileArgs g) {
+    URH_TAIL_PRIO();
     const EmitArgs &a = g.e;
     const ResolveArgs &r = g.r;
-    const int64_t c = (int64_t)blockIdx.x * kEmitWaves + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const bool is_chunk = c < r.n_chunks;
-    const bool idle = c > r.n_chunks;                     // wavefronts beyond the last tile only take part in the barrier
-    // ---- one round trip: everything this wavefront reads ----
-    // resolve workgroups composed on the left: the same for every chunk of this workgroup (kResolveBlock % kEmitWaves == 0) except
-    // for the totals wavefront, which takes them all.  Wavefront 0 composes them for the others (a look-back inside k_resolve_one
-    // that would hand every chunk its global prefix costs 5 us there; every wavefront composing for itself 11 us here).
-    static_assert(kResolveBlock % kEmitWaves == 0, "chunks of one emit workgroup share their resolve workgroup");
-    __shared__ ResElem s_fold;
-    const int wave = threadIdx.x >> 6;
-    const int64_t n_before = is_chunk ? c / kResolveBlock : resolve_blocks(r.n_chunks);
+    const int64_t w = (int64_t)blockIdx.x * kEmitWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n_cw = tail_waves(r.n_chunks);          // wavefronts that own chunks; wavefront n_cw: totals, last row, last tile
+    if (w > n_cw) return;
+    const bool totals = (w == n_cw);
+    const int64_t c0 = totals ? r.n_chunks : w * kTailCPW;
+    // ---- one round trip: everything this wavefront reads that does not depend on loaded data ----
+    // resolve workgroups composed on the left: the same for every chunk of this wavefront (kResolveBlock % kTailCPW == 0); the totals
+    // wavefront takes them all
+    const int64_t n_before = totals ? resolve_blocks(r.n_chunks) : c0 / kResolveBlock;
     const uint32_t init_state = a.chunks[0].init_state;
     ResElem first = res_identity();
-    const bool totals = c == r.n_chunks;
-    const bool folds = (wave == 0 && is_chunk) || totals;
-    if (folds && lane < n_before) first = g.ft.btot[lane];
-    ResElem pl = res_identity();
-    int cnt = 0, pend_stable = 0;
-    uint32_t c_first = 0, c_last = 0, c_pend = 0;
-    int64_t pend_pos = -1;
-    uint64_t rec = 0;
-    const uint64_t *slab = a.slab + c * a.slab_stride;
-    if (is_chunk) {
-        pl = g.ft.ploc[c];
-        const ChunkInfo *ch = a.chunks + c;
-        cnt = ch->cnt; pend_stable = ch->pend_stable; c_first = ch->first_state; c_last = ch->last_state; c_pend = ch->pend_state;
-        pend_pos = ch->pend_pos;
-        if (lane < a.slab_stride) rec = slab[lane];                  // speculative: the first 64 records (those beyond cnt are ignored)
+    if (lane < n_before) first = g.ft.btot[lane];
+    const int n_mine = totals ? 0 : (int)((r.n_chunks - c0 < kTailCPW) ? r.n_chunks - c0 : kTailCPW);
+    ResElem pl_l = res_identity();
+    int cnt_l = 0, fl_l = 0, pp_l = 0;                    // fl: first_state | last_state << 16 (0xFFFF = none); pp: pend_state | pend_stable << 16
+    int64_t pend_pos_l = -1;
+    if (lane < n_mine) {                                  // lane j: chunk c0 + j
+        pl_l = g.ft.ploc[c0 + lane];
+        const ChunkInfo *ch = a.chunks + c0 + lane;
+        cnt_l = ch->cnt; pend_pos_l = ch->pend_pos;
+        fl_l = (int)((uint32_t)ch->first_state | ((uint32_t)ch->last_state << 16));
+        pp_l = (int)((uint32_t)ch->pend_state | ((uint32_t)(ch->pend_stable ? 1 : 0) << 16));
     }
+    uint64_t rec = 0;
+    if (n_mine > 0 && lane < a.slab_stride) rec = (a.slab + c0 * a.slab_stride)[lane];     // speculative: the first 64 records (those beyond cnt are ignored)
     const ResElem init = res_make(init_state, -1, init_state, 0, false, -1, 0);
-    ResElem fold = res_identity();
-    if (folds) fold = res_fold_blocks(g.ft.btot, n_before, lane, first);
-    if (wave == 0 && lane == 0) s_fold = fold;          // (a totals wavefront in slot 0 has no chunk wavefronts behind it)
-    __syncthreads();
-    if (idle) return;
-    if (is_chunk) fold = s_fold;
-    const ResElem pre = res_combine(res_combine(init, fold), pl);      // state machine before this chunk (totals wavefront: at the end)
-    if (!is_chunk) {
+    const ResElem base = res_combine(init, res_fold_blocks(g.ft.btot, n_before, lane, first));   // state machine before this wavefront's resolve workgroup
+    if (totals) {
         // totals, the table's last row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487), last tile
+        const ResElem pre = base;
+        const int64_t c = r.n_chunks;
         if (lane == 0) {
             const int64_t P = pre.cnt;
             *r.d_n_acc = P;
@@ -919,60 +943,77 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
         }
         return;
     }
-    const uint32_t prev_state = pre.last_state();
-    const int first_acc = (cnt > 0) && (c_first != prev_state);
-    const uint32_t before_pend = (cnt > 0) ? c_last : prev_state;
-    const int pend_acc = pend_stable && (c_pend != before_pend);
-    const int skip = (cnt > 0 && !first_acc) ? 1 : 0;
-    const int64_t from_slab = (cnt > 0) ? cnt - skip : 0;
-    const int64_t total = from_slab + pend_acc;
-    const int64_t out_off = pre.cnt;
-    const int64_t prev_pos = pre.la_valid() ? pre.la_pos : -1;
-    const uint32_t prev_st = pre.la_valid() ? pre.la_state() : init_state;
-    // what the chunk's rows contribute to _ppseq_to_bits: bits (64-bit sum), long pauses and data rows (two 32-bit counts in one
-    // word); the samples need no sum at all -- row lengths telescope: sum = (position of the chunk's last accepted run) - prev_pos
-    int64_t acc_bits = 0;
-    uint64_t acc_ld = 0;
-    int64_t my_last_pos = 0;
-    const bool in_regs = cnt <= 64;                      // every record this chunk has is in `rec`
-    // record of row j's run (j + skip) and of the run before it, from the neighbours' registers
-    const uint64_t rec_j = skip ? (uint64_t)__shfl_down((long long)rec, 1) : rec;
-    const uint64_t rec_p = (uint64_t)__shfl_up((long long)rec_j, 1);
-    for (int64_t j = lane; j < total; j += 64) {
-        int64_t pos, ppos; uint32_t pst;
-        if (in_regs && j < 64) {
-            pos = (j < from_slab) ? rec_pos(rec_j) : pend_pos;
-            if (j == 0) { ppos = prev_pos; pst = prev_st; }
-            else { ppos = rec_pos(rec_p); pst = rec_state(rec_p); }
-        } else {
-            pos = (j < from_slab) ? rec_pos(slab[j + skip]) : pend_pos;
-            if (j == 0) { ppos = prev_pos; pst = prev_st; }
-            else { const uint64_t rr = slab[j - 1 + skip]; ppos = rec_pos(rr); pst = rec_state(rr); }
-        }
-        my_last_pos = pos;
-        const int64_t gi = out_off + j;
-        const int64_t len = (gi == 0) ? pos + 1 : pos - ppos;
-        const int64_t state = (int64_t)pst - 1;
-        if (gi < a.cap_rows) *(longlong2 *)(a.rows + 2 * gi) = longlong2{(long long)state, (long long)len};
-        if (g.ft.want_bits) {
-            const VecK<4> v = row_value(state, len, gi == 0, g.bp);
-            acc_bits += v.v[0];
-            acc_ld += (uint64_t)v.v[1] | ((uint64_t)v.v[3] << 32);
-            if (v.v[0] > kHugeBits) {
-                const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
-                if (slot < g.huge_cap) { g.huge[slot].tile = c; g.huge[slot].row = gi; }
+    for (int jc = 0; jc < n_mine; ++jc) {
+        const int64_t c = c0 + jc;
+        const uint64_t *slab = a.slab + c * a.slab_stride;
+        // the next chunk's records are on their way while this one is worked on
+        uint64_t rec_next = 0;
+        if (jc + 1 < n_mine && lane < a.slab_stride) rec_next = (slab + a.slab_stride)[lane];
+        ResElem pl;
+        pl.cnt = lane_bcast(pl_l.cnt, jc); pl.first_pos = lane_bcast(pl_l.first_pos, jc); pl.la_pos = lane_bcast(pl_l.la_pos, jc);
+        pl.meta = (uint64_t)lane_bcast((int64_t)pl_l.meta, jc);
+        const int cnt = lane_bcast(cnt_l, jc);
+        const uint32_t fl = (uint32_t)lane_bcast(fl_l, jc), pp = (uint32_t)lane_bcast(pp_l, jc);
+        const int64_t pend_pos = lane_bcast(pend_pos_l, jc);
+        const uint32_t c_first = fl & 0xFFFFu, c_last = fl >> 16, c_pend = pp & 0xFFFFu;
+        const int pend_stable = (int)(pp >> 16);
+        const ResElem pre = res_combine(base, pl);              // state machine before this chunk
+        const uint32_t prev_state = pre.last_state();
+        const int first_acc = (cnt > 0) && (c_first != prev_state);
+        const uint32_t before_pend = (cnt > 0) ? c_last : prev_state;
+        const int pend_acc = pend_stable && (c_pend != before_pend);
+        const int skip = (cnt > 0 && !first_acc) ? 1 : 0;
+        const int64_t from_slab = (cnt > 0) ? cnt - skip : 0;
+        const int64_t total = from_slab + pend_acc;
+        const int64_t out_off = pre.cnt;
+        const int64_t prev_pos = pre.la_valid() ? pre.la_pos : -1;
+        const uint32_t prev_st = pre.la_valid() ? pre.la_state() : init_state;
+        // what the chunk's rows contribute to _ppseq_to_bits: bits (64-bit sum), long pauses and data rows (two 32-bit counts in one
+        // word); the samples need no sum at all -- row lengths telescope: sum = (position of the chunk's last accepted run) - prev_pos
+        int64_t acc_bits = 0;
+        uint64_t acc_ld = 0;
+        int64_t my_last_pos = 0;
+        const bool in_regs = cnt <= 64;                      // every record this chunk has is in `rec`
+        // record of row j's run (j + skip) and of the run before it, from the neighbours' registers
+        const uint64_t rec_j = skip ? (uint64_t)__shfl_down((long long)rec, 1) : rec;
+        const uint64_t rec_p = (uint64_t)__shfl_up((long long)rec_j, 1);
+        for (int64_t j = lane; j < total; j += 64) {
+            int64_t pos, ppos; uint32_t pst;
+            if (in_regs && j < 64) {
+                pos = (j < from_slab) ? rec_pos(rec_j) : pend_pos;
+                if (j == 0) { ppos = prev_pos; pst = prev_st; }
+                else { ppos = rec_pos(rec_p); pst = rec_state(rec_p); }
+            } else {
+                pos = (j < from_slab) ? rec_pos(slab[j + skip]) : pend_pos;
+                if (j == 0) { ppos = prev_pos; pst = prev_st; }
+                else { const uint64_t rr = slab[j - 1 + skip]; ppos = rec_pos(rr); pst = rec_state(rr); }
+            }
+            my_last_pos = pos;
+            const int64_t gi = out_off + j;
+            const int64_t len = (gi == 0) ? pos + 1 : pos - ppos;
+            const int64_t state = (int64_t)pst - 1;
+            if (gi < a.cap_rows) *(longlong2 *)(a.rows + 2 * gi) = longlong2{(long long)state, (long long)len};
+            if (g.ft.want_bits) {
+                const VecK<4> v = row_value(state, len, gi == 0, g.bp);
+                acc_bits += v.v[0];
+                acc_ld += (uint64_t)v.v[1] | ((uint64_t)v.v[3] << 32);
+                if (v.v[0] > kHugeBits) {
+                    const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
+                    if (slot < g.huge_cap) { g.huge[slot].tile = c; g.huge[slot].row = gi; }
+                }
             }
         }
-    }
-    VecK<4> acc; acc.zero();
-    if (g.ft.want_bits && total > 0) {
+        VecK<4> acc; acc.zero();
+        if (g.ft.want_bits && total > 0) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { acc_bits += __shfl_xor(acc_bits, o); acc_ld += (uint64_t)__shfl_xor((long long)acc_ld, o); }
-        const int64_t last_pos = __shfl(my_last_pos, (int)((total - 1) & 63));       // the lane that wrote the chunk's last row
-        acc.v[0] = acc_bits; acc.v[1] = (int64_t)(acc_ld & 0xFFFFFFFFull); acc.v[3] = (int64_t)(acc_ld >> 32);
-        acc.v[2] = last_pos - prev_pos;                  // (prev_pos = -1 before the table's first row: its length is position + 1)
+            for (int o = 32; o > 0; o >>= 1) { acc_bits += __shfl_xor(acc_bits, o); acc_ld += (uint64_t)__shfl_xor((long long)acc_ld, o); }
+            const int64_t last_pos = __shfl(my_last_pos, (int)((total - 1) & 63));       // the lane that wrote the chunk's last row
+            acc.v[0] = acc_bits; acc.v[1] = (int64_t)(acc_ld & 0xFFFFFFFFull); acc.v[3] = (int64_t)(acc_ld >> 32);
+            acc.v[2] = last_pos - prev_pos;                  // (prev_pos = -1 before the table's first row: its length is position + 1)
+        }
+        if (lane == 0) { g.ft.agg[c] = acc; g.ft.tile_off[c] = out_off; g.ft.tile_cnt[c] = (int32_t)total; }
+        rec = rec_next;
     }
-    if (lane == 0) { g.ft.agg[c] = acc; g.ft.tile_off[c] = out_off; g.ft.tile_cnt[c] = (int32_t)total; }
 }
 
 // ---- tile scan: exclusive prefix per tile (one thread per tile, look-back across the few dozen workgroups); the tiles that hold a
@@ -992,7 +1033,8 @@ struct TileScanArgs {
     GranDesc *desc;
     unsigned long long epoch;
 };
-__global__ __launch_bounds__(kScanBlock) void k_tile_scan(const TileScanArgs a) {
+__global__ __launch_bounds__(kScanBlock) URH_TAIL_OCC void k_tile_scan(const TileScanArgs a) {
+    URH_TAIL_PRIO();
     __shared__ VecK<4> s_wave[kScanBlock / 64];
     __shared__ VecK<4> s_prefix;
     __shared__ VecK<4> s_ex[kScanBlock];                 // listed tiles: prefix, first row, end
@@ -1097,11 +1139,15 @@ struct ExpandTileArgs {
 };
 constexpr unsigned kHugeBlocksX = 16, kHugeBlocksY = 16;
 
-// one wavefront per tile; workgroups beyond the tiles expand the listed huge rows, kHugeBlocksX workgroups per row
-__global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// one wavefront per kTailCPW consecutive tiles (see kTailCPW); workgroups beyond the tiles expand the listed huge rows, kHugeBlocksX
+// workgroups per row
+__host__ __device__ static inline int64_t expand_tile_blocks(int64_t n_tiles) { return (tail_waves(n_tiles) + kEmitWaves - 1) / kEmitWaves; }
+
+__global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(const ExpandTileArgs a) {
+    URH_TAIL_PRIO();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int bps = (int)a.bp.bps;
-    const int64_t tile_blocks = (a.n_tiles + 3) / 4;
+    const int64_t tile_blocks = expand_tile_blocks(a.n_tiles);
     if ((int64_t)blockIdx.x >= tile_blocks) {
         // ---- huge rows ----
         const int64_t n = *a.d_n_rows;
@@ -1149,88 +1195,109 @@ __global__ __launch_bounds__(256) void k_expand_tiles(const ExpandTileArgs a) {
         }
         return;
     }
-    const int64_t t = (int64_t)blockIdx.x * 4 + wave;
-    if (t >= a.n_tiles) return;
-    // ---- round trip 1: everything that does not depend on loaded data ----
+    const int64_t t0 = ((int64_t)blockIdx.x * kEmitWaves + wave) * kTailCPW;
+    if (t0 >= a.n_tiles) return;
+    const int n_mine = (int)((a.n_tiles - t0 < kTailCPW) ? a.n_tiles - t0 : kTailCPW);
+    // ---- round trip 1: everything that does not depend on loaded data; lane j holds the metadata of tile t0 + j ----
     const int64_t n = *a.d_n_rows;
     const int64_t n_groups = *a.d_n_groups;
     const int hc = a.huge_count[a.parity];
-    const int64_t off = a.tile_off[t];
-    const int32_t tcnt = a.tile_cnt[t];
-    VecK<4> run = a.excl[t];
-    int64_t end = off + tcnt;
-    if (end > n) end = n;
-    if (end <= off) return;
+    int64_t off_l = 0; int32_t tcnt_l = 0;
+    VecK<4> run_l; run_l.zero();
+    if (lane < n_mine) { off_l = a.tile_off[t0 + lane]; tcnt_l = a.tile_cnt[t0 + lane]; run_l = a.excl[t0 + lane]; }
     const int64_t own_limit = (hc > a.huge_cap) ? INT64_MAX : kHugeBits;   // longer rows are on the list
-    // ---- round trip 2: the rows, and the group the tile starts in (nearly every row of the tile belongs to it) ----
-    const int64_t g0 = run.v[1];
-    GroupOut go0; go0.bits_start = 0; go0.out_bits = 0; go0.out_pos = 0; go0.is_msg = 0; go0.pad = 0;
+    // ---- round trip 2: the group every tile starts in (nearly every row of a tile belongs to it), and the first tile's rows ----
+    GroupOut go_l; go_l.bits_start = 0; go_l.out_bits = 0; go_l.out_pos = 0; go_l.is_msg = 0; go_l.pad = 0;
+    if (lane < n_mine && run_l.v[1] < n_groups) go_l = a.gout[run_l.v[1]];
+    const int64_t off_first = lane_bcast(off_l, 0);
+    int64_t end_first = off_first + lane_bcast((int)tcnt_l, 0);
+    if (end_first > n) end_first = n;
     longlong2 row0 = longlong2{0, 0};
-    if (off + lane < end) row0 = *(const longlong2 *)(a.rows + 2 * (off + lane));
-    if (g0 < n_groups) go0 = a.gout[g0];
-    for (int64_t i0 = off; i0 < end; i0 += 64) {
-        const int64_t i = i0 + lane;
-        VecK<4> v; v.zero();
-        int64_t type = 0;
-        if (i < end) {
-            const longlong2 row = (i0 == off) ? row0 : *(const longlong2 *)(a.rows + 2 * i);
-            type = row.x;
-            v = row_value(type, row.y, i == 0, a.bp);
+    if (off_first + lane < end_first) row0 = *(const longlong2 *)(a.rows + 2 * (off_first + lane));
+    for (int jt = 0; jt < n_mine; ++jt) {
+        const int64_t off = lane_bcast(off_l, jt);
+        const int32_t tcnt = lane_bcast((int)tcnt_l, jt);
+        VecK<4> run;
+        run.v[0] = lane_bcast(run_l.v[0], jt); run.v[1] = lane_bcast(run_l.v[1], jt); run.v[2] = lane_bcast(run_l.v[2], jt); run.v[3] = 0;
+        GroupOut go0;
+        go0.bits_start = lane_bcast(go_l.bits_start, jt); go0.out_bits = lane_bcast(go_l.out_bits, jt); go0.out_pos = lane_bcast(go_l.out_pos, jt);
+        go0.is_msg = lane_bcast((int)go_l.is_msg, jt); go0.pad = 0;
+        int64_t end = off + tcnt;
+        if (end > n) end = n;
+        // the next tile's first 64 rows are on their way while this tile is expanded
+        longlong2 row_next = longlong2{0, 0};
+        if (jt + 1 < n_mine) {
+            const int64_t off_n = lane_bcast(off_l, jt + 1);
+            int64_t end_n = off_n + lane_bcast((int)tcnt_l, jt + 1);
+            if (end_n > n) end_n = n;
+            if (off_n + lane < end_n) row_next = *(const longlong2 *)(a.rows + 2 * (off_n + lane));
         }
-        // inclusive wave scans of what the expansion needs: bits and samples (64-bit), long pauses (32-bit: a tile has few rows)
-        int64_t in_bits = v.v[0], in_ts = v.v[2];
-        int in_l = (int)v.v[1];
+        const int64_t g0 = run.v[1];
+        for (int64_t i0 = off; i0 < end; i0 += 64) {
+            const int64_t i = i0 + lane;
+            VecK<4> v; v.zero();
+            int64_t type = 0;
+            if (i < end) {
+                const longlong2 row = (i0 == off) ? row0 : *(const longlong2 *)(a.rows + 2 * i);
+                type = row.x;
+                v = row_value(type, row.y, i == 0, a.bp);
+            }
+            // inclusive wave scans of what the expansion needs: bits and samples (64-bit), long pauses (32-bit: a tile has few rows)
+            int64_t in_bits = v.v[0], in_ts = v.v[2];
+            int in_l = (int)v.v[1];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int64_t ub = __shfl_up(in_bits, o), ut = __shfl_up(in_ts, o);
-            const int ul = __shfl_up(in_l, o);
-            if (lane >= o) { in_bits += ub; in_ts += ut; in_l += ul; }
-        }
-        int64_t kb = 0, ob = 0, op = 0, ts = 0;
-        if (i < end && v.v[0] > 0 && v.v[0] <= own_limit) {
-            const int64_t grp = run.v[1] + in_l - v.v[1];
-            if (grp < n_groups) {
-                GroupOut go = go0;
-                if (grp != g0) go = a.gout[grp];
-                if (go.is_msg) {
-                    const int64_t bit_prefix = run.v[0] + in_bits - v.v[0];
-                    kb = v.v[0];
-                    ob = go.out_bits + (bit_prefix - go.bits_start);
-                    op = go.out_pos + (bit_prefix - go.bits_start);
-                    ts = run.v[2] + in_ts - v.v[2];
+            for (int o = 1; o < 64; o <<= 1) {
+                const int64_t ub = __shfl_up(in_bits, o), ut = __shfl_up(in_ts, o);
+                const int ul = __shfl_up(in_l, o);
+                if (lane >= o) { in_bits += ub; in_ts += ut; in_l += ul; }
+            }
+            int64_t kb = 0, ob = 0, op = 0, ts = 0;
+            if (i < end && v.v[0] > 0 && v.v[0] <= own_limit) {
+                const int64_t grp = run.v[1] + in_l - v.v[1];
+                if (grp < n_groups) {
+                    GroupOut go = go0;
+                    if (grp != g0) go = a.gout[grp];
+                    if (go.is_msg) {
+                        const int64_t bit_prefix = run.v[0] + in_bits - v.v[0];
+                        kb = v.v[0];
+                        ob = go.out_bits + (bit_prefix - go.bits_start);
+                        op = go.out_pos + (bit_prefix - go.bits_start);
+                        ts = run.v[2] + in_ts - v.v[2];
+                    }
                 }
             }
-        }
-        constexpr int kShort = 16;
-        if (kb > 0 && kb <= kShort) {
-            // a few bits per row (the common case): capacity checks hoisted out of the loop, positions by repeated addition
-            const int nb = (ob + kb <= a.cap_bits) ? (int)kb : (int)((a.cap_bits > ob) ? a.cap_bits - ob : 0);
-            const int np = !a.bp.write_pos ? 0 : ((op + kb <= a.cap_pos) ? (int)kb : (int)((a.cap_pos > op) ? a.cap_pos - op : 0));
-            uint8_t *bp8 = a.bits + ob;
-            int64_t *pp = a.pos + op;
-            int64_t tsk = ts;
-            int sh = bps - 1;
-            for (int k = 0; k < (int)kb; ++k) {
-                const uint8_t b = (type < 0) ? 0 : (uint8_t)((type >> sh) & 1);
-                sh = (sh == 0) ? bps - 1 : sh - 1;
-                if (k < nb) bp8[k] = b;
-                if (k < np) pp[k] = tsk;
-                tsk += a.bp.samples_per_bit;
+            constexpr int kShort = 16;
+            if (kb > 0 && kb <= kShort) {
+                // a few bits per row (the common case): capacity checks hoisted out of the loop, positions by repeated addition
+                const int nb = (ob + kb <= a.cap_bits) ? (int)kb : (int)((a.cap_bits > ob) ? a.cap_bits - ob : 0);
+                const int np = !a.bp.write_pos ? 0 : ((op + kb <= a.cap_pos) ? (int)kb : (int)((a.cap_pos > op) ? a.cap_pos - op : 0));
+                uint8_t *bp8 = a.bits + ob;
+                int64_t *pp = a.pos + op;
+                int64_t tsk = ts;
+                int sh = bps - 1;
+                for (int k = 0; k < (int)kb; ++k) {
+                    const uint8_t b = (type < 0) ? 0 : (uint8_t)((type >> sh) & 1);
+                    sh = (sh == 0) ? bps - 1 : sh - 1;
+                    if (k < nb) bp8[k] = b;
+                    if (k < np) pp[k] = tsk;
+                    tsk += a.bp.samples_per_bit;
+                }
             }
-        }
-        unsigned long long big = __ballot(kb > kShort);
-        while (big) {
-            const int src = __builtin_ctzll(big);
-            big &= big - 1;
-            const int64_t kb_s = __shfl(kb, src), ob_s = __shfl(ob, src), op_s = __shfl(op, src), ts_s = __shfl(ts, src),
-                          ty_s = __shfl(type, src);
-            for (int64_t k = lane; k < kb_s; k += 64) {
-                const uint8_t b = symbol_bit(ty_s, k, bps);
-                if (ob_s + k < a.cap_bits) a.bits[ob_s + k] = b;
-                if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
+            unsigned long long big = __ballot(kb > kShort);
+            while (big) {
+                const int src = __builtin_ctzll(big);
+                big &= big - 1;
+                const int64_t kb_s = __shfl(kb, src), ob_s = __shfl(ob, src), op_s = __shfl(op, src), ts_s = __shfl(ts, src),
+                              ty_s = __shfl(type, src);
+                for (int64_t k = lane; k < kb_s; k += 64) {
+                    const uint8_t b = symbol_bit(ty_s, k, bps);
+                    if (ob_s + k < a.cap_bits) a.bits[ob_s + k] = b;
+                    if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
+                }
             }
+            run.v[0] += lane_bcast(in_bits, 63); run.v[1] += lane_bcast(in_l, 63); run.v[2] += lane_bcast(in_ts, 63);     // wave-uniform: scalar registers
         }
-        run.v[0] += __shfl(in_bits, 63); run.v[1] += __shfl(in_l, 63); run.v[2] += __shfl(in_ts, 63);
+        row0 = row_next;
     }
 }
 
@@ -1380,7 +1447,7 @@ int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap
     ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(b.nb + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
-    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};
+    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed, o.h_counts};
     // the groups (usually a handful: one workgroup) go through the single-pass look-back scan: one launch instead of two
     hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
@@ -1447,7 +1514,7 @@ int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem 
     if (bp) { g.bp = *bp; g.ft.want_bits = 1; }
     const unsigned gb = (unsigned)resolve_blocks(r.n_chunks);
     hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft);
-    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((r.n_chunks + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
+    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((tail_waves(r.n_chunks) + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
     return URHGPU_OK;
 }
 
@@ -1469,13 +1536,13 @@ int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d
     hipLaunchKernelGGL(k_tile_scan, dim3(nb_ts), dim3(kScanBlock), 0, s, ta);
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
-    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed};
+    BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed, o.h_counts};
     hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, b.d_n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
                       bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt};
-    const unsigned tile_blocks = (unsigned)((nt + 3) / 4);
-    hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(256), 0, s, ea);
+    const unsigned tile_blocks = (unsigned)expand_tile_blocks(nt);
+    hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     return URHGPU_OK;
 }
 

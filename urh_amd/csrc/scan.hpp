@@ -285,6 +285,7 @@ template <int K, class Load, class Store, class Final, int ITEMS = kScanItems>
 __global__ __launch_bounds__(kScanBlock) __attribute__((amdgpu_waves_per_eu(6))) void k_scan_lookback(const int64_t *d_n, Load load, ScanDesc<K> *desc, int64_t nblocks_max,
                                                                Store store, Final fin, unsigned long long epoch, int32_t *ticket,
                                                                int elect) {
+    URH_TAIL_PRIO();
     __shared__ VecK<K> s_wave[kScanBlock / 64];
     __shared__ VecK<K> s_prefix;
     const int64_t n = *d_n;

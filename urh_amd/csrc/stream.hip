@@ -3,7 +3,7 @@
 // SURVEY §8(d)'s window for the IQ -> bits path is "IQ resident in HBM ... compact outputs on the host".  One capture at a time that is
 // hot kernel + tail + copy, strictly one after the other (0.44 + 0.4 ms per GiB in round 2).  A consumer that processes capture
 // after capture -- the reference's own live mode is one (ProtocolSniffer.py:161-202) -- lets three things overlap:
-//     hot kernel of pass i      | tail of pass i - 1 (second stream, urhgpu_ctx_set_pipelined) | D2H of pass i - 2 (copy engine)
+//     hot kernel of pass i      | tail of pass i - 1 (second stream, urhgpu_ctx_set_pipelined) | pack + D2H of pass i - 2 (third stream)
 // Three output slots rotate; the compact blob (compact.hip) makes the copy ONE hipMemcpyAsync of 9 MB per GiB (3.5 MB without
 // bit_sample_pos) into pinned memory, which hides under the 0.29 ms hot kernel.  The host blocks only on the tail of the pass before
 // last -- finished by the time the hot kernel before this one ends --, so the GPU always has the next hot kernel queued.
@@ -67,6 +67,11 @@ int issue_copy(urhgpu_stream *st, urhgpu_stream::Slot &s) {
     URH_HIP(hipEventSynchronize(s.ev_tail));
     const BlobLayout L = blob_layout(s.h_counts, st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
     if (L.total > st->cap_blob) return URHGPU_ERR_CAPACITY;
+    // the blob is packed HERE, on the copy stream, not at the end of the pass's tail: the tail chain of a pass (five dependent kernels
+    // that share the machine with the next hot kernel) is what bounds the rate of pipelined passes, and the pack kernel would
+    // lengthen it; on the copy stream it runs beside the tail of the next pass instead
+    URH_TRY(launch_pack_blob(&s.out, st->want_pos, st->copy_stream));
+    URH_HIP(hipGetLastError());
     URH_HIP(hipMemcpyAsync(s.h_blob, s.out.blob, (size_t)L.total, hipMemcpyDeviceToHost, st->copy_stream));
     URH_HIP(hipEventRecord(s.ev_copy, st->copy_stream));
     s.state = 2;
@@ -184,8 +189,12 @@ int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_ho
     // ...and nothing of this pass may be written into the slot's device buffers before that copy has read them
     if (s.state == 3) URH_HIP(hipStreamWaitEvent(ctx->tail_stream, s.ev_copy, 0));
     s.state = 0;
-    URH_TRY(urhgpu_iq_to_bits_dev(ctx, d_iq, n, &st->p, &s.out));
-    URH_HIP(hipMemcpyAsync(s.h_counts, s.out.counts, 40, hipMemcpyDeviceToHost, ctx->tail_stream));
+    {
+        urhgpu_outputs pass_out = s.out;
+        pass_out.blob = nullptr; pass_out.cap_blob = 0;    // packed later, on the copy stream (issue_copy)
+        pass_out.h_counts = s.h_counts;                    // the counts land in pinned host memory by a store of the kernel that finalises them
+        URH_TRY(urhgpu_iq_to_bits_dev(ctx, d_iq, n, &st->p, &pass_out));
+    }
     URH_HIP(hipEventRecord(s.ev_tail, ctx->tail_stream));
     s.state = 1; s.seq = i; s.n = n;
     st->seq = i + 1;

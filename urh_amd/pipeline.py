@@ -268,7 +268,9 @@ class DevicePipeline:
         self._bufs = {}
         self.tail_stream = None
         if pipelined:
-            self.tail_stream = torch.cuda.Stream(self.device)
+            import os
+            # URH_TAIL_STREAM_PRIORITY=-1: the tail's stream at the device's high priority (experiment knob; default: same priority)
+            self.tail_stream = torch.cuda.Stream(self.device, priority=int(os.environ.get("URH_TAIL_STREAM_PRIORITY", "0")))
             self.ctx.set_pipelined(True, self.tail_stream.cuda_stream)
 
     def tail_context(self):
