@@ -168,15 +168,17 @@ def test_oracle_estimators_vs_reference_python(oracle):
 
 
 def test_config1_reference_plumbing_cpu():
-    """BASELINE.json configs[0]: the reference's own tests/test_demodulations.py on the compiled Cython
-    path, CPU only -- the same driver tests/test_reference_dropin.py runs on the GPU box with liburhgpu.so patched in."""
+    """BASELINE.json configs[0]: the reference's own headless hot-path tests (tests/test_demodulations.py with the
+    tests/data FSK capture first of all) on the compiled Cython path, CPU only -- the same driver tests/test_reference_dropin.py runs
+    on the GPU box with liburhgpu.so bound underneath."""
     import json
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_driver.py"), "--no-patch"], capture_output=True, text=True,
-                       timeout=600)
+                       timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     if out.get("unavailable"):
         pytest.skip("oracle/_ref not built")
-    assert out["ran"] == 7 and out["failures"] == 0 and out["errors"] == 0, out["details"]
-    assert out["calls"]["afp_demod"] >= 8 and out["calls"]["grab_pulse_lens"] >= 8
+    assert out["per_module"]["tests.test_demodulations"]["ran"] == 7
+    assert out["ran"] == 75 and out["failures"] == 0 and out["errors"] == 0, out["details"]
+    assert out["calls"]["signal_functions.afp_demod"] >= 8 and out["calls"]["signal_functions.grab_pulse_lens"] >= 8
