@@ -298,18 +298,25 @@ def extra_config3(pipe, dev, args):
     (filt, noise), t_fir_noise = _timed(torch, lambda: estimators.fir_filter_detect_noise_dev(pipe, iq, d_taps))
     fused_equal = bool(torch.equal(filt, filt_u) and float(noise) == float(noise_u))
     del filt_u
-    est, t_est = _timed(torch, lambda: estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK"))
+    keep = {}
+    est, t_est = _timed(torch, lambda: estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK", keep=keep))
     est_stages = {}
     estimators.estimate_dev(pipe, filt, noise=noise, modulation="OOK", timings=est_stages)
     center = float(est["center"]) if est else 0.0
     p = DemodParams("ASK", 1, float(noise), center, 1.0, 5, 100, 0.1, 8, True)
-    res, t_bits = _timed(torch, lambda: pipe.iq_to_bits_checked(filt, p, want_qad=True))
+    # estimate has demodulated the capture with the parameters the Signal now has (afp_demod(iq, noise, "ASK", 2)): that IS Signal.qad
+    # (Signal.py:421-431 caches it; urh_amd.signal.Signal.auto_detect keeps it) -- the bits are sliced from it, 4 B per sample
+    qad_kept = keep["qad"]
+    res, t_bits = _timed(torch, lambda: pipe.qad_to_bits(qad_kept, p))
+    res_fused, t_bits_fused = _timed(torch, lambda: pipe.iq_to_bits_checked(filt, p, want_qad=True))     # for comparison: demodulating again
     total_ms = t_fir_noise + t_est + t_bits
     rec = {"workload": "configs[2]: 1 GiB OOK (Manchester, 124 messages) + 64-tap complex FIR + auto noise threshold + estimate + bits",
            "samples": n, "ms": round(total_ms, 3),
            "timing": "every stage: median of 5 wall times (GPU drained before and after) following 30 ms of repeats of the same stage (clock ramp)",
            "stages_ms": {"fir_filter_with_fused_noise_statistics": round(t_fir_noise, 3), "estimate": round(t_est, 3),
-                         "iq_to_bits_ask": round(t_bits, 3)},
+                         "bits_from_the_qad_estimate_left": round(t_bits, 3)},
+           "for_comparison_ms": {"iq_to_bits_ask_demodulating_again": round(t_bits_fused, 3),
+                                 "same_outputs": bool(res_fused.host_counts()[:4] == res.host_counts()[:4])},
            "unfused_ms": {"fir_filter": round(t_fir, 3), "detect_noise_level": round(t_noise, 3), "fused_result_equal": fused_equal},
            "estimate_stages_ms": est_stages,
            "estimated": {k: (float(v) if not isinstance(v, str) else v) for k, v in (est or {}).items()},

@@ -524,11 +524,12 @@ def bit_lengths_batched(all_plateaus):
     return _bit_lengths_raw(lens, off, lambda m: all_plateaus[m])
 
 
-def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings: dict = None):
+def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings: dict = None, keep: dict = None):
     """AutoInterpretation.estimate (AutoInterpretation.py:373-470) for a float32 capture resident on the GPU: noise threshold,
     message ranges (segmentation + OOK merge on the device), modulation vote over the first 100 messages (device), demodulation, then
     three batched calls over ALL messages -- center statistics with peak picking, plateau boundaries, bit-length decisions -- and the
-    vote over the messages.  Per capture the host sees a few numbers per message."""
+    vote over the messages.  Per capture the host sees a few numbers per message.  keep (a dict): receives the demodulated signal
+    (device tensor) and the parameters it was demodulated with, so that the caller can slice it instead of demodulating again."""
     from .pipeline import DemodParams
     import time
     torch = pipe.torch
@@ -571,6 +572,8 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
         raise ValueError("Unsupported Modulation")
     lap("modulation_and_merge_ms")
     data = pipe.afp_demod(iq, DemodParams(mod, 1, float(noise)))
+    if keep is not None:                             # the demodulated signal and what it was demodulated with: the caller's Signal.qad cache
+        keep.update(qad=data, mod=mod, noise=float(noise))
     lap("afp_demod_ms")
     all_centers = centers_batched(pipe, data, message_indices)
     lap("centers_ms")

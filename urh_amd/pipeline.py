@@ -356,6 +356,48 @@ class DevicePipeline:
             res.check_capacity()
         return res
 
+    def qad_to_bits(self, qad, p: DemodParams, cap_rows=None, slot=0) -> BitsResult:
+        """grab_pulse_lens + _ppseq_to_bits on an already demodulated signal (float32 (N,) on this device) -- what the reference does
+        whenever only slicing parameters changed, and after AutoInterpretation.estimate has demodulated the capture (Signal.qad is
+        cached, Signal.py:421-431): 4 B per sample read instead of the IQ stream again.  Outputs as iq_to_bits (qad = the input)."""
+        torch = self.torch
+        if qad.dtype != torch.float32 or qad.dim() != 1 or not qad.is_contiguous():
+            raise ValueError("Buffer dtype mismatch, expected 'float' (grab_pulse_lens takes float[::1])")
+        n = int(qad.shape[0])
+        cp = p.to_c(np.float32)
+        if cap_rows is None:
+            cap_rows = n // (p.tolerance + 1) + 2            # exact bound: one pass, no retry (the table is sliced from a resident signal)
+        cap_rows, cap_bits, cap_msg, cap_pos = self.capacities(n, p, cap_rows)
+        sfx = f"q{slot}:"
+        rows = self._buf(sfx + "rows", (cap_rows, 2), torch.int64)
+        n_rows = self._buf(sfx + "n_rows", (1,), torch.int64)
+        bits = self._buf(sfx + "bits", (cap_bits,), torch.uint8)
+        msg_off = self._buf(sfx + "msg_off", (cap_msg + 1,), torch.int64)
+        pauses = self._buf(sfx + "pauses", (cap_msg,), torch.int64)
+        pos_off = self._buf(sfx + "pos_off", (cap_msg + 1,), torch.int64)
+        pos = self._buf(sfx + "pos", (cap_pos,), torch.int64) if p.write_bit_sample_pos else None
+        counts = self._buf(sfx + "counts", (5,), torch.int64)
+        lib = _lib.load()
+        self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        if n == 0:
+            counts.zero_()
+            msg_off[:1] = 0
+            pos_off[:1] = 0
+            return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, None)
+        _lib.check(lib.urhgpu_grab_pulse_lens_dev(self.ctx.handle, C.c_void_p(qad.data_ptr()), n, C.byref(cp), C.c_void_p(rows.data_ptr()), cap_rows,
+                                                  C.c_void_p(n_rows.data_ptr())))
+        o = _lib.Outputs()
+        o.qad = None
+        o.rows = rows.data_ptr(); o.cap_rows = cap_rows
+        o.bits = bits.data_ptr(); o.cap_bits = cap_bits
+        o.msg_off = msg_off.data_ptr(); o.pauses = pauses.data_ptr(); o.cap_msg = cap_msg
+        o.pos = pos.data_ptr() if pos is not None else None
+        o.cap_pos = cap_pos if pos is not None else 0
+        o.pos_off = pos_off.data_ptr(); o.counts = counts.data_ptr()
+        _lib.check(lib.urhgpu_ppseq_to_bits_dev(self.ctx.handle, C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr()), cap_rows, C.byref(cp),
+                                                C.byref(o)))
+        return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, None)
+
     def afp_demod(self, iq, p: DemodParams):
         torch = self.torch
         if iq.dtype == torch.complex64:

@@ -215,47 +215,15 @@ class Signal:
         if n == 0:
             z = np.zeros(0, np.int64)
             return (np.zeros((0, 2), np.int64), np.zeros(0, np.uint8), np.zeros(1, np.int64), z, z, np.zeros(1, np.int64))
-        rows, n_rows, bits, msg_off, pauses, pos, pos_off, counts, (cap_msg, cap_bits, cap_pos) = self._digitize_dev(q, p)
-        c = counts.cpu().numpy()
-        nr = int(n_rows.cpu().numpy()[0])
-        n_msg, n_bits, n_pos = int(c[1]), int(c[2]), int(c[3])
-        if n_msg > cap_msg or n_bits > cap_bits or n_pos > cap_pos:
-            raise _lib.UrhGpuError(_lib.ERR_CAPACITY, "output capacity too small")
-        out = (rows[:nr].cpu().numpy(), bits[:n_bits].cpu().numpy(), msg_off[:n_msg + 1].cpu().numpy(), pauses[:n_msg].cpu().numpy(),
-               pos[:n_pos].cpu().numpy(), pos_off[:n_msg + 1].cpu().numpy())
+        res = self._digitize_dev(q, p)
+        out = (res.ppseq().copy(),) + tuple(x.copy() for x in res.flat())
         self._bits, self._bits_key = out, self._slice_key()
         return out
 
     def _digitize_dev(self, q, p):
         """The device part of _digitize: grab_pulse_lens + _ppseq_to_bits on the cached qad, outputs left in the pipeline's buffers
-        (no host synchronisation): (rows, n_rows, bits, msg_off, pauses, pos, pos_off, counts, (cap_msg, cap_bits, cap_pos))."""
-        import ctypes as C
-        torch = self.pipe.torch
-        n = int(q.shape[0])
-        pipe = self.pipe
-        cp = p.to_c(np.float32)
-        cap_rows = n // (p.tolerance + 1) + 2
-        cap_rows, cap_bits, cap_msg, cap_pos = pipe.capacities(n, p, cap_rows)
-        rows = pipe._buf("sig:rows", (cap_rows, 2), torch.int64)
-        n_rows = pipe._buf("sig:n_rows", (1,), torch.int64)
-        pipe.ctx.set_stream(torch.cuda.current_stream(pipe.device).cuda_stream)
-        _lib.check(_lib.load().urhgpu_grab_pulse_lens_dev(pipe.ctx.handle, C.c_void_p(q.data_ptr()), n, C.byref(cp),
-                                                          C.c_void_p(rows.data_ptr()), cap_rows, C.c_void_p(n_rows.data_ptr())))
-        o = _lib.Outputs()
-        bits = pipe._buf("sig:bits", (cap_bits,), torch.uint8)
-        msg_off = pipe._buf("sig:msg_off", (cap_msg + 1,), torch.int64)
-        pauses = pipe._buf("sig:pauses", (cap_msg,), torch.int64)
-        pos_off = pipe._buf("sig:pos_off", (cap_msg + 1,), torch.int64)
-        pos = pipe._buf("sig:pos", (cap_pos,), torch.int64)
-        counts = pipe._buf("sig:counts", (5,), torch.int64)
-        o.qad = None
-        o.rows = rows.data_ptr(); o.cap_rows = cap_rows
-        o.bits = bits.data_ptr(); o.cap_bits = cap_bits
-        o.msg_off = msg_off.data_ptr(); o.pauses = pauses.data_ptr(); o.cap_msg = cap_msg
-        o.pos = pos.data_ptr(); o.cap_pos = cap_pos; o.pos_off = pos_off.data_ptr(); o.counts = counts.data_ptr()
-        _lib.check(_lib.load().urhgpu_ppseq_to_bits_dev(pipe.ctx.handle, C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr()),
-                                                        cap_rows, C.byref(cp), C.byref(o)))
-        return rows, n_rows, bits, msg_off, pauses, pos, pos_off, counts, (cap_msg, cap_bits, cap_pos)
+        (no host synchronisation): a BitsResult."""
+        return self.pipe.qad_to_bits(q, p, slot=7)
 
     def ppseq(self) -> np.ndarray:
         """signal_functions.grab_pulse_lens(signal.qad, center, tolerance, modulation_type, samples_per_symbol, bits_per_symbol,
@@ -286,7 +254,8 @@ class Signal:
         from .estimators import estimate_dev
         modulation = None if detect_modulation else ("OOK" if self.bits_per_symbol == 1 and self.modulation_type == "ASK"
                                                      else self.modulation_type)
-        est = estimate_dev(self.pipe, self._iq, noise=None if detect_noise else self.noise_threshold, modulation=modulation)
+        keep = {}
+        est = estimate_dev(self.pipe, self._iq, noise=None if detect_noise else self.noise_threshold, modulation=modulation, keep=keep)
         if est is None:
             return False
         if detect_noise:
@@ -296,6 +265,14 @@ class Signal:
         self.center = est["center"]
         self.tolerance = est["tolerance"]
         self.samples_per_symbol = est["bit_length"]
+        # estimate demodulated the capture with afp_demod(iq, noise, mod, 2) (AutoInterpretation.py:397-402): when that is what
+        # Signal.qad would compute for the parameters just applied, it IS the cache (the reference demodulates once more here)
+        q = keep.get("qad")
+        if q is not None and self._qad is None and not self.already_demodulated and int(q.shape[0]) == self.num_samples and \
+                keep["mod"] == self.modulation_type and self.bits_per_symbol == 1 and \
+                np.float32(keep["noise"]) == np.float32(self.noise_threshold) and self.noise_threshold < self.max_magnitude and \
+                (keep["mod"] != "PSK" or np.float32(self.costas_loop_bandwidth) == np.float32(0.1)) and self.num_samples > 2:
+            self._qad = q
         return True
 
     # ---- edits ------------------------------------------------------------------------------------------------------------
