@@ -82,6 +82,23 @@ def copy_ceiling(torch, pipe, iq, n):
     return rec
 
 
+def tuning_from_env():
+    """Developer A/B knobs (tools/*.sh): the environment is read HERE, the library itself reads none (urhgpu_ctx_set_tuning).
+    Returns (tuning dict for DevicePipeline, torch priority of the tail's stream)."""
+    t = {}
+    e = os.environ
+    if "URH_HOT_LDS_KB" in e:
+        t["hot_lds_kb"] = t["hot_lds_kb_sharded"] = int(e["URH_HOT_LDS_KB"])
+    if "URH_HOT_STOP_EVENT" in e:
+        t["hot_stop_event"] = int(e["URH_HOT_STOP_EVENT"])
+    if e.get("URH_ARENA_WAIT") == "stream":
+        t["arena_wait_stream"] = 1
+    if "URH_PROFILE_BRACKET" in e:
+        t["profile_bracket"] = 1
+    prio = int(e.get("URH_TAIL_STREAM_PRIORITY", "-1" if e.get("URH_TAIL_PRIORITY") else "0"))
+    return t, prio
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -520,6 +537,7 @@ def main():
     ap.add_argument("--torch-capture", action="store_true", help="round-1 capture (torch RNG, clean fp64 phase ramp) instead of the §8(d) bytes")
     ap.add_argument("--no-reference-loop", action="store_true", help="skip the un-pipelined reference steps after the timed region (profiling runs)")
     ap.add_argument("--no-d2h", action="store_true", help="skip the D2H-inclusive measurements (profiling runs: their passes overlap copies)")
+    ap.add_argument("--no-device-loop", action="store_true", help="profiling runs: only the capture-stream loop (no run without positions, no device-only loop)")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[2] and configs[4] at full size (they add about a minute)")
     ap.add_argument("--fir-halo", action="store_true", help="N > 1: prepend the 64-tap FIR with halo exchange (configs[3] 'FIR-halo' variant)")
     ap.add_argument("--pipeline", action="store_true",
@@ -575,15 +593,16 @@ def main():
         capture = "SURVEY 8(d) config 2 bytes: modulate_c segments (default_rng(1234+k) bits) + default_rng(5678+k) AWGN 0.05"
     n = iq.shape[0]
     fir_taps = None
+    tuning, tail_prio = tuning_from_env()
     if sharded:
         from urh_amd.shard_engine import GpuShardEngine
         from urh_amd.sharding import ShardedPipeline, TorchDistComm
-        pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=args.pipeline), TorchDistComm())
+        pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=args.pipeline, tuning=tuning, tail_stream_priority=tail_prio), TorchDistComm())
         if args.fir_halo:
             from urh_amd.synth import spec_fir_taps
             fir_taps = torch.from_numpy(spec_fir_taps().view("float32").reshape(-1, 2).copy()).to(dev)     # (64, 2): 64 complex taps
     else:
-        pipe = DevicePipeline(local_rank, pipelined=args.pipeline)
+        pipe = DevicePipeline(local_rank, pipelined=args.pipeline, tuning=tuning, tail_stream_priority=tail_prio)
     pipe.reserve(n, p)
     want_qad = not args.bits_only
 
@@ -678,9 +697,25 @@ def main():
         torch.cuda.synchronize()
         headline_dt = time.perf_counter() - t0
         kernel_ms = pipe.ctx.profile_end()
+        # where the host's time goes in such a loop (a second, untimed run of the same K steps): inside push() -- which blocks until the
+        # tail of the pass before last has finished -- and between two pushes (Python: wrapping the result)
+        t_in, t_out, t_prev = [], [], None
+        for _ in range(args.steps):
+            ta = time.perf_counter()
+            if t_prev is not None:
+                t_out.append(ta - t_prev)
+            st.push(iq)
+            t_prev = time.perf_counter()
+            t_in.append(t_prev - ta)
+        st.flush()
+        torch.cuda.synchronize()
+        t_in.sort(); t_out.sort()
+        host_rec = {"push_us_median": round(t_in[len(t_in) // 2] * 1e6, 1), "push_us_min": round(t_in[0] * 1e6, 1),
+                    "between_pushes_us_median": round(t_out[len(t_out) // 2] * 1e6, 1)}
         assert len(results) == args.steps and [r.seq for r in results[-3:]] == sorted(r.seq for r in results[-3:])
         last_host = results[-1].check()
         stream_rec = {"single_capture_incl_compact_d2h_ms": round(min(one) * 1e3, 4), "d2h_bytes_per_step": last_host.blob_bytes + 40,
+                      "host_loop": host_rec,
                       "d2h_format": "compact blob: int32 length + int8 state per pulse-table row, packed bits, uint32 bit_sample_pos, "
                                     "int64 pauses / offsets (include/urhgpu.h)"}
         # the last timed step's outputs for the parity record: host copies of the blob's sections + its qad read back from HBM
@@ -694,28 +729,34 @@ def main():
             _ulib.check(_ulib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(last_host.d_qad_ptr), qad_host.ctypes.data_as(C.c_void_p), n * 4))
         st.close()
         # the same without bit_sample_pos (the reference makes them optional: write_bit_sample_pos, ProtocolAnalyzer.py:323, 396-401)
-        from dataclasses import replace
-        st = pipe.stream(n, replace(p, write_bit_sample_pos=False), want_qad=want_qad, want_pos=False)
-        ramp(lambda: stream_steps(10))
-        torch.cuda.synchronize()
-        t_np = time.perf_counter()
-        r_np = stream_steps(args.steps)
-        torch.cuda.synchronize()
-        stream_rec["ms_per_step_without_positions"] = round((time.perf_counter() - t_np) / args.steps * 1e3, 4)
-        stream_rec["d2h_bytes_per_step_without_positions"] = r_np[-1].blob_bytes + 40
-        st.close()
-        del st, results, r_np
+        if not args.no_device_loop:
+            from dataclasses import replace
+            st = pipe.stream(n, replace(p, write_bit_sample_pos=False), want_qad=want_qad, want_pos=False)
+            ramp(lambda: stream_steps(10))
+            torch.cuda.synchronize()
+            t_np = time.perf_counter()
+            r_np = stream_steps(args.steps)
+            torch.cuda.synchronize()
+            stream_rec["ms_per_step_without_positions"] = round((time.perf_counter() - t_np) / args.steps * 1e3, 4)
+            stream_rec["d2h_bytes_per_step_without_positions"] = r_np[-1].blob_bytes + 40
+            st.close()
+            del r_np
+        del st, results
 
     # ---- device only (outputs left in HBM): what round 2 reported as the headline; the timed region of sharded runs ------------------
-    rp_dev = ramp(lambda: device_steps(10))
-    if not use_stream:
-        ramp_passes = rp_dev
+    if use_stream and args.no_device_loop:
+        args_steps_dev = 1
+    else:
+        args_steps_dev = args.steps
+        rp_dev = ramp(lambda: device_steps(10))
+        if not use_stream:
+            ramp_passes = rp_dev
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     pipe.ctx.profile_begin(0 if (os.environ.get("URH_BENCH_NO_PROFILE") or use_stream) else args.steps)
     t0 = time.perf_counter()
-    res = device_steps(args.steps)
+    res = device_steps(args_steps_dev)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -729,7 +770,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    device_only_ms = dt / args.steps * 1e3
+    device_only_ms = dt / args_steps_dev * 1e3
     if headline_dt is None:
         headline_dt = dt
 

@@ -80,12 +80,17 @@ int urhgpu_ctx_sync(urhgpu_ctx *ctx);
  * urhgpu_ctx_sync; every other entry point joins first.  enable = 0 switches back (synchronises).
  * Measured on MI355X: 0.30 ms per 1 GiB pass against 0.34 ms one after the other; bench.py times this mode.
  * A caller that runs more than two passes ahead of the GPU is held back on the HOST at the start of the next pass until the tail
- * that last used the pass's scratch arena has finished (bounded run-ahead; URH_ARENA_WAIT=stream makes the context's stream wait
- * instead and keeps the host asynchronous, at the price of one more barrier packet between two hot kernels).
- * Environment knobs read here (experiments; defaults are what is measured): URH_HOT_STOP_EVENT=0 (record an event behind the hot
- * kernel instead of waiting on its dispatch's completion signal), URH_HOT_LDS_KB=<n> (dynamic LDS per hot workgroup: fewer of them
- * per CU; default 0, and 33 for the urhgpu_shard_* passes, whose longer tail needs the room), URH_TAIL_PRIORITY=1 (private tail stream at the highest priority). */
+ * that last used the pass's scratch arena has finished (bounded run-ahead; urhgpu_ctx_set_tuning("arena_wait_stream", 1) makes the
+ * context's stream wait instead and keeps the host asynchronous, at the price of one more barrier packet between two hot kernels).
+ * The library reads no environment variable; tuning values of this mode are set with urhgpu_ctx_set_tuning. */
 int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
+/* Tuning values of the pipelined mode (the defaults are what is measured and shipped; the A/B tools set others): key = "hot_lds_kb"
+ * (dynamic LDS per hot workgroup in KiB: fewer of them per CU; default 0), "hot_lds_kb_sharded" (the same for urhgpu_shard_* passes;
+ * default 33), "hot_stop_event" (1: the tail waits on the hot dispatch's own completion signal; 0: on an event recorded behind it),
+ * "arena_wait_stream" (1: arena reuse guarded by a stream wait instead of bounded host run-ahead), "tail_priority" (1: a private tail
+ * stream at the device's highest priority; set before urhgpu_ctx_set_pipelined), "profile_bracket" (1: urhgpu_ctx_profile_* report the
+ * stream-level bracket, which reads 3-5 % longer than the kernel runs).  Unknown key: URHGPU_ERR_ARG. */
+int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value);
 int urhgpu_ctx_join(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no
  * allocation happens inside later calls (bench / steady state). */
@@ -105,8 +110,8 @@ int urhgpu_ctx_costas_stats(urhgpu_ctx *ctx, int32_t *out4);
  * HIP events on the context's stream: begin(max_records) arms up to max_records records (one per call); end()
  * synchronises the stream and returns the per-call durations in ms.  The bit-plane kernel's dispatch carries the start /
  * stop events itself (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps, the duration rocprofv3 reports);
- * hot launches made of several kernels are bracketed by events recorded before and after them (environment
- * URH_PROFILE_BRACKET=1: always report the bracket, which reads 3-5 % longer than the kernel runs). */
+ * hot launches made of several kernels are bracketed by events recorded before and after them (urhgpu_ctx_set_tuning("profile_bracket",
+ * 1): always report the bracket, which reads 3-5 % longer than the kernel runs). */
 int urhgpu_ctx_profile_begin(urhgpu_ctx *ctx, int max_records);
 int urhgpu_ctx_profile_end(urhgpu_ctx *ctx, float *ms_out, int cap, int *n_records);
 
@@ -267,14 +272,16 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
 /* ---- a stream of captures, results on the host -------------------------------------------------------------------------------
  * SURVEY.md §8(d)'s window for this path ends with the compact outputs ON THE HOST.  For capture after capture (the reference's live
  * mode is such a consumer: ProtocolSniffer.py:161-202) three things overlap: the hot kernel of pass i, the tail of pass i - 1 (second
- * stream, urhgpu_ctx_set_pipelined: the stream switches the context to that mode) and the D2H copy of pass i - 2's blob (copy engine,
- * pinned memory owned by the stream).  Three output slots rotate.
+ * stream, urhgpu_ctx_set_pipelined: the stream switches the context to that mode) and the pack kernel + D2H copy of pass i - 2's blob
+ * (third stream / copy engine, pinned memory owned by the stream).  Three output slots rotate.
  *   urhgpu_stream_create   n_max: largest capture (samples, < 2^31); p: demodulation + slicing parameters of every pass (ASK / FSK /
  *                          OTHER; PSK synchronises with the host inside the Costas loop: URHGPU_ERR_UNSUPPORTED); want_qad: the
  *                          demodulated signal is materialised (stays in HBM: urhgpu_host_result::d_qad); want_pos: bit_sample_pos
  *                          is produced and shipped; cap_rows: 0 = the default (urhgpu_stream_capacities), else the pulse-table capacity.
- *   urhgpu_stream_push     queue pass i on d_iq (device; must stay valid until the pass has run) and return WITHOUT waiting for it;
- *                          *ready receives the result of pass i - 3 (seq = -1: none yet), valid until the push after next.
+ *   urhgpu_stream_push     queue pass i on d_iq (device; must stay valid until the pass has run), its pack kernel and its D2H copy and
+ *                          return WITHOUT waiting for any of it (the copy's size is predicted from the pass before; what a prediction
+ *                          misses is fetched when the result is handed out); *ready receives the result of pass i - 3 (seq = -1: none
+ *                          yet), valid until three pushes later.
  *   urhgpu_stream_flush    wait for every outstanding pass; out3 receives up to three results, oldest first.
  * The pointers of a result are pinned host memory owned by the stream. */
 typedef struct urhgpu_stream urhgpu_stream;

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "urhgpu_ctx_use_private_stream": (_i, [_vp]),
     "urhgpu_ctx_sync": (_i, [_vp]),
     "urhgpu_ctx_set_pipelined": (_i, [_vp, _i, _vp]),
+    "urhgpu_ctx_set_tuning": (_i, [_vp, C.c_char_p, _i]),
     "urhgpu_ctx_join": (_i, [_vp]),
     "urhgpu_ctx_reserve": (_i, [_vp, _i64, _i]),
     "urhgpu_ctx_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i64), C.c_char_p, _i]),
@@ -231,6 +232,10 @@ class Context:
     def set_pipelined(self, enable: bool, tail_stream_ptr=None):
         """see urhgpu_ctx_set_pipelined (include/urhgpu.h): outputs of iq_to_bits are then complete after join() / sync()"""
         check(load().urhgpu_ctx_set_pipelined(self._h, 1 if enable else 0, C.c_void_p(tail_stream_ptr or 0)))
+
+    def set_tuning(self, key: str, value: int):
+        """see urhgpu_ctx_set_tuning (include/urhgpu.h): tuning values of the pipelined mode (developer tooling)"""
+        check(load().urhgpu_ctx_set_tuning(self._h, key.encode(), int(value)))
 
     def join(self):
         check(load().urhgpu_ctx_join(self._h))

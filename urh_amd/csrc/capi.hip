@@ -449,9 +449,7 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
     if (!enable) return URHGPU_OK;
     if (tail_stream) ctx->tail_stream = (hipStream_t)tail_stream;
     else {
-        // experiment knob: URH_TAIL_PRIORITY=1 creates the tail stream at the device's highest priority
-        const char *pe = getenv("URH_TAIL_PRIORITY");
-        if (pe && atoi(pe) != 0) {
+        if (ctx->tune_tail_priority) {                     // urhgpu_ctx_set_tuning("tail_priority", 1): the device's highest stream priority
             int lo = 0, hi = 0;
             URH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
             URH_HIP(hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, hi));
@@ -467,19 +465,28 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[2], hipEventDisableTiming));
     }
     ctx->pipelined = true;
-    {   // experiment knob: URH_HOT_LDS_KB=<KiB of dynamic LDS per hot workgroup> (0 / unset: the default below)
-        const char *e = getenv("URH_HOT_LDS_KB");
-        ctx->hot_lds_pad = (e ? atoi(e) : 0) * 1024;       // (21 KiB was the default while the row kernel had 8-wavefront workgroups)
-        // Sharded passes: their tail is the generic one with three exchanges in it -- 0.18 ms on an idle machine, 0.38 ms beside hot
-        // workgroups that fill every SIMD's register file, which made the tail the bound of the pass (0.365-0.40 ms).  33 KiB per hot
-        // workgroup = four of them per CU: the hot kernel takes 0.31 ms and the tail keeps up (0.317 ms per pass; 21 / 27 KiB = 6 / 5
-        // per CU: 0.36 / 0.34; 38 KiB and more = 3: 0.34-0.42; tools/sharded_two_engines.py under URH_HOT_LDS_KB).
-        ctx->hot_lds_pad_sharded = (e ? atoi(e) : 33) * 1024;
-        const char *se = getenv("URH_HOT_STOP_EVENT");     // 0: record an event behind the hot kernel instead (comparison)
-        ctx->hot_stop_event = se ? atoi(se) != 0 : true;
-        const char *aw = getenv("URH_ARENA_WAIT");         // "stream": never hold the host back (see begin_pipelined_pass)
-        ctx->arena_wait_on_stream = aw && strcmp(aw, "stream") == 0;
-    }
+    return URHGPU_OK;
+}
+
+// Tuning values of the pipelined mode (defaults = what is measured and shipped; the A/B tools set others: tools/r3_ab.sh through
+// bench.py's URH_TUNE_* environment, read THERE -- the library itself reads no environment variable).
+//   hot_lds_kb          dynamic LDS per hot workgroup in KiB (fewer of them per CU: room for the previous pass's tail); default 0
+//   hot_lds_kb_sharded  the same for the urhgpu_shard_* passes, whose longer tail (three exchanges) needs the room; default 33: four hot
+//                       workgroups per CU, the hot kernel takes 0.31 ms and the tail keeps up (21 / 27 KiB = 6 / 5 per CU: 0.36 / 0.34 ms
+//                       per pass; 38 KiB and more = 3: 0.34-0.42)
+//   hot_stop_event      1 (default): the tail stream waits on the hot dispatch's own completion signal; 0: on an event recorded behind it
+//   arena_wait_stream   1: arena reuse is guarded by a stream wait instead of bounded host run-ahead (see begin_pipelined_pass); default 0
+//   tail_priority       1: a private tail stream is created at the device's highest priority (before urhgpu_ctx_set_pipelined); default 0
+//   profile_bracket     1: urhgpu_ctx_profile_* report the stream-level bracket around the hot launch instead of the dispatch's own timing
+int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
+    if (!ctx || !key) return URHGPU_ERR_ARG;
+    if (!strcmp(key, "hot_lds_kb")) { if (value < 0 || value > 150) return URHGPU_ERR_ARG; ctx->hot_lds_pad = value * 1024; }
+    else if (!strcmp(key, "hot_lds_kb_sharded")) { if (value < 0 || value > 150) return URHGPU_ERR_ARG; ctx->hot_lds_pad_sharded = value * 1024; }
+    else if (!strcmp(key, "hot_stop_event")) ctx->hot_stop_event = value != 0;
+    else if (!strcmp(key, "arena_wait_stream")) ctx->arena_wait_on_stream = value != 0;
+    else if (!strcmp(key, "tail_priority")) ctx->tune_tail_priority = value != 0;
+    else if (!strcmp(key, "profile_bracket")) ctx->prof_bracket = value != 0;
+    else return URHGPU_ERR_ARG;
     return URHGPU_OK;
 }
 
@@ -521,7 +528,6 @@ int urhgpu_ctx_profile_begin(urhgpu_ctx *ctx, int max_records) {
     }
     ctx->prof_used = 0;
     ctx->prof_on = max_records > 0;
-    ctx->prof_bracket = getenv("URH_PROFILE_BRACKET") != nullptr;
     return URHGPU_OK;
 }
 

@@ -87,7 +87,8 @@ struct urhgpu_ctx {
     // `tail_stream`, with two scratch arenas used alternately, so that the hot kernel of the NEXT pass overlaps the
     // (latency-bound, nearly empty) tail of this one -- and, with three arenas, of the one before.  Outputs are complete after urhgpu_ctx_join / urhgpu_ctx_sync.
     bool pipelined = false;
-    int hot_lds_pad_sharded = 0;   // the same for the urhgpu_shard_* passes (their tail is longer: see urhgpu_ctx_set_pipelined)
+    int hot_lds_pad_sharded = 33 * 1024;   // the same for the urhgpu_shard_* passes (their tail is longer: see urhgpu_ctx_set_tuning)
+    bool tune_tail_priority = false;
     int hot_lds_pad = 0;           // pipelined mode: dynamic LDS bytes added to every hot-kernel workgroup (see RunArgs::lds_pad)
     bool hot_stop_event = true;
     bool arena_wait_on_stream = false;   // pipelined mode: arena reuse guarded by a stream wait instead of bounded host run-ahead (URH_ARENA_WAIT=stream)

@@ -81,7 +81,10 @@ int launch_pack_blob(const urhgpu_outputs *o, int write_pos, hipStream_t s) {
     PackArgs a{o->rows, o->bits, o->msg_off, o->pauses, o->pos_off, o->pos, o->counts, o->cap_rows, o->cap_bits, o->cap_msg, o->cap_pos, has_pos,
                (char *)o->blob, o->cap_blob};
     // sized for a typical result (a few million elements), stride loops for the rest: the counts are only known on the device
-    hipLaunchKernelGGL(k_pack_blob, dim3(512), dim3(256), 0, s, a);
+#ifndef URH_PACK_BLOCKS
+#define URH_PACK_BLOCKS 512
+#endif
+    hipLaunchKernelGGL(k_pack_blob, dim3(URH_PACK_BLOCKS), dim3(256), 0, s, a);
     return URHGPU_OK;
 }
 

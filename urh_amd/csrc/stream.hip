@@ -3,10 +3,10 @@
 // SURVEY §8(d)'s window for the IQ -> bits path is "IQ resident in HBM ... compact outputs on the host".  One capture at a time that is
 // hot kernel + tail + copy, strictly one after the other (0.44 + 0.4 ms per GiB in round 2).  A consumer that processes capture
 // after capture -- the reference's own live mode is one (ProtocolSniffer.py:161-202) -- lets three things overlap:
-//     hot kernel of pass i      | tail of pass i - 1 (second stream, urhgpu_ctx_set_pipelined) | pack + D2H of pass i - 2 (third stream)
+//     hot kernel of pass i + 1  | tail of pass i (second stream, urhgpu_ctx_set_pipelined) | pack + D2H of pass i - 1 (third stream)
 // Three output slots rotate; the compact blob (compact.hip) makes the copy ONE hipMemcpyAsync of 9 MB per GiB (3.5 MB without
-// bit_sample_pos) into pinned memory, which hides under the 0.29 ms hot kernel.  The host blocks only on the tail of the pass before
-// last -- finished by the time the hot kernel before this one ends --, so the GPU always has the next hot kernel queued.
+// bit_sample_pos) into pinned memory, which hides under the 0.29 ms hot kernel.  The host never waits for the GPU inside push() beyond
+// the bounded run-ahead of pipelined passes: the copy is queued behind the tail with a predicted size (queue_copy).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -26,14 +26,18 @@ struct urhgpu_stream {
     struct Slot {
         void *dev = nullptr;               // one allocation: qad | rows | bits | msg_off | pauses | pos_off | pos | counts | blob
         urhgpu_outputs out;
-        char *h_blob = nullptr;            // pinned
+        char *h_blob2[2] = {nullptr, nullptr};   // pinned, used alternately by the slot's passes: the result handed out at push i (pass i - 3)
+                                                 // stays untouched while pass i's copy lands in the other one
+        char *h_blob = nullptr;            // the one the slot's current pass copies into
         int64_t *h_counts = nullptr;       // pinned int64[8]
         hipEvent_t ev_tail = nullptr, ev_copy = nullptr;
-        int64_t seq = -1, n = 0;
+        int64_t seq = -1, n = 0, copied = 0;
         int state = 0;                     // 0 free, 1 pass launched (tail pending), 2 copy issued, 3 result handed out
     } slot[3];
     hipStream_t copy_stream = nullptr;
     int64_t seq = 0;
+    int64_t predicted_bytes = 0;           // blob bytes the next pass's copy is sized for (0: header only, the rest fetched on demand)
+    int64_t short_copies = 0;              // passes whose prediction fell short (diagnostics)
     bool was_pipelined = false;
 };
 
@@ -61,28 +65,39 @@ void fill_result(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *
     (void)st;
 }
 
-// the host waits for the tail of the slot's pass, sizes the blob from the counts and queues its copy
-int issue_copy(urhgpu_stream *st, urhgpu_stream::Slot &s) {
+// Queue the pack kernel and the copy of the slot's blob behind the pass's tail, WITHOUT involving the host: the copy stream waits for
+// the tail's event, and the number of bytes to copy is PREDICTED from the pass before (captures of a stream resemble each other:
+// the last blob's size plus an eighth).  The host therefore never waits for the GPU inside push() -- it runs ahead as in the
+// device-only loop (waiting for the counts first made the host the pacemaker: it could queue the next hot kernel only after the tail of
+// the pass before last had finished, 0.31 ms per step instead of 0.296).  finish_copy() fetches what a prediction missed.
+int queue_copy(urhgpu_stream *st, urhgpu_stream::Slot &s) {
     if (s.state != 1) return URHGPU_OK;
-    URH_HIP(hipEventSynchronize(s.ev_tail));
-    const BlobLayout L = blob_layout(s.h_counts, st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
-    if (L.total > st->cap_blob) return URHGPU_ERR_CAPACITY;
-    // the blob is packed HERE, on the copy stream, not at the end of the pass's tail: the tail chain of a pass (five dependent kernels
-    // that share the machine with the next hot kernel) is what bounds the rate of pipelined passes, and the pack kernel would
-    // lengthen it; on the copy stream it runs beside the tail of the next pass instead
+    URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_tail, 0));
     URH_TRY(launch_pack_blob(&s.out, st->want_pos, st->copy_stream));
     URH_HIP(hipGetLastError());
-    URH_HIP(hipMemcpyAsync(s.h_blob, s.out.blob, (size_t)L.total, hipMemcpyDeviceToHost, st->copy_stream));
+    int64_t guess = st->predicted_bytes > 0 ? st->predicted_bytes : URHGPU_BLOB_HEADER_BYTES;
+    if (guess > st->cap_blob) guess = st->cap_blob;
+    URH_HIP(hipMemcpyAsync(s.h_blob, s.out.blob, (size_t)guess, hipMemcpyDeviceToHost, st->copy_stream));
     URH_HIP(hipEventRecord(s.ev_copy, st->copy_stream));
+    s.copied = guess;
     s.state = 2;
     return URHGPU_OK;
 }
 
 int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r) {
-    if (s.state == 1) URH_TRY(issue_copy(st, s));
+    if (s.state == 1) URH_TRY(queue_copy(st, s));
     if (s.state != 2) return URHGPU_ERR_ARG;
     URH_HIP(hipEventSynchronize(s.ev_copy));
-    if (((const int64_t *)s.h_blob)[0] != URHGPU_BLOB_MAGIC) return URHGPU_ERR_ARG;
+    const int64_t *hdr = (const int64_t *)s.h_blob;
+    if (hdr[0] != URHGPU_BLOB_MAGIC || hdr[6] < 0 || hdr[6] > st->cap_blob) return URHGPU_ERR_ARG;
+    const int64_t total = hdr[6];
+    if (total > s.copied) {                                 // the prediction was short (the first pass of a stream, a denser capture): the rest, now
+        URH_HIP(hipMemcpyAsync(s.h_blob + s.copied, (const char *)s.out.blob + s.copied, (size_t)(total - s.copied), hipMemcpyDeviceToHost,
+                               st->copy_stream));
+        URH_HIP(hipStreamSynchronize(st->copy_stream));
+        st->short_copies += 1;
+    }
+    st->predicted_bytes = total + total / 8 + 65536;
     fill_result(st, s, r);
     s.state = 3;
     return URHGPU_OK;
@@ -134,7 +149,8 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
     for (auto &s : st->slot) {
         memset(&s.out, 0, sizeof(s.out));
         if (hipMalloc(&s.dev, b_qad + b_rows + b_bits + 3 * b_off + b_pos + 256 + b_blob) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_blob, (size_t)st->cap_blob) != hipSuccess || hipHostMalloc((void **)&s.h_counts, 64) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_blob2[0], (size_t)st->cap_blob) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_blob2[1], (size_t)st->cap_blob) != hipSuccess || hipHostMalloc((void **)&s.h_counts, 64) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_tail, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_copy, hipEventDisableTiming) != hipSuccess) {
             urhgpu_stream_destroy(st);
@@ -163,7 +179,8 @@ int urhgpu_stream_destroy(urhgpu_stream *st) {
     if (st->copy_stream) { (void)hipStreamSynchronize(st->copy_stream); (void)hipStreamDestroy(st->copy_stream); }
     for (auto &s : st->slot) {
         if (s.dev) (void)hipFree(s.dev);
-        if (s.h_blob) (void)hipHostFree(s.h_blob);
+        if (s.h_blob2[0]) (void)hipHostFree(s.h_blob2[0]);
+        if (s.h_blob2[1]) (void)hipHostFree(s.h_blob2[1]);
         if (s.h_counts) (void)hipHostFree(s.h_counts);
         if (s.ev_tail) (void)hipEventDestroy(s.ev_tail);
         if (s.ev_copy) (void)hipEventDestroy(s.ev_copy);
@@ -180,7 +197,8 @@ int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_ho
     const int64_t i = st->seq;
     urhgpu_stream::Slot &s = st->slot[i % 3];
     if (ready) { memset(ready, 0, sizeof(*ready)); ready->seq = -1; }
-    // the slot's previous pass (i - 3): its copy was queued two pushes ago; hand the result out now (valid until push i + 2)
+    // the slot's previous pass (i - 3): its copy was queued with it; hand the result out now (valid until push i + 3 queues the copy
+    // that reuses its host buffer)
     if (s.state == 1 || s.state == 2) {
         urhgpu_host_result r;
         URH_TRY(finish_copy(st, s, &r));
@@ -191,15 +209,15 @@ int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_ho
     s.state = 0;
     {
         urhgpu_outputs pass_out = s.out;
-        pass_out.blob = nullptr; pass_out.cap_blob = 0;    // packed later, on the copy stream (issue_copy)
-        pass_out.h_counts = s.h_counts;                    // the counts land in pinned host memory by a store of the kernel that finalises them
+        pass_out.blob = nullptr; pass_out.cap_blob = 0;    // packed later, on the copy stream (queue_copy)
+        pass_out.h_counts = s.h_counts;                    // the counts also land in pinned host memory (a store of the kernel that finalises them)
         URH_TRY(urhgpu_iq_to_bits_dev(ctx, d_iq, n, &st->p, &pass_out));
     }
     URH_HIP(hipEventRecord(s.ev_tail, ctx->tail_stream));
     s.state = 1; s.seq = i; s.n = n;
+    s.h_blob = s.h_blob2[(i / 3) & 1];
     st->seq = i + 1;
-    // the pass before last: its tail ran beside the previous hot kernel and is done (or about to be): size and queue its copy
-    if (i >= 2) URH_TRY(issue_copy(st, st->slot[(i - 2) % 3]));
+    URH_TRY(queue_copy(st, s));                            // pack + copy behind this pass's tail, on the copy stream; the host does not wait
     return URHGPU_OK;
 }
 

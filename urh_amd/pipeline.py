@@ -164,7 +164,7 @@ class BitsResult:
 
 class HostBits:
     """One pass's results ON THE HOST, from the compact blob (include/urhgpu.h "compact result blob"): numpy views of pinned memory
-    owned by the stream -- valid until the push after next; copy what has to live longer.  The accessors widen to the reference's own
+    owned by the stream -- valid until three pushes later; copy what has to live longer.  The accessors widen to the reference's own
     shapes and types: ppseq() is grab_pulse_lens' int64 (P, 2), bits() one byte per bit, bit_sample_pos() int64."""
 
     def __init__(self, r: "_lib.HostResult", params):
@@ -256,9 +256,10 @@ class CaptureStream:
 class DevicePipeline:
     """Owns a liburhgpu context bound to torch's current stream and the output buffers."""
 
-    def __init__(self, device=None, pipelined=False):
+    def __init__(self, device=None, pipelined=False, tuning=None, tail_stream_priority=0):
         """pipelined: back-to-back iq_to_bits passes overlap (the hot kernel of a pass runs while the tail of the previous
-        one finishes on a second stream, see urhgpu_ctx_set_pipelined); results synchronise when they are read."""
+        one finishes on a second stream, see urhgpu_ctx_set_pipelined); results synchronise when they are read.
+        tuning: {key: value} for urhgpu_ctx_set_tuning (A/B tooling); tail_stream_priority: torch stream priority of the tail's stream."""
         import torch
         self.torch = torch
         if not torch.cuda.is_available():
@@ -267,10 +268,10 @@ class DevicePipeline:
         self.ctx = _lib.Context(self.device.index)
         self._bufs = {}
         self.tail_stream = None
+        for key, value in (tuning or {}).items():
+            self.ctx.set_tuning(key, value)
         if pipelined:
-            import os
-            # URH_TAIL_STREAM_PRIORITY=-1: the tail's stream at the device's high priority (experiment knob; default: same priority)
-            self.tail_stream = torch.cuda.Stream(self.device, priority=int(os.environ.get("URH_TAIL_STREAM_PRIORITY", "0")))
+            self.tail_stream = torch.cuda.Stream(self.device, priority=int(tail_stream_priority))
             self.ctx.set_pipelined(True, self.tail_stream.cuda_stream)
 
     def tail_context(self):
