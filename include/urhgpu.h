@@ -79,6 +79,9 @@ int urhgpu_ctx_sync(urhgpu_ctx *ctx);
  * pass are complete only after urhgpu_ctx_join (the context's stream waits for the tail; the host does not block) or
  * urhgpu_ctx_sync; every other entry point joins first.  enable = 0 switches back (synchronises).
  * Measured on MI355X: 0.30 ms per 1 GiB pass against 0.34 ms one after the other; bench.py times this mode.
+ * The hot kernel itself is launched on a private stream of the context (CU-masked, see "hot_cus_removed_per_xcd" below), ordered
+ * behind what the caller has queued on the context's stream; it is a stream with default flags, i.e. it synchronises with the NULL
+ * stream as every such stream does: callers that queue unrelated work on the NULL stream meanwhile serialise with the hot kernels.
  * A caller that runs more than two passes ahead of the GPU is held back on the HOST at the start of the next pass until the tail
  * that last used the pass's scratch arena has finished (bounded run-ahead; urhgpu_ctx_set_tuning("arena_wait_stream", 1) makes the
  * context's stream wait instead and keeps the host asynchronous, at the price of one more barrier packet between two hot kernels).
@@ -89,7 +92,10 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
  * default 33), "hot_stop_event" (1: the tail waits on the hot dispatch's own completion signal; 0: on an event recorded behind it),
  * "arena_wait_stream" (1: arena reuse guarded by a stream wait instead of bounded host run-ahead), "tail_priority" (1: a private tail
  * stream at the device's highest priority; set before urhgpu_ctx_set_pipelined), "profile_bracket" (1: urhgpu_ctx_profile_* report the
- * stream-level bracket, which reads 3-5 % longer than the kernel runs).  Unknown key: URHGPU_ERR_ARG. */
+ * stream-level bracket, which reads 3-5 % longer than the kernel runs), "hot_cus_removed_per_xcd" (0 .. 16, default 4; set before
+ * urhgpu_ctx_set_pipelined: the hot kernel of a pipelined pass runs on a private stream whose CU mask leaves that many CUs of every XCD
+ * out -- on 224 of the MI355X's 256 CUs the kernel is 5 % faster than on all of them, and the CUs left alone serve the previous pass's
+ * tail; 0: no mask, the hot kernel runs on the caller's stream).  Unknown key: URHGPU_ERR_ARG. */
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value);
 int urhgpu_ctx_join(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no
@@ -533,7 +539,8 @@ int urhgpu_bgra_lookup_dev(urhgpu_ctx *ctx, const float *d_db, int64_t frames, i
  * on this GPU, timed with events over `reps` launches.  shape 0: the hot kernel's access structure without its arithmetic (one
  * workgroup of four wavefronts per 8192 samples, 16-byte non-temporal loads two rows ahead, 8-byte non-temporal stores: 8 B in + 4 B
  * out per sample, d_in float32[2 n], d_out float32[n]); shape 1: a plain grid-stride float4 copy of n float32 values (4 B in + 4 B
- * out per value).  n_samples a multiple of 8192.  Synchronous. */
+ * out per value); shape 2: shape 0 on the CU-masked stream the hot kernel of pipelined passes runs on (URHGPU_ERR_UNSUPPORTED on a context
+ * without one).  n_samples a multiple of 8192.  Synchronous. */
 int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_out, int64_t n_samples, int shape, int reps, float *ms_per_copy);
 /* Synchronous device -> host copy after urhgpu_ctx_sync (for callers that hold raw device pointers, e.g. urhgpu_host_result::d_qad). */
 int urhgpu_memcpy_to_host(urhgpu_ctx *ctx, const void *d_src, void *host_dst, int64_t bytes);

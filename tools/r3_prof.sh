@@ -3,7 +3,7 @@
 TAG=${1:-r3p}; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG; mkdir -p $OUT
-(cd /tmp && TMPDIR=/tmp timeout 400 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $OUT/trace -o b -- python $R/bench.py --steps 60 --warmup 3 --no-cpu-baseline --no-extra --no-reference-loop "$@" > $OUT/log.txt 2>&1)
+(cd /tmp && TMPDIR=/tmp timeout 400 rocprofv3 --kernel-trace ${PROF_COPY:+--memory-copy-trace} --stats --output-format csv -d $OUT/trace -o b -- python $R/bench.py --steps 60 --warmup 3 --no-cpu-baseline --no-extra --no-reference-loop "$@" > $OUT/log.txt 2>&1)
 tail -2 $OUT/log.txt | cut -c1-600
 python $R/tools/timeline.py $OUT/trace --passes 14 > $OUT/timeline.txt 2>&1
 cat $OUT/timeline.txt

@@ -164,11 +164,29 @@ int prof_end_record(urhgpu_ctx *ctx, hipStream_t s) {
     return URHGPU_OK;
 }
 
+// pipelined passes: the stream the hot kernel is launched on -- the CU-masked private one (see urhgpu_ctx_set_pipelined), ordered
+// behind what the caller has queued on the context's stream so far
+int hot_stream_begin(urhgpu_ctx *ctx, hipStream_t *out) {
+    *out = ctx->stream;
+    if (!ctx->pipelined || !ctx->hot_masked) return URHGPU_OK;
+    // The masked stream has default flags: what the caller has queued on the NULL stream is ordered before its work by the runtime
+    // itself (and costs nothing when the NULL stream is idle).  An explicit event on the NULL stream would make THAT stream wait for the
+    // previous hot kernel first and hand over afterwards: two cross-queue hand-overs between consecutive hot kernels (measured: a
+    // 50 us gap instead of 5).  Any other stream of the caller's hands over through an event.
+    if (ctx->stream != nullptr) {
+        URH_HIP(hipEventRecord(ctx->ev_in, ctx->stream));
+        URH_HIP(hipStreamWaitEvent(ctx->hot_masked, ctx->ev_in, 0));
+    }
+    *out = ctx->hot_masked;
+    return URHGPU_OK;
+}
+
 int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const urhgpu_params *p, float *d_qad,
              int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows, int64_t *d_n_rows_needed, int64_t *d_n_acc,
              const Plan &pl, int seg_mode = 0, hipStream_t s_tail = nullptr, const BitsParams *tile_bp = nullptr,
              TileTailMem *tile_out = nullptr) {
     hipStream_t s = ctx->stream;
+    if (s_tail) URH_TRY(hot_stream_begin(ctx, &s));
     if (tile_out) tile_out->mem = nullptr;
     RunArgs a;
     memset(&a, 0, sizeof(a));
@@ -405,6 +423,8 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     ctx->aux.release();
     ctx->arena_alt.release();
     ctx->arena_alt2.release();
+    if (ctx->hot_masked) { (void)hipStreamSynchronize(ctx->hot_masked); (void)hipStreamDestroy(ctx->hot_masked); }
+    if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
     if (ctx->ev_hot) { (void)hipEventDestroy(ctx->ev_hot); (void)hipEventDestroy(ctx->ev_tail[0]); (void)hipEventDestroy(ctx->ev_tail[1]); (void)hipEventDestroy(ctx->ev_tail[2]); }
@@ -434,6 +454,7 @@ int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx) {
 
 int urhgpu_ctx_sync(urhgpu_ctx *ctx) {
     if (!ctx) return URHGPU_ERR_ARG;
+    if (ctx->hot_masked) URH_HIP(hipStreamSynchronize(ctx->hot_masked));
     if (ctx->tail_stream) URH_HIP(hipStreamSynchronize(ctx->tail_stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
     ctx->tail_pending = false;
@@ -447,6 +468,7 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
     if (ctx->own_tail_stream && ctx->tail_stream) { (void)hipStreamDestroy(ctx->tail_stream); }
     ctx->tail_stream = nullptr; ctx->own_tail_stream = false; ctx->pipelined = false;
     if (!enable) return URHGPU_OK;
+    if (ctx->hot_masked) { (void)hipStreamSynchronize(ctx->hot_masked); (void)hipStreamDestroy(ctx->hot_masked); ctx->hot_masked = nullptr; }
     if (tail_stream) ctx->tail_stream = (hipStream_t)tail_stream;
     else {
         if (ctx->tune_tail_priority) {                     // urhgpu_ctx_set_tuning("tail_priority", 1): the device's highest stream priority
@@ -463,6 +485,23 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[0], hipEventDisableTiming));
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[1], hipEventDisableTiming));
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[2], hipEventDisableTiming));
+    }
+    // The hot kernel of a pipelined pass runs on a private stream whose CU mask leaves hot_cus_removed CUs per XCD out (default 4: 224 of
+    // the 256 CUs).  Measured (tools/cumask_probe.py, round 3): the kernel -- and a pure copy of its shape -- is FASTEST there: 0.2666 ms
+    // = 6.04 TB/s on 224 CUs against 0.2799 ms = 5.75 TB/s on all 256 (248 / 240 / 232 CUs: 0.2746 / 0.2718 / 0.2708; 208 / 192: 0.2746 /
+    // 0.2752; 160: 0.311): 256 CUs of streaming wavefronts ask more of the HBM than it serves well.  And the 32 CUs it leaves alone are
+    // where the previous pass's tail, the blob packing and the collectives of sharded passes find their wave slots at once.  The mask
+    // bits of the removed CUs are chosen so that every XCD loses the same number whichever way bits map to XCDs (bit i -> XCD i / 32 or
+    // i % 8): class (i % 8 - i / 32) mod 8 and slot (i / 8) % 4 enumerate 32 sets of 8 CUs, one per XCD each.
+    if (ctx->tune_hot_cus_removed > 0 && ctx->prop.multiProcessorCount == 256) {
+        const int ncu = 256, words = ncu / 32;
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < ncu; ++i) {
+            const int c = ((i % 8) - (i / 32) + 8) % 8, k = (i / 8) % 4;
+            if (c * 4 + k >= ctx->tune_hot_cus_removed) mask[i / 32] |= 1u << (i % 32);
+        }
+        URH_HIP(hipExtStreamCreateWithCUMask(&ctx->hot_masked, (uint32_t)words, mask));
+        if (!ctx->ev_in) URH_HIP(hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
     }
     ctx->pipelined = true;
     return URHGPU_OK;
@@ -486,6 +525,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "arena_wait_stream")) ctx->arena_wait_on_stream = value != 0;
     else if (!strcmp(key, "tail_priority")) ctx->tune_tail_priority = value != 0;
     else if (!strcmp(key, "profile_bracket")) ctx->prof_bracket = value != 0;
+    else if (!strcmp(key, "hot_cus_removed_per_xcd")) { if (value < 0 || value > 16) return URHGPU_ERR_ARG; ctx->tune_hot_cus_removed = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;
 }
@@ -534,6 +574,7 @@ int urhgpu_ctx_profile_begin(urhgpu_ctx *ctx, int max_records) {
 int urhgpu_ctx_profile_end(urhgpu_ctx *ctx, float *ms_out, int cap, int *n_records) {
     if (!ctx || !n_records) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
+    if (ctx->hot_masked) URH_HIP(hipStreamSynchronize(ctx->hot_masked));
     URH_HIP(hipStreamSynchronize(ctx->stream));
     ctx->prof_on = false;
     const int n = ctx->prof_used;
@@ -716,6 +757,7 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     ss->piped = ctx->pipelined;
     if (ss->piped) URH_TRY(begin_pipelined_pass(ctx)); else URH_TRY(join_tail(ctx));
     hipStream_t s = ctx->stream;
+    if (ss->piped) URH_TRY(hot_stream_begin(ctx, &s));
     ss->phase = 0; ss->rank = rank; ss->world = world; ss->n_local = n_local; ss->pos_base = pos_base; ss->n_total = n_total;
     ss->p = *p; ss->out = *out;
     const Plan pl = make_plan(ctx, n_local, p->tolerance);
@@ -1315,17 +1357,22 @@ int urhgpu_path_minmax(urhgpu_ctx *ctx, const void *samples, int dtype, int64_t 
 }
 
 int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_out, int64_t n_samples, int shape, int reps, float *ms_per_copy) {
-    if (!ctx || !d_in || !d_out || !ms_per_copy || n_samples < 8192 || n_samples % 8192 || reps < 1 || (shape != 0 && shape != 1)) return URHGPU_ERR_ARG;
+    if (!ctx || !d_in || !d_out || !ms_per_copy || n_samples < 8192 || n_samples % 8192 || reps < 1 || shape < 0 || shape > 2) return URHGPU_ERR_ARG;
     if (((uintptr_t)d_in & 15) || ((uintptr_t)d_out & 15)) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
-    URH_TRY(join_tail(ctx));
+    URH_TRY(urhgpu_ctx_sync(ctx));
+    hipStream_t cs = ctx->stream;
+    if (shape == 2) {                                      // shape 0 on the CUs the hot kernel of pipelined passes runs on
+        if (!ctx->hot_masked) return URHGPU_ERR_UNSUPPORTED;
+        cs = ctx->hot_masked; shape = 0;
+    }
     hipEvent_t e0, e1;
     URH_HIP(hipEventCreate(&e0));
     URH_HIP(hipEventCreate(&e1));
-    for (int k = 0; k < 3; ++k) launch_copy_shape(d_in, d_out, n_samples, shape, ctx->stream);
-    URH_HIP(hipEventRecord(e0, ctx->stream));
-    for (int k = 0; k < reps; ++k) launch_copy_shape(d_in, d_out, n_samples, shape, ctx->stream);
-    URH_HIP(hipEventRecord(e1, ctx->stream));
+    for (int k = 0; k < 3; ++k) launch_copy_shape(d_in, d_out, n_samples, shape, cs);
+    URH_HIP(hipEventRecord(e0, cs));
+    for (int k = 0; k < reps; ++k) launch_copy_shape(d_in, d_out, n_samples, shape, cs);
+    URH_HIP(hipEventRecord(e1, cs));
     URH_HIP(hipEventSynchronize(e1));
     float ms = 0.f;
     URH_HIP(hipEventElapsedTime(&ms, e0, e1));

@@ -89,6 +89,9 @@ struct urhgpu_ctx {
     bool pipelined = false;
     int hot_lds_pad_sharded = 33 * 1024;   // the same for the urhgpu_shard_* passes (their tail is longer: see urhgpu_ctx_set_tuning)
     bool tune_tail_priority = false;
+    int tune_hot_cus_removed = 4;          // CUs per XCD the hot kernel of a pipelined pass leaves alone (0: no mask); see urhgpu_ctx_set_pipelined
+    hipStream_t hot_masked = nullptr;      // private CU-masked stream of the hot kernel (pipelined mode)
+    hipEvent_t ev_in = nullptr;
     int hot_lds_pad = 0;           // pipelined mode: dynamic LDS bytes added to every hot-kernel workgroup (see RunArgs::lds_pad)
     bool hot_stop_event = true;
     bool arena_wait_on_stream = false;   // pipelined mode: arena reuse guarded by a stream wait instead of bounded host run-ahead (URH_ARENA_WAIT=stream)
