@@ -40,7 +40,7 @@ def test_stream_of_different_captures_equals_oracle(oracle, mod, bps, want_pos):
     def keep(r):
         if r is not None:
             r.check()
-            got[r.seq] = (r.ppseq(), r.bits(), r.msg_off.copy(), r.pauses.copy(), r.bit_sample_pos(), r.pos_off.copy(), r.blob_bytes, r.n_samples)
+            got[r.seq] = (r.ppseq(), r.bits(), r.msg_off.copy(), r.pauses.copy(), r.bit_sample_pos(), r.pos_offsets(), r.blob_bytes, r.n_samples)
     for d in dev:
         keep(st.push(d))
     for r in st.flush():
@@ -49,15 +49,13 @@ def test_stream_of_different_captures_equals_oracle(oracle, mod, bps, want_pos):
     for i, iq in enumerate(caps):
         qad = oracle.afp_demod(iq, 0.1, mod, 2 ** bps)
         pp = oracle.grab_pulse_lens(qad, center, 5, mod, 100, bps, spacing)
-        bits, off, pauses, pos, poff = oracle.ppseq_to_bits_flat(pp, 100, bps, want_pos, 8)
+        bits, off, pauses, pos, poff = oracle.ppseq_to_bits_flat(pp, 100, bps, True, 8)
         g = got[i]
         assert g[7] == len(iq)
         assert np.array_equal(g[0], pp), i
         assert np.array_equal(g[1], bits) and np.array_equal(g[2], off) and np.array_equal(g[3], pauses), i
-        if want_pos:
-            assert np.array_equal(g[4], pos) and np.array_equal(g[5], poff), i
-        else:
-            assert len(g[4]) == 0
+        # positions: the device's (want_pos) or derived on the host from the shipped pulse table (HostBits.bit_sample_pos): the same
+        assert np.array_equal(g[4], pos) and np.array_equal(g[5], poff), i
         # what crossed PCIe: 5 B per row, 1 bit per bit, 4 B per position, 24 B per message (+ header and alignment)
         assert g[6] <= 5 * len(pp) + len(bits) // 8 + 4 * len(pos) * (1 if want_pos else 0) + 24 * len(pauses) + 512, (i, g[6])
     st.close()

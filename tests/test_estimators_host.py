@@ -142,3 +142,30 @@ def test_detect_modulation_equals_reference(ref):
         assert ne.detect_modulation(msg) == AI.detect_modulation(msg)
         n_checked += 1
     assert n_checked > 20
+
+
+def test_positions_derived_from_the_pulse_table_equal_the_oracle(oracle):
+    """urh_amd.pipeline.positions_from_rows (what HostBits.bit_sample_pos() gives when a capture stream ships no positions): the
+    bit_sample_pos arrays of ProtocolAnalyzer._ppseq_to_bits (:346-411) from the pulse table alone, on random tables (groups without data,
+    leading pauses, long pauses with and without a message before them, every pause_threshold rule) and on the golden captures."""
+    from conftest import GOLDEN_CASES, load_golden
+    from urh_amd.pipeline import DemodParams, positions_from_rows
+    rng = np.random.default_rng(4)
+    for it in range(600):
+        n = int(rng.integers(0, 80))
+        sps = int(rng.choice([1, 7, 100]))
+        bps = int(rng.choice([1, 2, 3]))
+        pt = int(rng.choice([0, 1, 8]))
+        pp = np.stack([rng.integers(-1, 2 ** bps, n), rng.integers(1, sps * 14 + 3, n)], 1).astype(np.int64).reshape(-1, 2)
+        want = oracle.ppseq_to_bits_flat(pp, sps, bps, True, pt)
+        pos, off = positions_from_rows(pp[:, 0], pp[:, 1], DemodParams("FSK", bps, 0, 0, 1, 5, sps, 0.1, pt, False))
+        assert np.array_equal(pos, want[3]) and np.array_equal(off, want[4]), (it, pp.tolist())
+    for name in GOLDEN_CASES:
+        g = load_golden(name)
+        if "ppseq" not in g or g["modulation_type"] == "PSK":
+            continue
+        pp = g["ppseq"]
+        want = oracle.ppseq_to_bits_flat(pp, g["samples_per_symbol"], g["bits_per_symbol"], True, g["pause_threshold"])
+        pos, off = positions_from_rows(pp[:, 0], pp[:, 1], DemodParams(g["modulation_type"], g["bits_per_symbol"], 0, 0, 1, 5, g["samples_per_symbol"], 0.1,
+                                                                       g["pause_threshold"], False))
+        assert np.array_equal(pos, want[3]) and np.array_equal(off, want[4]), name

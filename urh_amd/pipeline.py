@@ -202,11 +202,78 @@ class HostBits:
         return np.unpackbits(self.bits_packed, count=self.n_bits) if self.n_bits else np.zeros(0, np.uint8)
 
     def bit_sample_pos(self) -> np.ndarray:
-        return self.pos32.astype(np.int64) if self.pos32 is not None else np.zeros(0, np.int64)
+        """All messages' bit_sample_pos back to back (int64; message m: [pos_offsets()[m], pos_offsets()[m + 1])).  With positions shipped
+        (want_pos) they are the device's; without, they are derived HERE from the pulse table that was shipped -- they are a function
+        of it (ProtocolAnalyzer.py:346-401 computes them from ppseq too), so not shipping them costs no information, only host time
+        when somebody asks."""
+        if self.pos32 is not None:
+            return self.pos32.astype(np.int64)
+        return self._derived_positions()[0]
+
+    def pos_offsets(self) -> np.ndarray:
+        return self.pos_off.copy() if self.pos32 is not None else self._derived_positions()[1]
+
+    def _derived_positions(self):
+        if getattr(self, "_derived", None) is None:
+            self._derived = positions_from_rows(self.row_state, self.row_len, self.params)
+        return self._derived
 
     def flat(self):
         """(bits u8, msg_off i64, pauses i64, pos i64, pos_off i64): what BitsResult.flat() gives"""
-        return self.bits(), self.msg_off.copy(), self.pauses.copy(), self.bit_sample_pos(), self.pos_off.copy()
+        return self.bits(), self.msg_off.copy(), self.pauses.copy(), self.bit_sample_pos(), self.pos_offsets()
+
+
+def positions_from_rows(row_state, row_len, p):
+    """bit_sample_pos of every message from the pulse table, as ProtocolAnalyzer._ppseq_to_bits builds them (:346-411), on whole arrays:
+    (positions int64, back to back; offsets int64[n_msg + 1]).  A message's entries: one position per bit (total_samples + k *
+    samples_per_bit), then [start, end] of the long pause that closed it -- or the capture's total_samples for the trailing message."""
+    st = np.asarray(row_state, dtype=np.int64)
+    ln = np.asarray(row_len, dtype=np.int64)
+    n = len(st)
+    sps, bps, pt = int(p.samples_per_symbol), int(p.bits_per_symbol), int(p.pause_threshold)
+    spb = int(sps / bps)
+    if n == 0:
+        return np.zeros(0, np.int64), np.zeros(1, np.int64)
+    ts = np.concatenate([[0], np.cumsum(ln)[:-1]])              # total_samples before each row
+    q = ln // sps
+    nsym = q + (2 * (ln - q * sps) > sps)                         # int(x) + (fraction > 0.5): exact for these integers
+    pause = st == -1
+    long_pause = pause & (nsym > pt) & (pt != 0)
+    nbits = np.where(long_pause, 0, nsym * bps)
+    data = ~pause & (nsym > 0)
+    if pause[0]:                                                  # "Starts with Pause": only seeds total_samples
+        nbits[0] = 0
+        long_pause[0] = False
+    grp = np.cumsum(long_pause) - long_pause                      # group of each row (a long pause closes its own group)
+    n_grp = int(grp[-1]) + 1
+    has_data = np.bincount(grp[data], minlength=n_grp) > 0
+    # "elif not there_was_data": a long pause after a group without data drops what was gathered; such a group is no message
+    closed = np.zeros(n_grp, dtype=bool)
+    closed[grp[long_pause]] = True
+    close_row = np.full(n_grp, -1, dtype=np.int64)
+    close_row[grp[long_pause]] = np.nonzero(long_pause)[0]
+    kept = has_data
+    row_kept = kept[grp] & (nbits > 0)
+    cnt = nbits[row_kept]
+    per_bit_base = np.repeat(ts[row_kept], cnt)
+    first = np.cumsum(cnt) - cnt
+    k = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(first, cnt)
+    bit_pos = per_bit_base + k * spb
+    bits_per_group = np.bincount(grp[row_kept], weights=cnt, minlength=n_grp).astype(np.int64)
+    msgs = np.nonzero(kept)[0]
+    total_end = int(ts[-1] + ln[-1])
+    out, off = [], [0]
+    bit_cursor = np.concatenate([[0], np.cumsum(bits_per_group[msgs])])
+    for j, g in enumerate(msgs.tolist()):
+        out.append(bit_pos[bit_cursor[j]:bit_cursor[j + 1]])
+        if closed[g]:
+            r = int(close_row[g])
+            out.append(np.array([ts[r], ts[r] + ln[r]], dtype=np.int64))
+        else:
+            out.append(np.array([total_end], dtype=np.int64))
+        off.append(off[-1] + int(bits_per_group[g]) + (2 if closed[g] else 1))
+    pos = np.concatenate(out) if out else np.zeros(0, np.int64)
+    return pos.astype(np.int64), np.asarray(off, dtype=np.int64)
 
 
 class CaptureStream:
