@@ -633,6 +633,11 @@ def main():
         lat.append(time.perf_counter() - t_l)
     d2h_bytes_wide = None
     use_stream = not sharded and args.pipeline and not args.no_d2h
+    # A full collection of Python's cyclic garbage collector takes 30-40 ms in a process that has torch and numpy loaded (a hundred
+    # steps' worth: tools/stream_probe.py caught one inside a timed region): the timed regions run with the collector off.
+    import gc
+    gc.collect()
+    gc.disable()
     if not sharded and not args.no_d2h:
         pinned = {}
         for _ in range(6):
@@ -727,8 +732,9 @@ def main():
                     "between_pushes_us_median": round(t_out[len(t_out) // 2] * 1e6, 1)}
         assert len(results) == args.steps and [r.seq for r in results[-3:]] == sorted(r.seq for r in results[-3:])
         last_host = results[-1].check()
+        stream_stats = st.stats()
         stream_rec = {"single_capture_incl_compact_d2h_ms": round(min(one) * 1e3, 4), "d2h_bytes_per_step": last_host.blob_bytes + 40,
-                      "host_loop": host_rec,
+                      "host_loop": host_rec, "stream_stats": stream_stats,
                       "d2h_format": "compact blob: int32 length + int8 state per pulse-table row, packed bits, int64 pauses / message offsets "
                                     "(include/urhgpu.h); bit_sample_pos derived on the host from the shipped pulse table when asked for"}
         # the last timed step's outputs for the parity record: host copies of the blob's sections + its qad read back from HBM
@@ -750,6 +756,7 @@ def main():
             r_np = stream_steps(args.steps)
             torch.cuda.synchronize()
             stream_rec["ms_per_step_with_device_positions"] = round((time.perf_counter() - t_np) / args.steps * 1e3, 4)
+            stream_rec["with_device_positions_stream_stats"] = st.stats()
             stream_rec["d2h_bytes_per_step_with_device_positions"] = r_np[-1].blob_bytes + 40
             import numpy as np
             stream_rec["device_positions_equal_derived"] = bool(np.array_equal(r_np[-1].bit_sample_pos(), host_copy["flat"][3]) and

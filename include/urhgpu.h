@@ -310,6 +310,9 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
 int urhgpu_stream_destroy(urhgpu_stream *st);
 int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_host_result *ready);
 int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out);
+/* Diagnostics: out4 = {passes pushed, passes whose predicted copy size fell short (their rest was fetched when the result was handed
+ * out), bytes the next copy is sized for, blob capacity}. */
+int urhgpu_stream_stats(urhgpu_stream *st, int64_t *out4);
 
 /* ---- sharded captures: one long capture split sample-contiguously over the GPUs of a node ------------------
  * (there is no reference counterpart: the reference processes a capture in one process.)

@@ -85,3 +85,35 @@ def test_stream_reports_a_truncated_pulse_table(oracle):
     (r,) = st.flush()
     assert not r.truncated and np.array_equal(r.ppseq(), pp)
     st.close()
+
+
+def test_stream_pushed_from_a_side_stream_with_the_capture_produced_there(oracle):
+    """The hot kernel of a pipelined pass runs on a private CU-masked stream of the context: work the caller has queued on ITS stream --
+    here a kernel that produces the capture on a non-default torch stream right before every push -- is ordered before it through an
+    event (from torch's default = NULL stream the runtime's own NULL-stream ordering does it)."""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    n = 1 << 21
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, False)
+    caps = [synth_fsk(n, sps=100, seed=300 + i, noise=0.04, pause_every=n // 3, pause_len=n // 23) for i in range(6)]
+    side = torch.cuda.Stream()
+    got = {}
+    with torch.cuda.stream(side):
+        pipe = DevicePipeline(0, pipelined=True)
+        st = pipe.stream(n, p, want_qad=False, want_pos=False)
+        staging = [torch.from_numpy(c).cuda() for c in caps]
+        work = [torch.empty_like(staging[0]) for _ in range(len(caps))]      # (an input buffer must stay untouched until its pass has run)
+        torch.cuda.synchronize()
+        for i in range(len(caps)):
+            buf = work[i]
+            buf.copy_(staging[i])                       # a kernel on the side stream: the capture is not there before it has run
+            r = st.push(buf)
+            if r is not None:
+                got[r.seq] = (r.check().ppseq(), r.bits(), r.pauses.copy())
+        for r in st.flush():
+            got[r.seq] = (r.check().ppseq(), r.bits(), r.pauses.copy())
+        st.close()
+    for i, iq in enumerate(caps):
+        pp = oracle.grab_pulse_lens(oracle.afp_demod(iq, 0.1, "FSK", 2), 0.0, 5, "FSK", 100, 1, 1.0)
+        bits, off, pauses, pos, poff = oracle.ppseq_to_bits_flat(pp, 100, 1, True, 8)
+        assert np.array_equal(got[i][0], pp) and np.array_equal(got[i][1], bits) and np.array_equal(got[i][2], pauses), i

@@ -19,10 +19,16 @@ pipe = DevicePipeline(0, pipelined=True)
 pipe.reserve(n, p)
 
 
+KEEP = os.environ.get("PROBE_KEEP") == "1"
+
+
 def run(st, k):
+    out = []
     for _ in range(k):
-        st.push(iq)
-    return st.flush()
+        r = st.push(iq)
+        if KEEP and r is not None:
+            out.append(r)
+    return out + st.flush()
 
 
 def measure(want_pos, tag):

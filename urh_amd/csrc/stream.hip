@@ -221,6 +221,12 @@ int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_ho
     return URHGPU_OK;
 }
 
+int urhgpu_stream_stats(urhgpu_stream *st, int64_t *out4) {
+    if (!st || !out4) return URHGPU_ERR_ARG;
+    out4[0] = st->seq; out4[1] = st->short_copies; out4[2] = st->predicted_bytes; out4[3] = st->cap_blob;
+    return URHGPU_OK;
+}
+
 int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out) {
     if (!st || !out3 || !n_out) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(st->ctx->device));

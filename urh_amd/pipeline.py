@@ -173,19 +173,27 @@ class HostBits:
         self.rows_needed, self.truncated, self.blob_bytes = int(r.rows_needed), bool(r.truncated), int(r.blob_bytes)
         self.params = params
         self.d_qad_ptr = r.d_qad
+        # the views are made when somebody looks (a push per 0.3 ms must not allocate a dozen objects each)
+        self._ptr = dict(row_len=(r.row_len, self.n_rows, np.int32), row_state=(r.row_state, self.n_rows, np.int8),
+                         bits_packed=(r.bits_packed, (self.n_bits + 7) // 8, np.uint8), msg_off=(r.msg_off, self.n_msg + 1, np.int64),
+                         pauses=(r.pauses, self.n_msg, np.int64), pos_off=(r.pos_off, self.n_msg + 1, np.int64),
+                         pos32=(r.pos32, self.n_pos, np.uint32) if r.pos32 else None)
 
-        def view(ptr, count, dtype):
+    def __getattr__(self, name):
+        spec = self.__dict__.get("_ptr", {}).get(name, False)
+        if spec is False:
+            raise AttributeError(name)
+        if spec is None:
+            value = None
+        else:
+            ptr, count, dtype = spec
             if not ptr or count <= 0:
-                return np.zeros(0, dtype)
-            nbytes = count * np.dtype(dtype).itemsize
-            return np.frombuffer((C.c_ubyte * nbytes).from_address(ptr), dtype=dtype, count=count)
-        self.row_len = view(r.row_len, self.n_rows, np.int32)
-        self.row_state = view(r.row_state, self.n_rows, np.int8)
-        self.bits_packed = view(r.bits_packed, (self.n_bits + 7) // 8, np.uint8)
-        self.msg_off = view(r.msg_off, self.n_msg + 1, np.int64)
-        self.pauses = view(r.pauses, self.n_msg, np.int64)
-        self.pos_off = view(r.pos_off, self.n_msg + 1, np.int64)
-        self.pos32 = view(r.pos32, self.n_pos, np.uint32) if r.pos32 else None
+                value = np.zeros(0, dtype)
+            else:
+                nbytes = count * np.dtype(dtype).itemsize
+                value = np.frombuffer((C.c_ubyte * nbytes).from_address(ptr), dtype=dtype, count=count)
+        self.__dict__[name] = value
+        return value
 
     def check(self):
         if self.truncated:
@@ -307,6 +315,11 @@ class CaptureStream:
         n = C.c_int(0)
         _lib.check(_lib.load().urhgpu_stream_flush(self._h, arr, C.byref(n)))
         return [HostBits(arr[k], self.params) for k in range(n.value)]
+
+    def stats(self) -> dict:
+        out = (C.c_int64 * 4)()
+        _lib.check(_lib.load().urhgpu_stream_stats(self._h, out))
+        return {"pushed": int(out[0]), "short_copies": int(out[1]), "predicted_bytes": int(out[2]), "blob_capacity": int(out[3])}
 
     def close(self):
         if self._h:
