@@ -186,7 +186,9 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
              const Plan &pl, int seg_mode = 0, hipStream_t s_tail = nullptr, const BitsParams *tile_bp = nullptr,
              TileTailMem *tile_out = nullptr) {
     hipStream_t s = ctx->stream;
-    if (s_tail) URH_TRY(hot_stream_begin(ctx, &s));
+    // the CU-masked hot stream pays for float32 / complex64 captures, whose kernel is bound by the HBM (1-3 % per pipelined step, 5 % for
+    // the kernel on its own); integer captures and wide FSK deviations are VALU-bound and LOSE 2-5 % on 224 CUs (tools/mask_policy_probe.py)
+    if (s_tail && from_iq && p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s));
     if (tile_out) tile_out->mem = nullptr;
     RunArgs a;
     memset(&a, 0, sizeof(a));
