@@ -1,0 +1,4 @@
+#!/bin/bash
+mkdir -p gpurun_out/r3u
+python -m pytest tests/test_gpu_parity.py tests/test_full_size.py tests/test_signal_shim.py tests/test_reference_dropin.py -m gpu -q -x -k "center or estimate or statistic or config3 or config5 or detect or hot_path or signal" 2>&1 | tail -4 | tee gpurun_out/r3u/tests.txt
+PYTHONPATH=. python tools/prof_estimate.py --reps 20 2>&1 | tail -3 | tee gpurun_out/r3u/estimate.txt

@@ -77,6 +77,7 @@ __device__ __forceinline__ const float *me_src(const float *x, const float *kept
 __global__ __launch_bounds__(kMeBlock) void k_me_count(const float *x, const MsgState *st, const MsgTile *tiles, int32_t *tile_cnt) {
     __shared__ int s_w[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
+    if (st[t.msg].kept == st[t.msg].end - st[t.msg].start) return;     // confirmed by k_me_first: its counts stand (their sum is the length)
     const int64_t base = st[t.msg].start + (int64_t)t.idx * kMeTile, end = st[t.msg].end;
     float v[kMePer];
 #pragma unroll
@@ -89,6 +90,82 @@ __global__ __launch_bounds__(kMeBlock) void k_me_count(const float *x, const Msg
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+
+// ---- stage 1, speculative form: ONE pass that counts AND -- assuming nothing will be filtered (ASK magnitudes never are; an FSK / PSK
+// message without a single noise sample is not either) -- takes min / max and the first-round leaf sums (np.mean) of the trimmed range.
+// With k = len the trim is known up front (a = int(0.05 len), L = int(0.95 len) - a), so tile t reads the window [a + 4096 t, a + 4096
+// (t + 1)) of its message in the leaf geometry of k_me_leaves (8 threads per 128-element leaf) and counts x > -4 there; the head [0, a)
+// of the message is counted in slices, one per tile.  When the count confirms k == len the separate min / max pass and the first leaf
+// pass are skipped (k_me_minmax, k_me_leaves mode 0 return at once); otherwise the message's tiles are counted again in their natural
+// ranges (k_me_count, which skips confirmed messages) and the general path runs as before.  Three passes over a clean message
+// instead of five.
+__global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, const MsgState *st, const MsgTile *tiles, int32_t *tile_cnt, float2 *tile_mm,
+                                                        float *leaf_sums) {
+    __shared__ int s_c[kMeBlock / 64];
+    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
+    const MsgTile t = tiles[blockIdx.x];
+    const MsgState m = st[t.msg];
+    const int64_t len = m.end - m.start;
+    const int64_t a = (int64_t)(0.05 * (double)len), b = (int64_t)(0.95 * (double)len);       // k_me_trim's arithmetic with k = len
+    const int64_t L = b > a ? b - a : 0;
+    const int64_t nt = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
+    const float *src = x + m.start;
+    const int lf = threadIdx.x >> 3, j = threadIdx.x & 7;
+    const int64_t q0 = (int64_t)t.idx * kMeTile + (int64_t)lf * kPwLeafM + j;                  // index in the trimmed range of this thread's first element
+    float v[kPwLeafM / 8];
+#pragma unroll
+    for (int i = 0; i < kPwLeafM / 8; ++i) { const int64_t s = a + q0 + 8 * i; v[i] = (s < len) ? src[s] : -5.0f; }
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < kPwLeafM / 8; ++i) c += (v[i] > -4.0f) ? 1 : 0;
+    // the head [0, a): slice t of nt
+    if (a > 0) {
+        const int64_t h = (a + nt - 1) / nt, h0 = (int64_t)t.idx * h, h1 = (h0 + h < a) ? h0 + h : a;
+        for (int64_t k = h0 + threadIdx.x; k < h1; k += kMeBlock) c += (src[k] > -4.0f) ? 1 : 0;
+    }
+    // min / max over the elements inside the trimmed range, seeded with its first element (util.minmax: a NaN there stays)
+    const bool any = L > 0 && (int64_t)t.idx * kMeTile < L;
+    const float first = L > 0 ? src[a] : 0.f;
+    float mn = first, mx = first;
+#pragma unroll
+    for (int i = 0; i < kPwLeafM / 8; ++i) {
+        const float w = (q0 + 8 * i < L) ? v[i] : first;
+        if (w < mn) mn = w;
+        if (w > mx) mx = w;
+    }
+    // leaf sums of the FULL chunks (k_me_leaves, mode 0): accumulator j of the leaf, then ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+    const int64_t n_full_leaves = (L / kPwChunkM) * (kPwChunkM / kPwLeafM);
+    const int64_t leaf = (int64_t)t.idx * kLeavesPerTile + lf;
+    float acc = v[0];
+#pragma unroll
+    for (int i = 1; i < kPwLeafM / 8; ++i) acc += v[i];
+    acc = acc + __shfl_down(acc, 1);
+    acc = acc + __shfl_down(acc, 2);
+    acc = acc + __shfl_down(acc, 4);
+    if (leaf < n_full_leaves && j == 0) leaf_sums[m.first_tile * kLeavesPerTile + leaf] = acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        c += __shfl_xor(c, o);
+        const float u = __shfl_xor(mn, o), w = __shfl_xor(mx, o);
+        if (u < mn) mn = u;
+        if (w > mx) mx = w;
+    }
+    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = c; s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tile_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+        for (int w = 1; w < kMeBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
+        if (any) tile_mm[blockIdx.x] = float2{mn, mx};
+    }
+}
+// after the scan of k_me_first's counts: kept of every message; a message whose count differs from its length is counted again in
+// natural tiles (k_me_count) for the compaction
+__global__ void k_me_spec(MsgState *st, int n_msgs, const int64_t *tile_pre) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_msgs) return;
+    const int64_t len = st[m].end - st[m].start, nt = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
+    st[m].kept = tile_pre[st[m].first_tile + nt] - tile_pre[st[m].first_tile];
 }
 
 // exclusive prefix of the per-tile counts over the whole tile table (ONE workgroup: the table has n / 4096 entries); a tile's
@@ -176,6 +253,7 @@ __global__ __launch_bounds__(kMeBlock) void k_me_minmax(const float *x, const fl
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
     if (m.L <= 0 || (int64_t)t.idx * kMeTile >= m.L) return;
+    if (m.kept == m.end - m.start) return;                   // nothing filtered: k_me_first has written this tile's min / max
     const float *r = me_src(x, kept, m) + m.a;
     const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
     const float first = r[0];                                // the seed of every partial fold: a NaN there stays (as in util.minmax)
@@ -240,6 +318,7 @@ __global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *x, const fl
                                                          float *leaf_sums) {
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
+    if (mode == 0 && m.kept == m.end - m.start) return;      // nothing filtered: k_me_first has written these leaf sums
     const int64_t n_full_leaves = (m.L / kPwChunkM) * (kPwChunkM / kPwLeafM);
     const int64_t leaf = (int64_t)t.idx * kLeavesPerTile + (threadIdx.x >> 3);
     const int j = threadIdx.x & 7;
@@ -743,7 +822,10 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
     URH_HIP(hipMemsetAsync(d_hist, 0, (size_t)n_msgs * (size_t)max_bins * 4, s));
     const unsigned gt = (unsigned)b.n_tiles, gm = (unsigned)((n_msgs + 63) / 64);
-    hipLaunchKernelGGL(k_me_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
+    hipLaunchKernelGGL(k_me_first, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_mm, d_leaf);
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
+    hipLaunchKernelGGL(k_me_spec, dim3(gm), dim3(64), 0, s, d_st, n_msgs, d_pre);
+    hipLaunchKernelGGL(k_me_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);          // (messages with filtered samples only)
     hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
     hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_kept);
     hipLaunchKernelGGL(k_me_trim, dim3(gm), dim3(64), 0, s, d_st, n_msgs);
