@@ -48,7 +48,10 @@ struct MsgState {            // one per message, device resident between the sta
     double center;           // center handed to urhgpu_msg_plateaus (NaN: none)
     double peak_center;      // urhgpu_msg_center_stats: center picked from the histogram (k_me_peaks)
     int64_t peak_flag;       // 0 none, 1 peak_center valid, 2 more bins than the pool holds, 3 equally populated peaks compete for a slot
+    int64_t skip;            // 1: the message's first sample is filtered (x <= -4: afp_demod's result[0] = NOISE of FSK / PSK) -- k_me_first
 };
+// nothing filtered but (possibly) the first sample: the kept samples ARE x[start + skip : end], no compaction needed
+__host__ __device__ inline bool me_clean(const MsgState &m) { return m.kept == (m.end - m.start) - m.skip; }
 
 // Tile geometry: thread `tid` of a tile looks at samples j * 256 + tid (j = 0..15): every load instruction of a wavefront reads 256
 // consecutive bytes.  Order-preserving work (the compaction, the boundary lists) ranks a sample by (row j, wavefront, lane) from
@@ -70,14 +73,14 @@ __device__ __forceinline__ int me_cell_scan(int *s_cell, int *s_total) {
 }
 // samples of a message after the x > -4 filter: the capture itself when nothing was filtered (ASK magnitudes: always)
 __device__ __forceinline__ const float *me_src(const float *x, const float *kept, const MsgState &m) {
-    return (m.kept == m.end - m.start) ? x + m.start : kept + m.start;
+    return me_clean(m) ? x + m.start + m.skip : kept + m.start;
 }
 
 // ---- stage 1: stable compaction of x > -4 per message into kept[start + j] ----------------------------------------------
 __global__ __launch_bounds__(kMeBlock) void k_me_count(const float *x, const MsgState *st, const MsgTile *tiles, int32_t *tile_cnt) {
     __shared__ int s_w[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
-    if (st[t.msg].kept == st[t.msg].end - st[t.msg].start) return;     // confirmed by k_me_first: its counts stand (their sum is the length)
+    if (me_clean(st[t.msg])) return;                          // confirmed by k_me_first: its counts stand (their sum is the kept count)
     const int64_t base = st[t.msg].start + (int64_t)t.idx * kMeTile, end = st[t.msg].end;
     float v[kMePer];
 #pragma unroll
@@ -96,21 +99,26 @@ __global__ __launch_bounds__(kMeBlock) void k_me_count(const float *x, const Msg
 // message without a single noise sample is not either) -- takes min / max and the first-round leaf sums (np.mean) of the trimmed range.
 // With k = len the trim is known up front (a = int(0.05 len), L = int(0.95 len) - a), so tile t reads the window [a + 4096 t, a + 4096
 // (t + 1)) of its message in the leaf geometry of k_me_leaves (8 threads per 128-element leaf) and counts x > -4 there; the head [0, a)
-// of the message is counted in slices, one per tile.  When the count confirms k == len the separate min / max pass and the first leaf
-// pass are skipped (k_me_minmax, k_me_leaves mode 0 return at once); otherwise the message's tiles are counted again in their natural
+// of the message is counted in slices, one per tile.  When the count confirms k == len the first leaf
+// pass is skipped (k_me_leaves mode 0 returns at once); otherwise the message's tiles are counted again in their natural
 // ranges (k_me_count, which skips confirmed messages) and the general path runs as before.  Three passes over a clean message
 // instead of five.
-__global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, const MsgState *st, const MsgTile *tiles, int32_t *tile_cnt, float2 *tile_mm,
+__global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState *st, const MsgTile *tiles, int32_t *tile_cnt, float2 *tile_mm,
                                                         float *leaf_sums) {
     __shared__ int s_c[kMeBlock / 64];
     __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
-    const int64_t len = m.end - m.start;
+    // The demodulated signal of an FSK / PSK capture STARTS with a filtered sample (result[0] = NOISE = -4, signal_functions.pyx:361): the
+    // speculation is "nothing is filtered but, possibly, the first sample" -- the kept samples are then x[start + skip : end], contiguous.
+    const int64_t skip = (m.end > m.start && !(x[m.start] > -4.0f)) ? 1 : 0;
+    if (t.idx == 0 && threadIdx.x == 0) st[t.msg].skip = skip;
+    const int64_t len = m.end - m.start - skip;
     const int64_t a = (int64_t)(0.05 * (double)len), b = (int64_t)(0.95 * (double)len);       // k_me_trim's arithmetic with k = len
     const int64_t L = b > a ? b - a : 0;
-    const int64_t nt = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
-    const float *src = x + m.start;
+    const int64_t full = m.end - m.start;
+    const int64_t nt = ((full > 1 ? full : 1) + kMeTile - 1) / kMeTile;       // tiles of the message (build_batch)
+    const float *src = x + m.start + skip;
     const int lf = threadIdx.x >> 3, j = threadIdx.x & 7;
     const int64_t q0 = (int64_t)t.idx * kMeTile + (int64_t)lf * kPwLeafM + j;                  // index in the trimmed range of this thread's first element
     float v[kPwLeafM / 8];
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgStat
     const int64_t len = end - start, n_tiles = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
     const int64_t kept_total = tile_pre[first_tile + n_tiles] - tile_pre[first_tile];
     if (threadIdx.x == 0 && t.idx == n_tiles - 1) st[t.msg].kept = kept_total;
-    if (kept_total == len) return;                           // nothing filtered: the later stages read the capture (me_src)
+    if (kept_total == len - st[t.msg].skip) return;          // nothing filtered (but the first sample): the later stages read the capture (me_src)
     const int64_t before = tile_pre[blockIdx.x] - tile_pre[first_tile];         // kept samples in the message's earlier tiles
     const int64_t base = start + (int64_t)t.idx * kMeTile;
     const int wave = threadIdx.x >> 6;
@@ -248,46 +256,30 @@ __global__ void k_me_trim(MsgState *st, int n_msgs) {
 }
 
 // ---- stage 3: min / max (util.minmax: seeded with element 0, `<` / `>` folds -- NaN never replaces a value) ----------------
-__global__ __launch_bounds__(kMeBlock) void k_me_minmax(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, float2 *tile_mm) {
-    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
-    const MsgTile t = tiles[blockIdx.x];
-    const MsgState m = st[t.msg];
-    if (m.L <= 0 || (int64_t)t.idx * kMeTile >= m.L) return;
-    if (m.kept == m.end - m.start) return;                   // nothing filtered: k_me_first has written this tile's min / max
-    const float *r = me_src(x, kept, m) + m.a;
-    const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
-    const float first = r[0];                                // the seed of every partial fold: a NaN there stays (as in util.minmax)
-    float v[kMePer];
-#pragma unroll
-    for (int j = 0; j < kMePer; ++j) { const int64_t i = i0 + (int64_t)j * kMeBlock; v[j] = (i < m.L) ? r[i] : first; }
-    float mn = first, mx = first;
-#pragma unroll
-    for (int j = 0; j < kMePer; ++j) { if (v[j] < mn) mn = v[j]; if (v[j] > mx) mx = v[j]; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
-        if (a < mn) mn = a;
-        if (b > mx) mx = b;
-    }
-    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kMeBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
-        tile_mm[blockIdx.x] = float2{mn, mx};
-    }
-}
+// Per-tile partials come out of the pass that reads the samples anyway: k_me_first for messages without filtered samples (tile t = window
+// [4096 t, 4096 (t + 1)) of the trimmed range), k_me_leaves (mode 0) for the others (tile t = the 32 full leaves it sums); the
+// irregular rest of those (< 8192 elements behind the full chunks) is folded in by k_me_minmax_fin itself.
 constexpr int kMeFinBlock = 1024;            // one message can be the whole capture: 32 768 tiles
 __global__ __launch_bounds__(kMeFinBlock) void k_me_minmax_fin(MsgState *st, const float2 *tile_mm, const float *x, const float *kept) {
     __shared__ float s_mn[kMeFinBlock / 64], s_mx[kMeFinBlock / 64];
     const int m = blockIdx.x;
     MsgState s = st[m];
     if (s.L <= 0) return;
-    const int64_t nt = (s.L + kMeTile - 1) / kMeTile;
-    float mn = me_src(x, kept, s)[s.a], mx = mn;
+    const bool spec = me_clean(s);                           // partials by k_me_first (every tile of the trimmed range) or by k_me_leaves (full chunks)
+    const int64_t nt = spec ? (s.L + kMeTile - 1) / kMeTile : (s.L / kPwChunkM) * (kPwChunkM / kMeTile);
+    const float *r = me_src(x, kept, s) + s.a;
+    float mn = r[0], mx = mn;
     for (int64_t u = threadIdx.x; u < nt; u += kMeFinBlock) {
         const float2 p = tile_mm[s.first_tile + u];
         if (p.x < mn) mn = p.x;
         if (p.y > mx) mx = p.y;
+    }
+    if (!spec) {
+        for (int64_t i = (s.L / kPwChunkM) * kPwChunkM + threadIdx.x; i < s.L; i += kMeFinBlock) {
+            const float v = r[i];
+            if (v < mn) mn = v;
+            if (v > mx) mx = v;
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -315,15 +307,39 @@ __device__ __forceinline__ float me_elem(const float *r, int64_t i, int mode, fl
 }
 // leaf sums of the FULL chunks: 8 threads per leaf (one per accumulator), 32 leaves per tile
 __global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int mode,
-                                                         float *leaf_sums) {
+                                                         float *leaf_sums, float2 *tile_mm) {
+    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
-    if (mode == 0 && m.kept == m.end - m.start) return;      // nothing filtered: k_me_first has written these leaf sums
+    if (mode == 0 && me_clean(m)) return;                    // nothing filtered: k_me_first has written these leaf sums
     const int64_t n_full_leaves = (m.L / kPwChunkM) * (kPwChunkM / kPwLeafM);
     const int64_t leaf = (int64_t)t.idx * kLeavesPerTile + (threadIdx.x >> 3);
     const int j = threadIdx.x & 7;
     float acc = 0.f;
     const bool live = leaf < n_full_leaves;
+    if (mode == 0 && (int64_t)t.idx * kLeavesPerTile < n_full_leaves) {
+        // the tile's min / max from the elements this pass reads anyway (workgroup-uniform branch: a tile of full leaves)
+        const float *r0 = me_src(x, kept, m) + m.a;
+        const float first = r0[0];
+        float mn = first, mx = first;
+        if (live) {
+            const float *r = r0 + leaf * kPwLeafM;
+#pragma unroll
+            for (int i = 0; i < kPwLeafM; i += 8) { const float v = r[i + j]; if (v < mn) mn = v; if (v > mx) mx = v; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float u = __shfl_xor(mn, o), w = __shfl_xor(mx, o);
+            if (u < mn) mn = u;
+            if (w > mx) mx = w;
+        }
+        if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kMeBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
+            tile_mm[blockIdx.x] = float2{mn, mx};
+        }
+    }
     if (live) {
         const float *r = me_src(x, kept, m) + m.a + leaf * kPwLeafM;
         acc = me_elem(r, j, mode, m.mean);
@@ -829,10 +845,9 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
     hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_kept);
     hipLaunchKernelGGL(k_me_trim, dim3(gm), dim3(64), 0, s, d_st, n_msgs);
-    hipLaunchKernelGGL(k_me_minmax, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, d_mm);
-    hipLaunchKernelGGL(k_me_minmax_fin, dim3((unsigned)n_msgs), dim3(kMeFinBlock), 0, s, d_st, d_mm, d_x, d_kept);
     for (int mode = 0; mode < 2; ++mode) {
-        hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, mode, d_leaf);
+        hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, mode, d_leaf, d_mm);
+        if (mode == 0) hipLaunchKernelGGL(k_me_minmax_fin, dim3((unsigned)n_msgs), dim3(kMeFinBlock), 0, s, d_st, d_mm, d_x, d_kept);
         hipLaunchKernelGGL(k_me_chunk_trees, dim3(gt), dim3(64), 0, s, d_st, d_tiles, d_leaf, d_chunk);
         hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeRestSlots), 0, s, d_x, d_kept, d_st, d_chunk, mode);
     }
