@@ -469,8 +469,8 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
     URH_TRY(urhgpu_ctx_sync(ctx));
     if (ctx->own_tail_stream && ctx->tail_stream) { (void)hipStreamDestroy(ctx->tail_stream); }
     ctx->tail_stream = nullptr; ctx->own_tail_stream = false; ctx->pipelined = false;
-    if (!enable) return URHGPU_OK;
     if (ctx->hot_masked) { (void)hipStreamSynchronize(ctx->hot_masked); (void)hipStreamDestroy(ctx->hot_masked); ctx->hot_masked = nullptr; }
+    if (!enable) return URHGPU_OK;
     if (tail_stream) ctx->tail_stream = (hipStream_t)tail_stream;
     else {
         if (ctx->tune_tail_priority) {                     // urhgpu_ctx_set_tuning("tail_priority", 1): the device's highest stream priority
