@@ -76,36 +76,18 @@ __device__ __forceinline__ const float *me_src(const float *x, const float *kept
     return me_clean(m) ? x + m.start + m.skip : kept + m.start;
 }
 
-// ---- stage 1: stable compaction of x > -4 per message into kept[start + j] ----------------------------------------------
-__global__ __launch_bounds__(kMeBlock) void k_me_count(const float *x, const MsgState *st, const MsgTile *tiles, int32_t *tile_cnt) {
-    __shared__ int s_w[kMeBlock / 64];
-    const MsgTile t = tiles[blockIdx.x];
-    if (me_clean(st[t.msg])) return;                          // confirmed by k_me_first: its counts stand (their sum is the kept count)
-    const int64_t base = st[t.msg].start + (int64_t)t.idx * kMeTile, end = st[t.msg].end;
-    float v[kMePer];
-#pragma unroll
-    for (int j = 0; j < kMePer; ++j) { const int64_t i = base + j * kMeBlock + threadIdx.x; v[j] = (i < end) ? x[i] : -5.0f; }
-    int c = 0;
-#pragma unroll
-    for (int j = 0; j < kMePer; ++j) c += (v[j] > -4.0f) ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
+// ---- stage 1: count x > -4 per natural tile, stable compaction per message into kept[start + j] -----------------------------
 // ---- stage 1, speculative form: ONE pass that counts AND -- assuming nothing will be filtered (ASK magnitudes never are; an FSK / PSK
 // message without a single noise sample is not either) -- takes min / max and the first-round leaf sums (np.mean) of the trimmed range.
 // With k = len the trim is known up front (a = int(0.05 len), L = int(0.95 len) - a), so tile t reads the window [a + 4096 t, a + 4096
 // (t + 1)) of its message in the leaf geometry of k_me_leaves (8 threads per 128-element leaf) and counts x > -4 there; the head [0, a)
 // of the message is counted in slices, one per tile.  When the count confirms k == len the first leaf
-// pass is skipped (k_me_leaves mode 0 returns at once); otherwise the message's tiles are counted again in their natural
-// ranges (k_me_count, which skips confirmed messages) and the general path runs as before.  Three passes over a clean message
-// instead of five.
+// pass is skipped (k_me_leaves mode 0 returns at once); otherwise the general path runs on the counts this pass has left per natural
+// tile (compaction, then the leaf passes).  Three passes over a clean message instead of five; five reads and one write instead of
+// six and one over a message with filtered samples.
 __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState *st, const MsgTile *tiles, int32_t *tile_cnt, float2 *tile_mm,
                                                         float *leaf_sums) {
-    __shared__ int s_c[kMeBlock / 64];
+    __shared__ int s_c[4 * (kMeBlock / 64)];
     __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
@@ -124,13 +106,26 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
     float v[kPwLeafM / 8];
 #pragma unroll
     for (int i = 0; i < kPwLeafM / 8; ++i) { const int64_t s = a + q0 + 8 * i; v[i] = (s < len) ? src[s] : -5.0f; }
-    int c = 0;
+    // The counts are kept per NATURAL tile of the message (samples [4096 u, 4096 (u + 1)) from its start) although the reads are not
+    // aligned to them: the compaction of a message that does have filtered samples needs those, and this way nobody reads the message
+    // a second time just to count.  A window meets two natural tiles, a head slice (at most 5 % of 4096 samples) two as well.
+    const int64_t wa = (skip + a + (int64_t)t.idx * kMeTile) / kMeTile;         // natural tile of the window's first sample
+    int c[4] = {0, 0, 0, 0};                               // window: tiles wa, wa + 1; head slice: tiles ha, ha + 1
 #pragma unroll
-    for (int i = 0; i < kPwLeafM / 8; ++i) c += (v[i] > -4.0f) ? 1 : 0;
-    // the head [0, a): slice t of nt
-    if (a > 0) {
+    for (int i = 0; i < kPwLeafM / 8; ++i) {
+        const int hit = (v[i] > -4.0f) ? 1 : 0;
+        const bool second = (skip + a + q0 + 8 * i) / kMeTile != wa;
+        c[0] += second ? 0 : hit; c[1] += second ? hit : 0;
+    }
+    int64_t ha = 0;
+    if (a > 0) {                                           // the head [0, a): slice t of nt
         const int64_t h = (a + nt - 1) / nt, h0 = (int64_t)t.idx * h, h1 = (h0 + h < a) ? h0 + h : a;
-        for (int64_t k = h0 + threadIdx.x; k < h1; k += kMeBlock) c += (src[k] > -4.0f) ? 1 : 0;
+        ha = (skip + h0) / kMeTile;
+        for (int64_t k = h0 + threadIdx.x; k < h1; k += kMeBlock) {
+            const int hit = (src[k] > -4.0f) ? 1 : 0;
+            const bool second = (skip + k) / kMeTile != ha;
+            c[2] += second ? 0 : hit; c[3] += second ? hit : 0;
+        }
     }
     // min / max over the elements inside the trimmed range, seeded with its first element (util.minmax: a NaN there stays)
     const bool any = L > 0 && (int64_t)t.idx * kMeTile < L;
@@ -154,21 +149,30 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
     if (leaf < n_full_leaves && j == 0) leaf_sums[m.first_tile * kLeavesPerTile + leaf] = acc;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-        c += __shfl_xor(c, o);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] += __shfl_xor(c[k], o);
         const float u = __shfl_xor(mn, o), w = __shfl_xor(mx, o);
         if (u < mn) mn = u;
         if (w > mx) mx = w;
     }
-    if ((threadIdx.x & 63) == 0) { s_c[threadIdx.x >> 6] = c; s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s_c[(threadIdx.x >> 6) * 4 + k] = c[k];
+        s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx;
+    }
     __syncthreads();
+    if (threadIdx.x < 4) {                                 // thread k: counter k of the workgroup -> its natural tile (tile_cnt is zeroed before the launch)
+        const int k = threadIdx.x;
+        const int total = s_c[k] + s_c[4 + k] + s_c[8 + k] + s_c[12 + k];
+        const int64_t u = (k < 2 ? wa : ha) + (k & 1);
+        if (total > 0 && u < nt) atomicAdd(&tile_cnt[m.first_tile + u], total);
+    }
     if (threadIdx.x == 0) {
-        tile_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
         for (int w = 1; w < kMeBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
         if (any) tile_mm[blockIdx.x] = float2{mn, mx};
     }
 }
-// after the scan of k_me_first's counts: kept of every message; a message whose count differs from its length is counted again in
-// natural tiles (k_me_count) for the compaction
+// after the scan of k_me_first's counts: kept of every message
 __global__ void k_me_spec(MsgState *st, int n_msgs, const int64_t *tile_pre) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_msgs) return;
@@ -838,11 +842,10 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
     URH_HIP(hipMemsetAsync(d_hist, 0, (size_t)n_msgs * (size_t)max_bins * 4, s));
     const unsigned gt = (unsigned)b.n_tiles, gm = (unsigned)((n_msgs + 63) / 64);
+    URH_HIP(hipMemsetAsync(d_cnt, 0, (size_t)b.n_tiles * 4, s));
     hipLaunchKernelGGL(k_me_first, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_mm, d_leaf);
     hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
     hipLaunchKernelGGL(k_me_spec, dim3(gm), dim3(64), 0, s, d_st, n_msgs, d_pre);
-    hipLaunchKernelGGL(k_me_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);          // (messages with filtered samples only)
-    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
     hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_kept);
     hipLaunchKernelGGL(k_me_trim, dim3(gm), dim3(64), 0, s, d_st, n_msgs);
     for (int mode = 0; mode < 2; ++mode) {
