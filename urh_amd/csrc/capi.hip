@@ -502,8 +502,13 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
             const int c = ((i % 8) - (i / 32) + 8) % 8, k = (i / 8) % 4;
             if (c * 4 + k >= ctx->tune_hot_cus_removed) mask[i / 32] |= 1u << (i % 32);
         }
-        URH_HIP(hipExtStreamCreateWithCUMask(&ctx->hot_masked, (uint32_t)words, mask));
-        if (!ctx->ev_in) URH_HIP(hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming));
+        // (a runtime that cannot make the masked stream is no reason to fail: the hot kernel then runs on the caller's stream as before)
+        if (hipExtStreamCreateWithCUMask(&ctx->hot_masked, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ctx->hot_masked = nullptr; }
+        if (ctx->hot_masked && !ctx->ev_in && hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamDestroy(ctx->hot_masked);
+            ctx->hot_masked = nullptr;
+        }
     }
     ctx->pipelined = true;
     return URHGPU_OK;
