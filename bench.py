@@ -613,9 +613,23 @@ def main():
     pipe.reserve(n, p)
     want_qad = not args.bits_only
 
+    # Sharded runs: every rank but the first holds the two samples before its shard as well (the end of the previous rank's last segment,
+    # 16 bytes a loader reads with the shard), so a pass needs two all-gathers -- summaries, flags -- and no halo exchange;
+    # URH_BENCH_HALO_EXCHANGE=1 exchanges the halos instead (three all-gathers).  The FIR variant filters first: its halo is exchanged.
+    halo_given = sharded and fir_taps is None and os.environ.get("URH_BENCH_HALO_EXCHANGE") != "1"
+    left_halo = None
+    if halo_given and rank > 0:
+        prev, _ = (fsk_capture if args.torch_capture else spec_fsk_capture)(1, dev, **(dict(seed=1234, sps=sps, first_segment=rank * args.segments - 1)
+                                                                                   if args.torch_capture else
+                                                                                   dict(first_segment=rank * args.segments - 1, sps=sps)))
+        left_halo = prev[-2:].clone()
+        del prev
+
     def step():
-        x = pipe.fir_filter(iq, fir_taps) if fir_taps is not None else iq
-        return pipe.iq_to_bits(x, p, want_qad=want_qad)
+        if sharded:
+            x = pipe.fir_filter(iq, fir_taps) if fir_taps is not None else iq
+            return pipe.iq_to_bits(x, p, want_qad=want_qad, halo_given=halo_given, left_halo=left_halo)
+        return pipe.iq_to_bits(iq, p, want_qad=want_qad)
 
     for _ in range(args.warmup):
         res = step()
@@ -867,7 +881,9 @@ def main():
                        "single_step_plus_wide_d2h_ms": round(min(lat_d2h) * 1e3, 4) if lat_d2h else None, "wide_d2h_bytes": d2h_bytes_wide,
                        **stream_rec,
                        "unpipelined_ms_per_step": round(alone_ms, 4) if alone_ms is not None else None,
-                       "rccl_world_size": world if dist else None, "ranks": ranks_info},
+                       "rccl_world_size": world if dist else None,
+                       "all_gathers_per_pass": (None if not sharded else (2 if halo_given else 3) + (1 if fir_taps is not None else 0)),
+                       "ranks": ranks_info},
             "roofline": {"bound": "hbm", "kernel": "k_demod_runs_bp", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": n * bytes_per_sample,

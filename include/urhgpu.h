@@ -320,6 +320,8 @@ int urhgpu_stream_stats(urhgpu_stream *st, int64_t *out4);
  * all-gathers a few bytes per rank (urh_amd/sharding.py does it with torch.distributed = RCCL over xGMI):
  *
  *   halo    : the last 2 IQ samples of every shard                          -> d_left_halo of the next rank
+ *             (not exchanged at all when whoever distributed the capture gave every rank the two samples before its shard:
+ *             urhgpu_shard_launch_dev; a pass then needs two all-gathers, ASK three)
  *   runs    : hot kernel on the shard + its 72-byte summary (d_summary out) -> all-gather -> d_summaries
  *   rows    : this rank's pulse-table rows; ASK: d_merge (5 x int64) out    -> all-gather -> d_merge_all
  *   prepare : cross-shard ASK merge, per-row scan; d_flags (3 x int64) out  -> all-gather -> d_flags_all
@@ -346,6 +348,10 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
  * context's stream never waits for a collective. */
 int urhgpu_shard_prelaunch_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
                                int rank, int world, const urhgpu_params *p, const urhgpu_outputs *out);
+/* The halo is known up front (d_left_halo: the two samples before the shard, NULL on rank 0): the whole hot launch, on the context's
+ * stream (pipelined contexts: their hot stream); urhgpu_shard_runs_dev (same arguments) then only adds the summary. */
+int urhgpu_shard_launch_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
+                            int rank, int world, const void *d_left_halo, const urhgpu_params *p, const urhgpu_outputs *out);
 int urhgpu_shard_rows_dev(urhgpu_ctx *ctx, const void *d_summaries, int64_t *d_merge);
 int urhgpu_shard_bits_prepare_dev(urhgpu_ctx *ctx, const int64_t *d_merge_all, int64_t *d_flags);
 int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all);

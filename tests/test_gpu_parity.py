@@ -383,12 +383,14 @@ def test_sharded_equals_single_gpu(pipe, oracle, mod, world):
         cuts = [0] + sorted(int(c) * 8 for c in rng.choice(np.arange(1, n // 8), size=world - 1, replace=False)) + [n]
         for bounds in (shard_bounds(n, world), [(cuts[r], cuts[r + 1]) for r in range(world)]):
             shards = [dev_iq[a:b] for a, b in bounds]
-            res = run_threads(world, lambda r: GpuShardEngine(0), shards, bounds, n, p)
-            got = stitch(res)
-            for k, (a, b) in enumerate(zip(got, want)):
-                assert np.array_equal(a, b), (mod, world, n, bounds, k, len(a), len(b))
-            got_qad = np.concatenate([r.qad.cpu().numpy() for r in res])
-            assert bits_equal(got_qad, want_qad)
+            # the halo through the first exchange, and handed over with the shard (urhgpu_shard_launch_dev: no halo exchange)
+            for halos in (None, [None] + [dev_iq[a - 2:a].clone() for a, _ in bounds[1:]]):
+                res = run_threads(world, lambda r: GpuShardEngine(0), shards, bounds, n, p, halos)
+                got = stitch(res)
+                for k, (a, b) in enumerate(zip(got, want)):
+                    assert np.array_equal(a, b), (mod, world, n, bounds, halos is not None, k, len(a), len(b))
+                got_qad = np.concatenate([r.qad.cpu().numpy() for r in res])
+                assert bits_equal(got_qad, want_qad)
 
 
 # ---- filters, magnitudes, noise estimator ------------------------------------------------------------------
@@ -1342,8 +1344,9 @@ def test_get_protocol_from_signal_goldens(pipe):
 @pytest.mark.parametrize("mod", ["FSK", "ASK"])
 def test_sharded_pipelined_passes(pipe, mod):
     """The sharded path in pipelined mode (bench.py uses it for --gpus N > 1: the exchange-laden tail of a pass overlaps the hot
-    kernel of the next one): three back-to-back passes per rank over two alternating captures, two simulated ranks with
-    persistent pipelined engines; every pass equals the single-GPU result."""
+    kernel of the next one): four back-to-back passes per rank over two alternating captures, two simulated ranks with
+    persistent pipelined engines, the halo exchanged (even passes) or handed over with the shard (odd passes); every pass equals the
+    single-GPU result."""
     import threading
     import torch
     from urh_amd.pipeline import DemodParams
@@ -1362,15 +1365,18 @@ def test_sharded_pipelined_passes(pipe, mod):
         want = (single.ppseq().copy(),) + tuple(x.copy() for x in single.flat())
         caps.append((dev, p, want, single.qad.cpu().numpy().copy(), shard_bounds(n, world), n))
     shared = ThreadComm.Shared(world)
-    results, err = [[None] * world for _ in range(3)], []
+    n_it = 4
+    results, err = [[None] * world for _ in range(n_it)], []
 
     def work(r):
         try:
             sp = ShardedPipeline(GpuShardEngine(0, pipelined=True), ThreadComm(shared, r))
-            for it in range(3):
-                dev, p, _, _, bounds, n = caps[it % 2]
+            for it in range(n_it):
+                dev, p, _, _, bounds, n = caps[(it // 2) % 2] if it >= 2 else caps[it % 2]
                 a, b = bounds[r]
-                res = sp.iq_to_bits(dev[a:b], p, want_qad=True, pos_base=a, n_total=n)
+                given = it % 2 == 1
+                res = sp.iq_to_bits(dev[a:b], p, want_qad=True, pos_base=a, n_total=n, halo_given=given,
+                                    left_halo=dev[a - 2:a].clone() if given and r > 0 else None)
                 results[it][r] = (res.piece(), res.qad.cpu().numpy().copy())
         except BaseException as e:          # noqa: BLE001 -- re-raised in the main thread
             err.append(e)
@@ -1382,8 +1388,8 @@ def test_sharded_pipelined_passes(pipe, mod):
         t.join()
     if err:
         raise err[0]
-    for it in range(3):
-        _, _, want, want_qad, _, _ = caps[it % 2]
+    for it in range(n_it):
+        _, _, want, want_qad, _, _ = caps[(it // 2) % 2] if it >= 2 else caps[it % 2]
         got = stitch([results[it][r][0] for r in range(world)])
         for k, (x, y) in enumerate(zip(got, want)):
             assert np.array_equal(x, y), (mod, it, k, len(x), len(y))

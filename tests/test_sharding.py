@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 import model_shard
+import torch
 from urh_amd.pipeline import DemodParams
 from urh_amd.sharding import ShardedPipeline, ThreadComm, TorchDistComm, shard_bounds, stitch
 
@@ -27,15 +28,17 @@ def _signal(rng, n, mod, bps, noise_val):
     return x
 
 
-def run_threads(world, make_engine, shards, bounds, n_total, p):
-    """Run the sharded protocol with `world` ranks as threads; returns the per-rank results."""
+def run_threads(world, make_engine, shards, bounds, n_total, p, halos=None):
+    """Run the sharded protocol with `world` ranks as threads; returns the per-rank results.
+    halos: per rank, the samples before its shard (None for rank 0) -> no halo exchange (halo_given)."""
     shared = ThreadComm.Shared(world)
     out, err = [None] * world, []
 
     def work(r):
         try:
             pipe = ShardedPipeline(make_engine(r), ThreadComm(shared, r))
-            out[r] = pipe.iq_to_bits(shards[r], p, want_qad=True, pos_base=bounds[r][0], n_total=n_total)
+            out[r] = pipe.iq_to_bits(shards[r], p, want_qad=True, pos_base=bounds[r][0], n_total=n_total,
+                                     halo_given=halos is not None, left_halo=halos[r] if halos is not None else None)
         except BaseException as e:          # noqa: BLE001 -- re-raised in the main thread
             err.append(e)
             shared.barrier.abort()
@@ -81,9 +84,11 @@ def test_sharded_model_equals_oracle(oracle):
         edges = [0] + [int(c) for c in cuts] + [n]
         bounds = [(edges[r], edges[r + 1]) for r in range(world)]
         shards = [x[a:b] for a, b in bounds]
+        # every other case: the halo comes with the shard instead of through the first exchange
+        halos = [None] + [torch.tensor([float(x[a - 1])], dtype=torch.float32) for a, _ in bounds[1:]] if it % 2 else None
         res = run_threads(world, lambda r: model_shard.ModelShardEngine(tile=int(rng.choice([16, 32])), span=8,
                                                                         chunk_tiles=int(rng.choice([1, 2]))),
-                          shards, bounds, n, p)
+                          shards, bounds, n, p, halos)
         assert_same(stitch(res), reference_result(oracle, x, p), (it, world, n, mod, bps, tol, sps, pt, bounds))
 
 

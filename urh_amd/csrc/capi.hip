@@ -93,7 +93,7 @@ size_t digitize_scratch_bytes(const Plan &pl, int64_t cap_rows, bool ask, bool b
     b += align256((size_t)(pl.n_chunks + kMaxWorld) * sizeof(ChunkInfo));
     b += align256((size_t)pl.n_chunks * pl.slab_stride * 8);
     b += align256(resolve_scratch_bytes(pl.n_chunks + kMaxWorld)) + 2 * 256;
-    b += align256(tile_tail_bytes(pl.n_chunks)) + 256;
+    b += align256(tile_tail_bytes(pl.n_chunks + kMaxWorld)) + 256;
     if (ask) b += align256((size_t)cap_rows * 16) + align256(merge_scratch_bytes(cap_rows));
     if (bits) b += align256(bits_scratch_bytes(cap_rows));
     b += 4096;
@@ -181,6 +181,25 @@ int hot_stream_begin(urhgpu_ctx *ctx, hipStream_t *out) {
     return URHGPU_OK;
 }
 
+// scratch (from the arena) and persistent descriptors of the tile tail over a table of n_entries chunks
+int tile_tail_mem(urhgpu_ctx *ctx, int64_t n_entries, bool expands_bits, TileTailMem *tm) {
+    tm->mem = ctx->arena.take(tile_tail_bytes(n_entries));
+    tm->n_chunks = n_entries; tm->huge_count = ctx->d_tickets + 8;
+    tm->parity = expands_bits ? (ctx->tile_parity ^= 1) : ctx->tile_parity;   // only passes that expand bits consume a counter
+    tm->d_row_base = nullptr;
+    if (!tm->mem) return URHGPU_ERR_ARG;
+    const size_t rd = tile_rdesc_bytes(n_entries);
+    if (rd > ctx->rdesc_cap) {
+        if (ctx->d_rdesc) { URH_HIP(hipFree(ctx->d_rdesc)); ctx->d_rdesc = nullptr; ctx->rdesc_cap = 0; }
+        const size_t want = (rd + 65535) & ~size_t(65535);
+        URH_HIP(hipMalloc(&ctx->d_rdesc, want));
+        URH_HIP(hipMemset(ctx->d_rdesc, 0, want));
+        ctx->rdesc_cap = want;
+    }
+    tm->rdesc = ctx->d_rdesc; tm->epoch = ++ctx->scan_epoch;
+    return URHGPU_OK;
+}
+
 int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const urhgpu_params *p, float *d_qad,
              int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows, int64_t *d_n_rows_needed, int64_t *d_n_acc,
              const Plan &pl, int seg_mode = 0, hipStream_t s_tail = nullptr, const BitsParams *tile_bp = nullptr,
@@ -258,18 +277,7 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     if (!ask && g_tile_tail) {
         // tile tail: one composed scan instead of three, rows + their bit aggregates in one pass (pulse_table.hip)
         TileTailMem tm;
-        tm.mem = ctx->arena.take(tile_tail_bytes(pl.n_chunks));
-        tm.n_chunks = pl.n_chunks; tm.huge_count = ctx->d_tickets + 8; tm.parity = tile_out ? (ctx->tile_parity ^= 1) : ctx->tile_parity;   // only passes that expand bits consume a counter
-        if (!tm.mem) return URHGPU_ERR_ARG;
-        const size_t rd = tile_rdesc_bytes(pl.n_chunks);
-        if (rd > ctx->rdesc_cap) {
-            if (ctx->d_rdesc) { URH_HIP(hipFree(ctx->d_rdesc)); ctx->d_rdesc = nullptr; ctx->rdesc_cap = 0; }
-            const size_t want = (rd + 65535) & ~size_t(65535);
-            URH_HIP(hipMalloc(&ctx->d_rdesc, want));
-            URH_HIP(hipMemset(ctx->d_rdesc, 0, want));
-            ctx->rdesc_cap = want;
-        }
-        tm.rdesc = ctx->d_rdesc; tm.epoch = ++ctx->scan_epoch;
+        URH_TRY(tile_tail_mem(ctx, pl.n_chunks, tile_out != nullptr, &tm));
         URH_TRY(launch_tile_rows(r, e, tm, tile_out ? tile_bp : nullptr, s));
         if (tile_out) *tile_out = tm;
         URH_HIP(hipGetLastError());
@@ -296,7 +304,7 @@ BitsParams bits_params(const urhgpu_params *p) {
 // State of one sharded pass (urhgpu_shard_*): lives in the context between the phases; every pointer is
 // carved from ctx->arena, which is not reset until the next pass begins.
 struct ShardSession {
-    int phase = 0;                 // 1: runs done, 2: rows done, 3: bits prepared
+    int phase = 0;                 // -1: hot launch without the first chunk, -2: whole hot launch; 1: runs done, 2: rows done, 3: bits prepared
     bool piped = false;            // pipelined mode: phases after the hot kernel run on ctx->tail_stream
     RunArgs run;                   // kernel arguments of the hot launch (kept for the deferred first chunk)
     int rank = 0, world = 1;
@@ -310,8 +318,10 @@ struct ShardSession {
     void *rs_mem = nullptr;
     int64_t *rows_stage = nullptr; void *merge_scratch = nullptr; int64_t *d_n_stage = nullptr;
     void *bits_scratch = nullptr;
-    int64_t *d_small = nullptr;    // [0] ts_carry, [1] absorbed, [2] extra (2 x int32), [3] n_rows (final)
+    int64_t *d_small = nullptr;    // [0] ts_carry, [1] absorbed, [2] extra (2 x int32), [3] n_rows (final), [4] row_base (tile tail)
     const int64_t *d_row_base = nullptr;
+    bool use_tile = false;         // everything but ASK: the tile tail over the table (pulse_table.hip), as on a single GPU
+    TileTailMem tile;
 };
 
 // descriptor memory of the single-pass scans for pulse tables of up to cap_rows rows
@@ -763,14 +773,17 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     if (!ss) return URHGPU_ERR_ARG;
     ss->piped = ctx->pipelined;
     if (ss->piped) URH_TRY(begin_pipelined_pass(ctx)); else URH_TRY(join_tail(ctx));
-    // (sharded passes keep the caller's stream for the hot kernel and the 33 KiB of LDS padding per hot workgroup instead of the CU mask
-    // of single-GPU pipelined passes: measured on a 1-rank RCCL group, round 3: 0.35-0.36 ms per pass either way, 0.40 with both)
+    // ASK passes (generic tail: a dozen under-occupied launches and one more exchange) keep the caller's stream for the hot kernel and
+    // 33 KiB of LDS padding per hot workgroup; everything else runs as on a single GPU: tile tail, CU-masked hot stream for float32
+    // captures (measured on a 1-rank RCCL group, round 3: the generic tail ran 0.35-0.36 ms per pass with either, 0.40 with both)
+    const bool ask = (p->mod == URHGPU_MOD_ASK);
+    ss->use_tile = !ask && g_tile_tail;
     hipStream_t s = ctx->stream;
+    if (ss->piped && ss->use_tile && p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s));
     ss->phase = 0; ss->rank = rank; ss->world = world; ss->n_local = n_local; ss->pos_base = pos_base; ss->n_total = n_total;
     ss->p = *p; ss->out = *out;
     const Plan pl = make_plan(ctx, n_local, p->tolerance);
     ss->pl = pl;
-    const bool ask = (p->mod == URHGPU_MOD_ASK);
     URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, out->cap_rows, ask, true)));
     ctx->arena.reset();
     const int64_t n_table = pl.n_chunks + world - 1;
@@ -789,6 +802,10 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     if (!ss->table || !ss->slab || !ss->rs_mem || !ss->d_small || !ss->bits_scratch || !ss->rows_stage ||
         !ss->d_n_stage || (ask && !ss->merge_scratch))
         return URHGPU_ERR_ARG;
+    if (ss->use_tile) {
+        URH_TRY(tile_tail_mem(ctx, n_table, true, &ss->tile));
+        if (world > 1) ss->tile.d_row_base = ss->d_small + 4;
+    }
     RunArgs &a = ss->run;
     memset(&a, 0, sizeof(a));
     URH_TRY(fill_thresholds(a, p));
@@ -797,7 +814,7 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     a.noise_sqrd = p->noise_threshold * p->noise_threshold;
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
-    a.lds_pad = ctx->pipelined ? ctx->hot_lds_pad_sharded : 0;
+    a.lds_pad = !ctx->pipelined ? 0 : (ss->use_tile ? ctx->hot_lds_pad : ctx->hot_lds_pad_sharded);
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     a.chunks = ss->table + rank;               // this rank's chunks sit at table[rank .. rank + n_chunks)
     a.slab = ss->slab;
@@ -834,6 +851,14 @@ int urhgpu_shard_prelaunch_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_loca
     return URHGPU_OK;
 }
 
+int urhgpu_shard_launch_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
+                            int rank, int world, const void *d_left_halo, const urhgpu_params *p, const urhgpu_outputs *out) {
+    if ((rank == 0) != (d_left_halo == nullptr)) return URHGPU_ERR_ARG;
+    URH_TRY(shard_launch(ctx, d_iq, n_local, pos_base, n_total, rank, world, d_left_halo, p, out, 0));
+    ((ShardSession *)ctx->shard)->phase = -2;
+    return URHGPU_OK;
+}
+
 int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int64_t pos_base, int64_t n_total,
                           int rank, int world, const void *d_left_halo, const urhgpu_params *p,
                           const urhgpu_outputs *out, void *d_summary) {
@@ -841,12 +866,12 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
     if ((rank == 0) != (d_left_halo == nullptr)) return URHGPU_ERR_ARG;
     ShardSession *ss = (ShardSession *)ctx->shard;
     hipStream_t s;
-    if (ss && ss->phase == -1) {
-        // prelaunched: only the first chunk (it needs the halo) is still missing
+    if (ss && (ss->phase == -1 || ss->phase == -2)) {
+        // prelaunched: only the first chunk (it needs the halo) is still missing, or (-2) nothing
         if (ss->rank != rank || ss->world != world || ss->n_local != n_local || ss->run.in != d_iq) return URHGPU_ERR_ARG;
         URH_HIP(hipSetDevice(ctx->device));
         s = ss->piped ? ctx->tail_stream : ctx->stream;
-        if (rank > 0) {
+        if (rank > 0 && ss->phase == -1) {
             RunArgs a = ss->run;
             a.left_halo = d_left_halo; a.launch_part = 2;
             URH_TRY(launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s));
@@ -898,14 +923,23 @@ int urhgpu_shard_rows_dev(urhgpu_ctx *ctx, const void *d_summaries, int64_t *d_m
     r.local_pass = 0; r.aux = ss->aux; r.summary_out = nullptr; r.chunk_first = rank; r.n_local = pl.n_chunks;
     r.d_ts_carry = ss->d_small;
     URH_HIP(hipMemsetAsync(ss->d_small, 0, 8 * 8, s));
-    URH_TRY(launch_resolve(r, ctx->d_tickets, s));
     EmitArgs e;
     e.sc = r.sc;
     e.chunks = ss->table; e.chunk_first = rank; e.slab = ss->slab; e.slab_stride = pl.slab_stride;
     e.rows = ss->rows_stage; e.cap_rows = ss->out.cap_rows; e.d_ts_carry = ss->d_small; e.is_ask = ask ? 1 : 0;
     e.sps = ss->p.samples_per_symbol;
-    URH_TRY(launch_emit_rows(e, pl.n_chunks, s));
-    ss->d_row_base = r.sc.out_off + rank;
+    if (ss->use_tile) {
+        // resolve + rows + per-tile bit aggregates over the table: two launches (total_samples before my first row comes out of the
+        // tile scan, the summaries being tiles of their own: no ts_carry)
+        BitsParams bp = bits_params(&ss->p);
+        bp.d_row_base = ss->tile.d_row_base;
+        URH_TRY(launch_tile_rows(r, e, ss->tile, &bp, s));
+        ss->d_row_base = ss->tile.d_row_base;
+    } else {
+        URH_TRY(launch_resolve(r, ctx->d_tickets, s));
+        URH_TRY(launch_emit_rows(e, pl.n_chunks, s));
+        ss->d_row_base = r.sc.out_off + rank;
+    }
     if (ask) {
         URH_TRY(launch_merge_rows_ask(ss->rows_stage, ss->d_n_stage, ss->out.cap_rows, ss->out.rows, ss->out.cap_rows,
                                       ss->d_small + 3, ss->merge_scratch, ctx->d_tickets, s));
@@ -931,8 +965,15 @@ int urhgpu_shard_bits_prepare_dev(urhgpu_ctx *ctx, const int64_t *d_merge_all, i
     bp.d_row_base = ss->d_row_base; bp.d_ts_carry = ss->d_small; bp.d_absorbed = ask ? ss->d_small + 1 : nullptr;
     bp.d_extra = (const int32_t *)(ss->d_small + 2); bp.is_last_rank = (ss->rank == ss->world - 1) ? 1 : 0;
     ScanState sst;
-    URH_TRY(scan_state(ctx, std::max<int64_t>(ss->out.cap_rows, 1), &sst));
-    URH_TRY(launch_bits_prepare(ss->out.rows, d_n_rows, std::max<int64_t>(ss->out.cap_rows, 1), bp, ss->bits_scratch, d_flags, sst, s));
+    const int64_t cap = std::max<int64_t>(ss->out.cap_rows, 1);
+    if (ss->use_tile) {
+        bp.d_ts_carry = nullptr;
+        URH_TRY(scan_state(ctx, tile_desc_cap(cap, ss->tile.n_chunks), &sst));
+        URH_TRY(launch_tile_bits_prepare(ss->tile, ss->out.rows, d_n_rows, cap, bp, ss->bits_scratch, d_flags, sst, s));
+    } else {
+        URH_TRY(scan_state(ctx, cap, &sst));
+        URH_TRY(launch_bits_prepare(ss->out.rows, d_n_rows, cap, bp, ss->bits_scratch, d_flags, sst, s));
+    }
     URH_HIP(hipGetLastError());
     ss->phase = 3;
     return URHGPU_OK;
@@ -953,8 +994,15 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
     const urhgpu_outputs &o = ss->out;
     BitsOut bo{o.bits, o.cap_bits, o.msg_off, o.pauses, o.cap_msg, o.pos, o.cap_pos, o.pos_off, o.counts};
     ScanState sst;
-    URH_TRY(scan_state(ctx, std::max<int64_t>(o.cap_rows, 1), &sst));
-    URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, std::max<int64_t>(o.cap_rows, 1), bp, bo, ss->bits_scratch, sst, s));
+    const int64_t cap = std::max<int64_t>(o.cap_rows, 1);
+    if (ss->use_tile) {
+        bp.d_ts_carry = nullptr;
+        URH_TRY(scan_state(ctx, tile_desc_cap(cap, ss->tile.n_chunks), &sst));
+        URH_TRY(launch_tile_bits_finish(ss->tile, o.rows, ss->d_small + 3, cap, bp, bo, ss->bits_scratch, sst, s));
+    } else {
+        URH_TRY(scan_state(ctx, cap, &sst));
+        URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, cap, bp, bo, ss->bits_scratch, sst, s));
+    }
     URH_HIP(hipGetLastError());
     ss->phase = 0;
     if (ss->piped) URH_TRY(end_pipelined_pass(ctx));

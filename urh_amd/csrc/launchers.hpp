@@ -210,6 +210,7 @@ struct TileTailMem {
     int parity;              // which of the two this pass uses (alternates)
     void *rdesc;             // tile_rdesc_bytes(n_chunks) of persistent, initially zeroed memory: look-back descriptors of the resolve scan
     unsigned long long epoch; // pass counter carried by their flags (never repeats on a context)
+    int64_t *d_row_base = nullptr;   // sharded captures: device word that receives the global index of this GPU's first row
 };
 size_t tile_rdesc_bytes(int64_t n_chunks);
 size_t tile_tail_bytes(int64_t n_chunks);
@@ -217,6 +218,12 @@ int64_t tile_desc_cap(int64_t cap_rows, int64_t n_chunks);
 int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams *bp, hipStream_t s);
 int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
                      const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
+// the same in two halves around the flags exchange of a sharded capture (d_flags[3]: long pause present, data before the first / after
+// the last one; nullptr: none wanted)
+int launch_tile_bits_prepare(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                             void *scratch, int64_t *d_flags, const ScanState &ss, hipStream_t s);
+int launch_tile_bits_finish(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                            const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
 // ASK, sharded: summary of the locally merged table {n_rows, first state, first length, last state, last length}
 void launch_merge_summary(const int64_t *rows, const int64_t *d_n_rows, int64_t *d_out5, hipStream_t s);
 // ASK, sharded: merge equal-state rows across shard boundaries (d_all: world x 5 int64)

@@ -757,6 +757,7 @@ struct TileTail {            // scratch of the tile tail (carved from the contex
     int want_bits;
     GranDesc *rdesc;         // look-back descriptors of k_resolve_one (persistent, tagged with the pass number)
     unsigned long long epoch;
+    int64_t *d_row_base;     // sharded captures: receives the global index of this GPU's first row (nullptr on a single GPU)
 };
 
 // The kernels below are latency chains of a few memory round trips on a nearly idle chip, not bandwidth: every load whose
@@ -821,6 +822,16 @@ __device__ __forceinline__ ResElem res_fold_blocks(const ResElem *btot, int64_t 
     return carry;
 }
 
+// state machine before table entry c (c == n_chunks: behind the last one): the resolve workgroups before c's, then c's workgroup-local prefix
+__device__ __forceinline__ ResElem res_before_entry(const TileTail &ft, const ResElem &init, int64_t c, int64_t n_chunks, int lane) {
+    const int64_t nb = (c >= n_chunks) ? resolve_blocks(n_chunks) : c / kResolveBlock;
+    ResElem first = res_identity();
+    if (lane < nb) first = ft.btot[lane];
+    ResElem pre = res_combine(init, res_fold_blocks(ft.btot, nb, lane, first));
+    if (c < n_chunks) pre = res_combine(pre, ft.ploc[c]);
+    return pre;
+}
+
 // What one row contributes to _ppseq_to_bits (ProtocolAnalyzer.py:346-401): v[0] bits, v[1] long pause, v[2] samples, v[3] data row
 __device__ __forceinline__ VecK<4> row_value(int64_t type, int64_t len, bool global_row0, const BitsParams &bp) {
     VecK<4> v; v.zero();
@@ -880,6 +891,11 @@ struct EmitTileArgs {
 
 __host__ __device__ static inline int64_t tail_waves(int64_t n_items) { return (n_items + kTailCPW - 1) / kTailCPW; }
 
+// Sharded captures run the same kernel over the TABLE of the generic resolve pass -- the other shards' summaries around this GPU's
+// chunks (ResolveArgs::chunk_first / n_local).  A summary entry is a chunk whose records live elsewhere: it writes no rows, but what its
+// rows span (positions telescope) is its tile's sample count, so that the exclusive tile scan hands this GPU's first tile the
+// total_samples before its first row; bits, long pauses and data rows stay per GPU (their cross-shard part is the flags exchange).
+// Rows are indexed from this GPU's first one (row_base, also left in *ft.d_row_base for the kernels that follow).
 __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitTileArgs g) {
     URH_TAIL_PRIO();
     const EmitArgs &a = g.e;
@@ -889,6 +905,8 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
     const int64_t n_cw = tail_waves(r.n_chunks);          // wavefronts that own chunks; wavefront n_cw: totals, last row, last tile
     if (w > n_cw) return;
     const bool totals = (w == n_cw);
+    const bool table = (r.n_local != r.n_chunks);         // sharded: entries outside [lc0, lc1) are the other shards' summaries
+    const int64_t lc0 = a.chunk_first, lc1 = a.chunk_first + r.n_local;
     const int64_t c0 = totals ? r.n_chunks : w * kTailCPW;
     // ---- one round trip: everything this wavefront reads that does not depend on loaded data ----
     // resolve workgroups composed on the left: the same for every chunk of this wavefront (kResolveBlock % kTailCPW == 0); the totals
@@ -900,55 +918,65 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
     const int n_mine = totals ? 0 : (int)((r.n_chunks - c0 < kTailCPW) ? r.n_chunks - c0 : kTailCPW);
     ResElem pl_l = res_identity();
     int cnt_l = 0, fl_l = 0, pp_l = 0;                    // fl: first_state | last_state << 16 (0xFFFF = none); pp: pend_state | pend_stable << 16
-    int64_t pend_pos_l = -1;
+    int64_t pend_pos_l = -1, last_pos_l = 0;
     if (lane < n_mine) {                                  // lane j: chunk c0 + j
         pl_l = g.ft.ploc[c0 + lane];
         const ChunkInfo *ch = a.chunks + c0 + lane;
         cnt_l = ch->cnt; pend_pos_l = ch->pend_pos;
+        if (table) last_pos_l = ch->last_pos;
         fl_l = (int)((uint32_t)ch->first_state | ((uint32_t)ch->last_state << 16));
         pp_l = (int)((uint32_t)ch->pend_state | ((uint32_t)(ch->pend_stable ? 1 : 0) << 16));
     }
     uint64_t rec = 0;
-    if (n_mine > 0 && lane < a.slab_stride) rec = (a.slab + c0 * a.slab_stride)[lane];     // speculative: the first 64 records (those beyond cnt are ignored)
+    if (n_mine > 0 && c0 >= lc0 && c0 < lc1 && lane < a.slab_stride)
+        rec = (a.slab + (c0 - lc0) * a.slab_stride)[lane];     // speculative: the first 64 records (those beyond cnt are ignored)
     const ResElem init = res_make(init_state, -1, init_state, 0, false, -1, 0);
     const ResElem base = res_combine(init, res_fold_blocks(g.ft.btot, n_before, lane, first));   // state machine before this wavefront's resolve workgroup
+    int64_t row_base = 0;                                 // global index of this GPU's first row
+    if (table) row_base = res_before_entry(g.ft, init, lc0, r.n_chunks, lane).cnt;
     if (totals) {
         // totals, the table's last row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487), last tile
         const ResElem pre = base;
         const int64_t c = r.n_chunks;
+        int64_t row_end = pre.cnt;                         // this GPU's rows are global rows [row_base, row_end) (+ the last row on the last GPU)
+        if (table && lc1 < r.n_chunks) row_end = res_before_entry(g.ft, init, lc1, r.n_chunks, lane).cnt;
         if (lane == 0) {
             const int64_t P = pre.cnt;
             *r.d_n_acc = P;
-            int64_t n_rows = P;
+            int64_t n_rows = row_end - row_base;
+            int64_t o = n_rows;
             VecK<4> v; v.zero();
             int32_t tcnt = 0;
             if (P < r.n_total && r.write_last_row) {
-                n_rows = P + 1;
+                o = P - row_base;
+                n_rows = o + 1;
                 tcnt = 1;
                 const int64_t fpos = pre.la_valid() ? pre.la_pos : -1;
                 const uint32_t fstate = pre.la_valid() ? pre.la_state() : init_state;
                 const int64_t len = (P == 0) ? (r.n_total - r.tol) : (r.n_total - 1 - fpos - r.tol);
-                if (r.rows != nullptr && P < r.cap_rows) { r.rows[2 * P] = (int64_t)fstate - 1; r.rows[2 * P + 1] = len; }
+                if (r.rows != nullptr && o < r.cap_rows) { r.rows[2 * o] = (int64_t)fstate - 1; r.rows[2 * o + 1] = len; }
                 if (g.ft.want_bits) {
                     v = row_value((int64_t)fstate - 1, len, P == 0, g.bp);
                     if (v.v[0] > kHugeBits) {
                         const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
-                        if (slot < g.huge_cap) { g.huge[slot].tile = c; g.huge[slot].row = P; }
+                        if (slot < g.huge_cap) { g.huge[slot].tile = c; g.huge[slot].row = o; }
                     }
                 }
             }
             *r.d_n_rows_needed = n_rows;
             *r.d_n_rows = (r.rows != nullptr && n_rows > r.cap_rows) ? r.cap_rows : n_rows;
-            g.ft.agg[c] = v; g.ft.tile_off[c] = P; g.ft.tile_cnt[c] = tcnt;
+            if (g.ft.d_row_base) *g.ft.d_row_base = row_base;
+            g.ft.agg[c] = v; g.ft.tile_off[c] = o; g.ft.tile_cnt[c] = tcnt;
         }
         return;
     }
     for (int jc = 0; jc < n_mine; ++jc) {
         const int64_t c = c0 + jc;
-        const uint64_t *slab = a.slab + c * a.slab_stride;
+        const bool local = (c >= lc0 && c < lc1);
+        const uint64_t *slab = a.slab + (c - lc0) * a.slab_stride;          // (local entries only)
         // the next chunk's records are on their way while this one is worked on
         uint64_t rec_next = 0;
-        if (jc + 1 < n_mine && lane < a.slab_stride) rec_next = (slab + a.slab_stride)[lane];
+        if (jc + 1 < n_mine && c + 1 >= lc0 && c + 1 < lc1 && lane < a.slab_stride) rec_next = (a.slab + (c + 1 - lc0) * a.slab_stride)[lane];
         ResElem pl;
         pl.cnt = lane_bcast(pl_l.cnt, jc); pl.first_pos = lane_bcast(pl_l.first_pos, jc); pl.la_pos = lane_bcast(pl_l.la_pos, jc);
         pl.meta = (uint64_t)lane_bcast((int64_t)pl_l.meta, jc);
@@ -968,6 +996,14 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
         const int64_t out_off = pre.cnt;
         const int64_t prev_pos = pre.la_valid() ? pre.la_pos : -1;
         const uint32_t prev_st = pre.la_valid() ? pre.la_state() : init_state;
+        if (!local) {
+            // another shard's summary: no rows of this GPU, only the samples its rows span
+            VecK<4> acc; acc.zero();
+            if (g.ft.want_bits && total > 0) acc.v[2] = (pend_acc ? pend_pos : lane_bcast(last_pos_l, jc)) - prev_pos;
+            if (lane == 0) { g.ft.agg[c] = acc; g.ft.tile_off[c] = 0; g.ft.tile_cnt[c] = 0; }
+            rec = rec_next;
+            continue;
+        }
         // what the chunk's rows contribute to _ppseq_to_bits: bits (64-bit sum), long pauses and data rows (two 32-bit counts in one
         // word); the samples need no sum at all -- row lengths telescope: sum = (position of the chunk's last accepted run) - prev_pos
         int64_t acc_bits = 0;
@@ -989,17 +1025,17 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
                 else { const uint64_t rr = slab[j - 1 + skip]; ppos = rec_pos(rr); pst = rec_state(rr); }
             }
             my_last_pos = pos;
-            const int64_t gi = out_off + j;
+            const int64_t gi = out_off + j;                  // global row; this GPU's row gi - row_base
             const int64_t len = (gi == 0) ? pos + 1 : pos - ppos;
             const int64_t state = (int64_t)pst - 1;
-            if (gi < a.cap_rows) *(longlong2 *)(a.rows + 2 * gi) = longlong2{(long long)state, (long long)len};
+            if (gi - row_base < a.cap_rows) *(longlong2 *)(a.rows + 2 * (gi - row_base)) = longlong2{(long long)state, (long long)len};
             if (g.ft.want_bits) {
                 const VecK<4> v = row_value(state, len, gi == 0, g.bp);
                 acc_bits += v.v[0];
                 acc_ld += (uint64_t)v.v[1] | ((uint64_t)v.v[3] << 32);
                 if (v.v[0] > kHugeBits) {
                     const int slot = atomicAdd(g.ft.huge_count + g.ft.parity, 1);
-                    if (slot < g.huge_cap) { g.huge[slot].tile = c; g.huge[slot].row = gi; }
+                    if (slot < g.huge_cap) { g.huge[slot].tile = c; g.huge[slot].row = gi - row_base; }
                 }
             }
         }
@@ -1011,7 +1047,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
             acc.v[0] = acc_bits; acc.v[1] = (int64_t)(acc_ld & 0xFFFFFFFFull); acc.v[3] = (int64_t)(acc_ld >> 32);
             acc.v[2] = last_pos - prev_pos;                  // (prev_pos = -1 before the table's first row: its length is position + 1)
         }
-        if (lane == 0) { g.ft.agg[c] = acc; g.ft.tile_off[c] = out_off; g.ft.tile_cnt[c] = (int32_t)total; }
+        if (lane == 0) { g.ft.agg[c] = acc; g.ft.tile_off[c] = out_off - row_base; g.ft.tile_cnt[c] = (int32_t)total; }
         rec = rec_next;
     }
 }
@@ -1045,6 +1081,7 @@ __global__ __launch_bounds__(kScanBlock) URH_TAIL_OCC void k_tile_scan(const Til
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // one round trip
     const int64_t n = *a.d_n_rows;
+    const bool row0g = !a.bp.d_row_base || *a.bp.d_row_base == 0;     // this GPU's row 0 is the capture's row 0
     VecK<4> mine; mine.zero();
     int64_t off = 0; int32_t cnt = 0;
     if (t < a.n_tiles) { mine = a.agg[t]; off = a.tile_off[t]; cnt = a.tile_cnt[t]; }
@@ -1096,7 +1133,7 @@ __global__ __launch_bounds__(kScanBlock) URH_TAIL_OCC void k_tile_scan(const Til
             if (i < e) {
                 const longlong2 row = *(const longlong2 *)(a.rows + 2 * i);
                 type = row.x; len = row.y;
-                v = row_value(type, len, i == 0, a.bp);
+                v = row_value(type, len, i == 0 && row0g, a.bp);
             }
             const VecK<4> incl = wave_incl_scan_vec<4>(v, lane);
             VecK<4> before = run;
@@ -1151,6 +1188,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
     if ((int64_t)blockIdx.x >= tile_blocks) {
         // ---- huge rows ----
         const int64_t n = *a.d_n_rows;
+        const bool row0g = !a.bp.d_row_base || *a.bp.d_row_base == 0;
         const int64_t hb = (int64_t)blockIdx.x - tile_blocks;
         const int hx = (int)(hb % kHugeBlocksX), hy = (int)(hb / kHugeBlocksX);
         if (hb == 0 && threadIdx.x == 0) a.huge_count[a.parity ^ 1] = 0;       // the other parity's counter: free for the next pass
@@ -1167,7 +1205,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
                 for (int64_t i0 = off; i0 <= h.row; i0 += 64) {
                     const int64_t i = i0 + lane;
                     VecK<4> v; v.zero();
-                    if (i < h.row && i < n) v = row_value(a.rows[2 * i], a.rows[2 * i + 1], i == 0, a.bp);
+                    if (i < h.row && i < n) v = row_value(a.rows[2 * i], a.rows[2 * i + 1], i == 0 && row0g, a.bp);
                     run.add(wave_sum_vec<4>(v));
                 }
                 if (lane == 0) {
@@ -1176,7 +1214,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
                         const GroupOut go = a.gout[run.v[1]];
                         if (go.is_msg) {
                             ty = a.rows[2 * h.row];
-                            kb = row_value(ty, a.rows[2 * h.row + 1], h.row == 0, a.bp).v[0];
+                            kb = row_value(ty, a.rows[2 * h.row + 1], h.row == 0 && row0g, a.bp).v[0];
                             ob = go.out_bits + (run.v[0] - go.bits_start);
                             op = go.out_pos + (run.v[0] - go.bits_start);
                         }
@@ -1201,6 +1239,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
     // ---- round trip 1: everything that does not depend on loaded data; lane j holds the metadata of tile t0 + j ----
     const int64_t n = *a.d_n_rows;
     const int64_t n_groups = *a.d_n_groups;
+    const bool row0g = !a.bp.d_row_base || *a.bp.d_row_base == 0;
     const int hc = a.huge_count[a.parity];
     int64_t off_l = 0; int32_t tcnt_l = 0;
     VecK<4> run_l; run_l.zero();
@@ -1240,7 +1279,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
             if (i < end) {
                 const longlong2 row = (i0 == off) ? row0 : *(const longlong2 *)(a.rows + 2 * i);
                 type = row.x;
-                v = row_value(type, row.y, i == 0, a.bp);
+                v = row_value(type, row.y, i == 0 && row0g, a.bp);
             }
             // inclusive wave scans of what the expansion needs: bits and samples (64-bit), long pauses (32-bit: a tile has few rows)
             int64_t in_bits = v.v[0], in_ts = v.v[2];
@@ -1487,6 +1526,7 @@ TileCarve carve_tile(const TileTailMem &m) {
     tc.ft.want_bits = 0;
     tc.ft.rdesc = (GranDesc *)m.rdesc;
     tc.ft.epoch = m.epoch;
+    tc.ft.d_row_base = m.d_row_base;
     return tc;
 }
 }  // namespace
@@ -1504,9 +1544,13 @@ size_t tile_tail_bytes(int64_t n_chunks) {
            64 + (size_t)kTileHugeCap * sizeof(HugeRef) + 10 * 256;
 }
 
-// resolve + rows (+ per-tile bit aggregates when bp != nullptr) of a single-GPU, non-ASK capture: two launches
+// resolve + rows (+ per-tile bit aggregates when bp != nullptr) of a non-ASK capture: two launches.  Sharded captures pass the table of
+// the generic resolve pass (the other shards' summaries around this GPU's chunks: r.chunk_first, r.n_local) and m.d_row_base.
 int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams *bp, hipStream_t s) {
-    if (r.n_chunks <= 0 || r.local_pass || r.chunk_first != 0 || r.n_local != r.n_chunks || e.chunk_first != 0 || e.is_ask) return URHGPU_ERR_ARG;
+    if (r.n_chunks <= 0 || r.local_pass || r.chunk_first != e.chunk_first || r.chunk_first < 0 || r.chunk_first + r.n_local > r.n_chunks ||
+        m.n_chunks != r.n_chunks || e.is_ask)
+        return URHGPU_ERR_ARG;
+    if ((r.n_local != r.n_chunks) != (m.d_row_base != nullptr)) return URHGPU_ERR_ARG;
     TileCarve tc = carve_tile(m);
     EmitTileArgs g;
     g.e = e; g.r = r; g.ft = tc.ft; g.huge = tc.huge; g.huge_cap = kTileHugeCap;
@@ -1518,9 +1562,20 @@ int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem 
     return URHGPU_OK;
 }
 
-// bits / pauses / bit_sample_pos from the tiles launch_tile_rows left behind: tile scan, group scan, expansion
-int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
-                     const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s) {
+// bits / pauses / bit_sample_pos from the tiles launch_tile_rows left behind: tile scan, group scan, expansion.
+// Sharded captures stop after the tile scan for the flags exchange (d_flags: what GroupCountFinal gives the generic path).
+namespace {
+__global__ void k_tile_flags(const int64_t *d_n_rows, const GroupInfo *groups, const int64_t *d_n_groups, int64_t *d_flags) {
+    const int64_t n = *d_n_rows, ng = *d_n_groups;
+    const int64_t n_l = (n > 0 && ng > 0) ? ng - 1 : 0;
+    d_flags[0] = n_l > 0;
+    d_flags[1] = (n > 0) && groups[0].data_end > 0;
+    d_flags[2] = (n > 0) && (groups[n_l].data_end - (n_l ? groups[n_l - 1].data_end : 0) > 0);
+}
+}  // namespace
+
+int launch_tile_bits_prepare(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                             void *scratch, int64_t *d_flags, const ScanState &ss, hipStream_t s) {
     if (cap_rows <= 0) cap_rows = 1;
     const int64_t nt = m.n_chunks + 1;
     const int64_t cap_desc = tile_desc_cap(cap_rows, m.n_chunks);
@@ -1528,12 +1583,24 @@ int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d
     const TileCarve tc = carve_tile(m);
     const BitsScratch b = carve_bits(scratch, cap_rows);
     const int64_t cap_groups = cap_rows + 1;
-    ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(scan_blocks(cap_desc) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
     GranDesc *tdesc = (GranDesc *)m.rdesc + resolve_blocks(m.n_chunks) + 2;
     TileScanArgs ta{rows, d_n_rows, tc.ft.agg, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, b.d_n_groups, nt, bp, tdesc,
                     m.epoch};
     const unsigned nb_ts = (unsigned)((nt + kScanBlock - 1) / kScanBlock);
     hipLaunchKernelGGL(k_tile_scan, dim3(nb_ts), dim3(kScanBlock), 0, s, ta);
+    if (d_flags) hipLaunchKernelGGL(k_tile_flags, dim3(1), dim3(1), 0, s, d_n_rows, b.groups, b.d_n_groups, d_flags);
+    return URHGPU_OK;
+}
+
+int launch_tile_bits_finish(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                            const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s) {
+    if (cap_rows <= 0) cap_rows = 1;
+    const int64_t nt = m.n_chunks + 1;
+    const int64_t cap_desc = tile_desc_cap(cap_rows, m.n_chunks);
+    if (ss.desc_bytes < bits_desc_bytes(cap_desc)) return URHGPU_ERR_ARG;
+    const TileCarve tc = carve_tile(m);
+    const BitsScratch b = carve_bits(scratch, cap_rows);
+    ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(scan_blocks(cap_desc) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed, o.h_counts};
@@ -1544,6 +1611,12 @@ int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(nt);
     hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     return URHGPU_OK;
+}
+
+int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
+                     const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s) {
+    URH_TRY(launch_tile_bits_prepare(m, rows, d_n_rows, cap_rows, bp, scratch, nullptr, ss, s));
+    return launch_tile_bits_finish(m, rows, d_n_rows, cap_rows, bp, o, scratch, ss, s);
 }
 
 // ---- sharded captures: the tiny cross-shard fix-ups (one thread each; world <= a few dozen) ---------------

@@ -63,6 +63,15 @@ class GpuShardEngine(DevicePipeline):
             iq_local = torch.view_as_real(iq_local)
         return iq_local[-2:].contiguous()                     # (2, 2): samples n-2, n-1
 
+    def halo_view(self, left_halo):
+        """(2, 2) view of a caller-provided halo (complex64 (2,) or (2, 2) in the capture's dtype)"""
+        torch = self.torch
+        if left_halo.dtype == torch.complex64:
+            left_halo = torch.view_as_real(left_halo)
+        if tuple(left_halo.shape) != (2, 2):
+            raise ValueError("left_halo: the two samples before the shard, shape (2, 2)")
+        return left_halo.contiguous()
+
     def fir_tail(self, iq_local, k):
         torch = self.torch
         if iq_local.dtype == torch.complex64:
@@ -126,6 +135,15 @@ class GpuShardEngine(DevicePipeline):
         self._pre = (iq, n, cp, o)
         _lib.check(_lib.load().urhgpu_shard_prelaunch_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, int(pos_base), int(n_total),
                                                           int(rank), int(world), C.byref(cp), C.byref(o)))
+
+    def runs_launch(self, iq, left, pos_base, n_total, rank, world, p, want_qad):
+        """the whole hot launch: the halo came with the shard (no exchange)"""
+        iq, n, cp, o = self._setup(iq, p, want_qad)
+        self._pre = (iq, n, cp, o)
+        self._keep += (left,)
+        _lib.check(_lib.load().urhgpu_shard_launch_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, int(pos_base), int(n_total),
+                                                       int(rank), int(world), C.c_void_p(left.data_ptr()) if left is not None else None,
+                                                       C.byref(cp), C.byref(o)))
 
     def runs(self, iq, left, pos_base, n_total, rank, world, p, want_qad):
         torch = self.torch
