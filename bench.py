@@ -603,8 +603,11 @@ def main():
     tuning, tail_prio = tuning_from_env()
     if sharded:
         from urh_amd.shard_engine import GpuShardEngine
-        from urh_amd.sharding import ShardedPipeline, TorchDistComm
-        pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=args.pipeline, tuning=tuning, tail_stream_priority=tail_prio), TorchDistComm())
+        from urh_amd.sharding import RcclComm, ShardedPipeline, TorchDistComm
+        # the exchanges go straight through RCCL (a communicator of the library's own, a few us of host time each);
+        # URH_BENCH_TORCH_COLLECTIVES=1: torch.distributed's all_gather_into_tensor instead (55-80 us of host time each)
+        comm = TorchDistComm() if os.environ.get("URH_BENCH_TORCH_COLLECTIVES") == "1" else RcclComm.create()
+        pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=args.pipeline, tuning=tuning, tail_stream_priority=tail_prio), comm)
         if args.fir_halo:
             from urh_amd.synth import spec_fir_taps
             fir_taps = torch.from_numpy(spec_fir_taps().view("float32").reshape(-1, 2).copy()).to(dev)     # (64, 2): 64 complex taps
@@ -664,6 +667,14 @@ def main():
         d2h_bytes_wide = int(sum(x.nbytes for x in host_out))
         del pinned, host_out
     latency_ms = min(lat) * 1e3
+
+    # Anything slow between the clock ramp and a timed region lets the part's clocks fall again (tools/idle_probe.py: 1 ms of idling
+    # before K = 20 passes costs 3 %, 5 ms 13 %): the profile records' events (a hipEventCreate each) and the process group's first
+    # barrier are paid for here, not there.
+    pipe.ctx.profile_begin(args.steps)
+    pipe.ctx.profile_end()
+    if dist:
+        dist.barrier()
 
     def ramp(run10):
         """The part takes some 30 ms of sustained load to reach its clocks (tools/ramp_probe.py: 0.34 -> 0.30 ms per pipelined pass over
@@ -883,6 +894,7 @@ def main():
                        "unpipelined_ms_per_step": round(alone_ms, 4) if alone_ms is not None else None,
                        "rccl_world_size": world if dist else None,
                        "all_gathers_per_pass": (None if not sharded else (2 if halo_given else 3) + (1 if fir_taps is not None else 0)),
+                       "collectives": (None if not sharded else type(pipe.comm).__name__),
                        "ranks": ranks_info},
             "roofline": {"bound": "hbm", "kernel": "k_demod_runs_bp", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",

@@ -20,7 +20,7 @@ def main():
     from conftest import synth_fsk
     from urh_amd.pipeline import DemodParams
     from urh_amd.shard_engine import GpuShardEngine
-    from urh_amd.sharding import ShardedPipeline, TorchDistComm, shard_bounds, stitch
+    from urh_amd.sharding import RcclComm, ShardedPipeline, TorchDistComm, shard_bounds, stitch
     from urh_amd.synth import spec_fir_taps
     rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ["LOCAL_RANK"])
     torch.cuda.set_device(local)
@@ -31,14 +31,21 @@ def main():
     taps = spec_fir_taps()
     a, b = shard_bounds(n, world)[rank]
     shard = torch.from_numpy(iq[a:b]).to(dev)
-    for pipelined in (False, True):
-        pipe = ShardedPipeline(GpuShardEngine(local, pipelined=pipelined), TorchDistComm())
+    rccl = RcclComm(None)                                     # the direct communicator must come up here (no fallback in the test)
+    for pipelined, comm in ((False, TorchDistComm()), (True, TorchDistComm()), (False, rccl), (True, rccl)):
+        pipe = ShardedPipeline(GpuShardEngine(local, pipelined=pipelined), comm)
         assert pipe.world == world and pipe.rank == rank
         p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
         d_taps = torch.from_numpy(taps.view(np.float32).reshape(-1, 2).copy()).to(dev)
-        for _ in range(3 if pipelined else 1):
+        for it in range(4 if pipelined else 1):
             filt = pipe.fir_filter(shard, d_taps)
-            res = pipe.iq_to_bits(filt, p, want_qad=True, pos_base=a, n_total=n)
+            # odd passes: the halo comes with the shard (here: gathered by hand beforehand), two exchanges per pass
+            given = it % 2 == 1
+            left = None
+            if given:
+                tails = comm.all_gather(filt[-2:].contiguous())
+                left = tails[rank - 1].clone() if rank > 0 else None
+            res = pipe.iq_to_bits(filt, p, want_qad=True, pos_base=a, n_total=n, halo_given=given, left_halo=left)
         pipe.ctx.join()
         torch.cuda.synchronize()
         piece = res.piece()
@@ -62,6 +69,7 @@ def main():
         if pipelined:
             pipe.ctx.set_pipelined(False)
     dist.barrier()
+    rccl.close()
     if rank == 0:
         print(f"RCCL_SHARD_OK {world} backend={dist.get_backend()}")
     dist.destroy_process_group()

@@ -15,7 +15,7 @@ import torch.distributed as dist
 
 from urh_amd.pipeline import DemodParams
 from urh_amd.shard_engine import GpuShardEngine
-from urh_amd.sharding import ShardedPipeline, TorchDistComm
+from urh_amd.sharding import RcclComm, ShardedPipeline, TorchDistComm
 from urh_amd.synth import spec_fsk_capture
 
 
@@ -26,9 +26,9 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=dev)
     p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, True)
-    iq, _ = spec_fsk_capture(int(os.environ.get("SEGMENTS", "1024")), dev, first_segment=0, sps=100)
+    iq, _ = spec_fsk_capture(int(os.environ.get("SEGMENTS", "128")), dev, first_segment=0, sps=100)
     e = GpuShardEngine(0, pipelined=True)
-    sp = ShardedPipeline(e, TorchDistComm())
+    sp = ShardedPipeline(e, TorchDistComm() if os.environ.get("COMM", "rccl") == "torch" else RcclComm.create())
     sp.reserve(iq.shape[0], p)
     acc = {}
 
@@ -44,8 +44,9 @@ def main():
     c = sp.comm
     c.all_gather_start = timed("all_gather_start", c.all_gather_start)
     c.all_gather = timed("all_gather(incl. start)", c.all_gather)
+    given = os.environ.get("HALO", "given") == "given"
     for _ in range(300):
-        sp.iq_to_bits(iq, p)
+        sp.iq_to_bits(iq, p, halo_given=given)
     sp.ctx.join(); torch.cuda.synchronize()
     gc.collect(); gc.disable()
     out = {}
@@ -54,13 +55,13 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(K):
-            sp.iq_to_bits(iq, p)
+            sp.iq_to_bits(iq, p, halo_given=given)
         t_issue = time.perf_counter() - t0
         sp.ctx.join(); torch.cuda.synchronize()
         t_all = time.perf_counter() - t0
         out[K] = dict(ms_per_step=round(t_all / K * 1e3, 4), issue_ms_per_step=round(t_issue / K * 1e3, 4),
                       host_us_per_step={k: round(v / K * 1e6, 1) for k, v in acc.items()})
-    print(json.dumps(out, indent=1))
+    print(json.dumps(dict(comm=type(sp.comm).__name__, halo_given=given, **{str(k): v for k, v in out.items()})))
     dist.destroy_process_group()
 
 

@@ -359,6 +359,12 @@ class DevicePipeline:
         import contextlib
         return self.torch.cuda.stream(self.tail_stream) if self.tail_stream is not None else contextlib.nullcontext()
 
+    def halo_context(self):
+        """tail_context for work that reads what the caller's stream has produced: the tail stream waits for it first"""
+        if self.tail_stream is not None:
+            self.tail_stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        return self.tail_context()
+
     def join(self):
         self.ctx.join()
 

@@ -56,6 +56,103 @@ class TorchDistComm:
         return wait
 
 
+class RcclComm:
+    """all_gather straight through RCCL: ncclAllGather (ctypes on the librccl.so torch itself has loaded) enqueued on the CURRENT
+    torch stream with a communicator of its own -- a few microseconds of host time per exchange and no hop through a collective
+    stream, against 55-80 us per torch.distributed all_gather_into_tensor (tools/shard_host_probe.py: three of those per pass made
+    the sharded pass host-bound).  The communicator's unique id travels through the torch.distributed group once, at start-up;
+    torch.distributed is still what launches and synchronises the ranks.  `RcclComm.create(group)` falls back to TorchDistComm when
+    the library or the communicator cannot be had."""
+
+    _UID_BYTES = 128
+
+    def __init__(self, group=None, lib_path=None):
+        import ctypes as C
+        import os
+        import torch
+        import torch.distributed as dist
+        self.torch, self.C = torch, C
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        if lib_path is None:
+            lib_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        lib = C.CDLL(lib_path)
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_byte * RcclComm._UID_BYTES)]
+        lib.ncclGetUniqueId.restype = C.c_int
+        lib.ncclGetUniqueId.argtypes = [C.POINTER(UniqueId)]
+        lib.ncclCommInitRank.restype = C.c_int
+        lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+        lib.ncclAllGather.restype = C.c_int
+        lib.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        lib.ncclCommDestroy.restype = C.c_int
+        lib.ncclCommDestroy.argtypes = [C.c_void_p]
+        lib.ncclGetErrorString.restype = C.c_char_p
+        lib.ncclGetErrorString.argtypes = [C.c_int]
+        self.lib = lib
+        uid = UniqueId()
+        if self.rank == 0:
+            self._check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(dev)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        uid = UniqueId.from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
+        comm = C.c_void_p()
+        self._check(lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
+        self.comm = comm
+
+    @classmethod
+    def create(cls, group=None):
+        """RcclComm, or TorchDistComm when RCCL cannot be reached directly (every rank takes the same branch: the outcome is agreed
+        on through the group)."""
+        import torch
+        import torch.distributed as dist
+        comm, ok = None, 1
+        try:
+            comm = cls(group)
+        except Exception:                                     # noqa: BLE001 -- any failure means "use torch.distributed"
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            return comm
+        if comm is not None:
+            comm.close()
+        return TorchDistComm(group)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what}: {self.lib.ncclGetErrorString(rc).decode()} ({rc})")
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+    def _gather(self, t, stream):
+        torch = self.torch
+        t = t.contiguous()
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        nbytes = t.numel() * t.element_size()
+        self._check(self.lib.ncclAllGather(t.data_ptr(), out.data_ptr(), nbytes, 1, self.comm, stream.cuda_stream), "ncclAllGather")   # 1 = ncclUint8
+        return t, out
+
+    def all_gather(self, t):
+        """on the current stream, in order with the kernels around it (no event, no other stream)"""
+        torch = self.torch
+        with torch.cuda.device(t.device):
+            keep, out = self._gather(t, torch.cuda.current_stream(t.device))
+        out._urh_keep = keep                                  # the send buffer lives as long as the result
+        return out
+
+    def all_gather_start(self, t):
+        """the same, as a function to call for the result (the engine-agnostic orchestration starts the halo exchange before the hot
+        kernel and picks the result up after it): enqueued right here, on the current stream"""
+        out = self.all_gather(t)
+        return lambda: out
+
+
 class ThreadComm:
     """W ranks as W threads of one process (lock-step through a barrier): lets a 1-GPU box (and plain CPU
     tests) execute the sharded path for any world size."""
@@ -147,8 +244,11 @@ class ShardedPipeline:
             raise ValueError("halo_given: ranks > 0 pass the two samples before their shard as left_halo")
         pending = left = None
         if not halo_given:
-            pending = c.all_gather_start(e.tail(iq_local, p))
-            if hasattr(e, "runs_begin"):           # the halo exchange overlaps the hot kernel (all chunks but the first)
+            # the halo exchange overlaps the hot kernel (all chunks but the first); on a pipelined engine it is issued on the tail
+            # stream (behind the previous pass's exchanges), which first waits for whatever produced the shard on the caller's stream
+            with (e.halo_context() if hasattr(e, "halo_context") else contextlib.nullcontext()):
+                pending = c.all_gather_start(e.tail(iq_local, p))
+            if hasattr(e, "runs_begin"):
                 e.runs_begin(iq_local, pos_base, n_total, self.rank, self.world, p, want_qad)
         else:
             if self.rank > 0:
