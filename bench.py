@@ -100,6 +100,8 @@ def tuning_from_env():
         t["arena_wait_stream"] = 1
     if "URH_PROFILE_BRACKET" in e:
         t["profile_bracket"] = 1
+    if "URH_TAIL_MASKED" in e:
+        t["tail_masked"] = int(e["URH_TAIL_MASKED"])
     if "URH_HOT_CUS_REMOVED" in e:
         t["hot_cus_removed_per_xcd"] = int(e["URH_HOT_CUS_REMOVED"])
     prio = int(e.get("URH_TAIL_STREAM_PRIORITY", "-1" if e.get("URH_TAIL_PRIORITY") else "0"))

@@ -95,7 +95,9 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
  * stream-level bracket, which reads 3-5 % longer than the kernel runs), "hot_cus_removed_per_xcd" (0 .. 16, default 4; set before
  * urhgpu_ctx_set_pipelined: the hot kernel of a pipelined pass runs on a private stream whose CU mask leaves that many CUs of every XCD
  * out -- on 224 of the MI355X's 256 CUs the kernel is 5 % faster than on all of them, and the CUs left alone serve the previous pass's
- * tail; 0: no mask, the hot kernel runs on the caller's stream).  Unknown key: URHGPU_ERR_ARG. */
+ * tail; 0: no mask, the hot kernel runs on the caller's stream), "tail_masked" (1, before urhgpu_ctx_set_pipelined: the tail runs on a
+ * private stream masked to exactly the CUs the hot mask leaves out, replacing the caller's tail stream; measured no faster -- the hot
+ * kernel gains 1 % and a single capture's latency loses 30 % -- default 0).  Unknown key: URHGPU_ERR_ARG. */
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value);
 int urhgpu_ctx_join(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no

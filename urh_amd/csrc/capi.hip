@@ -519,6 +519,16 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
             (void)hipStreamDestroy(ctx->hot_masked);
             ctx->hot_masked = nullptr;
         }
+        if (ctx->hot_masked && ctx->tune_tail_masked) {
+            // A/B: the tail on a private stream masked to exactly the CUs the hot kernel leaves alone (replaces the caller's tail stream)
+            uint32_t inv[8];
+            for (int w = 0; w < words; ++w) inv[w] = ~mask[w];
+            hipStream_t ts = nullptr;
+            if (hipExtStreamCreateWithCUMask(&ts, (uint32_t)words, inv) == hipSuccess) {
+                if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
+                ctx->tail_stream = ts; ctx->own_tail_stream = true;
+            } else (void)hipGetLastError();
+        }
     }
     ctx->pipelined = true;
     return URHGPU_OK;
@@ -534,6 +544,9 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
 //   arena_wait_stream   1: arena reuse is guarded by a stream wait instead of bounded host run-ahead (see begin_pipelined_pass); default 0
 //   tail_priority       1: a private tail stream is created at the device's highest priority (before urhgpu_ctx_set_pipelined); default 0
 //   profile_bracket     1: urhgpu_ctx_profile_* report the stream-level bracket around the hot launch instead of the dispatch's own timing
+//   tail_masked         1: the tail on a private stream masked to the CUs the hot mask leaves out (tools/r3_tailmask.sh, round 3: with 4 / 6 /
+//                       8 / 12 CUs per XCD for the tail 0.301 / 0.323 / 0.313 / 0.335 ms per step with D2H against 0.298-0.302 unmasked,
+//                       hot kernel 0.274-0.277 against 0.276-0.279: what slows the hot kernel inside the run is not the tail's wave slots)
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return URHGPU_ERR_ARG;
     if (!strcmp(key, "hot_lds_kb")) { if (value < 0 || value > 150) return URHGPU_ERR_ARG; ctx->hot_lds_pad = value * 1024; }
@@ -542,6 +555,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "arena_wait_stream")) ctx->arena_wait_on_stream = value != 0;
     else if (!strcmp(key, "tail_priority")) ctx->tune_tail_priority = value != 0;
     else if (!strcmp(key, "profile_bracket")) ctx->prof_bracket = value != 0;
+    else if (!strcmp(key, "tail_masked")) ctx->tune_tail_masked = value != 0;
     else if (!strcmp(key, "hot_cus_removed_per_xcd")) { if (value < 0 || value > 16) return URHGPU_ERR_ARG; ctx->tune_hot_cus_removed = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;

@@ -89,6 +89,7 @@ struct urhgpu_ctx {
     bool pipelined = false;
     int hot_lds_pad_sharded = 33 * 1024;   // the same for the urhgpu_shard_* passes (their tail is longer: see urhgpu_ctx_set_tuning)
     bool tune_tail_priority = false;
+    bool tune_tail_masked = false;         // the tail stream is a private one masked to the CUs the hot mask leaves out (A/B knob)
     int tune_hot_cus_removed = 4;          // CUs per XCD the hot kernel of a pipelined pass leaves alone (0: no mask); see urhgpu_ctx_set_pipelined
     hipStream_t hot_masked = nullptr;      // private CU-masked stream of the hot kernel (pipelined mode)
     hipEvent_t ev_in = nullptr;
