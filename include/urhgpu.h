@@ -382,6 +382,13 @@ int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_
  * then fetches every segment and takes that decision in numpy's order.  Synchronous. */
 int urhgpu_message_ranges_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold, int64_t *seg_out, int64_t cap_seg_out,
                               int64_t *n_seg_out, int64_t *merged_out, int64_t cap_merged_out, int64_t *n_merged_out, int *merge_ambiguous);
+/* The same pass that also leaves afp_demod(iq, noise_threshold, "ASK") (signal_functions.pyx:343-378) in d_qad_ask (DEVICE float[n]):
+ * AutoInterpretation.estimate segments by the noise threshold and then demodulates with it (AutoInterpretation.py:386-404) -- for
+ * an OOK / ASK capture both read the same samples, so one pass over them serves both (8 B read + 4 B written per sample instead of
+ * 8 + 8 + 4).  float32 / complex64 captures only (URHGPU_ERR_UNSUPPORTED otherwise, and for a NaN threshold). */
+int urhgpu_message_ranges_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold, int64_t *seg_out,
+                                    int64_t cap_seg_out, int64_t *n_seg_out, int64_t *merged_out, int64_t cap_merged_out,
+                                    int64_t *n_merged_out, int *merge_ambiguous, float *d_qad_ask);
 /* rect[rect > thr] (AutoInterpretation.py:227), order preserved; *d_count (device) = number kept. */
 int urhgpu_compact_gt_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, float thr, float *d_out, int64_t *d_count);
 /* positions i >= 1 where (x[i] <= center) != (x[i-1] <= center), ascending (get_plateau_lengths,

@@ -747,6 +747,34 @@ def test_message_ranges_ook_bursts(pipe, oracle):
     assert n_amb == 0                                   # the test captures are not borderline: the device decided all of them
 
 
+def test_segmentation_pass_leaves_the_ask_demodulation(pipe, oracle):
+    """urhgpu_message_ranges_demod_dev: the segmentation pass's by-product equals afp_demod(iq, noise, "ASK") bit for bit (oracle and the
+    library's own afp_demod), and its ranges equal the plain pass's -- capture lengths around the tile / chunk sizes, a threshold
+    that gates many samples and one that gates none"""
+    import torch
+    from urh_amd import estimators
+    from urh_amd.pipeline import DemodParams
+    for n, seed in ((1, 1), (2, 2), (2047, 3), (2048, 4), (2049, 5), (8192 * 3, 6), (300_001, 7), (1_234_567, 8)):
+        rng = np.random.default_rng(seed)
+        env = np.repeat(rng.integers(0, 2, n // 20 + 1), 20)[:n] * (rng.random(n // 2000 + 1) > 0.4).repeat(2000)[:n]
+        c = (env * np.exp(2j * np.pi * 0.013 * np.arange(n))) + 0.02 * (rng.standard_normal(n) + 1j * rng.standard_normal(n))
+        iq = np.ascontiguousarray(c.astype(np.complex64).view(np.float32).reshape(-1, 2))
+        dev = torch.from_numpy(iq).cuda()
+        for nt in (0.0, 0.1, 0.7):
+            qad = torch.full((n,), 7.0, dtype=torch.float32, device="cuda")
+            got = estimators.message_ranges_dev(pipe, dev, nt, qad_ask=qad)
+            plain = estimators.message_ranges_dev(pipe, dev, nt)
+            assert np.array_equal(got[0], plain[0]) and got[1] == plain[1] and np.array_equal(got[2], plain[2]) and got[3:] == plain[3:], (n, nt)
+            want = oracle.afp_demod(iq, nt, "ASK", 2)
+            assert bits_equal(qad.cpu().numpy(), want), (n, nt)
+            assert bits_equal(pipe.afp_demod(dev, DemodParams("ASK", 1, nt)).cpu().numpy(), want), (n, nt)
+    # integer captures keep the two-pass form
+    from urh_amd import _lib
+    i8 = torch.zeros((4096, 2), dtype=torch.int8, device="cuda")
+    with pytest.raises(_lib.UrhGpuError):
+        estimators.message_ranges_dev(pipe, i8, 0.1, qad_ask=torch.empty(4096, dtype=torch.float32, device="cuda"))
+
+
 def test_estimate_takes_the_numpy_merge_when_the_device_merge_is_borderline(pipe):
     """a pulse length within rounding of mean +- std makes urhgpu_message_ranges_dev hand the OOK merge to numpy: forced here, the
     estimate must come out the same"""

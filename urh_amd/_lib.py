@@ -112,6 +112,7 @@ PROTOTYPES = {
     "urhgpu_magnitude_chunk_stats_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp, _vp]),
     "urhgpu_segment_runs_dev": (_i, [_vp, _vp, _i, _i64, _f, _vp, _i64, _vp]),
     "urhgpu_message_ranges_dev": (_i, [_vp, _vp, _i, _i64, _f, _vp, _i64, C.POINTER(_i64), _vp, _i64, C.POINTER(_i64), C.POINTER(_i)]),
+    "urhgpu_message_ranges_demod_dev": (_i, [_vp, _vp, _i, _i64, _f, _vp, _i64, C.POINTER(_i64), _vp, _i64, C.POINTER(_i64), C.POINTER(_i), _vp]),
     "urhgpu_compact_gt_dev": (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     "urhgpu_edges_le_dev": (_i, [_vp, _vp, _i64, _f, _vp, _i64, _vp]),
     "urhgpu_minmax_f32_dev": (_i, [_vp, _vp, _i64, _vp]),

@@ -223,6 +223,12 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
         // message segmentation: state = (|sample| > noise threshold) with the 10-sample outlier tolerance.  Reuses the
         // ASK arithmetic with max_magnitude 1 (q = sqrtf(I*I + Q*Q) exactly), no noise gating, threshold = noise level.
         a.seg_mode = 1; a.max_magnitude = 1.0f; a.noise_sqrd = -1.0f; a.noise_val = __builtin_nanf("");
+        if (d_qad) {
+            // the pass also leaves afp_demod(iq, noise_threshold, "ASK") in d_qad (float32 captures; p->center is the noise threshold here)
+            if (!from_iq || p->dtype != URHGPU_DT_F32) return URHGPU_ERR_UNSUPPORTED;
+            a.dm_noise_sqrd = p->center * p->center; a.dm_noise_val = 0.0f;
+            URH_TRY(max_magnitude_for(p->dtype, &a.dm_max_magnitude));
+        }
     }
     ChunkInfo *chunks = (ChunkInfo *)ctx->arena.take((size_t)pl.n_chunks * sizeof(ChunkInfo));
     uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
@@ -1028,8 +1034,8 @@ namespace {
 __global__ void k_set_i64(int64_t *p, int64_t v) { *p = v; }
 }
 
-int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold,
-                            int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows) {
+static int segment_runs_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold,
+                             int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows, float *d_qad_ask) {
     if (!ctx || n < 0 || !d_n_rows || cap_rows < 0) return URHGPU_ERR_ARG;
     if (dtype_bytes(dtype) == 0) return URHGPU_ERR_DTYPE;
     URH_HIP(hipSetDevice(ctx->device));
@@ -1044,11 +1050,37 @@ int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_
     const Plan pl = make_plan(ctx, n, p.tolerance);
     URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, cap_rows, false, false)));
     ctx->arena.reset();
-    return digitize(ctx, true, d_iq, n, &p, nullptr, d_rows, cap_rows, d_n_rows, ctx->d_counts + 8, ctx->d_counts + 9, pl, 1);
+    return digitize(ctx, true, d_iq, n, &p, d_qad_ask, d_rows, cap_rows, d_n_rows, ctx->d_counts + 8, ctx->d_counts + 9, pl, 1);
 }
+
+int urhgpu_segment_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold,
+                            int64_t *d_rows, int64_t cap_rows, int64_t *d_n_rows) {
+    return segment_runs_impl(ctx, d_iq, dtype, n, noise_threshold, d_rows, cap_rows, d_n_rows, nullptr);
+}
+
+static int message_ranges_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold, int64_t *seg_out, int64_t cap_seg_out,
+                               int64_t *n_seg_out, int64_t *merged_out, int64_t cap_merged_out, int64_t *n_merged_out, int *merge_ambiguous,
+                               float *d_qad_ask);
 
 int urhgpu_message_ranges_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold, int64_t *seg_out, int64_t cap_seg_out,
                               int64_t *n_seg_out, int64_t *merged_out, int64_t cap_merged_out, int64_t *n_merged_out, int *merge_ambiguous) {
+    return message_ranges_impl(ctx, d_iq, dtype, n, noise_threshold, seg_out, cap_seg_out, n_seg_out, merged_out, cap_merged_out, n_merged_out,
+                               merge_ambiguous, nullptr);
+}
+
+int urhgpu_message_ranges_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold, int64_t *seg_out,
+                                    int64_t cap_seg_out, int64_t *n_seg_out, int64_t *merged_out, int64_t cap_merged_out, int64_t *n_merged_out,
+                                    int *merge_ambiguous, float *d_qad_ask) {
+    if (!d_qad_ask || ((uintptr_t)d_qad_ask & 7)) return URHGPU_ERR_ARG;
+    if (dtype != URHGPU_DT_F32) return URHGPU_ERR_UNSUPPORTED;
+    if (n > 0 && noise_threshold != noise_threshold) return URHGPU_ERR_UNSUPPORTED;     // (no segmentation pass runs for a NaN threshold)
+    return message_ranges_impl(ctx, d_iq, dtype, n, noise_threshold, seg_out, cap_seg_out, n_seg_out, merged_out, cap_merged_out, n_merged_out,
+                               merge_ambiguous, d_qad_ask);
+}
+
+static int message_ranges_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int64_t n, float noise_threshold, int64_t *seg_out, int64_t cap_seg_out,
+                               int64_t *n_seg_out, int64_t *merged_out, int64_t cap_merged_out, int64_t *n_merged_out, int *merge_ambiguous,
+                               float *d_qad_ask) {
     if (!ctx || n < 0 || !n_seg_out || cap_seg_out < 0 || cap_merged_out < 0 || (cap_seg_out > 0 && !seg_out) || (cap_merged_out > 0 && !merged_out))
         return URHGPU_ERR_ARG;
     if (dtype_bytes(dtype) == 0) return URHGPU_ERR_DTYPE;
@@ -1071,7 +1103,8 @@ int urhgpu_message_ranges_dev(urhgpu_ctx *ctx, const void *d_iq, int dtype, int6
     SegCtl *d_ctl = (SegCtl *)ctx->staging.take(seg_ctl_bytes());
     int64_t *d_n_rows = (int64_t *)ctx->staging.take(64);
     if (!d_rows || !d_seg || !d_msgs || !scratch || !d_ctl || !d_n_rows) return URHGPU_ERR_ARG;
-    URH_TRY(urhgpu_segment_runs_dev(ctx, d_iq, dtype, n, noise_threshold, d_rows, cap_rows, d_n_rows));
+    URH_TRY(segment_runs_impl(ctx, d_iq, dtype, n, noise_threshold, d_rows, cap_rows, d_n_rows, d_qad_ask));
+    if (d_qad_ask && n <= 2) URH_HIP(hipMemsetAsync(d_qad_ask, 0, (size_t)n * 4, ctx->stream));     // afp_demod of up to two samples: zeros (signal_functions.pyx:335-336)
     URH_TRY(launch_message_ranges(d_rows, d_n_rows, cap_rows, d_iq, dtype, n, noise_threshold, merge ? 1 : 0, d_seg, d_msgs, cap_seg, d_ctl, scratch,
                                   ctx->stream));
     URH_HIP(hipGetLastError());

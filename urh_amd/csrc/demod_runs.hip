@@ -785,13 +785,20 @@ __global__ __launch_bounds__(kBlock, URH_MINWAVES) void k_demod_runs(const RunAr
                     if (SRC == SRC_IQ) {
                         if (j == 0 && rb == 0 && first_row && !p.seg_mode) q0[0] = p.noise_val;   // result[0] = NOISE (:361)
                         if (WRITE_QAD) {
+                            float w0 = q0[j], w1 = q1[j];
+                            if (MOD == URHGPU_MOD_ASK && DT == URHGPU_DT_F32 && p.seg_mode) {     // see k_demod_runs_bp
+                                const float m0 = cur[j].c0 * cur[j].c0 + cur[j].d0 * cur[j].d0, m1 = cur[j].c1 * cur[j].c1 + cur[j].d1 * cur[j].d1;
+                                w0 = (m0 <= p.dm_noise_sqrd) ? p.dm_noise_val : __builtin_sqrtf(m0) / p.dm_max_magnitude;
+                                w1 = (m1 <= p.dm_noise_sqrd) ? p.dm_noise_val : __builtin_sqrtf(m1) / p.dm_max_magnitude;
+                                if (j == 0 && rb == 0 && first_row) w0 = p.dm_noise_val;
+                            }
 #if URH_NT
                             typedef float v2s __attribute__((ext_vector_type(2)));
-                            if (FULL || ta + off + 1 < a1) { const v2s qq = {q0[j], q1[j]}; __builtin_nontemporal_store(qq, (v2s *)(p.qad + ta + off)); }
+                            if (FULL || ta + off + 1 < a1) { const v2s qq = {w0, w1}; __builtin_nontemporal_store(qq, (v2s *)(p.qad + ta + off)); }
 #else
-                            if (FULL || ta + off + 1 < a1) *(float2 *)(p.qad + ta + off) = make_float2(q0[j], q1[j]);
+                            if (FULL || ta + off + 1 < a1) *(float2 *)(p.qad + ta + off) = make_float2(w0, w1);
 #endif
-                            else if (ta + off < a1) p.qad[ta + off] = q0[j];
+                            else if (ta + off < a1) p.qad[ta + off] = w0;
                         }
                     }
                     uint32_t st0, st1;
@@ -1065,12 +1072,21 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
             if (SRC == SRC_IQ) {
                 if (row0 && lane == 0 && !p.seg_mode) q0[0] = p.noise_val;            // result[0] = NOISE (:361)
                 if (WRITE_QAD) {
+                    float w0 = q0[j], w1 = q1[j];
+                    if (MOD == URHGPU_MOD_ASK && DT == URHGPU_DT_F32 && p.seg_mode) {
+                        // the segmentation pass leaves the ASK demodulation of the same samples (signal_functions.pyx:343-378, ASK branch,
+                        // with the demodulation's own constants; result[0] = NOISE): the estimator needs both and this one has the samples
+                        const float m0 = cur[j].c0 * cur[j].c0 + cur[j].d0 * cur[j].d0, m1 = cur[j].c1 * cur[j].c1 + cur[j].d1 * cur[j].d1;
+                        w0 = (m0 <= p.dm_noise_sqrd) ? p.dm_noise_val : __builtin_sqrtf(m0) / p.dm_max_magnitude;
+                        w1 = (m1 <= p.dm_noise_sqrd) ? p.dm_noise_val : __builtin_sqrtf(m1) / p.dm_max_magnitude;
+                        if (row0 && lane == 0) w0 = p.dm_noise_val;
+                    }
 #if URH_NT
                     typedef float v2s __attribute__((ext_vector_type(2)));
-                    const v2s qq = {q0[j], q1[j]};
+                    const v2s qq = {w0, w1};
                     __builtin_nontemporal_store(qq, (v2s *)(p.qad + a0 + off));
 #else
-                    *(float2 *)(p.qad + a0 + off) = make_float2(q0[j], q1[j]);
+                    *(float2 *)(p.qad + a0 + off) = make_float2(w0, w1);
 #endif
                 }
             }

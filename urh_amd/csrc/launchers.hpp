@@ -30,6 +30,9 @@ struct RunArgs {
     int launch_part;         // 0 all chunks, 1 all but the first, 2 the first only (launchers; see launch_runs_4)
     int seg_mode;            // 1: message segmentation on magnitudes (auto_interpretation.pyx:55-111): sample 0 is an
                              // ordinary sample (no result[0] = NOISE) and the state machine starts in ITS state
+    // seg_mode with a qad buffer (float32 captures): the segmentation pass also leaves afp_demod(iq, noise, "ASK") there, from its own
+    // constants (noise_sqrd / max_magnitude / noise_val above are the segmentation's: no gating, magnitude 1)
+    float dm_noise_sqrd, dm_max_magnitude, dm_noise_val;
     int lds_pad;             // extra dynamic LDS bytes per workgroup of k_demod_runs_bp: caps its workgroups per CU so that
                              // wave slots stay free for the tail of the previous pass (pipelined mode)
     float thr[kMaxOrder - 1];

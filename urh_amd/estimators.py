@@ -139,10 +139,12 @@ def segment_messages_dev(pipe, iq, noise_threshold: float, as_array: bool = Fals
     return seg if as_array else _as_tuples(seg)
 
 
-def message_ranges_dev(pipe, iq, noise_threshold: float, merge: bool = True, cap_seg: int = 4096, cap_merged: int = 65536):
+def message_ranges_dev(pipe, iq, noise_threshold: float, merge: bool = True, cap_seg: int = 4096, cap_merged: int = 65536, qad_ask=None):
     """Segmentation and (optionally) the OOK merge without the per-pulse table leaving the GPU (urhgpu_message_ranges_dev).
     Returns (segments[:cap_seg], n_segments, merged[:cap_merged] or None, n_merged, ambiguous): (K, 2) int64 arrays as
-    segment_messages_dev(as_array=True) / merge_message_segments_for_ook give them, truncated to the capacities."""
+    segment_messages_dev(as_array=True) / merge_message_segments_for_ook give them, truncated to the capacities.
+    qad_ask: a float32 device tensor (n,) that the same pass fills with afp_demod(iq, noise_threshold, "ASK") (float32 captures:
+    urhgpu_message_ranges_demod_dev)."""
     torch = pipe.torch
     if iq.dtype == torch.complex64:
         iq = torch.view_as_real(iq)
@@ -152,10 +154,15 @@ def message_ranges_dev(pipe, iq, noise_threshold: float, merge: bool = True, cap
     seg = np.empty((cap_seg, 2), np.int64)
     mrg = np.empty((cap_merged, 2), np.int64) if merge else None
     n_seg, n_mrg, amb = C.c_int64(0), C.c_int64(0), C.c_int(0)
-    _lib.check(_lib.load().urhgpu_message_ranges_dev(
-        pipe.ctx.handle, C.c_void_p(iq.data_ptr()), dtype_code(_torch_dtype(iq)), n, float(noise_threshold),
-        seg.ctypes.data_as(C.c_void_p), cap_seg, C.byref(n_seg),
-        mrg.ctypes.data_as(C.c_void_p) if merge else None, cap_merged if merge else 0, C.byref(n_mrg) if merge else None, C.byref(amb)))
+    args = (pipe.ctx.handle, C.c_void_p(iq.data_ptr()), dtype_code(_torch_dtype(iq)), n, float(noise_threshold),
+            seg.ctypes.data_as(C.c_void_p), cap_seg, C.byref(n_seg),
+            mrg.ctypes.data_as(C.c_void_p) if merge else None, cap_merged if merge else 0, C.byref(n_mrg) if merge else None, C.byref(amb))
+    if qad_ask is not None:
+        if qad_ask.dtype != torch.float32 or qad_ask.numel() != n or not qad_ask.is_contiguous():
+            raise ValueError("qad_ask: contiguous float32 tensor with one element per sample")
+        _lib.check(_lib.load().urhgpu_message_ranges_demod_dev(*args, C.c_void_p(qad_ask.data_ptr())))
+    else:
+        _lib.check(_lib.load().urhgpu_message_ranges_dev(*args))
     return (seg[:min(n_seg.value, cap_seg)], n_seg.value, mrg[:min(n_mrg.value, cap_merged)] if merge else None, n_mrg.value,
             bool(amb.value))
 
@@ -547,7 +554,12 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
     lap("noise_ms")
     # one row per OOK pulse before merging: hundreds of thousands, which stay on the GPU -- the host gets the first segments
     # (modulation detection looks at 100) and the merged messages
-    segments, n_segments, merged, n_merged, ambiguous = message_ranges_dev(pipe, iq, noise)
+    # an OOK / ASK capture named as such is demodulated by the segmentation pass itself (the same samples, the same threshold): one pass
+    # over the capture instead of two
+    data = None
+    if modulation in ("OOK", "ASK") and iq.dtype == torch.float32 and int(iq.shape[0]) > 0 and float(noise) == float(noise):
+        data = torch.empty(int(iq.shape[0]), dtype=torch.float32, device=iq.device)
+    segments, n_segments, merged, n_merged, ambiguous = message_ranges_dev(pipe, iq, noise, qad_ask=data)
     lap("segment_messages_ms")
     if modulation is None:
         modulation = detect_modulation_for_messages_dev(iq, segments[:100].tolist(), pipe=pipe)
@@ -571,7 +583,8 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
     else:
         raise ValueError("Unsupported Modulation")
     lap("modulation_and_merge_ms")
-    data = pipe.afp_demod(iq, DemodParams(mod, 1, float(noise)))
+    if data is None:
+        data = pipe.afp_demod(iq, DemodParams(mod, 1, float(noise)))
     if keep is not None:                             # the demodulated signal and what it was demodulated with: the caller's Signal.qad cache
         keep.update(qad=data, mod=mod, noise=float(noise))
     lap("afp_demod_ms")
