@@ -505,24 +505,36 @@ __global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins) {
 __device__ __forceinline__ double me_edge(const MsgState &s, int64_t i) { return s.e0 + (double)i * s.delta; }
 
 constexpr int kMeHistLds = 4096;             // bins kept in LDS per workgroup (the pool's max_bins is at most this)
-constexpr int kMeEdgeLds = 2048;             // edges kept in LDS (histograms with more bins evaluate the edges per sample)
 __device__ __forceinline__ double me_edge32(const MsgState &s, int i) { return s.e0 + (double)i * s.delta; }
+// smallest float32 that is >= the float64 edge / largest float32 that is <= it: a float32 sample compares with the float64 edge exactly
+// as it compares with this float32 (np.histogram casts the samples to float64 and searches the float64 edges)
+__device__ __forceinline__ float me_f32_at_or_above(double e) {
+    float f = (float)e;
+    if ((double)f < e) f = __uint_as_float(f >= 0.f ? (f == 0.f ? 1u : __float_as_uint(f) + 1u) : __float_as_uint(f) - 1u);
+    return f;
+}
+__device__ __forceinline__ float me_f32_at_or_below(double e) {
+    float f = (float)e;
+    if ((double)f > e) f = __uint_as_float(f > 0.f ? __float_as_uint(f) - 1u : (f == 0.f ? 0x80000001u : __float_as_uint(f) + 1u));
+    return f;
+}
 constexpr int kMeHistGroup = 8;              // consecutive tiles per workgroup: one flush of the LDS counters per message and group
 __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int64_t n_tiles,
                                                        int64_t max_bins, unsigned int *counts) {
     // demodulated signals sit on two or four levels: nearly every sample of a message lands in a handful of bins.  Counting
     // straight into device memory serialises the whole pass on those few addresses (40 ms for a 1 GiB capture).  A wavefront
-    // counts the lanes that share a bin with one ballot per distinct bin (one to three rounds per 64 samples), the workgroup
-    // accumulates in LDS, and only the non-empty bins of a tile reach device memory.
-    // The pass is bound by instruction issue, not by HBM: the bin is guessed in float32 and checked against the exact float64
-    // edges, which come from an LDS table (evaluating first + i * delta per sample costs two conversions and four float64 operations
-    // per edge).  A workgroup walks kMeHistGroup consecutive tiles and flushes its LDS counters when the message changes or at the end
-    // (a capture that is ONE message had 32 768 workgroups adding their counters to the same few words of device memory: 371 us).
+    // counts the lanes that share a bin with one ballot per distinct bin for the first two bins it meets in a row of 64 samples and
+    // sends what is left of the row (a noisy amplitude spreads over a dozen bins) through LDS atomics; the workgroup accumulates in
+    // LDS, and only the non-empty bins of a tile reach device memory.
+    // The pass is bound by instruction issue, not by HBM: the bin is guessed in float32 and checked against a float32 table of the
+    // edges in LDS that decides exactly as the float64 edges do (me_f32_at_or_above).  A workgroup walks kMeHistGroup consecutive
+    // tiles and flushes its LDS counters when the message changes or at the end (a capture that is ONE message had 32 768
+    // workgroups adding their counters to the same few words of device memory: 371 us).
     __shared__ unsigned int s_c[kMeHistLds];
-    __shared__ double s_e[kMeEdgeLds + 2];
+    __shared__ float s_e[kMeHistLds + 2];                   // s_e[k] = first float32 inside bin k or above; s_e[nb] = first float32 beyond the last bin
     const int64_t tile0 = (int64_t)blockIdx.x * kMeHistGroup, tile1 = (tile0 + kMeHistGroup < n_tiles) ? tile0 + kMeHistGroup : n_tiles;
     int cur_msg = -1, nb = 0;
-    bool valid = false, in_lds = false, table = false;
+    bool valid = false, big = false;
     MsgState m = st[0];
     unsigned int *out = counts;
     const int lane = threadIdx.x & 63;
@@ -530,7 +542,7 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
     const bool last = tix == tile1;
     MsgTile t = tiles[last ? tile1 - 1 : tix];
     if (last || t.msg != cur_msg) {                            // (workgroup-uniform)
-        if (valid && in_lds) {                                 // flush the message's counters
+        if (valid) {                                           // flush the message's counters
             __syncthreads();
             for (int k = threadIdx.x; k < nb; k += kMeBlock) if (s_c[k]) atomicAdd(&out[k], s_c[k]);
             __syncthreads();
@@ -538,48 +550,71 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
         if (last) break;
         cur_msg = t.msg;
         m = st[t.msg];
+        big = false;
         valid = !(m.L <= 0 || m.n_edges < 2 || m.n_edges - 1 > max_bins || m.n_edges - 1 > INT32_MAX - 1);
-        nb = valid ? (int)(m.n_edges - 1) : 0;
-        in_lds = nb <= kMeHistLds; table = nb + 1 <= kMeEdgeLds;
+        if (valid && m.n_edges - 1 > kMeHistLds) { valid = false; big = true; }       // more bins than the LDS holds: the plain path below
+        nb = (valid || big) ? (int)(m.n_edges - 1) : 0;
         out = counts + (int64_t)t.msg * max_bins;
         if (valid) {
-            if (in_lds) for (int k = threadIdx.x; k < nb; k += kMeBlock) s_c[k] = 0u;
-            if (table) for (int k = threadIdx.x; k <= nb; k += kMeBlock) s_e[k] = me_edge32(m, k);
+            for (int k = threadIdx.x; k < nb; k += kMeBlock) s_c[k] = 0u;
+            for (int k = threadIdx.x; k <= nb; k += kMeBlock) {
+                // the last bin is closed on the right: "beyond it" starts at the first float32 above the last edge
+                float e = me_f32_at_or_above(me_edge32(m, k));
+                if (k == nb) { const float top = me_f32_at_or_below(me_edge32(m, nb)); e = __uint_as_float(top >= 0.f ? (top == 0.f ? 1u : __float_as_uint(top) + 1u) : __float_as_uint(top) - 1u); }
+                s_e[k] = e;
+            }
             __syncthreads();
         }
     }
+    if (big && (int64_t)t.idx * kMeTile < m.L) {
+        // a histogram of more than kMeHistLds bins (a caller with a larger pool): float64 edges per sample, counters in device memory
+        const double e0 = m.e0, eN = me_edge32(m, nb);
+        const float e0f = (float)e0, invf = (m.delta > 0.0) ? (float)(1.0 / m.delta) : 0.f;
+        const float *r = me_src(x, kept, m) + m.a;
+        for (int j = 0; j < kMePer; ++j) {
+            const int64_t i = (int64_t)t.idx * kMeTile + threadIdx.x + (int64_t)j * kMeBlock;
+            if (i >= m.L) continue;
+            const double v = (double)r[i];
+            if (!(v >= e0 && v <= eN)) continue;
+            const float g = (r[i] - e0f) * invf;
+            int k = (g >= 0.f) ? ((g < (float)(nb - 1)) ? (int)g : nb - 1) : 0;
+            while (k > 0 && me_edge32(m, k) > v) --k;
+            while (k < nb - 1 && me_edge32(m, k + 1) <= v) ++k;      // last bin closed on the right
+            atomicAdd(&out[k], 1u);
+        }
+        continue;
+    }
     if (!valid || (int64_t)t.idx * kMeTile >= m.L) continue;
-    const double e0 = m.e0, eN = me_edge32(m, nb);
-    const float e0f = (float)e0, invf = (m.delta > 0.0) ? (float)(1.0 / m.delta) : 0.f;
+    const float lo_all = s_e[0], hi_all = s_e[nb];             // inside: lo_all <= v < hi_all (NaN: neither)
+    const float e0f = (float)m.e0, invf = (m.delta > 0.0) ? (float)(1.0 / m.delta) : 0.f;
     const float *r = me_src(x, kept, m) + m.a;
     const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
     float val[kMePer];
 #pragma unroll
     for (int j = 0; j < kMePer; ++j) { const int64_t i = i0 + (int64_t)j * kMeBlock; val[j] = (i < m.L) ? r[i] : __builtin_nanf(""); }
     int bin[kMePer];
-    if (table) {
+    {
         // straight-line code for all 16 rows (their LDS reads overlap): guess, one step either way, check.  The float32 guess is off by
-        // far less than one bin for <= 2047 bins (3 roundings of 2^-24 each), so the check never fails -- if it ever does, the exact
-        // search below repairs it.  (A float32-only fast path for samples far from every edge was tried: slower, the rows that need
-        // the float64 edges anyway pay for both.)
+        // less than one bin for a few thousand bins (three roundings of 2^-24 each), so the check hardly ever fails -- where it does, the
+        // exact search below repairs it.
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < kMePer; ++j) {
-            const double v = (double)val[j];
-            const bool in = v >= e0 && v <= eN;                // inside (and not NaN)
-            const float g = (val[j] - e0f) * invf;
+            const float v = val[j];
+            const bool in = v >= lo_all && v < hi_all;         // inside (and not NaN)
+            const float g = (v - e0f) * invf;
             int k = (g >= 0.f) ? ((g < (float)(nb - 1)) ? (int)g : nb - 1) : 0;
             k = in ? k : 0;
-            const double lo = s_e[k], hi = s_e[k + 1];
+            const float lo = s_e[k], hi = s_e[k + 1];
             k += (v >= hi && k < nb - 1) ? 1 : ((v < lo && k > 0) ? -1 : 0);
-            const double lo2 = s_e[k], hi2 = s_e[k + 1];
-            bad |= in && !(v >= lo2 && (v < hi2 || k == nb - 1));
+            const float lo2 = s_e[k], hi2 = s_e[k + 1];
+            bad |= in && !(v >= lo2 && v < hi2);
             bin[j] = in ? k : -1;
         }
         if (__any(bad)) {
 #pragma unroll
             for (int j = 0; j < kMePer; ++j) {
-                const double v = (double)val[j];
+                const float v = val[j];
                 int k = bin[j];
                 if (k >= 0) {
                     while (k > 0 && s_e[k] > v) --k;
@@ -588,25 +623,13 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
                 }
             }
         }
-    } else {
-#pragma unroll
-        for (int j = 0; j < kMePer; ++j) {
-            const double v = (double)val[j];
-            int k = -1;
-            if (v >= e0 && v <= eN) {
-                const float g = (val[j] - e0f) * invf;         // a guess; the exact edge arithmetic decides
-                k = (g >= 0.f) ? ((g < (float)(nb - 1)) ? (int)g : nb - 1) : 0;
-                while (k > 0 && me_edge32(m, k) > v) --k;
-                while (k < nb - 1 && me_edge32(m, k + 1) <= v) ++k;      // last bin closed on the right
-            }
-            bin[j] = k;
-        }
     }
-    // count: a bin first seen in row j is counted over rows j..15 at once (a demodulated signal has two or three bins per wavefront)
+    // count: a bin first seen in row j is counted over rows j..15 at once (a demodulated signal has two or three bins per wavefront);
+    // after two such rounds what is left of the row goes through LDS atomics, one per sample
 #pragma unroll
     for (int j = 0; j < kMePer; ++j) {
         unsigned long long todo = __ballot(bin[j] >= 0);
-        while (todo) {
+        for (int round = 0; todo && round < 2; ++round) {
             const int leader = __ffsll((long long)todo) - 1;
             const int kl = __shfl(bin[j], leader);
             unsigned int cnt = 0;
@@ -616,8 +639,12 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
                 cnt += (unsigned)__popcll(__ballot(same));
                 bin[q] = same ? -1 : bin[q];
             }
-            if (lane == leader) { if (in_lds) atomicAdd(&s_c[kl], cnt); else atomicAdd(&out[kl], cnt); }
+            if (lane == leader) atomicAdd(&s_c[kl], cnt);
             todo = __ballot(bin[j] >= 0);
+        }
+        if (todo) {
+            if (bin[j] >= 0) atomicAdd(&s_c[bin[j]], 1u);
+            bin[j] = -1;
         }
     }
     }
