@@ -111,7 +111,10 @@ def _gloo_worker(rank, world, port, n, seed, q):
         x[n // 2 - 40:n // 2 + 25] = -4.0                      # a pause straddling the shard boundary
         p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 20, 0.1, 8, True)
         a, b = (0, n // 2) if rank == 0 else (n // 2, n)
-        pipe = ShardedPipeline(model_shard.ModelShardEngine(tile=32, span=8, chunk_tiles=2), TorchDistComm())
+        from urh_amd.sharding import RcclComm
+        comm = RcclComm.create()                          # no RCCL on a gloo group: every rank agrees on torch.distributed's all-gathers
+        assert isinstance(comm, TorchDistComm)
+        pipe = ShardedPipeline(model_shard.ModelShardEngine(tile=32, span=8, chunk_tiles=2), comm)
         res = pipe.iq_to_bits(x[a:b], p, want_qad=True, pos_base=a, n_total=n)
         q.put((rank, res))
     finally:

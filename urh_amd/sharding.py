@@ -104,16 +104,19 @@ class RcclComm:
 
     @classmethod
     def create(cls, group=None):
-        """RcclComm, or TorchDistComm when RCCL cannot be reached directly (every rank takes the same branch: the outcome is agreed
-        on through the group)."""
+        """RcclComm, or TorchDistComm when RCCL cannot be reached directly (no GPU, no librccl.so beside torch, communicator set-up
+        failed).  Every rank takes the same branch: the outcome is agreed on through the group."""
         import torch
         import torch.distributed as dist
         comm, ok = None, 1
         try:
+            if not torch.cuda.is_available() or dist.get_backend(group) != "nccl":
+                raise RuntimeError("not an RCCL process group")
             comm = cls(group)
         except Exception:                                     # noqa: BLE001 -- any failure means "use torch.distributed"
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        on_gpu = torch.cuda.is_available() and dist.get_backend(group) == "nccl"
+        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag.item()) == 1:
             return comm
