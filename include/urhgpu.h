@@ -448,6 +448,16 @@ int urhgpu_detect_modulation_dev(urhgpu_ctx *ctx, const float *d_iq, int64_t n, 
  * bitlen_out[m]: bit length, -1 (fewer than two merged plateaus: no vote) or -2 (the reference's result depends on numpy's order of
  * equal counts: decide that message with numpy). */
 int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs, int64_t *tol_out, int64_t *bitlen_out);
+/* urhgpu_msg_plateaus and urhgpu_msg_bit_lengths in one call: the plateau lengths stay on the GPU, which counts every message's
+ * distinct lengths (a few dozen per message against thousands of plateaus); the decisions that depend on the multiset only -- all of
+ * them for a message without glitches (tolerance 0) -- are taken from those (value, count) pairs, and only messages with a positive
+ * tolerance (merge_plateaus walks the sequence, auto_interpretation.pyx:145-176) have their sequences fetched.  Arguments as
+ * urhgpu_msg_plateaus, results as urhgpu_msg_bit_lengths; tol_out[m] = bitlen_out[m] = -3: the search window of message m did not reach
+ * the percentage mark (repeat that message through urhgpu_msg_plateaus with a larger window).  Synchronous. */
+int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
+                                 int percentage, int64_t extra_window, int64_t *tol_out, int64_t *bitlen_out);
+/* Test hook (host arithmetic): the multiset form of one message's decision; -3 in both where the sequence would be asked for. */
+int urhgpu_test_bit_length_from_counts(const uint64_t *lens, int64_t n, int64_t *tol_out, int64_t *bitlen_out);
 /* The two halves around np.argsort for a message urhgpu_msg_bit_lengths reported as -2 (equal counts in the divisor histogram: the
  * reference's result is whatever order np.argsort gives equal keys).  urhgpu_msg_divisor_histogram: tolerance, merged and rounded
  * plateaus (AutoInterpretation.py:280-326), then the dense uint64 histogram the reference sorts (auto_interpretation.pyx:113-143):

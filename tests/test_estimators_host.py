@@ -59,6 +59,42 @@ def test_plateau_logic_equals_reference(ref):
         assert (got_tol2, got_len2) == (got_tol, got_len), it
 
 
+def test_multiset_decisions_equal_the_sequence_decisions():
+    """urhgpu_msg_plateau_decisions decides a message from the (value, count) pairs of its plateau lengths where the order does not matter
+    (tolerance <= 0): the multiset form (host hook) gives what urhgpu_msg_bit_lengths gives on the sequence, and asks for the sequence
+    exactly where the tolerance is positive.  No reference needed: two implementations of this library against each other."""
+    import ctypes as C
+    from urh_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    seen = {"counts": 0, "sequence": 0, "ties": 0}
+    for it in range(3000):
+        if it % 3 == 0:                                    # clean messages: multiples of a symbol length with jitter, thousands of plateaus
+            n = int(rng.integers(0, 6000))
+            base = int(rng.choice([8, 25, 100, 295, 1000, 12345]))
+            p = base * rng.integers(1, 5, n) + rng.integers(-2, 3, n) * int(rng.integers(0, 2))
+            p = np.maximum(p, 1).astype(np.uint64)
+        else:
+            p = _plateaus(rng)
+        if it % 50 == 1:
+            p = p[:int(rng.integers(0, 3))]
+        off = np.array([0, len(p)], dtype=np.int64)
+        tol, bl = np.zeros(1, np.int64), np.zeros(1, np.int64)
+        buf = p if len(p) else np.zeros(1, np.uint64)
+        _lib.check(lib.urhgpu_msg_bit_lengths(buf.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), 1, tol.ctypes.data_as(C.c_void_p),
+                                              bl.ctypes.data_as(C.c_void_p)))
+        t2, b2 = C.c_int64(0), C.c_int64(0)
+        _lib.check(lib.urhgpu_test_bit_length_from_counts(buf.ctypes.data_as(C.c_void_p), len(p), C.byref(t2), C.byref(b2)))
+        if t2.value == -3:
+            assert b2.value == -3 and tol[0] > 0, (it, tol[0], bl[0])
+            seen["sequence"] += 1
+        else:
+            assert (t2.value, b2.value) == (int(tol[0]), int(bl[0])), (it, t2.value, b2.value, tol[0], bl[0], len(p))
+            seen["counts"] += 1
+            seen["ties"] += int(bl[0] == -2)
+    assert seen["counts"] > 800 and seen["sequence"] > 300, seen
+
+
 def test_peaks_center_equals_reference_walk(ref):
     """estimators.peaks_center (array form, used where np.argsort has to break a tie) against the reference's loop over
     np.argsort(y)[::-1] (AutoInterpretation.py:250-277, restated in numpy_estimators.center_from_histogram)"""

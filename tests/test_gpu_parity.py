@@ -775,6 +775,67 @@ def test_segmentation_pass_leaves_the_ask_demodulation(pipe, oracle):
         estimators.message_ranges_dev(pipe, i8, 0.1, qad_ask=torch.empty(4096, dtype=torch.float32, device="cuda"))
 
 
+def test_plateau_decisions_on_device_counts_equal_the_sequence_path(pipe):
+    """urhgpu_msg_plateau_decisions (plateau lengths counted on the GPU, sequences fetched only for messages with glitches) gives the
+    (tolerance, bit length) pairs of urhgpu_msg_plateaus + urhgpu_msg_bit_lengths: clean and glitchy OOK messages, messages without a
+    center; and a message with more distinct lengths than the device table holds (decided from its sequence)"""
+    import torch
+    from urh_amd import estimators
+    rng = np.random.default_rng(21)
+    n = 3_000_000
+    x = np.zeros(n, np.float32)
+    ranges, cen = [], []
+    pos = 1000
+    k = 0
+    while pos < n - 400_000:
+        kind = k % 4
+        nsym = int(rng.integers(300, 3000))
+        sps = int(rng.choice([20, 57, 100]))
+        bits = rng.integers(0, 2, nsym)
+        sym = np.repeat(bits, sps).astype(np.float32)
+        if kind == 1:                                      # glitches: single-sample flips -> positive tolerance
+            flips = rng.random(len(sym)) < 0.002
+            sym = np.where(flips, 1 - sym, sym)
+        seg = (0.1 + 0.8 * sym + 0.01 * rng.standard_normal(len(sym))).astype(np.float32)
+        x[pos:pos + len(seg)] = seg
+        ranges.append((pos, pos + len(seg)))
+        cen.append(np.nan if kind == 2 and k % 8 == 2 else 0.5)
+        pos += len(seg) + int(rng.integers(100, 5000))
+        k += 1
+    ranges = np.ascontiguousarray(ranges, dtype=np.int64)
+    cen = np.array(cen, dtype=np.float64)
+    dev = torch.from_numpy(x).cuda()
+    tol, bl = estimators._plateau_decisions(pipe, dev, ranges, cen, 25)
+    lens, off = estimators._plateaus_raw(pipe, dev, ranges, cen, 25)
+    assert not (off < 0).any() and not (tol == -3).any()
+    want = estimators._bit_lengths_raw(lens, off, lambda m: lens[int(off[m]):int(off[m + 1])])
+    # (-2: "numpy's order decides" is resolved by _bit_lengths_raw; compare what the native call itself says)
+    import ctypes as C
+    from urh_amd import _lib
+    t2, b2 = np.zeros(len(ranges), np.int64), np.zeros(len(ranges), np.int64)
+    _lib.check(_lib.load().urhgpu_msg_bit_lengths(lens.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), len(ranges),
+                                                  t2.ctypes.data_as(C.c_void_p), b2.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(tol, t2) and np.array_equal(bl, b2), (tol.tolist(), t2.tolist(), bl.tolist(), b2.tolist())
+    assert (t2 > 0).sum() >= 3 and (t2 == 0).sum() >= 3 and len(want) == len(ranges)
+    del dev
+    # one message whose first quarter holds some 3500 plateaus of as many distinct lengths (190 .. 3789: no glitches, tolerance 0): more
+    # than the device's table takes, so its sequence is fetched -- same answer as the two-step path
+    lengths = rng.permutation(np.arange(190, 3790))
+    level = (np.arange(len(lengths)) % 2).astype(np.float32)
+    head = np.repeat(level, lengths)
+    big = np.concatenate([np.zeros(64, np.float32), 0.1 + 0.8 * head, np.full(int(2.9 * len(head)), 0.9, np.float32)])
+    r2 = np.array([[64, len(big)]], dtype=np.int64)
+    c2 = np.array([0.5])
+    dev2 = torch.from_numpy(big).cuda()
+    tol_b, bl_b = estimators._plateau_decisions(pipe, dev2, r2, c2, 25)
+    lens_b, off_b = estimators._plateaus_raw(pipe, dev2, r2, c2, 25)
+    assert off_b[1] >= 3300 and len(np.unique(lens_b[:off_b[1]])) > 3072, off_b
+    t3, b3 = np.zeros(1, np.int64), np.zeros(1, np.int64)
+    _lib.check(_lib.load().urhgpu_msg_bit_lengths(lens_b.ctypes.data_as(C.c_void_p), off_b.ctypes.data_as(C.c_void_p), 1,
+                                                  t3.ctypes.data_as(C.c_void_p), b3.ctypes.data_as(C.c_void_p)))
+    assert (int(tol_b[0]), int(bl_b[0])) == (int(t3[0]), int(b3[0])) and t3[0] == 0, (tol_b, bl_b, t3, b3)
+
+
 def test_estimate_takes_the_numpy_merge_when_the_device_merge_is_borderline(pipe):
     """a pulse length within rounding of mean +- std makes urhgpu_message_ranges_dev hand the OOK merge to numpy: forced here, the
     estimate must come out the same"""

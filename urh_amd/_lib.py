@@ -122,6 +122,8 @@ PROTOTYPES = {
     "urhgpu_msg_plateaus": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp, _i64]),
     "urhgpu_detect_modulation_dev": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp]),
     "urhgpu_msg_bit_lengths": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "urhgpu_msg_plateau_decisions": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp]),
+    "urhgpu_test_bit_length_from_counts": (_i, [_vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "urhgpu_msg_divisor_histogram": (_i, [_vp, _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "urhgpu_bit_length_from_order": (_i, [_vp, _vp, _i64, C.POINTER(_i64)]),
     "urhgpu_merge_plateaus": (_i, [_vp, _i64, C.c_uint64, C.c_uint64, _vp, C.POINTER(_i64)]),

@@ -49,6 +49,8 @@ struct MsgState {            // one per message, device resident between the sta
     double peak_center;      // urhgpu_msg_center_stats: center picked from the histogram (k_me_peaks)
     int64_t peak_flag;       // 0 none, 1 peak_center valid, 2 more bins than the pool holds, 3 equally populated peaks compete for a slot
     int64_t skip;            // 1: the message's first sample is filtered (x <= -4: afp_demod's result[0] = NOISE of FSK / PSK) -- k_me_first
+    int64_t pairs_base;      // urhgpu_msg_plateau_decisions: first (value, count) pair of the message's plateau lengths in the pool ...
+    int64_t pairs_n;         // ... and how many; -1: more distinct lengths than the table holds / the pool is full (the sequence decides)
 };
 // nothing filtered but (possibly) the first sample: the kept samples ARE x[start + skip : end], no compaction needed
 __host__ __device__ inline bool me_clean(const MsgState &m) { return m.kept == (m.end - m.start) - m.skip; }
@@ -801,6 +803,68 @@ __global__ __launch_bounds__(64) void k_me_gather(const MsgState *st, const int3
     for (int64_t i = threadIdx.x; i < k; i += 64) out[o + i] = (uint64_t)(uint32_t)src[i];
 }
 
+// the selected messages only (out_begin[m] < 0: not wanted)
+__global__ __launch_bounds__(64) void k_me_gather_some(const MsgState *st, const int32_t *lengths, const int64_t *out_begin, uint64_t *out) {
+    const int m = blockIdx.x;
+    const int64_t k = st[m].n_plateaus, o = out_begin[m];
+    if (o < 0) return;
+    const int32_t *src = lengths + st[m].start;
+    for (int64_t i = threadIdx.x; i < k; i += 64) out[o + i] = (uint64_t)(uint32_t)src[i];
+}
+
+// What AutoInterpretation.estimate does with a message's plateau lengths (AutoInterpretation.py:416-433) depends, for a message
+// without glitches, on the MULTISET of lengths only: the tolerance on the distinct values, the rounding on the digit counts, the divisor
+// histogram on (value, multiplicity).  A demodulated message has thousands of plateaus and a few dozen distinct lengths: one
+// workgroup per message counts them in an LDS hash table and appends its (value, count) pairs to a pool -- kilobytes cross PCIe instead
+// of 8 bytes per plateau.  (Messages with glitches need merge_plateaus, which walks the sequence: the host asks for those.)
+constexpr int kLcSlots = 4096, kLcMaxDistinct = 3072;
+__global__ __launch_bounds__(kMeBlock) void k_me_len_counts(MsgState *st, const int32_t *lengths, unsigned long long *pool_count, uint64_t *pool,
+                                                             int64_t cap_pairs) {
+    __shared__ int s_key[kLcSlots];                       // length + 1, 0 = empty
+    __shared__ unsigned int s_cnt[kLcSlots];
+    __shared__ int s_distinct, s_over, s_pos;
+    __shared__ long long s_base;
+    const int m = blockIdx.x;
+    const int64_t k = st[m].n_plateaus;
+    for (int i = threadIdx.x; i < kLcSlots; i += kMeBlock) { s_key[i] = 0; s_cnt[i] = 0u; }
+    if (threadIdx.x == 0) { s_distinct = 0; s_over = 0; s_pos = 0; s_base = 0; }
+    __syncthreads();
+    const int32_t *src = lengths + st[m].start;
+    for (int64_t i = threadIdx.x; i < k; i += kMeBlock) {
+        const int32_t v = src[i];
+        if (v < 0 || v == INT32_MAX) { s_over = 1; break; }
+        const int key = v + 1;
+        unsigned h = ((unsigned)v * 2654435761u) >> 20;    // 12 bits
+        for (int probe = 0; probe < kLcSlots; ++probe) {
+            if (s_over) break;
+            const int old = atomicCAS(&s_key[h], 0, key);
+            if (old == 0 && atomicAdd(&s_distinct, 1) >= kLcMaxDistinct) s_over = 1;
+            if (old == 0 || old == key) { atomicAdd(&s_cnt[h], 1u); break; }
+            h = (h + 1) & (kLcSlots - 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long base = 0;
+        if (!s_over && s_distinct > 0) {
+            base = (long long)atomicAdd(pool_count, (unsigned long long)s_distinct);
+            if (base + s_distinct > cap_pairs) s_over = 1;
+        }
+        s_base = base;
+        st[m].pairs_base = base;
+        st[m].pairs_n = s_over ? -1 : (k > 0 ? s_distinct : 0);
+    }
+    __syncthreads();
+    if (s_over || k <= 0) return;
+    for (int i = threadIdx.x; i < kLcSlots; i += kMeBlock) {
+        if (s_key[i]) {
+            const int pidx = atomicAdd(&s_pos, 1);
+            pool[2 * (s_base + pidx)] = (uint64_t)(s_key[i] - 1);
+            pool[2 * (s_base + pidx) + 1] = (uint64_t)s_cnt[i];
+        }
+    }
+}
+
 }  // namespace urh
 
 using namespace urh;
@@ -1051,12 +1115,10 @@ double np_sum_f64(const double *a, int64_t n) {
     return total;
 }
 
-// AutoInterpretation.estimate_tolerance_from_plateau_lengths (AutoInterpretation.py:280-298); -1: None, -2: undefined in the reference
-int64_t tolerance_of(const std::vector<uint64_t> &p) {
-    if (p.size() <= 1) return -1;
-    std::vector<uint64_t> u(p);
-    std::sort(u.begin(), u.end());
-    u.erase(std::unique(u.begin(), u.end()), u.end());
+// AutoInterpretation.estimate_tolerance_from_plateau_lengths (AutoInterpretation.py:280-298); -1: None, -2: undefined in the reference.
+// u: the distinct lengths, ascending; total: how many plateaus there are
+int64_t tolerance_of_unique(const std::vector<uint64_t> &u, size_t total) {
+    if (total <= 1) return -1;
     const int64_t n = (int64_t)u.size();
     std::vector<double> d((size_t)n);
     for (int64_t i = 0; i < n; ++i) d[(size_t)i] = (double)u[(size_t)i];
@@ -1077,6 +1139,13 @@ int64_t tolerance_of(const std::vector<uint64_t> &p) {
     }
     return (int64_t)result;
 }
+int64_t tolerance_of(const std::vector<uint64_t> &p) {
+    if (p.size() <= 1) return -1;
+    std::vector<uint64_t> u(p);
+    std::sort(u.begin(), u.end());
+    u.erase(std::unique(u.begin(), u.end()), u.end());
+    return tolerance_of_unique(u, p.size());
+}
 
 int digits_of(uint64_t v) { int d = 1; while (v >= 10) { v /= 10; ++d; } return d; }
 
@@ -1094,17 +1163,9 @@ void round_lengths(std::vector<uint64_t> &m) {
     for (auto &v : m) v = (uint64_t)nearbyint((double)v / f) * (uint64_t)f;
 }
 
-// get_threshold_divisor_histogram (auto_interpretation.pyx:113-143) from the multiset of values: the non-zero entries as (count, index)
-void divisor_histogram(const std::vector<uint64_t> &m, std::vector<std::pair<uint64_t, uint64_t>> &hist, float threshold = 0.2f) {
-    std::vector<uint64_t> vals(m);
-    std::sort(vals.begin(), vals.end());
-    std::vector<std::pair<uint64_t, uint64_t>> vc;              // (value, count), value != 0, ascending
-    for (size_t i = 0; i < vals.size();) {
-        size_t j = i;
-        while (j < vals.size() && vals[j] == vals[i]) ++j;
-        if (vals[i] != 0) vc.push_back({vals[i], (uint64_t)(j - i)});
-        i = j;
-    }
+// get_threshold_divisor_histogram (auto_interpretation.pyx:113-143) from the multiset of values: the non-zero entries as (count, index).
+// vc: (value, multiplicity), value != 0, ascending
+void divisor_histogram_vc(const std::vector<std::pair<uint64_t, uint64_t>> &vc, std::vector<std::pair<uint64_t, uint64_t>> &hist, float threshold) {
     const double thr = (double)threshold;
     hist.clear();
     for (size_t a = 0; a < vc.size(); ++a) {
@@ -1116,15 +1177,22 @@ void divisor_histogram(const std::vector<uint64_t> &m, std::vector<std::pair<uin
         if (c) hist.push_back({c, vc[a].first});
     }
 }
+void divisor_histogram(const std::vector<uint64_t> &m, std::vector<std::pair<uint64_t, uint64_t>> &hist, float threshold = 0.2f) {
+    std::vector<uint64_t> vals(m);
+    std::sort(vals.begin(), vals.end());
+    std::vector<std::pair<uint64_t, uint64_t>> vc;              // (value, count), value != 0, ascending
+    for (size_t i = 0; i < vals.size();) {
+        size_t j = i;
+        while (j < vals.size() && vals[j] == vals[i]) ++j;
+        if (vals[i] != 0) vc.push_back({vals[i], (uint64_t)(j - i)});
+        i = j;
+    }
+    divisor_histogram_vc(vc, hist, threshold);
+}
 
-// get_bit_length_from_plateau_lengths (:344-370) on the merged lengths (rounded in place); -2: the outcome depends on how
+// the selection loop of get_bit_length_from_plateau_lengths (:358-370) on the histogram's non-zero entries; -2: the outcome depends on how
 // np.argsort orders equal counts (the caller lets numpy order the histogram: urhgpu_msg_divisor_histogram / urhgpu_bit_length_from_order)
-int64_t bit_length_of(std::vector<uint64_t> &m) {
-    if (m.empty()) return 0;
-    if (m.size() == 1) return (int64_t)m[0];
-    round_lengths(m);
-    std::vector<std::pair<uint64_t, uint64_t>> hist;
-    divisor_histogram(m, hist);
+int64_t select_bit_length(std::vector<std::pair<uint64_t, uint64_t>> &hist) {
     if (hist.empty()) return -2;                                // all counts zero: argsort's order of equal elements decides
     std::sort(hist.begin(), hist.end(), [](const std::pair<uint64_t, uint64_t> &x, const std::pair<uint64_t, uint64_t> &y) { return x.first > y.first; });
     const uint64_t max_count = hist[0].first;
@@ -1136,6 +1204,41 @@ int64_t bit_length_of(std::vector<uint64_t> &m) {
     }
     if (hist.size() > 1 && hist[1].first == max_count) return -2;
     return result;
+}
+
+// get_bit_length_from_plateau_lengths (:344-370) on the merged lengths (rounded in place)
+int64_t bit_length_of(std::vector<uint64_t> &m) {
+    if (m.empty()) return 0;
+    if (m.size() == 1) return (int64_t)m[0];
+    round_lengths(m);
+    std::vector<std::pair<uint64_t, uint64_t>> hist;
+    divisor_histogram(m, hist);
+    return select_bit_length(hist);
+}
+
+// the same from the multiset of lengths: vc = (value, multiplicity), ascending by value, at least two plateaus in all
+int64_t bit_length_of_counts(const std::vector<std::pair<uint64_t, uint64_t>> &vc) {
+    // round_plateau_lengths: the median number of digits over ALL plateaus (np.percentile(..., 50): linear interpolation)
+    size_t dhist[24] = {0};
+    size_t total = 0;
+    for (const auto &e : vc) { dhist[digits_of(e.first)] += (size_t)e.second; total += (size_t)e.second; }
+    auto kth = [&](size_t k) { size_t c = 0; for (int d = 0; d < 24; ++d) { c += dhist[d]; if (k < c) return d; } return 23; };
+    const double idx = 0.5 * (double)(total - 1);
+    const size_t lo = (size_t)floor(idx), hi = (size_t)ceil(idx);
+    const double med = (double)kth(lo) + ((double)kth(hi) - (double)kth(lo)) * (idx - (double)lo);
+    const int n_digits = std::min(3, (int)med);
+    double f = 1.0;
+    for (int k = 1; k < n_digits; ++k) f *= 10.0;
+    std::vector<std::pair<uint64_t, uint64_t>> r;               // rounded values (rounding is monotone: still ascending), equal ones joined
+    for (const auto &e : vc) {
+        const uint64_t v = (uint64_t)nearbyint((double)e.first / f) * (uint64_t)f;
+        if (!r.empty() && r.back().first == v) r.back().second += e.second;
+        else r.push_back({v, e.second});
+    }
+    if (!r.empty() && r.front().first == 0) r.erase(r.begin());
+    std::vector<std::pair<uint64_t, uint64_t>> hist;
+    divisor_histogram_vc(r, hist, 0.2f);
+    return select_bit_length(hist);
 }
 
 // tolerance + merged plateaus of one message (AutoInterpretation.py:416-420); false: the tolerance is undefined
@@ -1230,6 +1333,126 @@ int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs,
     };
     // the messages are independent: a few host threads when there are many of them (a sort of a few thousand values each)
     host_pool_run(n_msgs, n_msgs >= 16 ? 24 : 1, one);
+    return URHGPU_OK;
+}
+
+// urhgpu_msg_plateaus + urhgpu_msg_bit_lengths in one call that moves (value, count) pairs instead of plateau sequences
+// (k_me_len_counts): tol_out / bitlen_out as urhgpu_msg_bit_lengths gives them, -3 in both for a message whose search window did not
+// reach the percentage mark (the caller takes that message through urhgpu_msg_plateaus with a larger window).  Messages whose
+// tolerance is positive (glitches: merge_plateaus walks the sequence) or whose lengths overflow the table are decided from their
+// sequences, fetched in a second copy -- the same arithmetic as urhgpu_msg_bit_lengths.
+int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
+                                 int percentage, int64_t extra_window, int64_t *tol_out, int64_t *bitlen_out) {
+    if (!ctx || n < 0 || n_msgs < 0 || percentage < 0 || extra_window < 0 || (n_msgs > 0 && (!ranges || !centers || !tol_out || !bitlen_out || !d_x)))
+        return URHGPU_ERR_ARG;
+    if (n_msgs == 0) return URHGPU_OK;
+    URH_HIP(hipSetDevice(ctx->device));
+    std::vector<int64_t> windows((size_t)n_msgs);
+    for (int m = 0; m < n_msgs; ++m) {
+        const int64_t len = ranges[2 * m + 1] - ranges[2 * m];
+        if (len > INT32_MAX) return URHGPU_ERR_UNSUPPORTED;       // positions inside a message are 32-bit
+        const int64_t limit = ((int64_t)percentage * len) / 100;
+        windows[(size_t)m] = std::min<int64_t>(len, limit + extra_window);
+    }
+    URH_TRY(join_tail(ctx));
+    MsgBatch b;
+    URH_TRY(build_batch(ctx, ranges, n_msgs, n, windows.data(), b));
+    for (int m = 0; m < n_msgs; ++m) b.host[(size_t)m].center = centers[m];
+    const int64_t cap_pairs = std::max<int64_t>(4096, (int64_t)n_msgs * 256);     // a message beyond its share of the pool is decided from its sequence
+    const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)(b.n_tiles + 1) * (sizeof(MsgTile) + 4 + 8) + (size_t)std::max<int64_t>(n, 1) * 4 +
+                        (size_t)cap_pairs * 16 + 10 * 256;
+    URH_TRY(ctx->arena.reserve(need));
+    ctx->arena.reset();
+    MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
+    MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
+    int32_t *d_cnt = (int32_t *)ctx->arena.take((size_t)b.n_tiles * 4);
+    int64_t *d_pre = (int64_t *)ctx->arena.take((size_t)(b.n_tiles + 1) * 8);
+    int32_t *d_edges = (int32_t *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
+    unsigned long long *d_pool_count = (unsigned long long *)ctx->arena.take(64);
+    uint64_t *d_pool = (uint64_t *)ctx->arena.take((size_t)cap_pairs * 16);
+    if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_edges || !d_pool_count || !d_pool) return URHGPU_ERR_ARG;
+    hipStream_t s = ctx->stream;
+    URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
+    URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
+    URH_HIP(hipMemsetAsync(d_pool_count, 0, 8, s));
+    const unsigned gt = (unsigned)b.n_tiles;
+    hipLaunchKernelGGL(k_me_edge_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
+    hipLaunchKernelGGL(k_me_edge_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_edges);
+    hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
+    hipLaunchKernelGGL(k_me_len_counts, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_edges, d_pool_count, d_pool, cap_pairs);
+    URH_HIP(hipGetLastError());
+    unsigned long long pool_used = 0;
+    URH_HIP(hipMemcpyAsync(b.host.data(), d_st, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost, s));
+    URH_HIP(hipMemcpyAsync(&pool_used, d_pool_count, 8, hipMemcpyDeviceToHost, s));
+    URH_HIP(hipStreamSynchronize(s));
+    std::vector<uint64_t> pool((size_t)std::min<unsigned long long>(pool_used, (unsigned long long)cap_pairs) * 2);
+    if (!pool.empty()) {
+        URH_HIP(hipMemcpyAsync(pool.data(), d_pool, pool.size() * 8, hipMemcpyDeviceToHost, s));
+        URH_HIP(hipStreamSynchronize(s));
+    }
+    // messages decided from their multiset; the rest need their sequences
+    std::vector<int64_t> begin((size_t)n_msgs, -1);
+    int64_t total = 0;
+    for (int m = 0; m < n_msgs; ++m) {
+        const MsgState &st = b.host[(size_t)m];
+        const int64_t k = st.n_plateaus;
+        if (k < 0) { tol_out[m] = -3; bitlen_out[m] = -3; continue; }
+        bool need_seq = st.pairs_n < 0;
+        if (!need_seq) {
+            std::vector<std::pair<uint64_t, uint64_t>> vc((size_t)st.pairs_n);
+            for (int64_t i = 0; i < st.pairs_n; ++i) vc[(size_t)i] = {pool[2 * (size_t)(st.pairs_base + i)], pool[2 * (size_t)(st.pairs_base + i) + 1]};
+            std::sort(vc.begin(), vc.end());
+            std::vector<uint64_t> u(vc.size());
+            for (size_t i = 0; i < vc.size(); ++i) u[i] = vc[i].first;
+            const int64_t tol = tolerance_of_unique(u, (size_t)k);
+            if (tol > 0) need_seq = true;                      // glitches: merge_plateaus needs the order
+            else {
+                tol_out[m] = tol;
+                bitlen_out[m] = (tol == -2) ? -2 : (k < 2 ? -1 : bit_length_of_counts(vc));
+            }
+        }
+        if (need_seq) { begin[(size_t)m] = total; total += k; }
+    }
+    if (total > 0) {
+        URH_TRY(ctx->staging.reserve((size_t)n_msgs * 8 + (size_t)total * 8 + 1024));
+        ctx->staging.reset();
+        int64_t *d_begin = (int64_t *)ctx->staging.take((size_t)n_msgs * 8);
+        uint64_t *d_out = (uint64_t *)ctx->staging.take((size_t)total * 8);
+        if (!d_begin || !d_out) return URHGPU_ERR_ARG;
+        std::vector<uint64_t> lens((size_t)total);
+        URH_HIP(hipMemcpyAsync(d_begin, begin.data(), (size_t)n_msgs * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_me_gather_some, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, d_begin, d_out);
+        URH_HIP(hipGetLastError());
+        URH_HIP(hipMemcpyAsync(lens.data(), d_out, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+        URH_HIP(hipStreamSynchronize(s));
+        std::vector<int> todo;
+        for (int m = 0; m < n_msgs; ++m) if (begin[(size_t)m] >= 0) todo.push_back(m);
+        auto one = [&](int j) {
+            const int m = todo[(size_t)j];
+            std::vector<uint64_t> merged;
+            if (!merged_lengths(lens.data() + begin[(size_t)m], b.host[(size_t)m].n_plateaus, &tol_out[m], merged)) { bitlen_out[m] = -2; return; }
+            bitlen_out[m] = merged.size() < 2 ? -1 : bit_length_of(merged);
+        };
+        host_pool_run((int)todo.size(), todo.size() >= 16 ? 24 : 1, one);
+    }
+    return URHGPU_OK;
+}
+
+// Test hook (host arithmetic): the multiset form of the decision on ONE message's plateau lengths, as urhgpu_msg_plateau_decisions
+// takes it from the device's (value, count) pairs; *tol_out = *bitlen_out = -3 where that call would ask for the sequence.
+int urhgpu_test_bit_length_from_counts(const uint64_t *lens, int64_t n, int64_t *tol_out, int64_t *bitlen_out) {
+    if (n < 0 || !tol_out || !bitlen_out || (n > 0 && !lens)) return URHGPU_ERR_ARG;
+    std::vector<uint64_t> v(lens, lens + n);
+    std::sort(v.begin(), v.end());
+    std::vector<std::pair<uint64_t, uint64_t>> vc;
+    for (size_t i = 0; i < v.size();) { size_t j = i; while (j < v.size() && v[j] == v[i]) ++j; vc.push_back({v[i], (uint64_t)(j - i)}); i = j; }
+    std::vector<uint64_t> u(vc.size());
+    for (size_t i = 0; i < vc.size(); ++i) u[i] = vc[i].first;
+    const int64_t tol = tolerance_of_unique(u, (size_t)n);
+    if (tol > 0) { *tol_out = -3; *bitlen_out = -3; return URHGPU_OK; }
+    *tol_out = tol;
+    *bitlen_out = (tol == -2) ? -2 : (n < 2 ? -1 : bit_length_of_counts(vc));
     return URHGPU_OK;
 }
 

@@ -454,6 +454,18 @@ def _plateaus_raw(pipe, x, ranges, cen, percentage):
         return lens, off
 
 
+def _plateau_decisions(pipe, x, ranges, cen, percentage):
+    """urhgpu_msg_plateau_decisions: (tolerance, bit_length) int64 arrays over the messages (-1 None, -2 numpy's order decides, -3 the
+    search window was too small), the plateau lengths never leaving the GPU unless a message's glitches need their order"""
+    n_msgs = len(ranges)
+    tol = np.zeros(n_msgs, dtype=np.int64)
+    bl = np.zeros(n_msgs, dtype=np.int64)
+    _lib.check(_lib.load().urhgpu_msg_plateau_decisions(
+        pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p), cen.ctypes.data_as(C.c_void_p),
+        n_msgs, int(percentage), 1 << 16, tol.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p)))
+    return tol, bl
+
+
 def plateau_lengths_batched(pipe, data, message_indices, centers, percentage: int = 25):
     """get_plateau_lengths (auto_interpretation.pyx:179-208) of every message that has a center: one batched device pass
     (urhgpu_msg_plateaus), one read-back.  Returns a list of uint64 arrays (empty for messages without a center)."""
@@ -592,14 +604,17 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
     lap("centers_ms")
     ranges = np.ascontiguousarray(message_indices, dtype=np.int64).reshape(-1, 2)
     cen = np.array([np.nan if c is None else float(np.float32(c)) for c in all_centers], dtype=np.float64)
-    lens, off = _plateaus_raw(pipe, _dev_f32(pipe, data), ranges, cen, 25) if len(ranges) else (np.zeros(1, np.uint64), np.zeros(1, np.int64))
-    if (off < 0).any():                              # a message whose first plateau outlasts the search window: the per-message path
+    x32 = _dev_f32(pipe, data)
+    tol_raw, bl_raw = _plateau_decisions(pipe, x32, ranges, cen, 25) if len(ranges) else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+    lap("plateaus_ms")
+    if (tol_raw == -3).any():                        # a message whose first plateau outlasts the search window: the per-message path
         all_plateaus = plateau_lengths_batched(pipe, data, message_indices, all_centers)
-        lap("plateaus_ms")
         decisions = bit_lengths_batched(all_plateaus)
     else:
-        lap("plateaus_ms")
-        decisions = _bit_lengths_raw(lens, off, lambda m: lens[int(off[m]):int(off[m + 1])])
+        decisions = [(None if t < 0 else t, None if b < 0 else b) for t, b in zip(tol_raw.tolist(), bl_raw.tolist())]
+        for m in np.nonzero((bl_raw == -2) | (tol_raw == -2))[0].tolist():      # numpy's order of equal histogram counts decides
+            decisions[m] = _bit_length_with_numpy_order(
+                get_plateau_lengths_dev(pipe, x32[int(ranges[m, 0]):int(ranges[m, 1])], all_centers[m], 25))
     # the votes (AutoInterpretation.py:407-470) on arrays: a message with a center contributes its tolerance; it votes for a center and
     # a bit length when its merged plateaus gave a bit length above tolerance + 1
     has_center = np.array([c is not None for c in all_centers], dtype=bool)
