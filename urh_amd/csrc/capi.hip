@@ -1108,8 +1108,15 @@ static int message_ranges_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int
     URH_TRY(launch_message_ranges(d_rows, d_n_rows, cap_rows, d_iq, dtype, n, noise_threshold, merge ? 1 : 0, d_seg, d_msgs, cap_seg, d_ctl, scratch,
                                   ctx->stream));
     URH_HIP(hipGetLastError());
+    // one round trip for the usual case: the control block together with the first segments / merged messages the caller has room for
+    // (the counts are not known yet: a prefix of each table is copied speculatively, the rest -- rarely -- afterwards)
     std::vector<char> ctl(seg_ctl_bytes());
+    const int64_t spec_seg = std::min<int64_t>(std::min<int64_t>(cap_seg_out, cap_seg), 4096);
+    const int64_t spec_mrg = merge ? std::min<int64_t>(std::min<int64_t>(cap_merged_out, cap_seg), 1024) : 0;
+    std::vector<int64_t> spec_m((size_t)spec_mrg * 2);
     URH_HIP(hipMemcpyAsync(ctl.data(), d_ctl, ctl.size(), hipMemcpyDeviceToHost, ctx->stream));
+    if (spec_seg > 0) URH_HIP(hipMemcpyAsync(seg_out, d_seg, (size_t)spec_seg * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (spec_mrg > 0) URH_HIP(hipMemcpyAsync(spec_m.data(), d_msgs, (size_t)spec_mrg * 16, hipMemcpyDeviceToHost, ctx->stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
     int64_t n_seg = 0, n_msgs = 0;
     int ambiguous = 0;
@@ -1117,15 +1124,26 @@ static int message_ranges_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int
     if (n_seg > cap_seg) return URHGPU_ERR_CAPACITY;       // cannot happen (a segment needs two state changes)
     *n_seg_out = n_seg;
     const int64_t take = std::min(n_seg, cap_seg_out);
-    if (take > 0) URH_HIP(hipMemcpyAsync(seg_out, d_seg, (size_t)take * 16, hipMemcpyDeviceToHost, ctx->stream));
+    bool more = false;
+    if (take > spec_seg) { URH_HIP(hipMemcpyAsync(seg_out + 2 * spec_seg, d_seg + 2 * spec_seg, (size_t)(take - spec_seg) * 16, hipMemcpyDeviceToHost, ctx->stream)); more = true; }
     if (merge) {
         const bool merged = n_seg > 1;                     // AutoInterpretation.py:108: one segment is returned as it is
         *n_merged_out = merged ? n_msgs : n_seg;
         if (merge_ambiguous) *merge_ambiguous = merged ? ambiguous : 0;
         const int64_t take_m = std::min(*n_merged_out, cap_merged_out);
-        if (take_m > 0) URH_HIP(hipMemcpyAsync(merged_out, merged ? d_msgs : d_seg, (size_t)take_m * 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (!merged) {
+            // the single segment is the message: it is in seg_out already when the caller has room for a segment, else fetch it
+            if (take_m > 0) {
+                if (take >= 1) { merged_out[0] = seg_out[0]; merged_out[1] = seg_out[1]; }
+                else { URH_HIP(hipMemcpyAsync(merged_out, d_seg, 16, hipMemcpyDeviceToHost, ctx->stream)); more = true; }
+            }
+        } else {
+            const int64_t have = std::min(take_m, spec_mrg);
+            if (have > 0) memcpy(merged_out, spec_m.data(), (size_t)have * 16);
+            if (take_m > have) { URH_HIP(hipMemcpyAsync(merged_out + 2 * have, d_msgs + 2 * have, (size_t)(take_m - have) * 16, hipMemcpyDeviceToHost, ctx->stream)); more = true; }
+        }
     }
-    URH_HIP(hipStreamSynchronize(ctx->stream));
+    if (more) URH_HIP(hipStreamSynchronize(ctx->stream));
     return URHGPU_OK;
 }
 

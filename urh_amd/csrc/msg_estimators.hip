@@ -865,6 +865,19 @@ __global__ __launch_bounds__(kMeBlock) void k_me_len_counts(MsgState *st, const 
     }
 }
 
+// the tile table from the message table: tile t belongs to the message whose [first_tile, next first_tile) holds it (the host uploads
+// one MsgState per message, not one entry per 4096 samples)
+__global__ __launch_bounds__(256) void k_me_fill_tiles(const MsgState *st, int n_msgs, MsgTile *tiles, int64_t n_tiles) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_tiles) return;
+    int lo = 0, hi = n_msgs - 1;                            // last message with first_tile <= t
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (st[mid].first_tile <= t) lo = mid; else hi = mid - 1;
+    }
+    tiles[t] = MsgTile{lo, (int32_t)(t - st[lo].first_tile)};
+}
+
 }  // namespace urh
 
 using namespace urh;
@@ -873,7 +886,6 @@ namespace {
 
 struct MsgBatch {
     std::vector<MsgState> host;
-    std::vector<MsgTile> tiles;
     MsgState *d_state = nullptr;
     MsgTile *d_tiles = nullptr;
     int64_t n_tiles = 0;
@@ -882,7 +894,7 @@ struct MsgBatch {
 // tile table over [start, start + span_m) of every message; span = whole message (window = nullptr) or the given windows
 int build_batch(urhgpu_ctx *ctx, const int64_t *ranges, int n_msgs, int64_t n, const int64_t *windows, MsgBatch &b) {
     b.host.resize((size_t)n_msgs);
-    b.tiles.clear();
+    int64_t n_tiles = 0;
     for (int m = 0; m < n_msgs; ++m) {
         const int64_t s = ranges[2 * m], e = ranges[2 * m + 1];
         if (s < 0 || e < s || e > n) return URHGPU_ERR_ARG;
@@ -891,16 +903,16 @@ int build_batch(urhgpu_ctx *ctx, const int64_t *ranges, int n_msgs, int64_t n, c
         if (m > 0 && s < ranges[2 * m - 1]) return URHGPU_ERR_ARG;
         MsgState st;
         memset(&st, 0, sizeof(st));
-        st.start = s; st.end = e; st.first_tile = (int64_t)b.tiles.size();
+        st.start = s; st.end = e; st.first_tile = n_tiles;
         st.center = __builtin_nan("");
         const int64_t span = windows ? windows[m] : e - s;
         st.window = span;
         const int64_t nt = (std::max<int64_t>(span, 1) + kMeTile - 1) / kMeTile;
         if (nt > INT32_MAX) return URHGPU_ERR_UNSUPPORTED;
-        for (int64_t j = 0; j < nt; ++j) b.tiles.push_back(MsgTile{m, (int32_t)j});
+        n_tiles += nt;
         b.host[(size_t)m] = st;
     }
-    b.n_tiles = (int64_t)b.tiles.size();
+    b.n_tiles = n_tiles;
     return URHGPU_OK;
 }
 
@@ -930,7 +942,7 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_mm || !d_leaf || !d_chunk || !d_kept || !d_hist) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
     URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
-    URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
     URH_HIP(hipMemsetAsync(d_hist, 0, (size_t)n_msgs * (size_t)max_bins * 4, s));
     const unsigned gt = (unsigned)b.n_tiles, gm = (unsigned)((n_msgs + 63) / 64);
     URH_HIP(hipMemsetAsync(d_cnt, 0, (size_t)b.n_tiles * 4, s));
@@ -1026,7 +1038,7 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
     if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_edges) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
     URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
-    URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
     const unsigned gt = (unsigned)b.n_tiles;
     hipLaunchKernelGGL(k_me_edge_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
     hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
@@ -1373,7 +1385,7 @@ int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, c
     if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_edges || !d_pool_count || !d_pool) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
     URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
-    URH_HIP(hipMemcpyAsync(d_tiles, b.tiles.data(), (size_t)b.n_tiles * sizeof(MsgTile), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
     URH_HIP(hipMemsetAsync(d_pool_count, 0, 8, s));
     const unsigned gt = (unsigned)b.n_tiles;
     hipLaunchKernelGGL(k_me_edge_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
