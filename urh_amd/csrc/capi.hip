@@ -428,6 +428,7 @@ int urhgpu_ctx_create(int device, urhgpu_ctx **out) {
     }
     URH_HIP(hipHostMalloc((void **)&ctx->h_counts, 32 * sizeof(int64_t)));
     memset(ctx->h_counts, 0, 32 * sizeof(int64_t));
+    if (hipHostMalloc((void **)&ctx->h_small, kSmallPinned) != hipSuccess) { (void)hipGetLastError(); ctx->h_small = nullptr; }   // (optional: pageable copies work too)
     *out = ctx;
     return URHGPU_OK;
 }
@@ -453,6 +454,7 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     if (ctx->d_desc) (void)hipFree(ctx->d_desc);
     if (ctx->d_rdesc) (void)hipFree(ctx->d_rdesc);
     if (ctx->h_counts) (void)hipHostFree(ctx->h_counts);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return URHGPU_OK;
@@ -1114,16 +1116,27 @@ static int message_ranges_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int
     const int64_t spec_seg = std::min<int64_t>(std::min<int64_t>(cap_seg_out, cap_seg), 4096);
     const int64_t spec_mrg = merge ? std::min<int64_t>(std::min<int64_t>(cap_merged_out, cap_seg), 1024) : 0;
     std::vector<int64_t> spec_m((size_t)spec_mrg * 2);
-    URH_HIP(hipMemcpyAsync(ctl.data(), d_ctl, ctl.size(), hipMemcpyDeviceToHost, ctx->stream));
-    if (spec_seg > 0) URH_HIP(hipMemcpyAsync(seg_out, d_seg, (size_t)spec_seg * 16, hipMemcpyDeviceToHost, ctx->stream));
-    if (spec_mrg > 0) URH_HIP(hipMemcpyAsync(spec_m.data(), d_msgs, (size_t)spec_mrg * 16, hipMemcpyDeviceToHost, ctx->stream));
+    // (through the context's pinned landing zone when it fits: three copies to pageable memory are three synchronous round trips)
+    const size_t ctl_pad = (ctl.size() + 255) & ~size_t(255);
+    const bool pinned = ctx->h_small && ctl_pad + (size_t)(spec_seg + spec_mrg) * 16 <= kSmallPinned;
+    char *l_ctl = pinned ? ctx->h_small : ctl.data();
+    int64_t *l_seg = pinned ? (int64_t *)(ctx->h_small + ctl_pad) : seg_out;
+    int64_t *l_mrg = pinned ? l_seg + 2 * spec_seg : spec_m.data();
+    URH_HIP(hipMemcpyAsync(l_ctl, d_ctl, ctl.size(), hipMemcpyDeviceToHost, ctx->stream));
+    if (spec_seg > 0) URH_HIP(hipMemcpyAsync(l_seg, d_seg, (size_t)spec_seg * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (spec_mrg > 0) URH_HIP(hipMemcpyAsync(l_mrg, d_msgs, (size_t)spec_mrg * 16, hipMemcpyDeviceToHost, ctx->stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
+    if (pinned) {
+        memcpy(ctl.data(), l_ctl, ctl.size());
+        if (spec_mrg > 0) memcpy(spec_m.data(), l_mrg, (size_t)spec_mrg * 16);
+    }
     int64_t n_seg = 0, n_msgs = 0;
     int ambiguous = 0;
     seg_ctl_read(ctl.data(), &n_seg, &n_msgs, &ambiguous);
     if (n_seg > cap_seg) return URHGPU_ERR_CAPACITY;       // cannot happen (a segment needs two state changes)
     *n_seg_out = n_seg;
     const int64_t take = std::min(n_seg, cap_seg_out);
+    if (pinned && std::min(take, spec_seg) > 0) memcpy(seg_out, l_seg, (size_t)std::min(take, spec_seg) * 16);
     bool more = false;
     if (take > spec_seg) { URH_HIP(hipMemcpyAsync(seg_out + 2 * spec_seg, d_seg + 2 * spec_seg, (size_t)(take - spec_seg) * 16, hipMemcpyDeviceToHost, ctx->stream)); more = true; }
     if (merge) {

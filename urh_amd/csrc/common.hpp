@@ -58,6 +58,7 @@ struct Arena {
 
 }  // namespace urh
 
+constexpr size_t kSmallPinned = size_t(1) << 20;
 struct urhgpu_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -68,6 +69,7 @@ struct urhgpu_ctx {
     urh::Arena aux;          // Costas candidate / checkpoint states (lives across the arena / staging users)
     int64_t *d_counts = nullptr;   // small device result block (8 x int64)
     int64_t *h_counts = nullptr;   // pinned host mirror
+    char *h_small = nullptr;       // pinned landing zone of the estimators' small results (kSmallPinned bytes): copies into it are truly asynchronous
     int32_t *d_tickets = nullptr;  // 8 zeroed ints: elections of the fused scan kernels (scan.hpp)
     void *d_desc = nullptr;        // descriptors of the single-pass scans: dedicated, zeroed when (re)allocated
     size_t desc_cap = 0;

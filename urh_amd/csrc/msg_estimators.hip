@@ -963,12 +963,15 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     hipLaunchKernelGGL(k_me_peaks, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_hist, max_bins);
     URH_HIP(hipGetLastError());
     std::vector<unsigned int> hist;
-    URH_HIP(hipMemcpyAsync(b.host.data(), d_st, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost, s));
+    const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState);
+    const bool st_pinned = ctx->h_small && st_bytes <= kSmallPinned;     // (a truly asynchronous copy; pageable memory otherwise)
+    URH_HIP(hipMemcpyAsync(st_pinned ? (void *)ctx->h_small : (void *)b.host.data(), d_st, st_bytes, hipMemcpyDeviceToHost, s));
     if (out_hist) {                                          // the histograms themselves: only a caller that has to break a tie wants them
         hist.resize((size_t)n_msgs * (size_t)max_bins);
         URH_HIP(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
     }
     URH_HIP(hipStreamSynchronize(s));
+    if (st_pinned) memcpy(b.host.data(), ctx->h_small, st_bytes);
     for (int m = 0; m < n_msgs; ++m) {
         const MsgState &st = b.host[(size_t)m];
         double *o = out_stats + 8 * (size_t)m;
@@ -1394,14 +1397,24 @@ int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, c
     hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
     hipLaunchKernelGGL(k_me_len_counts, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_edges, d_pool_count, d_pool, cap_pairs);
     URH_HIP(hipGetLastError());
+    // states, pool fill and (speculatively) the first pairs of the pool land in the context's pinned zone in ONE round trip when they fit
     unsigned long long pool_used = 0;
-    URH_HIP(hipMemcpyAsync(b.host.data(), d_st, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost, s));
-    URH_HIP(hipMemcpyAsync(&pool_used, d_pool_count, 8, hipMemcpyDeviceToHost, s));
+    const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState), st_pad = (st_bytes + 255) & ~size_t(255);
+    const bool pinned = ctx->h_small && st_pad + 256 + 4096 <= kSmallPinned;
+    const int64_t spec_pairs = pinned ? std::min<int64_t>(std::min<int64_t>(cap_pairs, 8192), (int64_t)((kSmallPinned - st_pad - 256) / 16)) : 0;
+    URH_HIP(hipMemcpyAsync(pinned ? (void *)ctx->h_small : (void *)b.host.data(), d_st, st_bytes, hipMemcpyDeviceToHost, s));
+    URH_HIP(hipMemcpyAsync(pinned ? (void *)(ctx->h_small + st_pad) : (void *)&pool_used, d_pool_count, 8, hipMemcpyDeviceToHost, s));
+    if (spec_pairs > 0) URH_HIP(hipMemcpyAsync(ctx->h_small + st_pad + 256, d_pool, (size_t)spec_pairs * 16, hipMemcpyDeviceToHost, s));
     URH_HIP(hipStreamSynchronize(s));
+    if (pinned) { memcpy(b.host.data(), ctx->h_small, st_bytes); memcpy(&pool_used, ctx->h_small + st_pad, 8); }
     std::vector<uint64_t> pool((size_t)std::min<unsigned long long>(pool_used, (unsigned long long)cap_pairs) * 2);
     if (!pool.empty()) {
-        URH_HIP(hipMemcpyAsync(pool.data(), d_pool, pool.size() * 8, hipMemcpyDeviceToHost, s));
-        URH_HIP(hipStreamSynchronize(s));
+        const size_t have = std::min<size_t>(pool.size() / 2, (size_t)spec_pairs);
+        if (have > 0) memcpy(pool.data(), ctx->h_small + st_pad + 256, have * 16);
+        if (pool.size() / 2 > have) {
+            URH_HIP(hipMemcpyAsync(pool.data() + 2 * have, d_pool + 2 * have, (pool.size() / 2 - have) * 16, hipMemcpyDeviceToHost, s));
+            URH_HIP(hipStreamSynchronize(s));
+        }
     }
     // messages decided from their multiset; the rest need their sequences
     std::vector<int64_t> begin((size_t)n_msgs, -1);
