@@ -410,7 +410,9 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
     const float *cs = chunk_sums + s.first_tile;
     // total = ((0 + c0) + c1) + ...: strictly sequential float adds (16 384 of them when the capture is one message).  Wavefront 0
     // holds 64 chunk sums in its lanes and adds them through v_readlane (the next 64 are already loaded): a dependent add every few
-    // cycles instead of an LDS round trip per term.
+    // cycles instead of an LDS round trip per term.  (Running the chain through the lanes instead -- acc[s] = acc[s - 1] + v[s] as one
+    // v_add_f32_dpp wave_shr:1 per term -- is one instruction per term instead of two but was slower, 160 against 101 us for 16 384
+    // terms: the DPP operand's wait states weigh more than the second instruction, which is off the dependent chain here.)
     float total = 0.f;
     if (tid < 64) {
         float v = (tid < n_chunks) ? cs[tid] : 0.f;
