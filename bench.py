@@ -610,6 +610,7 @@ def main():
         # URH_BENCH_TORCH_COLLECTIVES=1: torch.distributed's all_gather_into_tensor instead (55-80 us of host time each)
         comm = TorchDistComm() if os.environ.get("URH_BENCH_TORCH_COLLECTIVES") == "1" else RcclComm.create()
         pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=args.pipeline, tuning=tuning, tail_stream_priority=tail_prio), comm)
+        pipe.engine.host_results = False                     # switched on for the headline loop below
         if args.fir_halo:
             from urh_amd.synth import spec_fir_taps
             fir_taps = torch.from_numpy(spec_fir_taps().view("float32").reshape(-1, 2).copy()).to(dev)     # (64, 2): 64 complex taps
@@ -792,18 +793,59 @@ def main():
             del r_np
         del st, results
 
-    # ---- device only (outputs left in HBM): what round 2 reported as the headline; the timed region of sharded runs ------------------
+    # ---- the headline of sharded runs (N > 1): the same window per rank -- every pass's compact blob (this rank's piece: pulse table,
+    # bits, pauses, offsets; bit_sample_pos derived on the host when asked for) copied to pinned host memory by a third stream while
+    # the following passes run (GpuShardEngine(host_results=True)); the region ends when every rank has its last blob ------------------
+    sharded_host = sharded and args.pipeline and not args.no_d2h and fir_taps is None
+    host_piece = None
+    if sharded_host:
+        from dataclasses import replace
+        p_host = replace(p, write_bit_sample_pos=False)
+
+        def host_steps(k):
+            pend, last = [], None
+            for _ in range(k):
+                pend.append(pipe.iq_to_bits(iq, p_host, want_qad=want_qad, halo_given=halo_given, left_halo=left_halo))
+                if len(pend) > 2:                             # two passes behind the one just issued: its copy has had a pass to finish
+                    last = pend.pop(0).host()
+            for r in pend:
+                last = r.host()
+            return last
+        pipe.engine.host_results = True
+        ramp_passes = ramp(lambda: host_steps(10))
+        dist.barrier()
+        torch.cuda.synchronize()
+        pipe.ctx.profile_begin(0 if os.environ.get("URH_BENCH_NO_PROFILE") else args.steps)
+        t0 = time.perf_counter()
+        host_piece = host_steps(args.steps).check()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        headline_dt = time.perf_counter() - t0
+        kernel_ms = pipe.ctx.profile_end()
+        t = torch.tensor([headline_dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        headline_dt = float(t.item())
+        stream_rec = {"d2h_bytes_per_step": host_piece.blob_bytes,
+                      "d2h_format": "compact blob of this rank's piece: int32 length + int8 state per pulse-table row, packed bits, int64 pauses / "
+                                    "message offsets (include/urhgpu.h); bit_sample_pos derived on the host from the shipped pulse table when asked for"}
+        host_copy = {"rows": host_piece.ppseq().copy(), "bits": host_piece.bits().copy(), "pauses": host_piece.pauses.copy()}
+        pipe.engine.host_results = False
+        pipe.ctx.join()
+        torch.cuda.synchronize()
+
+    # ---- device only (outputs left in HBM): what round 2 reported as the headline ----------------------------------------------------
     if use_stream and args.no_device_loop:
         args_steps_dev = 1
     else:
         args_steps_dev = args.steps
         rp_dev = ramp(lambda: device_steps(10))
-        if not use_stream:
+        if not use_stream and not sharded_host:
             ramp_passes = rp_dev
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    pipe.ctx.profile_begin(0 if (os.environ.get("URH_BENCH_NO_PROFILE") or use_stream) else args.steps)
+    pipe.ctx.profile_begin(0 if (os.environ.get("URH_BENCH_NO_PROFILE") or use_stream or sharded_host) else args.steps)
     t0 = time.perf_counter()
     res = device_steps(args_steps_dev)
     torch.cuda.synchronize()
@@ -811,7 +853,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if not use_stream:
+    if not use_stream and not sharded_host:
         kernel_ms = pipe.ctx.profile_end()
     else:
         pipe.ctx.profile_end()
@@ -825,6 +867,13 @@ def main():
 
     counts = res.host_counts()
     res.check_capacity()
+    host_equals_device = None
+    if sharded_host:                                         # what arrived on the host is what the device-resident pass holds
+        import numpy as np
+        pc = res.piece()
+        host_equals_device = bool(np.array_equal(host_copy["rows"], pc["rows"]) and np.array_equal(host_copy["bits"], pc["bits"]) and
+                                  np.array_equal(host_copy["pauses"], pc["pauses"]))
+        assert host_equals_device, "host blob differs from the device-resident outputs"
     if use_stream:
         assert tuple(host_copy["counts"][:3]) == tuple(counts[:3]), (host_copy["counts"], counts)     # (the stream's blob ships no positions)
 
@@ -873,7 +922,7 @@ def main():
             return round(n * bytes_per_sample / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None
         out = {
             "metric": "Msamples/s IQ->bits (1 GiB complex64 2-FSK per GPU, qad materialised"
-                      + (", compact outputs copied to the host)" if use_stream else ")"),
+                      + (", compact outputs copied to the host)" if (use_stream or sharded_host) else ")"),
             "value": round(value, 1), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -884,6 +933,9 @@ def main():
                        "timed_region": ("K steps through urhgpu_stream_*: IQ resident in HBM -> qad (HBM) + pulse table + bits + pauses + bit_sample_pos -> "
                                         "compact blob -> pinned host memory; hot kernel of step i, tail of step i - 1 and D2H copy of step i - 2 overlap; "
                                         "the region ends when the last step's copy has arrived (SURVEY 8(d) window)") if use_stream else
+                                       ("K sharded steps per rank: IQ shard resident in HBM -> qad (HBM) + this rank's piece of pulse table / bits / pauses "
+                                        "-> compact blob -> pinned host memory (copy stream, three slots); two all-gathers of a few bytes per step; the "
+                                        "region ends when every rank holds its last blob (SURVEY 8(d) window per rank)") if sharded_host else
                                        "K device-resident steps (outputs left in HBM)",
                        "samples_per_gpu": n, "samples_per_symbol": sps, "tolerance": tol, "noise_sigma": 0.05,
                        "outputs": "qad+ppseq+bits+pauses+bit_sample_pos" if want_qad else "ppseq+bits+pauses+bit_sample_pos",
@@ -897,6 +949,7 @@ def main():
                        "rccl_world_size": world if dist else None,
                        "all_gathers_per_pass": (None if not sharded else (2 if halo_given else 3) + (1 if fir_taps is not None else 0)),
                        "collectives": (None if not sharded else type(pipe.comm).__name__),
+                       "host_blob_equals_device_outputs": host_equals_device,
                        "ranks": ranks_info},
             "roofline": {"bound": "hbm", "kernel": "k_demod_runs_bp", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",

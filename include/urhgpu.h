@@ -337,6 +337,7 @@ int urhgpu_stream_stats(urhgpu_stream *st, int64_t *out4);
  *   - msg_off[m + 1] / pos_off[m + 1] are the LOCAL end offsets of the m-th message that closes on this rank;
  *     bits / pos may continue past the last one (the message closes on a later rank);
  *   - counts = {local rows, messages closed here, local bits, local positions}.
+ * out->blob (FSK / other, not ASK: URHGPU_ERR_UNSUPPORTED): the finish phase also packs this rank's piece into the compact blob.
  * PSK (Costas loop) does not shard: URHGPU_ERR_UNSUPPORTED. */
 #define URHGPU_ROW_ABSORBED (-(INT64_C(1) << 62))
 #define URHGPU_SHARD_SUMMARY_BYTES 72 /* one shard summary (d_summary; d_summaries = world of them, back to back) */

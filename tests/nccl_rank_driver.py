@@ -33,7 +33,7 @@ def main():
     shard = torch.from_numpy(iq[a:b]).to(dev)
     rccl = RcclComm(None)                                     # the direct communicator must come up here (no fallback in the test)
     for pipelined, comm in ((False, TorchDistComm()), (True, TorchDistComm()), (False, rccl), (True, rccl)):
-        pipe = ShardedPipeline(GpuShardEngine(local, pipelined=pipelined), comm)
+        pipe = ShardedPipeline(GpuShardEngine(local, pipelined=pipelined, host_results=pipelined), comm)   # pipelined: + the blob on the host
         assert pipe.world == world and pipe.rank == rank
         p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
         d_taps = torch.from_numpy(taps.view(np.float32).reshape(-1, 2).copy()).to(dev)
@@ -49,6 +49,10 @@ def main():
         pipe.ctx.join()
         torch.cuda.synchronize()
         piece = res.piece()
+        if pipelined:
+            h = res.host().check()
+            assert np.array_equal(h.ppseq(), piece["rows"]) and np.array_equal(h.bits(), piece["bits"]), "host blob differs from the device outputs"
+            assert np.array_equal(h.pauses, piece["pauses"]) and np.array_equal(h.bit_sample_pos(), piece["pos"]), "host blob: pauses / positions"
         piece["qad"] = res.qad.cpu().numpy()
         piece["filt"] = filt.cpu().numpy()
         pieces = [None] * world

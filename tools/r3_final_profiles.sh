@@ -20,23 +20,7 @@ find gpurun_out/prof_$TAG -name "*.csv" -size +2M -delete
 tail -5 gpurun_out/$TAG/pmc_summary.txt
 cat gpurun_out/$TAG/timeline_pipelined.txt | tail -4
 # the sharded code path on a 1-rank RCCL group (what every rank of --gpus N runs) and the estimator kernels at full size
-export RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1
-for v in given:A=1 given_torch_collectives:URH_BENCH_TORCH_COLLECTIVES=1 halo_exchanged_torch_collectives:URH_BENCH_HALO_EXCHANGE=1,URH_BENCH_TORCH_COLLECTIVES=1; do
-  label=${v%%:*}; envs=${v#*:}
-  for rep in 1 2; do
-    env ${envs//,/ } URH_BENCH_FORCE_SHARDED=1 MASTER_PORT=29571 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extra --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > /tmp/sb.json
-    python - >> gpurun_out/$TAG/sharded.txt <<PY
-import json
-try:
-    d=json.loads(open("/tmp/sb.json").read())
-    print("$label", "ms_per_step", d["ms_per_step"], "hot_kernel_ms", d["roofline"]["kernel_ms"], "frac", d["roofline"]["frac"], d["config"]["collectives"], "all_gathers_per_pass", d["config"]["all_gathers_per_pass"])
-except Exception as e:
-    print("$label", "failed", e)
-PY
-  done
-done
-unset RANK WORLD_SIZE LOCAL_RANK MASTER_ADDR
-cat gpurun_out/$TAG/sharded.txt
+bash tools/r3_sharded_lines.sh $TAG
 bash tools/r3_est_prof.sh ${TAG}_est > /dev/null 2>&1
 python - > gpurun_out/$TAG/estimate_kernels.txt <<PY
 import csv, json

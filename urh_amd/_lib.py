@@ -17,6 +17,8 @@ ERR_HIP, ERR_DTYPE, ERR_ARG, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NO_DEVICE = -1, 
 DT_I8, DT_U8, DT_I16, DT_U16, DT_F32 = 0, 1, 2, 3, 4
 MOD_ASK, MOD_FSK, MOD_PSK, MOD_OTHER = 0, 1, 2, 3
 ROW_ABSORBED = -(1 << 62)
+BLOB_MAGIC = 0x55524842424C4F42           # URHGPU_BLOB_MAGIC
+BLOB_HEADER_BYTES = 128
 
 
 class UrhGpuError(RuntimeError):

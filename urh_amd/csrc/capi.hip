@@ -1025,6 +1025,11 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
         URH_TRY(scan_state(ctx, cap, &sst));
         URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, cap, bp, bo, ss->bits_scratch, sst, s));
     }
+    if (o.blob) {
+        // the compact mirror of this rank's piece (compact.hip); an absorbed first row (ASK) has no 8-bit state: wide outputs only
+        if (ask) return URHGPU_ERR_UNSUPPORTED;
+        URH_TRY(launch_pack_blob(&o, ss->p.write_bit_sample_pos, s));
+    }
     URH_HIP(hipGetLastError());
     ss->phase = 0;
     if (ss->piped) URH_TRY(end_pipelined_pass(ctx));

@@ -195,6 +195,25 @@ class HostBits:
         self.__dict__[name] = value
         return value
 
+    @classmethod
+    def from_blob(cls, host_ptr: int, params, seq: int = 0, n_samples: int = 0, d_qad: int = 0):
+        """the same object from a compact blob that lies in host memory at host_ptr (header first; include/urhgpu.h): what
+        urhgpu_stream_* hands out for a single-GPU stream, made here for blobs copied by other means (sharded passes)"""
+        hdr = np.frombuffer((C.c_ubyte * 128).from_address(host_ptr), dtype=np.int64, count=16)
+        if int(hdr[0]) != _lib.BLOB_MAGIC:
+            raise ValueError("not a result blob")
+        r = _lib.HostResult()
+        r.seq, r.n_samples = seq, n_samples
+        r.n_rows, r.n_msg, r.n_bits, r.n_pos, r.rows_needed = (int(hdr[k]) for k in (1, 2, 3, 4, 5))
+        r.blob_bytes = abs(int(hdr[6]))
+        r.truncated = int(hdr[15])
+        r.pauses, r.msg_off, r.pos_off = host_ptr + int(hdr[8]), host_ptr + int(hdr[9]), host_ptr + int(hdr[10])
+        r.row_state, r.bits_packed, r.row_len = host_ptr + int(hdr[11]), host_ptr + int(hdr[12]), host_ptr + int(hdr[13])
+        r.pos32 = host_ptr + int(hdr[14]) if int(hdr[7]) else None
+        r.blob = host_ptr
+        r.d_qad = d_qad or None
+        return cls(r, params)
+
     def check(self):
         if self.truncated:
             raise _lib.UrhGpuError(_lib.ERR_CAPACITY, f"output capacity too small: the pulse table needs {self.rows_needed} rows")
@@ -222,6 +241,9 @@ class HostBits:
         return self.pos_off.copy() if self.pos32 is not None else self._derived_positions()[1]
 
     def _derived_positions(self):
+        if self.__dict__.get("sharded_piece"):
+            raise ValueError("a rank's piece of a sharded capture does not start at sample 0 of the capture: its positions are not derivable "
+                             "from its rows alone -- run the pass with write_bit_sample_pos=True to have them shipped")
         if getattr(self, "_derived", None) is None:
             self._derived = positions_from_rows(self.row_state, self.row_len, self.params)
         return self._derived

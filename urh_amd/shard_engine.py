@@ -18,6 +18,7 @@ class ShardResult:
         self.counts, self.params = counts, params
         self._host_counts = None
         self._ctx = ctx
+        self._host = None
 
     def host_counts(self):
         if self._host_counts is None:
@@ -47,6 +48,18 @@ class ShardResult:
                     pos=self.pos_buf[:n_pos].cpu().numpy() if self.pos_buf is not None else np.zeros(0, np.int64),
                     pos_end=self.pos_off_buf[1:n_msg + 1].cpu().numpy())
 
+    def host(self):
+        """This rank's piece ON THE HOST from the compact blob (GpuShardEngine(host_results=True): packed at the end of the pass, copied
+        by the copy stream while later passes run): a pipeline.HostBits whose views are valid until three passes later.  Rows, bits,
+        pauses and offsets are the rank's LOCAL piece, as in `piece()`."""
+        from .pipeline import HostBits
+        if self._host is None:
+            raise ValueError("the engine was not asked for host results (host_results=True)")
+        if not isinstance(self._host, HostBits):
+            eng, slot, copied = self._host
+            self._host = eng._finish_host_copy(slot, copied, self.params, self.qad)
+        return self._host
+
     # `stitch` accepts mappings: make the result itself usable as a piece
     def __getitem__(self, k):
         if not hasattr(self, "_piece"):
@@ -55,7 +68,63 @@ class ShardResult:
 
 
 class GpuShardEngine(DevicePipeline):
-    """DevicePipeline (context, stream, output buffers) + the shard phases."""
+    """DevicePipeline (context, stream, output buffers) + the shard phases.
+    host_results=True (FSK / other modulations, not ASK): every pass also leaves its compact result blob (include/urhgpu.h) in pinned
+    host memory -- packed at the end of the pass's tail, copied by a third stream while the following passes run, three blob slots in
+    rotation, the copy sized by the previous pass's blob (what a prediction misses is fetched when the result is looked at):
+    ShardResult.host().  The same window as the single-GPU CaptureStream, per rank."""
+
+    def __init__(self, device: int = 0, pipelined: bool = False, tuning=None, tail_stream_priority: int = 0, host_results: bool = False):
+        super().__init__(device, pipelined=pipelined, tuning=tuning, tail_stream_priority=tail_stream_priority)
+        self.host_results = bool(host_results)
+        self._pass = 0
+        self._hslots = None                                 # [(device blob, pinned host blob, copy-done event)] x 3
+        self._copy_stream = None
+        self._predicted = 0                                 # bytes the next copy is sized for (0: the whole blob)
+
+    def _host_slot(self, cap_rows, cap_bits, cap_msg, cap_pos, has_pos):
+        torch = self.torch
+        cap = int(_lib.load().urhgpu_blob_capacity(cap_rows, cap_bits, cap_msg, cap_pos, 1 if has_pos else 0))
+        if self._hslots is None or self._hslots[0][0].numel() < cap:
+            self._hslots = [(torch.empty(cap, dtype=torch.uint8, device=self.device), torch.empty(cap, dtype=torch.uint8).pin_memory(),
+                             torch.cuda.Event()) for _ in range(3)]
+            self._copy_stream = torch.cuda.Stream(self.device)
+            self._predicted = 0
+        k = self._pass % 3
+        self._pass += 1
+        return k, cap
+
+    def _queue_host_copy(self, k):
+        """behind the pass's tail (the current stream), on the copy stream: the first `predicted` bytes of the blob"""
+        torch = self.torch
+        dblob, hblob, done = self._hslots[k]
+        n = dblob.numel() if self._predicted <= 0 else min(dblob.numel(), self._predicted)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._copy_stream.wait_event(ev)
+        with torch.cuda.stream(self._copy_stream):
+            hblob[:n].copy_(dblob[:n], non_blocking=True)
+            done.record(self._copy_stream)
+        return n
+
+    def _finish_host_copy(self, k, copied, params, qad):
+        from .pipeline import HostBits
+        dblob, hblob, done = self._hslots[k]
+        done.synchronize()
+        hdr = hblob[:128].numpy().view(np.int64)
+        total = abs(int(hdr[6]))
+        if total > copied:                                   # the prediction fell short: the rest now
+            with self.torch.cuda.stream(self._copy_stream):
+                hblob[copied:total].copy_(dblob[copied:total], non_blocking=False)
+        self._predicted = total + total // 8 + 65536
+        h = self._host_bits(HostBits, hblob, params, qad)
+        h.sharded_piece = True
+        return h
+
+    @staticmethod
+    def _host_bits(HostBits, hblob, params, qad):
+        return HostBits.from_blob(hblob.data_ptr(), params, n_samples=int(qad.shape[0]) if qad is not None else 0,
+                                  d_qad=qad.data_ptr() if qad is not None else 0)
 
     def tail(self, iq_local, p):
         torch = self.torch
@@ -123,6 +192,16 @@ class GpuShardEngine(DevicePipeline):
         o.cap_pos = cap_pos if pos is not None else 0
         o.pos_off = pos_off.data_ptr()
         o.counts = counts.data_ptr()
+        self._hslot = None
+        if self.host_results:
+            if p.modulation_type == "ASK":
+                raise ValueError("host_results: the compact blob has no 8-bit code for an absorbed ASK row")
+            k, cap = self._host_slot(cap_rows, cap_bits, cap_msg, cap_pos if pos is not None else 0, pos is not None)
+            dblob, _, done = self._hslots[k]
+            # the blob slot is written by this pass's tail: behind the copy that last read it (three passes ago)
+            (self.tail_stream if self.tail_stream is not None else torch.cuda.current_stream(self.device)).wait_event(done)
+            o.blob = dblob.data_ptr(); o.cap_blob = cap
+            self._hslot = k
         self._res = ShardResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, self.ctx)
         self._ask = p.modulation_type == "ASK"
         self._keep = (iq,)                                     # keep the inputs alive until the pass is over
@@ -182,6 +261,8 @@ class GpuShardEngine(DevicePipeline):
     def bits_finish(self, flags_all):
         self._keep += (flags_all,)
         _lib.check(_lib.load().urhgpu_shard_bits_finish_dev(self.ctx.handle, C.c_void_p(flags_all.data_ptr())))
+        if self._hslot is not None:
+            self._res._host = (self, self._hslot, self._queue_host_copy(self._hslot))
         res, self._res = self._res, None
         res._keep = self._keep
         self._keep = ()
