@@ -991,6 +991,10 @@ def main():
                                       "bit_exact": (ex.get("parity") or {}).get("bit_exact"), "error": ex.get("error")}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:
+        pipe.ctx.join()
+        torch.cuda.synchronize()
+        if hasattr(pipe.comm, "close"):
+            pipe.comm.close()                                # the library's own RCCL communicator, before torch's
         dist.destroy_process_group()
 
 
