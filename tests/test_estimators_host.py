@@ -205,3 +205,54 @@ def test_positions_derived_from_the_pulse_table_equal_the_oracle(oracle):
         pos, off = positions_from_rows(pp[:, 0], pp[:, 1], DemodParams(g["modulation_type"], g["bits_per_symbol"], 0, 0, 1, 5, g["samples_per_symbol"], 0.1,
                                                                        g["pause_threshold"], False))
         assert np.array_equal(pos, want[3]) and np.array_equal(off, want[4]), name
+
+
+def test_host_bits_from_a_blob_in_host_memory():
+    """pipeline.HostBits.from_blob: the compact result blob (include/urhgpu.h) parsed from plain host memory -- the layout restated here
+    byte for byte: header of 16 int64 with the section offsets, 16-byte aligned sections"""
+    import ctypes as C
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams, HostBits
+    rng = np.random.default_rng(5)
+    n_rows, n_msg = 37, 3
+    row_state = rng.integers(-1, 2, n_rows).astype(np.int8)
+    row_len = rng.integers(1, 5000, n_rows).astype(np.int32)
+    bits = rng.integers(0, 2, 101).astype(np.uint8)
+    msg_off = np.array([0, 40, 77, 101], np.int64)
+    pauses = np.array([300, 0, 12345], np.int64)
+    pos = np.sort(rng.integers(0, 1 << 31, 101 + 2 * n_msg)).astype(np.uint32)
+    pos_off = np.array([0, 42, 81, 107], np.int64)
+    for has_pos in (1, 0):
+        sections, off = {}, 128
+
+        def put(name, arr):
+            nonlocal off
+            off = (off + 15) & ~15
+            sections[name] = (off, np.ascontiguousarray(arr).tobytes())
+            off += len(sections[name][1])
+        put("pauses", pauses); put("msg_off", msg_off); put("pos_off", pos_off); put("row_state", row_state)
+        put("bits", np.packbits(bits)); put("row_len", row_len)
+        if has_pos:
+            put("pos32", pos)
+        total = off
+        hdr = np.zeros(16, np.int64)
+        hdr[:8] = [_lib.BLOB_MAGIC, n_rows, n_msg, len(bits), len(pos) if has_pos else 0, n_rows, total, has_pos]
+        hdr[8:15] = [sections["pauses"][0], sections["msg_off"][0], sections["pos_off"][0], sections["row_state"][0], sections["bits"][0],
+                     sections["row_len"][0], sections["pos32"][0] if has_pos else 0]
+        blob = bytearray(total)
+        blob[:128] = hdr.tobytes()
+        for o, b in sections.values():
+            blob[o:o + len(b)] = b
+        buf = (C.c_ubyte * total).from_buffer(blob)
+        h = HostBits.from_blob(C.addressof(buf), DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, bool(has_pos)), seq=7, n_samples=1 << 20).check()
+        assert (h.seq, h.n_rows, h.n_msg, h.n_bits, h.blob_bytes, h.truncated) == (7, n_rows, n_msg, len(bits), total, False)
+        assert np.array_equal(h.ppseq(), np.stack([row_state.astype(np.int64), row_len.astype(np.int64)], axis=1))
+        assert np.array_equal(h.bits(), bits) and np.array_equal(h.pauses, pauses) and np.array_equal(h.msg_off, msg_off)
+        if has_pos:
+            assert np.array_equal(h.bit_sample_pos(), pos.astype(np.int64)) and np.array_equal(h.pos_offsets(), pos_off)
+        else:
+            h.sharded_piece = True                           # a rank's piece of a sharded capture: positions must have been shipped
+            with pytest.raises(ValueError):
+                h.bit_sample_pos()
+    with pytest.raises(ValueError):
+        HostBits.from_blob(C.addressof((C.c_ubyte * 128)()), None)
