@@ -579,8 +579,8 @@ int urhgpu_memcpy_to_host(urhgpu_ctx *ctx, const void *d_src, void *host_dst, in
  * state-byte kernel as well, so that tests can compare the two on the same input.  Process-wide. */
 int urhgpu_test_force_state_bytes(int on);
 
-/* Test hook: single-GPU captures of every modulation but ASK go from chunk records to bits through the five-launch "tile"
- * tail; on != 0 routes them through the generic tail (the one ASK and sharded captures use) so that tests can compare the two
+/* Test hook: captures of every modulation but ASK (on one GPU and sharded) go from chunk records to bits through the five-launch "tile"
+ * tail; on != 0 routes them through the generic tail (the one ASK captures use) so that tests can compare the two
  * on the same input.  Process-wide. */
 int urhgpu_test_force_generic_tail(int on);
 
