@@ -802,6 +802,9 @@ def test_plateau_decisions_on_device_counts_equal_the_sequence_path(pipe):
         cen.append(np.nan if kind == 2 and k % 8 == 2 else 0.5)
         pos += len(seg) + int(rng.integers(100, 5000))
         k += 1
+    for a, b in ((pos, pos), (pos + 10, pos + 11), (pos + 20, pos + 25), (pos + 40, pos + 400)):      # degenerate messages: empty, one sample, a few
+        x[a:b] = 0.9
+        ranges.append((a, b)); cen.append(0.5)
     ranges = np.ascontiguousarray(ranges, dtype=np.int64)
     cen = np.array(cen, dtype=np.float64)
     dev = torch.from_numpy(x).cuda()
