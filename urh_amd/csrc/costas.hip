@@ -19,7 +19,11 @@
 //     the next chunk start is known without touching a sample.  Where nothing matches (acquisition, long gated
 //     stretches) it evaluates the chunk serially from the true state, leaving it as soon as the state equals a
 //     candidate's checkpoint.  Either way the TRUE state at every chunk start comes out.
-//   * k_costas_final re-evaluates every chunk from its true start state, in parallel, and writes the output.
+//   * k_costas_final re-evaluates every chunk from its true start state, in parallel, and writes the output.  (Tried in round 3:
+//     the candidate pass keeps every distinct candidate's output -- collected 16 samples at a time, written as whole 64-byte lines into
+//     a slot per candidate -- and a gather kernel copies the true candidate's slot per chunk, so that this pass only re-evaluates
+//     chunks without one.  Bit-identical, but no faster: the candidate pass grew from 1.96 to 2.22 ms, the gather took 0.23, against
+//     0.69 saved here: 3.36 instead of 3.39 ms per 2^27 samples, for 2 GB more scratch.  Not kept.)
 // The result is exact by construction (equality is tested on the state bits, never assumed); only the speed depends on
 // how quickly candidates converge.  Work: (K warm + D kChunk + kChunk) steps per chunk instead of kChunk (D <= K distinct candidates).
 // Loop orders other than 2 and 4 leave the output unwritten in the reference; they use the serial kernel.
@@ -180,7 +184,12 @@ __global__ __launch_bounds__(64) void k_costas(const CostasArgs a) {
 }
 
 // ---- speculative parallel evaluation ----------------------------------------------------------------------------------
-constexpr int kChunk = 4096;        // samples per chunk
+// samples per chunk.  Round 3, config-5 capture (tools/costas_chunk_ab.py, libraries built with -DURH_COSTAS_CHUNK=...): 1024 / 2048 / 4096 /
+// 8192 samples per chunk take 5.04 / 3.83 / 3.39 / 3.92 ms -- shorter chains, but as many warm-up steps per chunk as before.
+#ifndef URH_COSTAS_CHUNK
+#define URH_COSTAS_CHUNK 4096
+#endif
+constexpr int kChunk = URH_COSTAS_CHUNK;
 constexpr int kWarmBackFactor = 16; // a candidate looks back at most 16 x its warm-up length for un-gated samples
 constexpr int kCkpt = 256;          // checkpoint spacing inside a chunk
 constexpr int kNumCkpt = kChunk / kCkpt;   // checkpoints at offsets kCkpt, 2 kCkpt, ... < kChunk  (index j = off / kCkpt - 1)
