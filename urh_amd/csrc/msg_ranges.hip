@@ -114,9 +114,16 @@ __global__ __launch_bounds__(256) void k_seg_moments(const int64_t *seg, const S
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = (s_p[0] + s_p[1]) + (s_p[2] + s_p[3]);
 }
-__global__ void k_seg_moments_fin(const double *part, int n_part, int pass, SegCtl *ctl) {
+// the partial sums added in block order by one thread -- after ALL of them have been loaded in one round trip (the first version
+// loaded them one after the other: 256 dependent loads, 12-15 us)
+constexpr int kSegParts = 256;
+__global__ __launch_bounds__(kSegParts) void k_seg_moments_fin(const double *part, int n_part, int pass, SegCtl *ctl) {
+    __shared__ double s_part[kSegParts];
+    s_part[threadIdx.x] = ((int)threadIdx.x < n_part) ? part[threadIdx.x] : 0.0;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     double t = 0.0;
-    for (int b = 0; b < n_part; ++b) t += part[b];
+    for (int b = 0; b < n_part; ++b) t += s_part[b];
     if (pass == 0) ctl->sum = t; else ctl->sq = t;
 }
 __global__ __launch_bounds__(256) void k_seg_min_pulse(const int64_t *seg, SegCtl *ctl) {
@@ -194,10 +201,10 @@ int launch_message_ranges(const int64_t *d_rows, const int64_t *d_n_rows, int64_
         default: return URHGPU_ERR_DTYPE;
     }
     if (!ook_merge) return URHGPU_OK;
-    const int gp = 256;
+    const int gp = kSegParts;
     for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(k_seg_moments, dim3(gp), dim3(256), 0, s, d_seg, d_ctl, pass, dpart);
-        hipLaunchKernelGGL(k_seg_moments_fin, dim3(1), dim3(1), 0, s, dpart, gp, pass, d_ctl);
+        hipLaunchKernelGGL(k_seg_moments_fin, dim3(1), dim3(kSegParts), 0, s, dpart, gp, pass, d_ctl);
     }
     hipLaunchKernelGGL(k_seg_min_pulse, dim3(gp), dim3(256), 0, s, d_seg, d_ctl);
     hipLaunchKernelGGL(k_seg_count_ptr, dim3(1), dim3(1), 0, s, d_ctl, d_nseg);
