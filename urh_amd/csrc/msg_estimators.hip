@@ -533,7 +533,8 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
     // The pass is bound by instruction issue, not by HBM: the bin is guessed in float32 and checked against a float32 table of the
     // edges in LDS that decides exactly as the float64 edges do (me_f32_at_or_above).  A workgroup walks kMeHistGroup consecutive
     // tiles and flushes its LDS counters when the message changes or at the end (a capture that is ONE message had 32 768
-    // workgroups adding their counters to the same few words of device memory: 371 us).
+    // workgroups adding their counters to the same few words of device memory: 371 us).  (Requesting the next tile's samples before
+    // the current tile is binned -- 16 more registers -- made the kernel slower, 213 -> 280 us: not the loads' latency.)
     __shared__ unsigned int s_c[kMeHistLds];
     __shared__ float s_e[kMeHistLds + 2];                   // s_e[k] = first float32 inside bin k or above; s_e[nb] = first float32 beyond the last bin
     const int64_t tile0 = (int64_t)blockIdx.x * kMeHistGroup, tile1 = (tile0 + kMeHistGroup < n_tiles) ? tile0 + kMeHistGroup : n_tiles;
