@@ -81,6 +81,7 @@ class GpuShardEngine(DevicePipeline):
         self._hslots = None                                 # [(device blob, pinned host blob, copy-done event)] x 3
         self._copy_stream = None
         self._predicted = 0                                 # bytes the next copy is sized for (0: the whole blob)
+        self._hqueued = [False, False, False]               # a copy has been queued for the slot (its event means something)
 
     def _host_slot(self, cap_rows, cap_bits, cap_msg, cap_pos, has_pos):
         torch = self.torch
@@ -90,6 +91,7 @@ class GpuShardEngine(DevicePipeline):
                              torch.cuda.Event()) for _ in range(3)]
             self._copy_stream = torch.cuda.Stream(self.device)
             self._predicted = 0
+            self._hqueued = [False, False, False]
         k = self._pass % 3
         self._pass += 1
         return k, cap
@@ -98,7 +100,15 @@ class GpuShardEngine(DevicePipeline):
         """behind the pass's tail (the current stream), on the copy stream: the first `predicted` bytes of the blob"""
         torch = self.torch
         dblob, hblob, done = self._hslots[k]
+        if self._predicted <= 0:
+            # nobody has looked at a result yet: size the copy by whichever earlier blob has already arrived (else: the whole slot)
+            for j in range(3):
+                if j != k and self._hqueued[j] and self._hslots[j][2].query():
+                    hdr = self._hslots[j][1][:128].numpy().view(np.int64)
+                    if int(hdr[0]) == _lib.BLOB_MAGIC:
+                        self._predicted = max(self._predicted, abs(int(hdr[6])) + abs(int(hdr[6])) // 8 + 65536)
         n = dblob.numel() if self._predicted <= 0 else min(dblob.numel(), self._predicted)
+        self._hqueued[k] = True
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._copy_stream.wait_event(ev)
