@@ -104,28 +104,40 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
     const int64_t nt = ((full > 1 ? full : 1) + kMeTile - 1) / kMeTile;       // tiles of the message (build_batch)
     const float *src = x + m.start + skip;
     const int lf = threadIdx.x >> 3, j = threadIdx.x & 7;
-    const int64_t q0 = (int64_t)t.idx * kMeTile + (int64_t)lf * kPwLeafM + j;                  // index in the trimmed range of this thread's first element
+    // Everything per element is 32-bit arithmetic relative to wave-uniform 64-bit bases (the first version indexed every element in 64
+    // bits: 35 VALU instructions per 64 samples, 116 us of instruction issue for a pass whose bytes take 95 -- profiles/r03d_estimator_pmc.txt)
+    const int64_t wbase = a + (int64_t)t.idx * kMeTile;                      // first sample of this tile's window, in src
+    const float *win = src + wbase;
+    const int rel0 = lf * kPwLeafM + j;                                      // this thread's first element of the window
+    const int64_t left_len = len - wbase, left_L = L - (int64_t)t.idx * kMeTile;
+    const int lim_len = (int)(left_len < 0 ? 0 : (left_len > kMeTile ? kMeTile : left_len));   // samples of the window that exist ...
+    const int lim_L = (int)(left_L < 0 ? 0 : (left_L > kMeTile ? kMeTile : left_L));           // ... and that lie in the trimmed range
     float v[kPwLeafM / 8];
 #pragma unroll
-    for (int i = 0; i < kPwLeafM / 8; ++i) { const int64_t s = a + q0 + 8 * i; v[i] = (s < len) ? src[s] : -5.0f; }
+    for (int i = 0; i < kPwLeafM / 8; ++i) v[i] = (rel0 + 8 * i < lim_len) ? win[rel0 + 8 * i] : -5.0f;
     // The counts are kept per NATURAL tile of the message (samples [4096 u, 4096 (u + 1)) from its start) although the reads are not
     // aligned to them: the compaction of a message that does have filtered samples needs those, and this way nobody reads the message
     // a second time just to count.  A window meets two natural tiles, a head slice (at most 5 % of 4096 samples) two as well.
-    const int64_t wa = (skip + a + (int64_t)t.idx * kMeTile) / kMeTile;         // natural tile of the window's first sample
+    static_assert((kMeTile & (kMeTile - 1)) == 0, "natural tiles by shift and mask");
+    const int64_t wa = (skip + wbase) / kMeTile;                             // natural tile of the window's first sample
+    const int woff = (int)((skip + wbase) & (kMeTile - 1));                  // ... and where in it the window starts
     int c[4] = {0, 0, 0, 0};                               // window: tiles wa, wa + 1; head slice: tiles ha, ha + 1
 #pragma unroll
     for (int i = 0; i < kPwLeafM / 8; ++i) {
         const int hit = (v[i] > -4.0f) ? 1 : 0;
-        const bool second = (skip + a + q0 + 8 * i) / kMeTile != wa;
+        const bool second = woff + rel0 + 8 * i >= kMeTile;
         c[0] += second ? 0 : hit; c[1] += second ? hit : 0;
     }
     int64_t ha = 0;
     if (a > 0) {                                           // the head [0, a): slice t of nt
         const int64_t h = (a + nt - 1) / nt, h0 = (int64_t)t.idx * h, h1 = (h0 + h < a) ? h0 + h : a;
         ha = (skip + h0) / kMeTile;
-        for (int64_t k = h0 + threadIdx.x; k < h1; k += kMeBlock) {
-            const int hit = (src[k] > -4.0f) ? 1 : 0;
-            const bool second = (skip + k) / kMeTile != ha;
+        const int hoff = (int)((skip + h0) & (kMeTile - 1));
+        const int hn = (int)(h1 > h0 ? h1 - h0 : 0);        // (a slice holds at most a / nt + 1 <= 0.05 * 4096 + 1 samples)
+        const float *head = src + h0;
+        for (int k = threadIdx.x; k < hn; k += kMeBlock) {
+            const int hit = (head[k] > -4.0f) ? 1 : 0;
+            const bool second = hoff + k >= kMeTile;
             c[2] += second ? 0 : hit; c[3] += second ? hit : 0;
         }
     }
@@ -135,7 +147,7 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
     float mn = first, mx = first;
 #pragma unroll
     for (int i = 0; i < kPwLeafM / 8; ++i) {
-        const float w = (q0 + 8 * i < L) ? v[i] : first;
+        const float w = (rel0 + 8 * i < lim_L) ? v[i] : first;
         if (w < mn) mn = w;
         if (w > mx) mx = w;
     }
