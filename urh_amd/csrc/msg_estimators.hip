@@ -604,11 +604,13 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
     if (!valid || (int64_t)t.idx * kMeTile >= m.L) continue;
     const float lo_all = s_e[0], hi_all = s_e[nb];             // inside: lo_all <= v < hi_all (NaN: neither)
     const float e0f = (float)m.e0, invf = (m.delta > 0.0) ? (float)(1.0 / m.delta) : 0.f;
-    const float *r = me_src(x, kept, m) + m.a;
-    const int64_t i0 = (int64_t)t.idx * kMeTile + threadIdx.x;
+    // (32-bit offsets from a wave-uniform base, as in k_me_first)
+    const int64_t tbase = (int64_t)t.idx * kMeTile, left = m.L - tbase;
+    const float *r = me_src(x, kept, m) + m.a + tbase;
+    const int lim = (int)(left < 0 ? 0 : (left > kMeTile ? kMeTile : left));
     float val[kMePer];
 #pragma unroll
-    for (int j = 0; j < kMePer; ++j) { const int64_t i = i0 + (int64_t)j * kMeBlock; val[j] = (i < m.L) ? r[i] : __builtin_nanf(""); }
+    for (int j = 0; j < kMePer; ++j) { const int i = (int)threadIdx.x + j * kMeBlock; val[j] = (i < lim) ? r[i] : __builtin_nanf(""); }
     int bin[kMePer];
     {
         // straight-line code for all 16 rows (their LDS reads overlap): guess, one step either way, check.  The float32 guess is off by
