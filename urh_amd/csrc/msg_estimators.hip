@@ -494,7 +494,8 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
 }
 
 // ---- stage 5: bin edges (np.arange(min, max + step, step) in float64) and histogram ---------------------------------------
-__global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins) {
+constexpr int kMeHistSmallBins = 512;        // see k_me_hist
+__global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins, unsigned int *any_wide) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_msgs) return;
     MsgState s = st[m];
@@ -516,6 +517,7 @@ __global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins) {
         if (ne < 2) ne = 0;                                    // np.histogram needs at least two edges (ValueError -> None)
     }
     st[m].n_edges = ne; st[m].e0 = e0; st[m].delta = delta;
+    if (ne - 1 > kMeHistSmallBins) *any_wide = 1u;          // some message needs the wide histogram kernel (k_me_hist<kMeHistLds>)
     (void)max_bins;
 }
 __device__ __forceinline__ double me_edge(const MsgState &s, int64_t i) { return s.e0 + (double)i * s.delta; }
@@ -535,8 +537,15 @@ __device__ __forceinline__ float me_f32_at_or_below(double e) {
     return f;
 }
 constexpr int kMeHistGroup = 8;              // consecutive tiles per workgroup: one flush of the LDS counters per message and group
+// Two instantiations share the tiles: BINS = kMeHistSmall serves the messages with at most that many bins (a demodulated message
+// has a few dozen) out of 4 KiB of LDS -- eight workgroups per CU instead of four: the pass is bound by instruction issue and by the
+// latency of each tile's loads, and twice the wavefronts hide twice as much of it -- BINS = kMeHistLds serves the others; a workgroup
+// skips the messages of the other class.
+constexpr int kMeHistSmall = kMeHistSmallBins;
+template <int BINS>
 __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int64_t n_tiles,
-                                                       int64_t max_bins, unsigned int *counts) {
+                                                       int64_t max_bins, unsigned int *counts, const unsigned int *any_wide) {
+    if (BINS != kMeHistSmall && *any_wide == 0u) return;     // no message of this class in the batch (k_me_bins)
     // demodulated signals sit on two or four levels: nearly every sample of a message lands in a handful of bins.  Counting
     // straight into device memory serialises the whole pass on those few addresses (40 ms for a 1 GiB capture).  A wavefront
     // counts the lanes that share a bin with one ballot per distinct bin for the first two bins it meets in a row of 64 samples and
@@ -547,8 +556,8 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
     // tiles and flushes its LDS counters when the message changes or at the end (a capture that is ONE message had 32 768
     // workgroups adding their counters to the same few words of device memory: 371 us).  (Requesting the next tile's samples before
     // the current tile is binned -- 16 more registers -- made the kernel slower, 213 -> 280 us: not the loads' latency.)
-    __shared__ unsigned int s_c[kMeHistLds];
-    __shared__ float s_e[kMeHistLds + 2];                   // s_e[k] = first float32 inside bin k or above; s_e[nb] = first float32 beyond the last bin
+    __shared__ unsigned int s_c[BINS];
+    __shared__ float s_e[BINS + 2];                         // s_e[k] = first float32 inside bin k or above; s_e[nb] = first float32 beyond the last bin
     const int64_t tile0 = (int64_t)blockIdx.x * kMeHistGroup, tile1 = (tile0 + kMeHistGroup < n_tiles) ? tile0 + kMeHistGroup : n_tiles;
     int cur_msg = -1, nb = 0;
     bool valid = false, big = false;
@@ -569,7 +578,8 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
         m = st[t.msg];
         big = false;
         valid = !(m.L <= 0 || m.n_edges < 2 || m.n_edges - 1 > max_bins || m.n_edges - 1 > INT32_MAX - 1);
-        if (valid && m.n_edges - 1 > kMeHistLds) { valid = false; big = true; }       // more bins than the LDS holds: the plain path below
+        if (valid && m.n_edges - 1 > kMeHistLds) { valid = false; big = (BINS == kMeHistLds); }   // more bins than the LDS holds: the plain path below
+        if (valid && ((BINS == kMeHistSmall) != (m.n_edges - 1 <= kMeHistSmall))) valid = false;  // the other instantiation's message
         nb = (valid || big) ? (int)(m.n_edges - 1) : 0;
         out = counts + (int64_t)t.msg * max_bins;
         if (valid) {
@@ -944,7 +954,7 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     URH_TRY(build_batch(ctx, ranges, n_msgs, n, nullptr, b));
     // scratch: state, tiles, per-tile counts / min-max, leaf sums, the compacted samples, the histogram pool
     const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)(b.n_tiles + 1) * (sizeof(MsgTile) + 4 + 8 + 8 + 4 + kLeavesPerTile * 4) +
-                        (size_t)n * 4 + (size_t)n_msgs * (size_t)max_bins * 4 + 16 * 256;
+                        (size_t)n * 4 + (size_t)n_msgs * (size_t)max_bins * 4 + 17 * 256;
     URH_TRY(ctx->arena.reserve(need));
     ctx->arena.reset();
     MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
@@ -955,12 +965,13 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     float *d_leaf = (float *)ctx->arena.take((size_t)b.n_tiles * kLeavesPerTile * 4);
     float *d_chunk = (float *)ctx->arena.take((size_t)(b.n_tiles + 1) * 4);
     float *d_kept = (float *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
-    unsigned int *d_hist = (unsigned int *)ctx->arena.take((size_t)n_msgs * (size_t)max_bins * 4);
+    unsigned int *d_hist = (unsigned int *)ctx->arena.take((size_t)n_msgs * (size_t)max_bins * 4 + 256);     // (+ the any_wide flag, cleared with the pool)
+    unsigned int *d_any_wide = d_hist ? d_hist + (size_t)n_msgs * (size_t)max_bins : nullptr;
     if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_mm || !d_leaf || !d_chunk || !d_kept || !d_hist) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
     URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
-    URH_HIP(hipMemsetAsync(d_hist, 0, (size_t)n_msgs * (size_t)max_bins * 4, s));
+    URH_HIP(hipMemsetAsync(d_hist, 0, (size_t)n_msgs * (size_t)max_bins * 4 + 256, s));
     const unsigned gt = (unsigned)b.n_tiles, gm = (unsigned)((n_msgs + 63) / 64);
     URH_HIP(hipMemsetAsync(d_cnt, 0, (size_t)b.n_tiles * 4, s));
     hipLaunchKernelGGL(k_me_first, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_mm, d_leaf);
@@ -974,9 +985,11 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
         hipLaunchKernelGGL(k_me_chunk_trees, dim3(gt), dim3(64), 0, s, d_st, d_tiles, d_leaf, d_chunk);
         hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeRestSlots), 0, s, d_x, d_kept, d_st, d_chunk, mode);
     }
-    hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins);
-    hipLaunchKernelGGL(k_me_hist, dim3((unsigned)((b.n_tiles + kMeHistGroup - 1) / kMeHistGroup)), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, b.n_tiles,
-                       max_bins, d_hist);
+    hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins, d_any_wide);
+    hipLaunchKernelGGL((k_me_hist<kMeHistSmall>), dim3((unsigned)((b.n_tiles + kMeHistGroup - 1) / kMeHistGroup)), dim3(kMeBlock), 0, s, d_x, d_kept, d_st,
+                       d_tiles, b.n_tiles, max_bins, d_hist, d_any_wide);
+    hipLaunchKernelGGL((k_me_hist<kMeHistLds>), dim3((unsigned)((b.n_tiles + kMeHistGroup - 1) / kMeHistGroup)), dim3(kMeBlock), 0, s, d_x, d_kept, d_st,
+                       d_tiles, b.n_tiles, max_bins, d_hist, d_any_wide);
     hipLaunchKernelGGL(k_me_peaks, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_hist, max_bins);
     URH_HIP(hipGetLastError());
     std::vector<unsigned int> hist;
