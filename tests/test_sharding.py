@@ -116,7 +116,10 @@ def _gloo_worker(rank, world, port, n, seed, q):
         assert isinstance(comm, TorchDistComm)
         pipe = ShardedPipeline(model_shard.ModelShardEngine(tile=32, span=8, chunk_tiles=2), comm)
         res = pipe.iq_to_bits(x[a:b], p, want_qad=True, pos_base=a, n_total=n)
-        q.put((rank, res))
+        # the same with the halo handed over with the shard: two all-gathers instead of three
+        res2 = pipe.iq_to_bits(x[a:b], p, want_qad=True, pos_base=a, n_total=n, halo_given=True,
+                               left_halo=torch.tensor([float(x[a - 1])], dtype=torch.float32) if rank > 0 else None)
+        q.put((rank, res, res2))
     finally:
         dist.destroy_process_group()
 
@@ -130,7 +133,9 @@ def test_sharded_protocol_over_gloo(oracle):
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, n, seed, q)) for r in range(2)]
     for pr in procs:
         pr.start()
-    got = dict(q.get(timeout=120) for _ in range(2))
+    items = [q.get(timeout=120) for _ in range(2)]
+    got = {r: a for r, a, _ in items}
+    got2 = {r: b for r, _, b in items}
     for pr in procs:
         pr.join(timeout=60)
         assert pr.exitcode == 0
@@ -139,3 +144,4 @@ def test_sharded_protocol_over_gloo(oracle):
     x[n // 2 - 40:n // 2 + 25] = -4.0
     p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 20, 0.1, 8, True)
     assert_same(stitch([got[0], got[1]]), reference_result(oracle, x, p), "gloo")
+    assert_same(stitch([got2[0], got2[1]]), reference_result(oracle, x, p), "gloo, halo with the shard")
