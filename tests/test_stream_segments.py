@@ -1,0 +1,168 @@
+"""Streamed passes (urhgpu_stream_*, pulse_table.hip "Segments"): the tail of a capture runs in SEGMENTS beside the hot kernel, every
+segment storing its share of the compact blob straight into pinned host memory.  Whatever the segmentation -- number of segments, equal
+or halving, the open message group a boundary cuts through, groups without a data row that are dropped after all -- the host receives
+exactly what the reference computes for the capture (oracle = the C restatement pinned on the reference, tests/test_oracle.py).
+
+Captures are cut into chunks of ONE tile here (urhgpu_test_force_tiles_per_chunk), so that 2^22 samples are 2048 chunks = eight
+segment-alignment units: every boundary a 1 GiB capture's segmentation can have is exercised at a size the oracle finishes in a second."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import synth_fsk
+
+pytestmark = pytest.mark.gpu
+
+N = 1 << 22
+UNIT = 256 * 2048          # samples per segment-alignment unit with one tile per chunk
+
+
+def _events_capture(n, seed, boundary_trains=True):
+    """2-FSK bursts under an on/off envelope: long data bursts, long pauses (close a message), short pauses (zero bits) and TINY bursts
+    (longer than the tolerance, shorter than half a symbol: a data row of zero symbols -- a message group that holds only those and
+    short pauses has no data and is dropped when its long pause comes).  boundary_trains: trains of tiny bursts and short pauses
+    across every multiple of UNIT, some ended by a data burst (kept), some by a long pause (dropped)."""
+    rng = np.random.default_rng(seed)
+    env = np.zeros(n, np.float32)
+    i = int(rng.integers(0, 3000))
+    while i < n:
+        kind = rng.choice(4, p=[0.35, 0.2, 0.25, 0.2])
+        if kind == 0:
+            ln = int(rng.integers(300, 6000)); env[i:i + ln] = 1
+        elif kind == 1:
+            ln = int(rng.integers(900, 9000))
+        elif kind == 2:
+            ln = int(rng.integers(60, 790))
+        else:
+            ln = int(rng.integers(8, 45)); env[i:i + ln] = 1
+        i += ln
+    if boundary_trains:
+        for k, b in enumerate(range(UNIT, n, UNIT)):
+            a = b - int(rng.integers(2000, 9000))
+            env[a - 3000:a] = 0                                          # a long pause opens a fresh group
+            j = a
+            stop = b + int(rng.integers(500, 6000))
+            while j < stop:
+                t = int(rng.integers(8, 45)); env[j:j + t] = 1; j += t    # tiny burst: zero symbols
+                g = int(rng.integers(60, 700)); env[j:j + g] = 0; j += g  # short pause: zero bits
+            if k % 2 == 0:
+                env[j:j + 2500] = 1                                       # data after all: the group is a message
+                env[j + 2500:j + 5000] = 0
+            else:
+                env[j:j + 4000] = 0                                       # closed by a long pause: dropped
+    iq = synth_fsk(n, sps=100, seed=seed + 1, noise=0.0)
+    iq = iq * env[:, None] + 0.012 * rng.standard_normal((n, 2)).astype(np.float32)
+    return iq.astype(np.float32)
+
+
+def _oracle_flat(oracle, iq, p):
+    qad = oracle.afp_demod(iq, p.noise_threshold, p.modulation_type, 2 ** p.bits_per_symbol)
+    pp = oracle.grab_pulse_lens(qad, p.center, p.tolerance, p.modulation_type, p.samples_per_symbol, p.bits_per_symbol, p.center_spacing)
+    return (pp,) + tuple(oracle.ppseq_to_bits_flat(pp, p.samples_per_symbol, p.bits_per_symbol, True, p.pause_threshold))
+
+
+def _got(r):
+    r.check()
+    return (r.ppseq(), r.bits(), r.msg_off.copy(), r.pauses.copy(), r.bit_sample_pos(), r.pos_offsets())
+
+
+def _assert_equal(got, ref, tag):
+    names = ("rows", "bits", "msg_off", "pauses", "pos", "pos_off")
+    for name, g, e in zip(names, got, ref):
+        if not np.array_equal(g, e):
+            g, e = np.asarray(g), np.asarray(e)
+            first = int(np.argmax(g[:min(len(g), len(e))].reshape(min(len(g), len(e)), -1) != e[:min(len(g), len(e))].reshape(min(len(g), len(e)), -1))) \
+                if min(len(g), len(e)) else -1
+            raise AssertionError(f"{tag}: {name} differs (got {g.shape}, expected {e.shape}, first difference near flat index {first})")
+
+
+@pytest.fixture()
+def one_tile_chunks():
+    from urh_amd import _lib
+    lib = _lib.load()
+    lib.urhgpu_test_force_tiles_per_chunk(1)
+    yield
+    lib.urhgpu_test_force_tiles_per_chunk(0)
+
+
+@pytest.mark.parametrize("segments,shape", [(2, 0), (3, 0), (5, 0), (8, 0), (4, 1), (6, 1), (8, 1)])
+@pytest.mark.parametrize("want_pos", [True, False])
+def test_segmented_tail_equals_oracle(oracle, one_tile_chunks, segments, shape, want_pos):
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, want_pos)
+    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_segments": segments, "stream_shape": shape})
+    st = pipe.stream(N, p, want_qad=True, want_pos=want_pos)
+    caps = [_events_capture(N, 11), _events_capture(N, 12), _events_capture(N, 13, boundary_trains=False),
+            synth_fsk(N, sps=100, seed=5, noise=0.04),                                      # one message, no pause at all
+            (0.02 * np.random.default_rng(3).standard_normal((N, 2))).astype(np.float32),     # nothing above the noise gate: one pause row
+            _events_capture(N, 14)]
+    dev = [torch.from_numpy(c).cuda() for c in caps]
+    got = {}
+    for d in dev:
+        r = st.push(d)
+        if r is not None:
+            got[r.seq] = _got(r)
+    for r in st.flush():
+        got[r.seq] = _got(r)
+    stats = st.stats()
+    st.close()
+    assert stats["predicted_bytes"] == -len(caps), stats       # every pass took the segmented route
+    for i, iq in enumerate(caps):
+        _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i}, {segments} segments (shape {shape})")
+
+
+def test_segmented_tail_order4_int16_and_qad(oracle, one_tile_chunks):
+    """4-FSK (three thresholds: the order-4 bit planes) on an int16 capture (not on the CU-masked stream), qad of every pass read back"""
+    import torch
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    p = DemodParams("FSK", 2, 0.0, 0.0, 0.03, 5, 100, 0.1, 8, True)
+    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_segments": 8})
+    caps = [synth_fsk(N, sps=100, seed=40 + i, noise=0.03, pause_every=N // (3 + i), pause_len=3000 + 977 * i, dtype=np.int16) for i in range(4)]
+    st = pipe.stream(N, p, want_qad=True, want_pos=True, dtype=np.int16)
+    dev = [torch.from_numpy(c).cuda() for c in caps]
+    got, qads = {}, {}
+
+    def keep(r):
+        got[r.seq] = _got(r)
+        q = np.empty(N, np.float32)
+        _lib.check(_lib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(r.d_qad_ptr), q.ctypes.data_as(C.c_void_p), N * 4))
+        qads[r.seq] = q
+    for d in dev:
+        r = st.push(d)
+        if r is not None:
+            keep(r)
+    for r in st.flush():
+        keep(r)
+    assert st.stats()["predicted_bytes"] == -len(caps)
+    st.close()
+    for i, iq in enumerate(caps):
+        ref = _oracle_flat(oracle, iq, p)
+        _assert_equal(got[i], ref, f"capture {i}")
+        qad = oracle.afp_demod(iq, 0.0, "FSK", 4)
+        assert np.array_equal(qads[i].view(np.uint32), qad.view(np.uint32)), i
+
+
+def test_segmented_and_plain_passes_interleave(oracle, one_tile_chunks):
+    """captures that qualify (whole tiles) and captures that do not (a partial tile at the end: the ordinary tail, pack kernel and copy)
+    through ONE stream: the slots, arenas, progress counters and host blobs of the two routes do not disturb each other"""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_segments": 8})
+    st = pipe.stream(N, p, want_qad=False, want_pos=True)
+    sizes = [N, N - 777, N, N // 2, N - 2048, N, 70_001, N]
+    caps = [_events_capture(N, 60 + i)[:n].copy() for i, n in enumerate(sizes)]
+    dev = [torch.from_numpy(c).cuda() for c in caps]
+    got = {}
+    for d in dev:
+        r = st.push(d)
+        if r is not None:
+            got[r.seq] = _got(r)
+    for r in st.flush():
+        got[r.seq] = _got(r)
+    st.close()
+    for i, iq in enumerate(caps):
+        _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i} ({sizes[i]} samples)")

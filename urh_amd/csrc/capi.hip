@@ -252,6 +252,9 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     if (s_tail) {                                   // pipelined: everything after the hot kernel goes to the tail stream
         if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot, s)); hot_done = ctx->ev_hot; }
         URH_HIP(hipStreamWaitEvent(s_tail, hot_done, 0));
+        // the hot kernel ran on the private masked stream: what the caller queues on ITS stream afterwards (overwriting the capture, the
+        // allocator handing its memory out again) must come behind it.  (The NULL stream synchronises with the masked stream by itself.)
+        if (s != ctx->stream && ctx->stream != nullptr) URH_HIP(hipStreamWaitEvent(ctx->stream, hot_done, 0));
         s = s_tail;
     }
 
@@ -381,6 +384,156 @@ ShardSession *session(urhgpu_ctx *ctx) {
 
 }  // namespace
 
+namespace urh {
+
+// Segment boundaries (in chunks) of a streamed pass: S segments on kSegAlign chunks, the last one takes the remainder.
+static int segment_bounds(int64_t n_chunks, int wanted, int shape, int64_t *bound /*[kMaxSegments + 1]*/) {
+    const int64_t blocks = n_chunks / kSegAlign;              // whole alignment units; what is left over belongs to the last segment
+    int S = wanted;
+    if (S > kMaxSegments) S = kMaxSegments;
+    if (S > blocks) S = (int)blocks;
+    if (S < 1) S = 1;
+    bound[0] = 0;
+    if (shape == 1 && S > 2) {
+        // halving: 1/2, 1/4, ... of the capture; the last two segments are equal.  The tail of a long first segment runs beside the
+        // hot kernel anyway; what is exposed at the end of the capture is the tail of the LAST segment only.
+        int64_t left = blocks, at = 0;
+        for (int k = 0; k < S - 1; ++k) {
+            int64_t take = (k < S - 2) ? left / 2 : left / 2;
+            const int64_t must_leave = S - 1 - k;             // at least one unit per remaining segment
+            if (take < 1) take = 1;
+            if (left - take < must_leave) take = left - must_leave;
+            at += take; left -= take;
+            bound[k + 1] = at * kSegAlign;
+        }
+    } else {
+        for (int k = 1; k < S; ++k) bound[k] = (blocks * k / S) * kSegAlign;
+    }
+    bound[S] = n_chunks;
+    for (int k = 0; k < S; ++k)
+        if (bound[k + 1] <= bound[k]) return 0;
+    return S;
+}
+
+int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, const urhgpu_outputs *out, void *host_blob,
+                        int64_t cap_host, hipEvent_t ev_ready, bool *streamed) {
+    *streamed = false;
+    if (!ctx || !p || !out || n <= 0 || !d_iq || !out->rows || !out->counts) return URHGPU_ERR_ARG;
+    if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
+    const bool want_bits = out->bits && out->msg_off && out->pauses && out->pos_off;
+    if (!ctx->pipelined || !ctx->tail_stream || n <= 2 || p->mod == URHGPU_MOD_PSK || p->mod == URHGPU_MOD_ASK || !g_tile_tail || !want_bits ||
+        ctx->tune_stream_segments < 2 || out->cap_rows < 1)
+        return URHGPU_OK;
+    URH_TRY(check_params(p, true));
+    if (((uintptr_t)d_iq & 15) || (out->qad && ((uintptr_t)out->qad & 7))) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    const Plan pl = make_plan(ctx, n, p->tolerance);
+    RunArgs a;
+    memset(&a, 0, sizeof(a));
+    URH_TRY(fill_thresholds(a, p));
+    a.in = d_iq; a.qad = out->qad; a.left_halo = nullptr; a.n = n; a.pos_base = 0;
+    a.chunk_len = pl.chunk_len; a.slab_stride = pl.slab_stride;
+    a.noise_sqrd = p->noise_threshold * p->noise_threshold;
+    a.noise_val = noise_for(p);
+    a.tol = p->tolerance;
+    a.lds_pad = ctx->hot_lds_pad;
+    URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
+    int64_t bound[kMaxSegments + 1];
+    const int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, ctx->tune_stream_segments, ctx->tune_stream_shape, bound) : 0;
+    if (S < 2) return URHGPU_OK;                               // too short to cut, or not the bit-plane kernel's work: the ordinary path
+    if (!ctx->d_seg) {
+        URH_HIP(hipMalloc(&ctx->d_seg, 3 * kSegBlockBytes));
+        URH_HIP(hipMemset(ctx->d_seg, 0, 3 * kSegBlockBytes));
+        for (int k = 0; k < 3; ++k) URH_HIP(hipEventCreateWithFlags(&ctx->ev_hot_done[k], hipEventDisableTiming));
+    }
+    URH_TRY(begin_pipelined_pass(ctx));
+    const int slot = ctx->flip;
+    uint32_t *progress = (uint32_t *)((char *)ctx->d_seg + (size_t)slot * kSegBlockBytes);
+    SegState *st = (SegState *)((char *)progress + 256);
+    static_assert(kMaxSegments * 4 <= 256 && 256 + sizeof(SegState) <= kSegBlockBytes, "segment block");
+    if (ctx->seg_dirty[slot]) {                                // an earlier pass on this arena died half-way: its counters may not be zero
+        URH_HIP(hipMemset(progress, 0, kSegBlockBytes));
+        ctx->seg_dirty[slot] = false;
+    }
+    URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, out->cap_rows, false, true)));
+    ctx->arena.reset();
+    ctx->seg_dirty[slot] = true;                               // until the last segment has been queued
+    hipStream_t s = ctx->stream;
+    if (p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s));
+    ChunkInfo *chunks = (ChunkInfo *)ctx->arena.take((size_t)pl.n_chunks * sizeof(ChunkInfo));
+    uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
+    void *rs_mem = ctx->arena.take(resolve_scratch_bytes(pl.n_chunks));
+    if (!chunks || !slab || !rs_mem) return URHGPU_ERR_ARG;
+    a.chunks = chunks; a.slab = slab;
+    // a segment's counter covers its chunks and the first chunk of the next segment (the resolve kernel's look-ahead), less the first
+    // chunk of its own, which the segment before already waited for
+    a.progress = progress; a.n_seg = S;
+    uint32_t target[kMaxSegments];
+    for (int k = 0; k < S; ++k) {
+        const int64_t hi = (k < S - 1) ? bound[k + 1] + 1 : pl.n_chunks, lo = (k == 0) ? 0 : bound[k] + 1;
+        a.seg_end[k] = (int32_t)hi;
+        target[k] = (uint32_t)(hi - lo);
+    }
+    const bool prof = prof_begin_record(ctx, s);
+    // the hot kernel's completion: the dispatch's own completion signal where the launcher takes events (an event recorded behind the
+    // kernel is one more barrier packet between two hot kernels); nobody waits for it before the last segment has been queued
+    hipEvent_t hot_done = nullptr;
+    if (ctx->hot_stop_event) {
+        if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot_done[slot]; }
+        hot_done = g_hot_events.stop;
+    }
+    {
+        const int stl = launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s);
+        if (stl != URHGPU_OK) { g_hot_events = HotEvents(); return stl; }
+    }
+    if (hot_done && !g_hot_events.used) hot_done = nullptr;
+    if (prof) URH_TRY(prof_end_record(ctx, s));
+    else g_hot_events = HotEvents();
+    if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot_done[slot], s)); hot_done = ctx->ev_hot_done[slot]; }
+    // ---- the tail, segment by segment, on the tail stream: it never waits for the hot kernel as a whole ----
+    hipStream_t ts = ctx->tail_stream;
+    const ResolveScratch rsc = resolve_scratch_carve(rs_mem, pl.n_chunks);
+    ResolveArgs r;
+    memset(&r, 0, sizeof(r));
+    r.sc = rsc;
+    r.chunks = chunks; r.n_chunks = pl.n_chunks; r.n_total = n; r.tol = p->tolerance;
+    r.rows = out->rows; r.cap_rows = out->cap_rows; r.d_n_acc = &st->n_acc; r.d_n_rows = &st->n_rows;
+    r.d_n_rows_needed = &st->rows_needed; r.write_last_row = 1;
+    r.local_pass = 0; r.aux = (ResolveAux *)(ctx->d_tickets + 4); r.summary_out = nullptr; r.chunk_first = 0; r.n_local = pl.n_chunks; r.d_ts_carry = nullptr;
+    EmitArgs e;
+    e.sc = rsc;
+    e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
+    e.rows = out->rows; e.cap_rows = out->cap_rows; e.d_ts_carry = nullptr; e.is_ask = 0; e.sps = p->samples_per_symbol;
+    TileTailMem tm;
+    URH_TRY(tile_tail_mem(ctx, pl.n_chunks, true, &tm));
+    const int64_t cap = std::max<int64_t>(out->cap_rows, 1);
+    void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
+    if (!scratch) return URHGPU_ERR_ARG;
+    BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts, out->h_counts};
+    BitsParams bp = bits_params(p);
+    ScanState ss;
+    URH_TRY(scan_state(ctx, tile_desc_cap(cap, pl.n_chunks), &ss));
+    SegPackDst dst{host_blob, cap_host, progress, ctx->tune_pack_blocks};
+    for (int k = 0; k < S; ++k) {
+        TailSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], progress, target[k], st};
+        URH_TRY(launch_tile_segment(r, e, tm, bp, bo, scratch, ss, out->rows, out->cap_rows, sg, &dst, ts));
+    }
+    URH_HIP(hipGetLastError());
+    if (!host_blob) {                                          // nobody zeroes the counters then
+        URH_HIP(hipMemsetAsync(progress, 0, kMaxSegments * 4, ts));
+    }
+    ctx->seg_dirty[slot] = false;
+    if (ev_ready) URH_HIP(hipEventRecord(ev_ready, ts));
+    // the pass is over when the hot kernel has retired too (its last qad stores): cheap here, the last gate has just seen its last chunk
+    URH_HIP(hipStreamWaitEvent(ts, hot_done, 0));
+    if (s != ctx->stream && ctx->stream != nullptr) URH_HIP(hipStreamWaitEvent(ctx->stream, hot_done, 0));   // input reuse in stream order
+    URH_TRY(end_pipelined_pass(ctx));
+    *streamed = true;
+    return URHGPU_OK;
+}
+
+}  // namespace urh
+
 extern "C" {
 
 int urhgpu_version(void) { return URHGPU_VERSION; }
@@ -446,6 +599,7 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
+    if (ctx->d_seg) { (void)hipFree(ctx->d_seg); for (hipEvent_t e : ctx->ev_hot_done) if (e) (void)hipEventDestroy(e); }
     if (ctx->ev_hot) { (void)hipEventDestroy(ctx->ev_hot); (void)hipEventDestroy(ctx->ev_tail[0]); (void)hipEventDestroy(ctx->ev_tail[1]); (void)hipEventDestroy(ctx->ev_tail[2]); }
     delete (ShardSession *)ctx->shard;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
@@ -565,6 +719,9 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "profile_bracket")) ctx->prof_bracket = value != 0;
     else if (!strcmp(key, "tail_masked")) ctx->tune_tail_masked = value != 0;
     else if (!strcmp(key, "hot_cus_removed_per_xcd")) { if (value < 0 || value > 16) return URHGPU_ERR_ARG; ctx->tune_hot_cus_removed = value; }
+    else if (!strcmp(key, "stream_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_segments = value; }
+    else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 1) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
+    else if (!strcmp(key, "pack_blocks")) { if (value < 0 || value > 4096) return URHGPU_ERR_ARG; ctx->tune_pack_blocks = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;
 }
@@ -861,6 +1018,7 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
         // so the halo of pass i + 1 queues behind the last exchange of pass i's tail).
         if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot, s)); hot_done = ctx->ev_hot; }
         URH_HIP(hipStreamWaitEvent(ctx->tail_stream, hot_done, 0));
+        if (s != ctx->stream && ctx->stream != nullptr) URH_HIP(hipStreamWaitEvent(ctx->stream, hot_done, 0));   // (see digitize)
     }
     URH_HIP(hipGetLastError());
     return URHGPU_OK;

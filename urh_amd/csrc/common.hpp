@@ -107,7 +107,23 @@ struct urhgpu_ctx {
     int flip = 0;
     bool tail_pending = false;
     int tile_parity = 0;           // which of the two huge-row counters (d_tickets[8..9]) the current pass appends to
+    // streamed passes (urhgpu_stream_*; capi.hip: iq_to_bits_streamed): per scratch arena 16 progress counters + one SegState
+    void *d_seg = nullptr;         // 3 x kSegBlockBytes, zero between passes
+    bool seg_dirty[3] = {false, false, false};   // a pass failed between its hot launch and its last segment: counters not trusted
+    int tune_stream_segments = 8;  // segments of a streamed pass's tail (1: no streaming), urhgpu_ctx_set_tuning("stream_segments")
+    int tune_stream_shape = 0;     // 0: equal segments; 1: halving (1/2, 1/4, ... of the capture, the last two equal)
+    int tune_pack_blocks = 0;      // workgroups of a segment's pack kernel (0: default)
+    hipEvent_t ev_hot_done[3] = {nullptr, nullptr, nullptr};   // behind the hot kernel of the pass in arena slot k (streamed passes)
 };
+constexpr size_t kSegBlockBytes = 512;
+
+namespace urh {
+// A pass whose tail runs in segments beside the hot kernel, every segment storing its share of the compact blob into pinned host memory
+// (pulse_table.hip "Segments").  *streamed = false: the arguments do not qualify (nothing was launched; take the ordinary path).
+// ev_ready (may be nullptr) is recorded on the tail stream behind the last segment's pack kernel: the host blob is complete.
+int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, const urhgpu_outputs *out, void *host_blob,
+                        int64_t cap_host, hipEvent_t ev_ready, bool *streamed);
+}
 
 namespace urh {
 int join_tail(urhgpu_ctx *ctx);    // capi.hip: the caller's stream waits for the tail of the last pipelined pass

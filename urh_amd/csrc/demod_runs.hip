@@ -1244,12 +1244,18 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
     }
     const int incl = wave_incl_scan(cnt, lane);
     const int total = __builtin_amdgcn_readlane(incl, 63);
+    // streamed pass (RunArgs::progress): the records go THROUGH to memory (agent-scope stores: no dirty line stays in this XCD's L2), so
+    // that an acknowledged store is visible to the tail kernels of this chunk's segment, which start while this kernel is still running
+    const bool through = (p.progress != nullptr);
     {
         int o = incl - cnt;
         const int64_t base = p.pos_base + a0 + (int64_t)lane * kRowSamples;
         while (ae | ao) {
             const int pos = bp_first(ae, ao);
-            slab[o++] = rec_make(base + pos, state_at(pos));
+            const uint64_t rec = rec_make(base + pos, state_at(pos));
+            if (through) __hip_atomic_store(slab + o, rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else slab[o] = rec;
+            ++o;
             if (pos & 1) ao &= ao - 1; else ae &= ae - 1;
         }
     }
@@ -1275,7 +1281,26 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
         ci.last_pos = last_pos;
         ci.init_state = (uint16_t)chunk_init_state<SRC, DT, MOD, NPL == 1>(p, chunk);
         ci.first_acc = 0; ci.pend_acc = 0; ci.pend_stable = 0; ci.pad = 0;
-        p.chunks[chunk] = ci;
+        if (through) {
+            static_assert(sizeof(ChunkInfo) % 8 == 0, "ChunkInfo is written as 64-bit words");
+            uint64_t w[sizeof(ChunkInfo) / 8];
+            __builtin_memcpy(w, &ci, sizeof(ChunkInfo));
+            uint64_t *dst = (uint64_t *)(p.chunks + chunk);
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(ChunkInfo) / 8); ++k) __hip_atomic_store(dst + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            p.chunks[chunk] = ci;
+        }
+    }
+    if (through) {
+        // every lane's write-through stores acknowledged (gfx9: vmcnt counts stores too), THEN the chunk counts itself into its segment:
+        // what the LLVM memory model does for a release at agent scope, minus the L2 write-back that ordinary (cached) stores would need
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            int k = 0;
+            while (k < p.n_seg - 1 && chunk >= (int64_t)p.seg_end[k]) ++k;
+            __hip_atomic_fetch_add(p.progress + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1359,7 +1384,9 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
     const int part = a.launch_part;
     const int64_t n_full = (a.n / kTile) * kTile;
     const int64_t n_main = (n_full + a.chunk_len - 1) / a.chunk_len;
-    const int64_t c_lo = (part == 1) ? 1 : 0, c_hi = (part == 2) ? std::min<int64_t>(n_main, 1) : n_main;
+    int64_t c_lo = (part == 1) ? 1 : 0, c_hi = (part == 2) ? std::min<int64_t>(n_main, 1) : n_main;
+    const bool ranged = a.launch_hi > 0;                      // an explicit chunk range (streamed passes that upload piece by piece)
+    if (ranged) { c_lo = std::min<int64_t>(a.launch_lo, n_main); c_hi = std::min<int64_t>(a.launch_hi, n_main); }
     if (c_hi > c_lo) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
         // orders 2 and 4: the bit-plane kernel; anything else: the state-byte kernel
@@ -1376,7 +1403,8 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
             hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock), 0, s, a);
     }
     const bool tail_is_first = (n_main == 0);                 // a capture shorter than one tile: its only chunk
-    if (n_full < a.n && ((part == 0) || (part == 1 && !tail_is_first) || (part == 2 && tail_is_first))) {
+    if (ranged ? (n_full < a.n && a.launch_lo <= n_main && a.launch_hi > n_main)
+               : (n_full < a.n && ((part == 0) || (part == 1 && !tail_is_first) || (part == 2 && tail_is_first)))) {
         a.range_begin = n_full; a.range_end = a.n; a.chunk_base = n_main;
         hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, false>), dim3(1), dim3(kBlock), 0, s, a);
     }
@@ -1414,6 +1442,13 @@ int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, h
         case URHGPU_DT_U16: return launch_runs_2<URHGPU_DT_U16>(a, mod, write_qad, s);
         default: return URHGPU_ERR_DTYPE;
     }
+}
+
+// Can a pass with these arguments be streamed (RunArgs::progress)?  Only the bit-plane kernel counts its chunks: orders 2 and 4,
+// tolerance within its range, whole tiles only (the partial tile at the end of a capture goes through the state-byte kernel).
+bool runs_streamable(const RunArgs &a) {
+    return URH_BITPLANE && (a.order == 2 || a.order == 4) && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples &&
+           !g_force_state_bytes && a.n >= kTile && a.n % kTile == 0;
 }
 
 // Run segmentation over an already demodulated float32 signal (grab_pulse_lens proper).

@@ -35,6 +35,16 @@ struct RunArgs {
     float dm_noise_sqrd, dm_max_magnitude, dm_noise_val;
     int lds_pad;             // extra dynamic LDS bytes per workgroup of k_demod_runs_bp: caps its workgroups per CU so that
                              // wave slots stay free for the tail of the previous pass (pipelined mode)
+    // Streamed passes (segmented tail, pulse_table.hip "segments"): the tail of the first chunks runs while the hot kernel is still
+    // working on the later ones.  progress != nullptr: the bit-plane kernel writes every chunk's records THROUGH to memory (agent-scope
+    // stores), waits for their acknowledgement and then counts the chunk into progress[k], k = the first segment with chunk <
+    // seg_end[k]; a gate kernel on the tail stream (k_seg_gate) lets segment k's tail start when its counter is complete.
+    uint32_t *progress;
+    int32_t n_seg;
+    int32_t seg_end[kMaxSegments];
+    // chunks [launch_lo, launch_hi) only (launch_hi == 0: governed by launch_part); the partial tile at the end of the capture counts as
+    // chunk n_main
+    int64_t launch_lo, launch_hi;
     float thr[kMaxOrder - 1];
 };
 extern bool g_force_state_bytes;
@@ -44,6 +54,7 @@ struct HotEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false
 extern thread_local HotEvents g_hot_events;   // test hook: order 2 through the state-byte kernel too
 int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s);
 int launch_runs_qad(const RunArgs &a, hipStream_t s);
+bool runs_streamable(const RunArgs &a);       // RunArgs::progress is honoured for these arguments (bit-plane kernel, whole tiles)
 int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t s);
 void launch_test_div(uint64_t seed, int reps, unsigned long long *d_mismatches, hipStream_t s);
 void launch_test_sincosf_fast(unsigned long long *d_mismatches, hipStream_t s);
@@ -205,6 +216,43 @@ int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t ca
                         void *scratch, int64_t *d_flags, const ScanState &ss, hipStream_t s);
 int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
                        const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
+// ---- streamed passes: the tile tail in SEGMENTS (pulse_table.hip "segments") --------------------------------------------------
+// Device-resident state that carries a pass from one segment of its tail to the next (one block per scratch arena, zeroed by the
+// first segment's gate).  `in[k & 1]` is what segment k starts from, written by segment k - 1's group scan (its Final functor).
+struct SegState {
+    int64_t n_rows;          // pulse-table rows that are final after the current segment, clamped to cap_rows: d_n_rows of its kernels
+    int64_t rows_needed;     // the same, unclamped (the table's size before clamping once the last segment has run)
+    int64_t n_acc;           // accepted runs so far
+    int64_t n_groups;        // groups so far, the open (trailing) one included: d_n_groups
+    int64_t n_groups_local;  // groups the current segment's group scan covers: [in.g0, n_groups)
+    int64_t end_bits, end_pos, end_msgs;   // bits / positions written and messages closed after the current segment
+    int64_t err;             // != 0: a gate gave up waiting for the hot kernel (the pass's results are void)
+    int64_t pad[7];
+    struct In {
+        int64_t g0;          // the group that was open at the end of the segment before: this segment's group scan starts with it
+        int64_t carry[3];    // exclusive prefix at g0: messages closed, kept bits, kept positions before it
+        int64_t ship_rows, ship_bits, ship_pos, ship_msgs;   // what the host already holds: the segment's pack kernel starts there
+    } in[2];
+};
+static_assert(sizeof(SegState) == 256, "SegState");
+// one segment of a streamed pass: tiles / chunks [c0, c1) of the capture's n_chunks (c0 a multiple of kSegAlign; c1 too, or n_chunks)
+constexpr int64_t kSegAlign = 256;   // resolve workgroups, tile-scan workgroups and the wavefronts' chunk quadruples all start on it
+struct TailSegment {
+    int index;               // k
+    int final;               // the capture's last segment: totals, last row, trailing group closed by the end of the capture
+    int64_t c0, c1;
+    const uint32_t *progress;   // nullptr: no gate (the hot kernel is known to have finished)
+    uint32_t target;            // chunks that count into progress[index]
+    SegState *state;
+};
+struct SegPackDst {          // where a segment's share of the compact blob goes: pinned HOST memory (device-accessible), see k_pack_seg
+    void *host;              // nullptr: nothing is shipped
+    int64_t cap_host;        // >= blob_capacity of the pass's capacities
+    uint32_t *progress_reset;   // the counters the last segment zeroes (nullptr: none)
+    int blocks;              // workgroups of the pack kernel (0: default)
+};
+size_t seg_state_bytes();
+
 // Tile tail (single GPU, not ASK): resolve + rows in two launches, bits in three more; see pulse_table.hip.
 struct TileTailMem {
     void *mem;               // tile_tail_bytes(n_chunks) of scratch that lives from launch_tile_rows to launch_tile_bits
@@ -227,6 +275,9 @@ int launch_tile_bits_prepare(const TileTailMem &m, const int64_t *rows, const in
                              void *scratch, int64_t *d_flags, const ScanState &ss, hipStream_t s);
 int launch_tile_bits_finish(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
                             const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
+// one segment of a streamed pass (see "Segments" in pulse_table.hip)
+int launch_tile_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams &bp, const BitsOut &o, void *scratch,
+                        const ScanState &ss, int64_t *rows, int64_t cap_rows, const TailSegment &sg, const SegPackDst *dst, hipStream_t s);
 // ASK, sharded: summary of the locally merged table {n_rows, first state, first length, last state, last length}
 void launch_merge_summary(const int64_t *rows, const int64_t *d_n_rows, int64_t *d_out5, hipStream_t s);
 // ASK, sharded: merge equal-state rows across shard boundaries (d_all: world x 5 int64)

@@ -7,7 +7,10 @@
 // element counts passed through device memory so that nothing synchronises with the host.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.hpp"
+#include "compact.hpp"
 #include "launchers.hpp"
 #include "runs.hpp"
 #include "scan.hpp"
@@ -464,9 +467,12 @@ struct GroupLoad {
     const int32_t *d_extra;
     int is_last_rank;
     int write_pos;
+    int tentative_open = 0;  // a segment of a streamed pass before the last one: the group that is still open counts as kept -- whether
+                             // it holds data is only known when it closes; its rows are expanded where its bits WOULD go (see SegFinal)
     __device__ bool kept(int64_t g, const GroupInfo &gi) const {
         const int64_t d0 = g ? groups[g - 1].data_end : 0;
         if (gi.data_end - d0 > 0) return true;
+        if (tentative_open && !gi.closed) return true;
         if (!d_extra) return false;
         return (g == 0 && d_extra[0]) || (!gi.closed && d_extra[1]);
     }
@@ -763,14 +769,18 @@ struct TileTail {            // scratch of the tile tail (carved from the contex
 // The kernels below are latency chains of a few memory round trips on a nearly idle chip, not bandwidth: every load whose
 // address does not depend on loaded data is issued BEFORE the first use of any of them (measured: the same kernels written in
 // natural order spent 9 us per wavefront in 5 serialised round trips).
-__global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs a, const TileTail ft) {
+// blk0: first resolve workgroup of this launch -- 0 for a whole capture; a SEGMENT of a streamed pass (see "segments" below) covers the
+// workgroups [blk0, blk0 + gridDim.x), its look-ahead into the chunk behind the segment's last one reads a record the hot kernel has
+// already finished (the segment's gate waits for that chunk too)
+__global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs a, const TileTail ft, const int64_t blk0) {
     URH_TAIL_PRIO();
     __shared__ ResElem s_w[kResolveBlock / 64];
-    const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
+    const int64_t blk = blk0 + blockIdx.x;
+    const int64_t c = blk * kResolveBlock + threadIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // this pass's huge-row counter starts at zero whatever an earlier pass of the same parity left behind (one that failed between
-    // its row and its expansion launches never reached the kernel that clears the counter for its successor)
-    if (c == 0 && ft.want_bits) ft.huge_count[ft.parity] = 0;
+    // this pass's (segment's) huge-row counter starts at zero whatever an earlier pass of the same parity left behind (one that failed
+    // between its row and its expansion launches never reached the kernel that clears the counter for its successor)
+    if (blockIdx.x == 0 && t == 0 && ft.want_bits) ft.huge_count[ft.parity] = 0;
     ResElem e = res_identity();
     if (c < a.n_chunks) {
         ChunkInfo *ch = a.chunks + c;
@@ -807,7 +817,7 @@ __global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs
     if (lane == 0) ex = res_identity();
     ex = res_combine(base, ex);
     if (c < a.n_chunks) ft.ploc[c] = ex;                  // exclusive prefix inside this workgroup
-    if (t == 0) ft.btot[blockIdx.x] = tot;                // consumers compose the totals of the workgroups before theirs
+    if (t == 0) ft.btot[blk] = tot;                       // consumers compose the totals of the workgroups before theirs
 }
 
 // composition of btot[0 .. count) by one wavefront, in order (every lane gets it); `first` = btot[lane] already loaded
@@ -887,6 +897,12 @@ struct EmitTileArgs {
     BitsParams bp;
     HugeRef *huge;
     int32_t huge_cap;
+    // Wavefronts [w0, w_end) own chunks, wavefront w_end writes the totals.  A whole capture: w0 = 0, w_end = tail_waves(n_chunks),
+    // final_seg = 1.  A segment of a streamed pass covers the chunks [w0, w_end) * kTailCPW; before the last one (final_seg = 0) the
+    // totals wavefront only notes how many rows are final now (seg->n_rows: what the segment's later kernels take as the row count).
+    int64_t w0, w_end;
+    int final_seg;
+    SegState *seg;
 };
 
 __host__ __device__ static inline int64_t tail_waves(int64_t n_items) { return (n_items + kTailCPW - 1) / kTailCPW; }
@@ -901,17 +917,17 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
     const EmitArgs &a = g.e;
     const ResolveArgs &r = g.r;
     const int lane = threadIdx.x & 63;
-    const int64_t w = (int64_t)blockIdx.x * kEmitWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t n_cw = tail_waves(r.n_chunks);          // wavefronts that own chunks; wavefront n_cw: totals, last row, last tile
+    const int64_t w = g.w0 + (int64_t)blockIdx.x * kEmitWaves + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t n_cw = g.w_end;                         // wavefronts below it own chunks; wavefront n_cw: totals, last row, last tile
     if (w > n_cw) return;
     const bool totals = (w == n_cw);
     const bool table = (r.n_local != r.n_chunks);         // sharded: entries outside [lc0, lc1) are the other shards' summaries
     const int64_t lc0 = a.chunk_first, lc1 = a.chunk_first + r.n_local;
-    const int64_t c0 = totals ? r.n_chunks : w * kTailCPW;
+    const int64_t c0 = totals ? (g.final_seg ? r.n_chunks : n_cw * kTailCPW) : w * kTailCPW;
     // ---- one round trip: everything this wavefront reads that does not depend on loaded data ----
     // resolve workgroups composed on the left: the same for every chunk of this wavefront (kResolveBlock % kTailCPW == 0); the totals
     // wavefront takes them all
-    const int64_t n_before = totals ? resolve_blocks(r.n_chunks) : c0 / kResolveBlock;
+    const int64_t n_before = (totals && g.final_seg) ? resolve_blocks(r.n_chunks) : c0 / kResolveBlock;
     const uint32_t init_state = a.chunks[0].init_state;
     ResElem first = res_identity();
     if (lane < n_before) first = g.ft.btot[lane];
@@ -937,6 +953,15 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
     if (totals) {
         // totals, the table's last row (signal_functions.pyx:485-493; skipped when the table already has n rows, :487), last tile
         const ResElem pre = base;
+        if (!g.final_seg) {
+            // a segment of a streamed pass that is not the last: every accepted run of the chunks so far has its row (a row ends where
+            // the next accepted run begins), so rows [0, pre.cnt) are final
+            if (lane == 0) {
+                g.seg->n_acc = pre.cnt; g.seg->rows_needed = pre.cnt;
+                g.seg->n_rows = (r.rows != nullptr && pre.cnt > r.cap_rows) ? r.cap_rows : pre.cnt;
+            }
+            return;
+        }
         const int64_t c = r.n_chunks;
         int64_t row_end = pre.cnt;                         // this GPU's rows are global rows [row_base, row_end) (+ the last row on the last GPU)
         if (table && lc1 < r.n_chunks) row_end = res_before_entry(g.ft, init, lc1, r.n_chunks, lane).cnt;
@@ -1068,6 +1093,12 @@ struct TileScanArgs {
     BitsParams bp;
     GranDesc *desc;
     unsigned long long epoch;
+    // a segment of a streamed pass: workgroups [b0, b0 + gridDim.x) -- the look-back reaches into the descriptors the earlier segments'
+    // launches published under the same epoch --, n_tiles = the segment's end, *d_n_rows = the rows that are final so far (the
+    // "trailing group" the walk records is then the group that is still open: what the segment's group scan starts the next one from)
+    int64_t b0;
+    SegState *seg;
+    int seg_parity;          // segment index & 1
 };
 __global__ __launch_bounds__(kScanBlock) URH_TAIL_OCC void k_tile_scan(const TileScanArgs a) {
     URH_TAIL_PRIO();
@@ -1076,7 +1107,7 @@ __global__ __launch_bounds__(kScanBlock) URH_TAIL_OCC void k_tile_scan(const Til
     __shared__ VecK<4> s_ex[kScanBlock];                 // listed tiles: prefix, first row, end
     __shared__ int64_t s_off[kScanBlock], s_end[kScanBlock];
     __shared__ int s_count;
-    const int64_t b = blockIdx.x, nb = gridDim.x;
+    const int64_t b = a.b0 + blockIdx.x, nb = a.b0 + gridDim.x;
     const int64_t t = b * kScanBlock + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // one round trip
@@ -1106,6 +1137,10 @@ __global__ __launch_bounds__(kScanBlock) URH_TAIL_OCC void k_tile_scan(const Til
                 int64_t g = (n > 0) ? incl.v[1] + 1 : 0;
                 if (g > a.cap_groups) g = a.cap_groups;
                 *a.d_n_groups = g;
+                if (a.seg) {                              // the segment's group scan covers the groups from the one that was open before it
+                    const int64_t g0 = a.seg->in[a.seg_parity].g0;
+                    a.seg->n_groups_local = (g > g0) ? g - g0 : 0;
+                }
             }
         }
     }
@@ -1173,6 +1208,7 @@ struct ExpandTileArgs {
     int32_t huge_cap;
     int parity;
     int64_t n_tiles;
+    int64_t t_base;          // first tile of this launch (0; a segment of a streamed pass: its first chunk)
 };
 constexpr unsigned kHugeBlocksX = 16, kHugeBlocksY = 16;
 
@@ -1184,7 +1220,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
     URH_TAIL_PRIO();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int bps = (int)a.bp.bps;
-    const int64_t tile_blocks = expand_tile_blocks(a.n_tiles);
+    const int64_t tile_blocks = expand_tile_blocks(a.n_tiles - a.t_base);
     if ((int64_t)blockIdx.x >= tile_blocks) {
         // ---- huge rows ----
         const int64_t n = *a.d_n_rows;
@@ -1233,7 +1269,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
         }
         return;
     }
-    const int64_t t0 = ((int64_t)blockIdx.x * kEmitWaves + wave) * kTailCPW;
+    const int64_t t0 = a.t_base + ((int64_t)blockIdx.x * kEmitWaves + wave) * kTailCPW;
     if (t0 >= a.n_tiles) return;
     const int n_mine = (int)((a.n_tiles - t0 < kTailCPW) ? a.n_tiles - t0 : kTailCPW);
     // ---- round trip 1: everything that does not depend on loaded data; lane j holds the metadata of tile t0 + j ----
@@ -1557,7 +1593,8 @@ int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem 
     memset(&g.bp, 0, sizeof(g.bp));
     if (bp) { g.bp = *bp; g.ft.want_bits = 1; }
     const unsigned gb = (unsigned)resolve_blocks(r.n_chunks);
-    hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft);
+    g.w0 = 0; g.w_end = tail_waves(r.n_chunks); g.final_seg = 1; g.seg = nullptr;
+    hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft, (int64_t)0);
     hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((tail_waves(r.n_chunks) + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
     return URHGPU_OK;
 }
@@ -1585,7 +1622,7 @@ int launch_tile_bits_prepare(const TileTailMem &m, const int64_t *rows, const in
     const int64_t cap_groups = cap_rows + 1;
     GranDesc *tdesc = (GranDesc *)m.rdesc + resolve_blocks(m.n_chunks) + 2;
     TileScanArgs ta{rows, d_n_rows, tc.ft.agg, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, b.d_n_groups, nt, bp, tdesc,
-                    m.epoch};
+                    m.epoch, 0, nullptr, 0};
     const unsigned nb_ts = (unsigned)((nt + kScanBlock - 1) / kScanBlock);
     hipLaunchKernelGGL(k_tile_scan, dim3(nb_ts), dim3(kScanBlock), 0, s, ta);
     if (d_flags) hipLaunchKernelGGL(k_tile_flags, dim3(1), dim3(1), 0, s, d_n_rows, b.groups, b.d_n_groups, d_flags);
@@ -1607,7 +1644,7 @@ int launch_tile_bits_finish(const TileTailMem &m, const int64_t *rows, const int
     hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, b.d_n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
-                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt};
+                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt, 0};
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(nt);
     hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     return URHGPU_OK;
@@ -1617,6 +1654,231 @@ int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d
                      const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s) {
     URH_TRY(launch_tile_bits_prepare(m, rows, d_n_rows, cap_rows, bp, scratch, nullptr, ss, s));
     return launch_tile_bits_finish(m, rows, d_n_rows, cap_rows, bp, o, scratch, ss, s);
+}
+
+// =====================================================================================================
+// Segments: the tile tail of a STREAMED pass (urhgpu_stream_*).
+//
+// One capture on an otherwise idle GPU used to be hot kernel, then tail, then pack, then copy -- 0.45 ms for a 1 GiB capture whose
+// hot kernel takes 0.28 (SURVEY 8(d)'s window ends with the compact outputs on the host).  Everything behind the hot kernel is
+// CAUSAL: the state machine before a chunk, its row offset, the bits / pauses / samples before a tile and the messages before a group
+// are prefix compositions.  So the capture's chunks are cut into a few SEGMENTS (boundaries on kSegAlign chunks), and segment k's tail
+// -- the same five kernels over its range of chunks / tiles, then a pack kernel that stores the segment's share of the compact blob
+// straight into pinned host memory -- runs while the hot kernel is still working on the chunks behind it:
+//   * the hot kernel (ONE launch: kernel boundaries cost 10 us each) writes its records through to memory and counts every finished
+//     chunk into the counter of its segment (demod_runs.hip: RunArgs::progress); k_seg_gate, first on the tail stream, waits for it.
+//     A segment's counter also covers the FIRST chunk of the next segment: the resolve kernel looks one chunk ahead (does a trailing
+//     short run continue?);
+//   * resolve / rows: workgroup totals (btot) and per-tile aggregates of the earlier segments are in memory: the later segments'
+//     wavefronts fold / look back into them exactly as the later workgroups of a single launch do;
+//   * rows are final as soon as they are written; a GROUP (message candidate) may still be open at the end of a segment: its rows are
+//     expanded where its bits would go (GroupLoad::tentative_open), and the pack kernel of the next segment ships again from the
+//     start of a group that had no data row yet -- should it be dropped after all, the next kept group overwrites its bits (SegFinal);
+//   * per segment the host receives: its rows, the bytes of packed bits that are complete, the positions, and the messages closed.
+// Results are bit-identical to the one-launch tail (tests/test_stream_segments.py compares them on random captures and boundaries).
+// =====================================================================================================
+__global__ void k_seg_gate(const uint32_t *progress, int k, uint32_t target, SegState *seg, int init, long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    if (init) {
+        int64_t *w = (int64_t *)seg;
+        for (int i = 0; i < (int)(sizeof(SegState) / 8); ++i) w[i] = 0;
+    }
+    if (!progress) return;
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(progress + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((long long)wall_clock64() - t0 > max_ticks) { seg->err = 1 + k; break; }       // (the hot kernel was never launched: a bug, not a hang)
+    }
+}
+
+struct SegGroupLoad {
+    GroupLoad ld;
+    const SegState *seg;
+    int parity;
+    __device__ VecK<3> operator()(int64_t i) const { return ld(seg->in[parity].g0 + i); }
+};
+struct SegGroupStore {
+    GroupStore st;
+    const SegState *seg;
+    int parity;
+    __device__ void operator()(int64_t i, const VecK<3> &val, const VecK<3> &ex) const {
+        const int64_t g0 = seg->in[parity].g0;
+        VecK<3> e = ex;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) e.v[k] += seg->in[parity].carry[k];
+        st(g0 + i, val, e);
+    }
+};
+// after the segment's group scan: what the next segment starts from, what the pack kernel ships; the last segment: the pass's counts
+struct SegFinal {
+    SegGroupLoad ld;
+    SegState *seg;
+    int parity;
+    int final;
+    BitsCountsFinal counts;
+    __device__ void operator()(const VecK<3> &grand) const {
+        const SegState::In in = seg->in[parity];
+        const int64_t nl = seg->n_groups_local;
+        VecK<3> tot;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tot.v[k] = in.carry[k] + grand.v[k];
+        if (final) {
+            counts(tot);
+            const bool any = seg->n_rows > 0;
+            seg->end_msgs = any ? tot.v[0] : 0; seg->end_bits = any ? tot.v[1] : 0; seg->end_pos = any ? tot.v[2] : 0;
+            return;
+        }
+        SegState::In nx = in;
+        nx.ship_rows = seg->n_rows;
+        if (nl <= 0) {                                        // no row yet
+            seg->end_msgs = 0; seg->end_bits = 0; seg->end_pos = 0;
+        } else {
+            const int64_t g_open = in.g0 + nl - 1;
+            const VecK<3> vo = ld(nl - 1);
+            VecK<3> exo;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) exo.v[k] = tot.v[k] - vo.v[k];
+            const int64_t d0 = g_open ? ld.ld.groups[g_open - 1].data_end : 0;
+            const bool has_data = ld.ld.groups[g_open].data_end - d0 > 0;
+            nx.g0 = g_open;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) nx.carry[k] = exo.v[k];
+            seg->end_msgs = exo.v[0]; seg->end_bits = exo.v[1] + vo.v[1]; seg->end_pos = exo.v[2] + vo.v[2];
+            // an open group without a data row may still be dropped: the next segment ships from its start again
+            nx.ship_msgs = exo.v[0];
+            nx.ship_bits = has_data ? exo.v[1] + vo.v[1] : exo.v[1];
+            nx.ship_pos = has_data ? exo.v[2] + vo.v[2] : exo.v[2];
+        }
+        seg->in[parity ^ 1] = nx;
+    }
+};
+
+// The segment's share of the compact blob (include/urhgpu.h), stored straight into the pinned host blob: the sections sit at the
+// offsets the CAPACITIES give (blob_layout of the capacities), so every segment knows where its elements go and the host needs no
+// assembly; the last segment writes the header.
+struct SegPack {
+    const int64_t *rows; const uint8_t *bits; const int64_t *msg_off, *pauses, *pos_off, *pos; const int64_t *counts;
+    int64_t cap_rows, cap_bits, cap_msg, cap_pos;
+    int has_pos;
+    char *host;
+    BlobLayout L;            // blob_layout(capacities)
+    SegState *seg;
+    int parity, final;
+    uint32_t *progress;      // the last segment zeroes the pass's counters for the next pass on this arena
+};
+__global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
+    URH_TAIL_PRIO();
+    const int64_t gtid = blockIdx.x * 256ll + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    const SegState::In in = a.seg->in[a.parity];
+    auto lim = [](int64_t x, int64_t cap) { return x < cap ? (x < 0 ? 0 : x) : cap; };
+    const int64_t r0 = lim(in.ship_rows, a.cap_rows), r1 = lim(a.seg->n_rows, a.cap_rows);
+    const int64_t nbits = lim(a.seg->end_bits, a.cap_bits);
+    const int64_t j0 = lim(in.ship_bits, a.cap_bits) / 8, j1 = a.final ? (nbits + 7) / 8 : nbits / 8;
+    const int64_t p0 = a.has_pos ? lim(in.ship_pos, a.cap_pos) : 0, p1 = a.has_pos ? lim(a.seg->end_pos, a.cap_pos) : 0;
+    const int64_t m0 = lim(in.ship_msgs, a.cap_msg), m1 = lim(a.seg->end_msgs, a.cap_msg);
+    {
+        int32_t *len = (int32_t *)(a.host + a.L.off_row_len);
+        int8_t *st = (int8_t *)(a.host + a.L.off_row_state);
+        for (int64_t i = r0 + gtid; i < r1; i += stride) {
+            const longlong2 r = *(const longlong2 *)(a.rows + 2 * i);
+            st[i] = (int8_t)r.x; len[i] = (int32_t)r.y;
+        }
+    }
+    {
+        uint8_t *out = (uint8_t *)(a.host + a.L.off_bits);
+        const unsigned long long *in8 = (const unsigned long long *)a.bits;
+        for (int64_t j = j0 + gtid; j < j1; j += stride) {
+            unsigned long long w;
+            if (8 * j + 8 <= nbits) w = in8[j];
+            else { w = 0; for (int k = 0; k < 8 && 8 * j + k < nbits; ++k) w |= (unsigned long long)a.bits[8 * j + k] << (8 * k); }
+            out[j] = (uint8_t)(((w & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
+        }
+    }
+    if (a.has_pos) {
+        uint32_t *p32 = (uint32_t *)(a.host + a.L.off_pos32);
+        for (int64_t i = p0 + gtid; i < p1; i += stride) p32[i] = (uint32_t)a.pos[i];
+    }
+    {
+        int64_t *pa = (int64_t *)(a.host + a.L.off_pauses), *mo = (int64_t *)(a.host + a.L.off_msg_off), *po = (int64_t *)(a.host + a.L.off_pos_off);
+        if (gtid == 0 && m0 == 0) { mo[0] = 0; po[0] = 0; }
+        for (int64_t i = m0 + gtid; i < m1; i += stride) { pa[i] = a.pauses[i]; mo[i + 1] = a.msg_off[i + 1]; po[i + 1] = a.pos_off[i + 1]; }
+    }
+    if (gtid == 0) {
+        const int64_t shipped = (r1 - r0) * 5 + (j1 - j0) + (p1 - p0) * 4 + (m1 - m0) * 24;
+        a.seg->pad[0] += shipped;
+        if (a.final) {
+            int64_t *hdr = (int64_t *)a.host;
+            const int64_t *c = a.counts;
+            hdr[1] = r1; hdr[2] = m1; hdr[3] = nbits; hdr[4] = p1; hdr[5] = c[4];
+            hdr[6] = a.seg->pad[0] + URHGPU_BLOB_HEADER_BYTES; hdr[7] = a.has_pos;
+            hdr[8] = a.L.off_pauses; hdr[9] = a.L.off_msg_off; hdr[10] = a.L.off_pos_off; hdr[11] = a.L.off_row_state; hdr[12] = a.L.off_bits;
+            hdr[13] = a.L.off_row_len; hdr[14] = a.L.off_pos32;
+            hdr[15] = ((c[1] > a.cap_msg || c[2] > a.cap_bits || (a.has_pos && c[3] > a.cap_pos) || c[4] > a.cap_rows) ? 1 : 0) | (a.seg->err ? 2 : 0);
+            hdr[0] = URHGPU_BLOB_MAGIC;
+        }
+    }
+    if (a.final && a.progress && gtid < kMaxSegments) a.progress[gtid] = 0;
+}
+
+size_t seg_state_bytes() { return sizeof(SegState); }
+
+// One segment's kernels on stream s: gate, resolve, rows, tile scan, group scan, expansion, pack.  r / e / m / bp / o / scratch / ss as
+// launch_tile_rows + launch_tile_bits take them for the WHOLE capture (r.n_chunks, m.n_chunks: all chunks), with r.d_n_rows,
+// r.d_n_rows_needed and r.d_n_acc pointing into *sg.state; m.epoch and m.parity the same for every segment of the pass.
+int launch_tile_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams &bp, const BitsOut &o, void *scratch,
+                        const ScanState &ss, int64_t *rows, int64_t cap_rows, const TailSegment &sg, const SegPackDst *dst, hipStream_t s) {
+    if (r.n_chunks <= 0 || r.local_pass || r.chunk_first != 0 || e.chunk_first != 0 || r.n_local != r.n_chunks || m.n_chunks != r.n_chunks ||
+        e.is_ask || m.d_row_base != nullptr || !sg.state)
+        return URHGPU_ERR_ARG;
+    if (sg.c0 < 0 || sg.c0 % kSegAlign || sg.c1 <= sg.c0 || sg.c1 > r.n_chunks || (sg.final ? sg.c1 != r.n_chunks : (sg.c1 % kSegAlign != 0 || sg.c1 >= r.n_chunks)))
+        return URHGPU_ERR_ARG;
+    static_assert(kSegAlign % kResolveBlock == 0 && kSegAlign % kScanBlock == 0 && kSegAlign % (kTailCPW * kEmitWaves) == 0, "segment alignment");
+    if (r.d_n_rows != &sg.state->n_rows || r.d_n_rows_needed != &sg.state->rows_needed) return URHGPU_ERR_ARG;
+    if (cap_rows <= 0) cap_rows = 1;
+    const int64_t cap_desc = tile_desc_cap(cap_rows, m.n_chunks);
+    if (ss.desc_bytes < bits_desc_bytes(cap_desc)) return URHGPU_ERR_ARG;
+    const TileCarve tc = carve_tile(m);
+    const BitsScratch b = carve_bits(scratch, cap_rows);
+    SegState *st = sg.state;
+    const int parity = sg.index & 1;
+    hipLaunchKernelGGL(k_seg_gate, dim3(1), dim3(64), 0, s, sg.progress, sg.index, sg.target, st, sg.index == 0 ? 1 : 0, (long long)200000000);   // 2 s at 100 MHz
+    // resolve + rows
+    EmitTileArgs g;
+    g.e = e; g.r = r; g.ft = tc.ft; g.huge = tc.huge; g.huge_cap = kTileHugeCap;
+    g.bp = bp; g.ft.want_bits = 1;
+    g.w0 = sg.c0 / kTailCPW; g.w_end = sg.final ? tail_waves(r.n_chunks) : sg.c1 / kTailCPW; g.final_seg = sg.final; g.seg = st;
+    hipLaunchKernelGGL(k_resolve_one, dim3((unsigned)resolve_blocks(sg.c1 - sg.c0)), dim3(kResolveBlock), 0, s, r, g.ft, sg.c0 / kResolveBlock);
+    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((g.w_end - g.w0 + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
+    // tile scan over the segment's tiles (the last segment: + the tile of the table's last row)
+    const int64_t t1 = sg.final ? r.n_chunks + 1 : sg.c1;
+    const int64_t cap_groups = cap_rows + 1;
+    GranDesc *tdesc = (GranDesc *)m.rdesc + resolve_blocks(m.n_chunks) + 2;
+    TileScanArgs ta{rows, &st->n_rows, tc.ft.agg, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, &st->n_groups, t1, bp, tdesc,
+                    m.epoch, sg.c0 / kScanBlock, st, parity};
+    hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((t1 - sg.c0 + kScanBlock - 1) / kScanBlock)), dim3(kScanBlock), 0, s, ta);
+    // groups [the one that was open before this segment, the one that is open now]
+    ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(scan_blocks(cap_desc) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
+    GroupLoad gl{b.groups, &st->n_groups, nullptr, sg.final ? 1 : 0, bp.write_pos, sg.final ? 0 : 1};
+    GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
+    SegGroupLoad sl{gl, st, parity};
+    SegGroupStore sst{gs, st, parity};
+    SegFinal fin{sl, st, parity, sg.final ? 1 : 0, BitsCountsFinal{&st->n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, &st->rows_needed, o.h_counts}};
+    hipLaunchKernelGGL((k_scan_lookback<3, SegGroupLoad, SegGroupStore, SegFinal, kGroupItems>), dim3((unsigned)std::min<int64_t>(scan_grid(b.nbg), 32)),
+                       dim3(kScanBlock), 0, s, &st->n_groups_local, sl, desc3, b.nbg, sst, fin, ++*ss.epoch, ss.tickets + 2, 0);
+    ExpandTileArgs ea{rows, &st->n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, &st->n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
+                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, t1, sg.c0};
+    const unsigned tile_blocks = (unsigned)expand_tile_blocks(t1 - sg.c0);
+    hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
+    if (dst && dst->host) {
+        if (((uintptr_t)o.bits & 7) || ((uintptr_t)rows & 15) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
+        const int has_pos = (bp.write_pos && o.pos) ? 1 : 0;
+        const int64_t caps[5] = {cap_rows, o.cap_msg, o.cap_bits, o.cap_pos, cap_rows};
+        SegPack pk{rows, o.bits, o.msg_off, o.pauses, o.pos_off, o.pos, o.counts, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos, (char *)dst->host,
+                   blob_layout(caps, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos), st, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr};
+        if (dst->cap_host < pk.L.total) return URHGPU_ERR_CAPACITY;
+        hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 64), dim3(256), 0, s, pk);
+    }
+    return URHGPU_OK;
 }
 
 // ---- sharded captures: the tiny cross-shard fix-ups (one thread each; world <= a few dozen) ---------------

@@ -24,7 +24,8 @@ struct urhgpu_stream {
     int want_qad = 0, want_pos = 0;
     int64_t n_max = 0, cap_rows = 0, cap_bits = 0, cap_msg = 0, cap_pos = 0, cap_blob = 0;
     struct Slot {
-        void *dev = nullptr;               // one allocation: qad | rows | bits | msg_off | pauses | pos_off | pos | counts | blob
+        void *dev = nullptr;               // one allocation: rows | bits | msg_off | pauses | pos_off | pos | counts | blob
+        float *qad = nullptr;              // the qad buffer (of the ring below) this slot's current pass wrote
         urhgpu_outputs out;
         char *h_blob2[2] = {nullptr, nullptr};   // pinned, used alternately by the slot's passes: the result handed out at push i (pass i - 3)
                                                  // stays untouched while pass i's copy lands in the other one
@@ -34,8 +35,12 @@ struct urhgpu_stream {
         int64_t seq = -1, n = 0, copied = 0;
         int state = 0;                     // 0 free, 1 pass launched (tail pending), 2 copy issued, 3 result handed out
     } slot[3];
+    // The demodulated signal of pass i lives in qad_ring[i % 4]: four buffers for three result slots, so that the result handed out by
+    // push i (pass i - 3) still owns its qad while pass i's hot kernel writes another one -- it is overwritten by push i + 1.
+    float *qad_ring[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t copy_stream = nullptr;
     int64_t seq = 0;
+    int64_t streamed_passes = 0;           // passes whose tail ran in segments (diagnostics)
     int64_t predicted_bytes = 0;           // blob bytes the next pass's copy is sized for (0: header only, the rest fetched on demand)
     int64_t short_copies = 0;              // passes whose prediction fell short (diagnostics)
     bool was_pipelined = false;
@@ -61,7 +66,7 @@ void fill_result(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *
     r->row_len = (const int32_t *)(s.h_blob + hdr[13]);
     r->pos32 = hdr[7] ? (const uint32_t *)(s.h_blob + hdr[14]) : nullptr;
     r->blob = s.h_blob;
-    r->d_qad = s.out.qad;
+    r->d_qad = s.qad;
     (void)st;
 }
 
@@ -90,6 +95,10 @@ int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r
     URH_HIP(hipEventSynchronize(s.ev_copy));
     const int64_t *hdr = (const int64_t *)s.h_blob;
     if (hdr[0] != URHGPU_BLOB_MAGIC || hdr[6] < 0 || hdr[6] > st->cap_blob) return URHGPU_ERR_ARG;
+    if (hdr[15] & 2) {                                      // a segment's gate gave up waiting for the hot kernel (k_seg_gate): nothing of this pass is valid
+        snprintf(urh::g_hip_err, sizeof(urh::g_hip_err), "streamed pass %lld: a segment waited 2 s for the hot kernel", (long long)s.seq);
+        return URHGPU_ERR_HIP;
+    }
     const int64_t total = hdr[6];
     if (total > s.copied) {                                 // the prediction was short (the first pass of a stream, a denser capture): the rest, now
         URH_HIP(hipMemcpyAsync(s.h_blob + s.copied, (const char *)s.out.blob + s.copied, (size_t)(total - s.copied), hipMemcpyDeviceToHost,
@@ -146,9 +155,12 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
     if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess) { urhgpu_stream_destroy(st); return URHGPU_ERR_HIP; }
     const size_t b_qad = st->want_qad ? a256((size_t)n_max * 4) : 0, b_rows = a256((size_t)st->cap_rows * 16), b_bits = a256((size_t)st->cap_bits),
                  b_off = a256((size_t)(st->cap_msg + 1) * 8), b_pos = st->want_pos ? a256((size_t)st->cap_pos * 8) : 0, b_blob = a256((size_t)st->cap_blob);
+    if (st->want_qad)
+        for (auto &q : st->qad_ring)
+            if (hipMalloc((void **)&q, b_qad) != hipSuccess) { urhgpu_stream_destroy(st); return URHGPU_ERR_HIP; }
     for (auto &s : st->slot) {
         memset(&s.out, 0, sizeof(s.out));
-        if (hipMalloc(&s.dev, b_qad + b_rows + b_bits + 3 * b_off + b_pos + 256 + b_blob) != hipSuccess ||
+        if (hipMalloc(&s.dev, b_rows + b_bits + 3 * b_off + b_pos + 256 + b_blob) != hipSuccess ||
             hipHostMalloc((void **)&s.h_blob2[0], (size_t)st->cap_blob) != hipSuccess ||
             hipHostMalloc((void **)&s.h_blob2[1], (size_t)st->cap_blob) != hipSuccess || hipHostMalloc((void **)&s.h_counts, 64) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_tail, hipEventDisableTiming) != hipSuccess ||
@@ -157,7 +169,6 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
             return URHGPU_ERR_HIP;
         }
         char *d = (char *)s.dev;
-        if (st->want_qad) { s.out.qad = (float *)d; d += b_qad; }
         s.out.rows = (int64_t *)d; d += b_rows; s.out.cap_rows = st->cap_rows;
         s.out.bits = (uint8_t *)d; d += b_bits; s.out.cap_bits = st->cap_bits;
         s.out.msg_off = (int64_t *)d; d += b_off;
@@ -179,12 +190,14 @@ int urhgpu_stream_destroy(urhgpu_stream *st) {
     if (st->copy_stream) { (void)hipStreamSynchronize(st->copy_stream); (void)hipStreamDestroy(st->copy_stream); }
     for (auto &s : st->slot) {
         if (s.dev) (void)hipFree(s.dev);
+        s.dev = nullptr;
         if (s.h_blob2[0]) (void)hipHostFree(s.h_blob2[0]);
         if (s.h_blob2[1]) (void)hipHostFree(s.h_blob2[1]);
         if (s.h_counts) (void)hipHostFree(s.h_counts);
         if (s.ev_tail) (void)hipEventDestroy(s.ev_tail);
         if (s.ev_copy) (void)hipEventDestroy(s.ev_copy);
     }
+    for (auto &q : st->qad_ring) if (q) (void)hipFree(q);
     if (!st->was_pipelined) (void)urhgpu_ctx_set_pipelined(st->ctx, 0, nullptr);
     delete st;
     return URHGPU_OK;
@@ -207,15 +220,26 @@ int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_ho
     // ...and nothing of this pass may be written into the slot's device buffers before that copy has read them
     if (s.state == 3) URH_HIP(hipStreamWaitEvent(ctx->tail_stream, s.ev_copy, 0));
     s.state = 0;
-    {
-        urhgpu_outputs pass_out = s.out;
-        pass_out.blob = nullptr; pass_out.cap_blob = 0;    // packed later, on the copy stream (queue_copy)
-        pass_out.h_counts = s.h_counts;                    // the counts also land in pinned host memory (a store of the kernel that finalises them)
-        URH_TRY(urhgpu_iq_to_bits_dev(ctx, d_iq, n, &st->p, &pass_out));
+    s.h_blob = s.h_blob2[(i / 3) & 1];
+    s.qad = st->want_qad ? st->qad_ring[i & 3] : nullptr;
+    urhgpu_outputs pass_out = s.out;
+    pass_out.qad = s.qad;
+    pass_out.blob = nullptr; pass_out.cap_blob = 0;        // packed later, on the copy stream (queue_copy) -- or, streamed, by the segments
+    pass_out.h_counts = s.h_counts;                        // the counts also land in pinned host memory (a store of the kernel that finalises them)
+    // Streamed pass (pulse_table.hip "Segments"): the tail runs in segments beside the hot kernel and every segment stores its share of
+    // the compact blob straight into the pinned host blob -- no pack launch at the end, no copy engine, no predicted size.  Captures the
+    // bit-plane kernel does not take, or too short to cut, go the ordinary way: tail behind the hot kernel, pack + copy behind the tail.
+    bool streamed = false;
+    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed));
+    if (streamed) {
+        s.state = 2; s.seq = i; s.n = n; s.copied = st->cap_blob;
+        st->seq = i + 1;
+        st->streamed_passes += 1;
+        return URHGPU_OK;
     }
+    URH_TRY(urhgpu_iq_to_bits_dev(ctx, d_iq, n, &st->p, &pass_out));
     URH_HIP(hipEventRecord(s.ev_tail, ctx->tail_stream));
     s.state = 1; s.seq = i; s.n = n;
-    s.h_blob = s.h_blob2[(i / 3) & 1];
     st->seq = i + 1;
     URH_TRY(queue_copy(st, s));                            // pack + copy behind this pass's tail, on the copy stream; the host does not wait
     return URHGPU_OK;
@@ -224,6 +248,7 @@ int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_ho
 int urhgpu_stream_stats(urhgpu_stream *st, int64_t *out4) {
     if (!st || !out4) return URHGPU_ERR_ARG;
     out4[0] = st->seq; out4[1] = st->short_copies; out4[2] = st->predicted_bytes; out4[3] = st->cap_blob;
+    if (st->streamed_passes > 0) out4[2] = -st->streamed_passes;       // streamed passes predict nothing: their count, negated
     return URHGPU_OK;
 }
 
@@ -241,6 +266,9 @@ int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out)
             *n_out += 1;
         }
     }
+    // a streamed pass's blob is complete a moment before its hot kernel has retired (the last qad stores): d_qad of the results handed
+    // out here is read by the caller next
+    if (st->streamed_passes > 0) URH_TRY(urhgpu_ctx_sync(st->ctx));
     return URHGPU_OK;
 }
 
