@@ -104,7 +104,8 @@ def tuning_from_env():
         t["tail_masked"] = int(e["URH_TAIL_MASKED"])
     if "URH_HOT_CUS_REMOVED" in e:
         t["hot_cus_removed_per_xcd"] = int(e["URH_HOT_CUS_REMOVED"])
-    for env, key in (("URH_STREAM_SEGMENTS", "stream_segments"), ("URH_STREAM_SHAPE", "stream_shape"), ("URH_PACK_BLOCKS", "pack_blocks")):
+    for env, key in (("URH_STREAM_SEGMENTS", "stream_segments"), ("URH_STREAM_SHAPE", "stream_shape"), ("URH_PACK_BLOCKS", "pack_blocks"),
+                     ("URH_STREAM_BITS_SEGMENTS", "stream_bits_segments"), ("URH_STREAM_POLICY", "stream_policy")):
         if env in e:
             t[key] = int(e[env])
     prio = int(e.get("URH_TAIL_STREAM_PRIORITY", "-1" if e.get("URH_TAIL_PRIORITY") else "0"))

@@ -106,6 +106,14 @@ int urhgpu_ctx_reserve(urhgpu_ctx *ctx, int64_t n_samples, int tolerance);
 /* Device properties the host side needs to size launches / report rooflines. */
 int urhgpu_ctx_info(urhgpu_ctx *ctx, int *compute_units, int *wavefront, int64_t *hbm_bytes, char *name, int name_cap);
 
+/* Run-time guard for the libm the reference would use on THIS host: the reference's Costas loop and FSK demodulation call the host's
+ * sinf / cosf / atan2f (signal_functions.pyx:252-330, :375), which are not correctly rounded -- x86-64 glibc picks an FMA or a non-FMA
+ * build of sinf / cosf by CPU, differing on about one float in 10^9 -- and the device code restates the FMA build.  out4 = {sinf / cosf
+ * results compared with the host's (including every argument below 120 on which the two builds differ), mismatches, atan2f results
+ * compared, mismatches}.  Mismatches != 0: the reference on this host is not the function the GPU path is bit-exact with.  Host
+ * arithmetic; works without a GPU. */
+int urhgpu_host_libm_check(int64_t *out4);
+
 /* After a PSK demodulation (Costas loop) of more than 8192 samples: how the chunk chain of the exact parallel evaluation was
  * resolved -- out4 = {chunks whose true start state matched a speculative candidate, chunks evaluated serially until they
  * met a candidate's checkpoint, chunks evaluated serially to the end (or fully gated), re-speculation rounds}.

@@ -86,13 +86,15 @@ def one_tile_chunks():
     lib.urhgpu_test_force_tiles_per_chunk(0)
 
 
-@pytest.mark.parametrize("segments,shape", [(2, 0), (3, 0), (5, 0), (8, 0), (4, 1), (6, 1), (8, 1)])
+@pytest.mark.parametrize("segments,shape,bits_segments", [(2, 0, 1), (2, 0, 2), (3, 0, 3), (5, 0, 2), (8, 0, 3), (8, 0, 8), (4, 1, 4), (6, 1, 3), (8, 1, 1)])
 @pytest.mark.parametrize("want_pos", [True, False])
-def test_segmented_tail_equals_oracle(oracle, one_tile_chunks, segments, shape, want_pos):
+def test_segmented_tail_equals_oracle(oracle, one_tile_chunks, segments, shape, bits_segments, want_pos):
+    """segments: rows segments (resolve + rows, shipped as they are written); bits_segments: the coarser segments of the second stream
+    (tile scan, group scan, expansion, pack), the last of which is the last rows segment alone"""
     import torch
     from urh_amd.pipeline import DemodParams, DevicePipeline
     p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, want_pos)
-    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_segments": segments, "stream_shape": shape})
+    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_policy": 1, "stream_segments": segments, "stream_shape": shape, "stream_bits_segments": bits_segments})
     st = pipe.stream(N, p, want_qad=True, want_pos=want_pos)
     caps = [_events_capture(N, 11), _events_capture(N, 12), _events_capture(N, 13, boundary_trains=False),
             synth_fsk(N, sps=100, seed=5, noise=0.04),                                      # one message, no pause at all
@@ -110,7 +112,7 @@ def test_segmented_tail_equals_oracle(oracle, one_tile_chunks, segments, shape, 
     st.close()
     assert stats["predicted_bytes"] == -len(caps), stats       # every pass took the segmented route
     for i, iq in enumerate(caps):
-        _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i}, {segments} segments (shape {shape})")
+        _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i}, {segments} rows / {bits_segments} bits segments (shape {shape})")
 
 
 def test_segmented_tail_order4_int16_and_qad(oracle, one_tile_chunks):
@@ -119,7 +121,7 @@ def test_segmented_tail_order4_int16_and_qad(oracle, one_tile_chunks):
     from urh_amd import _lib
     from urh_amd.pipeline import DemodParams, DevicePipeline
     p = DemodParams("FSK", 2, 0.0, 0.0, 0.03, 5, 100, 0.1, 8, True)
-    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_segments": 8})
+    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_policy": 1, "stream_segments": 8})
     caps = [synth_fsk(N, sps=100, seed=40 + i, noise=0.03, pause_every=N // (3 + i), pause_len=3000 + 977 * i, dtype=np.int16) for i in range(4)]
     st = pipe.stream(N, p, want_qad=True, want_pos=True, dtype=np.int16)
     dev = [torch.from_numpy(c).cuda() for c in caps]
@@ -151,7 +153,7 @@ def test_segmented_and_plain_passes_interleave(oracle, one_tile_chunks):
     import torch
     from urh_amd.pipeline import DemodParams, DevicePipeline
     p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
-    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_segments": 8})
+    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_policy": 1, "stream_segments": 8})
     st = pipe.stream(N, p, want_qad=False, want_pos=True)
     sizes = [N, N - 777, N, N // 2, N - 2048, N, 70_001, N]
     caps = [_events_capture(N, 60 + i)[:n].copy() for i, n in enumerate(sizes)]

@@ -8,6 +8,8 @@
 
 #include "common.hpp"
 #include "compact.hpp"
+#include "fdlibm_atan2f.h"
+#include "glibc_sincosf.h"
 #include "runs.hpp"
 
 namespace urh {
@@ -356,6 +358,7 @@ using urh::join_tail;
 int begin_pipelined_pass(urhgpu_ctx *ctx) {
     std::swap(ctx->arena, ctx->arena_alt);
     std::swap(ctx->arena_alt, ctx->arena_alt2);
+    ctx->passes_begun += 1;
     // Has the tail that last used this arena finished?  A caller that runs more than two passes ahead of the GPU (a tight loop of
     // passes) is held back HERE, on the host, until it has (bounded run-ahead; the GPU still has the previous hot kernel queued
     // behind the running one): a stream-level wait would put one more barrier packet between two hot kernels (about 4 us of the
@@ -441,16 +444,28 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     int64_t bound[kMaxSegments + 1];
     const int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, ctx->tune_stream_segments, ctx->tune_stream_shape, bound) : 0;
     if (S < 2) return URHGPU_OK;                               // too short to cut, or not the bit-plane kernel's work: the ordinary path
+    if (ctx->tune_stream_policy == 2) return URHGPU_OK;
+    if (ctx->tune_stream_policy == 0 && ctx->passes_begun > 0) {
+        // is anything of the pass before still running?  Then this pass's tail will run beside ITS successor's hot kernel as well: one piece
+        const hipError_t q = hipEventQuery(ctx->ev_tail[(ctx->flip + 2) % 3]);
+        if (q == hipErrorNotReady) { (void)hipGetLastError(); return URHGPU_OK; }
+        if (q != hipSuccess) URH_HIP(q);
+    }
     if (!ctx->d_seg) {
         URH_HIP(hipMalloc(&ctx->d_seg, 3 * kSegBlockBytes));
         URH_HIP(hipMemset(ctx->d_seg, 0, 3 * kSegBlockBytes));
-        for (int k = 0; k < 3; ++k) URH_HIP(hipEventCreateWithFlags(&ctx->ev_hot_done[k], hipEventDisableTiming));
+        URH_HIP(hipStreamCreateWithFlags(&ctx->bits_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 3; ++k) {
+            URH_HIP(hipEventCreateWithFlags(&ctx->ev_hot_done[k], hipEventDisableTiming));
+            URH_HIP(hipEventCreateWithFlags(&ctx->ev_bits[k], hipEventDisableTiming));
+            for (int j = 0; j < kMaxSegments; ++j) URH_HIP(hipEventCreateWithFlags(&ctx->ev_rows[k][j], hipEventDisableTiming));
+        }
     }
     URH_TRY(begin_pipelined_pass(ctx));
     const int slot = ctx->flip;
     uint32_t *progress = (uint32_t *)((char *)ctx->d_seg + (size_t)slot * kSegBlockBytes);
-    SegState *st = (SegState *)((char *)progress + 256);
-    static_assert(kMaxSegments * 4 <= 256 && 256 + sizeof(SegState) <= kSegBlockBytes, "segment block");
+    SegState *st = (SegState *)((char *)progress + kMaxSegments * kProgressStride * 4);
+    static_assert(kMaxSegments * kProgressStride * 4 + sizeof(SegState) <= kSegBlockBytes && kMaxSegments <= 16, "segment block");
     if (ctx->seg_dirty[slot]) {                                // an earlier pass on this arena died half-way: its counters may not be zero
         URH_HIP(hipMemset(progress, 0, kSegBlockBytes));
         ctx->seg_dirty[slot] = false;
@@ -490,14 +505,15 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     if (prof) URH_TRY(prof_end_record(ctx, s));
     else g_hot_events = HotEvents();
     if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot_done[slot], s)); hot_done = ctx->ev_hot_done[slot]; }
-    // ---- the tail, segment by segment, on the tail stream: it never waits for the hot kernel as a whole ----
-    hipStream_t ts = ctx->tail_stream;
+    // ---- the tail in segments: rows segments on the tail stream, bits segments on the bits stream behind the rows they expand; neither
+    // ever waits for the hot kernel as a whole ----
+    hipStream_t ts = ctx->tail_stream, tb = ctx->bits_stream;
     const ResolveScratch rsc = resolve_scratch_carve(rs_mem, pl.n_chunks);
     ResolveArgs r;
     memset(&r, 0, sizeof(r));
     r.sc = rsc;
     r.chunks = chunks; r.n_chunks = pl.n_chunks; r.n_total = n; r.tol = p->tolerance;
-    r.rows = out->rows; r.cap_rows = out->cap_rows; r.d_n_acc = &st->n_acc; r.d_n_rows = &st->n_rows;
+    r.rows = out->rows; r.cap_rows = out->cap_rows; r.d_n_acc = &st->n_acc; r.d_n_rows = &st->rows_at[S - 1];
     r.d_n_rows_needed = &st->rows_needed; r.write_last_row = 1;
     r.local_pass = 0; r.aux = (ResolveAux *)(ctx->d_tickets + 4); r.summary_out = nullptr; r.chunk_first = 0; r.n_local = pl.n_chunks; r.d_ts_carry = nullptr;
     EmitArgs e;
@@ -513,18 +529,46 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     BitsParams bp = bits_params(p);
     ScanState ss;
     URH_TRY(scan_state(ctx, tile_desc_cap(cap, pl.n_chunks), &ss));
+    // where the rows go on the host: the capacity layout of the compact blob (k_pack_seg)
+    const int has_pos = (bp.write_pos && out->pos) ? 1 : 0;
+    int8_t *h_state = nullptr; int32_t *h_len = nullptr;
+    if (host_blob) {
+        const int64_t caps[5] = {out->cap_rows, out->cap_msg, out->cap_bits, out->cap_pos, out->cap_rows};
+        const BlobLayout L = blob_layout(caps, out->cap_rows, out->cap_bits, out->cap_msg, out->cap_pos, has_pos);
+        if (cap_host < L.total) return URHGPU_ERR_CAPACITY;
+        h_state = (int8_t *)((char *)host_blob + L.off_row_state); h_len = (int32_t *)((char *)host_blob + L.off_row_len);
+    }
     SegPackDst dst{host_blob, cap_host, progress, ctx->tune_pack_blocks};
+    // bits segments: the last one is the last rows segment alone (what is exposed behind the hot kernel), the others share the rest
+    int Sb = ctx->tune_stream_bits_segments;
+    if (Sb > S) Sb = S;
+    if (Sb < 1) Sb = 1;
+    int bits_end_at[kMaxSegments];                             // bits segment j ends with rows segment bits_end_at[j]
+    for (int j = 0; j < Sb - 1; ++j) bits_end_at[j] = (int)((int64_t)(S - 1) * (j + 1) / (Sb - 1)) - 1;
+    bits_end_at[Sb - 1] = S - 1;
+    int jb = 0;
+    int64_t bits_from = 0;
     for (int k = 0; k < S; ++k) {
-        TailSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], progress, target[k], st};
-        URH_TRY(launch_tile_segment(r, e, tm, bp, bo, scratch, ss, out->rows, out->cap_rows, sg, &dst, ts));
+        RowsSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], SegGate{progress, k, target[k], k == 0 ? 1 : 0, st, (long long)200000000}, h_state, h_len};
+        URH_TRY(launch_rows_segment(r, e, tm, bp, st, sg, ts));
+        while (jb < Sb && bits_end_at[jb] < k) ++jb;           // (a bits segment that would end before the first rows segment: none)
+        if (jb < Sb && bits_end_at[jb] == k) {
+            URH_HIP(hipEventRecord(ctx->ev_rows[slot][jb], ts));
+            URH_HIP(hipStreamWaitEvent(tb, ctx->ev_rows[slot][jb], 0));
+            BitsSegment bs{jb, jb == Sb - 1 ? 1 : 0, bits_from, bound[k + 1], k, st};
+            URH_TRY(launch_bits_segment(tm, bp, bo, scratch, ss, out->rows, out->cap_rows, bs, &dst, tb));
+            bits_from = bound[k + 1];
+            ++jb;
+        }
     }
     URH_HIP(hipGetLastError());
-    if (!host_blob) {                                          // nobody zeroes the counters then
-        URH_HIP(hipMemsetAsync(progress, 0, kMaxSegments * 4, ts));
-    }
+    if (!host_blob) URH_HIP(hipMemsetAsync(progress, 0, kMaxSegments * kProgressStride * 4, tb));       // (nobody else zeroes the counters then)
     ctx->seg_dirty[slot] = false;
-    if (ev_ready) URH_HIP(hipEventRecord(ev_ready, ts));
-    // the pass is over when the hot kernel has retired too (its last qad stores): cheap here, the last gate has just seen its last chunk
+    if (ev_ready) URH_HIP(hipEventRecord(ev_ready, tb));         // the host blob is complete
+    // the pass is over when the bits stream has finished and the hot kernel has retired (its last qad stores): cheap here, the last
+    // gate has just seen its last chunk
+    URH_HIP(hipEventRecord(ctx->ev_bits[slot], tb));
+    URH_HIP(hipStreamWaitEvent(ts, ctx->ev_bits[slot], 0));
     URH_HIP(hipStreamWaitEvent(ts, hot_done, 0));
     if (s != ctx->stream && ctx->stream != nullptr) URH_HIP(hipStreamWaitEvent(ctx->stream, hot_done, 0));   // input reuse in stream order
     URH_TRY(end_pipelined_pass(ctx));
@@ -599,7 +643,15 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
-    if (ctx->d_seg) { (void)hipFree(ctx->d_seg); for (hipEvent_t e : ctx->ev_hot_done) if (e) (void)hipEventDestroy(e); }
+    if (ctx->d_seg) {
+        (void)hipFree(ctx->d_seg);
+        if (ctx->bits_stream) { (void)hipStreamSynchronize(ctx->bits_stream); (void)hipStreamDestroy(ctx->bits_stream); }
+        for (int k = 0; k < 3; ++k) {
+            if (ctx->ev_hot_done[k]) (void)hipEventDestroy(ctx->ev_hot_done[k]);
+            if (ctx->ev_bits[k]) (void)hipEventDestroy(ctx->ev_bits[k]);
+            for (hipEvent_t e : ctx->ev_rows[k]) if (e) (void)hipEventDestroy(e);
+        }
+    }
     if (ctx->ev_hot) { (void)hipEventDestroy(ctx->ev_hot); (void)hipEventDestroy(ctx->ev_tail[0]); (void)hipEventDestroy(ctx->ev_tail[1]); (void)hipEventDestroy(ctx->ev_tail[2]); }
     delete (ShardSession *)ctx->shard;
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
@@ -629,6 +681,7 @@ int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx) {
 int urhgpu_ctx_sync(urhgpu_ctx *ctx) {
     if (!ctx) return URHGPU_ERR_ARG;
     if (ctx->hot_masked) URH_HIP(hipStreamSynchronize(ctx->hot_masked));
+    if (ctx->bits_stream) URH_HIP(hipStreamSynchronize(ctx->bits_stream));
     if (ctx->tail_stream) URH_HIP(hipStreamSynchronize(ctx->tail_stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
     ctx->tail_pending = false;
@@ -720,7 +773,9 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "tail_masked")) ctx->tune_tail_masked = value != 0;
     else if (!strcmp(key, "hot_cus_removed_per_xcd")) { if (value < 0 || value > 16) return URHGPU_ERR_ARG; ctx->tune_hot_cus_removed = value; }
     else if (!strcmp(key, "stream_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_segments = value; }
+    else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
     else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 1) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
+    else if (!strcmp(key, "stream_bits_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_bits_segments = value; }
     else if (!strcmp(key, "pack_blocks")) { if (value < 0 || value > 4096) return URHGPU_ERR_ARG; ctx->tune_pack_blocks = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;
@@ -730,6 +785,49 @@ int urhgpu_ctx_join(urhgpu_ctx *ctx) {
     if (!ctx) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
     return join_tail(ctx);
+}
+
+// Does this host's libm evaluate sinf / cosf / atan2f the way the device code restates them?  The reference's Costas loop and FSK
+// demodulation call the HOST's libm (signal_functions.pyx:252-330, :375, compiled as C++: sinf / cosf / atan2f), which is not correctly
+// rounded: x86-64 glibc picks an FMA or a non-FMA build of sinf / cosf at run time, and the two differ on about one float in 10^9.  The
+// device code restates the FMA build (glibc_sincosf.h, URH_SINCOSF_FMA = 1).  Checked: the 17 arguments below |x| = 120 on which the two
+// builds differ (tools/libm_probe/scan.c finds them: an exhaustive scan), both signs, plus pseudo-random arguments; atan2f (one build
+// in glibc) on pseudo-random operand pairs of every quadrant.  out4 = {sinf / cosf results compared, mismatches, atan2f results
+// compared, mismatches}.  A mismatch means: on THIS host the reference itself would produce other bits than on the hosts the parity
+// tests ran on, and the GPU's PSK / FSK output follows those, not this host's reference.  Host arithmetic only; no GPU needed.
+int urhgpu_host_libm_check(int64_t *out4) {
+    if (!out4) return URHGPU_ERR_ARG;
+    static const uint32_t kDiscriminating[17] = {0x418a3adbu, 0x418a3adcu, 0x418a3addu, 0x418a3adeu, 0x41bc76d9u, 0x4202eb4bu, 0x4255b0a9u, 0x4280ce28u,
+                                                 0x42687a55u, 0x42a35c07u, 0x42a35d44u, 0x42870e40u, 0x42a97360u, 0x42c55faau, 0x42d8d23eu, 0x42e87a55u,
+                                                 0x42cf5854u};
+    int64_t n_sc = 0, bad_sc = 0, n_at = 0, bad_at = 0;
+    auto same = [](float a, float b) { uint32_t x, y; memcpy(&x, &a, 4); memcpy(&y, &b, 4); return x == y || (a != a && b != b); };
+    auto check_sc = [&](float x) {
+        volatile float vx = x;                                   // (keep the compiler from folding the libm calls)
+        n_sc += 2;
+        if (!same(sinf(vx), urh_sinf(x))) ++bad_sc;
+        if (!same(cosf(vx), urh_cosf(x))) ++bad_sc;
+    };
+    for (uint32_t u : kDiscriminating) {
+        float x; memcpy(&x, &u, 4);
+        check_sc(x); check_sc(-x);
+    }
+    uint64_t s = 0x243f6a8885a308d3ull;
+    auto next = [&]() { s += 0x9e3779b97f4a7c15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull; z = (z ^ (z >> 27)) * 0x94d049bb133111ebull; return z ^ (z >> 31); };
+    for (int i = 0; i < 4096; ++i) {
+        const uint64_t z = next();
+        check_sc((float)((double)(int64_t)(z >> 11) * (1.0 / 9007199254740992.0) * 240.0 - 120.0));      // uniform in (-120, 120)
+        const uint32_t a = (uint32_t)z, b = (uint32_t)(z >> 32);
+        // operands of every sign and of magnitudes 2^-20 .. 2^20
+        float y, x;
+        const uint32_t uy = (a & 0x807fffffu) | (((a >> 23) % 41u + 107u) << 23), ux = (b & 0x807fffffu) | (((b >> 23) % 41u + 107u) << 23);
+        memcpy(&y, &uy, 4); memcpy(&x, &ux, 4);
+        volatile float vy = y, vx = x;
+        ++n_at;
+        if (!same(atan2f(vy, vx), urh_atan2f(y, x))) ++bad_at;
+    }
+    out4[0] = n_sc; out4[1] = bad_sc; out4[2] = n_at; out4[3] = bad_at;
+    return URHGPU_OK;
 }
 
 int urhgpu_ctx_info(urhgpu_ctx *ctx, int *compute_units, int *wavefront, int64_t *hbm_bytes, char *name, int name_cap) {

@@ -110,12 +110,21 @@ struct urhgpu_ctx {
     // streamed passes (urhgpu_stream_*; capi.hip: iq_to_bits_streamed): per scratch arena 16 progress counters + one SegState
     void *d_seg = nullptr;         // 3 x kSegBlockBytes, zero between passes
     bool seg_dirty[3] = {false, false, false};   // a pass failed between its hot launch and its last segment: counters not trusted
-    int tune_stream_segments = 8;  // segments of a streamed pass's tail (1: no streaming), urhgpu_ctx_set_tuning("stream_segments")
+    int tune_stream_segments = 5;  // rows segments of a streamed pass's tail (1: no streaming), urhgpu_ctx_set_tuning("stream_segments")
+    int tune_stream_policy = 0;    // 0: stream a pass only when the pipeline is idle (nothing of an earlier pass still running: a single
+                                   // capture, where the latency of the tail counts); 1: every qualifying pass; 2: never.  Beside the hot kernel
+                                   // of a FOLLOWING pass the segments' short kernels are slower than one tail over the whole capture
+                                   // (memory latency under a saturated HBM), so back-to-back passes keep the one-piece tail
+    long long passes_begun = 0;    // pipelined passes started on this context
     int tune_stream_shape = 0;     // 0: equal segments; 1: halving (1/2, 1/4, ... of the capture, the last two equal)
+    int tune_stream_bits_segments = 3;   // bits segments (tile scan, group scan, expansion, pack) of a streamed pass, on their own stream
     int tune_pack_blocks = 0;      // workgroups of a segment's pack kernel (0: default)
     hipEvent_t ev_hot_done[3] = {nullptr, nullptr, nullptr};   // behind the hot kernel of the pass in arena slot k (streamed passes)
+    hipStream_t bits_stream = nullptr;   // second tail stream of streamed passes: the bits segments, behind the rows they expand
+    hipEvent_t ev_rows[3][16] = {};      // [arena slot][bits segment]: the rows below the bits segment's end have been written
+    hipEvent_t ev_bits[3] = {nullptr, nullptr, nullptr};   // the pass's last bits segment has been packed
 };
-constexpr size_t kSegBlockBytes = 512;
+constexpr size_t kSegBlockBytes = 4096;      // 16 progress counters on their own 128-byte lines, then the SegState
 
 namespace urh {
 // A pass whose tail runs in segments beside the hot kernel, every segment storing its share of the compact blob into pinned host memory

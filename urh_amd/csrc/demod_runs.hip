@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
         if (lane == 0) {
             int k = 0;
             while (k < p.n_seg - 1 && chunk >= (int64_t)p.seg_end[k]) ++k;
-            __hip_atomic_fetch_add(p.progress + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(p.progress + k * kProgressStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

@@ -216,42 +216,59 @@ int launch_bits_prepare(const int64_t *rows, const int64_t *d_n_rows, int64_t ca
                         void *scratch, int64_t *d_flags, const ScanState &ss, hipStream_t s);
 int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
                        const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
-// ---- streamed passes: the tile tail in SEGMENTS (pulse_table.hip "segments") --------------------------------------------------
-// Device-resident state that carries a pass from one segment of its tail to the next (one block per scratch arena, zeroed by the
-// first segment's gate).  `in[k & 1]` is what segment k starts from, written by segment k - 1's group scan (its Final functor).
+// ---- streamed passes: the tile tail in SEGMENTS (pulse_table.hip "Segments") --------------------------------------------------
+// Device-resident state that carries a pass from one segment of its tail to the next (one block per scratch arena).  The ROWS of the
+// pulse table are made by rows segments, the bits / pauses / positions by (fewer, coarser) bits segments on a second stream;
+// `in[j & 1]` is what bits segment j starts from, written by bits segment j - 1's group scan (its Final functor).
 struct SegState {
-    int64_t n_rows;          // pulse-table rows that are final after the current segment, clamped to cap_rows: d_n_rows of its kernels
-    int64_t rows_needed;     // the same, unclamped (the table's size before clamping once the last segment has run)
-    int64_t n_acc;           // accepted runs so far
-    int64_t n_groups;        // groups so far, the open (trailing) one included: d_n_groups
-    int64_t n_groups_local;  // groups the current segment's group scan covers: [in.g0, n_groups)
-    int64_t end_bits, end_pos, end_msgs;   // bits / positions written and messages closed after the current segment
+    int64_t rows_at[kMaxSegments];   // [k]: pulse-table rows that are final after rows segment k (clamped to cap_rows); the last: n_rows
+    int64_t rows_needed;     // unclamped row count (the table's size before clamping once the last rows segment has run)
+    int64_t n_acc;           // accepted runs (the last rows segment)
+    int64_t n_groups;        // groups so far, the open (trailing) one included: d_n_groups of the current bits segment
+    int64_t n_groups_local;  // groups the current bits segment's group scan covers: [in.g0, n_groups)
+    int64_t end_bits, end_pos, end_msgs;   // bits / positions written and messages closed after the current bits segment
     int64_t err;             // != 0: a gate gave up waiting for the hot kernel (the pass's results are void)
-    int64_t pad[7];
     struct In {
-        int64_t g0;          // the group that was open at the end of the segment before: this segment's group scan starts with it
+        int64_t g0;          // the group that was open at the end of the bits segment before: this one's group scan starts with it
         int64_t carry[3];    // exclusive prefix at g0: messages closed, kept bits, kept positions before it
-        int64_t ship_rows, ship_bits, ship_pos, ship_msgs;   // what the host already holds: the segment's pack kernel starts there
+        int64_t ship_bits, ship_pos, ship_msgs, pad;   // what the host already holds: the segment's pack kernel starts there
     } in[2];
 };
-static_assert(sizeof(SegState) == 256, "SegState");
-// one segment of a streamed pass: tiles / chunks [c0, c1) of the capture's n_chunks (c0 a multiple of kSegAlign; c1 too, or n_chunks)
-constexpr int64_t kSegAlign = 256;   // resolve workgroups, tile-scan workgroups and the wavefronts' chunk quadruples all start on it
-struct TailSegment {
-    int index;               // k
-    int final;               // the capture's last segment: totals, last row, trailing group closed by the end of the capture
-    int64_t c0, c1;
+static_assert(sizeof(SegState) == 128 + 64 + 128, "SegState");
+// segment boundaries are multiples of kSegAlign chunks (or the capture's end): resolve workgroups, tile-scan workgroups and the
+// wavefronts' chunk quadruples all start on it
+constexpr int64_t kSegAlign = 256;
+// the gate of a rows segment, inside its resolve kernel: every workgroup waits until `target` chunks have counted themselves into
+// progress[k] (RunArgs::progress); init: the pass's first segment also clears the state the bits segments carry along
+struct SegGate {
     const uint32_t *progress;   // nullptr: no gate (the hot kernel is known to have finished)
-    uint32_t target;            // chunks that count into progress[index]
+    int k;
+    uint32_t target;
+    int init;
+    SegState *seg;
+    long long max_ticks;        // of the 100 MHz wall clock: give up (seg->err) instead of hanging when the hot kernel never comes
+};
+struct RowsSegment {         // chunks [c0, c1) of the capture's n_chunks (c0 a multiple of kSegAlign; c1 too, or n_chunks)
+    int index;               // k
+    int final;               // the capture's last segment: totals, the table's last row
+    int64_t c0, c1;
+    SegGate gate;
+    int8_t *h_state;         // pinned HOST memory (device-accessible) that receives the rows as they are written: the compact blob's
+    int32_t *h_len;          // row_state / row_len sections (nullptr: rows are not shipped)
+};
+struct BitsSegment {         // tiles [c0, c1) (the last one: + the tile of the table's last row); needs the rows of chunks < c1
+    int index;               // j
+    int final;
+    int64_t c0, c1;
+    int rows_index;          // rows segment whose end is c1: d_n_rows = &state->rows_at[rows_index]
     SegState *state;
 };
-struct SegPackDst {          // where a segment's share of the compact blob goes: pinned HOST memory (device-accessible), see k_pack_seg
+struct SegPackDst {          // where a bits segment's share of the compact blob goes: pinned HOST memory (device-accessible), see k_pack_seg
     void *host;              // nullptr: nothing is shipped
     int64_t cap_host;        // >= blob_capacity of the pass's capacities
     uint32_t *progress_reset;   // the counters the last segment zeroes (nullptr: none)
     int blocks;              // workgroups of the pack kernel (0: default)
 };
-size_t seg_state_bytes();
 
 // Tile tail (single GPU, not ASK): resolve + rows in two launches, bits in three more; see pulse_table.hip.
 struct TileTailMem {
@@ -275,9 +292,13 @@ int launch_tile_bits_prepare(const TileTailMem &m, const int64_t *rows, const in
                              void *scratch, int64_t *d_flags, const ScanState &ss, hipStream_t s);
 int launch_tile_bits_finish(const TileTailMem &m, const int64_t *rows, const int64_t *d_n_rows, int64_t cap_rows, const BitsParams &bp,
                             const BitsOut &o, void *scratch, const ScanState &ss, hipStream_t s);
-// one segment of a streamed pass (see "Segments" in pulse_table.hip)
-int launch_tile_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams &bp, const BitsOut &o, void *scratch,
-                        const ScanState &ss, int64_t *rows, int64_t cap_rows, const TailSegment &sg, const SegPackDst *dst, hipStream_t s);
+// the segments of a streamed pass (see "Segments" in pulse_table.hip): r / e / m / bp / o / scratch / ss as launch_tile_rows and
+// launch_tile_bits take them for the WHOLE capture, with r.d_n_rows = &state->rows_at[last rows segment], r.d_n_rows_needed =
+// &state->rows_needed, r.d_n_acc = &state->n_acc; m.epoch and m.parity the same for every segment of the pass
+int launch_rows_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams &bp, SegState *state, const RowsSegment &sg,
+                        hipStream_t s);
+int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOut &o, void *scratch, const ScanState &ss, int64_t *rows,
+                        int64_t cap_rows, const BitsSegment &sg, const SegPackDst *dst, hipStream_t s);
 // ASK, sharded: summary of the locally merged table {n_rows, first state, first length, last state, last length}
 void launch_merge_summary(const int64_t *rows, const int64_t *d_n_rows, int64_t *d_out5, hipStream_t s);
 // ASK, sharded: merge equal-state rows across shard boundaries (d_all: world x 5 int64)

@@ -772,12 +772,17 @@ struct TileTail {            // scratch of the tile tail (carved from the contex
 // blk0: first resolve workgroup of this launch -- 0 for a whole capture; a SEGMENT of a streamed pass (see "segments" below) covers the
 // workgroups [blk0, blk0 + gridDim.x), its look-ahead into the chunk behind the segment's last one reads a record the hot kernel has
 // already finished (the segment's gate waits for that chunk too)
-__global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs a, const TileTail ft, const int64_t blk0) {
+__global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs a, const TileTail ft, const int64_t blk0, const SegGate gate) {
     URH_TAIL_PRIO();
     __shared__ ResElem s_w[kResolveBlock / 64];
     const int64_t blk = blk0 + blockIdx.x;
     const int64_t c = blk * kResolveBlock + threadIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (gate.seg && gate.init && blockIdx.x == 0 && t == 0) {
+        // the first rows segment of a streamed pass clears what the bits segments carry along (they start behind this kernel)
+        int64_t *w = (int64_t *)&gate.seg->in[0];
+        for (int i = 0; i < (int)(2 * sizeof(SegState::In) / 8); ++i) w[i] = 0;
+    }
     // this pass's (segment's) huge-row counter starts at zero whatever an earlier pass of the same parity left behind (one that failed
     // between its row and its expansion launches never reached the kernel that clears the counter for its successor)
     if (blockIdx.x == 0 && t == 0 && ft.want_bits) ft.huge_count[ft.parity] = 0;
@@ -903,6 +908,11 @@ struct EmitTileArgs {
     int64_t w0, w_end;
     int final_seg;
     SegState *seg;
+    int seg_k;               // rows segment index: seg->rows_at[seg_k] receives the rows that are final after it
+    // a streamed pass ships its rows while it writes them: the compact blob's row_state / row_len sections in pinned HOST memory
+    // (plain stores over PCIe, fire and forget; nullptr: not shipped)
+    int8_t *h_state;
+    int32_t *h_len;
 };
 
 __host__ __device__ static inline int64_t tail_waves(int64_t n_items) { return (n_items + kTailCPW - 1) / kTailCPW; }
@@ -956,10 +966,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
         if (!g.final_seg) {
             // a segment of a streamed pass that is not the last: every accepted run of the chunks so far has its row (a row ends where
             // the next accepted run begins), so rows [0, pre.cnt) are final
-            if (lane == 0) {
-                g.seg->n_acc = pre.cnt; g.seg->rows_needed = pre.cnt;
-                g.seg->n_rows = (r.rows != nullptr && pre.cnt > r.cap_rows) ? r.cap_rows : pre.cnt;
-            }
+            if (lane == 0) g.seg->rows_at[g.seg_k] = (r.rows != nullptr && pre.cnt > r.cap_rows) ? r.cap_rows : pre.cnt;
             return;
         }
         const int64_t c = r.n_chunks;
@@ -979,7 +986,10 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
                 const int64_t fpos = pre.la_valid() ? pre.la_pos : -1;
                 const uint32_t fstate = pre.la_valid() ? pre.la_state() : init_state;
                 const int64_t len = (P == 0) ? (r.n_total - r.tol) : (r.n_total - 1 - fpos - r.tol);
-                if (r.rows != nullptr && o < r.cap_rows) { r.rows[2 * o] = (int64_t)fstate - 1; r.rows[2 * o + 1] = len; }
+                if (r.rows != nullptr && o < r.cap_rows) {
+                    r.rows[2 * o] = (int64_t)fstate - 1; r.rows[2 * o + 1] = len;
+                    if (g.h_state) { g.h_state[o] = (int8_t)((int64_t)fstate - 1); g.h_len[o] = (int32_t)len; }
+                }
                 if (g.ft.want_bits) {
                     v = row_value((int64_t)fstate - 1, len, P == 0, g.bp);
                     if (v.v[0] > kHugeBits) {
@@ -1053,7 +1063,10 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
             const int64_t gi = out_off + j;                  // global row; this GPU's row gi - row_base
             const int64_t len = (gi == 0) ? pos + 1 : pos - ppos;
             const int64_t state = (int64_t)pst - 1;
-            if (gi - row_base < a.cap_rows) *(longlong2 *)(a.rows + 2 * (gi - row_base)) = longlong2{(long long)state, (long long)len};
+            if (gi - row_base < a.cap_rows) {
+                *(longlong2 *)(a.rows + 2 * (gi - row_base)) = longlong2{(long long)state, (long long)len};
+                if (g.h_state) { g.h_state[gi - row_base] = (int8_t)state; g.h_len[gi - row_base] = (int32_t)len; }
+            }
             if (g.ft.want_bits) {
                 const VecK<4> v = row_value(state, len, gi == 0, g.bp);
                 acc_bits += v.v[0];
@@ -1234,6 +1247,10 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
         for (int w = hy; w < cnt; w += kHugeBlocksY) {
             const HugeRef h = a.huge[w];
             __syncthreads();
+            // a bits segment of a streamed pass expands the listed rows of ITS tiles: the rows kernels of later segments may be appending to
+            // the list right now (an entry that is not the row of one of this launch's tiles -- another segment's, or one still being
+            // written -- is skipped; whatever passes the test is expanded from the row itself, so a duplicate is harmless)
+            if (h.tile < a.t_base || h.tile >= a.n_tiles || h.row < a.tile_off[h.tile] || h.row >= a.tile_off[h.tile] + a.tile_cnt[h.tile]) continue;
             if (wave == 0) {
                 // prefix of the row inside its tile: walk the tile's rows before it, 64 at a time
                 VecK<4> run = a.excl[h.tile];
@@ -1593,8 +1610,10 @@ int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem 
     memset(&g.bp, 0, sizeof(g.bp));
     if (bp) { g.bp = *bp; g.ft.want_bits = 1; }
     const unsigned gb = (unsigned)resolve_blocks(r.n_chunks);
-    g.w0 = 0; g.w_end = tail_waves(r.n_chunks); g.final_seg = 1; g.seg = nullptr;
-    hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft, (int64_t)0);
+    g.w0 = 0; g.w_end = tail_waves(r.n_chunks); g.final_seg = 1; g.seg = nullptr; g.seg_k = 0; g.h_state = nullptr; g.h_len = nullptr;
+    SegGate no_gate;
+    memset(&no_gate, 0, sizeof(no_gate));
+    hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft, (int64_t)0, no_gate);
     hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((tail_waves(r.n_chunks) + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
     return URHGPU_OK;
 }
@@ -1677,17 +1696,20 @@ int launch_tile_bits(const TileTailMem &m, const int64_t *rows, const int64_t *d
 //   * per segment the host receives: its rows, the bytes of packed bits that are complete, the positions, and the messages closed.
 // Results are bit-identical to the one-launch tail (tests/test_stream_segments.py compares them on random captures and boundaries).
 // =====================================================================================================
-__global__ void k_seg_gate(const uint32_t *progress, int k, uint32_t target, SegState *seg, int init, long long max_ticks) {
+// The gate of a rows segment: ONE wavefront, first on the tail stream, polls the segment's progress counter (its own 128-byte line) a few
+// times per microsecond until the hot kernel -- still running -- has counted the segment's chunks in; the chunks' records were written
+// through to memory and acknowledged before they counted (demod_runs.hip), and the kernels behind the gate start with an empty cache.
+// (Polling from every workgroup of the resolve kernel instead was measured: 8 to 32 workgroups hammering the counters' line slowed the
+// hot kernel from 0.28 to 0.5 - 0.9 ms.)
+__global__ void k_seg_gate(const SegGate gate) {
     if (threadIdx.x != 0) return;
-    if (init) {
-        int64_t *w = (int64_t *)seg;
-        for (int i = 0; i < (int)(sizeof(SegState) / 8); ++i) w[i] = 0;
-    }
-    if (!progress) return;
+    if (gate.init) gate.seg->err = 0;
+    if (!gate.progress) return;
+    const uint32_t *ctr = gate.progress + gate.k * kProgressStride;
     const long long t0 = (long long)wall_clock64();
-    while (__hip_atomic_load(progress + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(4);
-        if ((long long)wall_clock64() - t0 > max_ticks) { seg->err = 1 + k; break; }       // (the hot kernel was never launched: a bug, not a hang)
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate.target) {
+        __builtin_amdgcn_s_sleep(16);
+        if ((long long)wall_clock64() - t0 > gate.max_ticks) { gate.seg->err = 1 + gate.k; break; }       // (the hot kernel never came: a bug, not a hang)
     }
 }
 
@@ -1709,10 +1731,11 @@ struct SegGroupStore {
         st(g0 + i, val, e);
     }
 };
-// after the segment's group scan: what the next segment starts from, what the pack kernel ships; the last segment: the pass's counts
+// after a bits segment's group scan: what the next one starts from, what the pack kernel ships; the last segment: the pass's counts
 struct SegFinal {
     SegGroupLoad ld;
     SegState *seg;
+    const int64_t *d_n_rows;
     int parity;
     int final;
     BitsCountsFinal counts;
@@ -1724,12 +1747,11 @@ struct SegFinal {
         for (int k = 0; k < 3; ++k) tot.v[k] = in.carry[k] + grand.v[k];
         if (final) {
             counts(tot);
-            const bool any = seg->n_rows > 0;
+            const bool any = *d_n_rows > 0;
             seg->end_msgs = any ? tot.v[0] : 0; seg->end_bits = any ? tot.v[1] : 0; seg->end_pos = any ? tot.v[2] : 0;
             return;
         }
         SegState::In nx = in;
-        nx.ship_rows = seg->n_rows;
         if (nl <= 0) {                                        // no row yet
             seg->end_msgs = 0; seg->end_bits = 0; seg->end_pos = 0;
         } else {
@@ -1753,16 +1775,17 @@ struct SegFinal {
     }
 };
 
-// The segment's share of the compact blob (include/urhgpu.h), stored straight into the pinned host blob: the sections sit at the
+// A bits segment's share of the compact blob (include/urhgpu.h), stored straight into the pinned host blob: the sections sit at the
 // offsets the CAPACITIES give (blob_layout of the capacities), so every segment knows where its elements go and the host needs no
-// assembly; the last segment writes the header.
+// assembly (the rows went there as they were written: k_emit_rows_tiles); the last segment writes the header.
 struct SegPack {
-    const int64_t *rows; const uint8_t *bits; const int64_t *msg_off, *pauses, *pos_off, *pos; const int64_t *counts;
+    const uint8_t *bits; const int64_t *msg_off, *pauses, *pos_off, *pos; const int64_t *counts;
     int64_t cap_rows, cap_bits, cap_msg, cap_pos;
     int has_pos;
     char *host;
     BlobLayout L;            // blob_layout(capacities)
-    SegState *seg;
+    const SegState *seg;
+    const int64_t *d_n_rows;
     int parity, final;
     uint32_t *progress;      // the last segment zeroes the pass's counters for the next pass on this arena
 };
@@ -1771,19 +1794,10 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
     const int64_t gtid = blockIdx.x * 256ll + threadIdx.x, stride = (int64_t)gridDim.x * 256;
     const SegState::In in = a.seg->in[a.parity];
     auto lim = [](int64_t x, int64_t cap) { return x < cap ? (x < 0 ? 0 : x) : cap; };
-    const int64_t r0 = lim(in.ship_rows, a.cap_rows), r1 = lim(a.seg->n_rows, a.cap_rows);
     const int64_t nbits = lim(a.seg->end_bits, a.cap_bits);
     const int64_t j0 = lim(in.ship_bits, a.cap_bits) / 8, j1 = a.final ? (nbits + 7) / 8 : nbits / 8;
     const int64_t p0 = a.has_pos ? lim(in.ship_pos, a.cap_pos) : 0, p1 = a.has_pos ? lim(a.seg->end_pos, a.cap_pos) : 0;
     const int64_t m0 = lim(in.ship_msgs, a.cap_msg), m1 = lim(a.seg->end_msgs, a.cap_msg);
-    {
-        int32_t *len = (int32_t *)(a.host + a.L.off_row_len);
-        int8_t *st = (int8_t *)(a.host + a.L.off_row_state);
-        for (int64_t i = r0 + gtid; i < r1; i += stride) {
-            const longlong2 r = *(const longlong2 *)(a.rows + 2 * i);
-            st[i] = (int8_t)r.x; len[i] = (int32_t)r.y;
-        }
-    }
     {
         uint8_t *out = (uint8_t *)(a.host + a.L.off_bits);
         const unsigned long long *in8 = (const unsigned long long *)a.bits;
@@ -1803,57 +1817,67 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
         if (gtid == 0 && m0 == 0) { mo[0] = 0; po[0] = 0; }
         for (int64_t i = m0 + gtid; i < m1; i += stride) { pa[i] = a.pauses[i]; mo[i + 1] = a.msg_off[i + 1]; po[i + 1] = a.pos_off[i + 1]; }
     }
-    if (gtid == 0) {
-        const int64_t shipped = (r1 - r0) * 5 + (j1 - j0) + (p1 - p0) * 4 + (m1 - m0) * 24;
-        a.seg->pad[0] += shipped;
-        if (a.final) {
-            int64_t *hdr = (int64_t *)a.host;
-            const int64_t *c = a.counts;
-            hdr[1] = r1; hdr[2] = m1; hdr[3] = nbits; hdr[4] = p1; hdr[5] = c[4];
-            hdr[6] = a.seg->pad[0] + URHGPU_BLOB_HEADER_BYTES; hdr[7] = a.has_pos;
-            hdr[8] = a.L.off_pauses; hdr[9] = a.L.off_msg_off; hdr[10] = a.L.off_pos_off; hdr[11] = a.L.off_row_state; hdr[12] = a.L.off_bits;
-            hdr[13] = a.L.off_row_len; hdr[14] = a.L.off_pos32;
-            hdr[15] = ((c[1] > a.cap_msg || c[2] > a.cap_bits || (a.has_pos && c[3] > a.cap_pos) || c[4] > a.cap_rows) ? 1 : 0) | (a.seg->err ? 2 : 0);
-            hdr[0] = URHGPU_BLOB_MAGIC;
-        }
+    if (a.final && gtid == 0) {
+        int64_t *hdr = (int64_t *)a.host;
+        const int64_t *c = a.counts;
+        const int64_t n_rows = lim(*a.d_n_rows, a.cap_rows);
+        hdr[1] = n_rows; hdr[2] = m1; hdr[3] = nbits; hdr[4] = p1; hdr[5] = c[4];
+        hdr[6] = URHGPU_BLOB_HEADER_BYTES + n_rows * 5 + (nbits + 7) / 8 + p1 * 4 + m1 * 24 + 16;     // bytes that crossed PCIe for this pass
+        hdr[7] = a.has_pos;
+        hdr[8] = a.L.off_pauses; hdr[9] = a.L.off_msg_off; hdr[10] = a.L.off_pos_off; hdr[11] = a.L.off_row_state; hdr[12] = a.L.off_bits;
+        hdr[13] = a.L.off_row_len; hdr[14] = a.L.off_pos32;
+        hdr[15] = ((c[1] > a.cap_msg || c[2] > a.cap_bits || (a.has_pos && c[3] > a.cap_pos) || c[4] > a.cap_rows) ? 1 : 0) | (a.seg->err ? 2 : 0);
+        hdr[0] = URHGPU_BLOB_MAGIC;
     }
-    if (a.final && a.progress && gtid < kMaxSegments) a.progress[gtid] = 0;
+    if (a.final && a.progress && gtid < kMaxSegments) a.progress[gtid * kProgressStride] = 0;
 }
 
-size_t seg_state_bytes() { return sizeof(SegState); }
-
-// One segment's kernels on stream s: gate, resolve, rows, tile scan, group scan, expansion, pack.  r / e / m / bp / o / scratch / ss as
-// launch_tile_rows + launch_tile_bits take them for the WHOLE capture (r.n_chunks, m.n_chunks: all chunks), with r.d_n_rows,
-// r.d_n_rows_needed and r.d_n_acc pointing into *sg.state; m.epoch and m.parity the same for every segment of the pass.
-int launch_tile_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams &bp, const BitsOut &o, void *scratch,
-                        const ScanState &ss, int64_t *rows, int64_t cap_rows, const TailSegment &sg, const SegPackDst *dst, hipStream_t s) {
+// A rows segment's two kernels on stream s: resolve (with the gate) and rows (shipped to the host as they are written).
+int launch_rows_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams &bp, SegState *state, const RowsSegment &sg,
+                        hipStream_t s) {
     if (r.n_chunks <= 0 || r.local_pass || r.chunk_first != 0 || e.chunk_first != 0 || r.n_local != r.n_chunks || m.n_chunks != r.n_chunks ||
-        e.is_ask || m.d_row_base != nullptr || !sg.state)
+        e.is_ask || m.d_row_base != nullptr || !state || sg.index < 0 || sg.index >= kMaxSegments)
         return URHGPU_ERR_ARG;
     if (sg.c0 < 0 || sg.c0 % kSegAlign || sg.c1 <= sg.c0 || sg.c1 > r.n_chunks || (sg.final ? sg.c1 != r.n_chunks : (sg.c1 % kSegAlign != 0 || sg.c1 >= r.n_chunks)))
         return URHGPU_ERR_ARG;
     static_assert(kSegAlign % kResolveBlock == 0 && kSegAlign % kScanBlock == 0 && kSegAlign % (kTailCPW * kEmitWaves) == 0, "segment alignment");
-    if (r.d_n_rows != &sg.state->n_rows || r.d_n_rows_needed != &sg.state->rows_needed) return URHGPU_ERR_ARG;
+    if (sg.final && (r.d_n_rows != &state->rows_at[sg.index] || r.d_n_rows_needed != &state->rows_needed)) return URHGPU_ERR_ARG;
+    if ((sg.h_state == nullptr) != (sg.h_len == nullptr) || sg.gate.seg != state) return URHGPU_ERR_ARG;
+    const TileCarve tc = carve_tile(m);
+    EmitTileArgs g;
+    g.e = e; g.r = r; g.ft = tc.ft; g.huge = tc.huge; g.huge_cap = kTileHugeCap;
+    g.bp = bp; g.ft.want_bits = 1;
+    g.w0 = sg.c0 / kTailCPW; g.w_end = sg.final ? tail_waves(r.n_chunks) : sg.c1 / kTailCPW; g.final_seg = sg.final; g.seg = state; g.seg_k = sg.index;
+    g.h_state = sg.h_state; g.h_len = sg.h_len;
+    // the huge-row list is consumed by the bits segment that covers these tiles, which may cover several rows segments: only the pass's
+    // first rows segment starts the list (k_resolve_one clears the counter when want_bits is set)
+    TileTail ft_resolve = g.ft;
+    if (sg.index != 0) ft_resolve.want_bits = 0;
+    if (sg.gate.progress || sg.gate.init) hipLaunchKernelGGL(k_seg_gate, dim3(1), dim3(64), 0, s, sg.gate);
+    hipLaunchKernelGGL(k_resolve_one, dim3((unsigned)resolve_blocks(sg.c1 - sg.c0)), dim3(kResolveBlock), 0, s, r, ft_resolve, sg.c0 / kResolveBlock, sg.gate);
+    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((g.w_end - g.w0 + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
+    return URHGPU_OK;
+}
+
+// A bits segment's kernels on stream s (which has waited for the rows of the chunks below sg.c1): tile scan, group scan, expansion, pack.
+int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOut &o, void *scratch, const ScanState &ss, int64_t *rows,
+                        int64_t cap_rows, const BitsSegment &sg, const SegPackDst *dst, hipStream_t s) {
+    if (m.n_chunks <= 0 || m.d_row_base != nullptr || !sg.state || sg.rows_index < 0 || sg.rows_index >= kMaxSegments) return URHGPU_ERR_ARG;
+    if (sg.c0 < 0 || sg.c0 % kSegAlign || sg.c1 <= sg.c0 || sg.c1 > m.n_chunks || (sg.final ? sg.c1 != m.n_chunks : (sg.c1 % kSegAlign != 0 || sg.c1 >= m.n_chunks)))
+        return URHGPU_ERR_ARG;
     if (cap_rows <= 0) cap_rows = 1;
     const int64_t cap_desc = tile_desc_cap(cap_rows, m.n_chunks);
     if (ss.desc_bytes < bits_desc_bytes(cap_desc)) return URHGPU_ERR_ARG;
     const TileCarve tc = carve_tile(m);
     const BitsScratch b = carve_bits(scratch, cap_rows);
     SegState *st = sg.state;
+    const int64_t *d_n_rows = &st->rows_at[sg.rows_index];
     const int parity = sg.index & 1;
-    hipLaunchKernelGGL(k_seg_gate, dim3(1), dim3(64), 0, s, sg.progress, sg.index, sg.target, st, sg.index == 0 ? 1 : 0, (long long)200000000);   // 2 s at 100 MHz
-    // resolve + rows
-    EmitTileArgs g;
-    g.e = e; g.r = r; g.ft = tc.ft; g.huge = tc.huge; g.huge_cap = kTileHugeCap;
-    g.bp = bp; g.ft.want_bits = 1;
-    g.w0 = sg.c0 / kTailCPW; g.w_end = sg.final ? tail_waves(r.n_chunks) : sg.c1 / kTailCPW; g.final_seg = sg.final; g.seg = st;
-    hipLaunchKernelGGL(k_resolve_one, dim3((unsigned)resolve_blocks(sg.c1 - sg.c0)), dim3(kResolveBlock), 0, s, r, g.ft, sg.c0 / kResolveBlock);
-    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((g.w_end - g.w0 + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
     // tile scan over the segment's tiles (the last segment: + the tile of the table's last row)
-    const int64_t t1 = sg.final ? r.n_chunks + 1 : sg.c1;
+    const int64_t t1 = sg.final ? m.n_chunks + 1 : sg.c1;
     const int64_t cap_groups = cap_rows + 1;
     GranDesc *tdesc = (GranDesc *)m.rdesc + resolve_blocks(m.n_chunks) + 2;
-    TileScanArgs ta{rows, &st->n_rows, tc.ft.agg, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, &st->n_groups, t1, bp, tdesc,
+    TileScanArgs ta{rows, d_n_rows, tc.ft.agg, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, &st->n_groups, t1, bp, tdesc,
                     m.epoch, sg.c0 / kScanBlock, st, parity};
     hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((t1 - sg.c0 + kScanBlock - 1) / kScanBlock)), dim3(kScanBlock), 0, s, ta);
     // groups [the one that was open before this segment, the one that is open now]
@@ -1862,21 +1886,22 @@ int launch_tile_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailM
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     SegGroupLoad sl{gl, st, parity};
     SegGroupStore sst{gs, st, parity};
-    SegFinal fin{sl, st, parity, sg.final ? 1 : 0, BitsCountsFinal{&st->n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, &st->rows_needed, o.h_counts}};
+    SegFinal fin{sl, st, d_n_rows, parity, sg.final ? 1 : 0, BitsCountsFinal{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, &st->rows_needed, o.h_counts}};
     hipLaunchKernelGGL((k_scan_lookback<3, SegGroupLoad, SegGroupStore, SegFinal, kGroupItems>), dim3((unsigned)std::min<int64_t>(scan_grid(b.nbg), 32)),
                        dim3(kScanBlock), 0, s, &st->n_groups_local, sl, desc3, b.nbg, sst, fin, ++*ss.epoch, ss.tickets + 2, 0);
-    ExpandTileArgs ea{rows, &st->n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, &st->n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
+    ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, &st->n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
                       bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, t1, sg.c0};
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(t1 - sg.c0);
     hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     if (dst && dst->host) {
-        if (((uintptr_t)o.bits & 7) || ((uintptr_t)rows & 15) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
+        if (((uintptr_t)o.bits & 7) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
         const int has_pos = (bp.write_pos && o.pos) ? 1 : 0;
         const int64_t caps[5] = {cap_rows, o.cap_msg, o.cap_bits, o.cap_pos, cap_rows};
-        SegPack pk{rows, o.bits, o.msg_off, o.pauses, o.pos_off, o.pos, o.counts, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos, (char *)dst->host,
-                   blob_layout(caps, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos), st, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr};
+        SegPack pk{o.bits, o.msg_off, o.pauses, o.pos_off, o.pos, o.counts, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos, (char *)dst->host,
+                   blob_layout(caps, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos), st, d_n_rows, parity, sg.final ? 1 : 0,
+                   sg.final ? dst->progress_reset : nullptr};
         if (dst->cap_host < pk.L.total) return URHGPU_ERR_CAPACITY;
-        hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 64), dim3(256), 0, s, pk);
+        hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 32), dim3(256), 0, s, pk);
     }
     return URHGPU_OK;
 }

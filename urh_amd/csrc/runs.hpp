@@ -32,6 +32,7 @@ constexpr uint32_t kStPause = 0;
 constexpr uint32_t kStNone = 0xFF;
 constexpr int kMaxOrder = 128;                 // bits_per_symbol <= 7
 constexpr int kMaxSegments = 16;               // segments of a streamed pass (segmented tail, pulse_table.hip)
+constexpr int kProgressStride = 32;            // uint32 words between two segments' progress counters: a 128-byte line each
 
 // One accepted/stable run start: sample position | state byte << 56.
 __host__ __device__ inline uint64_t rec_make(int64_t pos, uint32_t st) { return (uint64_t)pos | ((uint64_t)st << 56); }

@@ -268,7 +268,7 @@ int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out)
     }
     // a streamed pass's blob is complete a moment before its hot kernel has retired (the last qad stores): d_qad of the results handed
     // out here is read by the caller next
-    if (st->streamed_passes > 0) URH_TRY(urhgpu_ctx_sync(st->ctx));
+    if (st->streamed_passes > 0 && st->ctx->tail_pending) URH_HIP(hipEventSynchronize(st->ctx->ev_tail[(st->ctx->flip + 2) % 3]));
     return URHGPU_OK;
 }
 
