@@ -259,12 +259,21 @@ typedef struct urhgpu_outputs {
  *   uint8 bits[(n_bits + 7) / 8]   eight bits per byte, most significant first (numpy.packbits / unpackbits order)
  *   int32 row_len[n_rows]     (grab_pulse_lens' column 1; captures of up to 2^31 - 1 samples)
  *   uint32 pos32[n_pos]       (bit_sample_pos; absent when the pass wrote no positions)
- * truncated != 0: a capacity was exceeded (rows_needed > cap_rows, or more messages / bits / positions than fit): the sections hold
- * what fitted, the caller repeats the pass with larger capacities.  The counts come first (40 bytes from `counts`), then ONE copy of
+ * truncated != 0: bit 0: a capacity was exceeded (rows_needed > cap_rows, or more messages / bits / positions than fit): the sections
+ * hold what fitted, the caller repeats the pass with larger capacities; bit 2: a row length did not fit int32, a position uint32 or a
+ * state int8 (captures of 2^31 samples and more; sharded captures whose positions are absolute): use the wide outputs; bit 1: a
+ * streamed pass's segment gave up waiting for the hot kernel (urhgpu_stream_* reports that as an error).  The counts come first (40 bytes from `counts`), then ONE copy of
  * total_bytes moves everything; urhgpu_stream_* below does that overlapped with the following passes. */
 #define URHGPU_BLOB_MAGIC INT64_C(0x55524842424C4F42) /* "URHBBLOB" */
 #define URHGPU_BLOB_HEADER_BYTES 128
 int64_t urhgpu_blob_capacity(int64_t cap_rows, int64_t cap_bits, int64_t cap_msg, int64_t cap_pos, int has_pos);
+
+/* The results of a pass that is over, on the host through the compact blob: out = the descriptor the pass was given with out->blob /
+ * cap_blob naming a device blob (the pass itself need not have packed it); pack kernel, header, ONE copy of header.total_bytes into
+ * host_dst (pinned memory: at PCIe speed).  *total_bytes = the blob's size (also on URHGPU_ERR_CAPACITY: cap_dst too small).
+ * Synchronous.  What the boundary objects fetch (urh_amd.pipeline.BitsResult.host(), urh_amd.signal.Signal.bits()) instead of the
+ * wide int64 tables; reference shape: ProtocolAnalyzer.py:227-287, :323-414. */
+int urhgpu_outputs_to_host(urhgpu_ctx *ctx, const urhgpu_outputs *out, int write_pos, void *host_dst, int64_t cap_dst, int64_t *total_bytes);
 
 /* afp_demod on device memory (ASK/FSK/OTHER: one streaming kernel; PSK: Costas loop). */
 int urhgpu_afp_demod_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad);

@@ -99,6 +99,8 @@ PROTOTYPES = {
     "urhgpu_ppseq_to_bits_dev": (_i, [_vp, _vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
     "urhgpu_iq_to_bits_dev": (_i, [_vp, _vp, _i64, C.POINTER(Params), C.POINTER(Outputs)]),
     "urhgpu_blob_capacity": (_i64, [_i64, _i64, _i64, _i64, _i]),
+    "urhgpu_outputs_to_host": (_i, [_vp, C.POINTER(Outputs), _i, _vp, _i64, C.POINTER(_i64)]),
+    "urhgpu_host_libm_check": (_i, [C.POINTER(_i64)]),
     "urhgpu_stream_capacities": (_i, [_i64, C.POINTER(Params), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "urhgpu_stream_create": (_i, [_vp, _i64, C.POINTER(Params), _i, _i, _i64, C.POINTER(_vp)]),
     "urhgpu_stream_destroy": (_i, [_vp]),
@@ -198,6 +200,14 @@ def load():
                 fn.argtypes = args
             _lib = lib
     return _lib
+
+
+def host_libm_check():
+    """urhgpu_host_libm_check: {sincosf compared, mismatches, atan2f compared, mismatches} -- does the reference on THIS host call the libm
+    the device code restates (include/urhgpu.h)?  Host arithmetic: works without a GPU."""
+    out = (C.c_int64 * 4)()
+    check(load().urhgpu_host_libm_check(out))
+    return {"sincosf_compared": int(out[0]), "sincosf_mismatches": int(out[1]), "atan2f_compared": int(out[2]), "atan2f_mismatches": int(out[3])}
 
 
 def check(status: int):

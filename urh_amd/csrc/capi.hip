@@ -1028,6 +1028,28 @@ int urhgpu_iq_to_bits_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
     return st;
 }
 
+// The results of a pass that is over (out: the descriptor the pass was given, with out->blob / cap_blob naming a device blob), on the
+// host: pack kernel, the header, then ONE copy of header.total_bytes -- what the boundary objects (Signal.bits(), BitsResult.ppseq() ...)
+// fetch instead of the wide int64 tables.  host_dst: pinned memory (hipHostMalloc / torch pin_memory) for an asynchronous copy at PCIe
+// speed; pageable memory works (the runtime stages it).  Synchronous.
+int urhgpu_outputs_to_host(urhgpu_ctx *ctx, const urhgpu_outputs *out, int write_pos, void *host_dst, int64_t cap_dst, int64_t *total_bytes) {
+    if (!ctx || !out || !out->blob || !host_dst || !total_bytes || cap_dst < URHGPU_BLOB_HEADER_BYTES) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(launch_pack_blob(out, write_pos, ctx->stream));
+    URH_HIP(hipGetLastError());
+    int64_t *hdr = ctx->h_small ? (int64_t *)ctx->h_small : (int64_t *)host_dst;
+    URH_HIP(hipMemcpyAsync(hdr, out->blob, URHGPU_BLOB_HEADER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    if (hdr[0] != URHGPU_BLOB_MAGIC) return URHGPU_ERR_ARG;
+    const int64_t total = hdr[6] < 0 ? -hdr[6] : hdr[6];
+    *total_bytes = total;
+    if (hdr[6] < 0 || total > cap_dst) return URHGPU_ERR_CAPACITY;
+    URH_HIP(hipMemcpyAsync(host_dst, out->blob, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
 int64_t urhgpu_blob_capacity(int64_t cap_rows, int64_t cap_bits, int64_t cap_msg, int64_t cap_pos, int has_pos) {
     if (cap_rows < 0 || cap_bits < 0 || cap_msg < 0 || cap_pos < 0) return 0;
     return urh::blob_capacity(cap_rows, cap_bits, cap_msg, cap_pos, has_pos ? 1 : 0);

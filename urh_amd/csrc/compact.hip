@@ -36,8 +36,11 @@ __global__ __launch_bounds__(256) void k_pack_blob(const PackArgs a) {
         hdr[6] = fits ? L.total : -L.total; hdr[7] = a.has_pos;
         hdr[8] = L.off_pauses; hdr[9] = L.off_msg_off; hdr[10] = L.off_pos_off; hdr[11] = L.off_row_state; hdr[12] = L.off_bits;
         hdr[13] = L.off_row_len; hdr[14] = L.off_pos32;
-        hdr[15] = (a.counts[1] > a.cap_msg || a.counts[2] > a.cap_bits || (a.has_pos && a.counts[3] > a.cap_pos) || a.counts[4] > a.cap_rows) ? 1 : 0;   // truncated
+        // truncated (bit 0); bit 2 (a value that does not fit its narrow type) is OR-ed in below: the launcher has zeroed the word
+        if (a.counts[1] > a.cap_msg || a.counts[2] > a.cap_bits || (a.has_pos && a.counts[3] > a.cap_pos) || a.counts[4] > a.cap_rows)
+            atomicOr((unsigned long long *)&hdr[15], 1ull);
     }
+    bool narrow_fail = false;
     if (!fits) return;                                     // (cannot happen with a blob of blob_capacity bytes)
     // bits: eight bytes in, one byte out; the bits beyond n_bits of the last byte are zero
     {
@@ -57,12 +60,18 @@ __global__ __launch_bounds__(256) void k_pack_blob(const PackArgs a) {
         for (int64_t i = gtid; i < L.n_rows; i += stride) {
             const longlong2 r = *(const longlong2 *)(a.rows + 2 * i);
             st[i] = (int8_t)r.x; len[i] = (int32_t)r.y;
+            narrow_fail |= (r.x < -128 || r.x > 127 || r.y < 0 || r.y > 0x7fffffffll);
         }
     }
     if (a.has_pos) {
         uint32_t *p32 = (uint32_t *)(a.blob + L.off_pos32);
-        for (int64_t i = gtid; i < L.n_pos; i += stride) p32[i] = (uint32_t)a.pos[i];
+        for (int64_t i = gtid; i < L.n_pos; i += stride) {
+            const int64_t v = a.pos[i];
+            p32[i] = (uint32_t)v;
+            narrow_fail |= (v < 0 || v > 0xffffffffll);
+        }
     }
+    if (narrow_fail) atomicOr((unsigned long long *)&hdr[15], 4ull);
     {
         int64_t *pa = (int64_t *)(a.blob + L.off_pauses), *mo = (int64_t *)(a.blob + L.off_msg_off), *po = (int64_t *)(a.blob + L.off_pos_off);
         for (int64_t i = gtid; i <= L.n_msg; i += stride) {
@@ -84,6 +93,7 @@ int launch_pack_blob(const urhgpu_outputs *o, int write_pos, hipStream_t s) {
 #ifndef URH_PACK_BLOCKS
 #define URH_PACK_BLOCKS 512
 #endif
+    if (hipMemsetAsync((char *)o->blob + 15 * 8, 0, 8, s) != hipSuccess) return URHGPU_ERR_HIP;       // header[15]: the kernel ORs its flags in
     hipLaunchKernelGGL(k_pack_blob, dim3(URH_PACK_BLOCKS), dim3(256), 0, s, a);
     return URHGPU_OK;
 }

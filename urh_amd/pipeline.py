@@ -79,13 +79,48 @@ def _torch_dtype(t):
 class BitsResult:
     """Device-resident outputs of one IQ->bits pass (torch tensors) + lazy host views."""
 
-    def __init__(self, qad, rows, bits, msg_off, pauses, pos, pos_off, counts, params, ctx=None):
+    def __init__(self, qad, rows, bits, msg_off, pauses, pos, pos_off, counts, params, ctx=None, pipe=None, outputs=None):
         self.qad, self.rows_buf, self.bits_buf = qad, rows, bits
         self.msg_off_buf, self.pauses_buf, self.pos_buf, self.pos_off_buf = msg_off, pauses, pos, pos_off
         self.counts = counts
         self.params = params
         self._host_counts = None
         self._ctx = ctx
+        self._pipe, self._outputs = pipe, outputs          # the pipeline and the C descriptor of the pass: host() packs through them
+        self._hostbits = None
+
+    def host(self, pool=None) -> "HostBits":
+        """The results ON THE HOST through the compact blob (include/urhgpu.h): one more kernel packs them (5 B per pulse-table row, one bit
+        per bit, 4 B per position), ONE copy into pinned memory moves them -- instead of five synchronous pageable copies of the wide int64
+        tables (28 ms for a million rows; this: well under a millisecond).  pool: a dict owned by the caller that keeps the pinned buffer
+        (the HostBits views it: valid until the next host() with the same pool); default: a buffer of the pipeline, valid until its next
+        host() call."""
+        if self._hostbits is not None and pool is None:
+            return self._hostbits
+        if self._pipe is None or self._outputs is None:
+            raise ValueError("this result was not made by a DevicePipeline pass")
+        pipe, o = self._pipe, self._outputs
+        torch = pipe.torch
+        has_pos = self.pos_buf is not None
+        cap = int(_lib.load().urhgpu_blob_capacity(int(o.cap_rows), int(o.cap_bits), int(o.cap_msg), int(o.cap_pos), 1 if has_pos else 0))
+        dblob = pipe._buf("blob", (cap,), torch.uint8)
+        keep = pipe._pinned if pool is None else pool
+        hbuf = keep.get("blob")
+        if hbuf is None or hbuf.numel() < cap:
+            hbuf = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            keep["blob"] = hbuf
+        o2 = _lib.Outputs()
+        C.memmove(C.byref(o2), C.byref(o), C.sizeof(_lib.Outputs))
+        o2.blob = dblob.data_ptr(); o2.cap_blob = cap
+        total = C.c_int64(0)
+        pipe.ctx.set_stream(torch.cuda.current_stream(pipe.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_outputs_to_host(pipe.ctx.handle, C.byref(o2), 1 if has_pos else 0, C.c_void_p(hbuf.data_ptr()), cap, C.byref(total)))
+        h = HostBits.from_blob(hbuf.data_ptr(), self.params, n_samples=int(self.qad.shape[0]) if self.qad is not None else 0,
+                               d_qad=self.qad.data_ptr() if self.qad is not None else 0)
+        h._keep = hbuf
+        if pool is None:
+            self._hostbits = h
+        return h
 
     def host_counts(self):
         """(n_rows, n_msg, n_bits, n_pos): one 32-byte D2H copy (synchronises)."""
@@ -104,13 +139,23 @@ class BitsResult:
             raise _lib.UrhGpuError(_lib.ERR_CAPACITY, f"output capacity too small: rows={self._rows_needed} msgs={n_msg} "
                                                       f"bits={n_bits} pos={n_pos}")
 
+    def _through_blob(self):
+        return self._pipe is not None and self._outputs is not None
+
     def ppseq(self) -> np.ndarray:
+        if self._through_blob():
+            return self.host().check().ppseq()
         self.check_capacity()             # an overflowing table is clamped to cap_rows on the device: never hand that out
         n_rows = self.host_counts()[0]
         return self.rows_buf[:n_rows].cpu().numpy()
 
     def flat(self):
-        """(bits u8, msg_off i64, pauses i64, pos i64, pos_off i64) on the host."""
+        """(bits u8, msg_off i64, pauses i64, pos i64, pos_off i64) on the host (fresh arrays: they outlive the pipeline's buffers)."""
+        if self._through_blob():
+            h = self.host().check()
+            if self.pos_buf is None:
+                return h.bits(), h.msg_off.copy(), h.pauses.copy(), np.zeros(0, np.int64), h.pos_off.copy()
+            return h.flat()
         self.check_capacity()
         _, n_msg, n_bits, n_pos = self.host_counts()
         bits = self.bits_buf[:n_bits].cpu().numpy()
@@ -160,6 +205,52 @@ class BitsResult:
     def plain_bits_str(self):
         data, _, _ = self.messages()
         return ["".join(map(str, d)) for d in data]
+
+
+class LazyDigitized:
+    """(ppseq, bits, msg_off, pauses, pos, pos_off) of one digitisation as a sequence whose members are widened to the reference's
+    types when somebody looks: what crossed PCIe is the compact blob (a HostBits over pinned memory), and a caller that only wants
+    the bits never pays for the int64 pulse table.  materialize() widens everything and lets go of the pinned buffer."""
+
+    def __init__(self, host: "HostBits", want_pos: bool = True):
+        self._h = host.check()
+        self._want_pos = want_pos
+        self._v = [None] * 6
+
+    def _get(self, i):
+        if self._v[i] is None:
+            h = self._h
+            if i == 0:
+                self._v[0] = h.ppseq()
+            elif i == 1:
+                self._v[1] = h.bits()
+            elif i == 2:
+                self._v[2] = h.msg_off.copy()
+            elif i == 3:
+                self._v[3] = h.pauses.copy()
+            elif i == 4:
+                self._v[4] = h.bit_sample_pos() if self._want_pos else np.zeros(0, np.int64)
+            else:
+                self._v[5] = h.pos_offsets() if self._want_pos else h.pos_off.copy()
+        return self._v[i]
+
+    def materialize(self):
+        if self._h is not None:
+            for i in range(6):
+                self._get(i)
+            self._h = None
+        return self
+
+    def __len__(self):
+        return 6
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return tuple(self._get(i) for i in range(*k.indices(6)))
+        return self._get(range(6)[k])
+
+    def __iter__(self):
+        return (self._get(i) for i in range(6))
 
 
 class HostBits:
@@ -369,6 +460,7 @@ class DevicePipeline:
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.ctx = _lib.Context(self.device.index)
         self._bufs = {}
+        self._pinned = {}                                   # pinned host buffers of BitsResult.host()
         self.tail_stream = None
         for key, value in (tuning or {}).items():
             self.ctx.set_tuning(key, value)
@@ -448,7 +540,7 @@ class DevicePipeline:
         o.counts = counts.data_ptr()
         self.ctx.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(_lib.load().urhgpu_iq_to_bits_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, C.byref(cp), C.byref(o)))
-        return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, self.ctx)
+        return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, self.ctx, pipe=self, outputs=o)
 
     def iq_to_bits_checked(self, iq, p: DemodParams, want_qad=True) -> BitsResult:
         """iq_to_bits with the output capacities verified (one 40-byte read-back) and, if the default capacities were
@@ -505,7 +597,7 @@ class DevicePipeline:
         o.pos_off = pos_off.data_ptr(); o.counts = counts.data_ptr()
         _lib.check(lib.urhgpu_ppseq_to_bits_dev(self.ctx.handle, C.c_void_p(rows.data_ptr()), C.c_void_p(n_rows.data_ptr()), cap_rows, C.byref(cp),
                                                 C.byref(o)))
-        return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, None)
+        return BitsResult(qad, rows, bits, msg_off, pauses, pos, pos_off, counts, p, None, pipe=self, outputs=o)
 
     def afp_demod(self, iq, p: DemodParams):
         torch = self.torch

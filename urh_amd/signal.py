@@ -191,10 +191,23 @@ class Signal:
                     self._bits, self._bits_key = self._detach(res), self._slice_key()
         return self._qad
 
-    @staticmethod
-    def _detach(res):
-        """host copies of the compact outputs (the pipeline's output buffers are overwritten by the next pass)"""
-        return (res.ppseq().copy(),) + tuple(x.copy() for x in res.flat())
+    def _detach(self, res):
+        """The pass's results on the host (the pipeline's output buffers are overwritten by the next pass): ONE pinned copy of the compact
+        blob (BitsResult.host) into a buffer of this Signal's; the reference-shaped arrays -- int64 pulse table, a byte per bit, int64
+        positions -- are made from it when somebody asks (LazyDigitized).  Two pinned buffers alternate: a digitisation that is still
+        referenced when its buffer comes up for reuse is widened first."""
+        import weakref
+        from .pipeline import LazyDigitized
+        pools = self.__dict__.setdefault("_host_pools", [{}, {}])
+        users = self.__dict__.setdefault("_host_users", [None, None])
+        k = self.__dict__.get("_host_turn", 0)
+        self.__dict__["_host_turn"] = k ^ 1
+        old = users[k]() if users[k] is not None else None
+        if old is not None:
+            old.materialize()
+        out = LazyDigitized(res.host(pool=pools[k]), want_pos=res.pos_buf is not None)
+        users[k] = weakref.ref(out)
+        return out
 
     def qad_host(self) -> np.ndarray:
         return self.qad.cpu().numpy()
@@ -216,7 +229,7 @@ class Signal:
             z = np.zeros(0, np.int64)
             return (np.zeros((0, 2), np.int64), np.zeros(0, np.uint8), np.zeros(1, np.int64), z, z, np.zeros(1, np.int64))
         res = self._digitize_dev(q, p)
-        out = (res.ppseq().copy(),) + tuple(x.copy() for x in res.flat())
+        out = self._detach(res)
         self._bits, self._bits_key = out, self._slice_key()
         return out
 
