@@ -105,6 +105,7 @@ def tuning_from_env():
     if "URH_HOT_CUS_REMOVED" in e:
         t["hot_cus_removed_per_xcd"] = int(e["URH_HOT_CUS_REMOVED"])
     for env, key in (("URH_STREAM_SEGMENTS", "stream_segments"), ("URH_STREAM_SHAPE", "stream_shape"), ("URH_PACK_BLOCKS", "pack_blocks"),
+                     ("URH_STREAM_LAST_UNITS", "stream_last_units"), ("URH_UPLOAD_PIECES", "upload_pieces"), ("URH_STREAM_FUSE_GATE", "stream_fuse_gate"), ("URH_STREAM_FINAL_ON_ROWS", "stream_final_on_rows"),
                      ("URH_STREAM_BITS_SEGMENTS", "stream_bits_segments"), ("URH_STREAM_POLICY", "stream_policy")):
         if env in e:
             t[key] = int(e[env])
@@ -552,6 +553,7 @@ def main():
     ap.add_argument("--no-d2h", action="store_true", help="skip the D2H-inclusive measurements (profiling runs: their passes overlap copies)")
     ap.add_argument("--no-device-loop", action="store_true", help="profiling runs: only the capture-stream loop (no run without positions, no device-only loop)")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[2] and configs[4] at full size (they add about a minute)")
+    ap.add_argument("--no-upload", action="store_true", help="skip the H2D-inclusive measurement (1 GiB of pinned host memory)")
     ap.add_argument("--fir-halo", action="store_true", help="N > 1: prepend the 64-tap FIR with halo exchange (configs[3] 'FIR-halo' variant)")
     ap.add_argument("--pipeline", action="store_true",
                     help="(default) software-pipeline consecutive steps: the hot kernel of step i+1 on the main stream while the tail of "
@@ -741,7 +743,9 @@ def main():
             one.append(time.perf_counter() - t_l)
         ramp_passes = ramp(lambda: stream_steps(10))
         torch.cuda.synchronize()
-        pipe.ctx.profile_begin(0 if os.environ.get("URH_BENCH_NO_PROFILE") else args.steps)
+        # (no timing events in this loop: the dispatch-attached pair costs 5-7 us per pass while a profile record is open; the hot kernel's
+        # duration is measured in the device-only loop below, whose event timing agrees with rocprofv3 -- URH_BENCH_HEADLINE_EVENTS=1: here)
+        pipe.ctx.profile_begin(args.steps if os.environ.get("URH_BENCH_HEADLINE_EVENTS") else 0)
         t0 = time.perf_counter()
         results = stream_steps(args.steps)                   # K pushes, then the copies still in flight: ends with the last byte on the host
         torch.cuda.synchronize()
@@ -778,6 +782,40 @@ def main():
         if want_qad and last_host.d_qad_ptr:
             qad_host = np.empty(n, np.float32)
             _ulib.check(_ulib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(last_host.d_qad_ptr), qad_host.ctypes.data_as(C.c_void_p), n * 4))
+        # ---- one capture that starts ON THE HOST (pinned memory): bare H2D copy of the capture against upload + demodulation + results on
+        # the host, the pieces demodulated as they land (urhgpu_stream_push_upload) -- SURVEY 8(d): "report H2D-inclusive time separately"
+        if not args.no_upload:
+            try:
+                pinned = torch.empty(iq.shape, dtype=iq.dtype, pin_memory=True)
+                pinned.copy_(iq)
+                dst = torch.empty_like(iq)
+                torch.cuda.synchronize()
+                bare, incl = [], []
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    t_l = time.perf_counter()
+                    dst.copy_(pinned, non_blocking=True)
+                    torch.cuda.synchronize()
+                    bare.append(time.perf_counter() - t_l)
+                for _ in range(4):
+                    dst.zero_()
+                    torch.cuda.synchronize()
+                    t_l = time.perf_counter()
+                    st.push_upload(pinned, dst)
+                    up = st.flush()
+                    incl.append(time.perf_counter() - t_l)
+                up_host = up[-1].check()
+                same = (up_host.n_rows, up_host.n_msg, up_host.n_bits) == (last_host.n_rows, last_host.n_msg, last_host.n_bits) and \
+                    bool(np.array_equal(up_host.ppseq(), host_copy["ppseq"]) and np.array_equal(up_host.bits(), host_copy["flat"][0]))
+                stream_rec.update({"bare_pinned_h2d_ms": round(min(bare) * 1e3, 3), "h2d_inclusive_ms": round(min(incl) * 1e3, 3),
+                                   "h2d_inclusive_over_bare": round(min(incl) / min(bare), 4),
+                                   "h2d_gbs": round(n * 8 / min(bare) / 1e9, 1),
+                                   "h2d_inclusive_equals_resident_result": same,
+                                   "h2d_inclusive_what": "pinned host capture -> urhgpu_stream_push_upload (pieces copied and demodulated as they land) -> "
+                                                         "compact outputs in pinned host memory; min of 4, against the bare copy of the same 1 GiB"})
+                del pinned, dst, up, up_host
+            except Exception as exc:                          # (a box without 1 GiB of pinnable memory: the line says so)
+                stream_rec["h2d_inclusive_error"] = repr(exc)[:200]
         st.close()
         # the same with bit_sample_pos computed on the device and shipped (uint32 per bit: 8.9 MB per GiB instead of 3.5)
         if not args.no_device_loop:
@@ -819,7 +857,7 @@ def main():
         ramp_passes = ramp(lambda: host_steps(10))
         dist.barrier()
         torch.cuda.synchronize()
-        pipe.ctx.profile_begin(0 if os.environ.get("URH_BENCH_NO_PROFILE") else args.steps)
+        pipe.ctx.profile_begin(args.steps if os.environ.get("URH_BENCH_HEADLINE_EVENTS") else 0)
         t0 = time.perf_counter()
         host_piece = host_steps(args.steps).check()
         torch.cuda.synchronize()
@@ -849,7 +887,8 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    pipe.ctx.profile_begin(0 if (os.environ.get("URH_BENCH_NO_PROFILE") or use_stream or sharded_host) else args.steps)
+    kernel_from_device_loop = not kernel_ms and not os.environ.get("URH_BENCH_NO_PROFILE") and args_steps_dev == args.steps
+    pipe.ctx.profile_begin(args.steps if kernel_from_device_loop else 0)
     t0 = time.perf_counter()
     res = device_steps(args_steps_dev)
     torch.cuda.synchronize()
@@ -857,7 +896,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if not use_stream and not sharded_host:
+    if kernel_from_device_loop:
         kernel_ms = pipe.ctx.profile_end()
     else:
         pipe.ctx.profile_end()
@@ -934,7 +973,7 @@ def main():
                        if world == 1 else f"configs[3]-style: {world} GiB complex64 2-FSK sharded sample-contiguously over {world} GPUs"
                        + (" with the 64-tap FIR (63-sample halo exchange) in front" if fir_taps is not None else ""),
                        "capture": capture,
-                       "timed_region": ("K steps through urhgpu_stream_*: IQ resident in HBM -> qad (HBM) + pulse table + bits + pauses + bit_sample_pos -> "
+                       "timed_region": ("K steps through urhgpu_stream_*: IQ resident in HBM -> qad (HBM) + pulse table + bits + pauses -> "
                                         "compact blob -> pinned host memory; hot kernel of step i, tail of step i - 1 and D2H copy of step i - 2 overlap; "
                                         "the region ends when the last step's copy has arrived (SURVEY 8(d) window)") if use_stream else
                                        ("K sharded steps per rank: IQ shard resident in HBM -> qad (HBM) + this rank's piece of pulse table / bits / pauses "
@@ -942,7 +981,10 @@ def main():
                                         "region ends when every rank holds its last blob (SURVEY 8(d) window per rank)") if sharded_host else
                                        "K device-resident steps (outputs left in HBM)",
                        "samples_per_gpu": n, "samples_per_symbol": sps, "tolerance": tol, "noise_sigma": 0.05,
-                       "outputs": "qad+ppseq+bits+pauses+bit_sample_pos" if want_qad else "ppseq+bits+pauses+bit_sample_pos",
+                       "outputs": (("qad (HBM) + " if want_qad else "") + "pulse table + bits + pauses + message offsets on the host; bit_sample_pos NOT shipped in the "
+                                   "headline steps (derived on the host from the shipped pulse table when asked for: HostBits.bit_sample_pos, compared with the "
+                                   "reference's in `parity`); shipped as uint32 in ms_per_step_with_device_positions") if (use_stream or sharded_host) else
+                                  (("qad+" if want_qad else "") + "ppseq+bits+pauses+bit_sample_pos, left in HBM"),
                        "rows": counts[0], "messages": counts[1], "bits": counts[2],
                        "steps_pipelined": args.pipeline, "clock_ramp_passes_before_timing": ramp_passes,
                        "device_only_ms_per_step": round(device_only_ms, 4),
@@ -959,7 +1001,10 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
                          "traffic_source": traffic_src, "algorithmic_bytes": n * bytes_per_sample,
                          "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_sample": bytes_per_sample,
-                         "kernel_timing": "HIP events attached to the kernel's dispatch, inside the timed region (beside the previous step's tail and the copy before that)",
+                         "kernel_timing": ("HIP events attached to the kernel's dispatch (hipExtLaunchKernelGGL: the kernel's own begin / end timestamps), K pipelined "
+                                           "device-only steps right after the timed region -- beside the previous step's tail, as in the timed region, whose loop carries "
+                                           "no events (they cost 5-7 us per pass)") if (use_stream or sharded_host) and not os.environ.get("URH_BENCH_HEADLINE_EVENTS") else
+                                          "HIP events attached to the kernel's dispatch, inside the timed region",
                          "kernel_ms_unshared": round(alone_kernel_ms, 4) if alone_kernel_ms else None,
                          "frac_unshared": frac_of(alone_kernel_ms),
                          "copy_ceiling": ceiling,

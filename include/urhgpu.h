@@ -97,7 +97,13 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
  * out -- on 224 of the MI355X's 256 CUs the kernel is 5 % faster than on all of them, and the CUs left alone serve the previous pass's
  * tail; 0: no mask, the hot kernel runs on the caller's stream), "tail_masked" (1, before urhgpu_ctx_set_pipelined: the tail runs on a
  * private stream masked to exactly the CUs the hot mask leaves out, replacing the caller's tail stream; measured no faster -- the hot
- * kernel gains 1 % and a single capture's latency loses 30 % -- default 0).  Unknown key: URHGPU_ERR_ARG. */
+ * kernel gains 1 % and a single capture's latency loses 30 % -- default 0).  Streamed passes of urhgpu_stream_* (the tail in segments
+ * beside the hot kernel): "stream_policy" (0, default: a pass is streamed when nothing of an earlier pass is still running -- one capture,
+ * where the tail's latency counts; 1: every qualifying pass; 2: never), "stream_segments" (rows segments, 1 .. 16, default 6),
+ * "stream_bits_segments" (default 3), "stream_shape" (0: equal segments; 1: halving; 2: equal segments and a short last one of
+ * "stream_last_units" x 256 chunks), "stream_fuse_gate" / "stream_final_on_rows" (1, default: the last segment's gate inside its
+ * one-workgroup resolve kernel; its bits kernels on the rows stream), "pack_blocks" (workgroups of a segment's pack kernel),
+ * "upload_pieces" (2 .. 16, default 4: pieces of urhgpu_stream_push_upload, the last one short).  Unknown key: URHGPU_ERR_ARG. */
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value);
 int urhgpu_ctx_join(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no
@@ -328,6 +334,14 @@ int urhgpu_stream_capacities(int64_t n_max, const urhgpu_params *p, int64_t *cap
 int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p, int want_qad, int want_pos, int64_t cap_rows, urhgpu_stream **out);
 int urhgpu_stream_destroy(urhgpu_stream *st);
 int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_host_result *ready);
+/* The same for a capture that is still ON THE HOST (the reference: IQArray.from_file, IQArray.py:206-227 -> Signal.py:111-112, then
+ * ProtocolAnalyzer.get_protocol_from_signal): h_iq (host; pinned memory for PCIe speed) is copied into d_iq (device, n samples of the
+ * stream's dtype, the caller's: the capture stays resident there) in PIECES, and every piece is demodulated as it lands -- hot kernel
+ * on the piece, the piece's share of the tail, its share of the compact blob stored into pinned host memory.  1 GiB takes some 20 ms
+ * over PCIe and 0.3 ms to demodulate: "file in host memory -> bits on the host" costs the upload plus the last piece's kernels.
+ * Captures the segmented path does not take (ASK, a partial tile at the end, too short) are uploaded in one copy in front of an
+ * ordinary pass.  The copies are ordered behind what the caller has queued on the context's stream. */
+int urhgpu_stream_push_upload(urhgpu_stream *st, const void *h_iq, void *d_iq, int64_t n, urhgpu_host_result *ready);
 int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out);
 /* Diagnostics: out4 = {passes pushed, passes whose predicted copy size fell short (their rest was fetched when the result was handed
  * out), bytes the next copy is sized for, blob capacity}. */

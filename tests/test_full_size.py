@@ -58,3 +58,55 @@ def test_full_size_config5_psk_costas_center_bits(bench_mod):
     assert par["bit_exact"]
     assert rec["costas_chunks"]["speculative_hit_rate"] > 0.99, rec["costas_chunks"]
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("variant,upload", [("2", False), ("2b", False), ("2", True)])
+def test_full_size_streamed_single_capture_equals_reference(oracle, variant, upload):
+    """ONE 1 GiB capture through urhgpu_stream_* on an idle GPU -- the tail in segments beside the hot kernel, every segment's share of
+    the compact blob stored straight into pinned host memory; upload: the capture starts on the host and is demodulated piece by piece
+    as it lands -- equals the real reference (oracle/_ref) element for element: demodulated signal (uint32 view), pulse table, bits,
+    pauses, message offsets, bit_sample_pos (variant 2b: the bursty capture, 128 messages)."""
+    import ctypes as C
+
+    import numpy as np
+    import torch
+    from test_gpu_parity import full_size_reference
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    from urh_amd.synth import spec_fsk_capture
+    if variant == "2":
+        iq, _ = spec_fsk_capture(128, "cuda:0")
+        p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    else:
+        iq, _ = spec_fsk_capture(128, "cuda:0", seg_len=1 << 20, sps=100, n_symbols=10465)
+        p = DemodParams("FSK", 1, 0.2, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    n = iq.shape[0]
+    assert n == 1 << 27
+    pipe = DevicePipeline(0, pipelined=True)
+    st = pipe.stream(n, p, want_qad=True, want_pos=True)
+    host = iq.cpu().numpy()
+    if upload:
+        pinned = torch.from_numpy(host).pin_memory()
+        iq.zero_()
+        torch.cuda.synchronize()
+        assert st.push_upload(pinned, iq) is None
+    else:
+        assert st.push(iq) is None
+    (r,) = st.flush()
+    stats = st.stats()
+    assert stats["predicted_bytes"] == -1, stats               # the pass took the segmented route
+    r.check()
+    rows, bits, msg_off, pauses, pos, pos_off = r.ppseq(), r.bits(), r.msg_off.copy(), r.pauses.copy(), r.bit_sample_pos(), r.pos_offsets()
+    got_qad = np.empty(n, np.float32)
+    _lib.check(_lib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(r.d_qad_ptr), got_qad.ctypes.data_as(C.c_void_p), n * 4))
+    if upload:
+        assert np.array_equal(iq.cpu().numpy().view(np.uint32), host.view(np.uint32)), "the device buffer does not hold the uploaded capture"
+    st.close()
+    del iq
+    torch.cuda.empty_cache()
+    qad, pp, flat = full_size_reference(host, p, oracle)
+    assert int((got_qad.view(np.uint32) != qad.view(np.uint32)).sum()) == 0
+    assert np.array_equal(rows, pp), (len(rows), len(pp))
+    for name, a, b in zip(("bits", "msg_off", "pauses", "pos", "pos_off"), (bits, msg_off, pauses, pos, pos_off), flat):
+        assert np.array_equal(a, b), (name, len(a), len(b))
+    assert len(pauses) == (1 if variant == "2" else 128)

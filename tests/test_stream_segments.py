@@ -86,7 +86,8 @@ def one_tile_chunks():
     lib.urhgpu_test_force_tiles_per_chunk(0)
 
 
-@pytest.mark.parametrize("segments,shape,bits_segments", [(2, 0, 1), (2, 0, 2), (3, 0, 3), (5, 0, 2), (8, 0, 3), (8, 0, 8), (4, 1, 4), (6, 1, 3), (8, 1, 1)])
+@pytest.mark.parametrize("segments,shape,bits_segments", [(2, 0, 1), (2, 0, 2), (3, 0, 3), (5, 0, 2), (8, 0, 3), (8, 0, 8), (4, 1, 4), (6, 1, 3), (8, 1, 1),
+                                                          (2, 2, 2), (5, 2, 3), (8, 2, 8), (4, 2, 1)])
 @pytest.mark.parametrize("want_pos", [True, False])
 def test_segmented_tail_equals_oracle(oracle, one_tile_chunks, segments, shape, bits_segments, want_pos):
     """segments: rows segments (resolve + rows, shipped as they are written); bits_segments: the coarser segments of the second stream
@@ -168,3 +169,86 @@ def test_segmented_and_plain_passes_interleave(oracle, one_tile_chunks):
     st.close()
     for i, iq in enumerate(caps):
         _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i} ({sizes[i]} samples)")
+
+
+@pytest.mark.parametrize("final_on_rows,fuse_gate", [(0, 0), (1, 0), (0, 1)])
+def test_segmented_tail_chain_variants(oracle, one_tile_chunks, final_on_rows, fuse_gate):
+    """the knobs of the chain behind the hot kernel's end -- the last bits segment on the rows stream or on the bits stream, the last
+    segment's gate inside its one-workgroup resolve kernel or as a kernel of its own (the defaults, both on, run everywhere above)"""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_policy": 1, "stream_segments": 6, "stream_shape": 2, "stream_bits_segments": 3,
+                                                     "stream_final_on_rows": final_on_rows, "stream_fuse_gate": fuse_gate})
+    st = pipe.stream(N, p, want_qad=False, want_pos=True)
+    caps = [_events_capture(N, 90 + i) for i in range(4)]
+    dev = [torch.from_numpy(c).cuda() for c in caps]
+    got = {}
+    for d in dev:
+        r = st.push(d)
+        if r is not None:
+            got[r.seq] = _got(r)
+    for r in st.flush():
+        got[r.seq] = _got(r)
+    assert st.stats()["predicted_bytes"] == -len(caps)
+    st.close()
+    for i, iq in enumerate(caps):
+        _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i}")
+
+
+@pytest.mark.parametrize("pieces", [8, 3, 16, 2])
+def test_upload_piece_by_piece_equals_oracle(oracle, one_tile_chunks, pieces):
+    """urhgpu_stream_push_upload: the capture starts on the HOST (pinned memory); pieces are copied into the device buffer and demodulated
+    as they land.  The host receives what the reference computes for the capture, the device buffer holds the capture, the demodulated
+    signal of every pass equals the oracle's.  Captures the segmented path does not take (a partial tile at the end) are uploaded in
+    one copy in front of an ordinary pass."""
+    import torch
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    pipe = DevicePipeline(0, pipelined=True, tuning={"upload_pieces": pieces})
+    st = pipe.stream(N, p, want_qad=True, want_pos=True)
+    sizes = [N, N, N - 777, N, N // 2]
+    caps = [_events_capture(N, 70 + i)[:n].copy() for i, n in enumerate(sizes)]
+    host = [torch.from_numpy(c).pin_memory() for c in caps]
+    dev = [torch.zeros_like(h, device="cuda") for h in host]
+    got, qads = {}, {}
+
+    def keep(r):
+        got[r.seq] = _got(r)
+        n = sizes[r.seq]
+        q = np.empty(n, np.float32)
+        _lib.check(_lib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(r.d_qad_ptr), q.ctypes.data_as(C.c_void_p), n * 4))
+        qads[r.seq] = q
+    for h, d in zip(host, dev):
+        r = st.push_upload(h, d)
+        for x in ([r] if r is not None else []) + st.flush():       # one capture at a time: every result's qad is read before the next pass
+            keep(x)
+    st.close()
+    torch.cuda.synchronize()
+    for i, iq in enumerate(caps):
+        assert np.array_equal(dev[i].cpu().numpy().view(np.uint32), iq.view(np.uint32)), f"capture {i}: the device buffer does not hold the capture"
+        _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i} ({sizes[i]} samples, {pieces} pieces)")
+        qad = oracle.afp_demod(iq, p.noise_threshold, "FSK", 2)
+        assert np.array_equal(qads[i].view(np.uint32), qad.view(np.uint32)), f"capture {i}: qad"
+
+
+def test_upload_back_to_back(oracle, one_tile_chunks):
+    """uploads pushed back to back (results handed out three pushes later), numpy sources (pageable memory: slower, same results)"""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, False)
+    pipe = DevicePipeline(0, pipelined=True)
+    st = pipe.stream(N, p, want_qad=False, want_pos=False)
+    caps = [_events_capture(N, 80 + i) for i in range(5)]
+    dev = [torch.zeros(N, 2, dtype=torch.float32, device="cuda") for _ in caps]
+    got = {}
+    for c, d in zip(caps, dev):
+        r = st.push_upload(c, d)
+        if r is not None:
+            got[r.seq] = _got(r)
+    for r in st.flush():
+        got[r.seq] = _got(r)
+    st.close()
+    for i, iq in enumerate(caps):
+        _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i}")

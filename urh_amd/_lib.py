@@ -105,6 +105,7 @@ PROTOTYPES = {
     "urhgpu_stream_create": (_i, [_vp, _i64, C.POINTER(Params), _i, _i, _i64, C.POINTER(_vp)]),
     "urhgpu_stream_destroy": (_i, [_vp]),
     "urhgpu_stream_push": (_i, [_vp, _vp, _i64, C.POINTER(HostResult)]),
+    "urhgpu_stream_push_upload": (_i, [_vp, _vp, _vp, _i64, C.POINTER(HostResult)]),
     "urhgpu_stream_flush": (_i, [_vp, C.POINTER(HostResult), C.POINTER(_i)]),
     "urhgpu_stream_stats": (_i, [_vp, C.POINTER(_i64)]),
     "urhgpu_shard_runs_dev": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, _vp, C.POINTER(Params), C.POINTER(Outputs), _vp]),

@@ -196,6 +196,10 @@ int tile_tail_mem(urhgpu_ctx *ctx, int64_t n_entries, bool expands_bits, TileTai
         const size_t want = (rd + 65535) & ~size_t(65535);
         URH_HIP(hipMalloc(&ctx->d_rdesc, want));
         URH_HIP(hipMemset(ctx->d_rdesc, 0, want));
+        // (the memset is work of the NULL stream: it runs behind everything queued on the blocking streams -- a hot kernel that waits for
+        // an upload --, and the tail's non-blocking streams do not wait for it: descriptors published by the pass's first kernels were
+        // wiped by it.  Allocation time only: wait until it has happened.)
+        URH_HIP(hipDeviceSynchronize());
         ctx->rdesc_cap = want;
     }
     tm->rdesc = ctx->d_rdesc; tm->epoch = ++ctx->scan_epoch;
@@ -343,6 +347,7 @@ int scan_state(urhgpu_ctx *ctx, int64_t cap_rows, ScanState *out) {
         const size_t want = (need + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
         URH_HIP(hipMalloc(&ctx->d_desc, want));
         URH_HIP(hipMemset(ctx->d_desc, 0, want));
+        URH_HIP(hipDeviceSynchronize());                   // (see tile_tail_mem: the NULL stream's memset must not land behind the pass's kernels)
         ctx->desc_cap = want;
     }
     out->tickets = ctx->d_tickets; out->desc = ctx->d_desc; out->desc_bytes = ctx->desc_cap; out->epoch = &ctx->scan_epoch;
@@ -390,7 +395,7 @@ ShardSession *session(urhgpu_ctx *ctx) {
 namespace urh {
 
 // Segment boundaries (in chunks) of a streamed pass: S segments on kSegAlign chunks, the last one takes the remainder.
-static int segment_bounds(int64_t n_chunks, int wanted, int shape, int64_t *bound /*[kMaxSegments + 1]*/) {
+static int segment_bounds(int64_t n_chunks, int wanted, int shape, int last_units, int64_t *bound /*[kMaxSegments + 1]*/) {
     const int64_t blocks = n_chunks / kSegAlign;              // whole alignment units; what is left over belongs to the last segment
     int S = wanted;
     if (S > kMaxSegments) S = kMaxSegments;
@@ -409,6 +414,14 @@ static int segment_bounds(int64_t n_chunks, int wanted, int shape, int64_t *boun
             at += take; left -= take;
             bound[k + 1] = at * kSegAlign;
         }
+    } else if (shape == 2 && S > 1) {
+        // S - 1 equal segments and a SHORT last one (last_units alignment units + the remainder): the segments before it run beside the
+        // hot kernel; what is exposed behind the hot kernel's end is the last segment's chain of six small kernels, whose length hardly
+        // depends on the segment's size (5 - 8 us each) -- so it should be short in the hot kernel's terms too
+        int64_t last = last_units < 1 ? 1 : last_units;
+        if (last > blocks - (S - 1)) last = blocks - (S - 1);
+        const int64_t rest = blocks - last;
+        for (int k = 1; k < S; ++k) bound[k] = (rest * k / (S - 1)) * kSegAlign;
     } else {
         for (int k = 1; k < S; ++k) bound[k] = (blocks * k / S) * kSegAlign;
     }
@@ -419,13 +432,13 @@ static int segment_bounds(int64_t n_chunks, int wanted, int shape, int64_t *boun
 }
 
 int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, const urhgpu_outputs *out, void *host_blob,
-                        int64_t cap_host, hipEvent_t ev_ready, bool *streamed) {
+                        int64_t cap_host, hipEvent_t ev_ready, bool *streamed, const void *h_iq) {
     *streamed = false;
     if (!ctx || !p || !out || n <= 0 || !d_iq || !out->rows || !out->counts) return URHGPU_ERR_ARG;
     if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
     const bool want_bits = out->bits && out->msg_off && out->pauses && out->pos_off;
     if (!ctx->pipelined || !ctx->tail_stream || n <= 2 || p->mod == URHGPU_MOD_PSK || p->mod == URHGPU_MOD_ASK || !g_tile_tail || !want_bits ||
-        ctx->tune_stream_segments < 2 || out->cap_rows < 1)
+        (ctx->tune_stream_segments < 2 && !h_iq) || out->cap_rows < 1)
         return URHGPU_OK;
     URH_TRY(check_params(p, true));
     if (((uintptr_t)d_iq & 15) || (out->qad && ((uintptr_t)out->qad & 7))) return URHGPU_ERR_ARG;
@@ -442,10 +455,10 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     a.lds_pad = ctx->hot_lds_pad;
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     int64_t bound[kMaxSegments + 1];
-    const int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, ctx->tune_stream_segments, ctx->tune_stream_shape, bound) : 0;
+    const int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, h_iq ? ctx->tune_upload_pieces : ctx->tune_stream_segments, h_iq ? 2 : ctx->tune_stream_shape, ctx->tune_stream_last_units, bound) : 0;
     if (S < 2) return URHGPU_OK;                               // too short to cut, or not the bit-plane kernel's work: the ordinary path
-    if (ctx->tune_stream_policy == 2) return URHGPU_OK;
-    if (ctx->tune_stream_policy == 0 && ctx->passes_begun > 0) {
+    if (ctx->tune_stream_policy == 2 && !h_iq) return URHGPU_OK;
+    if (ctx->tune_stream_policy == 0 && ctx->passes_begun > 0 && !h_iq) {
         // is anything of the pass before still running?  Then this pass's tail will run beside ITS successor's hot kernel as well: one piece
         const hipError_t q = hipEventQuery(ctx->ev_tail[(ctx->flip + 2) % 3]);
         if (q == hipErrorNotReady) { (void)hipGetLastError(); return URHGPU_OK; }
@@ -454,7 +467,9 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     if (!ctx->d_seg) {
         URH_HIP(hipMalloc(&ctx->d_seg, 3 * kSegBlockBytes));
         URH_HIP(hipMemset(ctx->d_seg, 0, 3 * kSegBlockBytes));
+        URH_HIP(hipDeviceSynchronize());
         URH_HIP(hipStreamCreateWithFlags(&ctx->bits_stream, hipStreamNonBlocking));
+        for (int k = 0; k < kMaxSegments; ++k) URH_HIP(hipEventCreateWithFlags(&ctx->ev_piece[k], hipEventDisableTiming));
         for (int k = 0; k < 3; ++k) {
             URH_HIP(hipEventCreateWithFlags(&ctx->ev_hot_done[k], hipEventDisableTiming));
             URH_HIP(hipEventCreateWithFlags(&ctx->ev_bits[k], hipEventDisableTiming));
@@ -467,7 +482,9 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     SegState *st = (SegState *)((char *)progress + kMaxSegments * kProgressStride * 4);
     static_assert(kMaxSegments * kProgressStride * 4 + sizeof(SegState) <= kSegBlockBytes && kMaxSegments <= 16, "segment block");
     if (ctx->seg_dirty[slot]) {                                // an earlier pass on this arena died half-way: its counters may not be zero
+        URH_HIP(hipDeviceSynchronize());
         URH_HIP(hipMemset(progress, 0, kSegBlockBytes));
+        URH_HIP(hipDeviceSynchronize());
         ctx->seg_dirty[slot] = false;
     }
     URH_TRY(ctx->arena.reserve(digitize_scratch_bytes(pl, out->cap_rows, false, true)));
@@ -480,6 +497,14 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     void *rs_mem = ctx->arena.take(resolve_scratch_bytes(pl.n_chunks));
     if (!chunks || !slab || !rs_mem) return URHGPU_ERR_ARG;
     a.chunks = chunks; a.slab = slab;
+    // everything that may allocate (and zero) descriptor memory BEFORE anything of the pass is queued
+    TileTailMem tm;
+    URH_TRY(tile_tail_mem(ctx, pl.n_chunks, true, &tm));
+    const int64_t cap = std::max<int64_t>(out->cap_rows, 1);
+    void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
+    if (!scratch) return URHGPU_ERR_ARG;
+    ScanState ss;
+    URH_TRY(scan_state(ctx, tile_desc_cap(cap, pl.n_chunks), &ss));
     // a segment's counter covers its chunks and the first chunk of the next segment (the resolve kernel's look-ahead), less the first
     // chunk of its own, which the segment before already waited for
     a.progress = progress; a.n_seg = S;
@@ -489,10 +514,48 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         a.seg_end[k] = (int32_t)hi;
         target[k] = (uint32_t)(hi - lo);
     }
+    hipEvent_t hot_done = nullptr;
+    if (h_iq) {
+        // Upload mode (urhgpu_stream_push_upload): the capture arrives from the host in PIECES, and the hot kernel runs piece by piece
+        // behind them (RunArgs::launch_lo / launch_hi; a chunk reads the two samples before it: the pieces arrive in order).  Piece k =
+        // the chunks of segment k plus the first chunk of segment k + 1 -- the chunk segment k's resolve kernel looks ahead into, so that
+        // the segment's tail does not wait for the next piece.  1 GiB over PCIe takes 70 times as long as its hot kernel: what is left
+        // behind the last byte's arrival is the last (short) piece's kernel and the last segment's tail.
+        // The copies go onto the HOT stream itself: copy 0, kernel 0, copy 1, kernel 1, ...  A stream of their own (copies fully beside
+        // the kernels) was measured first and is not robust: HIP maps streams onto a handful of hardware queues, and depending on which
+        // streams happened to share one the same pass took 19.4 or 35 ms (tools/r4_upload_probe.py, round 4: the first pipeline of a
+        // process was fine, later ones were not).  In one in-order stream a piece's kernel sits between two copies: 283 us of kernels
+        // per GiB whatever the number of pieces, plus some 25 us of hand-over per piece -- 1.04 x the bare copy at four pieces.
+        // No polling gates here: a gate kernel would spin for the milliseconds a piece takes to arrive; the rows segment of piece k
+        // waits for an event behind the piece's hot kernel instead (plain stores in that kernel, no progress counters).
+        a.progress = nullptr; a.n_seg = 0;
+        const size_t bps = (size_t)dtype_bytes(p->dtype);
+        int64_t piece_lo[kMaxSegments], piece_hi[kMaxSegments];
+        for (int k = 0, lo = 0; k < S; ++k) {
+            piece_lo[k] = k == 0 ? 0 : piece_hi[k - 1];
+            piece_hi[k] = (k < S - 1) ? std::min<int64_t>(bound[k + 1] + 1, pl.n_chunks) : pl.n_chunks;
+            (void)lo;
+        }
+        auto copy_piece = [&](int k) -> int {
+            const int64_t s0 = piece_lo[k] * pl.chunk_len, s1 = std::min<int64_t>(piece_hi[k] * pl.chunk_len, n);
+            URH_HIP(hipMemcpyAsync((char *)const_cast<void *>(d_iq) + (size_t)s0 * bps, (const char *)h_iq + (size_t)s0 * bps, (size_t)(s1 - s0) * bps,
+                                   hipMemcpyHostToDevice, s));
+            return URHGPU_OK;
+        };
+        for (int k = 0; k < S; ++k) {
+            URH_TRY(copy_piece(k));
+            a.launch_lo = piece_lo[k]; a.launch_hi = piece_hi[k];
+            const int stl = launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s);
+            if (stl != URHGPU_OK) return stl;
+            URH_HIP(hipEventRecord(ctx->ev_piece[k], s));
+        }
+        a.launch_lo = 0; a.launch_hi = 0;
+        URH_HIP(hipEventRecord(ctx->ev_hot_done[slot], s));
+        hot_done = ctx->ev_hot_done[slot];
+    } else {
     const bool prof = prof_begin_record(ctx, s);
     // the hot kernel's completion: the dispatch's own completion signal where the launcher takes events (an event recorded behind the
     // kernel is one more barrier packet between two hot kernels); nobody waits for it before the last segment has been queued
-    hipEvent_t hot_done = nullptr;
     if (ctx->hot_stop_event) {
         if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot_done[slot]; }
         hot_done = g_hot_events.stop;
@@ -505,6 +568,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     if (prof) URH_TRY(prof_end_record(ctx, s));
     else g_hot_events = HotEvents();
     if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot_done[slot], s)); hot_done = ctx->ev_hot_done[slot]; }
+    }
     // ---- the tail in segments: rows segments on the tail stream, bits segments on the bits stream behind the rows they expand; neither
     // ever waits for the hot kernel as a whole ----
     hipStream_t ts = ctx->tail_stream, tb = ctx->bits_stream;
@@ -520,15 +584,8 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     e.sc = rsc;
     e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
     e.rows = out->rows; e.cap_rows = out->cap_rows; e.d_ts_carry = nullptr; e.is_ask = 0; e.sps = p->samples_per_symbol;
-    TileTailMem tm;
-    URH_TRY(tile_tail_mem(ctx, pl.n_chunks, true, &tm));
-    const int64_t cap = std::max<int64_t>(out->cap_rows, 1);
-    void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
-    if (!scratch) return URHGPU_ERR_ARG;
     BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts, out->h_counts};
     BitsParams bp = bits_params(p);
-    ScanState ss;
-    URH_TRY(scan_state(ctx, tile_desc_cap(cap, pl.n_chunks), &ss));
     // where the rows go on the host: the capacity layout of the compact blob (k_pack_seg)
     const int has_pos = (bp.write_pos && out->pos) ? 1 : 0;
     int8_t *h_state = nullptr; int32_t *h_len = nullptr;
@@ -548,27 +605,45 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     bits_end_at[Sb - 1] = S - 1;
     int jb = 0;
     int64_t bits_from = 0;
+    // the LAST bits segment goes onto the rows stream, right behind the last rows (tune_stream_final_on_rows): no event hop between two
+    // streams on the chain that is exposed behind the hot kernel's end; the rows stream then waits for the bits segments before it
+    const bool final_on_rows = ctx->tune_stream_final_on_rows;
+    hipStream_t last_stream = tb;
     for (int k = 0; k < S; ++k) {
-        RowsSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], SegGate{progress, k, target[k], k == 0 ? 1 : 0, st, (long long)200000000}, h_state, h_len};
+        if (h_iq) URH_HIP(hipStreamWaitEvent(ts, ctx->ev_piece[k], 0));
+        RowsSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], SegGate{h_iq ? nullptr : progress, k, target[k], k == 0 ? 1 : 0, st, (long long)200000000, 0},
+                       h_state, h_len, ctx->tune_stream_fuse_gate ? 1 : 0};
         URH_TRY(launch_rows_segment(r, e, tm, bp, st, sg, ts));
         while (jb < Sb && bits_end_at[jb] < k) ++jb;           // (a bits segment that would end before the first rows segment: none)
         if (jb < Sb && bits_end_at[jb] == k) {
-            URH_HIP(hipEventRecord(ctx->ev_rows[slot][jb], ts));
-            URH_HIP(hipStreamWaitEvent(tb, ctx->ev_rows[slot][jb], 0));
-            BitsSegment bs{jb, jb == Sb - 1 ? 1 : 0, bits_from, bound[k + 1], k, st};
-            URH_TRY(launch_bits_segment(tm, bp, bo, scratch, ss, out->rows, out->cap_rows, bs, &dst, tb));
+            const bool last = (jb == Sb - 1);
+            BitsSegment bs{jb, last ? 1 : 0, bits_from, bound[k + 1], k, st};
+            if (last && final_on_rows) {
+                if (jb > 0) {                                  // behind the bits segments before it (their carries, their packed bytes)
+                    URH_HIP(hipEventRecord(ctx->ev_bits[slot], tb));
+                    URH_HIP(hipStreamWaitEvent(ts, ctx->ev_bits[slot], 0));
+                }
+                URH_TRY(launch_bits_segment(tm, bp, bo, scratch, ss, out->rows, out->cap_rows, bs, &dst, ts));
+                last_stream = ts;
+            } else {
+                URH_HIP(hipEventRecord(ctx->ev_rows[slot][jb], ts));
+                URH_HIP(hipStreamWaitEvent(tb, ctx->ev_rows[slot][jb], 0));
+                URH_TRY(launch_bits_segment(tm, bp, bo, scratch, ss, out->rows, out->cap_rows, bs, &dst, tb));
+            }
             bits_from = bound[k + 1];
             ++jb;
         }
     }
     URH_HIP(hipGetLastError());
-    if (!host_blob) URH_HIP(hipMemsetAsync(progress, 0, kMaxSegments * kProgressStride * 4, tb));       // (nobody else zeroes the counters then)
+    if (!host_blob) URH_HIP(hipMemsetAsync(progress, 0, kMaxSegments * kProgressStride * 4, last_stream));       // (nobody else zeroes the counters then)
     ctx->seg_dirty[slot] = false;
-    if (ev_ready) URH_HIP(hipEventRecord(ev_ready, tb));         // the host blob is complete
+    if (ev_ready) URH_HIP(hipEventRecord(ev_ready, last_stream));         // the host blob is complete
     // the pass is over when the bits stream has finished and the hot kernel has retired (its last qad stores): cheap here, the last
     // gate has just seen its last chunk
-    URH_HIP(hipEventRecord(ctx->ev_bits[slot], tb));
-    URH_HIP(hipStreamWaitEvent(ts, ctx->ev_bits[slot], 0));
+    if (last_stream != ts) {
+        URH_HIP(hipEventRecord(ctx->ev_bits[slot], tb));
+        URH_HIP(hipStreamWaitEvent(ts, ctx->ev_bits[slot], 0));
+    }
     URH_HIP(hipStreamWaitEvent(ts, hot_done, 0));
     if (s != ctx->stream && ctx->stream != nullptr) URH_HIP(hipStreamWaitEvent(ctx->stream, hot_done, 0));   // input reuse in stream order
     URH_TRY(end_pipelined_pass(ctx));
@@ -646,6 +721,7 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     if (ctx->d_seg) {
         (void)hipFree(ctx->d_seg);
         if (ctx->bits_stream) { (void)hipStreamSynchronize(ctx->bits_stream); (void)hipStreamDestroy(ctx->bits_stream); }
+        for (hipEvent_t e : ctx->ev_piece) if (e) (void)hipEventDestroy(e);
         for (int k = 0; k < 3; ++k) {
             if (ctx->ev_hot_done[k]) (void)hipEventDestroy(ctx->ev_hot_done[k]);
             if (ctx->ev_bits[k]) (void)hipEventDestroy(ctx->ev_bits[k]);
@@ -774,7 +850,12 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "hot_cus_removed_per_xcd")) { if (value < 0 || value > 16) return URHGPU_ERR_ARG; ctx->tune_hot_cus_removed = value; }
     else if (!strcmp(key, "stream_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_segments = value; }
     else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
-    else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 1) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
+    else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
+    else if (!strcmp(key, "stream_spin")) { if (value < 0) return URHGPU_ERR_ARG; ctx->tune_stream_spin = value; }
+    else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }
+    else if (!strcmp(key, "stream_last_units")) { if (value < 1 || value > 64) return URHGPU_ERR_ARG; ctx->tune_stream_last_units = value; }
+    else if (!strcmp(key, "stream_fuse_gate")) { ctx->tune_stream_fuse_gate = value != 0; }
+    else if (!strcmp(key, "stream_final_on_rows")) { ctx->tune_stream_final_on_rows = value != 0; }
     else if (!strcmp(key, "stream_bits_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_bits_segments = value; }
     else if (!strcmp(key, "pack_blocks")) { if (value < 0 || value > 4096) return URHGPU_ERR_ARG; ctx->tune_pack_blocks = value; }
     else return URHGPU_ERR_ARG;

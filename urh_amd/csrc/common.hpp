@@ -110,13 +110,20 @@ struct urhgpu_ctx {
     // streamed passes (urhgpu_stream_*; capi.hip: iq_to_bits_streamed): per scratch arena 16 progress counters + one SegState
     void *d_seg = nullptr;         // 3 x kSegBlockBytes, zero between passes
     bool seg_dirty[3] = {false, false, false};   // a pass failed between its hot launch and its last segment: counters not trusted
-    int tune_stream_segments = 5;  // rows segments of a streamed pass's tail (1: no streaming), urhgpu_ctx_set_tuning("stream_segments")
+    int tune_stream_segments = 6;  // rows segments of a streamed pass's tail (1: no streaming), urhgpu_ctx_set_tuning("stream_segments")
     int tune_stream_policy = 0;    // 0: stream a pass only when the pipeline is idle (nothing of an earlier pass still running: a single
                                    // capture, where the latency of the tail counts); 1: every qualifying pass; 2: never.  Beside the hot kernel
                                    // of a FOLLOWING pass the segments' short kernels are slower than one tail over the whole capture
                                    // (memory latency under a saturated HBM), so back-to-back passes keep the one-piece tail
     long long passes_begun = 0;    // pipelined passes started on this context
-    int tune_stream_shape = 0;     // 0: equal segments; 1: halving (1/2, 1/4, ... of the capture, the last two equal)
+    int tune_stream_shape = 0;     // 0: equal segments; 1: halving (1/2, 1/4, ... of the capture, the last two equal); 2: equal segments and
+                                   // a short last one (tune_stream_last_units alignment units of 256 chunks)
+    int tune_stream_last_units = 1;
+    int tune_stream_spin = 4000;            // hipEventQuery polls before the host parks in hipEventSynchronize (urhgpu_stream_* results)
+    int tune_upload_pieces = 4;             // pieces of urhgpu_stream_push_upload: pieces - 1 equal ones and a short last one (shape 2)
+    bool tune_stream_fuse_gate = true;      // the last segment's gate inside its one-workgroup resolve kernel (SegGate::fused)
+    bool tune_stream_final_on_rows = true;  // the last bits segment on the rows stream, right behind the last rows (no cross-stream hop)
+    hipEvent_t ev_piece[16] = {};           // the hot kernel of piece k has finished (the rows segment k waits for it: no polling gate in upload mode)
     int tune_stream_bits_segments = 3;   // bits segments (tile scan, group scan, expansion, pack) of a streamed pass, on their own stream
     int tune_pack_blocks = 0;      // workgroups of a segment's pack kernel (0: default)
     hipEvent_t ev_hot_done[3] = {nullptr, nullptr, nullptr};   // behind the hot kernel of the pass in arena slot k (streamed passes)
@@ -130,8 +137,10 @@ namespace urh {
 // A pass whose tail runs in segments beside the hot kernel, every segment storing its share of the compact blob into pinned host memory
 // (pulse_table.hip "Segments").  *streamed = false: the arguments do not qualify (nothing was launched; take the ordinary path).
 // ev_ready (may be nullptr) is recorded on the tail stream behind the last segment's pack kernel: the host blob is complete.
+// h_iq != nullptr: upload mode -- the capture is copied from h_iq (host, pinned for PCIe speed) into d_iq piece by piece and every piece
+// demodulated as it lands (urhgpu_stream_push_upload).
 int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, const urhgpu_outputs *out, void *host_blob,
-                        int64_t cap_host, hipEvent_t ev_ready, bool *streamed);
+                        int64_t cap_host, hipEvent_t ev_ready, bool *streamed, const void *h_iq = nullptr);
 }
 
 namespace urh {

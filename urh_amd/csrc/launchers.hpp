@@ -247,6 +247,8 @@ struct SegGate {
     int init;
     SegState *seg;
     long long max_ticks;        // of the 100 MHz wall clock: give up (seg->err) instead of hanging when the hot kernel never comes
+    int fused;                  // launch_rows_segment: the segment's resolve kernel is ONE workgroup, whose first thread does the polling itself
+                                // (one kernel less on the chain behind the hot kernel's end: the capture's last, short segment)
 };
 struct RowsSegment {         // chunks [c0, c1) of the capture's n_chunks (c0 a multiple of kSegAlign; c1 too, or n_chunks)
     int index;               // k
@@ -255,6 +257,7 @@ struct RowsSegment {         // chunks [c0, c1) of the capture's n_chunks (c0 a 
     SegGate gate;
     int8_t *h_state;         // pinned HOST memory (device-accessible) that receives the rows as they are written: the compact blob's
     int32_t *h_len;          // row_state / row_len sections (nullptr: rows are not shipped)
+    int fuse_gate;           // allow the gate inside a one-workgroup resolve kernel (SegGate::fused)
 };
 struct BitsSegment {         // tiles [c0, c1) (the last one: + the tile of the table's last row); needs the rows of chunks < c1
     int index;               // j

@@ -778,6 +778,21 @@ __global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs
     const int64_t blk = blk0 + blockIdx.x;
     const int64_t c = blk * kResolveBlock + threadIdx.x;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (gate.fused) {
+        // the gate of a short segment (k_seg_gate's loop, see "Segments" below) inside its only resolve workgroup: ONE thread polls the
+        // segment's counter; the acquire fence behind it (every thread: L1 and the non-local lines of this XCD's L2 are dropped) orders the
+        // loads below after the hot kernel's acknowledged write-through stores
+        if (t == 0) {
+            const uint32_t *ctr = gate.progress + gate.k * kProgressStride;
+            const long long t0 = (long long)wall_clock64();
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gate.target) {
+                __builtin_amdgcn_s_sleep(8);
+                if ((long long)wall_clock64() - t0 > gate.max_ticks) { gate.seg->err = 1 + gate.k; break; }
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     if (gate.seg && gate.init && blockIdx.x == 0 && t == 0) {
         // the first rows segment of a streamed pass clears what the bits segments carry along (they start behind this kernel)
         int64_t *w = (int64_t *)&gate.seg->in[0];
@@ -1853,8 +1868,10 @@ int launch_rows_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailM
     // first rows segment starts the list (k_resolve_one clears the counter when want_bits is set)
     TileTail ft_resolve = g.ft;
     if (sg.index != 0) ft_resolve.want_bits = 0;
-    if (sg.gate.progress || sg.gate.init) hipLaunchKernelGGL(k_seg_gate, dim3(1), dim3(64), 0, s, sg.gate);
-    hipLaunchKernelGGL(k_resolve_one, dim3((unsigned)resolve_blocks(sg.c1 - sg.c0)), dim3(kResolveBlock), 0, s, r, ft_resolve, sg.c0 / kResolveBlock, sg.gate);
+    SegGate gate = sg.gate;
+    gate.fused = (sg.fuse_gate && gate.progress && !gate.init && resolve_blocks(sg.c1 - sg.c0) == 1) ? 1 : 0;
+    if (!gate.fused && (gate.progress || gate.init)) hipLaunchKernelGGL(k_seg_gate, dim3(1), dim3(64), 0, s, gate);
+    hipLaunchKernelGGL(k_resolve_one, dim3((unsigned)resolve_blocks(sg.c1 - sg.c0)), dim3(kResolveBlock), 0, s, r, ft_resolve, sg.c0 / kResolveBlock, gate);
     hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((g.w_end - g.w0 + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
     return URHGPU_OK;
 }

@@ -41,6 +41,7 @@ struct urhgpu_stream {
     hipStream_t copy_stream = nullptr;
     int64_t seq = 0;
     int64_t streamed_passes = 0;           // passes whose tail ran in segments (diagnostics)
+    int64_t uploaded_passes = 0;           // ... of which the capture was uploaded piece by piece (urhgpu_stream_push_upload)
     int64_t predicted_bytes = 0;           // blob bytes the next pass's copy is sized for (0: header only, the rest fetched on demand)
     int64_t short_copies = 0;              // passes whose prediction fell short (diagnostics)
     bool was_pipelined = false;
@@ -89,10 +90,23 @@ int queue_copy(urhgpu_stream *st, urhgpu_stream::Slot &s) {
     return URHGPU_OK;
 }
 
+// hipEventSynchronize parks the thread (an interrupt and a wake-up: 10 - 20 us behind the event); for results that are a fraction of a
+// millisecond away the host polls the event for a while first -- what a capture's latency ends with
+int wait_event(hipEvent_t e, int spins = 4000) {
+    for (int i = 0; i < spins; ++i) {                        // (hipEventQuery reads the completion signal from host memory: well under a microsecond)
+        const hipError_t q = hipEventQuery(e);
+        if (q == hipSuccess) return URHGPU_OK;
+        if (q != hipErrorNotReady) URH_HIP(q);
+        (void)hipGetLastError();
+    }
+    URH_HIP(hipEventSynchronize(e));
+    return URHGPU_OK;
+}
+
 int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r) {
     if (s.state == 1) URH_TRY(queue_copy(st, s));
     if (s.state != 2) return URHGPU_ERR_ARG;
-    URH_HIP(hipEventSynchronize(s.ev_copy));
+    URH_TRY(wait_event(s.ev_copy, st->ctx->tune_stream_spin));
     const int64_t *hdr = (const int64_t *)s.h_blob;
     if (hdr[0] != URHGPU_BLOB_MAGIC || hdr[6] < 0 || hdr[6] > st->cap_blob) return URHGPU_ERR_ARG;
     if (hdr[15] & 2) {                                      // a segment's gate gave up waiting for the hot kernel (k_seg_gate): nothing of this pass is valid
@@ -203,7 +217,18 @@ int urhgpu_stream_destroy(urhgpu_stream *st) {
     return URHGPU_OK;
 }
 
+static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, int64_t n, urhgpu_host_result *ready);
+
 int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_host_result *ready) {
+    return stream_push(st, nullptr, d_iq, n, ready);
+}
+
+int urhgpu_stream_push_upload(urhgpu_stream *st, const void *h_iq, void *d_iq, int64_t n, urhgpu_host_result *ready) {
+    if (!h_iq) return URHGPU_ERR_ARG;
+    return stream_push(st, h_iq, d_iq, n, ready);
+}
+
+static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, int64_t n, urhgpu_host_result *ready) {
     if (!st || !d_iq || n <= 2 || n > st->n_max) return URHGPU_ERR_ARG;
     urhgpu_ctx *ctx = st->ctx;
     URH_HIP(hipSetDevice(ctx->device));
@@ -230,12 +255,19 @@ int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_ho
     // the compact blob straight into the pinned host blob -- no pack launch at the end, no copy engine, no predicted size.  Captures the
     // bit-plane kernel does not take, or too short to cut, go the ordinary way: tail behind the hot kernel, pack + copy behind the tail.
     bool streamed = false;
-    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed));
+    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq));
     if (streamed) {
         s.state = 2; s.seq = i; s.n = n; s.copied = st->cap_blob;
         st->seq = i + 1;
         st->streamed_passes += 1;
+        if (h_iq) st->uploaded_passes += 1;
         return URHGPU_OK;
+    }
+    if (h_iq) {
+        // a capture the segmented path does not take (ASK, a partial tile at the end, too short to cut): one copy on the caller's stream, in
+        // front of the ordinary pass
+        const size_t bps = st->p.dtype == URHGPU_DT_F32 ? 8 : (st->p.dtype == URHGPU_DT_I16 || st->p.dtype == URHGPU_DT_U16) ? 4 : 2;
+        URH_HIP(hipMemcpyAsync(const_cast<void *>(d_iq), h_iq, (size_t)n * bps, hipMemcpyHostToDevice, ctx->stream));
     }
     URH_TRY(urhgpu_iq_to_bits_dev(ctx, d_iq, n, &st->p, &pass_out));
     URH_HIP(hipEventRecord(s.ev_tail, ctx->tail_stream));
@@ -268,7 +300,7 @@ int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out)
     }
     // a streamed pass's blob is complete a moment before its hot kernel has retired (the last qad stores): d_qad of the results handed
     // out here is read by the caller next
-    if (st->streamed_passes > 0 && st->ctx->tail_pending) URH_HIP(hipEventSynchronize(st->ctx->ev_tail[(st->ctx->flip + 2) % 3]));
+    if (st->streamed_passes > 0 && st->ctx->tail_pending) URH_TRY(wait_event(st->ctx->ev_tail[(st->ctx->flip + 2) % 3], st->ctx->tune_stream_spin));
     return URHGPU_OK;
 }
 

@@ -140,7 +140,12 @@ class BitsResult:
                                                       f"bits={n_bits} pos={n_pos}")
 
     def _through_blob(self):
-        return self._pipe is not None and self._outputs is not None
+        """Do the host accessors go through the compact blob?  Not for a result the pipeline did not make, and not when the pack kernel found
+        a value its narrow types cannot hold (truncated bit 2: a capture of 2^31 samples and more -- or the NEGATIVE length / position the
+        reference produces for a capture shorter than the tolerance, signal_functions.pyx:485-493): then the wide device tables are copied."""
+        if self._pipe is None or self._outputs is None:
+            return False
+        return not (self.host().truncated & 4)
 
     def ppseq(self) -> np.ndarray:
         if self._through_blob():
@@ -261,7 +266,7 @@ class HostBits:
     def __init__(self, r: "_lib.HostResult", params):
         self.seq, self.n_samples = int(r.seq), int(r.n_samples)
         self.n_rows, self.n_msg, self.n_bits, self.n_pos = int(r.n_rows), int(r.n_msg), int(r.n_bits), int(r.n_pos)
-        self.rows_needed, self.truncated, self.blob_bytes = int(r.rows_needed), bool(r.truncated), int(r.blob_bytes)
+        self.rows_needed, self.truncated, self.blob_bytes = int(r.rows_needed), int(r.truncated), int(r.blob_bytes)
         self.params = params
         self.d_qad_ptr = r.d_qad
         # the views are made when somebody looks (a push per 0.3 ms must not allocate a dozen objects each)
@@ -306,6 +311,9 @@ class HostBits:
         return cls(r, params)
 
     def check(self):
+        if self.truncated & 4:
+            raise _lib.UrhGpuError(_lib.ERR_UNSUPPORTED, "a row length, position or state does not fit the compact blob's narrow types "
+                                                         "(take the wide device outputs)")
         if self.truncated:
             raise _lib.UrhGpuError(_lib.ERR_CAPACITY, f"output capacity too small: the pulse table needs {self.rows_needed} rows")
         return self
@@ -421,6 +429,26 @@ class CaptureStream:
         r = _lib.HostResult()
         self.pipe.ctx.set_stream(torch.cuda.current_stream(self.pipe.device).cuda_stream)
         _lib.check(_lib.load().urhgpu_stream_push(self._h, C.c_void_p(iq.data_ptr()), int(iq.shape[0]), C.byref(r)))
+        return HostBits(r, self.params) if r.seq >= 0 else None
+
+    def push_upload(self, host_iq, dev_iq):
+        """A capture that is still on the host (urhgpu_stream_push_upload): host_iq -- a torch CPU tensor (pinned: PCIe speed) or a numpy
+        array, (N, 2) of the stream's dtype or complex64 -- is copied into dev_iq (device tensor of the same shape: the capture stays
+        resident there, e.g. as a Signal's data) piece by piece, and every piece is demodulated as it lands.  Returns like push()."""
+        torch = self.pipe.torch
+        if isinstance(host_iq, np.ndarray):
+            host_iq = torch.from_numpy(host_iq)
+        if host_iq.dtype == torch.complex64:
+            host_iq = torch.view_as_real(host_iq)
+        if dev_iq.dtype == torch.complex64:
+            dev_iq = torch.view_as_real(dev_iq)
+        if host_iq.is_cuda or not dev_iq.is_cuda or _torch_dtype(host_iq) != self._dtype or _torch_dtype(dev_iq) != self._dtype \
+                or not host_iq.is_contiguous() or not dev_iq.is_contiguous() or host_iq.shape != dev_iq.shape:
+            raise ValueError("push_upload: a contiguous host capture and a device tensor of the same shape, both of " + str(self._dtype))
+        r = _lib.HostResult()
+        self.pipe.ctx.set_stream(torch.cuda.current_stream(self.pipe.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_stream_push_upload(self._h, C.c_void_p(host_iq.data_ptr()), C.c_void_p(dev_iq.data_ptr()), int(host_iq.shape[0]),
+                                                         C.byref(r)))
         return HostBits(r, self.params) if r.seq >= 0 else None
 
     def flush(self):

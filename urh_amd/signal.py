@@ -205,7 +205,10 @@ class Signal:
         old = users[k]() if users[k] is not None else None
         if old is not None:
             old.materialize()
-        out = LazyDigitized(res.host(pool=pools[k]), want_pos=res.pos_buf is not None)
+        h = res.host(pool=pools[k])
+        if h.truncated & 4:                       # a value the blob's narrow types cannot hold (a capture shorter than the tolerance): wide copies
+            return (res.ppseq().copy(),) + tuple(x.copy() for x in res.flat())
+        out = LazyDigitized(h, want_pos=res.pos_buf is not None)
         users[k] = weakref.ref(out)
         return out
 
