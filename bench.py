@@ -340,12 +340,20 @@ def extra_config3(pipe, dev, args):
     qad_kept = keep["qad"]
     res, t_bits = _timed(torch, lambda: pipe.qad_to_bits(qad_kept, p))
     res_fused, t_bits_fused = _timed(torch, lambda: pipe.iq_to_bits_checked(filt, p, want_qad=True))     # for comparison: demodulating again
+    # SURVEY 8(d)'s window ends with the compact outputs ON THE HOST: the slicing pass + pack kernel + one pinned copy of the blob
+    pool = {}
+    hb, t_bits_host = _timed(torch, lambda: pipe.qad_to_bits(qad_kept, p).host(pool=pool).check())
+    host_counts = (hb.n_rows, hb.n_msg, hb.n_bits)
     total_ms = t_fir_noise + t_est + t_bits
+    total_host_ms = t_fir_noise + t_est + t_bits_host
     rec = {"workload": "configs[2]: 1 GiB OOK (Manchester, 124 messages) + 64-tap complex FIR + auto noise threshold + estimate + bits",
-           "samples": n, "ms": round(total_ms, 3),
+           "samples": n, "ms": round(total_ms, 3), "ms_incl_d2h": round(total_host_ms, 3),
+           "ms_meaning": "ms: the stages with the outputs left in HBM; ms_incl_d2h: SURVEY 8(d)'s window -- the last stage ends with pulse table, bits, pauses, "
+                         "offsets and bit_sample_pos in pinned host memory (compact blob: pack kernel + one copy)",
            "timing": "every stage: median of 5 wall times (GPU drained before and after) following 30 ms of repeats of the same stage (clock ramp)",
            "stages_ms": {"fir_filter_with_fused_noise_statistics": round(t_fir_noise, 3), "estimate": round(t_est, 3),
-                         "bits_from_the_qad_estimate_left": round(t_bits, 3)},
+                         "bits_from_the_qad_estimate_left": round(t_bits, 3), "bits_from_the_qad_estimate_left_plus_d2h": round(t_bits_host, 3),
+                         "d2h_bytes": hb.blob_bytes, "host_counts_equal_device": bool(tuple(res.host_counts()[:3]) == host_counts)},
            "for_comparison_ms": {"iq_to_bits_ask_demodulating_again": round(t_bits_fused, 3),
                                  "same_outputs": bool(res_fused.host_counts()[:4] == res.host_counts()[:4])},
            "unfused_ms": {"fir_filter": round(t_fir, 3), "detect_noise_level": round(t_noise, 3), "fused_result_equal": fused_equal},
@@ -459,6 +467,9 @@ def extra_config5(pipe, dev, args):
     total_ii = t_costas + out["ii_center_0"][1]
     rec = {"workload": "configs[4]: 1 GiB 4-PSK, Costas loop (order 4, bandwidth 0.1) + detect_center + bits",
            "samples": n, "ms": round(total_i, 3), "ms_center_0": round(total_ii, 3),
+           "ms_incl_d2h": round(t_costas + t_center + out["i_auto_center"][3], 3), "ms_center_0_incl_d2h": round(t_costas + out["ii_center_0"][3], 3),
+           "ms_meaning": "ms: the stages with the outputs left in HBM; ms_incl_d2h: SURVEY 8(d)'s window -- the slicing stage ends with pulse table, bits, pauses, "
+                         "offsets and bit_sample_pos in pinned host memory (urh_amd.signal.Signal._digitize: compact blob, pack kernel + one copy)",
            "timing": "every stage: median of 5 wall times (GPU drained before and after) following 30 ms of repeats of the same stage (clock ramp)",
            "stages_ms": {"costas_demod": round(t_costas, 3), "detect_center": round(t_center, 3),
                          "grab_pulse_lens_plus_bits_auto_center": round(out["i_auto_center"][1], 3),
@@ -526,6 +537,108 @@ def run_extras(pipe, dev, args):
     return out
 
 
+def sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, fir_taps, halo_given, left_halo, with_oracle, steps=0):
+    """N > 1: the sharded result proves itself in the same run (every rank calls this; rank 0 returns the record).  One more pass with
+    bit_sample_pos on; rank 0 gathers every rank's piece (pulse-table rows that end in the shard, their bits, pauses, offsets, positions)
+    and every rank's SHARD, and compares
+      (ii) the stitched pieces with ONE single-GPU pass over the whole world x n capture on rank 0 (the path the -m gpu suite and the
+           N = 1 line check against the reference at 2^27) -- rows, bits, message offsets, pauses, positions, element for element --
+           and rank 0's demodulated shard with the first n samples of that pass's;
+      (i)  (with_oracle) rank 0's shard with the real reference (oracle/_ref: Cython afp_demod + grab_pulse_lens on the shard's 2^27
+           samples, C port of the Python tail): the demodulated signal (uint32 view), every row but the reference's last one (cut
+           short by the shard's end), and the bits those rows expand to.
+    fir_taps: the FIR-halo variant (BASELINE.json configs[3]: signal_functions.pyx:513-525 in front, 63-sample halo exchange); the
+    single-GPU side then filters the whole capture in one launch.  steps > 0: also time that many passes (per rank, max over ranks)."""
+    import numpy as np
+    from dataclasses import replace
+    from urh_amd.shard_engine import GpuShardEngine
+    from urh_amd.sharding import stitch
+    n = int(iq.shape[0])
+    dev = iq.device
+    p_pos = replace(p, write_bit_sample_pos=True)
+    hg = halo_given and fir_taps is None
+    was_host = pipe.engine.host_results
+    pipe.engine.host_results = False
+
+    def one():
+        x = pipe.fir_filter(iq, fir_taps) if fir_taps is not None else iq
+        return pipe.iq_to_bits(x, p_pos, want_qad=True, halo_given=hg, left_halo=left_halo if hg else None)
+    rec = {}
+    if steps > 0:
+        for _ in range(max(10, steps)):                       # clocks
+            one()
+        pipe.ctx.join(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one()
+        pipe.ctx.join(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rec["ms_per_step"] = round(float(t.item()) / steps * 1e3, 4)
+        rec["steps"] = steps
+    res = one()
+    pipe.ctx.join()
+    torch.cuda.synchronize()
+    pc = res.piece()
+    pieces = [None] * world if rank == 0 else None
+    dist.gather_object(pc, pieces, dst=0)
+    whole = torch.empty((world * n, 2), dtype=iq.dtype, device=dev) if rank == 0 else None
+    dist.gather(iq, [whole[r * n:(r + 1) * n] for r in range(world)] if rank == 0 else None, dst=0)
+    torch.cuda.synchronize()
+    pipe.engine.host_results = was_host
+    if rank != 0:
+        return None
+    names = ("rows", "bits", "msg_off", "pauses", "bit_sample_pos", "pos_off")
+    got = stitch(pieces)
+    single = GpuShardEngine(local_rank)
+    xs = single.fir(whole, fir_taps, None) if fir_taps is not None else whole
+    r1 = single.iq_to_bits_checked(xs, p_pos, want_qad=True)
+    want = (r1.ppseq(),) + tuple(r1.flat())
+    rec.update({"against": f"one single-GPU pass over the whole {world} x {n}-sample capture on rank 0" +
+                           (" (64-tap FIR over the whole capture in one launch first)" if fir_taps is not None else ""),
+                "rows": int(len(want[0])), "n_bits": int(len(want[1])), "n_messages": int(len(want[3]))})
+    for nm, a, b in zip(names, got, want):
+        rec[nm + "_equal"] = bool(np.array_equal(a, b))
+    rec["qad_rank0_shard_mismatches"] = int((res.qad.view(torch.int32) != r1.qad[:n].view(torch.int32)).sum().item())
+    ok = all(rec[nm + "_equal"] for nm in names) and rec["qad_rank0_shard_mismatches"] == 0
+    if fir_taps is not None:
+        rec["halo_bytes_per_rank"] = (int(fir_taps.shape[0]) - 1) * 8
+    if with_oracle and fir_taps is None:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import build_ref
+            import urh_oracle as oracle
+            host = iq.cpu().numpy()
+            order = 2 ** p.bits_per_symbol
+            if build_ref.built():
+                sf = build_ref.import_ref()[0]
+                qad = np.asarray(sf.afp_demod(host, p.noise_threshold, p.modulation_type, order, p.costas_loop_bandwidth))
+                pp = np.asarray(sf.grab_pulse_lens(qad, p.center, p.tolerance, p.modulation_type, p.samples_per_symbol, p.bits_per_symbol, p.center_spacing))
+                kind = "oracle/_ref (the reference's Cython afp_demod + grab_pulse_lens) on rank 0's shard"
+            else:
+                qad = oracle.afp_demod(host, p.noise_threshold, p.modulation_type, order)
+                pp = oracle.grab_pulse_lens(qad, p.center, p.tolerance, p.modulation_type, p.samples_per_symbol, p.bits_per_symbol, p.center_spacing)
+                kind = "oracle/ C restatement on rank 0's shard"
+            flat = oracle.ppseq_to_bits_flat(pp, p.samples_per_symbol, p.bits_per_symbol, True, p.pause_threshold)
+            k = max(len(pp) - 1, 0)                           # the reference's last row is cut short by the shard's end
+            m = max(0, len(flat[0]) - (int(pp[-1][1]) // p.samples_per_symbol + 2) * p.bits_per_symbol) if len(pp) else 0
+            orc = {"against": kind, "samples": n,
+                   "qad_mismatches": int((res.qad.cpu().numpy().view(np.uint32) != qad.view(np.uint32)).sum()),
+                   "rows_compared": k, "rows_prefix_equal": bool(np.array_equal(got[0][:k], pp[:k])),
+                   "bits_compared": m, "bits_prefix_equal": bool(np.array_equal(got[1][:m], flat[0][:m]))}
+            orc["bit_exact"] = orc["qad_mismatches"] == 0 and orc["rows_prefix_equal"] and orc["bits_prefix_equal"]
+            rec["oracle_shard0"] = orc
+            ok = ok and orc["bit_exact"]
+        except Exception as exc:                               # noqa: BLE001 (the check must not take the benchmark down: it says so instead)
+            rec["oracle_shard0"] = {"error": repr(exc)[:200]}
+            ok = False
+    rec["bit_exact"] = bool(ok)
+    del whole, xs, r1, single
+    torch.cuda.empty_cache()
+    return rec
+
+
+
 def self_launch(args):
     """`python bench.py --gpus N` (N > 1) from a bare interpreter: become `python -m torch.distributed.run ... bench.py ...`."""
     with socket.socket() as s:
@@ -553,6 +666,8 @@ def main():
     ap.add_argument("--no-d2h", action="store_true", help="skip the D2H-inclusive measurements (profiling runs: their passes overlap copies)")
     ap.add_argument("--no-device-loop", action="store_true", help="profiling runs: only the capture-stream loop (no run without positions, no device-only loop)")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[2] and configs[4] at full size (they add about a minute)")
+    ap.add_argument("--no-sharded-check", action="store_true", help="N > 1: skip the self-check (stitched pieces against a single-GPU pass over the whole "
+                                                                     "capture and the reference on rank 0's shard) and the FIR-halo variant")
     ap.add_argument("--no-upload", action="store_true", help="skip the H2D-inclusive measurement (1 GiB of pinned host memory)")
     ap.add_argument("--fir-halo", action="store_true", help="N > 1: prepend the 64-tap FIR with halo exchange (configs[3] 'FIR-halo' variant)")
     ap.add_argument("--pipeline", action="store_true",
@@ -615,6 +730,7 @@ def main():
         # the exchanges go straight through RCCL (a communicator of the library's own, a few us of host time each);
         # URH_BENCH_TORCH_COLLECTIVES=1: torch.distributed's all_gather_into_tensor instead (55-80 us of host time each)
         comm = TorchDistComm() if os.environ.get("URH_BENCH_TORCH_COLLECTIVES") == "1" else RcclComm.create()
+        comm_fallback_reason = ("URH_BENCH_TORCH_COLLECTIVES=1" if os.environ.get("URH_BENCH_TORCH_COLLECTIVES") == "1" else RcclComm.last_fallback_reason)
         pipe = ShardedPipeline(GpuShardEngine(local_rank, pipelined=args.pipeline, tuning=tuning, tail_stream_priority=tail_prio), comm)
         pipe.engine.host_results = False                     # switched on for the headline loop below
         if args.fir_halo:
@@ -944,6 +1060,25 @@ def main():
         assert rp.host_counts() == counts
         res = rp
 
+    # ---- N > 1: the line proves itself -- stitched pieces against a single-GPU pass over the whole capture on rank 0 and against the
+    # reference on rank 0's shard; then the FIR-halo variant BASELINE.json configs[3] names (timed, checked the same way) ---------------
+    shard_parity = fir_halo_rec = None
+    if sharded and not args.no_sharded_check:
+        pipe.ctx.join()
+        torch.cuda.synchronize()
+        shard_parity = sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, fir_taps, halo_given, left_halo,
+                                          with_oracle=not args.no_cpu_baseline)
+        if fir_taps is None:
+            from urh_amd.synth import spec_fir_taps
+            taps64 = torch.from_numpy(spec_fir_taps().view("float32").reshape(-1, 2).copy()).to(dev)
+            fir_halo_rec = sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, taps64, False, None, with_oracle=False,
+                                              steps=min(args.steps, 10))
+            if fir_halo_rec is not None:
+                fir_halo_rec["what"] = ("configs[3] FIR-halo variant: every rank filters its shard with the 64-tap complex FIR, its left neighbour's last 63 samples "
+                                        "as history (one all-gather of 504 bytes per rank), then the sharded IQ->bits pass with its halo exchanged "
+                                        "(three all-gathers); device-resident steps, max over ranks")
+                fir_halo_rec["Msamples_per_s"] = round(n * world / (fir_halo_rec["ms_per_step"] * 1e-3) / 1e6, 1)
+
     ranks_info = None
     if dist:
         info = [None] * world
@@ -995,7 +1130,10 @@ def main():
                        "rccl_world_size": world if dist else None,
                        "all_gathers_per_pass": (None if not sharded else (2 if halo_given else 3) + (1 if fir_taps is not None else 0)),
                        "collectives": (None if not sharded else type(pipe.comm).__name__),
+                       "collectives_fallback_reason": (comm_fallback_reason if sharded else None),
                        "host_blob_equals_device_outputs": host_equals_device,
+                       "sharded_parity": shard_parity, "parity_bit_exact": (shard_parity or {}).get("bit_exact") if sharded else None,
+                       "fir_halo": fir_halo_rec,
                        "ranks": ranks_info},
             "roofline": {"bound": "hbm", "kernel": "k_demod_runs_bp", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes/launch",
@@ -1036,7 +1174,7 @@ def main():
             out["extra"] = run_extras(DevicePipeline(local_rank, pipelined=False), dev, args)     # stage by stage: nothing overlapped
             # the driver keeps `config` and `roofline`: the other configurations' verdicts and times in short form there
             for key, ex in zip(("configs2_ook_fir", "configs4_psk_costas"), out["extra"]):
-                out["config"][key] = {"ms": ex.get("ms"), "Msamples_per_s": ex.get("value"),
+                out["config"][key] = {"ms": ex.get("ms"), "ms_incl_d2h": ex.get("ms_incl_d2h"), "Msamples_per_s": ex.get("value"),
                                       "bit_exact": (ex.get("parity") or {}).get("bit_exact"), "error": ex.get("error")}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist:

@@ -1702,3 +1702,24 @@ def test_bandpass_argument_errors(pipe):
         uf.convolve_dev(pipe, x, np.ones(40_000, dtype=np.complex128), 0, 100)        # more taps than the LDS window holds
     with pytest.raises(ValueError):
         uf.apply_bandpass_filter(np.zeros(0, np.complex64), 0.1, 0.2)
+
+
+def test_shard_result_host_looked_at_too_late_raises():
+    """Three blob slots rotate (GpuShardEngine(host_results=True)): a result whose host() is asked for after three later passes have been
+    issued would read another pass's blob -- it raises instead; results looked at in time are unaffected."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.shard_engine import GpuShardEngine
+    from urh_amd.sharding import ShardedPipeline, ThreadComm
+    n = 300_000
+    p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 50, 0.1, 8, True)
+    caps = [torch.from_numpy(synth_fsk(n, sps=50, seed=70 + i, noise=0.05)).cuda() for i in range(5)]
+    sp = ShardedPipeline(GpuShardEngine(0, pipelined=True, host_results=True), ThreadComm(ThreadComm.Shared(1), 0))
+    res = [sp.iq_to_bits(c, p, want_qad=True) for c in caps]
+    with pytest.raises(RuntimeError, match="reused"):
+        res[0].host()
+    with pytest.raises(RuntimeError, match="reused"):
+        res[1].host()
+    for k in (2, 3, 4):
+        h = res[k].host().check()
+        assert np.array_equal(h.ppseq(), res[k].piece()["rows"]) if k == 4 else h.n_rows > 0

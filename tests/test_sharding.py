@@ -145,3 +145,94 @@ def test_sharded_protocol_over_gloo(oracle):
     p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 20, 0.1, 8, True)
     assert_same(stitch([got[0], got[1]]), reference_result(oracle, x, p), "gloo")
     assert_same(stitch([got2[0], got2[1]]), reference_result(oracle, x, p), "gloo, halo with the shard")
+
+
+class _FakeRccl:
+    """stand-in for librccl.so (RcclComm.create's lib_loader hook): the five entry points, failing where told"""
+
+    def __init__(self, fail_uid=False, fail_init=False, hang_init=False):
+        import ctypes as C
+
+        class UniqueId(C.Structure):
+            _fields_ = [("internal", C.c_byte * 128)]
+        self.UniqueId = UniqueId
+        self.fail_uid, self.fail_init, self.hang_init = fail_uid, fail_init, hang_init
+        self.destroyed = 0
+
+    def ncclGetUniqueId(self, ref):
+        return 5 if self.fail_uid else 0
+
+    def ncclCommInitRank(self, ref, world, uid, rank):
+        if self.hang_init:
+            import time
+            time.sleep(30)
+        if self.fail_init:
+            return 3
+        ref._obj.value = 0x1234                              # (the communicator handle)
+        return 0
+
+    def ncclCommDestroy(self, comm):
+        self.destroyed += 1
+        return 0
+
+    def ncclGetErrorString(self, rc):
+        return b"fake"
+
+
+def _fallback_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from urh_amd.sharding import RcclComm
+        out = []
+        cpu = torch.device("cpu")
+
+        def attempt(tag, loader):
+            comm = RcclComm.create(lib_loader=loader, flag_device=cpu)
+            out.append((tag, type(comm).__name__, RcclComm.last_fallback_reason))
+            # the group is still in step afterwards: one more collective that every rank must reach
+            t = torch.tensor([rank + 1], dtype=torch.int32)
+            dist.all_reduce(t)
+            assert int(t.item()) == world * (world + 1) // 2
+
+        def load_fails_on_rank_1():
+            if rank == 1:
+                raise OSError("librccl.so: cannot open shared object file")
+            return _FakeRccl()
+        attempt("load fails on rank 1", load_fails_on_rank_1)
+        attempt("unique id fails on rank 0", lambda: _FakeRccl(fail_uid=(rank == 0)))
+        lib_ok = _FakeRccl()
+        attempt("init fails on rank 1", lambda: _FakeRccl(fail_init=True) if rank == 1 else lib_ok)
+        out.append(("destroyed on the rank that had succeeded", lib_ok.destroyed if rank == 0 else None, None))
+        RcclComm.INIT_TIMEOUT_S = 1.0
+        attempt("init hangs on rank 0", lambda: _FakeRccl(hang_init=(rank == 0)))
+        attempt("every step succeeds", lambda: _FakeRccl())
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_comm_create_agrees_on_the_fallback():
+    """RcclComm.create when ONE rank fails on its own -- the library does not load, rank 0 gets no unique id, ncclCommInitRank fails or
+    does not return: every rank ends with a TorchDistComm (none is left waiting in a broadcast or a rendezvous) and says why; with every
+    step succeeding on every rank it is an RcclComm.  (A stand-in library through create()'s lib_loader hook; flags on the CPU, gloo.)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    port = 31500 + os.getpid() % 2000
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    items = dict(q.get(timeout=120) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    for rank in (0, 1):
+        res = {tag: (kind, why) for tag, kind, why in items[rank]}
+        for tag in ("load fails on rank 1", "unique id fails on rank 0", "init fails on rank 1", "init hangs on rank 0"):
+            assert res[tag][0] == "TorchDistComm" and res[tag][1], (rank, tag, res[tag])
+        assert res["every step succeeds"] == ("RcclComm", None), (rank, res)
+    assert dict((t, k) for t, k, _ in items[0])["destroyed on the rank that had succeeded"] == 1
+    assert "cannot open" in dict((t, w) for t, _, w in items[1])["load fails on rank 1"]

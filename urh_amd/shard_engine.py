@@ -56,8 +56,8 @@ class ShardResult:
         if self._host is None:
             raise ValueError("the engine was not asked for host results (host_results=True)")
         if not isinstance(self._host, HostBits):
-            eng, slot, copied = self._host
-            self._host = eng._finish_host_copy(slot, copied, self.params, self.qad)
+            eng, slot, copied, pass_no = self._host
+            self._host = eng._finish_host_copy(slot, copied, self.params, self.qad, pass_no)
         return self._host
 
     # `stitch` accepts mappings: make the result itself usable as a piece
@@ -82,6 +82,7 @@ class GpuShardEngine(DevicePipeline):
         self._copy_stream = None
         self._predicted = 0                                 # bytes the next copy is sized for (0: the whole blob)
         self._hqueued = [False, False, False]               # a copy has been queued for the slot (its event means something)
+        self._slot_pass = [-1, -1, -1]                      # the pass whose blob the slot holds: a result looked at too late says so
 
     def _host_slot(self, cap_rows, cap_bits, cap_msg, cap_pos, has_pos):
         torch = self.torch
@@ -92,7 +93,9 @@ class GpuShardEngine(DevicePipeline):
             self._copy_stream = torch.cuda.Stream(self.device)
             self._predicted = 0
             self._hqueued = [False, False, False]
+            self._slot_pass = [-1, -1, -1]                  # (results of earlier passes point at the old buffers: host() on them raises)
         k = self._pass % 3
+        self._slot_pass[k] = self._pass
         self._pass += 1
         return k, cap
 
@@ -117,8 +120,11 @@ class GpuShardEngine(DevicePipeline):
             done.record(self._copy_stream)
         return n
 
-    def _finish_host_copy(self, k, copied, params, qad):
+    def _finish_host_copy(self, k, copied, params, qad, pass_no):
         from .pipeline import HostBits
+        if self._slot_pass[k] != pass_no:
+            raise RuntimeError(f"ShardResult.host(): the blob slot of pass {pass_no} has been reused by pass {self._slot_pass[k]} (three blob slots "
+                               f"rotate: look at a result before three later passes have been issued) or the slots were reallocated")
         dblob, hblob, done = self._hslots[k]
         done.synchronize()
         hdr = hblob[:128].numpy().view(np.int64)
@@ -272,7 +278,7 @@ class GpuShardEngine(DevicePipeline):
         self._keep += (flags_all,)
         _lib.check(_lib.load().urhgpu_shard_bits_finish_dev(self.ctx.handle, C.c_void_p(flags_all.data_ptr())))
         if self._hslot is not None:
-            self._res._host = (self, self._hslot, self._queue_host_copy(self._hslot))
+            self._res._host = (self, self._hslot, self._queue_host_copy(self._hslot), self._slot_pass[self._hslot])
         res, self._res = self._res, None
         res._keep = self._keep
         self._keep = ()

@@ -62,18 +62,19 @@ class RcclComm:
     stream, against 55-80 us per torch.distributed all_gather_into_tensor (tools/shard_host_probe.py: three of those per pass made
     the sharded pass host-bound).  The communicator's unique id travels through the torch.distributed group once, at start-up;
     torch.distributed is still what launches and synchronises the ranks.  `RcclComm.create(group)` falls back to TorchDistComm when
-    the library or the communicator cannot be had."""
+    the library or the communicator cannot be had -- on EVERY rank or on none: each step's outcome is agreed on through the group
+    before the next collective step begins (`last_fallback_reason` says which step failed)."""
 
     _UID_BYTES = 128
+    INIT_TIMEOUT_S = 120.0                 # ncclCommInitRank that has not returned by then counts as failed (the rank falls back with the others)
+    last_fallback_reason = None            # why the last create() returned a TorchDistComm (None: it returned an RcclComm)
 
-    def __init__(self, group=None, lib_path=None):
+    @staticmethod
+    def load_library(lib_path=None):
+        """librccl.so beside torch with the five entry points this class calls, prototypes set (raises when it cannot be had)"""
         import ctypes as C
         import os
         import torch
-        import torch.distributed as dist
-        self.torch, self.C = torch, C
-        self.rank = dist.get_rank(group)
-        self.world = dist.get_world_size(group)
         if lib_path is None:
             lib_path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         lib = C.CDLL(lib_path)
@@ -90,39 +91,100 @@ class RcclComm:
         lib.ncclCommDestroy.argtypes = [C.c_void_p]
         lib.ncclGetErrorString.restype = C.c_char_p
         lib.ncclGetErrorString.argtypes = [C.c_int]
-        self.lib = lib
-        uid = UniqueId()
-        if self.rank == 0:
-            self._check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        dev = torch.device("cuda", torch.cuda.current_device())
-        t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(dev)
-        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        uid = UniqueId.from_buffer_copy(bytes(t.cpu().numpy().tobytes()))
-        comm = C.c_void_p()
-        self._check(lib.ncclCommInitRank(C.byref(comm), self.world, uid, self.rank), "ncclCommInitRank")
-        self.comm = comm
+        lib.UniqueId = UniqueId
+        return lib
+
+    def __init__(self, group=None, lib_path=None):
+        """every step on every rank succeeds or raises: use create() when a rank may fail on its own"""
+        import torch
+        comm, reason = self._create(group, lambda: self.load_library(lib_path), torch.device("cuda", torch.cuda.current_device()), into=self)
+        if comm is None:
+            raise RuntimeError(reason)
 
     @classmethod
-    def create(cls, group=None):
-        """RcclComm, or TorchDistComm when RCCL cannot be reached directly (no GPU, no librccl.so beside torch, communicator set-up
-        failed).  Every rank takes the same branch: the outcome is agreed on through the group."""
+    def create(cls, group=None, lib_loader=None, flag_device=None):
+        """RcclComm, or TorchDistComm when RCCL cannot be reached directly (no GPU, no librccl.so beside torch, the unique id or the
+        communicator could not be made, ncclCommInitRank did not return within INIT_TIMEOUT_S).  Every rank takes the same branch:
+        after each step that a rank can fail on its own -- loading the library, rank 0's ncclGetUniqueId, ncclCommInitRank -- the
+        ranks agree on the outcome (all_reduce MIN over the group) BEFORE any of them enters the next collective step; a rank that
+        failed early therefore never leaves the others waiting in a broadcast or a communicator rendezvous.
+        lib_loader / flag_device: test hooks (a stand-in library; flags on the CPU under gloo)."""
         import torch
         import torch.distributed as dist
-        comm, ok = None, 1
-        try:
-            if not torch.cuda.is_available() or dist.get_backend(group) != "nccl":
-                raise RuntimeError("not an RCCL process group")
-            comm = cls(group)
-        except Exception:                                     # noqa: BLE001 -- any failure means "use torch.distributed"
-            ok = 0
         on_gpu = torch.cuda.is_available() and dist.get_backend(group) == "nccl"
-        flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-        if int(flag.item()) == 1:
-            return comm
-        if comm is not None:
-            comm.close()
-        return TorchDistComm(group)
+        dev = flag_device if flag_device is not None else (torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu"))
+        if lib_loader is None:
+            def lib_loader():
+                if not on_gpu:
+                    raise RuntimeError("not an RCCL process group (no GPU, or the group's backend is not nccl)")
+                return cls.load_library()
+        comm, reason = cls._create(group, lib_loader, dev)
+        cls.last_fallback_reason = reason
+        return comm if comm is not None else TorchDistComm(group)
+
+    @classmethod
+    def _create(cls, group, lib_loader, dev, into=None):
+        import ctypes as C
+        import threading
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+
+        def agree(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return int(flag.item()) == 1
+
+        # step 1 (every rank on its own): the library and its symbols
+        lib, err = None, None
+        try:
+            lib = lib_loader()
+        except Exception as exc:                              # noqa: BLE001 -- any failure means "use torch.distributed"
+            err = f"rank {rank}: librccl.so not usable: {exc!r}"
+        if not agree(lib is not None):
+            return None, err or "another rank could not load librccl.so"
+        # step 2 (rank 0 on its own, then one broadcast every rank takes part in): the unique id, with rank 0's verdict in front
+        uid = lib.UniqueId()
+        ok0 = 1
+        if rank == 0:
+            try:
+                rc = lib.ncclGetUniqueId(C.byref(uid))
+                if rc != 0:
+                    ok0, err = 0, f"ncclGetUniqueId: {rc}"
+            except Exception as exc:                          # noqa: BLE001
+                ok0, err = 0, f"ncclGetUniqueId: {exc!r}"
+        t = torch.frombuffer(bytearray(bytes([ok0]) + bytes(uid)), dtype=torch.uint8).to(dev)
+        dist.broadcast(t, src=src, group=group)
+        raw = bytes(t.cpu().numpy().tobytes())
+        if raw[0] != 1:
+            return None, err or "rank 0 could not make a unique id"
+        uid = lib.UniqueId.from_buffer_copy(raw[1:])
+        # step 3 (a rendezvous of the ranks inside RCCL): bounded by a timeout, and agreed on afterwards
+        comm = C.c_void_p()
+        box = {}
+
+        def init():
+            try:
+                box["rc"] = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+            except Exception as exc:                          # noqa: BLE001
+                box["exc"] = exc
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(cls.INIT_TIMEOUT_S)
+        ok = (not th.is_alive()) and box.get("rc") == 0
+        if not ok:
+            err = (f"rank {rank}: ncclCommInitRank did not return within {cls.INIT_TIMEOUT_S:.0f} s" if th.is_alive() else
+                   f"rank {rank}: ncclCommInitRank: {box.get('exc') or box.get('rc')}")
+        self = into if into is not None else cls.__new__(cls)
+        self.torch, self.C, self.lib = torch, C, lib
+        self.rank, self.world = rank, world
+        self.comm = comm if ok else None
+        if not agree(ok):
+            if ok:
+                self.close()
+            return None, err or "another rank could not join the communicator"
+        return self, None
 
     def _check(self, rc, what):
         if rc != 0:
@@ -132,6 +194,9 @@ class RcclComm:
         if getattr(self, "comm", None):
             self.lib.ncclCommDestroy(self.comm)
             self.comm = None
+
+    def __repr__(self):
+        return f"RcclComm(rank={self.rank}, world={self.world})"
 
     def _gather(self, t, stream):
         torch = self.torch
