@@ -61,6 +61,59 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
+def pmc_traffic_live(segments, kernel_substr, passes=3):
+    """HBM bytes per launch of the dominant kernel from PMC passes launched BY THIS RUN: two short rocprofv3 children of this file
+    (--pmc-child: the same capture, `passes` un-pipelined IQ->bits passes), FETCH_SIZE and WRITE_SIZE in a pass of their own each with
+    --kernel-trace only, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (both in KiB; FETCH_SIZE reports half
+    the bytes of wide coalesced streaming reads).  None when rocprofv3 is not there or a child fails (the caller then quotes the
+    committed profile and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    mean = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="urh_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--kernel-include-regex", "k_demod_runs_bp", "--output-format", "csv", "-d", d, "-o", "b", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--segments", str(segments), "--steps", str(passes)]
+            subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=180, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == ctr and kernel_substr in r.get("Kernel_Name", ""):
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"the {ctr} pass returned no rows for the kernel"
+            mean[ctr] = sum(vals) / len(vals)
+        except Exception as exc:                               # noqa: BLE001
+            return None, repr(exc)[:160]
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = mean["FETCH_SIZE"] * 1024 * 2 + mean["WRITE_SIZE"] * 1024
+    return int(total), (f"rocprofv3 --kernel-trace --pmc passes launched by this run (FETCH_SIZE {mean['FETCH_SIZE']:.0f} KiB x 2 [gfx950 wide-read correction] + "
+                        f"WRITE_SIZE {mean['WRITE_SIZE']:.0f} KiB, mean over {passes} un-pipelined passes of the same capture)")
+
+
+def pmc_child(args):
+    """what the PMC passes profile: the same capture, a few un-pipelined IQ->bits passes (qad materialised), nothing else"""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    from urh_amd.synth import spec_fsk_capture
+    dev = torch.device("cuda", 0)
+    iq, _ = spec_fsk_capture(args.segments, dev)
+    p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    pipe = DevicePipeline(0, pipelined=False)
+    pipe.reserve(iq.shape[0], p)
+    for _ in range(max(1, args.steps)):
+        pipe.iq_to_bits(iq, p, want_qad=True)
+    torch.cuda.synchronize()
+
+
 def copy_ceiling(torch, pipe, iq, n):
     """What a pure copy gets out of the HBM on THIS box, measured now (urhgpu_bench_copy_ceiling_dev): the hot kernel's access shape
     without its arithmetic (8 B in + 4 B out per sample) and the guide's plain float4 copy."""
@@ -674,7 +727,11 @@ def main():
                     help="(default) software-pipeline consecutive steps: the hot kernel of step i+1 on the main stream while the tail of "
                          "step i runs on a second stream")
     ap.add_argument("--no-pipeline", action="store_true", help="run the passes one after the other (profiling: the dominant kernel alone)")
+    ap.add_argument("--no-pmc", action="store_true", help="do not launch the two rocprofv3 --pmc children for roofline.traffic (quote the committed profile)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
@@ -1093,8 +1150,15 @@ def main():
         k_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
         bytes_per_sample = ALGO_BYTES_PER_SAMPLE if want_qad else 8
         achieved = (n * bytes_per_sample) / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, traffic_src = (pmc_traffic("k_demod_runs_bp<0, 4, 1, true") if want_qad and n == 128 * SEG
-                                else (None, None))
+        traffic = traffic_src = None
+        if want_qad and n == 128 * SEG:
+            if world == 1 and not force_sharded and not args.no_pmc and not args.no_extra:
+                traffic, traffic_src = pmc_traffic_live(args.segments, "k_demod_runs_bp<0, 4, 1, true")
+            if traffic is None:
+                why = traffic_src
+                traffic, traffic_src = pmc_traffic("k_demod_runs_bp<0, 4, 1, true")
+                if traffic is not None and why:
+                    traffic_src += f" [no live PMC pass: {why}]"
 
         def frac_of(ms):
             return round(n * bytes_per_sample / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None

@@ -16,4 +16,5 @@ for dt in (np.float32, np.int16, np.int8, np.uint8):
     for _ in range(20): r = pipe.iq_to_bits(x, p, want_qad=True)
     torch.cuda.synchronize(); dt_s = (time.perf_counter() - t0) / 20
     bps = x.element_size() * 2 + 4
-    print(f"{np.dtype(dt).name:8s} {dt_s * 1e3:.3f} ms/step  {n / dt_s / 1e9:.0f} Gsamples/s  {n * bps / dt_s / 1e12:.2f} TB/s algorithmic ({bps} B/sample)  counts {r.host_counts()[:3]}")
+    note = "" if dt != np.uint8 else "  [uint8: afp_demod takes unsigned samples as they are (the reference's IQArray makes .cu8 captures signed first): the +128 offset is part of THIS signal -- other rows / bits, not comparable with the lines above]"
+    print(f"{np.dtype(dt).name:8s} {dt_s * 1e3:.3f} ms/step  {n / dt_s / 1e9:.0f} Gsamples/s  {n * bps / dt_s / 1e12:.2f} TB/s algorithmic ({bps} B/sample)  counts {r.host_counts()[:3]}{note}")

@@ -27,11 +27,30 @@ def _newest_source() -> float:
     return t
 
 
+def _source_hash(extra_flags=()) -> str:
+    """sha256 over every source / header of the library and the compiler flags: what a built library is valid for"""
+    import hashlib
+    h = hashlib.sha256(" ".join([*FLAGS, *extra_flags]).encode())
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for f in sorted(os.listdir(root)):
+            if f.endswith((".hip", ".hpp", ".h")):
+                h.update(f.encode())
+                with open(os.path.join(root, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False, extra_flags=(), lib: str = LIB, tag: str = "") -> str:
     """extra_flags / lib / tag: A/B builds of tuning knobs (-DURH_...) into a differently named library that
-    URHGPU_LIB=<path> makes urh_amd._lib load (developer tooling; the product is the default build)."""
-    if not force and os.path.exists(lib) and os.path.getmtime(lib) >= _newest_source():
-        return lib
+    URHGPU_LIB=<path> makes urh_amd._lib load (developer tooling; the product is the default build).
+    A library is reused only when the hash of the sources it was built from (a side file next to it) matches the sources that are there
+    now -- an in-tree library of unknown origin (shipped, or older than an edit with a skewed clock) is rebuilt, not trusted."""
+    want = _source_hash(extra_flags)
+    stamp = lib + ".srchash"
+    if not force and os.path.exists(lib) and os.path.exists(stamp):
+        with open(stamp) as fh:
+            if fh.read().strip() == want:
+                return lib
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
@@ -47,6 +66,8 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), lib: str =
         raise RuntimeError(f"hipcc failed on {', '.join(failed)}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
     subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(want + "\n")
     return lib
 
 
