@@ -155,6 +155,8 @@ def tuning_from_env():
         t["profile_bracket"] = 1
     if "URH_TAIL_MASKED" in e:
         t["tail_masked"] = int(e["URH_TAIL_MASKED"])
+    if "URH_HOT_ANY_ORDER" in e:
+        t["hot_any_order"] = int(e["URH_HOT_ANY_ORDER"])
     if "URH_HOT_CUS_REMOVED" in e:
         t["hot_cus_removed_per_xcd"] = int(e["URH_HOT_CUS_REMOVED"])
     for env, key in (("URH_STREAM_SEGMENTS", "stream_segments"), ("URH_STREAM_SHAPE", "stream_shape"), ("URH_PACK_BLOCKS", "pack_blocks"),

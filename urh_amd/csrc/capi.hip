@@ -247,6 +247,11 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     if (s_tail && from_iq && ctx->hot_stop_event && n % kTile == 0) {
         if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot; }
         hot_done = g_hot_events.stop;
+        // Consecutive hot kernels of pipelined passes share nothing they write (scratch arenas rotate, the tail of the arena's last user
+        // has finished: begin_pipelined_pass) -- the next one need not wait for this one's last wavefronts and its end-of-kernel cache
+        // write-back (about 10 us between two hot kernels: profiles/r04b_timeline_pipelined.txt).  hipExtAnyOrderLaunch clears the
+        // dispatch packet's barrier bit; barrier packets (waits for events) still hold the queue.  A/B knob, off by default.
+        if (ctx->tune_hot_any_order && s != ctx->stream) g_hot_events.flags = 1u /* hipExtAnyOrderLaunch */;
     }
     {
         const int st = from_iq ? launch_demod_runs_iq(a, p->dtype, p->mod, d_qad != nullptr, s) : launch_runs_qad(a, s);
@@ -851,6 +856,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "stream_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_segments = value; }
     else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
     else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
+    else if (!strcmp(key, "hot_any_order")) { ctx->tune_hot_any_order = value != 0; }
     else if (!strcmp(key, "stream_spin")) { if (value < 0) return URHGPU_ERR_ARG; ctx->tune_stream_spin = value; }
     else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }
     else if (!strcmp(key, "stream_last_units")) { if (value < 1 || value > 64) return URHGPU_ERR_ARG; ctx->tune_stream_last_units = value; }

@@ -97,6 +97,7 @@ struct urhgpu_ctx {
     hipEvent_t ev_in = nullptr;
     int hot_lds_pad = 0;           // pipelined mode: dynamic LDS bytes added to every hot-kernel workgroup (see RunArgs::lds_pad)
     bool hot_stop_event = true;
+    bool tune_hot_any_order = false;      // pipelined passes: the hot dispatch without the AQL barrier bit (hipExtAnyOrderLaunch), see digitize()
     bool arena_wait_on_stream = false;   // pipelined mode: arena reuse guarded by a stream wait instead of bounded host run-ahead (URH_ARENA_WAIT=stream)
       // pipelined mode: the tail waits for the hot dispatch's own completion signal (URH_HOT_STOP_EVENT)
     hipStream_t tail_stream = nullptr;

@@ -1393,7 +1393,7 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
         const bool planes_ok = URH_BITPLANE && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes;
         if (planes_ok && O2 && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
             hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
-                                  (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
+                                  (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, g_hot_events.flags, a);
             g_hot_events.used = true;
         } else if (planes_ok && O2)
             hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);

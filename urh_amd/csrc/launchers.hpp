@@ -50,7 +50,7 @@ struct RunArgs {
 extern bool g_force_state_bytes;
 // urhgpu_ctx_profile_*: start / stop events attached to the next bit-plane hot-kernel dispatch itself (hipExtLaunchKernelGGL:
 // the kernel's own begin / end timestamps, what rocprofv3 reports); `used` says the launcher took them
-struct HotEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false; };
+struct HotEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false; unsigned flags = 0; };   // flags: hipExtLaunchKernelGGL's (hipExtAnyOrderLaunch)
 extern thread_local HotEvents g_hot_events;   // test hook: order 2 through the state-byte kernel too
 int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s);
 int launch_runs_qad(const RunArgs &a, hipStream_t s);
