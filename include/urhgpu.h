@@ -604,6 +604,8 @@ int urhgpu_bgra_lookup_dev(urhgpu_ctx *ctx, const float *d_db, int64_t frames, i
 int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_out, int64_t n_samples, int shape, int reps, float *ms_per_copy);
 /* Synchronous device -> host copy after urhgpu_ctx_sync (for callers that hold raw device pointers, e.g. urhgpu_host_result::d_qad). */
 int urhgpu_memcpy_to_host(urhgpu_ctx *ctx, const void *d_src, void *host_dst, int64_t bytes);
+/* ... and device -> device (a result's d_qad into memory the caller owns, before the stream's qad ring moves on). */
+int urhgpu_memcpy_dtod(urhgpu_ctx *ctx, void *d_dst, const void *d_src, int64_t bytes);
 
 /* Test hook: modulation order 2 (2-FSK, OOK, message segmentation) normally runs the bit-plane kernel
  * (k_demod_runs_bp) and every other order the state-byte kernel (k_demod_runs); on != 0 routes order 2 through the

@@ -244,3 +244,41 @@ def test_against_the_real_reference_signal_object(pipe):
                 msgs = mine.get_protocol()
                 assert [m.pause for m in msgs] == [m.pause for m in pa.messages], (name, key, val)
                 assert [list(m.bit_sample_pos) for m in msgs] == [list(m.bit_sample_pos) for m in pa.messages], (name, key, val)
+
+
+@pytest.mark.parametrize("ext,dtype,n", [(".complex", np.float32, 1 << 23), (".complex", np.float32, (1 << 20) - 777), (".complex32s", np.int16, 1 << 23),
+                                         (".cs8", np.int8, 3 << 21), (".cu8", np.uint8, 1 << 19)])
+def test_from_file_streamed_equals_from_file(oracle, tmp_path, ext, dtype, n):
+    """Signal.from_file_streamed -- the file read into pinned memory, uploaded piece by piece and demodulated as it lands -- leaves the
+    Signal in the state Signal.from_file + qad + bits() reach lazily: the capture on the device, the demodulated signal, the pulse table,
+    bits, pauses, positions; all of it equal to the oracle.  (2^23 samples of whole tiles: the segmented upload, four pieces; a partial
+    tile or fewer than 512 chunks: one copy + an ordinary pass; unsigned samples: the from_file fallback, converted on the device as the reference's IQArray does on the host.)"""
+    from urh_amd.signal import Signal
+    iq = synth_fsk(n, sps=100, seed=31, noise=0.04, pause_every=n // 5, pause_len=4000, dtype=dtype)
+    f = str(tmp_path / ("capture" + ext))
+    iq.tofile(f)
+    scale = 1.0 if dtype == np.float32 else float(np.abs(iq.astype(np.float64) - (128 if dtype == np.uint8 else 0)).max())
+    par = dict(modulation_type="FSK", samples_per_symbol=100, center=0.0, tolerance=5, noise_threshold=0.1 * scale, pause_threshold=8)
+    s = Signal.from_file_streamed(f, **par)
+    ref = Signal.from_file(f)
+    for k, v in par.items():
+        setattr(ref, k, v)
+    assert np.array_equal(s.iq.cpu().numpy(), ref.iq.cpu().numpy())
+    upload_passes = s.demod_passes
+    assert np.array_equal(s.qad.cpu().numpy().view(np.uint32), ref.qad.cpu().numpy().view(np.uint32))
+    passes = s.demod_passes
+    assert np.array_equal(s.ppseq(), ref.ppseq())
+    for a, b in zip(s._digitize()[1:], ref._digitize()[1:]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    if dtype != np.uint8:
+        assert s.demod_passes == upload_passes == 1               # nothing was demodulated again: the upload pass left everything in place
+    host = ref.iq.cpu().numpy()
+    qad = oracle.afp_demod(host, par["noise_threshold"], "FSK", 2)
+    pp = oracle.grab_pulse_lens(qad, 0.0, 5, "FSK", 100, 1, 1.0)
+    assert np.array_equal(s.qad.cpu().numpy().view(np.uint32), qad.view(np.uint32)) and np.array_equal(s.ppseq(), pp)
+    flat = oracle.ppseq_to_bits_flat(pp, 100, 1, True, 8)
+    for a, b in zip(s._digitize()[1:], flat):
+        assert np.array_equal(np.asarray(a), b)
+    s.center = 0.05                                               # a slicing parameter: re-sliced from the cached qad, no new pass over the samples
+    pp2 = oracle.grab_pulse_lens(qad, 0.05, 5, "FSK", 100, 1, 1.0)
+    assert np.array_equal(s.ppseq(), pp2) and s.demod_passes == passes

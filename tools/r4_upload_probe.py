@@ -23,7 +23,9 @@ for _ in range(6):
     torch.cuda.synchronize(); bare.append((time.perf_counter() - t0) * 1e3)
 print(f"bare pinned H2D of {n * 8 / 2**30:.2f} GiB: min {min(bare):.3f} ms ({n * 8 / min(bare) / 1e6:.1f} GB/s), all {[round(x, 3) for x in bare]}", flush=True)
 for pieces in [int(x) for x in (sys.argv[1:] or ["8", "4", "16", "2"])]:
-    pipe = DevicePipeline(0, pipelined=True, tuning={"upload_pieces": pieces})
+    tun = {"upload_pieces": pieces}
+    tun.update(dict((k, int(v)) for k, v in (kv.split("=") for kv in os.environ.get("UP_TUNE", "").split(",") if kv)))
+    pipe = DevicePipeline(0, pipelined=True, tuning=tun)
     pipe.reserve(n, p)
     st = pipe.stream(n, p, want_qad=True, want_pos=False)
     st.push(iq); st.flush()
@@ -33,10 +35,10 @@ for pieces in [int(x) for x in (sys.argv[1:] or ["8", "4", "16", "2"])]:
         st.push_upload(pinned, dst); r = st.flush()
         t.append((time.perf_counter() - t0) * 1e3)
     ok = bool(torch.equal(dst, iq))
-    print(f"upload in {pieces:2d} pieces: min {min(t):.3f} ms = bare + {min(t) - min(bare):+.3f} ms ({min(t) / min(bare):.4f} x), all {[round(x, 3) for x in t]}; "
+    print(f"{os.environ.get('UP_TUNE', '')} upload in {pieces:2d} pieces: min {min(t):.3f} ms = bare + {min(t) - min(bare):+.3f} ms ({min(t) / min(bare):.4f} x), all {[round(x, 3) for x in t]}; "
           f"rows {r[-1].n_rows} bits {r[-1].n_bits}; device copy equal {ok}; {st.stats()}", flush=True)
     st.close(); del st, pipe
-for tun in ({}, {"stream_policy": 2}):
+for tun in (() if os.environ.get("UP_ONLY") else ({}, {"stream_policy": 2})):
     pipe = DevicePipeline(0, pipelined=True, tuning=tun)
     pipe.reserve(n, p)
     st = pipe.stream(n, p, want_qad=True, want_pos=False)

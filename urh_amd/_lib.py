@@ -152,6 +152,7 @@ PROTOTYPES = {
     "urhgpu_path_minmax": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _vp]),
     "urhgpu_bench_copy_ceiling_dev": (_i, [_vp, _vp, _vp, _i64, _i, _i, C.POINTER(_f)]),
     "urhgpu_memcpy_to_host": (_i, [_vp, _vp, _vp, _i64]),
+    "urhgpu_memcpy_dtod": (_i, [_vp, _vp, _vp, _i64]),
     "urhgpu_test_force_state_bytes": (_i, [_i]),
     "urhgpu_test_force_tiles_per_chunk": (_i, [_i]),
     "urhgpu_test_force_generic_tail": (_i, [_i]),

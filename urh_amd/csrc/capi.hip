@@ -541,14 +541,31 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
             piece_hi[k] = (k < S - 1) ? std::min<int64_t>(bound[k + 1] + 1, pl.n_chunks) : pl.n_chunks;
             (void)lo;
         }
-        auto copy_piece = [&](int k) -> int {
-            const int64_t s0 = piece_lo[k] * pl.chunk_len, s1 = std::min<int64_t>(piece_hi[k] * pl.chunk_len, n);
-            URH_HIP(hipMemcpyAsync((char *)const_cast<void *>(d_iq) + (size_t)s0 * bps, (const char *)h_iq + (size_t)s0 * bps, (size_t)(s1 - s0) * bps,
-                                   hipMemcpyHostToDevice, s));
-            return URHGPU_OK;
-        };
+        // A/B (tuning "upload_own_stream"): the copies on a stream of their own after all -- a CU-masked one (full mask), which owns its
+        // hardware queue like the masked hot stream does, so that nothing else can end up sharing a queue with them
+        hipStream_t up = s;
+        if (ctx->tune_upload_own_stream && s == ctx->hot_masked && ctx->hot_masked) {
+            if (!ctx->upload_stream) {
+                uint32_t full[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
+                if (hipExtStreamCreateWithCUMask(&ctx->upload_stream, 8, full) != hipSuccess) { (void)hipGetLastError(); ctx->upload_stream = nullptr; }
+                for (int k = 0; ctx->upload_stream && k < kMaxSegments; ++k) URH_HIP(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
+            }
+            if (ctx->upload_stream) {
+                up = ctx->upload_stream;
+                URH_HIP(hipEventRecord(ctx->ev_piece[0], s));            // behind what the hot stream holds (and, through it, the caller's stream)
+                URH_HIP(hipStreamWaitEvent(up, ctx->ev_piece[0], 0));
+            }
+        }
         for (int k = 0; k < S; ++k) {
-            URH_TRY(copy_piece(k));
+            {
+                const int64_t s0 = piece_lo[k] * pl.chunk_len, s1 = std::min<int64_t>(piece_hi[k] * pl.chunk_len, n);
+                URH_HIP(hipMemcpyAsync((char *)const_cast<void *>(d_iq) + (size_t)s0 * bps, (const char *)h_iq + (size_t)s0 * bps, (size_t)(s1 - s0) * bps,
+                                       hipMemcpyHostToDevice, up));
+                if (up != s) {
+                    URH_HIP(hipEventRecord(ctx->ev_up[k], up));
+                    URH_HIP(hipStreamWaitEvent(s, ctx->ev_up[k], 0));
+                }
+            }
             a.launch_lo = piece_lo[k]; a.launch_hi = piece_hi[k];
             const int stl = launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s);
             if (stl != URHGPU_OK) return stl;
@@ -727,6 +744,8 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
         (void)hipFree(ctx->d_seg);
         if (ctx->bits_stream) { (void)hipStreamSynchronize(ctx->bits_stream); (void)hipStreamDestroy(ctx->bits_stream); }
         for (hipEvent_t e : ctx->ev_piece) if (e) (void)hipEventDestroy(e);
+        if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
+        for (hipEvent_t e : ctx->ev_up) if (e) (void)hipEventDestroy(e);
         for (int k = 0; k < 3; ++k) {
             if (ctx->ev_hot_done[k]) (void)hipEventDestroy(ctx->ev_hot_done[k]);
             if (ctx->ev_bits[k]) (void)hipEventDestroy(ctx->ev_bits[k]);
@@ -858,6 +877,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
     else if (!strcmp(key, "hot_any_order")) { ctx->tune_hot_any_order = value != 0; }
     else if (!strcmp(key, "stream_spin")) { if (value < 0) return URHGPU_ERR_ARG; ctx->tune_stream_spin = value; }
+    else if (!strcmp(key, "upload_own_stream")) { ctx->tune_upload_own_stream = value != 0; }
     else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }
     else if (!strcmp(key, "stream_last_units")) { if (value < 1 || value > 64) return URHGPU_ERR_ARG; ctx->tune_stream_last_units = value; }
     else if (!strcmp(key, "stream_fuse_gate")) { ctx->tune_stream_fuse_gate = value != 0; }
@@ -1890,6 +1910,14 @@ int urhgpu_memcpy_to_host(urhgpu_ctx *ctx, const void *d_src, void *host_dst, in
     URH_HIP(hipSetDevice(ctx->device));
     URH_TRY(urhgpu_ctx_sync(ctx));
     if (bytes) URH_HIP(hipMemcpy(host_dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return URHGPU_OK;
+}
+
+int urhgpu_memcpy_dtod(urhgpu_ctx *ctx, void *d_dst, const void *d_src, int64_t bytes) {
+    if (!ctx || bytes < 0 || (bytes > 0 && (!d_src || !d_dst))) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(urhgpu_ctx_sync(ctx));
+    if (bytes) URH_HIP(hipMemcpy(d_dst, d_src, (size_t)bytes, hipMemcpyDeviceToDevice));
     return URHGPU_OK;
 }
 

@@ -120,10 +120,13 @@ struct urhgpu_ctx {
     int tune_stream_shape = 0;     // 0: equal segments; 1: halving (1/2, 1/4, ... of the capture, the last two equal); 2: equal segments and
                                    // a short last one (tune_stream_last_units alignment units of 256 chunks)
     int tune_stream_last_units = 1;
-    int tune_stream_spin = 4000;            // hipEventQuery polls before the host parks in hipEventSynchronize (urhgpu_stream_* results)
+    int tune_stream_spin = 0;               // hipEventQuery polls before the host parks in hipEventSynchronize (urhgpu_stream_* results)
     int tune_upload_pieces = 4;             // pieces of urhgpu_stream_push_upload: pieces - 1 equal ones and a short last one (shape 2)
     bool tune_stream_fuse_gate = true;      // the last segment's gate inside its one-workgroup resolve kernel (SegGate::fused)
     bool tune_stream_final_on_rows = true;  // the last bits segment on the rows stream, right behind the last rows (no cross-stream hop)
+    hipStream_t upload_stream = nullptr;    // upload mode, tune_upload_own_stream: the copies on a CU-masked (full mask) stream of their own -- such a stream owns its hardware queue
+    hipEvent_t ev_up[16] = {};              // piece k has landed (tune_upload_own_stream)
+    bool tune_upload_own_stream = false;
     hipEvent_t ev_piece[16] = {};           // the hot kernel of piece k has finished (the rows segment k waits for it: no polling gate in upload mode)
     int tune_stream_bits_segments = 3;   // bits segments (tile scan, group scan, expansion, pack) of a streamed pass, on their own stream
     int tune_pack_blocks = 0;      // workgroups of a segment's pack kernel (0: default)

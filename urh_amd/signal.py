@@ -66,6 +66,71 @@ class Signal:
         s.iq = from_file(filename, device=s.pipe.device)
         return s
 
+    @classmethod
+    def from_file_streamed(cls, filename, pinned=None, **params):
+        """`Signal(filename)` followed by `get_protocol_from_signal()` (Signal.py:42-112, IQArray.py:206-227, ProtocolAnalyzer.py:227-287)
+        for a capture whose parameters are already known (a project file keeps them per signal): the file is read into PINNED host
+        memory, and the upload does not wait for anything -- pieces are copied into the device buffer the Signal keeps and demodulated
+        as they land (urhgpu_stream_push_upload); when the call returns the Signal holds the capture, its demodulated signal and the
+        digitisation for the given parameters (`bits()` / `get_protocol()` cost nothing more).  params: the Signal's parameters
+        (modulation_type, samples_per_symbol, center, tolerance, noise_threshold, ...) plus the constructor's keywords.
+        Float32 / signed captures of ASK-less, PSK-less modulations take this route; everything else (unsigned sample types, which the
+        reference converts first; ASK; PSK) falls back to from_file + the ordinary lazy passes -- same results either way.
+        pinned: an optional dict that keeps the pinned read buffer between calls (a file browser opening capture after capture)."""
+        ctor = {k: params.pop(k) for k in ("name", "sample_rate", "timestamp", "pipe", "device") if k in params}
+        if "modulation_type" in params:
+            ctor["modulation"] = params.pop("modulation_type")
+        signed = {".complex16s": np.int8, ".cs8": np.int8, ".complex32s": np.int16, ".cs16": np.int16}
+        unsigned = (".complex16u", ".cu8", ".complex32u", ".cu16")
+        s = cls(None, **ctor)
+        for k, v in params.items():
+            setattr(s, k, v)
+        dt = np.dtype(next((t for ext, t in signed.items() if filename.endswith(ext)), np.float32))
+        lo, hi = _limits(dt)
+        gated = not (s.noise_threshold < (2 * max(lo ** 2, hi ** 2)) ** 0.5)      # quad_demod's zeros(2) case (:474-484)
+        if filename.endswith(unsigned) or s.modulation_type != "FSK" or gated:
+            from .iq_array import from_file
+            s.iq = from_file(filename, device=s.pipe.device)
+            return s
+        torch = s.pipe.torch
+        import os
+        n_values = os.path.getsize(filename) // dt.itemsize // 2 * 2          # convert_array_to_iq drops the last half sample (:238-239)
+        n = n_values // 2
+        if n < 3:
+            from .iq_array import from_file
+            s.iq = from_file(filename, device=s.pipe.device)
+            return s
+        keep = pinned if pinned is not None else {}
+        tdt = {np.dtype(np.float32): torch.float32, np.dtype(np.int8): torch.int8, np.dtype(np.int16): torch.int16}[dt]
+        buf = keep.get("buf")
+        if buf is None or buf.dtype != tdt or buf.numel() < n_values:
+            buf = torch.empty(n_values, dtype=tdt).pin_memory()
+            keep["buf"] = buf
+        host = buf[:n_values]
+        with open(filename, "rb") as fh:                                       # straight into the pinned buffer: no pageable copy
+            got = fh.readinto(memoryview(host.numpy()).cast("B"))
+        if got != n_values * dt.itemsize:
+            raise OSError(f"short read from {filename}")
+        host = host.view(n, 2)
+        dev = torch.empty((n, 2), dtype=tdt, device=s.pipe.device)
+        p = s.params()
+        st = s.pipe.stream(n, p, want_qad=True, want_pos=True, dtype=dt)
+        try:
+            st.push_upload(host, dev)
+            (h,) = st.flush()
+            h.check()
+            from .pipeline import LazyDigitized
+            qad = torch.empty(n, dtype=torch.float32, device=s.pipe.device)
+            import ctypes as C
+            _lib.check(_lib.load().urhgpu_memcpy_dtod(s.pipe.ctx.handle, C.c_void_p(qad.data_ptr()), C.c_void_p(h.d_qad_ptr), n * 4))
+            s._iq = dev
+            s._qad = qad
+            s.demod_passes += 1
+            s._bits, s._bits_key = LazyDigitized(h, want_pos=True).materialize(), s._slice_key()      # (the stream's pinned blob goes away with it)
+        finally:
+            st.close()
+        return s
+
     @property
     def iq(self):
         return self._iq
