@@ -264,6 +264,7 @@ typedef struct urhgpu_outputs {
  *   int8  row_state[n_rows]   (-1 = pause; grab_pulse_lens' column 0)
  *   uint8 bits[(n_bits + 7) / 8]   eight bits per byte, most significant first (numpy.packbits / unpackbits order)
  *   int32 row_len[n_rows]     (grab_pulse_lens' column 1; captures of up to 2^31 - 1 samples)
+ *   (row_state -128: URHGPU_ROW_ABSORBED -- the first row of a rank's piece of a sharded ASK capture that was merged into the previous rank's last row)
  *   uint32 pos32[n_pos]       (bit_sample_pos; absent when the pass wrote no positions)
  * truncated != 0: bit 0: a capacity was exceeded (rows_needed > cap_rows, or more messages / bits / positions than fit): the sections
  * hold what fitted, the caller repeats the pass with larger capacities; bit 2: a row length did not fit int32, a position uint32 or a

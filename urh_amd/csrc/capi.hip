@@ -1411,8 +1411,7 @@ int urhgpu_shard_bits_finish_dev(urhgpu_ctx *ctx, const int64_t *d_flags_all) {
         URH_TRY(launch_bits_finish(o.rows, ss->d_small + 3, cap, bp, bo, ss->bits_scratch, sst, s));
     }
     if (o.blob) {
-        // the compact mirror of this rank's piece (compact.hip); an absorbed first row (ASK) has no 8-bit state: wide outputs only
-        if (ask) return URHGPU_ERR_UNSUPPORTED;
+        // the compact mirror of this rank's piece (compact.hip); an absorbed first row (ASK) is shipped as state -128
         URH_TRY(launch_pack_blob(&o, ss->p.write_bit_sample_pos, s));
     }
     URH_HIP(hipGetLastError());

@@ -59,10 +59,13 @@ __global__ __launch_bounds__(256) void k_pack_blob(const PackArgs a) {
         int8_t *st = (int8_t *)(a.blob + L.off_row_state);
         for (int64_t i = gtid; i < L.n_rows; i += stride) {
             const longlong2 r = *(const longlong2 *)(a.rows + 2 * i);
-            st[i] = (int8_t)r.x; len[i] = (int32_t)r.y;
+            // (a rank's piece of a sharded ASK capture may start with a row that was merged into the previous rank's last one:
+            // URHGPU_ROW_ABSORBED, shipped as state -128)
+            const bool absorbed = (r.x == kRowAbsorbed);
+            st[i] = absorbed ? (int8_t)-128 : (int8_t)r.x; len[i] = (int32_t)r.y;
             // (a length may be NEGATIVE: the reference's last row is pulse_length - tolerance, signal_functions.pyx:485-493, below zero for a
             // capture shorter than the tolerance; int32 holds that)
-            narrow_fail |= (r.x < -128 || r.x > 127 || r.y < -0x80000000ll || r.y > 0x7fffffffll);
+            narrow_fail |= ((!absorbed && (r.x < -127 || r.x > 127)) || r.y < -0x80000000ll || r.y > 0x7fffffffll);
         }
     }
     if (a.has_pos) {

@@ -322,6 +322,8 @@ class HostBits:
         out = np.empty((self.n_rows, 2), np.int64)
         out[:, 0] = self.row_state
         out[:, 1] = self.row_len
+        if self.n_rows and self.row_state[0] == -128:        # a sharded ASK piece whose first row was merged into the previous rank's last
+            return out[1:]                                   # row (URHGPU_ROW_ABSORBED): not a row of this piece, as ShardResult.piece() has it
         return out
 
     def bits(self) -> np.ndarray:

@@ -69,7 +69,7 @@ class ShardResult:
 
 class GpuShardEngine(DevicePipeline):
     """DevicePipeline (context, stream, output buffers) + the shard phases.
-    host_results=True (FSK / other modulations, not ASK): every pass also leaves its compact result blob (include/urhgpu.h) in pinned
+    host_results=True: every pass also leaves its compact result blob (include/urhgpu.h) in pinned
     host memory -- packed at the end of the pass's tail, copied by a third stream while the following passes run, three blob slots in
     rotation, the copy sized by the previous pass's blob (what a prediction misses is fetched when the result is looked at):
     ShardResult.host().  The same window as the single-GPU CaptureStream, per rank."""
@@ -210,8 +210,6 @@ class GpuShardEngine(DevicePipeline):
         o.counts = counts.data_ptr()
         self._hslot = None
         if self.host_results:
-            if p.modulation_type == "ASK":
-                raise ValueError("host_results: the compact blob has no 8-bit code for an absorbed ASK row")
             k, cap = self._host_slot(cap_rows, cap_bits, cap_msg, cap_pos if pos is not None else 0, pos is not None)
             dblob, _, done = self._hslots[k]
             # the blob slot is written by this pass's tail: behind the copy that last read it (three passes ago)
