@@ -98,8 +98,11 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
  * tail; 0: no mask, the hot kernel runs on the caller's stream), "tail_masked" (1, before urhgpu_ctx_set_pipelined: the tail runs on a
  * private stream masked to exactly the CUs the hot mask leaves out, replacing the caller's tail stream; measured no faster -- the hot
  * kernel gains 1 % and a single capture's latency loses 30 % -- default 0).  Streamed passes of urhgpu_stream_* (the tail in segments
- * beside the hot kernel): "stream_policy" (0, default: a pass is streamed when nothing of an earlier pass is still running -- one capture,
- * where the tail's latency counts; 1: every qualifying pass; 2: never), "stream_segments" (rows segments, 1 .. 16, default 6),
+ * beside the hot kernel): "stream_policy" (5, default: 3 for passes that ship no positions, 0 for those that do; 0: a pass is streamed when nothing
+ * of an earlier pass is still running -- one capture, where the tail's latency counts --, else its blob is packed at the end and copied by the
+ * copy engine; 1: every qualifying pass in segments; 2: never; 3: every qualifying pass DIRECT -- one segment, the ordinary tail
+ * behind the hot kernel, whose kernels store rows and packed results into the pinned host blob themselves (no pack of the whole table,
+ * no copy engine); 4: segments when idle, direct otherwise), "stream_segments" (rows segments, 1 .. 16, default 6),
  * "stream_bits_segments" (default 3), "stream_shape" (0: equal segments; 1: halving; 2: equal segments and a short last one of
  * "stream_last_units" x 256 chunks), "stream_fuse_gate" / "stream_final_on_rows" (1, default: the last segment's gate inside its
  * one-workgroup resolve kernel; its bits kernels on the rows stream), "pack_blocks" (workgroups of a segment's pack kernel),

@@ -460,15 +460,30 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     a.lds_pad = ctx->hot_lds_pad;
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     int64_t bound[kMaxSegments + 1];
-    const int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, h_iq ? ctx->tune_upload_pieces : ctx->tune_stream_segments, h_iq ? 2 : ctx->tune_stream_shape, ctx->tune_stream_last_units, bound) : 0;
-    if (S < 2) return URHGPU_OK;                               // too short to cut, or not the bit-plane kernel's work: the ordinary path
-    if (ctx->tune_stream_policy == 2 && !h_iq) return URHGPU_OK;
-    if (ctx->tune_stream_policy == 0 && ctx->passes_begun > 0 && !h_iq) {
+    int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, h_iq ? ctx->tune_upload_pieces : ctx->tune_stream_segments, h_iq ? 2 : ctx->tune_stream_shape, ctx->tune_stream_last_units, bound) : 0;
+    // DIRECT passes (stream_policy 3, or 4 for the passes that policy 0 would not stream): ONE segment -- the ordinary tail behind the hot
+    // kernel (an event, no gate), but rows and packed results are STORED into the pinned host blob by the tail's own kernels: no pack of
+    // the whole table at the end, no copy engine, no predicted copy size.
+    // Policy 5 (the default): direct when the pass ships no positions (measured, profiles/r04c_ab_direct.txt: 0.294-0.300 ms per
+    // pipelined step against 0.306 through pack + copy engine, one capture alone the same as with segments), policy 0 when it does --
+    // 5.4 MB of uint32 positions stored over PCIe by a pack kernel take longer than the copy engine needs for the whole blob (0.41 ms).
+    int policy = ctx->tune_stream_policy;
+    if (policy == 5) policy = (p->write_bit_sample_pos && out->pos) ? 0 : 3;
+    bool direct = false;
+    if (!h_iq && runs_streamable(a) && host_blob && policy == 3) direct = true;
+    if (S < 2 && !direct) return URHGPU_OK;                    // too short to cut, or not the bit-plane kernel's work: the ordinary path
+    if (policy == 2 && !h_iq) return URHGPU_OK;
+    if ((policy == 0 || policy == 4) && ctx->passes_begun > 0 && !h_iq) {
         // is anything of the pass before still running?  Then this pass's tail will run beside ITS successor's hot kernel as well: one piece
         const hipError_t q = hipEventQuery(ctx->ev_tail[(ctx->flip + 2) % 3]);
-        if (q == hipErrorNotReady) { (void)hipGetLastError(); return URHGPU_OK; }
-        if (q != hipSuccess) URH_HIP(q);
+        if (q == hipErrorNotReady) {
+            (void)hipGetLastError();
+            if (policy == 0 || !host_blob) return URHGPU_OK;
+            direct = true;
+        } else if (q != hipSuccess) URH_HIP(q);
     }
+    if (direct) { S = 1; bound[0] = 0; bound[1] = pl.n_chunks; }
+    const bool event_start = (h_iq != nullptr) || direct;      // the rows segments start behind events, not behind polling gates
     if (!ctx->d_seg) {
         URH_HIP(hipMalloc(&ctx->d_seg, 3 * kSegBlockBytes));
         URH_HIP(hipMemset(ctx->d_seg, 0, 3 * kSegBlockBytes));
@@ -575,6 +590,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         URH_HIP(hipEventRecord(ctx->ev_hot_done[slot], s));
         hot_done = ctx->ev_hot_done[slot];
     } else {
+    if (direct) { a.progress = nullptr; a.n_seg = 0; }         // (plain stores in the hot kernel, no counters: the tail starts behind its end)
     const bool prof = prof_begin_record(ctx, s);
     // the hot kernel's completion: the dispatch's own completion signal where the launcher takes events (an event recorded behind the
     // kernel is one more barrier packet between two hot kernels); nobody waits for it before the last segment has been queued
@@ -633,7 +649,8 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     hipStream_t last_stream = tb;
     for (int k = 0; k < S; ++k) {
         if (h_iq) URH_HIP(hipStreamWaitEvent(ts, ctx->ev_piece[k], 0));
-        RowsSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], SegGate{h_iq ? nullptr : progress, k, target[k], k == 0 ? 1 : 0, st, (long long)200000000, 0},
+        else if (direct) URH_HIP(hipStreamWaitEvent(ts, hot_done, 0));
+        RowsSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], SegGate{event_start ? nullptr : progress, k, target[k], k == 0 ? 1 : 0, st, (long long)200000000, 0},
                        h_state, h_len, ctx->tune_stream_fuse_gate ? 1 : 0};
         URH_TRY(launch_rows_segment(r, e, tm, bp, st, sg, ts));
         while (jb < Sb && bits_end_at[jb] < k) ++jb;           // (a bits segment that would end before the first rows segment: none)
@@ -873,7 +890,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "tail_masked")) ctx->tune_tail_masked = value != 0;
     else if (!strcmp(key, "hot_cus_removed_per_xcd")) { if (value < 0 || value > 16) return URHGPU_ERR_ARG; ctx->tune_hot_cus_removed = value; }
     else if (!strcmp(key, "stream_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_segments = value; }
-    else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
+    else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 5) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
     else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
     else if (!strcmp(key, "hot_any_order")) { ctx->tune_hot_any_order = value != 0; }
     else if (!strcmp(key, "stream_spin")) { if (value < 0) return URHGPU_ERR_ARG; ctx->tune_stream_spin = value; }

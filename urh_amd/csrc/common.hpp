@@ -112,7 +112,9 @@ struct urhgpu_ctx {
     void *d_seg = nullptr;         // 3 x kSegBlockBytes, zero between passes
     bool seg_dirty[3] = {false, false, false};   // a pass failed between its hot launch and its last segment: counters not trusted
     int tune_stream_segments = 6;  // rows segments of a streamed pass's tail (1: no streaming), urhgpu_ctx_set_tuning("stream_segments")
-    int tune_stream_policy = 0;    // 0: stream a pass only when the pipeline is idle (nothing of an earlier pass still running: a single
+    int tune_stream_policy = 5;    // 5 (default): 3 for passes that ship no positions, 0 for those that do; 3: every pass DIRECT (one segment behind the hot
+                                   // kernel, rows and packed results stored into the pinned host blob by the tail's kernels); 4: segments when idle, direct
+                                   // otherwise; 0: stream a pass only when the pipeline is idle (nothing of an earlier pass still running: a single
                                    // capture, where the latency of the tail counts); 1: every qualifying pass; 2: never.  Beside the hot kernel
                                    // of a FOLLOWING pass the segments' short kernels are slower than one tail over the whole capture
                                    // (memory latency under a saturated HBM), so back-to-back passes keep the one-piece tail

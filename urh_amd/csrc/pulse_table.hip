@@ -794,6 +794,7 @@ __global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     if (gate.seg && gate.init && blockIdx.x == 0 && t == 0) {
+        if (!gate.progress) gate.seg->err = 0;               // (no gate kernel in front of this segment: its part of the initialisation)
         // the first rows segment of a streamed pass clears what the bits segments carry along (they start behind this kernel)
         int64_t *w = (int64_t *)&gate.seg->in[0];
         for (int i = 0; i < (int)(2 * sizeof(SegState::In) / 8); ++i) w[i] = 0;
@@ -1870,7 +1871,7 @@ int launch_rows_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailM
     if (sg.index != 0) ft_resolve.want_bits = 0;
     SegGate gate = sg.gate;
     gate.fused = (sg.fuse_gate && gate.progress && !gate.init && resolve_blocks(sg.c1 - sg.c0) == 1) ? 1 : 0;
-    if (!gate.fused && (gate.progress || gate.init)) hipLaunchKernelGGL(k_seg_gate, dim3(1), dim3(64), 0, s, gate);
+    if (!gate.fused && gate.progress) hipLaunchKernelGGL(k_seg_gate, dim3(1), dim3(64), 0, s, gate);
     hipLaunchKernelGGL(k_resolve_one, dim3((unsigned)resolve_blocks(sg.c1 - sg.c0)), dim3(kResolveBlock), 0, s, r, ft_resolve, sg.c0 / kResolveBlock, gate);
     hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((g.w_end - g.w0 + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
     return URHGPU_OK;
