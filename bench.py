@@ -160,7 +160,7 @@ def tuning_from_env():
     if "URH_HOT_CUS_REMOVED" in e:
         t["hot_cus_removed_per_xcd"] = int(e["URH_HOT_CUS_REMOVED"])
     for env, key in (("URH_STREAM_SEGMENTS", "stream_segments"), ("URH_STREAM_SHAPE", "stream_shape"), ("URH_PACK_BLOCKS", "pack_blocks"),
-                     ("URH_STREAM_LAST_UNITS", "stream_last_units"), ("URH_UPLOAD_PIECES", "upload_pieces"), ("URH_STREAM_FUSE_GATE", "stream_fuse_gate"), ("URH_STREAM_FINAL_ON_ROWS", "stream_final_on_rows"),
+                     ("URH_STREAM_LAST_UNITS", "stream_last_units"), ("URH_STREAM_POS_DIRECT", "stream_pos_direct"), ("URH_UPLOAD_PIECES", "upload_pieces"), ("URH_STREAM_FUSE_GATE", "stream_fuse_gate"), ("URH_STREAM_FINAL_ON_ROWS", "stream_final_on_rows"),
                      ("URH_STREAM_BITS_SEGMENTS", "stream_bits_segments"), ("URH_STREAM_POLICY", "stream_policy")):
         if env in e:
             t[key] = int(e[env])

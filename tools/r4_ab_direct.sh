@@ -8,7 +8,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); c=d["config"]; r=d["roofline"]
 print(sys.argv[1], "headline", d["ms_per_step"], "with pos", c.get("ms_per_step_with_device_positions"), "device only", c.get("device_only_ms_per_step"), "kernel", r["kernel_ms"], "single", c.get("single_capture_incl_compact_d2h_ms"), c.get("stream_stats"))'
 for rep in 1 2 3; do
-  python bench.py $F 2>/dev/null | python -c "$show" policy0
-  URH_STREAM_POLICY=3 python bench.py $F 2>/dev/null | python -c "$show" policy3
-  URH_STREAM_POLICY=4 python bench.py $F 2>/dev/null | python -c "$show" policy4
+  URH_STREAM_POLICY=0 python bench.py $F 2>/dev/null | python -c "$show" policy0
+  URH_STREAM_POLICY=5 python bench.py $F 2>/dev/null | python -c "$show" policy5_default
+  URH_STREAM_POS_DIRECT=0 python bench.py $F 2>/dev/null | python -c "$show" policy5_pos_via_pack
 done

@@ -122,6 +122,7 @@ struct urhgpu_ctx {
     int tune_stream_shape = 0;     // 0: equal segments; 1: halving (1/2, 1/4, ... of the capture, the last two equal); 2: equal segments and
                                    // a short last one (tune_stream_last_units alignment units of 256 chunks)
     int tune_stream_last_units = 1;
+    bool tune_stream_pos_direct = true;    // direct passes ship positions themselves (group scan + expansion store uint32 into the host blob)
     int tune_stream_spin = 0;               // hipEventQuery polls before the host parks in hipEventSynchronize (urhgpu_stream_* results)
     int tune_upload_pieces = 4;             // pieces of urhgpu_stream_push_upload: pieces - 1 equal ones and a short last one (shape 2)
     bool tune_stream_fuse_gate = true;      // the last segment's gate inside its one-workgroup resolve kernel (SegGate::fused)

@@ -501,6 +501,7 @@ struct GroupStore {
     GroupOut *gout;
     int64_t *msg_off, *pauses, *pos_off, *pos;
     int64_t cap_msg, cap_pos;
+    uint32_t *h_pos = nullptr;   // direct passes that ship positions: the compact blob's pos32 section in pinned HOST memory (stored as they are written)
     __device__ void operator()(int64_t g, const VecK<3> &val, const VecK<3> &ex) const {
         const GroupInfo gi = ld.groups[g];
         const bool kept = ld.kept(g, gi);
@@ -519,9 +520,12 @@ struct GroupStore {
         if (kept && ld.write_pos) {
             const int64_t p0 = ex.v[2] + val.v[1];            // sentinels follow the per-bit positions
             if (gi.closed) {
-                if (p0 + 1 < cap_pos) { pos[p0] = gi.ts_close; pos[p0 + 1] = gi.ts_close + gi.pause; }
+                if (p0 + 1 < cap_pos) {
+                    pos[p0] = gi.ts_close; pos[p0 + 1] = gi.ts_close + gi.pause;
+                    if (h_pos) { h_pos[p0] = (uint32_t)gi.ts_close; h_pos[p0 + 1] = (uint32_t)(gi.ts_close + gi.pause); }
+                }
             } else if (ld.is_last_rank) {
-                if (p0 < cap_pos) pos[p0] = gi.ts_close;
+                if (p0 < cap_pos) { pos[p0] = gi.ts_close; if (h_pos) h_pos[p0] = (uint32_t)gi.ts_close; }
             }
         }
     }
@@ -1238,6 +1242,7 @@ struct ExpandTileArgs {
     int parity;
     int64_t n_tiles;
     int64_t t_base;          // first tile of this launch (0; a segment of a streamed pass: its first chunk)
+    uint32_t *h_pos;         // see GroupStore::h_pos (nullptr: positions are not shipped by this kernel)
 };
 constexpr unsigned kHugeBlocksX = 16, kHugeBlocksY = 16;
 
@@ -1297,7 +1302,10 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
                 const int sh = (bps == 1) ? 0 : bps - 1 - (int)(k % bps);
                 const uint8_t b = (ty < 0) ? 0 : (uint8_t)((ty >> sh) & 1);
                 if (ob + k < a.cap_bits) a.bits[ob + k] = b;
-                if (a.bp.write_pos && op + k < a.cap_pos) a.pos[op + k] = ts + k * a.bp.samples_per_bit;
+                if (a.bp.write_pos && op + k < a.cap_pos) {
+                    a.pos[op + k] = ts + k * a.bp.samples_per_bit;
+                    if (a.h_pos) a.h_pos[op + k] = (uint32_t)(ts + k * a.bp.samples_per_bit);
+                }
             }
         }
         return;
@@ -1381,13 +1389,14 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
                 const int np = !a.bp.write_pos ? 0 : ((op + kb <= a.cap_pos) ? (int)kb : (int)((a.cap_pos > op) ? a.cap_pos - op : 0));
                 uint8_t *bp8 = a.bits + ob;
                 int64_t *pp = a.pos + op;
+                uint32_t *hp = a.h_pos ? a.h_pos + op : nullptr;
                 int64_t tsk = ts;
                 int sh = bps - 1;
                 for (int k = 0; k < (int)kb; ++k) {
                     const uint8_t b = (type < 0) ? 0 : (uint8_t)((type >> sh) & 1);
                     sh = (sh == 0) ? bps - 1 : sh - 1;
                     if (k < nb) bp8[k] = b;
-                    if (k < np) pp[k] = tsk;
+                    if (k < np) { pp[k] = tsk; if (hp) hp[k] = (uint32_t)tsk; }
                     tsk += a.bp.samples_per_bit;
                 }
             }
@@ -1400,7 +1409,10 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
                 for (int64_t k = lane; k < kb_s; k += 64) {
                     const uint8_t b = symbol_bit(ty_s, k, bps);
                     if (ob_s + k < a.cap_bits) a.bits[ob_s + k] = b;
-                    if (a.bp.write_pos && op_s + k < a.cap_pos) a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
+                    if (a.bp.write_pos && op_s + k < a.cap_pos) {
+                        a.pos[op_s + k] = ts_s + k * a.bp.samples_per_bit;
+                        if (a.h_pos) a.h_pos[op_s + k] = (uint32_t)(ts_s + k * a.bp.samples_per_bit);
+                    }
                 }
             }
             run.v[0] += lane_bcast(in_bits, 63); run.v[1] += lane_bcast(in_l, 63); run.v[2] += lane_bcast(in_ts, 63);     // wave-uniform: scalar registers
@@ -1679,7 +1691,7 @@ int launch_tile_bits_finish(const TileTailMem &m, const int64_t *rows, const int
     hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
                        b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, b.d_n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
-                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt, 0};
+                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt, 0, nullptr};
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(nt);
     hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     return URHGPU_OK;
@@ -1804,6 +1816,7 @@ struct SegPack {
     const int64_t *d_n_rows;
     int parity, final;
     uint32_t *progress;      // the last segment zeroes the pass's counters for the next pass on this arena
+    int pos_shipped;         // the positions have been stored into the host blob by the kernels that wrote them (GroupStore::h_pos)
 };
 __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
     URH_TAIL_PRIO();
@@ -1824,7 +1837,7 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
             out[j] = (uint8_t)(((w & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
         }
     }
-    if (a.has_pos) {
+    if (a.has_pos && !a.pos_shipped) {
         uint32_t *p32 = (uint32_t *)(a.host + a.L.off_pos32);
         for (int64_t i = p0 + gtid; i < p1; i += stride) p32[i] = (uint32_t)a.pos[i];
     }
@@ -1901,23 +1914,29 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
     // groups [the one that was open before this segment, the one that is open now]
     ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(scan_blocks(cap_desc) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
     GroupLoad gl{b.groups, &st->n_groups, nullptr, sg.final ? 1 : 0, bp.write_pos, sg.final ? 0 : 1};
-    GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
+    // A pass of ONE segment (direct passes) that ships positions: the kernels that write them -- group scan (the sentinels behind a
+    // message's bits) and expansion -- also store them as uint32 into the pinned host blob's pos32 section, spread over their run time like
+    // the rows; the pack kernel then has no positions to move.  (With several segments an open group is expanded tentatively and may be
+    // shipped again: those passes' positions go through the pack kernel.)
+    const int has_pos = (bp.write_pos && o.pos) ? 1 : 0;
+    const int64_t caps[5] = {cap_rows, o.cap_msg, o.cap_bits, o.cap_pos, cap_rows};
+    const BlobLayout L = blob_layout(caps, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos);
+    const bool pos_direct = dst && dst->host && has_pos && sg.final && sg.c0 == 0 && dst->pos_direct;
+    uint32_t *h_pos = pos_direct ? (uint32_t *)((char *)dst->host + L.off_pos32) : nullptr;
+    GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos, h_pos};
     SegGroupLoad sl{gl, st, parity};
     SegGroupStore sst{gs, st, parity};
     SegFinal fin{sl, st, d_n_rows, parity, sg.final ? 1 : 0, BitsCountsFinal{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, &st->rows_needed, o.h_counts}};
     hipLaunchKernelGGL((k_scan_lookback<3, SegGroupLoad, SegGroupStore, SegFinal, kGroupItems>), dim3((unsigned)std::min<int64_t>(scan_grid(b.nbg), 32)),
                        dim3(kScanBlock), 0, s, &st->n_groups_local, sl, desc3, b.nbg, sst, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, &st->n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
-                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, t1, sg.c0};
+                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, t1, sg.c0, h_pos};
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(t1 - sg.c0);
     hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     if (dst && dst->host) {
         if (((uintptr_t)o.bits & 7) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
-        const int has_pos = (bp.write_pos && o.pos) ? 1 : 0;
-        const int64_t caps[5] = {cap_rows, o.cap_msg, o.cap_bits, o.cap_pos, cap_rows};
         SegPack pk{o.bits, o.msg_off, o.pauses, o.pos_off, o.pos, o.counts, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos, (char *)dst->host,
-                   blob_layout(caps, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos), st, d_n_rows, parity, sg.final ? 1 : 0,
-                   sg.final ? dst->progress_reset : nullptr};
+                   L, st, d_n_rows, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr, pos_direct ? 1 : 0};
         if (dst->cap_host < pk.L.total) return URHGPU_ERR_CAPACITY;
         hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 32), dim3(256), 0, s, pk);
     }
