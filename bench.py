@@ -1165,6 +1165,7 @@ def main():
                                         "region ends when every rank holds its last blob (SURVEY 8(d) window per rank)") if sharded_host else
                                        "K device-resident steps (outputs left in HBM)",
                        "samples_per_gpu": n, "samples_per_symbol": sps, "tolerance": tol, "noise_sigma": 0.05,
+                       "host_libm": __import__("urh_amd._lib", fromlist=["_lib"]).host_libm_verdict(warn=False),
                        "outputs": (("qad (HBM) + " if want_qad else "") + "pulse table + bits + pauses + message offsets on the host; bit_sample_pos NOT shipped in the "
                                    "headline steps (derived on the host from the shipped pulse table when asked for: HostBits.bit_sample_pos, compared with the "
                                    "reference's in `parity`); shipped as uint32 in ms_per_step_with_device_positions") if (use_stream or sharded_host) else

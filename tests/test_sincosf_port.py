@@ -61,3 +61,24 @@ def test_port_equals_libm():
         subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fopenmp"] + (["-mfma"] if fma else []) + [c, "-o", exe, "-lm"])
         out = subprocess.check_output([exe, "64000000"]).decode().strip()
     assert out.split() == ["0", "0"], f"{out}: mismatches against libm / of the branch-free pair against the branchy functions"
+
+
+def test_host_libm_guard_reports_this_host():
+    """urhgpu_host_libm_check (host arithmetic, no GPU): the device code restates glibc's FMA build of sinf / cosf and fdlibm's atan2f; on a
+    host with FMA (every x86-64 box this runs on) the reference calls exactly those -- zero mismatches over the probes, which include the
+    arguments on which glibc's two builds differ; a host without FMA is the case the guard exists for and must report mismatches."""
+    from urh_amd import _lib
+    v = _lib.host_libm_check()
+    assert v["sincosf_compared"] >= 8000 and v["atan2f_compared"] >= 4000, v
+    has_fma = False
+    try:
+        with open("/proc/cpuinfo") as fh:
+            has_fma = any(line.startswith("flags") and " fma " in line + " " for line in fh)
+    except OSError:
+        pass
+    assert v["atan2f_mismatches"] == 0, v
+    if has_fma:
+        assert v["sincosf_mismatches"] == 0, v
+    else:
+        assert v["sincosf_mismatches"] > 0, v
+    assert _lib.host_libm_verdict(warn=False) == v

@@ -212,6 +212,25 @@ def host_libm_check():
     return {"sincosf_compared": int(out[0]), "sincosf_mismatches": int(out[1]), "atan2f_compared": int(out[2]), "atan2f_mismatches": int(out[3])}
 
 
+_libm_verdict = None
+
+
+def host_libm_verdict(warn: bool = True):
+    """host_libm_check(), once per process: a host whose libm is not the one the device code restates (a CPU without FMA: glibc then
+    picks the other build of sinf / cosf) is told so -- the GPU results are then not bit-identical with what the reference computes ON
+    THIS HOST for the Costas loop (about one sample in 10^9), though they still equal the reference run on an FMA host."""
+    global _libm_verdict
+    if _libm_verdict is None:
+        _libm_verdict = host_libm_check()
+        if warn and (_libm_verdict["sincosf_mismatches"] or _libm_verdict["atan2f_mismatches"]):
+            import warnings
+            warnings.warn("liburhgpu: this host's libm differs from the one the device code restates "
+                          f"(sinf/cosf: {_libm_verdict['sincosf_mismatches']} of {_libm_verdict['sincosf_compared']}, atan2f: "
+                          f"{_libm_verdict['atan2f_mismatches']} of {_libm_verdict['atan2f_compared']} probes): PSK / FSK results may differ from the "
+                          "reference run on THIS host in isolated samples", RuntimeWarning, stacklevel=3)
+    return _libm_verdict
+
+
 def check(status: int):
     if status == OK:
         return

@@ -489,6 +489,7 @@ class DevicePipeline:
             raise _lib.UrhGpuError(_lib.ERR_NO_DEVICE, "no GPU visible to torch: the IQ->bits path has no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
         self.ctx = _lib.Context(self.device.index)
+        _lib.host_libm_verdict()                             # (once per process: a host libm the device code does not restate is reported)
         self._bufs = {}
         self._pinned = {}                                   # pinned host buffers of BitsResult.host()
         self.tail_stream = None
