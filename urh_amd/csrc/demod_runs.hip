@@ -58,6 +58,9 @@ enum { SRC_IQ = 0, SRC_QAD = 1 };
 #ifndef URH_ASK_WPB
 #define URH_ASK_WPB 8      // ... when it demodulates ASK (magnitudes: little per-wavefront start-up work, measured faster with 8)
 #endif
+#ifndef URH_QAD_THROUGH
+#define URH_QAD_THROUGH 0   // see the qad store of k_demod_runs_bp
+#endif
 #ifndef URH_NT
 #define URH_NT 1          // non-temporal IQ loads / qad stores (streamed once): +8 % on the copy ceiling, tools/kbench
 #endif
@@ -1081,7 +1084,12 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
                         w1 = (m1 <= p.dm_noise_sqrd) ? p.dm_noise_val : __builtin_sqrtf(m1) / p.dm_max_magnitude;
                         if (row0 && lane == 0) w0 = p.dm_noise_val;
                     }
-#if URH_NT
+#if URH_QAD_THROUGH
+                    // A/B (round 4): the demodulated signal written THROUGH to memory (agent-scope relaxed 64-bit store: sc1), so that no dirty
+                    // line of it waits in this XCD's L2 for the write-back at the kernel's end
+                    unsigned long long qq64 = (unsigned long long)__float_as_uint(w0) | ((unsigned long long)__float_as_uint(w1) << 32);
+                    __hip_atomic_store((unsigned long long *)(p.qad + a0 + off), qq64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#elif URH_NT
                     typedef float v2s __attribute__((ext_vector_type(2)));
                     const v2s qq = {w0, w1};
                     __builtin_nontemporal_store(qq, (v2s *)(p.qad + a0 + off));
