@@ -279,3 +279,34 @@ def test_direct_passes_equal_oracle(oracle, one_tile_chunks, policy, want_pos, p
         assert -stats["predicted_bytes"] >= sum(1 for n in sizes if n % 2048 == 0) - 1, stats      # the whole-tile captures took the kernel-written route
     for i, iq in enumerate(caps):
         _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i} ({sizes[i]} samples), policy {policy}")
+
+
+def test_upload_and_resident_pushes_interleave_order4_and_tiny(oracle, one_tile_chunks):
+    """uploads and resident pushes through ONE stream, back to back without a flush in between; 4-FSK (the order-4 bit planes); captures
+    of a few samples (shorter than a tile: one copy + the state-byte kernel) -- every result equals the oracle, every device buffer holds
+    its capture"""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    p = DemodParams("FSK", 2, 0.05, 0.0, 0.03, 5, 100, 0.1, 8, True)
+    pipe = DevicePipeline(0, pipelined=True)
+    st = pipe.stream(N, p, want_qad=False, want_pos=True)
+    sizes = [N, 5, N, N // 2, 2047, N, 3, N - 4096]
+    caps = [synth_fsk(N, sps=100, seed=140 + i, noise=0.03, pause_every=N // (3 + i % 3), pause_len=2500 + 311 * i)[:n].copy() for i, n in enumerate(sizes)]
+    host = [torch.from_numpy(c).pin_memory() for c in caps]
+    dev = [torch.zeros_like(h, device="cuda") for h in host]
+    got = {}
+    for i, (h, d) in enumerate(zip(host, dev)):
+        if i % 3 == 2:                                    # every third capture is resident already
+            d.copy_(h)
+            r = st.push(d)
+        else:
+            r = st.push_upload(h, d)
+        if r is not None:
+            got[r.seq] = _got(r)
+    for r in st.flush():
+        got[r.seq] = _got(r)
+    st.close()
+    torch.cuda.synchronize()
+    for i, iq in enumerate(caps):
+        assert np.array_equal(dev[i].cpu().numpy().view(np.uint32), iq.view(np.uint32)), i
+        _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i} ({sizes[i]} samples)")
