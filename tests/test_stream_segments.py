@@ -310,3 +310,41 @@ def test_upload_and_resident_pushes_interleave_order4_and_tiny(oracle, one_tile_
     for i, iq in enumerate(caps):
         assert np.array_equal(dev[i].cpu().numpy().view(np.uint32), iq.view(np.uint32)), i
         _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i} ({sizes[i]} samples)")
+
+
+@pytest.mark.parametrize("policy", [5, 1])
+def test_stream_randomised_vs_oracle(oracle, one_tile_chunks, policy):
+    """differential fuzz of the stream routes: random parameter sets (tolerance, samples per symbol, noise gate, center, pause threshold,
+    orders 2 and 4, float32 / int16 / int8 captures), a stream each, captures of random length pushed back to back -- whole tiles (direct
+    passes / segments where the capture is long enough), partial tiles and captures shorter than a tile (pack + copy)"""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    rng = np.random.default_rng(4242 + policy)
+    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_policy": policy, "stream_segments": 4})
+    n_max = 1 << 21
+    for s_i in range(10):
+        dtype = [np.float32, np.int16, np.float32, np.int8][s_i % 4]
+        sps = int(rng.choice([5, 17, 100, 333]))
+        tol = int(rng.choice([0, 1, 5, 9, 40]))
+        bps, spacing = ((2, float(rng.choice([0.05, 0.3]))) if s_i % 3 == 2 else (1, 1.0))
+        want_pos = bool(s_i % 2)
+        scale = 1.0 if dtype == np.float32 else float(np.iinfo(dtype).max) * 0.7
+        p = DemodParams("FSK", bps, float(rng.choice([0.0, 0.2])) * scale, float(rng.choice([0.0, 0.1, -0.2])), spacing, tol, sps, 0.1,
+                        int(rng.choice([0, 1, 8])), want_pos)
+        st = pipe.stream(n_max, p, want_qad=False, want_pos=want_pos, dtype=dtype, cap_rows=n_max // (tol + 1) + 2)     # (worst case: noise only)
+        sizes = [int(x) for x in rng.choice([2048 * int(rng.integers(1, 1024)), 2048 * int(rng.integers(512, 1024)), int(rng.integers(3, 5000)),
+                                             int(rng.integers(5000, 900_000)), n_max], size=7)]
+        caps = [synth_fsk(n, sps=sps, seed=1000 * s_i + k, noise=float(rng.choice([0.0, 0.03, 0.3])), pause_every=int(rng.choice([0, max(n // 3, 1), 2500])),
+                          pause_len=int(rng.choice([7, 130, 2100])), dtype=dtype) for k, n in enumerate(sizes)]
+        dev = [torch.from_numpy(c).cuda() for c in caps]
+        got = {}
+        for d in dev:
+            r = st.push(d)
+            if r is not None:
+                got[r.seq] = _got(r) if want_pos else (r.check().ppseq(), r.bits(), r.msg_off.copy(), r.pauses.copy())
+        for r in st.flush():
+            got[r.seq] = _got(r) if want_pos else (r.check().ppseq(), r.bits(), r.msg_off.copy(), r.pauses.copy())
+        st.close()
+        for k, iq in enumerate(caps):
+            ref = _oracle_flat(oracle, iq, p)
+            _assert_equal(got[k], ref[:len(got[k])], f"stream {s_i} ({np.dtype(dtype).name}, sps {sps}, tol {tol}, order {2 ** bps}) capture {k} ({sizes[k]} samples)")
