@@ -541,6 +541,9 @@ constexpr int kMeHistGroup = 8;              // consecutive tiles per workgroup:
 // has a few dozen) out of 4 KiB of LDS -- eight workgroups per CU instead of four: the pass is bound by instruction issue and by the
 // latency of each tile's loads, and twice the wavefronts hide twice as much of it -- BINS = kMeHistLds serves the others; a workgroup
 // skips the messages of the other class.
+#ifndef URH_HIST_ROUNDS
+#define URH_HIST_ROUNDS 2      // ballot rounds per row of k_me_hist before what is left goes through LDS atomics (A/B: 0, 1)
+#endif
 constexpr int kMeHistSmall = kMeHistSmallBins;
 template <int BINS>
 __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int64_t n_tiles,
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
 #pragma unroll
     for (int j = 0; j < kMePer; ++j) {
         unsigned long long todo = __ballot(bin[j] >= 0);
-        for (int round = 0; todo && round < 2; ++round) {
+        for (int round = 0; todo && round < URH_HIST_ROUNDS; ++round) {
             const int leader = __ffsll((long long)todo) - 1;
             const int kl = __shfl(bin[j], leader);
             unsigned int cnt = 0;
