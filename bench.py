@@ -910,12 +910,14 @@ def main():
                 if r is not None:
                     out.append(r)
             return out + st.flush()
-        one = []
-        for _ in range(5):                                   # ONE capture start to finish: pass + its copy, nothing to overlap with
-            torch.cuda.synchronize()
-            t_l = time.perf_counter()
-            stream_steps(1)
-            one.append(time.perf_counter() - t_l)
+        one, one_tp = [], []
+        for mode, acc in ((1, one), (0, one_tp)):            # ONE capture start to finish, nothing to overlap with: the stream in its latency setting
+            pipe.ctx.set_tuning("stream_latency", mode)      # (an idle pipeline: the tail in segments beside the hot kernel) and in the
+            for _ in range(6):                               # throughput setting the K-step loop below runs in (direct passes)
+                torch.cuda.synchronize()
+                t_l = time.perf_counter()
+                stream_steps(1)
+                acc.append(time.perf_counter() - t_l)
         ramp_passes = ramp(lambda: stream_steps(10))
         torch.cuda.synchronize()
         # (no timing events in this loop: the dispatch-attached pair costs 5-7 us per pass while a profile record is open; the hot kernel's
@@ -944,7 +946,11 @@ def main():
         assert len(results) == args.steps and [r.seq for r in results[-3:]] == sorted(r.seq for r in results[-3:])
         last_host = results[-1].check()
         stream_stats = st.stats()
-        stream_rec = {"single_capture_incl_compact_d2h_ms": round(min(one) * 1e3, 4), "d2h_bytes_per_step": last_host.blob_bytes + 40,
+        stream_rec = {"single_capture_incl_compact_d2h_ms": round(min(one) * 1e3, 4),
+                      "single_capture_setting": "CaptureStream(latency=True) / tuning stream_latency=1: a pass that finds the pipeline idle runs its tail in 7 rows "
+                                                "segments + 1 bits segment beside the hot kernel; the K-step loop runs in the throughput setting (direct passes), in "
+                                                "which one capture alone takes single_capture_throughput_setting_ms",
+                      "single_capture_throughput_setting_ms": round(min(one_tp) * 1e3, 4), "d2h_bytes_per_step": last_host.blob_bytes + 40,
                       "host_loop": host_rec, "stream_stats": stream_stats,
                       "d2h_format": "compact blob: int32 length + int8 state per pulse-table row, packed bits, int64 pauses / message offsets "
                                     "(include/urhgpu.h); bit_sample_pos derived on the host from the shipped pulse table when asked for"}

@@ -102,8 +102,10 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
  * of an earlier pass is still running -- one capture, where the tail's latency counts --, else its blob is packed at the end and copied by the
  * copy engine; 1: every qualifying pass in segments; 2: never; 3: every qualifying pass DIRECT -- one segment, the ordinary tail
  * behind the hot kernel, whose kernels store rows and packed results into the pinned host blob themselves (no pack of the whole table,
- * no copy engine); 4: segments when idle, direct otherwise), "stream_segments" (rows segments, 1 .. 16, default 6),
- * "stream_bits_segments" (default 3), "stream_shape" (0: equal segments; 1: halving; 2: equal segments and a short last one of
+ * no copy engine); 4: segments when idle, direct otherwise), "stream_latency" (1: under the default policy a pass that finds the pipeline idle -- ONE capture -- runs its tail in segments
+ * beside the hot kernel, which gives the lowest latency, 0.39 against 0.41 ms per GiB; 0, default: direct passes throughout, which gives the
+ * highest throughput for back-to-back passes), "stream_segments" (rows segments, 1 .. 16, default 7),
+ * "stream_bits_segments" (default 1), "stream_shape" (0: equal segments; 1: halving; 2: equal segments and a short last one of
  * "stream_last_units" x 256 chunks), "stream_fuse_gate" / "stream_final_on_rows" (1, default: the last segment's gate inside its
  * one-workgroup resolve kernel; its bits kernels on the rows stream), "pack_blocks" (workgroups of a segment's pack kernel),
  * "upload_pieces" (2 .. 16, default 4: pieces of urhgpu_stream_push_upload, the last one short).  Unknown key: URHGPU_ERR_ARG. */

@@ -348,3 +348,28 @@ def test_stream_randomised_vs_oracle(oracle, one_tile_chunks, policy):
         for k, iq in enumerate(caps):
             ref = _oracle_flat(oracle, iq, p)
             _assert_equal(got[k], ref[:len(got[k])], f"stream {s_i} ({np.dtype(dtype).name}, sps {sps}, tol {tol}, order {2 ** bps}) capture {k} ({sizes[k]} samples)")
+
+
+def test_latency_setting_one_capture_at_a_time(oracle, one_tile_chunks):
+    """CaptureStream(latency=True): every capture pushed and flushed on its own finds the pipeline idle and runs its tail in the default
+    segmentation (7 rows segments, 1 bits segment); two pushed back to back: the second one direct.  All equal to the oracle."""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    pipe = DevicePipeline(0, pipelined=True)
+    st = pipe.stream(N, p, want_qad=False, want_pos=True, latency=True)
+    caps = [_events_capture(N, 160 + i) for i in range(4)]
+    dev = [torch.from_numpy(c).cuda() for c in caps]
+    got = {}
+    for d in dev[:2]:
+        assert st.push(d) is None
+        (r,) = st.flush()
+        got[r.seq] = _got(r)
+    for d in dev[2:]:
+        st.push(d)
+    for r in st.flush():
+        got[r.seq] = _got(r)
+    st.close()
+    pipe.ctx.set_tuning("stream_latency", 0)
+    for i, iq in enumerate(caps):
+        _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i}")

@@ -468,7 +468,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     // pipelined step against 0.306 through pack + copy engine, one capture alone the same as with segments), policy 0 when it does --
     // 5.4 MB of uint32 positions stored over PCIe by a pack kernel take longer than the copy engine needs for the whole blob (0.41 ms).
     int policy = ctx->tune_stream_policy;
-    if (policy == 5) policy = (p->write_bit_sample_pos && out->pos && !ctx->tune_stream_pos_direct) ? 0 : 3;
+    if (policy == 5) policy = (p->write_bit_sample_pos && out->pos && !ctx->tune_stream_pos_direct) ? 0 : (ctx->tune_stream_latency ? 4 : 3);
     bool direct = false;
     if (!h_iq && runs_streamable(a) && host_blob && policy == 3) direct = true;
     if (S < 2 && !direct) return URHGPU_OK;                    // too short to cut, or not the bit-plane kernel's work: the ordinary path
@@ -635,7 +635,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     }
     SegPackDst dst{host_blob, cap_host, progress, ctx->tune_pack_blocks, (direct && ctx->tune_stream_pos_direct) ? 1 : 0};
     // bits segments: the last one is the last rows segment alone (what is exposed behind the hot kernel), the others share the rest
-    int Sb = ctx->tune_stream_bits_segments;
+    int Sb = h_iq ? S : ctx->tune_stream_bits_segments;       // (an upload: every piece's bits behind its rows -- the pieces are milliseconds apart)
     if (Sb > S) Sb = S;
     if (Sb < 1) Sb = 1;
     int bits_end_at[kMaxSegments];                             // bits segment j ends with rows segment bits_end_at[j]
@@ -892,6 +892,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "stream_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_segments = value; }
     else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 5) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
     else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
+    else if (!strcmp(key, "stream_latency")) { ctx->tune_stream_latency = value != 0; }
     else if (!strcmp(key, "stream_pos_direct")) { ctx->tune_stream_pos_direct = value != 0; }
     else if (!strcmp(key, "hot_any_order")) { ctx->tune_hot_any_order = value != 0; }
     else if (!strcmp(key, "stream_spin")) { if (value < 0) return URHGPU_ERR_ARG; ctx->tune_stream_spin = value; }

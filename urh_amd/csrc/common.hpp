@@ -111,7 +111,7 @@ struct urhgpu_ctx {
     // streamed passes (urhgpu_stream_*; capi.hip: iq_to_bits_streamed): per scratch arena 16 progress counters + one SegState
     void *d_seg = nullptr;         // 3 x kSegBlockBytes, zero between passes
     bool seg_dirty[3] = {false, false, false};   // a pass failed between its hot launch and its last segment: counters not trusted
-    int tune_stream_segments = 6;  // rows segments of a streamed pass's tail (1: no streaming), urhgpu_ctx_set_tuning("stream_segments")
+    int tune_stream_segments = 7;  // rows segments of a streamed pass's tail (1: no streaming), urhgpu_ctx_set_tuning("stream_segments")
     int tune_stream_policy = 5;    // 5 (default): 3 for passes that ship no positions, 0 for those that do; 3: every pass DIRECT (one segment behind the hot
                                    // kernel, rows and packed results stored into the pinned host blob by the tail's kernels); 4: segments when idle, direct
                                    // otherwise; 0: stream a pass only when the pipeline is idle (nothing of an earlier pass still running: a single
@@ -122,6 +122,7 @@ struct urhgpu_ctx {
     int tune_stream_shape = 0;     // 0: equal segments; 1: halving (1/2, 1/4, ... of the capture, the last two equal); 2: equal segments and
                                    // a short last one (tune_stream_last_units alignment units of 256 chunks)
     int tune_stream_last_units = 1;
+    bool tune_stream_latency = false;      // policy 5: a pass that finds the pipeline idle runs its tail in segments (lowest latency for ONE capture)
     bool tune_stream_pos_direct = true;    // direct passes ship positions themselves (group scan + expansion store uint32 into the host blob)
     int tune_stream_spin = 0;               // hipEventQuery polls before the host parks in hipEventSynchronize (urhgpu_stream_* results)
     int tune_upload_pieces = 4;             // pieces of urhgpu_stream_push_upload: pieces - 1 equal ones and a short last one (shape 2)
@@ -131,7 +132,8 @@ struct urhgpu_ctx {
     hipEvent_t ev_up[16] = {};              // piece k has landed (tune_upload_own_stream)
     bool tune_upload_own_stream = false;
     hipEvent_t ev_piece[16] = {};           // the hot kernel of piece k has finished (the rows segment k waits for it: no polling gate in upload mode)
-    int tune_stream_bits_segments = 3;   // bits segments (tile scan, group scan, expansion, pack) of a streamed pass, on their own stream
+    int tune_stream_bits_segments = 1;   // (one: measured best for ONE capture with 7 rows segments, profiles/r04e_single_capture_segments.txt)
+                                         // bits segments (tile scan, group scan, expansion, pack) of a streamed pass, on their own stream
     int tune_pack_blocks = 0;      // workgroups of a segment's pack kernel (0: default)
     hipEvent_t ev_hot_done[3] = {nullptr, nullptr, nullptr};   // behind the hot kernel of the pass in arena slot k (streamed passes)
     hipStream_t bits_stream = nullptr;   // second tail stream of streamed passes: the bits segments, behind the rows they expand

@@ -412,7 +412,12 @@ class CaptureStream:
     of the pass pushed three calls earlier (or None); flush() waits for the rest.  The hot kernel of pass i, the tail of pass i - 1
     and the D2H copy of pass i - 2's compact blob overlap."""
 
-    def __init__(self, pipe: "DevicePipeline", n_max: int, p: DemodParams, want_qad=True, want_pos=True, dtype=np.float32, cap_rows=0):
+    def __init__(self, pipe: "DevicePipeline", n_max: int, p: DemodParams, want_qad=True, want_pos=True, dtype=np.float32, cap_rows=0, latency=None):
+        """latency: True -- ONE capture at a time, its results as early as possible (a pass that finds the pipeline idle runs its tail in
+        segments beside the hot kernel); False -- capture after capture, highest throughput (direct passes); None: leave the context's
+        setting (urhgpu_ctx_set_tuning "stream_latency") as it is"""
+        if latency is not None:
+            pipe.ctx.set_tuning("stream_latency", 1 if latency else 0)
         self.pipe, self.params = pipe, p
         self._cp = p.to_c(dtype)
         h = C.c_void_p()
@@ -535,9 +540,9 @@ class DevicePipeline:
     def reserve(self, n: int, p: DemodParams):
         self.ctx.reserve(n, p.tolerance)
 
-    def stream(self, n_max: int, p: DemodParams, want_qad=True, want_pos=True, dtype=np.float32, cap_rows=0) -> CaptureStream:
+    def stream(self, n_max: int, p: DemodParams, want_qad=True, want_pos=True, dtype=np.float32, cap_rows=0, latency=None) -> CaptureStream:
         """a CaptureStream on this pipeline's context (which it switches to pipelined passes)"""
-        return CaptureStream(self, n_max, p, want_qad, want_pos, dtype, cap_rows)
+        return CaptureStream(self, n_max, p, want_qad, want_pos, dtype, cap_rows, latency)
 
     def iq_to_bits(self, iq, p: DemodParams, want_qad=True, cap_rows=None, slot=0) -> BitsResult:
         """iq: torch tensor on this device, shape (N, 2) of int8/uint8/int16/uint16/float32, or complex64 (N,).

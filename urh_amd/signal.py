@@ -114,7 +114,7 @@ class Signal:
         host = host.view(n, 2)
         dev = torch.empty((n, 2), dtype=tdt, device=s.pipe.device)
         p = s.params()
-        st = s.pipe.stream(n, p, want_qad=True, want_pos=True, dtype=dt)
+        st = s.pipe.stream(n, p, want_qad=True, want_pos=True, dtype=dt)          # (an upload: its own piece-wise route whatever the latency setting)
         try:
             st.push_upload(host, dev)
             (h,) = st.flush()
