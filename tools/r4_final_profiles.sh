@@ -19,7 +19,7 @@ bash tools/prof_pmc.sh $TAG --no-upload --no-pmc > $G/pmc_files.txt 2>&1
 python tools/prof_collect.py gpurun_out/prof_$TAG $G/fsk_1gib > $G/pmc_summary.txt 2>&1
 find gpurun_out/prof_$TAG -name "*.csv" -size +2M -delete
 # one streamed capture on an idle GPU, one uploaded capture: kernel (+ copy) timelines
-SB=3 bash tools/r4_seg_prof.sh "6 0" > /dev/null 2>&1; cp gpurun_out/r4seg_6_0.txt $G/single_capture_timeline.txt
+POLICY=1 SB=1 bash tools/r4_seg_prof.sh "7 0" > /dev/null 2>&1; cp gpurun_out/r4seg_7_0.txt $G/single_capture_timeline.txt
 OUT=$R/$G/up; mkdir -p $OUT
 (cd /tmp && TMPDIR=/tmp timeout 200 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -o b -- python $R/tools/r4_upload_probe.py 4 > $OUT/log.txt 2>&1)
 grep "upload in\|bare pinned" $OUT/log.txt > $G/upload_timeline.txt
