@@ -155,6 +155,10 @@ def tuning_from_env():
         t["profile_bracket"] = 1
     if "URH_TAIL_MASKED" in e:
         t["tail_masked"] = int(e["URH_TAIL_MASKED"])
+    if "URH_HOT_OVERLAP" in e:
+        t["hot_overlap"] = int(e["URH_HOT_OVERLAP"])
+    if "URH_HOT_OVERLAP_PCT" in e:
+        t["hot_overlap_pct"] = int(e["URH_HOT_OVERLAP_PCT"])
     if "URH_HOT_ANY_ORDER" in e:
         t["hot_any_order"] = int(e["URH_HOT_ANY_ORDER"])
     if "URH_HOT_CUS_REMOVED" in e:

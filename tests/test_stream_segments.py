@@ -254,14 +254,17 @@ def test_upload_back_to_back(oracle, one_tile_chunks):
         _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i}")
 
 
-@pytest.mark.parametrize("policy,want_pos,pos_direct", [(3, True, 1), (3, False, 1), (4, True, 1), (3, True, 0), (5, True, 1), (5, True, 0)])
-def test_direct_passes_equal_oracle(oracle, one_tile_chunks, policy, want_pos, pos_direct):
+@pytest.mark.parametrize("policy,want_pos,pos_direct,overlap", [(3, True, 1, 0), (3, False, 1, 0), (4, True, 1, 0), (3, True, 0, 0), (5, True, 1, 0), (5, True, 0, 0),
+                                                                (3, True, 1, 1), (5, False, 1, 1)])
+def test_direct_passes_equal_oracle(oracle, one_tile_chunks, policy, want_pos, pos_direct, overlap):
     """stream_policy 3 / 4: passes whose tail is ONE segment behind the hot kernel (an event, no gate) and stores rows and packed
-    results into the pinned host blob itself -- back to back, whole-tile and partial-tile captures mixed (the latter: pack + copy)"""
+    results into the pinned host blob itself -- back to back, whole-tile and partial-tile captures mixed (the latter: pack + copy);
+    overlap: consecutive hot kernels on two alternating masked streams, the next one let go by a gate when the previous one is nearly
+    through (tuning hot_overlap)"""
     import torch
     from urh_amd.pipeline import DemodParams, DevicePipeline
     p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, want_pos)
-    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_policy": policy, "stream_pos_direct": pos_direct})
+    pipe = DevicePipeline(0, pipelined=True, tuning={"stream_policy": policy, "stream_pos_direct": pos_direct, "hot_overlap": overlap})
     st = pipe.stream(N, p, want_qad=True, want_pos=want_pos)
     sizes = [N, N, N - 2048, N, N - 777, N, N // 2, N]
     caps = [_events_capture(N, 120 + i)[:n].copy() for i, n in enumerate(sizes)]

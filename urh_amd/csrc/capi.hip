@@ -168,19 +168,37 @@ int prof_end_record(urhgpu_ctx *ctx, hipStream_t s) {
 
 // pipelined passes: the stream the hot kernel is launched on -- the CU-masked private one (see urhgpu_ctx_set_pipelined), ordered
 // behind what the caller has queued on the context's stream so far
-int hot_stream_begin(urhgpu_ctx *ctx, hipStream_t *out) {
+int hot_stream_begin(urhgpu_ctx *ctx, hipStream_t *out, bool overlap_ok = false) {
     *out = ctx->stream;
     if (!ctx->pipelined || !ctx->hot_masked) return URHGPU_OK;
+    hipStream_t hot = ctx->hot_masked;
+    if (overlap_ok && ctx->tune_hot_overlap && ctx->hot_masked2 && ctx->d_hot_ctr) {
+        hot = (ctx->hot_turn ^= 1) ? ctx->hot_masked2 : ctx->hot_masked;      // (the caller puts the gate in front of its kernel: hot_overlap_gate)
+    } else if (ctx->last_hot_stream && ctx->last_hot_stream != hot && ctx->last_hot_event) {
+        // the hot kernel before this one ran on the other masked stream (an overlapped pass): in order behind it
+        URH_HIP(hipStreamWaitEvent(hot, ctx->last_hot_event, 0));
+    }
     // The masked stream has default flags: what the caller has queued on the NULL stream is ordered before its work by the runtime
     // itself (and costs nothing when the NULL stream is idle).  An explicit event on the NULL stream would make THAT stream wait for the
     // previous hot kernel first and hand over afterwards: two cross-queue hand-overs between consecutive hot kernels (measured: a
     // 50 us gap instead of 5).  Any other stream of the caller's hands over through an event.
     if (ctx->stream != nullptr) {
         URH_HIP(hipEventRecord(ctx->ev_in, ctx->stream));
-        URH_HIP(hipStreamWaitEvent(ctx->hot_masked, ctx->ev_in, 0));
+        URH_HIP(hipStreamWaitEvent(hot, ctx->ev_in, 0));
     }
-    *out = ctx->hot_masked;
+    *out = hot;
     return URHGPU_OK;
+}
+// after a hot launch on `s`: what the next launch orders itself behind / gates on
+void hot_launched(urhgpu_ctx *ctx, hipStream_t s, hipEvent_t done) {
+    ctx->last_hot_stream = s; ctx->last_hot_event = done;
+    if (g_hot_counted > 0) {
+        ctx->hot_gate_target = ctx->hot_total + (unsigned long long)((g_hot_counted * (long long)ctx->tune_hot_overlap_pct) / 100);
+        ctx->hot_total += (unsigned long long)g_hot_counted;
+    } else {
+        ctx->hot_gate_target = ctx->hot_total;             // (nothing of this launch counts: the next gate does not wait)
+    }
+    g_hot_counted = 0;
 }
 
 // scratch (from the arena) and persistent descriptors of the tile tail over a table of n_entries chunks
@@ -262,6 +280,7 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     else g_hot_events = HotEvents();
     if (s_tail) {                                   // pipelined: everything after the hot kernel goes to the tail stream
         if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot, s)); hot_done = ctx->ev_hot; }
+        hot_launched(ctx, s, hot_done);
         URH_HIP(hipStreamWaitEvent(s_tail, hot_done, 0));
         // the hot kernel ran on the private masked stream: what the caller queues on ITS stream afterwards (overwriting the capture, the
         // allocator handing its memory out again) must come behind it.  (The NULL stream synchronises with the masked stream by itself.)
@@ -511,7 +530,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     ctx->arena.reset();
     ctx->seg_dirty[slot] = true;                               // until the last segment has been queued
     hipStream_t s = ctx->stream;
-    if (p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s));
+    if (p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s, direct));
     ChunkInfo *chunks = (ChunkInfo *)ctx->arena.take((size_t)pl.n_chunks * sizeof(ChunkInfo));
     uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
     void *rs_mem = ctx->arena.take(resolve_scratch_bytes(pl.n_chunks));
@@ -589,8 +608,15 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         a.launch_lo = 0; a.launch_hi = 0;
         URH_HIP(hipEventRecord(ctx->ev_hot_done[slot], s));
         hot_done = ctx->ev_hot_done[slot];
+        hot_launched(ctx, s, hot_done);
     } else {
     if (direct) { a.progress = nullptr; a.n_seg = 0; }         // (plain stores in the hot kernel, no counters: the tail starts behind its end)
+    if (direct && ctx->tune_hot_overlap && ctx->d_hot_ctr && ctx->hot_masked2 && (s == ctx->hot_masked || s == ctx->hot_masked2)) {
+        // overlapped hot kernels (common.hpp): behind a gate that opens when the previous hot kernel -- on the other masked stream -- is
+        // nearly through; this kernel counts its workgroups for the next one's gate
+        if (ctx->last_hot_stream && ctx->last_hot_stream != s) launch_hot_gate(ctx->d_hot_ctr, ctx->hot_gate_target, s);
+        a.done_ctr = ctx->d_hot_ctr;
+    }
     const bool prof = prof_begin_record(ctx, s);
     // the hot kernel's completion: the dispatch's own completion signal where the launcher takes events (an event recorded behind the
     // kernel is one more barrier packet between two hot kernels); nobody waits for it before the last segment has been queued
@@ -606,6 +632,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     if (prof) URH_TRY(prof_end_record(ctx, s));
     else g_hot_events = HotEvents();
     if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot_done[slot], s)); hot_done = ctx->ev_hot_done[slot]; }
+    hot_launched(ctx, s, hot_done);
     }
     // ---- the tail in segments: rows segments on the tail stream, bits segments on the bits stream behind the rows they expand; neither
     // ever waits for the hot kernel as a whole ----
@@ -754,6 +781,8 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     ctx->arena_alt.release();
     ctx->arena_alt2.release();
     if (ctx->hot_masked) { (void)hipStreamSynchronize(ctx->hot_masked); (void)hipStreamDestroy(ctx->hot_masked); }
+    if (ctx->hot_masked2) { (void)hipStreamSynchronize(ctx->hot_masked2); (void)hipStreamDestroy(ctx->hot_masked2); }
+    if (ctx->d_hot_ctr) (void)hipFree(ctx->d_hot_ctr);
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
@@ -798,6 +827,7 @@ int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx) {
 int urhgpu_ctx_sync(urhgpu_ctx *ctx) {
     if (!ctx) return URHGPU_ERR_ARG;
     if (ctx->hot_masked) URH_HIP(hipStreamSynchronize(ctx->hot_masked));
+    if (ctx->hot_masked2) URH_HIP(hipStreamSynchronize(ctx->hot_masked2));
     if (ctx->bits_stream) URH_HIP(hipStreamSynchronize(ctx->bits_stream));
     if (ctx->tail_stream) URH_HIP(hipStreamSynchronize(ctx->tail_stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
@@ -812,6 +842,8 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
     if (ctx->own_tail_stream && ctx->tail_stream) { (void)hipStreamDestroy(ctx->tail_stream); }
     ctx->tail_stream = nullptr; ctx->own_tail_stream = false; ctx->pipelined = false;
     if (ctx->hot_masked) { (void)hipStreamSynchronize(ctx->hot_masked); (void)hipStreamDestroy(ctx->hot_masked); ctx->hot_masked = nullptr; }
+    if (ctx->hot_masked2) { (void)hipStreamSynchronize(ctx->hot_masked2); (void)hipStreamDestroy(ctx->hot_masked2); ctx->hot_masked2 = nullptr; }
+    ctx->last_hot_stream = nullptr; ctx->last_hot_event = nullptr; ctx->hot_turn = 0;
     if (!enable) return URHGPU_OK;
     if (tail_stream) ctx->tail_stream = (hipStream_t)tail_stream;
     else {
@@ -846,6 +878,16 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
         }
         // (a runtime that cannot make the masked stream is no reason to fail: the hot kernel then runs on the caller's stream as before)
         if (hipExtStreamCreateWithCUMask(&ctx->hot_masked, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ctx->hot_masked = nullptr; }
+        if (ctx->hot_masked && !ctx->hot_masked2) {
+            if (hipExtStreamCreateWithCUMask(&ctx->hot_masked2, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ctx->hot_masked2 = nullptr; }
+            if (ctx->hot_masked2 && !ctx->d_hot_ctr) {
+                if (hipMalloc((void **)&ctx->d_hot_ctr, 256) != hipSuccess || hipMemset(ctx->d_hot_ctr, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+                    (void)hipGetLastError();
+                    ctx->d_hot_ctr = nullptr;
+                }
+                ctx->hot_total = 0; ctx->hot_gate_target = 0;
+            }
+        }
         if (ctx->hot_masked && !ctx->ev_in && hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipStreamDestroy(ctx->hot_masked);
@@ -894,6 +936,8 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
     else if (!strcmp(key, "stream_latency")) { ctx->tune_stream_latency = value != 0; }
     else if (!strcmp(key, "stream_pos_direct")) { ctx->tune_stream_pos_direct = value != 0; }
+    else if (!strcmp(key, "hot_overlap")) { ctx->tune_hot_overlap = value != 0; }
+    else if (!strcmp(key, "hot_overlap_pct")) { if (value < 50 || value > 100) return URHGPU_ERR_ARG; ctx->tune_hot_overlap_pct = value; }
     else if (!strcmp(key, "hot_any_order")) { ctx->tune_hot_any_order = value != 0; }
     else if (!strcmp(key, "stream_spin")) { if (value < 0) return URHGPU_ERR_ARG; ctx->tune_stream_spin = value; }
     else if (!strcmp(key, "upload_own_stream")) { ctx->tune_upload_own_stream = value != 0; }
@@ -995,6 +1039,7 @@ int urhgpu_ctx_profile_end(urhgpu_ctx *ctx, float *ms_out, int cap, int *n_recor
     if (!ctx || !n_records) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
     if (ctx->hot_masked) URH_HIP(hipStreamSynchronize(ctx->hot_masked));
+    if (ctx->hot_masked2) URH_HIP(hipStreamSynchronize(ctx->hot_masked2));
     URH_HIP(hipStreamSynchronize(ctx->stream));
     ctx->prof_on = false;
     const int n = ctx->prof_used;

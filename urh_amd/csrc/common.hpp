@@ -94,6 +94,20 @@ struct urhgpu_ctx {
     bool tune_tail_masked = false;         // the tail stream is a private one masked to the CUs the hot mask leaves out (A/B knob)
     int tune_hot_cus_removed = 4;          // CUs per XCD the hot kernel of a pipelined pass leaves alone (0: no mask); see urhgpu_ctx_set_pipelined
     hipStream_t hot_masked = nullptr;      // private CU-masked stream of the hot kernel (pipelined mode)
+    // Overlapped hot kernels (tuning "hot_overlap", direct passes of urhgpu_stream_*): kernels of ONE stream never overlap on this
+    // runtime (tools/kbench/anyorder.hip), and 10 us lie between the end of one hot kernel and the start of the next.  Consecutive passes
+    // therefore alternate between two masked streams; the hot kernel counts its finished workgroups into d_hot_ctr (never reset: a running
+    // total), and a one-wavefront gate in front of the next hot kernel lets it go when the previous one has finished hot_overlap_pct % of
+    // its workgroups -- the next kernel's ramp then meets the previous one's last wavefronts instead of an empty machine.
+    hipStream_t hot_masked2 = nullptr;
+    unsigned long long *d_hot_ctr = nullptr;
+    unsigned long long hot_total = 0;      // workgroups of every counting hot launch so far
+    unsigned long long hot_gate_target = 0;   // the counter value at which the NEXT hot kernel may start
+    int hot_turn = 0;
+    hipStream_t last_hot_stream = nullptr; // where the most recent hot kernel was launched, and the event behind it (other launch paths order
+    hipEvent_t last_hot_event = nullptr;   // themselves behind it when they use the other stream)
+    bool tune_hot_overlap = false;
+    int tune_hot_overlap_pct = 97;
     hipEvent_t ev_in = nullptr;
     int hot_lds_pad = 0;           // pipelined mode: dynamic LDS bytes added to every hot-kernel workgroup (see RunArgs::lds_pad)
     bool hot_stop_event = true;

@@ -1135,6 +1135,9 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
     }
 
     if (!RUNS) return;
+    // hot_overlap: this workgroup's loads and qad stores are issued -- the next pass's hot kernel may take the slot over (a hint for the
+    // gate in front of it, not a data dependency: nobody reads this pass's results before its completion event)
+    if (p.done_ctr && w == 0 && lane == 0) atomicAdd(p.done_ctr, 1ull);
     // the chunk's planes come together in wavefront 0 (lane r <- row r)
     if (W > 1) {
         if (w != 0) {
@@ -1382,6 +1385,19 @@ __global__ void k_test_atan2f(const float *y, const float *x, int64_t n, float *
 // test hook (urhgpu_test_force_state_bytes): route order-2 work through the state-byte kernel as well
 bool g_force_state_bytes = false;
 thread_local HotEvents g_hot_events;
+thread_local long long g_hot_counted = 0;
+
+__global__ void k_hot_gate(const unsigned long long *ctr, unsigned long long target) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = (long long)wall_clock64();
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if ((long long)wall_clock64() - t0 > 100000000ll) break;          // (1 s: the kernel it waits for never came -- go ahead, it is only a hint)
+    }
+}
+void launch_hot_gate(const unsigned long long *ctr, unsigned long long target, hipStream_t s) {
+    hipLaunchKernelGGL(k_hot_gate, dim3(1), dim3(64), 0, s, ctr, target);
+}
 
 // `a` describes the whole capture (a.n samples, chunk table / slab for n_main + has_tail chunks):
 // one launch over the whole tiles, one one-workgroup launch for the partial tile at the end.
@@ -1395,10 +1411,12 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
     int64_t c_lo = (part == 1) ? 1 : 0, c_hi = (part == 2) ? std::min<int64_t>(n_main, 1) : n_main;
     const bool ranged = a.launch_hi > 0;                      // an explicit chunk range (streamed passes that upload piece by piece)
     if (ranged) { c_lo = std::min<int64_t>(a.launch_lo, n_main); c_hi = std::min<int64_t>(a.launch_hi, n_main); }
+    g_hot_counted = 0;
     if (c_hi > c_lo) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
         // orders 2 and 4: the bit-plane kernel; anything else: the state-byte kernel
         const bool planes_ok = URH_BITPLANE && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes;
+        if (planes_ok && (O2 || a.order == 4) && a.done_ctr) g_hot_counted = c_hi - c_lo;
         if (planes_ok && O2 && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
             hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
                                   (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, g_hot_events.flags, a);
