@@ -570,10 +570,9 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         a.progress = nullptr; a.n_seg = 0;
         const size_t bps = (size_t)dtype_bytes(p->dtype);
         int64_t piece_lo[kMaxSegments], piece_hi[kMaxSegments];
-        for (int k = 0, lo = 0; k < S; ++k) {
+        for (int k = 0; k < S; ++k) {
             piece_lo[k] = k == 0 ? 0 : piece_hi[k - 1];
             piece_hi[k] = (k < S - 1) ? std::min<int64_t>(bound[k + 1] + 1, pl.n_chunks) : pl.n_chunks;
-            (void)lo;
         }
         // A/B (tuning "upload_own_stream"): the copies on a stream of their own after all -- a CU-masked one (full mask), which owns its
         // hardware queue like the masked hot stream does, so that nothing else can end up sharing a queue with them
