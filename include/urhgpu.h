@@ -346,7 +346,8 @@ int urhgpu_stream_push(urhgpu_stream *st, const void *d_iq, int64_t n, urhgpu_ho
  * on the piece, the piece's share of the tail, its share of the compact blob stored into pinned host memory.  1 GiB takes some 20 ms
  * over PCIe and 0.3 ms to demodulate: "file in host memory -> bits on the host" costs the upload plus the last piece's kernels.
  * Captures the segmented path does not take (ASK, a partial tile at the end, too short) are uploaded in one copy in front of an
- * ordinary pass.  The copies are ordered behind what the caller has queued on the context's stream. */
+ * ordinary pass.  The copies are ordered behind what the caller has queued on the context's stream; h_iq must stay valid and unchanged, and d_iq
+ * untouched, until the pass's result has been handed out (a later push's `ready`, or urhgpu_stream_flush). */
 int urhgpu_stream_push_upload(urhgpu_stream *st, const void *h_iq, void *d_iq, int64_t n, urhgpu_host_result *ready);
 int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out);
 /* Diagnostics: out4 = {passes pushed, passes whose predicted copy size fell short (their rest was fetched when the result was handed
