@@ -5,9 +5,10 @@
 
 A "step" is one full pass of the hot path over one synthetic capture that is already resident in HBM:
 IQ (complex64) -> demodulated signal (Signal.qad, materialised, stays in HBM) -> pulse table -> bits / pauses /
-bit_sample_pos -> D2H copy of those compact outputs into pinned host memory (SURVEY.md §8(d)'s timing window).  At N=1 the steps
-run through urhgpu_stream_* (urh_amd.pipeline.CaptureStream): the hot kernel of step i, the tail of step i - 1 and the copy of
-step i - 2 overlap, and `value` counts K steps INCLUDING the copies of all K (the timed region ends after the last copy);
+(bit_sample_pos: see config.outputs) -> the compact outputs in pinned host memory (SURVEY.md §8(d)'s timing window).  At N=1 the steps
+run through urhgpu_stream_* (urh_amd.pipeline.CaptureStream): the hot kernel of step i + 1 overlaps the tail of step i, whose kernels
+store the rows and the packed results into the pinned host blob themselves (round 4: direct passes), and `value` counts K steps
+INCLUDING the delivery of all K (the timed region ends when the last step's results are on the host);
 the device-only figure of the same steps is config.device_only_ms_per_step.  Workload at N=1: BASELINE.json configs[1]
 ("1 GiB synthetic complex64 2-FSK @ 100 samples/symbol, single MI355X") on the bytes SURVEY.md §8(d) config 2
 specifies (128 segments of 2^20 samples: numpy-seeded bits through modulate_c + numpy-seeded AWGN, see
@@ -20,7 +21,12 @@ one process per GPU over RCCL) unless it already runs inside such a launch (WORL
 Prints ONE JSON line on rank 0 (see the driver contract) with extra objects:
   roofline      the dominant kernel (k_demod_runs_bp: demodulation + run segmentation) against HBM peak;
                 achieved = algorithmic bytes (12 B/sample) / mean kernel time measured with HIP events
-                attached to the kernel's dispatch on its launch stream, inside the timed region
+                attached to the kernel's dispatch on its launch stream, in K pipelined device-only steps right behind the timed
+                region (the timed loop itself carries no events); traffic = HBM bytes per launch from two rocprofv3 --pmc children
+                of this run (FETCH_SIZE, WRITE_SIZE in a pass of their own each, gfx950 corrections)
+  config        also: one capture start to finish in the stream's latency setting, the H2D-inclusive time of a capture that starts on
+                the host (urhgpu_stream_push_upload) against the bare pinned copy, the step with bit_sample_pos shipped, and -- N > 1 --
+                the sharded result's self-check and the FIR-halo variant (sharded_parity, fir_halo)
   parity        the LAST timed step's outputs (qad as uint32, pulse table, bits, pauses, offsets, bit_sample_pos) of the full
                 2^27-sample capture compared element for element with the CPU reference on the same bytes
   cpu_baseline  the reference's own path on this box's host cores (oracle/_ref = the reference's Cython modules compiled
