@@ -542,6 +542,11 @@ def extra_config5(pipe, dev, args):
                          "grab_pulse_lens_plus_bits_plus_d2h_auto_center": round(out["i_auto_center"][3], 3),
                          "grab_pulse_lens_plus_bits_plus_d2h_center_0": round(out["ii_center_0"][3], 3)},
            "center_detected": None if center is None else float(center),
+           "detect_center_roofline": {"passes_today": "5 reads + 1 write of the demodulated signal (count, compaction read + write, two leaf passes, histogram)",
+                                      "gbs_at_6_passes": round(6 * 4 * n / (t_center * 1e-3) / 1e9, 1),
+                                      "gbs_at_the_3_reads_a_fused_compaction_would_need": round(3 * 4 * n / (t_center * 1e-3) / 1e9, 1),
+                                      "hbm_frac_at_6_passes": round(6 * 4 * n / (t_center * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                      "note": "two strictly sequential float32 sums over 16 384 chunk sums (numpy's order) take 0.2 ms of it whatever the passes cost"},
            "costas_chunks": {"matched_by_a_candidate": stats[0], "met_at_a_checkpoint": stats[1], "evaluated_serially": stats[2],
                              "respeculation_rounds": stats[3],
                              "speculative_hit_rate": round(stats[0] / max(1, stats[0] + stats[1] + stats[2]), 5)},
