@@ -90,6 +90,7 @@ class GpuShardEngine(DevicePipeline):
         if self._hslots is None or self._hslots[0][0].numel() < cap:
             self._hslots = [(torch.empty(cap, dtype=torch.uint8, device=self.device), torch.empty(cap, dtype=torch.uint8).pin_memory(),
                              torch.cuda.Event()) for _ in range(3)]
+            self._hevents = [torch.cuda.Event() for _ in range(3)]     # "the pass's tail has packed the blob" (one per slot: no event made per pass)
             self._copy_stream = torch.cuda.Stream(self.device)
             self._predicted = 0
             self._hqueued = [False, False, False]
@@ -112,7 +113,7 @@ class GpuShardEngine(DevicePipeline):
                         self._predicted = max(self._predicted, abs(int(hdr[6])) + abs(int(hdr[6])) // 8 + 65536)
         n = dblob.numel() if self._predicted <= 0 else min(dblob.numel(), self._predicted)
         self._hqueued[k] = True
-        ev = torch.cuda.Event()
+        ev = self._hevents[k]
         ev.record(torch.cuda.current_stream(self.device))
         self._copy_stream.wait_event(ev)
         with torch.cuda.stream(self._copy_stream):
