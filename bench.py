@@ -147,34 +147,17 @@ def copy_ceiling(torch, pipe, iq, n):
 
 
 def tuning_from_env():
-    """Developer A/B knobs (tools/*.sh): the environment is read HERE, the library itself reads none (urhgpu_ctx_set_tuning).
+    """Developer A/B knobs (tools/ab.sh): the environment is read HERE, the library itself reads none (urhgpu_ctx_set_tuning).
+    URH_TUNE_<KEY>=value for every key of urhgpu_ctx_set_tuning (include/urhgpu.h), e.g. URH_TUNE_HOT_GRADED=784.
     Returns (tuning dict for DevicePipeline, torch priority of the tail's stream)."""
     t = {}
     e = os.environ
-    if "URH_HOT_LDS_KB" in e:
-        t["hot_lds_kb"] = t["hot_lds_kb_sharded"] = int(e["URH_HOT_LDS_KB"])
-    if "URH_HOT_STOP_EVENT" in e:
-        t["hot_stop_event"] = int(e["URH_HOT_STOP_EVENT"])
-    if e.get("URH_ARENA_WAIT") == "stream":
-        t["arena_wait_stream"] = 1
-    if "URH_PROFILE_BRACKET" in e:
-        t["profile_bracket"] = 1
-    if "URH_TAIL_MASKED" in e:
-        t["tail_masked"] = int(e["URH_TAIL_MASKED"])
-    if "URH_HOT_OVERLAP" in e:
-        t["hot_overlap"] = int(e["URH_HOT_OVERLAP"])
-    if "URH_HOT_OVERLAP_PCT" in e:
-        t["hot_overlap_pct"] = int(e["URH_HOT_OVERLAP_PCT"])
-    if "URH_HOT_ANY_ORDER" in e:
-        t["hot_any_order"] = int(e["URH_HOT_ANY_ORDER"])
-    if "URH_HOT_CUS_REMOVED" in e:
-        t["hot_cus_removed_per_xcd"] = int(e["URH_HOT_CUS_REMOVED"])
-    for env, key in (("URH_STREAM_SEGMENTS", "stream_segments"), ("URH_STREAM_SHAPE", "stream_shape"), ("URH_PACK_BLOCKS", "pack_blocks"),
-                     ("URH_STREAM_LAST_UNITS", "stream_last_units"), ("URH_STREAM_POS_DIRECT", "stream_pos_direct"), ("URH_UPLOAD_PIECES", "upload_pieces"), ("URH_STREAM_FUSE_GATE", "stream_fuse_gate"), ("URH_STREAM_FINAL_ON_ROWS", "stream_final_on_rows"),
-                     ("URH_STREAM_BITS_SEGMENTS", "stream_bits_segments"), ("URH_STREAM_POLICY", "stream_policy")):
+    for key in ("hot_lds_kb", "hot_lds_kb_sharded", "hot_cus_removed_per_xcd", "hot_graded", "profile_bracket", "stream_policy", "stream_latency",
+                "stream_segments", "stream_pos_direct", "upload_pieces"):
+        env = "URH_TUNE_" + key.upper()
         if env in e:
             t[key] = int(e[env])
-    prio = int(e.get("URH_TAIL_STREAM_PRIORITY", "-1" if e.get("URH_TAIL_PRIORITY") else "0"))
+    prio = int(e.get("URH_TAIL_STREAM_PRIORITY", "0"))
     return t, prio
 
 

@@ -83,32 +83,31 @@ int urhgpu_ctx_sync(urhgpu_ctx *ctx);
  * behind what the caller has queued on the context's stream; it is a stream with default flags, i.e. it synchronises with the NULL
  * stream as every such stream does: callers that queue unrelated work on the NULL stream meanwhile serialise with the hot kernels.
  * A caller that runs more than two passes ahead of the GPU is held back on the HOST at the start of the next pass until the tail
- * that last used the pass's scratch arena has finished (bounded run-ahead; urhgpu_ctx_set_tuning("arena_wait_stream", 1) makes the
- * context's stream wait instead and keeps the host asynchronous, at the price of one more barrier packet between two hot kernels).
+ * that last used the pass's scratch arena has finished (bounded run-ahead).
  * The library reads no environment variable; tuning values of this mode are set with urhgpu_ctx_set_tuning. */
 int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
-/* Tuning values of the pipelined mode (the defaults are what is measured and shipped; the A/B tools set others): key = "hot_lds_kb"
- * (dynamic LDS per hot workgroup in KiB: fewer of them per CU; default 0), "hot_lds_kb_sharded" (the same for urhgpu_shard_* passes;
- * default 33), "hot_stop_event" (1: the tail waits on the hot dispatch's own completion signal; 0: on an event recorded behind it),
- * "arena_wait_stream" (1: arena reuse guarded by a stream wait instead of bounded host run-ahead), "tail_priority" (1: a private tail
- * stream at the device's highest priority; set before urhgpu_ctx_set_pipelined), "profile_bracket" (1: urhgpu_ctx_profile_* report the
- * stream-level bracket, which reads 3-5 % longer than the kernel runs), "hot_cus_removed_per_xcd" (0 .. 16, default 4; set before
- * urhgpu_ctx_set_pipelined: the hot kernel of a pipelined pass runs on a private stream whose CU mask leaves that many CUs of every XCD
- * out -- on 224 of the MI355X's 256 CUs the kernel is 5 % faster than on all of them, and the CUs left alone serve the previous pass's
- * tail; 0: no mask, the hot kernel runs on the caller's stream), "tail_masked" (1, before urhgpu_ctx_set_pipelined: the tail runs on a
- * private stream masked to exactly the CUs the hot mask leaves out, replacing the caller's tail stream; measured no faster -- the hot
- * kernel gains 1 % and a single capture's latency loses 30 % -- default 0).  Streamed passes of urhgpu_stream_* (the tail in segments
- * beside the hot kernel): "stream_policy" (5, default: 3 for passes that ship no positions, 0 for those that do; 0: a pass is streamed when nothing
- * of an earlier pass is still running -- one capture, where the tail's latency counts --, else its blob is packed at the end and copied by the
- * copy engine; 1: every qualifying pass in segments; 2: never; 3: every qualifying pass DIRECT -- one segment, the ordinary tail
- * behind the hot kernel, whose kernels store rows and packed results into the pinned host blob themselves (no pack of the whole table,
- * no copy engine); 4: segments when idle, direct otherwise), "stream_latency" (1: under the default policy a pass that finds the pipeline idle -- ONE capture -- runs its tail in segments
- * beside the hot kernel, which gives the lowest latency, 0.39 against 0.41 ms per GiB; 0, default: direct passes throughout, which gives the
- * highest throughput for back-to-back passes), "stream_segments" (rows segments, 1 .. 16, default 7),
- * "stream_bits_segments" (default 1), "stream_shape" (0: equal segments; 1: halving; 2: equal segments and a short last one of
- * "stream_last_units" x 256 chunks), "stream_fuse_gate" / "stream_final_on_rows" (1, default: the last segment's gate inside its
- * one-workgroup resolve kernel; its bits kernels on the rows stream), "pack_blocks" (workgroups of a segment's pack kernel),
- * "upload_pieces" (2 .. 16, default 4: pieces of urhgpu_stream_push_upload, the last one short).  Unknown key: URHGPU_ERR_ARG. */
+/* Tuning values of the pipelined mode (the defaults are what is measured and shipped; tools/ab.sh sets others).  Ten keys; the knobs
+ * earlier rounds measured as useless are gone (their records: profiles/HISTORY.md).
+ *   "hot_lds_kb"               dynamic LDS per hot workgroup in KiB (fewer of them per CU); default 0
+ *   "hot_lds_kb_sharded"       the same for the urhgpu_shard_* passes that keep the generic tail (ASK); default 33
+ *   "hot_cus_removed_per_xcd"  0 .. 16, default 4; set before urhgpu_ctx_set_pipelined: the hot kernel of a pipelined pass runs on a private
+ *                              stream whose CU mask leaves that many CUs of every XCD out -- on 224 of the MI355X's 256 CUs the kernel is 5 %
+ *                              faster than on all of them, and the CUs left alone serve the previous pass's tail; 0: no mask
+ *   "hot_graded"               graded tail of the hot launch: that many of its last chunks are cut into four short ones each (the launch's
+ *                              last residency wave then drains in a quarter of the time); 0: uniform chunks
+ *   "profile_bracket"          1: urhgpu_ctx_profile_* report the stream-level bracket, which reads 3-5 % longer than the kernel runs
+ *   "stream_policy"            which tail a pass of urhgpu_stream_* takes.  5 (default): 3 for passes that ship no positions or ship them
+ *                              directly, 0 otherwise; 0: segments beside the hot kernel when nothing of an earlier pass is still running (one
+ *                              capture, where the tail's latency counts), else the blob is packed at the end and copied by the copy engine;
+ *                              1: every qualifying pass in segments; 2: never; 3: every qualifying pass DIRECT -- the ordinary tail behind the
+ *                              hot kernel, whose kernels store rows and packed results into the pinned host blob themselves; 4: segments when
+ *                              idle, direct otherwise
+ *   "stream_latency"           1: under the default policy a pass that finds the pipeline idle -- ONE capture -- runs its tail in segments
+ *                              (lowest latency); 0, default: direct passes throughout (highest throughput for back-to-back passes)
+ *   "stream_segments"          rows segments of a segmented pass, 1 .. 16, default 7
+ *   "stream_pos_direct"        1, default: direct passes ship bit_sample_pos themselves (uint32 stores of the kernels that compute them)
+ *   "upload_pieces"            2 .. 16, default 4: pieces of urhgpu_stream_push_upload, the last one short
+ * Unknown key: URHGPU_ERR_ARG. */
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value);
 int urhgpu_ctx_join(urhgpu_ctx *ctx);
 /* Pre-size the scratch arena for captures of up to n samples with the given tolerance so that no
@@ -609,6 +608,16 @@ int urhgpu_bgra_lookup_dev(urhgpu_ctx *ctx, const float *d_db, int64_t frames, i
  * out per value); shape 2: shape 0 on the CU-masked stream the hot kernel of pipelined passes runs on (URHGPU_ERR_UNSUPPORTED on a context
  * without one).  n_samples a multiple of 8192.  Synchronous. */
 int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_out, int64_t n_samples, int shape, int reps, float *ms_per_copy);
+/* Measurement hook (tools/boundary_probe.py -> profiles/r05_boundary_anatomy.txt): `launches` back-to-back launches of the hot kernel alone
+ * (complex64 2-FSK, n a multiple of 2048, qad written, no tail) on the context's stream (stream_kind 0) or its CU-masked hot stream (1; a
+ * pipelined context).  event_mode 0: plain launches; 1: a completion event attached to every dispatch as pipelined passes do; 2: the same
+ * with hipEventDisableSystemFence | hipEventReleaseToDevice; 3: timing events on every dispatch (dur_ms[launches], gap_ms[launches - 1]:
+ * the dispatches' own durations and the time from one's end to the next one's begin).  graded: that many of the launch's last chunks are
+ * cut into four short ones each.  Wavefront 0 of every workgroup leaves three s_memrealtime stamps (10 ns units, low 32 bits: entry,
+ * streaming phase over, ChunkInfo written) and its hardware ids in the ChunkInfo's first_acc / pend_stable / pad / pend_acc fields; the
+ * tables of the last `keep` launches are copied to d_chunks_out (keep * *n_chunks_out * URHGPU_SHARD_SUMMARY_BYTES bytes).  Synchronous. */
+int urhgpu_test_hot_probe(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, int stream_kind, int event_mode,
+                          int graded, int launches, int keep, void *d_chunks_out, int64_t *n_chunks_out, float *dur_ms, float *gap_ms);
 /* Synchronous device -> host copy after urhgpu_ctx_sync (for callers that hold raw device pointers, e.g. urhgpu_host_result::d_qad). */
 int urhgpu_memcpy_to_host(urhgpu_ctx *ctx, const void *d_src, void *host_dst, int64_t bytes);
 /* ... and device -> device (a result's d_qad into memory the caller owns, before the stream's qad ring moves on). */

@@ -84,5 +84,6 @@ def test_the_library_reads_no_environment_variable():
     offenders = [f for f in glob.glob(os.path.join(root, "urh_amd", "csrc", "*.h*")) if "getenv" in open(f).read()]
     assert not offenders, offenders
     header = open(os.path.join(root, "include", "urhgpu.h")).read()
-    for key in ("hot_lds_kb", "hot_lds_kb_sharded", "hot_stop_event", "arena_wait_stream", "tail_priority", "profile_bracket"):
+    for key in ("hot_lds_kb", "hot_lds_kb_sharded", "hot_cus_removed_per_xcd", "profile_bracket", "stream_policy", "stream_segments", "stream_latency",
+                "stream_pos_direct", "upload_pieces", "hot_graded"):
         assert '"' + key + '"' in header, key

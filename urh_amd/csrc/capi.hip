@@ -48,6 +48,8 @@ int join_tail(urhgpu_ctx *ctx) {
 
 using namespace urh;
 
+#define URH_PROBE_WPB 4     // wavefronts per chunk of the complex64 FSK bit-plane kernel (demod_runs.hip: URH_WPB)
+
 namespace {
 
 struct Plan {                 // how a capture of n samples is cut into chunks
@@ -168,16 +170,10 @@ int prof_end_record(urhgpu_ctx *ctx, hipStream_t s) {
 
 // pipelined passes: the stream the hot kernel is launched on -- the CU-masked private one (see urhgpu_ctx_set_pipelined), ordered
 // behind what the caller has queued on the context's stream so far
-int hot_stream_begin(urhgpu_ctx *ctx, hipStream_t *out, bool overlap_ok = false) {
+int hot_stream_begin(urhgpu_ctx *ctx, hipStream_t *out) {
     *out = ctx->stream;
     if (!ctx->pipelined || !ctx->hot_masked) return URHGPU_OK;
     hipStream_t hot = ctx->hot_masked;
-    if (overlap_ok && ctx->tune_hot_overlap && ctx->hot_masked2 && ctx->d_hot_ctr) {
-        hot = (ctx->hot_turn ^= 1) ? ctx->hot_masked2 : ctx->hot_masked;      // (the caller puts the gate in front of its kernel: hot_overlap_gate)
-    } else if (ctx->last_hot_stream && ctx->last_hot_stream != hot && ctx->last_hot_event) {
-        // the hot kernel before this one ran on the other masked stream (an overlapped pass): in order behind it
-        URH_HIP(hipStreamWaitEvent(hot, ctx->last_hot_event, 0));
-    }
     // The masked stream has default flags: what the caller has queued on the NULL stream is ordered before its work by the runtime
     // itself (and costs nothing when the NULL stream is idle).  An explicit event on the NULL stream would make THAT stream wait for the
     // previous hot kernel first and hand over afterwards: two cross-queue hand-overs between consecutive hot kernels (measured: a
@@ -189,18 +185,6 @@ int hot_stream_begin(urhgpu_ctx *ctx, hipStream_t *out, bool overlap_ok = false)
     *out = hot;
     return URHGPU_OK;
 }
-// after a hot launch on `s`: what the next launch orders itself behind / gates on
-void hot_launched(urhgpu_ctx *ctx, hipStream_t s, hipEvent_t done) {
-    ctx->last_hot_stream = s; ctx->last_hot_event = done;
-    if (g_hot_counted > 0) {
-        ctx->hot_gate_target = ctx->hot_total + (unsigned long long)((g_hot_counted * (long long)ctx->tune_hot_overlap_pct) / 100);
-        ctx->hot_total += (unsigned long long)g_hot_counted;
-    } else {
-        ctx->hot_gate_target = ctx->hot_total;             // (nothing of this launch counts: the next gate does not wait)
-    }
-    g_hot_counted = 0;
-}
-
 // scratch (from the arena) and persistent descriptors of the tile tail over a table of n_entries chunks
 int tile_tail_mem(urhgpu_ctx *ctx, int64_t n_entries, bool expands_bits, TileTailMem *tm) {
     tm->mem = ctx->arena.take(tile_tail_bytes(n_entries));
@@ -262,14 +246,9 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     // pipelined: the tail stream waits for the completion signal of the hot dispatch itself where one launch covers the capture (no
     // partial tile at the end) -- an event recorded behind it is one more barrier packet between two hot kernels
     hipEvent_t hot_done = nullptr;
-    if (s_tail && from_iq && ctx->hot_stop_event && n % kTile == 0) {
+    if (s_tail && from_iq && n % kTile == 0) {
         if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot; }
         hot_done = g_hot_events.stop;
-        // Consecutive hot kernels of pipelined passes share nothing they write (scratch arenas rotate, the tail of the arena's last user
-        // has finished: begin_pipelined_pass) -- the next one need not wait for this one's last wavefronts and its end-of-kernel cache
-        // write-back (about 10 us between two hot kernels: profiles/r04b_timeline_pipelined.txt).  hipExtAnyOrderLaunch clears the
-        // dispatch packet's barrier bit; barrier packets (waits for events) still hold the queue.  A/B knob, off by default.
-        if (ctx->tune_hot_any_order && s != ctx->stream) g_hot_events.flags = 1u /* hipExtAnyOrderLaunch */;
     }
     {
         const int st = from_iq ? launch_demod_runs_iq(a, p->dtype, p->mod, d_qad != nullptr, s) : launch_runs_qad(a, s);
@@ -280,7 +259,6 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     else g_hot_events = HotEvents();
     if (s_tail) {                                   // pipelined: everything after the hot kernel goes to the tail stream
         if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot, s)); hot_done = ctx->ev_hot; }
-        hot_launched(ctx, s, hot_done);
         URH_HIP(hipStreamWaitEvent(s_tail, hot_done, 0));
         // the hot kernel ran on the private masked stream: what the caller queues on ITS stream afterwards (overwriting the capture, the
         // allocator handing its memory out again) must come behind it.  (The NULL stream synchronises with the masked stream by itself.)
@@ -391,12 +369,11 @@ int begin_pipelined_pass(urhgpu_ctx *ctx) {
     // Has the tail that last used this arena finished?  A caller that runs more than two passes ahead of the GPU (a tight loop of
     // passes) is held back HERE, on the host, until it has (bounded run-ahead; the GPU still has the previous hot kernel queued
     // behind the running one): a stream-level wait would put one more barrier packet between two hot kernels (about 4 us of the
-    // gap).  URH_ARENA_WAIT=stream keeps the host asynchronous and makes the stream wait instead.
+    // gap; measured in round 2, tools/ab.sh history in profiles/HISTORY.md).
     const hipError_t q = hipEventQuery(ctx->ev_tail[ctx->flip]);
     if (q == hipErrorNotReady) {
         (void)hipGetLastError();                   // "not ready" is an answer, not an error: keep it out of the sticky last-error slot
-        if (ctx->arena_wait_on_stream) URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[ctx->flip], 0));
-        else URH_HIP(hipEventSynchronize(ctx->ev_tail[ctx->flip]));
+        URH_HIP(hipEventSynchronize(ctx->ev_tail[ctx->flip]));
     } else if (q != hipSuccess) {
         URH_HIP(q);
     }
@@ -479,7 +456,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     a.lds_pad = ctx->hot_lds_pad;
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     int64_t bound[kMaxSegments + 1];
-    int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, h_iq ? ctx->tune_upload_pieces : ctx->tune_stream_segments, h_iq ? 2 : ctx->tune_stream_shape, ctx->tune_stream_last_units, bound) : 0;
+    int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, h_iq ? ctx->tune_upload_pieces : ctx->tune_stream_segments, h_iq ? 2 : 0, 1, bound) : 0;
     // DIRECT passes (stream_policy 3, or 4 for the passes that policy 0 would not stream): ONE segment -- the ordinary tail behind the hot
     // kernel (an event, no gate), but rows and packed results are STORED into the pinned host blob by the tail's own kernels: no pack of
     // the whole table at the end, no copy engine, no predicted copy size.
@@ -530,7 +507,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     ctx->arena.reset();
     ctx->seg_dirty[slot] = true;                               // until the last segment has been queued
     hipStream_t s = ctx->stream;
-    if (p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s, direct));
+    if (p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s));
     ChunkInfo *chunks = (ChunkInfo *)ctx->arena.take((size_t)pl.n_chunks * sizeof(ChunkInfo));
     uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
     void *rs_mem = ctx->arena.take(resolve_scratch_bytes(pl.n_chunks));
@@ -574,30 +551,12 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
             piece_lo[k] = k == 0 ? 0 : piece_hi[k - 1];
             piece_hi[k] = (k < S - 1) ? std::min<int64_t>(bound[k + 1] + 1, pl.n_chunks) : pl.n_chunks;
         }
-        // A/B (tuning "upload_own_stream"): the copies on a stream of their own after all -- a CU-masked one (full mask), which owns its
-        // hardware queue like the masked hot stream does, so that nothing else can end up sharing a queue with them
         hipStream_t up = s;
-        if (ctx->tune_upload_own_stream && s == ctx->hot_masked && ctx->hot_masked) {
-            if (!ctx->upload_stream) {
-                uint32_t full[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
-                if (hipExtStreamCreateWithCUMask(&ctx->upload_stream, 8, full) != hipSuccess) { (void)hipGetLastError(); ctx->upload_stream = nullptr; }
-                for (int k = 0; ctx->upload_stream && k < kMaxSegments; ++k) URH_HIP(hipEventCreateWithFlags(&ctx->ev_up[k], hipEventDisableTiming));
-            }
-            if (ctx->upload_stream) {
-                up = ctx->upload_stream;
-                URH_HIP(hipEventRecord(ctx->ev_piece[0], s));            // behind what the hot stream holds (and, through it, the caller's stream)
-                URH_HIP(hipStreamWaitEvent(up, ctx->ev_piece[0], 0));
-            }
-        }
         for (int k = 0; k < S; ++k) {
             {
                 const int64_t s0 = piece_lo[k] * pl.chunk_len, s1 = std::min<int64_t>(piece_hi[k] * pl.chunk_len, n);
                 URH_HIP(hipMemcpyAsync((char *)const_cast<void *>(d_iq) + (size_t)s0 * bps, (const char *)h_iq + (size_t)s0 * bps, (size_t)(s1 - s0) * bps,
                                        hipMemcpyHostToDevice, up));
-                if (up != s) {
-                    URH_HIP(hipEventRecord(ctx->ev_up[k], up));
-                    URH_HIP(hipStreamWaitEvent(s, ctx->ev_up[k], 0));
-                }
             }
             a.launch_lo = piece_lo[k]; a.launch_hi = piece_hi[k];
             const int stl = launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s);
@@ -607,22 +566,13 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         a.launch_lo = 0; a.launch_hi = 0;
         URH_HIP(hipEventRecord(ctx->ev_hot_done[slot], s));
         hot_done = ctx->ev_hot_done[slot];
-        hot_launched(ctx, s, hot_done);
     } else {
     if (direct) { a.progress = nullptr; a.n_seg = 0; }         // (plain stores in the hot kernel, no counters: the tail starts behind its end)
-    if (direct && ctx->tune_hot_overlap && ctx->d_hot_ctr && ctx->hot_masked2 && (s == ctx->hot_masked || s == ctx->hot_masked2)) {
-        // overlapped hot kernels (common.hpp): behind a gate that opens when the previous hot kernel -- on the other masked stream -- is
-        // nearly through; this kernel counts its workgroups for the next one's gate
-        if (ctx->last_hot_stream && ctx->last_hot_stream != s) launch_hot_gate(ctx->d_hot_ctr, ctx->hot_gate_target, s);
-        a.done_ctr = ctx->d_hot_ctr;
-    }
     const bool prof = prof_begin_record(ctx, s);
     // the hot kernel's completion: the dispatch's own completion signal where the launcher takes events (an event recorded behind the
     // kernel is one more barrier packet between two hot kernels); nobody waits for it before the last segment has been queued
-    if (ctx->hot_stop_event) {
-        if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot_done[slot]; }
-        hot_done = g_hot_events.stop;
-    }
+    if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot_done[slot]; }
+    hot_done = g_hot_events.stop;
     {
         const int stl = launch_demod_runs_iq(a, p->dtype, p->mod, out->qad != nullptr, s);
         if (stl != URHGPU_OK) { g_hot_events = HotEvents(); return stl; }
@@ -631,7 +581,6 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     if (prof) URH_TRY(prof_end_record(ctx, s));
     else g_hot_events = HotEvents();
     if (!hot_done) { URH_HIP(hipEventRecord(ctx->ev_hot_done[slot], s)); hot_done = ctx->ev_hot_done[slot]; }
-    hot_launched(ctx, s, hot_done);
     }
     // ---- the tail in segments: rows segments on the tail stream, bits segments on the bits stream behind the rows they expand; neither
     // ever waits for the hot kernel as a whole ----
@@ -659,9 +608,9 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         if (cap_host < L.total) return URHGPU_ERR_CAPACITY;
         h_state = (int8_t *)((char *)host_blob + L.off_row_state); h_len = (int32_t *)((char *)host_blob + L.off_row_len);
     }
-    SegPackDst dst{host_blob, cap_host, progress, ctx->tune_pack_blocks, (direct && ctx->tune_stream_pos_direct) ? 1 : 0};
+    SegPackDst dst{host_blob, cap_host, progress, 0, (direct && ctx->tune_stream_pos_direct) ? 1 : 0};
     // bits segments: the last one is the last rows segment alone (what is exposed behind the hot kernel), the others share the rest
-    int Sb = h_iq ? S : ctx->tune_stream_bits_segments;       // (an upload: every piece's bits behind its rows -- the pieces are milliseconds apart)
+    int Sb = h_iq ? S : 1;       // (an upload: every piece's bits behind its rows -- the pieces are milliseconds apart)
     if (Sb > S) Sb = S;
     if (Sb < 1) Sb = 1;
     int bits_end_at[kMaxSegments];                             // bits segment j ends with rows segment bits_end_at[j]
@@ -669,15 +618,15 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     bits_end_at[Sb - 1] = S - 1;
     int jb = 0;
     int64_t bits_from = 0;
-    // the LAST bits segment goes onto the rows stream, right behind the last rows (tune_stream_final_on_rows): no event hop between two
+    // the LAST bits segment goes onto the rows stream, right behind the last rows: no event hop between two
     // streams on the chain that is exposed behind the hot kernel's end; the rows stream then waits for the bits segments before it
-    const bool final_on_rows = ctx->tune_stream_final_on_rows;
+    const bool final_on_rows = true;
     hipStream_t last_stream = tb;
     for (int k = 0; k < S; ++k) {
         if (h_iq) URH_HIP(hipStreamWaitEvent(ts, ctx->ev_piece[k], 0));
         else if (direct) URH_HIP(hipStreamWaitEvent(ts, hot_done, 0));
         RowsSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], SegGate{event_start ? nullptr : progress, k, target[k], k == 0 ? 1 : 0, st, (long long)200000000, 0},
-                       h_state, h_len, ctx->tune_stream_fuse_gate ? 1 : 0};
+                       h_state, h_len, 1};
         URH_TRY(launch_rows_segment(r, e, tm, bp, st, sg, ts));
         while (jb < Sb && bits_end_at[jb] < k) ++jb;           // (a bits segment that would end before the first rows segment: none)
         if (jb < Sb && bits_end_at[jb] == k) {
@@ -780,8 +729,6 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     ctx->arena_alt.release();
     ctx->arena_alt2.release();
     if (ctx->hot_masked) { (void)hipStreamSynchronize(ctx->hot_masked); (void)hipStreamDestroy(ctx->hot_masked); }
-    if (ctx->hot_masked2) { (void)hipStreamSynchronize(ctx->hot_masked2); (void)hipStreamDestroy(ctx->hot_masked2); }
-    if (ctx->d_hot_ctr) (void)hipFree(ctx->d_hot_ctr);
     if (ctx->ev_in) (void)hipEventDestroy(ctx->ev_in);
     if (ctx->tail_stream) (void)hipStreamSynchronize(ctx->tail_stream);
     if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
@@ -789,8 +736,6 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
         (void)hipFree(ctx->d_seg);
         if (ctx->bits_stream) { (void)hipStreamSynchronize(ctx->bits_stream); (void)hipStreamDestroy(ctx->bits_stream); }
         for (hipEvent_t e : ctx->ev_piece) if (e) (void)hipEventDestroy(e);
-        if (ctx->upload_stream) { (void)hipStreamSynchronize(ctx->upload_stream); (void)hipStreamDestroy(ctx->upload_stream); }
-        for (hipEvent_t e : ctx->ev_up) if (e) (void)hipEventDestroy(e);
         for (int k = 0; k < 3; ++k) {
             if (ctx->ev_hot_done[k]) (void)hipEventDestroy(ctx->ev_hot_done[k]);
             if (ctx->ev_bits[k]) (void)hipEventDestroy(ctx->ev_bits[k]);
@@ -826,7 +771,6 @@ int urhgpu_ctx_use_private_stream(urhgpu_ctx *ctx) {
 int urhgpu_ctx_sync(urhgpu_ctx *ctx) {
     if (!ctx) return URHGPU_ERR_ARG;
     if (ctx->hot_masked) URH_HIP(hipStreamSynchronize(ctx->hot_masked));
-    if (ctx->hot_masked2) URH_HIP(hipStreamSynchronize(ctx->hot_masked2));
     if (ctx->bits_stream) URH_HIP(hipStreamSynchronize(ctx->bits_stream));
     if (ctx->tail_stream) URH_HIP(hipStreamSynchronize(ctx->tail_stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
@@ -841,18 +785,10 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
     if (ctx->own_tail_stream && ctx->tail_stream) { (void)hipStreamDestroy(ctx->tail_stream); }
     ctx->tail_stream = nullptr; ctx->own_tail_stream = false; ctx->pipelined = false;
     if (ctx->hot_masked) { (void)hipStreamSynchronize(ctx->hot_masked); (void)hipStreamDestroy(ctx->hot_masked); ctx->hot_masked = nullptr; }
-    if (ctx->hot_masked2) { (void)hipStreamSynchronize(ctx->hot_masked2); (void)hipStreamDestroy(ctx->hot_masked2); ctx->hot_masked2 = nullptr; }
-    ctx->last_hot_stream = nullptr; ctx->last_hot_event = nullptr; ctx->hot_turn = 0;
     if (!enable) return URHGPU_OK;
     if (tail_stream) ctx->tail_stream = (hipStream_t)tail_stream;
     else {
-        if (ctx->tune_tail_priority) {                     // urhgpu_ctx_set_tuning("tail_priority", 1): the device's highest stream priority
-            int lo = 0, hi = 0;
-            URH_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            URH_HIP(hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, hi));
-        } else {
-            URH_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
-        }
+        URH_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
         ctx->own_tail_stream = true;
     }
     if (!ctx->ev_hot) {
@@ -877,75 +813,41 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
         }
         // (a runtime that cannot make the masked stream is no reason to fail: the hot kernel then runs on the caller's stream as before)
         if (hipExtStreamCreateWithCUMask(&ctx->hot_masked, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ctx->hot_masked = nullptr; }
-        if (ctx->hot_masked && !ctx->hot_masked2) {
-            if (hipExtStreamCreateWithCUMask(&ctx->hot_masked2, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ctx->hot_masked2 = nullptr; }
-            if (ctx->hot_masked2 && !ctx->d_hot_ctr) {
-                if (hipMalloc((void **)&ctx->d_hot_ctr, 256) != hipSuccess || hipMemset(ctx->d_hot_ctr, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-                    (void)hipGetLastError();
-                    ctx->d_hot_ctr = nullptr;
-                }
-                ctx->hot_total = 0; ctx->hot_gate_target = 0;
-            }
-        }
         if (ctx->hot_masked && !ctx->ev_in && hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             (void)hipStreamDestroy(ctx->hot_masked);
             ctx->hot_masked = nullptr;
-        }
-        if (ctx->hot_masked && ctx->tune_tail_masked) {
-            // A/B: the tail on a private stream masked to exactly the CUs the hot kernel leaves alone (replaces the caller's tail stream)
-            uint32_t inv[8];
-            for (int w = 0; w < words; ++w) inv[w] = ~mask[w];
-            hipStream_t ts = nullptr;
-            if (hipExtStreamCreateWithCUMask(&ts, (uint32_t)words, inv) == hipSuccess) {
-                if (ctx->own_tail_stream && ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
-                ctx->tail_stream = ts; ctx->own_tail_stream = true;
-            } else (void)hipGetLastError();
         }
     }
     ctx->pipelined = true;
     return URHGPU_OK;
 }
 
-// Tuning values of the pipelined mode (defaults = what is measured and shipped; the A/B tools set others: tools/r3_ab.sh through
-// bench.py's URH_TUNE_* environment, read THERE -- the library itself reads no environment variable).
-//   hot_lds_kb          dynamic LDS per hot workgroup in KiB (fewer of them per CU: room for the previous pass's tail); default 0
-//   hot_lds_kb_sharded  the same for the urhgpu_shard_* passes, whose longer tail (three exchanges) needs the room; default 33: four hot
-//                       workgroups per CU, the hot kernel takes 0.31 ms and the tail keeps up (21 / 27 KiB = 6 / 5 per CU: 0.36 / 0.34 ms
-//                       per pass; 38 KiB and more = 3: 0.34-0.42)
-//   hot_stop_event      1 (default): the tail stream waits on the hot dispatch's own completion signal; 0: on an event recorded behind it
-//   arena_wait_stream   1: arena reuse is guarded by a stream wait instead of bounded host run-ahead (see begin_pipelined_pass); default 0
-//   tail_priority       1: a private tail stream is created at the device's highest priority (before urhgpu_ctx_set_pipelined); default 0
-//   profile_bracket     1: urhgpu_ctx_profile_* report the stream-level bracket around the hot launch instead of the dispatch's own timing
-//   tail_masked         1: the tail on a private stream masked to the CUs the hot mask leaves out (tools/r3_tailmask.sh, round 3: with 4 / 6 /
-//                       8 / 12 CUs per XCD for the tail 0.301 / 0.323 / 0.313 / 0.335 ms per step with D2H against 0.298-0.302 unmasked,
-//                       hot kernel 0.274-0.277 against 0.276-0.279: what slows the hot kernel inside the run is not the tail's wave slots)
+// Tuning values of the pipelined mode (defaults = what is measured and shipped; the A/B tool tools/ab.sh sets others through bench.py's
+// URH_TUNE_* environment, read THERE -- the library itself reads no environment variable).  The knobs earlier rounds measured as useless
+// are gone; their records are in profiles/HISTORY.md.
+//   hot_lds_kb               dynamic LDS per hot workgroup in KiB (fewer of them per CU: room for the previous pass's tail); default 0
+//   hot_lds_kb_sharded       the same for the urhgpu_shard_* passes that keep the generic tail (ASK); default 33
+//   hot_cus_removed_per_xcd  CUs per XCD the hot kernel of a pipelined pass leaves alone (before urhgpu_ctx_set_pipelined); default 4, 0: no mask
+//   profile_bracket          1: urhgpu_ctx_profile_* report the stream-level bracket around the hot launch instead of the dispatch's own timing
+//   stream_policy            which tail a pass of urhgpu_stream_* takes (common.hpp: tune_stream_policy); default 5
+//   stream_segments          rows segments of a segmented pass; default 7
+//   stream_latency           1: a pass that finds the pipeline idle runs its tail in segments (lowest latency for ONE capture); default 0
+//   stream_pos_direct        1 (default): direct passes ship bit_sample_pos themselves
+//   upload_pieces            pieces of urhgpu_stream_push_upload; default 4
+//   hot_graded               the hot launch's last `value` chunks are cut into four short ones each (graded tail); default kGradedDefault
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return URHGPU_ERR_ARG;
     if (!strcmp(key, "hot_lds_kb")) { if (value < 0 || value > 150) return URHGPU_ERR_ARG; ctx->hot_lds_pad = value * 1024; }
     else if (!strcmp(key, "hot_lds_kb_sharded")) { if (value < 0 || value > 150) return URHGPU_ERR_ARG; ctx->hot_lds_pad_sharded = value * 1024; }
-    else if (!strcmp(key, "hot_stop_event")) ctx->hot_stop_event = value != 0;
-    else if (!strcmp(key, "arena_wait_stream")) ctx->arena_wait_on_stream = value != 0;
-    else if (!strcmp(key, "tail_priority")) ctx->tune_tail_priority = value != 0;
     else if (!strcmp(key, "profile_bracket")) ctx->prof_bracket = value != 0;
-    else if (!strcmp(key, "tail_masked")) ctx->tune_tail_masked = value != 0;
     else if (!strcmp(key, "hot_cus_removed_per_xcd")) { if (value < 0 || value > 16) return URHGPU_ERR_ARG; ctx->tune_hot_cus_removed = value; }
     else if (!strcmp(key, "stream_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_segments = value; }
     else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 5) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
-    else if (!strcmp(key, "stream_shape")) { if (value < 0 || value > 2) return URHGPU_ERR_ARG; ctx->tune_stream_shape = value; }
     else if (!strcmp(key, "stream_latency")) { ctx->tune_stream_latency = value != 0; }
     else if (!strcmp(key, "stream_pos_direct")) { ctx->tune_stream_pos_direct = value != 0; }
-    else if (!strcmp(key, "hot_overlap")) { ctx->tune_hot_overlap = value != 0; }
-    else if (!strcmp(key, "hot_overlap_pct")) { if (value < 50 || value > 100) return URHGPU_ERR_ARG; ctx->tune_hot_overlap_pct = value; }
-    else if (!strcmp(key, "hot_any_order")) { ctx->tune_hot_any_order = value != 0; }
-    else if (!strcmp(key, "stream_spin")) { if (value < 0) return URHGPU_ERR_ARG; ctx->tune_stream_spin = value; }
-    else if (!strcmp(key, "upload_own_stream")) { ctx->tune_upload_own_stream = value != 0; }
     else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }
-    else if (!strcmp(key, "stream_last_units")) { if (value < 1 || value > 64) return URHGPU_ERR_ARG; ctx->tune_stream_last_units = value; }
-    else if (!strcmp(key, "stream_fuse_gate")) { ctx->tune_stream_fuse_gate = value != 0; }
-    else if (!strcmp(key, "stream_final_on_rows")) { ctx->tune_stream_final_on_rows = value != 0; }
-    else if (!strcmp(key, "stream_bits_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_bits_segments = value; }
-    else if (!strcmp(key, "pack_blocks")) { if (value < 0 || value > 4096) return URHGPU_ERR_ARG; ctx->tune_pack_blocks = value; }
+    else if (!strcmp(key, "hot_graded")) { if (value < 0 || value > (1 << 20)) return URHGPU_ERR_ARG; ctx->tune_hot_graded = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;
 }
@@ -1038,7 +940,6 @@ int urhgpu_ctx_profile_end(urhgpu_ctx *ctx, float *ms_out, int cap, int *n_recor
     if (!ctx || !n_records) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
     if (ctx->hot_masked) URH_HIP(hipStreamSynchronize(ctx->hot_masked));
-    if (ctx->hot_masked2) URH_HIP(hipStreamSynchronize(ctx->hot_masked2));
     URH_HIP(hipStreamSynchronize(ctx->stream));
     ctx->prof_on = false;
     const int n = ctx->prof_used;
@@ -1291,7 +1192,7 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     if (part == 1 && rank > 0 && !a.left_halo) a.left_halo = d_iq;    // any non-null value: only chunk 0 reads the halo
     const bool prof = prof_begin_record(ctx, s);
     hipEvent_t hot_done = nullptr;                 // pipelined: what the tail stream waits for (see digitize)
-    if (ss->piped && ctx->hot_stop_event && n_local % kTile == 0) {
+    if (ss->piped && n_local % kTile == 0) {
         if (!prof) { g_hot_events = HotEvents(); g_hot_events.stop = ctx->ev_hot; }
         hot_done = g_hot_events.stop;
     }
@@ -1964,6 +1865,62 @@ int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_o
     URH_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms_per_copy = ms / (float)reps;
+    return URHGPU_OK;
+}
+
+// Probe (tools/boundary_probe.py; profiles/r05_boundary_anatomy.txt): `launches` back-to-back launches of the hot kernel ALONE (complex64
+// 2-FSK, qad written, no tail) on one stream, every wavefront 0 leaving its s_memrealtime stamps in its ChunkInfo.
+int urhgpu_test_hot_probe(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, int stream_kind, int event_mode,
+                          int graded, int launches, int keep, void *d_chunks_out, int64_t *n_chunks_out, float *dur_ms, float *gap_ms) {
+    if (!ctx || !d_iq || !p || !d_qad || !d_chunks_out || !n_chunks_out || launches < 1 || keep < 1 || keep > launches || n < kTile || n % kTile) return URHGPU_ERR_ARG;
+    if (p->dtype != URHGPU_DT_F32 || p->mod != URHGPU_MOD_FSK || p->bits_per_symbol != 1) return URHGPU_ERR_UNSUPPORTED;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(urhgpu_ctx_sync(ctx));
+    const Plan pl = make_plan(ctx, n, p->tolerance);
+    const int64_t g = std::min<int64_t>(std::max(graded, 0), pl.n_chunks);
+    const int64_t short_len = pl.chunk_len / 4;
+    if (g > 0 && ((short_len % (URH_PROBE_WPB * kRowSamples)) != 0 || n % pl.chunk_len != 0)) return URHGPU_ERR_UNSUPPORTED;
+    const int64_t n_launch = pl.n_chunks + 3 * g;              // the last g chunks cut into four short ones each
+    URH_TRY(ctx->arena.reserve((size_t)n_launch * sizeof(ChunkInfo) + (size_t)n_launch * pl.slab_stride * 8 + 4096));
+    ctx->arena.reset();
+    ChunkInfo *chunks = (ChunkInfo *)ctx->arena.take((size_t)n_launch * sizeof(ChunkInfo));
+    uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)n_launch * pl.slab_stride * 8);
+    if (!chunks || !slab) return URHGPU_ERR_ARG;
+    RunArgs a;
+    memset(&a, 0, sizeof(a));
+    URH_TRY(fill_thresholds(a, p));
+    a.in = d_iq; a.qad = d_qad; a.n = n; a.chunk_len = pl.chunk_len; a.slab_stride = pl.slab_stride;
+    a.noise_sqrd = p->noise_threshold * p->noise_threshold; a.noise_val = noise_for(p); a.tol = p->tolerance;
+    URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
+    a.chunks = chunks; a.slab = slab; a.stamp_probe = 1;
+    if (g > 0) { a.graded_from = pl.n_chunks - g; a.graded_len = short_len; }
+    hipStream_t s = ctx->stream;
+    if (stream_kind == 1) { if (!ctx->hot_masked) return URHGPU_ERR_UNSUPPORTED; s = ctx->hot_masked; }
+    // event_mode 0: plain launches; 1: a completion event (timing disabled) attached to every dispatch, as the product's pipelined passes
+    // do; 2: the same, created with hipEventDisableSystemFence | hipEventReleaseToDevice; 3: timing events (start + stop) on every dispatch
+    std::vector<hipEvent_t> ev((size_t)launches * 2, nullptr);
+    if (event_mode != 0) {
+        const unsigned fl = event_mode == 1 ? hipEventDisableTiming : event_mode == 2 ? (hipEventDisableTiming | hipEventDisableSystemFence | hipEventReleaseToDevice) : hipEventDefault;
+        for (auto &e : ev) URH_HIP(hipEventCreateWithFlags(&e, fl));
+    }
+    for (int j = 0; j < launches; ++j) {
+        // the last `keep` launches write their chunk tables straight into the caller's buffer (nothing between two hot kernels)
+        a.chunks = (j >= launches - keep) ? (ChunkInfo *)d_chunks_out + (size_t)(j - (launches - keep)) * n_launch : chunks;
+        if (event_mode != 0) { g_hot_events = HotEvents(); g_hot_events.start = event_mode == 3 ? ev[2 * j] : nullptr; g_hot_events.stop = ev[2 * j + 1]; }
+        const int st = launch_demod_runs_iq(a, p->dtype, p->mod, true, s);
+        g_hot_events = HotEvents();
+        if (st != URHGPU_OK) return st;
+    }
+    URH_HIP(hipStreamSynchronize(s));
+    if (event_mode == 3 && dur_ms && gap_ms) {
+        for (int j = 0; j < launches; ++j) {
+            URH_HIP(hipEventElapsedTime(&dur_ms[j], ev[2 * j], ev[2 * j + 1]));
+            if (j + 1 < launches) URH_HIP(hipEventElapsedTime(&gap_ms[j], ev[2 * j + 1], ev[2 * j + 2]));
+        }
+    }
+    for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    *n_chunks_out = n_launch;
     return URHGPU_OK;
 }
 

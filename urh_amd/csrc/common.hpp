@@ -90,30 +90,11 @@ struct urhgpu_ctx {
     // (latency-bound, nearly empty) tail of this one -- and, with three arenas, of the one before.  Outputs are complete after urhgpu_ctx_join / urhgpu_ctx_sync.
     bool pipelined = false;
     int hot_lds_pad_sharded = 33 * 1024;   // the same for the urhgpu_shard_* passes (their tail is longer: see urhgpu_ctx_set_tuning)
-    bool tune_tail_priority = false;
-    bool tune_tail_masked = false;         // the tail stream is a private one masked to the CUs the hot mask leaves out (A/B knob)
     int tune_hot_cus_removed = 4;          // CUs per XCD the hot kernel of a pipelined pass leaves alone (0: no mask); see urhgpu_ctx_set_pipelined
     hipStream_t hot_masked = nullptr;      // private CU-masked stream of the hot kernel (pipelined mode)
-    // Overlapped hot kernels (tuning "hot_overlap", direct passes of urhgpu_stream_*): kernels of ONE stream never overlap on this
-    // runtime (tools/kbench/anyorder.hip), and 10 us lie between the end of one hot kernel and the start of the next.  Consecutive passes
-    // therefore alternate between two masked streams; the hot kernel counts its finished workgroups into d_hot_ctr (never reset: a running
-    // total), and a one-wavefront gate in front of the next hot kernel lets it go when the previous one has finished hot_overlap_pct % of
-    // its workgroups -- the next kernel's ramp then meets the previous one's last wavefronts instead of an empty machine.
-    hipStream_t hot_masked2 = nullptr;
-    unsigned long long *d_hot_ctr = nullptr;
-    unsigned long long hot_total = 0;      // workgroups of every counting hot launch so far
-    unsigned long long hot_gate_target = 0;   // the counter value at which the NEXT hot kernel may start
-    int hot_turn = 0;
-    hipStream_t last_hot_stream = nullptr; // where the most recent hot kernel was launched, and the event behind it (other launch paths order
-    hipEvent_t last_hot_event = nullptr;   // themselves behind it when they use the other stream)
-    bool tune_hot_overlap = false;
-    int tune_hot_overlap_pct = 97;
     hipEvent_t ev_in = nullptr;
     int hot_lds_pad = 0;           // pipelined mode: dynamic LDS bytes added to every hot-kernel workgroup (see RunArgs::lds_pad)
-    bool hot_stop_event = true;
-    bool tune_hot_any_order = false;      // pipelined passes: the hot dispatch without the AQL barrier bit (hipExtAnyOrderLaunch), see digitize()
-    bool arena_wait_on_stream = false;   // pipelined mode: arena reuse guarded by a stream wait instead of bounded host run-ahead (URH_ARENA_WAIT=stream)
-      // pipelined mode: the tail waits for the hot dispatch's own completion signal (URH_HOT_STOP_EVENT)
+    int tune_hot_graded = 0;       // graded tail of the hot launch (RunArgs::graded_from): this many of its last chunks are cut into four short ones
     hipStream_t tail_stream = nullptr;
     bool own_tail_stream = false;
     urh::Arena arena_alt, arena_alt2;   // three scratch arenas in rotation: the hot kernel of pass i + 2 does not wait for the tail of pass i
@@ -133,22 +114,10 @@ struct urhgpu_ctx {
                                    // of a FOLLOWING pass the segments' short kernels are slower than one tail over the whole capture
                                    // (memory latency under a saturated HBM), so back-to-back passes keep the one-piece tail
     long long passes_begun = 0;    // pipelined passes started on this context
-    int tune_stream_shape = 0;     // 0: equal segments; 1: halving (1/2, 1/4, ... of the capture, the last two equal); 2: equal segments and
-                                   // a short last one (tune_stream_last_units alignment units of 256 chunks)
-    int tune_stream_last_units = 1;
     bool tune_stream_latency = false;      // policy 5: a pass that finds the pipeline idle runs its tail in segments (lowest latency for ONE capture)
     bool tune_stream_pos_direct = true;    // direct passes ship positions themselves (group scan + expansion store uint32 into the host blob)
-    int tune_stream_spin = 0;               // hipEventQuery polls before the host parks in hipEventSynchronize (urhgpu_stream_* results)
     int tune_upload_pieces = 4;             // pieces of urhgpu_stream_push_upload: pieces - 1 equal ones and a short last one (shape 2)
-    bool tune_stream_fuse_gate = true;      // the last segment's gate inside its one-workgroup resolve kernel (SegGate::fused)
-    bool tune_stream_final_on_rows = true;  // the last bits segment on the rows stream, right behind the last rows (no cross-stream hop)
-    hipStream_t upload_stream = nullptr;    // upload mode, tune_upload_own_stream: the copies on a CU-masked (full mask) stream of their own -- such a stream owns its hardware queue
-    hipEvent_t ev_up[16] = {};              // piece k has landed (tune_upload_own_stream)
-    bool tune_upload_own_stream = false;
     hipEvent_t ev_piece[16] = {};           // the hot kernel of piece k has finished (the rows segment k waits for it: no polling gate in upload mode)
-    int tune_stream_bits_segments = 1;   // (one: measured best for ONE capture with 7 rows segments, profiles/r04e_single_capture_segments.txt)
-                                         // bits segments (tile scan, group scan, expansion, pack) of a streamed pass, on their own stream
-    int tune_pack_blocks = 0;      // workgroups of a segment's pack kernel (0: default)
     hipEvent_t ev_hot_done[3] = {nullptr, nullptr, nullptr};   // behind the hot kernel of the pass in arena slot k (streamed passes)
     hipStream_t bits_stream = nullptr;   // second tail stream of streamed passes: the bits segments, behind the rows they expand
     hipEvent_t ev_rows[3][16] = {};      // [arena slot][bits segment]: the rows below the bits segment's end have been written

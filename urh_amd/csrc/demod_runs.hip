@@ -58,9 +58,6 @@ enum { SRC_IQ = 0, SRC_QAD = 1 };
 #ifndef URH_ASK_WPB
 #define URH_ASK_WPB 8      // ... when it demodulates ASK (magnitudes: little per-wavefront start-up work, measured faster with 8)
 #endif
-#ifndef URH_QAD_THROUGH
-#define URH_QAD_THROUGH 0   // see the qad store of k_demod_runs_bp
-#endif
 #ifndef URH_NT
 #define URH_NT 1          // non-temporal IQ loads / qad stores (streamed once): +8 % on the copy ceiling, tools/kbench
 #endif
@@ -1019,14 +1016,9 @@ __device__ __forceinline__ uint32_t put_lane(uint32_t value, int row, uint32_t o
 // order 4 (planes = the two bits of state - 1, from the three threshold masks).
 template <int SRC, int MOD> constexpr int bp_waves() { return (SRC == SRC_IQ && MOD == URHGPU_MOD_ASK) ? URH_ASK_WPB : URH_WPB; }
 
-// A/B build knob (python -m urh_amd.build --tag w8 -DURH_BP_WAVES_PER_EU=8): occupancy the compiler has to reach for this kernel
-#ifdef URH_BP_WAVES_PER_EU
-#define URH_BP_OCC __attribute__((amdgpu_waves_per_eu(URH_BP_WAVES_PER_EU, URH_BP_WAVES_PER_EU)))
-#else
-#define URH_BP_OCC
-#endif
-template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1>
-__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_demod_runs_bp(const RunArgs p) {
+template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1, bool STAMPS = false>
+__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) __attribute__((amdgpu_waves_per_eu(STAMPS ? 7 : 1, STAMPS ? 7 : 8)))
+void k_demod_runs_bp(const RunArgs p) {
     // One workgroup per chunk, URH_WPB wavefronts: wavefront w streams the w-th share of the chunk's rows on its own
     // (no barrier inside the streaming phase), so that the wavefronts resident on the chip cover a NARROW window of
     // the capture (DRAM page locality: a wavefront per 16 KiB measured 8 % faster than a wavefront per 64 KiB on a
@@ -1036,12 +1028,20 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
     const int lane = threadIdx.x & 63;
     const int w = (W > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;     // wavefront-uniform
     const int64_t chunk = p.chunk_base + blockIdx.x;
-    const int64_t a0 = p.range_begin + (int64_t)blockIdx.x * p.chunk_len;
-    const int64_t a1 = (a0 + p.chunk_len < p.range_end) ? a0 + p.chunk_len : p.range_end;
-    const int nr = (int)((a1 - a0) / kRowSamples);            // whole rows in this chunk: 16, 32, 48 or 64
+    int64_t a0 = p.range_begin + (int64_t)blockIdx.x * p.chunk_len;
+    int64_t a1 = (a0 + p.chunk_len < p.range_end) ? a0 + p.chunk_len : p.range_end;
+    if (p.graded_from > 0 && chunk >= p.graded_from) {        // graded tail (RunArgs::graded_from): the launch's last chunks are short
+        a0 = p.graded_from * p.chunk_len + (chunk - p.graded_from) * p.graded_len;
+        a1 = (a0 + p.graded_len < p.range_end) ? a0 + p.graded_len : p.range_end;
+    }
+    const int nr = (int)((a1 - a0) / kRowSamples);            // whole rows in this chunk: a multiple of W, at most 64
     const int R = nr / W;                                     // rows of this wavefront: [w R, w R + R)
     const int r0 = w * R;
     uint64_t *slab = RUNS ? p.slab + chunk * p.slab_stride : nullptr;
+    // STAMPS (probe only, tools/boundary_probe.py): wavefront 0 leaves three s_memrealtime stamps (10 ns units, low 32 bits: entry, streaming
+    // phase over, ChunkInfo written) and its hardware ids in the ChunkInfo fields the resolve kernels fill in later
+    // (stored at once, re-read for the ChunkInfo store: a value kept in a register across the streaming loop costs this kernel its seventh wavefront)
+    if (STAMPS && w == 0 && lane == 0) p.chunks[chunk].first_acc = (int32_t)(uint32_t)wall_clock64();
     const bool global_start = (p.left_halo == nullptr);
     const bool first_row = (a0 == 0) && global_start && (w == 0);   // this wavefront holds sample 0 of the capture
 
@@ -1084,12 +1084,7 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
                         w1 = (m1 <= p.dm_noise_sqrd) ? p.dm_noise_val : __builtin_sqrtf(m1) / p.dm_max_magnitude;
                         if (row0 && lane == 0) w0 = p.dm_noise_val;
                     }
-#if URH_QAD_THROUGH
-                    // A/B (round 4): the demodulated signal written THROUGH to memory (agent-scope relaxed 64-bit store: sc1), so that no dirty
-                    // line of it waits in this XCD's L2 for the write-back at the kernel's end
-                    unsigned long long qq64 = (unsigned long long)__float_as_uint(w0) | ((unsigned long long)__float_as_uint(w1) << 32);
-                    __hip_atomic_store((unsigned long long *)(p.qad + a0 + off), qq64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#elif URH_NT
+#if URH_NT
                     typedef float v2s __attribute__((ext_vector_type(2)));
                     const v2s qq = {w0, w1};
                     __builtin_nontemporal_store(qq, (v2s *)(p.qad + a0 + off));
@@ -1135,9 +1130,7 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
     }
 
     if (!RUNS) return;
-    // hot_overlap: this workgroup's loads and qad stores are issued -- the next pass's hot kernel may take the slot over (a hint for the
-    // gate in front of it, not a data dependency: nobody reads this pass's results before its completion event)
-    if (p.done_ctr && w == 0 && lane == 0) atomicAdd(p.done_ctr, 1ull);
+    if (STAMPS && w == 0 && lane == 0) p.chunks[chunk].pend_stable = (int32_t)(uint32_t)wall_clock64();
     // the chunk's planes come together in wavefront 0 (lane r <- row r)
     if (W > 1) {
         if (w != 0) {
@@ -1292,6 +1285,13 @@ __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) URH_BP_OCC void k_
         ci.last_pos = last_pos;
         ci.init_state = (uint16_t)chunk_init_state<SRC, DT, MOD, NPL == 1>(p, chunk);
         ci.first_acc = 0; ci.pend_acc = 0; ci.pend_stable = 0; ci.pad = 0;
+        if (STAMPS) {
+            // gfx9 HW_REG_HW_ID: wave / SIMD / CU / SE ids; the XCC id is its own register (HW_REG_XCC_ID = 20)
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (3 << 11));
+            ci.first_acc = p.chunks[chunk].first_acc; ci.pend_stable = p.chunks[chunk].pend_stable; ci.pad = (int32_t)(uint32_t)wall_clock64();
+            ci.pend_acc = (int32_t)((hw & 0xFFFFu) | ((xcc & 0xFu) << 16));
+        }
         if (through) {
             static_assert(sizeof(ChunkInfo) % 8 == 0, "ChunkInfo is written as 64-bit words");
             uint64_t w[sizeof(ChunkInfo) / 8];
@@ -1385,19 +1385,6 @@ __global__ void k_test_atan2f(const float *y, const float *x, int64_t n, float *
 // test hook (urhgpu_test_force_state_bytes): route order-2 work through the state-byte kernel as well
 bool g_force_state_bytes = false;
 thread_local HotEvents g_hot_events;
-thread_local long long g_hot_counted = 0;
-
-__global__ void k_hot_gate(const unsigned long long *ctr, unsigned long long target) {
-    if (threadIdx.x != 0) return;
-    const long long t0 = (long long)wall_clock64();
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(8);
-        if ((long long)wall_clock64() - t0 > 100000000ll) break;          // (1 s: the kernel it waits for never came -- go ahead, it is only a hint)
-    }
-}
-void launch_hot_gate(const unsigned long long *ctr, unsigned long long target, hipStream_t s) {
-    hipLaunchKernelGGL(k_hot_gate, dim3(1), dim3(64), 0, s, ctr, target);
-}
 
 // `a` describes the whole capture (a.n samples, chunk table / slab for n_main + has_tail chunks):
 // one launch over the whole tiles, one one-workgroup launch for the partial tile at the end.
@@ -1409,19 +1396,24 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
     const int64_t n_full = (a.n / kTile) * kTile;
     const int64_t n_main = (n_full + a.chunk_len - 1) / a.chunk_len;
     int64_t c_lo = (part == 1) ? 1 : 0, c_hi = (part == 2) ? std::min<int64_t>(n_main, 1) : n_main;
+    if (a.graded_from > 0 && part == 0 && a.launch_hi == 0) c_hi = n_main + (n_main - a.graded_from) * (a.chunk_len / a.graded_len - 1);   // graded tail: more, shorter chunks at the end
     const bool ranged = a.launch_hi > 0;                      // an explicit chunk range (streamed passes that upload piece by piece)
     if (ranged) { c_lo = std::min<int64_t>(a.launch_lo, n_main); c_hi = std::min<int64_t>(a.launch_hi, n_main); }
-    g_hot_counted = 0;
     if (c_hi > c_lo) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
         // orders 2 and 4: the bit-plane kernel; anything else: the state-byte kernel
         const bool planes_ok = URH_BITPLANE && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes;
-        if (planes_ok && (O2 || a.order == 4) && a.done_ctr) g_hot_counted = c_hi - c_lo;
-        if (planes_ok && O2 && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
-            hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
-                                  (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, g_hot_events.flags, a);
+        if (planes_ok && O2 && a.stamp_probe && SRC == SRC_IQ && DT == URHGPU_DT_F32 && MOD == URHGPU_MOD_FSK && WQ && (g_hot_events.start || g_hot_events.stop)) {
+            hipExtLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, URHGPU_DT_F32, URHGPU_MOD_FSK, true, true, 1, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
+                                  (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
             g_hot_events.used = true;
-        } else if (planes_ok && O2)
+        } else if (planes_ok && O2 && !a.stamp_probe && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
+            hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
+                                  (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
+            g_hot_events.used = true;
+        } else if (planes_ok && O2 && a.stamp_probe && SRC == SRC_IQ && DT == URHGPU_DT_F32 && MOD == URHGPU_MOD_FSK && WQ)
+            hipLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, URHGPU_DT_F32, URHGPU_MOD_FSK, true, true, 1, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
+        else if (planes_ok && O2)
             hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
         else if (planes_ok && a.order == 4)
             hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 2>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);

@@ -45,17 +45,19 @@ struct RunArgs {
     // chunks [launch_lo, launch_hi) only (launch_hi == 0: governed by launch_part); the partial tile at the end of the capture counts as
     // chunk n_main
     int64_t launch_lo, launch_hi;
-    unsigned long long *done_ctr;   // nullptr, or a device counter every workgroup of the bit-plane kernel adds 1 to when its streaming phase is over (hot_overlap)
+    // Graded tail (bit-plane kernel): chunks [0, graded_from) are chunk_len samples long, the chunks from graded_from on graded_len
+    // (a multiple of W rows): the launch's last residency wave then consists of short-lived workgroups, so that the machine drains in a
+    // quarter of the time.  graded_from == 0: uniform chunks.
+    int64_t graded_from, graded_len;
+    int stamp_probe;         // tools/boundary_probe.py: the STAMPS instantiation of the bit-plane kernel (complex64 2-FSK only); 0 in the product
     float thr[kMaxOrder - 1];
 };
 extern bool g_force_state_bytes;
 // urhgpu_ctx_profile_*: start / stop events attached to the next bit-plane hot-kernel dispatch itself (hipExtLaunchKernelGGL:
 // the kernel's own begin / end timestamps, what rocprofv3 reports); `used` says the launcher took them
-struct HotEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false; unsigned flags = 0; };   // flags: hipExtLaunchKernelGGL's (hipExtAnyOrderLaunch)
+struct HotEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false; };
 extern thread_local HotEvents g_hot_events;   // test hook: order 2 through the state-byte kernel too
 int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s);
-extern thread_local long long g_hot_counted;   // workgroups of the last launch_demod_runs_iq that count into RunArgs::done_ctr (0: none do)
-void launch_hot_gate(const unsigned long long *ctr, unsigned long long target, hipStream_t s);
 int launch_runs_qad(const RunArgs &a, hipStream_t s);
 bool runs_streamable(const RunArgs &a);       // RunArgs::progress is honoured for these arguments (bit-plane kernel, whole tiles)
 int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t s);
