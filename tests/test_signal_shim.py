@@ -282,3 +282,56 @@ def test_from_file_streamed_equals_from_file(oracle, tmp_path, ext, dtype, n):
     s.center = 0.05                                               # a slicing parameter: re-sliced from the cached qad, no new pass over the samples
     pp2 = oracle.grab_pulse_lens(qad, 0.05, 5, "FSK", 100, 1, 1.0)
     assert np.array_equal(s.ppseq(), pp2) and s.demod_passes == passes
+
+
+@pytest.mark.gpu
+def test_from_file_streamed_falls_back_when_the_stream_cannot_take_the_capture(oracle, tmp_path):
+    """A noise-dominated capture read with tolerance 0 and no noise gate has far more pulse-table rows than the stream's default capacity
+    (about four per symbol): the streamed route reports `truncated` and the Signal falls back to the ordinary passes with their capacity
+    retry on the capture that is by then resident -- the same qad, pulse table and bits as from_file, equal to the oracle.  Slicing
+    parameters the stream rejects (samples_per_symbol = 0) leave a Signal that raises where the reference raises, in bits()."""
+    from urh_amd.signal import Signal
+    n = 1 << 22
+    iq = (0.3 * np.random.default_rng(8).standard_normal((n, 2))).astype(np.float32)
+    f = str(tmp_path / "noise.complex")
+    iq.tofile(f)
+    par = dict(modulation_type="FSK", samples_per_symbol=100, center=0.0, tolerance=0, noise_threshold=0.0, pause_threshold=8)
+    s = Signal.from_file_streamed(f, **par)
+    assert np.array_equal(s.iq.cpu().numpy(), iq)
+    qad = oracle.afp_demod(iq, 0.0, "FSK", 2)
+    pp = oracle.grab_pulse_lens(qad, 0.0, 0, "FSK", 100, 1, 1.0)
+    assert len(pp) > 4 * (n // 100) + 4096                          # (beyond the stream's default capacity: the fallback was needed)
+    assert np.array_equal(s.qad.cpu().numpy().view(np.uint32), qad.view(np.uint32))
+    assert np.array_equal(s.ppseq(), pp)
+    flat = oracle.ppseq_to_bits_flat(pp, 100, 1, True, 8)
+    for a, b in zip(s._digitize()[1:], flat):
+        assert np.array_equal(np.asarray(a), b)
+    s2 = Signal.from_file_streamed(f, **dict(par, samples_per_symbol=0, tolerance=5))
+    assert np.array_equal(s2.iq.cpu().numpy(), iq)
+    assert np.array_equal(s2.qad.cpu().numpy().view(np.uint32), qad.view(np.uint32))
+    with pytest.raises(ZeroDivisionError):
+        s2.bits()
+
+
+@pytest.mark.gpu
+def test_two_live_results_do_not_share_a_stale_host_cache(oracle):
+    """BitsResult.host() views a pinned buffer of the pipeline that every result's host() overwrites: r0.ppseq(); r1.ppseq(); r0.flat() must
+    give r0's bits, not r1's blob read with r0's offsets."""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    pipe = DevicePipeline(0)
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, True)
+    caps = [synth_fsk(1 << 20, sps=100, seed=60 + i, noise=0.04, pause_every=(1 << 20) // (3 + 2 * i), pause_len=3000 + 500 * i) for i in range(2)]
+    want = []
+    for iq in caps:
+        qad = oracle.afp_demod(iq, 0.1, "FSK", 2)
+        pp = oracle.grab_pulse_lens(qad, 0.0, 5, "FSK", 100, 1, 1.0)
+        want.append((pp, oracle.ppseq_to_bits_flat(pp, 100, 1, True, 8)))
+    r = [pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=False, slot=i) for i, iq in enumerate(caps)]
+    assert np.array_equal(r[0].ppseq(), want[0][0])
+    assert np.array_equal(r[1].ppseq(), want[1][0])
+    for a, b in zip(r[0].flat(), want[0][1]):
+        assert np.array_equal(a, b)
+    for a, b in zip(r[1].flat(), want[1][1]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(r[0].ppseq(), want[0][0])

@@ -40,6 +40,9 @@ VARIANTS = {                      # name: (stream_kind, event_mode, graded, what
     "H": (1, 1, 1568, "masked, completion event, graded tail: last 1568 chunks (1.0)"),
     "I": (1, 1, 2352, "masked, completion event, graded tail: last 2352 chunks (1.5)"),
     "J": (0, 1, 784, "256 CUs, completion event, graded tail: last 784 chunks"),
+    "K": (1, 1, 0, "masked, completion event, a 20 us bubble between two hot kernels", 20),
+    "L": (1, 1, 0, "masked, completion event, a 60 us bubble between two hot kernels", 60),
+    "M": (0, 1, 0, "256 CUs, completion event, a 60 us bubble between two hot kernels", 60),
 }
 
 
@@ -51,6 +54,59 @@ def d32(a, b):
 def pct(x, qs=(50, 90, 99, 100)):
     x = np.asarray(x, np.float64)
     return " ".join(f"p{q}={np.percentile(x, q):.2f}" for q in qs)
+
+
+def analyse(tab, graded=0, dur=None, gap=None):
+    """tab: (launches, chunks) structured array of consecutive launches, oldest first"""
+    keep, nc = tab.shape
+    ent, end, mid = tab["t_entry"], tab["t_end"], tab["t_streamed"]
+    # reference points per launch (stamps wrap at 43 s: differences only)
+    first = np.array([ent[j][np.argmin(d32(ent[j], ent[j][0]))] for j in range(keep)], np.int64)
+    last = np.array([end[j][np.argmax(d32(end[j], ent[j][0]))] for j in range(keep)], np.int64)
+    wdur = d32(last, first)
+    print(f"   first wavefront's entry -> last wavefront's end {wdur.mean():8.2f} us  ({pct(wdur, (0, 50, 100))})")
+    if keep > 1:
+        period = d32(first[1:], first[:-1])
+        wgap = d32(first[1:], last[:-1])
+        print(f"   period           {period.mean():8.2f} us  ({pct(period, (0, 50, 100))})")
+        print(f"   last end -> next launch's first entry          {wgap.mean():8.2f} us  ({pct(wgap, (0, 50, 100))})")
+    if dur is not None:
+        print(f"   dispatch-level (HIP events on the dispatch): duration {dur.mean():8.2f} us, gap {gap.mean():6.2f} us  -> dispatch begin..first entry + last end..dispatch end = "
+              f"{dur.mean() - wdur.mean():.2f} us; of the gap {gap.mean():.2f} + that = {gap.mean() + dur.mean() - wdur.mean():.2f} us lie between the waves")
+    j = max(keep - 2, 0)
+    e0 = d32(ent[j], first[j]); e1 = d32(end[j], first[j]); m1 = d32(mid[j], first[j])
+    life = e1 - e0
+    print(f"   workgroup life   {pct(life, (1, 50, 90, 99, 100))} us; streaming part {pct(m1 - e0, (50, 99))}; run phase + ChunkInfo {pct(e1 - m1, (50, 99))}")
+    q = nc // 4
+    print("   workgroup life by quarter of the launch (p50): " + " ".join(f"{np.percentile(life[k * q:(k + 1) * q], 50):.2f}" for k in range(4)))
+    if graded:
+        g0 = nc - 4 * graded
+        print(f"     long chunks: {pct(life[:g0], (50, 99))}; short chunks: {pct(life[g0:], (50, 99))}")
+    T1 = e1.max()
+    ts = np.arange(0, 32.1, 2.0)
+    ramp = [(int(((e0 <= t) & (e1 > t)).sum())) for t in ts]
+    drain = [(int(((e0 <= T1 - t) & (e1 > T1 - t)).sum())) for t in ts]
+    print("   workgroups alive at t = 0, 2, .. 32 us after the first entry: " + " ".join(map(str, ramp)))
+    print("   workgroups alive at t = 0, 2, .. 32 us before the last end:   " + " ".join(map(str, drain)))
+    if keep > 1 and j + 1 < keep:
+        nxt0 = d32(ent[j + 1], first[j + 1])
+        print(f"   entries of the NEXT launch's first residency wave: {pct(nxt0[:1500], (1, 50, 99))} us after its first entry")
+    # in-order-ness and what a chained look-back would wait for
+    order = np.argsort(e0, kind="stable")
+    disp = np.abs(order - np.arange(nc))
+    pm = np.maximum.accumulate(e1)
+    wait = np.maximum(0.0, pm[:-1] - e1[1:])
+    print(f"   start order vs chunk id: {float((np.diff(e0) < 0).mean()) * 100:.1f} % of chunks enter before their predecessor, displacement {pct(disp, (50, 99, 100))} chunks")
+    print(f"   when chunk c ends, the LAST of its predecessors ends {pct(wait, (50, 90, 99, 100))} us later (mean {wait.mean():.2f}); "
+          f"{float((wait > 0).mean()) * 100:.1f} % of chunks would wait at all")
+    for grp in (16, 64, 256):
+        ng = nc // grp
+        gend = e1[: ng * grp].reshape(ng, grp).max(axis=1)      # when a group's last arriver arrives
+        gw = np.maximum(0.0, np.maximum.accumulate(gend)[:-1] - gend[1:])
+        print(f"   groups of {grp} chunks, the last arriver looks back over groups: it waits {pct(gw, (50, 90, 99, 100))} us (mean {gw.mean():.2f}); "
+              f"the group is complete {np.mean(gend - e1[: ng * grp].reshape(ng, grp).mean(axis=1)):.2f} us after its average member")
+    xcc = (tab["hw"][j] >> 16) & 0xF
+    print("   workgroups per XCC id: " + " ".join(f"{k}:{int((xcc == k).sum())}" for k in range(8)) + f"; chunk id mod 8 == XCC id for {float((xcc == (np.arange(nc) % 8)).mean()) * 100:.1f} %")
 
 
 def main():
@@ -77,66 +133,24 @@ def main():
     out = torch.zeros(args.keep * cap_chunks * 72, dtype=torch.uint8, device=dev)
     print(f"# {torch.cuda.get_device_name(0)}; capture {n} samples; {args.launches} launches per variant, the last {args.keep} analysed")
     for name in args.variants.split(","):
-        kind, mode, graded, what = VARIANTS[name]
+        kind, mode, graded, what = VARIANTS[name][:4]
+        bubble = VARIANTS[name][4] if len(VARIANTS[name]) > 4 else 0
         nch = C.c_int64(0)
         dur = (C.c_float * args.launches)()
         gap = (C.c_float * args.launches)()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         st = lib.urhgpu_test_hot_probe(pipe.ctx.handle, C.c_void_p(iq.data_ptr()), n, C.byref(cp), C.c_void_p(qad.data_ptr()), kind, mode, graded,
-                                       args.launches, args.keep, C.c_void_p(out.data_ptr()), C.byref(nch), dur, gap)
+                                       args.launches, args.keep, C.c_void_p(out.data_ptr()), C.byref(nch), dur, gap, bubble)
         wall = time.perf_counter() - t0
         if st != 0:
             print(f"== {name}: {what}: status {st} ({lib.urhgpu_strerror(st).decode()}) {lib.urhgpu_last_hip_error().decode()}")
             continue
         nc = nch.value
         tab = out[: args.keep * nc * 72].cpu().numpy().view(CHUNK).reshape(args.keep, nc)
-        ent, end, mid = tab["t_entry"], tab["t_end"], tab["t_streamed"]
-        # reference points per launch (stamps wrap at 43 s: differences only)
-        first = np.array([ent[j][np.argmin(d32(ent[j], ent[j][0]))] for j in range(args.keep)], np.int64)
-        last = np.array([end[j][np.argmax(d32(end[j], ent[j][0]))] for j in range(args.keep)], np.int64)
-        period = d32(first[1:], first[:-1])
-        wdur = d32(last, first)
-        wgap = d32(first[1:], last[:-1])
         print(f"\n== {name}: {what}   [{nc} workgroups, wall {wall / args.launches * 1e3:.4f} ms per launch incl. set-up]")
-        print(f"   period           {period.mean():8.2f} us  ({pct(period, (0, 50, 100))})")
-        print(f"   first wavefront's entry -> last wavefront's end {wdur.mean():8.2f} us  ({pct(wdur, (0, 50, 100))})")
-        print(f"   last end -> next launch's first entry          {wgap.mean():8.2f} us  ({pct(wgap, (0, 50, 100))})")
-        if mode == 3:
-            dd = np.array(dur[args.launches - args.keep:]) * 1e3
-            gg = np.array(gap[args.launches - args.keep: args.launches - 1]) * 1e3
-            print(f"   dispatch-level (HIP events on the dispatch): duration {dd.mean():8.2f} us, gap {gg.mean():6.2f} us  -> dispatch begin..first entry + last end..dispatch end = "
-                  f"{dd.mean() - wdur.mean():.2f} us; of the gap {gg.mean():.2f} + that = {gg.mean() + dd.mean() - wdur.mean():.2f} us lie between the waves ({wgap.mean():.2f} measured)")
-        j = args.keep - 2
-        e0 = d32(ent[j], first[j]); e1 = d32(end[j], first[j]); m1 = d32(mid[j], first[j])
-        life = e1 - e0
-        print(f"   workgroup life   {pct(life, (1, 50, 90, 99, 100))} us; streaming part {pct(m1 - e0, (50, 99))}; run phase + ChunkInfo {pct(e1 - m1, (50, 99))}")
-        if graded:
-            g0 = nc - 4 * graded
-            print(f"     long chunks: {pct(life[:g0], (50, 99))}; short chunks: {pct(life[g0:], (50, 99))}")
-        T1 = e1.max()
-        ts = np.arange(0, 32.1, 2.0)
-        ramp = [(int(((e0 <= t) & (e1 > t)).sum())) for t in ts]
-        drain = [(int(((e0 <= T1 - t) & (e1 > T1 - t)).sum())) for t in ts]
-        print("   workgroups alive at t = 0, 2, .. 32 us after the first entry: " + " ".join(map(str, ramp)))
-        print("   workgroups alive at t = 0, 2, .. 32 us before the last end:   " + " ".join(map(str, drain)))
-        nxt0 = d32(ent[j + 1], first[j + 1])
-        print(f"   entries of the NEXT launch's first residency wave: {pct(nxt0[:1500], (1, 50, 99))} us after its first entry")
-        # in-order-ness and what a chained look-back would wait for
-        order = np.argsort(e0, kind="stable")
-        disp = np.abs(order - np.arange(nc))
-        pm = np.maximum.accumulate(e1)
-        wait = np.maximum(0.0, pm[:-1] - e1[1:])
-        print(f"   start order vs chunk id: {float((np.diff(e0) < 0).mean()) * 100:.1f} % of chunks enter before their predecessor, displacement {pct(disp, (50, 99, 100))} chunks")
-        print(f"   when chunk c ends, the LAST of its predecessors ends {pct(wait, (50, 90, 99, 100))} us later (mean {wait.mean():.2f}); "
-              f"{float((wait > 0).mean()) * 100:.1f} % of chunks would wait at all")
-        srt = np.sort(e1)
-        unfinished = np.array([c - np.searchsorted(np.sort(e1[:c]), e1[c]) for c in range(1, nc, 37)])
-        print(f"   predecessors still running when a chunk ends (look-back window): {pct(unfinished, (50, 90, 99, 100))}")
-        xcc = (tab["hw"][j] >> 16) & 0xF
-        cu = (tab["hw"][j] >> 8) & 0xF
-        print("   workgroups per XCC id: " + " ".join(f"{k}:{int((xcc == k).sum())}" for k in range(8)) + f"; chunk id mod 8 == XCC id for {float((xcc == (np.arange(nc) % 8)).mean()) * 100:.1f} %")
-        del srt, cu
+        analyse(tab, graded=graded, dur=np.array(dur[args.launches - args.keep:]) * 1e3 if mode == 3 else None,
+                gap=np.array(gap[args.launches - args.keep: args.launches - 1]) * 1e3 if mode == 3 else None)
 
 
 if __name__ == "__main__":

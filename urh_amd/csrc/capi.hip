@@ -492,6 +492,18 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
             for (int j = 0; j < kMaxSegments; ++j) URH_HIP(hipEventCreateWithFlags(&ctx->ev_rows[k][j], hipEventDisableTiming));
         }
     }
+    // where the rows go on the host: the capacity layout of the compact blob (k_pack_seg) -- checked BEFORE anything of the pass is
+    // queued or the arenas rotate (an error return below this point would leave a pass half-begun)
+    const BitsParams bp = bits_params(p);
+    const int has_pos = (bp.write_pos && out->pos) ? 1 : 0;
+    int8_t *h_state = nullptr; int32_t *h_len = nullptr;
+    BlobLayout host_layout;
+    memset(&host_layout, 0, sizeof(host_layout));
+    if (host_blob) {
+        const int64_t caps[5] = {out->cap_rows, out->cap_msg, out->cap_bits, out->cap_pos, out->cap_rows};
+        host_layout = blob_layout(caps, out->cap_rows, out->cap_bits, out->cap_msg, out->cap_pos, has_pos);
+        if (cap_host < host_layout.total) return URHGPU_ERR_CAPACITY;
+    }
     URH_TRY(begin_pipelined_pass(ctx));
     const int slot = ctx->flip;
     uint32_t *progress = (uint32_t *)((char *)ctx->d_seg + (size_t)slot * kSegBlockBytes);
@@ -598,16 +610,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     e.chunks = chunks; e.chunk_first = 0; e.slab = slab; e.slab_stride = pl.slab_stride;
     e.rows = out->rows; e.cap_rows = out->cap_rows; e.d_ts_carry = nullptr; e.is_ask = 0; e.sps = p->samples_per_symbol;
     BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts, out->h_counts};
-    BitsParams bp = bits_params(p);
-    // where the rows go on the host: the capacity layout of the compact blob (k_pack_seg)
-    const int has_pos = (bp.write_pos && out->pos) ? 1 : 0;
-    int8_t *h_state = nullptr; int32_t *h_len = nullptr;
-    if (host_blob) {
-        const int64_t caps[5] = {out->cap_rows, out->cap_msg, out->cap_bits, out->cap_pos, out->cap_rows};
-        const BlobLayout L = blob_layout(caps, out->cap_rows, out->cap_bits, out->cap_msg, out->cap_pos, has_pos);
-        if (cap_host < L.total) return URHGPU_ERR_CAPACITY;
-        h_state = (int8_t *)((char *)host_blob + L.off_row_state); h_len = (int32_t *)((char *)host_blob + L.off_row_len);
-    }
+    if (host_blob) { h_state = (int8_t *)((char *)host_blob + host_layout.off_row_state); h_len = (int32_t *)((char *)host_blob + host_layout.off_row_len); }
     SegPackDst dst{host_blob, cap_host, progress, 0, (direct && ctx->tune_stream_pos_direct) ? 1 : 0};
     // bits segments: the last one is the last rows segment alone (what is exposed behind the hot kernel), the others share the rest
     int Sb = h_iq ? S : 1;       // (an upload: every piece's bits behind its rows -- the pieces are milliseconds apart)
@@ -1870,8 +1873,33 @@ int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_o
 
 // Probe (tools/boundary_probe.py; profiles/r05_boundary_anatomy.txt): `launches` back-to-back launches of the hot kernel ALONE (complex64
 // 2-FSK, qad written, no tail) on one stream, every wavefront 0 leaving its s_memrealtime stamps in its ChunkInfo.
+__global__ void k_probe_spin(long long ticks) {              // one wavefront that does nothing for `ticks` x 10 ns (a bubble between two hot kernels)
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+int urhgpu_test_hot_stamps(int on) {
+    urh::g_stamp_probe = (on != 0);
+    return URHGPU_OK;
+}
+
+// the chunk tables of the three most recent pipelined passes (current, previous, the one before), n_chunks entries each -- the table is
+// the first thing a pass takes from its scratch arena
+int urhgpu_test_fetch_chunk_tables(urhgpu_ctx *ctx, void *host_dst, int64_t n_chunks) {
+    if (!ctx || !host_dst || n_chunks < 1) return URHGPU_ERR_ARG;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(urhgpu_ctx_sync(ctx));
+    const size_t bytes = (size_t)n_chunks * sizeof(ChunkInfo);
+    const urh::Arena *order[3] = {&ctx->arena, &ctx->arena_alt2, &ctx->arena_alt};
+    for (int k = 0; k < 3; ++k) {
+        if (!order[k]->base || order[k]->cap < bytes) { memset((char *)host_dst + k * bytes, 0, bytes); continue; }
+        URH_HIP(hipMemcpy((char *)host_dst + k * bytes, order[k]->base, bytes, hipMemcpyDeviceToHost));
+    }
+    return URHGPU_OK;
+}
+
 int urhgpu_test_hot_probe(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, int stream_kind, int event_mode,
-                          int graded, int launches, int keep, void *d_chunks_out, int64_t *n_chunks_out, float *dur_ms, float *gap_ms) {
+                          int graded, int launches, int keep, void *d_chunks_out, int64_t *n_chunks_out, float *dur_ms, float *gap_ms, int bubble_us) {
     if (!ctx || !d_iq || !p || !d_qad || !d_chunks_out || !n_chunks_out || launches < 1 || keep < 1 || keep > launches || n < kTile || n % kTile) return URHGPU_ERR_ARG;
     if (p->dtype != URHGPU_DT_F32 || p->mod != URHGPU_MOD_FSK || p->bits_per_symbol != 1) return URHGPU_ERR_UNSUPPORTED;
     URH_HIP(hipSetDevice(ctx->device));
@@ -1911,6 +1939,7 @@ int urhgpu_test_hot_probe(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
         const int st = launch_demod_runs_iq(a, p->dtype, p->mod, true, s);
         g_hot_events = HotEvents();
         if (st != URHGPU_OK) return st;
+        if (bubble_us > 0) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, s, (long long)bubble_us * 100);
     }
     URH_HIP(hipStreamSynchronize(s));
     if (event_mode == 3 && dur_ms && gap_ms) {

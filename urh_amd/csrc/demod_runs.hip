@@ -1384,6 +1384,7 @@ __global__ void k_test_atan2f(const float *y, const float *x, int64_t n, float *
 // ---- host-side launchers ---------------------------------------------------------------------------
 // test hook (urhgpu_test_force_state_bytes): route order-2 work through the state-byte kernel as well
 bool g_force_state_bytes = false;
+bool g_stamp_probe = false;          // test hook (urhgpu_test_hot_stamps): complex64 2-FSK passes run the STAMPS instantiation of the bit-plane kernel
 thread_local HotEvents g_hot_events;
 
 // `a` describes the whole capture (a.n samples, chunk table / slab for n_main + has_tail chunks):
@@ -1393,6 +1394,7 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
     // a.launch_part: 0 = every chunk; 1 = every chunk but the first (it alone needs the left halo of a sharded capture,
     // which may still be in flight); 2 = the first chunk only
     const int part = a.launch_part;
+    if (g_stamp_probe) a.stamp_probe = 1;
     const int64_t n_full = (a.n / kTile) * kTile;
     const int64_t n_main = (n_full + a.chunk_len - 1) / a.chunk_len;
     int64_t c_lo = (part == 1) ? 1 : 0, c_hi = (part == 2) ? std::min<int64_t>(n_main, 1) : n_main;

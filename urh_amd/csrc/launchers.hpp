@@ -53,6 +53,7 @@ struct RunArgs {
     float thr[kMaxOrder - 1];
 };
 extern bool g_force_state_bytes;
+extern bool g_stamp_probe;
 // urhgpu_ctx_profile_*: start / stop events attached to the next bit-plane hot-kernel dispatch itself (hipExtLaunchKernelGGL:
 // the kernel's own begin / end timestamps, what rocprofv3 reports); `used` says the launcher took them
 struct HotEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false; };

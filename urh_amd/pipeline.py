@@ -64,6 +64,7 @@ class DemodParams:
 
 
 _TORCH_DT = None
+_PINNED_START = 1 << 20            # first size of a pinned result buffer (grown to the blob's real size on demand)
 
 
 def _torch_dtype(t):
@@ -93,31 +94,42 @@ class BitsResult:
         """The results ON THE HOST through the compact blob (include/urhgpu.h): one more kernel packs them (5 B per pulse-table row, one bit
         per bit, 4 B per position), ONE copy into pinned memory moves them -- instead of five synchronous pageable copies of the wide int64
         tables (28 ms for a million rows; this: well under a millisecond).  pool: a dict owned by the caller that keeps the pinned buffer
-        (the HostBits views it: valid until the next host() with the same pool); default: a buffer of the pipeline, valid until its next
-        host() call."""
-        if self._hostbits is not None and pool is None:
-            return self._hostbits
+        (the HostBits views it: valid until the next host() with the same pool); default: a buffer of the pipeline, valid until ANY
+        result's next host() call -- the buffer is stamped with its current owner, and a result whose views were overwritten by another
+        result's host() packs again instead of handing out a stale cache (ppseq() / flat() / messages() return copies).
+        The pinned buffer follows the blob's REAL size (header first), not its capacity -- a pulse table's capacity is the worst case
+        n / (tolerance + 1) rows, hundreds of MB for a 1 GiB capture whose blob is a few MB."""
         if self._pipe is None or self._outputs is None:
             raise ValueError("this result was not made by a DevicePipeline pass")
         pipe, o = self._pipe, self._outputs
+        keep = pipe._pinned if pool is None else pool
+        if self._hostbits is not None and pool is None and keep.get("owner") is self._hostbits:
+            return self._hostbits
         torch = pipe.torch
         has_pos = self.pos_buf is not None
         cap = int(_lib.load().urhgpu_blob_capacity(int(o.cap_rows), int(o.cap_bits), int(o.cap_msg), int(o.cap_pos), 1 if has_pos else 0))
         dblob = pipe._buf("blob", (cap,), torch.uint8)
-        keep = pipe._pinned if pool is None else pool
-        hbuf = keep.get("blob")
-        if hbuf is None or hbuf.numel() < cap:
-            hbuf = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            keep["blob"] = hbuf
         o2 = _lib.Outputs()
         C.memmove(C.byref(o2), C.byref(o), C.sizeof(_lib.Outputs))
         o2.blob = dblob.data_ptr(); o2.cap_blob = cap
         total = C.c_int64(0)
         pipe.ctx.set_stream(torch.cuda.current_stream(pipe.device).cuda_stream)
-        _lib.check(_lib.load().urhgpu_outputs_to_host(pipe.ctx.handle, C.byref(o2), 1 if has_pos else 0, C.c_void_p(hbuf.data_ptr()), cap, C.byref(total)))
+        keep["owner"] = None                                  # whatever viewed the buffer is stale from here on
+        hbuf = keep.get("blob")
+        if hbuf is None:
+            hbuf = torch.empty(min(cap, _PINNED_START), dtype=torch.uint8).pin_memory()
+            keep["blob"] = hbuf
+        st = _lib.load().urhgpu_outputs_to_host(pipe.ctx.handle, C.byref(o2), 1 if has_pos else 0, C.c_void_p(hbuf.data_ptr()), int(hbuf.numel()), C.byref(total))
+        if st == _lib.ERR_CAPACITY and int(total.value) > hbuf.numel():
+            # the blob is larger than the buffer so far: grow to what it needs (+ 25 %: the next, similar pass fits at once) and fetch again
+            hbuf = torch.empty(min(cap, int(total.value) + int(total.value) // 4 + 4096), dtype=torch.uint8).pin_memory()
+            keep["blob"] = hbuf
+            st = _lib.load().urhgpu_outputs_to_host(pipe.ctx.handle, C.byref(o2), 1 if has_pos else 0, C.c_void_p(hbuf.data_ptr()), int(hbuf.numel()), C.byref(total))
+        _lib.check(st)
         h = HostBits.from_blob(hbuf.data_ptr(), self.params, n_samples=int(self.qad.shape[0]) if self.qad is not None else 0,
                                d_qad=self.qad.data_ptr() if self.qad is not None else 0)
         h._keep = hbuf
+        keep["owner"] = h
         if pool is None:
             self._hostbits = h
         return h

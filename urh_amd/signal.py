@@ -113,10 +113,15 @@ class Signal:
             raise OSError(f"short read from {filename}")
         host = host.view(n, 2)
         dev = torch.empty((n, 2), dtype=tdt, device=s.pipe.device)
-        p = s.params()
-        st = s.pipe.stream(n, p, want_qad=True, want_pos=True, dtype=dt)          # (an upload: its own piece-wise route whatever the latency setting)
+        # Whatever the streamed route cannot take -- a pulse table beyond the stream's default capacity (a noise-dominated capture, a low
+        # noise threshold: ERR_CAPACITY / `truncated`), a capture of 2^31 samples and more or slicing parameters the stream rejects (ERR_ARG /
+        # ERR_UNSUPPORTED and the reference's own ZeroDivisionError / OverflowError for them) -- falls back to the ordinary lazy passes with
+        # their capacity retry, on the capture that is by then resident: same results either way.
+        st = None
         try:
-            st.push_upload(host, dev)
+            p = s.params()
+            st = s.pipe.stream(n, p, want_qad=True, want_pos=True, dtype=dt)      # (an upload: its own piece-wise route whatever the latency setting)
+            st.push_upload(host, dev)                                             # (host / dev stay referenced by this frame until flush() returns)
             (h,) = st.flush()
             h.check()
             from .pipeline import LazyDigitized
@@ -127,8 +132,17 @@ class Signal:
             s._qad = qad
             s.demod_passes += 1
             s._bits, s._bits_key = LazyDigitized(h, want_pos=True).materialize(), s._slice_key()      # (the stream's pinned blob goes away with it)
+        except (ZeroDivisionError, OverflowError, ValueError, _lib.UrhGpuError) as exc:
+            if isinstance(exc, _lib.UrhGpuError) and exc.status not in (_lib.ERR_CAPACITY, _lib.ERR_ARG, _lib.ERR_UNSUPPORTED):
+                raise
+            s.pipe.ctx.sync()
+            if st is None or st.stats()["pushed"] == 0:
+                dev.copy_(host, non_blocking=False)                               # the stream never took the capture: one plain copy
+            s._iq = dev
+            s._drop_cache()
         finally:
-            st.close()
+            if st is not None:
+                st.close()
         return s
 
     @property
@@ -209,6 +223,16 @@ class Signal:
         self._qad = None
         self._bits = None
         self._bits_key = None
+        # the pinned host buffers of the digitisations go with the cache (a digitisation somebody still holds is widened first)
+        users = self.__dict__.get("_host_users")
+        if users is not None:
+            for k, ref in enumerate(users):
+                old = ref() if ref is not None else None
+                if old is not None:
+                    old.materialize()
+                users[k] = None
+            for pool in self.__dict__.get("_host_pools", ()):
+                pool.clear()
 
     def _slice_key(self):
         return tuple(self._par[k] for k in _SLICE_KEYS[:5])
