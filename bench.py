@@ -311,6 +311,80 @@ def parity_record(res, ref_out, tx_bits, kind, got_qad=None):
     return rec
 
 
+def variant_steps(torch, pipe, iq, p, n, args, ramp, headline_copy):
+    """What SURVEY 8(d) asks for beside the headline, in the driver's line: the fused bits-only mode against 8 B per
+    sample, and the integer sample types real captures have (signal_functions.pyx:343-354) against THEIR bytes -- complex int16 4 + 4,
+    complex int8 2 + 4 B per sample --, each K pipelined steps through the capture stream like the headline, each checked: bits-only
+    against the headline's last outputs (themselves compared with the reference in `parity`), the integer captures against the
+    reference (oracle/_ref, else the C restatement) run on the same integer bytes, qad included."""
+    import numpy as np
+    from dataclasses import replace
+    import ctypes as C
+    from urh_amd import _lib as _ulib
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import urh_oracle as oracle
+    rec = {}
+    p_np = replace(p, write_bit_sample_pos=False)
+
+    def run(st, x, k):
+        out = []
+        for _ in range(k):
+            r = st.push(x)
+            if r is not None:
+                out.append(r)
+        return out + st.flush()
+
+    def timed(st, x):
+        ramp(lambda: run(st, x, 10))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = run(st, x, args.steps)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.steps * 1e3, res[-1].check()
+
+    def frac(ms, bytes_per_sample):
+        return round(n * bytes_per_sample / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    # ---- bits-only: qad is not materialised (8 B per sample) ----
+    st = pipe.stream(n, p_np, want_qad=False, want_pos=False)
+    ms, last = timed(st, iq)
+    same = bool(np.array_equal(last.ppseq(), headline_copy["ppseq"]) and all(np.array_equal(a, b) for a, b in zip(last.flat()[:3], headline_copy["flat"][:3])))
+    rec["bits_only"] = {"ms_per_step": round(ms, 4), "bytes_per_sample": 8, "frac_of_8TBs": frac(ms, 8), "Msamples_per_s": round(n / ms / 1e3, 1),
+                        "equals_headline_outputs": same}
+    st.close()
+    # ---- integer captures: the same signal quantised (amplitude 1 -> 8192 / 64 LSB), demodulated from their own 4 / 2 bytes per sample ----
+    ref = _ref_modules()
+    for name, tdt, ndt, scale, bps in (("int16", torch.int16, np.int16, 8192.0, 8), ("int8", torch.int8, np.int8, 64.0, 6)):
+        x = (iq * scale).round().clamp(-32767 if ndt is np.int16 else -127, 32767 if ndt is np.int16 else 127).to(tdt).contiguous()
+        st = pipe.stream(n, p_np, want_qad=True, want_pos=False, dtype=ndt)
+        ms, last = timed(st, x)
+        r = {"ms_per_step": round(ms, 4), "bytes_per_sample": bps, "frac_of_8TBs": frac(ms, bps), "Msamples_per_s": round(n / ms / 1e3, 1),
+             "capture": f"the headline capture x {scale:g}, rounded to {name}"}
+        if not args.no_cpu_baseline:
+            host = x.cpu().numpy()
+            if ref is not None:
+                sf = ref[0]
+                q = np.asarray(sf.afp_demod(host, p.noise_threshold, "FSK", 2, p.costas_loop_bandwidth))
+                pp = np.asarray(sf.grab_pulse_lens(q, p.center, p.tolerance, "FSK", p.samples_per_symbol, 1, p.center_spacing))
+                r["against"] = "oracle/_ref (the reference's Cython afp_demod + grab_pulse_lens on the integer bytes)"
+            else:
+                q = oracle.afp_demod(host, p.noise_threshold, "FSK", 2)
+                pp = oracle.grab_pulse_lens(q, p.center, p.tolerance, "FSK", p.samples_per_symbol, 1, p.center_spacing)
+                r["against"] = "oracle/ C restatement"
+            flat = oracle.ppseq_to_bits_flat(pp, p.samples_per_symbol, 1, True, p.pause_threshold)
+            got_q = np.empty(n, np.float32)
+            _ulib.check(_ulib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(last.d_qad_ptr), got_q.ctypes.data_as(C.c_void_p), n * 4))
+            r["qad_mismatches"] = int((got_q.view(np.uint32) != q.view(np.uint32)).sum())
+            r["rows"] = int(len(pp))
+            r["bit_exact"] = bool(r["qad_mismatches"] == 0 and np.array_equal(last.ppseq(), pp) and
+                                  all(np.array_equal(a, b) for a, b in zip(last.flat()[:3], flat[:3])) and
+                                  np.array_equal(last.bit_sample_pos(), flat[3]) and np.array_equal(last.pos_offsets(), flat[4]))
+            del host, q, pp, flat, got_q
+        rec[name] = r
+        st.close()
+        del x
+    return rec
+
+
 def _timed(torch, fn, reps=5, ramp_ms=30.0):
     """(result, MEDIAN wall time in ms over `reps`) of fn() with the GPU drained before and after.  The part needs about 30 ms of
     sustained load to reach its clocks (tools/ramp_probe.py) and falls back within half a second of idling -- the
@@ -718,6 +792,7 @@ def main():
     ap.add_argument("--no-reference-loop", action="store_true", help="skip the un-pipelined reference steps after the timed region (profiling runs)")
     ap.add_argument("--no-d2h", action="store_true", help="skip the D2H-inclusive measurements (profiling runs: their passes overlap copies)")
     ap.add_argument("--no-device-loop", action="store_true", help="profiling runs: only the capture-stream loop (no run without positions, no device-only loop)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the bits-only / int16 / int8 steps (profiling runs)")
     ap.add_argument("--no-extra", action="store_true", help="skip configs[2] and configs[4] at full size (they add about a minute)")
     ap.add_argument("--no-sharded-check", action="store_true", help="N > 1: skip the self-check (stitched pieces against a single-GPU pass over the whole "
                                                                      "capture and the reference on rank 0's shard) and the FIR-halo variant")
@@ -1012,7 +1087,13 @@ def main():
                                                                  np.array_equal(r_np[-1].pos_offsets(), host_copy["flat"][4]))
             st.close()
             del r_np
+            stream_rec["value_with_positions"] = round(n / stream_rec["ms_per_step_with_device_positions"] / 1e3, 1)
         del st, results
+        if not args.no_device_loop and not args.no_variants:
+            try:
+                stream_rec["variants"] = variant_steps(torch, pipe, iq, p, n, args, ramp, host_copy)
+            except Exception as exc:                          # noqa: BLE001 (the headline stands; the line says what went wrong)
+                stream_rec["variants"] = {"error": repr(exc)[:300]}
 
     # ---- the headline of sharded runs (N > 1): the same window per rank -- every pass's compact blob (this rank's piece: pulse table,
     # bits, pauses, offsets; bit_sample_pos derived on the host when asked for) copied to pinned host memory by a third stream while
@@ -1220,6 +1301,10 @@ def main():
             else:
                 out["parity"] = parity_record(res, ref_out, tx_bits, rec["kind"])
             out["config"]["parity_bit_exact"] = out["parity"]["bit_exact"]
+            bo = (out["config"].get("variants") or {}).get("bits_only")
+            if bo is not None:                               # the bits-only steps gave the headline's outputs, which equal the reference's
+                bo["bit_exact"] = bool(bo.get("equals_headline_outputs") and out["parity"]["rows_equal"] and out["parity"]["bits_equal"]
+                                       and out["parity"]["msg_off_equal"] and out["parity"]["pauses_equal"])
             del host, ref_out
         if not args.no_extra and world == 1 and not force_sharded:
             del iq

@@ -617,12 +617,19 @@ int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_o
  * streaming phase over, ChunkInfo written) and its hardware ids in the ChunkInfo's first_acc / pend_stable / pad / pend_acc fields; the
  * tables of the last `keep` launches are copied to d_chunks_out (keep * *n_chunks_out * URHGPU_SHARD_SUMMARY_BYTES bytes).  Synchronous. */
 int urhgpu_test_hot_probe(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, int stream_kind, int event_mode,
-                          int graded, int launches, int keep, void *d_chunks_out, int64_t *n_chunks_out, float *dur_ms, float *gap_ms, int bubble_us);
-/* ... bubble_us > 0: a one-wavefront kernel that idles for that long between two hot kernels.  The same stamps inside the PRODUCT's passes
+                          int graded, int launches, int keep, void *d_chunks_out, int64_t *n_chunks_out, float *dur_ms, float *gap_ms, int bubble_us,
+                          int load_kind);
+/* ... bubble_us > 0: a one-wavefront kernel that idles for that long between two hot kernels; load_kind != 0 (event_mode 1 or 2): synthetic
+ * company on a second stream beside every hot kernel (capi.hip: arithmetic / random loads on the CUs the hot mask leaves out, thousands of
+ * short high-priority workgroups, six empty kernels).  The same stamps inside the PRODUCT's passes
  * (tools/inrun_anatomy.py): urhgpu_test_hot_stamps(1) makes every complex64 2-FSK pass run the stamped instantiation (process-wide; the
  * stamps sit in ChunkInfo fields the tile tail does not read), urhgpu_test_fetch_chunk_tables copies the chunk tables of the context's three
  * most recent pipelined passes (newest first, n_chunks x URHGPU_SHARD_SUMMARY_BYTES bytes each) to host_dst.  Synchronous. */
 int urhgpu_test_hot_stamps(int on);
+/* Measurement hook: leave kernels of the tile tail out (bit 0 k_resolve_one, 1 k_emit_rows_tiles, 2 k_tile_scan, 3 group scan, 4
+ * k_expand_tiles, 5 k_pack_seg) to see what each costs the hot kernel it runs beside; outputs are only meaningful while every pass
+ * processes the same capture (the buffers then hold the previous pass's identical results).  Process-wide; 0 restores the product. */
+int urhgpu_test_tail_skip(int mask);
 int urhgpu_test_fetch_chunk_tables(urhgpu_ctx *ctx, void *host_dst, int64_t n_chunks);
 /* Synchronous device -> host copy after urhgpu_ctx_sync (for callers that hold raw device pointers, e.g. urhgpu_host_result::d_qad). */
 int urhgpu_memcpy_to_host(urhgpu_ctx *ctx, const void *d_src, void *host_dst, int64_t bytes);

@@ -43,6 +43,11 @@ VARIANTS = {                      # name: (stream_kind, event_mode, graded, what
     "K": (1, 1, 0, "masked, completion event, a 20 us bubble between two hot kernels", 20),
     "L": (1, 1, 0, "masked, completion event, a 60 us bubble between two hot kernels", 60),
     "M": (0, 1, 0, "256 CUs, completion event, a 60 us bubble between two hot kernels", 60),
+    "N": (1, 1, 0, "masked + company: 256 wavefronts of arithmetic for 200 us on the 32 CUs the mask leaves out", 0, 1),
+    "O": (1, 1, 0, "masked + company: the same at s_setprio 3", 0, 2),
+    "P": (1, 1, 0, "masked + company: 4096 workgroups x 4 wavefronts x 4 us of arithmetic at s_setprio 3, anywhere", 0, 3),
+    "Q": (1, 1, 0, "masked + company: 256 wavefronts of dependent random loads for 200 us on the 32 CUs left out", 0, 4),
+    "R": (1, 1, 0, "masked + company: six empty one-wavefront kernels in a row (kernel boundaries)", 0, 5),
 }
 
 
@@ -56,7 +61,7 @@ def pct(x, qs=(50, 90, 99, 100)):
     return " ".join(f"p{q}={np.percentile(x, q):.2f}" for q in qs)
 
 
-def analyse(tab, graded=0, dur=None, gap=None):
+def analyse(tab, graded=0, dur=None, gap=None, brief=False):
     """tab: (launches, chunks) structured array of consecutive launches, oldest first"""
     keep, nc = tab.shape
     ent, end, mid = tab["t_entry"], tab["t_end"], tab["t_streamed"]
@@ -77,6 +82,8 @@ def analyse(tab, graded=0, dur=None, gap=None):
     e0 = d32(ent[j], first[j]); e1 = d32(end[j], first[j]); m1 = d32(mid[j], first[j])
     life = e1 - e0
     print(f"   workgroup life   {pct(life, (1, 50, 90, 99, 100))} us; streaming part {pct(m1 - e0, (50, 99))}; run phase + ChunkInfo {pct(e1 - m1, (50, 99))}")
+    if brief:
+        return
     q = nc // 4
     print("   workgroup life by quarter of the launch (p50): " + " ".join(f"{np.percentile(life[k * q:(k + 1) * q], 50):.2f}" for k in range(4)))
     if graded:
@@ -114,7 +121,7 @@ def main():
     ap.add_argument("--segments", type=int, default=128)
     ap.add_argument("--launches", type=int, default=150)
     ap.add_argument("--keep", type=int, default=12)
-    ap.add_argument("--variants", default=",".join(VARIANTS))
+    ap.add_argument("--variants", default="A,B,C,E,F,G,H,I,J")
     args = ap.parse_args()
     import torch
     from urh_amd import _lib
@@ -135,13 +142,14 @@ def main():
     for name in args.variants.split(","):
         kind, mode, graded, what = VARIANTS[name][:4]
         bubble = VARIANTS[name][4] if len(VARIANTS[name]) > 4 else 0
+        load = VARIANTS[name][5] if len(VARIANTS[name]) > 5 else 0
         nch = C.c_int64(0)
         dur = (C.c_float * args.launches)()
         gap = (C.c_float * args.launches)()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         st = lib.urhgpu_test_hot_probe(pipe.ctx.handle, C.c_void_p(iq.data_ptr()), n, C.byref(cp), C.c_void_p(qad.data_ptr()), kind, mode, graded,
-                                       args.launches, args.keep, C.c_void_p(out.data_ptr()), C.byref(nch), dur, gap, bubble)
+                                       args.launches, args.keep, C.c_void_p(out.data_ptr()), C.byref(nch), dur, gap, bubble, load)
         wall = time.perf_counter() - t0
         if st != 0:
             print(f"== {name}: {what}: status {st} ({lib.urhgpu_strerror(st).decode()}) {lib.urhgpu_last_hip_error().decode()}")

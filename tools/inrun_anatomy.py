@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--segments", type=int, default=128)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--no-stamps", action="store_true", help="the product kernel (no tables): wall-clock per step only")
+    ap.add_argument("--skips", default="", help="comma-separated urhgpu_test_tail_skip masks: the headline loop once per mask, brief analysis (then nothing else)")
     args = ap.parse_args()
     import torch
     from dataclasses import replace
@@ -60,6 +61,25 @@ def main():
         return (time.perf_counter() - t0) / steps * 1e3
 
     print(f"# {torch.cuda.get_device_name(0)}; {n} samples; tuning {tuning}; stamps {'off' if args.no_stamps else 'on'}")
+    if args.skips:
+        names = ["k_resolve_one", "k_emit_rows_tiles", "k_tile_scan", "group scan", "k_expand_tiles", "k_pack_seg"]
+        st = pipe.stream(n, replace(p, write_bit_sample_pos=False), want_qad=True, want_pos=False)
+
+        def pushes(k):
+            for _ in range(k):
+                st.push(iq)
+            st.flush()
+        timed(pushes, args.steps)                            # every arena and host blob holds a full pass's outputs
+        for mask in [int(x) for x in args.skips.split(",")]:
+            lib.urhgpu_test_tail_skip(mask)
+            ms = timed(pushes, args.steps)
+            left = [nm for b, nm in enumerate(names) if mask >> b & 1]
+            print(f"\n== headline loop without {', '.join(left) if left else 'nothing (the product)'} [mask {mask}]: {ms:.4f} ms per step (K = {args.steps})")
+            if not args.no_stamps:
+                analyse(tables(), brief=True)
+        lib.urhgpu_test_tail_skip(0)
+        st.close()
+        return
     for want_pos, label in ((False, "capture stream, compact outputs to the host, no positions (the headline loop)"),
                             (True, "capture stream with bit_sample_pos produced and shipped")):
         st = pipe.stream(n, replace(p, write_bit_sample_pos=want_pos), want_qad=True, want_pos=want_pos)

@@ -137,8 +137,9 @@ PROTOTYPES = {
     "urhgpu_get_plateau_lengths": (_i, [_vp, _vp, _i64, _f, _i, _vp, _i64, C.POINTER(_i64)]),
     "urhgpu_threshold_divisor_histogram": (_i, [_vp, _i64, _f, _vp, _i64, C.POINTER(_i64)]),
     "urhgpu_median_filter": (_i, [_vp, _vp, _i64, C.c_uint, _vp]),
-    "urhgpu_test_hot_probe": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(_i64), _vp, _vp, _i]),
+    "urhgpu_test_hot_probe": (_i, [_vp, _vp, _i64, C.POINTER(Params), _vp, _i, _i, _i, _i, _i, _vp, C.POINTER(_i64), _vp, _vp, _i, _i]),
     "urhgpu_test_hot_stamps": (_i, [_i]),
+    "urhgpu_test_tail_skip": (_i, [_i]),
     "urhgpu_test_fetch_chunk_tables": (_i, [_vp, _vp, _i64]),
     "urhgpu_test_fast_division_dev": (_i, [_vp, C.c_uint64, _i, C.POINTER(C.c_uint64)]),
     "urhgpu_test_sincosf_fast_dev": (_i, [_vp, C.POINTER(C.c_uint64)]),

@@ -386,6 +386,15 @@ int end_pipelined_pass(urhgpu_ctx *ctx) {
     return URHGPU_OK;
 }
 
+// CU mask of the hot stream on a 256-CU part: `removed` CUs of every XCD left out (see urhgpu_ctx_set_pipelined)
+void hot_cu_mask(int removed, uint32_t mask[8]) {
+    for (int w = 0; w < 8; ++w) mask[w] = 0;
+    for (int i = 0; i < 256; ++i) {
+        const int c = ((i % 8) - (i / 32) + 8) % 8, k = (i / 8) % 4;
+        if (c * 4 + k >= removed) mask[i / 32] |= 1u << (i % 32);
+    }
+}
+
 ShardSession *session(urhgpu_ctx *ctx) {
     if (!ctx->shard) ctx->shard = new (std::nothrow) ShardSession();
     return (ShardSession *)ctx->shard;
@@ -808,12 +817,9 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
     // bits of the removed CUs are chosen so that every XCD loses the same number whichever way bits map to XCDs (bit i -> XCD i / 32 or
     // i % 8): class (i % 8 - i / 32) mod 8 and slot (i / 8) % 4 enumerate 32 sets of 8 CUs, one per XCD each.
     if (ctx->tune_hot_cus_removed > 0 && ctx->prop.multiProcessorCount == 256) {
-        const int ncu = 256, words = ncu / 32;
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < ncu; ++i) {
-            const int c = ((i % 8) - (i / 32) + 8) % 8, k = (i / 8) % 4;
-            if (c * 4 + k >= ctx->tune_hot_cus_removed) mask[i / 32] |= 1u << (i % 32);
-        }
+        const int words = 8;
+        uint32_t mask[8];
+        hot_cu_mask(ctx->tune_hot_cus_removed, mask);
         // (a runtime that cannot make the masked stream is no reason to fail: the hot kernel then runs on the caller's stream as before)
         if (hipExtStreamCreateWithCUMask(&ctx->hot_masked, (uint32_t)words, mask) != hipSuccess) { (void)hipGetLastError(); ctx->hot_masked = nullptr; }
         if (ctx->hot_masked && !ctx->ev_in && hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming) != hipSuccess) {
@@ -1873,6 +1879,29 @@ int urhgpu_bench_copy_ceiling_dev(urhgpu_ctx *ctx, const float *d_in, float *d_o
 
 // Probe (tools/boundary_probe.py; profiles/r05_boundary_anatomy.txt): `launches` back-to-back launches of the hot kernel ALONE (complex64
 // 2-FSK, qad written, no tail) on one stream, every wavefront 0 leaving its s_memrealtime stamps in its ChunkInfo.
+// synthetic company for the hot kernel (urhgpu_test_hot_probe: load_kind): dependent integer / float arithmetic for `ticks` x 10 ns ...
+__global__ void k_probe_valu(long long ticks, int prio, float *sink) {
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    const long long t0 = (long long)wall_clock64();
+    float x = (float)threadIdx.x, y = 1.0f;
+    unsigned long long z = threadIdx.x;
+    do {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) { x = x * 1.0001f + y; y = y * 0.9999f + x; z = z * 6364136223846793005ull + 1442695040888963407ull; }
+    } while ((long long)wall_clock64() - t0 < ticks);
+    if (x == 12345.678f && z == 42) *sink = y;
+}
+// ... or dependent random 64-byte-line loads over `lines` lines of `mem`
+__global__ void k_probe_latency(long long ticks, const unsigned long long *mem, unsigned long long lines, unsigned long long *sink) {
+    const long long t0 = (long long)wall_clock64();
+    unsigned long long at = (blockIdx.x * 256ull + threadIdx.x) * 0x9e3779b97f4a7c15ull, acc = 0;
+    do {
+#pragma unroll 1
+        for (int k = 0; k < 8; ++k) { const unsigned long long v = mem[(at % lines) * 8]; acc += v; at = at * 6364136223846793005ull + v + 1442695040888963407ull; }
+    } while ((long long)wall_clock64() - t0 < ticks);
+    if (acc == 0x1234567ull) *sink = acc;
+}
+
 __global__ void k_probe_spin(long long ticks) {              // one wavefront that does nothing for `ticks` x 10 ns (a bubble between two hot kernels)
     const long long t0 = (long long)wall_clock64();
     while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
@@ -1880,6 +1909,11 @@ __global__ void k_probe_spin(long long ticks) {              // one wavefront th
 
 int urhgpu_test_hot_stamps(int on) {
     urh::g_stamp_probe = (on != 0);
+    return URHGPU_OK;
+}
+
+int urhgpu_test_tail_skip(int mask) {
+    urh::g_tail_skip = mask;
     return URHGPU_OK;
 }
 
@@ -1899,7 +1933,8 @@ int urhgpu_test_fetch_chunk_tables(urhgpu_ctx *ctx, void *host_dst, int64_t n_ch
 }
 
 int urhgpu_test_hot_probe(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, float *d_qad, int stream_kind, int event_mode,
-                          int graded, int launches, int keep, void *d_chunks_out, int64_t *n_chunks_out, float *dur_ms, float *gap_ms, int bubble_us) {
+                          int graded, int launches, int keep, void *d_chunks_out, int64_t *n_chunks_out, float *dur_ms, float *gap_ms, int bubble_us,
+                          int load_kind) {
     if (!ctx || !d_iq || !p || !d_qad || !d_chunks_out || !n_chunks_out || launches < 1 || keep < 1 || keep > launches || n < kTile || n % kTile) return URHGPU_ERR_ARG;
     if (p->dtype != URHGPU_DT_F32 || p->mod != URHGPU_MOD_FSK || p->bits_per_symbol != 1) return URHGPU_ERR_UNSUPPORTED;
     URH_HIP(hipSetDevice(ctx->device));
@@ -1932,6 +1967,25 @@ int urhgpu_test_hot_probe(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
         const unsigned fl = event_mode == 1 ? hipEventDisableTiming : event_mode == 2 ? (hipEventDisableTiming | hipEventDisableSystemFence | hipEventReleaseToDevice) : hipEventDefault;
         for (auto &e : ev) URH_HIP(hipEventCreateWithFlags(&e, fl));
     }
+    // load_kind: synthetic company on a second stream, started behind hot kernel j's completion event (so it runs beside hot kernel j + 1, as
+    // the product's tail does).  1: 256 wavefronts of arithmetic for 200 us on the CUs the hot mask leaves out; 2: the same at s_setprio 3;
+    // 3: 4096 workgroups of 4 wavefronts, 4 us of arithmetic each at s_setprio 3, anywhere on the chip; 4: 256 wavefronts of dependent random
+    // loads for 200 us on the CUs left out; 5: six empty one-wavefront kernels in a row (kernel boundaries: cache write-back / invalidate)
+    hipStream_t s2 = nullptr;
+    void *load_mem = nullptr;
+    if (load_kind != 0) {
+        if (event_mode == 0 || event_mode == 3) return URHGPU_ERR_ARG;
+        if (load_kind == 3 || load_kind == 5) URH_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        else {
+            uint32_t m[8], inv[8];
+            hot_cu_mask(ctx->tune_hot_cus_removed, m);
+            for (int w = 0; w < 8; ++w) inv[w] = ~m[w];
+            URH_HIP(hipExtStreamCreateWithCUMask(&s2, 8, inv));
+        }
+        URH_HIP(hipMalloc(&load_mem, size_t(256) << 20));
+        URH_HIP(hipMemset(load_mem, 1, size_t(256) << 20));
+        URH_HIP(hipDeviceSynchronize());
+    }
     for (int j = 0; j < launches; ++j) {
         // the last `keep` launches write their chunk tables straight into the caller's buffer (nothing between two hot kernels)
         a.chunks = (j >= launches - keep) ? (ChunkInfo *)d_chunks_out + (size_t)(j - (launches - keep)) * n_launch : chunks;
@@ -1940,8 +1994,16 @@ int urhgpu_test_hot_probe(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
         g_hot_events = HotEvents();
         if (st != URHGPU_OK) return st;
         if (bubble_us > 0) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, s, (long long)bubble_us * 100);
+        if (load_kind != 0) {
+            URH_HIP(hipStreamWaitEvent(s2, ev[2 * j + 1], 0));
+            if (load_kind == 1 || load_kind == 2) hipLaunchKernelGGL(k_probe_valu, dim3(64), dim3(256), 0, s2, 20000ll, load_kind == 2 ? 1 : 0, (float *)load_mem);
+            else if (load_kind == 3) hipLaunchKernelGGL(k_probe_valu, dim3(4096), dim3(256), 0, s2, 400ll, 1, (float *)load_mem);
+            else if (load_kind == 4) hipLaunchKernelGGL(k_probe_latency, dim3(64), dim3(256), 0, s2, 20000ll, (const unsigned long long *)load_mem, (unsigned long long)((size_t(256) << 20) / 64), (unsigned long long *)load_mem);
+            else for (int k = 0; k < 6; ++k) hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, s2, 100ll);
+        }
     }
     URH_HIP(hipStreamSynchronize(s));
+    if (s2) { URH_HIP(hipStreamSynchronize(s2)); (void)hipStreamDestroy(s2); (void)hipFree(load_mem); }
     if (event_mode == 3 && dur_ms && gap_ms) {
         for (int j = 0; j < launches; ++j) {
             URH_HIP(hipEventElapsedTime(&dur_ms[j], ev[2 * j], ev[2 * j + 1]));

@@ -54,6 +54,7 @@ struct RunArgs {
 };
 extern bool g_force_state_bytes;
 extern bool g_stamp_probe;
+extern int g_tail_skip;            // pulse_table.hip: measurement hook (urhgpu_test_tail_skip)
 // urhgpu_ctx_profile_*: start / stop events attached to the next bit-plane hot-kernel dispatch itself (hipExtLaunchKernelGGL:
 // the kernel's own begin / end timestamps, what rocprofv3 reports); `used` says the launcher took them
 struct HotEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false; };

@@ -1569,8 +1569,9 @@ int launch_bits_finish(const int64_t *rows, const int64_t *d_n_rows, int64_t cap
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed, o.h_counts};
     // the groups (usually a handful: one workgroup) go through the single-pass look-back scan: one launch instead of two
-    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
-                       b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
+    if (!(g_tail_skip & 8))
+        hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
+                           b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandArgs ea{rows, d_n_rows, b.info, b.gout, o.bits, o.cap_bits, o.pos, o.cap_pos, bp, b.huge, b.huge_count, kHugeCap};
     const int64_t eb = std::min<int64_t>((cap_rows + 255) / 256, kExpandMaxBlocks);
     hipLaunchKernelGGL(k_expand_bits, dim3((unsigned)eb), dim3(256), 0, s, ea);
@@ -1586,6 +1587,10 @@ int launch_ppseq_to_bits(const int64_t *rows, const int64_t *d_n_rows, int64_t c
 
 
 // ---- tile tail: host side ----------------------------------------------------------------------------------------------
+// Measurement hook (urhgpu_test_tail_skip, tools/inrun_anatomy.py): bits 0 .. 5 leave out k_resolve_one, k_emit_rows_tiles, k_tile_scan, the
+// group scan, k_expand_tiles, k_pack_seg of the tile tail -- what each of them costs the hot kernel it runs beside.  Results are only
+// meaningful when every pass processes the same capture (the buffers then still hold the previous pass's identical outputs).
+int g_tail_skip = 0;
 namespace {
 constexpr int kTileHugeCap = 8192;
 struct TileCarve { TileTail ft; HugeRef *huge; };
@@ -1641,8 +1646,8 @@ int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem 
     g.w0 = 0; g.w_end = tail_waves(r.n_chunks); g.final_seg = 1; g.seg = nullptr; g.seg_k = 0; g.h_state = nullptr; g.h_len = nullptr;
     SegGate no_gate;
     memset(&no_gate, 0, sizeof(no_gate));
-    hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft, (int64_t)0, no_gate);
-    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((tail_waves(r.n_chunks) + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
+    if (!(g_tail_skip & 1)) hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft, (int64_t)0, no_gate);
+    if (!(g_tail_skip & 2)) hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((tail_waves(r.n_chunks) + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
     return URHGPU_OK;
 }
 
@@ -1671,7 +1676,7 @@ int launch_tile_bits_prepare(const TileTailMem &m, const int64_t *rows, const in
     TileScanArgs ta{rows, d_n_rows, tc.ft.agg, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, b.d_n_groups, nt, bp, tdesc,
                     m.epoch, 0, nullptr, 0};
     const unsigned nb_ts = (unsigned)((nt + kScanBlock - 1) / kScanBlock);
-    hipLaunchKernelGGL(k_tile_scan, dim3(nb_ts), dim3(kScanBlock), 0, s, ta);
+    if (!(g_tail_skip & 4)) hipLaunchKernelGGL(k_tile_scan, dim3(nb_ts), dim3(kScanBlock), 0, s, ta);
     if (d_flags) hipLaunchKernelGGL(k_tile_flags, dim3(1), dim3(1), 0, s, d_n_rows, b.groups, b.d_n_groups, d_flags);
     return URHGPU_OK;
 }
@@ -1688,12 +1693,13 @@ int launch_tile_bits_finish(const TileTailMem &m, const int64_t *rows, const int
     GroupLoad gl{b.groups, b.d_n_groups, bp.d_extra, bp.is_last_rank, bp.write_pos};
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos};
     BitsCountsFinal fin{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, bp.d_rows_needed, o.h_counts};
-    hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
-                       b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
+    if (!(g_tail_skip & 8))
+        hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
+                           b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, b.d_n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
                       bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt, 0, nullptr};
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(nt);
-    hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
+    if (!(g_tail_skip & 16)) hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     return URHGPU_OK;
 }
 
@@ -1885,8 +1891,8 @@ int launch_rows_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailM
     SegGate gate = sg.gate;
     gate.fused = (sg.fuse_gate && gate.progress && !gate.init && resolve_blocks(sg.c1 - sg.c0) == 1) ? 1 : 0;
     if (!gate.fused && gate.progress) hipLaunchKernelGGL(k_seg_gate, dim3(1), dim3(64), 0, s, gate);
-    hipLaunchKernelGGL(k_resolve_one, dim3((unsigned)resolve_blocks(sg.c1 - sg.c0)), dim3(kResolveBlock), 0, s, r, ft_resolve, sg.c0 / kResolveBlock, gate);
-    hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((g.w_end - g.w0 + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
+    if (!(g_tail_skip & 1)) hipLaunchKernelGGL(k_resolve_one, dim3((unsigned)resolve_blocks(sg.c1 - sg.c0)), dim3(kResolveBlock), 0, s, r, ft_resolve, sg.c0 / kResolveBlock, gate);
+    if (!(g_tail_skip & 2)) hipLaunchKernelGGL(k_emit_rows_tiles, dim3((unsigned)((g.w_end - g.w0 + 1 + kEmitWaves - 1) / kEmitWaves)), dim3(64 * kEmitWaves), 0, s, g);
     return URHGPU_OK;
 }
 
@@ -1910,7 +1916,7 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
     GranDesc *tdesc = (GranDesc *)m.rdesc + resolve_blocks(m.n_chunks) + 2;
     TileScanArgs ta{rows, d_n_rows, tc.ft.agg, tc.ft.tile_off, tc.ft.tile_cnt, tc.ft.excl, b.groups, cap_groups, &st->n_groups, t1, bp, tdesc,
                     m.epoch, sg.c0 / kScanBlock, st, parity};
-    hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((t1 - sg.c0 + kScanBlock - 1) / kScanBlock)), dim3(kScanBlock), 0, s, ta);
+    if (!(g_tail_skip & 4)) hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((t1 - sg.c0 + kScanBlock - 1) / kScanBlock)), dim3(kScanBlock), 0, s, ta);
     // groups [the one that was open before this segment, the one that is open now]
     ScanDesc<3> *desc3 = (ScanDesc<3> *)((char *)ss.desc + (((size_t)(scan_blocks(cap_desc) + 1) * sizeof(ScanDesc<4>) + 255) & ~size_t(255)));
     GroupLoad gl{b.groups, &st->n_groups, nullptr, sg.final ? 1 : 0, bp.write_pos, sg.final ? 0 : 1};
@@ -1927,18 +1933,19 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
     SegGroupLoad sl{gl, st, parity};
     SegGroupStore sst{gs, st, parity};
     SegFinal fin{sl, st, d_n_rows, parity, sg.final ? 1 : 0, BitsCountsFinal{d_n_rows, o.msg_off, o.pos_off, o.counts, b.huge_count, &st->rows_needed, o.h_counts}};
-    hipLaunchKernelGGL((k_scan_lookback<3, SegGroupLoad, SegGroupStore, SegFinal, kGroupItems>), dim3((unsigned)std::min<int64_t>(scan_grid(b.nbg), 32)),
-                       dim3(kScanBlock), 0, s, &st->n_groups_local, sl, desc3, b.nbg, sst, fin, ++*ss.epoch, ss.tickets + 2, 0);
+    if (!(g_tail_skip & 8))
+        hipLaunchKernelGGL((k_scan_lookback<3, SegGroupLoad, SegGroupStore, SegFinal, kGroupItems>), dim3((unsigned)std::min<int64_t>(scan_grid(b.nbg), 32)),
+                           dim3(kScanBlock), 0, s, &st->n_groups_local, sl, desc3, b.nbg, sst, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, &st->n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
                       bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, t1, sg.c0, h_pos};
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(t1 - sg.c0);
-    hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
+    if (!(g_tail_skip & 16)) hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     if (dst && dst->host) {
         if (((uintptr_t)o.bits & 7) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
         SegPack pk{o.bits, o.msg_off, o.pauses, o.pos_off, o.pos, o.counts, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos, (char *)dst->host,
                    L, st, d_n_rows, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr, pos_direct ? 1 : 0};
         if (dst->cap_host < pk.L.total) return URHGPU_ERR_CAPACITY;
-        hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 32), dim3(256), 0, s, pk);
+        if (!(g_tail_skip & 32)) hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 32), dim3(256), 0, s, pk);
     }
     return URHGPU_OK;
 }
