@@ -93,8 +93,8 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
  *   "hot_cus_removed_per_xcd"  0 .. 16, default 4; set before urhgpu_ctx_set_pipelined: the hot kernel of a pipelined pass runs on a private
  *                              stream whose CU mask leaves that many CUs of every XCD out -- on 224 of the MI355X's 256 CUs the kernel is 5 %
  *                              faster than on all of them, and the CUs left alone serve the previous pass's tail; 0: no mask
- *   "hot_fused_rows"           1, default: the row stage (chunk resolution, pulse-table rows, per-tile bit aggregates) runs INSIDE the hot
- *                              kernel for the passes that qualify (FSK of order 2 / 4 on a whole, unsharded capture of whole tiles); 0: behind it
+ *   "hot_graded"               graded tail of the hot launch: that many of its last chunks are cut into four short ones each (the launch's
+ *                              last residency wave then drains in a quarter of the time); 0: uniform chunks
  *   "profile_bracket"          1: urhgpu_ctx_profile_* report the stream-level bracket, which reads 3-5 % longer than the kernel runs
  *   "stream_policy"            which tail a pass of urhgpu_stream_* takes.  5 (default): 3 for passes that ship no positions or ship them
  *                              directly, 0 otherwise; 0: segments beside the hot kernel when nothing of an earlier pass is still running (one

@@ -186,14 +186,10 @@ int hot_stream_begin(urhgpu_ctx *ctx, hipStream_t *out) {
     return URHGPU_OK;
 }
 // scratch (from the arena) and persistent descriptors of the tile tail over a table of n_entries chunks
-int tile_tail_mem(urhgpu_ctx *ctx, int64_t n_entries, bool expands_bits, TileTailMem *tm, bool fused = false) {
+int tile_tail_mem(urhgpu_ctx *ctx, int64_t n_entries, bool expands_bits, TileTailMem *tm) {
     tm->mem = ctx->arena.take(tile_tail_bytes(n_entries));
     tm->n_chunks = n_entries; tm->huge_count = ctx->d_tickets + 8;
     tm->parity = expands_bits ? (ctx->tile_parity ^= 1) : ctx->tile_parity;   // only passes that expand bits consume a counter
-    tm->fused = fused ? 1 : 0;
-    // a fused pass appends to its huge-row list from the hot kernel, beside the tails of the two passes before it: one counter per scratch
-    // arena in rotation (d_tickets[8 .. 10]), cleared by the pass's own first chunk
-    if (fused) tm->parity = ctx->pipelined ? ctx->flip : 0;
     tm->d_row_base = nullptr;
     if (!tm->mem) return URHGPU_ERR_ARG;
     const size_t rd = tile_rdesc_bytes(n_entries);
@@ -246,17 +242,6 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
     if (!chunks || !slab) return URHGPU_ERR_ARG;
     a.chunks = chunks; a.slab = slab;
-    // The row stage inside the hot kernel (FusedRows) where the pass qualifies: no resolve / row kernels behind it.
-    const bool fuse = from_iq && ctx->tune_hot_fused && g_tile_tail && runs_fusable(a, p->mod) && d_rows != nullptr;
-    TileTailMem tm_fused;
-    if (fuse) {
-        URH_TRY(tile_tail_mem(ctx, pl.n_chunks, tile_out != nullptr, &tm_fused, true));
-        tile_fused_args(tm_fused, tile_out != nullptr && tile_bp != nullptr, &a.fused);
-        a.fused.n_total = n; a.fused.rows = d_rows; a.fused.cap_rows = cap_rows;
-        a.fused.d_n_acc = d_n_acc; a.fused.d_n_rows = d_n_rows; a.fused.d_n_rows_needed = d_n_rows_needed;
-        if (tile_bp) { a.fused.sps = tile_bp->sps; a.fused.bps = tile_bp->bps; a.fused.pause_threshold = tile_bp->pause_threshold; }
-        else { a.fused.sps = 1; a.fused.bps = 1; a.fused.pause_threshold = 0; }
-    }
     const bool prof = prof_begin_record(ctx, s);
     // pipelined: the tail stream waits for the completion signal of the hot dispatch itself where one launch covers the capture (no
     // partial tile at the end) -- an event recorded behind it is one more barrier packet between two hot kernels
@@ -281,11 +266,6 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
         s = s_tail;
     }
 
-    if (fuse) {                                     // rows, counts and tile aggregates are the hot kernel's
-        if (tile_out) *tile_out = tm_fused;
-        URH_HIP(hipGetLastError());
-        return URHGPU_OK;
-    }
     const bool ask = (p->mod == URHGPU_MOD_ASK) && !seg_mode;
     int64_t *rows_stage = d_rows;
     int64_t *d_n_stage = d_n_rows;
@@ -494,15 +474,11 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     // 5.4 MB of uint32 positions stored over PCIe by a pack kernel take longer than the copy engine needs for the whole blob (0.41 ms).
     int policy = ctx->tune_stream_policy;
     if (policy == 5) policy = (p->write_bit_sample_pos && out->pos && !ctx->tune_stream_pos_direct) ? 0 : (ctx->tune_stream_latency ? 4 : 3);
-    // The row stage inside the hot kernel (FusedRows) where the pass qualifies: the rows reach the device table and the host blob while the
-    // hot kernel runs, whatever the policy asked for -- behind it only the bits stage is left (ONE bits segment, started by an event).
-    const bool fuse = !h_iq && host_blob && ctx->tune_hot_fused && runs_fusable(a, p->mod) && policy != 2 &&
-                      !(policy == 0 && p->write_bit_sample_pos && out->pos);       // (positions through pack + copy engine: the ordinary path, fused there too)
-    bool direct = fuse;
+    bool direct = false;
     if (!h_iq && runs_streamable(a) && host_blob && policy == 3) direct = true;
     if (S < 2 && !direct) return URHGPU_OK;                    // too short to cut, or not the bit-plane kernel's work: the ordinary path
     if (policy == 2 && !h_iq) return URHGPU_OK;
-    if ((policy == 0 || policy == 4) && ctx->passes_begun > 0 && !h_iq && !fuse) {
+    if ((policy == 0 || policy == 4) && ctx->passes_begun > 0 && !h_iq) {
         // is anything of the pass before still running?  Then this pass's tail will run beside ITS successor's hot kernel as well: one piece
         const hipError_t q = hipEventQuery(ctx->ev_tail[(ctx->flip + 2) % 3]);
         if (q == hipErrorNotReady) {
@@ -560,7 +536,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     a.chunks = chunks; a.slab = slab;
     // everything that may allocate (and zero) descriptor memory BEFORE anything of the pass is queued
     TileTailMem tm;
-    URH_TRY(tile_tail_mem(ctx, pl.n_chunks, true, &tm, fuse));
+    URH_TRY(tile_tail_mem(ctx, pl.n_chunks, true, &tm));
     const int64_t cap = std::max<int64_t>(out->cap_rows, 1);
     void *scratch = ctx->arena.take(bits_scratch_bytes(cap));
     if (!scratch) return URHGPU_ERR_ARG;
@@ -613,14 +589,6 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         hot_done = ctx->ev_hot_done[slot];
     } else {
     if (direct) { a.progress = nullptr; a.n_seg = 0; }         // (plain stores in the hot kernel, no counters: the tail starts behind its end)
-    if (fuse) {
-        tile_fused_args(tm, true, &a.fused);
-        a.fused.n_total = n; a.fused.rows = out->rows; a.fused.cap_rows = out->cap_rows;
-        a.fused.h_state = (int8_t *)((char *)host_blob + host_layout.off_row_state); a.fused.h_len = (int32_t *)((char *)host_blob + host_layout.off_row_len);
-        a.fused.d_n_acc = &st->n_acc; a.fused.d_n_rows = &st->rows_at[0]; a.fused.d_n_rows_needed = &st->rows_needed;
-        a.fused.sps = bp.sps; a.fused.bps = bp.bps; a.fused.pause_threshold = bp.pause_threshold;
-        a.fused.err = &st->err; a.fused.seg_in = (int64_t *)&st->in[0]; a.fused.seg_in_words = (int32_t)(2 * sizeof(SegState::In) / 8);
-    }
     const bool prof = prof_begin_record(ctx, s);
     // the hot kernel's completion: the dispatch's own completion signal where the launcher takes events (an event recorded behind the
     // kernel is one more barrier packet between two hot kernels); nobody waits for it before the last segment has been queued
@@ -671,7 +639,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         else if (direct) URH_HIP(hipStreamWaitEvent(ts, hot_done, 0));
         RowsSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], SegGate{event_start ? nullptr : progress, k, target[k], k == 0 ? 1 : 0, st, (long long)200000000, 0},
                        h_state, h_len, 1};
-        if (!fuse) URH_TRY(launch_rows_segment(r, e, tm, bp, st, sg, ts));
+        URH_TRY(launch_rows_segment(r, e, tm, bp, st, sg, ts));
         while (jb < Sb && bits_end_at[jb] < k) ++jb;           // (a bits segment that would end before the first rows segment: none)
         if (jb < Sb && bits_end_at[jb] == k) {
             const bool last = (jb == Sb - 1);
@@ -876,7 +844,7 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
 //   stream_latency           1: a pass that finds the pipeline idle runs its tail in segments (lowest latency for ONE capture); default 0
 //   stream_pos_direct        1 (default): direct passes ship bit_sample_pos themselves
 //   upload_pieces            pieces of urhgpu_stream_push_upload; default 4
-//   hot_fused_rows           1 (default): the row stage runs inside the hot kernel where the pass qualifies (FusedRows); 0: always behind it
+//   hot_graded               the hot launch's last `value` chunks are cut into four short ones each (graded tail); default kGradedDefault
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return URHGPU_ERR_ARG;
     if (!strcmp(key, "hot_lds_kb")) { if (value < 0 || value > 150) return URHGPU_ERR_ARG; ctx->hot_lds_pad = value * 1024; }
@@ -888,7 +856,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "stream_latency")) { ctx->tune_stream_latency = value != 0; }
     else if (!strcmp(key, "stream_pos_direct")) { ctx->tune_stream_pos_direct = value != 0; }
     else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }
-    else if (!strcmp(key, "hot_fused_rows")) { ctx->tune_hot_fused = value != 0; }
+    else if (!strcmp(key, "hot_graded")) { if (value < 0 || value > (1 << 20)) return URHGPU_ERR_ARG; ctx->tune_hot_graded = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;
 }

@@ -33,7 +33,6 @@
 #include "common.hpp"
 #include "fdlibm_atan2f.h"
 #include "launchers.hpp"
-#include "rows.hpp"
 #include "runs.hpp"
 
 namespace urh {
@@ -1017,41 +1016,8 @@ __device__ __forceinline__ uint32_t put_lane(uint32_t value, int row, uint32_t o
 // order 4 (planes = the two bits of state - 1, from the three threshold masks).
 template <int SRC, int MOD> constexpr int bp_waves() { return (SRC == SRC_IQ && MOD == URHGPU_MOD_ASK) ? URH_ASK_WPB : URH_WPB; }
 
-// ---- FUSED: the row stage inside the hot kernel (launchers.hpp: FusedRows) -----------------------------------------------------------
-// One descriptor per chunk.  flag = tag << 32 | state << 30 | pend_state << 16 | (offset of the chunk's pending run + 1, 0: none):
-//   state 1  the chunk has finished its run phase: its pending run (the trailing run that is still <= tolerance long) is known
-//   state 2  + agg  = what the chunk does to the state machine (its own stable runs, preceded by the pending run of the chunk before it
-//                     should that one grow past the tolerance here: a chunk OWNS its predecessor's pending run, so nobody looks ahead)
-//   state 3  + incl = the composition of all chunks up to and including this one
-// Payloads are written through to memory and acknowledged (s_waitcnt) before the flag that announces them: a reader that sees the flag
-// finds the payload (sc1 loads).  Memory is zero or holds older tags before a pass.
-struct FusedDesc {
-    unsigned long long flag;
-    unsigned long long pad0;
-    ResElem agg;
-    ResElem incl;
-    unsigned long long pad1[6];
-};
-static_assert(sizeof(FusedDesc) == 128 && sizeof(ResElem) == 32, "FusedDesc");
-constexpr int kFusedSpinLimit = 1 << 22;
-
-__device__ __forceinline__ void fused_store_res(ResElem *dst, const ResElem &x) {
-    unsigned long long w[4];
-    __builtin_memcpy(w, &x, 32);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) __hip_atomic_store((unsigned long long *)dst + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ ResElem fused_load_res(const ResElem *src) {
-    unsigned long long w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) w[k] = __hip_atomic_load((const unsigned long long *)src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ResElem x;
-    __builtin_memcpy(&x, w, 32);
-    return x;
-}
-
-template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1, bool STAMPS = false, bool FUSED = false>
-__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) __attribute__((amdgpu_waves_per_eu((STAMPS || FUSED) ? 7 : 1, (STAMPS || FUSED) ? 7 : 8)))
+template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1, bool STAMPS = false>
+__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) __attribute__((amdgpu_waves_per_eu(STAMPS ? 7 : 1, STAMPS ? 7 : 8)))
 void k_demod_runs_bp(const RunArgs p) {
     // One workgroup per chunk, URH_WPB wavefronts: wavefront w streams the w-th share of the chunk's rows on its own
     // (no barrier inside the streaming phase), so that the wavefronts resident on the chip cover a NARROW window of
@@ -1285,7 +1251,7 @@ void k_demod_runs_bp(const RunArgs p) {
     // streamed pass (RunArgs::progress): the records go THROUGH to memory (agent-scope stores: no dirty line stays in this XCD's L2), so
     // that an acknowledged store is visible to the tail kernels of this chunk's segment, which start while this kernel is still running
     const bool through = (p.progress != nullptr);
-    if (!FUSED) {
+    {
         int o = incl - cnt;
         const int64_t base = p.pos_base + a0 + (int64_t)lane * kRowSamples;
         while (ae | ao) {
@@ -1306,183 +1272,6 @@ void k_demod_runs_bp(const RunArgs p) {
     }
     const uint32_t last_state = hm ? (uint32_t)__builtin_amdgcn_readlane(my_last, 63 - __builtin_clzll(hm)) : 0xFFFFu;
 
-    if constexpr (FUSED) {
-        // ======== the row stage, here (FusedRows) ========
-        const FusedRows &f = p.fused;
-        FusedDesc *desc = (FusedDesc *)f.desc;
-        const unsigned long long tagw = (unsigned long long)f.tag << 32;
-        const uint32_t init_state = kStPause;             // afp_demod: result[0] = NOISE, so the machine starts in PAUSE (signal_functions.pyx:361, :421-423)
-        if (chunk == 0) {
-            // this pass's huge-row counter and error word start at zero whatever an earlier pass left behind; acknowledged before anything of
-            // this chunk is published, and nobody appends (or gives up) before it has seen every predecessor's publication
-            if (lane == 0 && f.huge_count) __hip_atomic_store(f.huge_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane == 0 && f.err) __hip_atomic_store((unsigned long long *)f.err, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        // (1) my pending run, for my successor
-        const unsigned long long pend_bits = (pend_pos >= 0) ? ((unsigned long long)(pend_pos - a0 + 1) | ((unsigned long long)(pend_state & 0xFFu) << 16)) : 0ull;
-        if (lane == 0) __hip_atomic_store(&desc[chunk].flag, tagw | (1ull << 30) | pend_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        bool gave_up = false;
-        // (2) my predecessor's pending run: stable when it grows past the tolerance inside my leading stretch
-        bool stable_p = false; int64_t pp = -1; uint32_t sp = 0;
-        if (chunk > 0) {
-            unsigned long long fp = 0;
-            for (;;) {
-                fp = __hip_atomic_load(&desc[chunk - 1].flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if ((fp >> 32) == (unsigned long long)f.tag && ((fp >> 30) & 3ull) >= 1ull) break;
-                if (++spins > kFusedSpinLimit) { gave_up = true; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fp);
-            if (!gave_up && (pw & 0x3FFFu) != 0) {
-                pp = a0 - p.chunk_len + (int64_t)((pw & 0x3FFFu) - 1u);
-                sp = (pw >> 16) & 0xFFu;
-                stable_p = (a0 - pp) + lead > (int64_t)p.tol;
-            }
-        }
-        // (3) what this chunk does to the state machine: the predecessor's pending run (if stable), then my own stable runs (the records;
-        //     my own pending run belongs to my successor)
-        ResElem e = res_of_chunk(total, first_state, last_state, 0u, last_pos, -1, 0);
-        if (stable_p) e = res_combine(res_make(sp, pp, sp, 0, false, -1, 0), e);
-        if (lane == 0) fused_store_res(&desc[chunk].agg, e);
-        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&desc[chunk].flag, tagw | (2ull << 30) | pend_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (4) look back: lane l of a window looks at chunk top - l; aggregates until a chunk that already carries its inclusive prefix
-        ResElem carry = res_identity();
-        {
-            int64_t top = chunk - 1;
-            while (top >= 0 && !gave_up) {
-                const int64_t j = top - lane;
-                unsigned long long fl = 0;
-                if (j >= 0) fl = __hip_atomic_load(&desc[j].flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t stt = (j >= 0 && (fl >> 32) == (unsigned long long)f.tag) ? (uint32_t)((fl >> 30) & 3ull) : 0u;
-                const bool ready = (j < 0) || stt >= 2u;
-                const unsigned long long m_incl = __builtin_amdgcn_ballot_w64(stt == 3u);
-                const unsigned long long m_not_ready = __builtin_amdgcn_ballot_w64(!ready);
-                const int first_incl = m_incl ? __builtin_ctzll(m_incl) : 64;
-                const unsigned long long need = (first_incl >= 63) ? ~0ull : ((2ull << first_incl) - 1ull);
-                if (m_not_ready & need) {
-                    if (++spins > kFusedSpinLimit) { gave_up = true; break; }
-                    __builtin_amdgcn_s_sleep(12);
-                    continue;
-                }
-                ResElem mine = res_identity();
-                if (j >= 0 && lane <= first_incl) mine = fused_load_res(lane == first_incl ? &desc[j].incl : &desc[j].agg);
-                if (first_incl != 0) {                     // (the chunk right before me already has its prefix: nothing to compose)
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const ResElem u = res_shfl_down(mine, o);       // chunks further to the left
-                        if (lane + o < 64) mine = res_combine(u, mine);
-                    }
-                }
-                carry = res_combine(res_shfl(mine, 0), carry);
-                if (m_incl) break;
-                top -= 64;
-            }
-        }
-        if (lane == 0) fused_store_res(&desc[chunk].incl, res_combine(carry, e));
-        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&desc[chunk].flag, tagw | (3ull << 30) | pend_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gave_up && lane == 0 && f.err) __hip_atomic_store((unsigned long long *)f.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // (5) my rows.  P: the state machine before this chunk
-        const ResElem P = res_combine(res_make(init_state, -1, init_state, 0, false, -1, 0), carry);
-        const int64_t la0_pos = P.la_valid() ? P.la_pos : -1;
-        const uint32_t la0_st = P.la_valid() ? P.la_state() : init_state;
-        const bool acc_p = stable_p && (sp != P.last_state());
-        const uint32_t s1 = stable_p ? sp : P.last_state();                 // stable state my own runs are entered with
-        const int64_t la1_pos = acc_p ? pp : la0_pos;
-        const uint32_t la1_st = acc_p ? sp : la0_st;
-        const int64_t g1 = P.cnt + (acc_p ? 1 : 0);                          // global index of my first own row
-        const int skip = (total > 0 && first_state == s1) ? 1 : 0;          // record 0 is no state change
-        const int n_own = total - skip;
-        BitsParams bp;
-        bp.sps = f.sps; bp.bps = f.bps; bp.pause_threshold = f.pause_threshold;
-        const bool want_bits = (f.agg != nullptr);
-        int64_t acc_bits = 0;
-        unsigned long long acc_ld = 0;
-        auto emit = [&](int64_t g, uint32_t pst, int64_t len) {
-            const int64_t state = (int64_t)pst - 1;
-            if (g < f.cap_rows) {
-                *(longlong2 *)(f.rows + 2 * g) = longlong2{(long long)state, (long long)len};
-                if (f.h_state) { f.h_state[g] = (int8_t)state; f.h_len[g] = (int32_t)len; }
-            }
-            if (want_bits) {
-                const VecK<4> v = row_value(state, len, g == 0, bp);
-                acc_bits += v.v[0];
-                acc_ld += (unsigned long long)v.v[1] | ((unsigned long long)v.v[3] << 32);
-                if (v.v[0] > kHugeBits) {
-                    const int slot = atomicAdd(f.huge_count, 1);
-                    if (slot < f.huge_cap) { ((HugeRef *)f.huge)[slot].tile = chunk; ((HugeRef *)f.huge)[slot].row = g; }
-                }
-            }
-        };
-        if (acc_p && lane == 0) emit(P.cnt, la0_st, pp - la0_pos);          // (la0_pos = -1 before the table's first row: length = position + 1)
-        {
-            // the accepted run before a lane's first record: the last record of the nearest lower lane that has one
-            const int64_t base = p.pos_base + a0 + (int64_t)lane * kRowSamples;
-            const int64_t my_last_abs = base + last_acc;
-            const uint32_t my_last_st = (cnt > 0) ? state_at(last_acc < 0 ? 0 : last_acc) : 0u;
-            const uint64_t lower = am & ((1ull << lane) - 1ull);
-            const int src = lower ? 63 - __builtin_clzll(lower) : 0;
-            int64_t ppos = __shfl(my_last_abs, src);
-            uint32_t pst = __shfl(my_last_st, src);
-            int o = incl - cnt;                             // index of my first record among the chunk's
-            while (ae | ao) {
-                const int pos = bp_first(ae, ao);
-                const uint32_t st = state_at(pos);
-                if (o == skip) { ppos = la1_pos; pst = la1_st; }            // the first row of my own: behind the run accepted before me
-                if (o >= skip) emit(g1 + (o - skip), pst, base + pos - ppos);
-                ppos = base + pos; pst = st;
-                ++o;
-                if (pos & 1) ao &= ao - 1; else ae &= ae - 1;
-            }
-        }
-        const int tcnt = (acc_p ? 1 : 0) + n_own;
-        if (want_bits) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { acc_bits += __shfl_xor(acc_bits, o); acc_ld += (unsigned long long)__shfl_xor((long long)acc_ld, o); }
-            if (lane == 0) {
-                VecK<4> acc; acc.zero();
-                if (tcnt > 0) {
-                    acc.v[0] = acc_bits; acc.v[1] = (int64_t)(acc_ld & 0xFFFFFFFFull); acc.v[3] = (int64_t)(acc_ld >> 32);
-                    acc.v[2] = ((n_own > 0) ? last_pos : pp) - la0_pos;     // row lengths telescope
-                }
-                ((VecK<4> *)f.agg)[chunk] = acc; f.tile_off[chunk] = P.cnt; f.tile_cnt[chunk] = tcnt;
-            }
-        }
-        // (6) the capture's last chunk: totals, the table's last row (signal_functions.pyx:485-493; skipped when the table already has n
-        //     rows, :487) and its tile
-        if (chunk == f.n_chunks - 1 && lane == 0) {
-            const ResElem pre = res_combine(P, e);
-            const int64_t Pn = pre.cnt;
-            *f.d_n_acc = Pn;
-            int64_t n_rows = Pn, o = Pn;
-            VecK<4> v; v.zero();
-            int32_t tc = 0;
-            if (Pn < f.n_total) {
-                n_rows = Pn + 1; tc = 1;
-                const int64_t fpos = pre.la_valid() ? pre.la_pos : -1;
-                const uint32_t fstate = pre.la_valid() ? pre.la_state() : init_state;
-                const int64_t len = (Pn == 0) ? (f.n_total - p.tol) : (f.n_total - 1 - fpos - p.tol);
-                if (o < f.cap_rows) {
-                    f.rows[2 * o] = (int64_t)fstate - 1; f.rows[2 * o + 1] = len;
-                    if (f.h_state) { f.h_state[o] = (int8_t)((int64_t)fstate - 1); f.h_len[o] = (int32_t)len; }
-                }
-                if (want_bits) {
-                    v = row_value((int64_t)fstate - 1, len, Pn == 0, bp);
-                    if (v.v[0] > kHugeBits) {
-                        const int slot = atomicAdd(f.huge_count, 1);
-                        if (slot < f.huge_cap) { ((HugeRef *)f.huge)[slot].tile = f.n_chunks; ((HugeRef *)f.huge)[slot].row = o; }
-                    }
-                }
-            }
-            *f.d_n_rows_needed = n_rows;
-            *f.d_n_rows = (n_rows > f.cap_rows) ? f.cap_rows : n_rows;
-            if (want_bits) { ((VecK<4> *)f.agg)[f.n_chunks] = v; f.tile_off[f.n_chunks] = o; f.tile_cnt[f.n_chunks] = tc; }
-            for (int k = 0; f.seg_in && k < f.seg_in_words; ++k) f.seg_in[k] = 0;      // what the bits segments of a streamed pass carry along starts empty
-        }
-    }
     if (lane == 0) {
         ChunkInfo ci;
         ci.pend_pos = (pend_pos >= 0) ? pend_pos + p.pos_base : -1;
@@ -1598,17 +1387,6 @@ bool g_force_state_bytes = false;
 bool g_stamp_probe = false;          // test hook (urhgpu_test_hot_stamps): complex64 2-FSK passes run the STAMPS instantiation of the bit-plane kernel
 thread_local HotEvents g_hot_events;
 
-// the bit-plane kernel's launch: with the profile's / the pipeline's events attached to the dispatch itself where there are any
-template <class K>
-static void launch_bp(K kernel, unsigned grid, unsigned block, const RunArgs &a, hipStream_t s) {
-    if ((g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
-        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
-        g_hot_events.used = true;
-    } else {
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), (size_t)a.lds_pad, s, a);
-    }
-}
-
 // `a` describes the whole capture (a.n samples, chunk table / slab for n_main + has_tail chunks):
 // one launch over the whole tiles, one one-workgroup launch for the partial tile at the end.
 template <int SRC, int DT, int MOD, bool O2, bool WQ>
@@ -1627,17 +1405,20 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
         // orders 2 and 4: the bit-plane kernel; anything else: the state-byte kernel
         const bool planes_ok = URH_BITPLANE && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes;
-        const unsigned grid = (unsigned)(c_hi - c_lo), block = kBlock * bp_waves<SRC, MOD>();
-        constexpr bool kFsk = (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK);
-        const bool fused = kFsk && a.fused.desc != nullptr && planes_ok && (O2 || a.order == 4);
-        if (a.fused.desc != nullptr && !fused) a.fused.desc = nullptr;      // (the caller asked for a pass this kernel does not fuse: see runs_fusable)
-        if (planes_ok && O2 && a.stamp_probe && kFsk && DT == URHGPU_DT_F32 && WQ) {
-            if (fused) launch_bp(k_demod_runs_bp<SRC_IQ, URHGPU_DT_F32, URHGPU_MOD_FSK, true, true, 1, true, true>, grid, block, a, s);
-            else launch_bp(k_demod_runs_bp<SRC_IQ, URHGPU_DT_F32, URHGPU_MOD_FSK, true, true, 1, true>, grid, block, a, s);
-        } else if (fused && O2) launch_bp(k_demod_runs_bp<SRC_IQ, DT, URHGPU_MOD_FSK, WQ, true, 1, false, true>, grid, block, a, s);
-        else if (fused) launch_bp(k_demod_runs_bp<SRC_IQ, DT, URHGPU_MOD_FSK, WQ, true, 2, false, true>, grid, block, a, s);
-        else if (planes_ok && O2) launch_bp(k_demod_runs_bp<SRC, DT, MOD, WQ>, grid, block, a, s);
-        else if (planes_ok && a.order == 4) launch_bp(k_demod_runs_bp<SRC, DT, MOD, WQ, true, 2>, grid, block, a, s);
+        if (planes_ok && O2 && a.stamp_probe && SRC == SRC_IQ && DT == URHGPU_DT_F32 && MOD == URHGPU_MOD_FSK && WQ && (g_hot_events.start || g_hot_events.stop)) {
+            hipExtLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, URHGPU_DT_F32, URHGPU_MOD_FSK, true, true, 1, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
+                                  (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
+            g_hot_events.used = true;
+        } else if (planes_ok && O2 && !a.stamp_probe && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
+            hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
+                                  (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
+            g_hot_events.used = true;
+        } else if (planes_ok && O2 && a.stamp_probe && SRC == SRC_IQ && DT == URHGPU_DT_F32 && MOD == URHGPU_MOD_FSK && WQ)
+            hipLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, URHGPU_DT_F32, URHGPU_MOD_FSK, true, true, 1, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
+        else if (planes_ok && O2)
+            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
+        else if (planes_ok && a.order == 4)
+            hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 2>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
         else
             hipLaunchKernelGGL((k_demod_runs<SRC, DT, MOD, O2, WQ, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock), 0, s, a);
     }
@@ -1688,15 +1469,6 @@ int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, h
 bool runs_streamable(const RunArgs &a) {
     return URH_BITPLANE && (a.order == 2 || a.order == 4) && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples &&
            !g_force_state_bytes && a.n >= kTile && a.n % kTile == 0;
-}
-
-// Can the row stage of a pass with these arguments run inside the hot kernel (RunArgs::fused)?  The bit-plane kernel's work on a whole,
-// unsharded capture: FSK of order 2 or 4, tolerance within its range (a chunk is then longer than the tolerance: a pending run that spans
-// a whole chunk is stable), whole tiles only, no message segmentation.
-bool runs_fusable(const RunArgs &a, int mod) {
-    return URH_BITPLANE && mod == URHGPU_MOD_FSK && (a.order == 2 || a.order == 4) && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples &&
-           a.chunk_len >= 256 && !g_force_state_bytes && a.n >= kTile && a.n % kTile == 0 && !a.seg_mode && a.left_halo == nullptr && a.pos_base == 0 &&
-           a.launch_part == 0 && a.progress == nullptr && a.graded_from == 0;
 }
 
 // Run segmentation over an already demodulated float32 signal (grab_pulse_lens proper).

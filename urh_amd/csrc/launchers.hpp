@@ -9,34 +9,6 @@
 namespace urh {
 
 // ---- demod_runs.hip ---------------------------------------------------------------------------------
-// The row stage inside the hot kernel (k_demod_runs_bp, FUSED instantiation; single GPU, whole tiles, FSK of order 2 / 4): wavefront 0 of
-// every chunk publishes what its chunk does to the reference's state machine (a ResElem, rows.hpp), looks back over its predecessors'
-// publications (chained scan: a 128-byte descriptor per chunk, flag words tagged with the pass number) and writes the chunk's pulse-table
-// rows -- device table and the pinned host blob -- and its tile's bit aggregates from the records it still holds in registers.  No slab,
-// no k_resolve_one / k_emit_rows_tiles behind the hot kernel.  desc == nullptr: not fused (the kernels of pulse_table.hip do it).
-struct FusedRows {
-    void *desc;              // [n_chunks] FusedDesc (demod_runs.hip): persistent memory, zero or older tags before the pass
-    uint32_t tag;            // pass tag of the flag words (never repeats on a context)
-    int32_t huge_cap;
-    int64_t n_chunks;        // chunks of the capture: the last one writes the totals, the table's last row and its tile
-    int64_t n_total;         // samples of the capture
-    int64_t *rows;           // pulse table int64[cap_rows][2]
-    int64_t cap_rows;
-    int8_t *h_state;         // pinned host blob sections (row_state / row_len) or nullptr
-    int32_t *h_len;
-    int64_t *d_n_acc, *d_n_rows, *d_n_rows_needed;
-    void *agg;               // VecK<4>[n_chunks + 1]: per tile (= chunk) bits / long pauses / samples / data rows; nullptr: rows only
-    int64_t *tile_off;       // [n_chunks + 1]
-    int32_t *tile_cnt;       // [n_chunks + 1]
-    void *huge;              // HugeRef[huge_cap]
-    int32_t *huge_count;     // the pass's counter (already offset by the parity)
-    int64_t sps, bps, pause_threshold;
-    int64_t *err;            // device word (SegState::err or nullptr): cleared by the first chunk, set to 1 when a wavefront gave up waiting
-                             // for a predecessor (the pass's results are void)
-    int64_t *seg_in;         // SegState::in of a streamed pass (nullptr: none): cleared by the last chunk, before the bits stage starts
-    int32_t seg_in_words;
-};
-
 struct RunArgs {
     const void *in;          // IQ (dtype) or qad (float) -- device pointer
     float *qad;              // demodulated output or nullptr
@@ -77,7 +49,6 @@ struct RunArgs {
     // (a multiple of W rows): the launch's last residency wave then consists of short-lived workgroups, so that the machine drains in a
     // quarter of the time.  graded_from == 0: uniform chunks.
     int64_t graded_from, graded_len;
-    FusedRows fused;         // the row stage inside the bit-plane kernel (fused.desc != nullptr)
     int stamp_probe;         // tools/boundary_probe.py: the STAMPS instantiation of the bit-plane kernel (complex64 2-FSK only); 0 in the product
     float thr[kMaxOrder - 1];
 };
@@ -90,7 +61,6 @@ struct HotEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false
 extern thread_local HotEvents g_hot_events;   // test hook: order 2 through the state-byte kernel too
 int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s);
 int launch_runs_qad(const RunArgs &a, hipStream_t s);
-bool runs_fusable(const RunArgs &a, int mod);  // RunArgs::fused is honoured for these arguments
 bool runs_streamable(const RunArgs &a);       // RunArgs::progress is honoured for these arguments (bit-plane kernel, whole tiles)
 int launch_afp_demod(const RunArgs &a, int dtype, int mod, int grid, hipStream_t s);
 void launch_test_div(uint64_t seed, int reps, unsigned long long *d_mismatches, hipStream_t s);
@@ -320,10 +290,8 @@ struct TileTailMem {
     void *rdesc;             // tile_rdesc_bytes(n_chunks) of persistent, initially zeroed memory: look-back descriptors of the resolve scan
     unsigned long long epoch; // pass counter carried by their flags (never repeats on a context)
     int64_t *d_row_base = nullptr;   // sharded captures: device word that receives the global index of this GPU's first row
-    int fused = 0;           // the rows came out of the hot kernel (FusedRows): parity is then the pass's arena slot (0..2), cleared by that kernel
 };
 size_t tile_rdesc_bytes(int64_t n_chunks);
-void tile_fused_args(const TileTailMem &m, bool want_bits, FusedRows *f);
 size_t tile_tail_bytes(int64_t n_chunks);
 int64_t tile_desc_cap(int64_t cap_rows, int64_t n_chunks);
 int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem &m, const BitsParams *bp, hipStream_t s);

@@ -12,7 +12,6 @@
 #include "common.hpp"
 #include "compact.hpp"
 #include "launchers.hpp"
-#include "rows.hpp"
 #include "runs.hpp"
 #include "scan.hpp"
 
@@ -367,6 +366,22 @@ __global__ void k_merge_finish(const VecK<2> *grand_total, const int64_t *grp_st
 //              L long pause (closes a message when data was seen, else discards what was gathered)
 //   groups   : stretches of rows between L rows; a group with at least one D row is a message.
 // =====================================================================================================
+__device__ __forceinline__ int64_t num_symbols_of(int64_t num_samples, int64_t sps) {
+    // int(n / sps) (+1 when the fractional part exceeds 0.5), in double like the Python source (:353-358).
+    // Below 2^32 the double quotient's floor and the sign of (fraction - 0.5) are those of the exact quotient (the nearest
+    // quotients to an integer or to a half differ from it by >= 1 / (2 sps) > 2^-33, against a rounding error < 2^-52 * 2^32):
+    // integer form q + (2 r > sps), one 32-bit division.
+    if ((((uint64_t)num_samples | (uint64_t)sps) >> 32) == 0) {
+        const uint32_t n32 = (uint32_t)num_samples, s32 = (uint32_t)sps;
+        const uint32_t q = n32 / s32, r = n32 - q * s32;
+        return (int64_t)q + ((2ull * r > s32) ? 1 : 0);
+    }
+    const double f = (double)num_samples / (double)sps;
+    int64_t k = (int64_t)f;
+    if (f - (double)k > 0.5) k += 1;
+    return k;
+}
+
 struct RowInfo {             // per-row scan results kept for the expansion kernel
     int64_t bit_prefix;      // bits before this row (all rows, kept or not)
     int64_t ts_prefix;       // total_samples before this row
@@ -546,6 +561,10 @@ __device__ __forceinline__ uint8_t symbol_bit(int64_t type, int64_t k, int bps) 
     return (uint8_t)((type >> (bps - 1 - r)) & 1);
 }
 
+struct HugeRow { int64_t kb, ob, op, ts, type; };   // a row that expands to more than kHugeBits bits
+constexpr int64_t kHugeBits = 4096;
+constexpr int kHugeCap = 8192;
+
 struct ExpandArgs {
     const int64_t *rows;
     const int64_t *d_n_rows;
@@ -659,6 +678,82 @@ __global__ __launch_bounds__(256) void k_expand_huge(const ExpandArgs a) {
 // passes over a 24-byte-per-row side table with 1.3 wavefronts per SIMD) this drops the RowInfo table, three launches and every
 // under-occupied pass.  ASK (rows merge across chunks after the short-pause rule) and sharded captures keep the generic path.
 // =====================================================================================================
+struct ResElem {             // effect of a stretch of chunks on the reference's state machine, as a function of the entry state
+    int64_t cnt;             // accepted runs, not counting the conditional first one
+    int64_t first_pos;       // position of the first stable run (meaningful while nothing else has been accepted)
+    int64_t la_pos;          // last run that is accepted whatever the entry state
+    uint64_t meta;           // first_state | last_state << 16 | la_state << 32 | has << 48 | la_valid << 49
+    __device__ __forceinline__ bool has() const { return (meta >> 48) & 1; }
+    __device__ __forceinline__ bool la_valid() const { return (meta >> 49) & 1; }
+    __device__ __forceinline__ uint32_t first_state() const { return (uint32_t)(meta & 0xFFFF); }
+    __device__ __forceinline__ uint32_t last_state() const { return (uint32_t)((meta >> 16) & 0xFFFF); }
+    __device__ __forceinline__ uint32_t la_state() const { return (uint32_t)((meta >> 32) & 0xFFFF); }
+};
+__device__ __forceinline__ ResElem res_identity() { ResElem e; e.cnt = 0; e.first_pos = -1; e.la_pos = -1; e.meta = 0; return e; }
+__device__ __forceinline__ ResElem res_make(uint32_t first_state, int64_t first_pos, uint32_t last_state, int64_t cnt, bool la_valid,
+                                            int64_t la_pos, uint32_t la_state) {
+    ResElem e;
+    e.cnt = cnt; e.first_pos = first_pos; e.la_pos = la_pos;
+    e.meta = (uint64_t)(first_state & 0xFFFF) | ((uint64_t)(last_state & 0xFFFF) << 16) | ((uint64_t)(la_state & 0xFFFF) << 32) |
+             (1ull << 48) | ((uint64_t)(la_valid ? 1 : 0) << 49);
+    return e;
+}
+// a, then b.  Written as per-field selects: returning one of several structs makes the compiler build them in scratch memory.
+__device__ __forceinline__ ResElem res_combine(const ResElem &a, const ResElem &b) {
+    const bool ah = a.has(), bh = b.has();
+    const bool acc = b.first_state() != a.last_state();        // b's first stable run switches the state machine
+    const bool blv = b.la_valid();
+    const int64_t both_cnt = a.cnt + b.cnt + (acc ? 1 : 0);
+    const int64_t both_la_pos = blv ? b.la_pos : (acc ? b.first_pos : a.la_pos);
+    const uint64_t both_la_state = blv ? b.la_state() : (acc ? b.first_state() : a.la_state());
+    const uint64_t both_lav = (blv || acc || a.la_valid()) ? 1 : 0;
+    const uint64_t both_meta = (uint64_t)a.first_state() | ((uint64_t)b.last_state() << 16) | (both_la_state << 32) | (1ull << 48) | (both_lav << 49);
+    ResElem r;
+    r.cnt = !ah ? b.cnt : (!bh ? a.cnt : both_cnt);
+    r.first_pos = !ah ? b.first_pos : a.first_pos;
+    r.la_pos = !ah ? b.la_pos : (!bh ? a.la_pos : both_la_pos);
+    r.meta = !ah ? b.meta : (!bh ? a.meta : both_meta);
+    return r;
+}
+__device__ __forceinline__ ResElem res_shfl_up(const ResElem &x, int o) {
+    ResElem r;
+    r.cnt = __shfl_up(x.cnt, o); r.first_pos = __shfl_up(x.first_pos, o); r.la_pos = __shfl_up(x.la_pos, o);
+    r.meta = (uint64_t)__shfl_up((long long)x.meta, o);
+    return r;
+}
+__device__ __forceinline__ ResElem res_shfl_down(const ResElem &x, int o) {
+    ResElem r;
+    r.cnt = __shfl_down(x.cnt, o); r.first_pos = __shfl_down(x.first_pos, o); r.la_pos = __shfl_down(x.la_pos, o);
+    r.meta = (uint64_t)__shfl_down((long long)x.meta, o);
+    return r;
+}
+__device__ __forceinline__ ResElem res_shfl(const ResElem &x, int src) {
+    ResElem r;
+    r.cnt = __shfl(x.cnt, src); r.first_pos = __shfl(x.first_pos, src); r.la_pos = __shfl(x.la_pos, src);
+    r.meta = (uint64_t)__shfl((long long)x.meta, src);
+    return r;
+}
+__device__ __forceinline__ ResElem res_wave_incl_scan(ResElem x, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const ResElem u = res_shfl_up(x, o);
+        if (lane >= o) x = res_combine(u, x);
+    }
+    return x;
+}
+// the stable runs of one chunk as an element (after chunk_stable has settled its pending run)
+__device__ __forceinline__ ResElem res_of_chunk(int cnt, uint32_t c_first_state, uint32_t c_last_state, uint32_t c_pend_state, int64_t c_last_pos,
+                                                int64_t c_pend_pos, int pend_stable) {
+    const bool pend_in = pend_stable && (cnt == 0 || c_pend_state != c_last_state);   // the pending run is a further stable run
+    const int k = cnt + (pend_in ? 1 : 0);
+    if (k == 0) return res_identity();
+    const uint32_t first_state = cnt > 0 ? c_first_state : c_pend_state;
+    const int64_t last_pos = pend_in ? c_pend_pos : c_last_pos;
+    const uint32_t last_state = pend_in ? c_pend_state : c_last_state;
+    // k == 1: the only stable run IS the first one (cnt == 1: last_pos is record 0's position)
+    return res_make(first_state, k == 1 ? last_pos : -1, last_state, k - 1, k >= 2, last_pos, last_state);
+}
+
 struct TileTail {            // scratch of the tile tail (carved from the context's arena)
     ResElem *ploc;           // [n_chunks] exclusive prefix inside the chunk's resolve workgroup
     ResElem *btot;           // [resolve workgroups] totals
@@ -772,6 +867,24 @@ __device__ __forceinline__ ResElem res_before_entry(const TileTail &ft, const Re
     return pre;
 }
 
+// What one row contributes to _ppseq_to_bits (ProtocolAnalyzer.py:346-401): v[0] bits, v[1] long pause, v[2] samples, v[3] data row
+__device__ __forceinline__ VecK<4> row_value(int64_t type, int64_t len, bool global_row0, const BitsParams &bp) {
+    VecK<4> v; v.zero();
+    v.v[2] = len;
+    if (type == kRowAbsorbed) return v;
+    if (global_row0 && type == -1) return v;             // "Starts with Pause" (:346-348): only seeds total_samples
+    const int64_t ns = num_symbols_of(len, bp.sps);
+    if (type == -1) {
+        if (ns <= bp.pause_threshold || bp.pause_threshold == 0) v.v[0] = (ns > 0) ? ns * bp.bps : 0;
+        else v.v[1] = 1;
+    } else {
+        v.v[0] = (ns > 0) ? ns * bp.bps : 0;
+        v.v[3] = (ns > 0) ? 1 : 0;
+    }
+    return v;
+}
+
+struct HugeRef { int64_t tile, row; };                   // a row of more than kHugeBits bits, found while the rows were emitted
 // Wavefronts per workgroup of k_emit_rows_tiles / k_expand_tiles.  Four, not eight: beside the next pass's hot kernel (pipelined passes)
 // a workgroup needs one free wave slot per SIMD, which retiring hot workgroups (four wavefronts) leave; eight-wavefront workgroups were
 // starved until the hot kernel had drained (the row kernel then took that kernel's whole 290 us).
@@ -795,6 +908,12 @@ constexpr int kTailCPW = URH_TAIL_CPW;
 #define URH_TAIL_OCC
 #endif
 static_assert(kResolveBlock % kTailCPW == 0 && kTailCPW <= 64, "the chunks of one wavefront share their resolve workgroup");
+
+__device__ __forceinline__ int64_t lane_bcast(int64_t v, int src) {          // src wave-uniform
+    const int lo = __builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, src), hi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), src);
+    return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ int lane_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
 struct EmitTileArgs {
     EmitArgs e;
@@ -1121,7 +1240,6 @@ struct ExpandTileArgs {
     int32_t *huge_count;     // [2]
     int32_t huge_cap;
     int parity;
-    int zero_other;          // 1: this launch clears the other parity's huge-row counter for the next pass (0: a fused pass, whose hot kernel clears its own)
     int64_t n_tiles;
     int64_t t_base;          // first tile of this launch (0; a segment of a streamed pass: its first chunk)
     uint32_t *h_pos;         // see GroupStore::h_pos (nullptr: positions are not shipped by this kernel)
@@ -1143,7 +1261,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(c
         const bool row0g = !a.bp.d_row_base || *a.bp.d_row_base == 0;
         const int64_t hb = (int64_t)blockIdx.x - tile_blocks;
         const int hx = (int)(hb % kHugeBlocksX), hy = (int)(hb / kHugeBlocksX);
-        if (hb == 0 && threadIdx.x == 0 && a.zero_other) a.huge_count[a.parity ^ 1] = 0;       // the other parity's counter: free for the next pass
+        if (hb == 0 && threadIdx.x == 0) a.huge_count[a.parity ^ 1] = 0;       // the other parity's counter: free for the next pass
         int cnt = a.huge_count[a.parity];
         if (cnt > a.huge_cap) cnt = 0;                      // list overflowed: the tiles' own wavefronts expand every row
         __shared__ int64_t s_h[5];
@@ -1502,23 +1620,8 @@ TileCarve carve_tile(const TileTailMem &m) {
 // the tile scan runs one workgroup per 256 tiles: descriptor memory sized (bits_desc_bytes) for this many "rows" holds them
 int64_t tile_desc_cap(int64_t cap_rows, int64_t n_chunks) { return std::max<int64_t>(cap_rows, 8 * (n_chunks + 2) + kScanTile); }
 
-static size_t tile_rdesc_scan_bytes(int64_t n_chunks) {        // resolve scan + tile scan descriptors
+size_t tile_rdesc_bytes(int64_t n_chunks) {        // resolve scan + tile scan descriptors
     return (size_t)(resolve_blocks(n_chunks) + 2 + (n_chunks + 1 + kScanBlock - 1) / kScanBlock + 2) * sizeof(GranDesc);
-}
-size_t tile_rdesc_bytes(int64_t n_chunks) {        // ... + one 128-byte descriptor per chunk for the row stage inside the hot kernel (FusedRows)
-    return tile_rdesc_scan_bytes(n_chunks) + (size_t)(n_chunks + 1) * 128;
-}
-
-// the tile tail's side of a fused pass (launchers.hpp: FusedRows): where the hot kernel leaves every tile's aggregates, its descriptors
-// and the huge-row list; rows / counts / host sections / slicing parameters are the caller's
-void tile_fused_args(const TileTailMem &m, bool want_bits, FusedRows *f) {
-    const TileCarve tc = carve_tile(m);
-    f->desc = (char *)m.rdesc + tile_rdesc_scan_bytes(m.n_chunks);
-    f->tag = (uint32_t)m.epoch;
-    f->n_chunks = m.n_chunks;
-    f->agg = want_bits ? (void *)tc.ft.agg : nullptr;
-    f->tile_off = tc.ft.tile_off; f->tile_cnt = tc.ft.tile_cnt;
-    f->huge = tc.huge; f->huge_count = m.huge_count + m.parity; f->huge_cap = kTileHugeCap;
 }
 
 size_t tile_tail_bytes(int64_t n_chunks) {
@@ -1594,7 +1697,7 @@ int launch_tile_bits_finish(const TileTailMem &m, const int64_t *rows, const int
         hipLaunchKernelGGL((k_scan_lookback<3, GroupLoad, GroupStore, BitsCountsFinal, kGroupItems>), dim3(scan_grid(b.nbg)), dim3(kScanBlock), 0, s,
                            b.d_n_groups, gl, desc3, b.nbg, gs, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, b.d_n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
-                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, m.fused ? 0 : 1, nt, 0, nullptr};
+                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, nt, 0, nullptr};
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(nt);
     if (!(g_tail_skip & 16)) hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     return URHGPU_OK;
@@ -1834,7 +1937,7 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
         hipLaunchKernelGGL((k_scan_lookback<3, SegGroupLoad, SegGroupStore, SegFinal, kGroupItems>), dim3((unsigned)std::min<int64_t>(scan_grid(b.nbg), 32)),
                            dim3(kScanBlock), 0, s, &st->n_groups_local, sl, desc3, b.nbg, sst, fin, ++*ss.epoch, ss.tickets + 2, 0);
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, &st->n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
-                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, m.fused ? 0 : 1, t1, sg.c0, h_pos};
+                      bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, t1, sg.c0, h_pos};
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(t1 - sg.c0);
     if (!(g_tail_skip & 16)) hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     if (dst && dst->host) {
