@@ -148,11 +148,11 @@ def copy_ceiling(torch, pipe, iq, n):
 
 def tuning_from_env():
     """Developer A/B knobs (tools/ab.sh): the environment is read HERE, the library itself reads none (urhgpu_ctx_set_tuning).
-    URH_TUNE_<KEY>=value for every key of urhgpu_ctx_set_tuning (include/urhgpu.h), e.g. URH_TUNE_HOT_GRADED=784.
+    URH_TUNE_<KEY>=value for every key of urhgpu_ctx_set_tuning (include/urhgpu.h), e.g. URH_TUNE_STREAM_POLICY=0.
     Returns (tuning dict for DevicePipeline, torch priority of the tail's stream)."""
     t = {}
     e = os.environ
-    for key in ("hot_lds_kb", "hot_lds_kb_sharded", "hot_cus_removed_per_xcd", "hot_graded", "profile_bracket", "stream_policy", "stream_latency",
+    for key in ("hot_lds_kb", "hot_lds_kb_sharded", "hot_cus_removed_per_xcd", "profile_bracket", "stream_policy", "stream_latency",
                 "stream_segments", "stream_pos_direct", "upload_pieces"):
         env = "URH_TUNE_" + key.upper()
         if env in e:

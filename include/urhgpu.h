@@ -86,15 +86,13 @@ int urhgpu_ctx_sync(urhgpu_ctx *ctx);
  * that last used the pass's scratch arena has finished (bounded run-ahead).
  * The library reads no environment variable; tuning values of this mode are set with urhgpu_ctx_set_tuning. */
 int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
-/* Tuning values of the pipelined mode (the defaults are what is measured and shipped; tools/ab.sh sets others).  Ten keys; the knobs
+/* Tuning values of the pipelined mode (the defaults are what is measured and shipped; tools/ab.sh sets others).  Nine keys; the knobs
  * earlier rounds measured as useless are gone (their records: profiles/HISTORY.md).
  *   "hot_lds_kb"               dynamic LDS per hot workgroup in KiB (fewer of them per CU); default 0
  *   "hot_lds_kb_sharded"       the same for the urhgpu_shard_* passes that keep the generic tail (ASK); default 33
  *   "hot_cus_removed_per_xcd"  0 .. 16, default 4; set before urhgpu_ctx_set_pipelined: the hot kernel of a pipelined pass runs on a private
  *                              stream whose CU mask leaves that many CUs of every XCD out -- on 224 of the MI355X's 256 CUs the kernel is 5 %
  *                              faster than on all of them, and the CUs left alone serve the previous pass's tail; 0: no mask
- *   "hot_graded"               graded tail of the hot launch: that many of its last chunks are cut into four short ones each (the launch's
- *                              last residency wave then drains in a quarter of the time); 0: uniform chunks
  *   "profile_bracket"          1: urhgpu_ctx_profile_* report the stream-level bracket, which reads 3-5 % longer than the kernel runs
  *   "stream_policy"            which tail a pass of urhgpu_stream_* takes.  5 (default): 3 for passes that ship no positions or ship them
  *                              directly, 0 otherwise; 0: segments beside the hot kernel when nothing of an earlier pass is still running (one

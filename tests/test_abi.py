@@ -85,5 +85,5 @@ def test_the_library_reads_no_environment_variable():
     assert not offenders, offenders
     header = open(os.path.join(root, "include", "urhgpu.h")).read()
     for key in ("hot_lds_kb", "hot_lds_kb_sharded", "hot_cus_removed_per_xcd", "profile_bracket", "stream_policy", "stream_segments", "stream_latency",
-                "stream_pos_direct", "upload_pieces", "hot_graded"):
+                "stream_pos_direct", "upload_pieces"):
         assert '"' + key + '"' in header, key

@@ -844,7 +844,6 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
 //   stream_latency           1: a pass that finds the pipeline idle runs its tail in segments (lowest latency for ONE capture); default 0
 //   stream_pos_direct        1 (default): direct passes ship bit_sample_pos themselves
 //   upload_pieces            pieces of urhgpu_stream_push_upload; default 4
-//   hot_graded               the hot launch's last `value` chunks are cut into four short ones each (graded tail); default kGradedDefault
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return URHGPU_ERR_ARG;
     if (!strcmp(key, "hot_lds_kb")) { if (value < 0 || value > 150) return URHGPU_ERR_ARG; ctx->hot_lds_pad = value * 1024; }
@@ -856,7 +855,6 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "stream_latency")) { ctx->tune_stream_latency = value != 0; }
     else if (!strcmp(key, "stream_pos_direct")) { ctx->tune_stream_pos_direct = value != 0; }
     else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }
-    else if (!strcmp(key, "hot_graded")) { if (value < 0 || value > (1 << 20)) return URHGPU_ERR_ARG; ctx->tune_hot_graded = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;
 }

@@ -94,7 +94,6 @@ struct urhgpu_ctx {
     hipStream_t hot_masked = nullptr;      // private CU-masked stream of the hot kernel (pipelined mode)
     hipEvent_t ev_in = nullptr;
     int hot_lds_pad = 0;           // pipelined mode: dynamic LDS bytes added to every hot-kernel workgroup (see RunArgs::lds_pad)
-    int tune_hot_graded = 0;       // graded tail of the hot launch (RunArgs::graded_from): this many of its last chunks are cut into four short ones
     hipStream_t tail_stream = nullptr;
     bool own_tail_stream = false;
     urh::Arena arena_alt, arena_alt2;   // three scratch arenas in rotation: the hot kernel of pass i + 2 does not wait for the tail of pass i

@@ -45,9 +45,9 @@ struct RunArgs {
     // chunks [launch_lo, launch_hi) only (launch_hi == 0: governed by launch_part); the partial tile at the end of the capture counts as
     // chunk n_main
     int64_t launch_lo, launch_hi;
-    // Graded tail (bit-plane kernel): chunks [0, graded_from) are chunk_len samples long, the chunks from graded_from on graded_len
-    // (a multiple of W rows): the launch's last residency wave then consists of short-lived workgroups, so that the machine drains in a
-    // quarter of the time.  graded_from == 0: uniform chunks.
+    // Graded tail (bit-plane kernel; urhgpu_test_hot_probe only -- measured and NOT adopted, profiles/r05_boundary_anatomy.txt: 273-281 us against
+    // 269): chunks [0, graded_from) are chunk_len samples long, the chunks from graded_from on graded_len (a multiple of W rows), so that the
+    // launch's last residency wave consists of short-lived workgroups.  graded_from == 0: uniform chunks.
     int64_t graded_from, graded_len;
     int stamp_probe;         // tools/boundary_probe.py: the STAMPS instantiation of the bit-plane kernel (complex64 2-FSK only); 0 in the product
     float thr[kMaxOrder - 1];
