@@ -802,6 +802,9 @@ def main():
                     help="(default) software-pipeline consecutive steps: the hot kernel of step i+1 on the main stream while the tail of "
                          "step i runs on a second stream")
     ap.add_argument("--no-pipeline", action="store_true", help="run the passes one after the other (profiling: the dominant kernel alone)")
+    ap.add_argument("--selftest-only", action="store_true",
+                    help="N > 1 (or URH_BENCH_FORCE_SHARDED=1): ONE sharded pass and its self-check against a single-GPU pass over the whole "
+                         "capture (+ the reference on rank 0's shard), then a short line -- under a minute, for a first lease that may be short")
     ap.add_argument("--no-pmc", action="store_true", help="do not launch the two rocprofv3 --pmc children for roofline.traffic (quote the committed profile)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -884,6 +887,25 @@ def main():
                                                                                    dict(first_segment=rank * args.segments - 1, sps=sps)))
         left_halo = prev[-2:].clone()
         del prev
+
+    if args.selftest_only:
+        if not sharded:
+            raise SystemExit("--selftest-only checks the sharded path: --gpus N > 1, or URH_BENCH_FORCE_SHARDED=1 under torch.distributed.run")
+        t_s = time.perf_counter()
+        rec = sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, None, halo_given, left_halo, with_oracle=not args.no_cpu_baseline)
+        if rank == 0:
+            out = {"metric": "sharded self-test (no timing)", "value": None, "unit": None, "n_gpus": world, "steps": 1, "warmup": 0,
+                   "config": {"workload": f"{world} GiB complex64 2-FSK sharded over {world} GPUs: one pass, stitched pieces against a single-GPU pass over the "
+                                          "whole capture on rank 0" + ("" if args.no_cpu_baseline else " and rank 0's shard against the reference"),
+                              "collectives": type(pipe.comm).__name__, "collectives_fallback_reason": comm_fallback_reason,
+                              "sharded_parity": rec, "parity_bit_exact": (rec or {}).get("bit_exact"), "seconds": round(time.perf_counter() - t_s, 1)}}
+            os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        pipe.ctx.join()
+        torch.cuda.synchronize()
+        if hasattr(pipe.comm, "close"):
+            pipe.comm.close()
+        dist.destroy_process_group()
+        return
 
     def step():
         if sharded:

@@ -492,6 +492,13 @@ int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs,
  * the percentage mark (repeat that message through urhgpu_msg_plateaus with a larger window).  Synchronous. */
 int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
                                  int percentage, int64_t extra_window, int64_t *tol_out, int64_t *bitlen_out);
+/* urhgpu_msg_center_stats followed by urhgpu_msg_plateau_decisions with the centers it picked, in ONE call: the centers never leave the
+ * device, the scratch of both stages is one reservation, one synchronisation ends the call (AutoInterpretation.py:397-433 per message).
+ * out_stats[8 * n_msgs], out_center, out_flag as urhgpu_msg_center_stats gives them; tol_out / bitlen_out as urhgpu_msg_plateau_decisions,
+ * -4 for a message whose center needs the host first (out_flag 2 or 3: settle it, then urhgpu_msg_plateau_decisions for that message).
+ * URHGPU_ERR_UNSUPPORTED: n_msgs * max_bins counters do not fit one batch of the histogram pool (take the two calls). */
+int urhgpu_msg_estimate(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins, int percentage,
+                        int64_t extra_window, double *out_stats, double *out_center, int32_t *out_flag, int64_t *tol_out, int64_t *bitlen_out);
 /* Test hook (host arithmetic): the multiset form of one message's decision; -3 in both where the sequence would be asked for. */
 int urhgpu_test_bit_length_from_counts(const uint64_t *lens, int64_t n, int64_t *tol_out, int64_t *bitlen_out);
 /* The two halves around np.argsort for a message urhgpu_msg_bit_lengths reported as -2 (equal counts in the divisor histogram: the

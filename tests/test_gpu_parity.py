@@ -1001,6 +1001,14 @@ def test_batched_centers_dense_messages_and_tied_peaks(pipe, oracle):
     got = estimators.centers_batched(pipe, torch.from_numpy(both).cuda(), [(0, 100_000), (100_000, 150_000)])
     want = [oracle.detect_center(both[:100_000]), oracle.detect_center(flat)]
     assert all((g is None and w is None) or float(g) == float(w) for g, w in zip(got, want)), (got, want)
+    # ONE native call for centers + plateau decisions (urhgpu_msg_estimate) equals the two calls, the tied message (flag 3) and the
+    # nearly constant one (flag 2) settled by the host in between
+    for sig, bnd in ((dev, bounds), (torch.from_numpy(both).cuda(), [(0, 100_000), (100_000, 150_000)])):
+        r = np.array(bnd, np.int64)
+        c1, t1, b1 = estimators.centers_and_decisions(pipe, sig, r, 25)
+        c2 = estimators.centers_array(pipe, sig, r)
+        t2, b2 = estimators._plateau_decisions(pipe, sig, r, c2.astype(np.float32).astype(np.float64), 25)
+        assert np.array_equal(c1, c2, equal_nan=True) and np.array_equal(t1, t2) and np.array_equal(b1, b2), (c1, c2, t1, t2, b1, b2)
 
 
 def test_branch_free_sincosf_equals_branchy_for_every_float_below_120(pipe):

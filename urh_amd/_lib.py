@@ -128,6 +128,7 @@ PROTOTYPES = {
     "urhgpu_detect_modulation_dev": (_i, [_vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp]),
     "urhgpu_msg_bit_lengths": (_i, [_vp, _vp, _i, _vp, _vp]),
     "urhgpu_msg_plateau_decisions": (_i, [_vp, _vp, _i64, _vp, _vp, _i, _i, _i64, _vp, _vp]),
+    "urhgpu_msg_estimate": (_i, [_vp, _vp, _i64, _vp, _i, _i64, _i, _i64, _vp, _vp, _vp, _vp, _vp]),
     "urhgpu_test_bit_length_from_counts": (_i, [_vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "urhgpu_msg_divisor_histogram": (_i, [_vp, _i64, _vp, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "urhgpu_bit_length_from_order": (_i, [_vp, _vp, _i64, C.POINTER(_i64)]),

@@ -168,6 +168,12 @@ int prof_end_record(urhgpu_ctx *ctx, hipStream_t s) {
     return URHGPU_OK;
 }
 
+// Which captures take the CU-masked hot stream in pipelined mode (A/B build knob -DURH_MASK_ALL_DTYPES=1: every sample type)
+#ifndef URH_MASK_ALL_DTYPES
+#define URH_MASK_ALL_DTYPES 0
+#endif
+static inline bool masked_hot_stream(const urhgpu_params *p) { return URH_MASK_ALL_DTYPES || p->dtype == URHGPU_DT_F32; }
+
 // pipelined passes: the stream the hot kernel is launched on -- the CU-masked private one (see urhgpu_ctx_set_pipelined), ordered
 // behind what the caller has queued on the context's stream so far
 int hot_stream_begin(urhgpu_ctx *ctx, hipStream_t *out) {
@@ -215,7 +221,7 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     hipStream_t s = ctx->stream;
     // the CU-masked hot stream pays for float32 / complex64 captures, whose kernel is bound by the HBM (1-3 % per pipelined step, 5 % for
     // the kernel on its own); integer captures and wide FSK deviations are VALU-bound and LOSE 2-5 % on 224 CUs (tools/mask_policy_probe.py)
-    if (s_tail && from_iq && p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s));
+    if (s_tail && from_iq && masked_hot_stream(p)) URH_TRY(hot_stream_begin(ctx, &s));
     if (tile_out) tile_out->mem = nullptr;
     RunArgs a;
     memset(&a, 0, sizeof(a));
@@ -528,7 +534,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     ctx->arena.reset();
     ctx->seg_dirty[slot] = true;                               // until the last segment has been queued
     hipStream_t s = ctx->stream;
-    if (p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s));
+    if (masked_hot_stream(p)) URH_TRY(hot_stream_begin(ctx, &s));
     ChunkInfo *chunks = (ChunkInfo *)ctx->arena.take((size_t)pl.n_chunks * sizeof(ChunkInfo));
     uint64_t *slab = (uint64_t *)ctx->arena.take((size_t)pl.n_chunks * pl.slab_stride * 8);
     void *rs_mem = ctx->arena.take(resolve_scratch_bytes(pl.n_chunks));
@@ -1156,7 +1162,7 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     const bool ask = (p->mod == URHGPU_MOD_ASK);
     ss->use_tile = !ask && g_tile_tail;
     hipStream_t s = ctx->stream;
-    if (ss->piped && ss->use_tile && p->dtype == URHGPU_DT_F32) URH_TRY(hot_stream_begin(ctx, &s));
+    if (ss->piped && ss->use_tile && masked_hot_stream(p)) URH_TRY(hot_stream_begin(ctx, &s));
     ss->phase = 0; ss->rank = rank; ss->world = world; ss->n_local = n_local; ss->pos_base = pos_base; ss->n_total = n_total;
     ss->p = *p; ss->out = *out;
     const Plan pl = make_plan(ctx, n_local, p->tolerance);

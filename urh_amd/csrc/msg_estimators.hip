@@ -908,6 +908,14 @@ __global__ __launch_bounds__(256) void k_me_fill_tiles(const MsgState *st, int n
     tiles[t] = MsgTile{lo, (int32_t)(t - st[lo].first_tile)};
 }
 
+// stage 2's center of a chained call: what the host would hand over -- the picked center as a C float (get_plateau_lengths takes `float
+// center`, auto_interpretation.pyx:179), NaN where stage 1 has none to give (no histogram, more bins than the pool, a tie numpy decides)
+__global__ void k_me_chain_center(const MsgState *st1, MsgState *st2, int n_msgs) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_msgs) return;
+    st2[m].center = (st1[m].peak_flag == 1) ? (double)(float)st1[m].peak_center : __builtin_nan("");
+}
+
 }  // namespace urh
 
 using namespace urh;
@@ -919,6 +927,15 @@ struct MsgBatch {
     MsgState *d_state = nullptr;
     MsgTile *d_tiles = nullptr;
     int64_t n_tiles = 0;
+};
+
+// urhgpu_msg_estimate: center statistics and plateau decisions back to back -- the centers stay on the device (k_me_chain_center), the
+// scratch of both stages comes from ONE reservation, the states of both land in the pinned zone behind ONE synchronisation
+struct EstChain {
+    MsgBatch b1;             // stage 1's batch (host mirror filled when the chain's synchronisation has happened)
+    MsgState *d_st1 = nullptr;
+    bool st1_pinned = false;
+    size_t pinned_used = 0;  // bytes of ctx->h_small stage 1's states occupy
 };
 
 // tile table over [start, start + span_m) of every message; span = whole message (window = nullptr) or the given windows
@@ -951,14 +968,18 @@ int build_batch(urhgpu_ctx *ctx, const int64_t *ranges, int n_msgs, int64_t n, c
 extern "C" {
 
 // one batch of urhgpu_msg_center_stats: at most kCenterBatchBytes of histogram pool (see below)
+static void center_stats_collect(const MsgBatch &b, int n_msgs, int64_t max_bins, const std::vector<unsigned int> &hist, double *out_stats,
+                                 int64_t *out_hist, double *out_center, int32_t *out_flag);
+
 static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins,
-                              double *out_stats, int64_t *out_hist, double *out_center, int32_t *out_flag) {
-    MsgBatch b;
+                              double *out_stats, int64_t *out_hist, double *out_center, int32_t *out_flag, EstChain *chain = nullptr) {
+    MsgBatch local;
+    MsgBatch &b = chain ? chain->b1 : local;
     URH_TRY(build_batch(ctx, ranges, n_msgs, n, nullptr, b));
     // scratch: state, tiles, per-tile counts / min-max, leaf sums, the compacted samples, the histogram pool
     const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)(b.n_tiles + 1) * (sizeof(MsgTile) + 4 + 8 + 8 + 4 + kLeavesPerTile * 4) +
                         (size_t)n * 4 + (size_t)n_msgs * (size_t)max_bins * 4 + 17 * 256;
-    URH_TRY(ctx->arena.reserve(need));
+    if (!chain) { URH_TRY(ctx->arena.reserve(need)); }       // (a chained call has reserved both stages' scratch)
     ctx->arena.reset();
     MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
     MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
@@ -997,14 +1018,24 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     URH_HIP(hipGetLastError());
     std::vector<unsigned int> hist;
     const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState);
-    const bool st_pinned = ctx->h_small && st_bytes <= kSmallPinned;     // (a truly asynchronous copy; pageable memory otherwise)
+    const bool st_pinned = ctx->h_small && st_bytes <= (chain ? kSmallPinned / 4 : kSmallPinned);     // (a truly asynchronous copy; pageable memory otherwise)
     URH_HIP(hipMemcpyAsync(st_pinned ? (void *)ctx->h_small : (void *)b.host.data(), d_st, st_bytes, hipMemcpyDeviceToHost, s));
+    if (chain) {                                             // stage 2 goes on from here; its synchronisation covers this copy
+        chain->d_st1 = d_st; chain->st1_pinned = st_pinned; chain->pinned_used = st_pinned ? ((st_bytes + 255) & ~size_t(255)) : 0;
+        return URHGPU_OK;
+    }
     if (out_hist) {                                          // the histograms themselves: only a caller that has to break a tie wants them
         hist.resize((size_t)n_msgs * (size_t)max_bins);
         URH_HIP(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
     }
     URH_HIP(hipStreamSynchronize(s));
     if (st_pinned) memcpy(b.host.data(), ctx->h_small, st_bytes);
+    center_stats_collect(b, n_msgs, max_bins, hist, out_stats, out_hist, out_center, out_flag);
+    return URHGPU_OK;
+}
+
+static void center_stats_collect(const MsgBatch &b, int n_msgs, int64_t max_bins, const std::vector<unsigned int> &hist, double *out_stats,
+                                 int64_t *out_hist, double *out_center, int32_t *out_flag) {
     for (int m = 0; m < n_msgs; ++m) {
         const MsgState &st = b.host[(size_t)m];
         double *o = out_stats + 8 * (size_t)m;
@@ -1018,7 +1049,6 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
             for (int64_t k = 0; k < max_bins; ++k) h[k] = (k < nb) ? (int64_t)hist[(size_t)m * (size_t)max_bins + (size_t)k] : 0;
         }
     }
-    return URHGPU_OK;
 }
 
 // The histogram pool holds max_bins counters per message and is cleared for every call: a capture cut into 10^5 .. 10^6 segments (a
@@ -1389,9 +1419,9 @@ int urhgpu_msg_bit_lengths(const uint64_t *lens, const int64_t *off, int n_msgs,
 // reach the percentage mark (the caller takes that message through urhgpu_msg_plateaus with a larger window).  Messages whose
 // tolerance is positive (glitches: merge_plateaus walks the sequence) or whose lengths overflow the table are decided from their
 // sequences, fetched in a second copy -- the same arithmetic as urhgpu_msg_bit_lengths.
-int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
-                                 int percentage, int64_t extra_window, int64_t *tol_out, int64_t *bitlen_out) {
-    if (!ctx || n < 0 || n_msgs < 0 || percentage < 0 || extra_window < 0 || (n_msgs > 0 && (!ranges || !centers || !tol_out || !bitlen_out || !d_x)))
+static int plateau_decisions_impl(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
+                                  int percentage, int64_t extra_window, int64_t *tol_out, int64_t *bitlen_out, EstChain *chain) {
+    if (!ctx || n < 0 || n_msgs < 0 || percentage < 0 || extra_window < 0 || (n_msgs > 0 && (!ranges || (!centers && !chain) || !tol_out || !bitlen_out || !d_x)))
         return URHGPU_ERR_ARG;
     if (n_msgs == 0) return URHGPU_OK;
     URH_HIP(hipSetDevice(ctx->device));
@@ -1402,15 +1432,17 @@ int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, c
         const int64_t limit = ((int64_t)percentage * len) / 100;
         windows[(size_t)m] = std::min<int64_t>(len, limit + extra_window);
     }
-    URH_TRY(join_tail(ctx));
+    if (!chain) { URH_TRY(join_tail(ctx)); }
     MsgBatch b;
     URH_TRY(build_batch(ctx, ranges, n_msgs, n, windows.data(), b));
-    for (int m = 0; m < n_msgs; ++m) b.host[(size_t)m].center = centers[m];
+    for (int m = 0; m < n_msgs; ++m) b.host[(size_t)m].center = chain ? __builtin_nan("") : centers[m];
     const int64_t cap_pairs = std::max<int64_t>(4096, (int64_t)n_msgs * 256);     // a message beyond its share of the pool is decided from its sequence
     const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)(b.n_tiles + 1) * (sizeof(MsgTile) + 4 + 8) + (size_t)std::max<int64_t>(n, 1) * 4 +
                         (size_t)cap_pairs * 16 + 10 * 256;
-    URH_TRY(ctx->arena.reserve(need));
-    ctx->arena.reset();
+    if (!chain) {                                            // (a chained call: behind stage 1's scratch, in the reservation made for both)
+        URH_TRY(ctx->arena.reserve(need));
+        ctx->arena.reset();
+    }
     MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
     MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
     int32_t *d_cnt = (int32_t *)ctx->arena.take((size_t)b.n_tiles * 4);
@@ -1421,6 +1453,7 @@ int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, c
     if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_edges || !d_pool_count || !d_pool) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
     URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
+    if (chain) hipLaunchKernelGGL(k_me_chain_center, dim3((unsigned)((n_msgs + 63) / 64)), dim3(64), 0, s, chain->d_st1, d_st, n_msgs);
     hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
     URH_HIP(hipMemsetAsync(d_pool_count, 0, 8, s));
     const unsigned gt = (unsigned)b.n_tiles;
@@ -1433,17 +1466,20 @@ int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, c
     // states, pool fill and (speculatively) the first pairs of the pool land in the context's pinned zone in ONE round trip when they fit
     unsigned long long pool_used = 0;
     const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState), st_pad = (st_bytes + 255) & ~size_t(255);
-    const bool pinned = ctx->h_small && st_pad + 256 + 4096 <= kSmallPinned;
-    const int64_t spec_pairs = pinned ? std::min<int64_t>(std::min<int64_t>(cap_pairs, 8192), (int64_t)((kSmallPinned - st_pad - 256) / 16)) : 0;
-    URH_HIP(hipMemcpyAsync(pinned ? (void *)ctx->h_small : (void *)b.host.data(), d_st, st_bytes, hipMemcpyDeviceToHost, s));
-    URH_HIP(hipMemcpyAsync(pinned ? (void *)(ctx->h_small + st_pad) : (void *)&pool_used, d_pool_count, 8, hipMemcpyDeviceToHost, s));
-    if (spec_pairs > 0) URH_HIP(hipMemcpyAsync(ctx->h_small + st_pad + 256, d_pool, (size_t)spec_pairs * 16, hipMemcpyDeviceToHost, s));
+    const size_t zone0 = chain ? chain->pinned_used : 0;     // (a chained call: stage 1's states lie in front)
+    const bool pinned = ctx->h_small && zone0 + st_pad + 256 + 4096 <= kSmallPinned;
+    char *zone = pinned ? ctx->h_small + zone0 : nullptr;
+    const int64_t spec_pairs = pinned ? std::min<int64_t>(std::min<int64_t>(cap_pairs, 8192), (int64_t)((kSmallPinned - zone0 - st_pad - 256) / 16)) : 0;
+    URH_HIP(hipMemcpyAsync(pinned ? (void *)zone : (void *)b.host.data(), d_st, st_bytes, hipMemcpyDeviceToHost, s));
+    URH_HIP(hipMemcpyAsync(pinned ? (void *)(zone + st_pad) : (void *)&pool_used, d_pool_count, 8, hipMemcpyDeviceToHost, s));
+    if (spec_pairs > 0) URH_HIP(hipMemcpyAsync(zone + st_pad + 256, d_pool, (size_t)spec_pairs * 16, hipMemcpyDeviceToHost, s));
     URH_HIP(hipStreamSynchronize(s));
-    if (pinned) { memcpy(b.host.data(), ctx->h_small, st_bytes); memcpy(&pool_used, ctx->h_small + st_pad, 8); }
+    if (pinned) { memcpy(b.host.data(), zone, st_bytes); memcpy(&pool_used, zone + st_pad, 8); }
+    if (chain && chain->st1_pinned) memcpy(chain->b1.host.data(), ctx->h_small, (size_t)n_msgs * sizeof(MsgState));
     std::vector<uint64_t> pool((size_t)std::min<unsigned long long>(pool_used, (unsigned long long)cap_pairs) * 2);
     if (!pool.empty()) {
         const size_t have = std::min<size_t>(pool.size() / 2, (size_t)spec_pairs);
-        if (have > 0) memcpy(pool.data(), ctx->h_small + st_pad + 256, have * 16);
+        if (have > 0) memcpy(pool.data(), zone + st_pad + 256, have * 16);
         if (pool.size() / 2 > have) {
             URH_HIP(hipMemcpyAsync(pool.data() + 2 * have, d_pool + 2 * have, (pool.size() / 2 - have) * 16, hipMemcpyDeviceToHost, s));
             URH_HIP(hipStreamSynchronize(s));
@@ -1494,6 +1530,46 @@ int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, c
         };
         host_pool_run((int)todo.size(), todo.size() >= 16 ? 24 : 1, one);
     }
+    return URHGPU_OK;
+}
+
+int urhgpu_msg_plateau_decisions(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, const double *centers, int n_msgs,
+                                 int percentage, int64_t extra_window, int64_t *tol_out, int64_t *bitlen_out) {
+    if (!centers) return URHGPU_ERR_ARG;
+    return plateau_decisions_impl(ctx, d_x, n, ranges, centers, n_msgs, percentage, extra_window, tol_out, bitlen_out, nullptr);
+}
+
+// urhgpu_msg_center_stats followed by urhgpu_msg_plateau_decisions with the picked centers, in ONE native call: no host round trip between
+// the stages (AutoInterpretation.py:397-433 per message: detect_center, get_plateau_lengths(center), tolerance / merge / bit length).  A
+// message whose center needs the host (peak_flag 2: more bins than the pool holds; 3: a tie np.argsort decides) comes back with its flag
+// and tol_out = bitlen_out = -4: the caller settles its center and repeats the second stage for it.  URHGPU_ERR_UNSUPPORTED: the
+// messages' histogram pool would not fit one batch (take the two calls).
+int urhgpu_msg_estimate(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int64_t *ranges, int n_msgs, int64_t max_bins, int percentage,
+                        int64_t extra_window, double *out_stats, double *out_center, int32_t *out_flag, int64_t *tol_out, int64_t *bitlen_out) {
+    if (!ctx || n < 0 || n_msgs < 0 || max_bins < 1 || percentage < 0 || extra_window < 0 ||
+        (n_msgs > 0 && (!ranges || !out_stats || !out_center || !out_flag || !tol_out || !bitlen_out || !d_x)))
+        return URHGPU_ERR_ARG;
+    if (n_msgs == 0) return URHGPU_OK;
+    if ((size_t)n_msgs * (size_t)max_bins * 4 > kCenterBatchBytes) return URHGPU_ERR_UNSUPPORTED;
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    // one reservation for both stages (a reallocation between them would take stage 1's states away): bounds of their tile tables
+    const size_t tiles_max = (size_t)(n / kMeTile + n_msgs + 2);
+    const int64_t cap_pairs = std::max<int64_t>(4096, (int64_t)n_msgs * 256);
+    const size_t need1 = (size_t)n_msgs * sizeof(MsgState) + (tiles_max + 1) * (sizeof(MsgTile) + 4 + 8 + 8 + 4 + kLeavesPerTile * 4) + (size_t)n * 4 +
+                         (size_t)n_msgs * (size_t)max_bins * 4 + 17 * 256;
+    const size_t need2 = (size_t)n_msgs * sizeof(MsgState) + (tiles_max + 1) * (sizeof(MsgTile) + 4 + 8) + (size_t)std::max<int64_t>(n, 1) * 4 + (size_t)cap_pairs * 16 + 10 * 256;
+    URH_TRY(ctx->arena.reserve(need1 + need2 + 4096));
+    EstChain chain;
+    URH_TRY(center_stats_batch(ctx, d_x, n, ranges, n_msgs, max_bins, out_stats, nullptr, out_center, out_flag, &chain));
+    URH_TRY(plateau_decisions_impl(ctx, d_x, n, ranges, nullptr, n_msgs, percentage, extra_window, tol_out, bitlen_out, &chain));
+    if (!chain.st1_pinned) {                                 // (states too many for the pinned zone: fetched now)
+        URH_HIP(hipMemcpy(chain.b1.host.data(), chain.d_st1, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost));
+    }
+    std::vector<unsigned int> none;
+    center_stats_collect(chain.b1, n_msgs, max_bins, none, out_stats, nullptr, out_center, out_flag);
+    for (int m = 0; m < n_msgs; ++m)
+        if (out_flag[m] == 2 || out_flag[m] == 3) { tol_out[m] = -4; bitlen_out[m] = -4; }
     return URHGPU_OK;
 }
 

@@ -413,6 +413,44 @@ def centers_array(pipe, data, message_indices, max_bins: int = 4096) -> np.ndarr
     _lib.check(lib.urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
                                            n_msgs, max_bins, stats.ctypes.data_as(C.c_void_p), None, cen.ctypes.data_as(C.c_void_p),
                                            flag.ctypes.data_as(C.c_void_p)))
+    return _settle_centers(pipe, x, ranges, cen, flag, max_bins)
+
+
+def centers_and_decisions(pipe, data, message_indices, percentage: int = 25, max_bins: int = 4096):
+    """(centers float64 with NaN = none, tolerance, bit_length) of every message from ONE native call (urhgpu_msg_estimate: center
+    statistics, then plateau boundaries and length counts with the centers still on the device); tolerance / bit_length as
+    _plateau_decisions gives them.  Messages whose center the host has to settle (more bins than the pool holds, a tie numpy decides)
+    get their second stage in a call of their own; a capture whose histogram pool does not fit one batch takes the two calls."""
+    x = _dev_f32(pipe, data)
+    n_msgs = len(message_indices)
+    if n_msgs == 0:
+        return np.zeros(0, np.float64), np.zeros(0, np.int64), np.zeros(0, np.int64)
+    ranges = np.ascontiguousarray(message_indices, dtype=np.int64).reshape(-1, 2)
+    stats = np.zeros((n_msgs, 8), dtype=np.float64)
+    cen = np.zeros(n_msgs, dtype=np.float64)
+    flag = np.zeros(n_msgs, dtype=np.int32)
+    tol = np.zeros(n_msgs, dtype=np.int64)
+    bl = np.zeros(n_msgs, dtype=np.int64)
+    st = _lib.load().urhgpu_msg_estimate(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p), n_msgs, max_bins,
+                                         int(percentage), 1 << 16, stats.ctypes.data_as(C.c_void_p), cen.ctypes.data_as(C.c_void_p),
+                                         flag.ctypes.data_as(C.c_void_p), tol.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p))
+    if st == _lib.ERR_UNSUPPORTED:
+        centers = centers_array(pipe, x, ranges, max_bins)
+        t2, b2 = _plateau_decisions(pipe, x, ranges, centers.astype(np.float32).astype(np.float64), percentage)
+        return centers, t2, b2
+    _lib.check(st)
+    late = np.nonzero((flag == 2) | (flag == 3))[0]
+    centers = _settle_centers(pipe, x, ranges, cen, flag, max_bins)
+    if len(late):
+        sub = np.ascontiguousarray(ranges[late])
+        t2, b2 = _plateau_decisions(pipe, x, sub, centers[late].astype(np.float32).astype(np.float64), percentage)
+        tol[late], bl[late] = t2, b2
+    return centers, tol, bl
+
+
+def _settle_centers(pipe, x, ranges, cen, flag, max_bins):
+    """the centers of a batch as a float64 array (NaN: none), the messages the device could not settle (flag 2, 3) decided here"""
+    lib = _lib.load()
     centers = np.where(flag == 1, cen, np.nan)
 
     def put(m, c):
@@ -609,14 +647,13 @@ def estimate_dev(pipe, iq, noise: float = None, modulation: str = None, timings:
     if keep is not None:                             # the demodulated signal and what it was demodulated with: the caller's Signal.qad cache
         keep.update(qad=data, mod=mod, noise=float(noise))
     lap("afp_demod_ms")
-    center_of = centers_array(pipe, data, message_indices)          # float64, NaN = no center
-    lap("centers_ms")
+    # centers (float64, NaN = no center) and the plateau decisions of every message: ONE native call (round 5; two until then, with the
+    # centers crossing PCIe twice in between)
     ranges = np.ascontiguousarray(message_indices, dtype=np.int64).reshape(-1, 2)
-    has_center = center_of == center_of
-    cen = center_of.astype(np.float32).astype(np.float64)           # get_plateau_lengths takes the center as a C float
     x32 = _dev_f32(pipe, data)
-    tol_raw, bl_raw = _plateau_decisions(pipe, x32, ranges, cen, 25) if len(ranges) else (np.zeros(0, np.int64), np.zeros(0, np.int64))
-    lap("plateaus_ms")
+    center_of, tol_raw, bl_raw = centers_and_decisions(pipe, x32, ranges, 25)
+    has_center = center_of == center_of
+    lap("centers_and_plateaus_ms")
     if (tol_raw == -3).any():                        # a message whose first plateau outlasts the search window: the per-message path
         all_centers = [None if c != c else np.float64(c) for c in center_of.tolist()]
         decisions = bit_lengths_batched(plateau_lengths_batched(pipe, data, message_indices, all_centers))
