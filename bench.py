@@ -664,7 +664,7 @@ def run_extras(pipe, dev, args):
     return out
 
 
-def sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, fir_taps, halo_given, left_halo, with_oracle, steps=0):
+def sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, fir_taps, halo_given, left_halo, with_oracle, steps=0, left_raw=None):
     """N > 1: the sharded result proves itself in the same run (every rank calls this; rank 0 returns the record).  One more pass with
     bit_sample_pos on; rank 0 gathers every rank's piece (pulse-table rows that end in the shard, their bits, pauses, offsets, positions)
     and every rank's SHARD, and compares
@@ -687,7 +687,12 @@ def sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, fir_ta
     was_host = pipe.engine.host_results
     pipe.engine.host_results = False
 
+    raw_given = fir_taps is not None and (rank == 0 or left_raw is not None)     # the FIR-halo variant with the raw halo handed over: no exchange for it
+
     def one():
+        if fir_taps is not None and raw_given:
+            x, fh = pipe.fir_filter(iq, fir_taps, left_raw=left_raw, want_halo=True)
+            return pipe.iq_to_bits(x, p_pos, want_qad=True, halo_given=True, left_halo=fh)
         x = pipe.fir_filter(iq, fir_taps) if fir_taps is not None else iq
         return pipe.iq_to_bits(x, p_pos, want_qad=True, halo_given=hg, left_halo=left_halo if hg else None)
     rec = {}
@@ -729,7 +734,17 @@ def sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, fir_ta
     rec["qad_rank0_shard_mismatches"] = int((res.qad.view(torch.int32) != r1.qad[:n].view(torch.int32)).sum().item())
     ok = all(rec[nm + "_equal"] for nm in names) and rec["qad_rank0_shard_mismatches"] == 0
     if fir_taps is not None:
-        rec["halo_bytes_per_rank"] = (int(fir_taps.shape[0]) - 1) * 8
+        m_t = int(fir_taps.shape[0])
+        rec["halo_bytes_per_rank"] = (m_t + 1) * 8 if raw_given else (m_t - 1) * 8
+        rec["halo"] = ("the m + 1 raw samples before the shard come WITH the shard (their last m - 1 are the filter's history, filtering them gives the two "
+                       "filtered samples the demodulation needs): no exchange") if raw_given else "exchanged: one all-gather for the filter, one for the demodulation"
+        rec["all_gathers_per_pass"] = 2 if raw_given else 4
+        if rec.get("ms_per_step"):
+            t_s = rec["ms_per_step"] * 1e-3
+            rec["roofline"] = {"bytes_per_sample": 28, "what": "8 read + 8 written (the filtered IQ is materialised: it replaces the capture, Signal.filter_range) + 8 read + 4 written (qad)",
+                               "hbm_frac_of_8TBs": round(n * 28 / t_s / 8e12, 4),
+                               "valu_flop_per_sample": 8 * m_t, "valu_frac_of_78.6_TFLOPs_non_fma": round(n * 8 * m_t / t_s / 78.6e12, 4),
+                               "bound": "fp32 VALU (the reference's strict accumulation order: no FMA, no MFMA)"}
     if with_oracle and fir_taps is None:
         try:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -880,12 +895,14 @@ def main():
     # 16 bytes a loader reads with the shard), so a pass needs two all-gathers -- summaries, flags -- and no halo exchange;
     # URH_BENCH_HALO_EXCHANGE=1 exchanges the halos instead (three all-gathers).  The FIR variant filters first: its halo is exchanged.
     halo_given = sharded and fir_taps is None and os.environ.get("URH_BENCH_HALO_EXCHANGE") != "1"
-    left_halo = None
-    if halo_given and rank > 0:
+    left_halo = left_raw65 = None
+    if sharded and rank > 0:
         prev, _ = (fsk_capture if args.torch_capture else spec_fsk_capture)(1, dev, **(dict(seed=1234, sps=sps, first_segment=rank * args.segments - 1)
                                                                                    if args.torch_capture else
                                                                                    dict(first_segment=rank * args.segments - 1, sps=sps)))
-        left_halo = prev[-2:].clone()
+        if halo_given:
+            left_halo = prev[-2:].clone()
+        left_raw65 = prev[-65:].clone()                      # the FIR-halo variant: 64 taps + 1 raw samples before the shard, handed over with it
         del prev
 
     if args.selftest_only:
@@ -1364,11 +1381,11 @@ def main():
                 from urh_amd.synth import spec_fir_taps
                 taps64 = torch.from_numpy(spec_fir_taps().view("float32").reshape(-1, 2).copy()).to(dev)
                 fir_halo_rec = sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, taps64, False, None, with_oracle=False,
-                                                  steps=min(args.steps, 10))
+                                                  steps=min(args.steps, 10), left_raw=left_raw65)
                 if fir_halo_rec is not None:
-                    fir_halo_rec["what"] = ("configs[3] FIR-halo variant: every rank filters its shard with the 64-tap complex FIR, its left neighbour's last 63 samples "
-                                            "as history (one all-gather of 504 bytes per rank), then the sharded IQ->bits pass with its halo exchanged "
-                                            "(three all-gathers); device-resident steps, max over ranks")
+                    fir_halo_rec["what"] = ("configs[3] FIR-halo variant: every rank filters its shard with the 64-tap complex FIR, the 63 samples before the shard "
+                                            "as history, then the sharded IQ->bits pass on the filtered shard (two all-gathers: summaries, flags); the halo -- 65 raw "
+                                            "samples, 520 bytes -- comes with the shard; device-resident steps, max over ranks")
                     fir_halo_rec["Msamples_per_s"] = round(n * world / (fir_halo_rec["ms_per_step"] * 1e-3) / 1e6, 1)
         except Exception as exc:                                 # noqa: BLE001 (said in the line; the timed numbers stand)
             shard_parity = {"error": repr(exc)[:300]}

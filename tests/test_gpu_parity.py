@@ -1415,6 +1415,30 @@ def test_sharded_fir_halo_then_bits(pipe, oracle):
     assert cbits_equal(np.concatenate(filt).view(np.complex64).reshape(-1), want_f)
     for k, (a, b) in enumerate(zip(stitch(out), want)):
         assert np.array_equal(a, b), k
+    # the same with NO halo exchange (round 5): every rank but the first is handed the m + 1 raw samples before its shard with the shard;
+    # their last m - 1 are the filter's history, filtering them gives the two filtered samples the demodulation needs
+    shared2 = ThreadComm.Shared(world)
+    out2, filt2, err2 = [None] * world, [None] * world, []
+
+    def work2(r):
+        try:
+            sp = ShardedPipeline(GpuShardEngine(0), ThreadComm(shared2, r))
+            a, b = bounds[r]
+            raw = dev_iq[a - (m + 1):a].contiguous() if r > 0 else None
+            f, halo = sp.fir_filter(dev_iq[a:b], dev_taps, left_raw=raw, want_halo=True)
+            filt2[r] = f.cpu().numpy()
+            out2[r] = sp.iq_to_bits(f, p, want_qad=True, pos_base=a, n_total=n, halo_given=True, left_halo=halo)
+        except BaseException as e:          # noqa: BLE001
+            err2.append(e)
+            shared2.barrier.abort()
+    ts = [threading.Thread(target=work2, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    if err2:
+        raise err2[0]
+    assert cbits_equal(np.concatenate(filt2).view(np.complex64).reshape(-1), want_f)
+    for k, (a, b) in enumerate(zip(stitch(out2), want)):
+        assert np.array_equal(a, b), k
 
 
 def test_get_protocol_from_signal_goldens(pipe):
