@@ -14,7 +14,7 @@ for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=Tru
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 rows = (1 << 27) // 128
-names = {"<0, 4, 1, true, true, 1, false>": "complex64", "<0, 3, 1, true, true, 1, false>": "int16", "<0, 0, 1, true, true, 1, false>": "int8"}
+names = {"<0, 4, 1, true, true, 1, false>": "complex64", "<0, 2, 1, true, true, 1, false>": "int16", "<0, 0, 1, true, true, 1, false>": "int8"}
 print("# k_demod_runs_bp, 2^27 samples = %d rows of 128: wave-instructions per launch (mean over the launches of tools/dtype_probe.py) and per row" % rows)
 for k, cs in sorted(acc.items()):
     label = next((v for s, v in names.items() if s in k), None)
@@ -25,6 +25,6 @@ for k, cs in sorted(acc.items()):
     if "SQ_INSTS_VALU" in m:
         print(f"{'':10s} per row: VALU {m['SQ_INSTS_VALU'] / rows:.1f}  SALU {m.get('SQ_INSTS_SALU', 0) / rows:.1f}  VMEM rd {m.get('SQ_INSTS_VMEM_RD', 0) / rows:.2f} wr {m.get('SQ_INSTS_VMEM_WR', 0) / rows:.2f}  LDS {m.get('SQ_INSTS_LDS', 0) / rows:.2f}")
     if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m:
-        print(f"{'':10s} VALU issue: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE) = {m['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * m['GRBM_GUI_ACTIVE']):.3f}")
+        print(f"{'':10s} VALU issue: SQ_ACTIVE_INST_VALU x 4 cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs) = {m['SQ_ACTIVE_INST_VALU'] * 4 / (1024 * m['GRBM_GUI_ACTIVE'] / 8):.3f}  (un-pipelined passes: all 256 CUs)")
 PY
 rm -rf $OUT

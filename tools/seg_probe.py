@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Round 4: what a streamed pass looks like on the GPU.  python tools/r4_seg_probe.py <segments> <shape> [singles] [burst]
+"""Round 4: what a streamed pass looks like on the GPU.  python tools/seg_probe.py <segments> <unused> [singles] [burst]
 single captures (push + flush, the machine idle before each), then a burst of back-to-back pushes; run under rocprofv3 --kernel-trace
-and read the timeline with tools/r4_seg_timeline.py."""
+and read the timeline with tools/seg_timeline.py."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,9 +16,7 @@ dev = torch.device("cuda", 0)
 iq, _ = spec_fsk_capture(int(os.environ.get("SEGMENTS", "128")), dev)
 n = iq.shape[0]
 p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, False)
-tuning = {"stream_policy": int(os.environ.get("POLICY", "1")), "stream_segments": S, "stream_shape": shape, "stream_bits_segments": int(os.environ.get("SB", "3"))}
-if "URH_PACK_BLOCKS" in os.environ:
-    tuning["pack_blocks"] = int(os.environ["URH_PACK_BLOCKS"])
+tuning = {"stream_policy": int(os.environ.get("POLICY", "1")), "stream_segments": S}
 pipe = DevicePipeline(0, pipelined=True, tuning=tuning)
 pipe.reserve(n, p)
 st = pipe.stream(n, p, want_qad=True, want_pos=False)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/r4_seg_timeline.py <rocprofv3 dir> [which]: kernels of the LAST single capture of tools/r4_seg_probe.py (the last hot kernel that
+"""tools/seg_timeline.py <rocprofv3 dir> [which]: kernels of the LAST single capture of tools/seg_probe.py (the last hot kernel that
 is followed by an idle gap before the burst) relative to the start of its hot kernel; and 3 passes from the middle of the burst."""
 import csv, glob, os, sys
 f = glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)[0]

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/r4_upload_trace.py <rocprofv3 dir>: memory copies and kernels of the LAST upload pass, relative to its first copy"""
+"""tools/upload_trace.py <rocprofv3 dir>: memory copies and kernels of the LAST upload pass, relative to its first copy"""
 import csv, glob, os, sys
 d = sys.argv[1]
 def load(pat):

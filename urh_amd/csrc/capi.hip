@@ -168,11 +168,11 @@ int prof_end_record(urhgpu_ctx *ctx, hipStream_t s) {
     return URHGPU_OK;
 }
 
-// Which captures take the CU-masked hot stream in pipelined mode (A/B build knob -DURH_MASK_ALL_DTYPES=1: every sample type)
-#ifndef URH_MASK_ALL_DTYPES
-#define URH_MASK_ALL_DTYPES 0
-#endif
-static inline bool masked_hot_stream(const urhgpu_params *p) { return URH_MASK_ALL_DTYPES || p->dtype == URHGPU_DT_F32; }
+// Which captures take the CU-masked hot stream in pipelined mode: all of them.  Until round 5 integer captures kept the caller's stream --
+// their kernel ALONE loses 2-5 % on 224 CUs (it is VALU-bound: profiles/r03a_mask_policy_probe.txt) --, but beside a hot kernel that
+// fills all 256 CUs the previous pass's tail finds no wave slots and the passes serialise: pipelined steps through the capture stream
+// 0.348 -> 0.280 ms (int16) and 0.361 -> 0.276 ms (int8) with the mask, complex64 unchanged (profiles/r05_dtype_stream_ab.txt).
+static inline bool masked_hot_stream(const urhgpu_params *p) { (void)p; return true; }
 
 // pipelined passes: the stream the hot kernel is launched on -- the CU-masked private one (see urhgpu_ctx_set_pipelined), ordered
 // behind what the caller has queued on the context's stream so far
