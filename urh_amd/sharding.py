@@ -169,9 +169,16 @@ class RcclComm:
                 box["rc"] = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
             except Exception as exc:                          # noqa: BLE001
                 box["exc"] = exc
+            if box.get("abandoned") and box.get("rc") == 0:   # it came up after the timeout, when every rank had fallen back: nobody will use it
+                try:
+                    lib.ncclCommDestroy(comm)
+                except Exception:                             # noqa: BLE001
+                    pass
         th = threading.Thread(target=init, daemon=True)
         th.start()
         th.join(cls.INIT_TIMEOUT_S)
+        if th.is_alive():
+            box["abandoned"] = True
         ok = (not th.is_alive()) and box.get("rc") == 0
         if not ok:
             err = (f"rank {rank}: ncclCommInitRank did not return within {cls.INIT_TIMEOUT_S:.0f} s" if th.is_alive() else
