@@ -41,6 +41,8 @@ import socket
 import sys
 import time
 
+_FLAG_DEV = None          # where the ranks' scalar reductions live: the GPU under nccl, the host under a gloo group (main())
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -704,7 +706,7 @@ def sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, fir_ta
         for _ in range(steps):
             one()
         pipe.ctx.join(); torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=_FLAG_DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         rec["ms_per_step"] = round(float(t.item()) / steps * 1e3, 4)
         rec["steps"] = steps
@@ -715,7 +717,14 @@ def sharded_self_check(torch, dist, pipe, iq, p, rank, world, local_rank, fir_ta
     pieces = [None] * world if rank == 0 else None
     dist.gather_object(pc, pieces, dst=0)
     whole = torch.empty((world * n, 2), dtype=iq.dtype, device=dev) if rank == 0 else None
-    dist.gather(iq, [whole[r * n:(r + 1) * n] for r in range(world)] if rank == 0 else None, dst=0)
+    if _FLAG_DEV.type == "cpu":                              # (a gloo group: through the host)
+        parts = [torch.empty((n, 2), dtype=iq.dtype) for _ in range(world)] if rank == 0 else None
+        dist.gather(iq.cpu(), parts, dst=0)
+        if rank == 0:
+            for r in range(world):
+                whole[r * n:(r + 1) * n].copy_(parts[r])
+    else:
+        dist.gather(iq, [whole[r * n:(r + 1) * n] for r in range(world)] if rank == 0 else None, dst=0)
     torch.cuda.synchronize()
     pipe.engine.host_results = was_host
     if rank != 0:
@@ -846,8 +855,16 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    # URH_BENCH_SHARE_GPU=1 + URH_BENCH_DIST_BACKEND=gloo (tools/two_ranks_one_gpu.sh): every rank on device 0 and the group over gloo --
+    # RCCL refuses two ranks on one device -- so that a 1-GPU box executes the N > 1 line with real processes (rank > 0 branches,
+    # exchanges, the self-check); its timings mean nothing
+    if os.environ.get("URH_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
+    backend = os.environ.get("URH_BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    global _FLAG_DEV
+    _FLAG_DEV = dev if backend == "nccl" else torch.device("cpu")
     dist = None
     # URH_BENCH_FORCE_SHARDED=1 (with torch.distributed.run --nproc-per-node 1) drives the sharded code path -- RCCL process
     # group, all-gathers, urhgpu_shard_* phases -- on a single GPU: a smoke test of the N > 1 plumbing on a 1-GPU box.
@@ -855,7 +872,10 @@ def main():
     sharded = world > 1 or force_sharded
     if sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     sps, tol = 100, 5
     p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, tol, sps, 0.1, 8, True)
@@ -1164,7 +1184,7 @@ def main():
         torch.cuda.synchronize()
         headline_dt = time.perf_counter() - t0
         kernel_ms = pipe.ctx.profile_end()
-        t = torch.tensor([headline_dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([headline_dt], dtype=torch.float64, device=_FLAG_DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         headline_dt = float(t.item())
         stream_rec = {"d2h_bytes_per_step": host_piece.blob_bytes,
@@ -1200,7 +1220,7 @@ def main():
     else:
         pipe.ctx.profile_end()
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=_FLAG_DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     device_only_ms = dt / args_steps_dev * 1e3

@@ -45,6 +45,14 @@ class TorchDistComm:
         """Enqueue the all-gather and return a function that waits for it (stream-level on GPU tensors: the host does not
         block) and returns the gathered tensor: work enqueued in between overlaps the collective."""
         import torch
+        if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+            # GPU tensors over a gloo group (two ranks sharing ONE GPU, which RCCL refuses: tools/two_ranks_one_gpu.sh): through the host
+            torch.cuda.current_stream(t.device).synchronize()
+            host = t.contiguous().cpu()
+            out_h = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype)
+            self.dist.all_gather_into_tensor(out_h.view(-1).view(torch.uint8), host.view(-1).view(torch.uint8), group=self.group)
+            out_d = out_h.to(t.device)
+            return lambda: out_d
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
         # gathered as raw bytes: halos of uint16 captures are torch.uint16 tensors, which the nccl / gloo backends do not all take
         work = self.dist.all_gather_into_tensor(out.view(-1).view(torch.uint8), t.contiguous().view(-1).view(torch.uint8),
@@ -164,8 +172,15 @@ class RcclComm:
         comm = C.c_void_p()
         box = {}
 
+        # The communicator binds to the CALLING THREAD's current device, and a new thread starts on device 0 whatever the process has
+        # selected: without the set_device below every rank of a node with all GPUs visible would offer device 0 to RCCL
+        # (ncclInvalidUsage, the same refusal as two ranks on one GPU -- profiles/r05_rccl_two_ranks_one_gpu.txt).
+        cur_dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+
         def init():
             try:
+                if cur_dev is not None:
+                    torch.cuda.set_device(cur_dev)
                 box["rc"] = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
             except Exception as exc:                          # noqa: BLE001
                 box["exc"] = exc
