@@ -347,3 +347,81 @@ def test_latency_setting_one_capture_at_a_time(oracle, one_tile_chunks):
     pipe.ctx.set_tuning("stream_latency", 0)
     for i, iq in enumerate(caps):
         _assert_equal(got[i], _oracle_flat(oracle, iq, p), f"capture {i}")
+
+
+def _synth_ask(n, sps, seed, noise, pause_every, pause_len, dtype):
+    """seeded OOK-like capture: a carrier keyed by random symbols (amplitudes 1.0 / 0.15), AWGN, optional silent gaps"""
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2, n // sps + 1)
+    env = np.repeat(np.where(bits == 1, 1.0, 0.15), sps)[:n]
+    phase = 2 * np.pi * 0.013 * np.arange(n)
+    iq = np.stack([env * np.cos(phase), env * np.sin(phase)], axis=1)
+    if pause_every:
+        for a in range(pause_every, n, pause_every + pause_len):
+            iq[a:a + pause_len] = 0
+    iq = iq + noise * rng.standard_normal((n, 2))
+    if np.dtype(dtype) == np.float32:
+        return iq.astype(np.float32)
+    info = np.iinfo(dtype)
+    scale = (info.max - info.min) / 2 * 0.7
+    off = (info.max + info.min + 1) / 2
+    return np.clip(np.round(iq * scale + off), info.min, info.max).astype(dtype)
+
+
+def test_stream_fuzz_extended(oracle, one_tile_chunks):
+    """the long form of the differential fuzz (URH_FUZZ_ROUNDS rounds, default 6; URH_FUZZ_SEED): FSK and ASK, all five sample types, every
+    stream policy and segment count, the latency setting, qad wanted or not, positions shipped or not -- a stream per round, seven captures
+    of random length each, all against the oracle (signal_functions.pyx:333-495, ProtocolAnalyzer.py:262-330)"""
+    import os
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    rounds = int(os.environ.get("URH_FUZZ_ROUNDS", "6"))
+    seed0 = int(os.environ.get("URH_FUZZ_SEED", "0"))
+    n_max = 1 << 21
+    for s_i in range(rounds):
+        rng = np.random.default_rng([777, seed0, s_i])
+        policy = int(rng.choice([5, 1, 3, 4, 0, 2]))
+        segs = int(rng.integers(1, 10))
+        pipe = DevicePipeline(0, pipelined=True, tuning={"stream_policy": policy, "stream_segments": segs})
+        dtype = [np.float32, np.int16, np.int8, np.uint8, np.uint16][int(rng.integers(0, 5))]
+        mod = "FSK" if rng.random() < 0.6 else "ASK"
+        sps = int(rng.choice([5, 17, 100, 333]))
+        tol = int(rng.choice([0, 1, 5, 9, 40]))
+        bps, spacing = ((2, float(rng.choice([0.05, 0.3]))) if (mod == "FSK" and rng.random() < 0.3) else (1, 1.0))
+        want_pos = bool(rng.integers(0, 2))
+        want_qad = bool(rng.integers(0, 2))
+        latency = bool(rng.integers(0, 2))
+        scale = 1.0 if dtype == np.float32 else (float(np.iinfo(dtype).max) - float(np.iinfo(dtype).min)) / 2 * 0.7
+        if mod == "FSK":
+            noise_thr, center = float(rng.choice([0.0, 0.2])) * scale, float(rng.choice([0.0, 0.1, -0.2]))
+        else:
+            noise_thr, center = float(rng.choice([0.0, 0.05])) * scale, float(rng.choice([0.5, 0.4, 0.7])) * scale
+        p = DemodParams(mod, bps, noise_thr, center, spacing, tol, sps, 0.1, int(rng.choice([0, 1, 8])), want_pos)
+        st = pipe.stream(n_max, p, want_qad=want_qad, want_pos=want_pos, dtype=dtype, cap_rows=n_max // (tol + 1) + 2, latency=latency)
+        sizes = [int(x) for x in rng.choice([2048 * int(rng.integers(1, 1024)), 2048 * int(rng.integers(512, 1024)), int(rng.integers(3, 5000)),
+                                             int(rng.integers(5000, 900_000)), n_max], size=7)]
+        gen = synth_fsk if mod == "FSK" else None
+        caps = []
+        for k, n in enumerate(sizes):
+            nz = float(rng.choice([0.0, 0.03, 0.3])); pe = int(rng.choice([0, max(n // 3, 1), 2500])); pl = int(rng.choice([7, 130, 2100]))
+            caps.append(synth_fsk(n, sps=sps, seed=100000 * seed0 + 1000 * s_i + k, noise=nz, pause_every=pe, pause_len=pl, dtype=dtype) if gen
+                        else _synth_ask(n, sps, 100000 * seed0 + 1000 * s_i + k, nz, pe, pl, dtype))
+        dev = [torch.from_numpy(c).cuda() for c in caps]
+        take = (lambda r: _got(r)) if want_pos else (lambda r: (r.check().ppseq(), r.bits(), r.msg_off.copy(), r.pauses.copy()))
+        got = {}
+        for j, d in enumerate(dev):
+            r = st.push(d)
+            if r is not None:
+                got[r.seq] = take(r)
+            if latency and rng.random() < 0.5:
+                for r in st.flush():
+                    got[r.seq] = take(r)
+        for r in st.flush():
+            got[r.seq] = take(r)
+        st.close()
+        tag0 = (f"round {s_i} seed {seed0} ({mod}, {np.dtype(dtype).name}, sps {sps}, tol {tol}, order {2 ** bps}, policy {policy}, segments {segs}, "
+                f"latency {latency}, qad {want_qad}, pos {want_pos})")
+        for k, iq in enumerate(caps):
+            ref = _oracle_flat(oracle, iq, p)
+            _assert_equal(got[k], ref[:len(got[k])], f"{tag0} capture {k} ({sizes[k]} samples)")
+        del pipe
