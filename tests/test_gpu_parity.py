@@ -393,6 +393,61 @@ def test_sharded_equals_single_gpu(pipe, oracle, mod, world):
                 assert bits_equal(got_qad, want_qad)
 
 
+def test_sharded_fuzz_extended(pipe, oracle):
+    """long form of the sharded check (URH_FUZZ_ROUNDS rounds, default 6; URH_FUZZ_SEED): random world (2 .. 12), shard boundaries
+    anywhere (multiples of 8 samples; shards of a few samples, shards inside a pause, shards without a single run), FSK orders 2 / 4 and
+    ASK, float32 / int16 / int8 captures, halos exchanged or handed over: the stitched pieces equal ONE single-GPU pass (itself compared
+    with the oracle on the shorter captures), bit for bit, qad included (signal_functions.pyx:333-495 across shard boundaries)."""
+    import os
+    import torch
+    from test_sharding import run_threads
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.shard_engine import GpuShardEngine
+    from urh_amd.sharding import stitch
+    rounds = int(os.environ.get("URH_FUZZ_ROUNDS", "6"))
+    seed0 = int(os.environ.get("URH_FUZZ_SEED", "0"))
+    for it in range(rounds):
+        rng = np.random.default_rng([991, seed0, it])
+        world = int(rng.integers(2, 13))
+        n = int(rng.choice([int(rng.integers(8 * world + 8, 5000)), int(rng.integers(5000, 400_000)), int(rng.integers(400_000, 1 << 21))]))
+        n -= n % 8
+        sps = int(rng.choice([5, 20, 100, 333]))
+        dtype = [np.float32, np.int16, np.int8][int(rng.integers(0, 3))]
+        mod = "FSK" if rng.random() < 0.6 else "ASK"
+        bps, spacing = ((2, float(rng.choice([0.05, 0.3]))) if (mod == "FSK" and rng.random() < 0.3) else (1, 1.0))
+        tol = int(rng.choice([0, 1, 3, 9, 40]))
+        pe = int(rng.choice([0, max(n // 5, 1), 2500]))
+        iq = synth_fsk(n, sps=sps, seed=int(rng.integers(0, 1 << 30)), noise=float(rng.choice([0.0, 0.05, 0.3])), pause_every=pe,
+                       pause_len=int(rng.choice([7, 130, max(n // 23, 1)])), dtype=dtype)
+        scale = 1.0 if dtype == np.float32 else float(np.iinfo(dtype).max) * 0.7
+        if mod == "ASK":
+            env = np.repeat(rng.integers(0, 2, n // sps + 1), sps)[:n]
+            iq = (iq.astype(np.float32) * (0.05 + 0.95 * env)[:, None]).astype(dtype)
+            noise, center = float(rng.choice([0.0, 0.2])) * scale, float(rng.choice([0.35, 0.5])) * scale
+        else:
+            noise, center = float(rng.choice([0.0, 0.2])) * scale, float(rng.choice([0.0, 0.1, -0.2]))
+        p = DemodParams(mod, bps, noise, center, spacing, tol, sps, 0.1, int(rng.choice([0, 1, 8])), True)
+        dev_iq = torch.from_numpy(iq).cuda()
+        single = pipe.iq_to_bits_checked(dev_iq, p, want_qad=True)
+        want = (single.ppseq(),) + tuple(single.flat())
+        want_qad = single.qad.cpu().numpy().copy()
+        if n <= 400_000:
+            qad = oracle.afp_demod(iq, noise, mod, 2 ** bps)
+            pp = oracle.grab_pulse_lens(qad, center, tol, mod, sps, bps, spacing)
+            assert np.array_equal(want[0], pp) and bits_equal(want_qad, qad), (it, seed0)
+        cuts = [0] + sorted(int(c) * 8 for c in rng.choice(np.arange(1, n // 8), size=world - 1, replace=False)) + [n]
+        bounds = [(cuts[r], cuts[r + 1]) for r in range(world)]
+        shards = [dev_iq[a:b] for a, b in bounds]
+        halos = None if rng.random() < 0.5 else [None] + [dev_iq[a - 2:a].clone() for a, _ in bounds[1:]]
+        tag = (it, seed0, mod, 2 ** bps, np.dtype(dtype).name, world, n, sps, tol, bounds, halos is not None)
+        res = run_threads(world, lambda r: GpuShardEngine(0, worst_case_rows=True), shards, bounds, n, p, halos)
+        got = stitch(res)
+        for k, (a, b) in enumerate(zip(got, want)):
+            assert np.array_equal(a, b), (tag, k, len(a), len(b))
+        got_qad = np.concatenate([r.qad.cpu().numpy() for r in res])
+        assert bits_equal(got_qad, want_qad), tag
+
+
 # ---- filters, magnitudes, noise estimator ------------------------------------------------------------------
 def cbits_equal(a, b):
     a, b = np.ascontiguousarray(a, np.complex64).view(np.uint32), np.ascontiguousarray(b, np.complex64).view(np.uint32)

@@ -74,8 +74,12 @@ class GpuShardEngine(DevicePipeline):
     rotation, the copy sized by the previous pass's blob (what a prediction misses is fetched when the result is looked at):
     ShardResult.host().  The same window as the single-GPU CaptureStream, per rank."""
 
-    def __init__(self, device: int = 0, pipelined: bool = False, tuning=None, tail_stream_priority: int = 0, host_results: bool = False):
+    def __init__(self, device: int = 0, pipelined: bool = False, tuning=None, tail_stream_priority: int = 0, host_results: bool = False,
+                 worst_case_rows: bool = False):
+        """worst_case_rows: size the pulse table for one row per (tolerance + 1) samples (a shard of noise) instead of the default
+        four rows per symbol, which a pass that needs more reports as ERR_CAPACITY"""
         super().__init__(device, pipelined=pipelined, tuning=tuning, tail_stream_priority=tail_stream_priority)
+        self.worst_case_rows = bool(worst_case_rows)
         self.host_results = bool(host_results)
         self._pass = 0
         self._hslots = None                                 # [(device blob, pinned host blob, copy-done event)] x 3
@@ -182,7 +186,7 @@ class GpuShardEngine(DevicePipeline):
         self._fir_keep = (x, h, left)
         return out if iq_local.dtype != torch.complex64 else torch.view_as_complex(out)
 
-    def _setup(self, iq, p, want_qad):
+    def _setup(self, iq, p, want_qad, n_total=0):
         torch = self.torch
         if iq.dtype == torch.complex64:
             iq = torch.view_as_real(iq)
@@ -191,7 +195,12 @@ class GpuShardEngine(DevicePipeline):
         npdt = _torch_dtype(iq)
         n = iq.shape[0]
         cp = p.to_c(npdt)
-        cap_rows, cap_bits, cap_msg, cap_pos = self.capacities(n, p)
+        cap_rows, cap_bits, cap_msg, cap_pos = self.capacities(n, p, (n // (p.tolerance + 1) + 2) if self.worst_case_rows else None)
+        # a rank owns the rows that END in its shard -- one that began in an earlier shard (a stuck carrier across the boundary) -- and, ASK,
+        # the equal-state rows of LATER shards merged into its last one: a row can span the whole capture, whatever the shard's size
+        extra = (max(int(n_total) - n, 0) // max(int(p.samples_per_symbol), 1) + 1) * int(p.bits_per_symbol)
+        cap_bits += extra
+        cap_pos += extra
         qad = self._buf("qad", (n,), torch.float32) if want_qad else None
         rows = self._buf("rows", (cap_rows, 2), torch.int64)
         bits = self._buf("bits", (cap_bits,), torch.uint8)
@@ -225,14 +234,14 @@ class GpuShardEngine(DevicePipeline):
 
     def runs_begin(self, iq, pos_base, n_total, rank, world, p, want_qad):
         """start the hot kernel on every chunk but the first while the halo all-gather is still in flight"""
-        iq, n, cp, o = self._setup(iq, p, want_qad)
+        iq, n, cp, o = self._setup(iq, p, want_qad, n_total)
         self._pre = (iq, n, cp, o)
         _lib.check(_lib.load().urhgpu_shard_prelaunch_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, int(pos_base), int(n_total),
                                                           int(rank), int(world), C.byref(cp), C.byref(o)))
 
     def runs_launch(self, iq, left, pos_base, n_total, rank, world, p, want_qad):
         """the whole hot launch: the halo came with the shard (no exchange)"""
-        iq, n, cp, o = self._setup(iq, p, want_qad)
+        iq, n, cp, o = self._setup(iq, p, want_qad, n_total)
         self._pre = (iq, n, cp, o)
         self._keep += (left,)
         _lib.check(_lib.load().urhgpu_shard_launch_dev(self.ctx.handle, C.c_void_p(iq.data_ptr()), n, int(pos_base), int(n_total),
@@ -246,7 +255,7 @@ class GpuShardEngine(DevicePipeline):
             iq, n, cp, o = pre
             self._pre = None
         else:
-            iq, n, cp, o = self._setup(iq, p, want_qad)
+            iq, n, cp, o = self._setup(iq, p, want_qad, n_total)
         self._keep += (left,)
         if left is not None and getattr(self, "tail_stream", None) is not None:
             left.record_stream(self.tail_stream)                # gathered under the caller's stream, read by the first chunk on the tail stream
