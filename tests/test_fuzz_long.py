@@ -1,0 +1,128 @@
+"""Long-form differential fuzzes of the state-carrying and order-sensitive kernels against the oracle (URH_FUZZ_ROUNDS rounds each,
+default a handful inside `-m gpu`; URH_FUZZ_SEED picks another stream of cases): the Costas loop's speculative chunk evaluation
+(signal_functions.pyx:252-330), the batched center statistics / plateau lengths (AutoInterpretation.py:226-277, :179-224) and the FIR
+with its checked fallback (signal_functions.pyx:513-525)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROUNDS = int(os.environ.get("URH_FUZZ_ROUNDS", "4"))
+SEED0 = int(os.environ.get("URH_FUZZ_SEED", "0"))
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    from urh_amd.pipeline import DevicePipeline
+    return DevicePipeline()
+
+
+def test_costas_fuzz(oracle):
+    """random orders, sample types, carrier offsets, loop bandwidths, SNRs, gated pauses and un-gated noise stretches, lengths around the
+    4096-sample chunk grid: the demodulated signal equals the serial recurrence from sample 1 on"""
+    from urh_amd import signal_functions as sf
+    for it in range(ROUNDS):
+        rng = np.random.default_rng([313, SEED0, it])
+        order = int(rng.choice([2, 4]))
+        dtype = [np.float32, np.int16, np.int8, np.uint8, np.uint16][int(rng.integers(0, 5))]
+        n = int(rng.choice([int(rng.integers(2, 9000)), 4096 * int(rng.integers(1, 40)) + int(rng.integers(-2, 3)), int(rng.integers(9000, 700_000))]))
+        n = max(n, 2)
+        sps = int(rng.choice([8, 64, 100, 500]))
+        offset = float(rng.choice([0.0, 0.04, -0.006, 0.013, 0.2, float(rng.uniform(-0.3, 0.3))]))
+        bw = float(rng.choice([0.1, 0.05, 0.25, 0.01, 0.5]))
+        sym = rng.integers(0, order, n // sps + 1)
+        phases = (np.array([-135, -45, 45, 135]) if order == 4 else np.array([-90, 90]))[sym] * np.pi / 180
+        ph = np.repeat(phases, sps)[:n] + 2 * np.pi * offset * np.arange(n)
+        iq = np.stack([np.cos(ph), np.sin(ph)], 1) + float(rng.choice([0.0, 0.07, 0.3, 1.0])) * np.sqrt(0.5) * rng.standard_normal((n, 2))
+        for _ in range(int(rng.integers(0, 4))):                       # gated pauses / un-gated noise
+            a, ln = int(rng.integers(0, n)), int(rng.choice([1, 50, 4096, 30_000]))
+            if rng.random() < 0.5:
+                iq[a:a + ln] *= 0.01
+            else:
+                iq[a:a + ln] = 0.5 * rng.standard_normal((len(iq[a:a + ln]), 2))
+        if dtype == np.float32:
+            iq, noise = iq.astype(np.float32), float(rng.choice([0.2, 0.0, 0.05]))
+        else:
+            info = np.iinfo(dtype)
+            scale, off = (info.max - info.min) / 2 * 0.7, (info.max + info.min + 1) / 2
+            iq = np.clip(np.round(iq * scale + off), info.min, info.max).astype(dtype)
+            noise = 0.0 if np.dtype(dtype).kind == "u" else float(rng.choice([0.2, 0.0])) * scale
+        want = oracle.afp_demod(iq, noise, "PSK", order, bw)
+        got = sf.afp_demod(iq, noise, "PSK", order, bw)
+        assert got.shape == want.shape and bits_equal(got[1:], want[1:]), \
+            (it, SEED0, order, np.dtype(dtype).name, n, sps, offset, bw, noise, int((got[1:].view(np.uint32) != want[1:].view(np.uint32)).sum()))
+
+
+def test_center_and_plateau_fuzz(pipe, oracle):
+    """random rectangular signals (two or four levels, noise, gated samples, NaN / inf sprinkled rarely, constant stretches) cut into random
+    messages: every message's center equals the oracle's detect_center as a float, its plateau lengths equal get_plateau_lengths"""
+    import torch
+    from urh_amd import estimators
+    for it in range(ROUNDS):
+        rng = np.random.default_rng([515, SEED0, it])
+        n = int(rng.choice([int(rng.integers(10, 5000)), int(rng.integers(5000, 300_000)), int(rng.integers(300_000, 2_000_000))]))
+        sps = int(rng.choice([7, 40, 50, 300]))
+        levels = int(rng.choice([2, 4]))
+        amp, off = float(rng.choice([1.1, 0.9, 3.0, 1e-3])), float(rng.choice([-0.55, 0.05, -1.5, 0.0]))
+        qad = (np.repeat(rng.integers(0, levels, n // sps + 1), sps)[:n] * amp / (levels - 1) + off
+               + float(rng.choice([0.0, 0.03, 0.08, 0.4])) * amp * rng.standard_normal(n)).astype(np.float32)
+        if rng.random() < 0.7:
+            qad[rng.integers(0, n, int(rng.integers(0, max(n // 50, 1))))] = -4.0
+        for _ in range(int(rng.integers(0, 3))):
+            a, ln = int(rng.integers(0, n)), int(rng.choice([1, 100, 5000, 70_000]))
+            qad[a:a + ln] = float(rng.choice([-4.0, 0.25, -4.0]))
+        if rng.random() < 0.1:
+            qad[int(rng.integers(0, n))] = np.float32(rng.choice([np.nan, np.inf]))
+        k = int(rng.integers(1, 14))
+        cuts = np.sort(rng.integers(0, n + 1, 2 * k))
+        bounds = [(int(cuts[2 * i]), int(cuts[2 * i + 1])) for i in range(k)]
+        if rng.random() < 0.15:
+            bounds = [(0, n)]                                          # the whole signal as one message (what detect_center itself sees)
+        dev = torch.from_numpy(qad).cuda()
+        try:
+            centers = estimators.centers_batched(pipe, dev, bounds)
+        except Exception as exc:
+            raise AssertionError((it, SEED0, n, bounds, repr(exc))) from exc
+        with np.errstate(all="ignore"):
+            for (a, b), c in zip(bounds, centers):
+                want = oracle.detect_center(qad[a:b]) if b > a else None
+                same = (c is None and want is None) or (c is not None and want is not None and
+                                                        (float(c) == float(want) or (np.isnan(c) and np.isnan(want))))
+                assert same, (it, SEED0, n, (a, b), c, want)
+        use = [c if (c is not None and np.isfinite(c)) else (float(rng.choice([0.1, 0.0, -0.3])) if i % 2 else None) for i, c in enumerate(centers)]
+        plats = estimators.plateau_lengths_batched(pipe, dev, bounds, use)
+        for (a, b), c, got in zip(bounds, use, plats):
+            want = oracle.get_plateau_lengths(qad[a:b], c, 25) if c is not None else np.zeros(0, np.uint64)
+            assert np.array_equal(np.asarray(got, dtype=np.uint64), np.asarray(want, dtype=np.uint64)), (it, SEED0, n, (a, b), c, len(got), len(want))
+        # the chained call equals the two calls
+        r = np.array(bounds, np.int64).reshape(-1, 2)
+        c1, t1, b1 = estimators.centers_and_decisions(pipe, dev, r, 25)
+        c2 = estimators.centers_array(pipe, dev, r)
+        t2, b2 = estimators._plateau_decisions(pipe, dev, r, c2.astype(np.float32).astype(np.float64), 25)
+        assert np.array_equal(c1, c2, equal_nan=True) and np.array_equal(t1, t2) and np.array_equal(b1, b2), (it, SEED0, n, bounds)
+
+
+def test_fir_fuzz(oracle):
+    """random lengths, tap counts (1 .. 300), magnitudes up to the checked kernel's hand-over threshold and beyond, inf / NaN sprinkled"""
+    from urh_amd import signal_functions as sf
+    for it in range(ROUNDS):
+        rng = np.random.default_rng([717, SEED0, it])
+        n = int(rng.choice([int(rng.integers(1, 300)), int(rng.integers(300, 20_000)), int(rng.integers(20_000, 600_000))]))
+        m = int(rng.choice([1, 2, 3, 10, 63, 64, 65, int(rng.integers(1, 300))]))
+        mag = float(rng.choice([1.0, 1e-20, 1e18, 1e30]))
+        x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * mag).astype(np.complex64)
+        h = ((rng.standard_normal(m) + 1j * rng.standard_normal(m)) * float(rng.choice([1.0, 0.05, 1e10]))).astype(np.complex64)
+        for _ in range(int(rng.integers(0, 3))):
+            x[int(rng.integers(0, n))] = np.complex64(rng.choice([np.inf, -np.inf, np.nan, 0.0]) + 1j * rng.choice([0.0, np.inf, np.nan, 1.0]))
+        with np.errstate(all="ignore"):
+            want = oracle.fir_filter(x, h)
+        got = sf.fir_filter(x, h)
+        a, b = np.ascontiguousarray(got, np.complex64).view(np.uint32), np.ascontiguousarray(want, np.complex64).view(np.uint32)
+        fa, fb = a.view(np.float32), b.view(np.float32)
+        assert bool(((a == b) | (np.isnan(fa) & np.isnan(fb))).all()), (it, SEED0, n, m, mag, int(((a != b) & ~(np.isnan(fa) & np.isnan(fb))).sum()))
