@@ -967,7 +967,7 @@ def main():
     d2h_bytes_wide = None
     use_stream = not sharded and args.pipeline and not args.no_d2h
     # A full collection of Python's cyclic garbage collector takes 30-40 ms in a process that has torch and numpy loaded (a hundred
-    # steps' worth: tools/stream_probe.py caught one inside a timed region): the timed regions run with the collector off.
+    # steps' worth: a round-3 probe caught one inside a timed region): the timed regions run with the collector off.
     import gc
     gc.collect()
     gc.disable()
@@ -984,7 +984,7 @@ def main():
         del pinned, host_out
     latency_ms = min(lat) * 1e3
 
-    # Anything slow between the clock ramp and a timed region lets the part's clocks fall again (tools/idle_probe.py: 1 ms of idling
+    # Anything slow between the clock ramp and a timed region lets the part's clocks fall again (round 3, profiles/HISTORY.md: 1 ms of idling
     # before K = 20 passes costs 3 %, 5 ms 13 %): the profile records' events (a hipEventCreate each) and the process group's first
     # barrier are paid for here, not there.
     pipe.ctx.profile_begin(args.steps)

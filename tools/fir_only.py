@@ -1,4 +1,4 @@
-"""FIR only (64 taps, 1 GiB): target of tools/prof_cmd.sh"""
+"""FIR only (64 taps, 1 GiB): target of tools/profiles_round.sh"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -566,7 +566,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         // behind the last byte's arrival is the last (short) piece's kernel and the last segment's tail.
         // The copies go onto the HOT stream itself: copy 0, kernel 0, copy 1, kernel 1, ...  A stream of their own (copies fully beside
         // the kernels) was measured first and is not robust: HIP maps streams onto a handful of hardware queues, and depending on which
-        // streams happened to share one the same pass took 19.4 or 35 ms (tools/r4_upload_probe.py, round 4: the first pipeline of a
+        // streams happened to share one the same pass took 19.4 or 35 ms (tools/upload_probe.py, round 4: the first pipeline of a
         // process was fine, later ones were not).  In one in-order stream a piece's kernel sits between two copies: 283 us of kernels
         // per GiB whatever the number of pieces, plus some 25 us of hand-over per piece -- 1.04 x the bare copy at four pieces.
         // No polling gates here: a gate kernel would spin for the milliseconds a piece takes to arrive; the rows segment of piece k
@@ -816,7 +816,7 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
         URH_HIP(hipEventCreateWithFlags(&ctx->ev_tail[2], hipEventDisableTiming));
     }
     // The hot kernel of a pipelined pass runs on a private stream whose CU mask leaves hot_cus_removed CUs per XCD out (default 4: 224 of
-    // the 256 CUs).  Measured (tools/cumask_probe.py, round 3): the kernel -- and a pure copy of its shape -- is FASTEST there: 0.2666 ms
+    // the 256 CUs).  Measured (round 3, profiles/HISTORY.md): the kernel -- and a pure copy of its shape -- is FASTEST there: 0.2666 ms
     // = 6.04 TB/s on 224 CUs against 0.2799 ms = 5.75 TB/s on all 256 (248 / 240 / 232 CUs: 0.2746 / 0.2718 / 0.2708; 208 / 192: 0.2746 /
     // 0.2752; 160: 0.311): 256 CUs of streaming wavefronts ask more of the HBM than it serves well.  And the 32 CUs it leaves alone are
     // where the previous pass's tail, the blob packing and the collectives of sharded passes find their wave slots at once.  The mask

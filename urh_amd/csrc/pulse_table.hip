@@ -893,7 +893,7 @@ constexpr int kEmitWaves = 4;
 // starts only when a hot workgroup retires (rocprofv3 timeline of round 3: one chunk per wavefront = 4096 workgroups took 110 us
 // beside the hot kernel against 18 us on an idle machine -- the kernel was bound by the number of workgroups that had to find a
 // slot, not by its work).  kTailCPW chunks per wavefront: the per-chunk metadata of all of them arrives in ONE round trip (lane j holds
-// chunk j's), the records of the next chunk are requested before the current one is processed.  Measured (tools/r3_ab.sh, round 3):
+// chunk j's), the records of the next chunk are requested before the current one is processed.  Measured (round 3, profiles/HISTORY.md):
 // 1 / 4 / 8 / 16 chunks per wavefront give 0.319 / 0.311 / 0.311 / 0.311 ms per pipelined step with D2H, but 0.402 / 0.402 / 0.406 /
 // 0.444 ms for ONE capture on an idle machine (fewer wavefronts = less parallelism there): four.
 #ifndef URH_TAIL_CPW

@@ -67,7 +67,7 @@ class TorchDistComm:
 class RcclComm:
     """all_gather straight through RCCL: ncclAllGather (ctypes on the librccl.so torch itself has loaded) enqueued on the CURRENT
     torch stream with a communicator of its own -- a few microseconds of host time per exchange and no hop through a collective
-    stream, against 55-80 us per torch.distributed all_gather_into_tensor (tools/shard_host_probe.py: three of those per pass made
+    stream, against 55-80 us per torch.distributed all_gather_into_tensor (round 3, profiles/HISTORY.md: three of those per pass made
     the sharded pass host-bound).  The communicator's unique id travels through the torch.distributed group once, at start-up;
     torch.distributed is still what launches and synchronises the ranks.  `RcclComm.create(group)` falls back to TorchDistComm when
     the library or the communicator cannot be had -- on EVERY rank or on none: each step's outcome is agreed on through the group
