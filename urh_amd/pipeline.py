@@ -438,6 +438,13 @@ class CaptureStream:
                                                     1 if want_pos else 0, int(cap_rows), C.byref(h)))
         self._h = h
         self._dtype = np.dtype(dtype)
+        # the captures of the passes that may still be running (three are in flight at most): a caller's temporary -- a pinned host buffer
+        # under the DMA of push_upload in particular, which no allocator knows to be in use -- lives until its pass has been handed out
+        self._inflight = []
+
+    def _hold(self, *tensors):
+        self._inflight.append(tensors)
+        del self._inflight[:-4]
 
     def push(self, iq):
         torch = self.pipe.torch
@@ -448,6 +455,7 @@ class CaptureStream:
         r = _lib.HostResult()
         self.pipe.ctx.set_stream(torch.cuda.current_stream(self.pipe.device).cuda_stream)
         _lib.check(_lib.load().urhgpu_stream_push(self._h, C.c_void_p(iq.data_ptr()), int(iq.shape[0]), C.byref(r)))
+        self._hold(iq)
         return HostBits(r, self.params) if r.seq >= 0 else None
 
     def push_upload(self, host_iq, dev_iq):
@@ -468,12 +476,14 @@ class CaptureStream:
         self.pipe.ctx.set_stream(torch.cuda.current_stream(self.pipe.device).cuda_stream)
         _lib.check(_lib.load().urhgpu_stream_push_upload(self._h, C.c_void_p(host_iq.data_ptr()), C.c_void_p(dev_iq.data_ptr()), int(host_iq.shape[0]),
                                                          C.byref(r)))
+        self._hold(host_iq, dev_iq)
         return HostBits(r, self.params) if r.seq >= 0 else None
 
     def flush(self):
         arr = (_lib.HostResult * 3)()
         n = C.c_int(0)
         _lib.check(_lib.load().urhgpu_stream_flush(self._h, arr, C.byref(n)))
+        self._inflight = []                                   # (every pass has finished)
         return [HostBits(arr[k], self.params) for k in range(n.value)]
 
     def stats(self) -> dict:
@@ -485,6 +495,7 @@ class CaptureStream:
         if self._h:
             _lib.load().urhgpu_stream_destroy(self._h)
             self._h = None
+            self._inflight = []
 
     def __del__(self):
         try:
