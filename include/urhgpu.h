@@ -576,6 +576,13 @@ int urhgpu_modulate_gfsk(urhgpu_ctx *ctx, const uint8_t *bits, int64_t num_bits,
 /* IQArray.convert_to (IQArray.py:127-203) on device memory: n VALUES (two per IQ sample) of src_dtype -> dst_dtype, any
  * pair of different URHGPU_DT_* codes, with the reference's wrapping / truncating numpy semantics.  Asynchronous. */
 int urhgpu_convert_dev(urhgpu_ctx *ctx, const void *d_src, int src_dtype, void *d_dst, int dst_dtype, int64_t n);
+/* Signal.__load_wav_file (Signal.py:114-173) on device memory: the PCM frames of a WAV file (d_raw: n_frames * channels * sample_width
+ * bytes as wave.readframes returns them; sample_width 1: unsigned bytes, 2 / 3 / 4: signed little endian) -> float32 IQ d_out[n_frames][2]:
+ * (sample - center) * (1 / max) in float64, rounded once to float32, as numpy evaluates the reference's expression; one channel: the
+ * imaginary part is 0 (an already demodulated capture, :155-156), two: left -> real, right -> imag.  Also what a Flipper .sub capture goes
+ * through once its run lengths are expanded to bytes 255 / 0 (:175-205).  Other channel counts / widths: URHGPU_ERR_ARG (the reference
+ * raises ValueError, :133, :164).  Asynchronous. */
+int urhgpu_pcm_to_iq_dev(urhgpu_ctx *ctx, const void *d_raw, int64_t n_frames, int channels, int sample_width, float *d_out);
 /* The plain numpy cast between float32 and one of the four integer sample types (no IQArray scaling): what Filter.apply_fir_filter
  * does to an integer capture before filtering (`tmp.real = input_signal[0::2]`, Filter.py:37-41: the raw values as float32) and what
  * IQArray.__setitem__ does with the filtered complex64 range (`self.real[key] = value.real`, IQArray.py:31-33: truncation toward zero

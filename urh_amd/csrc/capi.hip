@@ -1817,6 +1817,16 @@ int urhgpu_astype_dev(urhgpu_ctx *ctx, const void *d_src, int src_dtype, void *d
     return URHGPU_OK;
 }
 
+int urhgpu_pcm_to_iq_dev(urhgpu_ctx *ctx, const void *d_raw, int64_t n_frames, int channels, int sample_width, float *d_out) {
+    if (!ctx || n_frames < 0 || (n_frames > 0 && (!d_raw || !d_out))) return URHGPU_ERR_ARG;
+    if (channels < 1 || channels > 2 || sample_width < 1 || sample_width > 4) return URHGPU_ERR_ARG;      // (ValueError in the reference, :133, :164)
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(launch_pcm_to_iq(d_raw, n_frames, channels, sample_width, d_out, ctx->stream));
+    URH_HIP(hipGetLastError());
+    return URHGPU_OK;
+}
+
 static int plot_elem_bytes(int dtype) {
     switch (dtype) {
         case URHGPU_DT_I8: case URHGPU_DT_U8: return 1;

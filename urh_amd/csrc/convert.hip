@@ -119,6 +119,36 @@ int launch_astype(const void *src, int src_dtype, void *dst, int dst_dtype, int6
     return URHGPU_ERR_DTYPE;
 }
 
+// ---- PCM frames of a WAV file -> float32 IQ (Signal.__load_wav_file, Signal.py:114-173) ----------------------------------
+// One thread per frame.  A sample of `width` bytes (1: unsigned, 2 / 3 / 4: signed little endian, three bytes sign-extended as the
+// reference does with its fourth byte, :137-146) becomes np.multiply(1 / max, np.subtract(sample, center)) -- float64 arithmetic, rounded
+// once into the float32 IQArray (:151-163) -- with max = 255 / 32767 / 8388607 / 2147483647 and center = (min + max) / 2 = 127.5 / -0.5.
+// Mono: the imaginary part is 0 (the capture counts as already demodulated, :155-156); stereo: left -> real, right -> imag.
+// 1-8 B read, 8 B written per frame: HBM-bound, byte loads (a 3-byte sample has no alignment).
+__global__ __launch_bounds__(256) void k_pcm_to_iq(const uint8_t *raw, int64_t n_frames, int channels, int width, float *out) {
+    const double mx = (width == 1) ? 255.0 : (width == 2) ? 32767.0 : (width == 3) ? 8388607.0 : 2147483647.0;
+    const double center = (width == 1) ? 127.5 : -0.5, scale = 1.0 / mx;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_frames; i += (int64_t)gridDim.x * blockDim.x) {
+        float v[2] = {0.f, 0.f};
+        for (int c = 0; c < channels; ++c) {
+            const uint8_t *q = raw + (i * channels + c) * (int64_t)width;
+            int32_t x;
+            if (width == 1) x = (int32_t)q[0];
+            else if (width == 2) x = (int32_t)(int16_t)((uint16_t)q[0] | ((uint16_t)q[1] << 8));
+            else if (width == 3) x = (int32_t)(((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16)) << 8) >> 8;
+            else x = (int32_t)((uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24));
+            v[c] = (float)(scale * ((double)x - center));
+        }
+        *(float2 *)(out + 2 * i) = float2{v[0], v[1]};
+    }
+}
+int launch_pcm_to_iq(const void *raw, int64_t n_frames, int channels, int width, float *out, hipStream_t s) {
+    if (n_frames <= 0) return URHGPU_OK;
+    int64_t g = (n_frames + 255) / 256; if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(k_pcm_to_iq, dim3((unsigned)g), dim3(256), 0, s, (const uint8_t *)raw, n_frames, channels, width, out);
+    return URHGPU_OK;
+}
+
 // n = number of VALUES (2 per IQ sample); src_dtype != dst_dtype
 int launch_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, hipStream_t s) {
     if (n <= 0) return URHGPU_OK;

@@ -68,21 +68,90 @@ def as_complex64(data, ctx=None):
     return torch.view_as_complex(convert_to(data, np.float32, ctx).reshape(-1, 2))
 
 
+def _raw_by_extension(name: str, read):
+    """IQArray.from_file's extension table (:205-227): (flat values as stored, the IQArray's sample type).  read(dtype) -> numpy array."""
+    if name.endswith(".complex16u") or name.endswith(".cu8"):
+        return read(np.uint8), np.int8
+    if name.endswith(".complex16s") or name.endswith(".cs8"):
+        return read(np.int8), np.int8
+    if name.endswith(".complex32u") or name.endswith(".cu16"):
+        return read(np.uint16), np.int16
+    if name.endswith(".complex32s") or name.endswith(".cs16"):
+        return read(np.int16), np.int16
+    return read(np.float32), np.float32
+
+
 def from_file(filename: str, device=None, ctx=None):
     """IQArray.from_file (:205-227): the capture is read once and uploaded; unsigned captures (.complex16u / .cu8,
-    .complex32u / .cu16) become signed on the GPU, as the reference does on the host.  Returns an (N, 2) device tensor."""
+    .complex32u / .cu16) become signed on the GPU, as the reference does on the host.  A `.coco` file (Signal.__load_compressed_complex,
+    Signal.py:207-213) is a tar archive whose FIRST member is such a capture, typed by the member's own name.
+    Returns an (N, 2) device tensor."""
     import torch
-    if filename.endswith(".complex16u") or filename.endswith(".cu8"):
-        raw, target = np.fromfile(filename, dtype=np.uint8), np.int8
-    elif filename.endswith(".complex16s") or filename.endswith(".cs8"):
-        raw, target = np.fromfile(filename, dtype=np.int8), np.int8
-    elif filename.endswith(".complex32u") or filename.endswith(".cu16"):
-        raw, target = np.fromfile(filename, dtype=np.uint16), np.int16
-    elif filename.endswith(".complex32s") or filename.endswith(".cs16"):
-        raw, target = np.fromfile(filename, dtype=np.int16), np.int16
+    if filename.endswith(".coco"):
+        import tarfile
+        with tarfile.open(filename, "r") as tar:
+            member = tar.getmembers()[0]
+            blob = tar.extractfile(member).read()
+        raw, target = _raw_by_extension(member.name, lambda dt: np.frombuffer(blob, dtype=dt, count=len(blob) // np.dtype(dt).itemsize).copy())
     else:
-        raw, target = np.fromfile(filename, dtype=np.float32), np.float32
+        raw, target = _raw_by_extension(filename, lambda dt: np.fromfile(filename, dtype=dt))
     if len(raw) % 2:
         raw = raw[:-1]                                   # convert_array_to_iq drops the last half sample (:238-239)
     t = torch.from_numpy(raw.reshape(-1, 2)).to(device if device is not None else "cuda")
     return convert_to(t, target, ctx)
+
+
+def pcm_to_iq(frames: bytes, n_frames: int, channels: int, sample_width: int, device=None, ctx=None):
+    """PCM frames -> float32 (N, 2) on the device (urhgpu_pcm_to_iq_dev: Signal.py:148-163 evaluated in float64 per sample)."""
+    import torch
+    dev = device if device is not None else "cuda"
+    out = torch.empty((n_frames, 2), dtype=torch.float32, device=dev)
+    if n_frames == 0:
+        return out
+    raw = torch.frombuffer(bytearray(frames), dtype=torch.uint8).to(dev)
+    ctx = ctx or _lib.default_context()
+    ctx.set_stream(torch.cuda.current_stream(out.device).cuda_stream)
+    _lib.check(_lib.load().urhgpu_pcm_to_iq_dev(ctx.handle, C.c_void_p(raw.data_ptr()), int(n_frames), int(channels), int(sample_width),
+                                                C.c_void_p(out.data_ptr())))
+    out._urh_keep = raw                                  # (asynchronous: the upload lives as long as the result)
+    return out
+
+
+def from_wav(filename: str, device=None, ctx=None):
+    """Signal.__load_wav_file (Signal.py:114-173): (iq float32 (N, 2) on the device, sample_rate, already_demodulated).  8-bit unsigned and
+    16 / 24 / 32-bit signed PCM; one channel = an already demodulated capture (the samples are the real part), two = I and Q."""
+    import wave
+    wav = wave.open(filename, "r")
+    try:
+        channels, width, rate, n_frames, _, _ = wav.getparams()
+        if width not in (1, 2, 3, 4):
+            raise ValueError("Can't handle sample width {0}".format(width))
+        frames = wav.readframes(n_frames * channels)
+    finally:
+        wav.close()
+    if channels not in (1, 2):
+        raise ValueError("Can't handle {0} channels. Only 1 and 2 are supported.".format(channels))
+    if len(frames) != n_frames * channels * width:        # (the reference's assignment into its n_frames-long IQArray fails the same way)
+        raise ValueError("could not broadcast input array: the file holds {0} bytes of frames, its header promises {1}".format(
+            len(frames), n_frames * channels * width))
+    return pcm_to_iq(frames, n_frames, channels, width, device, ctx), rate, channels == 1
+
+
+def from_sub(filename: str, device=None, ctx=None):
+    """Signal.__load_sub_file (Signal.py:175-205), the Flipper Zero RAW format (OOK): every `RAW_Data:` line holds run lengths in samples,
+    positive = above the center (byte 255), negative = below (byte 0); values that are no integers are skipped (the reference logs
+    them).  Returns the float32 (N, 2) device tensor (real part +-0.5, an already demodulated capture)."""
+    import re
+    runs = []
+    with open(filename, "r") as fh:
+        for line in fh:
+            m = re.match(r"RAW_Data:\s*([-0-9 ]+)\s*$", line)
+            if m:
+                for value in m[1].strip().split(" "):
+                    try:
+                        runs.append(int(value))
+                    except ValueError:
+                        pass
+    r = np.asarray(runs, dtype=np.int64)
+    data = np.repeat(np.where(r > 0, 255, 0).astype(np.uint8), np.abs(r)) if len(r) else np.zeros(0, np.uint8)
+    return pcm_to_iq(data.tobytes(), len(data), 1, 1, device, ctx)

@@ -44,6 +44,7 @@ class Signal:
         self.sample_rate = float(sample_rate)
         self.timestamp = float(timestamp)
         self.already_demodulated = bool(already_demodulated)
+        self.filename, self.wav_mode, self.flipper_raw_mode = "", False, False          # (Signal.py:69-70, :109)
         self._par = dict(modulation_type=modulation or "FSK", bits_per_symbol=1, costas_loop_bandwidth=0.1, noise_threshold=0,
                          center=0, center_spacing=1, tolerance=5, samples_per_symbol=100, pause_threshold=8,
                          message_length_divisor=1)
@@ -58,12 +59,31 @@ class Signal:
 
     # ---- samples --------------------------------------------------------------------------------------------------
     @classmethod
-    def from_file(cls, filename, **kw):
-        """IQArray.from_file by extension (IQArray.py:205-227); mono WAV / .sub are not read here (already_demodulated inputs
-        are handed over as arrays)."""
-        from .iq_array import from_file
+    def from_file(cls, filename, default_noise_threshold=None, **kw):
+        """Signal(filename) (Signal.py:69-109): complex captures by extension (IQArray.py:205-227), `.coco` (a tar archive around one,
+        :207-213), `.wav` (:114-173: 8 / 16 / 24 / 32-bit PCM; mono = already demodulated, stereo = I / Q; the file's sample rate becomes
+        the Signal's) and Flipper `.sub` (:175-205: already demodulated).  default_noise_threshold: the reference's setting of that name
+        (:97-107) -- "automatic": detect_noise_level of the magnitudes, a number: that many percent of max_magnitude; None (default here):
+        the threshold stays 0 until the caller sets it."""
+        from . import iq_array
         s = cls(None, **kw)
-        s.iq = from_file(filename, device=s.pipe.device)
+        s.wav_mode, s.flipper_raw_mode = filename.endswith(".wav"), filename.endswith(".sub")
+        if s.wav_mode:
+            iq, rate, demod = iq_array.from_wav(filename, device=s.pipe.device)
+            s.already_demodulated = bool(demod)
+            s.iq = iq
+            s.sample_rate = float(rate)
+        elif s.flipper_raw_mode:
+            s.already_demodulated = True
+            s.iq = iq_array.from_sub(filename, device=s.pipe.device)
+        else:
+            s.iq = iq_array.from_file(filename, device=s.pipe.device)
+        s.filename = filename
+        if default_noise_threshold == "automatic":
+            from .estimators import detect_noise_level_dev
+            s.noise_threshold = detect_noise_level_dev(s.pipe, s._iq)
+        elif default_noise_threshold is not None:
+            s.noise_threshold = float(default_noise_threshold) / 100 * s.max_magnitude
         return s
 
     @classmethod
