@@ -583,6 +583,11 @@ int urhgpu_convert_dev(urhgpu_ctx *ctx, const void *d_src, int src_dtype, void *
  * through once its run lengths are expanded to bytes 255 / 0 (:175-205).  Other channel counts / widths: URHGPU_ERR_ARG (the reference
  * raises ValueError, :133, :164).  Asynchronous. */
 int urhgpu_pcm_to_iq_dev(urhgpu_ctx *ctx, const void *d_raw, int64_t n_frames, int channels, int sample_width, float *d_out);
+/* The run lengths IQArray.export_to_sub writes (IQArray.py:275-304) from the uint8 conversion of a capture: values[i * stride] is sample
+ * i's first component (HOST memory; stride 2 for an (N, 2) array).  runs_out[k] > 0: that many samples above 127, < 0: at or below; the
+ * reference's walk is restated exactly (a run of ONE sample never ends: the samples that differ from it are dropped until its value
+ * comes back).  *n_runs is set also on URHGPU_ERR_CAPACITY.  Host arithmetic; works without a GPU. */
+int urhgpu_sub_encode_runs(const uint8_t *values, int64_t n, int64_t stride, int64_t *runs_out, int64_t cap, int64_t *n_runs);
 /* The plain numpy cast between float32 and one of the four integer sample types (no IQArray scaling): what Filter.apply_fir_filter
  * does to an integer capture before filtering (`tmp.real = input_signal[0::2]`, Filter.py:37-41: the raw values as float32) and what
  * IQArray.__setitem__ does with the filtered complex64 range (`self.real[key] = value.real`, IQArray.py:31-33: truncation toward zero

@@ -1827,6 +1827,30 @@ int urhgpu_pcm_to_iq_dev(urhgpu_ctx *ctx, const void *d_raw, int64_t n_frames, i
     return URHGPU_OK;
 }
 
+// IQArray.export_to_sub's run lengths (IQArray.py:275-304), host arithmetic on the bytes convert_to(uint8) produced on the device: the
+// reference walks the FIRST component of every sample with (lastvalue, counter) -- equal to lastvalue: counter += 1; different: when
+// counter > 1 the run is appended (positive above 127, negative otherwise) and the new value starts a run of 1, when counter is 1
+// NOTHING happens (the value is dropped and lastvalue stays: a single sample never ends a run); the last run is always appended.
+int urhgpu_sub_encode_runs(const uint8_t *values, int64_t n, int64_t stride, int64_t *runs_out, int64_t cap, int64_t *n_runs) {
+    if (!values || n <= 0 || stride < 1 || !n_runs || cap < 0 || (cap > 0 && !runs_out)) return URHGPU_ERR_ARG;     // (an empty array: NameError in the reference)
+    int64_t k = 0, counter = 0;
+    uint8_t last = values[0];
+    for (int64_t i = 0; i < n; ++i) {
+        const uint8_t v = values[i * stride];
+        if (v == last) { ++counter; continue; }
+        if (counter > 1) {
+            if (k < cap) runs_out[k] = last > 127 ? counter : -counter;
+            ++k;
+            counter = 1;
+            last = v;
+        }
+    }
+    if (k < cap) runs_out[k] = last > 127 ? counter : -counter;
+    ++k;
+    *n_runs = k;
+    return k > cap ? URHGPU_ERR_CAPACITY : URHGPU_OK;
+}
+
 static int plot_elem_bytes(int dtype) {
     switch (dtype) {
         case URHGPU_DT_I8: case URHGPU_DT_U8: return 1;

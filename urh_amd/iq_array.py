@@ -155,3 +155,86 @@ def from_sub(filename: str, device=None, ctx=None):
     r = np.asarray(runs, dtype=np.int64)
     data = np.repeat(np.where(r > 0, 255, 0).astype(np.uint8), np.abs(r)) if len(r) else np.zeros(0, np.uint8)
     return pcm_to_iq(data.tobytes(), len(data), 1, 1, device, ctx)
+
+
+# ---- the way out: IQArray.tofile / export_to_wav / save_compressed / export_to_sub, FileOperator.save_data -----------------------
+def _converted_bytes(data, target_dtype, ctx=None) -> np.ndarray:
+    """convert_to(target) on the device, then ONE copy to the host: the (N, 2) array whose bytes go into the file"""
+    return convert_to(data, target_dtype, ctx).cpu().numpy()
+
+
+def _target_by_extension(filename: str):
+    if filename.endswith(".complex16u") or filename.endswith(".cu8"):
+        return np.uint8
+    if filename.endswith(".complex16s") or filename.endswith(".cs8"):
+        return np.int8
+    if filename.endswith(".complex32u") or filename.endswith(".cu16"):
+        return np.uint16
+    if filename.endswith(".complex32s") or filename.endswith(".cs16"):
+        return np.int16
+    return np.float32
+
+
+def tofile(data, filename: str, ctx=None):
+    """IQArray.tofile (:115-125): the capture converted to the sample type the extension names, raw"""
+    _converted_bytes(data, _target_by_extension(filename), ctx).tofile(filename)
+
+
+def export_to_wav(data, filename: str, num_channels: int, sample_rate, ctx=None):
+    """IQArray.export_to_wav (:267-273): 16-bit PCM of convert_to(int16), I and Q interleaved (with num_channels = 1 the same bytes are
+    2 N mono frames, as in the reference)"""
+    import wave
+    f = wave.open(filename, "w")
+    f.setnchannels(num_channels)
+    f.setsampwidth(2)
+    f.setframerate(sample_rate)
+    f.writeframes(_converted_bytes(data, np.int16, ctx))
+    f.close()
+
+
+def save_compressed(data, filename: str, ctx=None):
+    """IQArray.save_compressed (:260-265): a bz2 tar archive around ONE member, the capture as float32 (the member carries no extension)"""
+    import os
+    import tarfile
+    import tempfile
+    with tarfile.open(filename, "w:bz2") as tar_write:
+        tmp_name = tempfile.mkstemp()[1]
+        _converted_bytes(data, np.float32, ctx).tofile(tmp_name)
+        tar_write.add(tmp_name)
+    os.remove(tmp_name)
+
+
+def export_to_sub(data, filename: str, frequency=433920000, preset="FuriHalSubGhzPresetOok650Async", ctx=None):
+    """IQArray.export_to_sub (:275-323): the uint8 conversion's first component as Flipper RAW run lengths (urhgpu_sub_encode_runs restates
+    the reference's walk), 512 values per RAW_Data line"""
+    u8 = _converted_bytes(data, np.uint8, ctx)
+    flat = np.ascontiguousarray(u8)
+    n = int(flat.shape[0])
+    stride = int(flat.shape[1]) if flat.ndim > 1 else 1
+    lib = _lib.load()
+    cap = max(n, 1)
+    runs = np.zeros(cap, dtype=np.int64)
+    n_runs = C.c_int64(0)
+    _lib.check(lib.urhgpu_sub_encode_runs(flat.ctypes.data_as(C.c_void_p), n, stride, runs.ctypes.data_as(C.c_void_p), cap, C.byref(n_runs)))
+    arr = runs[:n_runs.value].tolist()
+    with open(filename, "w") as subfile:
+        subfile.write("Filetype: Flipper SubGhz RAW File\n")
+        subfile.write("Version: 1\n")
+        subfile.write("Frequency: {}\n".format(frequency))
+        subfile.write("Preset: {}\n".format(preset))
+        subfile.write("Protocol: RAW")
+        for lo in range(0, len(arr), 512):
+            subfile.write("\nRAW_Data: " + " ".join(map(str, arr[lo:lo + 512])))
+        subfile.write("\n")
+
+
+def save_data(data, filename: str, sample_rate=1e6, num_channels=2, ctx=None):
+    """FileOperator.save_data (FileOperator.py:185-196) for a capture on the device (or a numpy array, which is uploaded)"""
+    if filename.endswith(".wav"):
+        export_to_wav(data, filename, num_channels, sample_rate, ctx)
+    elif filename.endswith(".coco"):
+        save_compressed(data, filename, ctx)
+    elif filename.endswith(".sub"):
+        export_to_sub(data, filename, ctx=ctx)
+    else:
+        tofile(data, filename, ctx)

@@ -86,6 +86,21 @@ class Signal:
             s.noise_threshold = float(default_noise_threshold) / 100 * s.max_magnitude
         return s
 
+    def save(self):
+        """Signal.save (:462-464)"""
+        if self.changed:
+            self.save_as(self.filename)
+
+    def save_as(self, filename: str):
+        """Signal.save_as (:466-472) -> FileOperator.save_signal (FileOperator.py:208-209): the capture converted on the device to what the
+        extension names (raw sample types, `.wav`, `.coco`, `.sub`), written, the Signal renamed after the file"""
+        import os
+        from . import iq_array
+        self.filename = filename
+        iq_array.save_data(self._iq, filename, self.sample_rate)
+        self.name = os.path.splitext(os.path.basename(filename))[0]
+        self.changed = False
+
     @classmethod
     def from_file_streamed(cls, filename, pinned=None, **params):
         """`Signal(filename)` followed by `get_protocol_from_signal()` (Signal.py:42-112, IQArray.py:206-227, ProtocolAnalyzer.py:227-287)
