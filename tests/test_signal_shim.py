@@ -335,3 +335,44 @@ def test_two_live_results_do_not_share_a_stale_host_cache(oracle):
     for a, b in zip(r[1].flat(), want[1][1]):
         assert np.array_equal(a, b)
     assert np.array_equal(r[0].ppseq(), want[0][0])
+
+
+def test_dialog_helpers_against_the_real_signal(pipe):
+    """calc_relative_noise_threshold_from_range / get_thresholds_for_center / center_thresholds / create_new / from_samples on the real
+    reference Signal and on the shim: the same numbers (Signal.py:486-535, :659-664)"""
+    import ref_python
+    if not ref_python.available():
+        pytest.skip("oracle/_ref (compiled reference + Python sources) not present")
+    ref_python.setup()
+    from urh.signalprocessing.IQArray import IQArray
+    from urh.signalprocessing.Signal import Signal as RefSignal
+    from urh_amd.signal import Signal
+    rng = np.random.default_rng(77)
+    for dtype in (np.float32, np.int8, np.uint8, np.int16, np.uint16):
+        iq = synth_fsk(50_000, sps=80, seed=9, noise=0.05, pause_every=12_000, pause_len=3000, dtype=dtype)
+        ref = RefSignal.from_samples(iq, "x", 2e6)
+        mine = Signal.from_samples(iq, "x", 2e6, pipe=pipe)
+        assert mine.sample_rate == 2e6 and mine.name == "x"
+        for a, b in [(0, 50_000), (12_001, 14_999), (14_999, 12_001), (7, 8), (33_333, 33_334), (100, 100), (-3000, -1), (49_000, 60_000)] + \
+                    [tuple(int(v) for v in rng.integers(0, 50_000, 2)) for _ in range(10)]:
+            want = ref.calc_relative_noise_threshold_from_range(a, b)
+            got = mine.calc_relative_noise_threshold_from_range(a, b)
+            assert float(got) == float(want) or (np.isnan(got) and np.isnan(want)), (np.dtype(dtype).name, a, b, got, want)    # (uint16: NaN in both)
+        for mod_bits, center, spacing in ((1, 0.02, 1.0), (2, -0.1, 0.3), (3, 0.0, 0.05)):
+            ref.bits_per_symbol = mine.bits_per_symbol = mod_bits
+            ref.center = mine.center = center
+            ref.center_spacing = mine.center_spacing = spacing
+            assert np.array_equal(np.asarray(ref.center_thresholds, np.float32).view(np.uint32), np.asarray(mine.center_thresholds, np.float32).view(np.uint32))
+            assert np.array_equal(np.asarray(ref.get_thresholds_for_center(0.3, 0.2), np.float32).view(np.uint32),
+                                  np.asarray(mine.get_thresholds_for_center(0.3, 0.2), np.float32).view(np.uint32))
+        ref.noise_threshold = mine.noise_threshold = 3.0 if dtype != np.float32 else 0.03
+        ref.samples_per_symbol = mine.samples_per_symbol = 80
+        rn, mn = ref.create_new(1000, 9000), mine.create_new(1000, 9000)
+        assert np.array_equal(mn.iq.cpu().numpy(), rn.iq_array.data) and mn.name == rn.name and mn.changed and rn.changed
+        assert (mn.noise_threshold, mn.samples_per_symbol, mn.bits_per_symbol, mn.center, mn.sample_rate, mn.timestamp) == \
+               (rn.noise_threshold, rn.samples_per_symbol, rn.bits_per_symbol, rn.center, rn.sample_rate, rn.timestamp)
+        other = synth_fsk(777, sps=10, seed=3, dtype=dtype)
+        rn, mn = ref.create_new(new_data=other, new_timestamp=4.5), mine.create_new(new_data=other, new_timestamp=4.5)
+        assert np.array_equal(mn.iq.cpu().numpy(), rn.iq_array.data) and mn.timestamp == rn.timestamp == 4.5
+    mine.eliminate()
+    assert mine.iq is None

@@ -277,6 +277,75 @@ class Signal:
     def real_plot_data(self):
         return self._iq[:, 0] if self._iq is not None else self.pipe.torch.zeros(0, dtype=self.pipe.torch.float32, device=self.pipe.device)
 
+    @property
+    def imag_plot_data(self):
+        return self._iq[:, 1] if self._iq is not None else self.pipe.torch.zeros(0, dtype=self.pipe.torch.float32, device=self.pipe.device)
+
+    # ---- what the reference's dialogs ask a Signal besides its bits ----------------------------------------------------------
+    def get_thresholds_for_center(self, center: float, spacing=None):
+        """Signal.get_thresholds_for_center (:531-535)"""
+        from .signal_functions import get_center_thresholds
+        return get_center_thresholds(center, self.center_spacing if spacing is None else spacing, self.modulation_order)
+
+    @property
+    def center_thresholds(self):
+        return self.get_thresholds_for_center(self.center)
+
+    def calc_relative_noise_threshold_from_range(self, noise_start: int, noise_end: int):
+        """Signal.calc_relative_noise_threshold_from_range (:486-506): the largest normalised magnitude of the selected range, rounded up to
+        four digits -- one pass of the magnitude statistics kernel over the range (urhgpu_magnitude_chunk_stats_dev), the arithmetic on its
+        ONE number as numpy does it (float32 magnitude / float64 norm).  An empty range: the current relative threshold, as the reference."""
+        import ctypes as C
+        num_digits = 4
+        noise_start, noise_end = int(noise_start), int(noise_end)
+        if noise_start > noise_end:
+            noise_start, noise_end = noise_end, noise_start
+        n = self.num_samples
+        lo = max(noise_start + n, 0) if noise_start < 0 else min(noise_start, n)       # (numpy slice semantics of subarray(start, stop))
+        hi = max(noise_end + n, 0) if noise_end < 0 else min(noise_end, n)
+        if hi <= lo:
+            return self.noise_threshold_relative
+        torch = self.pipe.torch
+        rng = self._iq[lo:hi]
+        out = torch.empty(2, dtype=torch.float64, device=self.pipe.device)
+        from .iq_array import _DT
+        self.pipe.ctx.set_stream(torch.cuda.current_stream(self.pipe.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_magnitude_chunk_stats_dev(self.pipe.ctx.handle, C.c_void_p(rng.data_ptr()), _DT[_torch_dtype(rng)], hi - lo, hi - lo, 1,
+                                                                C.c_void_p(out[0:1].data_ptr()), C.c_void_p(out[1:2].data_ptr())))
+        mi, ma = _limits(self.dtype)
+        maximum = np.float64(np.float32(out[1].item())) / np.sqrt(ma ** 2.0 + mi ** 2.0)
+        return np.ceil(maximum * 10 ** num_digits) / 10 ** num_digits
+
+    def create_new(self, start=0, end=0, new_data=None, new_timestamp=0):
+        """Signal.create_new (:508-529): a Signal over a slice of this capture (a device copy) or over new samples, carrying this one's
+        noise threshold, samples_per_symbol, bits_per_symbol, center, sample rate and file-mode flags; marked changed."""
+        new = Signal(None, name="New " + self.name, sample_rate=self.sample_rate, pipe=self.pipe, already_demodulated=self.already_demodulated)
+        if new_data is None:
+            new.iq = self._iq[start:end].clone()
+            new.timestamp = self.timestamp + (start / self.sample_rate)
+        else:
+            new.iq = new_data
+            new.timestamp = new_timestamp
+        for k in ("noise_threshold", "samples_per_symbol", "bits_per_symbol", "center"):
+            setattr(new, k, self._par[k])
+        new.wav_mode, new.flipper_raw_mode = self.wav_mode, self.flipper_raw_mode
+        new.changed = True
+        return new
+
+    @staticmethod
+    def from_samples(samples, name: str, sample_rate: float, pipe=None):
+        """Signal.from_samples (:659-664)"""
+        return Signal(samples, name=name, sample_rate=sample_rate, pipe=pipe)
+
+    def silent_set_modulation_type(self, mod_type: str):
+        """Signal.silent_set_modulation_type (:608-609): no invalidation (the caller knows the cache is still right)"""
+        self._par["modulation_type"] = mod_type
+
+    def eliminate(self):
+        """Signal.eliminate (:603-606): drop the samples and everything derived from them"""
+        self._iq = None
+        self._drop_cache()
+
     def quad_demod(self):
         """Signal.quad_demod (:474-484): a fresh demodulation (device tensor), or zeros(2) when everything is below the noise gate."""
         torch = self.pipe.torch
