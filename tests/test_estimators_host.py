@@ -256,3 +256,45 @@ def test_host_bits_from_a_blob_in_host_memory():
                 h.bit_sample_pos()
     with pytest.raises(ValueError):
         HostBits.from_blob(C.addressof((C.c_ubyte * 128)()), None)
+
+
+def test_peaks_center_linear_form_equals_the_offset_loop():
+    """peaks_center finds the strict maxima with two sliding-window maxima (linear in the bins: a nearly constant message has millions);
+    the per-offset comparison loop it replaced is the checker here (AutoInterpretation.py:250-277)"""
+    from urh_amd.estimators import peaks_center
+
+    def by_offsets(counts, edges):
+        y = np.asarray(counts, dtype=np.int64)
+        nb = len(y)
+        reach = max(2, int(0.05 * nb) + 1) - 1
+        padded = np.concatenate([np.zeros(reach, np.int64), y, np.zeros(reach, np.int64)])
+        peak = y > 0
+        for d in range(1, reach + 1):
+            peak &= (y > padded[reach - d:reach - d + nb]) & (y > padded[reach + d:reach + d + nb])
+        if not peak.any():
+            return None
+        walk = np.argsort(counts)[::-1]
+        return np.mean(np.asarray(edges)[walk[peak[walk]][:2]])
+    rng = np.random.default_rng(3)
+    for it in range(1500):
+        nb = int(rng.choice([1, 2, 3, 5, 19, 20, 21, 40, 41, 100, 777, int(rng.integers(1, 3000))]))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            y = rng.integers(0, 5, nb)
+        elif kind == 1:
+            y = np.zeros(nb, np.int64)
+            y[rng.integers(0, nb, max(1, nb // 20))] += rng.integers(1, 4, max(1, nb // 20))
+        elif kind == 2:
+            y = rng.integers(0, 1000, nb)
+        else:
+            y = np.full(nb, int(rng.integers(0, 3)))
+        e = np.arange(nb + 1) * 0.37 - 5
+        a, b = by_offsets(y, e), peaks_center(y, e)
+        assert (a is None and b is None) or a == b, (it, nb, a, b)
+    import time
+    y = np.zeros(2_000_000, np.int64)
+    y[rng.integers(0, len(y), 80)] += 1
+    y[1000], y[1_500_000] = 9, 7
+    t0 = time.perf_counter()
+    assert peaks_center(y, np.arange(len(y) + 1) * 1e-9) == np.mean([1000e-9, 1_500_000e-9])
+    assert time.perf_counter() - t0 < 20.0

@@ -280,20 +280,33 @@ def detect_center_dev(pipe, rect, max_size=None, _single=False):
     return peaks_center(d_counts.cpu().numpy(), edges)
 
 
+def _sliding_max(p: np.ndarray, w: int) -> np.ndarray:
+    """m[j] = max(p[j : j + w]) for every full window, in O(len(p)) (block prefix / suffix maxima: van Herk, Gil-Werman)"""
+    n = len(p)
+    blocks = -(-n // w)
+    q = np.full(blocks * w, np.iinfo(np.int64).min, dtype=np.int64)
+    q[:n] = p
+    b = q.reshape(blocks, w)
+    pre = np.maximum.accumulate(b, axis=1).reshape(-1)
+    suf = np.maximum.accumulate(b[:, ::-1], axis=1)[:, ::-1].reshape(-1)
+    j = np.arange(n - w + 1)
+    return np.maximum(suf[j], pre[j + w - 1])
+
+
 def peaks_center(counts: np.ndarray, edges: np.ndarray):
     """detect_center's pick (AutoInterpretation.py:250-277) from a histogram: the two most populated bins that are strict maxima
     over +-(window - 1) bins (bins outside the histogram count as 0), mean of their left edges; None without such a bin.  Written
-    on whole arrays: peak mask from shifted comparisons, candidates taken in the order np.argsort gives the bins (the reference's
-    walk order, which is what decides between equally populated peaks)."""
+    on whole arrays: the peak mask from sliding-window maxima to either side (linear in the number of bins -- a nearly constant message
+    has millions of them, and a comparison per bin AND offset took a minute there), candidates taken in the order np.argsort gives the
+    bins (the reference's walk order, which is what decides between equally populated peaks)."""
     y = np.asarray(counts, dtype=np.int64)
     nb = len(y)
     if nb == 0:
         return None
     reach = max(2, int(0.05 * nb) + 1) - 1
     padded = np.concatenate([np.zeros(reach, np.int64), y, np.zeros(reach, np.int64)])
-    peak = y > 0
-    for d in range(1, reach + 1):
-        peak &= (y > padded[reach - d:reach - d + nb]) & (y > padded[reach + d:reach + d + nb])
+    side = _sliding_max(padded, reach)                    # side[j] = max(padded[j : j + reach]); bin i's left window starts at padded[i]
+    peak = (y > 0) & (y > side[0:nb]) & (y > side[reach + 1:reach + 1 + nb])
     if not peak.any():
         return None
     walk = np.argsort(counts)[::-1]
