@@ -126,3 +126,66 @@ def test_fir_fuzz(oracle):
         a, b = np.ascontiguousarray(got, np.complex64).view(np.uint32), np.ascontiguousarray(want, np.complex64).view(np.uint32)
         fa, fb = a.view(np.float32), b.view(np.float32)
         assert bool(((a == b) | (np.isnan(fa) & np.isnan(fb))).all()), (it, SEED0, n, m, mag, int(((a != b) & ~(np.isnan(fa) & np.isnan(fb))).sum()))
+
+
+def test_estimate_fuzz(pipe):
+    """AutoInterpretation.estimate (AutoInterpretation.py:373-470) end to end against the REAL reference (oracle/ref_python.py) on random
+    bursty captures: FSK and OOK / ASK, random message lengths, pauses, symbol lengths, SNRs, sample types; modulation given or detected,
+    noise given or automatic.  The dict -- modulation, bit length, tolerance, center and noise as floats -- must be identical."""
+    import sys
+    import torch
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_python
+    if not ref_python.available():
+        pytest.skip("oracle/_ref (compiled reference + Python sources) not present")
+    ref_python.setup()
+    from urh.ainterpretation import AutoInterpretation as AI
+    from urh_amd import estimators
+    for it in range(ROUNDS):
+        rng = np.random.default_rng([919, SEED0, it])
+        mod = str(rng.choice(["FSK", "OOK", "ASK"]))
+        sps = int(rng.choice([8, 20, 50, 100, 250]))
+        n_msgs = int(rng.integers(1, 9))
+        sigma = float(rng.choice([0.005, 0.02, 0.06]))
+        parts = [sigma * rng.standard_normal((int(rng.integers(200, 4000)), 2))]
+        for _ in range(n_msgs):
+            nsym = int(rng.integers(12, 200))
+            bits = rng.integers(0, 2, nsym)
+            bits[:8] = [1, 0, 1, 0, 1, 0, 1, 0]
+            t = np.arange(nsym * sps)
+            if mod == "FSK":
+                f = np.repeat(np.where(bits == 1, 0.03, -0.03), sps)
+                ph = 2 * np.pi * np.cumsum(f)
+                msg = np.stack([np.cos(ph), np.sin(ph)], 1)
+            else:
+                env = np.repeat(np.where(bits == 1, 1.0, 0.0 if mod == "OOK" else 0.3), sps)
+                ph = 2 * np.pi * 0.011 * t
+                msg = np.stack([env * np.cos(ph), env * np.sin(ph)], 1)
+            amp = float(rng.choice([1.0, 0.6, 0.35]))
+            parts.append(amp * msg + sigma * rng.standard_normal(msg.shape))
+            parts.append(sigma * rng.standard_normal((int(rng.choice([sps * 15, sps * 40, 3000, 20_000])), 2)))
+        x = np.concatenate(parts)
+        dtype = [np.float32, np.float32, np.int8, np.int16][int(rng.integers(0, 4))]
+        if dtype == np.float32:
+            iq = x.astype(np.float32)
+        else:
+            info = np.iinfo(dtype)
+            iq = np.clip(np.round(x * info.max * 0.7), info.min, info.max).astype(dtype)
+        given_mod = None if rng.random() < 0.4 else mod
+        with np.errstate(all="ignore"):
+            want = AI.estimate(iq, noise=None, modulation=given_mod)
+        if given_mod is None:
+            dev_iq = torch.from_numpy(iq).cuda()
+            nz = estimators.detect_noise_level_dev(pipe, dev_iq)
+            if estimators.detect_modulation_for_messages_dev(dev_iq, estimators.segment_messages_dev(pipe, dev_iq, nz)) == "PSK":
+                continue                 # the reference's Costas demodulator leaves result[0] uninitialised: not reproducible (see the golden test)
+        got = estimators.estimate_dev(pipe, torch.from_numpy(iq).cuda(), noise=None, modulation=given_mod)
+        tag = (it, SEED0, mod, given_mod, sps, n_msgs, sigma, np.dtype(dtype).name, len(iq))
+        if want is None:
+            assert got is None, (tag, got)
+            continue
+        assert got is not None, (tag, want)
+        assert got["modulation_type"] == want["modulation_type"] and int(got["bit_length"]) == int(want["bit_length"]) \
+            and int(got["tolerance"]) == int(want["tolerance"]), (tag, got, want)
+        assert float(got["center"]) == float(want["center"]) and float(got["noise"]) == float(want["noise"]), (tag, got, want)
