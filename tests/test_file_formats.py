@@ -152,3 +152,15 @@ def test_sub_run_encoder_equals_the_reference_walk():
         assert out[:k.value].tolist() == want, (it, v.tolist(), want, out[:k.value].tolist())
     k = C.c_int64(0)
     assert lib.urhgpu_sub_encode_runs(buf.ctypes.data_as(C.c_void_p), 0, 1, None, 0, C.byref(k)) == _lib.ERR_ARG
+
+
+def test_sub_file_parser_equals_the_reference_samples():
+    """the host half of the `.sub` loader: the bytes the run lengths stand for, against the samples the real Signal held after loading the
+    same file (+0.5 where the byte is 255, -0.5 where it is 0) -- incl. the line the reference's pattern rejects, the empty value of a
+    double blank and the zero-length run (make_fileformats_golden.py)"""
+    from urh_amd import iq_array
+    exp = np.load(os.path.join(FILES, "expected.npz"))
+    want = exp["flipper.sub/iq"]
+    got = iq_array.sub_file_bytes(os.path.join(FILES, "flipper.sub"))
+    assert got.dtype == np.uint8 and len(got) == len(want) and set(np.unique(got).tolist()) <= {0, 255}
+    assert np.array_equal(np.where(got == 255, np.float32(0.5), np.float32(-0.5)), want[:, 0]) and not want[:, 1].any()

@@ -137,10 +137,10 @@ def from_wav(filename: str, device=None, ctx=None):
     return pcm_to_iq(frames, n_frames, channels, width, device, ctx), rate, channels == 1
 
 
-def from_sub(filename: str, device=None, ctx=None):
-    """Signal.__load_sub_file (Signal.py:175-205), the Flipper Zero RAW format (OOK): every `RAW_Data:` line holds run lengths in samples,
-    positive = above the center (byte 255), negative = below (byte 0); values that are no integers are skipped (the reference logs
-    them).  Returns the float32 (N, 2) device tensor (real part +-0.5, an already demodulated capture)."""
+def sub_file_bytes(filename: str) -> np.ndarray:
+    """The uint8 samples a Flipper `.sub` file stands for (Signal.__load_sub_file, Signal.py:175-200): every `RAW_Data:` line holds run
+    lengths in samples, positive = above the center (byte 255), negative = below (byte 0); values that are no integers are skipped (the
+    reference logs them), a line with anything but digits, minus signs and blanks is no RAW_Data line at all.  Host parsing only."""
     import re
     runs = []
     with open(filename, "r") as fh:
@@ -153,7 +153,14 @@ def from_sub(filename: str, device=None, ctx=None):
                     except ValueError:
                         pass
     r = np.asarray(runs, dtype=np.int64)
-    data = np.repeat(np.where(r > 0, 255, 0).astype(np.uint8), np.abs(r)) if len(r) else np.zeros(0, np.uint8)
+    return np.repeat(np.where(r > 0, 255, 0).astype(np.uint8), np.abs(r)) if len(r) else np.zeros(0, np.uint8)
+
+
+def from_sub(filename: str, device=None, ctx=None):
+    """Signal.__load_sub_file (Signal.py:175-205), the Flipper Zero RAW format (OOK): the file's run lengths as bytes (sub_file_bytes),
+    then (byte - 127.5) * (1 / 255) on the device like a mono 8-bit WAV.  Returns the float32 (N, 2) device tensor (real part +-0.5, an
+    already demodulated capture)."""
+    data = sub_file_bytes(filename)
     return pcm_to_iq(data.tobytes(), len(data), 1, 1, device, ctx)
 
 
