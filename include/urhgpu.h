@@ -587,6 +587,11 @@ int urhgpu_pcm_to_iq_dev(urhgpu_ctx *ctx, const void *d_raw, int64_t n_frames, i
  * i's first component (HOST memory; stride 2 for an (N, 2) array).  runs_out[k] > 0: that many samples above 127, < 0: at or below; the
  * reference's walk is restated exactly (a run of ONE sample never ends: the samples that differ from it are dropped until its value
  * comes back).  *n_runs is set also on URHGPU_ERR_CAPACITY.  Host arithmetic; works without a GPU. */
+/* Signal.estimate_frequency's core (Signal.py:578-601): the bin k of the largest |FFT| of n = 2^m complex64 samples (d_x: float32[n][2] on the
+ * device), the smallest such k -- what np.argmax(np.abs(np.fft.fft(data))) returns whenever the peak stands out by more than float32 rounding
+ * (single-precision butterflies like numpy's complex64 transform, twiddles rounded from float64).  n up to 2^26 (URHGPU_ERR_UNSUPPORTED
+ * beyond; n not a power of two: URHGPU_ERR_ARG).  Synchronous: *peak_index is a host value. */
+int urhgpu_fft_peak_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, int64_t *peak_index);
 int urhgpu_sub_encode_runs(const uint8_t *values, int64_t n, int64_t stride, int64_t *runs_out, int64_t cap, int64_t *n_runs);
 /* The plain numpy cast between float32 and one of the four integer sample types (no IQArray scaling): what Filter.apply_fir_filter
  * does to an integer capture before filtering (`tmp.real = input_signal[0::2]`, Filter.py:37-41: the raw values as float32) and what

@@ -376,3 +376,60 @@ def test_dialog_helpers_against_the_real_signal(pipe):
         assert np.array_equal(mn.iq.cpu().numpy(), rn.iq_array.data) and mn.timestamp == rn.timestamp == 4.5
     mine.eliminate()
     assert mine.iq is None
+
+
+def _np_estimate_frequency(iq_c64, start, end, sample_rate):
+    """Signal.estimate_frequency (Signal.py:578-601), the reference's lines on a complex64 array"""
+    import math
+    length = 2 ** int(math.log2(end - start))
+    data = iq_c64[start:start + length]
+    try:
+        w = np.fft.fft(data)
+        frequencies = np.fft.fftfreq(len(w))
+        idx = np.argmax(np.abs(w))
+        return abs(frequencies[idx] * sample_rate), w, int(idx)
+    except ValueError:
+        return 100e3, None, None
+
+
+def test_estimate_frequency_equals_numpy(pipe):
+    """tones (one dominant carrier + a weaker one + noise) over windows of 2 .. 2^24 samples -- one LDS-sized transform up to 8192, the
+    four-step form beyond --, float32 and int16 captures: the frequency numpy's FFT gives (Signal.py:578-601).  Pure noise: the bin found
+    holds a magnitude within float32 rounding of numpy's largest."""
+    from urh_amd.signal import Signal
+    rng = np.random.default_rng(31)
+    n_all = (1 << 24) + 12345
+    t = np.arange(n_all, dtype=np.float64)
+    for case, (f0, dtype) in enumerate([(0.0371, np.float32), (-0.2113, np.float32), (0.4983, np.int16), (0.00002, np.float32)]):
+        x = np.exp(2j * np.pi * f0 * t) + 0.3 * np.exp(2j * np.pi * (f0 / 3 + 0.11) * t)
+        x = x + 0.2 * (rng.standard_normal(n_all) + 1j * rng.standard_normal(n_all))
+        iq = np.stack([x.real, x.imag], 1)
+        if dtype == np.float32:
+            iq = (iq * 0.5).astype(np.float32)
+            c64 = iq.view(np.complex64).reshape(-1)
+        else:
+            iq = np.clip(np.round(iq * 8000), -32768, 32767).astype(np.int16)
+            c64 = (iq.astype(np.float32) / np.float32(32768.0)).view(np.complex64).reshape(-1)      # IQArray.as_complex64 (:92-93, :171-181)
+        sig = Signal(iq, pipe=pipe)
+        for log2len in [1, 2, 3, 5, 8, 12, 13, 14, 15, 17, 20, 22] + ([24] if case == 0 else []):
+            if n_all > (2 << log2len):
+                start = int(rng.integers(0, n_all - (2 << log2len)))
+                end = start + (1 << log2len) + int(rng.integers(0, 1 << log2len))   # the window is the largest power of two that fits
+            else:
+                start, end = 77, n_all
+            want, w, idx = _np_estimate_frequency(c64, start, end, 2e6)
+            got = sig.estimate_frequency(start, end, 2e6)
+            if got != want:                                  # a near-tie between bins (short windows): the magnitudes must agree to rounding
+                mags = np.abs(w)
+                k = int(round(got / 2e6 * len(w)))
+                cand = [mags[k % len(w)], mags[(-k) % len(w)]]
+                assert max(cand) >= mags[idx] * (1 - 2e-5), (case, log2len, start, got, want)
+            if log2len >= 12:
+                assert got == want, (case, log2len, start, got, want)
+    assert sig.estimate_frequency(100, 100, 1e6) == 100e3 and sig.estimate_frequency(200, 100, 1e6) == 100e3
+    noise = (rng.standard_normal((1 << 16, 2))).astype(np.float32)
+    sig = Signal(noise, pipe=pipe)
+    want, w, idx = _np_estimate_frequency(noise.view(np.complex64).reshape(-1), 0, 1 << 16, 1.0)
+    got = sig.estimate_frequency(0, 1 << 16, 1.0)
+    k = int(round(got * (1 << 16)))
+    assert max(np.abs(w)[k], np.abs(w)[-k]) >= np.abs(w)[idx] * (1 - 2e-5)

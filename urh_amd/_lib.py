@@ -154,6 +154,7 @@ PROTOTYPES = {
     "urhgpu_convert_dev": (_i, [_vp, _vp, _i, _vp, _i, _i64]),
     "urhgpu_pcm_to_iq_dev": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "urhgpu_sub_encode_runs": (_i, [_vp, _i64, _i64, _vp, _i64, _vp]),
+    "urhgpu_fft_peak_dev": (_i, [_vp, _vp, _i64, _vp]),
     "urhgpu_astype_dev": (_i, [_vp, _vp, _i, _vp, _i, _i64]),
     "urhgpu_path_minmax_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _vp]),
     "urhgpu_path_minmax": (_i, [_vp, _vp, _i, _i64, _i64, _i64, _i64, _vp]),

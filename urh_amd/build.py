@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liburhgpu.so")
-SOURCES = ["demod_runs.hip", "pulse_table.hip", "filters.hip", "bandpass.hip", "modulate.hip", "plot.hip", "convert.hip", "spectrogram.hip", "costas.hip", "estimators.hip", "msg_estimators.hip", "msg_ranges.hip", "modulation.hip", "compact.hip", "stream.hip", "capi.hip"]
+SOURCES = ["demod_runs.hip", "pulse_table.hip", "filters.hip", "bandpass.hip", "modulate.hip", "plot.hip", "convert.hip", "fft_peak.hip", "spectrogram.hip", "costas.hip", "estimators.hip", "msg_estimators.hip", "msg_ranges.hip", "modulation.hip", "compact.hip", "stream.hip", "capi.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 

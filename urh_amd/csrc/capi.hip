@@ -1827,6 +1827,25 @@ int urhgpu_pcm_to_iq_dev(urhgpu_ctx *ctx, const void *d_raw, int64_t n_frames, i
     return URHGPU_OK;
 }
 
+int urhgpu_fft_peak_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, int64_t *peak_index) {
+    if (!ctx || !peak_index || n < 1 || (n & (n - 1)) != 0 || !d_x) return URHGPU_ERR_ARG;
+    int log2n = 0;
+    while (((int64_t)1 << log2n) < n) ++log2n;
+    if (log2n > 26) return URHGPU_ERR_UNSUPPORTED;           // (two LDS-sized factors of at most 8192 each)
+    URH_HIP(hipSetDevice(ctx->device));
+    URH_TRY(join_tail(ctx));
+    URH_TRY(ctx->arena.reserve(fft_peak_scratch_bytes(n) + 4096));
+    ctx->arena.reset();
+    void *scratch = ctx->arena.take(fft_peak_scratch_bytes(n));
+    int64_t *d_peak = (int64_t *)ctx->arena.take(256);
+    if (!scratch || !d_peak) return URHGPU_ERR_ARG;
+    URH_TRY(launch_fft_peak((const float2 *)d_x, log2n, scratch, d_peak, ctx->stream));
+    URH_HIP(hipGetLastError());
+    URH_HIP(hipMemcpyAsync(peak_index, d_peak, 8, hipMemcpyDeviceToHost, ctx->stream));
+    URH_HIP(hipStreamSynchronize(ctx->stream));
+    return URHGPU_OK;
+}
+
 // IQArray.export_to_sub's run lengths (IQArray.py:275-304), host arithmetic on the bytes convert_to(uint8) produced on the device: the
 // reference walks the FIRST component of every sample with (lastvalue, counter) -- equal to lastvalue: counter += 1; different: when
 // counter > 1 the run is appended (positive above 127, negative otherwise) and the new value starts a run of 1, when counter is 1

@@ -105,6 +105,8 @@ int launch_bgra_lookup(const float *data, int64_t frames, int ws, const uint32_t
 int launch_convert(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, hipStream_t s);
 int launch_astype(const void *src, int src_dtype, void *dst, int dst_dtype, int64_t n, hipStream_t s);
 int launch_pcm_to_iq(const void *raw, int64_t n_frames, int channels, int width, float *out, hipStream_t s);
+size_t fft_peak_scratch_bytes(int64_t n);
+int launch_fft_peak(const float2 *x, int log2n, void *scratch, int64_t *d_peak, hipStream_t s);
 
 // ---- plot.hip ----------------------------------------------------------------------------------------
 int launch_path_minmax(const void *samples, int dtype, int64_t start, int64_t end, int64_t spp, void *values, hipStream_t s);

@@ -316,6 +316,32 @@ class Signal:
         maximum = np.float64(np.float32(out[1].item())) / np.sqrt(ma ** 2.0 + mi ** 2.0)
         return np.ceil(maximum * 10 ** num_digits) / 10 ** num_digits
 
+    def estimate_frequency(self, start: int, end: int, sample_rate: float):
+        """Signal.estimate_frequency (:578-601): the frequency of the strongest FFT bin over the largest power-of-two window that fits
+        [start, end), in Hertz (absolute value) -- urhgpu_fft_peak_dev on the window's complex64 conversion; the reference's fallback of
+        100 kHz where its FFT raises (an empty or reversed range)."""
+        import ctypes as C
+        import math
+        try:
+            length = 2 ** int(math.log2(end - start))
+        except ValueError:
+            return 100e3
+        from .iq_array import convert_to
+        data = convert_to(self._iq[start:start + length], np.float32, self.pipe.ctx).contiguous()
+        n = int(data.shape[0])
+        if n == 0:
+            return 100e3                                      # (np.fft.fft of an empty array: ValueError in the reference)
+        n_fft = n if (n & (n - 1)) == 0 else None
+        if n_fft is None:                                     # the window ran past the end of the capture: numpy transforms what is there;
+            raise ValueError("estimate_frequency: the window [start, start + 2^k) must lie inside the capture")   # not a power of two -- not built
+        peak = C.c_int64(0)
+        torch = self.pipe.torch
+        self.pipe.ctx.set_stream(torch.cuda.current_stream(self.pipe.device).cuda_stream)
+        _lib.check(_lib.load().urhgpu_fft_peak_dev(self.pipe.ctx.handle, C.c_void_p(data.data_ptr()), n, C.byref(peak)))
+        idx = int(peak.value)
+        freq = idx / n if idx < (n + 1) // 2 else (idx - n) / n          # np.fft.fftfreq(n)[idx]
+        return abs(freq * sample_rate)
+
     def create_new(self, start=0, end=0, new_data=None, new_timestamp=0):
         """Signal.create_new (:508-529): a Signal over a slice of this capture (a device copy) or over new samples, carrying this one's
         noise threshold, samples_per_symbol, bits_per_symbol, center, sample rate and file-mode flags; marked changed."""
