@@ -229,50 +229,3 @@ def test_gpu_modulate_errors_and_edges():
         sf.modulate_c([1, 0], 10, "OQPSK", [-1.0, 1.0], 1, 1.0, 0.0, 0.0, 1e6, 0, 0)          # bits_per_symbol must be 2
     with pytest.raises(AssertionError):
         sf.modulate_c([1, 0], 10, "QAM", [-1.0, 1.0], 1, 1.0, 0.0, 0.0, 1e6, 0, 0)
-
-
-@pytest.mark.gpu
-def test_modulator_object_equals_the_real_modulator():
-    """urh_amd.modulator.Modulator.modulate / get_default_parameters against the REAL reference Modulator (oracle/ref_python.py): every
-    modulation type with its default parameters at orders 2 / 4 (8 for ASK / FSK), float32 / int16 / int8 output, pauses, a start offset,
-    a carrier phase (Modulator.py:215-283).  GFSK: like test_gfsk_* -- the frequencies from numpy's convolution on this host."""
-    import os
-    import sys
-    from conftest import ROOT
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import ref_python
-    if not ref_python.available():
-        pytest.skip("oracle/_ref (compiled reference + Python sources) not present")
-    ref_python.setup()
-    from urh.signalprocessing.Modulator import Modulator as RefModulator
-    from urh_amd.modulator import Modulator
-    rng = np.random.default_rng(8)
-    for mod in ("ASK", "FSK", "PSK", "OQPSK"):
-        for bps in ((2,) if mod == "OQPSK" else (1, 2, 3) if mod in ("ASK", "FSK") else (1, 2)):
-            for dtype in (np.float32, np.int16, np.int8):
-                r, m = RefModulator("x"), Modulator("x")
-                sps = int(rng.choice([7, 40, 100]))
-                for o in (r, m):
-                    o.modulation_type = mod
-                    o.bits_per_symbol = bps
-                    o.samples_per_symbol = sps
-                    rng2 = np.random.default_rng(bps * 10 + len(mod))
-                    o.carrier_freq_hz = float(rng2.choice([40e3, 12345.0]))
-                    o.carrier_phase_deg = float(rng2.choice([0, 30]))
-                    o.carrier_amplitude = float(rng2.choice([1, 0.5]))
-                    o.sample_rate = float(rng2.choice([1e6, 2.5e5]))
-                    o.parameters = o.get_default_parameters()
-                assert r.parameters == m.parameters and r.samples_per_symbol == m.samples_per_symbol, (mod, bps)
-                bits = "".join(map(str, rng.integers(0, 2, bps * int(rng.integers(3, 60)))))
-                pause, start = int(rng.choice([0, 17, 1000])), int(rng.choice([0, 250]))
-                want = r.modulate(bits, pause=pause, start=start, dtype=dtype).data
-                got = m.modulate(bits, pause=pause, start=start, dtype=dtype)
-                assert got.dtype == want.dtype and got.shape == want.shape, (mod, bps, np.dtype(dtype).name)
-                a, b = np.ascontiguousarray(got), np.ascontiguousarray(want)
-                same = np.array_equal(a.view(np.uint32), b.view(np.uint32)) if a.dtype == np.float32 else np.array_equal(a, b)
-                assert same, (mod, bps, np.dtype(dtype).name, int((a != b).sum()))
-    assert Modulator("a") == Modulator("a") and not (Modulator("a") == Modulator("b"))
-    m = Modulator("legacy")
-    m.modulation_type = 2
-    assert m.modulation_type == "PSK" and m.is_phase_based and not m.is_frequency_based
-    assert m.modulate("").shape == (0, 2)
