@@ -236,3 +236,49 @@ def test_rccl_comm_create_agrees_on_the_fallback():
         assert res["every step succeeds"] == ("RcclComm", None), (rank, res)
     assert dict((t, k) for t, k, _ in items[0])["destroyed on the rank that had succeeded"] == 1
     assert "cannot open" in dict((t, w) for t, _, w in items[1])["load fails on rank 1"]
+
+
+class _FirEngine:
+    """the two FIR entry points of an engine, counting; the filter is a running sum so the arithmetic is checkable"""
+
+    def fir(self, iq, taps, hist):
+        x = np.concatenate([np.zeros((len(taps) - 1, 2), np.float32) if hist is None else np.asarray(hist), np.asarray(iq)])
+        m = len(taps)
+        return torch.from_numpy(np.stack([x[i:i + m].sum(0) for i in range(len(iq))]).astype(np.float32))
+
+    def fir_tail(self, iq, k):
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(iq)[-k:]))
+
+
+class _CountingComm:
+    def __init__(self, rank, world):
+        self.rank, self.world, self.calls = rank, world, 0
+
+    def all_gather(self, t):
+        self.calls += 1
+        raise AssertionError("no collective may be entered in raw-halo mode")
+
+
+def test_fir_filter_mode_is_the_same_on_every_rank():
+    """rank 0 took "raw halo" from want_halo, ranks > 0 from left_raw -- with left_raw missing everywhere rank 0
+    returned early and the others blocked in the all-gather.  The mode is one flag now: in raw mode NO rank enters a collective and a
+    rank > 0 without left_raw raises; want_halo without raw mode raises on every rank."""
+    m = 4
+    taps = np.ones((m, 2), np.float32)
+    x = torch.arange(40, dtype=torch.float32).reshape(20, 2)
+    for rank in (0, 1):
+        pipe = ShardedPipeline(_FirEngine(), _CountingComm(rank, 2))
+        if rank == 0:
+            out, halo = pipe.fir_filter(x[:10], taps, want_halo=True)
+            assert halo is None and out.shape == (10, 2)
+        else:
+            with pytest.raises(ValueError, match="left_raw"):
+                pipe.fir_filter(x[10:], taps, want_halo=True)
+            with pytest.raises(ValueError, match="left_raw"):
+                pipe.fir_filter(x[10:], taps, raw_halo=True)
+            out, halo = pipe.fir_filter(x[10:], taps, left_raw=x[10 - (m + 1):10], want_halo=True)
+            whole = _FirEngine().fir(x, taps, None)
+            assert torch.equal(out, whole[10:]) and torch.equal(halo, whole[8:10])
+        with pytest.raises(ValueError, match="raw_halo"):
+            pipe.fir_filter(x[:10], taps, want_halo=True, raw_halo=False)
+        assert pipe.comm.calls == 0

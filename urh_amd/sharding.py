@@ -303,7 +303,7 @@ class ShardedPipeline:
     def reserve(self, n_local, p):
         self.engine.reserve(n_local, p)
 
-    def fir_filter(self, iq_local, taps, left_raw=None, want_halo=False):
+    def fir_filter(self, iq_local, taps, left_raw=None, want_halo=False, raw_halo=None):
         """Signal.filter_range semantics on a sharded capture (BASELINE.json configs[3], "FIR-halo exchange"): every rank
         filters its shard with the m-1 samples that precede it as history; rank 0 starts from zero history like the
         reference's fir_filter (signal_functions.pyx:513-525).  Returns the filtered shard (same shape as iq_local).
@@ -311,18 +311,28 @@ class ShardedPipeline:
         left_raw given (every rank but the first; round 5): whoever distributed the capture handed the rank the m + 1 RAW samples
         that precede its shard ((m + 1, 2) float32 / complex64 (m + 1,): 520 bytes for 64 taps) -- no exchange at all: the last
         m - 1 of them are the filter's history, and filtering the m + 1 themselves gives, in their last two outputs, the two FILTERED
-        samples before the shard, i.e. the demodulation's halo (want_halo=True: returns (filtered shard, that halo or None))."""
+        samples before the shard, i.e. the demodulation's halo (want_halo=True: returns (filtered shard, that halo or None)).
+        raw_halo states the mode and must be THE SAME ON EVERY RANK (a rank that guessed it from its own arguments could skip a
+        collective the others enter): True = raw mode (rank 0 passes no left_raw, every other rank must), False = exchange,
+        None = raw mode iff want_halo (the halo only exists in raw mode; left_raw without want_halo also selects it on ranks > 0,
+        where rank 0 then has to say raw_halo=True)."""
         e, c = self.engine, self.comm
+        if raw_halo is None:
+            raw_halo = bool(want_halo) or left_raw is not None
         m = int(taps.shape[0])                     # complex64 (m,) or float32 (m, 2): rows = taps
         if m <= 1 or self.world == 1:
             out = e.fir(iq_local, taps, None)
             return (out, None) if want_halo else out
         if int(iq_local.shape[0]) < m - 1:
             raise ValueError("shard shorter than the filter history")
-        if left_raw is not None or (want_halo and self.rank == 0):
+        if want_halo and not raw_halo:
+            raise ValueError("want_halo needs raw_halo: the filtered halo comes from the raw samples handed over with the shard")
+        if raw_halo:
             if self.rank == 0:
                 out = e.fir(iq_local, taps, None)
                 return (out, None) if want_halo else out
+            if left_raw is None:
+                raise ValueError("raw_halo: ranks > 0 pass the m + 1 raw samples that precede their shard as left_raw")
             raw = left_raw
             if hasattr(e, "torch") and raw.dtype == e.torch.complex64:
                 raw = e.torch.view_as_real(raw)
@@ -333,8 +343,7 @@ class ShardedPipeline:
                 return out
             return out, e.fir(raw.contiguous(), taps, None)[-2:].contiguous()     # outputs m - 1 and m have their full history inside `raw`
         tails = c.all_gather(e.fir_tail(iq_local, m - 1))
-        out = e.fir(iq_local, taps, tails[self.rank - 1] if self.rank > 0 else None)
-        return (out, None) if want_halo else out
+        return e.fir(iq_local, taps, tails[self.rank - 1] if self.rank > 0 else None)
 
     def iq_to_bits(self, iq_local, p, want_qad=True, pos_base=None, n_total=None, halo_given=False, left_halo=None):
         """iq_local: this rank's shard.  pos_base / n_total default to equal shards of len(iq_local).
