@@ -85,6 +85,11 @@ template <> struct Iq<URHGPU_DT_F32> {
     static __device__ __forceinline__ void load1(const void *b, int64_t i, float &c, float &d) {
         float2 v = ((const float2 *)b)[i]; c = v.x; d = v.y;
     }
+    // a lane's two samples at `ptr` (16-byte aligned)
+    static __device__ __forceinline__ void ld(const void *ptr, float &c0, float &d0, float &c1, float &d1) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load((const v4f *)ptr); c0 = v.x; d0 = v.y; c1 = v.z; d1 = v.w;
+    }
 };
 template <> struct Iq<URHGPU_DT_I8> {
     static constexpr int kBytes = 2;
@@ -93,6 +98,9 @@ template <> struct Iq<URHGPU_DT_I8> {
     }
     static __device__ __forceinline__ void load1(const void *b, int64_t i, float &c, float &d) {
         char2 v = ((const char2 *)b)[i]; c = (float)v.x; d = (float)v.y;
+    }
+    static __device__ __forceinline__ void ld(const void *ptr, float &c0, float &d0, float &c1, float &d1) {
+        char4 v = *(const char4 *)ptr; c0 = (float)v.x; d0 = (float)v.y; c1 = (float)v.z; d1 = (float)v.w;
     }
 };
 template <> struct Iq<URHGPU_DT_U8> {
@@ -103,6 +111,9 @@ template <> struct Iq<URHGPU_DT_U8> {
     static __device__ __forceinline__ void load1(const void *b, int64_t i, float &c, float &d) {
         uchar2 v = ((const uchar2 *)b)[i]; c = (float)v.x; d = (float)v.y;
     }
+    static __device__ __forceinline__ void ld(const void *ptr, float &c0, float &d0, float &c1, float &d1) {
+        uchar4 v = *(const uchar4 *)ptr; c0 = (float)v.x; d0 = (float)v.y; c1 = (float)v.z; d1 = (float)v.w;
+    }
 };
 template <> struct Iq<URHGPU_DT_I16> {
     static constexpr int kBytes = 4;
@@ -112,6 +123,9 @@ template <> struct Iq<URHGPU_DT_I16> {
     static __device__ __forceinline__ void load1(const void *b, int64_t i, float &c, float &d) {
         short2 v = ((const short2 *)b)[i]; c = (float)v.x; d = (float)v.y;
     }
+    static __device__ __forceinline__ void ld(const void *ptr, float &c0, float &d0, float &c1, float &d1) {
+        short4 v = *(const short4 *)ptr; c0 = (float)v.x; d0 = (float)v.y; c1 = (float)v.z; d1 = (float)v.w;
+    }
 };
 template <> struct Iq<URHGPU_DT_U16> {
     static constexpr int kBytes = 4;
@@ -120,6 +134,9 @@ template <> struct Iq<URHGPU_DT_U16> {
     }
     static __device__ __forceinline__ void load1(const void *b, int64_t i, float &c, float &d) {
         ushort2 v = ((const ushort2 *)b)[i]; c = (float)v.x; d = (float)v.y;
+    }
+    static __device__ __forceinline__ void ld(const void *ptr, float &c0, float &d0, float &c1, float &d1) {
+        ushort4 v = *(const ushort4 *)ptr; c0 = (float)v.x; d0 = (float)v.y; c1 = (float)v.z; d1 = (float)v.w;
     }
 };
 
@@ -229,6 +246,7 @@ __device__ __forceinline__ void atan_reduce(float ax, bool mid, float t, float &
 
 // two quotients at once: the fma chain as 2-vectors (v_pk_fma_f32 / v_pk_mul_f32)
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void div_fast2(float n0, float d0, float n1, float d1, float &q0, float &q1) {
     const v2f n = {n0, n1}, d = {d0, d1}, one = {1.0f, 1.0f};
     v2f r = {__builtin_amdgcn_rcpf(d0), __builtin_amdgcn_rcpf(d1)};
@@ -375,6 +393,36 @@ __device__ __forceinline__ void load_rows(const RunArgs &p, int64_t ta, int rb, 
             if (FULL || i0 + 1 < a1) Iq<DT>::load2(p.in, i0, r[j].c0, r[j].d0, r[j].c1, r[j].d1);
             else if (i0 < a1) Iq<DT>::load1(p.in, i0, r[j].c0, r[j].d0);
         }
+    }
+}
+
+// The bit-plane kernel's loader: whole rows only; row rb + j of the chunk at sample a0 is a wavefront-uniform base (scalar arithmetic)
+// plus the lane's 32-bit byte offset -- the global_load's SGPR-base + VGPR-offset form, no 64-bit VALU address arithmetic per row.
+template <int SRC, int DT, int NB>
+__device__ __forceinline__ void load_rows_bp(const RunArgs &p, int64_t a0, int rb, int lane, RowIn (&r)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int64_t i0 = a0 + (int64_t)(rb + j) * kRowSamples;            // first sample of the row (uniform)
+        if (SRC == SRC_QAD) {
+            const char *row = (const char *)((const float *)p.in + i0);
+            const float2 v = *(const float2 *)(row + (uint32_t)lane * 8u);
+            r[j].c0 = v.x; r[j].d0 = v.y; r[j].c1 = r[j].d1 = 0.f;
+        } else {
+            const char *row = (const char *)p.in + i0 * Iq<DT>::kBytes;
+            Iq<DT>::ld(row + (uint32_t)lane * (2u * Iq<DT>::kBytes), r[j].c0, r[j].d0, r[j].c1, r[j].d1);
+        }
+    }
+}
+
+// ... the same rows as whole 4-vectors (the complex64 FSK fast loop keeps them as the load delivers them)
+template <int DT, int NB>
+__device__ __forceinline__ void load_rows_v4(const RunArgs &p, int64_t a0, int rb, int lane, v4f (&r)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const char *row = (const char *)p.in + (a0 + (int64_t)(rb + j) * kRowSamples) * Iq<DT>::kBytes;
+        float c0, d0, c1, d1;
+        Iq<DT>::ld(row + (uint32_t)lane * (2u * Iq<DT>::kBytes), c0, d0, c1, d1);
+        r[j].x = c0; r[j].y = d0; r[j].z = c1; r[j].w = d1;
     }
 }
 
@@ -531,6 +579,86 @@ __device__ __forceinline__ void fsk_row_general(const RowIn &r, float prev_c, fl
         if (s) out[1] = q; else out[0] = q;
     }
     q0 = out[0]; q1 = out[1];
+}
+
+// ---- the batch-level FSK fast path (round 6: the VALU diet of the hot loop) ---------------------------------------------------
+// spec_pair's arithmetic for a whole batch of rows with ONE flag for the batch, in two halves so that the rows' registers are free for
+// the next batch's loads after the first:
+//   fsk_front   the products, on the register pairs the 16-byte load delivers -- X0 = (c0, d0), X1 = (c1, d1): every v_pk_* reads
+//               aligned pairs as they are (no v_mov marshalling):
+//                 A = P * X0 = (pc c0, pd d0)    re0 = A.x + A.y       C = X0 * X1    = (c0 c1, d0 d1)   re1 = C.x + C.y
+//                 B = P * X0.yx = (pc d0, pd c0) im0 = B.x - B.y       D = X0 * X1.yx = (c0 d1, d0 c1)   im1 = D.x - D.y
+//               (the same products, sums and differences, each rounded once, as spec_pair's), the smallest |sample|^2 of the batch,
+//               and the seam operand for the batch after it;
+//   fsk_divide  t = im / re (div_fast), z = t t, and the batch's flag.  The range tests are taken over the batch with integer
+//               min / max on the BIT PATTERNS (a NaN or a negative float is a large unsigned number: nothing hides, unlike v_max_f32):
+//                 re in [2^-40, 2^40)                 the fast division's window;
+//                 z = fl(t t) in [2^-58, 0.4375^2)    <=> 2^-29 <= |t| < 0.4375: both bounds are exactly representable squares and
+//                                                     rounding is monotonic (the largest float below 0.4375 squares to 1.75 ulp below
+//                                                     0.19140625); z is never negative;
+//                 min |sample|^2 > noise_sqrd         nothing gated (v_min_f32 skips a NaN operand, but a NaN sample makes re a NaN).
+//               An exactly zero cross product has z = 0: flagged.
+//   fsk_finish  q = t - poly(t) for the batches that were not flagged.
+// A flagged batch goes through demod_batch (the per-row pass) on its rows loaded again.
+constexpr uint32_t kZLo = 0x22800000u /* 2^-58 */, kZHi = 0x3e440000u /* 0.19140625 = 0.4375^2 */;
+__device__ __forceinline__ v2f atanf_poly2(v2f x, v2f z) {          // urh_atanf_poly on two samples: x (s1 + s2), z = x x given
+    const float aT0 = 3.3333334327e-01f, aT1 = -2.0000000298e-01f, aT2 = 1.4285714924e-01f, aT3 = -1.1111110449e-01f,
+                aT4 = 9.0908870101e-02f, aT5 = -7.6918758452e-02f, aT6 = 6.6610731184e-02f, aT7 = -5.8335702866e-02f,
+                aT8 = 4.9768779427e-02f, aT9 = -3.6531571299e-02f, aT10 = 1.6285819933e-02f;
+    const v2f w = z * z;
+    const v2f s1 = z * (aT0 + w * (aT2 + w * (aT4 + w * (aT6 + w * (aT8 + w * aT10)))));
+    const v2f s2 = w * (aT1 + w * (aT3 + w * (aT5 + w * (aT7 + w * aT9))));
+    return x * (s1 + s2);
+}
+__device__ __forceinline__ v2f div_fast2v(v2f n, v2f d) {
+    const v2f one = {1.0f, 1.0f};
+    v2f r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const v2f e = __builtin_elementwise_fma(-d, r, one);
+    r = __builtin_elementwise_fma(e, r, r);
+    v2f q = n * r;
+    const v2f e2 = __builtin_elementwise_fma(-d, q, n);
+    q = __builtin_elementwise_fma(e2, r, q);
+    const v2f e3 = __builtin_elementwise_fma(-d, q, n);
+    return __builtin_elementwise_fma(e3, r, q);
+}
+template <int NB> struct FskFront { v2f re[NB], im[NB]; float mag_min; };
+// rows as the load delivers them: (c0, d0, c1, d1) in four consecutive registers
+template <int NB>
+__device__ __forceinline__ void fsk_front(const v4f (&cur)[NB], float &prev_c, float &prev_d, FskFront<NB> &f) {
+    float mag_min = 0.f;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const v2f X0 = cur[j].xy, X1 = cur[j].zw;
+        const v2f M0 = X0 * X0, M1 = X1 * X1;
+        const float m = __builtin_fminf(M0.x + M0.y, M1.x + M1.y);
+        mag_min = (j == 0) ? m : __builtin_fminf(mag_min, m);
+        const v2f P = {dpp_wave_shr1(X1.x, prev_c), dpp_wave_shr1(X1.y, prev_d)};
+        const v2f A = P * X0, B = P * X0.yx, C = X0 * X1, D = X0 * X1.yx;
+        // the four horizontal sums as scalar instructions into the halves of re / im (left alone, the compiler gathers their operands
+        // into pairs with three v_mov per v_pk_add)
+        float re0 = A.x + A.y, re1 = C.x + C.y, im0 = B.x - B.y, im1 = D.x - D.y;
+        __asm__("" : "+v"(re0)); __asm__("" : "+v"(re1)); __asm__("" : "+v"(im0)); __asm__("" : "+v"(im1));
+        f.re[j] = v2f{re0, re1}; f.im[j] = v2f{im0, im1};
+        prev_c = lane63(X1.x); prev_d = lane63(X1.y);
+    }
+    f.mag_min = mag_min;
+}
+template <int NB>
+__device__ __forceinline__ bool fsk_divide(const FskFront<NB> &f, const RunArgs &p, v2f (&t)[NB], v2f (&z)[NB]) {
+    uint32_t re_max = 0u, re_min = 0u, z_max = 0u, z_min = 0u;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        t[j] = div_fast2v(f.im[j], f.re[j]);
+        z[j] = t[j] * t[j];
+        const uint32_t r0b = __float_as_uint(f.re[j].x), r1b = __float_as_uint(f.re[j].y), z0b = __float_as_uint(z[j].x), z1b = __float_as_uint(z[j].y);
+        re_max = (j == 0) ? max(r0b, r1b) : max(re_max, max(r0b, r1b)); re_min = (j == 0) ? min(r0b, r1b) : min(re_min, min(r0b, r1b));
+        z_max = (j == 0) ? max(z0b, z1b) : max(z_max, max(z0b, z1b)); z_min = (j == 0) ? min(z0b, z1b) : min(z_min, min(z0b, z1b));
+    }
+    // (one ballot per compare: the masks are OR-ed on the scalar unit; a ballot of the OR-ed condition costs a v_cndmask + v_cmp)
+    const uint64_t any = __builtin_amdgcn_ballot_w64(re_max >= kReLo + kReSpan) | __builtin_amdgcn_ballot_w64(re_min < kReLo) |
+                         __builtin_amdgcn_ballot_w64(z_max >= kZHi) | __builtin_amdgcn_ballot_w64(z_min < kZLo) |
+                         __builtin_amdgcn_ballot_w64(f.mag_min <= p.noise_sqrd);
+    return any != 0;
 }
 
 // Demodulate one batch of NB rows (cur[j] = a lane's two samples of row j).  (prev_c, prev_d) is the IQ sample before
@@ -1023,7 +1151,7 @@ template <int SRC, int MOD> constexpr int bp_waves() { return (SRC == SRC_IQ && 
 #define URH_INT_WAVES7 1
 #endif
 template <int SRC, int DT, int MOD, bool RUNS, int NPL> constexpr bool bp_seven() {
-    return URH_INT_WAVES7 && SRC == SRC_IQ && DT != URHGPU_DT_F32 && MOD == URHGPU_MOD_FSK && RUNS && NPL == 1;
+    return URH_INT_WAVES7 && SRC == SRC_IQ && MOD == URHGPU_MOD_FSK && RUNS && NPL == 1;
 }
 template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1, bool STAMPS = false>
 __global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) __attribute__((amdgpu_waves_per_eu((STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? 7 : 1, (STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? 7 : 8)))
@@ -1056,8 +1184,11 @@ void k_demod_runs_bp(const RunArgs p) {
 
     // the first batch of rows is requested before the prologue's (dependent, wavefront-uniform) loads: their latency overlaps
     constexpr int kBatch = URH_KBATCH;
-    RowIn cur[kBatch], nxt[kBatch];
-    load_rows<SRC, DT, true>(p, a0, r0, lane, a1, cur);
+    constexpr bool kFskFast = URH_SPEC && SRC == SRC_IQ && MOD == URHGPU_MOD_FSK && DT == URHGPU_DT_F32;
+    RowIn cur[kBatch] = {}, nxt[kBatch];
+    v4f cv[kBatch], nv[kBatch];                               // kFskFast: the rows as 4-vectors
+    if (kFskFast) load_rows_v4<DT>(p, a0, r0, lane, cv);
+    else load_rows_bp<SRC, DT>(p, a0, r0, lane, cur);
     if (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK) { atan_table_init(); __syncthreads(); }      // (the loads above are in flight)
 
     float prev_c = 0.f, prev_d = 0.f;                         // IQ sample before my first row (FSK seam operand)
@@ -1072,15 +1203,13 @@ void k_demod_runs_bp(const RunArgs p) {
     // ================= phase 1: demodulate, one compare mask per plane and parity, parked in lane `row` ==============
     uint32_t spec_hint = 0;                                    // demod_batch: batches left that skip the speculative pass
     uint32_t pl[NPL + 1][2][2] = {};                          // [state planes ..., PAUSE][even, odd samples][low, high word]: lane r <- row r
-#pragma unroll 1
-    for (int rb = r0; rb < r0 + R; rb += kBatch) {
-        if (rb + kBatch < r0 + R) load_rows<SRC, DT, true>(p, a0, rb + kBatch, lane, a1, nxt);
-        float q0[kBatch], q1[kBatch];
-        const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1, spec_hint);
+    // what follows the demodulation of a batch: qad stores (wavefront-uniform row base + the lane's 32-bit offset: no VALU address
+    // arithmetic), the compare masks, their parking
+    auto emit = [&](const RowIn (&rows)[kBatch], float (&q0)[kBatch], float (&q1)[kBatch], const uint32_t gated, const int rb, const bool may_row0) {
+        float *const qrow = WRITE_QAD ? p.qad + a0 + (int64_t)rb * kRowSamples : nullptr;     // wavefront-uniform
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
-            const int off = (rb + j) * kRowSamples + 2 * lane;
-            const bool row0 = (j == 0) && (rb == 0) && first_row;
+            const bool row0 = may_row0 && (j == 0) && (rb == 0) && first_row;
             if (SRC == SRC_IQ) {
                 if (row0 && lane == 0 && !p.seg_mode) q0[0] = p.noise_val;            // result[0] = NOISE (:361)
                 if (WRITE_QAD) {
@@ -1088,17 +1217,18 @@ void k_demod_runs_bp(const RunArgs p) {
                     if (MOD == URHGPU_MOD_ASK && DT == URHGPU_DT_F32 && p.seg_mode) {
                         // the segmentation pass leaves the ASK demodulation of the same samples (signal_functions.pyx:343-378, ASK branch,
                         // with the demodulation's own constants; result[0] = NOISE): the estimator needs both and this one has the samples
-                        const float m0 = cur[j].c0 * cur[j].c0 + cur[j].d0 * cur[j].d0, m1 = cur[j].c1 * cur[j].c1 + cur[j].d1 * cur[j].d1;
+                        const float m0 = rows[j].c0 * rows[j].c0 + rows[j].d0 * rows[j].d0, m1 = rows[j].c1 * rows[j].c1 + rows[j].d1 * rows[j].d1;
                         w0 = (m0 <= p.dm_noise_sqrd) ? p.dm_noise_val : __builtin_sqrtf(m0) / p.dm_max_magnitude;
                         w1 = (m1 <= p.dm_noise_sqrd) ? p.dm_noise_val : __builtin_sqrtf(m1) / p.dm_max_magnitude;
                         if (row0 && lane == 0) w0 = p.dm_noise_val;
                     }
-#if URH_NT
                     typedef float v2s __attribute__((ext_vector_type(2)));
                     const v2s qq = {w0, w1};
-                    __builtin_nontemporal_store(qq, (v2s *)(p.qad + a0 + off));
+                    v2s *const dst = (v2s *)((char *)(qrow + j * kRowSamples) + (uint32_t)lane * 8u);
+#if URH_NT
+                    __builtin_nontemporal_store(qq, dst);
 #else
-                    *(float2 *)(p.qad + a0 + off) = make_float2(w0, w1);
+                    *dst = qq;
 #endif
                 }
             }
@@ -1134,8 +1264,53 @@ void k_demod_runs_bp(const RunArgs p) {
                 }
             }
         }
+    };
+    // complex64 FSK: the batch-level fast path (fsk_front / fsk_divide / atanf_poly2) as a tight inner loop of its own -- nothing of the
+    // per-row machinery (hint forms, re-dos, the general atan2f) shares its registers or its instruction-cache lines; a flagged batch
+    // -- rare -- leaves it for ONE step of the generic body (demod_batch), which may set the hint that keeps the following batches there.
+    // The capture's very first batch (result[0] = NOISE) is a generic step too.
+    const int r_end = r0 + R;
+    if (kFskFast) {
+        int rb = r0;
+        for (;;) {
+#pragma unroll 1
+            while (rb < r_end && spec_hint == 0 && !(first_row && rb == 0)) {
+                if (rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);
+                FskFront<kBatch> f;
+                float nc = prev_c, nd = prev_d;
+                fsk_front<kBatch>(cv, nc, nd, f);
+                v2f t[kBatch], z[kBatch];
+                if (__builtin_expect(fsk_divide<kBatch>(f, p, t, z), 0)) break;          // cv still holds batch rb
+                float q0[kBatch], q1[kBatch];
 #pragma unroll
-        for (int j = 0; j < kBatch; ++j) cur[j] = nxt[j];
+                for (int j = 0; j < kBatch; ++j) { const v2f q = t[j] - atanf_poly2(t[j], z[j]); q0[j] = q.x; q1[j] = q.y; }
+                prev_c = nc; prev_d = nd;
+                emit(cur, q0, q1, 0u, rb, false);          // (`cur`: read by the float32 segmentation pass only, not this instantiation)
+#pragma unroll
+                for (int j = 0; j < kBatch; ++j) cv[j] = nv[j];
+                rb += kBatch;
+            }
+            if (rb >= r_end) break;
+            float q0[kBatch], q1[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) { cur[j].c0 = cv[j].x; cur[j].d0 = cv[j].y; cur[j].c1 = cv[j].z; cur[j].d1 = cv[j].w; }
+            if (rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);
+            const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1, spec_hint);
+            emit(cur, q0, q1, gated, rb, true);
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) cv[j] = nv[j];
+            rb += kBatch;
+        }
+    } else {
+#pragma unroll 1
+        for (int rb = r0; rb < r_end; rb += kBatch) {
+            float q0[kBatch], q1[kBatch];
+            if (rb + kBatch < r_end) load_rows_bp<SRC, DT>(p, a0, rb + kBatch, lane, nxt);
+            const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1, spec_hint);
+            emit(cur, q0, q1, gated, rb, true);
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) cur[j] = nxt[j];
+        }
     }
 
     if (!RUNS) return;
