@@ -94,12 +94,15 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
  *                              stream whose CU mask leaves that many CUs of every XCD out -- on 224 of the MI355X's 256 CUs the kernel is 5 %
  *                              faster than on all of them, and the CUs left alone serve the previous pass's tail; 0: no mask
  *   "profile_bracket"          1: urhgpu_ctx_profile_* report the stream-level bracket, which reads 3-5 % longer than the kernel runs
- *   "stream_policy"            which tail a pass of urhgpu_stream_* takes.  5 (default): 3 for passes that ship no positions or ship them
- *                              directly, 0 otherwise; 0: segments beside the hot kernel when nothing of an earlier pass is still running (one
+ *   "stream_policy"            which tail a pass of urhgpu_stream_* takes.  5 (default): 6 (4 with "stream_latency") for passes that ship no
+ *                              positions or ship them directly, 0 otherwise; 0: segments beside the hot kernel when nothing of an earlier pass is still running (one
  *                              capture, where the tail's latency counts), else the blob is packed at the end and copied by the copy engine;
  *                              1: every qualifying pass in segments; 2: never; 3: every qualifying pass DIRECT -- the ordinary tail behind the
  *                              hot kernel, whose kernels store rows and packed results into the pinned host blob themselves; 4: segments when
- *                              idle, direct otherwise
+ *                              idle, direct otherwise; 6 (what 5 resolves to for back-to-back passes since round 6): STAGED -- the direct pass's
+ *                              kernels store into a staging blob in HBM, one small kernel tightens it and the copy engine ships it with one
+ *                              copy of the predicted size (kernel stores into pinned host memory beside the next hot kernel cost that kernel
+ *                              10 us per GiB pass: profiles/r06b_skips.txt)
  *   "stream_latency"           1: under the default policy a pass that finds the pipeline idle -- ONE capture -- runs its tail in segments
  *                              (lowest latency); 0, default: direct passes throughout (highest throughput for back-to-back passes)
  *   "stream_segments"          rows segments of a segmented pass, 1 .. 16, default 7

@@ -448,8 +448,9 @@ static int segment_bounds(int64_t n_chunks, int wanted, int shape, int last_unit
 }
 
 int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, const urhgpu_outputs *out, void *host_blob,
-                        int64_t cap_host, hipEvent_t ev_ready, bool *streamed, const void *h_iq) {
+                        int64_t cap_host, hipEvent_t ev_ready, bool *streamed, const void *h_iq, void *stage_blob, bool *staged, hipEvent_t ev_rows) {
     *streamed = false;
+    if (staged) *staged = false;
     if (!ctx || !p || !out || n <= 0 || !d_iq || !out->rows || !out->counts) return URHGPU_ERR_ARG;
     if (dtype_bytes(p->dtype) == 0) return URHGPU_ERR_DTYPE;
     const bool want_bits = out->bits && out->msg_off && out->pauses && out->pos_off;
@@ -478,10 +479,17 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     // Policy 5 (the default): direct when the pass ships no positions (measured, profiles/r04c_ab_direct.txt: 0.294-0.300 ms per
     // pipelined step against 0.306 through pack + copy engine, one capture alone the same as with segments), policy 0 when it does --
     // 5.4 MB of uint32 positions stored over PCIe by a pack kernel take longer than the copy engine needs for the whole blob (0.41 ms).
+    // STAGED passes (stream_policy 6; round 6): a direct pass whose "host blob" is a staging blob in HBM (stage_blob, the split layout of
+    // compact.hpp: staged_layout); the caller ships it with the copy engine -- the row sections behind ev_rows, i.e. while the bits are
+    // still being expanded, the head behind ev_ready.  Why: the row kernel's 1- and 4-byte
+    // stores into pinned host memory -- 3.3 MB per GiB as some 10^5 partial-line PCIe writes issued over the 100 us the kernel runs beside
+    // the next hot kernel -- cost that hot kernel 10 us per step (profiles/r06b_skips.txt: 0.2855 -> 0.2751 ms without them, the same as
+    // without the row kernel altogether); the copy engine's writes do not pass through the shader's memory path.
     int policy = ctx->tune_stream_policy;
-    if (policy == 5) policy = (p->write_bit_sample_pos && out->pos && !ctx->tune_stream_pos_direct) ? 0 : (ctx->tune_stream_latency ? 4 : 3);
-    bool direct = false;
-    if (!h_iq && runs_streamable(a) && host_blob && policy == 3) direct = true;
+    if (policy == 5) policy = (p->write_bit_sample_pos && out->pos && !ctx->tune_stream_pos_direct) ? 0 : (ctx->tune_stream_latency ? 4 : (stage_blob ? 6 : 3));
+    if (policy == 6 && !stage_blob) policy = 3;
+    bool direct = false, to_stage = false;
+    if (!h_iq && runs_streamable(a) && host_blob && (policy == 3 || policy == 6)) { direct = true; to_stage = (policy == 6); }
     if (S < 2 && !direct) return URHGPU_OK;                    // too short to cut, or not the bit-plane kernel's work: the ordinary path
     if (policy == 2 && !h_iq) return URHGPU_OK;
     if ((policy == 0 || policy == 4) && ctx->passes_begun > 0 && !h_iq) {
@@ -490,10 +498,11 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         if (q == hipErrorNotReady) {
             (void)hipGetLastError();
             if (policy == 0 || !host_blob) return URHGPU_OK;
-            direct = true;
+            direct = true; to_stage = (stage_blob != nullptr);
         } else if (q != hipSuccess) URH_HIP(q);
     }
     if (direct) { S = 1; bound[0] = 0; bound[1] = pl.n_chunks; }
+    if (to_stage) { host_blob = stage_blob; if (staged) *staged = true; }
     const bool event_start = (h_iq != nullptr) || direct;      // the rows segments start behind events, not behind polling gates
     if (!ctx->d_seg) {
         URH_HIP(hipMalloc(&ctx->d_seg, 3 * kSegBlockBytes));
@@ -626,7 +635,11 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     e.rows = out->rows; e.cap_rows = out->cap_rows; e.d_ts_carry = nullptr; e.is_ask = 0; e.sps = p->samples_per_symbol;
     BitsOut bo{out->bits, out->cap_bits, out->msg_off, out->pauses, out->cap_msg, out->pos, out->cap_pos, out->pos_off, out->counts, out->h_counts};
     if (host_blob) { h_state = (int8_t *)((char *)host_blob + host_layout.off_row_state); h_len = (int32_t *)((char *)host_blob + host_layout.off_row_len); }
-    SegPackDst dst{host_blob, cap_host, progress, 0, (direct && ctx->tune_stream_pos_direct) ? 1 : 0};
+    if (to_stage) {
+        const StagedLayout SL = staged_layout(out->cap_rows, out->cap_bits, out->cap_msg, out->cap_pos, has_pos);
+        h_state = (int8_t *)((char *)host_blob + SL.off_row_state); h_len = (int32_t *)((char *)host_blob + SL.off_row_len);
+    }
+    SegPackDst dst{host_blob, cap_host, progress, 0, (direct && ctx->tune_stream_pos_direct) ? 1 : 0, to_stage ? 1 : 0};
     // bits segments: the last one is the last rows segment alone (what is exposed behind the hot kernel), the others share the rest
     int Sb = h_iq ? S : 1;       // (an upload: every piece's bits behind its rows -- the pieces are milliseconds apart)
     if (Sb > S) Sb = S;
@@ -646,6 +659,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         RowsSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], SegGate{event_start ? nullptr : progress, k, target[k], k == 0 ? 1 : 0, st, (long long)200000000, 0},
                        h_state, h_len, 1};
         URH_TRY(launch_rows_segment(r, e, tm, bp, st, sg, ts));
+        if (to_stage && ev_rows) URH_HIP(hipEventRecord(ev_rows, ts));      // (one segment: every row section is in the staging blob)
         while (jb < Sb && bits_end_at[jb] < k) ++jb;           // (a bits segment that would end before the first rows segment: none)
         if (jb < Sb && bits_end_at[jb] == k) {
             const bool last = (jb == Sb - 1);
@@ -857,7 +871,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "profile_bracket")) ctx->prof_bracket = value != 0;
     else if (!strcmp(key, "hot_cus_removed_per_xcd")) { if (value < 0 || value > 16) return URHGPU_ERR_ARG; ctx->tune_hot_cus_removed = value; }
     else if (!strcmp(key, "stream_segments")) { if (value < 1 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_stream_segments = value; }
-    else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 5) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
+    else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 6) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
     else if (!strcmp(key, "stream_latency")) { ctx->tune_stream_latency = value != 0; }
     else if (!strcmp(key, "stream_pos_direct")) { ctx->tune_stream_pos_direct = value != 0; }
     else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }

@@ -37,6 +37,23 @@ __host__ __device__ inline BlobLayout blob_layout(const int64_t *counts5, int64_
     return L;
 }
 
+// Staged passes (urhgpu_stream_*, stream_policy 6): the blob in a SPLIT layout -- a head region (header + pauses / msg_off / pos_off / bits,
+// tight by their counts: what the pass's last kernel writes) and, behind the head's capacity, the three big sections at offsets the
+// CAPACITIES give (row_state, row_len: stored by the row kernel as it emits rows; pos32), so that the rows can be copied to the host
+// while the bits are still being expanded.  Same total as blob_capacity (the same sections in another order).
+struct StagedLayout { int64_t head_cap, off_row_state, off_row_len, off_pos32, total; };
+__host__ __device__ inline StagedLayout staged_layout(int64_t cap_rows, int64_t cap_bits, int64_t cap_msg, int64_t cap_pos, int has_pos) {
+    const int64_t c[5] = {0, cap_msg, cap_bits, 0, 0};
+    auto up = [](int64_t x) { return (x + 15) & ~int64_t(15); };
+    StagedLayout S;
+    S.head_cap = blob_layout(c, cap_rows, cap_bits, cap_msg, cap_pos, 0).total;
+    S.off_row_state = S.head_cap;
+    S.off_row_len = up(S.off_row_state + cap_rows);
+    S.off_pos32 = up(S.off_row_len + 4 * cap_rows);
+    S.total = up(S.off_pos32 + (has_pos ? 4 * cap_pos : 0));
+    return S;
+}
+
 // capacity of a blob for the given output capacities (what the caller allocates)
 inline int64_t blob_capacity(int64_t cap_rows, int64_t cap_bits, int64_t cap_msg, int64_t cap_pos, int has_pos) {
     const int64_t c[5] = {cap_rows, cap_msg, cap_bits, cap_pos, cap_rows};

@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitT
             const int64_t len = (gi == 0) ? pos + 1 : pos - ppos;
             const int64_t state = (int64_t)pst - 1;
             if (gi - row_base < a.cap_rows) {
-                *(longlong2 *)(a.rows + 2 * (gi - row_base)) = longlong2{(long long)state, (long long)len};
+                if (a.rows) *(longlong2 *)(a.rows + 2 * (gi - row_base)) = longlong2{(long long)state, (long long)len};
                 if (g.h_state) { g.h_state[gi - row_base] = (int8_t)state; g.h_len[gi - row_base] = (int32_t)len; }
             }
             if (g.ft.want_bits) {
@@ -1823,6 +1823,7 @@ struct SegPack {
     int parity, final;
     uint32_t *progress;      // the last segment zeroes the pass's counters for the next pass on this arena
     int pos_shipped;         // the positions have been stored into the host blob by the kernels that wrote them (GroupStore::h_pos)
+    int split;               // staged pass (one segment): the small sections go tight behind the header, L's row / position offsets are the split layout's
 };
 __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
     URH_TAIL_PRIO();
@@ -1833,8 +1834,14 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
     const int64_t j0 = lim(in.ship_bits, a.cap_bits) / 8, j1 = a.final ? (nbits + 7) / 8 : nbits / 8;
     const int64_t p0 = a.has_pos ? lim(in.ship_pos, a.cap_pos) : 0, p1 = a.has_pos ? lim(a.seg->end_pos, a.cap_pos) : 0;
     const int64_t m0 = lim(in.ship_msgs, a.cap_msg), m1 = lim(a.seg->end_msgs, a.cap_msg);
+    BlobLayout L = a.L;
+    if (a.split) {                                         // (one segment: every count is final here)
+        const int64_t c5[5] = {0, m1, nbits, 0, 0};
+        const BlobLayout T = blob_layout(c5, a.cap_rows, a.cap_bits, a.cap_msg, a.cap_pos, 0);
+        L.off_pauses = T.off_pauses; L.off_msg_off = T.off_msg_off; L.off_pos_off = T.off_pos_off; L.off_bits = T.off_bits;
+    }
     {
-        uint8_t *out = (uint8_t *)(a.host + a.L.off_bits);
+        uint8_t *out = (uint8_t *)(a.host + L.off_bits);
         const unsigned long long *in8 = (const unsigned long long *)a.bits;
         for (int64_t j = j0 + gtid; j < j1; j += stride) {
             unsigned long long w;
@@ -1844,11 +1851,11 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
         }
     }
     if (a.has_pos && !a.pos_shipped) {
-        uint32_t *p32 = (uint32_t *)(a.host + a.L.off_pos32);
+        uint32_t *p32 = (uint32_t *)(a.host + L.off_pos32);
         for (int64_t i = p0 + gtid; i < p1; i += stride) p32[i] = (uint32_t)a.pos[i];
     }
     {
-        int64_t *pa = (int64_t *)(a.host + a.L.off_pauses), *mo = (int64_t *)(a.host + a.L.off_msg_off), *po = (int64_t *)(a.host + a.L.off_pos_off);
+        int64_t *pa = (int64_t *)(a.host + L.off_pauses), *mo = (int64_t *)(a.host + L.off_msg_off), *po = (int64_t *)(a.host + L.off_pos_off);
         if (gtid == 0 && m0 == 0) { mo[0] = 0; po[0] = 0; }
         for (int64_t i = m0 + gtid; i < m1; i += stride) { pa[i] = a.pauses[i]; mo[i + 1] = a.msg_off[i + 1]; po[i + 1] = a.pos_off[i + 1]; }
     }
@@ -1859,8 +1866,8 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
         hdr[1] = n_rows; hdr[2] = m1; hdr[3] = nbits; hdr[4] = p1; hdr[5] = c[4];
         hdr[6] = URHGPU_BLOB_HEADER_BYTES + n_rows * 5 + (nbits + 7) / 8 + p1 * 4 + m1 * 24 + 16;     // bytes that crossed PCIe for this pass
         hdr[7] = a.has_pos;
-        hdr[8] = a.L.off_pauses; hdr[9] = a.L.off_msg_off; hdr[10] = a.L.off_pos_off; hdr[11] = a.L.off_row_state; hdr[12] = a.L.off_bits;
-        hdr[13] = a.L.off_row_len; hdr[14] = a.L.off_pos32;
+        hdr[8] = L.off_pauses; hdr[9] = L.off_msg_off; hdr[10] = L.off_pos_off; hdr[11] = L.off_row_state; hdr[12] = L.off_bits;
+        hdr[13] = L.off_row_len; hdr[14] = L.off_pos32;
         hdr[15] = ((c[1] > a.cap_msg || c[2] > a.cap_bits || (a.has_pos && c[3] > a.cap_pos) || c[4] > a.cap_rows) ? 1 : 0) | (a.seg->err ? 2 : 0);
         hdr[0] = URHGPU_BLOB_MAGIC;
     }
@@ -1884,6 +1891,8 @@ int launch_rows_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailM
     g.bp = bp; g.ft.want_bits = 1;
     g.w0 = sg.c0 / kTailCPW; g.w_end = sg.final ? tail_waves(r.n_chunks) : sg.c1 / kTailCPW; g.final_seg = sg.final; g.seg = state; g.seg_k = sg.index;
     g.h_state = sg.h_state; g.h_len = sg.h_len;
+    if (g_tail_skip & 64) { g.h_state = nullptr; g.h_len = nullptr; }      // measurement: the row kernel without its host stores
+    if (g_tail_skip & 128) g.e.rows = nullptr;                              // measurement: ... without the int64 table
     // the huge-row list is consumed by the bits segment that covers these tiles, which may cover several rows segments: only the pass's
     // first rows segment starts the list (k_resolve_one clears the counter when want_bits is set)
     TileTail ft_resolve = g.ft;
@@ -1926,7 +1935,13 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
     // shipped again: those passes' positions go through the pack kernel.)
     const int has_pos = (bp.write_pos && o.pos) ? 1 : 0;
     const int64_t caps[5] = {cap_rows, o.cap_msg, o.cap_bits, o.cap_pos, cap_rows};
-    const BlobLayout L = blob_layout(caps, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos);
+    BlobLayout L = blob_layout(caps, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos);
+    const bool split = dst && dst->host && dst->split;
+    if (split) {
+        if (!sg.final || sg.c0 != 0) return URHGPU_ERR_ARG;             // the split layout's head is written by ONE segment
+        const StagedLayout SL = staged_layout(cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos);
+        L.off_row_state = SL.off_row_state; L.off_row_len = SL.off_row_len; L.off_pos32 = SL.off_pos32;
+    }
     const bool pos_direct = dst && dst->host && has_pos && sg.final && sg.c0 == 0 && dst->pos_direct;
     uint32_t *h_pos = pos_direct ? (uint32_t *)((char *)dst->host + L.off_pos32) : nullptr;
     GroupStore gs{gl, b.gout, o.msg_off, o.pauses, o.pos_off, o.pos, o.cap_msg, o.cap_pos, h_pos};
@@ -1943,7 +1958,7 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
     if (dst && dst->host) {
         if (((uintptr_t)o.bits & 7) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
         SegPack pk{o.bits, o.msg_off, o.pauses, o.pos_off, o.pos, o.counts, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos, (char *)dst->host,
-                   L, st, d_n_rows, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr, pos_direct ? 1 : 0};
+                   L, st, d_n_rows, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr, pos_direct ? 1 : 0, split ? 1 : 0};
         if (dst->cap_host < pk.L.total) return URHGPU_ERR_CAPACITY;
         if (!(g_tail_skip & 32)) hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 32), dim3(256), 0, s, pk);
     }

@@ -24,15 +24,18 @@ struct urhgpu_stream {
     int want_qad = 0, want_pos = 0;
     int64_t n_max = 0, cap_rows = 0, cap_bits = 0, cap_msg = 0, cap_pos = 0, cap_blob = 0;
     struct Slot {
-        void *dev = nullptr;               // one allocation: rows | bits | msg_off | pauses | pos_off | pos | counts | blob
+        void *dev = nullptr;               // one allocation: rows | bits | msg_off | pauses | pos_off | pos | counts | blob | staging blob
+        char *stage = nullptr;             // staged passes: the compact sections in the capacity layout, in HBM (tightened into `blob`)
         float *qad = nullptr;              // the qad buffer (of the ring below) this slot's current pass wrote
         urhgpu_outputs out;
         char *h_blob2[2] = {nullptr, nullptr};   // pinned, used alternately by the slot's passes: the result handed out at push i (pass i - 3)
                                                  // stays untouched while pass i's copy lands in the other one
         char *h_blob = nullptr;            // the one the slot's current pass copies into
         int64_t *h_counts = nullptr;       // pinned int64[8]
-        hipEvent_t ev_tail = nullptr, ev_copy = nullptr;
+        hipEvent_t ev_tail = nullptr, ev_copy = nullptr, ev_rows = nullptr;
         int64_t seq = -1, n = 0, copied = 0;
+        bool staged = false;               // the pass's blob arrived in the split layout: copied = head bytes, copied_rows / copied_pos = elements
+        int64_t copied_rows = 0, copied_pos = 0;
         int state = 0;                     // 0 free, 1 pass launched (tail pending), 2 copy issued, 3 result handed out
     } slot[3];
     // The demodulated signal of pass i lives in qad_ring[i % 4]: four buffers for three result slots, so that the result handed out by
@@ -41,8 +44,10 @@ struct urhgpu_stream {
     hipStream_t copy_stream = nullptr;
     int64_t seq = 0;
     int64_t streamed_passes = 0;           // passes whose tail ran in segments (diagnostics)
+    int64_t staged_passes = 0;             // passes whose tail stored into the staging blob (tightened + copied by the copy engine)
     int64_t uploaded_passes = 0;           // ... of which the capture was uploaded piece by piece (urhgpu_stream_push_upload)
     int64_t predicted_bytes = 0;           // blob bytes the next pass's copy is sized for (0: header only, the rest fetched on demand)
+    int64_t predicted_head = 0, predicted_rows = 0, predicted_pos = 0;   // staged passes: head bytes, rows, positions of the next pass's copies
     int64_t short_copies = 0;              // passes whose prediction fell short (diagnostics)
     bool was_pipelined = false;
 };
@@ -106,6 +111,32 @@ int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r
         snprintf(urh::g_hip_err, sizeof(urh::g_hip_err), "streamed pass %lld: a segment waited 2 s for the hot kernel", (long long)s.seq);
         return URHGPU_ERR_HIP;
     }
+    if (s.staged) {
+        // split layout: what the predictions missed, now -- the rest of the head (it ends with the packed bits), of the two row sections, of the positions
+        const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
+        const int64_t n_rows = hdr[1], n_pos = hdr[7] ? hdr[4] : 0;
+        const int64_t head = (hdr[12] + (hdr[3] + 7) / 8 + 15) & ~int64_t(15);
+        if (n_rows < 0 || n_rows > st->cap_rows || n_pos < 0 || n_pos > st->cap_pos || head < URHGPU_BLOB_HEADER_BYTES || head > SL.head_cap) return URHGPU_ERR_ARG;
+        bool more = false;
+        auto fetch = [&](int64_t off, int64_t bytes) -> int {
+            URH_HIP(hipMemcpyAsync(s.h_blob + off, s.stage + off, (size_t)bytes, hipMemcpyDeviceToHost, st->copy_stream));
+            more = true;
+            return URHGPU_OK;
+        };
+        if (head > s.copied) URH_TRY(fetch(s.copied, head - s.copied));
+        if (n_rows > s.copied_rows) {
+            URH_TRY(fetch(SL.off_row_state + s.copied_rows, n_rows - s.copied_rows));
+            URH_TRY(fetch(SL.off_row_len + 4 * s.copied_rows, 4 * (n_rows - s.copied_rows)));
+        }
+        if (n_pos > s.copied_pos) URH_TRY(fetch(SL.off_pos32 + 4 * s.copied_pos, 4 * (n_pos - s.copied_pos)));
+        if (more) { URH_HIP(hipStreamSynchronize(st->copy_stream)); st->short_copies += 1; }
+        st->predicted_head = head + head / 8 + 4096;
+        st->predicted_rows = n_rows + n_rows / 8 + 4096;
+        st->predicted_pos = n_pos + n_pos / 8 + 4096;
+        fill_result(st, s, r);
+        s.state = 3;
+        return URHGPU_OK;
+    }
     const int64_t total = hdr[6];
     if (total > s.copied) {                                 // the prediction was short (the first pass of a stream, a denser capture): the rest, now
         URH_HIP(hipMemcpyAsync(s.h_blob + s.copied, (const char *)s.out.blob + s.copied, (size_t)(total - s.copied), hipMemcpyDeviceToHost,
@@ -167,11 +198,12 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
             if (hipMalloc((void **)&q, b_qad) != hipSuccess) { urhgpu_stream_destroy(st); return URHGPU_ERR_HIP; }
     for (auto &s : st->slot) {
         memset(&s.out, 0, sizeof(s.out));
-        if (hipMalloc(&s.dev, b_rows + b_bits + 3 * b_off + b_pos + 256 + b_blob) != hipSuccess ||
+        if (hipMalloc(&s.dev, b_rows + b_bits + 3 * b_off + b_pos + 256 + 2 * b_blob) != hipSuccess ||
             hipHostMalloc((void **)&s.h_blob2[0], (size_t)st->cap_blob) != hipSuccess ||
             hipHostMalloc((void **)&s.h_blob2[1], (size_t)st->cap_blob) != hipSuccess || hipHostMalloc((void **)&s.h_counts, 64) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_tail, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.ev_copy, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s.ev_copy, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_rows, hipEventDisableTiming) != hipSuccess) {
             urhgpu_stream_destroy(st);
             return URHGPU_ERR_HIP;
         }
@@ -183,7 +215,8 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
         s.out.pos_off = (int64_t *)d; d += b_off;
         if (st->want_pos) { s.out.pos = (int64_t *)d; d += b_pos; s.out.cap_pos = st->cap_pos; }
         s.out.counts = (int64_t *)d; d += 256;
-        s.out.blob = d; s.out.cap_blob = st->cap_blob;
+        s.out.blob = d; s.out.cap_blob = st->cap_blob; d += b_blob;
+        s.stage = d;
         memset(s.h_counts, 0, 64);
     }
     *out = st;
@@ -203,6 +236,7 @@ int urhgpu_stream_destroy(urhgpu_stream *st) {
         if (s.h_counts) (void)hipHostFree(s.h_counts);
         if (s.ev_tail) (void)hipEventDestroy(s.ev_tail);
         if (s.ev_copy) (void)hipEventDestroy(s.ev_copy);
+        if (s.ev_rows) (void)hipEventDestroy(s.ev_rows);
     }
     for (auto &q : st->qad_ring) if (q) (void)hipFree(q);
     if (!st->was_pipelined) (void)urhgpu_ctx_set_pipelined(st->ctx, 0, nullptr);
@@ -247,8 +281,32 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
     // Streamed pass (pulse_table.hip "Segments"): the tail runs in segments beside the hot kernel and every segment stores its share of
     // the compact blob straight into the pinned host blob -- no pack launch at the end, no copy engine, no predicted size.  Captures the
     // bit-plane kernel does not take, or too short to cut, go the ordinary way: tail behind the hot kernel, pack + copy behind the tail.
-    bool streamed = false;
-    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq));
+    // Staged pass (the default for back-to-back passes since round 6): the same one-segment tail, but its kernels store the compact sections
+    // into the slot's staging blob in HBM (split layout) and the COPY ENGINE ships them, sized by prediction like queue_copy: the row
+    // sections as soon as the row kernel is through (while the bits are expanded), the head (+ positions) behind the pass's last kernel.
+    bool streamed = false, staged = false;
+    s.staged = false;
+    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq, s.stage, &staged, s.ev_rows));
+    if (streamed && staged) {
+        const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
+        const int64_t rows = std::min<int64_t>(st->predicted_rows, st->cap_rows), npos = st->want_pos ? std::min<int64_t>(st->predicted_pos, st->cap_pos) : 0;
+        const int64_t head = std::min<int64_t>(std::max<int64_t>(st->predicted_head, URHGPU_BLOB_HEADER_BYTES), SL.head_cap);
+        const bool skip_copy = (urh::g_tail_skip & 512) != 0;                  // (measurement hook: urhgpu_test_tail_skip)
+        if (rows > 0 && !skip_copy) {
+            URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_rows, 0));
+            URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_state, s.stage + SL.off_row_state, (size_t)rows, hipMemcpyDeviceToHost, st->copy_stream));
+            URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_len, s.stage + SL.off_row_len, (size_t)rows * 4, hipMemcpyDeviceToHost, st->copy_stream));
+        }
+        URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_copy, 0));           // (recorded behind the pass's last kernel: the staging blob is complete)
+        if (!skip_copy) URH_HIP(hipMemcpyAsync(s.h_blob, s.stage, (size_t)head, hipMemcpyDeviceToHost, st->copy_stream));
+        if (npos > 0 && !skip_copy)
+            URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_pos32, s.stage + SL.off_pos32, (size_t)npos * 4, hipMemcpyDeviceToHost, st->copy_stream));
+        URH_HIP(hipEventRecord(s.ev_copy, st->copy_stream));
+        s.state = 2; s.seq = i; s.n = n; s.copied = head; s.copied_rows = rows; s.copied_pos = npos; s.staged = true;
+        st->seq = i + 1;
+        st->staged_passes += 1;
+        return URHGPU_OK;
+    }
     if (streamed) {
         s.state = 2; s.seq = i; s.n = n; s.copied = st->cap_blob;
         st->seq = i + 1;
@@ -273,7 +331,8 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
 int urhgpu_stream_stats(urhgpu_stream *st, int64_t *out4) {
     if (!st || !out4) return URHGPU_ERR_ARG;
     out4[0] = st->seq; out4[1] = st->short_copies; out4[2] = st->predicted_bytes; out4[3] = st->cap_blob;
-    if (st->streamed_passes > 0) out4[2] = -st->streamed_passes;       // streamed passes predict nothing: their count, negated
+    // passes whose compact sections were written by the tail's own kernels (segments, direct, staged): their count, negated
+    if (st->streamed_passes + st->staged_passes > 0) out4[2] = -(st->streamed_passes + st->staged_passes);
     return URHGPU_OK;
 }
 
@@ -293,7 +352,7 @@ int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out)
     }
     // a streamed pass's blob is complete a moment before its hot kernel has retired (the last qad stores): d_qad of the results handed
     // out here is read by the caller next
-    if (st->streamed_passes > 0 && st->ctx->tail_pending) URH_TRY(wait_event(st->ctx->ev_tail[(st->ctx->flip + 2) % 3]));
+    if (st->streamed_passes + st->staged_passes > 0 && st->ctx->tail_pending) URH_TRY(wait_event(st->ctx->ev_tail[(st->ctx->flip + 2) % 3]));
     return URHGPU_OK;
 }
 
