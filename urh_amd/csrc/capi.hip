@@ -502,6 +502,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         } else if (q != hipSuccess) URH_HIP(q);
     }
     if (direct) { S = 1; bound[0] = 0; bound[1] = pl.n_chunks; }
+    void *const real_host_blob = host_blob;                   // (staged: the head still goes there, stored by the pass's last kernel)
     if (to_stage) { host_blob = stage_blob; if (staged) *staged = true; }
     const bool event_start = (h_iq != nullptr) || direct;      // the rows segments start behind events, not behind polling gates
     if (!ctx->d_seg) {
@@ -639,7 +640,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         const StagedLayout SL = staged_layout(out->cap_rows, out->cap_bits, out->cap_msg, out->cap_pos, has_pos);
         h_state = (int8_t *)((char *)host_blob + SL.off_row_state); h_len = (int32_t *)((char *)host_blob + SL.off_row_len);
     }
-    SegPackDst dst{host_blob, cap_host, progress, 0, (direct && ctx->tune_stream_pos_direct) ? 1 : 0, to_stage ? 1 : 0};
+    SegPackDst dst{host_blob, cap_host, progress, 0, (direct && ctx->tune_stream_pos_direct) ? 1 : 0, to_stage ? 1 : 0, to_stage ? real_host_blob : nullptr};
     // bits segments: the last one is the last rows segment alone (what is exposed behind the hot kernel), the others share the rest
     int Sb = h_iq ? S : 1;       // (an upload: every piece's bits behind its rows -- the pieces are milliseconds apart)
     if (Sb > S) Sb = S;

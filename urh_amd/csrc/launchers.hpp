@@ -283,6 +283,7 @@ struct SegPackDst {          // where a bits segment's share of the compact blob
     int blocks;              // workgroups of the pack kernel (0: default)
     int pos_direct;          // a pass of ONE segment: positions are stored into the host blob by the kernels that write them (pulse_table.hip)
     int split;               // staged passes (ONE segment): `host` is the staging blob in HBM, in the split layout (compact.hpp: staged_layout)
+    void *host_head;         // ... and the head (header + pauses / offsets / packed bits: small) goes straight into this pinned HOST blob
 };
 
 // Tile tail (single GPU, not ASK): resolve + rows in two launches, bits in three more; see pulse_table.hip.

@@ -1824,6 +1824,7 @@ struct SegPack {
     uint32_t *progress;      // the last segment zeroes the pass's counters for the next pass on this arena
     int pos_shipped;         // the positions have been stored into the host blob by the kernels that wrote them (GroupStore::h_pos)
     int split;               // staged pass (one segment): the small sections go tight behind the header, L's row / position offsets are the split layout's
+    char *head;              // where header and small sections go (split: the pinned host blob; else == host)
 };
 __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
     URH_TAIL_PRIO();
@@ -1841,7 +1842,7 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
         L.off_pauses = T.off_pauses; L.off_msg_off = T.off_msg_off; L.off_pos_off = T.off_pos_off; L.off_bits = T.off_bits;
     }
     {
-        uint8_t *out = (uint8_t *)(a.host + L.off_bits);
+        uint8_t *out = (uint8_t *)(a.head + L.off_bits);
         const unsigned long long *in8 = (const unsigned long long *)a.bits;
         for (int64_t j = j0 + gtid; j < j1; j += stride) {
             unsigned long long w;
@@ -1855,12 +1856,12 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
         for (int64_t i = p0 + gtid; i < p1; i += stride) p32[i] = (uint32_t)a.pos[i];
     }
     {
-        int64_t *pa = (int64_t *)(a.host + L.off_pauses), *mo = (int64_t *)(a.host + L.off_msg_off), *po = (int64_t *)(a.host + L.off_pos_off);
+        int64_t *pa = (int64_t *)(a.head + L.off_pauses), *mo = (int64_t *)(a.head + L.off_msg_off), *po = (int64_t *)(a.head + L.off_pos_off);
         if (gtid == 0 && m0 == 0) { mo[0] = 0; po[0] = 0; }
         for (int64_t i = m0 + gtid; i < m1; i += stride) { pa[i] = a.pauses[i]; mo[i + 1] = a.msg_off[i + 1]; po[i + 1] = a.pos_off[i + 1]; }
     }
     if (a.final && gtid == 0) {
-        int64_t *hdr = (int64_t *)a.host;
+        int64_t *hdr = (int64_t *)a.head;
         const int64_t *c = a.counts;
         const int64_t n_rows = lim(*a.d_n_rows, a.cap_rows);
         hdr[1] = n_rows; hdr[2] = m1; hdr[3] = nbits; hdr[4] = p1; hdr[5] = c[4];
@@ -1958,7 +1959,8 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
     if (dst && dst->host) {
         if (((uintptr_t)o.bits & 7) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
         SegPack pk{o.bits, o.msg_off, o.pauses, o.pos_off, o.pos, o.counts, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos, (char *)dst->host,
-                   L, st, d_n_rows, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr, pos_direct ? 1 : 0, split ? 1 : 0};
+                   L, st, d_n_rows, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr, pos_direct ? 1 : 0, split ? 1 : 0,
+                   (split && dst->host_head) ? (char *)dst->host_head : (char *)dst->host};
         if (dst->cap_host < pk.L.total) return URHGPU_ERR_CAPACITY;
         if (!(g_tail_skip & 32)) hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 32), dim3(256), 0, s, pk);
     }

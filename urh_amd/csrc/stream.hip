@@ -47,7 +47,7 @@ struct urhgpu_stream {
     int64_t staged_passes = 0;             // passes whose tail stored into the staging blob (tightened + copied by the copy engine)
     int64_t uploaded_passes = 0;           // ... of which the capture was uploaded piece by piece (urhgpu_stream_push_upload)
     int64_t predicted_bytes = 0;           // blob bytes the next pass's copy is sized for (0: header only, the rest fetched on demand)
-    int64_t predicted_head = 0, predicted_rows = 0, predicted_pos = 0;   // staged passes: head bytes, rows, positions of the next pass's copies
+    int64_t predicted_rows = 0, predicted_pos = 0;   // staged passes: rows, positions the next pass's copies are sized for
     int64_t short_copies = 0;              // passes whose prediction fell short (diagnostics)
     bool was_pipelined = false;
 };
@@ -130,7 +130,6 @@ int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r
         }
         if (n_pos > s.copied_pos) URH_TRY(fetch(SL.off_pos32 + 4 * s.copied_pos, 4 * (n_pos - s.copied_pos)));
         if (more) { URH_HIP(hipStreamSynchronize(st->copy_stream)); st->short_copies += 1; }
-        st->predicted_head = head + head / 8 + 4096;
         st->predicted_rows = n_rows + n_rows / 8 + 4096;
         st->predicted_pos = n_pos + n_pos / 8 + 4096;
         fill_result(st, s, r);
@@ -290,19 +289,19 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
     if (streamed && staged) {
         const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
         const int64_t rows = std::min<int64_t>(st->predicted_rows, st->cap_rows), npos = st->want_pos ? std::min<int64_t>(st->predicted_pos, st->cap_pos) : 0;
-        const int64_t head = std::min<int64_t>(std::max<int64_t>(st->predicted_head, URHGPU_BLOB_HEADER_BYTES), SL.head_cap);
         const bool skip_copy = (urh::g_tail_skip & 512) != 0;                  // (measurement hook: urhgpu_test_tail_skip)
         if (rows > 0 && !skip_copy) {
             URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_rows, 0));
             URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_state, s.stage + SL.off_row_state, (size_t)rows, hipMemcpyDeviceToHost, st->copy_stream));
             URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_len, s.stage + SL.off_row_len, (size_t)rows * 4, hipMemcpyDeviceToHost, st->copy_stream));
         }
-        URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_copy, 0));           // (recorded behind the pass's last kernel: the staging blob is complete)
-        if (!skip_copy) URH_HIP(hipMemcpyAsync(s.h_blob, s.stage, (size_t)head, hipMemcpyDeviceToHost, st->copy_stream));
+        // (recorded behind the pass's last kernel, which has stored the head -- header, pauses, offsets, packed bits: small -- into the host
+        // blob itself: no copy of it, no hop to another stream at the end of the chain)
+        URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_copy, 0));
         if (npos > 0 && !skip_copy)
             URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_pos32, s.stage + SL.off_pos32, (size_t)npos * 4, hipMemcpyDeviceToHost, st->copy_stream));
         URH_HIP(hipEventRecord(s.ev_copy, st->copy_stream));
-        s.state = 2; s.seq = i; s.n = n; s.copied = head; s.copied_rows = rows; s.copied_pos = npos; s.staged = true;
+        s.state = 2; s.seq = i; s.n = n; s.copied = SL.head_cap; s.copied_rows = rows; s.copied_pos = npos; s.staged = true;
         st->seq = i + 1;
         st->staged_passes += 1;
         return URHGPU_OK;
