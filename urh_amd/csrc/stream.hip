@@ -32,7 +32,7 @@ struct urhgpu_stream {
                                                  // stays untouched while pass i's copy lands in the other one
         char *h_blob = nullptr;            // the one the slot's current pass copies into
         int64_t *h_counts = nullptr;       // pinned int64[8]
-        hipEvent_t ev_tail = nullptr, ev_copy = nullptr, ev_rows = nullptr;
+        hipEvent_t ev_tail = nullptr, ev_copy = nullptr, ev_rows = nullptr, ev_shipped = nullptr;   // ev_shipped: a staged pass's copies are through
         int64_t seq = -1, n = 0, copied = 0;
         bool staged = false;               // the pass's blob arrived in the split layout: copied = head bytes, copied_rows / copied_pos = elements
         int64_t copied_rows = 0, copied_pos = 0;
@@ -105,6 +105,7 @@ int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r
     if (s.state == 1) URH_TRY(queue_copy(st, s));
     if (s.state != 2) return URHGPU_ERR_ARG;
     URH_TRY(wait_event(s.ev_copy));
+    if (s.staged) URH_TRY(wait_event(s.ev_shipped));
     const int64_t *hdr = (const int64_t *)s.h_blob;
     if (hdr[0] != URHGPU_BLOB_MAGIC || hdr[6] < 0 || hdr[6] > st->cap_blob) return URHGPU_ERR_ARG;
     if (hdr[15] & 2) {                                      // a segment's gate gave up waiting for the hot kernel (k_seg_gate): nothing of this pass is valid
@@ -202,7 +203,8 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
             hipHostMalloc((void **)&s.h_blob2[1], (size_t)st->cap_blob) != hipSuccess || hipHostMalloc((void **)&s.h_counts, 64) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_tail, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_copy, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&s.ev_rows, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&s.ev_rows, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&s.ev_shipped, hipEventDisableTiming) != hipSuccess) {
             urhgpu_stream_destroy(st);
             return URHGPU_ERR_HIP;
         }
@@ -236,6 +238,7 @@ int urhgpu_stream_destroy(urhgpu_stream *st) {
         if (s.ev_tail) (void)hipEventDestroy(s.ev_tail);
         if (s.ev_copy) (void)hipEventDestroy(s.ev_copy);
         if (s.ev_rows) (void)hipEventDestroy(s.ev_rows);
+        if (s.ev_shipped) (void)hipEventDestroy(s.ev_shipped);
     }
     for (auto &q : st->qad_ring) if (q) (void)hipFree(q);
     if (!st->was_pipelined) (void)urhgpu_ctx_set_pipelined(st->ctx, 0, nullptr);
@@ -269,7 +272,10 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
         if (ready) *ready = r;
     }
     // ...and nothing of this pass may be written into the slot's device buffers before that copy has read them
-    if (s.state == 3) URH_HIP(hipStreamWaitEvent(ctx->tail_stream, s.ev_copy, 0));
+    if (s.state == 3) {
+        URH_HIP(hipStreamWaitEvent(ctx->tail_stream, s.ev_copy, 0));
+        if (s.staged) URH_HIP(hipStreamWaitEvent(ctx->tail_stream, s.ev_shipped, 0));     // (the copies out of the staging blob)
+    }
     s.state = 0;
     s.h_blob = s.h_blob2[(i / 3) & 1];
     s.qad = st->want_qad ? st->qad_ring[i & 3] : nullptr;
@@ -297,10 +303,13 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
         }
         // (recorded behind the pass's last kernel, which has stored the head -- header, pauses, offsets, packed bits: small -- into the host
         // blob itself: no copy of it, no hop to another stream at the end of the chain)
-        URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_copy, 0));
-        if (npos > 0 && !skip_copy)
+        // The host waits for BOTH ends (finish_copy): s.ev_copy on the tail stream, s.ev_shipped on the copy stream -- no hop from one stream
+        // to the other at the end of the chain, unless the pass ships positions (they are complete with the pass's last kernel).
+        if (npos > 0 && !skip_copy) {
+            URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_copy, 0));
             URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_pos32, s.stage + SL.off_pos32, (size_t)npos * 4, hipMemcpyDeviceToHost, st->copy_stream));
-        URH_HIP(hipEventRecord(s.ev_copy, st->copy_stream));
+        }
+        URH_HIP(hipEventRecord(s.ev_shipped, st->copy_stream));
         s.state = 2; s.seq = i; s.n = n; s.copied = SL.head_cap; s.copied_rows = rows; s.copied_pos = npos; s.staged = true;
         st->seq = i + 1;
         st->staged_passes += 1;
