@@ -643,7 +643,9 @@ __device__ __forceinline__ void fsk_front(const v4f (&cur)[NB], float &prev_c, f
     }
     f.mag_min = mag_min;
 }
-template <int NB>
+// ZEROS_OK (integer captures): an exactly zero cross product -- one sample in 700 at 8 bits -- does not flag the batch (z - 1 wraps to the
+// largest unsigned number for z = 0: it passes the lower bound and z itself the upper one); the caller settles those samples in place.
+template <int NB, bool ZEROS_OK>
 __device__ __forceinline__ bool fsk_divide(const FskFront<NB> &f, const RunArgs &p, v2f (&t)[NB], v2f (&z)[NB]) {
     uint32_t re_max = 0u, re_min = 0u, z_max = 0u, z_min = 0u;
 #pragma unroll
@@ -652,11 +654,13 @@ __device__ __forceinline__ bool fsk_divide(const FskFront<NB> &f, const RunArgs 
         z[j] = t[j] * t[j];
         const uint32_t r0b = __float_as_uint(f.re[j].x), r1b = __float_as_uint(f.re[j].y), z0b = __float_as_uint(z[j].x), z1b = __float_as_uint(z[j].y);
         re_max = (j == 0) ? max(r0b, r1b) : max(re_max, max(r0b, r1b)); re_min = (j == 0) ? min(r0b, r1b) : min(re_min, min(r0b, r1b));
-        z_max = (j == 0) ? max(z0b, z1b) : max(z_max, max(z0b, z1b)); z_min = (j == 0) ? min(z0b, z1b) : min(z_min, min(z0b, z1b));
+        z_max = (j == 0) ? max(z0b, z1b) : max(z_max, max(z0b, z1b));
+        const uint32_t l0 = ZEROS_OK ? z0b - 1u : z0b, l1 = ZEROS_OK ? z1b - 1u : z1b;
+        z_min = (j == 0) ? min(l0, l1) : min(z_min, min(l0, l1));
     }
     // (one ballot per compare: the masks are OR-ed on the scalar unit; a ballot of the OR-ed condition costs a v_cndmask + v_cmp)
     const uint64_t any = __builtin_amdgcn_ballot_w64(re_max >= kReLo + kReSpan) | __builtin_amdgcn_ballot_w64(re_min < kReLo) |
-                         __builtin_amdgcn_ballot_w64(z_max >= kZHi) | __builtin_amdgcn_ballot_w64(z_min < kZLo) |
+                         __builtin_amdgcn_ballot_w64(z_max >= kZHi) | __builtin_amdgcn_ballot_w64(z_min < (ZEROS_OK ? kZLo - 1u : kZLo)) |
                          __builtin_amdgcn_ballot_w64(f.mag_min <= p.noise_sqrd);
     return any != 0;
 }
@@ -1184,7 +1188,8 @@ void k_demod_runs_bp(const RunArgs p) {
 
     // the first batch of rows is requested before the prologue's (dependent, wavefront-uniform) loads: their latency overlaps
     constexpr int kBatch = URH_KBATCH;
-    constexpr bool kFskFast = URH_SPEC && SRC == SRC_IQ && MOD == URHGPU_MOD_FSK && DT == URHGPU_DT_F32;
+    constexpr bool kFskFast = URH_SPEC && SRC == SRC_IQ && MOD == URHGPU_MOD_FSK;
+    constexpr bool kIntCapture = DT != URHGPU_DT_F32;
     RowIn cur[kBatch] = {}, nxt[kBatch];
     v4f cv[kBatch], nv[kBatch];                               // kFskFast: the rows as 4-vectors
     if (kFskFast) load_rows_v4<DT>(p, a0, r0, lane, cv);
@@ -1280,10 +1285,28 @@ void k_demod_runs_bp(const RunArgs p) {
                 float nc = prev_c, nd = prev_d;
                 fsk_front<kBatch>(cv, nc, nd, f);
                 v2f t[kBatch], z[kBatch];
-                if (__builtin_expect(fsk_divide<kBatch>(f, p, t, z), 0)) break;          // cv still holds batch rb
+                if (__builtin_expect((fsk_divide<kBatch, kIntCapture>(f, p, t, z)), 0)) break;          // cv still holds batch rb
                 float q0[kBatch], q1[kBatch];
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) { const v2f q = t[j] - atanf_poly2(t[j], z[j]); q0[j] = q.x; q1[j] = q.y; }
+                if (kIntCapture) {
+                    // exactly zero cross products (integer samples: products and their difference are exact): atan2f(+-0, re > 0) = +-0, the
+                    // sign being that of the reference's product (conj_mul: its zeros are signed differently from the plain product's)
+                    uint64_t zany = 0;
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) zany |= __builtin_amdgcn_ballot_w64(f.im[j].x == 0.0f) | __builtin_amdgcn_ballot_w64(f.im[j].y == 0.0f);
+                    if (zany != 0) {
+                        float sc = prev_c, sd = prev_d;
+#pragma unroll
+                        for (int j = 0; j < kBatch; ++j) {
+                            const float pc = dpp_wave_shr1(cv[j].z, sc), pd = dpp_wave_shr1(cv[j].w, sd);
+                            float re_r, im_r;
+                            conj_mul(pc, pd, cv[j].x, cv[j].y, re_r, im_r); q0[j] = (f.im[j].x == 0.0f) ? im_r : q0[j];
+                            conj_mul(cv[j].x, cv[j].y, cv[j].z, cv[j].w, re_r, im_r); q1[j] = (f.im[j].y == 0.0f) ? im_r : q1[j];
+                            sc = lane63(cv[j].z); sd = lane63(cv[j].w);
+                        }
+                    }
+                }
                 prev_c = nc; prev_d = nd;
                 emit(cur, q0, q1, 0u, rb, false);          // (`cur`: read by the float32 segmentation pass only, not this instantiation)
 #pragma unroll
