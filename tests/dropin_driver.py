@@ -14,6 +14,8 @@ captures they read) with unittest:
 plus the known-answer test of tests/test_filter.py:20-31 (its class needs the GUI form in setUp; the same assertion is made here on
 the reference's Filter object).  Every patched function is wrapped in a call counter so that the caller can see that the GPU
 library, not the Cython module, did the work.  `--no-patch`: the Cython path itself (BASELINE configs[0], the CPU plumbing run).
+`--hook`: the binding goes through urh_amd.urh_hook.install() -- on a host without a GPU it declines (logged) and the reference's tests run
+on URH's own Cython functions (tests/test_oracle.py::test_hook_keeps_cython_without_gpu).
 Prints one JSON line: {"ran", "failures", "errors", "skipped", "per_module": {...}, "calls": {...}, "details": [...]}.
 """
 import json
@@ -71,13 +73,30 @@ def main():
         return wrapper
 
     use_gpu = "--no-patch" not in sys.argv           # --no-patch: BASELINE configs[0], the Cython path itself (CPU plumbing run)
-    for mod, names in PATCHED.items():
-        cy = importlib.import_module("urh.cythonext." + mod)
-        gpu = importlib.import_module("urh_amd." + mod)
-        for name in names:
-            key = mod + "." + name
-            calls[key] = 0
-            setattr(cy, name, counted(key, getattr(gpu if use_gpu else cy, name)))
+    hook = None
+    if "--hook" in sys.argv:
+        # the hook a maintainer installs (urh_amd/urh_hook.py): binds the GPU functions when a GPU is usable,
+        # says why not and keeps URH's Cython functions otherwise.  The counters then tell which side did the work.
+        from urh_amd import urh_hook
+        assert urh_hook.BIND == PATCHED
+        for mod, names in PATCHED.items():
+            for name in names:
+                calls[mod + "." + name] = 0
+        log = []
+
+        class _Log:
+            def warning(self, fmt, *a): log.append("warning: " + fmt % a)
+            def info(self, fmt, *a): log.append("info: " + fmt % a)
+        installed, reason = urh_hook.install(logger=_Log(), wrap=counted)
+        hook = {"installed": installed, "reason": reason, "log": log}
+    else:
+        for mod, names in PATCHED.items():
+            cy = importlib.import_module("urh.cythonext." + mod)
+            gpu = importlib.import_module("urh_amd." + mod)
+            for name in names:
+                key = mod + "." + name
+                calls[key] = 0
+                setattr(cy, name, counted(key, getattr(gpu if use_gpu else cy, name)))
     # -------------------------------------------------------------------------------------------------------------------
 
     only = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -100,7 +119,7 @@ def main():
         for k in total:
             total[k] += rec[k]
         details += [name + " :: " + str(t) + "\n" + tb for t, tb in res.failures + res.errors]
-    out = dict(total, per_module=per_module, calls=calls, details=details)
+    out = dict(total, per_module=per_module, calls=calls, details=details, hook=hook)
     print(json.dumps(out))
     return 0
 

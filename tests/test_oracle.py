@@ -182,3 +182,23 @@ def test_config1_reference_plumbing_cpu():
     assert out["per_module"]["tests.test_demodulations"]["ran"] == 7
     assert out["ran"] == 75 and out["failures"] == 0 and out["errors"] == 0, out["details"]
     assert out["calls"]["signal_functions.afp_demod"] >= 8 and out["calls"]["signal_functions.grab_pulse_lens"] >= 8
+
+
+def test_hook_keeps_cython_without_gpu():
+    """The reference-side hook (urh_amd/urh_hook.py) on a host WITHOUT a GPU: it probes
+    urhgpu_ctx_create, says why the library cannot be used and leaves URH's Cython functions bound -- the reference's 75 headless hot-path
+    tests then run green on the Cython path with the hook installed.  (On a GPU box the same flag binds the library:
+    tests/test_reference_dropin.py::test_hook_binds_on_a_gpu_box.)"""
+    import json
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the hook binds the library here (covered by the gpu test)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "dropin_driver.py"), "--hook"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    if out.get("unavailable"):
+        pytest.skip("oracle/_ref not built")
+    assert out["hook"]["installed"] is False and out["hook"]["log"] and "keeping the Cython functions" in out["hook"]["log"][0], out["hook"]
+    assert out["ran"] == 75 and out["failures"] == 0 and out["errors"] == 0, out["details"]
+    assert all(v == 0 for v in out["calls"].values()), out["calls"]          # nothing went through the (unusable) library

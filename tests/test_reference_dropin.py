@@ -52,6 +52,16 @@ def test_reference_hot_path_tests_on_gpu_functions():
         assert c[key] > 0, (key, c)
 
 
+def test_hook_binds_on_a_gpu_box():
+    """urh_amd/urh_hook.install() -- what a maintainer puts into src/urh/cythonext/__init__.py -- binds the
+    library where a GPU is usable (here); without one it keeps the Cython functions (tests/test_oracle.py::test_hook_keeps_cython_without_gpu)."""
+    out = _run_driver("--hook", "test_demodulations")
+    assert out["hook"]["installed"] is True, out["hook"]
+    rec = out["per_module"]["tests.test_demodulations"]
+    assert rec["ran"] == 7 and rec["failures"] == 0 and rec["errors"] == 0, out["details"]
+    assert out["calls"]["signal_functions.afp_demod"] >= 8 and out["calls"]["signal_functions.grab_pulse_lens"] >= 8, out["calls"]
+
+
 def _thread_job(k, out, errs):
     try:
         import urh_oracle as oracle
