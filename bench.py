@@ -384,6 +384,53 @@ def variant_steps(torch, pipe, iq, p, n, args, ramp, headline_copy):
         rec[name] = r
         st.close()
         del x
+    # ---- row density: every timing above is at 100 samples per symbol -- 671 k pulse-table rows per GiB.  The tail's work
+    # is proportional to the rows; the reference's own test uses 8 samples per symbol (tests/test_demodulations.py:55-72).  Two more captures
+    # of the same generator, K pipelined steps each, checked against the reference on their bytes:
+    #   sps10   10 samples per symbol, tolerance 1: ~ 13 M rows, 13 M bits per GiB
+    #   bursty  SURVEY 8(d) variant 2b: 10 465 symbols + a 2 076-sample gap per segment, noise_threshold 0.2: 128 messages
+    from urh_amd.synth import spec_fsk_capture
+    dev = iq.device
+    for name, gen, pv, what in (
+            ("sps10", dict(sps=10), replace(p_np, samples_per_symbol=10, tolerance=1),
+             "the configs[1] generator at 10 samples per symbol (modulate_c segments + AWGN 0.05), tolerance 1"),
+            ("bursty", dict(sps=100, n_symbols=10465), replace(p_np, noise_threshold=0.2),
+             "SURVEY 8(d) variant 2b: 10 465 symbols + a 2 076-sample gap per 2^20-sample segment, noise_threshold 0.2")):
+        try:
+            x, _ = spec_fsk_capture(n >> 20, dev, first_segment=0, **gen)
+            st = pipe.stream(n, pv, want_qad=True, want_pos=False)
+            ms, last = timed(st, x)
+            r = {"ms_per_step": round(ms, 4), "bytes_per_sample": 12, "frac_of_8TBs": frac(ms, 12), "Msamples_per_s": round(n / ms / 1e3, 1),
+                 "capture": what, "rows": int(len(last.ppseq())), "messages": int(len(last.flat()[2])), "d2h_bytes": int(last.blob_bytes),
+                 "d2h_gbs": round(int(last.blob_bytes) / (ms * 1e-3) / 1e9, 1),
+                 "bound": "what a step ships per pulse-table row (5 B) over PCIe: d2h_gbs is the link's rate" if int(last.blob_bytes) / (ms * 1e-3) > 30e9
+                          else "as the headline: the hot kernel (HBM) with the tail of the pass before beside it",
+                 "stream_stats": st.stats()}
+            if not args.no_cpu_baseline:
+                host = x.cpu().numpy()
+                if ref is not None:
+                    sf = ref[0]
+                    q = np.asarray(sf.afp_demod(host, pv.noise_threshold, "FSK", 2, pv.costas_loop_bandwidth))
+                    pp = np.asarray(sf.grab_pulse_lens(q, pv.center, pv.tolerance, "FSK", pv.samples_per_symbol, 1, pv.center_spacing))
+                    r["against"] = "oracle/_ref (the reference's Cython afp_demod + grab_pulse_lens)"
+                else:
+                    q = oracle.afp_demod(host, pv.noise_threshold, "FSK", 2)
+                    pp = oracle.grab_pulse_lens(q, pv.center, pv.tolerance, "FSK", pv.samples_per_symbol, 1, pv.center_spacing)
+                    r["against"] = "oracle/ C restatement"
+                flat = oracle.ppseq_to_bits_flat(pp, pv.samples_per_symbol, 1, True, pv.pause_threshold)
+                got_q = np.empty(n, np.float32)
+                _ulib.check(_ulib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(last.d_qad_ptr), got_q.ctypes.data_as(C.c_void_p), n * 4))
+                r["qad_mismatches"] = int((got_q.view(np.uint32) != q.view(np.uint32)).sum())
+                r["bit_exact"] = bool(r["qad_mismatches"] == 0 and np.array_equal(last.ppseq(), pp) and
+                                      all(np.array_equal(a, b) for a, b in zip(last.flat()[:3], flat[:3])) and
+                                      np.array_equal(last.bit_sample_pos(), flat[3]) and np.array_equal(last.pos_offsets(), flat[4]))
+                del host, q, pp, flat, got_q
+            rec[name] = r
+            st.close()
+            del x
+        except Exception as exc:          # noqa: BLE001  (a variant must not take the headline with it)
+            rec[name] = {"error": repr(exc)[:300]}
+        torch.cuda.empty_cache()
     return rec
 
 
@@ -485,9 +532,12 @@ def extra_config3(pipe, dev, args):
            "estimated": {k: (float(v) if not isinstance(v, str) else v) for k, v in (est or {}).items()},
            "roofline": {"algorithmic_bytes_per_sample": 28,
                         "hbm_frac": round(28 * n / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "fir_valu_frac": round(512.0 * n / (t_fir * 1e-3) / 78.6e12, 4),
+                        "fir_valu_frac": round(512.0 * n / (t_fir_noise * 1e-3) / 78.6e12, 4),
+                        "fir_valu_frac_unfused_filter_alone": round(512.0 * n / (t_fir * 1e-3) / 78.6e12, 4),
                         "note": "28 B/sample = FIR 8 + 8, demodulation 8 + 4 (SURVEY 8(d) config 3); the FIR is bound by un-fused fp32 VALU "
-                                "(512 flop per sample against 78.6 TFLOP/s of non-FMA packed fp32), not by HBM"},
+                                "(512 flop per sample against 78.6 TFLOP/s of non-FMA packed fp32), not by HBM.  fir_valu_frac follows the "
+                                "stage that is TIMED in `ms` (the filter with the noise statistics fused into its epilogue); the filter "
+                                "kernel alone is the second figure"},
            "messages": res.host_counts()[1], "bits": res.host_counts()[2]}
     mods = None if args.no_cpu_baseline else _ref_modules()
     if mods:
