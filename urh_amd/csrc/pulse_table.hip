@@ -903,9 +903,20 @@ constexpr int kTailCPW = URH_TAIL_CPW;
 // -DURH_TAIL_CAP80: at most 80 VGPRs (six wavefronts per SIMD) for the tail kernels that need more -- what ONE retiring hot wavefront
 // (72 + the 8 it never had) leaves free on a SIMD; costs spills (A/B knob)
 #ifdef URH_TAIL_CAP80
-#define URH_TAIL_OCC __attribute__((amdgpu_waves_per_eu(6)))
+#define URH_TAIL_OCC __attribute__((amdgpu_waves_per_eu(URH_TAIL_CAP80)))
 #else
 #define URH_TAIL_OCC
+#endif
+// the same per kernel (A/B builds): -DURH_OCC_EMIT=8 / -DURH_OCC_EXPAND=8 hold the row / expansion kernel to that many wavefronts per SIMD
+#ifdef URH_OCC_EMIT
+#define URH_EMIT_OCC __attribute__((amdgpu_waves_per_eu(URH_OCC_EMIT)))
+#else
+#define URH_EMIT_OCC
+#endif
+#ifdef URH_OCC_EXPAND
+#define URH_EXPAND_OCC __attribute__((amdgpu_waves_per_eu(URH_OCC_EXPAND)))
+#else
+#define URH_EXPAND_OCC URH_TAIL_OCC
 #endif
 static_assert(kResolveBlock % kTailCPW == 0 && kTailCPW <= 64, "the chunks of one wavefront share their resolve workgroup");
 
@@ -942,7 +953,7 @@ __host__ __device__ static inline int64_t tail_waves(int64_t n_items) { return (
 // rows span (positions telescope) is its tile's sample count, so that the exclusive tile scan hands this GPU's first tile the
 // total_samples before its first row; bits, long pauses and data rows stay per GPU (their cross-shard part is the flags exchange).
 // Rows are indexed from this GPU's first one (row_base, also left in *ft.d_row_base for the kernels that follow).
-__global__ __launch_bounds__(64 * kEmitWaves) void k_emit_rows_tiles(const EmitTileArgs g) {
+__global__ __launch_bounds__(64 * kEmitWaves) URH_EMIT_OCC void k_emit_rows_tiles(const EmitTileArgs g) {
     URH_TAIL_PRIO();
     const EmitArgs &a = g.e;
     const ResolveArgs &r = g.r;
@@ -1250,7 +1261,7 @@ constexpr unsigned kHugeBlocksX = 16, kHugeBlocksY = 16;
 // workgroups per row
 __host__ __device__ static inline int64_t expand_tile_blocks(int64_t n_tiles) { return (tail_waves(n_tiles) + kEmitWaves - 1) / kEmitWaves; }
 
-__global__ __launch_bounds__(64 * kEmitWaves) URH_TAIL_OCC void k_expand_tiles(const ExpandTileArgs a) {
+__global__ __launch_bounds__(64 * kEmitWaves) URH_EXPAND_OCC void k_expand_tiles(const ExpandTileArgs a) {
     URH_TAIL_PRIO();
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int bps = (int)a.bp.bps;
