@@ -18,7 +18,7 @@ for f in glob.glob("$OUT/**/*memory_copy_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") + " " + str(r.get("Size", ""))))
 rows.sort()
-first = "k_demod_runs_bp<0, 4, 0" if part == "ook" else "k_me_first"
+first = "void k_demod_runs_bp<0, 4, 0" if part == "ook" else "k_me_first"
 marks = [i for i, r in enumerate(rows) if r[2].startswith(first)]
 # the third-last call (the last one carries per-stage synchronisations)
 i0, i1 = marks[-3], marks[-2]

@@ -621,38 +621,51 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
     const int64_t tbase = (int64_t)t.idx * kMeTile, left = m.L - tbase;
     const float *r = me_src(x, kept, m) + m.a + tbase;
     const int lim = (int)(left < 0 ? 0 : (left > kMeTile ? kMeTile : left));
+    // Round 6: a histogram does not care which lane holds which sample -- thread t takes four runs of four CONSECUTIVE samples (16-byte
+    // loads, 4-byte aligned: a message starts anywhere), a quarter of the load instructions; and the bin of a sample is the float32 guess
+    // CHECKED ONCE against the table (one ds_read2: s_e[k] <= v < s_e[k + 1]) -- the trimmed range's minimum and maximum are the first and
+    // the last edge, so every sample lies inside, and the guess is off only within a rounding error of an edge.  A wavefront in which any
+    // check fails (that, a NaN, a sample outside) takes the exact path for its sixteen rows: guess, one step either way, check, search.
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     float val[kMePer];
 #pragma unroll
-    for (int j = 0; j < kMePer; ++j) { const int i = (int)threadIdx.x + j * kMeBlock; val[j] = (i < lim) ? r[i] : __builtin_nanf(""); }
+    for (int j = 0; j < kMePer / 4; ++j) {
+        const int i = 4 * ((int)threadIdx.x + j * kMeBlock);
+        if (i + 3 < lim) { const f4u q = *(const f4u *)(r + i); val[4 * j] = q.x; val[4 * j + 1] = q.y; val[4 * j + 2] = q.z; val[4 * j + 3] = q.w; }
+        else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[4 * j + e] = (i + e < lim) ? r[i + e] : __builtin_nanf("");
+        }
+    }
     int bin[kMePer];
     {
-        // straight-line code for all 16 rows (their LDS reads overlap): guess, one step either way, check.  The float32 guess is off by
-        // less than one bin for a few thousand bins (three roundings of 2^-24 each), so the check hardly ever fails -- where it does, the
-        // exact search below repairs it.
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < kMePer; ++j) {
             const float v = val[j];
-            const bool in = v >= lo_all && v < hi_all;         // inside (and not NaN)
-            const float g = (v - e0f) * invf;
-            int k = (g >= 0.f) ? ((g < (float)(nb - 1)) ? (int)g : nb - 1) : 0;
-            k = in ? k : 0;
+            int k = (int)((v - e0f) * invf);
+            k = (k < 0) ? 0 : ((k > nb - 1) ? nb - 1 : k);
             const float lo = s_e[k], hi = s_e[k + 1];
-            k += (v >= hi && k < nb - 1) ? 1 : ((v < lo && k > 0) ? -1 : 0);
-            const float lo2 = s_e[k], hi2 = s_e[k + 1];
-            bad |= in && !(v >= lo2 && v < hi2);
-            bin[j] = in ? k : -1;
+            const bool ok = v >= lo && v < hi;
+            bad |= !ok;                                            // any failed check (NaN included) sends the wavefront to the exact path
+            bin[j] = ok ? k : -1;
         }
+        // (the padding beyond the tile's last sample is NaN: a wavefront of the last tile takes the exact path, which leaves padding out)
         if (__any(bad)) {
 #pragma unroll
             for (int j = 0; j < kMePer; ++j) {
                 const float v = val[j];
-                int k = bin[j];
-                if (k >= 0) {
+                const bool in = v >= lo_all && v < hi_all;         // inside (and not NaN)
+                const float g = (v - e0f) * invf;
+                int k = (g >= 0.f) ? ((g < (float)(nb - 1)) ? (int)g : nb - 1) : 0;
+                k = in ? k : 0;
+                const float lo = s_e[k], hi = s_e[k + 1];
+                k += (v >= hi && k < nb - 1) ? 1 : ((v < lo && k > 0) ? -1 : 0);
+                if (in) {
                     while (k > 0 && s_e[k] > v) --k;
                     while (k < nb - 1 && s_e[k + 1] <= v) ++k;
-                    bin[j] = k;
                 }
+                bin[j] = in ? k : -1;
             }
         }
     }
