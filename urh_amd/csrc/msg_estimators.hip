@@ -414,6 +414,7 @@ __device__ __forceinline__ float me_leaf_sum(const float *a, int len, int mode, 
 constexpr int kMeRestSlots = kPwChunkM / 64, kMeRestDepth = 9;
 __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, const float *kept, MsgState *st, const float *chunk_sums, int mode) {
     __shared__ float s_val[kMeRestSlots + 1];
+    __shared__ __attribute__((aligned(16))) float s_cs[8192];
     const int m = blockIdx.x, tid = threadIdx.x;
     const MsgState s = st[m];
     if (s.L <= 0) return;
@@ -425,26 +426,31 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
     // cycles instead of an LDS round trip per term.  (Running the chain through the lanes instead -- acc[s] = acc[s - 1] + v[s] as one
     // v_add_f32_dpp wave_shr:1 per term -- is one instruction per term instead of two but was slower, 160 against 101 us for 16 384
     // terms: the DPP operand's wait states weigh more than the second instruction, which is off the dependent chain here.)
+    // Round 6: the terms come out of LDS.  The chain is ONE v_add_f32 per term -- a wavefront issues one VALU instruction every four cycles,
+    // and the v_readlane that fetched each term from the lanes (rounds 3-5) was a second VALU instruction per term: 9.5 cycles per
+    // term, 101 us for the 16 384 chunk sums of a 1 GiB message.  Staged in LDS (32 KiB per piece, copied by the whole workgroup) every
+    // lane reads the SAME four terms with one ds_read_b128 (a broadcast: the LDS pipe's instruction, off the VALU), the reads run ahead
+    // of the adds (unrolled: the next 32 terms are in registers), and the chain is the adds alone: 67 us (a dependent add every ~8 cycles).
     float total = 0.f;
-    if (tid < 64) {
-        float v = (tid < n_chunks) ? cs[tid] : 0.f;
-        float sv[64];                                        // the 64 terms of the current round, in scalar registers
+    constexpr int kPiece = 8192;                             // chunk sums per LDS piece (32 KiB)
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += kPiece) {
+        const int nc = (int)((n_chunks - c0 < kPiece) ? n_chunks - c0 : kPiece);
+        __syncthreads();                                     // (the piece before has been consumed)
+        for (int c = tid * 4; c < nc; c += kMeRestSlots * 4) {
+            if (c + 3 < nc && (((uintptr_t)(cs + c0 + c)) & 15) == 0) *(float4 *)(s_cs + c) = *(const float4 *)(cs + c0 + c);
+            else { for (int e = 0; e < 4 && c + e < nc; ++e) s_cs[c + e] = cs[c0 + c + e]; }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int c = 0;
+            for (; c + 32 <= nc; c += 32) {
+                float4 q[8];
 #pragma unroll
-        for (int c = 0; c < 64; ++c) sv[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), c));
-        for (int64_t c0 = 0; c0 < n_chunks; c0 += 64) {
-            const float nxt = (c0 + 64 + tid < n_chunks) ? cs[c0 + 64 + tid] : 0.f;
-            const int nc = (int)((n_chunks - c0 < 64) ? n_chunks - c0 : 64);
-            if (nc == 64) {
-                // a dependent add issues every ~9.5 cycles: the next round's v_readlane's go into the gaps
+                for (int e = 0; e < 8; ++e) q[e] = *(const float4 *)(s_cs + c + 4 * e);
 #pragma unroll
-                for (int c = 0; c < 64; ++c) {
-                    total = total + sv[c];
-                    sv[c] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nxt), c));
-                }
-            } else {
-                for (int c = 0; c < nc; ++c) total = total + __shfl(v, c);
+                for (int e = 0; e < 8; ++e) { total = total + q[e].x; total = total + q[e].y; total = total + q[e].z; total = total + q[e].w; }
             }
-            v = nxt;
+            for (; c < nc; ++c) total = total + s_cs[c];
         }
     }
     // pw(a, n) = pw(a, n2) + pw(a + n2, n - n2), n2 = n / 2 rounded down to a multiple of 8, down to leaves of <= 128 elements
