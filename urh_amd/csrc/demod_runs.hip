@@ -1612,15 +1612,19 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
         a.range_begin = c_lo * a.chunk_len; a.range_end = std::min<int64_t>(n_full, c_hi * a.chunk_len); a.chunk_base = c_lo;
         // orders 2 and 4: the bit-plane kernel; anything else: the state-byte kernel
         const bool planes_ok = URH_BITPLANE && a.tol <= kBpMaxTol && a.chunk_len <= (int64_t)kBpMaxRows * kRowSamples && !g_force_state_bytes;
-        if (planes_ok && O2 && a.stamp_probe && SRC == SRC_IQ && DT == URHGPU_DT_F32 && MOD == URHGPU_MOD_FSK && WQ && (g_hot_events.start || g_hot_events.stop)) {
+        // (the STAMPS instantiation exists for complex64 2-FSK with qad only: a probe request on any other pass is an ordinary launch, with its
+        // completion event -- ADVICE r5)
+        constexpr bool stamps_ok = SRC == SRC_IQ && DT == URHGPU_DT_F32 && MOD == URHGPU_MOD_FSK && WQ;
+        const bool stamps = a.stamp_probe && stamps_ok;
+        if (planes_ok && O2 && stamps && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
             hipExtLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, URHGPU_DT_F32, URHGPU_MOD_FSK, true, true, 1, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
                                   (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
             g_hot_events.used = true;
-        } else if (planes_ok && O2 && !a.stamp_probe && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
+        } else if (planes_ok && O2 && !stamps && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
             hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
                                   (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
             g_hot_events.used = true;
-        } else if (planes_ok && O2 && a.stamp_probe && SRC == SRC_IQ && DT == URHGPU_DT_F32 && MOD == URHGPU_MOD_FSK && WQ)
+        } else if (planes_ok && O2 && stamps)
             hipLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, URHGPU_DT_F32, URHGPU_MOD_FSK, true, true, 1, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
         else if (planes_ok && O2)
             hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
