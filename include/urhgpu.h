@@ -653,7 +653,9 @@ int urhgpu_test_hot_probe(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const ur
 int urhgpu_test_hot_stamps(int on);
 /* Measurement hook: leave kernels of the tile tail out (bit 0 k_resolve_one, 1 k_emit_rows_tiles, 2 k_tile_scan, 3 group scan, 4
  * k_expand_tiles, 5 k_pack_seg) to see what each costs the hot kernel it runs beside; outputs are only meaningful while every pass
- * processes the same capture (the buffers then hold the previous pass's identical results).  Process-wide; 0 restores the product. */
+ * processes the same capture (the buffers then hold the previous pass's identical results).  Round 6: bit 6 the row kernel without its stores
+ * into the (host or staging) blob, 7 without the int64 table, 9 a staged pass without its copies, 11 the expansion without its byte stores.
+ * Process-wide; 0 restores the product. */
 int urhgpu_test_tail_skip(int mask);
 int urhgpu_test_fetch_chunk_tables(urhgpu_ctx *ctx, void *host_dst, int64_t n_chunks);
 /* Synchronous device -> host copy after urhgpu_ctx_sync (for callers that hold raw device pointers, e.g. urhgpu_host_result::d_qad). */

@@ -62,7 +62,7 @@ def main():
 
     print(f"# {torch.cuda.get_device_name(0)}; {n} samples; tuning {tuning}; stamps {'off' if args.no_stamps else 'on'}")
     if args.skips:
-        names = ["k_resolve_one", "k_emit_rows_tiles", "k_tile_scan", "group scan", "k_expand_tiles", "k_pack_seg", "the row kernel's host stores", "the row kernel's int64 table", "the tighten kernel", "the blob's copy"]
+        names = ["k_resolve_one", "k_emit_rows_tiles", "k_tile_scan", "group scan", "k_expand_tiles", "k_pack_seg", "the row kernel's host stores", "the row kernel's int64 table", "(unused)", "the blob's copies", "(unused)", "the expansion's byte stores"]
         st = pipe.stream(n, replace(p, write_bit_sample_pos=False), want_qad=True, want_pos=False)
 
         def pushes(k):

@@ -130,12 +130,9 @@ int launch_fft_peak(const float2 *x, int log2n, void *scratch, int64_t *d_peak, 
     float2 *tw = (float2 *)take((size_t)(kFpMaxLen / 2) * 8);
     float *part_mag = (float *)take(1024 * 4);
     int64_t *part_k = (int64_t *)take(1024 * 8);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_fp_row_fft, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFpMaxLen * (int)sizeof(float2));
-        if (e != hipSuccess) return URHGPU_ERR_HIP;
-        attr_set = true;
-    }
+    // (the attribute is per DEVICE: set before every use -- a process-wide "done" flag left a second GPU's launches without the opt-in)
+    if (hipFuncSetAttribute((const void *)k_fp_row_fft, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kFpMaxLen * (int)sizeof(float2)) != hipSuccess)
+        return URHGPU_ERR_HIP;
     hipLaunchKernelGGL(k_fp_twiddles, dim3(kFpMaxLen / 2 / 256), dim3(256), 0, s, tw, kFpMaxLen / 2, kFpMaxLen);
     const float2 *result;
     int log2n1 = 0, log2n2 = log2n;       // e = k1 n2 + k2 with n1 = 1: k = k2 = e

@@ -1966,6 +1966,7 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
     ExpandTileArgs ea{rows, d_n_rows, tc.ft.excl, tc.ft.tile_off, tc.ft.tile_cnt, b.gout, &st->n_groups, o.bits, o.cap_bits, o.pos, o.cap_pos,
                       bp, tc.huge, m.huge_count, kTileHugeCap, m.parity, t1, sg.c0, h_pos};
     const unsigned tile_blocks = (unsigned)expand_tile_blocks(t1 - sg.c0);
+    if (g_tail_skip & 2048) ea.cap_bits = 0;                 // measurement: the expansion without its byte stores
     if (!(g_tail_skip & 16)) hipLaunchKernelGGL(k_expand_tiles, dim3(tile_blocks + kHugeBlocksX * kHugeBlocksY), dim3(64 * kEmitWaves), 0, s, ea);
     if (dst && dst->host) {
         if (((uintptr_t)o.bits & 7) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
