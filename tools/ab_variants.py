@@ -1,3 +1,5 @@
+"""K = 80 pipelined steps of the headline capture as complex64, bits-only and int8 (ms per step): the A/B harness of round 6's tail experiments
+(URHGPU_LIB=<tagged build> / URH_TUNE_<KEY>=<value> select the variant; profiles/r06_fir_pmc_account.txt)."""
 import sys, time, os, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -8,7 +10,7 @@ dev = torch.device("cuda", 0)
 iq, _ = spec_fsk_capture(128, dev, first_segment=0, sps=100)
 n = iq.shape[0]
 p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, False)
-pipe = DevicePipeline(0, pipelined=True)
+pipe = DevicePipeline(0, pipelined=True, tuning={k[9:].lower(): int(v) for k, v in os.environ.items() if k.startswith("URH_TUNE_")})
 pipe.reserve(n, p)
 x8 = (iq * 64.0).round().clamp(-127, 127).to(torch.int8).contiguous()
 out = {}
