@@ -6,8 +6,10 @@
 A "step" is one full pass of the hot path over one synthetic capture that is already resident in HBM:
 IQ (complex64) -> demodulated signal (Signal.qad, materialised, stays in HBM) -> pulse table -> bits / pauses /
 (bit_sample_pos: see config.outputs) -> the compact outputs in pinned host memory (SURVEY.md §8(d)'s timing window).  At N=1 the steps
-run through urhgpu_stream_* (urh_amd.pipeline.CaptureStream): the hot kernel of step i + 1 overlaps the tail of step i, whose kernels
-store the rows and the packed results into the pinned host blob themselves (round 4: direct passes), and `value` counts K steps
+run through urhgpu_stream_* (urh_amd.pipeline.CaptureStream): the hot kernel of step i + 1 overlaps the tail of step i -- STAGED passes
+since round 6: the tail's kernels store the pulse-table rows into a staging blob in HBM, the runtime's copy ships them to the pinned host
+blob while the bits are expanded, the last kernel stores the small head (header, pauses, offsets, packed bits) into the host blob itself
+(kernel stores into pinned memory beside the next hot kernel cost it 10 us per pass) --, and `value` counts K steps
 INCLUDING the delivery of all K (the timed region ends when the last step's results are on the host);
 the device-only figure of the same steps is config.device_only_ms_per_step.  Workload at N=1: BASELINE.json configs[1]
 ("1 GiB synthetic complex64 2-FSK @ 100 samples/symbol, single MI355X") on the bytes SURVEY.md §8(d) config 2
@@ -1095,7 +1097,7 @@ def main():
         one, one_tp = [], []
         for mode, acc in ((1, one), (0, one_tp)):            # ONE capture start to finish, nothing to overlap with: the stream in its latency setting
             pipe.ctx.set_tuning("stream_latency", mode)      # (an idle pipeline: the tail in segments beside the hot kernel) and in the
-            for _ in range(6):                               # throughput setting the K-step loop below runs in (direct passes)
+            for _ in range(6):                               # throughput setting the K-step loop below runs in (staged passes)
                 torch.cuda.synchronize()
                 t_l = time.perf_counter()
                 stream_steps(1)
@@ -1130,7 +1132,7 @@ def main():
         stream_stats = st.stats()
         stream_rec = {"single_capture_incl_compact_d2h_ms": round(min(one) * 1e3, 4),
                       "single_capture_setting": "CaptureStream(latency=True) / tuning stream_latency=1: a pass that finds the pipeline idle runs its tail in 7 rows "
-                                                "segments + 1 bits segment beside the hot kernel; the K-step loop runs in the throughput setting (direct passes), in "
+                                                "segments + 1 bits segment beside the hot kernel; the K-step loop runs in the throughput setting (staged passes), in "
                                                 "which one capture alone takes single_capture_throughput_setting_ms",
                       "single_capture_throughput_setting_ms": round(min(one_tp) * 1e3, 4), "d2h_bytes_per_step": last_host.blob_bytes + 40,
                       "host_loop": host_rec, "stream_stats": stream_stats,

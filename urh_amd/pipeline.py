@@ -426,7 +426,7 @@ class CaptureStream:
 
     def __init__(self, pipe: "DevicePipeline", n_max: int, p: DemodParams, want_qad=True, want_pos=True, dtype=np.float32, cap_rows=0, latency=None):
         """latency: True -- ONE capture at a time, its results as early as possible (a pass that finds the pipeline idle runs its tail in
-        segments beside the hot kernel); False -- capture after capture, highest throughput (direct passes); None: leave the context's
+        segments beside the hot kernel); False -- capture after capture, highest throughput (staged passes: rows through a staging blob in HBM and the runtime's copy); None: leave the context's
         setting (urhgpu_ctx_set_tuning "stream_latency") as it is"""
         if latency is not None:
             pipe.ctx.set_tuning("stream_latency", 1 if latency else 0)
