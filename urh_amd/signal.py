@@ -254,11 +254,13 @@ class Signal:
                            float(p["center_spacing"]), int(p["tolerance"]), int(p["samples_per_symbol"]),
                            float(p["costas_loop_bandwidth"]), int(p["pause_threshold"]), True)
 
-    def _drop_cache(self):
+    def _drop_cache(self, release: bool = False):
         self._qad = None
         self._bits = None
         self._bits_key = None
-        # the pinned host buffers of the digitisations go with the cache (a digitisation somebody still holds is widened first)
+        # the digitisations' views of the pinned host buffers go with the cache (a digitisation somebody still holds is widened first); the
+        # buffers themselves stay -- a noise threshold dragged through its range in the GUI lands here on every change, and pinning memory
+        # again each time is a hipHostMalloc per change -- and are released with the samples (eliminate)
         users = self.__dict__.get("_host_users")
         if users is not None:
             for k, ref in enumerate(users):
@@ -267,7 +269,10 @@ class Signal:
                     old.materialize()
                 users[k] = None
             for pool in self.__dict__.get("_host_pools", ()):
-                pool.clear()
+                if release:
+                    pool.clear()
+                else:
+                    pool["owner"] = None
 
     def _slice_key(self):
         return tuple(self._par[k] for k in _SLICE_KEYS[:5])
@@ -370,7 +375,7 @@ class Signal:
     def eliminate(self):
         """Signal.eliminate (:603-606): drop the samples and everything derived from them"""
         self._iq = None
-        self._drop_cache()
+        self._drop_cache(release=True)
 
     def quad_demod(self):
         """Signal.quad_demod (:474-484): a fresh demodulation (device tensor), or zeros(2) when everything is below the noise gate."""
