@@ -1151,6 +1151,13 @@ template <int SRC, int MOD> constexpr int bp_waves() { return (SRC == SRC_IQ && 
 // The integer instantiations of the 2-FSK kernel come out at 76-77 VGPRs (the conversions' temporaries): six wavefronts per SIMD where the
 // complex64 kernel has seven.  Held to seven they spill two registers in the rolled-up general atan2f path only (tools/kstats.sh + objdump:
 // one scratch store / load pair inside fsk_row_general's loop, none in the streaming loop).  -DURH_INT_WAVES7=0: the compiler's choice.
+#ifndef URH_HOT_WAVES
+#define URH_HOT_WAVES 7       // wavefronts per SIMD the 2-FSK bit-plane kernel is held to (A/B: 8 = 64 VGPRs)
+#endif
+#ifndef URH_HOT_WAVES_INT
+#define URH_HOT_WAVES_INT 8   // ... and its integer instantiations (64 VGPRs: the fast loop does not spill; measured 0.264 -> 0.259 ms per pipelined int8 step)
+#endif
+template <int DT> constexpr int bp_hot_waves() { return DT == URHGPU_DT_F32 ? URH_HOT_WAVES : URH_HOT_WAVES_INT; }
 #ifndef URH_INT_WAVES7
 #define URH_INT_WAVES7 1
 #endif
@@ -1158,7 +1165,7 @@ template <int SRC, int DT, int MOD, bool RUNS, int NPL> constexpr bool bp_seven(
     return URH_INT_WAVES7 && SRC == SRC_IQ && MOD == URHGPU_MOD_FSK && RUNS && NPL == 1;
 }
 template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1, bool STAMPS = false>
-__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) __attribute__((amdgpu_waves_per_eu((STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? 7 : 1, (STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? 7 : 8)))
+__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) __attribute__((amdgpu_waves_per_eu((STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? bp_hot_waves<DT>() : 1, (STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? bp_hot_waves<DT>() : 8)))
 void k_demod_runs_bp(const RunArgs p) {
     // One workgroup per chunk, URH_WPB wavefronts: wavefront w streams the w-th share of the chunk's rows on its own
     // (no barrier inside the streaming phase), so that the wavefronts resident on the chip cover a NARROW window of
