@@ -16,7 +16,17 @@
 #ifndef URH_TAIL_PRIO_LEVEL
 #define URH_TAIL_PRIO_LEVEL 3
 #endif
+// -DURH_TAIL_PAD=1 (A/B): every tail kernel also ALLOCATES 96 VGPRs, so that none of them fits beside seven hot wavefronts on a SIMD (80 of
+// 512 registers free at most when one has retired): the tail then lives on the CUs the hot stream's mask leaves out and nowhere else.
+// Measured (round 6): no difference -- the row and expansion kernels need more than 80 anyway, the small ones are too short to matter.
+#ifndef URH_TAIL_PAD
+#define URH_TAIL_PAD 0
+#endif
+#if URH_TAIL_PAD
+#define URH_TAIL_PRIO() do { __builtin_amdgcn_s_setprio(URH_TAIL_PRIO_LEVEL); __asm__ volatile("v_mov_b32 v95, 0" ::: "v95"); } while (0)
+#else
 #define URH_TAIL_PRIO() __builtin_amdgcn_s_setprio(URH_TAIL_PRIO_LEVEL)
+#endif
 
 namespace urh {
 
