@@ -405,7 +405,7 @@ def variant_steps(torch, pipe, iq, p, n, args, ramp, headline_copy):
             r = {"ms_per_step": round(ms, 4), "bytes_per_sample": 12, "frac_of_8TBs": frac(ms, 12), "Msamples_per_s": round(n / ms / 1e3, 1),
                  "capture": what, "rows": int(len(last.ppseq())), "messages": int(len(last.flat()[2])), "d2h_bytes": int(last.blob_bytes),
                  "d2h_gbs": round(int(last.blob_bytes) / (ms * 1e-3) / 1e9, 1),
-                 "bound": "what a step ships per pulse-table row (5 B) over PCIe: d2h_gbs is the link's rate" if int(last.blob_bytes) / (ms * 1e-3) > 30e9
+                 "bound": "what a step ships per pulse-table row (3 B) over PCIe: d2h_gbs is the link's rate" if int(last.blob_bytes) / (ms * 1e-3) > 30e9
                           else "as the headline: the hot kernel (HBM) with the tail of the pass before beside it",
                  "stream_stats": st.stats()}
             if not args.no_cpu_baseline:
@@ -1136,7 +1136,7 @@ def main():
                                                 "which one capture alone takes single_capture_throughput_setting_ms",
                       "single_capture_throughput_setting_ms": round(min(one_tp) * 1e3, 4), "d2h_bytes_per_step": last_host.blob_bytes + 40,
                       "host_loop": host_rec, "stream_stats": stream_stats,
-                      "d2h_format": "compact blob: int32 length + int8 state per pulse-table row, packed bits, int64 pauses / message offsets "
+                      "d2h_format": "compact blob: uint16 length (rows of 65535 samples and more through an escape list) + int8 state per pulse-table row, packed bits, int64 pauses / message offsets "
                                     "(include/urhgpu.h); bit_sample_pos derived on the host from the shipped pulse table when asked for"}
         # the last timed step's outputs for the parity record: host copies of the blob's sections + its qad read back from HBM
         import numpy as np

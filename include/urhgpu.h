@@ -271,6 +271,10 @@ typedef struct urhgpu_outputs {
  *   int32 row_len[n_rows]     (grab_pulse_lens' column 1; captures of up to 2^31 - 1 samples)
  *   (row_state -128: URHGPU_ROW_ABSORBED -- the first row of a rank's piece of a sharded ASK capture that was merged into the previous rank's last row)
  *   uint32 pos32[n_pos]       (bit_sample_pos; absent when the pass wrote no positions)
+ * header[7] holds flags: bit 0 has_pos; bit 1 (URHGPU_BLOB_LEN16; staged passes of urhgpu_stream_*, round 6): the row_len section holds
+ *   uint16 row_len16[n_rows] instead -- 3 bytes per pulse-table row over PCIe instead of 5 --, a length that does not fit (65535 and more,
+ *   or negative) is stored as 0xFFFF and listed behind the packed bits, at the next 16-byte boundary: int64 n_esc, then n_esc pairs
+ *   {uint32 row, int32 length} (a capture of n samples has at most n / 65535 + 2 of them)
  * truncated != 0: bit 0: a capacity was exceeded (rows_needed > cap_rows, or more messages / bits / positions than fit): the sections
  * hold what fitted, the caller repeats the pass with larger capacities; bit 2: a row length did not fit int32, a position uint32 or a
  * state int8 (captures of 2^31 samples and more; sharded captures whose positions are absolute): use the wide outputs; bit 1: a
@@ -278,6 +282,7 @@ typedef struct urhgpu_outputs {
  * total_bytes moves everything; urhgpu_stream_* below does that overlapped with the following passes. */
 #define URHGPU_BLOB_MAGIC INT64_C(0x55524842424C4F42) /* "URHBBLOB" */
 #define URHGPU_BLOB_HEADER_BYTES 128
+#define URHGPU_BLOB_LEN16 2      /* header[7] bit 1: 16-bit row lengths + escape list (see above) */
 int64_t urhgpu_blob_capacity(int64_t cap_rows, int64_t cap_bits, int64_t cap_msg, int64_t cap_pos, int has_pos);
 
 /* The results of a pass that is over, on the host through the compact blob: out = the descriptor the pass was given with out->blob /
@@ -328,7 +333,10 @@ typedef struct urhgpu_host_result {
     int64_t n_rows, n_msg, n_bits, n_pos, rows_needed;
     int64_t blob_bytes;          /* bytes that crossed PCIe for this pass (+ 40 for the counts) */
     int truncated;               /* see "compact result blob" */
-    const int32_t *row_len;      /* pulse table: grab_pulse_lens' [state, length] columns */
+    const int32_t *row_len;      /* pulse table: grab_pulse_lens' [state, length] columns; NULL when the blob carries 16-bit lengths: */
+    const uint16_t *row_len16;   /* ... then these (URHGPU_BLOB_LEN16), 0xFFFF = look the row up in esc */
+    const void *esc;             /* n_esc pairs {uint32 row, int32 length} */
+    int64_t n_esc;
     const int8_t *row_state;
     const uint8_t *bits_packed;  /* numpy.unpackbits(bits_packed)[msg_off[m] : msg_off[m + 1]] = message m */
     const int64_t *msg_off, *pauses, *pos_off;

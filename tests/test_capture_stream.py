@@ -56,7 +56,7 @@ def test_stream_of_different_captures_equals_oracle(oracle, mod, bps, want_pos):
         assert np.array_equal(g[1], bits) and np.array_equal(g[2], off) and np.array_equal(g[3], pauses), i
         # positions: the device's (want_pos) or derived on the host from the shipped pulse table (HostBits.bit_sample_pos): the same
         assert np.array_equal(g[4], pos) and np.array_equal(g[5], poff), i
-        # what crossed PCIe: 5 B per row, 1 bit per bit, 4 B per position, 24 B per message (+ header and alignment)
+        # what crossed PCIe: at most 5 B per row (3 + escapes with 16-bit lengths), 1 bit per bit, 4 B per position, 24 B per message (+ header and alignment)
         assert g[6] <= 5 * len(pp) + len(bits) // 8 + 4 * len(pos) * (1 if want_pos else 0) + 24 * len(pauses) + 512, (i, g[6])
     st.close()
     # the pipeline is usable as before afterwards
@@ -117,3 +117,43 @@ def test_stream_pushed_from_a_side_stream_with_the_capture_produced_there(oracle
         pp = oracle.grab_pulse_lens(oracle.afp_demod(iq, 0.1, "FSK", 2), 0.0, 5, "FSK", 100, 1, 1.0)
         bits, off, pauses, pos, poff = oracle.ppseq_to_bits_flat(pp, 100, 1, True, 8)
         assert np.array_equal(got[i][0], pp) and np.array_equal(got[i][1], bits) and np.array_equal(got[i][2], pauses), i
+
+
+def test_stream_ships_16_bit_lengths_with_escapes(oracle):
+    """Staged passes (round 6) ship 3 bytes per pulse-table row -- uint16 lengths, rows of 65535 samples and more through the escape list
+    (include/urhgpu.h: URHGPU_BLOB_LEN16): captures with pauses of 70 000 .. 300 000 samples (one of exactly 65 535 and one of 65 534: the boundary),
+    pushed back to back, come back with the reference's pulse table; the blob says how many rows took the list."""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    n = (1 << 20) + 4096 * 5
+    pipe = DevicePipeline(0, pipelined=True)
+    p = DemodParams("FSK", 1, 0.1, 0.0, 1.0, 5, 100, 0.1, 8, False)
+    caps = []
+    for i, gaps in enumerate(([(50_000, 70_000)], [(10_000, 65_535 + 11), (300_000, 65_534 + 11), (500_000, 300_000)], [], [(1000, 200_000), (400_000, 66_000)])):
+        iq = synth_fsk(n, sps=100, seed=300 + i, noise=0.02)
+        for a, ln in gaps:
+            iq[a:a + ln] = 0.0                                         # below the noise gate: one PAUSE row of about ln samples
+        caps.append(iq)
+    st = pipe.stream(n, p, want_qad=True, want_pos=False)
+    got = {}
+
+    def keep(r):
+        if r is not None:
+            r.check()
+            got[r.seq] = (r.ppseq(), r.bits(), r.pauses.copy(), r._len16[2] if r._len16 is not None else -1, r.blob_bytes)
+    for rep in range(2):
+        for c in caps:
+            keep(st.push(torch.from_numpy(c).cuda()))
+    for r in st.flush():
+        keep(r)
+    assert sorted(got) == list(range(2 * len(caps)))
+    for k in range(2 * len(caps)):
+        iq = caps[k % len(caps)]
+        pp = oracle.grab_pulse_lens(oracle.afp_demod(iq, 0.1, "FSK", 2), 0.0, 5, "FSK", 100, 1, 1.0)
+        bits, off, pauses, pos, poff = oracle.ppseq_to_bits_flat(pp, 100, 1, True, 8)
+        g = got[k]
+        assert np.array_equal(g[0], pp) and np.array_equal(g[1], bits) and np.array_equal(g[2], pauses), k
+        assert g[3] == int((pp[:, 1] >= 0xFFFF).sum() + (pp[:, 1] < 0).sum()), (k, g[3])          # 16-bit lengths were shipped, the long rows escaped
+        assert g[4] <= 3 * len(pp) + 8 * g[3] + len(bits) // 8 + 24 * len(pauses) + 512, (k, g[4])
+    assert any(got[k][3] > 0 for k in got)
+    st.close()

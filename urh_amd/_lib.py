@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(HERE, "liburhgpu.so")
 
 OK = 0
 ERR_HIP, ERR_DTYPE, ERR_ARG, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
+BLOB_LEN16 = 2            # header[7] bit 1 of a compact blob: 16-bit row lengths + escape list (include/urhgpu.h)
 
 DT_I8, DT_U8, DT_I16, DT_U16, DT_F32 = 0, 1, 2, 3, 4
 MOD_ASK, MOD_FSK, MOD_PSK, MOD_OTHER = 0, 1, 2, 3
@@ -56,7 +57,8 @@ class HostResult(C.Structure):
         ("seq", C.c_int64), ("n_samples", C.c_int64),
         ("n_rows", C.c_int64), ("n_msg", C.c_int64), ("n_bits", C.c_int64), ("n_pos", C.c_int64), ("rows_needed", C.c_int64),
         ("blob_bytes", C.c_int64), ("truncated", C.c_int),
-        ("row_len", C.c_void_p), ("row_state", C.c_void_p), ("bits_packed", C.c_void_p),
+        ("row_len", C.c_void_p), ("row_len16", C.c_void_p), ("esc", C.c_void_p), ("n_esc", C.c_int64),
+        ("row_state", C.c_void_p), ("bits_packed", C.c_void_p),
         ("msg_off", C.c_void_p), ("pauses", C.c_void_p), ("pos_off", C.c_void_p), ("pos32", C.c_void_p),
         ("blob", C.c_void_p), ("d_qad", C.c_void_p),
     ]

@@ -142,7 +142,7 @@ namespace urh {
 // demodulated as it lands (urhgpu_stream_push_upload).
 int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhgpu_params *p, const urhgpu_outputs *out, void *host_blob,
                         int64_t cap_host, hipEvent_t ev_ready, bool *streamed, const void *h_iq, void *stage_blob = nullptr, bool *staged = nullptr,
-                        hipEvent_t ev_rows = nullptr);
+                        hipEvent_t ev_rows = nullptr, int len16 = 0);
 }
 
 namespace urh {

@@ -268,6 +268,12 @@ struct RowsSegment {         // chunks [c0, c1) of the capture's n_chunks (c0 a 
     int8_t *h_state;         // pinned HOST memory (device-accessible) that receives the rows as they are written: the compact blob's
     int32_t *h_len;          // row_state / row_len sections (nullptr: rows are not shipped)
     int fuse_gate;           // allow the gate inside a one-workgroup resolve kernel (SegGate::fused)
+    // staged passes (round 6): lengths as uint16 INSTEAD of int32 (h_len then names the same section: 2 bytes per row), a length that does not
+    // fit -- 65535 and more, or negative -- is stored as 0xFFFF and appended to esc: esc[0] = count (zeroed by the resolve kernel), then
+    // {uint32 row, int32 length} pairs, esc_cap of them at most (a capture of n samples has at most n / 65535 + 2 such rows)
+    int len16;
+    int64_t *esc;
+    int64_t esc_cap;
 };
 struct BitsSegment {         // tiles [c0, c1) (the last one: + the tile of the table's last row); needs the rows of chunks < c1
     int index;               // j
@@ -284,6 +290,8 @@ struct SegPackDst {          // where a bits segment's share of the compact blob
     int pos_direct;          // a pass of ONE segment: positions are stored into the host blob by the kernels that write them (pulse_table.hip)
     int split;               // staged passes (ONE segment): `host` is the staging blob in HBM, in the split layout (compact.hpp: staged_layout)
     void *host_head;         // ... and the head (header + pauses / offsets / packed bits: small) goes straight into this pinned HOST blob
+    const int64_t *esc;      // staged passes with 16-bit row lengths: the escape list (RowsSegment::esc) the last kernel appends to the head; nullptr: int32 lengths
+    int64_t esc_cap;
 };
 
 // Tile tail (single GPU, not ASK): resolve + rows in two launches, bits in three more; see pulse_table.hip.

@@ -768,6 +768,7 @@ struct TileTail {            // scratch of the tile tail (carved from the contex
     GranDesc *rdesc;         // look-back descriptors of k_resolve_one (persistent, tagged with the pass number)
     unsigned long long epoch;
     int64_t *d_row_base;     // sharded captures: receives the global index of this GPU's first row (nullptr on a single GPU)
+    int64_t *esc;            // staged passes with 16-bit row lengths: the escape list, esc[0] = count (reset by k_resolve_one); else nullptr
 };
 
 // The kernels below are latency chains of a few memory round trips on a nearly idle chip, not bandwidth: every load whose
@@ -806,6 +807,7 @@ __global__ __launch_bounds__(kResolveBlock) void k_resolve_one(const ResolveArgs
     // this pass's (segment's) huge-row counter starts at zero whatever an earlier pass of the same parity left behind (one that failed
     // between its row and its expansion launches never reached the kernel that clears the counter for its successor)
     if (blockIdx.x == 0 && t == 0 && ft.want_bits) ft.huge_count[ft.parity] = 0;
+    if (blockIdx.x == 0 && t == 0 && ft.esc) ft.esc[0] = 0;
     ResElem e = res_identity();
     if (c < a.n_chunks) {
         ChunkInfo *ch = a.chunks + c;
@@ -944,9 +946,24 @@ struct EmitTileArgs {
     // (plain stores over PCIe, fire and forget; nullptr: not shipped)
     int8_t *h_state;
     int32_t *h_len;
+    int len16;               // h_len holds uint16 lengths, see RowsSegment::len16
+    int64_t *esc;
+    int64_t esc_cap;
 };
 
 __host__ __device__ static inline int64_t tail_waves(int64_t n_items) { return (n_items + kTailCPW - 1) / kTailCPW; }
+
+// a row's state and length into the shipped sections (EmitTileArgs::h_state / h_len): int32 lengths, or uint16 with the escape list
+__device__ __forceinline__ void ship_row(const EmitTileArgs &g, int64_t idx, int64_t state, int64_t len) {
+    g.h_state[idx] = (int8_t)state;
+    if (!g.len16) { g.h_len[idx] = (int32_t)len; return; }
+    const bool fits = len >= 0 && len < 0xFFFF;
+    ((uint16_t *)g.h_len)[idx] = fits ? (uint16_t)len : (uint16_t)0xFFFF;
+    if (!fits) {
+        const unsigned long long slot = atomicAdd((unsigned long long *)g.esc, 1ull);
+        if ((int64_t)slot < g.esc_cap) g.esc[1 + slot] = (int64_t)(((uint64_t)(uint32_t)(int32_t)len << 32) | (uint64_t)(uint32_t)idx);
+    }
+}
 
 // Sharded captures run the same kernel over the TABLE of the generic resolve pass -- the other shards' summaries around this GPU's
 // chunks (ResolveArgs::chunk_first / n_local).  A summary entry is a chunk whose records live elsewhere: it writes no rows, but what its
@@ -1019,7 +1036,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_EMIT_OCC void k_emit_rows_tile
                 const int64_t len = (P == 0) ? (r.n_total - r.tol) : (r.n_total - 1 - fpos - r.tol);
                 if (r.rows != nullptr && o < r.cap_rows) {
                     r.rows[2 * o] = (int64_t)fstate - 1; r.rows[2 * o + 1] = len;
-                    if (g.h_state) { g.h_state[o] = (int8_t)((int64_t)fstate - 1); g.h_len[o] = (int32_t)len; }
+                    if (g.h_state) ship_row(g, o, (int64_t)fstate - 1, len);
                 }
                 if (g.ft.want_bits) {
                     v = row_value((int64_t)fstate - 1, len, P == 0, g.bp);
@@ -1096,7 +1113,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_EMIT_OCC void k_emit_rows_tile
             const int64_t state = (int64_t)pst - 1;
             if (gi - row_base < a.cap_rows) {
                 if (a.rows) *(longlong2 *)(a.rows + 2 * (gi - row_base)) = longlong2{(long long)state, (long long)len};
-                if (g.h_state) { g.h_state[gi - row_base] = (int8_t)state; g.h_len[gi - row_base] = (int32_t)len; }
+                if (g.h_state) ship_row(g, gi - row_base, state, len);
             }
             if (g.ft.want_bits) {
                 const VecK<4> v = row_value(state, len, gi == 0, g.bp);
@@ -1624,6 +1641,7 @@ TileCarve carve_tile(const TileTailMem &m) {
     tc.ft.rdesc = (GranDesc *)m.rdesc;
     tc.ft.epoch = m.epoch;
     tc.ft.d_row_base = m.d_row_base;
+    tc.ft.esc = nullptr;
     return tc;
 }
 }  // namespace
@@ -1654,7 +1672,7 @@ int launch_tile_rows(const ResolveArgs &r, const EmitArgs &e, const TileTailMem 
     memset(&g.bp, 0, sizeof(g.bp));
     if (bp) { g.bp = *bp; g.ft.want_bits = 1; }
     const unsigned gb = (unsigned)resolve_blocks(r.n_chunks);
-    g.w0 = 0; g.w_end = tail_waves(r.n_chunks); g.final_seg = 1; g.seg = nullptr; g.seg_k = 0; g.h_state = nullptr; g.h_len = nullptr;
+    g.w0 = 0; g.w_end = tail_waves(r.n_chunks); g.final_seg = 1; g.seg = nullptr; g.seg_k = 0; g.h_state = nullptr; g.h_len = nullptr; g.len16 = 0; g.esc = nullptr; g.esc_cap = 0; g.ft.esc = nullptr;
     SegGate no_gate;
     memset(&no_gate, 0, sizeof(no_gate));
     if (!(g_tail_skip & 1)) hipLaunchKernelGGL(k_resolve_one, dim3(gb), dim3(kResolveBlock), 0, s, r, g.ft, (int64_t)0, no_gate);
@@ -1836,6 +1854,8 @@ struct SegPack {
     int pos_shipped;         // the positions have been stored into the host blob by the kernels that wrote them (GroupStore::h_pos)
     int split;               // staged pass (one segment): the small sections go tight behind the header, L's row / position offsets are the split layout's
     char *head;              // where header and small sections go (split: the pinned host blob; else == host)
+    const int64_t *esc;      // 16-bit row lengths: the escape list to append to the head (behind the packed bits); nullptr: int32 lengths
+    int64_t esc_cap;
 };
 __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
     URH_TAIL_PRIO();
@@ -1871,13 +1891,23 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
         if (gtid == 0 && m0 == 0) { mo[0] = 0; po[0] = 0; }
         for (int64_t i = m0 + gtid; i < m1; i += stride) { pa[i] = a.pauses[i]; mo[i + 1] = a.msg_off[i + 1]; po[i + 1] = a.pos_off[i + 1]; }
     }
+    int64_t n_esc = 0;
+    if (a.esc && a.final) {
+        // 16-bit row lengths: the escape list goes behind the packed bits -- int64 count, then the {row, length} pairs
+        n_esc = a.esc[0];
+        const bool over = n_esc > a.esc_cap;
+        if (over) n_esc = a.esc_cap;
+        int64_t *dst = (int64_t *)(a.head + ((L.off_bits + (nbits + 7) / 8 + 15) & ~int64_t(15)));
+        if (gtid == 0) dst[0] = over ? -n_esc : n_esc;            // (negative: the list overflowed -- cannot happen for esc_cap = n / 65535 + 2)
+        for (int64_t i = gtid; i < n_esc; i += stride) dst[1 + i] = a.esc[1 + i];
+    }
     if (a.final && gtid == 0) {
         int64_t *hdr = (int64_t *)a.head;
         const int64_t *c = a.counts;
         const int64_t n_rows = lim(*a.d_n_rows, a.cap_rows);
         hdr[1] = n_rows; hdr[2] = m1; hdr[3] = nbits; hdr[4] = p1; hdr[5] = c[4];
-        hdr[6] = URHGPU_BLOB_HEADER_BYTES + n_rows * 5 + (nbits + 7) / 8 + p1 * 4 + m1 * 24 + 16;     // bytes that crossed PCIe for this pass
-        hdr[7] = a.has_pos;
+        hdr[6] = URHGPU_BLOB_HEADER_BYTES + n_rows * (a.esc ? 3 : 5) + (a.esc ? 8 + n_esc * 8 : 0) + (nbits + 7) / 8 + p1 * 4 + m1 * 24 + 16;     // bytes that crossed PCIe for this pass
+        hdr[7] = a.has_pos | (a.esc ? URHGPU_BLOB_LEN16 : 0);
         hdr[8] = L.off_pauses; hdr[9] = L.off_msg_off; hdr[10] = L.off_pos_off; hdr[11] = L.off_row_state; hdr[12] = L.off_bits;
         hdr[13] = L.off_row_len; hdr[14] = L.off_pos32;
         hdr[15] = ((c[1] > a.cap_msg || c[2] > a.cap_bits || (a.has_pos && c[3] > a.cap_pos) || c[4] > a.cap_rows) ? 1 : 0) | (a.seg->err ? 2 : 0);
@@ -1903,6 +1933,8 @@ int launch_rows_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailM
     g.bp = bp; g.ft.want_bits = 1;
     g.w0 = sg.c0 / kTailCPW; g.w_end = sg.final ? tail_waves(r.n_chunks) : sg.c1 / kTailCPW; g.final_seg = sg.final; g.seg = state; g.seg_k = sg.index;
     g.h_state = sg.h_state; g.h_len = sg.h_len;
+    g.len16 = (sg.len16 && sg.esc && sg.h_len) ? 1 : 0; g.esc = g.len16 ? sg.esc : nullptr; g.esc_cap = sg.esc_cap;
+    g.ft.esc = (g.len16 && sg.index == 0) ? sg.esc : nullptr;          // (the pass's first rows segment resets the list)
     if (g_tail_skip & 64) { g.h_state = nullptr; g.h_len = nullptr; }      // measurement: the row kernel without its host stores
     if (g_tail_skip & 128) g.e.rows = nullptr;                              // measurement: ... without the int64 table
     // the huge-row list is consumed by the bits segment that covers these tiles, which may cover several rows segments: only the pass's
@@ -1972,7 +2004,7 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
         if (((uintptr_t)o.bits & 7) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
         SegPack pk{o.bits, o.msg_off, o.pauses, o.pos_off, o.pos, o.counts, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos, (char *)dst->host,
                    L, st, d_n_rows, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr, pos_direct ? 1 : 0, split ? 1 : 0,
-                   (split && dst->host_head) ? (char *)dst->host_head : (char *)dst->host};
+                   (split && dst->host_head) ? (char *)dst->host_head : (char *)dst->host, split ? dst->esc : nullptr, dst->esc_cap};
         if (dst->cap_host < pk.L.total) return URHGPU_ERR_CAPACITY;
         if (!(g_tail_skip & 32)) hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 32), dim3(256), 0, s, pk);
     }

@@ -44,6 +44,7 @@ struct urhgpu_stream {
     hipStream_t copy_stream = nullptr;
     int64_t seq = 0;
     int64_t streamed_passes = 0;           // passes whose tail ran in segments (diagnostics)
+    bool len16 = false;                    // staged passes ship 16-bit row lengths + an escape list (the staging blob's head region holds the list)
     int64_t staged_passes = 0;             // passes whose tail stored into the staging blob (tightened + copied by the copy engine)
     int64_t uploaded_passes = 0;           // ... of which the capture was uploaded piece by piece (urhgpu_stream_push_upload)
     int64_t predicted_bytes = 0;           // blob bytes the next pass's copy is sized for (0: header only, the rest fetched on demand)
@@ -70,7 +71,15 @@ void fill_result(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *
     r->row_state = (const int8_t *)(s.h_blob + hdr[11]);
     r->bits_packed = (const uint8_t *)(s.h_blob + hdr[12]);
     r->row_len = (const int32_t *)(s.h_blob + hdr[13]);
-    r->pos32 = hdr[7] ? (const uint32_t *)(s.h_blob + hdr[14]) : nullptr;
+    r->row_len16 = nullptr; r->esc = nullptr; r->n_esc = 0;
+    if (hdr[7] & URHGPU_BLOB_LEN16) {                        // 16-bit lengths + the escape list behind the packed bits
+        r->row_len = nullptr;
+        r->row_len16 = (const uint16_t *)(s.h_blob + hdr[13]);
+        const int64_t *e = (const int64_t *)(s.h_blob + ((hdr[12] + (hdr[3] + 7) / 8 + 15) & ~int64_t(15)));
+        r->n_esc = e[0] < 0 ? -e[0] : e[0];
+        r->esc = e + 1;
+    }
+    r->pos32 = (hdr[7] & 1) ? (const uint32_t *)(s.h_blob + hdr[14]) : nullptr;
     r->blob = s.h_blob;
     r->d_qad = s.qad;
     (void)st;
@@ -115,7 +124,8 @@ int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r
     if (s.staged) {
         // split layout: what the predictions missed, now -- the rest of the head (it ends with the packed bits), of the two row sections, of the positions
         const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
-        const int64_t n_rows = hdr[1], n_pos = hdr[7] ? hdr[4] : 0;
+        const int64_t n_rows = hdr[1], n_pos = (hdr[7] & 1) ? hdr[4] : 0;
+        const int64_t len_bytes = (hdr[7] & URHGPU_BLOB_LEN16) ? 2 : 4;
         const int64_t head = (hdr[12] + (hdr[3] + 7) / 8 + 15) & ~int64_t(15);
         if (n_rows < 0 || n_rows > st->cap_rows || n_pos < 0 || n_pos > st->cap_pos || head < URHGPU_BLOB_HEADER_BYTES || head > SL.head_cap) return URHGPU_ERR_ARG;
         bool more = false;
@@ -127,7 +137,7 @@ int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r
         if (head > s.copied) URH_TRY(fetch(s.copied, head - s.copied));
         if (n_rows > s.copied_rows) {
             URH_TRY(fetch(SL.off_row_state + s.copied_rows, n_rows - s.copied_rows));
-            URH_TRY(fetch(SL.off_row_len + 4 * s.copied_rows, 4 * (n_rows - s.copied_rows)));
+            URH_TRY(fetch(SL.off_row_len + len_bytes * s.copied_rows, len_bytes * (n_rows - s.copied_rows)));
         }
         if (n_pos > s.copied_pos) URH_TRY(fetch(SL.off_pos32 + 4 * s.copied_pos, 4 * (n_pos - s.copied_pos)));
         if (more) { URH_HIP(hipStreamSynchronize(st->copy_stream)); st->short_copies += 1; }
@@ -186,6 +196,11 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
         st->cap_pos = st->cap_bits + 2 * st->cap_msg + 2;
     }
     st->cap_blob = blob_capacity(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
+    {
+        // 16-bit row lengths for staged passes: their escape list lives in the staging blob's (otherwise unused) head region
+        const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
+        st->len16 = SL.head_cap - URHGPU_BLOB_HEADER_BYTES >= 8 + (n_max / 65535 + 2) * 8 + 16;
+    }
     st->was_pipelined = ctx->pipelined;
     if (!ctx->pipelined) { status = urhgpu_ctx_set_pipelined(ctx, 1, nullptr); if (status != URHGPU_OK) { delete st; return status; } }
     status = urhgpu_ctx_reserve(ctx, n_max, p->tolerance);
@@ -291,7 +306,7 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
     // sections as soon as the row kernel is through (while the bits are expanded), the head (+ positions) behind the pass's last kernel.
     bool streamed = false, staged = false;
     s.staged = false;
-    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq, s.stage, &staged, s.ev_rows));
+    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq, s.stage, &staged, s.ev_rows, st->len16 ? 1 : 0));
     if (streamed && staged) {
         const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
         const int64_t rows = std::min<int64_t>(st->predicted_rows, st->cap_rows), npos = st->want_pos ? std::min<int64_t>(st->predicted_pos, st->cap_pos) : 0;
@@ -300,7 +315,7 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
             // (behind the row kernel, not behind the pass's last kernel: measured the same to slightly better, 0.2839-0.2847 against 0.2848-0.2880 ms per step at K = 20)
             URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_rows, 0));
             URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_state, s.stage + SL.off_row_state, (size_t)rows, hipMemcpyDeviceToHost, st->copy_stream));
-            URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_len, s.stage + SL.off_row_len, (size_t)rows * 4, hipMemcpyDeviceToHost, st->copy_stream));
+            URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_len, s.stage + SL.off_row_len, (size_t)rows * (st->len16 ? 2 : 4), hipMemcpyDeviceToHost, st->copy_stream));
         }
         // (recorded behind the pass's last kernel, which has stored the head -- header, pauses, offsets, packed bits: small -- into the host
         // blob itself: no copy of it, no hop to another stream at the end of the chain)

@@ -282,6 +282,7 @@ class HostBits:
         self.params = params
         self.d_qad_ptr = r.d_qad
         # the views are made when somebody looks (a push per 0.3 ms must not allocate a dozen objects each)
+        self._len16 = (r.row_len16, r.esc, int(r.n_esc)) if r.row_len16 else None      # 16-bit lengths + escape list (URHGPU_BLOB_LEN16)
         self._ptr = dict(row_len=(r.row_len, self.n_rows, np.int32), row_state=(r.row_state, self.n_rows, np.int8),
                          bits_packed=(r.bits_packed, (self.n_bits + 7) // 8, np.uint8), msg_off=(r.msg_off, self.n_msg + 1, np.int64),
                          pauses=(r.pauses, self.n_msg, np.int64), pos_off=(r.pos_off, self.n_msg + 1, np.int64),
@@ -291,6 +292,20 @@ class HostBits:
         spec = self.__dict__.get("_ptr", {}).get(name, False)
         if spec is False:
             raise AttributeError(name)
+        if name == "row_len" and self.__dict__.get("_len16") is not None:
+            # widen the shipped uint16 lengths; 0xFFFF = look the row up in the escape list ({uint32 row, int32 length} pairs)
+            p16, pesc, n_esc = self._len16
+            if self.n_rows <= 0:
+                value = np.zeros(0, np.int32)
+            else:
+                value = np.frombuffer((C.c_ubyte * (2 * self.n_rows)).from_address(p16), dtype=np.uint16, count=self.n_rows).astype(np.int32)
+                if n_esc > 0:
+                    e = np.frombuffer((C.c_ubyte * (8 * n_esc)).from_address(pesc), dtype=np.uint32, count=2 * n_esc).reshape(-1, 2)
+                    value[e[:, 0].astype(np.int64)] = e[:, 1].copy().view(np.int32)
+                if (value == 0xFFFF).any():
+                    raise _lib.UrhGpuError(_lib.ERR_UNSUPPORTED, "compact blob: a 16-bit row length without its escape entry")
+            self.__dict__[name] = value
+            return value
         if spec is None:
             value = None
         else:
@@ -317,7 +332,11 @@ class HostBits:
         r.truncated = int(hdr[15])
         r.pauses, r.msg_off, r.pos_off = host_ptr + int(hdr[8]), host_ptr + int(hdr[9]), host_ptr + int(hdr[10])
         r.row_state, r.bits_packed, r.row_len = host_ptr + int(hdr[11]), host_ptr + int(hdr[12]), host_ptr + int(hdr[13])
-        r.pos32 = host_ptr + int(hdr[14]) if int(hdr[7]) else None
+        if int(hdr[7]) & _lib.BLOB_LEN16:
+            off_esc = (int(hdr[12]) + (int(hdr[3]) + 7) // 8 + 15) & ~15
+            n_esc = int(np.frombuffer((C.c_ubyte * 8).from_address(host_ptr + off_esc), dtype=np.int64, count=1)[0])
+            r.row_len16, r.row_len, r.esc, r.n_esc = r.row_len, None, host_ptr + off_esc + 8, abs(n_esc)
+        r.pos32 = host_ptr + int(hdr[14]) if int(hdr[7]) & 1 else None
         r.blob = host_ptr
         r.d_qad = d_qad or None
         return cls(r, params)
