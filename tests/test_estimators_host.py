@@ -258,6 +258,62 @@ def test_host_bits_from_a_blob_in_host_memory():
         HostBits.from_blob(C.addressof((C.c_ubyte * 128)()), None)
 
 
+def test_host_bits_from_a_blob_with_16_bit_row_lengths():
+    """The blob of a staged pass (include/urhgpu.h: URHGPU_BLOB_LEN16, header[7] bit 1): row_len as uint16, rows of 65535 samples and more -- and a
+    negative length (signal_functions.pyx:485-493: the last row of a capture shorter than the tolerance) -- as 0xFFFF with {uint32 row, int32 length}
+    entries in the escape list behind the packed bits.  HostBits widens; a 0xFFFF without its entry is an error, not a length."""
+    import ctypes as C
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams, HostBits
+    rng = np.random.default_rng(11)
+    n_rows = 53
+    row_state = rng.integers(-1, 2, n_rows).astype(np.int8)
+    row_len = rng.integers(1, 60000, n_rows).astype(np.int64)
+    row_len[[3, 17, 52]] = [65535, 1 << 30, -4]                 # the boundary, a long pause, a negative last row
+    row_len[9] = 65534                                           # the largest length that ships as it is
+    bits = rng.integers(0, 2, 77).astype(np.uint8)
+    msg_off, pauses, pos_off = np.array([0, 77], np.int64), np.array([0], np.int64), np.array([0, 78], np.int64)
+    for drop_entry in (False, True):
+        esc_rows = [r for r in range(n_rows) if not 0 <= row_len[r] < 0xFFFF]
+        assert esc_rows == [3, 17, 52]
+        len16 = np.where((row_len >= 0) & (row_len < 0xFFFF), row_len, 0xFFFF).astype(np.uint16)
+        listed = esc_rows[:-1] if drop_entry else esc_rows
+        esc = np.zeros(1 + len(listed), np.int64)
+        esc[0] = len(listed)
+        pairs = np.zeros((len(listed), 2), np.uint32)
+        pairs[:, 0] = listed
+        pairs[:, 1] = row_len[listed].astype(np.int32).view(np.uint32)
+        sections, off = {}, 128
+
+        def put(name, raw):
+            nonlocal off
+            off = (off + 15) & ~15
+            sections[name] = (off, raw)
+            off += len(raw)
+        put("pauses", pauses.tobytes()); put("msg_off", msg_off.tobytes()); put("pos_off", pos_off.tobytes())
+        put("bits", np.packbits(bits).tobytes())
+        put("esc", esc[:1].tobytes() + pairs.tobytes())              # behind the packed bits, at the next 16-byte boundary
+        put("row_state", row_state.tobytes()); put("row_len", len16.tobytes())
+        total = off
+        hdr = np.zeros(16, np.int64)
+        hdr[:8] = [_lib.BLOB_MAGIC, n_rows, 1, len(bits), 0, n_rows, total, _lib.BLOB_LEN16]
+        hdr[8:15] = [sections["pauses"][0], sections["msg_off"][0], sections["pos_off"][0], sections["row_state"][0], sections["bits"][0],
+                     sections["row_len"][0], 0]
+        blob = bytearray(total)
+        blob[:128] = hdr.tobytes()
+        for o, b in sections.values():
+            blob[o:o + len(b)] = b
+        buf = (C.c_ubyte * total).from_buffer(blob)
+        h = HostBits.from_blob(C.addressof(buf), DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, False), n_samples=1 << 20).check()
+        if drop_entry:
+            with pytest.raises(_lib.UrhGpuError):
+                h.ppseq()
+        else:
+            assert h.row_len.dtype == np.int32
+            assert np.array_equal(h.ppseq(), np.stack([row_state.astype(np.int64), row_len], axis=1))
+            assert np.array_equal(h.bits(), bits)
+
+
 def test_peaks_center_linear_form_equals_the_offset_loop():
     """peaks_center finds the strict maxima with two sliding-window maxima (linear in the bins: a nearly constant message has millions);
     the per-offset comparison loop it replaced is the checker here (AutoInterpretation.py:250-277)"""

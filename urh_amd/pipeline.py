@@ -299,11 +299,16 @@ class HostBits:
                 value = np.zeros(0, np.int32)
             else:
                 value = np.frombuffer((C.c_ubyte * (2 * self.n_rows)).from_address(p16), dtype=np.uint16, count=self.n_rows).astype(np.int32)
+                marked = value == 0xFFFF
+                rows = np.zeros(0, np.int64)
                 if n_esc > 0:
                     e = np.frombuffer((C.c_ubyte * (8 * n_esc)).from_address(pesc), dtype=np.uint32, count=2 * n_esc).reshape(-1, 2)
-                    value[e[:, 0].astype(np.int64)] = e[:, 1].copy().view(np.int32)
-                if (value == 0xFFFF).any():
-                    raise _lib.UrhGpuError(_lib.ERR_UNSUPPORTED, "compact blob: a 16-bit row length without its escape entry")
+                    rows = e[:, 0].astype(np.int64)
+                # every 0xFFFF has its entry and every entry its 0xFFFF (a true length of 65535 is an entry too)
+                if int(marked.sum()) != n_esc or (n_esc and (rows.max() >= self.n_rows or not marked[rows].all() or len(np.unique(rows)) != n_esc)):
+                    raise _lib.UrhGpuError(_lib.ERR_UNSUPPORTED, "compact blob: the 16-bit row lengths and their escape list do not match")
+                if n_esc > 0:
+                    value[rows] = e[:, 1].copy().view(np.int32)
             self.__dict__[name] = value
             return value
         if spec is None:
