@@ -78,6 +78,19 @@ __device__ __forceinline__ const float *me_src(const float *x, const float *kept
     return me_clean(m) ? x + m.start + m.skip : kept + m.start;
 }
 
+// A tile's 32 leaf sums (in lane 0 of every group of 8 lanes, leaf 8 w + g in group g of wavefront w) are half of a chunk's perfect
+// binary tree (s[i] = s[2 i] + s[2 i + 1], level by level): three levels inside the wavefront; its lane 0 leaves the wavefront's
+// subtree in s_h[w], and behind a barrier the tile's half is (s_h[0] + s_h[1]) + (s_h[2] + s_h[3]).  The chunk's sum is half 2 c + half
+// 2 c + 1 (k_me_sum_fin).  (Rounds 3-5: the leaf sums went to device memory and a kernel of its own built the trees, k_me_chunk_trees.)
+__device__ __forceinline__ float me_half_tree(float leaf_sum, float *s_h) {
+    float h = leaf_sum;
+    h = h + __shfl_down(h, 8);
+    h = h + __shfl_down(h, 16);
+    h = h + __shfl_down(h, 32);
+    if ((threadIdx.x & 63) == 0) s_h[threadIdx.x >> 6] = h;
+    return h;
+}
+
 // ---- stage 1: count x > -4 per natural tile, stable compaction per message into kept[start + j] -----------------------------
 // ---- stage 1, speculative form: ONE pass that counts AND -- assuming nothing will be filtered (ASK magnitudes never are; an FSK / PSK
 // message without a single noise sample is not either) -- takes min / max and the first-round leaf sums (np.mean) of the trimmed range.
@@ -88,9 +101,9 @@ __device__ __forceinline__ const float *me_src(const float *x, const float *kept
 // tile (compaction, then the leaf passes).  Three passes over a clean message instead of five; five reads and one write instead of
 // six and one over a message with filtered samples.
 __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState *st, const MsgTile *tiles, int32_t *tile_cnt, float2 *tile_mm,
-                                                        float *leaf_sums) {
+                                                        float *half_sums) {
     __shared__ int s_c[4 * (kMeBlock / 64)];
-    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
+    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64], s_h[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
     // The demodulated signal of an FSK / PSK capture STARTS with a filtered sample (result[0] = NOISE = -4, signal_functions.pyx:361): the
@@ -153,14 +166,13 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
     }
     // leaf sums of the FULL chunks (k_me_leaves, mode 0): accumulator j of the leaf, then ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
     const int64_t n_full_leaves = (L / kPwChunkM) * (kPwChunkM / kPwLeafM);
-    const int64_t leaf = (int64_t)t.idx * kLeavesPerTile + lf;
     float acc = v[0];
 #pragma unroll
     for (int i = 1; i < kPwLeafM / 8; ++i) acc += v[i];
     acc = acc + __shfl_down(acc, 1);
     acc = acc + __shfl_down(acc, 2);
     acc = acc + __shfl_down(acc, 4);
-    if (leaf < n_full_leaves && j == 0) leaf_sums[m.first_tile * kLeavesPerTile + leaf] = acc;
+    me_half_tree(acc, s_h);                                   // (s_h is read behind the barrier below)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
@@ -184,21 +196,16 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
     if (threadIdx.x == 0) {
         for (int w = 1; w < kMeBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
         if (any) tile_mm[blockIdx.x] = float2{mn, mx};
+        if ((int64_t)t.idx * kLeavesPerTile < n_full_leaves) half_sums[m.first_tile + t.idx] = (s_h[0] + s_h[1]) + (s_h[2] + s_h[3]);
     }
 }
-// after the scan of k_me_first's counts: kept of every message
-__global__ void k_me_spec(MsgState *st, int n_msgs, const int64_t *tile_pre) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_msgs) return;
-    const int64_t len = st[m].end - st[m].start, nt = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
-    st[m].kept = tile_pre[st[m].first_tile + nt] - tile_pre[st[m].first_tile];
-}
-
 // exclusive prefix of the per-tile counts over the whole tile table (ONE workgroup: the table has n / 4096 entries); a tile's
 // offset inside its message is pre[tile] - pre[message's first tile] -- no workgroup re-adds the counts of the tiles before it
 // (a capture that is ONE message of 2^27 samples has 32 768 tiles)
 constexpr int kMeScanBlock = 1024;
-__global__ __launch_bounds__(kMeScanBlock) void k_me_tile_scan(const int32_t *cnt, int64_t n_tiles, int64_t *pre) {
+// st != nullptr (the center statistics): the kept count and the trimmed range [a, a + L) of every message are this kernel's last step --
+// they need nothing but the prefix (rounds 3-5: two launches of their own, k_me_spec and k_me_trim)
+__global__ __launch_bounds__(kMeScanBlock) void k_me_tile_scan(const int32_t *cnt, int64_t n_tiles, int64_t *pre, MsgState *st, int n_msgs) {
     // every wavefront owns a contiguous stretch of the table and reads it 64 entries at a time (coalesced): first its sum, then --
     // after ONE exchange of the 16 sums -- a running wavefront scan over the stretch.  (The first version walked the whole table
     // 1024 entries at a time: 32 rounds of three barriers each for a 1 GiB capture, 31 us.)
@@ -232,6 +239,16 @@ __global__ __launch_bounds__(kMeScanBlock) void k_me_tile_scan(const int32_t *cn
         }
     }
     if (threadIdx.x == 0) pre[n_tiles] = total;
+    if (!st) return;
+    __syncthreads();                                          // (the prefix is visible to the whole workgroup)
+    for (int m = threadIdx.x; m < n_msgs; m += kMeScanBlock) {
+        const int64_t len = st[m].end - st[m].start, nt = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
+        const int64_t k = pre[st[m].first_tile + nt] - pre[st[m].first_tile];
+        st[m].kept = k;
+        const int64_t a = (int64_t)(0.05 * (double)k), b = (int64_t)(0.95 * (double)k);     // int(0.05 * len), int(0.95 * len) (:231)
+        st[m].a = a;
+        st[m].L = b > a ? b - a : 0;
+    }
 }
 
 __global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgState *st, const MsgTile *tiles, const int64_t *tile_pre,
@@ -242,7 +259,6 @@ __global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgStat
     const int64_t start = st[t.msg].start, end = st[t.msg].end, first_tile = st[t.msg].first_tile;
     const int64_t len = end - start, n_tiles = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
     const int64_t kept_total = tile_pre[first_tile + n_tiles] - tile_pre[first_tile];
-    if (threadIdx.x == 0 && t.idx == n_tiles - 1) st[t.msg].kept = kept_total;
     if (kept_total == len - st[t.msg].skip) return;          // nothing filtered (but the first sample): the later stages read the capture (me_src)
     const int64_t before = tile_pre[blockIdx.x] - tile_pre[first_tile];         // kept samples in the message's earlier tiles
     const int64_t base = start + (int64_t)t.idx * kMeTile;
@@ -263,56 +279,6 @@ __global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgStat
         if (v[j] > -4.0f) kept[start + before + s_cell[j * (kMeBlock / 64) + wave] + __popcll(bal[j] & below)] = v[j];
 }
 
-// ---- stage 2: trim, pairwise-summation geometry -------------------------------------------------------------------------
-__global__ void k_me_trim(MsgState *st, int n_msgs) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= n_msgs) return;
-    const int64_t k = st[m].kept;
-    const int64_t a = (int64_t)(0.05 * (double)k), b = (int64_t)(0.95 * (double)k);     // int(0.05 * len), int(0.95 * len) (:231)
-    st[m].a = a;
-    st[m].L = b > a ? b - a : 0;
-}
-
-// ---- stage 3: min / max (util.minmax: seeded with element 0, `<` / `>` folds -- NaN never replaces a value) ----------------
-// Per-tile partials come out of the pass that reads the samples anyway: k_me_first for messages without filtered samples (tile t = window
-// [4096 t, 4096 (t + 1)) of the trimmed range), k_me_leaves (mode 0) for the others (tile t = the 32 full leaves it sums); the
-// irregular rest of those (< 8192 elements behind the full chunks) is folded in by k_me_minmax_fin itself.
-constexpr int kMeFinBlock = 1024;            // one message can be the whole capture: 32 768 tiles
-__global__ __launch_bounds__(kMeFinBlock) void k_me_minmax_fin(MsgState *st, const float2 *tile_mm, const float *x, const float *kept) {
-    __shared__ float s_mn[kMeFinBlock / 64], s_mx[kMeFinBlock / 64];
-    const int m = blockIdx.x;
-    MsgState s = st[m];
-    if (s.L <= 0) return;
-    const bool spec = me_clean(s);                           // partials by k_me_first (every tile of the trimmed range) or by k_me_leaves (full chunks)
-    const int64_t nt = spec ? (s.L + kMeTile - 1) / kMeTile : (s.L / kPwChunkM) * (kPwChunkM / kMeTile);
-    const float *r = me_src(x, kept, s) + s.a;
-    float mn = r[0], mx = mn;
-    for (int64_t u = threadIdx.x; u < nt; u += kMeFinBlock) {
-        const float2 p = tile_mm[s.first_tile + u];
-        if (p.x < mn) mn = p.x;
-        if (p.y > mx) mx = p.y;
-    }
-    if (!spec) {
-        for (int64_t i = (s.L / kPwChunkM) * kPwChunkM + threadIdx.x; i < s.L; i += kMeFinBlock) {
-            const float v = r[i];
-            if (v < mn) mn = v;
-            if (v > mx) mx = v;
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
-        if (a < mn) mn = a;
-        if (b > mx) mx = b;
-    }
-    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kMeFinBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
-        st[m].mn = mn; st[m].mx = mx;
-    }
-}
-
 // ---- stage 4: numpy's float32 pairwise sums (np.mean, np.var) ---------------------------------------------------------------
 // see estimators.hip for the order: chunks of 8192 accumulated left to right, a full chunk = perfect binary tree over 64 leaves
 // of 128 elements, a leaf = 8 strided accumulators combined ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)); the irregular last chunk is
@@ -325,8 +291,8 @@ __device__ __forceinline__ float me_elem(const float *r, int64_t i, int mode, fl
 }
 // leaf sums of the FULL chunks: 8 threads per leaf (one per accumulator), 32 leaves per tile
 __global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int mode,
-                                                         float *leaf_sums, float2 *tile_mm) {
-    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
+                                                         float *half_sums, float2 *tile_mm) {
+    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64], s_h[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
     if (mode == 0 && me_clean(m)) return;                    // nothing filtered: k_me_first has written these leaf sums
@@ -368,24 +334,10 @@ __global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *x, const fl
     acc = acc + __shfl_down(acc, 1);
     acc = acc + __shfl_down(acc, 2);
     acc = acc + __shfl_down(acc, 4);
-    if (live && j == 0) leaf_sums[m.first_tile * kLeavesPerTile + leaf] = acc;
-}
-// full chunks: perfect binary tree over the 64 leaf sums of a chunk, one wavefront per chunk (a chunk = two tiles: the even tile's
-// workgroup does it).  chunk_sums[first_tile / 2 + message-local chunk] (first_tile counts tiles of the earlier messages).
-__global__ __launch_bounds__(64) void k_me_chunk_trees(const MsgState *st, const MsgTile *tiles, const float *leaf_sums, float *chunk_sums) {
-    const MsgTile t = tiles[blockIdx.x];
-    if (t.idx & 1) return;
-    const MsgState m = st[t.msg];
-    const int64_t c = t.idx >> 1;
-    if (c >= m.L / kPwChunkM) return;
-    float v = leaf_sums[m.first_tile * kLeavesPerTile + c * 64 + threadIdx.x];
-    v = v + __shfl_down(v, 1);                // s[i] = s[2i] + s[2i+1], level by level
-    v = v + __shfl_down(v, 2);
-    v = v + __shfl_down(v, 4);
-    v = v + __shfl_down(v, 8);
-    v = v + __shfl_down(v, 16);
-    v = v + __shfl_down(v, 32);
-    if (threadIdx.x == 0) chunk_sums[m.first_tile + c] = v;       // first_tile + c: distinct per (message, chunk), within the tile count
+    me_half_tree(acc, s_h);
+    __syncthreads();
+    // (32 leaves per tile, 64 per chunk: a tile's leaves are all full-chunk leaves or none is)
+    if (threadIdx.x == 0 && (int64_t)t.idx * kLeavesPerTile < n_full_leaves) half_sums[m.first_tile + t.idx] = (s_h[0] + s_h[1]) + (s_h[2] + s_h[3]);
 }
 // one wavefront per message: the left-to-right accumulation of the chunk sums, the irregular rest, the result
 __device__ __forceinline__ float me_leaf_sum(const float *a, int len, int mode, float mean) {      // pw(a, len) for len <= 128
@@ -412,15 +364,50 @@ __device__ __forceinline__ float me_leaf_sum(const float *a, int len, int mode, 
 // root (registers only), sums it, and the tree is combined level by level from the deepest one up -- the node values live in LDS at
 // the slot of the node's leftmost leaf, and the owner of that leaf adds the right child (left + right, as pw() does).
 constexpr int kMeRestSlots = kPwChunkM / 64, kMeRestDepth = 9;
-__global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, const float *kept, MsgState *st, const float *chunk_sums, int mode) {
+constexpr int kMeSumBlock = 1024;            // one message can be the whole capture: 32 768 tiles of min / max partials
+// mode 0 also settles min / max (util.minmax: seeded with element 0, `<` / `>` folds -- NaN never replaces a value) from the per-tile
+// partials of the pass that read the samples anyway: k_me_first for messages without filtered samples (tile t = window [4096 t, 4096 (t +
+// 1)) of the trimmed range), k_me_leaves (mode 0) for the others (tile t = the 32 full leaves it sums; the irregular rest behind the full
+// chunks is folded in here).  The wavefronts that have nothing to do while wavefront 0 walks the chain of chunk sums do it.  (Rounds 3-5:
+// a kernel of its own, k_me_minmax_fin.)
+__global__ __launch_bounds__(kMeSumBlock) void k_me_sum_fin(const float *x, const float *kept, MsgState *st, const float *half_sums, const float2 *tile_mm,
+                                                             int mode) {
     __shared__ float s_val[kMeRestSlots + 1];
+    __shared__ float s_mn[kMeSumBlock / 64], s_mx[kMeSumBlock / 64];
     __shared__ __attribute__((aligned(16))) float s_cs[8192];
     const int m = blockIdx.x, tid = threadIdx.x;
     const MsgState s = st[m];
     if (s.L <= 0) return;
     const int64_t n_chunks = s.L / kPwChunkM;
     const int rest = (int)(s.L % kPwChunkM);
-    const float *cs = chunk_sums + s.first_tile;
+    const float *hs = half_sums + s.first_tile;              // half 2 c and half 2 c + 1 of chunk c (me_half_tree)
+    const float *src = me_src(x, kept, s) + s.a;             // the trimmed samples
+    int mm_from = -1;                                        // min / max: done by threads [mm_from, kMeSumBlock)
+    auto minmax = [&](int from) {
+        const bool spec = me_clean(s);                       // partials by k_me_first (every tile of the trimmed range) or by k_me_leaves (full chunks)
+        const int64_t nt = spec ? (s.L + kMeTile - 1) / kMeTile : (s.L / kPwChunkM) * (kPwChunkM / kMeTile);
+        float mn = src[0], mx = mn;
+        const int step = kMeSumBlock - from;
+        for (int64_t u = tid - from; u < nt; u += step) {
+            const float2 p = tile_mm[s.first_tile + u];
+            if (p.x < mn) mn = p.x;
+            if (p.y > mx) mx = p.y;
+        }
+        if (!spec) {
+            for (int64_t i = (s.L / kPwChunkM) * kPwChunkM + (tid - from); i < s.L; i += step) {
+                const float v = src[i];
+                if (v < mn) mn = v;
+                if (v > mx) mx = v;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
+            if (a < mn) mn = a;
+            if (b > mx) mx = b;
+        }
+        if ((tid & 63) == 0) { s_mn[tid >> 6] = mn; s_mx[tid >> 6] = mx; }
+    };
     // total = ((0 + c0) + c1) + ...: strictly sequential float adds (16 384 of them when the capture is one message).  Wavefront 0
     // holds 64 chunk sums in its lanes and adds them through v_readlane (the next 64 are already loaded): a dependent add every few
     // cycles instead of an LDS round trip per term.  (Running the chain through the lanes instead -- acc[s] = acc[s - 1] + v[s] as one
@@ -436,9 +423,12 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
     for (int64_t c0 = 0; c0 < n_chunks; c0 += kPiece) {
         const int nc = (int)((n_chunks - c0 < kPiece) ? n_chunks - c0 : kPiece);
         __syncthreads();                                     // (the piece before has been consumed)
-        for (int c = tid * 4; c < nc; c += kMeRestSlots * 4) {
-            if (c + 3 < nc && (((uintptr_t)(cs + c0 + c)) & 15) == 0) *(float4 *)(s_cs + c) = *(const float4 *)(cs + c0 + c);
-            else { for (int e = 0; e < 4 && c + e < nc; ++e) s_cs[c + e] = cs[c0 + c + e]; }
+        for (int c = tid * 4; c < nc; c += kMeSumBlock * 4) {
+            const float *q = hs + 2 * (c0 + c);              // chunk = left half + right half: the root of its tree
+            if (c + 3 < nc && (((uintptr_t)q) & 15) == 0) {
+                const float4 u = *(const float4 *)q, w = *(const float4 *)(q + 4);
+                *(float4 *)(s_cs + c) = float4{u.x + u.y, u.z + u.w, w.x + w.y, w.z + w.w};
+            } else { for (int e = 0; e < 4 && c + e < nc; ++e) s_cs[c + e] = q[2 * e] + q[2 * e + 1]; }
         }
         __syncthreads();
         if (tid < 64) {
@@ -451,8 +441,10 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
                 for (int e = 0; e < 8; ++e) { total = total + q[e].x; total = total + q[e].y; total = total + q[e].z; total = total + q[e].w; }
             }
             for (; c < nc; ++c) total = total + s_cs[c];
-        }
+        } else if (mode == 0 && mm_from < 0) minmax(64);     // (beside the chain)
+        if (mode == 0 && mm_from < 0) mm_from = 64;
     }
+    if (mode == 0 && mm_from < 0) { minmax(0); mm_from = 0; }       // (no full chunk: nobody was waiting for a chain)
     // pw(a, n) = pw(a, n2) + pw(a + n2, n - n2), n2 = n / 2 rounded down to a multiple of 8, down to leaves of <= 128 elements
     const int e = tid * 64;                                  // this thread's element
     int off[kMeRestDepth], len[kMeRestDepth];
@@ -472,7 +464,7 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
         }
         owner = (e - o) < 64;                                // the first multiple of 64 inside the leaf [o, o + l)
         leaf_o = o;
-        if (owner) s_val[tid] = me_leaf_sum(me_src(x, kept, s) + s.a + n_chunks * kPwChunkM + o, l, mode, s.mean);
+        if (owner) s_val[tid] = me_leaf_sum(src + n_chunks * kPwChunkM + o, l, mode, s.mean);
         // (off / len at depths beyond the leaf repeat the leaf)
     }
     __syncthreads();
@@ -495,7 +487,12 @@ __global__ __launch_bounds__(kMeRestSlots) void k_me_sum_fin(const float *x, con
     if (tid == 0) {
         if (rest) total = total + s_val[0];
         const float res = total / (float)s.L;                   // float32 sum / float32 count
-        if (mode == 0) st[m].mean = res; else st[m].var = res;
+        if (mode == 0) {
+            st[m].mean = res;
+            float mn = src[0], mx = mn;
+            for (int w = mm_from / 64; w < kMeSumBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
+            st[m].mn = mn; st[m].mx = mx;
+        } else st[m].var = res;
     }
 }
 
@@ -529,6 +526,17 @@ __global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins, unsigned i
 __device__ __forceinline__ double me_edge(const MsgState &s, int64_t i) { return s.e0 + (double)i * s.delta; }
 
 constexpr int kMeHistLds = 4096;             // bins kept in LDS per workgroup (the pool's max_bins is at most this)
+// A message's row of the histogram pool holds max_bins counters and a demodulated message uses a handful: the workgroups of k_me_hist
+// add their counts to one of up to 64 REPLICAS of the histogram inside the row (replica r at r * stride, a multiple of 128 bytes), and
+// k_me_peaks folds them into replica 0 first.  (Device-wide atomic adds to ONE word are settled one after the other on the memory side:
+// the 12 288 adds of a capture that is one message -- 4096 workgroups, three bins -- held the histogram pass at 150-180 us whatever
+// the workgroups did before them; profiles/r06q_hist_ab.txt.)
+__host__ __device__ inline void me_replicas(int64_t nb, int64_t max_bins, int &R, int64_t &stride) {
+    stride = (nb + 31) & ~(int64_t)31;
+    const int64_t r = stride > 0 ? max_bins / stride : 1;
+    R = (int)(r > 64 ? 64 : r);
+    if (R < 1) { R = 1; stride = nb; }
+}
 __device__ __forceinline__ double me_edge32(const MsgState &s, int i) { return s.e0 + (double)i * s.delta; }
 // smallest float32 that is >= the float64 edge / largest float32 that is <= it: a float32 sample compares with the float64 edge exactly
 // as it compares with this float32 (np.histogram casts the samples to float64 and searches the float64 edges)
@@ -542,17 +550,31 @@ __device__ __forceinline__ float me_f32_at_or_below(double e) {
     if ((double)f > e) f = __uint_as_float(f > 0.f ? __float_as_uint(f) - 1u : (f == 0.f ? 0x80000001u : __float_as_uint(f) + 1u));
     return f;
 }
-constexpr int kMeHistGroup = 8;              // consecutive tiles per workgroup: one flush of the LDS counters per message and group
+#ifndef URH_HIST_GROUP
+#define URH_HIST_GROUP 8
+#endif
+constexpr int kMeHistGroup = URH_HIST_GROUP;              // consecutive tiles per workgroup: one flush of the LDS counters per message and group
 // Two instantiations share the tiles: BINS = kMeHistSmall serves the messages with at most that many bins (a demodulated message
 // has a few dozen) out of 4 KiB of LDS -- eight workgroups per CU instead of four: the pass is bound by instruction issue and by the
 // latency of each tile's loads, and twice the wavefronts hide twice as much of it -- BINS = kMeHistLds serves the others; a workgroup
 // skips the messages of the other class.
+#ifndef URH_HIST_WORDS
+#define URH_HIST_WORDS 2048    // LDS counter words of the small instantiation of k_me_hist (A/B: 1024, 4096)
+#endif
+#ifndef URH_HIST_LOGC_MAX
+#define URH_HIST_LOGC_MAX 8    // at most 2^this copies of a counter: 8 = one per thread of the workgroup (A/B: 6 = one per lane)
+#endif
 #ifndef URH_HIST_ROUNDS
 #define URH_HIST_ROUNDS 2      // ballot rounds per row of k_me_hist before what is left goes through LDS atomics (A/B: 0, 1)
 #endif
 constexpr int kMeHistSmall = kMeHistSmallBins;
+#ifdef URH_OCC_HIST
+#define URH_HIST_OCC __attribute__((amdgpu_waves_per_eu(URH_OCC_HIST)))
+#else
+#define URH_HIST_OCC
+#endif
 template <int BINS>
-__global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int64_t n_tiles,
+__global__ __launch_bounds__(kMeBlock) URH_HIST_OCC void k_me_hist(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int64_t n_tiles,
                                                        int64_t max_bins, unsigned int *counts, const unsigned int *any_wide) {
     if (BINS != kMeHistSmall && *any_wide == 0u) return;     // no message of this class in the batch (k_me_bins)
     // demodulated signals sit on two or four levels: nearly every sample of a message lands in a handful of bins.  Counting
@@ -565,8 +587,16 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
     // tiles and flushes its LDS counters when the message changes or at the end (a capture that is ONE message had 32 768
     // workgroups adding their counters to the same few words of device memory: 371 us).  (Requesting the next tile's samples before
     // the current tile is binned -- 16 more registers -- made the kernel slower, 213 -> 280 us: not the loads' latency.)
-    __shared__ unsigned int s_c[BINS];
+    // Round 6 (late): the small instantiation keeps 2^logC COPIES of every counter, copy (lane mod 2^logC) at word (bin << logC) + copy:
+    // with 64 copies (up to 32 bins -- a demodulated message has a handful) every lane of a wavefront owns its bank and the count is ONE
+    // ds_add_u32 per sample without a conflict, whatever the samples are; the ballot rounds below -- three VALU instructions and a
+    // scalar popcount per row and distinct bin, in dependent chains across the two pipes -- were most of the kernel's time.  (Plain LDS
+    // atomics on ONE copy serialise on the few populated addresses: +250 us, profiles/r04e_ab_hist_rounds.txt.)
+    constexpr bool kPriv = BINS == kMeHistSmall;
+    constexpr int kWords = kPriv ? URH_HIST_WORDS : BINS;      // counter words: bins << logC <= kWords
+    __shared__ unsigned int s_c[kWords + (kPriv ? 64 : 0)];    // (+ 64 words nobody reads: where the lanes without a sample add)
     __shared__ float s_e[BINS + 2];                         // s_e[k] = first float32 inside bin k or above; s_e[nb] = first float32 beyond the last bin
+    int logC = 0;
     const int64_t tile0 = (int64_t)blockIdx.x * kMeHistGroup, tile1 = (tile0 + kMeHistGroup < n_tiles) ? tile0 + kMeHistGroup : n_tiles;
     int cur_msg = -1, nb = 0;
     bool valid = false, big = false;
@@ -579,7 +609,29 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
     if (last || t.msg != cur_msg) {                            // (workgroup-uniform)
         if (valid) {                                           // flush the message's counters
             __syncthreads();
-            for (int k = threadIdx.x; k < nb; k += kMeBlock) if (s_c[k]) atomicAdd(&out[k], s_c[k]);
+            if (kPriv) {
+                // the copies of a bin are 2^logC consecutive words = consecutive lanes (256 is a multiple): fold them with shuffles
+                // (more than 64 copies -- a handful of bins: one copy per wavefront or per thread -- fold per wavefront first, and the
+                // wavefronts' partial sums meet in the first word of the bin)
+                const int C = 1 << logC, Cw = C < 64 ? C : 64;
+                for (int w0 = 0; w0 < (nb << logC); w0 += kMeBlock) {      // (nb << logC is a multiple of C; C > 64 only with kMeBlock | C * nb)
+                    const int w = w0 + (int)threadIdx.x;
+                    unsigned int v = (w < (nb << logC)) ? s_c[w] : 0u;
+                    for (int o = 1; o < Cw; o <<= 1) v += (unsigned int)__shfl_xor((int)v, o);
+                    if (C > 64) {
+                        const bool head = (w & (C - 1)) == 0 && w < (nb << logC);
+                        __syncthreads();                                 // (every thread has read its counter)
+                        if (head) s_c[w] = v;
+                        __syncthreads();
+                        if ((w & 63) == 0 && (w & (C - 1)) != 0 && w < (nb << logC) && v) atomicAdd(&s_c[w & ~(C - 1)], v);
+                        __syncthreads();
+                        v = head ? s_c[w] : 0u;
+                    }
+                    if ((w & (C - 1)) == 0 && v) atomicAdd(&out[w >> logC], v);
+                }
+            } else {
+                for (int k = threadIdx.x; k < nb; k += kMeBlock) if (s_c[k]) atomicAdd(&out[k], s_c[k]);
+            }
             __syncthreads();
         }
         if (last) break;
@@ -591,8 +643,14 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
         if (valid && ((BINS == kMeHistSmall) != (m.n_edges - 1 <= kMeHistSmall))) valid = false;  // the other instantiation's message
         nb = (valid || big) ? (int)(m.n_edges - 1) : 0;
         out = counts + (int64_t)t.msg * max_bins;
+        if (valid) {                                               // this workgroup's replica of the message's histogram
+            int R; int64_t stride;
+            me_replicas(nb, max_bins, R, stride);
+            out += (int64_t)(blockIdx.x % (unsigned)R) * stride;
+        }
         if (valid) {
-            for (int k = threadIdx.x; k < nb; k += kMeBlock) s_c[k] = 0u;
+            if (kPriv) { logC = 0; while (logC < URH_HIST_LOGC_MAX && (nb << (logC + 1)) <= kWords) ++logC; }
+            for (int k = threadIdx.x; k < (nb << logC); k += kMeBlock) s_c[k] = 0u;
             for (int k = threadIdx.x; k <= nb; k += kMeBlock) {
                 // the last bin is closed on the right: "beyond it" starts at the first float32 above the last edge
                 float e = me_f32_at_or_above(me_edge32(m, k));
@@ -642,6 +700,42 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
 #pragma unroll
             for (int e = 0; e < 4; ++e) val[4 * j + e] = (i + e < lim) ? r[i + e] : __builtin_nanf("");
         }
+    }
+    if (kPriv) {
+        // four samples at a time: guess, check (the table reads of the four are in flight together), count; a lane whose check fails (a
+        // rounding error next to an edge, a NaN, padding) searches the table on its own -- nothing here needs the wavefront to agree
+        const int sh = logC + 2;                                               // counter addresses in bytes: (bin << sh) + mine
+        const unsigned int mine = (unsigned int)((int)threadIdx.x & ((1 << logC) - 1)) * 4u, dump = (unsigned int)((nb << logC) + lane) * 4u;
+#pragma unroll
+        for (int j0 = 0; j0 < kMePer; j0 += 4) {
+            int k[4];
+            float lo[4], hi[4];
+            unsigned int at[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) k[e] = min(max((int)((val[j0 + e] - e0f) * invf), 0), nb - 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = s_e[k[e]]; hi[e] = s_e[k[e] + 1]; at[e] = ((unsigned int)k[e] << sh) + mine; }
+            bool ok[4], all = true;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { ok[e] = (val[j0 + e] >= lo[e]) & (val[j0 + e] < hi[e]); all = all & ok[e]; }
+            if (!all) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = val[j0 + e];
+                    if (!ok[e]) {
+                        int q = k[e];
+                        if ((v >= lo_all) & (v < hi_all)) {
+                            while (q > 0 && s_e[q] > v) --q;
+                            while (q < nb - 1 && s_e[q + 1] <= v) ++q;
+                            at[e] = ((unsigned int)q << sh) + mine;
+                        } else at[e] = dump;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd((unsigned int *)((char *)s_c + at[e]), 1u);
+        }
+        continue;
     }
     int bin[kMePer];
     {
@@ -706,7 +800,7 @@ __global__ __launch_bounds__(kMeBlock) void k_me_hist(const float *x, const floa
 // the center is the mean of their left edges.  Two strict maxima are at least `window` bins apart: at most 21 candidates.  The
 // reference walks the bins in np.argsort order, which leaves the order of equally populated bins to the sort implementation: that
 // matters only when the second and third candidate tie -- reported as flag 3, decided by the caller with numpy itself.
-__global__ __launch_bounds__(kMeBlock) void k_me_peaks(MsgState *st, const unsigned int *counts, int64_t max_bins) {
+__global__ __launch_bounds__(kMeBlock) void k_me_peaks(MsgState *st, unsigned int *counts, int64_t max_bins) {
     __shared__ int s_n;
     __shared__ int s_idx[64];
     __shared__ unsigned int s_cnt[64];
@@ -715,7 +809,30 @@ __global__ __launch_bounds__(kMeBlock) void k_me_peaks(MsgState *st, const unsig
     if (s.n_edges < 2) { if (threadIdx.x == 0) { st[m].peak_flag = 0; st[m].peak_center = 0.0; } return; }
     if (s.n_edges - 1 > max_bins) { if (threadIdx.x == 0) { st[m].peak_flag = 2; st[m].peak_center = 0.0; } return; }
     const int nb = (int)(s.n_edges - 1);
-    const unsigned int *y = counts + (int64_t)m * max_bins;
+    unsigned int *y = counts + (int64_t)m * max_bins;
+    if (nb <= kMeHistLds) {                                      // fold the replicas (k_me_hist; the plain path beyond kMeHistLds bins has one)
+        int R; int64_t stride;
+        me_replicas(nb, max_bins, R, stride);
+        if (R > 1 && nb <= kMeBlock) {                            // a handful of bins, 64 replicas: every (replica, bin) is one thread's load
+            __shared__ unsigned int s_fold[kMeBlock];
+            s_fold[threadIdx.x] = 0u;
+            __syncthreads();
+            for (int q = threadIdx.x; q < R * nb; q += kMeBlock) {
+                const unsigned int v = y[(int64_t)(q / nb) * stride + (q % nb)];
+                if (v) atomicAdd(&s_fold[q % nb], v);
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < nb) y[threadIdx.x] = s_fold[threadIdx.x];
+            __syncthreads();
+        } else if (R > 1) {                                       // (more than 256 bins: at most 16 replicas)
+            for (int i = threadIdx.x; i < nb; i += kMeBlock) {
+                unsigned int v = y[i];
+                for (int r = 1; r < R; ++r) v += y[(int64_t)r * stride + i];
+                y[i] = v;
+            }
+            __syncthreads();
+        }
+    }
     int w = (int)(0.05 * (double)nb) + 1;
     if (w < 2) w = 2;
     if (threadIdx.x == 0) s_n = 0;
@@ -1002,31 +1119,27 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     ctx->arena.reset();
     MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
     MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
-    int32_t *d_cnt = (int32_t *)ctx->arena.take((size_t)b.n_tiles * 4);
     int64_t *d_pre = (int64_t *)ctx->arena.take((size_t)(b.n_tiles + 1) * 8);
     float2 *d_mm = (float2 *)ctx->arena.take((size_t)b.n_tiles * 8);
-    float *d_leaf = (float *)ctx->arena.take((size_t)b.n_tiles * kLeavesPerTile * 4);
-    float *d_chunk = (float *)ctx->arena.take((size_t)(b.n_tiles + 1) * 4);
+    float *d_half = (float *)ctx->arena.take((size_t)(b.n_tiles + 1) * 4);
     float *d_kept = (float *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
-    unsigned int *d_hist = (unsigned int *)ctx->arena.take((size_t)n_msgs * (size_t)max_bins * 4 + 256);     // (+ the any_wide flag, cleared with the pool)
+    // the histogram pool, the any_wide flag behind it and the per-tile counts: what ONE fill clears before the passes
+    const size_t pool_bytes = ((size_t)n_msgs * (size_t)max_bins * 4 + 256 + 255) & ~size_t(255);
+    unsigned int *d_hist = (unsigned int *)ctx->arena.take(pool_bytes + (size_t)b.n_tiles * 4);
     unsigned int *d_any_wide = d_hist ? d_hist + (size_t)n_msgs * (size_t)max_bins : nullptr;
-    if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_mm || !d_leaf || !d_chunk || !d_kept || !d_hist) return URHGPU_ERR_ARG;
+    int32_t *d_cnt = d_hist ? (int32_t *)((char *)d_hist + pool_bytes) : nullptr;
+    if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_mm || !d_half || !d_kept || !d_hist) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
     URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
-    URH_HIP(hipMemsetAsync(d_hist, 0, (size_t)n_msgs * (size_t)max_bins * 4 + 256, s));
+    URH_HIP(hipMemsetAsync(d_hist, 0, pool_bytes + (size_t)b.n_tiles * 4, s));
     const unsigned gt = (unsigned)b.n_tiles, gm = (unsigned)((n_msgs + 63) / 64);
-    URH_HIP(hipMemsetAsync(d_cnt, 0, (size_t)b.n_tiles * 4, s));
-    hipLaunchKernelGGL(k_me_first, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_mm, d_leaf);
-    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
-    hipLaunchKernelGGL(k_me_spec, dim3(gm), dim3(64), 0, s, d_st, n_msgs, d_pre);
+    hipLaunchKernelGGL(k_me_first, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_mm, d_half);
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, d_st, n_msgs);
     hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_kept);
-    hipLaunchKernelGGL(k_me_trim, dim3(gm), dim3(64), 0, s, d_st, n_msgs);
     for (int mode = 0; mode < 2; ++mode) {
-        hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, mode, d_leaf, d_mm);
-        if (mode == 0) hipLaunchKernelGGL(k_me_minmax_fin, dim3((unsigned)n_msgs), dim3(kMeFinBlock), 0, s, d_st, d_mm, d_x, d_kept);
-        hipLaunchKernelGGL(k_me_chunk_trees, dim3(gt), dim3(64), 0, s, d_st, d_tiles, d_leaf, d_chunk);
-        hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeRestSlots), 0, s, d_x, d_kept, d_st, d_chunk, mode);
+        hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, mode, d_half, d_mm);
+        hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeSumBlock), 0, s, d_x, d_kept, d_st, d_half, d_mm, mode);
     }
     hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins, d_any_wide);
     hipLaunchKernelGGL((k_me_hist<kMeHistSmall>), dim3((unsigned)((b.n_tiles + kMeHistGroup - 1) / kMeHistGroup)), dim3(kMeBlock), 0, s, d_x, d_kept, d_st,
@@ -1126,7 +1239,7 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
     hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
     const unsigned gt = (unsigned)b.n_tiles;
     hipLaunchKernelGGL(k_me_edge_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
-    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, (MsgState *)nullptr, 0);
     hipLaunchKernelGGL(k_me_edge_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_edges);
     hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
     URH_HIP(hipGetLastError());
@@ -1477,7 +1590,7 @@ static int plateau_decisions_impl(urhgpu_ctx *ctx, const float *d_x, int64_t n, 
     URH_HIP(hipMemsetAsync(d_pool_count, 0, 8, s));
     const unsigned gt = (unsigned)b.n_tiles;
     hipLaunchKernelGGL(k_me_edge_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
-    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre);
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, (MsgState *)nullptr, 0);
     hipLaunchKernelGGL(k_me_edge_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_edges);
     hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
     hipLaunchKernelGGL(k_me_len_counts, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_edges, d_pool_count, d_pool, cap_pairs);
