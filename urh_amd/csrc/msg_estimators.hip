@@ -205,7 +205,9 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
 constexpr int kMeScanBlock = 1024;
 // st != nullptr (the center statistics): the kept count and the trimmed range [a, a + L) of every message are this kernel's last step --
 // they need nothing but the prefix (rounds 3-5: two launches of their own, k_me_spec and k_me_trim)
-__global__ __launch_bounds__(kMeScanBlock) void k_me_tile_scan(const int32_t *cnt, int64_t n_tiles, int64_t *pre, MsgState *st, int n_msgs) {
+// *any_dirty (cleared by the caller): some message has filtered samples -- the compaction and its trees have work to do
+__global__ __launch_bounds__(kMeScanBlock) void k_me_tile_scan(const int32_t *cnt, int64_t n_tiles, int64_t *pre, MsgState *st, int n_msgs,
+                                                                unsigned int *any_dirty) {
     // every wavefront owns a contiguous stretch of the table and reads it 64 entries at a time (coalesced): first its sum, then --
     // after ONE exchange of the 16 sums -- a running wavefront scan over the stretch.  (The first version walked the whole table
     // 1024 entries at a time: 32 rounds of three barriers each for a 1 GiB capture, 31 us.)
@@ -248,35 +250,149 @@ __global__ __launch_bounds__(kMeScanBlock) void k_me_tile_scan(const int32_t *cn
         const int64_t a = (int64_t)(0.05 * (double)k), b = (int64_t)(0.95 * (double)k);     // int(0.05 * len), int(0.95 * len) (:231)
         st[m].a = a;
         st[m].L = b > a ? b - a : 0;
+        if (k != len - st[m].skip) *any_dirty = 1u;
     }
 }
 
-__global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, MsgState *st, const MsgTile *tiles, const int64_t *tile_pre,
-                                                          float *kept) {
+// Round 6 (late): the compaction also delivers what the first leaf pass (np.mean) and the min / max pass read the compacted samples
+// for.  A tile's kept samples are consecutive ranks [before, before + cnt) of the message; the trimmed range starts at rank a, leaf l covers
+// the ranks a + 128 l .. a + 128 l + 127.  The leaves that lie WHOLLY inside the tile's ranks are summed from LDS, where the tile stages its
+// kept samples by rank (a leaf per row of 136 floats: the 8 leaves a wavefront sums at a time hit 64 different banks) -- in k_me_leaves'
+// order, 8 threads per leaf.  The one leaf that starts in the tile and ends in a later one is marked kLeafPending and summed from the
+// compacted samples by k_me_dirty_trees, which turns the leaf sums into the half-chunk sums k_me_sum_fin reads.  (A kept sample is never
+// a NaN -- the filter is x > -4 -- so no sum of samples carries that NaN's payload.)  Min / max partials: per natural tile, seeded with
+// +-inf (k_me_sum_fin seeds the fold with the first trimmed sample, as util.minmax does).
+constexpr int kMeStagePitch = kPwLeafM + 8;
+constexpr unsigned int kLeafPending = 0x7fc0deadu;
+constexpr int kMeCompactGroup = 4;             // consecutive tiles per workgroup (a batch without filtered samples: a quarter of the workgroups to retire)
+__global__ __launch_bounds__(kMeBlock) void k_me_compact(const float *x, const MsgState *st, const MsgTile *tiles, int64_t n_tiles_all, const int64_t *tile_pre,
+                                                          float *kept, float *leaf_sums, float2 *tile_mm, const unsigned int *any_dirty) {
     __shared__ int s_cell[kMePer * (kMeBlock / 64)];
     __shared__ int s_total;
-    const MsgTile t = tiles[blockIdx.x];
-    const int64_t start = st[t.msg].start, end = st[t.msg].end, first_tile = st[t.msg].first_tile;
-    const int64_t len = end - start, n_tiles = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
-    const int64_t kept_total = tile_pre[first_tile + n_tiles] - tile_pre[first_tile];
-    if (kept_total == len - st[t.msg].skip) return;          // nothing filtered (but the first sample): the later stages read the capture (me_src)
-    const int64_t before = tile_pre[blockIdx.x] - tile_pre[first_tile];         // kept samples in the message's earlier tiles
-    const int64_t base = start + (int64_t)t.idx * kMeTile;
+    __shared__ float s_v[kLeavesPerTile * kMeStagePitch];
+    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64];
+    if (*any_dirty == 0u) return;
     const int wave = threadIdx.x >> 6;
-    float v[kMePer];
-    unsigned long long bal[kMePer];
+    for (int64_t tix = (int64_t)blockIdx.x * kMeCompactGroup; tix < n_tiles_all && tix < ((int64_t)blockIdx.x + 1) * kMeCompactGroup; ++tix) {
+        const MsgTile t = tiles[tix];
+        const MsgState m = st[t.msg];
+        if (me_clean(m)) continue;                           // nothing filtered (but the first sample): the later stages read the capture (me_src)
+        const int64_t before = tile_pre[tix] - tile_pre[m.first_tile];             // kept samples in the message's earlier tiles
+        const int cnt = (int)(tile_pre[tix + 1] - tile_pre[tix]);
+        const int64_t base = m.start + (int64_t)t.idx * kMeTile;
+        float v[kMePer];
+        unsigned long long bal[kMePer];
 #pragma unroll
-    for (int j = 0; j < kMePer; ++j) { const int64_t i = base + j * kMeBlock + threadIdx.x; v[j] = (i < end) ? x[i] : -5.0f; }
+        for (int j = 0; j < kMePer; ++j) { const int64_t i = base + j * kMeBlock + threadIdx.x; v[j] = (i < m.end) ? x[i] : -5.0f; }
 #pragma unroll
-    for (int j = 0; j < kMePer; ++j) {
-        bal[j] = __ballot(v[j] > -4.0f);
-        if ((threadIdx.x & 63) == 0) s_cell[j * (kMeBlock / 64) + wave] = __popcll(bal[j]);
+        for (int j = 0; j < kMePer; ++j) {
+            bal[j] = __ballot(v[j] > -4.0f);
+            if ((threadIdx.x & 63) == 0) s_cell[j * (kMeBlock / 64) + wave] = __popcll(bal[j]);
+        }
+        me_cell_scan(s_cell, &s_total);
+        // trimmed-relative position of the kept sample of rank r (inside the tile): p = off + r
+        const int64_t off = before - m.a, p_hi = off + cnt;
+        const int64_t n_full_leaves = (m.L / kPwChunkM) * (kPwChunkM / kPwLeafM);
+        const int64_t l0 = off <= 0 ? 0 : (off + kPwLeafM - 1) / kPwLeafM;                          // first leaf that starts at or behind the tile's first kept sample
+        int64_t l1 = p_hi <= 0 ? 0 : p_hi / kPwLeafM;                                                // leaves that end inside the tile
+        const bool pending = l1 < n_full_leaves && l1 * kPwLeafM >= off && l1 * kPwLeafM < p_hi;     // leaf l1 starts here and ends later
+        if (l1 > n_full_leaves) l1 = n_full_leaves;
+        const int n_stage = l1 > l0 ? (int)(l1 - l0) : 0;                                            // whole leaves: at most 32
+        const int64_t sh64 = l0 * kPwLeafM - off;                                                    // rank of leaf l0's first sample
+        const int sh = (int)(sh64 > kMeTile ? kMeTile : sh64);
+        const int r_lo = (int)(off >= 0 ? 0 : (-off > kMeTile ? kMeTile : -off));                    // ranks inside the trimmed range: [r_lo, r_hi)
+        const int64_t r_hi64 = m.L - off;
+        const int r_hi = (int)(r_hi64 < 0 ? 0 : (r_hi64 > kMeTile ? kMeTile : r_hi64));
+        const unsigned long long below = me_lanes_below();
+        float mn = __builtin_inff(), mx = -__builtin_inff();
+        float *dst = kept + m.start + before;
+#pragma unroll
+        for (int j = 0; j < kMePer; ++j) {
+            if (v[j] > -4.0f) {
+                const int r = s_cell[j * (kMeBlock / 64) + wave] + __popcll(bal[j] & below);
+                dst[r] = v[j];
+                if (r >= r_lo && r < r_hi) { if (v[j] < mn) mn = v[j]; if (v[j] > mx) mx = v[j]; }
+                const int q = r - sh;
+                if (q >= 0 && q < n_stage * kPwLeafM) s_v[(q >> 7) * kMeStagePitch + (q & (kPwLeafM - 1))] = v[j];
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float u = __shfl_xor(mn, o), w = __shfl_xor(mx, o);
+            if (u < mn) mn = u;
+            if (w > mx) mx = w;
+        }
+        if ((threadIdx.x & 63) == 0) { s_mn[wave] = mn; s_mx[wave] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kMeBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
+            tile_mm[tix] = float2{mn, mx};
+            if (pending) ((unsigned int *)leaf_sums)[m.first_tile * kLeavesPerTile + l1] = kLeafPending;
+        }
+        // the whole leaves: accumulator j of leaf lf, then ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) (k_me_leaves)
+        const int lf = threadIdx.x >> 3, jj = threadIdx.x & 7;
+        const float *row = s_v + lf * kMeStagePitch + jj;
+        float acc = 0.f;
+        if (lf < n_stage) {
+            acc = row[0];
+#pragma unroll
+            for (int i = 8; i < kPwLeafM; i += 8) acc += row[i];
+        }
+        acc = acc + __shfl_down(acc, 1);
+        acc = acc + __shfl_down(acc, 2);
+        acc = acc + __shfl_down(acc, 4);
+        if (lf < n_stage && jj == 0) leaf_sums[m.first_tile * kLeavesPerTile + l0 + lf] = acc;
+        __syncthreads();                                     // (s_v, s_cell, s_mn are the next tile's)
     }
-    me_cell_scan(s_cell, &s_total);
-    const unsigned long long below = me_lanes_below();
+}
+// the leaf sums of a message with filtered samples -> half-chunk sums (me_half_tree's): one wavefront per chunk, lane = leaf; the
+// leaves k_me_compact has left pending (two or three per chunk) first, 8 lanes per leaf
+__global__ __launch_bounds__(kMeBlock) void k_me_dirty_trees(const float *kept, const MsgState *st, const MsgTile *tiles, int64_t n_tiles_all,
+                                                              const float *leaf_sums, float *half_sums, const unsigned int *any_dirty) {
+    if (*any_dirty == 0u) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t tix = (int64_t)blockIdx.x * (kMeBlock / 64) + (threadIdx.x >> 6);                 // a wavefront per tile: the chunk's even one works
+    if (tix >= n_tiles_all) return;
+    const MsgTile t = tiles[tix];
+    if (t.idx & 1) return;
+    const MsgState m = st[t.msg];
+    if (me_clean(m)) return;
+    const int64_t c = t.idx >> 1;
+    if (c >= m.L / kPwChunkM) return;
+    float v = leaf_sums[m.first_tile * kLeavesPerTile + c * 64 + lane];
+    unsigned long long pm = __ballot(__float_as_uint(v) == kLeafPending);
+    const float *r = kept + m.start + m.a + c * kPwChunkM;   // the chunk's trimmed samples
+    while (pm) {                                             // up to 8 pending leaves per round: group g of 8 lanes takes the g-th
+        int leaf_of[8];
+        unsigned long long tmp = pm;
 #pragma unroll
-    for (int j = 0; j < kMePer; ++j)
-        if (v[j] > -4.0f) kept[start + before + s_cell[j * (kMeBlock / 64) + wave] + __popcll(bal[j] & below)] = v[j];
+        for (int g = 0; g < 8; ++g) { leaf_of[g] = tmp ? __builtin_ctzll(tmp) : -1; if (tmp) tmp &= tmp - 1ull; }
+        int mine = -1;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) if ((lane >> 3) == g) mine = leaf_of[g];
+        float acc = 0.f;
+        if (mine >= 0) {
+            const float *q = r + mine * kPwLeafM + (lane & 7);
+            acc = q[0];
+#pragma unroll
+            for (int i = 8; i < kPwLeafM; i += 8) acc += q[i];
+        }
+        acc = acc + __shfl_down(acc, 1);
+        acc = acc + __shfl_down(acc, 2);
+        acc = acc + __shfl_down(acc, 4);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float sv = __shfl(acc, g * 8);
+            if (leaf_of[g] == lane) v = sv;
+        }
+        pm = tmp;
+    }
+    v = v + __shfl_down(v, 1);                // s[i] = s[2i] + s[2i+1], level by level: lanes 0 and 32 end with the two halves
+    v = v + __shfl_down(v, 2);
+    v = v + __shfl_down(v, 4);
+    v = v + __shfl_down(v, 8);
+    v = v + __shfl_down(v, 16);
+    if ((lane & 31) == 0) half_sums[m.first_tile + t.idx + (lane >> 5)] = v;
 }
 
 // ---- stage 4: numpy's float32 pairwise sums (np.mean, np.var) ---------------------------------------------------------------
@@ -289,55 +405,28 @@ __device__ __forceinline__ float me_elem(const float *r, int64_t i, int mode, fl
     const float d = v - mean;
     return d * d;
 }
-// leaf sums of the FULL chunks: 8 threads per leaf (one per accumulator), 32 leaves per tile
-__global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int mode,
-                                                         float *half_sums, float2 *tile_mm) {
-    __shared__ float s_mn[kMeBlock / 64], s_mx[kMeBlock / 64], s_h[kMeBlock / 64];
+// leaf sums of the FULL chunks of the squared deviations (np.var's second sum; the first one -- np.mean -- comes out of k_me_first or
+// k_me_compact): 8 threads per leaf (one per accumulator), 32 leaves per tile, the tile's half-chunk tree on top
+__global__ __launch_bounds__(kMeBlock) void k_me_leaves(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, float *half_sums) {
+    __shared__ float s_h[kMeBlock / 64];
     const MsgTile t = tiles[blockIdx.x];
     const MsgState m = st[t.msg];
-    if (mode == 0 && me_clean(m)) return;                    // nothing filtered: k_me_first has written these leaf sums
     const int64_t n_full_leaves = (m.L / kPwChunkM) * (kPwChunkM / kPwLeafM);
+    // (32 leaves per tile, 64 per chunk: a tile's leaves are all full-chunk leaves or none is)
+    if ((int64_t)t.idx * kLeavesPerTile >= n_full_leaves) return;
     const int64_t leaf = (int64_t)t.idx * kLeavesPerTile + (threadIdx.x >> 3);
     const int j = threadIdx.x & 7;
-    float acc = 0.f;
-    const bool live = leaf < n_full_leaves;
-    if (mode == 0 && (int64_t)t.idx * kLeavesPerTile < n_full_leaves) {
-        // the tile's min / max from the elements this pass reads anyway (workgroup-uniform branch: a tile of full leaves)
-        const float *r0 = me_src(x, kept, m) + m.a;
-        const float first = r0[0];
-        float mn = first, mx = first;
-        if (live) {
-            const float *r = r0 + leaf * kPwLeafM;
+    const float *r = me_src(x, kept, m) + m.a + leaf * kPwLeafM;
+    float acc = me_elem(r, j, 1, m.mean);
 #pragma unroll
-            for (int i = 0; i < kPwLeafM; i += 8) { const float v = r[i + j]; if (v < mn) mn = v; if (v > mx) mx = v; }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float u = __shfl_xor(mn, o), w = __shfl_xor(mx, o);
-            if (u < mn) mn = u;
-            if (w > mx) mx = w;
-        }
-        if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < kMeBlock / 64; ++w) { if (s_mn[w] < mn) mn = s_mn[w]; if (s_mx[w] > mx) mx = s_mx[w]; }
-            tile_mm[blockIdx.x] = float2{mn, mx};
-        }
-    }
-    if (live) {
-        const float *r = me_src(x, kept, m) + m.a + leaf * kPwLeafM;
-        acc = me_elem(r, j, mode, m.mean);
-#pragma unroll
-        for (int i = 8; i < kPwLeafM; i += 8) acc += me_elem(r, i + j, mode, m.mean);
-    }
+    for (int i = 8; i < kPwLeafM; i += 8) acc += me_elem(r, i + j, 1, m.mean);
     // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)) across the 8 lanes of the leaf
     acc = acc + __shfl_down(acc, 1);
     acc = acc + __shfl_down(acc, 2);
     acc = acc + __shfl_down(acc, 4);
     me_half_tree(acc, s_h);
     __syncthreads();
-    // (32 leaves per tile, 64 per chunk: a tile's leaves are all full-chunk leaves or none is)
-    if (threadIdx.x == 0 && (int64_t)t.idx * kLeavesPerTile < n_full_leaves) half_sums[m.first_tile + t.idx] = (s_h[0] + s_h[1]) + (s_h[2] + s_h[3]);
+    if (threadIdx.x == 0) half_sums[m.first_tile + t.idx] = (s_h[0] + s_h[1]) + (s_h[2] + s_h[3]);
 }
 // one wavefront per message: the left-to-right accumulation of the chunk sums, the irregular rest, the result
 __device__ __forceinline__ float me_leaf_sum(const float *a, int len, int mode, float mean) {      // pw(a, len) for len <= 128
@@ -367,8 +456,7 @@ constexpr int kMeRestSlots = kPwChunkM / 64, kMeRestDepth = 9;
 constexpr int kMeSumBlock = 1024;            // one message can be the whole capture: 32 768 tiles of min / max partials
 // mode 0 also settles min / max (util.minmax: seeded with element 0, `<` / `>` folds -- NaN never replaces a value) from the per-tile
 // partials of the pass that read the samples anyway: k_me_first for messages without filtered samples (tile t = window [4096 t, 4096 (t +
-// 1)) of the trimmed range), k_me_leaves (mode 0) for the others (tile t = the 32 full leaves it sums; the irregular rest behind the full
-// chunks is folded in here).  The wavefronts that have nothing to do while wavefront 0 walks the chain of chunk sums do it.  (Rounds 3-5:
+// 1)) of the trimmed range), k_me_compact for the others (its natural tiles).  The wavefronts that have nothing to do while wavefront 0 walks the chain of chunk sums do it.  (Rounds 3-5:
 // a kernel of its own, k_me_minmax_fin.)
 __global__ __launch_bounds__(kMeSumBlock) void k_me_sum_fin(const float *x, const float *kept, MsgState *st, const float *half_sums, const float2 *tile_mm,
                                                              int mode) {
@@ -384,21 +472,15 @@ __global__ __launch_bounds__(kMeSumBlock) void k_me_sum_fin(const float *x, cons
     const float *src = me_src(x, kept, s) + s.a;             // the trimmed samples
     int mm_from = -1;                                        // min / max: done by threads [mm_from, kMeSumBlock)
     auto minmax = [&](int from) {
-        const bool spec = me_clean(s);                       // partials by k_me_first (every tile of the trimmed range) or by k_me_leaves (full chunks)
-        const int64_t nt = spec ? (s.L + kMeTile - 1) / kMeTile : (s.L / kPwChunkM) * (kPwChunkM / kMeTile);
+        // partials by k_me_first (a tile per 4096 samples of the trimmed range) or by k_me_compact (every natural tile of the message)
+        const int64_t len = s.end - s.start;
+        const int64_t nt = me_clean(s) ? (s.L + kMeTile - 1) / kMeTile : ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
         float mn = src[0], mx = mn;
         const int step = kMeSumBlock - from;
         for (int64_t u = tid - from; u < nt; u += step) {
             const float2 p = tile_mm[s.first_tile + u];
             if (p.x < mn) mn = p.x;
             if (p.y > mx) mx = p.y;
-        }
-        if (!spec) {
-            for (int64_t i = (s.L / kPwChunkM) * kPwChunkM + (tid - from); i < s.L; i += step) {
-                const float v = src[i];
-                if (v < mn) mn = v;
-                if (v > mx) mx = v;
-            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -1122,25 +1204,30 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     int64_t *d_pre = (int64_t *)ctx->arena.take((size_t)(b.n_tiles + 1) * 8);
     float2 *d_mm = (float2 *)ctx->arena.take((size_t)b.n_tiles * 8);
     float *d_half = (float *)ctx->arena.take((size_t)(b.n_tiles + 1) * 4);
+    float *d_leaf = (float *)ctx->arena.take((size_t)b.n_tiles * kLeavesPerTile * 4);
     float *d_kept = (float *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
     // the histogram pool, the any_wide flag behind it and the per-tile counts: what ONE fill clears before the passes
     const size_t pool_bytes = ((size_t)n_msgs * (size_t)max_bins * 4 + 256 + 255) & ~size_t(255);
     unsigned int *d_hist = (unsigned int *)ctx->arena.take(pool_bytes + (size_t)b.n_tiles * 4);
     unsigned int *d_any_wide = d_hist ? d_hist + (size_t)n_msgs * (size_t)max_bins : nullptr;
+    unsigned int *d_any_dirty = d_any_wide ? d_any_wide + 1 : nullptr;
     int32_t *d_cnt = d_hist ? (int32_t *)((char *)d_hist + pool_bytes) : nullptr;
-    if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_mm || !d_half || !d_kept || !d_hist) return URHGPU_ERR_ARG;
+    if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_mm || !d_half || !d_leaf || !d_kept || !d_hist) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
     URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
     URH_HIP(hipMemsetAsync(d_hist, 0, pool_bytes + (size_t)b.n_tiles * 4, s));
     const unsigned gt = (unsigned)b.n_tiles, gm = (unsigned)((n_msgs + 63) / 64);
     hipLaunchKernelGGL(k_me_first, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt, d_mm, d_half);
-    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, d_st, n_msgs);
-    hipLaunchKernelGGL(k_me_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_kept);
-    for (int mode = 0; mode < 2; ++mode) {
-        hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, mode, d_half, d_mm);
-        hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeSumBlock), 0, s, d_x, d_kept, d_st, d_half, d_mm, mode);
-    }
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, d_st, n_msgs, d_any_dirty);
+    // messages with filtered samples (the two kernels retire at once when there is none): compaction with the first leaf sums and min / max
+    hipLaunchKernelGGL(k_me_compact, dim3((unsigned)((b.n_tiles + kMeCompactGroup - 1) / kMeCompactGroup)), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, b.n_tiles,
+                       d_pre, d_kept, d_leaf, d_mm, d_any_dirty);
+    hipLaunchKernelGGL(k_me_dirty_trees, dim3((unsigned)((b.n_tiles + kMeBlock / 64 - 1) / (kMeBlock / 64))), dim3(kMeBlock), 0, s, d_kept, d_st, d_tiles,
+                       b.n_tiles, d_leaf, d_half, d_any_dirty);
+    hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeSumBlock), 0, s, d_x, d_kept, d_st, d_half, d_mm, 0);
+    hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, d_half);
+    hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeSumBlock), 0, s, d_x, d_kept, d_st, d_half, d_mm, 1);
     hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins, d_any_wide);
     hipLaunchKernelGGL((k_me_hist<kMeHistSmall>), dim3((unsigned)((b.n_tiles + kMeHistGroup - 1) / kMeHistGroup)), dim3(kMeBlock), 0, s, d_x, d_kept, d_st,
                        d_tiles, b.n_tiles, max_bins, d_hist, d_any_wide);
@@ -1239,7 +1326,7 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
     hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
     const unsigned gt = (unsigned)b.n_tiles;
     hipLaunchKernelGGL(k_me_edge_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
-    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, (MsgState *)nullptr, 0);
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, (MsgState *)nullptr, 0, (unsigned int *)nullptr);
     hipLaunchKernelGGL(k_me_edge_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_edges);
     hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
     URH_HIP(hipGetLastError());
@@ -1590,7 +1677,7 @@ static int plateau_decisions_impl(urhgpu_ctx *ctx, const float *d_x, int64_t n, 
     URH_HIP(hipMemsetAsync(d_pool_count, 0, 8, s));
     const unsigned gt = (unsigned)b.n_tiles;
     hipLaunchKernelGGL(k_me_edge_count, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_cnt);
-    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, (MsgState *)nullptr, 0);
+    hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, (MsgState *)nullptr, 0, (unsigned int *)nullptr);
     hipLaunchKernelGGL(k_me_edge_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_edges);
     hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
     hipLaunchKernelGGL(k_me_len_counts, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_edges, d_pool_count, d_pool, cap_pairs);
