@@ -1485,10 +1485,13 @@ static int message_ranges_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int
     URH_TRY(ctx->staging.reserve(need));
     ctx->staging.reset();
     int64_t *d_rows = (int64_t *)ctx->staging.take((size_t)cap_rows * 16);
-    int64_t *d_seg = (int64_t *)ctx->staging.take((size_t)cap_seg * 16);
+    // (the control block directly in front of the segment table: the block and the first segments leave in ONE copy)
+    const size_t ctl_pad = (seg_ctl_bytes() + 255) & ~size_t(255);
+    char *d_ctl_seg = (char *)ctx->staging.take(ctl_pad + (size_t)cap_seg * 16);
+    SegCtl *d_ctl = (SegCtl *)d_ctl_seg;
+    int64_t *d_seg = d_ctl_seg ? (int64_t *)(d_ctl_seg + ctl_pad) : nullptr;
     int64_t *d_msgs = (int64_t *)ctx->staging.take((size_t)cap_seg * 16);
     void *scratch = ctx->staging.take(seg_scratch_bytes(cap_rows, cap_seg));
-    SegCtl *d_ctl = (SegCtl *)ctx->staging.take(seg_ctl_bytes());
     int64_t *d_n_rows = (int64_t *)ctx->staging.take(64);
     if (!d_rows || !d_seg || !d_msgs || !scratch || !d_ctl || !d_n_rows) return URHGPU_ERR_ARG;
     URH_TRY(segment_runs_impl(ctx, d_iq, dtype, n, noise_threshold, d_rows, cap_rows, d_n_rows, d_qad_ask));
@@ -1500,16 +1503,18 @@ static int message_ranges_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int
     // (the counts are not known yet: a prefix of each table is copied speculatively, the rest -- rarely -- afterwards)
     std::vector<char> ctl(seg_ctl_bytes());
     const int64_t spec_seg = std::min<int64_t>(std::min<int64_t>(cap_seg_out, cap_seg), 4096);
-    const int64_t spec_mrg = merge ? std::min<int64_t>(std::min<int64_t>(cap_merged_out, cap_seg), 1024) : 0;
+    const int64_t spec_mrg = merge ? std::min<int64_t>(std::min<int64_t>(cap_merged_out, cap_seg), 4096) : 0;     // (config 3's capture has 1500 messages: beyond the prefix costs a second round trip)
     std::vector<int64_t> spec_m((size_t)spec_mrg * 2);
     // (through the context's pinned landing zone when it fits: three copies to pageable memory are three synchronous round trips)
-    const size_t ctl_pad = (ctl.size() + 255) & ~size_t(255);
     const bool pinned = ctx->h_small && ctl_pad + (size_t)(spec_seg + spec_mrg) * 16 <= kSmallPinned;
     char *l_ctl = pinned ? ctx->h_small : ctl.data();
     int64_t *l_seg = pinned ? (int64_t *)(ctx->h_small + ctl_pad) : seg_out;
     int64_t *l_mrg = pinned ? l_seg + 2 * spec_seg : spec_m.data();
-    URH_HIP(hipMemcpyAsync(l_ctl, d_ctl, ctl.size(), hipMemcpyDeviceToHost, ctx->stream));
-    if (spec_seg > 0) URH_HIP(hipMemcpyAsync(l_seg, d_seg, (size_t)spec_seg * 16, hipMemcpyDeviceToHost, ctx->stream));
+    if (pinned) URH_HIP(hipMemcpyAsync(l_ctl, d_ctl, ctl_pad + (size_t)spec_seg * 16, hipMemcpyDeviceToHost, ctx->stream));
+    else {
+        URH_HIP(hipMemcpyAsync(l_ctl, d_ctl, ctl.size(), hipMemcpyDeviceToHost, ctx->stream));
+        if (spec_seg > 0) URH_HIP(hipMemcpyAsync(l_seg, d_seg, (size_t)spec_seg * 16, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (spec_mrg > 0) URH_HIP(hipMemcpyAsync(l_mrg, d_msgs, (size_t)spec_mrg * 16, hipMemcpyDeviceToHost, ctx->stream));
     URH_HIP(hipStreamSynchronize(ctx->stream));
     if (pinned) {

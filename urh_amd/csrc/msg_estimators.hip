@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kMeSumBlock) void k_me_sum_fin(const float *x, cons
 
 // ---- stage 5: bin edges (np.arange(min, max + step, step) in float64) and histogram ---------------------------------------
 constexpr int kMeHistSmallBins = 512;        // see k_me_hist
-__global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins, unsigned int *any_wide) {
+__global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins, unsigned int *n_wide, int *wide_list) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_msgs) return;
     MsgState s = st[m];
@@ -602,7 +602,9 @@ __global__ void k_me_bins(MsgState *st, int n_msgs, int64_t max_bins, unsigned i
         if (ne < 2) ne = 0;                                    // np.histogram needs at least two edges (ValueError -> None)
     }
     st[m].n_edges = ne; st[m].e0 = e0; st[m].delta = delta;
-    if (ne - 1 > kMeHistSmallBins) *any_wide = 1u;          // some message needs the wide histogram kernel (k_me_hist<kMeHistLds>)
+    // a message that needs the wide histogram kernel (k_me_hist<kMeHistLds>): on its list (rare: a nearly constant message; that kernel
+    // walks the listed messages' tiles instead of looking at every tile of the batch for one -- 17 us on config 3's capture)
+    if (ne - 1 > kMeHistSmallBins) wide_list[atomicAdd(n_wide, 1u)] = m;
     (void)max_bins;
 }
 __device__ __forceinline__ double me_edge(const MsgState &s, int64_t i) { return s.e0 + (double)i * s.delta; }
@@ -644,7 +646,7 @@ constexpr int kMeHistGroup = URH_HIST_GROUP;              // consecutive tiles p
 #define URH_HIST_WORDS 2048    // LDS counter words of the small instantiation of k_me_hist (A/B: 1024, 4096)
 #endif
 #ifndef URH_HIST_LOGC_MAX
-#define URH_HIST_LOGC_MAX 8    // at most 2^this copies of a counter: 8 = one per thread of the workgroup (A/B: 6 = one per lane)
+#define URH_HIST_LOGC_MAX 6    // at most 2^this copies of a counter: one per lane (one per thread, 8: no faster, profiles/r06q_hist_ab.txt)
 #endif
 #ifndef URH_HIST_ROUNDS
 #define URH_HIST_ROUNDS 2      // ballot rounds per row of k_me_hist before what is left goes through LDS atomics (A/B: 0, 1)
@@ -657,18 +659,15 @@ constexpr int kMeHistSmall = kMeHistSmallBins;
 #endif
 template <int BINS>
 __global__ __launch_bounds__(kMeBlock) URH_HIST_OCC void k_me_hist(const float *x, const float *kept, const MsgState *st, const MsgTile *tiles, int64_t n_tiles,
-                                                       int64_t max_bins, unsigned int *counts, const unsigned int *any_wide) {
-    if (BINS != kMeHistSmall && *any_wide == 0u) return;     // no message of this class in the batch (k_me_bins)
+                                                       int64_t max_bins, unsigned int *counts, const unsigned int *n_wide, const int *wide_list) {
+    if (BINS != kMeHistSmall && *n_wide == 0u) return;       // no message of this class in the batch (k_me_bins)
     // demodulated signals sit on two or four levels: nearly every sample of a message lands in a handful of bins.  Counting
-    // straight into device memory serialises the whole pass on those few addresses (40 ms for a 1 GiB capture).  A wavefront
-    // counts the lanes that share a bin with one ballot per distinct bin for the first two bins it meets in a row of 64 samples and
-    // sends what is left of the row (a noisy amplitude spreads over a dozen bins) through LDS atomics; the workgroup accumulates in
-    // LDS, and only the non-empty bins of a tile reach device memory.
-    // The pass is bound by instruction issue, not by HBM: the bin is guessed in float32 and checked against a float32 table of the
-    // edges in LDS that decides exactly as the float64 edges do (me_f32_at_or_above).  A workgroup walks kMeHistGroup consecutive
-    // tiles and flushes its LDS counters when the message changes or at the end (a capture that is ONE message had 32 768
-    // workgroups adding their counters to the same few words of device memory: 371 us).  (Requesting the next tile's samples before
-    // the current tile is binned -- 16 more registers -- made the kernel slower, 213 -> 280 us: not the loads' latency.)
+    // straight into device memory serialises the whole pass on those few addresses (40 ms for a 1 GiB capture): the workgroup counts in
+    // LDS, and only the non-empty bins of its tiles reach device memory -- when the message changes or at the end of its kMeHistGroup
+    // consecutive tiles, into one of the message's replicas (me_replicas).  The bin is guessed in float32 and checked against a float32
+    // table of the edges in LDS that decides exactly as the float64 edges do (me_f32_at_or_above).
+    // The wide instantiation (more than kMeHistSmall bins: rare) counts the lanes that share a bin with one ballot per distinct bin for the
+    // first two bins it meets in a row of 64 samples and sends what is left of the row through LDS atomics (rounds 3-6a: both did).
     // Round 6 (late): the small instantiation keeps 2^logC COPIES of every counter, copy (lane mod 2^logC) at word (bin << logC) + copy:
     // with 64 copies (up to 32 bins -- a demodulated message has a handful) every lane of a wavefront owns its bank and the count is ONE
     // ds_add_u32 per sample without a conflict, whatever the samples are; the ballot rounds below -- three VALU instructions and a
@@ -679,12 +678,14 @@ __global__ __launch_bounds__(kMeBlock) URH_HIST_OCC void k_me_hist(const float *
     __shared__ unsigned int s_c[kWords + (kPriv ? 64 : 0)];    // (+ 64 words nobody reads: where the lanes without a sample add)
     __shared__ float s_e[BINS + 2];                         // s_e[k] = first float32 inside bin k or above; s_e[nb] = first float32 beyond the last bin
     int logC = 0;
-    const int64_t tile0 = (int64_t)blockIdx.x * kMeHistGroup, tile1 = (tile0 + kMeHistGroup < n_tiles) ? tile0 + kMeHistGroup : n_tiles;
     int cur_msg = -1, nb = 0;
     bool valid = false, big = false;
     MsgState m = st[0];
     unsigned int *out = counts;
     const int lane = threadIdx.x & 63;
+    // the tiles [tile0, tile1) -- consecutive in the table -- with one flush per message met and one at the end
+    auto run = [&](const int64_t tile0, const int64_t tile1) {
+    cur_msg = -1; valid = false; big = false;
     for (int64_t tix = tile0; tix <= tile1; ++tix) {
     const bool last = tix == tile1;
     MsgTile t = tiles[last ? tile1 - 1 : tix];
@@ -692,23 +693,11 @@ __global__ __launch_bounds__(kMeBlock) URH_HIST_OCC void k_me_hist(const float *
         if (valid) {                                           // flush the message's counters
             __syncthreads();
             if (kPriv) {
-                // the copies of a bin are 2^logC consecutive words = consecutive lanes (256 is a multiple): fold them with shuffles
-                // (more than 64 copies -- a handful of bins: one copy per wavefront or per thread -- fold per wavefront first, and the
-                // wavefronts' partial sums meet in the first word of the bin)
-                const int C = 1 << logC, Cw = C < 64 ? C : 64;
-                for (int w0 = 0; w0 < (nb << logC); w0 += kMeBlock) {      // (nb << logC is a multiple of C; C > 64 only with kMeBlock | C * nb)
-                    const int w = w0 + (int)threadIdx.x;
-                    unsigned int v = (w < (nb << logC)) ? s_c[w] : 0u;
-                    for (int o = 1; o < Cw; o <<= 1) v += (unsigned int)__shfl_xor((int)v, o);
-                    if (C > 64) {
-                        const bool head = (w & (C - 1)) == 0 && w < (nb << logC);
-                        __syncthreads();                                 // (every thread has read its counter)
-                        if (head) s_c[w] = v;
-                        __syncthreads();
-                        if ((w & 63) == 0 && (w & (C - 1)) != 0 && w < (nb << logC) && v) atomicAdd(&s_c[w & ~(C - 1)], v);
-                        __syncthreads();
-                        v = head ? s_c[w] : 0u;
-                    }
+                // the copies of a bin are 2^logC <= 64 consecutive words = consecutive lanes (256 is a multiple): fold them with shuffles
+                const int C = 1 << logC;
+                for (int w = threadIdx.x; w < (nb << logC); w += kMeBlock) {
+                    unsigned int v = s_c[w];
+                    for (int o = 1; o < C; o <<= 1) v += (unsigned int)__shfl_xor((int)v, o);
                     if ((w & (C - 1)) == 0 && v) atomicAdd(&out[w >> logC], v);
                 }
             } else {
@@ -787,7 +776,7 @@ __global__ __launch_bounds__(kMeBlock) URH_HIST_OCC void k_me_hist(const float *
         // four samples at a time: guess, check (the table reads of the four are in flight together), count; a lane whose check fails (a
         // rounding error next to an edge, a NaN, padding) searches the table on its own -- nothing here needs the wavefront to agree
         const int sh = logC + 2;                                               // counter addresses in bytes: (bin << sh) + mine
-        const unsigned int mine = (unsigned int)((int)threadIdx.x & ((1 << logC) - 1)) * 4u, dump = (unsigned int)((nb << logC) + lane) * 4u;
+        const unsigned int mine = (unsigned int)(lane & ((1 << logC) - 1)) * 4u, dump = (unsigned int)((nb << logC) + lane) * 4u;
 #pragma unroll
         for (int j0 = 0; j0 < kMePer; j0 += 4) {
             int k[4];
@@ -874,6 +863,22 @@ __global__ __launch_bounds__(kMeBlock) URH_HIST_OCC void k_me_hist(const float *
             bin[j] = -1;
         }
     }
+    }
+    };
+    if (kPriv) {
+        const int64_t tile0 = (int64_t)blockIdx.x * kMeHistGroup;
+        run(tile0, (tile0 + kMeHistGroup < n_tiles) ? tile0 + kMeHistGroup : n_tiles);
+    } else {
+        // the listed messages' tiles, in groups of kMeHistGroup dealt round robin to the workgroups
+        const unsigned int nw = *n_wide;
+        for (unsigned int wi = 0; wi < nw; ++wi) {
+            const MsgState w = st[wide_list[wi]];
+            const int64_t len = w.end - w.start, nt = ((len > 1 ? len : 1) + kMeTile - 1) / kMeTile;
+            for (int64_t g = blockIdx.x; g * kMeHistGroup < nt; g += gridDim.x) {
+                const int64_t tile0 = w.first_tile + g * kMeHistGroup, tile_end = w.first_tile + nt;
+                run(tile0, (tile0 + kMeHistGroup < tile_end) ? tile0 + kMeHistGroup : tile_end);
+            }
+        }
     }
 }
 
@@ -1149,9 +1154,16 @@ struct MsgBatch {
 
 // urhgpu_msg_estimate: center statistics and plateau decisions back to back -- the centers stay on the device (k_me_chain_center), the
 // scratch of both stages comes from ONE reservation, the states of both land in the pinned zone behind ONE synchronisation
+// Round 6 (late): the states of both stages, the pool fill and the pool are ONE block of the arena -- [states 1 | states 2 | fill | pairs]
+// -- uploaded with one copy before stage 1 and fetched with one copy behind stage 2 (rounds 5-6a: an upload and a read-back per stage, in
+// the stream between the kernels, and three copies at the end: each with its ~9 us of idle stream around it).
 struct EstChain {
-    MsgBatch b1;             // stage 1's batch (host mirror filled when the chain's synchronisation has happened)
-    MsgState *d_st1 = nullptr;
+    MsgBatch b1, b2;         // the stages' batches (host mirrors filled when the chain's synchronisation has happened)
+    MsgState *d_st1 = nullptr, *d_st2 = nullptr;
+    unsigned long long *d_pool_count = nullptr;
+    uint64_t *d_pool = nullptr;
+    int64_t cap_pairs = 0;
+    size_t st_pad = 0;       // bytes of one stage's states in the block (and in the pinned zone)
     bool st1_pinned = false;
     size_t pinned_used = 0;  // bytes of ctx->h_small stage 1's states occupy
 };
@@ -1181,6 +1193,20 @@ int build_batch(urhgpu_ctx *ctx, const int64_t *ranges, int n_msgs, int64_t n, c
     return URHGPU_OK;
 }
 
+// the batch of the plateau stage: boundaries are searched in [0, percentage % + extra_window) of every message
+int plateau_batch(urhgpu_ctx *ctx, const int64_t *ranges, int n_msgs, int64_t n, int percentage, int64_t extra_window, MsgBatch &b) {
+    std::vector<int64_t> windows((size_t)n_msgs);
+    for (int m = 0; m < n_msgs; ++m) {
+        const int64_t len = ranges[2 * m + 1] - ranges[2 * m];
+        if (len > INT32_MAX) return URHGPU_ERR_UNSUPPORTED;       // positions inside a message are 32-bit
+        const int64_t limit = ((int64_t)percentage * len) / 100;
+        windows[(size_t)m] = std::min<int64_t>(len, limit + extra_window);
+    }
+    return build_batch(ctx, ranges, n_msgs, n, windows.data(), b);
+}
+// (value, count) pairs the pool holds: a message beyond its share of the pool is decided from its sequence
+int64_t plateau_cap_pairs(int n_msgs) { return std::max<int64_t>(4096, (int64_t)n_msgs * 256); }
+
 }  // namespace
 
 extern "C" {
@@ -1193,28 +1219,28 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
                               double *out_stats, int64_t *out_hist, double *out_center, int32_t *out_flag, EstChain *chain = nullptr) {
     MsgBatch local;
     MsgBatch &b = chain ? chain->b1 : local;
-    URH_TRY(build_batch(ctx, ranges, n_msgs, n, nullptr, b));
+    if (!chain) { URH_TRY(build_batch(ctx, ranges, n_msgs, n, nullptr, b)); }      // (a chained call: built, placed and uploaded by urhgpu_msg_estimate)
     // scratch: state, tiles, per-tile counts / min-max, leaf sums, the compacted samples, the histogram pool
     const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)(b.n_tiles + 1) * (sizeof(MsgTile) + 4 + 8 + 8 + 4 + kLeavesPerTile * 4) +
-                        (size_t)n * 4 + (size_t)n_msgs * (size_t)max_bins * 4 + 17 * 256;
-    if (!chain) { URH_TRY(ctx->arena.reserve(need)); }       // (a chained call has reserved both stages' scratch)
-    ctx->arena.reset();
-    MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
+                        (size_t)n * 4 + (size_t)n_msgs * (size_t)max_bins * 4 + (size_t)n_msgs * 4 + 18 * 256;
+    if (!chain) { URH_TRY(ctx->arena.reserve(need)); ctx->arena.reset(); }       // (a chained call has reserved both stages' scratch)
+    MsgState *d_st = chain ? chain->d_st1 : (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
     MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
     int64_t *d_pre = (int64_t *)ctx->arena.take((size_t)(b.n_tiles + 1) * 8);
     float2 *d_mm = (float2 *)ctx->arena.take((size_t)b.n_tiles * 8);
     float *d_half = (float *)ctx->arena.take((size_t)(b.n_tiles + 1) * 4);
     float *d_leaf = (float *)ctx->arena.take((size_t)b.n_tiles * kLeavesPerTile * 4);
     float *d_kept = (float *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
+    int *d_wide = (int *)ctx->arena.take((size_t)n_msgs * 4);
     // the histogram pool, the any_wide flag behind it and the per-tile counts: what ONE fill clears before the passes
     const size_t pool_bytes = ((size_t)n_msgs * (size_t)max_bins * 4 + 256 + 255) & ~size_t(255);
     unsigned int *d_hist = (unsigned int *)ctx->arena.take(pool_bytes + (size_t)b.n_tiles * 4);
     unsigned int *d_any_wide = d_hist ? d_hist + (size_t)n_msgs * (size_t)max_bins : nullptr;
     unsigned int *d_any_dirty = d_any_wide ? d_any_wide + 1 : nullptr;
     int32_t *d_cnt = d_hist ? (int32_t *)((char *)d_hist + pool_bytes) : nullptr;
-    if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_mm || !d_half || !d_leaf || !d_kept || !d_hist) return URHGPU_ERR_ARG;
+    if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_mm || !d_half || !d_leaf || !d_kept || !d_wide || !d_hist) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
-    URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
+    if (!chain) URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
     URH_HIP(hipMemsetAsync(d_hist, 0, pool_bytes + (size_t)b.n_tiles * 4, s));
     const unsigned gt = (unsigned)b.n_tiles, gm = (unsigned)((n_msgs + 63) / 64);
@@ -1228,21 +1254,18 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
     hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeSumBlock), 0, s, d_x, d_kept, d_st, d_half, d_mm, 0);
     hipLaunchKernelGGL(k_me_leaves, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_kept, d_st, d_tiles, d_half);
     hipLaunchKernelGGL(k_me_sum_fin, dim3((unsigned)n_msgs), dim3(kMeSumBlock), 0, s, d_x, d_kept, d_st, d_half, d_mm, 1);
-    hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins, d_any_wide);
+    hipLaunchKernelGGL(k_me_bins, dim3(gm), dim3(64), 0, s, d_st, n_msgs, max_bins, d_any_wide, d_wide);
     hipLaunchKernelGGL((k_me_hist<kMeHistSmall>), dim3((unsigned)((b.n_tiles + kMeHistGroup - 1) / kMeHistGroup)), dim3(kMeBlock), 0, s, d_x, d_kept, d_st,
-                       d_tiles, b.n_tiles, max_bins, d_hist, d_any_wide);
-    hipLaunchKernelGGL((k_me_hist<kMeHistLds>), dim3((unsigned)((b.n_tiles + kMeHistGroup - 1) / kMeHistGroup)), dim3(kMeBlock), 0, s, d_x, d_kept, d_st,
-                       d_tiles, b.n_tiles, max_bins, d_hist, d_any_wide);
+                       d_tiles, b.n_tiles, max_bins, d_hist, d_any_wide, d_wide);
+    hipLaunchKernelGGL((k_me_hist<kMeHistLds>), dim3((unsigned)std::min<int64_t>((b.n_tiles + kMeHistGroup - 1) / kMeHistGroup, 1024)), dim3(kMeBlock), 0, s,
+                       d_x, d_kept, d_st, d_tiles, b.n_tiles, max_bins, d_hist, d_any_wide, d_wide);
     hipLaunchKernelGGL(k_me_peaks, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_hist, max_bins);
     URH_HIP(hipGetLastError());
+    if (chain) return URHGPU_OK;                             // stage 2 goes on from here; the states come back with its own
     std::vector<unsigned int> hist;
     const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState);
-    const bool st_pinned = ctx->h_small && st_bytes <= (chain ? kSmallPinned / 4 : kSmallPinned);     // (a truly asynchronous copy; pageable memory otherwise)
+    const bool st_pinned = ctx->h_small && st_bytes <= kSmallPinned;     // (a truly asynchronous copy; pageable memory otherwise)
     URH_HIP(hipMemcpyAsync(st_pinned ? (void *)ctx->h_small : (void *)b.host.data(), d_st, st_bytes, hipMemcpyDeviceToHost, s));
-    if (chain) {                                             // stage 2 goes on from here; its synchronisation covers this copy
-        chain->d_st1 = d_st; chain->st1_pinned = st_pinned; chain->pinned_used = st_pinned ? ((st_bytes + 255) & ~size_t(255)) : 0;
-        return URHGPU_OK;
-    }
     if (out_hist) {                                          // the histograms themselves: only a caller that has to break a tie wants them
         hist.resize((size_t)n_msgs * (size_t)max_bins);
         URH_HIP(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
@@ -1644,34 +1667,30 @@ static int plateau_decisions_impl(urhgpu_ctx *ctx, const float *d_x, int64_t n, 
         return URHGPU_ERR_ARG;
     if (n_msgs == 0) return URHGPU_OK;
     URH_HIP(hipSetDevice(ctx->device));
-    std::vector<int64_t> windows((size_t)n_msgs);
-    for (int m = 0; m < n_msgs; ++m) {
-        const int64_t len = ranges[2 * m + 1] - ranges[2 * m];
-        if (len > INT32_MAX) return URHGPU_ERR_UNSUPPORTED;       // positions inside a message are 32-bit
-        const int64_t limit = ((int64_t)percentage * len) / 100;
-        windows[(size_t)m] = std::min<int64_t>(len, limit + extra_window);
+    MsgBatch local;
+    MsgBatch &b = chain ? chain->b2 : local;
+    if (!chain) {
+        URH_TRY(plateau_batch(ctx, ranges, n_msgs, n, percentage, extra_window, b));
+        for (int m = 0; m < n_msgs; ++m) b.host[(size_t)m].center = centers[m];
+        URH_TRY(join_tail(ctx));
     }
-    if (!chain) { URH_TRY(join_tail(ctx)); }
-    MsgBatch b;
-    URH_TRY(build_batch(ctx, ranges, n_msgs, n, windows.data(), b));
-    for (int m = 0; m < n_msgs; ++m) b.host[(size_t)m].center = chain ? __builtin_nan("") : centers[m];
-    const int64_t cap_pairs = std::max<int64_t>(4096, (int64_t)n_msgs * 256);     // a message beyond its share of the pool is decided from its sequence
+    const int64_t cap_pairs = chain ? chain->cap_pairs : plateau_cap_pairs(n_msgs);
     const size_t need = (size_t)n_msgs * sizeof(MsgState) + (size_t)(b.n_tiles + 1) * (sizeof(MsgTile) + 4 + 8) + (size_t)std::max<int64_t>(n, 1) * 4 +
                         (size_t)cap_pairs * 16 + 10 * 256;
     if (!chain) {                                            // (a chained call: behind stage 1's scratch, in the reservation made for both)
         URH_TRY(ctx->arena.reserve(need));
         ctx->arena.reset();
     }
-    MsgState *d_st = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
+    MsgState *d_st = chain ? chain->d_st2 : (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
     MsgTile *d_tiles = (MsgTile *)ctx->arena.take((size_t)b.n_tiles * sizeof(MsgTile));
     int32_t *d_cnt = (int32_t *)ctx->arena.take((size_t)b.n_tiles * 4);
     int64_t *d_pre = (int64_t *)ctx->arena.take((size_t)(b.n_tiles + 1) * 8);
     int32_t *d_edges = (int32_t *)ctx->arena.take((size_t)std::max<int64_t>(n, 1) * 4);
-    unsigned long long *d_pool_count = (unsigned long long *)ctx->arena.take(64);
-    uint64_t *d_pool = (uint64_t *)ctx->arena.take((size_t)cap_pairs * 16);
+    unsigned long long *d_pool_count = chain ? chain->d_pool_count : (unsigned long long *)ctx->arena.take(64);
+    uint64_t *d_pool = chain ? chain->d_pool : (uint64_t *)ctx->arena.take((size_t)cap_pairs * 16);
     if (!d_st || !d_tiles || !d_cnt || !d_pre || !d_edges || !d_pool_count || !d_pool) return URHGPU_ERR_ARG;
     hipStream_t s = ctx->stream;
-    URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
+    if (!chain) URH_HIP(hipMemcpyAsync(d_st, b.host.data(), (size_t)n_msgs * sizeof(MsgState), hipMemcpyHostToDevice, s));
     if (chain) hipLaunchKernelGGL(k_me_chain_center, dim3((unsigned)((n_msgs + 63) / 64)), dim3(64), 0, s, chain->d_st1, d_st, n_msgs);
     hipLaunchKernelGGL(k_me_fill_tiles, dim3((unsigned)((b.n_tiles + 255) / 256)), dim3(256), 0, s, d_st, n_msgs, d_tiles, b.n_tiles);
     URH_HIP(hipMemsetAsync(d_pool_count, 0, 8, s));
@@ -1685,13 +1704,18 @@ static int plateau_decisions_impl(urhgpu_ctx *ctx, const float *d_x, int64_t n, 
     // states, pool fill and (speculatively) the first pairs of the pool land in the context's pinned zone in ONE round trip when they fit
     unsigned long long pool_used = 0;
     const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState), st_pad = (st_bytes + 255) & ~size_t(255);
-    const size_t zone0 = chain ? chain->pinned_used : 0;     // (a chained call: stage 1's states lie in front)
+    const size_t zone0 = chain ? st_pad : 0;                 // (a chained call: stage 1's states lie in front -- in the block and in the zone)
     const bool pinned = ctx->h_small && zone0 + st_pad + 256 + 4096 <= kSmallPinned;
     char *zone = pinned ? ctx->h_small + zone0 : nullptr;
     const int64_t spec_pairs = pinned ? std::min<int64_t>(std::min<int64_t>(cap_pairs, 8192), (int64_t)((kSmallPinned - zone0 - st_pad - 256) / 16)) : 0;
-    URH_HIP(hipMemcpyAsync(pinned ? (void *)zone : (void *)b.host.data(), d_st, st_bytes, hipMemcpyDeviceToHost, s));
-    URH_HIP(hipMemcpyAsync(pinned ? (void *)(zone + st_pad) : (void *)&pool_used, d_pool_count, 8, hipMemcpyDeviceToHost, s));
-    if (spec_pairs > 0) URH_HIP(hipMemcpyAsync(zone + st_pad + 256, d_pool, (size_t)spec_pairs * 16, hipMemcpyDeviceToHost, s));
+    if (chain && pinned) {                                   // [states 1 | states 2 | fill | the first pairs]: one copy
+        URH_HIP(hipMemcpyAsync(ctx->h_small, chain->d_st1, 2 * st_pad + 256 + (size_t)spec_pairs * 16, hipMemcpyDeviceToHost, s));
+        chain->st1_pinned = true;
+    } else {
+        URH_HIP(hipMemcpyAsync(pinned ? (void *)zone : (void *)b.host.data(), d_st, st_bytes, hipMemcpyDeviceToHost, s));
+        URH_HIP(hipMemcpyAsync(pinned ? (void *)(zone + st_pad) : (void *)&pool_used, d_pool_count, 8, hipMemcpyDeviceToHost, s));
+        if (spec_pairs > 0) URH_HIP(hipMemcpyAsync(zone + st_pad + 256, d_pool, (size_t)spec_pairs * 16, hipMemcpyDeviceToHost, s));
+    }
     URH_HIP(hipStreamSynchronize(s));
     if (pinned) { memcpy(b.host.data(), zone, st_bytes); memcpy(&pool_used, zone + st_pad, 8); }
     if (chain && chain->st1_pinned) memcpy(chain->b1.host.data(), ctx->h_small, (size_t)n_msgs * sizeof(MsgState));
@@ -1776,10 +1800,28 @@ int urhgpu_msg_estimate(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
     const size_t tiles_max = (size_t)(n / kMeTile + n_msgs + 2);
     const int64_t cap_pairs = std::max<int64_t>(4096, (int64_t)n_msgs * 256);
     const size_t need1 = (size_t)n_msgs * sizeof(MsgState) + (tiles_max + 1) * (sizeof(MsgTile) + 4 + 8 + 8 + 4 + kLeavesPerTile * 4) + (size_t)n * 4 +
-                         (size_t)n_msgs * (size_t)max_bins * 4 + 17 * 256;
+                         (size_t)n_msgs * (size_t)max_bins * 4 + (size_t)n_msgs * 4 + 18 * 256;
     const size_t need2 = (size_t)n_msgs * sizeof(MsgState) + (tiles_max + 1) * (sizeof(MsgTile) + 4 + 8) + (size_t)std::max<int64_t>(n, 1) * 4 + (size_t)cap_pairs * 16 + 10 * 256;
     URH_TRY(ctx->arena.reserve(need1 + need2 + 4096));
+    ctx->arena.reset();
     EstChain chain;
+    URH_TRY(build_batch(ctx, ranges, n_msgs, n, nullptr, chain.b1));
+    URH_TRY(plateau_batch(ctx, ranges, n_msgs, n, percentage, extra_window, chain.b2));       // (center NaN: k_me_chain_center hands stage 1's over)
+    const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState);
+    chain.st_pad = (st_bytes + 255) & ~size_t(255);
+    chain.cap_pairs = cap_pairs;
+    char *blk = (char *)ctx->arena.take(2 * chain.st_pad + 256 + (size_t)cap_pairs * 16);
+    if (!blk) return URHGPU_ERR_ARG;
+    chain.d_st1 = (MsgState *)blk; chain.d_st2 = (MsgState *)(blk + chain.st_pad);
+    chain.d_pool_count = (unsigned long long *)(blk + 2 * chain.st_pad); chain.d_pool = (uint64_t *)(blk + 2 * chain.st_pad + 256);
+    if (ctx->h_small && 2 * chain.st_pad <= kSmallPinned) {  // both stages' states in ONE upload, out of the pinned zone
+        memcpy(ctx->h_small, chain.b1.host.data(), st_bytes);
+        memcpy(ctx->h_small + chain.st_pad, chain.b2.host.data(), st_bytes);
+        URH_HIP(hipMemcpyAsync(blk, ctx->h_small, chain.st_pad + st_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        URH_HIP(hipMemcpyAsync(chain.d_st1, chain.b1.host.data(), st_bytes, hipMemcpyHostToDevice, ctx->stream));
+        URH_HIP(hipMemcpyAsync(chain.d_st2, chain.b2.host.data(), st_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
     URH_TRY(center_stats_batch(ctx, d_x, n, ranges, n_msgs, max_bins, out_stats, nullptr, out_center, out_flag, &chain));
     URH_TRY(plateau_decisions_impl(ctx, d_x, n, ranges, nullptr, n_msgs, percentage, extra_window, tol_out, bitlen_out, &chain));
     if (!chain.st1_pinned) {                                 // (states too many for the pinned zone: fetched now)

@@ -30,6 +30,7 @@ struct SegCtl {              // device control block
     unsigned long long min_pulse;
     int ambiguous;           // a pulse sits within rounding of the outlier bound: the host repeats the decision in numpy's summation order
     int pad;
+    unsigned int tickets[2]; // k_seg_moments, per pass: workgroups that have delivered their partial sum (the last one adds them up)
 };
 
 struct SegLoad {
@@ -93,12 +94,17 @@ __global__ void k_seg_finish(const int64_t *rows, const int64_t *d_n_rows, const
         }
     }
     ctl->n_seg = n_seg; ctl->n_msgs = n_seg; ctl->ambiguous = 0; ctl->sum = 0.0; ctl->sq = 0.0; ctl->min_pulse = ~0ull;
+    ctl->tickets[0] = 0u; ctl->tickets[1] = 0u;
 }
 
 // ---- OOK merge: outlier-free minimum pulse, cuts at pauses >= 8 x that ---------------------------------------------------
-// mean / standard deviation of the pulse lengths by two-level sums (fixed order); min over |p - mean| <= std
-__global__ __launch_bounds__(256) void k_seg_moments(const int64_t *seg, const SegCtl *ctl, int pass, double *part) {
+// mean / standard deviation of the pulse lengths by two-level sums (fixed order); min over |p - mean| <= std.  The workgroup that
+// delivers the LAST partial sum of a pass adds the partial sums up (in block order, as a tree: the same result whichever workgroup it is)
+// -- rounds 3-6a had a one-workgroup kernel per pass for that, and one more that copied the segment count for the scan behind.
+constexpr int kSegParts = 256;
+__global__ __launch_bounds__(256) void k_seg_moments(const int64_t *seg, SegCtl *ctl, int pass, double *part) {
     __shared__ double s_p[4];
+    __shared__ bool s_last;
     const int64_t n = ctl->n_seg;
     const double mean = (pass == 1 && n > 0) ? ctl->sum / (double)n : 0.0;
     const int64_t per = (n + gridDim.x - 1) / gridDim.x;
@@ -112,22 +118,26 @@ __global__ __launch_bounds__(256) void k_seg_moments(const int64_t *seg, const S
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
     if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = (s_p[0] + s_p[1]) + (s_p[2] + s_p[3]);
-}
-// the partial sums added in block order by one thread -- after ALL of them have been loaded in one round trip (the first version
-// loaded them one after the other: 256 dependent loads, 12-15 us)
-constexpr int kSegParts = 256;
-__global__ __launch_bounds__(kSegParts) void k_seg_moments_fin(const double *part, int n_part, int pass, SegCtl *ctl) {
-    __shared__ double s_part[kSegParts];
-    s_part[threadIdx.x] = ((int)threadIdx.x < n_part) ? part[threadIdx.x] : 0.0;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&part[blockIdx.x], (s_p[0] + s_p[1]) + (s_p[2] + s_p[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(&ctl->tickets[pass], 1u) == gridDim.x - 1;
+    }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    double t = 0.0;
-    for (int b = 0; b < n_part; ++b) t += s_part[b];
-    if (pass == 0) ctl->sum = t; else ctl->sq = t;
+    if (!s_last) return;
+    __threadfence();
+    double v = (threadIdx.x < gridDim.x) ? __hip_atomic_load(&part[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    __syncthreads();                                          // (s_p has been read)
+    if ((threadIdx.x & 63) == 0) s_p[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { const double t = (s_p[0] + s_p[1]) + (s_p[2] + s_p[3]); if (pass == 0) ctl->sum = t; else ctl->sq = t; }
 }
-__global__ __launch_bounds__(256) void k_seg_min_pulse(const int64_t *seg, SegCtl *ctl) {
+__global__ __launch_bounds__(256) void k_seg_min_pulse(const int64_t *seg, SegCtl *ctl, int64_t *d_n) {
+    __shared__ unsigned long long s_b[4];
     const int64_t n = ctl->n_seg;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *d_n = n;      // the segment count where the scan behind this kernel reads its length
     if (n <= 1) return;
     const double mean = ctl->sum / (double)n, sd = sqrt(ctl->sq / (double)n);
     unsigned long long best = ~0ull;
@@ -141,7 +151,13 @@ __global__ __launch_bounds__(256) void k_seg_min_pulse(const int64_t *seg, SegCt
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long u = (unsigned long long)__shfl_down((long long)best, o); if (u < best) best = u; }
-    if ((threadIdx.x & 63) == 0 && best != ~0ull) atomicMin(&ctl->min_pulse, best);
+    if ((threadIdx.x & 63) == 0) s_b[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) if (s_b[w] < best) best = s_b[w];
+        // one atomic per workgroup, and only where it can lower the minimum (it only ever falls: a stale read costs an add, never a miss)
+        if (best != ~0ull && best < __hip_atomic_load(&ctl->min_pulse, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&ctl->min_pulse, best);
+    }
 }
 // message i starts after the i-th long pause: flag[j] = pause after segment j is long (j < n_seg - 1); messages by a scan of the flags
 struct CutLoad {
@@ -171,7 +187,6 @@ struct CutFinal {
     SegCtl *ctl;
     __device__ void operator()(const VecK<1> &grand) const { ctl->n_msgs = (ctl->n_seg > 0) ? grand.v[0] + 1 : 0; }
 };
-__global__ void k_seg_count_ptr(const SegCtl *ctl, int64_t *d_n) { *d_n = ctl->n_seg; }
 
 template <int DT>
 static void launch_seg_finish(const int64_t *rows, const int64_t *d_n_rows, const void *iq, int64_t n, float thr, int64_t *seg, int64_t cap,
@@ -202,12 +217,8 @@ int launch_message_ranges(const int64_t *d_rows, const int64_t *d_n_rows, int64_
     }
     if (!ook_merge) return URHGPU_OK;
     const int gp = kSegParts;
-    for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(k_seg_moments, dim3(gp), dim3(256), 0, s, d_seg, d_ctl, pass, dpart);
-        hipLaunchKernelGGL(k_seg_moments_fin, dim3(1), dim3(kSegParts), 0, s, dpart, gp, pass, d_ctl);
-    }
-    hipLaunchKernelGGL(k_seg_min_pulse, dim3(gp), dim3(256), 0, s, d_seg, d_ctl);
-    hipLaunchKernelGGL(k_seg_count_ptr, dim3(1), dim3(1), 0, s, d_ctl, d_nseg);
+    for (int pass = 0; pass < 2; ++pass) hipLaunchKernelGGL(k_seg_moments, dim3(gp), dim3(256), 0, s, d_seg, d_ctl, pass, dpart + pass * kSegParts);
+    hipLaunchKernelGGL(k_seg_min_pulse, dim3(gp), dim3(256), 0, s, d_seg, d_ctl, d_nseg);
     const int64_t nbs = std::max<int64_t>((cap + kScanTile - 1) / kScanTile, 1);
     VecK<1> *part2 = part;                                   // the first scan is done
     CutLoad cl{d_seg, d_ctl};
