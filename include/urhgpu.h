@@ -107,6 +107,8 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
  *                              (lowest latency); 0, default: direct passes throughout (highest throughput for back-to-back passes)
  *   "stream_segments"          rows segments of a segmented pass, 1 .. 16, default 7
  *   "stream_pos_direct"        1, default: direct passes ship bit_sample_pos themselves (uint32 stores of the kernels that compute them)
+ *   "spin_wait"                1, default: the estimator calls poll their stream instead of blocking in the runtime (a blocking wait wakes
+ *                              the host tens of microseconds late: 0.09 ms of config 3's estimate)
  *   "upload_pieces"            2 .. 16, default 4: pieces of urhgpu_stream_push_upload, the last one short
  * Unknown key: URHGPU_ERR_ARG. */
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value);

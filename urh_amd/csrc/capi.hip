@@ -1,5 +1,6 @@
 // capi.hip -- the extern "C" surface declared in include/urhgpu.h.
 #include <hip/hip_runtime.h>
+#include <chrono>
 
 #include <algorithm>
 #include <math.h>
@@ -32,6 +33,18 @@ void Arena::release() {
 // pipelined mode: make the caller's stream wait for the tail of the last pass (no host blocking).  Every entry point that takes
 // scratch from ctx->arena or launches on ctx->stream calls this first: on a pipelined context the arena is the one the last pass's
 // tail may still be working in.
+hipError_t wait_stream(const urhgpu_ctx *ctx, hipStream_t s) {
+    if (ctx->tune_spin_wait) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; ++it) {
+            const hipError_t q = hipStreamQuery(s);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        }
+    }
+    return hipStreamSynchronize(s);
+}
 int join_tail(urhgpu_ctx *ctx) {
     if (ctx->tail_pending) {
         URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[(ctx->flip + 2) % 3], 0));       // the pass recorded last
@@ -870,6 +883,7 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
 //   stream_latency           1: a pass that finds the pipeline idle runs its tail in segments (lowest latency for ONE capture); default 0
 //   stream_pos_direct        1 (default): direct passes ship bit_sample_pos themselves
 //   upload_pieces            pieces of urhgpu_stream_push_upload; default 4
+//   spin_wait                1 (default): the estimator calls poll their stream for the few hundred microseconds they wait (wait_stream)
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return URHGPU_ERR_ARG;
     if (!strcmp(key, "hot_lds_kb")) { if (value < 0 || value > 150) return URHGPU_ERR_ARG; ctx->hot_lds_pad = value * 1024; }
@@ -880,6 +894,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "stream_policy")) { if (value < 0 || value > 6) return URHGPU_ERR_ARG; ctx->tune_stream_policy = value; }
     else if (!strcmp(key, "stream_latency")) { ctx->tune_stream_latency = value != 0; }
     else if (!strcmp(key, "stream_pos_direct")) { ctx->tune_stream_pos_direct = value != 0; }
+    else if (!strcmp(key, "spin_wait")) { ctx->tune_spin_wait = value != 0; }
     else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;
@@ -1144,13 +1159,13 @@ int urhgpu_outputs_to_host(urhgpu_ctx *ctx, const urhgpu_outputs *out, int write
     URH_HIP(hipGetLastError());
     int64_t *hdr = ctx->h_small ? (int64_t *)ctx->h_small : (int64_t *)host_dst;
     URH_HIP(hipMemcpyAsync(hdr, out->blob, URHGPU_BLOB_HEADER_BYTES, hipMemcpyDeviceToHost, ctx->stream));
-    URH_HIP(hipStreamSynchronize(ctx->stream));
+    URH_HIP(wait_stream(ctx, ctx->stream));
     if (hdr[0] != URHGPU_BLOB_MAGIC) return URHGPU_ERR_ARG;
     const int64_t total = hdr[6] < 0 ? -hdr[6] : hdr[6];
     *total_bytes = total;
     if (hdr[6] < 0 || total > cap_dst) return URHGPU_ERR_CAPACITY;
     URH_HIP(hipMemcpyAsync(host_dst, out->blob, (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
-    URH_HIP(hipStreamSynchronize(ctx->stream));
+    URH_HIP(wait_stream(ctx, ctx->stream));
     return URHGPU_OK;
 }
 
@@ -1516,7 +1531,7 @@ static int message_ranges_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int
         if (spec_seg > 0) URH_HIP(hipMemcpyAsync(l_seg, d_seg, (size_t)spec_seg * 16, hipMemcpyDeviceToHost, ctx->stream));
     }
     if (spec_mrg > 0) URH_HIP(hipMemcpyAsync(l_mrg, d_msgs, (size_t)spec_mrg * 16, hipMemcpyDeviceToHost, ctx->stream));
-    URH_HIP(hipStreamSynchronize(ctx->stream));
+    URH_HIP(wait_stream(ctx, ctx->stream));
     if (pinned) {
         memcpy(ctl.data(), l_ctl, ctl.size());
         if (spec_mrg > 0) memcpy(spec_m.data(), l_mrg, (size_t)spec_mrg * 16);
@@ -1547,7 +1562,7 @@ static int message_ranges_impl(urhgpu_ctx *ctx, const void *d_iq, int dtype, int
             if (take_m > have) { URH_HIP(hipMemcpyAsync(merged_out + 2 * have, d_msgs + 2 * have, (size_t)(take_m - have) * 16, hipMemcpyDeviceToHost, ctx->stream)); more = true; }
         }
     }
-    if (more) URH_HIP(hipStreamSynchronize(ctx->stream));
+    if (more) URH_HIP(wait_stream(ctx, ctx->stream));
     return URHGPU_OK;
 }
 

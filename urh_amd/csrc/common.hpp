@@ -79,6 +79,7 @@ struct urhgpu_ctx {
     urh::Arena aux;          // Costas candidate / checkpoint states (lives across the arena / staging users)
     int64_t *d_counts = nullptr;   // small device result block (8 x int64)
     int64_t *h_counts = nullptr;   // pinned host mirror
+    bool tune_spin_wait = true;    // wait_stream polls (see there)
     char *h_small = nullptr;       // pinned landing zone of the estimators' small results (kSmallPinned bytes): copies into it are truly asynchronous
     int32_t *d_tickets = nullptr;  // 8 zeroed ints: elections of the fused scan kernels (scan.hpp)
     void *d_desc = nullptr;        // descriptors of the single-pass scans: dedicated, zeroed when (re)allocated
@@ -146,5 +147,9 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
 }
 
 namespace urh {
+// hipStreamSynchronize for the short waits of the estimator calls: the runtime's blocking wait wakes the host tens of microseconds after
+// the stream has drained; polling the stream does not (tuning key "spin_wait" 0 takes the blocking wait; after 5 ms of polling it is
+// taken anyway)
+hipError_t wait_stream(const urhgpu_ctx *ctx, hipStream_t s);
 int join_tail(urhgpu_ctx *ctx);    // capi.hip: the caller's stream waits for the tail of the last pipelined pass
 }

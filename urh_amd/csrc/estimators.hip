@@ -319,7 +319,7 @@ int pairwise_sum_f32(urhgpu_ctx *ctx, const float *d_x, int64_t n, int mode, flo
     std::vector<float> chunk((size_t)n_chunks), tail((size_t)n_extra);
     if (n_chunks) URH_HIP(hipMemcpyAsync(chunk.data(), d_chunk, (size_t)n_chunks * 4, hipMemcpyDeviceToHost, s));
     if (n_extra) URH_HIP(hipMemcpyAsync(tail.data(), d_sums + n_regular, (size_t)n_extra * 4, hipMemcpyDeviceToHost, s));
-    URH_HIP(hipStreamSynchronize(s));
+    URH_HIP(wait_stream(ctx, s));
     volatile float total = 0.0f;                                   // float32 adds, no excess precision
     for (int64_t c = 0; c < n_chunks; ++c) total = total + chunk[(size_t)c];
     if (rest) { int64_t next = 0; const float t = combine_leaves(rest, tail.data(), next); total = total + t; }

@@ -125,21 +125,48 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
     const int64_t left_len = len - wbase, left_L = L - (int64_t)t.idx * kMeTile;
     const int lim_len = (int)(left_len < 0 ? 0 : (left_len > kMeTile ? kMeTile : left_len));   // samples of the window that exist ...
     const int lim_L = (int)(left_L < 0 ? 0 : (left_L > kMeTile ? kMeTile : left_L));           // ... and that lie in the trimmed range
-    float v[kPwLeafM / 8];
-#pragma unroll
-    for (int i = 0; i < kPwLeafM / 8; ++i) v[i] = (rel0 + 8 * i < lim_len) ? win[rel0 + 8 * i] : -5.0f;
     // The counts are kept per NATURAL tile of the message (samples [4096 u, 4096 (u + 1)) from its start) although the reads are not
     // aligned to them: the compaction of a message that does have filtered samples needs those, and this way nobody reads the message
     // a second time just to count.  A window meets two natural tiles, a head slice (at most 5 % of 4096 samples) two as well.
     static_assert((kMeTile & (kMeTile - 1)) == 0, "natural tiles by shift and mask");
     const int64_t wa = (skip + wbase) / kMeTile;                             // natural tile of the window's first sample
     const int woff = (int)((skip + wbase) & (kMeTile - 1));                  // ... and where in it the window starts
-    int c[4] = {0, 0, 0, 0};                               // window: tiles wa, wa + 1; head slice: tiles ha, ha + 1
+    const bool any = L > 0 && (int64_t)t.idx * kMeTile < L;
+    const float first = L > 0 ? src[a] : 0.f;
+    float v[kPwLeafM / 8];
+    int cw[4] = {0, 0, 0, 0};                              // per WAVEFRONT: window in tiles wa, wa + 1; head slice in tiles ha, ha + 1
+    float mn = first, mx = first;                          // min / max over the elements inside the trimmed range, seeded with its first element (util.minmax: a NaN there stays)
+    if (lim_len == kMeTile && lim_L == kMeTile) {
+        // Round 6 (late): a window that lies wholly inside the message and the trimmed range -- all but two or three per message.  Loads
+        // without a bound, the count of a row of 64 samples from the compare's own lane mask (scalar popcounts), no range test in front
+        // of min / max: 7 VALU instructions per sample instead of 31 -- the pass was bound by them (PMC: VALU busy for 113 of its 106 us
+        // of wall time on the slowest SIMD; profiles/r06q_first_pmc.txt), now by its bytes.
 #pragma unroll
-    for (int i = 0; i < kPwLeafM / 8; ++i) {
-        const int hit = (v[i] > -4.0f) ? 1 : 0;
-        const bool second = woff + rel0 + 8 * i >= kMeTile;
-        c[0] += second ? 0 : hit; c[1] += second ? hit : 0;
+        for (int i = 0; i < kPwLeafM / 8; ++i) v[i] = win[rel0 + 8 * i];
+        const int thr = kMeTile - woff;                    // window positions from thr on lie in the second natural tile
+#pragma unroll
+        for (int i = 0; i < kPwLeafM / 8; ++i) {
+            const unsigned long long hit = __ballot(v[i] > -4.0f), sec = __ballot(rel0 + 8 * i >= thr);
+            cw[0] += __popcll(hit & ~sec); cw[1] += __popcll(hit & sec);
+            if (v[i] < mn) mn = v[i];
+            if (v[i] > mx) mx = v[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kPwLeafM / 8; ++i) v[i] = (rel0 + 8 * i < lim_len) ? win[rel0 + 8 * i] : -5.0f;
+        int c0 = 0, c1 = 0;
+#pragma unroll
+        for (int i = 0; i < kPwLeafM / 8; ++i) {
+            const int hit = (v[i] > -4.0f) ? 1 : 0;
+            const bool second = woff + rel0 + 8 * i >= kMeTile;
+            c0 += second ? 0 : hit; c1 += second ? hit : 0;
+            const float w = (rel0 + 8 * i < lim_L) ? v[i] : first;
+            if (w < mn) mn = w;
+            if (w > mx) mx = w;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o); c1 += __shfl_xor(c1, o); }
+        cw[0] = c0; cw[1] = c1;
     }
     int64_t ha = 0;
     if (a > 0) {                                           // the head [0, a): slice t of nt
@@ -148,21 +175,15 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
         const int hoff = (int)((skip + h0) & (kMeTile - 1));
         const int hn = (int)(h1 > h0 ? h1 - h0 : 0);        // (a slice holds at most a / nt + 1 <= 0.05 * 4096 + 1 samples)
         const float *head = src + h0;
+        int c2 = 0, c3 = 0;
         for (int k = threadIdx.x; k < hn; k += kMeBlock) {
             const int hit = (head[k] > -4.0f) ? 1 : 0;
             const bool second = hoff + k >= kMeTile;
-            c[2] += second ? 0 : hit; c[3] += second ? hit : 0;
+            c2 += second ? 0 : hit; c3 += second ? hit : 0;
         }
-    }
-    // min / max over the elements inside the trimmed range, seeded with its first element (util.minmax: a NaN there stays)
-    const bool any = L > 0 && (int64_t)t.idx * kMeTile < L;
-    const float first = L > 0 ? src[a] : 0.f;
-    float mn = first, mx = first;
 #pragma unroll
-    for (int i = 0; i < kPwLeafM / 8; ++i) {
-        const float w = (rel0 + 8 * i < lim_L) ? v[i] : first;
-        if (w < mn) mn = w;
-        if (w > mx) mx = w;
+        for (int o = 32; o > 0; o >>= 1) { c2 += __shfl_xor(c2, o); c3 += __shfl_xor(c3, o); }
+        cw[2] = c2; cw[3] = c3;
     }
     // leaf sums of the FULL chunks (k_me_leaves, mode 0): accumulator j of the leaf, then ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
     const int64_t n_full_leaves = (L / kPwChunkM) * (kPwChunkM / kPwLeafM);
@@ -175,15 +196,13 @@ __global__ __launch_bounds__(kMeBlock) void k_me_first(const float *x, MsgState 
     me_half_tree(acc, s_h);                                   // (s_h is read behind the barrier below)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) c[k] += __shfl_xor(c[k], o);
         const float u = __shfl_xor(mn, o), w = __shfl_xor(mx, o);
         if (u < mn) mn = u;
         if (w > mx) mx = w;
     }
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s_c[(threadIdx.x >> 6) * 4 + k] = c[k];
+        for (int k = 0; k < 4; ++k) s_c[(threadIdx.x >> 6) * 4 + k] = cw[k];
         s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx;
     }
     __syncthreads();
@@ -1071,8 +1090,26 @@ __global__ __launch_bounds__(64) void k_me_gather_some(const MsgState *st, const
 // workgroup per message counts them in an LDS hash table and appends its (value, count) pairs to a pool -- kilobytes cross PCIe instead
 // of 8 bytes per plateau.  (Messages with glitches need merge_plateaus, which walks the sequence: the host asks for those.)
 constexpr int kLcSlots = 4096, kLcMaxDistinct = 3072;
+// ---- the chained call's (urhgpu_msg_estimate) traffic with the host: message ranges in, one record per message out ----------------
+// Rounds 5-6a moved both stages' MsgState arrays both ways: 352 bytes per message built and copied on the host, uploaded, read back and
+// copied again -- 0.5 MB each way for config 3's 1500 messages, 60-70 us of host time around the kernels.  The states are built ON the
+// device from the uploaded ranges (16 bytes per message), and what the host needs of them comes back as one EstRec per message.
+struct EstRec {
+    double stats[8];         // urhgpu_msg_center_stats' row: kept, L, min, max, mean, var, n_edges, e0
+    double center;           // peak_center
+    int64_t flag;            // peak_flag
+    int64_t n_plateaus, pairs_base, pairs_n;     // stage 2 (k_me_plateaus, k_me_len_counts)
+};
+__device__ __forceinline__ void me_write_rec(EstRec *rec, const MsgState &s1, const MsgState &s2) {
+    EstRec r;
+    r.stats[0] = (double)s1.kept; r.stats[1] = (double)s1.L; r.stats[2] = (double)s1.mn; r.stats[3] = (double)s1.mx; r.stats[4] = (double)s1.mean;
+    r.stats[5] = (double)s1.var; r.stats[6] = (double)s1.n_edges; r.stats[7] = s1.e0;
+    r.center = s1.peak_center; r.flag = s1.peak_flag;
+    r.n_plateaus = s2.n_plateaus; r.pairs_base = s2.pairs_base; r.pairs_n = s2.pairs_n;
+    *rec = r;
+}
 __global__ __launch_bounds__(kMeBlock) void k_me_len_counts(MsgState *st, const int32_t *lengths, unsigned long long *pool_count, uint64_t *pool,
-                                                             int64_t cap_pairs) {
+                                                             int64_t cap_pairs, const MsgState *st1, EstRec *rec) {
     __shared__ int s_key[kLcSlots];                       // length + 1, 0 = empty
     __shared__ unsigned int s_cnt[kLcSlots];
     __shared__ int s_distinct, s_over, s_pos;
@@ -1106,6 +1143,7 @@ __global__ __launch_bounds__(kMeBlock) void k_me_len_counts(MsgState *st, const 
         s_base = base;
         st[m].pairs_base = base;
         st[m].pairs_n = s_over ? -1 : (k > 0 ? s_distinct : 0);
+        if (rec) me_write_rec(rec + m, st1[m], st[m]);       // a chained call: the message's record for the host (urhgpu_msg_estimate)
     }
     __syncthreads();
     if (s_over || k <= 0) return;
@@ -1131,6 +1169,47 @@ __global__ __launch_bounds__(256) void k_me_fill_tiles(const MsgState *st, int n
     tiles[t] = MsgTile{lo, (int32_t)(t - st[lo].first_tile)};
 }
 
+// one workgroup: both stages' states with their first_tile (an exclusive scan of the tile counts over the messages); stage 2 searches
+// [0, percentage % + extra_window) of every message for boundaries
+constexpr int kMeInitBlock = 1024;
+__device__ __forceinline__ int64_t me_tiles_of(int64_t span) { return ((span > 1 ? span : 1) + kMeTile - 1) / kMeTile; }
+__global__ __launch_bounds__(kMeInitBlock) void k_me_init_states(const int64_t *ranges, int n_msgs, int percentage, int64_t extra_window, MsgState *st1,
+                                                                  MsgState *st2) {
+    __shared__ int64_t s_a[kMeInitBlock / 64], s_b[kMeInitBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n_msgs + kMeInitBlock - 1) / kMeInitBlock;
+    const int lo = tid * per, hi = (lo + per < n_msgs) ? lo + per : n_msgs;
+    auto window_of = [&](int64_t len) { const int64_t limit = ((int64_t)percentage * len) / 100; return (len < limit + extra_window) ? len : limit + extra_window; };
+    int64_t a = 0, b = 0;                                    // tiles of this thread's messages: stage 1, stage 2
+    for (int m = lo; m < hi; ++m) {
+        const int64_t len = ranges[2 * m + 1] - ranges[2 * m];
+        a += me_tiles_of(len);
+        b += me_tiles_of(window_of(len));
+    }
+    int64_t ia = a, ib = b;                                  // inclusive scan over the threads
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int64_t ua = __shfl_up(ia, o), ub = __shfl_up(ib, o);
+        if (lane >= o) { ia += ua; ib += ub; }
+    }
+    if (lane == 63) { s_a[wave] = ia; s_b[wave] = ib; }
+    __syncthreads();
+    int64_t fa = ia - a, fb = ib - b;
+    for (int w = 0; w < wave; ++w) { fa += s_a[w]; fb += s_b[w]; }
+    for (int m = lo; m < hi; ++m) {
+        const int64_t start = ranges[2 * m], end = ranges[2 * m + 1], len = end - start;
+        MsgState z;
+        memset(&z, 0, sizeof(z));
+        z.start = start; z.end = end; z.center = __builtin_nan("");
+        z.first_tile = fa; z.window = len;
+        st1[m] = z;
+        z.first_tile = fb; z.window = window_of(len);
+        st2[m] = z;
+        fa += me_tiles_of(len);
+        fb += me_tiles_of(z.window);
+    }
+}
+
 // stage 2's center of a chained call: what the host would hand over -- the picked center as a C float (get_plateau_lengths takes `float
 // center`, auto_interpretation.pyx:179), NaN where stage 1 has none to give (no histogram, more bins than the pool, a tie numpy decides)
 __global__ void k_me_chain_center(const MsgState *st1, MsgState *st2, int n_msgs) {
@@ -1154,18 +1233,19 @@ struct MsgBatch {
 
 // urhgpu_msg_estimate: center statistics and plateau decisions back to back -- the centers stay on the device (k_me_chain_center), the
 // scratch of both stages comes from ONE reservation, the states of both land in the pinned zone behind ONE synchronisation
-// Round 6 (late): the states of both stages, the pool fill and the pool are ONE block of the arena -- [states 1 | states 2 | fill | pairs]
-// -- uploaded with one copy before stage 1 and fetched with one copy behind stage 2 (rounds 5-6a: an upload and a read-back per stage, in
-// the stream between the kernels, and three copies at the end: each with its ~9 us of idle stream around it).
+// Round 6 (late): message ranges up in one small copy, the states built on the device; the records, the pool fill and the first pairs of
+// the pool are ONE block of the arena, fetched with one copy behind stage 2 (rounds 5-6a: an upload and a read-back of the states per
+// stage, in the stream between the kernels, and three copies at the end: each with its ~9 us of idle stream around it).
 struct EstChain {
-    MsgBatch b1, b2;         // the stages' batches (host mirrors filled when the chain's synchronisation has happened)
+    MsgBatch b1, b2;         // the stages' batches: tile counts only (the states are built on the device, k_me_init_states)
     MsgState *d_st1 = nullptr, *d_st2 = nullptr;
+    EstRec *d_rec = nullptr; // [records | pool fill (256 bytes) | pool]: one block, fetched with one copy
     unsigned long long *d_pool_count = nullptr;
     uint64_t *d_pool = nullptr;
     int64_t cap_pairs = 0;
-    size_t st_pad = 0;       // bytes of one stage's states in the block (and in the pinned zone)
-    bool st1_pinned = false;
-    size_t pinned_used = 0;  // bytes of ctx->h_small stage 1's states occupy
+    size_t rec_pad = 0;      // bytes of the records in the block (and where they land)
+    std::vector<char> land;  // landing zone when the context's pinned one is too small
+    const char *landed = nullptr;       // where the block has landed (behind stage 2's synchronisation)
 };
 
 // tile table over [start, start + span_m) of every message; span = whole message (window = nullptr) or the given windows
@@ -1270,7 +1350,7 @@ static int center_stats_batch(urhgpu_ctx *ctx, const float *d_x, int64_t n, cons
         hist.resize((size_t)n_msgs * (size_t)max_bins);
         URH_HIP(hipMemcpyAsync(hist.data(), d_hist, hist.size() * 4, hipMemcpyDeviceToHost, s));
     }
-    URH_HIP(hipStreamSynchronize(s));
+    URH_HIP(wait_stream(ctx, s));
     if (st_pinned) memcpy(b.host.data(), ctx->h_small, st_bytes);
     center_stats_collect(b, n_msgs, max_bins, hist, out_stats, out_hist, out_center, out_flag);
     return URHGPU_OK;
@@ -1354,7 +1434,7 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
     hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
     URH_HIP(hipGetLastError());
     URH_HIP(hipMemcpyAsync(b.host.data(), d_st, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost, s));
-    URH_HIP(hipStreamSynchronize(s));
+    URH_HIP(wait_stream(ctx, s));
     // end offsets; a message whose window was too small has no plateaus here and is marked -(end + 1)
     std::vector<int64_t> begin((size_t)n_msgs);
     int64_t total = 0;
@@ -1375,7 +1455,7 @@ int urhgpu_msg_plateaus(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
         hipLaunchKernelGGL(k_me_gather, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, d_begin, d_out);
         URH_HIP(hipGetLastError());
         URH_HIP(hipMemcpyAsync(out_len, d_out, (size_t)total * 8, hipMemcpyDeviceToHost, s));
-        URH_HIP(hipStreamSynchronize(s));
+        URH_HIP(wait_stream(ctx, s));
     }
     return URHGPU_OK;
 }
@@ -1699,40 +1779,56 @@ static int plateau_decisions_impl(urhgpu_ctx *ctx, const float *d_x, int64_t n, 
     hipLaunchKernelGGL(k_me_tile_scan, dim3(1), dim3(kMeScanBlock), 0, s, d_cnt, b.n_tiles, d_pre, (MsgState *)nullptr, 0, (unsigned int *)nullptr);
     hipLaunchKernelGGL(k_me_edge_compact, dim3(gt), dim3(kMeBlock), 0, s, d_x, d_st, d_tiles, d_pre, d_edges);
     hipLaunchKernelGGL(k_me_plateaus, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, percentage);
-    hipLaunchKernelGGL(k_me_len_counts, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_edges, d_pool_count, d_pool, cap_pairs);
+    hipLaunchKernelGGL(k_me_len_counts, dim3((unsigned)n_msgs), dim3(kMeBlock), 0, s, d_st, d_edges, d_pool_count, d_pool, cap_pairs,
+                       chain ? (const MsgState *)chain->d_st1 : (const MsgState *)nullptr, chain ? chain->d_rec : (EstRec *)nullptr);
     URH_HIP(hipGetLastError());
-    // states, pool fill and (speculatively) the first pairs of the pool land in the context's pinned zone in ONE round trip when they fit
+    // states (a chained call: records), pool fill and (speculatively) the first pairs of the pool land in the context's pinned zone in ONE
+    // round trip when they fit
+    struct PlateauRes { int64_t n_plateaus, pairs_base, pairs_n; };
+    std::vector<PlateauRes> res((size_t)n_msgs);
     unsigned long long pool_used = 0;
-    const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState), st_pad = (st_bytes + 255) & ~size_t(255);
-    const size_t zone0 = chain ? st_pad : 0;                 // (a chained call: stage 1's states lie in front -- in the block and in the zone)
-    const bool pinned = ctx->h_small && zone0 + st_pad + 256 + 4096 <= kSmallPinned;
-    char *zone = pinned ? ctx->h_small + zone0 : nullptr;
-    const int64_t spec_pairs = pinned ? std::min<int64_t>(std::min<int64_t>(cap_pairs, 8192), (int64_t)((kSmallPinned - zone0 - st_pad - 256) / 16)) : 0;
-    if (chain && pinned) {                                   // [states 1 | states 2 | fill | the first pairs]: one copy
-        URH_HIP(hipMemcpyAsync(ctx->h_small, chain->d_st1, 2 * st_pad + 256 + (size_t)spec_pairs * 16, hipMemcpyDeviceToHost, s));
-        chain->st1_pinned = true;
+    const char *l_pairs = nullptr;
+    int64_t spec_pairs = 0;
+    if (chain) {
+        const size_t head = chain->rec_pad + 256;
+        const bool pinned = ctx->h_small && head + 4096 <= kSmallPinned;
+        spec_pairs = std::min<int64_t>(cap_pairs, 8192);
+        if (pinned) spec_pairs = std::min<int64_t>(spec_pairs, (int64_t)((kSmallPinned - head) / 16));
+        else chain->land.resize(head + (size_t)spec_pairs * 16);
+        char *land = pinned ? ctx->h_small : chain->land.data();
+        URH_HIP(hipMemcpyAsync(land, chain->d_rec, head + (size_t)spec_pairs * 16, hipMemcpyDeviceToHost, s));
+        URH_HIP(wait_stream(ctx, s));
+        chain->landed = land;
+        const EstRec *rec = (const EstRec *)land;
+        for (int m = 0; m < n_msgs; ++m) res[(size_t)m] = PlateauRes{rec[m].n_plateaus, rec[m].pairs_base, rec[m].pairs_n};
+        memcpy(&pool_used, land + chain->rec_pad, 8);
+        l_pairs = land + head;
     } else {
+        const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState), st_pad = (st_bytes + 255) & ~size_t(255);
+        const bool pinned = ctx->h_small && st_pad + 256 + 4096 <= kSmallPinned;
+        char *zone = pinned ? ctx->h_small : nullptr;
+        spec_pairs = pinned ? std::min<int64_t>(std::min<int64_t>(cap_pairs, 8192), (int64_t)((kSmallPinned - st_pad - 256) / 16)) : 0;
         URH_HIP(hipMemcpyAsync(pinned ? (void *)zone : (void *)b.host.data(), d_st, st_bytes, hipMemcpyDeviceToHost, s));
         URH_HIP(hipMemcpyAsync(pinned ? (void *)(zone + st_pad) : (void *)&pool_used, d_pool_count, 8, hipMemcpyDeviceToHost, s));
         if (spec_pairs > 0) URH_HIP(hipMemcpyAsync(zone + st_pad + 256, d_pool, (size_t)spec_pairs * 16, hipMemcpyDeviceToHost, s));
+        URH_HIP(wait_stream(ctx, s));
+        if (pinned) { memcpy(b.host.data(), zone, st_bytes); memcpy(&pool_used, zone + st_pad, 8); l_pairs = zone + st_pad + 256; }
+        for (int m = 0; m < n_msgs; ++m) res[(size_t)m] = PlateauRes{b.host[(size_t)m].n_plateaus, b.host[(size_t)m].pairs_base, b.host[(size_t)m].pairs_n};
     }
-    URH_HIP(hipStreamSynchronize(s));
-    if (pinned) { memcpy(b.host.data(), zone, st_bytes); memcpy(&pool_used, zone + st_pad, 8); }
-    if (chain && chain->st1_pinned) memcpy(chain->b1.host.data(), ctx->h_small, (size_t)n_msgs * sizeof(MsgState));
     std::vector<uint64_t> pool((size_t)std::min<unsigned long long>(pool_used, (unsigned long long)cap_pairs) * 2);
     if (!pool.empty()) {
         const size_t have = std::min<size_t>(pool.size() / 2, (size_t)spec_pairs);
-        if (have > 0) memcpy(pool.data(), zone + st_pad + 256, have * 16);
+        if (have > 0) memcpy(pool.data(), l_pairs, have * 16);
         if (pool.size() / 2 > have) {
             URH_HIP(hipMemcpyAsync(pool.data() + 2 * have, d_pool + 2 * have, (pool.size() / 2 - have) * 16, hipMemcpyDeviceToHost, s));
-            URH_HIP(hipStreamSynchronize(s));
+            URH_HIP(wait_stream(ctx, s));
         }
     }
     // messages decided from their multiset; the rest need their sequences
     std::vector<int64_t> begin((size_t)n_msgs, -1);
     int64_t total = 0;
     for (int m = 0; m < n_msgs; ++m) {
-        const MsgState &st = b.host[(size_t)m];
+        const PlateauRes &st = res[(size_t)m];
         const int64_t k = st.n_plateaus;
         if (k < 0) { tol_out[m] = -3; bitlen_out[m] = -3; continue; }
         bool need_seq = st.pairs_n < 0;
@@ -1762,13 +1858,13 @@ static int plateau_decisions_impl(urhgpu_ctx *ctx, const float *d_x, int64_t n, 
         hipLaunchKernelGGL(k_me_gather_some, dim3((unsigned)n_msgs), dim3(64), 0, s, d_st, d_edges, d_begin, d_out);
         URH_HIP(hipGetLastError());
         URH_HIP(hipMemcpyAsync(lens.data(), d_out, (size_t)total * 8, hipMemcpyDeviceToHost, s));
-        URH_HIP(hipStreamSynchronize(s));
+        URH_HIP(wait_stream(ctx, s));
         std::vector<int> todo;
         for (int m = 0; m < n_msgs; ++m) if (begin[(size_t)m] >= 0) todo.push_back(m);
         auto one = [&](int j) {
             const int m = todo[(size_t)j];
             std::vector<uint64_t> merged;
-            if (!merged_lengths(lens.data() + begin[(size_t)m], b.host[(size_t)m].n_plateaus, &tol_out[m], merged)) { bitlen_out[m] = -2; return; }
+            if (!merged_lengths(lens.data() + begin[(size_t)m], res[(size_t)m].n_plateaus, &tol_out[m], merged)) { bitlen_out[m] = -2; return; }
             bitlen_out[m] = merged.size() < 2 ? -1 : bit_length_of(merged);
         };
         host_pool_run((int)todo.size(), todo.size() >= 16 ? 24 : 1, one);
@@ -1802,33 +1898,41 @@ int urhgpu_msg_estimate(urhgpu_ctx *ctx, const float *d_x, int64_t n, const int6
     const size_t need1 = (size_t)n_msgs * sizeof(MsgState) + (tiles_max + 1) * (sizeof(MsgTile) + 4 + 8 + 8 + 4 + kLeavesPerTile * 4) + (size_t)n * 4 +
                          (size_t)n_msgs * (size_t)max_bins * 4 + (size_t)n_msgs * 4 + 18 * 256;
     const size_t need2 = (size_t)n_msgs * sizeof(MsgState) + (tiles_max + 1) * (sizeof(MsgTile) + 4 + 8) + (size_t)std::max<int64_t>(n, 1) * 4 + (size_t)cap_pairs * 16 + 10 * 256;
-    URH_TRY(ctx->arena.reserve(need1 + need2 + 4096));
+    URH_TRY(ctx->arena.reserve(need1 + need2 + (size_t)n_msgs * (sizeof(EstRec) + 16) + 8192));
     ctx->arena.reset();
     EstChain chain;
-    URH_TRY(build_batch(ctx, ranges, n_msgs, n, nullptr, chain.b1));
-    URH_TRY(plateau_batch(ctx, ranges, n_msgs, n, percentage, extra_window, chain.b2));       // (center NaN: k_me_chain_center hands stage 1's over)
-    const size_t st_bytes = (size_t)n_msgs * sizeof(MsgState);
-    chain.st_pad = (st_bytes + 255) & ~size_t(255);
-    chain.cap_pairs = cap_pairs;
-    char *blk = (char *)ctx->arena.take(2 * chain.st_pad + 256 + (size_t)cap_pairs * 16);
-    if (!blk) return URHGPU_ERR_ARG;
-    chain.d_st1 = (MsgState *)blk; chain.d_st2 = (MsgState *)(blk + chain.st_pad);
-    chain.d_pool_count = (unsigned long long *)(blk + 2 * chain.st_pad); chain.d_pool = (uint64_t *)(blk + 2 * chain.st_pad + 256);
-    if (ctx->h_small && 2 * chain.st_pad <= kSmallPinned) {  // both stages' states in ONE upload, out of the pinned zone
-        memcpy(ctx->h_small, chain.b1.host.data(), st_bytes);
-        memcpy(ctx->h_small + chain.st_pad, chain.b2.host.data(), st_bytes);
-        URH_HIP(hipMemcpyAsync(blk, ctx->h_small, chain.st_pad + st_bytes, hipMemcpyHostToDevice, ctx->stream));
-    } else {
-        URH_HIP(hipMemcpyAsync(chain.d_st1, chain.b1.host.data(), st_bytes, hipMemcpyHostToDevice, ctx->stream));
-        URH_HIP(hipMemcpyAsync(chain.d_st2, chain.b2.host.data(), st_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // the host's part of the batches: the ranges checked (build_batch's rules), the tile counts of both stages
+    int64_t nt1 = 0, nt2 = 0;
+    for (int m = 0; m < n_msgs; ++m) {
+        const int64_t s0 = ranges[2 * m], e0 = ranges[2 * m + 1], len = e0 - s0;
+        if (s0 < 0 || e0 < s0 || e0 > n || (m > 0 && s0 < ranges[2 * m - 1])) return URHGPU_ERR_ARG;
+        if (len > INT32_MAX) return URHGPU_ERR_UNSUPPORTED;       // positions inside a message are 32-bit
+        const int64_t limit = ((int64_t)percentage * len) / 100, window = std::min<int64_t>(len, limit + extra_window);
+        nt1 += (std::max<int64_t>(len, 1) + kMeTile - 1) / kMeTile;
+        nt2 += (std::max<int64_t>(window, 1) + kMeTile - 1) / kMeTile;
     }
+    chain.b1.n_tiles = nt1; chain.b2.n_tiles = nt2;
+    chain.cap_pairs = cap_pairs;
+    chain.rec_pad = ((size_t)n_msgs * sizeof(EstRec) + 255) & ~size_t(255);
+    char *blk = (char *)ctx->arena.take(chain.rec_pad + 256 + (size_t)cap_pairs * 16);
+    chain.d_st1 = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
+    chain.d_st2 = (MsgState *)ctx->arena.take((size_t)n_msgs * sizeof(MsgState));
+    int64_t *d_ranges = (int64_t *)ctx->arena.take((size_t)n_msgs * 16);
+    if (!blk || !chain.d_st1 || !chain.d_st2 || !d_ranges) return URHGPU_ERR_ARG;
+    chain.d_rec = (EstRec *)blk;
+    chain.d_pool_count = (unsigned long long *)(blk + chain.rec_pad); chain.d_pool = (uint64_t *)(blk + chain.rec_pad + 256);
+    const void *up = ranges;
+    if (ctx->h_small && (size_t)n_msgs * 16 <= kSmallPinned) { memcpy(ctx->h_small, ranges, (size_t)n_msgs * 16); up = ctx->h_small; }     // (a truly asynchronous copy)
+    URH_HIP(hipMemcpyAsync(d_ranges, up, (size_t)n_msgs * 16, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_me_init_states, dim3(1), dim3(kMeInitBlock), 0, ctx->stream, d_ranges, n_msgs, percentage, extra_window, chain.d_st1, chain.d_st2);
     URH_TRY(center_stats_batch(ctx, d_x, n, ranges, n_msgs, max_bins, out_stats, nullptr, out_center, out_flag, &chain));
     URH_TRY(plateau_decisions_impl(ctx, d_x, n, ranges, nullptr, n_msgs, percentage, extra_window, tol_out, bitlen_out, &chain));
-    if (!chain.st1_pinned) {                                 // (states too many for the pinned zone: fetched now)
-        URH_HIP(hipMemcpy(chain.b1.host.data(), chain.d_st1, (size_t)n_msgs * sizeof(MsgState), hipMemcpyDeviceToHost));
+    const EstRec *rec = (const EstRec *)chain.landed;
+    for (int m = 0; m < n_msgs; ++m) {
+        memcpy(out_stats + 8 * (size_t)m, rec[m].stats, 64);
+        out_center[m] = rec[m].center;
+        out_flag[m] = (int32_t)rec[m].flag;
     }
-    std::vector<unsigned int> none;
-    center_stats_collect(chain.b1, n_msgs, max_bins, none, out_stats, nullptr, out_center, out_flag);
     for (int m = 0; m < n_msgs; ++m)
         if (out_flag[m] == 2 || out_flag[m] == 3) { tol_out[m] = -4; bitlen_out[m] = -4; }
     return URHGPU_OK;

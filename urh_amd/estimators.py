@@ -155,8 +155,8 @@ def message_ranges_dev(pipe, iq, noise_threshold: float, merge: bool = True, cap
     mrg = np.empty((cap_merged, 2), np.int64) if merge else None
     n_seg, n_mrg, amb = C.c_int64(0), C.c_int64(0), C.c_int(0)
     args = (pipe.ctx.handle, C.c_void_p(iq.data_ptr()), dtype_code(_torch_dtype(iq)), n, float(noise_threshold),
-            seg.ctypes.data_as(C.c_void_p), cap_seg, C.byref(n_seg),
-            mrg.ctypes.data_as(C.c_void_p) if merge else None, cap_merged if merge else 0, C.byref(n_mrg) if merge else None, C.byref(amb))
+            C.c_void_p(seg.ctypes.data), cap_seg, C.byref(n_seg),
+            C.c_void_p(mrg.ctypes.data) if merge else None, cap_merged if merge else 0, C.byref(n_mrg) if merge else None, C.byref(amb))
     if qad_ask is not None:
         if qad_ask.dtype != torch.float32 or qad_ask.numel() != n or not qad_ask.is_contiguous():
             raise ValueError("qad_ask: contiguous float32 tensor with one element per sample")
@@ -356,8 +356,8 @@ def merge_plateaus(plateaus, tolerance, max_count=10000) -> np.ndarray:
     p = np.ascontiguousarray(plateaus, dtype=np.uint64)
     out = np.empty(len(p), dtype=np.uint64)
     n_out = C.c_int64(0)
-    _lib.check(_lib.load().urhgpu_merge_plateaus(p.ctypes.data_as(C.c_void_p), len(p), int(tolerance), int(max_count),
-                                                 out.ctypes.data_as(C.c_void_p), C.byref(n_out)))
+    _lib.check(_lib.load().urhgpu_merge_plateaus(C.c_void_p(p.ctypes.data), len(p), int(tolerance), int(max_count),
+                                                 C.c_void_p(out.ctypes.data), C.byref(n_out)))
     return out[:n_out.value]
 
 
@@ -380,8 +380,8 @@ def detect_modulation_dev(pipe, iq, message_indices, wavelet_scale=4, median_fil
     variances = np.zeros((max(n_msgs, 1), 4), dtype=np.float64)
     pipe.ctx.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
     _lib.check(_lib.load().urhgpu_detect_modulation_dev(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]),
-                                                        ranges.ctypes.data_as(C.c_void_p), n_msgs, int(wavelet_scale), int(median_filter_order),
-                                                        labels.ctypes.data_as(C.c_void_p), variances.ctypes.data_as(C.c_void_p)))
+                                                        C.c_void_p(ranges.ctypes.data), n_msgs, int(wavelet_scale), int(median_filter_order),
+                                                        C.c_void_p(labels.ctypes.data), C.c_void_p(variances.ctypes.data)))
     out = [_MOD_LABELS[int(v)] for v in labels[:n_msgs]]
     return (out, variances[:n_msgs]) if return_variances else out
 
@@ -423,9 +423,9 @@ def centers_array(pipe, data, message_indices, max_bins: int = 4096) -> np.ndarr
     cen = np.zeros(n_msgs, dtype=np.float64)
     flag = np.zeros(n_msgs, dtype=np.int32)
     lib = _lib.load()
-    _lib.check(lib.urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
-                                           n_msgs, max_bins, stats.ctypes.data_as(C.c_void_p), None, cen.ctypes.data_as(C.c_void_p),
-                                           flag.ctypes.data_as(C.c_void_p)))
+    _lib.check(lib.urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), C.c_void_p(ranges.ctypes.data),
+                                           n_msgs, max_bins, C.c_void_p(stats.ctypes.data), None, C.c_void_p(cen.ctypes.data),
+                                           C.c_void_p(flag.ctypes.data)))
     return _settle_centers(pipe, x, ranges, cen, flag, max_bins)
 
 
@@ -444,9 +444,9 @@ def centers_and_decisions(pipe, data, message_indices, percentage: int = 25, max
     flag = np.zeros(n_msgs, dtype=np.int32)
     tol = np.zeros(n_msgs, dtype=np.int64)
     bl = np.zeros(n_msgs, dtype=np.int64)
-    st = _lib.load().urhgpu_msg_estimate(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p), n_msgs, max_bins,
-                                         int(percentage), 1 << 16, stats.ctypes.data_as(C.c_void_p), cen.ctypes.data_as(C.c_void_p),
-                                         flag.ctypes.data_as(C.c_void_p), tol.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p))
+    st = _lib.load().urhgpu_msg_estimate(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), C.c_void_p(ranges.ctypes.data), n_msgs, max_bins,
+                                         int(percentage), 1 << 16, C.c_void_p(stats.ctypes.data), C.c_void_p(cen.ctypes.data),
+                                         C.c_void_p(flag.ctypes.data), C.c_void_p(tol.ctypes.data), C.c_void_p(bl.ctypes.data))
     if st == _lib.ERR_UNSUPPORTED:
         centers = centers_array(pipe, x, ranges, max_bins)
         t2, b2 = _plateau_decisions(pipe, x, ranges, centers.astype(np.float32).astype(np.float64), percentage)
@@ -478,8 +478,8 @@ def _settle_centers(pipe, x, ranges, cen, flag, max_bins):
         tr = np.ascontiguousarray(ranges[tie])
         tstats = np.zeros((len(tie), 8), dtype=np.float64)
         hist = np.zeros((len(tie), max_bins), dtype=np.int64)
-        _lib.check(lib.urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), tr.ctypes.data_as(C.c_void_p),
-                                               len(tie), max_bins, tstats.ctypes.data_as(C.c_void_p), hist.ctypes.data_as(C.c_void_p), None, None))
+        _lib.check(lib.urhgpu_msg_center_stats(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), C.c_void_p(tr.ctypes.data),
+                                               len(tie), max_bins, C.c_void_p(tstats.ctypes.data), C.c_void_p(hist.ctypes.data), None, None))
         for k, m in enumerate(tie.tolist()):
             n_edges = int(tstats[k, 6])
             hist_min, hist_max, step = float(tstats[k, 2]), float(tstats[k, 3]), float(tstats[k, 5])
@@ -504,9 +504,9 @@ def _plateaus_raw(pipe, x, ranges, cen, percentage):
     lib = _lib.load()
     while True:
         lens = np.empty(cap, dtype=np.uint64)
-        st = lib.urhgpu_msg_plateaus(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p),
-                                     cen.ctypes.data_as(C.c_void_p), n_msgs, int(percentage), 1 << 16, off.ctypes.data_as(C.c_void_p),
-                                     lens.ctypes.data_as(C.c_void_p), cap)
+        st = lib.urhgpu_msg_plateaus(pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), C.c_void_p(ranges.ctypes.data),
+                                     C.c_void_p(cen.ctypes.data), n_msgs, int(percentage), 1 << 16, C.c_void_p(off.ctypes.data),
+                                     C.c_void_p(lens.ctypes.data), cap)
         if st == _lib.ERR_CAPACITY:
             cap = int(off[n_msgs])
             continue
@@ -521,8 +521,8 @@ def _plateau_decisions(pipe, x, ranges, cen, percentage):
     tol = np.zeros(n_msgs, dtype=np.int64)
     bl = np.zeros(n_msgs, dtype=np.int64)
     _lib.check(_lib.load().urhgpu_msg_plateau_decisions(
-        pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), ranges.ctypes.data_as(C.c_void_p), cen.ctypes.data_as(C.c_void_p),
-        n_msgs, int(percentage), 1 << 16, tol.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p)))
+        pipe.ctx.handle, C.c_void_p(x.data_ptr()), int(x.shape[0]), C.c_void_p(ranges.ctypes.data), C.c_void_p(cen.ctypes.data),
+        n_msgs, int(percentage), 1 << 16, C.c_void_p(tol.ctypes.data), C.c_void_p(bl.ctypes.data)))
     return tol, bl
 
 
@@ -556,16 +556,16 @@ def _bit_length_with_numpy_order(plateau_lengths):
     lib = _lib.load()
     p = np.ascontiguousarray(plateau_lengths, dtype=np.uint64)
     hist_len, tol = C.c_int64(0), C.c_int64(0)
-    _lib.check(lib.urhgpu_msg_divisor_histogram(p.ctypes.data_as(C.c_void_p), len(p), None, 0, C.byref(hist_len), C.byref(tol)))
+    _lib.check(lib.urhgpu_msg_divisor_histogram(C.c_void_p(p.ctypes.data), len(p), None, 0, C.byref(hist_len), C.byref(tol)))
     tolerance = None if tol.value < 0 else tol.value
     if hist_len.value < 0:
         return tolerance, None
     hist = np.zeros(hist_len.value, dtype=np.uint64)
-    _lib.check(lib.urhgpu_msg_divisor_histogram(p.ctypes.data_as(C.c_void_p), len(p), hist.ctypes.data_as(C.c_void_p), len(hist),
+    _lib.check(lib.urhgpu_msg_divisor_histogram(C.c_void_p(p.ctypes.data), len(p), C.c_void_p(hist.ctypes.data), len(hist),
                                                 C.byref(hist_len), C.byref(tol)))
     order = np.ascontiguousarray(np.argsort(hist)[::-1], dtype=np.int64)
     out = C.c_int64(0)
-    _lib.check(lib.urhgpu_bit_length_from_order(hist.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p), len(hist), C.byref(out)))
+    _lib.check(lib.urhgpu_bit_length_from_order(C.c_void_p(hist.ctypes.data), C.c_void_p(order.ctypes.data), len(hist), C.byref(out)))
     return tolerance, out.value
 
 
@@ -582,8 +582,8 @@ def _bit_lengths_raw(lens, off, plateaus_of):
     tol = np.zeros(n_msgs, dtype=np.int64)
     bl = np.zeros(n_msgs, dtype=np.int64)
     lens = lens if len(lens) else np.zeros(1, np.uint64)
-    _lib.check(_lib.load().urhgpu_msg_bit_lengths(lens.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), n_msgs,
-                                                  tol.ctypes.data_as(C.c_void_p), bl.ctypes.data_as(C.c_void_p)))
+    _lib.check(_lib.load().urhgpu_msg_bit_lengths(C.c_void_p(lens.ctypes.data), C.c_void_p(off.ctypes.data), n_msgs,
+                                                  C.c_void_p(tol.ctypes.data), C.c_void_p(bl.ctypes.data)))
     out = [(None if t < 0 else t, None if b < 0 else b) for t, b in zip(tol.tolist(), bl.tolist())]
     for m in np.nonzero((bl == -2) | (tol == -2))[0].tolist():
         out[m] = _bit_length_with_numpy_order(np.array(plateaus_of(m), dtype=np.uint64))

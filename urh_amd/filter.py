@@ -74,8 +74,8 @@ def apply_bandpass_filter(data, f_low, f_high, filter_bw=0.08, ctx=None) -> np.n
     if n_out == 0:
         return out
     ctx = ctx or _lib.default_context()
-    _lib.check(_lib.load().urhgpu_bandpass(ctx.handle, x.ctypes.data_as(C.c_void_p), len(x), h.ctypes.data_as(C.c_void_p), len(h),
-                                           shift, n_out, out.ctypes.data_as(C.c_void_p)))
+    _lib.check(_lib.load().urhgpu_bandpass(ctx.handle, C.c_void_p(x.ctypes.data), len(x), C.c_void_p(h.ctypes.data), len(h),
+                                           shift, n_out, C.c_void_p(out.ctypes.data)))
     return out
 
 

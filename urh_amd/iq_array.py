@@ -222,7 +222,7 @@ def export_to_sub(data, filename: str, frequency=433920000, preset="FuriHalSubGh
     cap = max(n, 1)
     runs = np.zeros(cap, dtype=np.int64)
     n_runs = C.c_int64(0)
-    _lib.check(lib.urhgpu_sub_encode_runs(flat.ctypes.data_as(C.c_void_p), n, stride, runs.ctypes.data_as(C.c_void_p), cap, C.byref(n_runs)))
+    _lib.check(lib.urhgpu_sub_encode_runs(C.c_void_p(flat.ctypes.data), n, stride, C.c_void_p(runs.ctypes.data), cap, C.byref(n_runs)))
     arr = runs[:n_runs.value].tolist()
     with open(filename, "w") as subfile:
         subfile.write("Filetype: Flipper SubGhz RAW File\n")

@@ -28,8 +28,8 @@ def _minmax(samples, start, end, spp, ctx):
         if a.dtype not in _DT:
             raise ValueError("Unsupported dtype")
         values = np.zeros(2 * pixels, dtype=a.dtype)
-        _lib.check(lib.urhgpu_path_minmax(ctx.handle, a.ctypes.data_as(C.c_void_p), _DT[a.dtype], len(a), start, end, spp,
-                                          values.ctypes.data_as(C.c_void_p)))
+        _lib.check(lib.urhgpu_path_minmax(ctx.handle, C.c_void_p(a.ctypes.data), _DT[a.dtype], len(a), start, end, spp,
+                                          C.c_void_p(values.ctypes.data)))
         return values
     import torch                                     # device-resident signal
     from .pipeline import _torch_dtype

@@ -60,7 +60,7 @@ def _iq(samples) -> np.ndarray:
 
 
 def _vp(a: np.ndarray):
-    return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(a.ctypes.data)
 
 
 def afp_demod(samples, noise_mag: float, mod_type: str, mod_order: int, costas_loop_bandwidth: float = 0.1,
