@@ -578,6 +578,47 @@ def test_wide_deviation_reduced_argument_path(pipe, oracle, dtype):
             assert np.array_equal(res.ppseq(), pp), (step, sigma, noise)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.int16, np.int8, np.uint8])
+def test_wide_loop_every_angle_and_mode_switches(pipe, oracle, dtype):
+    """The batch-level wide loop of the hot kernel (fsk_wide: fdlibm's argument reduction for a whole batch, entered by a batch the fast
+    loop flags, left after four batches that one would have taken or by a batch outside its window): phase steps in every range of
+    atanf's reduction and beyond pi/2 (re < 0: pi - (z - pi_lo)), stretches of narrow and wide steps in turn (the loops hand over in
+    both directions), pauses and exact zeros inside wide stretches (the wide window fails: generic step, then back), and -- integer
+    samples -- exactly zero cross products with re < 0 (atan2f(+-0, re < 0) = +-pi with the sign of the reference's product)."""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    rng = np.random.default_rng(29)
+    n = 600_000
+    steps = np.concatenate([rng.choice([-s, s], 1500) for s in (0.1, 0.45, 0.1, 0.6, 0.9, 0.2, 1.4, 1.7, 0.05, 2.2, 2.9, 3.1, 0.3, 1.0)])
+    ph = np.cumsum(np.resize(steps.repeat(40), n))
+    amp = np.ones(n)
+    amp[150_000:150_700] = 0.0                                           # exact zeros inside a wide stretch
+    amp[330_000:333_000] = 0.02                                          # a pause below the noise threshold of the second pass
+    x = np.stack([amp * np.cos(ph), amp * np.sin(ph)], 1) + 0.02 * rng.standard_normal((n, 2)) * (amp[:, None] > 0)
+    if dtype == np.float32:
+        iq = x.astype(np.float32)
+        iq[400_000:400_256] = np.tile(np.array([[0.5, 0.25], [-0.5, -0.25]], np.float32), (128, 1))     # im == 0 exactly, re < 0: +-pi
+        scale = 1.0
+    else:
+        info = np.iinfo(dtype)
+        scale = 0.3 * (info.max - info.min) / 2 if dtype != np.int8 else 9.0     # int8 at a small amplitude: many exactly zero cross products
+        mid = (info.max + info.min + 1) // 2 if dtype == np.uint8 else 0
+        iq = np.clip(np.round(x * scale) + mid, info.min, info.max).astype(dtype)
+        k = np.array([[5, 3], [-5, -3], [-10, -6], [10, 6], [0, 7], [0, -7]])
+        iq[400_000:400_000 + 6 * 40] = (np.tile(k, (40, 1)) + mid).astype(dtype)
+    zero_back = 0
+    for noise in (0.0, 0.1 * scale):
+        p = DemodParams("FSK", 1, noise, 0.0, 1.0, 3, 40, 0.1, 8, True)
+        qad = oracle.afp_demod(iq, noise, "FSK", 2)
+        pp = oracle.grab_pulse_lens(qad, 0.0, 3, "FSK", 40, 1, 1.0)
+        res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True, cap_rows=n // 4 + 2)
+        got = res.qad.cpu().numpy()
+        assert bits_equal(got, qad), (noise, int((got.view(np.uint32) != qad.view(np.uint32)).sum()), np.nonzero(got.view(np.uint32) != qad.view(np.uint32))[0][:8])
+        assert np.array_equal(res.ppseq(), pp), noise
+        zero_back = max(zero_back, int((np.abs(qad) == np.float32(np.pi)).sum()))
+    assert dtype == np.uint8 or zero_back > 50                           # +-pi from exactly zero cross products behind: exercised (unsigned samples are not centred: re > 0)
+
+
 @pytest.mark.parametrize("bps", [1, 2])
 def test_many_huge_rows_expand(pipe, oracle, bps):
     """300 constant stretches of 4 500-9 000 symbols each (rows of more than 4096 bits go to k_expand_huge's work list, more

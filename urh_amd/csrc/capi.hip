@@ -30,9 +30,6 @@ void Arena::release() {
     if (base) { (void)hipFree(base); base = nullptr; cap = 0; used = 0; }
 }
 
-// pipelined mode: make the caller's stream wait for the tail of the last pass (no host blocking).  Every entry point that takes
-// scratch from ctx->arena or launches on ctx->stream calls this first: on a pipelined context the arena is the one the last pass's
-// tail may still be working in.
 hipError_t wait_stream(const urhgpu_ctx *ctx, hipStream_t s) {
     if (ctx->tune_spin_wait) {
         const auto t0 = std::chrono::steady_clock::now();
@@ -45,6 +42,9 @@ hipError_t wait_stream(const urhgpu_ctx *ctx, hipStream_t s) {
     }
     return hipStreamSynchronize(s);
 }
+// pipelined mode: make the caller's stream wait for the tail of the last pass (no host blocking).  Every entry point that takes
+// scratch from ctx->arena or launches on ctx->stream calls this first: on a pipelined context the arena is the one the last pass's
+// tail may still be working in.
 int join_tail(urhgpu_ctx *ctx) {
     if (ctx->tail_pending) {
         URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tail[(ctx->flip + 2) % 3], 0));       // the pass recorded last
@@ -777,6 +777,8 @@ int urhgpu_ctx_destroy(urhgpu_ctx *ctx) {
     ctx->arena.release();
     ctx->staging.release();
     ctx->aux.release();
+    ctx->fir_work.release();
+    if (ctx->ev_fir) (void)hipEventDestroy(ctx->ev_fir);
     ctx->arena_alt.release();
     ctx->arena_alt2.release();
     if (ctx->hot_masked) { (void)hipStreamSynchronize(ctx->hot_masked); (void)hipStreamDestroy(ctx->hot_masked); }
@@ -2267,17 +2269,31 @@ int urhgpu_ppseq_to_bits(urhgpu_ctx *ctx, const int64_t *rows, int64_t n_rows, i
     return URHGPU_OK;
 }
 
+// the FIR's own work area: one per context; a filter on another stream than the last one's waits for that one first
+static int fir_work_area(urhgpu_ctx *ctx, size_t bytes, void **work) {
+    if (!ctx->ev_fir) URH_HIP(hipEventCreateWithFlags(&ctx->ev_fir, hipEventDisableTiming));
+    else if (ctx->fir_stream != ctx->stream || bytes + 1024 > ctx->fir_work.cap) URH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fir, 0));
+    if (bytes + 1024 > ctx->fir_work.cap && ctx->fir_work.cap > 0) URH_HIP(hipEventSynchronize(ctx->ev_fir));      // (growing frees the old area)
+    URH_TRY(ctx->fir_work.reserve(bytes + 1024));
+    ctx->fir_work.reset();
+    *work = ctx->fir_work.take(bytes);
+    ctx->fir_stream = ctx->stream;
+    return *work ? URHGPU_OK : URHGPU_ERR_ARG;
+}
+
 int urhgpu_fir_filter_dev(urhgpu_ctx *ctx, const float *d_x, int64_t n, const float *d_taps, int64_t m,
                           const float *d_left_halo, float *d_out) {
     if (!ctx || n < 0 || m < 0 || (n > 0 && (!d_x || !d_out)) || (m > 0 && !d_taps)) return URHGPU_ERR_ARG;
     if (((uintptr_t)d_x & 7) || ((uintptr_t)d_out & 15) || ((uintptr_t)d_taps & 7) || m > (int64_t)1 << 20) return URHGPU_ERR_ARG;
     URH_HIP(hipSetDevice(ctx->device));
-    URH_TRY(join_tail(ctx));
-    URH_TRY(ctx->arena.reserve(fir_work_bytes(n, (int)m) + 1024));
-    ctx->arena.reset();
-    void *work = ctx->arena.take(fir_work_bytes(n, (int)m));
-    if (!work) return URHGPU_ERR_ARG;
+    // The filter's work area (padded taps + the list of tiles handed back: kilobytes) is the context's own, not the rotating arena: on a
+    // pipelined context the filter of capture i + 1 then runs BESIDE the tail of pass i instead of behind it (the FIR-halo variant of
+    // configs[3] paid filter + hot kernel + tail per step).  The caller's stream is already ordered behind the last pass's HOT kernel
+    // (digitize / shard_launch make it wait for that kernel's event), which is what d_out may alias: the capture that kernel read.
+    void *work = nullptr;
+    URH_TRY(fir_work_area(ctx, fir_work_bytes(n, (int)m), &work));
     URH_TRY(launch_fir((const float2 *)d_x, n, (const float2 *)d_taps, (int)m, (const float2 *)d_left_halo, (float2 *)d_out, ctx->stream, work));
+    URH_HIP(hipEventRecord(ctx->ev_fir, ctx->stream));
     URH_HIP(hipGetLastError());
     return URHGPU_OK;
 }

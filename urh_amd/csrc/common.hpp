@@ -77,6 +77,9 @@ struct urhgpu_ctx {
     urh::Arena arena;        // per-call scratch (tables, slabs, scan partials)
     urh::Arena staging;      // device mirrors of host buffers for the host-pointer entry points
     urh::Arena aux;          // Costas candidate / checkpoint states (lives across the arena / staging users)
+    urh::Arena fir_work;     // urhgpu_fir_filter_dev's padded taps + tile list (its own: the filter does not wait for a pipelined pass's tail)
+    hipEvent_t ev_fir = nullptr;       // behind the last filter that used fir_work, on fir_stream
+    hipStream_t fir_stream = nullptr;
     int64_t *d_counts = nullptr;   // small device result block (8 x int64)
     int64_t *h_counts = nullptr;   // pinned host mirror
     bool tune_spin_wait = true;    // wait_stream polls (see there)

@@ -300,19 +300,37 @@ __device__ __forceinline__ AtanRow *atan_table() {
     __shared__ __attribute__((aligned(32))) AtanRow s_atan[5];
     return s_atan;
 }
+__device__ __forceinline__ AtanRow atan_row_of(int k) {
+    AtanRow r;
+    r.a = (k == 1) ? 2.0f : ((k == 4) ? 0.0f : 1.0f);
+    r.b = (k == 0) ? 0.0f : ((k == 3) ? -1.5f : -1.0f);
+    r.c = (k == 0) ? 0.0f : ((k == 3) ? 1.5f : 1.0f);
+    r.d = (k == 0) ? 1.0f : ((k == 1) ? 2.0f : ((k == 4) ? 0.0f : 1.0f));
+    r.hi = (k == 0) ? 0.0f : ((k == 1) ? 4.6364760399e-01f : ((k == 2) ? 7.8539812565e-01f : ((k == 3) ? 9.8279368877e-01f : 1.5707962513e+00f)));
+    r.lo = (k == 0) ? 0.0f : ((k == 1) ? 5.0121582440e-09f : ((k == 2) ? 3.7748947079e-08f : ((k == 3) ? 3.4473217170e-08f : 7.5497894159e-08f)));
+    r.pad0 = r.pad1 = 0.0f;
+    return r;
+}
 // once per workgroup, before the first use (every kernel that reaches fsk_extended calls it, then a barrier)
 __device__ __forceinline__ void atan_table_init() {
-    if (threadIdx.x < 5) {
-        const int k = threadIdx.x;
-        AtanRow r;
-        r.a = (k == 1) ? 2.0f : ((k == 4) ? 0.0f : 1.0f);
-        r.b = (k == 0) ? 0.0f : ((k == 3) ? -1.5f : -1.0f);
-        r.c = (k == 0) ? 0.0f : ((k == 3) ? 1.5f : 1.0f);
-        r.d = (k == 0) ? 1.0f : ((k == 1) ? 2.0f : ((k == 4) ? 0.0f : 1.0f));
-        r.hi = (k == 0) ? 0.0f : ((k == 1) ? 4.6364760399e-01f : ((k == 2) ? 7.8539812565e-01f : ((k == 3) ? 9.8279368877e-01f : 1.5707962513e+00f)));
-        r.lo = (k == 0) ? 0.0f : ((k == 1) ? 5.0121582440e-09f : ((k == 2) ? 3.7748947079e-08f : ((k == 3) ? 3.4473217170e-08f : 7.5497894159e-08f)));
-        r.pad0 = r.pad1 = 0.0f;
-        atan_table()[k] = r;
+    if (threadIdx.x < 5) atan_table()[threadIdx.x] = atan_row_of((int)threadIdx.x);
+}
+// The same table indexed WITHOUT the four compares (the batch-level wide loop, fsk_wide): all four range bounds are multiples of 2^18 as
+// bit patterns (7/16 = 0xFB8 << 18, 11/16 = 0xFCC << 18, 19/16 = 0xFE6 << 18, 39/16 = 0x1007 << 18), so bits >> 18, clamped to
+// [0xFB7, 0x1007], names the range: 81 rows of (a, c, b, d, hi, lo) -- (a, c) and (b, d) as the pairs the packed multiply / add take.
+constexpr uint32_t kLutLo = 0xFB7u, kLutRows = 0x1007u - 0xFB7u + 1u;
+struct AtanLutRow { float a, c, b, d, hi, lo, pad0, pad1; };
+__device__ __forceinline__ AtanLutRow *atan_lut() {
+    __shared__ __attribute__((aligned(32))) AtanLutRow s_lut[kLutRows];
+    return s_lut;
+}
+__device__ __forceinline__ void atan_lut_init() {             // with atan_table_init(), in front of the same barrier
+    for (uint32_t i = threadIdx.x; i < kLutRows; i += blockDim.x) {
+        const uint32_t b = kLutLo + i;
+        const AtanRow r = atan_row_of((int)(b >= 0xFB8u) + (int)(b >= 0xFCCu) + (int)(b >= 0xFE6u) + (int)(b >= 0x1007u));
+        AtanLutRow o;
+        o.a = r.a; o.c = r.c; o.b = r.b; o.d = r.d; o.hi = r.hi; o.lo = r.lo; o.pad0 = o.pad1 = 0.0f;
+        atan_lut()[i] = o;
     }
 }
 __device__ __forceinline__ void atan_reduce_full(float ax, float &num, float &den, float &hi, float &lo) {
@@ -663,6 +681,68 @@ __device__ __forceinline__ bool fsk_divide(const FskFront<NB> &f, const RunArgs 
                          __builtin_amdgcn_ballot_w64(z_max >= kZHi) | __builtin_amdgcn_ballot_w64(z_min < (ZEROS_OK ? kZLo - 1u : kZLo)) |
                          __builtin_amdgcn_ballot_w64(f.mag_min <= p.noise_sqrd);
     return any != 0;
+}
+
+// ---- the batch-level WIDE form (round 6, late): fsk_extended for a whole batch on the same register pairs -------------------------------
+// A capture whose phase steps reach beyond atan(7/16) = 0.41 rad per sample -- deviations from about 50 kHz at 1 MS/s with some noise, few
+// samples per symbol, a filtered capture -- flags EVERY batch of the fast loop; the per-row forms it then went through (spec_pair ->
+// demod_pair -> ext_pair, scalar polynomials, four compares per range) cost 203-217 VALU wave-instructions per row against 89
+// (profiles/r06s_deviation_pmc.txt).  The wide loop is the fast loop with fdlibm's argument reduction in it:
+//   t = im / re (div_fast, signed), ax = |t|;  range row = lut[clamp(bits(ax) >> 18)]: (num, den) = (a, c) ax + (b, d) as ONE packed
+//   multiply and ONE packed add per sample;  u = num / den (div_fast);  z = hi - ((poly(u) - lo) - u);  re < 0: pi - (z - pi_lo);
+//   the sign of im on top -- statement for statement fsk_extended (whose results fdlibm's atan2f pins), the polynomial packed.
+// Window (one flag per batch, integer min / max over bit patterns as in fsk_divide): |re| in [2^-40, 2^40), 2^-29 <= ax < 2^25, nothing
+// gated.  Returns 1 when the batch lies outside it (q invalid), else 0, or 2 when it also lies inside the fast loop's window (the caller
+// counts those to find its way back).  ZEROS_OK (integer captures): exact zeros of im pass; the caller settles them.
+template <int NB, bool ZEROS_OK>
+__device__ __forceinline__ int fsk_wide(const FskFront<NB> &f, const RunArgs &p, float (&q0)[NB], float (&q1)[NB]) {
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    v2f t[NB];
+    uint32_t ax[NB][2];
+    uint32_t re_max = 0u, re_min = 0u, a_max = 0u, a_min = 0u, raw_max = 0u;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        t[j] = div_fast2v(f.im[j], f.re[j]);
+        ax[j][0] = __float_as_uint(t[j].x) & 0x7fffffffu; ax[j][1] = __float_as_uint(t[j].y) & 0x7fffffffu;
+        const uint32_t w0 = __float_as_uint(f.re[j].x), w1 = __float_as_uint(f.re[j].y), r0b = w0 & 0x7fffffffu, r1b = w1 & 0x7fffffffu;
+        const uint32_t l0 = ZEROS_OK ? ax[j][0] - 1u : ax[j][0], l1 = ZEROS_OK ? ax[j][1] - 1u : ax[j][1];
+        re_max = (j == 0) ? max(r0b, r1b) : max(re_max, max(r0b, r1b)); re_min = (j == 0) ? min(r0b, r1b) : min(re_min, min(r0b, r1b));
+        a_max = (j == 0) ? max(ax[j][0], ax[j][1]) : max(a_max, max(ax[j][0], ax[j][1]));
+        a_min = (j == 0) ? min(l0, l1) : min(a_min, min(l0, l1));
+        raw_max = (j == 0) ? max(w0, w1) : max(raw_max, max(w0, w1));
+    }
+    const uint64_t out = __builtin_amdgcn_ballot_w64(re_max >= kReLo + kReSpan) | __builtin_amdgcn_ballot_w64(re_min < kReLo) |
+                         __builtin_amdgcn_ballot_w64(a_max >= kAtanLo + kAtanExtSpan) | __builtin_amdgcn_ballot_w64(a_min < (ZEROS_OK ? kAtanLo - 1u : kAtanLo)) |
+                         __builtin_amdgcn_ballot_w64(f.mag_min <= p.noise_sqrd);
+    if (out != 0) return 1;
+    const uint64_t beyond = __builtin_amdgcn_ballot_w64(a_max >= kAtanLo + kAtanSpan) | __builtin_amdgcn_ballot_w64(raw_max >= 0x80000000u);
+    const AtanLutRow *const lut = atan_lut();
+    // (stage by stage over the batch's rows: the rows' chains interleave, as in the fast loop)
+    v2f n[NB], d[NB], hi[NB], lo[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const uint32_t i0 = min(max(ax[j][0] >> 18, kLutLo), kLutLo + kLutRows - 1u) - kLutLo, i1 = min(max(ax[j][1] >> 18, kLutLo), kLutLo + kLutRows - 1u) - kLutLo;
+        const v4f c0 = *(const v4f *)&lut[i0].a, c1 = *(const v4f *)&lut[i1].a;
+        const v2f h0 = *(const v2f *)&lut[i0].hi, h1 = *(const v2f *)&lut[i1].hi;
+        const float a0 = __uint_as_float(ax[j][0]), a1 = __uint_as_float(ax[j][1]);
+        const v2f nd0 = c0.xy * v2f{a0, a0} + c0.zw, nd1 = c1.xy * v2f{a1, a1} + c1.zw;        // (num, den) of each sample: multiply and add rounded separately
+        n[j] = v2f{nd0.x, nd1.x}; d[j] = v2f{nd0.y, nd1.y};
+        hi[j] = v2f{h0.x, h1.x}; lo[j] = v2f{h0.y, h1.y};
+    }
+    v2f u[NB], pp[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) u[j] = div_fast2v(n[j], d[j]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) pp[j] = atanf_poly2(u[j], u[j] * u[j]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const v2f z = hi[j] - ((pp[j] - lo[j]) - u[j]);
+        const v2f zb = v2f{pi, pi} - (z - v2f{pi_lo, pi_lo});
+        const float b0 = (__float_as_int(f.re[j].x) < 0) ? zb.x : z.x, b1 = (__float_as_int(f.re[j].y) < 0) ? zb.y : z.y;
+        q0[j] = __uint_as_float((__float_as_uint(b0) & 0x7fffffffu) | (__float_as_uint(f.im[j].x) & 0x80000000u));
+        q1[j] = __uint_as_float((__float_as_uint(b1) & 0x7fffffffu) | (__float_as_uint(f.im[j].y) & 0x80000000u));
+    }
+    return beyond != 0 ? 0 : 2;
 }
 
 // Demodulate one batch of NB rows (cur[j] = a lane's two samples of row j).  (prev_c, prev_d) is the IQ sample before
@@ -1201,7 +1281,7 @@ void k_demod_runs_bp(const RunArgs p) {
     v4f cv[kBatch], nv[kBatch];                               // kFskFast: the rows as 4-vectors
     if (kFskFast) load_rows_v4<DT>(p, a0, r0, lane, cv);
     else load_rows_bp<SRC, DT>(p, a0, r0, lane, cur);
-    if (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK) { atan_table_init(); __syncthreads(); }      // (the loads above are in flight)
+    if (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK) { atan_table_init(); if (kFskFast) atan_lut_init(); __syncthreads(); }      // (the loads above are in flight)
 
     float prev_c = 0.f, prev_d = 0.f;                         // IQ sample before my first row (FSK seam operand)
     uint32_t st_before = kStNone;                             // state of sample a0-1: wavefront 0 (it runs phase 2)
@@ -1284,51 +1364,93 @@ void k_demod_runs_bp(const RunArgs p) {
     const int r_end = r0 + R;
     if (kFskFast) {
         int rb = r0;
+        bool wide = false, have_nv = false;                   // wavefront-uniform: the wide loop is on; nv holds batch rb + kBatch
+        int calm = 0;                                         // ... consecutive batches of the wide loop the fast loop would have taken
+        // exactly zero cross products of integer samples (products and their difference are exact): atan2f(+-0, re > 0) = +-0 and
+        // atan2f(+-0, re < 0) = +-pi (e_atan2f.c: y = 0 -> y, pi + tiny, -pi - tiny), the sign being that of the reference's product
+        // (conj_mul: its zeros are signed differently from the plain product's); backward: only the wide loop meets re < 0
+        auto settle_zeros = [&](const FskFront<kBatch> &f, float (&q0)[kBatch], float (&q1)[kBatch], const bool backward) {
+            uint64_t zany = 0;
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) zany |= __builtin_amdgcn_ballot_w64(f.im[j].x == 0.0f) | __builtin_amdgcn_ballot_w64(f.im[j].y == 0.0f);
+            if (zany == 0) return;
+            float sc = prev_c, sd = prev_d;
+#pragma unroll
+            for (int j = 0; j < kBatch; ++j) {
+                const float pc = dpp_wave_shr1(cv[j].z, sc), pd = dpp_wave_shr1(cv[j].w, sd);
+                float re_r, im_r;
+                conj_mul(pc, pd, cv[j].x, cv[j].y, re_r, im_r);
+                if (backward && f.re[j].x < 0.0f) im_r = __uint_as_float((__float_as_uint(im_r) & 0x80000000u) | 0x40490fdbu);      // +-pi
+                q0[j] = (f.im[j].x == 0.0f) ? im_r : q0[j];
+                conj_mul(cv[j].x, cv[j].y, cv[j].z, cv[j].w, re_r, im_r);
+                if (backward && f.re[j].y < 0.0f) im_r = __uint_as_float((__float_as_uint(im_r) & 0x80000000u) | 0x40490fdbu);
+                q1[j] = (f.im[j].y == 0.0f) ? im_r : q1[j];
+                sc = lane63(cv[j].z); sd = lane63(cv[j].w);
+            }
+        };
         for (;;) {
 #pragma unroll 1
-            while (rb < r_end && spec_hint == 0 && !(first_row && rb == 0)) {
-                if (rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);
+            while (rb < r_end && spec_hint == 0 && !wide && !(first_row && rb == 0)) {
+                if (!have_nv && rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);
+                have_nv = true;
                 FskFront<kBatch> f;
                 float nc = prev_c, nd = prev_d;
                 fsk_front<kBatch>(cv, nc, nd, f);
                 v2f t[kBatch], z[kBatch];
-                if (__builtin_expect((fsk_divide<kBatch, kIntCapture>(f, p, t, z)), 0)) break;          // cv still holds batch rb
+                if (__builtin_expect((fsk_divide<kBatch, kIntCapture>(f, p, t, z)), 0)) {          // cv still holds batch rb
+                    wide = __builtin_amdgcn_ballot_w64(f.mag_min <= p.noise_sqrd) == 0;              // (a gated batch: the per-row forms know pauses)
+                    calm = 0;
+                    break;
+                }
                 float q0[kBatch], q1[kBatch];
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) { const v2f q = t[j] - atanf_poly2(t[j], z[j]); q0[j] = q.x; q1[j] = q.y; }
-                if (kIntCapture) {
-                    // exactly zero cross products (integer samples: products and their difference are exact): atan2f(+-0, re > 0) = +-0, the
-                    // sign being that of the reference's product (conj_mul: its zeros are signed differently from the plain product's)
-                    uint64_t zany = 0;
-#pragma unroll
-                    for (int j = 0; j < kBatch; ++j) zany |= __builtin_amdgcn_ballot_w64(f.im[j].x == 0.0f) | __builtin_amdgcn_ballot_w64(f.im[j].y == 0.0f);
-                    if (zany != 0) {
-                        float sc = prev_c, sd = prev_d;
-#pragma unroll
-                        for (int j = 0; j < kBatch; ++j) {
-                            const float pc = dpp_wave_shr1(cv[j].z, sc), pd = dpp_wave_shr1(cv[j].w, sd);
-                            float re_r, im_r;
-                            conj_mul(pc, pd, cv[j].x, cv[j].y, re_r, im_r); q0[j] = (f.im[j].x == 0.0f) ? im_r : q0[j];
-                            conj_mul(cv[j].x, cv[j].y, cv[j].z, cv[j].w, re_r, im_r); q1[j] = (f.im[j].y == 0.0f) ? im_r : q1[j];
-                            sc = lane63(cv[j].z); sd = lane63(cv[j].w);
-                        }
-                    }
-                }
+                if (kIntCapture) settle_zeros(f, q0, q1, false);
                 prev_c = nc; prev_d = nd;
                 emit(cur, q0, q1, 0u, rb, false);          // (`cur`: read by the float32 segmentation pass only, not this instantiation)
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) cv[j] = nv[j];
+                have_nv = false;
                 rb += kBatch;
             }
             if (rb >= r_end) break;
+            // the wide loop (fsk_wide): entered by a batch the fast loop flagged, left for the fast loop after four batches in a row that
+            // one would have taken, left for ONE generic step (and whatever its hint says) by a batch outside the wide window
+            if (wide) {
+                bool outside = false;
+#pragma unroll 1
+                while (rb < r_end) {
+                    if (!have_nv && rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);
+                    have_nv = true;
+                    FskFront<kBatch> f;
+                    float nc = prev_c, nd = prev_d;
+                    fsk_front<kBatch>(cv, nc, nd, f);
+                    float q0[kBatch], q1[kBatch];
+                    const int kind = fsk_wide<kBatch, kIntCapture>(f, p, q0, q1);
+                    if (__builtin_expect(kind == 1, 0)) { outside = true; break; }
+                    if (kIntCapture) settle_zeros(f, q0, q1, true);
+                    prev_c = nc; prev_d = nd;
+                    emit(cur, q0, q1, 0u, rb, false);
+#pragma unroll
+                    for (int j = 0; j < kBatch; ++j) cv[j] = nv[j];
+                    have_nv = false;
+                    rb += kBatch;
+                    calm = (kind == 2) ? calm + 1 : 0;
+                    if (calm >= 4) break;
+                }
+                wide = false;
+                if (rb >= r_end) break;
+                if (!outside) continue;                       // calm: back to the fast loop
+            }
             float q0[kBatch], q1[kBatch];
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) { cur[j].c0 = cv[j].x; cur[j].d0 = cv[j].y; cur[j].c1 = cv[j].z; cur[j].d1 = cv[j].w; }
-            if (rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);
+            if (!have_nv && rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);
             const uint32_t gated = demod_batch<SRC, DT, MOD, kBatch>(cur, prev_c, prev_d, p, q0, q1, spec_hint);
             emit(cur, q0, q1, gated, rb, true);
 #pragma unroll
             for (int j = 0; j < kBatch; ++j) cv[j] = nv[j];
+            have_nv = false;
             rb += kBatch;
         }
     } else {
