@@ -26,4 +26,19 @@ for name, x, dt, qad in (("f32", iq, np.float32, True), ("bits_only", iq, np.flo
         t0 = time.perf_counter(); run(80); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 80 * 1e3)
     out[name] = round(min(ts), 4)
     st.close()
+if "--sps10" in sys.argv:                                   # the 10-samples-per-symbol capture of bench.py's variants.sps10 (tolerance 1), K = 40
+    del iq, x8
+    iq10, _ = spec_fsk_capture(128, dev, first_segment=0, sps=10)
+    p10 = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 1, 10, 0.1, 8, False)
+    st = pipe.stream(n, p10, want_qad=True, want_pos=False, dtype=np.float32)
+    def run10(k):
+        for _ in range(k): st.push(iq10)
+        st.flush()
+    for _ in range(5): run10(20)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); run10(40); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / 40 * 1e3)
+    out["sps10"] = round(min(ts), 4)
+    st.close()
 print(json.dumps(out))

@@ -47,6 +47,9 @@ enum { SRC_IQ = 0, SRC_QAD = 1 };
 #define URH_MINWAVES 1
 #endif
 #ifndef URH_SPEC
+#ifndef URH_NO_WIDE
+#define URH_NO_WIDE 0     // A/B builds (tools/quick_tag.sh): 1 leaves the batch-level wide loop (fsk_wide) out
+#endif
 #define URH_SPEC 1        // branch-free speculative fast path per batch of rows (see spec_pair)
 #endif
 #ifndef URH_BITPLANE
@@ -324,10 +327,13 @@ __device__ __forceinline__ AtanLutRow *atan_lut() {
     __shared__ __attribute__((aligned(32))) AtanLutRow s_lut[kLutRows];
     return s_lut;
 }
-__device__ __forceinline__ void atan_lut_init() {             // with atan_table_init(), in front of the same barrier
-    for (uint32_t i = threadIdx.x; i < kLutRows; i += blockDim.x) {
+// Filled by the WAVEFRONT that enters the wide loop, when it first does (every wavefront writes the same values: no barrier, and a
+// wavefront's own LDS operations execute in order) -- a workgroup that never leaves the fast loop pays nothing for it (filled by every
+// workgroup up front it cost the headline capture 1.3 %: tools/ab_variants.py against -DURH_NO_WIDE=1).
+__device__ __forceinline__ void atan_lut_fill_wave(int lane) {       // (behind atan_table_init() and its barrier)
+    for (uint32_t i = (uint32_t)lane; i < kLutRows; i += 64u) {
         const uint32_t b = kLutLo + i;
-        const AtanRow r = atan_row_of((int)(b >= 0xFB8u) + (int)(b >= 0xFCCu) + (int)(b >= 0xFE6u) + (int)(b >= 0x1007u));
+        const AtanRow r = atan_table()[(int)(b >= 0xFB8u) + (int)(b >= 0xFCCu) + (int)(b >= 0xFE6u) + (int)(b >= 0x1007u)];
         AtanLutRow o;
         o.a = r.a; o.c = r.c; o.b = r.b; o.d = r.d; o.hi = r.hi; o.lo = r.lo; o.pad0 = o.pad1 = 0.0f;
         atan_lut()[i] = o;
@@ -1253,7 +1259,7 @@ void k_demod_runs_bp(const RunArgs p) {
     // pure copy of this shape) while the per-chunk work (prologue, run phase, ChunkInfo) is paid once per 64 rows.
     constexpr int W = bp_waves<SRC, MOD>();
     __shared__ uint32_t s_planes[W > 1 ? (NPL + 1) * 4 : 1][W > 1 ? 64 : 1];
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
     const int w = (W > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;     // wavefront-uniform
     const int64_t chunk = p.chunk_base + blockIdx.x;
     int64_t a0 = p.range_begin + (int64_t)blockIdx.x * p.chunk_len;
@@ -1277,11 +1283,14 @@ void k_demod_runs_bp(const RunArgs p) {
     constexpr int kBatch = URH_KBATCH;
     constexpr bool kFskFast = URH_SPEC && SRC == SRC_IQ && MOD == URHGPU_MOD_FSK;
     constexpr bool kIntCapture = DT != URHGPU_DT_F32;
+    // the wide loop (fsk_wide) for float32 captures only: the integer instantiations are held to 64 VGPRs (eight wavefronts per SIMD), and with
+    // the wide loop beside it their FAST loop reloads spilled registers in every iteration (int8 step 0.269 -> 0.294 ms)
+    constexpr bool kWideLoop = !kIntCapture && !URH_NO_WIDE;
     RowIn cur[kBatch] = {}, nxt[kBatch];
     v4f cv[kBatch], nv[kBatch];                               // kFskFast: the rows as 4-vectors
     if (kFskFast) load_rows_v4<DT>(p, a0, r0, lane, cv);
     else load_rows_bp<SRC, DT>(p, a0, r0, lane, cur);
-    if (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK) { atan_table_init(); if (kFskFast) atan_lut_init(); __syncthreads(); }      // (the loads above are in flight)
+    if (SRC == SRC_IQ && MOD == URHGPU_MOD_FSK) { atan_table_init(); __syncthreads(); }      // (the loads above are in flight)
 
     float prev_c = 0.f, prev_d = 0.f;                         // IQ sample before my first row (FSK seam operand)
     uint32_t st_before = kStNone;                             // state of sample a0-1: wavefront 0 (it runs phase 2)
@@ -1364,8 +1373,7 @@ void k_demod_runs_bp(const RunArgs p) {
     const int r_end = r0 + R;
     if (kFskFast) {
         int rb = r0;
-        bool wide = false, have_nv = false;                   // wavefront-uniform: the wide loop is on; nv holds batch rb + kBatch
-        int calm = 0;                                         // ... consecutive batches of the wide loop the fast loop would have taken
+        bool wide = false, have_nv = false, lut_ready = false;      // wavefront-uniform: the wide loop is on; nv holds batch rb + kBatch; this wavefront has filled the range table
         // exactly zero cross products of integer samples (products and their difference are exact): atan2f(+-0, re > 0) = +-0 and
         // atan2f(+-0, re < 0) = +-pi (e_atan2f.c: y = 0 -> y, pi + tiny, -pi - tiny), the sign being that of the reference's product
         // (conj_mul: its zeros are signed differently from the plain product's); backward: only the wide loop meets re < 0
@@ -1391,17 +1399,13 @@ void k_demod_runs_bp(const RunArgs p) {
         for (;;) {
 #pragma unroll 1
             while (rb < r_end && spec_hint == 0 && !wide && !(first_row && rb == 0)) {
-                if (!have_nv && rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);
+                if (rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);      // (have_nv is false on every way into this loop)
                 have_nv = true;
                 FskFront<kBatch> f;
                 float nc = prev_c, nd = prev_d;
                 fsk_front<kBatch>(cv, nc, nd, f);
                 v2f t[kBatch], z[kBatch];
-                if (__builtin_expect((fsk_divide<kBatch, kIntCapture>(f, p, t, z)), 0)) {          // cv still holds batch rb
-                    wide = __builtin_amdgcn_ballot_w64(f.mag_min <= p.noise_sqrd) == 0;              // (a gated batch: the per-row forms know pauses)
-                    calm = 0;
-                    break;
-                }
+                if (__builtin_expect((fsk_divide<kBatch, kIntCapture>(f, p, t, z)), 0)) break;          // cv still holds batch rb
                 float q0[kBatch], q1[kBatch];
 #pragma unroll
                 for (int j = 0; j < kBatch; ++j) { const v2f q = t[j] - atanf_poly2(t[j], z[j]); q0[j] = q.x; q1[j] = q.y; }
@@ -1414,10 +1418,20 @@ void k_demod_runs_bp(const RunArgs p) {
                 rb += kBatch;
             }
             if (rb >= r_end) break;
-            // the wide loop (fsk_wide): entered by a batch the fast loop flagged, left for the fast loop after four batches in a row that
-            // one would have taken, left for ONE generic step (and whatever its hint says) by a batch outside the wide window
-            if (wide) {
+            // The wide loop (fsk_wide): entered by a batch the fast loop flagged; left for the fast loop by the FIRST batch that one would
+            // have taken -- an isolated outlier (the headline capture has one batch in 120) costs its own batch and the next one here,
+            // about what the generic step it used to take cost (staying for four such batches cost that capture 2.5 %: the wavefronts that
+            // met an outlier ran the rest of their rows at 104 instead of 68 instructions and held their workgroups up); left for ONE
+            // generic step (and whatever its hint says) by a batch outside the wide window.
+            // (The fast loop's flagged exit carries no statement of its own: with one, the compiler splits the loop's body at the flag
+            // and the division's tail no longer interleaves with the polynomial.  The state is kept in plain bools and the loop entered
+            // unconditionally on a flag: the variations tried on this -- a counter of flags, one packed state word, a hint shared by the
+            // context's passes through memory so that wavefronts start in the right loop -- made the register allocator spill the bit
+            // planes, and the build with the shared hint stepped at 0.53 ms instead of 0.28: profiles/r06s_deviation_pmc.txt.)
+            wide = kWideLoop && spec_hint == 0 && !(first_row && rb == 0);      // i.e. the fast loop ended on a flagged batch
+            if (kWideLoop && wide) {
                 bool outside = false;
+                if (!lut_ready) { atan_lut_fill_wave(lane); lut_ready = true; }
 #pragma unroll 1
                 while (rb < r_end) {
                     if (!have_nv && rb + kBatch < r_end) load_rows_v4<DT>(p, a0, rb + kBatch, lane, nv);
@@ -1435,12 +1449,11 @@ void k_demod_runs_bp(const RunArgs p) {
                     for (int j = 0; j < kBatch; ++j) cv[j] = nv[j];
                     have_nv = false;
                     rb += kBatch;
-                    calm = (kind == 2) ? calm + 1 : 0;
-                    if (calm >= 4) break;
+                    if (kind == 2) break;
                 }
                 wide = false;
                 if (rb >= r_end) break;
-                if (!outside) continue;                       // calm: back to the fast loop
+                if (!outside) continue;                       // back to the fast loop
             }
             float q0[kBatch], q1[kBatch];
 #pragma unroll
@@ -1466,6 +1479,8 @@ void k_demod_runs_bp(const RunArgs p) {
     }
 
     if (!RUNS) return;
+    // (the lane number again, from the execution mask's bit count: kept across the streaming loops it is one register too many -- spilled)
+    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     if (STAMPS && w == 0 && lane == 0) p.chunks[chunk].pend_stable = (int32_t)(uint32_t)wall_clock64();
     // the chunk's planes come together in wavefront 0 (lane r <- row r)
     if (W > 1) {
