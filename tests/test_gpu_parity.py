@@ -252,6 +252,7 @@ def test_forced_chunk_plan_vs_oracle(pipe, oracle, tiles):
             test_bit_plane_kernel_equals_state_byte_kernel(pipe, oracle, mod)
         test_integer_capture_exact_zero_cross_products(pipe, oracle, np.int8)
         test_wide_deviation_reduced_argument_path(pipe, oracle, np.float32)
+        test_wide_loop_every_angle_and_mode_switches(pipe, oracle, np.float32)
     finally:
         lib.urhgpu_test_force_tiles_per_chunk(0)
     assert lib.urhgpu_test_force_tiles_per_chunk(5) == _lib.ERR_ARG
