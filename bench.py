@@ -405,8 +405,12 @@ def variant_steps(torch, pipe, iq, p, n, args, ramp, headline_copy):
             r = {"ms_per_step": round(ms, 4), "bytes_per_sample": 12, "frac_of_8TBs": frac(ms, 12), "Msamples_per_s": round(n / ms / 1e3, 1),
                  "capture": what, "rows": int(len(last.ppseq())), "messages": int(len(last.flat()[2])), "d2h_bytes": int(last.blob_bytes),
                  "d2h_gbs": round(int(last.blob_bytes) / (ms * 1e-3) / 1e9, 1),
-                 "bound": "what a step ships per pulse-table row (3 B) over PCIe: d2h_gbs is the link's rate" if int(last.blob_bytes) / (ms * 1e-3) > 30e9
-                          else "as the headline: the hot kernel (HBM) with the tail of the pass before beside it",
+                 "row_format": ("one uint16 per row: state and length (URHGPU_BLOB_ROW16, dense pulse tables: 2 B per row)" if getattr(last, "_row16", None) is not None
+                                else "int8 state + uint16 length per row (URHGPU_BLOB_LEN16: 3 B)" if getattr(last, "_len16", None) is not None
+                                else "int8 state + int32 length per row (5 B)"),
+                 "bound": ("what a step ships per pulse-table row over PCIe: d2h_gbs is the link's rate" if int(last.blob_bytes) / (ms * 1e-3) > 30e9
+                           else "the hot kernel's run phase and the tail over this many rows (DESIGN 7.1), not the link" if len(last.ppseq()) > n // 64
+                           else "as the headline: the hot kernel (HBM) with the tail of the pass before beside it"),
                  "stream_stats": st.stats()}
             if not args.no_cpu_baseline:
                 host = x.cpu().numpy()

@@ -277,6 +277,10 @@ typedef struct urhgpu_outputs {
  *   uint16 row_len16[n_rows] instead -- 3 bytes per pulse-table row over PCIe instead of 5 --, a length that does not fit (65535 and more,
  *   or negative) is stored as 0xFFFF and listed behind the packed bits, at the next 16-byte boundary: int64 n_esc, then n_esc pairs
  *   {uint32 row, int32 length} (a capture of n samples has at most n / 65535 + 2 of them)
+ *   bit 2 (URHGPU_BLOB_ROW16; the same passes when the pulse table is dense -- more than one row per 64 samples in the pass before): there is
+ *   no row_state section; the row_len section holds uint16 row16[n_rows] = (row_state + 1) << 13 | length -- 2 bytes per row --, a length
+ *   of 8191 samples and more (or negative) is stored as 0x1FFF and listed at offset header[11] of the blob (the slot names the row_state
+ *   section otherwise): int64 n_esc, then n_esc pairs {uint32 row, int32 length} (at most n / 8191 + 2)
  * truncated != 0: bit 0: a capacity was exceeded (rows_needed > cap_rows, or more messages / bits / positions than fit): the sections
  * hold what fitted, the caller repeats the pass with larger capacities; bit 2: a row length did not fit int32, a position uint32 or a
  * state int8 (captures of 2^31 samples and more; sharded captures whose positions are absolute): use the wide outputs; bit 1: a
@@ -285,6 +289,7 @@ typedef struct urhgpu_outputs {
 #define URHGPU_BLOB_MAGIC INT64_C(0x55524842424C4F42) /* "URHBBLOB" */
 #define URHGPU_BLOB_HEADER_BYTES 128
 #define URHGPU_BLOB_LEN16 2      /* header[7] bit 1: 16-bit row lengths + escape list (see above) */
+#define URHGPU_BLOB_ROW16 4      /* header[7] bit 2: state and length of a row in one uint16 + escape list (see above) */
 int64_t urhgpu_blob_capacity(int64_t cap_rows, int64_t cap_bits, int64_t cap_msg, int64_t cap_pos, int has_pos);
 
 /* The results of a pass that is over, on the host through the compact blob: out = the descriptor the pass was given with out->blob /
@@ -345,6 +350,8 @@ typedef struct urhgpu_host_result {
     const uint32_t *pos32;       /* bit_sample_pos or NULL */
     const void *blob;            /* the whole blob (header first) */
     const float *d_qad;          /* DEVICE: the pass's demodulated signal (overwritten three pushes later) or NULL */
+    const uint16_t *row16;       /* URHGPU_BLOB_ROW16: (row_state + 1) << 13 | length per row, 0x1FFF = look the row up in esc; row_len, row_len16 and
+                                    row_state are NULL then */
 } urhgpu_host_result;
 int urhgpu_stream_capacities(int64_t n_max, const urhgpu_params *p, int64_t *cap_rows, int64_t *cap_bits, int64_t *cap_msg, int64_t *cap_pos);
 int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p, int want_qad, int want_pos, int64_t cap_rows, urhgpu_stream **out);

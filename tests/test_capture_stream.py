@@ -157,3 +157,50 @@ def test_stream_ships_16_bit_lengths_with_escapes(oracle):
         assert g[4] <= 3 * len(pp) + 8 * g[3] + len(bits) // 8 + 24 * len(pauses) + 512, (k, g[4])
     assert any(got[k][3] > 0 for k in got)
     st.close()
+
+
+@pytest.mark.parametrize("bps", [1, 2])
+def test_stream_ships_packed_rows_for_dense_tables(oracle, bps):
+    """A stream whose last result held more than one pulse-table row per 64 samples ships state and length of a row in ONE uint16 (include/urhgpu.h:
+    URHGPU_BLOB_ROW16: 2 bytes per row; orders 2 and 4): captures at 8 samples per symbol with pauses of 8191 samples and more (one of exactly
+    8191 and one of 8190: the boundary of the escape list), a sparse capture in between (the stream goes back to 16-bit lengths for the pass
+    after it), pushed back to back, come back with the reference's pulse table, bits and pauses."""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    n = (1 << 20) + 4096 * 3
+    pipe = DevicePipeline(0, pipelined=True)
+    p = DemodParams("FSK", bps, 0.1, 0.0, 0.05 if bps == 2 else 1.0, 1, 8, 0.1, 8, False)
+    caps = []
+    for i, (sps, gaps) in enumerate(((8, [(50_000, 9000)]), (8, [(10_000, 8191 + 3), (300_000, 8190 + 3), (500_000, 300_000)]), (400, []),
+                                     (8, []), (8, [(1000, 70_000), (400_000, 8300)]))):
+        iq = synth_fsk(n, sps=sps, seed=500 + i, noise=0.02, deviation_hz=30e3)
+        for a, ln in gaps:
+            iq[a:a + ln] = 0.0                                         # below the noise gate: one PAUSE row of about ln samples
+        caps.append(iq)
+    st = pipe.stream(n, p, want_qad=True, want_pos=False)
+    got = {}
+
+    def keep(r):
+        if r is not None:
+            r.check()
+            got[r.seq] = (r.ppseq(), r.bits(), r.pauses.copy(), r._row16 is not None, r._row16[2] if r._row16 is not None else -1, r.blob_bytes)
+    for rep in range(2):
+        for c in caps:
+            keep(st.push(torch.from_numpy(c).cuda()))
+    for r in st.flush():
+        keep(r)
+    assert sorted(got) == list(range(2 * len(caps)))
+    packed = 0
+    for k in range(2 * len(caps)):
+        iq = caps[k % len(caps)]
+        pp = oracle.grab_pulse_lens(oracle.afp_demod(iq, 0.1, "FSK", 1 << bps), 0.0, 1, "FSK", 8, bps, p.center_spacing)
+        bits, off, pauses, pos, poff = oracle.ppseq_to_bits_flat(pp, 8, bps, True, 8)
+        g = got[k]
+        assert np.array_equal(g[0], pp) and np.array_equal(g[1], bits) and np.array_equal(g[2], pauses), k
+        if g[3]:
+            packed += 1
+            assert g[4] == int((pp[:, 1] >= 0x1FFF).sum() + (pp[:, 1] < 0).sum()), (k, g[4])      # the long rows took the list
+            assert g[5] <= 2 * len(pp) + 8 * g[4] + len(bits) // 8 + 24 * len(pauses) + 512, (k, g[5])
+    # the pass after a dense result is packed (the stream decides by the last result it has handed out: a few passes behind)
+    assert packed >= 3 and any(got[k][3] and got[k][4] > 0 for k in got) and not all(got[k][3] for k in got)
+    st.close()

@@ -314,6 +314,61 @@ def test_host_bits_from_a_blob_with_16_bit_row_lengths():
             assert np.array_equal(h.bits(), bits)
 
 
+def test_host_bits_from_a_blob_with_packed_rows():
+    """The blob of a staged pass over a dense pulse table (include/urhgpu.h: URHGPU_BLOB_ROW16, header[7] bit 2): no row_state section, one uint16
+    per row = (state + 1) << 13 | length, lengths of 8191 samples and more (and a negative one) as 0x1FFF with their entries in the escape list
+    at header[11].  HostBits gives row_state and row_len back; a 0x1FFF without its entry is an error."""
+    import ctypes as C
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams, HostBits
+    rng = np.random.default_rng(12)
+    n_rows = 61
+    row_state = rng.integers(-1, 4, n_rows).astype(np.int8)          # pause, and the four states of an order-4 capture
+    row_len = rng.integers(1, 8000, n_rows).astype(np.int64)
+    row_len[[2, 30, 60]] = [8191, 1 << 29, -7]                    # the boundary, a long pause, a negative last row
+    row_len[5] = 8190                                             # the largest length that ships as it is
+    bits = rng.integers(0, 2, 90).astype(np.uint8)
+    msg_off, pauses, pos_off = np.array([0, 90], np.int64), np.array([0], np.int64), np.array([0, 91], np.int64)
+    for drop_entry in (False, True):
+        esc_rows = [r for r in range(n_rows) if not 0 <= row_len[r] < 0x1FFF]
+        assert esc_rows == [2, 30, 60]
+        words = (((row_state.astype(np.int64) + 1) << 13) | np.where((row_len >= 0) & (row_len < 0x1FFF), row_len, 0x1FFF)).astype(np.uint16)
+        listed = esc_rows[1:] if drop_entry else esc_rows
+        pairs = np.zeros((len(listed), 2), np.uint32)
+        pairs[:, 0] = listed
+        pairs[:, 1] = row_len[listed].astype(np.int32).view(np.uint32)
+        sections, off = {}, 128
+
+        def put(name, raw):
+            nonlocal off
+            off = (off + 15) & ~15
+            sections[name] = (off, raw)
+            off += len(raw)
+        put("pauses", pauses.tobytes()); put("msg_off", msg_off.tobytes()); put("pos_off", pos_off.tobytes())
+        put("bits", np.packbits(bits).tobytes())
+        put("row_len", words.tobytes())
+        put("esc", np.array([len(listed)], np.int64).tobytes() + pairs.tobytes())        # a place of its own behind the sections
+        total = off
+        hdr = np.zeros(16, np.int64)
+        hdr[:8] = [_lib.BLOB_MAGIC, n_rows, 1, len(bits), 0, n_rows, total, _lib.BLOB_ROW16]
+        hdr[8:15] = [sections["pauses"][0], sections["msg_off"][0], sections["pos_off"][0], sections["esc"][0], sections["bits"][0],
+                     sections["row_len"][0], 0]
+        blob = bytearray(total)
+        blob[:128] = hdr.tobytes()
+        for o, b in sections.values():
+            blob[o:o + len(b)] = b
+        buf = (C.c_ubyte * total).from_buffer(blob)
+        h = HostBits.from_blob(C.addressof(buf), DemodParams("FSK", 2, 0.0, 0.0, 0.1, 1, 10, 0.1, 8, False), n_samples=1 << 20).check()
+        if drop_entry:
+            with pytest.raises(_lib.UrhGpuError):
+                h.ppseq()
+        else:
+            assert h.row_len.dtype == np.int32 and h.row_state.dtype == np.int8
+            assert np.array_equal(h.row_state, row_state)
+            assert np.array_equal(h.ppseq(), np.stack([row_state.astype(np.int64), row_len], axis=1))
+            assert np.array_equal(h.bits(), bits)
+
+
 def test_peaks_center_linear_form_equals_the_offset_loop():
     """peaks_center finds the strict maxima with two sliding-window maxima (linear in the bins: a nearly constant message has millions);
     the per-offset comparison loop it replaced is the checker here (AutoInterpretation.py:250-277)"""

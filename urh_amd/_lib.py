@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "liburhgpu.so")
 OK = 0
 ERR_HIP, ERR_DTYPE, ERR_ARG, ERR_CAPACITY, ERR_UNSUPPORTED, ERR_NO_DEVICE = -1, -2, -3, -4, -5, -6
 BLOB_LEN16 = 2            # header[7] bit 1 of a compact blob: 16-bit row lengths + escape list (include/urhgpu.h)
+BLOB_ROW16 = 4       # header[7] bit 2: state and length of a row in one uint16 (include/urhgpu.h)
 
 DT_I8, DT_U8, DT_I16, DT_U16, DT_F32 = 0, 1, 2, 3, 4
 MOD_ASK, MOD_FSK, MOD_PSK, MOD_OTHER = 0, 1, 2, 3
@@ -60,7 +61,7 @@ class HostResult(C.Structure):
         ("row_len", C.c_void_p), ("row_len16", C.c_void_p), ("esc", C.c_void_p), ("n_esc", C.c_int64),
         ("row_state", C.c_void_p), ("bits_packed", C.c_void_p),
         ("msg_off", C.c_void_p), ("pauses", C.c_void_p), ("pos_off", C.c_void_p), ("pos32", C.c_void_p),
-        ("blob", C.c_void_p), ("d_qad", C.c_void_p),
+        ("blob", C.c_void_p), ("d_qad", C.c_void_p), ("row16", C.c_void_p),
     ]
 
 

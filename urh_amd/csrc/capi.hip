@@ -653,12 +653,17 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         const StagedLayout SL = staged_layout(out->cap_rows, out->cap_bits, out->cap_msg, out->cap_pos, has_pos);
         h_state = (int8_t *)((char *)host_blob + SL.off_row_state); h_len = (int32_t *)((char *)host_blob + SL.off_row_len);
     }
-    // staged passes with 16-bit row lengths: the escape list (count, then pairs) sits in the staging blob's head region, behind the header's place
-    const bool l16 = to_stage && len16;
-    int64_t *esc = l16 ? (int64_t *)((char *)host_blob + URHGPU_BLOB_HEADER_BYTES) : nullptr;
-    const int64_t esc_cap = n / 65535 + 2;
+    // staged passes with 16-bit row lengths: the escape list (count, then pairs) sits in the staging blob's head region, behind the header's place;
+    // len16 == 2 (URHGPU_BLOB_ROW16: state and length in one uint16, escapes from 8191 samples on): the list is longer and has a place of
+    // its own behind every section of the split layout, in the staging blob while it is built and in the host blob (the caller sized both)
+    const bool l16 = to_stage && len16 != 0;
+    const bool row16 = l16 && len16 == 2;
+    int64_t row16_esc_off = 0;
+    if (row16) row16_esc_off = staged_layout(out->cap_rows, out->cap_bits, out->cap_msg, out->cap_pos, has_pos).total;
+    int64_t *esc = l16 ? (int64_t *)((char *)host_blob + (row16 ? row16_esc_off : (int64_t)URHGPU_BLOB_HEADER_BYTES)) : nullptr;
+    const int64_t esc_cap = row16 ? n / 8191 + 2 : n / 65535 + 2;
     SegPackDst dst{host_blob, cap_host, progress, 0, (direct && ctx->tune_stream_pos_direct) ? 1 : 0, to_stage ? 1 : 0, to_stage ? real_host_blob : nullptr,
-                   esc, esc_cap};
+                   esc, esc_cap, row16_esc_off};
     // bits segments: the last one is the last rows segment alone (what is exposed behind the hot kernel), the others share the rest
     int Sb = h_iq ? S : 1;       // (an upload: every piece's bits behind its rows -- the pieces are milliseconds apart)
     if (Sb > S) Sb = S;
@@ -676,7 +681,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
         if (h_iq) URH_HIP(hipStreamWaitEvent(ts, ctx->ev_piece[k], 0));
         else if (direct) URH_HIP(hipStreamWaitEvent(ts, hot_done, 0));
         RowsSegment sg{k, k == S - 1 ? 1 : 0, bound[k], bound[k + 1], SegGate{event_start ? nullptr : progress, k, target[k], k == 0 ? 1 : 0, st, (long long)200000000, 0},
-                       h_state, h_len, 1, l16 ? 1 : 0, esc, esc_cap};
+                       h_state, h_len, 1, l16 ? (row16 ? 2 : 1) : 0, esc, esc_cap};
         URH_TRY(launch_rows_segment(r, e, tm, bp, st, sg, ts));
         if (to_stage && ev_rows) URH_HIP(hipEventRecord(ev_rows, ts));      // (one segment: every row section is in the staging blob)
         while (jb < Sb && bits_end_at[jb] < k) ++jb;           // (a bits segment that would end before the first rows segment: none)

@@ -271,6 +271,8 @@ struct RowsSegment {         // chunks [c0, c1) of the capture's n_chunks (c0 a 
     // staged passes (round 6): lengths as uint16 INSTEAD of int32 (h_len then names the same section: 2 bytes per row), a length that does not
     // fit -- 65535 and more, or negative -- is stored as 0xFFFF and appended to esc: esc[0] = count (zeroed by the resolve kernel), then
     // {uint32 row, int32 length} pairs, esc_cap of them at most (a capture of n samples has at most n / 65535 + 2 such rows)
+    // len16 == 2 (URHGPU_BLOB_ROW16, dense pulse tables): ONE uint16 per row -- (state + 1) << 13 | length, 0x1FFF = escaped (8191 samples and
+    // more, or negative: at most n / 8191 + 2 rows) -- in the row_len section; nothing is stored into h_state
     int len16;
     int64_t *esc;
     int64_t esc_cap;
@@ -292,6 +294,7 @@ struct SegPackDst {          // where a bits segment's share of the compact blob
     void *host_head;         // ... and the head (header + pauses / offsets / packed bits: small) goes straight into this pinned HOST blob
     const int64_t *esc;      // staged passes with 16-bit row lengths: the escape list (RowsSegment::esc) the last kernel appends to the head; nullptr: int32 lengths
     int64_t esc_cap;
+    int64_t row16_esc_off;   // > 0: URHGPU_BLOB_ROW16 -- the list goes to this offset of host_head (behind every section: its own, sized place)
 };
 
 // Tile tail (single GPU, not ASK): resolve + rows in two launches, bits in three more; see pulse_table.hip.

@@ -946,7 +946,7 @@ struct EmitTileArgs {
     // (plain stores over PCIe, fire and forget; nullptr: not shipped)
     int8_t *h_state;
     int32_t *h_len;
-    int len16;               // h_len holds uint16 lengths, see RowsSegment::len16
+    int len16;               // 1: h_len holds uint16 lengths, 2: uint16 state | length words (no h_state stores); see RowsSegment::len16
     int64_t *esc;
     int64_t esc_cap;
 };
@@ -955,6 +955,16 @@ __host__ __device__ static inline int64_t tail_waves(int64_t n_items) { return (
 
 // a row's state and length into the shipped sections (EmitTileArgs::h_state / h_len): int32 lengths, or uint16 with the escape list
 __device__ __forceinline__ void ship_row(const EmitTileArgs &g, int64_t idx, int64_t state, int64_t len) {
+    if (g.len16 == 2) {
+        // URHGPU_BLOB_ROW16: state and length in ONE uint16 -- (state + 1) << 13 | length, 0x1FFF = look the row up in the escape list
+        const bool fits = len >= 0 && len < 0x1FFF;
+        ((uint16_t *)g.h_len)[idx] = (uint16_t)((((uint32_t)(state + 1) & 7u) << 13) | (fits ? (uint32_t)len : 0x1FFFu));
+        if (!fits) {
+            const unsigned long long slot = atomicAdd((unsigned long long *)g.esc, 1ull);
+            if ((int64_t)slot < g.esc_cap) g.esc[1 + slot] = (int64_t)(((uint64_t)(uint32_t)(int32_t)len << 32) | (uint64_t)(uint32_t)idx);
+        }
+        return;
+    }
     g.h_state[idx] = (int8_t)state;
     if (!g.len16) { g.h_len[idx] = (int32_t)len; return; }
     const bool fits = len >= 0 && len < 0xFFFF;
@@ -1856,6 +1866,7 @@ struct SegPack {
     char *head;              // where header and small sections go (split: the pinned host blob; else == host)
     const int64_t *esc;      // 16-bit row lengths: the escape list to append to the head (behind the packed bits); nullptr: int32 lengths
     int64_t esc_cap;
+    int64_t row16_esc_off;   // > 0: URHGPU_BLOB_ROW16 -- the escape list goes to this offset of the host blob instead (header[11] names it)
 };
 __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
     URH_TAIL_PRIO();
@@ -1897,7 +1908,7 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
         n_esc = a.esc[0];
         const bool over = n_esc > a.esc_cap;
         if (over) n_esc = a.esc_cap;
-        int64_t *dst = (int64_t *)(a.head + ((L.off_bits + (nbits + 7) / 8 + 15) & ~int64_t(15)));
+        int64_t *dst = (int64_t *)(a.head + (a.row16_esc_off > 0 ? a.row16_esc_off : ((L.off_bits + (nbits + 7) / 8 + 15) & ~int64_t(15))));
         if (gtid == 0) dst[0] = over ? -n_esc : n_esc;            // (negative: the list overflowed -- cannot happen for esc_cap = n / 65535 + 2)
         for (int64_t i = gtid; i < n_esc; i += stride) dst[1 + i] = a.esc[1 + i];
     }
@@ -1906,9 +1917,10 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
         const int64_t *c = a.counts;
         const int64_t n_rows = lim(*a.d_n_rows, a.cap_rows);
         hdr[1] = n_rows; hdr[2] = m1; hdr[3] = nbits; hdr[4] = p1; hdr[5] = c[4];
-        hdr[6] = URHGPU_BLOB_HEADER_BYTES + n_rows * (a.esc ? 3 : 5) + (a.esc ? 8 + n_esc * 8 : 0) + (nbits + 7) / 8 + p1 * 4 + m1 * 24 + 16;     // bytes that crossed PCIe for this pass
-        hdr[7] = a.has_pos | (a.esc ? URHGPU_BLOB_LEN16 : 0);
-        hdr[8] = L.off_pauses; hdr[9] = L.off_msg_off; hdr[10] = L.off_pos_off; hdr[11] = L.off_row_state; hdr[12] = L.off_bits;
+        const bool row16 = a.esc && a.row16_esc_off > 0;
+        hdr[6] = URHGPU_BLOB_HEADER_BYTES + n_rows * (row16 ? 2 : (a.esc ? 3 : 5)) + (a.esc ? 8 + n_esc * 8 : 0) + (nbits + 7) / 8 + p1 * 4 + m1 * 24 + 16;     // bytes that crossed PCIe for this pass
+        hdr[7] = a.has_pos | (row16 ? URHGPU_BLOB_ROW16 : (a.esc ? URHGPU_BLOB_LEN16 : 0));
+        hdr[8] = L.off_pauses; hdr[9] = L.off_msg_off; hdr[10] = L.off_pos_off; hdr[11] = row16 ? a.row16_esc_off : L.off_row_state; hdr[12] = L.off_bits;
         hdr[13] = L.off_row_len; hdr[14] = L.off_pos32;
         hdr[15] = ((c[1] > a.cap_msg || c[2] > a.cap_bits || (a.has_pos && c[3] > a.cap_pos) || c[4] > a.cap_rows) ? 1 : 0) | (a.seg->err ? 2 : 0);
         hdr[0] = URHGPU_BLOB_MAGIC;
@@ -1933,7 +1945,7 @@ int launch_rows_segment(const ResolveArgs &r, const EmitArgs &e, const TileTailM
     g.bp = bp; g.ft.want_bits = 1;
     g.w0 = sg.c0 / kTailCPW; g.w_end = sg.final ? tail_waves(r.n_chunks) : sg.c1 / kTailCPW; g.final_seg = sg.final; g.seg = state; g.seg_k = sg.index;
     g.h_state = sg.h_state; g.h_len = sg.h_len;
-    g.len16 = (sg.len16 && sg.esc && sg.h_len) ? 1 : 0; g.esc = g.len16 ? sg.esc : nullptr; g.esc_cap = sg.esc_cap;
+    g.len16 = (sg.len16 && sg.esc && sg.h_len) ? sg.len16 : 0; g.esc = g.len16 ? sg.esc : nullptr; g.esc_cap = sg.esc_cap;
     g.ft.esc = (g.len16 && sg.index == 0) ? sg.esc : nullptr;          // (the pass's first rows segment resets the list)
     if (g_tail_skip & 64) { g.h_state = nullptr; g.h_len = nullptr; }      // measurement: the row kernel without its host stores
     if (g_tail_skip & 128) g.e.rows = nullptr;                              // measurement: ... without the int64 table
@@ -2004,7 +2016,8 @@ int launch_bits_segment(const TileTailMem &m, const BitsParams &bp, const BitsOu
         if (((uintptr_t)o.bits & 7) || ((uintptr_t)dst->host & 15)) return URHGPU_ERR_ARG;
         SegPack pk{o.bits, o.msg_off, o.pauses, o.pos_off, o.pos, o.counts, cap_rows, o.cap_bits, o.cap_msg, o.cap_pos, has_pos, (char *)dst->host,
                    L, st, d_n_rows, parity, sg.final ? 1 : 0, sg.final ? dst->progress_reset : nullptr, pos_direct ? 1 : 0, split ? 1 : 0,
-                   (split && dst->host_head) ? (char *)dst->host_head : (char *)dst->host, split ? dst->esc : nullptr, dst->esc_cap};
+                   (split && dst->host_head) ? (char *)dst->host_head : (char *)dst->host, split ? dst->esc : nullptr, dst->esc_cap,
+                   (split && dst->esc) ? dst->row16_esc_off : 0};
         if (dst->cap_host < pk.L.total) return URHGPU_ERR_CAPACITY;
         if (!(g_tail_skip & 32)) hipLaunchKernelGGL(k_pack_seg, dim3(dst->blocks > 0 ? dst->blocks : 32), dim3(256), 0, s, pk);
     }

@@ -45,6 +45,9 @@ struct urhgpu_stream {
     int64_t seq = 0;
     int64_t streamed_passes = 0;           // passes whose tail ran in segments (diagnostics)
     bool len16 = false;                    // staged passes ship 16-bit row lengths + an escape list (the staging blob's head region holds the list)
+    bool row16_ok = false;                 // ... and may pack state and length into ONE uint16 per row (URHGPU_BLOB_ROW16) when the pulse table is dense: the blobs have room for that list
+    int64_t esc_extra = 0;                 // bytes behind the split layout's sections for URHGPU_BLOB_ROW16's escape list (staging and host blobs)
+    int64_t last_rows = 0;                 // rows of the last result handed out (dense: more than one row per 64 samples)
     int64_t staged_passes = 0;             // passes whose tail stored into the staging blob (tightened + copied by the copy engine)
     int64_t uploaded_passes = 0;           // ... of which the capture was uploaded piece by piece (urhgpu_stream_push_upload)
     int64_t predicted_bytes = 0;           // blob bytes the next pass's copy is sized for (0: header only, the rest fetched on demand)
@@ -71,8 +74,14 @@ void fill_result(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *
     r->row_state = (const int8_t *)(s.h_blob + hdr[11]);
     r->bits_packed = (const uint8_t *)(s.h_blob + hdr[12]);
     r->row_len = (const int32_t *)(s.h_blob + hdr[13]);
-    r->row_len16 = nullptr; r->esc = nullptr; r->n_esc = 0;
-    if (hdr[7] & URHGPU_BLOB_LEN16) {                        // 16-bit lengths + the escape list behind the packed bits
+    r->row_len16 = nullptr; r->esc = nullptr; r->n_esc = 0; r->row16 = nullptr;
+    if (hdr[7] & URHGPU_BLOB_ROW16) {                        // state | length words in the row_len section, the escape list at header[11]
+        r->row_len = nullptr; r->row_state = nullptr;
+        r->row16 = (const uint16_t *)(s.h_blob + hdr[13]);
+        const int64_t *e = (const int64_t *)(s.h_blob + hdr[11]);
+        r->n_esc = e[0] < 0 ? -e[0] : e[0];
+        r->esc = e + 1;
+    } else if (hdr[7] & URHGPU_BLOB_LEN16) {                        // 16-bit lengths + the escape list behind the packed bits
         r->row_len = nullptr;
         r->row_len16 = (const uint16_t *)(s.h_blob + hdr[13]);
         const int64_t *e = (const int64_t *)(s.h_blob + ((hdr[12] + (hdr[3] + 7) / 8 + 15) & ~int64_t(15)));
@@ -125,7 +134,8 @@ int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r
         // split layout: what the predictions missed, now -- the rest of the head (it ends with the packed bits), of the two row sections, of the positions
         const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
         const int64_t n_rows = hdr[1], n_pos = (hdr[7] & 1) ? hdr[4] : 0;
-        const int64_t len_bytes = (hdr[7] & URHGPU_BLOB_LEN16) ? 2 : 4;
+        const int64_t len_bytes = (hdr[7] & (URHGPU_BLOB_LEN16 | URHGPU_BLOB_ROW16)) ? 2 : 4;
+        const bool row16 = (hdr[7] & URHGPU_BLOB_ROW16) != 0;
         const int64_t head = (hdr[12] + (hdr[3] + 7) / 8 + 15) & ~int64_t(15);
         if (n_rows < 0 || n_rows > st->cap_rows || n_pos < 0 || n_pos > st->cap_pos || head < URHGPU_BLOB_HEADER_BYTES || head > SL.head_cap) return URHGPU_ERR_ARG;
         bool more = false;
@@ -136,12 +146,13 @@ int finish_copy(urhgpu_stream *st, urhgpu_stream::Slot &s, urhgpu_host_result *r
         };
         if (head > s.copied) URH_TRY(fetch(s.copied, head - s.copied));
         if (n_rows > s.copied_rows) {
-            URH_TRY(fetch(SL.off_row_state + s.copied_rows, n_rows - s.copied_rows));
+            if (!row16) URH_TRY(fetch(SL.off_row_state + s.copied_rows, n_rows - s.copied_rows));
             URH_TRY(fetch(SL.off_row_len + len_bytes * s.copied_rows, len_bytes * (n_rows - s.copied_rows)));
         }
         if (n_pos > s.copied_pos) URH_TRY(fetch(SL.off_pos32 + 4 * s.copied_pos, 4 * (n_pos - s.copied_pos)));
         if (more) { URH_HIP(hipStreamSynchronize(st->copy_stream)); st->short_copies += 1; }
         st->predicted_rows = n_rows + n_rows / 8 + 4096;
+        st->last_rows = n_rows;
         st->predicted_pos = n_pos + n_pos / 8 + 4096;
         fill_result(st, s, r);
         s.state = 3;
@@ -200,6 +211,10 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
         // 16-bit row lengths for staged passes: their escape list lives in the staging blob's (otherwise unused) head region
         const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
         st->len16 = SL.head_cap - URHGPU_BLOB_HEADER_BYTES >= 8 + (n_max / 65535 + 2) * 8 + 16;
+        // URHGPU_BLOB_ROW16 (dense pulse tables): its escape list -- a row of 8191 samples and more -- gets a place of its own behind the split
+        // layout's sections, in the staging blobs and in the host blobs
+        st->esc_extra = ((8 + (n_max / 8191 + 2) * 8 + 16 + 255) & ~int64_t(255)) + std::max<int64_t>(0, SL.total - st->cap_blob);
+        st->row16_ok = st->len16 && p->bits_per_symbol <= 2;                    // (state + 1 in three bits: orders 2 and 4)
     }
     st->was_pipelined = ctx->pipelined;
     if (!ctx->pipelined) { status = urhgpu_ctx_set_pipelined(ctx, 1, nullptr); if (status != URHGPU_OK) { delete st; return status; } }
@@ -207,15 +222,15 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
     if (status != URHGPU_OK) { urhgpu_stream_destroy(st); return status; }
     if (hipStreamCreateWithFlags(&st->copy_stream, hipStreamNonBlocking) != hipSuccess) { urhgpu_stream_destroy(st); return URHGPU_ERR_HIP; }
     const size_t b_qad = st->want_qad ? a256((size_t)n_max * 4) : 0, b_rows = a256((size_t)st->cap_rows * 16), b_bits = a256((size_t)st->cap_bits),
-                 b_off = a256((size_t)(st->cap_msg + 1) * 8), b_pos = st->want_pos ? a256((size_t)st->cap_pos * 8) : 0, b_blob = a256((size_t)st->cap_blob);
+                 b_off = a256((size_t)(st->cap_msg + 1) * 8), b_pos = st->want_pos ? a256((size_t)st->cap_pos * 8) : 0, b_blob = a256((size_t)(st->cap_blob + st->esc_extra));
     if (st->want_qad)
         for (auto &q : st->qad_ring)
             if (hipMalloc((void **)&q, b_qad) != hipSuccess) { urhgpu_stream_destroy(st); return URHGPU_ERR_HIP; }
     for (auto &s : st->slot) {
         memset(&s.out, 0, sizeof(s.out));
         if (hipMalloc(&s.dev, b_rows + b_bits + 3 * b_off + b_pos + 256 + 2 * b_blob) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_blob2[0], (size_t)st->cap_blob) != hipSuccess ||
-            hipHostMalloc((void **)&s.h_blob2[1], (size_t)st->cap_blob) != hipSuccess || hipHostMalloc((void **)&s.h_counts, 64) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_blob2[0], (size_t)(st->cap_blob + st->esc_extra)) != hipSuccess ||
+            hipHostMalloc((void **)&s.h_blob2[1], (size_t)(st->cap_blob + st->esc_extra)) != hipSuccess || hipHostMalloc((void **)&s.h_counts, 64) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_tail, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_copy, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&s.ev_rows, hipEventDisableTiming) != hipSuccess ||
@@ -306,7 +321,14 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
     // sections as soon as the row kernel is through (while the bits are expanded), the head (+ positions) behind the pass's last kernel.
     bool streamed = false, staged = false;
     s.staged = false;
-    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq, s.stage, &staged, s.ev_rows, st->len16 ? 1 : 0));
+    // 16-bit row lengths (3 bytes per row); a DENSE pulse table -- more than one row per 64 samples in the last result -- ships state and length
+    // in one uint16 (2 bytes per row: what a step ships over PCIe bounds such captures)
+#ifdef URH_NO_ROW16
+    const int len_mode = st->len16 ? 1 : 0;
+#else
+    const int len_mode = !st->len16 ? 0 : ((st->row16_ok && st->last_rows > n / 64) ? 2 : 1);
+#endif
+    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq, s.stage, &staged, s.ev_rows, len_mode));
     if (streamed && staged) {
         const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
         const int64_t rows = std::min<int64_t>(st->predicted_rows, st->cap_rows), npos = st->want_pos ? std::min<int64_t>(st->predicted_pos, st->cap_pos) : 0;
@@ -314,8 +336,8 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
         if (rows > 0 && !skip_copy) {
             // (behind the row kernel, not behind the pass's last kernel: measured the same to slightly better, 0.2839-0.2847 against 0.2848-0.2880 ms per step at K = 20)
             URH_HIP(hipStreamWaitEvent(st->copy_stream, s.ev_rows, 0));
-            URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_state, s.stage + SL.off_row_state, (size_t)rows, hipMemcpyDeviceToHost, st->copy_stream));
-            URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_len, s.stage + SL.off_row_len, (size_t)rows * (st->len16 ? 2 : 4), hipMemcpyDeviceToHost, st->copy_stream));
+            if (len_mode != 2) URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_state, s.stage + SL.off_row_state, (size_t)rows, hipMemcpyDeviceToHost, st->copy_stream));
+            URH_HIP(hipMemcpyAsync(s.h_blob + SL.off_row_len, s.stage + SL.off_row_len, (size_t)rows * (len_mode ? 2 : 4), hipMemcpyDeviceToHost, st->copy_stream));
         }
         // (recorded behind the pass's last kernel, which has stored the head -- header, pauses, offsets, packed bits: small -- into the host
         // blob itself: no copy of it, no hop to another stream at the end of the chain)

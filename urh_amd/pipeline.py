@@ -283,6 +283,7 @@ class HostBits:
         self.d_qad_ptr = r.d_qad
         # the views are made when somebody looks (a push per 0.3 ms must not allocate a dozen objects each)
         self._len16 = (r.row_len16, r.esc, int(r.n_esc)) if r.row_len16 else None      # 16-bit lengths + escape list (URHGPU_BLOB_LEN16)
+        self._row16 = (r.row16, r.esc, int(r.n_esc)) if getattr(r, "row16", None) else None      # state | length words + escape list (URHGPU_BLOB_ROW16)
         self._ptr = dict(row_len=(r.row_len, self.n_rows, np.int32), row_state=(r.row_state, self.n_rows, np.int8),
                          bits_packed=(r.bits_packed, (self.n_bits + 7) // 8, np.uint8), msg_off=(r.msg_off, self.n_msg + 1, np.int64),
                          pauses=(r.pauses, self.n_msg, np.int64), pos_off=(r.pos_off, self.n_msg + 1, np.int64),
@@ -292,6 +293,26 @@ class HostBits:
         spec = self.__dict__.get("_ptr", {}).get(name, False)
         if spec is False:
             raise AttributeError(name)
+        if name in ("row_len", "row_state") and self.__dict__.get("_row16") is not None:
+            # one uint16 per row: (state + 1) << 13 | length; a length field of 0x1FFF = look the row up in the escape list
+            p16, pesc, n_esc = self._row16
+            if self.n_rows <= 0:
+                state, value = np.zeros(0, np.int8), np.zeros(0, np.int32)
+            else:
+                w = np.frombuffer((C.c_ubyte * (2 * self.n_rows)).from_address(p16), dtype=np.uint16, count=self.n_rows)
+                state = ((w >> 13).astype(np.int16) - 1).astype(np.int8)
+                value = (w & 0x1FFF).astype(np.int32)
+                marked = value == 0x1FFF
+                rows = np.zeros(0, np.int64)
+                if n_esc > 0:
+                    e = np.frombuffer((C.c_ubyte * (8 * n_esc)).from_address(pesc), dtype=np.uint32, count=2 * n_esc).reshape(-1, 2)
+                    rows = e[:, 0].astype(np.int64)
+                if int(marked.sum()) != n_esc or (n_esc and (rows.max() >= self.n_rows or not marked[rows].all() or len(np.unique(rows)) != n_esc)):
+                    raise _lib.UrhGpuError(_lib.ERR_UNSUPPORTED, "compact blob: the packed rows and their escape list do not match")
+                if n_esc > 0:
+                    value[rows] = e[:, 1].copy().view(np.int32)
+            self.__dict__["row_len"], self.__dict__["row_state"] = value, state
+            return self.__dict__[name]
         if name == "row_len" and self.__dict__.get("_len16") is not None:
             # widen the shipped uint16 lengths; 0xFFFF = look the row up in the escape list ({uint32 row, int32 length} pairs)
             p16, pesc, n_esc = self._len16
@@ -337,7 +358,10 @@ class HostBits:
         r.truncated = int(hdr[15])
         r.pauses, r.msg_off, r.pos_off = host_ptr + int(hdr[8]), host_ptr + int(hdr[9]), host_ptr + int(hdr[10])
         r.row_state, r.bits_packed, r.row_len = host_ptr + int(hdr[11]), host_ptr + int(hdr[12]), host_ptr + int(hdr[13])
-        if int(hdr[7]) & _lib.BLOB_LEN16:
+        if int(hdr[7]) & _lib.BLOB_ROW16:
+            n_esc = int(np.frombuffer((C.c_ubyte * 8).from_address(host_ptr + int(hdr[11])), dtype=np.int64, count=1)[0])
+            r.row16, r.row_len, r.row_state, r.esc, r.n_esc = r.row_len, None, None, host_ptr + int(hdr[11]) + 8, abs(n_esc)
+        elif int(hdr[7]) & _lib.BLOB_LEN16:
             off_esc = (int(hdr[12]) + (int(hdr[3]) + 7) // 8 + 15) & ~15
             n_esc = int(np.frombuffer((C.c_ubyte * 8).from_address(host_ptr + off_esc), dtype=np.int64, count=1)[0])
             r.row_len16, r.row_len, r.esc, r.n_esc = r.row_len, None, host_ptr + off_esc + 8, abs(n_esc)
