@@ -113,7 +113,8 @@ int queue_copy(urhgpu_stream *st, urhgpu_stream::Slot &s) {
     return URHGPU_OK;
 }
 
-// (a bounded hipEventQuery spin in front of this was measured slower in round 4: 0.420 against 0.408 ms for one capture)
+// (a bounded hipEventQuery spin in front of this was measured slower in round 4: 0.420 against 0.408 ms for one capture; again in round 6 on the
+// K = 20 loop, tools/k20_probe.py: 0.2831-0.2840 with it, 0.2832-0.2837 without)
 int wait_event(hipEvent_t e) {
     URH_HIP(hipEventSynchronize(e));
     return URHGPU_OK;
