@@ -285,6 +285,37 @@ def test_from_file_streamed_equals_from_file(oracle, tmp_path, ext, dtype, n):
 
 
 @pytest.mark.gpu
+def test_from_file_streamed_keeps_its_stream_between_files(oracle, tmp_path):
+    """`pinned=` keeps the pinned read buffer and the capture stream between calls (a stream -- three output slots, six pinned
+    blobs -- was built and destroyed per file): three captures of one size class opened one after the other through ONE stream, each equal
+    to the reference's digitisation; another parameter set rebuilds the stream; the earlier Signals stay valid (their results were copied)."""
+    from urh_amd.signal import Signal
+    n = (1 << 20) + 4096
+    par = dict(modulation_type="FSK", samples_per_symbol=100, center=0.0, tolerance=5, noise_threshold=0.1, pause_threshold=8)
+    keep, sigs, files = {}, [], []
+    for i in range(3):
+        iq = synth_fsk(n - 8192 * i, sps=100, seed=70 + i, noise=0.04, pause_every=n // 4, pause_len=3000 + 500 * i)
+        f = str(tmp_path / f"c{i}.complex")
+        iq.tofile(f)
+        files.append(iq)
+        sigs.append(Signal.from_file_streamed(f, pinned=keep, **par))
+        if i == 0:
+            first_stream = keep["stream"]
+        assert keep["stream"] is first_stream and first_stream.stats()["pushed"] == i + 1
+    for iq, s in zip(files, sigs):
+        qad = oracle.afp_demod(iq, 0.1, "FSK", 2)
+        pp = oracle.grab_pulse_lens(qad, 0.0, 5, "FSK", 100, 1, 1.0)
+        assert np.array_equal(s.qad.cpu().numpy().view(np.uint32), qad.view(np.uint32)) and np.array_equal(s.ppseq(), pp)
+        for a, b in zip(s._digitize()[1:], oracle.ppseq_to_bits_flat(pp, 100, 1, True, 8)):
+            assert np.array_equal(np.asarray(a), b)
+    s4 = Signal.from_file_streamed(str(tmp_path / "c0.complex"), pinned=keep, **dict(par, tolerance=3))
+    assert keep["stream"] is not first_stream
+    pp = oracle.grab_pulse_lens(oracle.afp_demod(files[0], 0.1, "FSK", 2), 0.0, 3, "FSK", 100, 1, 1.0)
+    assert np.array_equal(s4.ppseq(), pp)
+    keep["stream"].close()
+
+
+@pytest.mark.gpu
 def test_from_file_streamed_falls_back_when_the_stream_cannot_take_the_capture(oracle, tmp_path):
     """A noise-dominated capture read with tolerance 0 and no noise gate has far more pulse-table rows than the stream's default capacity
     (about four per symbol): the streamed route reports `truncated` and the Signal falls back to the ordinary passes with their capacity

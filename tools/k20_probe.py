@@ -1,5 +1,5 @@
 """tools/k20_probe.py: the driver's measurement in small -- K = 20 pipelined steps of the headline capture through urhgpu_stream_* (push x K, flush,
-synchronize), median and minimum of 15 repetitions behind a clock ramp.  URHGPU_LIB selects an A/B build."""
+synchronize), median and minimum of 15 repetitions behind a clock ramp.  URHGPU_LIB selects an A/B build, URH_TUNE_<KEY>=<value> a tuning key."""
 import os, sys, time, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 iq, _ = spec_fsk_capture(128, dev, first_segment=0, sps=100)
 n = iq.shape[0]
 p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, False)
-pipe = DevicePipeline(0, pipelined=True)
+pipe = DevicePipeline(0, pipelined=True, tuning={k[9:].lower(): int(v) for k, v in os.environ.items() if k.startswith("URH_TUNE_")})
 pipe.reserve(n, p)
 st = pipe.stream(n, p, want_qad=True, want_pos=False)
 def run(k):

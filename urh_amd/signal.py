@@ -111,12 +111,18 @@ class Signal:
         (modulation_type, samples_per_symbol, center, tolerance, noise_threshold, ...) plus the constructor's keywords.
         Float32 / signed captures of ASK-less, PSK-less modulations take this route; everything else (unsigned sample types, which the
         reference converts first; ASK; PSK) falls back to from_file + the ordinary lazy passes -- same results either way.
-        pinned: an optional dict that keeps the pinned read buffer between calls (a file browser opening capture after capture)."""
+        pinned: an optional dict that keeps the pinned read buffer AND the capture stream (three output slots, six pinned blobs: what a
+        stream costs to build) between calls -- a file browser opening capture after capture with the same parameters; the stream is
+        rebuilt when the parameters, the sample type or the size class change, `pinned["stream"].close()` releases it."""
         ctor = {k: params.pop(k) for k in ("name", "sample_rate", "timestamp", "pipe", "device") if k in params}
         if "modulation_type" in params:
             ctor["modulation"] = params.pop("modulation_type")
         signed = {".complex16s": np.int8, ".cs8": np.int8, ".complex32s": np.int16, ".cs16": np.int16}
         unsigned = (".complex16u", ".cu8", ".complex32u", ".cu16")
+        if pinned is not None and ctor.get("pipe") is None:                      # the kept stream belongs to a pipeline: kept with it
+            if pinned.get("pipe") is None:
+                pinned["pipe"] = DevicePipeline(ctor.get("device"))
+            ctor["pipe"] = pinned["pipe"]
         s = cls(None, **ctor)
         for k, v in params.items():
             setattr(s, k, v)
@@ -153,9 +159,21 @@ class Signal:
         # ERR_UNSUPPORTED and the reference's own ZeroDivisionError / OverflowError for them) -- falls back to the ordinary lazy passes with
         # their capacity retry, on the capture that is by then resident: same results either way.
         st = None
+        pushed_before = 0
+        kept = False                                                              # the stream lives on in `pinned`
         try:
             p = s.params()
-            st = s.pipe.stream(n, p, want_qad=True, want_pos=True, dtype=dt)      # (an upload: its own piece-wise route whatever the latency setting)
+            key = (id(s.pipe), repr(p), dt.str)
+            if pinned is not None and keep.get("stream_key") == key and keep.get("stream") is not None and n <= keep.get("stream_n", 0):
+                st, kept = keep["stream"], True                                   # (its results were copied out by the call that made them)
+            else:
+                if pinned is not None and keep.get("stream") is not None:
+                    keep.pop("stream").close()
+                    keep.pop("stream_key", None)
+                st = s.pipe.stream(n, p, want_qad=True, want_pos=True, dtype=dt)      # (an upload: its own piece-wise route whatever the latency setting)
+                if pinned is not None:
+                    keep["stream"], keep["stream_key"], keep["stream_n"], kept = st, key, n, True
+            pushed_before = st.stats()["pushed"]
             st.push_upload(host, dev)                                             # (host / dev stay referenced by this frame until flush() returns)
             (h,) = st.flush()
             h.check()
@@ -171,12 +189,15 @@ class Signal:
             if isinstance(exc, _lib.UrhGpuError) and exc.status not in (_lib.ERR_CAPACITY, _lib.ERR_ARG, _lib.ERR_UNSUPPORTED):
                 raise
             s.pipe.ctx.sync()
-            if st is None or st.stats()["pushed"] == 0:
+            if st is None or st.stats()["pushed"] == pushed_before:
                 dev.copy_(host, non_blocking=False)                               # the stream never took the capture: one plain copy
             s._iq = dev
             s._drop_cache()
+            if kept and st is not None:                                           # a stream that failed is not kept
+                keep.pop("stream", None); keep.pop("stream_key", None)
+                kept = False
         finally:
-            if st is not None:
+            if st is not None and not kept:
                 st.close()
         return s
 
