@@ -47,6 +47,12 @@ enum { SRC_IQ = 0, SRC_QAD = 1 };
 #define URH_MINWAVES 1
 #endif
 #ifndef URH_SPEC
+#ifndef URH_WIDE_INT
+#define URH_WIDE_INT 0      // A/B builds: 1 gives the integer instantiations the wide loop too (with URH_HOT_WAVES_INT=7: at 64 VGPRs their fast loop spills
+                            // beside it).  Measured, int8: wide deviations 0.452-0.469 -> 0.343-0.349 ms per pass, but the narrow capture 0.2568 ->
+                            // 0.2687-0.2718 ms per pipelined step (seven wavefronts per SIMD, spills at the loop header): not the default; what it
+                            // wants is an instantiation of its own that the launcher picks from what the stream's last pass met
+#endif
 #ifndef URH_NO_WIDE
 #define URH_NO_WIDE 0     // A/B builds (tools/quick_tag.sh): 1 leaves the batch-level wide loop (fsk_wide) out
 #endif
@@ -1285,7 +1291,7 @@ void k_demod_runs_bp(const RunArgs p) {
     constexpr bool kIntCapture = DT != URHGPU_DT_F32;
     // the wide loop (fsk_wide) for float32 captures only: the integer instantiations are held to 64 VGPRs (eight wavefronts per SIMD), and with
     // the wide loop beside it their FAST loop reloads spilled registers in every iteration (int8 step 0.269 -> 0.294 ms)
-    constexpr bool kWideLoop = !kIntCapture && !URH_NO_WIDE;
+    constexpr bool kWideLoop = (!kIntCapture || URH_WIDE_INT) && !URH_NO_WIDE;
     RowIn cur[kBatch] = {}, nxt[kBatch];
     v4f cv[kBatch], nv[kBatch];                               // kFskFast: the rows as 4-vectors
     if (kFskFast) load_rows_v4<DT>(p, a0, r0, lane, cv);
