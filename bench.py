@@ -357,12 +357,20 @@ def variant_steps(torch, pipe, iq, p, n, args, ramp, headline_copy):
     st.close()
     # ---- integer captures: the same signal quantised (amplitude 1 -> 8192 / 64 LSB), demodulated from their own 4 / 2 bytes per sample ----
     ref = _ref_modules()
-    for name, tdt, ndt, scale, bps in (("int16", torch.int16, np.int16, 8192.0, 8), ("int8", torch.int8, np.int8, 64.0, 6)):
-        x = (iq * scale).round().clamp(-32767 if ndt is np.int16 else -127, 32767 if ndt is np.int16 else 127).to(tdt).contiguous()
+    for name, tdt, ndt, scale, bps in (("int16", torch.int16, np.int16, 8192.0, 8), ("int8", torch.int8, np.int8, 64.0, 6), ("int8_wide", torch.int8, np.int8, 64.0, 6)):
+        src = iq
+        if name == "int8_wide":
+            # the same generator at a deviation of +-100 kHz (0.63 rad per sample: every batch leaves the hot kernel's fast loop): the stream probes
+            # its captures and takes the integer instantiation with the wide loop (k_wide_probe; urh_amd/csrc/stream.hip)
+            from urh_amd.synth import spec_fsk_capture as _gen
+            src, _ = _gen(n >> 20, iq.device, first_segment=0, sps=p.samples_per_symbol, deviation_hz=100e3)
+        x = (src * scale).round().clamp(-32767 if ndt is np.int16 else -127, 32767 if ndt is np.int16 else 127).to(tdt).contiguous()
+        del src
         st = pipe.stream(n, p_np, want_qad=True, want_pos=False, dtype=ndt)
         ms, last = timed(st, x)
         r = {"ms_per_step": round(ms, 4), "bytes_per_sample": bps, "frac_of_8TBs": frac(ms, bps), "Msamples_per_s": round(n / ms / 1e3, 1),
-             "capture": f"the headline capture x {scale:g}, rounded to {name}"}
+             "capture": (f"the headline capture x {scale:g}, rounded to {name}" if name != "int8_wide" else
+                         "the configs[1] generator at a deviation of +-100 kHz (0.63 rad per sample) x 64, rounded to int8")}
         if not args.no_cpu_baseline:
             host = x.cpu().numpy()
             if ref is not None:

@@ -204,3 +204,45 @@ def test_stream_ships_packed_rows_for_dense_tables(oracle, bps):
     # the pass after a dense result is packed (the stream decides by the last result it has handed out: a few passes behind)
     assert packed >= 3 and any(got[k][3] and got[k][4] > 0 for k in got) and not all(got[k][3] for k in got)
     st.close()
+
+
+@pytest.mark.parametrize("dtype", [np.int8, np.int16])
+def test_integer_stream_switches_to_the_wide_instantiation_and_back(oracle, dtype):
+    """Streams of signed integer FSK captures probe their captures (k_wide_probe behind every pass: the share of phase steps beyond the fast loop's
+    window) and take the hot kernel's instantiation with the wide loop from 1 % on, the default one again below 0.3 %: narrow captures, then
+    wide ones (+-120 kHz at 1 MS/s: 0.75 rad per sample), then narrow ones again, pushed back to back -- every result equals the reference's
+    demodulated signal, pulse table, bits and pauses whichever instantiation its pass took."""
+    import ctypes as C
+    import torch
+    from urh_amd import _lib
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    n = (1 << 20) + 4096 * 2
+    pipe = DevicePipeline(0, pipelined=True)
+    amp = 0.6 * np.iinfo(dtype).max
+    p = DemodParams("FSK", 1, 0.1 * amp, 0.0, 1.0, 3, 50, 0.1, 8, False)
+    caps = []
+    for i, dev_hz in enumerate([20e3] * 4 + [120e3] * 6 + [20e3] * 5):
+        x = synth_fsk(n, sps=50, seed=900 + i, noise=0.03, pause_every=n // 3, pause_len=2500, deviation_hz=dev_hz)
+        caps.append(np.clip(np.round(x * amp), np.iinfo(dtype).min, np.iinfo(dtype).max).astype(dtype))
+    st = pipe.stream(n, p, want_qad=True, want_pos=False, dtype=dtype)
+    got = {}
+
+    def keep(r):
+        if r is not None:
+            r.check()
+            q = np.empty(n, np.float32)
+            _lib.check(_lib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(r.d_qad_ptr), q.ctypes.data_as(C.c_void_p), n * 4))
+            got[r.seq] = (q, r.ppseq(), r.bits(), r.pauses.copy())
+    for c in caps:
+        keep(st.push(torch.from_numpy(c).cuda()))
+    for r in st.flush():
+        keep(r)
+    assert sorted(got) == list(range(len(caps)))
+    for k, iq in enumerate(caps):
+        qad = oracle.afp_demod(iq, p.noise_threshold, "FSK", 2)
+        pp = oracle.grab_pulse_lens(qad, 0.0, 3, "FSK", 50, 1, 1.0)
+        bits, off, pauses, pos, poff = oracle.ppseq_to_bits_flat(pp, 50, 1, True, 8)
+        g = got[k]
+        assert np.array_equal(g[0].view(np.uint32), qad.view(np.uint32)), (k, int((g[0].view(np.uint32) != qad.view(np.uint32)).sum()))
+        assert np.array_equal(g[1], pp) and np.array_equal(g[2], bits) and np.array_equal(g[3], pauses), k
+    st.close()

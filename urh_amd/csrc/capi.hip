@@ -483,6 +483,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
     a.lds_pad = ctx->hot_lds_pad;
+    a.wide_int = ctx->wide_int_next;
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     int64_t bound[kMaxSegments + 1];
     int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, h_iq ? ctx->tune_upload_pieces : ctx->tune_stream_segments, h_iq ? 2 : 0, 1, bound) : 0;

@@ -83,6 +83,7 @@ struct urhgpu_ctx {
     int64_t *d_counts = nullptr;   // small device result block (8 x int64)
     int64_t *h_counts = nullptr;   // pinned host mirror
     bool tune_spin_wait = true;    // wait_stream polls (see there)
+    int wide_int_next = 0;         // the next streamed pass over a signed integer FSK capture takes the wide-loop instantiation (set by urhgpu_stream_*, RunArgs::wide_int)
     char *h_small = nullptr;       // pinned landing zone of the estimators' small results (kSmallPinned bytes): copies into it are truly asynchronous
     int32_t *d_tickets = nullptr;  // 8 zeroed ints: elections of the fused scan kernels (scan.hpp)
     void *d_desc = nullptr;        // descriptors of the single-pass scans: dedicated, zeroed when (re)allocated

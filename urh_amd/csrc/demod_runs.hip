@@ -1249,15 +1249,16 @@ template <int SRC, int MOD> constexpr int bp_waves() { return (SRC == SRC_IQ && 
 #ifndef URH_HOT_WAVES_INT
 #define URH_HOT_WAVES_INT 8   // ... and its integer instantiations (64 VGPRs: the fast loop does not spill; measured 0.264 -> 0.259 ms per pipelined int8 step)
 #endif
-template <int DT> constexpr int bp_hot_waves() { return DT == URHGPU_DT_F32 ? URH_HOT_WAVES : URH_HOT_WAVES_INT; }
+// (WIDEI: the integer instantiation WITH the wide loop -- seven wavefronts per SIMD as the float32 one: at eight its fast loop spills beside it)
+template <int DT, bool WIDEI = false> constexpr int bp_hot_waves() { return (DT == URHGPU_DT_F32 || WIDEI) ? URH_HOT_WAVES : URH_HOT_WAVES_INT; }
 #ifndef URH_INT_WAVES7
 #define URH_INT_WAVES7 1
 #endif
 template <int SRC, int DT, int MOD, bool RUNS, int NPL> constexpr bool bp_seven() {
     return URH_INT_WAVES7 && SRC == SRC_IQ && MOD == URHGPU_MOD_FSK && RUNS && NPL == 1;
 }
-template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1, bool STAMPS = false>
-__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) __attribute__((amdgpu_waves_per_eu((STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? bp_hot_waves<DT>() : 1, (STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? bp_hot_waves<DT>() : 8)))
+template <int SRC, int DT, int MOD, bool WRITE_QAD, bool RUNS = true, int NPL = 1, bool STAMPS = false, bool WIDEI = false>
+__global__ __launch_bounds__((kBlock * bp_waves<SRC, MOD>())) __attribute__((amdgpu_waves_per_eu((STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? bp_hot_waves<DT, WIDEI>() : 1, (STAMPS || bp_seven<SRC, DT, MOD, RUNS, NPL>()) ? bp_hot_waves<DT, WIDEI>() : 8)))
 void k_demod_runs_bp(const RunArgs p) {
     // One workgroup per chunk, URH_WPB wavefronts: wavefront w streams the w-th share of the chunk's rows on its own
     // (no barrier inside the streaming phase), so that the wavefronts resident on the chip cover a NARROW window of
@@ -1289,9 +1290,11 @@ void k_demod_runs_bp(const RunArgs p) {
     constexpr int kBatch = URH_KBATCH;
     constexpr bool kFskFast = URH_SPEC && SRC == SRC_IQ && MOD == URHGPU_MOD_FSK;
     constexpr bool kIntCapture = DT != URHGPU_DT_F32;
-    // the wide loop (fsk_wide) for float32 captures only: the integer instantiations are held to 64 VGPRs (eight wavefronts per SIMD), and with
-    // the wide loop beside it their FAST loop reloads spilled registers in every iteration (int8 step 0.269 -> 0.294 ms)
-    constexpr bool kWideLoop = (!kIntCapture || URH_WIDE_INT) && !URH_NO_WIDE;
+    // the wide loop (fsk_wide) for float32 captures, and for integer captures in an instantiation of its own (WIDEI: seven wavefronts per SIMD)
+    // that the launcher takes when RunArgs::wide_int says so (capture streams probe their captures: k_wide_probe): the default integer
+    // instantiations are held to 64 VGPRs (eight wavefronts per SIMD), where the FAST loop reloads spilled registers in every iteration with
+    // the wide loop beside it (int8 step 0.269 -> 0.294 ms), and at seven the narrow capture loses 5 % (profiles/r06s_deviation_pmc.txt)
+    constexpr bool kWideLoop = (!kIntCapture || WIDEI || URH_WIDE_INT) && !URH_NO_WIDE;
     RowIn cur[kBatch] = {}, nxt[kBatch];
     v4f cv[kBatch], nv[kBatch];                               // kFskFast: the rows as 4-vectors
     if (kFskFast) load_rows_v4<DT>(p, a0, r0, lane, cv);
@@ -1768,6 +1771,19 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
         // completion event -- ADVICE r5)
         constexpr bool stamps_ok = SRC == SRC_IQ && DT == URHGPU_DT_F32 && MOD == URHGPU_MOD_FSK && WQ;
         const bool stamps = a.stamp_probe && stamps_ok;
+        // integer FSK captures with wide phase steps (RunArgs::wide_int): the instantiation with the wide loop
+        constexpr bool widei_ok = SRC == SRC_IQ && (DT == URHGPU_DT_I8 || DT == URHGPU_DT_I16) && MOD == URHGPU_MOD_FSK;      // (unsigned samples are not centred: re > 0)
+        if (widei_ok && a.wide_int && planes_ok && (O2 || a.order == 4)) {
+            const bool ev = (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used;
+            if (O2 && ev) {
+                hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 1, false, widei_ok>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
+                                      (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
+                g_hot_events.used = true;
+            } else if (O2)
+                hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 1, false, widei_ok>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
+            else
+                hipLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 2, false, widei_ok>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()), (size_t)a.lds_pad, s, a);
+        } else
         if (planes_ok && O2 && stamps && (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used) {
             hipExtLaunchKernelGGL((k_demod_runs_bp<SRC_IQ, URHGPU_DT_F32, URHGPU_MOD_FSK, true, true, 1, true>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),
                                   (size_t)a.lds_pad, s, g_hot_events.start, g_hot_events.stop, 0, a);
@@ -1825,6 +1841,51 @@ int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, h
         case URHGPU_DT_U16: return launch_runs_2<URHGPU_DT_U16>(a, mod, write_qad, s);
         default: return URHGPU_ERR_DTYPE;
     }
+}
+
+// How wide are an integer capture's phase steps?  ONE workgroup samples 4096 pairs of neighbouring samples spread over the capture and counts
+// those the hot kernel's fast loop would flag -- re <= 0 or |im| >= 0.4375 re (a phase step of atan(7/16) = 0.41 rad and more) -- among the pairs
+// above the noise gate; out[0] = per mille of them, out[1] = pairs counted (pinned host memory: the stream reads it at its next push and picks
+// the instantiation, RunArgs::wide_int).  A statistic for a choice of code path only: no result depends on it.
+template <int DT>
+__global__ __launch_bounds__(1024) void k_wide_probe(const void *iq, int64_t n, float noise_sqrd, int32_t *out) {
+    __shared__ int s_w[16], s_v[16];
+    int wide = 0, valid = 0;
+    const int64_t stride = (n - 2) / 4096 > 0 ? (n - 2) / 4096 : 1;
+#pragma unroll
+    for (int k = threadIdx.x; k < 4096; k += 1024) {
+        const int64_t i = (int64_t)k * stride;
+        if (i + 1 >= n) break;
+        float a, b, c, d;
+        Iq<DT>::load1(iq, i, a, b);
+        Iq<DT>::load1(iq, i + 1, c, d);
+        if (!(c * c + d * d > noise_sqrd)) continue;
+        const float re = a * c + b * d, im = a * d - b * c;
+        ++valid;
+        if (!(re > 0.0f) || !(__builtin_fabsf(im) < 0.4375f * re)) ++wide;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { wide += __shfl_xor(wide, o); valid += __shfl_xor(valid, o); }
+    if ((threadIdx.x & 63) == 0) { s_w[threadIdx.x >> 6] = wide; s_v[threadIdx.x >> 6] = valid; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int w = 0, v = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { w += s_w[k]; v += s_v[k]; }
+        out[1] = v;
+        out[0] = v > 0 ? (int32_t)((int64_t)w * 1000 / v) : 0;
+    }
+}
+int launch_wide_probe(const void *d_iq, int dtype, int64_t n, float noise_sqrd, int32_t *h_out, hipStream_t s) {
+    if (n < 2 || !d_iq || !h_out) return URHGPU_ERR_ARG;
+    switch (dtype) {
+        case URHGPU_DT_I8: hipLaunchKernelGGL(k_wide_probe<URHGPU_DT_I8>, dim3(1), dim3(1024), 0, s, d_iq, n, noise_sqrd, h_out); break;
+        case URHGPU_DT_U8: hipLaunchKernelGGL(k_wide_probe<URHGPU_DT_U8>, dim3(1), dim3(1024), 0, s, d_iq, n, noise_sqrd, h_out); break;
+        case URHGPU_DT_I16: hipLaunchKernelGGL(k_wide_probe<URHGPU_DT_I16>, dim3(1), dim3(1024), 0, s, d_iq, n, noise_sqrd, h_out); break;
+        case URHGPU_DT_U16: hipLaunchKernelGGL(k_wide_probe<URHGPU_DT_U16>, dim3(1), dim3(1024), 0, s, d_iq, n, noise_sqrd, h_out); break;
+        default: return URHGPU_ERR_DTYPE;
+    }
+    return URHGPU_OK;
 }
 
 // Can a pass with these arguments be streamed (RunArgs::progress)?  Only the bit-plane kernel counts its chunks: orders 2 and 4,

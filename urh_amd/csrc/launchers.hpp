@@ -49,6 +49,7 @@ struct RunArgs {
     // 269): chunks [0, graded_from) are chunk_len samples long, the chunks from graded_from on graded_len (a multiple of W rows), so that the
     // launch's last residency wave consists of short-lived workgroups.  graded_from == 0: uniform chunks.
     int64_t graded_from, graded_len;
+    int wide_int;            // integer FSK captures: take the bit-plane kernel's instantiation with the wide loop (capture streams set it from k_wide_probe's count)
     int stamp_probe;         // tools/boundary_probe.py: the STAMPS instantiation of the bit-plane kernel (complex64 2-FSK only); 0 in the product
     float thr[kMaxOrder - 1];
 };
@@ -59,6 +60,7 @@ extern int g_tail_skip;            // pulse_table.hip: measurement hook (urhgpu_
 // the kernel's own begin / end timestamps, what rocprofv3 reports); `used` says the launcher took them
 struct HotEvents { hipEvent_t start = nullptr, stop = nullptr; bool used = false; };
 extern thread_local HotEvents g_hot_events;   // test hook: order 2 through the state-byte kernel too
+int launch_wide_probe(const void *d_iq, int dtype, int64_t n, float noise_sqrd, int32_t *h_out, hipStream_t s);      // demod_runs.hip: k_wide_probe
 int launch_demod_runs_iq(const RunArgs &a, int dtype, int mod, bool write_qad, hipStream_t s);
 int launch_runs_qad(const RunArgs &a, hipStream_t s);
 bool runs_streamable(const RunArgs &a);       // RunArgs::progress is honoured for these arguments (bit-plane kernel, whole tiles)

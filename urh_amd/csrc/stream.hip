@@ -48,6 +48,13 @@ struct urhgpu_stream {
     bool row16_ok = false;                 // ... and may pack state and length into ONE uint16 per row (URHGPU_BLOB_ROW16) when the pulse table is dense: the blobs have room for that list
     int64_t esc_extra = 0;                 // bytes behind the split layout's sections for URHGPU_BLOB_ROW16's escape list (staging and host blobs)
     int64_t last_rows = 0;                 // rows of the last result handed out (dense: more than one row per 64 samples)
+    // signed integer FSK captures: a one-workgroup probe behind every pass (k_wide_probe) reports the share of wide phase steps into pinned
+    // memory; the pushes that follow read it and take the hot kernel's instantiation with the wide loop from 1 % on (back below 0.3 %) --
+    // a quarter faster on wide captures, 5 % slower on narrow ones (profiles/r06s_deviation_pmc.txt), so it has to be chosen
+    int32_t *h_probe = nullptr;            // pinned: {per mille of wide pairs, pairs counted}
+    int wide_int = 0;
+    hipEvent_t ev_probe = nullptr;         // behind the last probe (it reads the capture: flush waits for it before the caller may let go of d_iq)
+    bool probe_pending = false;
     int64_t staged_passes = 0;             // passes whose tail stored into the staging blob (tightened + copied by the copy engine)
     int64_t uploaded_passes = 0;           // ... of which the capture was uploaded piece by piece (urhgpu_stream_push_upload)
     int64_t predicted_bytes = 0;           // blob bytes the next pass's copy is sized for (0: header only, the rest fetched on demand)
@@ -217,6 +224,10 @@ int urhgpu_stream_create(urhgpu_ctx *ctx, int64_t n_max, const urhgpu_params *p,
         st->esc_extra = ((8 + (n_max / 8191 + 2) * 8 + 16 + 255) & ~int64_t(255)) + std::max<int64_t>(0, SL.total - st->cap_blob);
         st->row16_ok = st->len16 && p->bits_per_symbol <= 2;                    // (state + 1 in three bits: orders 2 and 4)
     }
+    if (p->mod == URHGPU_MOD_FSK && (p->dtype == URHGPU_DT_I8 || p->dtype == URHGPU_DT_I16)) {
+        if (hipHostMalloc((void **)&st->h_probe, 64) != hipSuccess || hipEventCreateWithFlags(&st->ev_probe, hipEventDisableTiming) != hipSuccess) { delete st; return URHGPU_ERR_HIP; }
+        memset(st->h_probe, 0, 64);
+    }
     st->was_pipelined = ctx->pipelined;
     if (!ctx->pipelined) { status = urhgpu_ctx_set_pipelined(ctx, 1, nullptr); if (status != URHGPU_OK) { delete st; return status; } }
     status = urhgpu_ctx_reserve(ctx, n_max, p->tolerance);
@@ -272,6 +283,8 @@ int urhgpu_stream_destroy(urhgpu_stream *st) {
         if (s.ev_shipped) (void)hipEventDestroy(s.ev_shipped);
     }
     for (auto &q : st->qad_ring) if (q) (void)hipFree(q);
+    if (st->h_probe) (void)hipHostFree(st->h_probe);
+    if (st->ev_probe) (void)hipEventDestroy(st->ev_probe);
     if (!st->was_pipelined) (void)urhgpu_ctx_set_pipelined(st->ctx, 0, nullptr);
     delete st;
     return URHGPU_OK;
@@ -329,7 +342,22 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
 #else
     const int len_mode = !st->len16 ? 0 : ((st->row16_ok && st->last_rows > n / 64) ? 2 : 1);
 #endif
-    URH_TRY(urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq, s.stage, &staged, s.ev_rows, len_mode));
+    if (st->h_probe) {
+        const int permille = ((volatile int32_t *)st->h_probe)[0], pairs = ((volatile int32_t *)st->h_probe)[1];
+#ifndef URH_NO_INT_PROBE          // (A/B builds: the default integer instantiation whatever the probe says)
+        if (pairs >= 256) st->wide_int = st->wide_int ? (permille > 3) : (permille >= 10);
+#endif
+        ctx->wide_int_next = st->wide_int;
+    }
+    const int pass_status = urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq, s.stage, &staged, s.ev_rows, len_mode);
+    ctx->wide_int_next = 0;
+    URH_TRY(pass_status);
+    if (st->h_probe && streamed) {     // behind the pass's tail: the capture is complete there whichever way it arrived
+        const float nt = st->p.noise_threshold;
+        URH_TRY(launch_wide_probe(d_iq, st->p.dtype, n, nt * nt, st->h_probe, ctx->tail_stream));
+        URH_HIP(hipEventRecord(st->ev_probe, ctx->tail_stream));
+        st->probe_pending = true;
+    }
     if (streamed && staged) {
         const StagedLayout SL = staged_layout(st->cap_rows, st->cap_bits, st->cap_msg, st->cap_pos, st->want_pos);
         const int64_t rows = std::min<int64_t>(st->predicted_rows, st->cap_rows), npos = st->want_pos ? std::min<int64_t>(st->predicted_pos, st->cap_pos) : 0;
@@ -400,6 +428,7 @@ int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out)
     // a streamed pass's blob is complete a moment before its hot kernel has retired (the last qad stores): d_qad of the results handed
     // out here is read by the caller next
     if (st->streamed_passes + st->staged_passes > 0 && st->ctx->tail_pending) URH_TRY(wait_event(st->ctx->ev_tail[(st->ctx->flip + 2) % 3]));
+    if (st->probe_pending) { URH_TRY(wait_event(st->ev_probe)); st->probe_pending = false; }
     return URHGPU_OK;
 }
 
