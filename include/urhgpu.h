@@ -370,6 +370,9 @@ int urhgpu_stream_flush(urhgpu_stream *st, urhgpu_host_result *out3, int *n_out)
 /* Diagnostics: out4 = {passes pushed, passes whose predicted copy size fell short (their rest was fetched when the result was handed
  * out), bytes the next copy is sized for, blob capacity}. */
 int urhgpu_stream_stats(urhgpu_stream *st, int64_t *out4);
+/* passes of the stream whose hot kernel was the instantiation with the wide loop for integer captures (signed integer FSK streams probe their
+ * captures -- the share of phase steps beyond atan(7/16) per sample -- and pick it from 1 % on; 0 for every other stream) */
+int urhgpu_stream_wide_passes(urhgpu_stream *st, int64_t *n_passes);
 
 /* ---- sharded captures: one long capture split sample-contiguously over the GPUs of a node ------------------
  * (there is no reference counterpart: the reference processes a capture in one process.)

@@ -233,11 +233,16 @@ def test_integer_stream_switches_to_the_wide_instantiation_and_back(oracle, dtyp
             q = np.empty(n, np.float32)
             _lib.check(_lib.load().urhgpu_memcpy_to_host(pipe.ctx.handle, C.c_void_p(r.d_qad_ptr), q.ctypes.data_as(C.c_void_p), n * 4))
             got[r.seq] = (q, r.ppseq(), r.bits(), r.pauses.copy())
+    wide_after = []
     for c in caps:
         keep(st.push(torch.from_numpy(c).cuda()))
+        wide_after.append(st.stats()["wide_passes"])
     for r in st.flush():
         keep(r)
     assert sorted(got) == list(range(len(caps)))
+    # the narrow captures at the start took the default instantiation, some of the wide ones (the probe reports a pass late) the wide one,
+    # and the stream went back: nothing more is counted at the end
+    assert wide_after[3] == 0 and 1 <= wide_after[-1] <= 8 and wide_after[-1] == wide_after[-3], wide_after
     for k, iq in enumerate(caps):
         qad = oracle.afp_demod(iq, p.noise_threshold, "FSK", 2)
         pp = oracle.grab_pulse_lens(qad, 0.0, 3, "FSK", 50, 1, 1.0)

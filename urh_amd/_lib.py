@@ -111,6 +111,7 @@ PROTOTYPES = {
     "urhgpu_stream_push_upload": (_i, [_vp, _vp, _vp, _i64, C.POINTER(HostResult)]),
     "urhgpu_stream_flush": (_i, [_vp, C.POINTER(HostResult), C.POINTER(_i)]),
     "urhgpu_stream_stats": (_i, [_vp, C.POINTER(_i64)]),
+    "urhgpu_stream_wide_passes": (_i, [_vp, C.POINTER(_i64)]),
     "urhgpu_shard_runs_dev": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, _vp, C.POINTER(Params), C.POINTER(Outputs), _vp]),
     "urhgpu_shard_prelaunch_dev": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, C.POINTER(Params), C.POINTER(Outputs)]),
     "urhgpu_shard_launch_dev": (_i, [_vp, _vp, _i64, _i64, _i64, _i, _i, _vp, C.POINTER(Params), C.POINTER(Outputs)]),

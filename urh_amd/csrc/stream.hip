@@ -53,6 +53,7 @@ struct urhgpu_stream {
     // a quarter faster on wide captures, 5 % slower on narrow ones (profiles/r06s_deviation_pmc.txt), so it has to be chosen
     int32_t *h_probe = nullptr;            // pinned: {per mille of wide pairs, pairs counted}
     int wide_int = 0;
+    int64_t wide_passes = 0;               // passes launched with it (urhgpu_stream_wide_passes)
     hipEvent_t ev_probe = nullptr;         // behind the last probe (it reads the capture: flush waits for it before the caller may let go of d_iq)
     bool probe_pending = false;
     int64_t staged_passes = 0;             // passes whose tail stored into the staging blob (tightened + copied by the copy engine)
@@ -348,6 +349,7 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
         if (pairs >= 256) st->wide_int = st->wide_int ? (permille > 3) : (permille >= 10);
 #endif
         ctx->wide_int_next = st->wide_int;
+        if (st->wide_int) st->wide_passes += 1;
     }
     const int pass_status = urh::iq_to_bits_streamed(ctx, d_iq, n, &st->p, &pass_out, s.h_blob, st->cap_blob, s.ev_copy, &streamed, h_iq, s.stage, &staged, s.ev_rows, len_mode);
     ctx->wide_int_next = 0;
@@ -400,6 +402,12 @@ static int stream_push(urhgpu_stream *st, const void *h_iq, const void *d_iq, in
     s.state = 1; s.seq = i; s.n = n;
     st->seq = i + 1;
     URH_TRY(queue_copy(st, s));                            // pack + copy behind this pass's tail, on the copy stream; the host does not wait
+    return URHGPU_OK;
+}
+
+int urhgpu_stream_wide_passes(urhgpu_stream *st, int64_t *n_passes) {
+    if (!st || !n_passes) return URHGPU_ERR_ARG;
+    *n_passes = st->wide_passes;
     return URHGPU_OK;
 }
 

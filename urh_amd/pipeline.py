@@ -537,7 +537,10 @@ class CaptureStream:
     def stats(self) -> dict:
         out = (C.c_int64 * 4)()
         _lib.check(_lib.load().urhgpu_stream_stats(self._h, out))
-        return {"pushed": int(out[0]), "short_copies": int(out[1]), "predicted_bytes": int(out[2]), "blob_capacity": int(out[3])}
+        wide = C.c_int64(0)
+        _lib.check(_lib.load().urhgpu_stream_wide_passes(self._h, C.byref(wide)))
+        return {"pushed": int(out[0]), "short_copies": int(out[1]), "predicted_bytes": int(out[2]), "blob_capacity": int(out[3]),
+                "wide_passes": int(wide.value)}
 
     def close(self):
         if self._h:
