@@ -34,7 +34,8 @@ def main():
     iq, _ = spec_fsk_capture(128, dev)
     n = iq.shape[0]
     p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 5, 100, 0.1, 8, False)
-    pipe = ShardedPipeline(GpuShardEngine(0, pipelined=True), OneRank())
+    tuning = {k[9:].lower(): int(v) for k, v in os.environ.items() if k.startswith("URH_TUNE_")}       # URH_TUNE_<KEY>=<value>: urhgpu_ctx_set_tuning
+    pipe = ShardedPipeline(GpuShardEngine(0, pipelined=True, tuning=tuning), OneRank())
     pipe.reserve(n, p)
     e = pipe.engine
 
