@@ -394,6 +394,55 @@ def test_sharded_equals_single_gpu(pipe, oracle, mod, world):
                 assert bits_equal(got_qad, want_qad)
 
 
+def test_shard_summary_one_launch_equals_generic(pipe):
+    """the local pass of a sharded capture as ONE launch (k_shard_summary: the shard's chunks composed as ResElems) delivers the same 72
+    summary bytes as the three generic resolve launches (tuning key shard_summary_generic), for shards cut anywhere: inside runs, pauses
+    and messages, shards of a few samples, shards without a stable run, tolerances that leave trailing runs open at the shard end
+    (signal_functions.pyx:421-495 across a boundary)"""
+    import torch
+    from urh_amd.pipeline import DemodParams
+    from urh_amd.shard_engine import GpuShardEngine
+    one, gen = GpuShardEngine(0), GpuShardEngine(0, tuning={"shard_summary_generic": 1})
+    rng = np.random.default_rng(20260930)
+    seen_open = seen_empty = 0
+    for it in range(60):
+        n = int(rng.choice([int(rng.integers(64, 5000)), int(rng.integers(5000, 400_000)), int(rng.integers(400_000, 3 << 20))]))
+        n -= n % 8
+        sps = int(rng.choice([5, 20, 100, 333]))
+        dtype = [np.float32, np.int16, np.int8][int(rng.integers(0, 3))]
+        mod = "FSK" if rng.random() < 0.6 else "ASK"
+        iq = synth_fsk(n, sps=sps, seed=it, noise=0.05, pause_every=max(n // 5, 8), pause_len=max(n // 23, 1), dtype=dtype)
+        scale = 1.0 if dtype == np.float32 else (127.0 if dtype == np.int8 else 8192.0)
+        if mod == "ASK":
+            env = np.repeat(rng.integers(0, 2, n // sps + 1), sps)[:n]
+            iq = (iq.astype(np.float32) * (0.05 + 0.95 * env)[:, None]).astype(dtype)
+        tol = int(rng.choice([1, 3, 5, 40, 64, 200]))
+        p = DemodParams(mod, 1, 0.2 * scale, 0.0 if mod == "FSK" else 0.35, 1.0, tol, sps, 0.1, 8, False)
+        dev_iq = torch.from_numpy(iq).cuda()
+        world = int(rng.integers(2, 9))
+        cuts = [0] + sorted(int(c) * 8 for c in rng.choice(np.arange(1, n // 8), size=world - 1, replace=False)) + [n]
+        for r in range(world):
+            a, b = cuts[r], cuts[r + 1]
+            left = dev_iq[a - 2:a].clone() if r else None
+            got = []
+            for e in (one, gen):
+                got.append(e.runs(dev_iq[a:b], left, a, n, r, world, p, False).cpu().numpy().copy())
+                _lib_abort(e)
+            # (68 of the 72 bytes are fields; the last four are the struct's padding)
+            assert np.array_equal(got[0].view(np.uint8)[:68], got[1].view(np.uint8)[:68]), (it, mod, n, sps, tol, dtype, r, world, got[0], got[1])
+            seen_open += int(got[0][0] >= 0)
+            seen_empty += int((got[0][5] & 0xFFFFFFFF) == 0)
+    assert seen_open > 0 and seen_empty > 0              # summaries with an open trailing run / without an accepted run were among them
+
+
+def _lib_abort(engine):
+    """drop a sharded pass behind its local pass (the next urhgpu_shard_runs_dev starts a new one)"""
+    import torch
+    torch.cuda.synchronize()
+    engine._res = None
+    engine._keep = ()
+
+
 def test_sharded_fuzz_extended(pipe, oracle):
     """long form of the sharded check (URH_FUZZ_ROUNDS rounds, default 6; URH_FUZZ_SEED): random world (2 .. 12), shard boundaries
     anywhere (multiples of 8 samples; shards of a few samples, shards inside a pause, shards without a single run), FSK orders 2 / 4 and

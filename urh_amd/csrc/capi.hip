@@ -892,6 +892,7 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
 //   stream_pos_direct        1 (default): direct passes ship bit_sample_pos themselves
 //   upload_pieces            pieces of urhgpu_stream_push_upload; default 4
 //   spin_wait                1 (default): the estimator calls poll their stream for the few hundred microseconds they wait (wait_stream)
+//   shard_summary_generic    1: the local pass of urhgpu_shard_runs_dev as the three generic resolve launches instead of k_shard_summary; default 0
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return URHGPU_ERR_ARG;
     if (!strcmp(key, "hot_lds_kb")) { if (value < 0 || value > 150) return URHGPU_ERR_ARG; ctx->hot_lds_pad = value * 1024; }
@@ -903,6 +904,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "stream_latency")) { ctx->tune_stream_latency = value != 0; }
     else if (!strcmp(key, "stream_pos_direct")) { ctx->tune_stream_pos_direct = value != 0; }
     else if (!strcmp(key, "spin_wait")) { ctx->tune_spin_wait = value != 0; }
+    else if (!strcmp(key, "shard_summary_generic")) { ctx->tune_shard_summary_generic = value != 0; }
     else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;
@@ -1318,7 +1320,9 @@ int urhgpu_shard_runs_dev(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, in
     r.rows = nullptr; r.cap_rows = 0; r.d_n_acc = ctx->d_counts + 9; r.d_n_rows = ctx->d_counts + 10;
     r.d_n_rows_needed = ctx->d_counts + 8; r.write_last_row = 0;
     r.local_pass = 1; r.aux = ss->aux; r.summary_out = (ChunkInfo *)d_summary; r.chunk_first = 0; r.n_local = pl.n_chunks;
-    URH_TRY(launch_resolve(r, ctx->d_tickets, s));
+    // one launch (k_shard_summary) since round 6; the three generic resolve launches stay as tuning key shard_summary_generic (tests compare the two)
+    if (ctx->tune_shard_summary_generic) URH_TRY(launch_resolve(r, ctx->d_tickets, s));
+    else URH_TRY(launch_shard_summary(r, ctx->d_tickets + 1, s));
     URH_HIP(hipGetLastError());
     ss->phase = 1;
     return URHGPU_OK;

@@ -203,6 +203,7 @@ struct BitsOut {
     int64_t *h_counts = nullptr;   // optional second destination of the counts: pinned HOST memory (zero-copy store), see urhgpu_outputs::h_counts
 };
 int launch_resolve(const ResolveArgs &a, int32_t *tickets, hipStream_t s);
+int launch_shard_summary(const ResolveArgs &a, int32_t *ticket, hipStream_t s);   // local pass of a sharded capture in one launch (*ticket zero between launches)
 int launch_resolve_emit_single(const ResolveArgs &r, const EmitArgs &e, hipStream_t s);
 int launch_emit_rows(const EmitArgs &a, int64_t n_local_chunks, hipStream_t s);
 size_t merge_scratch_bytes(int64_t cap);

@@ -869,6 +869,108 @@ __device__ __forceinline__ ResElem res_before_entry(const TileTail &ft, const Re
     return pre;
 }
 
+// ---- local pass of a sharded capture as ONE launch --------------------------------------------------------------------------
+// The shard on its own -> the ChunkInfo that stands for it in the other ranks' tables (resolve_finish's local_pass branch spells the
+// fields out).  The generic local pass was the three resolve launches above (~ 40 us in front of the summary exchange, i.e. in the
+// tail chain that sets a sharded step's period); but every field of the summary is a function of the composition of the shard's
+// chunks as ResElems entered with an unknown state -- P = cnt + 1, first / last stable state, the last accepted run -- plus two
+// indices (first chunk with a run boundary, the chunk whose trailing short run reaches the shard end undecided): kResolveBlock
+// chunks per workgroup, the workgroup that delivers the last partial composes them in order.  Leaves chunks, scratch and aux alone.
+struct ShardPart { ResElem tot; int32_t first_nonlead, open_chunk; };
+__global__ __launch_bounds__(kResolveBlock) void k_shard_summary(const ResolveArgs a, ShardPart *part, int32_t *ticket) {
+    URH_TAIL_PRIO();
+    __shared__ ResElem s_w[kResolveBlock / 64];
+    __shared__ int32_t s_fn[kResolveBlock / 64], s_oc[kResolveBlock / 64];
+    __shared__ bool s_last;
+    const int64_t c = (int64_t)blockIdx.x * kResolveBlock + threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    ResElem e = res_identity();
+    int32_t fn = kAuxNone, oc = kAuxNone;
+    if (c < a.n_chunks) {
+        const ChunkInfo *ch = a.chunks + c;
+        const int64_t pend_pos = ch->pend_pos, start = ch->start, len = ch->len, last_pos = ch->last_pos, own_lead = ch->lead;
+        const int cnt = ch->cnt;
+        const uint32_t first_state = ch->first_state, last_state = ch->last_state, pend_state = ch->pend_state;
+        const bool has_next = c + 1 < a.n_chunks;
+        int64_t lead = has_next ? ch[1].lead : 0, nlen = has_next ? ch[1].len : 1;
+        int ps = 0;
+        if (pend_pos >= 0) {                                 // chunk_stable, local form: a run that reaches the shard end undecided stays open
+            int64_t run = start + len - pend_pos;
+            bool hit = false;
+            for (int64_t u = c + 1; run <= a.tol && u < a.n_chunks; ++u) {
+                if (u > c + 1) { lead = a.chunks[u].lead; nlen = a.chunks[u].len; }
+                run += lead;
+                if (lead < nlen) { hit = true; break; }
+            }
+            ps = run > a.tol;
+            if (!ps && !hit) oc = (int32_t)c;
+        }
+        e = res_of_chunk(cnt, first_state, last_state, pend_state, last_pos, pend_pos, ps);
+        if (own_lead < len) fn = (int32_t)c;
+    }
+    const ResElem incl = res_wave_incl_scan(e, lane);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { fn = min(fn, __shfl_down(fn, o)); oc = min(oc, __shfl_down(oc, o)); }
+    if (lane == 63) s_w[wave] = incl;
+    if (lane == 0) { s_fn[wave] = fn; s_oc[wave] = oc; }
+    __syncthreads();
+    if (t == 0) {
+        ResElem tot = res_identity();
+        int32_t f = kAuxNone, o = kAuxNone;
+#pragma unroll
+        for (int w = 0; w < kResolveBlock / 64; ++w) { tot = res_combine(tot, s_w[w]); f = min(f, s_fn[w]); o = min(o, s_oc[w]); }
+        ShardPart *p = part + blockIdx.x;
+        __hip_atomic_store(&p->tot.cnt, tot.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p->tot.first_pos, tot.first_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p->tot.la_pos, tot.la_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p->tot.meta, tot.meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p->first_nonlead, f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&p->open_chunk, o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1) == (int32_t)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last || wave != 0) return;
+    __threadfence();
+    const int64_t nb = gridDim.x;
+    ResElem tot = res_identity();
+    fn = kAuxNone; oc = kAuxNone;
+    for (int64_t u0 = 0; u0 < nb; u0 += 64) {
+        ResElem x = res_identity();
+        if (u0 + lane < nb) {
+            const ShardPart *p = part + u0 + lane;
+            x.cnt = __hip_atomic_load(&p->tot.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x.first_pos = __hip_atomic_load(&p->tot.first_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x.la_pos = __hip_atomic_load(&p->tot.la_pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            x.meta = __hip_atomic_load(&p->tot.meta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            fn = min(fn, __hip_atomic_load(&p->first_nonlead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            oc = min(oc, __hip_atomic_load(&p->open_chunk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        x = res_wave_incl_scan(x, lane);
+        tot = res_combine(tot, res_shfl(x, 63));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { fn = min(fn, __shfl_down(fn, o)); oc = min(oc, __shfl_down(oc, o)); }
+    if (lane != 0) return;
+    const ChunkInfo *ch = a.chunks;
+    const bool has = tot.has();
+    const int64_t P = has ? tot.cnt + 1 : 0;              // entered with an unknown state, the first stable run is accepted
+    ChunkInfo s;
+    s.start = ch[0].start; s.len = a.n_total;
+    s.lead = (fn >= a.n_chunks) ? a.n_total : ch[fn].start - ch[0].start + ch[fn].lead;
+    s.pend_pos = -1; s.pend_state = 0;
+    if (oc < a.n_chunks) { s.pend_pos = ch[oc].pend_pos; s.pend_state = ch[oc].pend_state; }
+    s.cnt = (int32_t)P;
+    s.first_state = has ? (uint16_t)tot.first_state() : (uint16_t)0xFFFFu;
+    s.last_state = has ? (uint16_t)tot.last_state() : (uint16_t)0xFFFFu;
+    s.last_pos = !has ? 0 : (tot.la_valid() ? tot.la_pos : tot.first_pos);
+    s.init_state = ch[0].init_state;
+    s.first_acc = 0; s.pend_acc = 0; s.pend_stable = 0; s.pad = 0;
+    *a.summary_out = s;
+    *a.d_n_acc = P;
+    *ticket = 0;
+}
+
 // What one row contributes to _ppseq_to_bits (ProtocolAnalyzer.py:346-401): v[0] bits, v[1] long pause, v[2] samples, v[3] data row
 __device__ __forceinline__ VecK<4> row_value(int64_t type, int64_t len, bool global_row0, const BitsParams &bp) {
     VecK<4> v; v.zero();
@@ -1467,6 +1569,15 @@ int launch_resolve(const ResolveArgs &a, int32_t *tickets, hipStream_t s) {
     hipLaunchKernelGGL(k_resolve_a, dim3(g), dim3(kResolveBlock), 0, s, a);
     hipLaunchKernelGGL(k_resolve_b, dim3(g), dim3(kResolveBlock), 0, s, a);
     hipLaunchKernelGGL(k_resolve_c, dim3(g), dim3(kResolveBlock), 0, s, a);
+    return URHGPU_OK;
+}
+
+// local pass of a sharded capture: the shard's summary in one launch (partials in the resolve scratch the table pass overwrites)
+int launch_shard_summary(const ResolveArgs &a, int32_t *ticket, hipStream_t s) {
+    if (a.n_chunks <= 0 || !a.local_pass || !a.summary_out || a.n_chunks >= kAuxNone) return URHGPU_ERR_ARG;
+    static_assert(sizeof(ShardPart) <= 256 && sizeof(ShardPart) <= (size_t)kResolveBlock * 8, "one partial per kResolveBlock chunks fits the out_cnt section (8 bytes per chunk, 256-byte granules)");
+    const unsigned g = (unsigned)resolve_blocks(a.n_chunks);
+    hipLaunchKernelGGL(k_shard_summary, dim3(g), dim3(kResolveBlock), 0, s, a, (ShardPart *)a.sc.out_cnt, ticket);
     return URHGPU_OK;
 }
 
