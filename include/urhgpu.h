@@ -699,6 +699,10 @@ int urhgpu_test_force_generic_tail(int on);
  * captures the oracle finishes in seconds exercise the plan the 1 GiB benchmark runs; 0 restores the default.  Process-wide. */
 int urhgpu_test_force_tiles_per_chunk(int tiles);
 
+/* Test hook: hot launches of this process that took the signed-integer instantiation WITH the wide loop (capture streams by their probe,
+ * one-shot and sharded passes by the tuning key "wide_int"): what a test of that instantiation checks it has exercised. */
+int64_t urhgpu_test_wide_int_launches(void);
+
 /* Test hook: elementwise bit-faithful atan2f (the device port of glibc 2.35 atan2f), device pointers. */
 int urhgpu_test_atan2f_dev(urhgpu_ctx *ctx, const float *d_y, const float *d_x, int64_t n, float *d_out);
 

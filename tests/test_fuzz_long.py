@@ -196,7 +196,10 @@ def test_fsk_loops_fuzz(pipe, oracle):
     random phase steps from a hundredth of a radian to beyond pi, random amplitudes (|re| at the division's window), noise, gated
     pauses, exact zeros and spikes, lengths around the 64-row chunk grid -- the demodulated signal bit for bit, the pulse table equal"""
     import torch
-    from urh_amd.pipeline import DemodParams
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    pipe_wide = DevicePipeline(0, tuning={"wide_int": 1})      # signed integer captures through the instantiation with the wide loop as well
+    from urh_amd import _lib as _l
+    wide0, wide_want = _l.load().urhgpu_test_wide_int_launches(), 0
     for it in range(4 * ROUNDS):
         rng = np.random.default_rng([717, SEED0, it])
         n = int(rng.choice([8192 * int(rng.integers(1, 60)) + int(rng.choice([0, 1, 127, 128, 2049])), int(rng.integers(2000, 900_000))]))
@@ -224,14 +227,18 @@ def test_fsk_loops_fuzz(pipe, oracle):
         pp = oracle.grab_pulse_lens(qad, p.center, tol, "FSK", sps, 1, 1.0)
         from urh_amd import _lib
         lib = _lib.load()
-        for tiles in (0, 4):                                  # the default chunk plan (short chunks for short captures) and the benchmark's 64-row chunks
+        for tiles, pl in [(0, pipe), (4, pipe)] + ([(0, pipe_wide), (4, pipe_wide)] if dtype != np.float32 else []):
+            # the default chunk plan (short chunks for short captures) and the benchmark's 64-row chunks
             assert lib.urhgpu_test_force_tiles_per_chunk(tiles) == 0
             try:
-                res = pipe.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True, cap_rows=n // (tol + 1) + 2)
+                res = pl.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True, cap_rows=n // (tol + 1) + 2)
                 got = res.qad.cpu().numpy()
                 rows = res.ppseq()
             finally:
                 lib.urhgpu_test_force_tiles_per_chunk(0)
             bad = np.nonzero(got.view(np.uint32) != qad.view(np.uint32))[0]
-            assert len(bad) == 0, (it, SEED0, tiles, n, np.dtype(dtype).name, noise, len(bad), bad[:6], got[bad[:6]], qad[bad[:6]])
-            assert np.array_equal(rows, pp), (it, SEED0, tiles, n, np.dtype(dtype).name)
+            assert len(bad) == 0, (it, SEED0, tiles, pl is pipe_wide, n, np.dtype(dtype).name, noise, len(bad), bad[:6], got[bad[:6]], qad[bad[:6]])
+            assert np.array_equal(rows, pp), (it, SEED0, tiles, pl is pipe_wide, n, np.dtype(dtype).name)
+            wide_want += int(pl is pipe_wide and n >= 2048)
+    launched = _l.load().urhgpu_test_wide_int_launches() - wide0
+    assert wide_want == 0 or launched >= wide_want // 2, (launched, wide_want)       # the keyed passes did take the wide instantiation

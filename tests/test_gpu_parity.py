@@ -669,6 +669,45 @@ def test_wide_loop_every_angle_and_mode_switches(pipe, oracle, dtype):
     assert dtype == np.uint8 or zero_back > 50                           # +-pi from exactly zero cross products behind: exercised (unsigned samples are not centred: re > 0)
 
 
+@pytest.mark.parametrize("dtype", [np.int8, np.int16])
+@pytest.mark.parametrize("bps", [1, 2])
+def test_wide_int_key_one_shot_and_orders(oracle, dtype, bps):
+    """tuning key wide_int: a ONE-SHOT pass over a signed integer FSK capture takes the hot kernel's instantiation with the wide loop
+    (capture streams pick it by their probe; a one-shot pass has the caller's word only) -- 2-FSK and 4-FSK (the two-plane instantiation),
+    narrow and wide deviations, a gated pause and exactly zero samples: demodulated signal bit for bit, pulse table and bits equal the
+    reference's whichever instantiation ran (signal_functions.pyx:363-376, 421-495)"""
+    import torch
+    from urh_amd.pipeline import DemodParams, DevicePipeline
+    n = (1 << 19) + 8192 * 3 + 1032
+    amp = 0.6 * np.iinfo(dtype).max
+    rng = np.random.default_rng(77 + bps)
+    plain, wide = DevicePipeline(0), DevicePipeline(0, tuning={"wide_int": 1})
+    from urh_amd import _lib
+    launches0 = _lib.load().urhgpu_test_wide_int_launches()
+    for dev_hz in (15e3, 120e3, 260e3):
+        x = synth_fsk(n, sps=40, seed=int(dev_hz) % 89 + bps, noise=0.03, pause_every=n // 3, pause_len=3000, deviation_hz=dev_hz)
+        if bps == 2:                                          # four tones: every second symbol at a third of the deviation
+            ph = np.unwrap(np.angle(x[:, 0] + 1j * x[:, 1]))
+            d = np.diff(ph, prepend=ph[0]) * np.repeat(rng.choice([1.0, 1.0 / 3.0], n // 40 + 1), 40)[:n]
+            mag = np.hypot(x[:, 0], x[:, 1])
+            x = np.stack([mag * np.cos(np.cumsum(d)), mag * np.sin(np.cumsum(d))], 1)
+        iq = np.clip(np.round(x * amp), np.iinfo(dtype).min, np.iinfo(dtype).max).astype(dtype)
+        iq[200_000:200_064] = 0
+        step = 2 * np.pi * dev_hz / 1e6
+        center, spacing = (0.0, 1.0) if bps == 1 else (0.0, 2.0 * step / 3.0)
+        p = DemodParams("FSK", bps, 0.1 * amp, center, spacing, 3, 40, 0.1, 8, True)
+        qad = oracle.afp_demod(iq, p.noise_threshold, "FSK", 1 << bps)
+        pp = oracle.grab_pulse_lens(qad, center, 3, "FSK", 40, bps, spacing)
+        fb = oracle.ppseq_to_bits_flat(pp, 40, bps, True, 8)
+        for pl in (plain, wide):
+            res = pl.iq_to_bits(torch.from_numpy(iq).cuda(), p, want_qad=True, cap_rows=n // 4 + 2)
+            got = res.qad.cpu().numpy()
+            assert bits_equal(got, qad), (dev_hz, pl is wide, int((got.view(np.uint32) != qad.view(np.uint32)).sum()))
+            assert np.array_equal(res.ppseq(), pp), (dev_hz, pl is wide)
+            assert all(np.array_equal(a, b) for a, b in zip(fb, res.flat())), (dev_hz, pl is wide)
+    assert _lib.load().urhgpu_test_wide_int_launches() - launches0 == 3       # the keyed pipeline's passes took that instantiation, the other's did not
+
+
 @pytest.mark.parametrize("bps", [1, 2])
 def test_many_huge_rows_expand(pipe, oracle, bps):
     """300 constant stretches of 4 500-9 000 symbols each (rows of more than 4096 bits go to k_expand_huge's work list, more

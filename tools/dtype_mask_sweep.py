@@ -23,7 +23,9 @@ cases = (("float32", torch.float32, np.float32, 1.0, True), ("bits_only", torch.
 xs = {name: (iq if ndt is np.float32 else (iq * scale).round().to(tdt).contiguous()) for name, tdt, ndt, scale, _ in cases}
 print("removed " + " ".join(f"{c[0]:>10s}" for c in cases))
 for r in removed:
-    pipe = DevicePipeline(0, pipelined=True, tuning={"hot_cus_removed_per_xcd": r})
+    tuning = {k[9:].lower(): int(v) for k, v in os.environ.items() if k.startswith("URH_TUNE_")}       # further keys: URH_TUNE_<KEY>=<value>
+    tuning["hot_cus_removed_per_xcd"] = r
+    pipe = DevicePipeline(0, pipelined=True, tuning=tuning)
     pipe.reserve(n, p)
     row = []
     for name, tdt, ndt, scale, wq in cases:

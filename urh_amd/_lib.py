@@ -167,6 +167,7 @@ PROTOTYPES = {
     "urhgpu_memcpy_dtod": (_i, [_vp, _vp, _vp, _i64]),
     "urhgpu_test_force_state_bytes": (_i, [_i]),
     "urhgpu_test_force_tiles_per_chunk": (_i, [_i]),
+    "urhgpu_test_wide_int_launches": (_i64, []),
     "urhgpu_test_force_generic_tail": (_i, [_i]),
     "urhgpu_test_atan2f_dev": (_i, [_vp, _vp, _vp, _i64, _vp]),
 }

@@ -245,6 +245,7 @@ int digitize(urhgpu_ctx *ctx, bool from_iq, const void *d_in, int64_t n, const u
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
     a.lds_pad = ctx->pipelined ? ctx->hot_lds_pad : 0;
+    a.wide_int = ctx->tune_wide_int ? 1 : 0;                 // (a one-shot pass has no probe of its capture to go by: the caller's word)
     if (from_iq) URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     if (seg_mode) {
         // message segmentation: state = (|sample| > noise threshold) with the 10-sample outlier tolerance.  Reuses the
@@ -483,7 +484,7 @@ int iq_to_bits_streamed(urhgpu_ctx *ctx, const void *d_iq, int64_t n, const urhg
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
     a.lds_pad = ctx->hot_lds_pad;
-    a.wide_int = ctx->wide_int_next;
+    a.wide_int = (ctx->wide_int_next || ctx->tune_wide_int) ? 1 : 0;
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     int64_t bound[kMaxSegments + 1];
     int S = runs_streamable(a) ? segment_bounds(pl.n_chunks, h_iq ? ctx->tune_upload_pieces : ctx->tune_stream_segments, h_iq ? 2 : 0, 1, bound) : 0;
@@ -892,6 +893,9 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream) {
 //   stream_pos_direct        1 (default): direct passes ship bit_sample_pos themselves
 //   upload_pieces            pieces of urhgpu_stream_push_upload; default 4
 //   spin_wait                1 (default): the estimator calls poll their stream for the few hundred microseconds they wait (wait_stream)
+//   wide_int                 1: passes over SIGNED INTEGER FSK captures take the hot kernel's instantiation with the wide loop (captures whose phase
+//                            steps leave the fast loop's window, DESIGN 4: a quarter faster there, 5 % slower on narrow ones).  Capture streams
+//                            decide by themselves (k_wide_probe); one-shot and sharded passes have no probe to go by: this key is the caller's word.  default 0
 //   shard_summary_generic    1: the local pass of urhgpu_shard_runs_dev as the three generic resolve launches instead of k_shard_summary; default 0
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     if (!ctx || !key) return URHGPU_ERR_ARG;
@@ -905,6 +909,7 @@ int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value) {
     else if (!strcmp(key, "stream_pos_direct")) { ctx->tune_stream_pos_direct = value != 0; }
     else if (!strcmp(key, "spin_wait")) { ctx->tune_spin_wait = value != 0; }
     else if (!strcmp(key, "shard_summary_generic")) { ctx->tune_shard_summary_generic = value != 0; }
+    else if (!strcmp(key, "wide_int")) { ctx->tune_wide_int = value != 0; }
     else if (!strcmp(key, "upload_pieces")) { if (value < 2 || value > kMaxSegments) return URHGPU_ERR_ARG; ctx->tune_upload_pieces = value; }
     else return URHGPU_ERR_ARG;
     return URHGPU_OK;
@@ -1243,6 +1248,7 @@ static int shard_launch(urhgpu_ctx *ctx, const void *d_iq, int64_t n_local, int6
     a.noise_val = noise_for(p);
     a.tol = p->tolerance;
     a.lds_pad = !ctx->pipelined ? 0 : (ss->use_tile ? ctx->hot_lds_pad : ctx->hot_lds_pad_sharded);
+    a.wide_int = ctx->tune_wide_int ? 1 : 0;
     URH_TRY(max_magnitude_for(p->dtype, &a.max_magnitude));
     a.chunks = ss->table + rank;               // this rank's chunks sit at table[rank .. rank + n_chunks)
     a.slab = ss->slab;
@@ -2149,6 +2155,8 @@ int urhgpu_test_force_generic_tail(int on) {
     g_tile_tail = (on == 0);
     return URHGPU_OK;
 }
+
+int64_t urhgpu_test_wide_int_launches(void) { return (int64_t)urh::g_wide_int_launches.load(); }
 
 int urhgpu_test_force_tiles_per_chunk(int tiles) {
     if (tiles < 0 || tiles > 4) return URHGPU_ERR_ARG;

@@ -83,6 +83,7 @@ struct urhgpu_ctx {
     int64_t *d_counts = nullptr;   // small device result block (8 x int64)
     int64_t *h_counts = nullptr;   // pinned host mirror
     bool tune_spin_wait = true;    // wait_stream polls (see there)
+    bool tune_wide_int = false;    // one-shot / sharded passes over signed integer FSK captures take the wide-loop instantiation (RunArgs::wide_int)
     bool tune_shard_summary_generic = false;   // urhgpu_shard_runs_dev: the local pass as launch_resolve (A/B, tests) instead of launch_shard_summary
     int wide_int_next = 0;         // the next streamed pass over a signed integer FSK capture takes the wide-loop instantiation (set by urhgpu_stream_*, RunArgs::wide_int)
     char *h_small = nullptr;       // pinned landing zone of the estimators' small results (kSmallPinned bytes): copies into it are truly asynchronous

@@ -25,6 +25,7 @@
 //                    r -- which meet in wavefront 0 through 2 KiB of LDS, where lane r analyses row r with 64-bit logic.
 //   k_demod_runs     (every other order, tolerance > 64, the partial last tile): one wavefront per chunk walks tiles of 2048
 //                    samples, state bytes in LDS in sample order, lane t owning 32 consecutive samples in the run phase.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -1746,6 +1747,7 @@ __global__ void k_test_atan2f(const float *y, const float *x, int64_t n, float *
 // ---- host-side launchers ---------------------------------------------------------------------------
 // test hook (urhgpu_test_force_state_bytes): route order-2 work through the state-byte kernel as well
 bool g_force_state_bytes = false;
+std::atomic<long long> g_wide_int_launches{0};   // urhgpu_test_wide_int_launches: hot launches that took the WIDEI instantiation
 bool g_stamp_probe = false;          // test hook (urhgpu_test_hot_stamps): complex64 2-FSK passes run the STAMPS instantiation of the bit-plane kernel
 thread_local HotEvents g_hot_events;
 
@@ -1774,6 +1776,7 @@ static void launch_runs_4(RunArgs a, hipStream_t s) {
         // integer FSK captures with wide phase steps (RunArgs::wide_int): the instantiation with the wide loop
         constexpr bool widei_ok = SRC == SRC_IQ && (DT == URHGPU_DT_I8 || DT == URHGPU_DT_I16) && MOD == URHGPU_MOD_FSK;      // (unsigned samples are not centred: re > 0)
         if (widei_ok && a.wide_int && planes_ok && (O2 || a.order == 4)) {
+            ++g_wide_int_launches;
             const bool ev = (g_hot_events.start || g_hot_events.stop) && !g_hot_events.used;
             if (O2 && ev) {
                 hipExtLaunchKernelGGL((k_demod_runs_bp<SRC, DT, MOD, WQ, true, 1, false, widei_ok>), dim3((unsigned)(c_hi - c_lo)), dim3(kBlock * bp_waves<SRC, MOD>()),

@@ -1,5 +1,6 @@
 // Argument structs and host-side launcher prototypes shared by the kernel files and capi.hip.
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -54,6 +55,7 @@ struct RunArgs {
     float thr[kMaxOrder - 1];
 };
 extern bool g_force_state_bytes;
+extern std::atomic<long long> g_wide_int_launches;
 extern bool g_stamp_probe;
 extern int g_tail_skip;            // pulse_table.hip: measurement hook (urhgpu_test_tail_skip)
 // urhgpu_ctx_profile_*: start / stop events attached to the next bit-plane hot-kernel dispatch itself (hipExtLaunchKernelGGL:
