@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT
+for rep in 1 2; do
+for lib in liburhgpu.so liburhgpu_nopw.so; do
+  echo "## $lib sps10"; URHGPU_LIB=$GRAFT_REPO_ROOT/urh_amd/$lib timeout 200 python tools/sps10_skips.py 2>&1 | grep -E "product|pack"
+  echo "## $lib sps100"; URH_SPS=100 URHGPU_LIB=$GRAFT_REPO_ROOT/urh_amd/$lib timeout 200 python tools/sps10_skips.py 2>&1 | grep -E "product"
+done; done

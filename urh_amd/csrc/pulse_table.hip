@@ -1004,6 +1004,12 @@ constexpr int kEmitWaves = 4;
 #define URH_TAIL_CPW 4
 #endif
 constexpr int kTailCPW = URH_TAIL_CPW;
+#ifndef URH_EXPAND_PREFETCH
+#define URH_EXPAND_PREFETCH 1
+#endif
+#ifndef URH_PACK_WORDS
+#define URH_PACK_WORDS 1
+#endif
 // -DURH_TAIL_CAP80: at most 80 VGPRs (six wavefronts per SIMD) for the tail kernels that need more -- what ONE retiring hot wavefront
 // (72 + the 8 it never had) leaves free on a SIMD; costs spills (A/B knob)
 #ifdef URH_TAIL_CAP80
@@ -1489,15 +1495,28 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_EXPAND_OCC void k_expand_tiles
             if (off_n + lane < end_n) row_next = *(const longlong2 *)(a.rows + 2 * (off_n + lane));
         }
         const int64_t g0 = run.v[1];
+        longlong2 row_cur = row0;
         for (int64_t i0 = off; i0 < end; i0 += 64) {
             const int64_t i = i0 + lane;
             VecK<4> v; v.zero();
             int64_t type = 0;
+#if URH_EXPAND_PREFETCH
+            // the tile's next 64 rows are requested before these are expanded (dense pulse tables -- 10 samples per symbol: 400 rows per tile --
+            // spent a memory round trip per 64 rows here, beside a hot kernel that saturates the HBM: profiles/r06fin_sps10_skips.txt)
+            longlong2 row_pf = longlong2{0, 0};
+            if (i + 64 < end) row_pf = *(const longlong2 *)(a.rows + 2 * (i + 64));
+            if (i < end) {
+                type = row_cur.x;
+                v = row_value(type, row_cur.y, i == 0 && row0g, a.bp);
+            }
+            row_cur = row_pf;
+#else
             if (i < end) {
                 const longlong2 row = (i0 == off) ? row0 : *(const longlong2 *)(a.rows + 2 * i);
                 type = row.x;
                 v = row_value(type, row.y, i == 0 && row0g, a.bp);
             }
+#endif
             // inclusive wave scans of what the expansion needs: bits and samples (64-bit), long pauses (32-bit: a tile has few rows)
             int64_t in_bits = v.v[0], in_ts = v.v[2];
             int in_l = (int)v.v[1];
@@ -1997,12 +2016,33 @@ __global__ __launch_bounds__(256) void k_pack_seg(const SegPack a) {
     {
         uint8_t *out = (uint8_t *)(a.head + L.off_bits);
         const unsigned long long *in8 = (const unsigned long long *)a.bits;
-        for (int64_t j = j0 + gtid; j < j1; j += stride) {
+        auto pack8 = [&](int64_t j) -> unsigned long long {   // bits 8 j .. 8 j + 7 as one byte
             unsigned long long w;
             if (8 * j + 8 <= nbits) w = in8[j];
             else { w = 0; for (int k = 0; k < 8 && 8 * j + k < nbits; ++k) w |= (unsigned long long)a.bits[8 * j + k] << (8 * k); }
-            out[j] = (uint8_t)(((w & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
+            return ((w & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56;
+        };
+#if URH_PACK_WORDS
+        // The destination is pinned HOST memory: one byte per thread made every wavefront's store a 64-byte PCIe write -- 1.7 MB of them for a
+        // dense pulse table (10 samples per symbol: 13 M bits), 100 us beside the hot kernel.  Eight bytes per thread instead: the bytes up to
+        // the destination's first 8-byte boundary, whole 64-bit words (512 contiguous bytes per wavefront store), the rest.
+        int64_t ja = j0 + (int64_t)((8 - ((uintptr_t)(out + j0) & 7)) & 7);
+        if (ja > j1) ja = j1;
+        int64_t nw = (j1 - ja) / 8;
+        const int64_t full = nbits / 8;                     // bytes whose eight bits all exist
+        if (ja + 8 * nw > full) nw = full > ja ? (full - ja) / 8 : 0;
+        for (int64_t k = gtid; k < nw; k += stride) {
+            const int64_t j = ja + 8 * k;
+            unsigned long long r = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) r |= (((in8[j + b] & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56) << (8 * b);
+            *(unsigned long long *)(out + j) = r;
         }
+        for (int64_t j = j0 + gtid; j < ja; j += stride) out[j] = (uint8_t)pack8(j);
+        for (int64_t j = ja + 8 * nw + gtid; j < j1; j += stride) out[j] = (uint8_t)pack8(j);
+#else
+        for (int64_t j = j0 + gtid; j < j1; j += stride) out[j] = (uint8_t)pack8(j);
+#endif
     }
     if (a.has_pos && !a.pos_shipped) {
         uint32_t *p32 = (uint32_t *)(a.host + L.off_pos32);
