@@ -1010,6 +1010,9 @@ constexpr int kTailCPW = URH_TAIL_CPW;
 #ifndef URH_PACK_WORDS
 #define URH_PACK_WORDS 1
 #endif
+#ifndef URH_EXPAND_EARLY_EXIT
+#define URH_EXPAND_EARLY_EXIT 1
+#endif
 // -DURH_TAIL_CAP80: at most 80 VGPRs (six wavefronts per SIMD) for the tail kernels that need more -- what ONE retiring hot wavefront
 // (72 + the 8 it never had) leaves free on a SIMD; costs spills (A/B knob)
 #ifdef URH_TAIL_CAP80
@@ -1542,6 +1545,30 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_EXPAND_OCC void k_expand_tiles
                 }
             }
             constexpr int kShort = 16;
+#if URH_EXPAND_EARLY_EXIT
+            {
+                // a few bits per row (the common case): capacity checks hoisted out of the loop, positions by repeated addition.  The loop ends
+                // when NO lane has a bit left (wave-uniform test): written as `for k < kb` the compiler unrolled it into sixteen predicated steps
+                // that every 64 rows paid in full -- 71 VALU and 32 memory instructions where a dense table's rows hold one or two bits each
+                const int kbs = (kb > 0 && kb <= kShort) ? (int)kb : 0;
+                const int nb = (ob + kbs <= a.cap_bits) ? kbs : (int)((a.cap_bits > ob) ? a.cap_bits - ob : 0);
+                const int np = !a.bp.write_pos ? 0 : ((op + kbs <= a.cap_pos) ? kbs : (int)((a.cap_pos > op) ? a.cap_pos - op : 0));
+                uint8_t *bp8 = a.bits + ob;
+                int64_t *pp = a.pos + op;
+                uint32_t *hp = a.h_pos ? a.h_pos + op : nullptr;
+                int64_t tsk = ts;
+                int sh = bps - 1;
+#pragma unroll 1
+                for (int k = 0; k < kShort; ++k) {
+                    if (__ballot(k < kbs) == 0ull) break;
+                    const uint8_t b = (type < 0) ? 0 : (uint8_t)((type >> sh) & 1);
+                    sh = (sh == 0) ? bps - 1 : sh - 1;
+                    if (k < nb) bp8[k] = b;
+                    if (k < np) { pp[k] = tsk; if (hp) hp[k] = (uint32_t)tsk; }
+                    tsk += a.bp.samples_per_bit;
+                }
+            }
+#else
             if (kb > 0 && kb <= kShort) {
                 // a few bits per row (the common case): capacity checks hoisted out of the loop, positions by repeated addition
                 const int nb = (ob + kb <= a.cap_bits) ? (int)kb : (int)((a.cap_bits > ob) ? a.cap_bits - ob : 0);
@@ -1559,6 +1586,7 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_EXPAND_OCC void k_expand_tiles
                     tsk += a.bp.samples_per_bit;
                 }
             }
+#endif
             unsigned long long big = __ballot(kb > kShort);
             while (big) {
                 const int src = __builtin_ctzll(big);
