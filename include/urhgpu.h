@@ -110,6 +110,11 @@ int urhgpu_ctx_set_pipelined(urhgpu_ctx *ctx, int enable, void *tail_stream);
  *   "spin_wait"                1, default: the estimator calls poll their stream instead of blocking in the runtime (a blocking wait wakes
  *                              the host tens of microseconds late: 0.09 ms of config 3's estimate)
  *   "upload_pieces"            2 .. 16, default 4: pieces of urhgpu_stream_push_upload, the last one short
+ *   "wide_int"                 1: one-shot and sharded passes over SIGNED INTEGER FSK captures take the hot kernel's instantiation with the
+ *                              wide loop (phase steps beyond the fast loop's window, e.g. +-100 kHz at 1 MS/s: a quarter faster there, 5 %
+ *                              slower on narrow captures); capture streams decide by themselves from a probe of their captures.  default 0
+ *   "shard_summary_generic"    1: the local pass of urhgpu_shard_runs_dev as the three generic resolve launches instead of the one-launch
+ *                              summary kernel (A/B and test use: the summaries are byte-equal).  default 0
  * Unknown key: URHGPU_ERR_ARG. */
 int urhgpu_ctx_set_tuning(urhgpu_ctx *ctx, const char *key, int value);
 int urhgpu_ctx_join(urhgpu_ctx *ctx);
