@@ -21,8 +21,9 @@ def run(k):
     st.flush()
 for _ in range(6): run(20)
 print(f"# {sps} samples per symbol, K = 40, ms per step (min of 3)")
-for mask, what in ((0, "product"), (8, "without the group scan"), (16, "without k_expand_tiles"), (24, "without both"), (32, "without the pack kernel"),
-                   (2, "without k_emit_rows_tiles"), (4, "without k_tile_scan"), (62, "resolve only"), (63, "no tail"), (0, "product")):
+masks = [int(a) for a in sys.argv[1:]]
+for mask, what in ([(m, "mask from the command line (bit 9: no staged copies, 11: expansion without byte stores, 6: rows without blob stores)") for m in masks] if masks else []) + list(() if masks else ((0, "product"), (8, "without the group scan"), (16, "without k_expand_tiles"), (24, "without both"), (32, "without the pack kernel"),
+                   (2, "without k_emit_rows_tiles"), (4, "without k_tile_scan"), (62, "resolve only"), (63, "no tail"), (0, "product"))):
     lib.urhgpu_test_tail_skip(mask)
     run(20); torch.cuda.synchronize()
     ts = []
