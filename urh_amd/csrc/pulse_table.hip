@@ -1523,12 +1523,16 @@ __global__ __launch_bounds__(64 * kEmitWaves) URH_EXPAND_OCC void k_expand_tiles
             // inclusive wave scans of what the expansion needs: bits and samples (64-bit), long pauses (32-bit: a tile has few rows)
             int64_t in_bits = v.v[0], in_ts = v.v[2];
             int in_l = (int)v.v[1];
+#if URH_DPP_SCAN
+            in_bits = wave_incl_sum_dpp(in_bits); in_ts = wave_incl_sum_dpp(in_ts); in_l = wave_incl_sum_dpp(in_l);
+#else
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const int64_t ub = __shfl_up(in_bits, o), ut = __shfl_up(in_ts, o);
                 const int ul = __shfl_up(in_l, o);
                 if (lane >= o) { in_bits += ub; in_ts += ut; in_l += ul; }
             }
+#endif
             int64_t kb = 0, ob = 0, op = 0, ts = 0;
             if (i < end && v.v[0] > 0 && v.v[0] <= own_limit) {
                 const int64_t grp = run.v[1] + in_l - v.v[1];

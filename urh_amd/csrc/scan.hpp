@@ -27,8 +27,38 @@ template <int K> struct VecK {
     }
 };
 
+// Inclusive wavefront prefix SUM by DPP (gfx9 row_shr / row_bcast controls): a Kogge-Stone scan inside each row of 16 lanes (row_shr 1, 2,
+// 4, 8: a lane whose source lies before its row keeps the 0 it was given), then row 0's / row 2's total into rows 1 / 3 (row_bcast:15, rows
+// 0xA) and lane 31 into rows 2 and 3 (row_bcast:31, rows 0xC).  Six steps of plain VALU moves and adds -- __shfl_up goes through the LDS
+// crossbar (ds_bpermute_b32: five of them and an lgkmcnt wait per step for the expansion's three channels; the tail's kernels are chains of
+// such latencies beside a hot kernel).  Every lane of the wavefront must be active, as for __shfl_up.
+// Measured at the round's end (profiles/r06last_dpp_scan_ab.txt: exact -- the whole gpu suite passes on it -- and no faster: 0.471-0.479 ms per
+// step either way at 10 samples per symbol, 0.2752-0.2760 against 0.2755-0.2768 on the headline capture): not the default; -DURH_DPP_SCAN=1 builds it.
+#ifndef URH_DPP_SCAN
+#define URH_DPP_SCAN 0
+#endif
+template <int CTRL, int ROWS> __device__ __forceinline__ int dpp_or_zero(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWS, 0xF, false); }
+template <int CTRL, int ROWS> __device__ __forceinline__ int64_t dpp_or_zero(int64_t x) {
+    const uint32_t lo = (uint32_t)dpp_or_zero<CTRL, ROWS>((int)(uint32_t)(uint64_t)x), hi = (uint32_t)dpp_or_zero<CTRL, ROWS>((int)(uint32_t)((uint64_t)x >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+template <class T> __device__ __forceinline__ T wave_incl_sum_dpp(T x) {
+    x += dpp_or_zero<0x111, 0xF>(x);                        // row_shr:1
+    x += dpp_or_zero<0x112, 0xF>(x);                        // row_shr:2
+    x += dpp_or_zero<0x114, 0xF>(x);                        // row_shr:4
+    x += dpp_or_zero<0x118, 0xF>(x);                        // row_shr:8
+    x += dpp_or_zero<0x142, 0xA>(x);                        // row_bcast:15 into rows 1 and 3
+    x += dpp_or_zero<0x143, 0xC>(x);                        // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 template <int K>
 __device__ __forceinline__ VecK<K> wave_incl_scan_vec(VecK<K> x, int lane) {
+#if URH_DPP_SCAN
+    (void)lane;
+#pragma unroll
+    for (int k = 0; k < K; ++k) x.v[k] = wave_incl_sum_dpp(x.v[k]);
+#else
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
 #pragma unroll
@@ -37,6 +67,7 @@ __device__ __forceinline__ VecK<K> wave_incl_scan_vec(VecK<K> x, int lane) {
             if (lane >= o) x.v[k] += u;
         }
     }
+#endif
     return x;
 }
 
