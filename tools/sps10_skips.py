@@ -14,7 +14,7 @@ n = iq.shape[0]
 p = DemodParams("FSK", 1, 0.0, 0.0, 1.0, 1 if sps < 50 else 5, sps, 0.1, 8, False)
 pipe = DevicePipeline(0, pipelined=True, tuning={k[9:].lower(): int(v) for k, v in os.environ.items() if k.startswith("URH_TUNE_")})
 pipe.reserve(n, p)
-st = pipe.stream(n, p, want_qad=True, want_pos=False, dtype=np.float32)
+st = pipe.stream(n, p, want_qad=os.environ.get("URH_NO_QAD") is None, want_pos=False, dtype=np.float32)      # URH_NO_QAD=1: the bits-only pass (the hot kernel writes nothing but its records)
 lib = _lib.load()
 def run(k):
     for _ in range(k): st.push(iq)
